@@ -1,0 +1,35 @@
+# Builds the product: librkmh_amd.so (HIP kernels + C ABI, gfx950 only) and the rkmh CLI.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH := gfx950
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result
+CSRC := rkmh_amd/csrc
+LIB := rkmh_amd/lib/librkmh_amd.so
+OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_api.o $(CSRC)/rk_parse.o $(CSRC)/rk_synth.o
+
+all: $(LIB) bin/rkmh oracle
+
+$(CSRC)/rk_kernels.o: $(CSRC)/rk_kernels.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/rk_api.o: $(CSRC)/rk_api.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp include/rkmh_amd.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/rk_parse.o: $(CSRC)/rk_parse.cpp include/rkmh_amd.h
+	g++ -O3 -std=c++17 -fPIC -Wall -c $< -o $@
+
+$(CSRC)/rk_synth.o: $(CSRC)/rk_synth.cpp include/rkmh_amd.h
+	g++ -O3 -std=c++17 -fPIC -Wall -pthread -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p rkmh_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz -lpthread
+
+bin/rkmh: $(CSRC)/rkmh_main.cpp $(LIB) include/rkmh_amd.h
+	@mkdir -p bin
+	g++ -O2 -std=c++17 -Wall -o $@ $(CSRC)/rkmh_main.cpp -Irkmh_amd/csrc -Lrkmh_amd/lib -lrkmh_amd -Wl,-rpath,'$$ORIGIN/../rkmh_amd/lib'
+
+oracle:
+	$(MAKE) -s -C oracle
+
+clean:
+	$(RM) $(OBJS) $(LIB) bin/rkmh
+	$(MAKE) -s -C oracle clean
+.PHONY: all clean oracle

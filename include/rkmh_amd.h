@@ -1,0 +1,193 @@
+/*
+ * rkmh_amd.h -- C ABI of the MI355X-native rkmh classify/stream hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI layer; the hot path sits behind
+ * two concentric interfaces, both mirrored here with plain pointers and sizes:
+ *
+ *   inner  = the mkmh free functions called from /root/reference/src/rkmh.cpp and src/equiv.hpp
+ *            (to_upper, calc_hashes, calc_hash, minhashes, mask_by_frequency,
+ *             minhashes_frequency_filter, hash_intersection_size, HASHTCounter), and
+ *   outer  = the per-read loop of main_stream (src/rkmh.cpp:813-898 and :904-948), which this
+ *            library replaces by batched entry points (rk_set_references + rk_classify_batch*).
+ *
+ * Every compute entry point runs hand-written HIP kernels on a gfx950 device; there is NO CPU
+ * fallback: without a usable GPU rk_ctx_create fails with RK_ERR_HIP and nothing else can be called.
+ *
+ * Ownership: buffers returned through `uint64_t**` are malloc'd by the library and released with
+ * rk_free (the reference's convention is callee-new[] / caller-delete[], e.g. src/rkmh.cpp:823,864;
+ * new[] must not cross a C ABI).  Batched entry points only use caller-owned buffers.
+ * Errors: every function returns RK_OK (0) or a negative RK_ERR_*; rk_last_error() gives the text
+ * (thread-local).  Threading: one rk_ctx per host thread (the reference calls mkmh concurrently from
+ * OpenMP workers on disjoint data, src/rkmh.cpp:845-870; here concurrency is the batch itself).
+ */
+#ifndef RKMH_AMD_H
+#define RKMH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RK_OK 0
+#define RK_ERR_ARG (-1)   /* bad argument */
+#define RK_ERR_HIP (-2)   /* HIP runtime / no device */
+#define RK_ERR_NOMEM (-3)
+#define RK_ERR_STATE (-4) /* e.g. classify before rk_set_references */
+#define RK_ERR_LIMIT (-5) /* exceeds a documented limit */
+#define RK_ERR_IO (-6)
+
+#define RK_MAX_KS 8     /* number of -k values per run (src/rkmh.cpp:680-682 pushes onto a vector) */
+#define RK_MAX_K 64     /* largest k-mer size */
+#define RK_MAX_SKETCH 16384 /* largest -s handled by the in-LDS sorter */
+
+/* Unpinned mkmh choices -- identical meaning to oracle/rk_oracle.h */
+enum { RK_FOLD_SWAP32 = 0, RK_FOLD_H1 = 1, RK_FOLD_W2W1 = 2 };
+typedef struct rk_policy {
+    int32_t fold;                /* U1 */
+    int32_t drop_last_window;    /* U3: 1 => len-k windows */
+    int32_t counter_counts_zero; /* U12 */
+    int32_t mask_strict_less;    /* U9 */
+    int32_t freq_max_inclusive;  /* U10 */
+    uint32_t seed;               /* 42, src/rkmh.cpp:497 */
+} rk_policy;
+void rk_default_policy(rk_policy* p);
+
+typedef struct rk_ctx rk_ctx;
+typedef struct rk_counter rk_counter;
+
+const char* rk_last_error(void);
+const char* rk_version(void);
+int rk_device_count(void);
+
+/* One context = one GPU (one process per GPU in multi-GPU runs). policy may be NULL (defaults). */
+int rk_ctx_create(int device, const rk_policy* policy, rk_ctx** out);
+void rk_ctx_destroy(rk_ctx* ctx);
+int rk_ctx_synchronize(rk_ctx* ctx);
+void rk_free(void* p);
+
+/* ------------------------------------------------------------------------------------------------
+ * INNER boundary: one-sequence mirrors of the mkmh calls (replaces, file:line of the call site):
+ * ---------------------------------------------------------------------------------------------- */
+/* mkmh::to_upper(char*, int)                         src/rkmh.cpp:227,818,856,908 */
+int rk_to_upper(rk_ctx* ctx, char* seq, int len);
+/* mkmh::calc_hashes(const char*, int, vector<int>&, hash_t*&, int&)   src/rkmh.cpp:821,860,2101 */
+int rk_calc_hashes(rk_ctx* ctx, const char* seq, int len, const int* ks, int nks, uint64_t** out, int* n);
+/* 6-arg form with HASHTCounter*                      src/rkmh.cpp:831,909,1611,1616 */
+int rk_calc_hashes_counted(rk_ctx* ctx, const char* seq, int len, const int* ks, int nks,
+                           uint64_t** out, int* n, rk_counter* counter);
+/* mkmh::calc_hash(string)                            src/rkmh.cpp:1811,1852,2198 */
+int rk_calc_hash(rk_ctx* ctx, const char* kmer, int k, uint64_t* out);
+/* mkmh::minhashes(hash_t*, int, int, hash_t*&, int&) src/rkmh.cpp:822,863,917 (sorts h in place) */
+int rk_minhashes(rk_ctx* ctx, uint64_t* h, int n, int sketch_size, uint64_t** mins, int* m);
+/* mkmh::mask_by_frequency(hash_t*, int, HASHTCounter*, int)  src/rkmh.cpp:916 */
+int rk_mask_by_frequency(rk_ctx* ctx, uint64_t* h, int n, const rk_counter* counter, int min_occ);
+/* mkmh::minhashes_frequency_filter(...)              src/rkmh.cpp:835-836 */
+int rk_minhashes_frequency_filter(rk_ctx* ctx, uint64_t* h, int n, int sketch_size, uint64_t** out, int* m,
+                                  const rk_counter* counter, int min_count, int max_count);
+/* mkmh::hash_intersection_size(const hash_t*, int, const hash_t*, int, int&)  src/rkmh.cpp:869,922 */
+int rk_hash_intersection_size(rk_ctx* ctx, const uint64_t* a, int na, const uint64_t* b, int nb, int* out);
+
+/* HASHTCounter (ctor src/rkmh.cpp:739,742,1187; increment :335; get :1218,1260): int32 slots in HBM,
+ * slot = key % slots.  rk_counter_wrap adopts caller-owned DEVICE memory (e.g. a torch tensor, so
+ * that the table can be all-reduced over RCCL between pass 1 and pass 2 of the -M path). */
+int rk_counter_create(rk_ctx* ctx, uint64_t slots, rk_counter** out);
+int rk_counter_wrap(rk_ctx* ctx, void* d_counts_int32, uint64_t slots, rk_counter** out);
+void rk_counter_destroy(rk_counter* c);
+int rk_counter_clear(rk_counter* c);
+int rk_counter_increment(rk_counter* c, uint64_t key);
+int rk_counter_get(const rk_counter* c, uint64_t key, int32_t* out);
+void* rk_counter_device_ptr(rk_counter* c);
+uint64_t rk_counter_slots(const rk_counter* c);
+
+/* ------------------------------------------------------------------------------------------------
+ * OUTER boundary: batched replacements of main_stream's loops.
+ * Sequences are concatenated ASCII bytes (any case; upper-casing happens on the device, as
+ * src/rkmh.cpp:856 does per read) + offsets[n+1] (offsets[i]..offsets[i+1] = sequence i).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* calc_hashes for a batch (hash sub-command, src/rkmh.cpp:2097-2104).  hash_offsets[n+1] (caller
+ * array) receives the per-sequence segment bounds; *out is malloc'd [hash_offsets[n]] (rk_free). */
+int rk_hash_batch(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, int64_t nseq,
+                  const int* ks, int nks, uint64_t** out, uint64_t* hash_offsets);
+
+/* calc_hashes + minhashes for a batch (src/rkmh.cpp:816-826 for refs, :860-863 for reads).
+ * sketches: caller [nseq * sketch_size] (zero padded), lens: caller [nseq]. */
+int rk_sketch_batch(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, int64_t nseq,
+                    const int* ks, int nks, int sketch_size, uint64_t* sketches, int32_t* lens);
+
+/* Reference side of main_stream (src/rkmh.cpp:783-785 + :816-826): sketch every reference on the
+ * GPU and build the resident lookup index.  max_samples < 0 => plain path; >= 0 => the -I path
+ * (src/rkmh.cpp:828-838) with a counter of counter_slots (0 => 200000000, src/rkmh.cpp:742). */
+int rk_set_references(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, int nref,
+                      const int* ks, int nks, int sketch_size, int max_samples, uint64_t counter_slots);
+/* Import already-built sketches (after an RCCL broadcast from the rank that sketched them). */
+int rk_set_reference_sketches(rk_ctx* ctx, const uint64_t* sketches, const int32_t* lens, int nref,
+                              const int* ks, int nks, int sketch_size);
+/* Export: sketches [nref*sketch_size], lens [nref] (caller arrays). */
+int rk_get_reference_sketches(rk_ctx* ctx, uint64_t* sketches, int32_t* lens);
+int rk_num_references(const rk_ctx* ctx);
+
+/* Read-depth filter (-M, src/rkmh.cpp:701-704): when set, classify masks hashes whose counter
+ * value is below min_kmer_occ (mask_by_frequency, :916) before sketching.  NULL disables. */
+int rk_set_depth_filter(rk_ctx* ctx, rk_counter* counter, int min_kmer_occ);
+
+/* Pass 1 of the -M path (src/rkmh.cpp:904-910): hash every read and increment the counter. */
+int rk_count_batch(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, rk_counter* counter);
+int rk_count_batch_device(rk_ctx* ctx, const void* d_bases, const void* d_offsets_u32, int64_t nreads,
+                          rk_counter* counter, void* hip_stream);
+
+/* The per-read hot loop (src/rkmh.cpp:845-898 / :911-948) for a batch of reads in HOST memory:
+ * to_upper -> calc_hashes -> minhashes -> hash_intersection_size vs every reference -> argmax/diff.
+ * out4[i*4+0..3] = max_id, max_shared, diff, min_num  (exactly the variables of :874-888).
+ * Staged through pinned buffers with hipMemcpyAsync overlapped with the kernels. */
+int rk_classify_batch(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, int32_t* out4);
+
+/* Same, inputs already resident in HBM (the measured configuration).  d_bases: 4-byte aligned, readable
+ * up to the next multiple of 4 past the last base; d_offsets_u32: uint32 [nreads+1] byte offsets into
+ * d_bases; d_out4: int32 [nreads*4].  max_read_len: upper bound of the read lengths in the batch (sizes the
+ * per-wave LDS image; 0 => determined by a device reduction, which costs one stream sync).
+ * hip_stream: a hipStream_t (NULL => the context's stream).  Asynchronous: returns after enqueueing.
+ * Reads the fused kernel cannot take (longer than 1024 bases, or more non-zero hashes than the sketch
+ * size) come back with max_id = -2; rk_classify_batch reroutes those itself. */
+int rk_classify_batch_device(rk_ctx* ctx, const void* d_bases, const void* d_offsets_u32, int64_t nreads,
+                             void* d_out4, uint32_t max_read_len, void* hip_stream);
+
+/* Formats one stdout line of stream/classify exactly as src/rkmh.cpp:887-893. Returns bytes written
+ * (excluding NUL) or a negative error if cap is too small. */
+int rk_format_stream_line(char* dst, size_t cap, const char* ref_name, const char* read_name,
+                          int max_shared, int diff, int min_num, int sketch_size, int min_matches, int min_diff);
+
+/* ------------------------------------------------------------------------------------------------
+ * FASTA/FASTQ(.gz) front end (parse_fastas, src/rkmh.cpp:238-292; grammar src/kseq.hpp:170-208).
+ * Host-side; fills malloc'd concatenated buffers (rk_free each).  names/quals are NUL-separated.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rk_seqset {
+    int64_t nseq;
+    uint8_t* bases;      /* concatenated, NOT upper-cased here (device does it) */
+    uint64_t* offsets;   /* [nseq+1] */
+    char* names;         /* name_0 \0 name_1 \0 ... */
+    uint64_t* name_offsets; /* [nseq+1] */
+    char* quals;         /* concatenated (same offsets as bases) or NULL when any record lacks quals */
+} rk_seqset;
+int rk_parse_files(const char* const* paths, int npaths, rk_seqset* out);
+void rk_seqset_free(rk_seqset* s);
+/* Streaming form (the build's replacement of KSEQ_Reader::get_next_buffer, src/rkmh.cpp:951-959, 2085-2094):
+ * up to max_records records / max_bases bases per call (0 = unlimited); out->nseq == 0 at end of input.
+ * path "-" reads STDIN. */
+typedef struct rk_reader rk_reader;
+int rk_reader_open(const char* path, rk_reader** out);
+int rk_reader_next(rk_reader* r, int64_t max_records, uint64_t max_bases, rk_seqset* out);
+void rk_reader_close(rk_reader* r);
+
+/* Synthetic-workload generator of the measured configuration: reads [lo,hi) of the
+ * global read set drawn from the reference panel with 1 % substitutions, strand flips and 1-in-1000 'N'.
+ * Host-side utility for bench.py and the tests; out holds (hi-lo)*read_len bytes. */
+int rk_synth_reads(const uint8_t* ref_bases, const uint64_t* ref_offsets, int nref, uint64_t lo, uint64_t hi,
+                   int read_len, uint64_t seed, uint8_t* out, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

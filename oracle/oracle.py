@@ -1,0 +1,262 @@
+"""ctypes front-end of the CPU ORACLE (oracle/rk_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package rkmh_amd/.
+PARITY UNPINNED: see oracle/rk_oracle.h (mkmh submodule absent; policy U1..U12 switchable).
+
+Also holds a small pure-Python restatement of the kseq record grammar
+(/root/reference/src/kseq.hpp:170-208) and of the stream/classify TSV line
+(/root/reference/src/rkmh.cpp:887-893) used to check the product's parser / CLI.
+"""
+import ctypes as C
+import gzip
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FOLD_SWAP32, FOLD_H1, FOLD_W2W1 = 0, 1, 2
+
+
+class Policy(C.Structure):
+    _fields_ = [("fold", C.c_int32), ("drop_last_window", C.c_int32),
+                ("counter_counts_zero", C.c_int32), ("mask_strict_less", C.c_int32),
+                ("freq_max_inclusive", C.c_int32), ("seed", C.c_uint32)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "librkoracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.rko_calc_hash.restype = C.c_uint64
+        _LIB.rko_counter_new.restype = C.c_void_p
+        _LIB.rko_counter_get.restype = C.c_int32
+        _LIB.rko_max_threads.restype = C.c_int
+    return _LIB
+
+
+def default_policy(**kw):
+    p = Policy()
+    lib().rko_default_policy(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def murmur3_x64_128(key: bytes, seed: int):
+    out = (C.c_uint64 * 2)()
+    lib().rko_murmur3_x64_128(key, len(key), C.c_uint32(seed), out)
+    return int(out[0]), int(out[1])
+
+
+def to_upper(s: bytes) -> bytes:
+    b = C.create_string_buffer(s, len(s))
+    lib().rko_to_upper(b, len(s))
+    return b.raw
+
+
+def calc_hash(kmer: bytes, policy=None) -> int:
+    policy = policy or default_policy()
+    return int(lib().rko_calc_hash(kmer, len(kmer), C.byref(policy)))
+
+
+def calc_hashes(seq: bytes, ks, policy=None) -> np.ndarray:
+    """calc_hashes on an ALREADY upper-cased sequence (as the reference call sites pass it)."""
+    policy = policy or default_policy()
+    ks = np.asarray(ks, dtype=np.int32)
+    out = C.POINTER(C.c_uint64)()
+    n = C.c_int()
+    lib().rko_calc_hashes(seq, len(seq), _p(ks, C.c_int), len(ks), C.byref(out), C.byref(n), C.byref(policy))
+    r = np.ctypeslib.as_array(out, shape=(max(n.value, 0),)).copy() if n.value > 0 else np.zeros(0, np.uint64)
+    lib().rko_free(out)
+    return r.astype(np.uint64)
+
+
+def minhashes(h: np.ndarray, S: int) -> np.ndarray:
+    h = np.ascontiguousarray(h, dtype=np.uint64).copy()
+    out = C.POINTER(C.c_uint64)()
+    m = C.c_int()
+    lib().rko_minhashes(_p(h, C.c_uint64), len(h), S, C.byref(out), C.byref(m))
+    r = np.ctypeslib.as_array(out, shape=(max(m.value, 1),))[: m.value].copy()
+    lib().rko_free(out)
+    return r.astype(np.uint64)
+
+
+def hash_intersection_size(a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = C.c_int()
+    lib().rko_hash_intersection_size(_p(a, C.c_uint64), len(a), _p(b, C.c_uint64), len(b), C.byref(out))
+    return out.value
+
+
+def argmax_diff(shared):
+    s = np.ascontiguousarray(shared, dtype=np.int32)
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    lib().rko_argmax_diff(_p(s, C.c_int), len(s), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def pack(seqs):
+    """list[bytes] -> (uint8 bases, uint64 offsets[n+1])"""
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if seqs:
+        offs[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if seqs else np.zeros(0, np.uint8)
+    return bases, offs
+
+
+def sketch_refs(bases, offsets, ks, S, policy=None, threads=1, max_samples=None, counter_slots=200000000):
+    policy = policy or default_policy()
+    ks = np.asarray(ks, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    nref = len(offsets) - 1
+    sk = np.zeros((nref, S), dtype=np.uint64)
+    ln = np.zeros(nref, dtype=np.int32)
+    if max_samples is None:
+        lib().rko_sketch_refs(_p(bases, C.c_char), _p(offsets, C.c_uint64), nref, _p(ks, C.c_int), len(ks), S,
+                              _p(sk, C.c_uint64), _p(ln, C.c_int32), C.byref(policy), threads)
+    else:
+        lib().rko_sketch_refs_maxsamples(_p(bases, C.c_char), _p(offsets, C.c_uint64), nref, _p(ks, C.c_int),
+                                         len(ks), S, int(max_samples), C.c_uint64(counter_slots),
+                                         _p(sk, C.c_uint64), _p(ln, C.c_int32), C.byref(policy), threads)
+    return sk, ln
+
+
+def classify_stream(bases, offsets, ks, S, ref_sketches, ref_lens, policy=None, threads=1,
+                    min_kmer_occ=None, counter_slots=200000000):
+    """The literal loop rkmh.cpp:845-898 (or :904-948 when min_kmer_occ is given).
+    Returns int32 [nreads,4] = (max_id, max_shared, diff, min_num)."""
+    policy = policy or default_policy()
+    ks = np.asarray(ks, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    ref_sketches = np.ascontiguousarray(ref_sketches, dtype=np.uint64)
+    ref_lens = np.ascontiguousarray(ref_lens, dtype=np.int32)
+    n = len(offsets) - 1
+    out = np.zeros((n, 4), dtype=np.int32)
+    if min_kmer_occ is None:
+        lib().rko_classify_stream(_p(bases, C.c_char), _p(offsets, C.c_uint64), C.c_int64(n),
+                                  _p(ks, C.c_int), len(ks), S, _p(ref_sketches, C.c_uint64),
+                                  _p(ref_lens, C.c_int32), len(ref_lens), _p(out, C.c_int32),
+                                  C.byref(policy), threads)
+    else:
+        lib().rko_classify_stream_depth(_p(bases, C.c_char), _p(offsets, C.c_uint64), C.c_int64(n),
+                                        _p(ks, C.c_int), len(ks), S, _p(ref_sketches, C.c_uint64),
+                                        _p(ref_lens, C.c_int32), len(ref_lens), int(min_kmer_occ),
+                                        C.c_uint64(counter_slots), _p(out, C.c_int32), C.byref(policy), threads)
+    return out
+
+
+def max_threads():
+    return lib().rko_max_threads()
+
+
+# ---------------------------------------------------------------------------------------------
+# kseq record grammar, restated from /root/reference/src/kseq.hpp:170-208 (byte-at-a-time).
+# Returns list of (name, seq, qual_or_None).  A truncated-quality record (-2) ENDS parsing, as
+# the reference's loop condition `kseq_read(seq) >= 0` (src/rkmh.cpp:251) does.
+# ---------------------------------------------------------------------------------------------
+def kseq_parse_bytes(data: bytes):
+    recs = []
+    pos, n = 0, len(data)
+    last_char = 0
+
+    def getc():
+        nonlocal pos
+        if pos >= n:
+            return -1
+        c = data[pos]
+        pos += 1
+        return c
+
+    SPACE = b" \t\n\v\f\r"
+    while True:
+        if last_char == 0:
+            while True:
+                c = getc()
+                if c == -1 or c == ord(">") or c == ord("@"):
+                    break
+            if c == -1:
+                break
+            last_char = c
+        # name: up to first whitespace (ks_getuntil delimiter 0 = isspace), kseq.hpp:181
+        if pos >= n:
+            break
+        start = pos
+        while pos < n and data[pos] not in SPACE:
+            pos += 1
+        name = data[start:pos]
+        c = data[pos] if pos < n else -1
+        if pos < n:
+            pos += 1
+        if c != ord("\n") and c != -1:
+            while pos < n and data[pos] != ord("\n"):  # comment, kseq.hpp:182
+                pos += 1
+            if pos < n:
+                pos += 1
+        seq = bytearray()
+        while True:
+            c = getc()
+            if c == -1 or c == ord(">") or c == ord("+") or c == ord("@"):
+                break
+            if 33 <= c <= 126:  # isgraph, kseq.hpp:184
+                seq.append(c)
+        if c == ord(">") or c == ord("@"):
+            last_char = c
+        if c != ord("+"):
+            recs.append((name, bytes(seq), None))
+            if c == -1:
+                break
+            continue
+        while True:  # skip rest of '+' line
+            c = getc()
+            if c == -1 or c == ord("\n"):
+                break
+        if c == -1:
+            break  # -2: truncated
+        qual = bytearray()
+        while True:
+            c = getc()
+            if c == -1 or not (len(qual) < len(seq)):
+                break
+            if 33 <= c <= 127:
+                qual.append(c)
+        last_char = 0
+        if len(qual) != len(seq):
+            break  # -2 ends the loop
+        recs.append((name, bytes(seq), bytes(qual)))
+    return recs
+
+
+def kseq_parse_file(path):
+    with open(path, "rb") as f:
+        head = f.read(2)
+    opener = gzip.open if head == b"\x1f\x8b" else open
+    with opener(path, "rb") as f:
+        return kseq_parse_bytes(f.read())
+
+
+def stream_line(ref_name, read_name, max_shared, diff, min_num, sketch_size, min_matches=-1, min_diff=0):
+    """One stdout line of stream/classify: /root/reference/src/rkmh.cpp:887-893."""
+    diff_filter = diff > min_diff
+    depth_filter = min_num <= min_matches
+    match_filter = max_shared < min_matches
+    return "%s\t%s\t%d\t%d%s\t%s\t%s\n" % (
+        ref_name, read_name, max_shared, sketch_size, "FAIL:DEPTH" if depth_filter else "",
+        "FAIL:MATCHES" if match_filter else "", "" if diff_filter else "FAIL:DIFF")

@@ -1,0 +1,393 @@
+"""ctypes binding of include/rkmh_amd.h (the C ABI of librkmh_amd.so).
+
+Mirrors the reference's interface for the hot path: the mkmh free functions called from
+/root/reference/src/rkmh.cpp (calc_hashes :860, minhashes :863, hash_intersection_size :869, ...) as
+methods of `Context`, plus the batched replacements of main_stream's loops (:813-898, :904-948).
+Fails loudly when the HIP library is missing -- there is no CPU implementation behind this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FOLD_SWAP32, FOLD_H1, FOLD_W2W1 = 0, 1, 2
+
+
+class RkmhError(RuntimeError):
+    pass
+
+
+class Policy(C.Structure):
+    _fields_ = [("fold", C.c_int32), ("drop_last_window", C.c_int32), ("counter_counts_zero", C.c_int32),
+                ("mask_strict_less", C.c_int32), ("freq_max_inclusive", C.c_int32), ("seed", C.c_uint32)]
+
+
+class SeqSet(C.Structure):
+    _fields_ = [("nseq", C.c_int64), ("bases", C.POINTER(C.c_uint8)), ("offsets", C.POINTER(C.c_uint64)),
+                ("names", C.POINTER(C.c_char)), ("name_offsets", C.POINTER(C.c_uint64)),
+                ("quals", C.POINTER(C.c_char))]
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "librkmh_amd.so")
+
+
+_u8p, _u64p, _i32p, _ip = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_int)
+
+_SIGS = {
+    "rk_default_policy": (None, [C.POINTER(Policy)]),
+    "rk_last_error": (C.c_char_p, []),
+    "rk_version": (C.c_char_p, []),
+    "rk_device_count": (C.c_int, []),
+    "rk_ctx_create": (C.c_int, [C.c_int, C.POINTER(Policy), C.POINTER(C.c_void_p)]),
+    "rk_ctx_destroy": (None, [C.c_void_p]),
+    "rk_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "rk_free": (None, [C.c_void_p]),
+    "rk_to_upper": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "rk_calc_hashes": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _ip, C.c_int, C.POINTER(_u64p), _ip]),
+    "rk_calc_hashes_counted": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _ip, C.c_int, C.POINTER(_u64p), _ip, C.c_void_p]),
+    "rk_calc_hash": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _u64p]),
+    "rk_minhashes": (C.c_int, [C.c_void_p, _u64p, C.c_int, C.c_int, C.POINTER(_u64p), _ip]),
+    "rk_mask_by_frequency": (C.c_int, [C.c_void_p, _u64p, C.c_int, C.c_void_p, C.c_int]),
+    "rk_minhashes_frequency_filter": (C.c_int, [C.c_void_p, _u64p, C.c_int, C.c_int, C.POINTER(_u64p), _ip, C.c_void_p, C.c_int, C.c_int]),
+    "rk_hash_intersection_size": (C.c_int, [C.c_void_p, _u64p, C.c_int, _u64p, C.c_int, _ip]),
+    "rk_counter_create": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "rk_counter_wrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "rk_counter_destroy": (None, [C.c_void_p]),
+    "rk_counter_clear": (C.c_int, [C.c_void_p]),
+    "rk_counter_increment": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "rk_counter_get": (C.c_int, [C.c_void_p, C.c_uint64, _i32p]),
+    "rk_counter_device_ptr": (C.c_void_p, [C.c_void_p]),
+    "rk_counter_slots": (C.c_uint64, [C.c_void_p]),
+    "rk_hash_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, _ip, C.c_int, C.POINTER(_u64p), _u64p]),
+    "rk_sketch_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, _ip, C.c_int, C.c_int, _u64p, _i32p]),
+    "rk_set_references": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.c_uint64]),
+    "rk_set_reference_sketches": (C.c_int, [C.c_void_p, _u64p, _i32p, C.c_int, _ip, C.c_int, C.c_int]),
+    "rk_get_reference_sketches": (C.c_int, [C.c_void_p, _u64p, _i32p]),
+    "rk_num_references": (C.c_int, [C.c_void_p]),
+    "rk_set_depth_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "rk_count_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, C.c_void_p]),
+    "rk_count_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rk_classify_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, _i32p]),
+    "rk_classify_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rk_format_stream_line": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rk_parse_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.POINTER(SeqSet)]),
+    "rk_seqset_free": (None, [C.POINTER(SeqSet)]),
+    "rk_reader_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "rk_reader_next": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(SeqSet)]),
+    "rk_reader_close": (None, [C.c_void_p]),
+    "rk_synth_reads": (C.c_int, [_u8p, _u64p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, _u8p, C.c_int]),
+}
+
+
+def load_library():
+    """Loads librkmh_amd.so (built in-tree by `make` / __graft_entry__.build()). No fallback."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RkmhError("%s is missing: build it with `make` (hipcc --offload-arch=gfx950). "
+                            "rkmh_amd has no CPU fallback." % path)
+        lib = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI drifted
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RkmhError("rkmh_amd error %d: %s" % (rc, load_library().rk_last_error().decode()))
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _ks(ks):
+    if np.isscalar(ks):
+        ks = [ks]
+    return np.ascontiguousarray(ks, dtype=np.int32)
+
+
+def _padded(bases):
+    """uint8 copy with >= 8 readable bytes past the end (device staging reads aligned dwords)."""
+    b = np.zeros(len(bases) + 16, dtype=np.uint8)
+    b[: len(bases)] = np.frombuffer(bases, dtype=np.uint8) if isinstance(bases, (bytes, bytearray)) else bases
+    return b
+
+
+def pack(seqs):
+    """list[bytes] -> (uint8 bases (padded), uint64 offsets[n+1])"""
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if len(seqs):
+        offs[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    return _padded(b"".join(seqs)), offs
+
+
+def _seqset_to_py(ss):
+    n = ss.nseq
+    offs = np.ctypeslib.as_array(ss.offsets, shape=(n + 1,)).copy()
+    nb = int(offs[-1])
+    bases = np.zeros(nb + 16, dtype=np.uint8)
+    if nb:
+        bases[:nb] = np.ctypeslib.as_array(ss.bases, shape=(nb,))
+    noffs = np.ctypeslib.as_array(ss.name_offsets, shape=(n + 1,)).copy()
+    names_raw = C.string_at(ss.names, int(noffs[-1])) if n else b""
+    names = [names_raw[int(noffs[i]): int(noffs[i + 1]) - 1] for i in range(n)]
+    quals = None
+    if ss.quals:
+        q = C.string_at(ss.quals, nb)
+        quals = [q[int(offs[i]): int(offs[i + 1])] for i in range(n)]
+    return {"bases": bases, "offsets": offs, "names": names, "quals": quals, "nseq": n}
+
+
+def parse_files(paths):
+    """parse_fastas (rkmh.cpp:238-292): FASTA/FASTQ(.gz) files -> dict(bases, offsets, names, quals)."""
+    lib = load_library()
+    arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+    ss = SeqSet()
+    _chk(lib.rk_parse_files(arr, len(paths), C.byref(ss)))
+    try:
+        return _seqset_to_py(ss)
+    finally:
+        lib.rk_seqset_free(C.byref(ss))
+
+
+class Reader:
+    """Streaming FASTA/FASTQ(.gz) reader (batches ready for Context.classify)."""
+
+    def __init__(self, path):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        _chk(self._lib.rk_reader_open(os.fsencode(path), C.byref(self._h)))
+
+    def next_batch(self, max_records=1 << 20, max_bases=1 << 28):
+        ss = SeqSet()
+        _chk(self._lib.rk_reader_next(self._h, max_records, max_bases, C.byref(ss)))
+        try:
+            return _seqset_to_py(ss) if ss.nseq else None
+        finally:
+            self._lib.rk_seqset_free(C.byref(ss))
+
+    def close(self):
+        if self._h:
+            self._lib.rk_reader_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_stream_line(ref_name, read_name, max_shared, diff, min_num, sketch_size, min_matches=-1, min_diff=0):
+    lib = load_library()
+    cap = len(ref_name) + len(read_name) + 128
+    buf = C.create_string_buffer(cap)
+    n = lib.rk_format_stream_line(buf, cap, ref_name, read_name, max_shared, diff, min_num, sketch_size,
+                                  min_matches, min_diff)
+    if n < 0:
+        _chk(n)
+    return buf.raw[:n]
+
+
+class Counter:
+    """HASHTCounter (rkmh.cpp:739): int32 table in HBM, slot = key % slots."""
+
+    def __init__(self, ctx, slots=None, device_ptr=None):
+        self._lib = load_library()
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        if device_ptr is not None:
+            _chk(self._lib.rk_counter_wrap(ctx._h, C.c_void_p(device_ptr), slots, C.byref(self._h)))
+        else:
+            _chk(self._lib.rk_counter_create(ctx._h, slots, C.byref(self._h)))
+
+    def increment(self, key):
+        _chk(self._lib.rk_counter_increment(self._h, int(key)))
+
+    def get(self, key):
+        v = C.c_int32()
+        _chk(self._lib.rk_counter_get(self._h, int(key), C.byref(v)))
+        return v.value
+
+    def clear(self):
+        _chk(self._lib.rk_counter_clear(self._h))
+
+    @property
+    def slots(self):
+        return int(self._lib.rk_counter_slots(self._h))
+
+    @property
+    def device_ptr(self):
+        return int(self._lib.rk_counter_device_ptr(self._h))
+
+    def destroy(self):
+        if self._h:
+            self._lib.rk_counter_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU. Methods are named after the reference's functions they replace."""
+
+    def __init__(self, device=0, **policy):
+        self._lib = load_library()
+        p = Policy()
+        self._lib.rk_default_policy(C.byref(p))
+        for k, v in policy.items():
+            setattr(p, k, v)
+        self.policy = p
+        self._h = C.c_void_p()
+        _chk(self._lib.rk_ctx_create(device, C.byref(p), C.byref(self._h)))
+        self.sketch_size = None
+        self.ks = None
+
+    def close(self):
+        if self._h:
+            self._lib.rk_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _chk(self._lib.rk_ctx_synchronize(self._h))
+
+    # ---- inner boundary (mkmh mirrors) -------------------------------------------------------
+    def to_upper(self, s: bytes) -> bytes:
+        b = C.create_string_buffer(s, len(s))
+        _chk(self._lib.rk_to_upper(self._h, b, len(s)))
+        return b.raw
+
+    def calc_hashes(self, seq: bytes, ks, counter=None) -> np.ndarray:
+        ks = _ks(ks)
+        out = _u64p()
+        n = C.c_int()
+        if counter is None:
+            _chk(self._lib.rk_calc_hashes(self._h, seq, len(seq), _p(ks, C.c_int), len(ks), C.byref(out), C.byref(n)))
+        else:
+            _chk(self._lib.rk_calc_hashes_counted(self._h, seq, len(seq), _p(ks, C.c_int), len(ks), C.byref(out),
+                                                  C.byref(n), counter._h))
+        r = np.ctypeslib.as_array(out, shape=(max(n.value, 1),))[: n.value].copy()
+        self._lib.rk_free(out)
+        return r
+
+    def calc_hash(self, kmer: bytes) -> int:
+        v = C.c_uint64()
+        _chk(self._lib.rk_calc_hash(self._h, kmer, len(kmer), C.byref(v)))
+        return int(v.value)
+
+    def minhashes(self, h: np.ndarray, sketch_size: int, counter=None, min_count=0, max_count=0):
+        """Returns (mins, sorted_input) -- the reference sorts its input in place."""
+        h = np.ascontiguousarray(h, dtype=np.uint64).copy()
+        out = _u64p()
+        m = C.c_int()
+        if counter is None:
+            _chk(self._lib.rk_minhashes(self._h, _p(h, C.c_uint64), len(h), sketch_size, C.byref(out), C.byref(m)))
+        else:
+            _chk(self._lib.rk_minhashes_frequency_filter(self._h, _p(h, C.c_uint64), len(h), sketch_size, C.byref(out),
+                                                         C.byref(m), counter._h, min_count, max_count))
+        r = np.ctypeslib.as_array(out, shape=(max(sketch_size, 1),))[: m.value].copy()
+        self._lib.rk_free(out)
+        return r, h
+
+    def mask_by_frequency(self, h: np.ndarray, counter, min_occ: int) -> np.ndarray:
+        h = np.ascontiguousarray(h, dtype=np.uint64).copy()
+        _chk(self._lib.rk_mask_by_frequency(self._h, _p(h, C.c_uint64), len(h), counter._h, min_occ))
+        return h
+
+    def hash_intersection_size(self, a, b) -> int:
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = C.c_int()
+        _chk(self._lib.rk_hash_intersection_size(self._h, _p(a, C.c_uint64), len(a), _p(b, C.c_uint64), len(b), C.byref(out)))
+        return out.value
+
+    # ---- outer boundary (batches) ------------------------------------------------------------
+    def hash_batch(self, bases, offsets, ks):
+        ks = _ks(ks)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        ho = np.zeros(n + 1, dtype=np.uint64)
+        out = _u64p()
+        _chk(self._lib.rk_hash_batch(self._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), n, _p(ks, C.c_int), len(ks),
+                                     C.byref(out), _p(ho, C.c_uint64)))
+        tot = int(ho[-1])
+        r = np.ctypeslib.as_array(out, shape=(max(tot, 1),))[:tot].copy()
+        self._lib.rk_free(out)
+        return r, ho
+
+    def sketch_batch(self, bases, offsets, ks, sketch_size):
+        ks = _ks(ks)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        sk = np.zeros((n, sketch_size), dtype=np.uint64)
+        ln = np.zeros(n, dtype=np.int32)
+        _chk(self._lib.rk_sketch_batch(self._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), n, _p(ks, C.c_int), len(ks),
+                                       sketch_size, _p(sk, C.c_uint64), _p(ln, C.c_int32)))
+        return sk, ln
+
+    def set_references(self, bases, offsets, ks, sketch_size, max_samples=None, counter_slots=0):
+        ks = _ks(ks)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _chk(self._lib.rk_set_references(self._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), len(offsets) - 1,
+                                         _p(ks, C.c_int), len(ks), sketch_size,
+                                         -1 if max_samples is None else int(max_samples), counter_slots))
+        self.sketch_size, self.ks = sketch_size, ks
+
+    def set_reference_sketches(self, sketches, lens, ks, sketch_size):
+        ks = _ks(ks)
+        sketches = np.ascontiguousarray(sketches, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        _chk(self._lib.rk_set_reference_sketches(self._h, _p(sketches, C.c_uint64), _p(lens, C.c_int32), len(lens),
+                                                 _p(ks, C.c_int), len(ks), sketch_size))
+        self.sketch_size, self.ks = sketch_size, ks
+
+    def get_reference_sketches(self):
+        n = self._lib.rk_num_references(self._h)
+        sk = np.zeros((n, self.sketch_size), dtype=np.uint64)
+        ln = np.zeros(n, dtype=np.int32)
+        _chk(self._lib.rk_get_reference_sketches(self._h, _p(sk, C.c_uint64), _p(ln, C.c_int32)))
+        return sk, ln
+
+    def set_depth_filter(self, counter, min_kmer_occ):
+        _chk(self._lib.rk_set_depth_filter(self._h, counter._h if counter is not None else None, min_kmer_occ))
+        self._depth = counter
+
+    def count_batch(self, bases, offsets, counter):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _chk(self._lib.rk_count_batch(self._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), len(offsets) - 1, counter._h))
+
+    def classify(self, bases, offsets) -> np.ndarray:
+        """main_stream's per-read loop for a host batch -> int32 [n,4] (max_id, max_shared, diff, min_num)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        out = np.zeros((n, 4), dtype=np.int32)
+        _chk(self._lib.rk_classify_batch(self._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), n, _p(out, C.c_int32)))
+        return out
+
+    def classify_device(self, d_bases_ptr, d_offsets_ptr, nreads, d_out_ptr, max_read_len=0, stream=0):
+        """Same with inputs resident in HBM (raw device pointers, e.g. torch tensors' data_ptr())."""
+        _chk(self._lib.rk_classify_batch_device(self._h, C.c_void_p(d_bases_ptr), C.c_void_p(d_offsets_ptr), nreads,
+                                                C.c_void_p(d_out_ptr), max_read_len, C.c_void_p(stream)))
+
+    def count_device(self, d_bases_ptr, d_offsets_ptr, nreads, counter, stream=0):
+        _chk(self._lib.rk_count_batch_device(self._h, C.c_void_p(d_bases_ptr), C.c_void_p(d_offsets_ptr), nreads,
+                                             counter._h, C.c_void_p(stream)))

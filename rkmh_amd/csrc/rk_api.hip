@@ -1,0 +1,784 @@
+// rk_api.hip -- the C ABI of include/rkmh_amd.h on top of the gfx950 kernels (rk_kernels.hip).
+// Host-side orchestration only: device memory, tile descriptors, the reference index build, the
+// pinned double-buffered H2D/D2H pipeline.  No CPU implementation of any hashing/sketching step lives
+// here: every entry point fails with RK_ERR_HIP when no GPU is usable.
+#include "../../include/rkmh_amd.h"
+#include "rk_kernels.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rk;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) return fail(RK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define RKCHK(expr) do { int _r = (expr); if (_r != RK_OK) return _r; } while (0)
+
+extern "C" const char* rk_last_error(void) { return g_err.c_str(); }
+extern "C" void rk__set_error(const char* msg) { g_err = msg ? msg : ""; }
+extern "C" const char* rk_version(void) { return "rkmh_amd 0.1 (gfx950)"; }
+extern "C" void rk_default_policy(rk_policy* p) {
+    p->fold = RK_FOLD_SWAP32; p->drop_last_window = 1; p->counter_counts_zero = 1;
+    p->mask_strict_less = 1; p->freq_max_inclusive = 1; p->seed = 42;
+}
+extern "C" int rk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" void rk_free(void* p) { free(p); }
+
+// growable device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return RK_OK;
+        if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
+        size_t want = bytes + (bytes >> 3) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(RK_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        cap = want;
+        return RK_OK;
+    }
+    void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; cap = 0; }
+    template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return RK_OK;
+        if (p) { hipError_t e = hipHostFree(p); (void)e; p = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc(&p, bytes + 256, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return fail(RK_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        cap = bytes + 256;
+        return RK_OK;
+    }
+    void release() { if (p) { hipError_t e = hipHostFree(p); (void)e; } p = nullptr; cap = 0; }
+    template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+struct rk_counter {
+    rk_ctx* ctx;
+    int32_t* d;
+    uint64_t slots;
+    bool owned;
+};
+
+struct Slot { // one half of the double-buffered classify pipeline
+    PinBuf h_bases, h_offs, h_out;
+    DevBuf d_bases, d_offs, d_out;
+    hipStream_t st = nullptr;
+    hipEvent_t done = nullptr;
+    int64_t first = 0, n = 0;
+    bool busy = false;
+};
+
+struct rk_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    DevPolicy pol{};
+    // references
+    int nref = 0, S = 0;
+    KsArr ks{};
+    std::vector<uint64_t> h_sk;
+    std::vector<int32_t> h_lens;
+    DevBuf d_keys, d_vals, d_post;
+    RefIndex ix{};
+    bool have_refs = false;
+    // -M
+    rk_counter* depth = nullptr;
+    int min_occ = 0;
+    // workspaces for the general path
+    DevBuf w_bases, w_tiles, w_hashes, w_segoff, w_ids, w_sk, w_lens, w_out, w_misc;
+    Slot slot[2];
+};
+
+static int set_dev(rk_ctx* c) { HIPCHK(hipSetDevice(c->device)); return RK_OK; }
+
+extern "C" int rk_ctx_create(int device, const rk_policy* policy, rk_ctx** out) {
+    if (!out) return fail(RK_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(RK_ERR_HIP, "no HIP device available (%s): rkmh_amd has no CPU fallback", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(RK_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    rk_ctx* c = new rk_ctx();
+    c->device = device;
+    rk_policy p;
+    if (policy) p = *policy; else rk_default_policy(&p);
+    c->pol.fold = p.fold; c->pol.drop_last_window = p.drop_last_window;
+    c->pol.counter_counts_zero = p.counter_counts_zero; c->pol.mask_strict_less = p.mask_strict_less;
+    c->pol.freq_max_inclusive = p.freq_max_inclusive; c->pol.seed = p.seed;
+    HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    for (auto& s : c->slot) {
+        HIPCHK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    *out = c;
+    return RK_OK;
+}
+extern "C" void rk_ctx_destroy(rk_ctx* c) {
+    if (!c) return;
+    hipError_t e = hipSetDevice(c->device); (void)e;
+    e = hipDeviceSynchronize(); (void)e;
+    for (DevBuf* b : {&c->d_keys, &c->d_vals, &c->d_post, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+                      &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc}) b->release();
+    for (auto& s : c->slot) {
+        s.h_bases.release(); s.h_offs.release(); s.h_out.release();
+        s.d_bases.release(); s.d_offs.release(); s.d_out.release();
+        if (s.done) { e = hipEventDestroy(s.done); (void)e; }
+        if (s.st) { e = hipStreamDestroy(s.st); (void)e; }
+    }
+    if (c->st) { e = hipStreamDestroy(c->st); (void)e; }
+    delete c;
+}
+extern "C" int rk_ctx_synchronize(rk_ctx* c) {
+    if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
+    RKCHK(set_dev(c));
+    HIPCHK(hipDeviceSynchronize());
+    return RK_OK;
+}
+
+static int check_ks(const int* ks, int nks, KsArr* out) {
+    if (!ks || nks < 1 || nks > RK_MAX_KS) return fail(RK_ERR_ARG, "need 1..%d k-mer sizes, got %d", RK_MAX_KS, nks);
+    out->n = nks;
+    for (int i = 0; i < nks; ++i) {
+        if (ks[i] < 1 || ks[i] > RK_MAX_K) return fail(RK_ERR_LIMIT, "k=%d outside [1,%d]", ks[i], RK_MAX_K);
+        out->k[i] = ks[i];
+    }
+    return RK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// General path: hash tiles -> (optional) in-LDS sort / sketch / intersect, for sequences of any length.
+struct GeneralOut {
+    uint64_t* hashes = nullptr;      // host, [total hashes of the batch] (caller sized via hash_offsets)
+    uint64_t* sketches = nullptr;    // host [n*S]
+    int32_t* lens = nullptr;         // host [n]
+    int32_t* out4 = nullptr;         // host [n*4]
+    bool write_back_sorted = false;  // hashes out = sorted segments (minhashes in-place semantics)
+};
+struct GeneralCfg {
+    KsArr ks;
+    int S = 0;
+    rk_counter* inc_counter = nullptr; // increment while hashing (6-arg calc_hashes)
+    const rk_counter* filt_counter = nullptr;
+    int filter_mode = FILTER_NONE, fmin = 0, fmax = 0;
+    bool single_kmer = false;          // calc_hash(string): exactly one window of len bases per sequence
+    bool classify = false;
+};
+
+static uint32_t next_pow2(uint32_t x) { uint32_t p = 64; while (p < x) p <<= 1; return p; }
+
+// d_bases: device pointer to the batch's bases when already resident (else nullptr => upload from `bases`)
+static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_in, const uint64_t* offsets, int64_t n,
+                       const GeneralCfg& cfg, const GeneralOut& out) {
+    RKCHK(set_dev(c));
+    if (n <= 0) return RK_OK;
+    const bool need_sort = out.sketches || out.lens || out.out4 || out.write_back_sorted;
+    if (cfg.classify && !c->have_refs) return fail(RK_ERR_STATE, "classify before rk_set_references");
+    const uint64_t MAX_CHUNK_BASES = 1ull << 28, MAX_CHUNK_HASHES = 1ull << 26;
+    std::vector<TileDesc> tiles;
+    std::vector<uint64_t> seg;
+    std::vector<std::vector<uint32_t>> classes(32);
+    uint64_t hash_cursor = 0; // position in out.hashes
+    int64_t i0 = 0;
+    while (i0 < n) {
+        // ---- pick a chunk [i0,i1)
+        int64_t i1 = i0;
+        uint64_t cb = 0, ch = 0;
+        tiles.clear(); seg.clear(); seg.push_back(0);
+        for (auto& v : classes) v.clear();
+        const uint64_t base0 = offsets[i0];
+        while (i1 < n) {
+            uint64_t len = offsets[i1 + 1] - offsets[i1];
+            uint64_t nh = 0;
+            if (cfg.single_kmer) nh = 1;
+            else for (int j = 0; j < cfg.ks.n; ++j) nh += (uint64_t)num_windows((int)len, cfg.ks.k[j], c->pol.drop_last_window);
+            if (len > 0x7fffffffull) return fail(RK_ERR_LIMIT, "sequence %lld longer than 2^31-1", (long long)i1);
+            if (i1 > i0 && (cb + len > MAX_CHUNK_BASES || ch + nh > MAX_CHUNK_HASHES)) break;
+            if (need_sort && nh > (uint64_t)SORT_MAX_P)
+                return fail(RK_ERR_LIMIT, "sequence %lld has %llu hashes; the in-LDS sketcher handles <= %d (radix-select path not built yet)",
+                            (long long)i1, (unsigned long long)nh, SORT_MAX_P);
+            // tiles
+            uint64_t o = seg.back();
+            uint64_t rel = offsets[i1] - base0;
+            if (cfg.single_kmer) {
+                if (len < 1 || len > RK_MAX_K) return fail(RK_ERR_LIMIT, "k-mer length %llu outside [1,%d]", (unsigned long long)len, RK_MAX_K);
+                tiles.push_back(TileDesc{rel, o, (uint32_t)len, 1u, (uint32_t)len, 0u});
+                o += 1;
+            } else {
+                for (int j = 0; j < cfg.ks.n; ++j) {
+                    int k = cfg.ks.k[j];
+                    uint32_t nw = (uint32_t)num_windows((int)len, k, c->pol.drop_last_window);
+                    for (uint32_t w0 = 0; w0 < nw; w0 += HASH_TILE_WIN) {
+                        uint32_t cnt = std::min<uint32_t>(HASH_TILE_WIN, nw - w0);
+                        tiles.push_back(TileDesc{rel + w0, o + w0, cnt + (uint32_t)k - 1u, cnt, (uint32_t)k, 0u});
+                    }
+                    o += nw;
+                }
+            }
+            seg.push_back(o);
+            if (need_sort) {
+                uint32_t P = next_pow2((uint32_t)nh);
+                int cls = 0; while ((64u << cls) < P) ++cls;
+                classes[cls].push_back((uint32_t)(i1 - i0));
+            }
+            cb += len; ch += nh; ++i1;
+        }
+        const int64_t cn = i1 - i0;
+        // ---- upload
+        const uint8_t* d_bases;
+        if (d_bases_in) d_bases = d_bases_in + base0;
+        else {
+            RKCHK(c->w_bases.reserve(cb + 64));
+            if (cb) HIPCHK(hipMemcpyAsync(c->w_bases.p, bases + base0, cb, hipMemcpyHostToDevice, c->st));
+            d_bases = c->w_bases.as<uint8_t>();
+        }
+        if (((uintptr_t)d_bases & 3) != 0) {
+            // stage_piece reads aligned dwords; a misaligned base pointer is folded into the tile offsets
+            uint64_t mis = (uintptr_t)d_bases & 3;
+            d_bases -= mis;
+            for (auto& t : tiles) t.base_off += mis;
+        }
+        RKCHK(c->w_tiles.reserve(tiles.size() * sizeof(TileDesc)));
+        RKCHK(c->w_segoff.reserve(seg.size() * 8));
+        RKCHK(c->w_hashes.reserve((ch + 1) * 8));
+        if (!tiles.empty()) HIPCHK(hipMemcpyAsync(c->w_tiles.p, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, c->st));
+        HIPCHK(hipMemcpyAsync(c->w_segoff.p, seg.data(), seg.size() * 8, hipMemcpyHostToDevice, c->st));
+        HIPCHK(launch_hash_tiles(d_bases, c->w_tiles.as<TileDesc>(), (uint32_t)tiles.size(), c->w_hashes.as<uint64_t>(),
+                                 cfg.inc_counter ? cfg.inc_counter->d : nullptr, cfg.inc_counter ? cfg.inc_counter->slots : 1,
+                                 c->pol, c->st));
+        if (out.hashes && !out.write_back_sorted && ch)
+            HIPCHK(hipMemcpyAsync(out.hashes + hash_cursor, c->w_hashes.p, ch * 8, hipMemcpyDeviceToHost, c->st));
+        if (need_sort) {
+            const int S = cfg.S;
+            if (out.sketches) RKCHK(c->w_sk.reserve((size_t)cn * S * 8));
+            if (out.lens) RKCHK(c->w_lens.reserve((size_t)cn * 4));
+            if (out.out4) RKCHK(c->w_out.reserve((size_t)cn * 16));
+            RKCHK(c->w_ids.reserve((size_t)cn * 4));
+            size_t id_cursor = 0;
+            for (int cls = 0; cls < 32; ++cls) {
+                auto& ids = classes[cls];
+                if (ids.empty()) continue;
+                uint32_t* d_ids = c->w_ids.as<uint32_t>() + id_cursor;
+                HIPCHK(hipMemcpyAsync(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->st));
+                id_cursor += ids.size();
+                SortArgs a{};
+                a.hashes = c->w_hashes.as<uint64_t>(); a.seg_off = c->w_segoff.as<uint64_t>();
+                a.seq_ids = d_ids; a.nlist = (uint32_t)ids.size(); a.P = 64u << cls; a.S = S;
+                a.write_back = out.write_back_sorted ? 1 : 0;
+                a.sketches = out.sketches ? c->w_sk.as<uint64_t>() : nullptr;
+                a.lens = out.lens ? c->w_lens.as<int32_t>() : nullptr;
+                a.out4 = out.out4 ? c->w_out.as<int32_t>() : nullptr;
+                a.counter = cfg.filt_counter ? cfg.filt_counter->d : nullptr;
+                a.slots = cfg.filt_counter ? cfg.filt_counter->slots : 1;
+                a.filter_mode = cfg.filter_mode; a.fmin = cfg.fmin; a.fmax = cfg.fmax;
+                HIPCHK(launch_sort_intersect(a, cfg.classify ? &c->ix : nullptr, c->pol, c->st));
+            }
+            // the ids vectors must outlive the async copies
+            HIPCHK(hipStreamSynchronize(c->st));
+            if (out.write_back_sorted && out.hashes && ch)
+                HIPCHK(hipMemcpyAsync(out.hashes + hash_cursor, c->w_hashes.p, ch * 8, hipMemcpyDeviceToHost, c->st));
+            if (out.sketches) HIPCHK(hipMemcpyAsync(out.sketches + (size_t)i0 * S, c->w_sk.p, (size_t)cn * S * 8, hipMemcpyDeviceToHost, c->st));
+            if (out.lens) HIPCHK(hipMemcpyAsync(out.lens + i0, c->w_lens.p, (size_t)cn * 4, hipMemcpyDeviceToHost, c->st));
+            if (out.out4) HIPCHK(hipMemcpyAsync(out.out4 + (size_t)i0 * 4, c->w_out.p, (size_t)cn * 16, hipMemcpyDeviceToHost, c->st));
+        }
+        HIPCHK(hipStreamSynchronize(c->st));
+        hash_cursor += ch;
+        i0 = i1;
+    }
+    return RK_OK;
+}
+
+static void fill_hash_offsets(const rk_ctx* c, const uint64_t* offsets, int64_t n, const KsArr& ks, uint64_t* ho) {
+    ho[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t len = offsets[i + 1] - offsets[i], nh = 0;
+        for (int j = 0; j < ks.n; ++j) nh += (uint64_t)num_windows((int)len, ks.k[j], c->pol.drop_last_window);
+        ho[i + 1] = ho[i] + nh;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// inner boundary
+extern "C" int rk_to_upper(rk_ctx* c, char* seq, int len) {
+    if (!c || (!seq && len > 0) || len < 0) return fail(RK_ERR_ARG, "bad arguments");
+    if (len == 0) return RK_OK;
+    RKCHK(set_dev(c));
+    RKCHK(c->w_bases.reserve((size_t)len));
+    HIPCHK(hipMemcpyAsync(c->w_bases.p, seq, (size_t)len, hipMemcpyHostToDevice, c->st));
+    HIPCHK(launch_to_upper(c->w_bases.as<uint8_t>(), (uint64_t)len, c->st));
+    HIPCHK(hipMemcpyAsync(seq, c->w_bases.p, (size_t)len, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return RK_OK;
+}
+
+static int calc_hashes_impl(rk_ctx* c, const char* seq, int len, const int* ks, int nks, uint64_t** out, int* n, rk_counter* counter) {
+    if (!c || !out || !n || (!seq && len > 0) || len < 0) return fail(RK_ERR_ARG, "bad arguments");
+    GeneralCfg cfg;
+    RKCHK(check_ks(ks, nks, &cfg.ks));
+    cfg.inc_counter = counter;
+    uint64_t offs[2] = {0, (uint64_t)len};
+    uint64_t ho[2];
+    fill_hash_offsets(c, offs, 1, cfg.ks, ho);
+    uint64_t* h = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(ho[1] ? ho[1] : 1));
+    if (!h) return fail(RK_ERR_NOMEM, "malloc");
+    // upper-casing is the caller's job in the reference (to_upper precedes calc_hashes, rkmh.cpp:856-860);
+    // the device upper-cases on the fly, which is idempotent for already upper-cased input.
+    GeneralOut go; go.hashes = h;
+    int r = general_run(c, (const uint8_t*)seq, nullptr, offs, 1, cfg, go);
+    if (r != RK_OK) { free(h); return r; }
+    *out = h; *n = (int)ho[1];
+    return RK_OK;
+}
+extern "C" int rk_calc_hashes(rk_ctx* c, const char* seq, int len, const int* ks, int nks, uint64_t** out, int* n) {
+    return calc_hashes_impl(c, seq, len, ks, nks, out, n, nullptr);
+}
+extern "C" int rk_calc_hashes_counted(rk_ctx* c, const char* seq, int len, const int* ks, int nks, uint64_t** out, int* n, rk_counter* counter) {
+    if (!counter) return fail(RK_ERR_ARG, "counter is NULL");
+    return calc_hashes_impl(c, seq, len, ks, nks, out, n, counter);
+}
+extern "C" int rk_calc_hash(rk_ctx* c, const char* kmer, int k, uint64_t* out) {
+    if (!c || !kmer || !out) return fail(RK_ERR_ARG, "bad arguments");
+    GeneralCfg cfg; cfg.single_kmer = true; cfg.ks.n = 1; cfg.ks.k[0] = k;
+    uint64_t offs[2] = {0, (uint64_t)k};
+    GeneralOut go; go.hashes = out;
+    return general_run(c, (const uint8_t*)kmer, nullptr, offs, 1, cfg, go);
+}
+
+// sort-only pipeline over hashes that are already on the host (minhashes & friends)
+static int minhashes_impl(rk_ctx* c, uint64_t* h, int n, int S, uint64_t** mins, int* m, const rk_counter* counter,
+                          int filter_mode, int fmin, int fmax, bool sort_input) {
+    if (!c || (!h && n > 0) || n < 0 || !mins || !m) return fail(RK_ERR_ARG, "bad arguments");
+    if (S < 1 || S > RK_MAX_SKETCH) return fail(RK_ERR_LIMIT, "sketch size %d outside [1,%d]", S, RK_MAX_SKETCH);
+    if (n > SORT_MAX_P) return fail(RK_ERR_LIMIT, "%d hashes; the in-LDS sketcher handles <= %d", n, SORT_MAX_P);
+    RKCHK(set_dev(c));
+    uint64_t* r = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)S);
+    if (!r) return fail(RK_ERR_NOMEM, "malloc");
+    int rc = RK_OK;
+    do {
+        if ((rc = c->w_hashes.reserve((size_t)(n + 1) * 8)) != RK_OK) break;
+        if ((rc = c->w_segoff.reserve(16)) != RK_OK) break;
+        if ((rc = c->w_ids.reserve(4)) != RK_OK) break;
+        if ((rc = c->w_sk.reserve((size_t)S * 8)) != RK_OK) break;
+        if ((rc = c->w_lens.reserve(4)) != RK_OK) break;
+        uint64_t seg[2] = {0, (uint64_t)n};
+        uint32_t id0 = 0;
+        int32_t len = 0;
+        hipError_t e = hipSuccess;
+        if (n) e = hipMemcpyAsync(c->w_hashes.p, h, (size_t)n * 8, hipMemcpyHostToDevice, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->w_segoff.p, seg, 16, hipMemcpyHostToDevice, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->w_ids.p, &id0, 4, hipMemcpyHostToDevice, c->st);
+        SortArgs a{};
+        a.hashes = c->w_hashes.as<uint64_t>(); a.seg_off = c->w_segoff.as<uint64_t>(); a.seq_ids = c->w_ids.as<uint32_t>();
+        a.nlist = 1; a.P = next_pow2((uint32_t)n); a.S = S; a.write_back = sort_input ? 1 : 0;
+        a.sketches = c->w_sk.as<uint64_t>(); a.lens = c->w_lens.as<int32_t>(); a.out4 = nullptr;
+        a.counter = counter ? counter->d : nullptr; a.slots = counter ? counter->slots : 1;
+        a.filter_mode = filter_mode; a.fmin = fmin; a.fmax = fmax;
+        if (e == hipSuccess) e = launch_sort_intersect(a, nullptr, c->pol, c->st);
+        if (e == hipSuccess && sort_input && n) e = hipMemcpyAsync(h, c->w_hashes.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(r, c->w_sk.p, (size_t)S * 8, hipMemcpyDeviceToHost, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&len, c->w_lens.p, 4, hipMemcpyDeviceToHost, c->st);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->st);
+        if (e != hipSuccess) { rc = fail(RK_ERR_HIP, "minhashes pipeline: %s", hipGetErrorString(e)); break; }
+        *m = len;
+    } while (0);
+    if (rc != RK_OK) { free(r); return rc; }
+    *mins = r;
+    return RK_OK;
+}
+extern "C" int rk_minhashes(rk_ctx* c, uint64_t* h, int n, int S, uint64_t** mins, int* m) {
+    return minhashes_impl(c, h, n, S, mins, m, nullptr, FILTER_NONE, 0, 0, true);
+}
+extern "C" int rk_minhashes_frequency_filter(rk_ctx* c, uint64_t* h, int n, int S, uint64_t** out, int* m,
+                                             const rk_counter* counter, int min_count, int max_count) {
+    if (!counter) return fail(RK_ERR_ARG, "counter is NULL");
+    return minhashes_impl(c, h, n, S, out, m, counter, FILTER_RANGE, min_count, max_count, true);
+}
+extern "C" int rk_mask_by_frequency(rk_ctx* c, uint64_t* h, int n, const rk_counter* counter, int min_occ) {
+    if (!c || !counter || (!h && n > 0) || n < 0) return fail(RK_ERR_ARG, "bad arguments");
+    if (n == 0) return RK_OK;
+    RKCHK(set_dev(c));
+    RKCHK(c->w_hashes.reserve((size_t)n * 8));
+    HIPCHK(hipMemcpyAsync(c->w_hashes.p, h, (size_t)n * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(launch_mask_by_frequency(c->w_hashes.as<uint64_t>(), (uint64_t)n, counter->d, counter->slots, min_occ, c->pol, c->st));
+    HIPCHK(hipMemcpyAsync(h, c->w_hashes.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return RK_OK;
+}
+
+extern "C" int rk_hash_intersection_size(rk_ctx* c, const uint64_t* a, int na, const uint64_t* b, int nb, int* out) {
+    if (!c || !out || na < 0 || nb < 0 || (!a && na) || (!b && nb)) return fail(RK_ERR_ARG, "bad arguments");
+    RKCHK(set_dev(c));
+    RKCHK(c->w_hashes.reserve((size_t)(na + nb + 2) * 8));
+    RKCHK(c->w_lens.reserve(4));
+    uint64_t* da = c->w_hashes.as<uint64_t>();
+    uint64_t* db = da + na;
+    if (na) HIPCHK(hipMemcpyAsync(da, a, (size_t)na * 8, hipMemcpyHostToDevice, c->st));
+    if (nb) HIPCHK(hipMemcpyAsync(db, b, (size_t)nb * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(launch_intersect_pair(da, na, db, nb, c->w_lens.as<int>(), c->st));
+    HIPCHK(hipMemcpyAsync(out, c->w_lens.p, 4, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return RK_OK;
+}
+
+// ---- HASHTCounter ------------------------------------------------------------------------------
+extern "C" int rk_counter_create(rk_ctx* c, uint64_t slots, rk_counter** out) {
+    if (!c || !out || slots == 0) return fail(RK_ERR_ARG, "bad arguments");
+    RKCHK(set_dev(c));
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, slots * 4);
+    if (e != hipSuccess) return fail(RK_ERR_NOMEM, "hipMalloc(%llu) for counter: %s", (unsigned long long)(slots * 4), hipGetErrorString(e));
+    HIPCHK(hipMemsetAsync(d, 0, slots * 4, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    *out = new rk_counter{c, (int32_t*)d, slots, true};
+    return RK_OK;
+}
+extern "C" int rk_counter_wrap(rk_ctx* c, void* d, uint64_t slots, rk_counter** out) {
+    if (!c || !out || !d || slots == 0) return fail(RK_ERR_ARG, "bad arguments");
+    *out = new rk_counter{c, (int32_t*)d, slots, false};
+    return RK_OK;
+}
+extern "C" void rk_counter_destroy(rk_counter* k) {
+    if (!k) return;
+    if (k->owned) { hipError_t e = hipSetDevice(k->ctx->device); (void)e; e = hipFree(k->d); (void)e; }
+    delete k;
+}
+extern "C" int rk_counter_clear(rk_counter* k) {
+    if (!k) return fail(RK_ERR_ARG, "counter is NULL");
+    RKCHK(set_dev(k->ctx));
+    HIPCHK(hipMemsetAsync(k->d, 0, k->slots * 4, k->ctx->st));
+    HIPCHK(hipStreamSynchronize(k->ctx->st));
+    return RK_OK;
+}
+extern "C" int rk_counter_increment(rk_counter* k, uint64_t key) {
+    if (!k) return fail(RK_ERR_ARG, "counter is NULL");
+    RKCHK(set_dev(k->ctx));
+    HIPCHK(launch_counter_inc(k->d, k->slots, key, k->ctx->st));
+    HIPCHK(hipStreamSynchronize(k->ctx->st));
+    return RK_OK;
+}
+extern "C" int rk_counter_get(const rk_counter* k, uint64_t key, int32_t* out) {
+    if (!k || !out) return fail(RK_ERR_ARG, "bad arguments");
+    RKCHK(set_dev(k->ctx));
+    HIPCHK(hipMemcpy(out, k->d + (key % k->slots), 4, hipMemcpyDeviceToHost));
+    return RK_OK;
+}
+extern "C" void* rk_counter_device_ptr(rk_counter* k) { return k ? k->d : nullptr; }
+extern "C" uint64_t rk_counter_slots(const rk_counter* k) { return k ? k->slots : 0; }
+
+// ---- batched: hash / sketch --------------------------------------------------------------------
+extern "C" int rk_hash_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int64_t nseq,
+                             const int* ks, int nks, uint64_t** out, uint64_t* hash_offsets) {
+    if (!c || !offsets || nseq < 0 || !out || !hash_offsets) return fail(RK_ERR_ARG, "bad arguments");
+    GeneralCfg cfg;
+    RKCHK(check_ks(ks, nks, &cfg.ks));
+    fill_hash_offsets(c, offsets, nseq, cfg.ks, hash_offsets);
+    uint64_t total = hash_offsets[nseq];
+    uint64_t* h = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(total ? total : 1));
+    if (!h) return fail(RK_ERR_NOMEM, "malloc");
+    GeneralOut go; go.hashes = h;
+    int r = general_run(c, bases, nullptr, offsets, nseq, cfg, go);
+    if (r != RK_OK) { free(h); return r; }
+    *out = h;
+    return RK_OK;
+}
+
+extern "C" int rk_sketch_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int64_t nseq,
+                               const int* ks, int nks, int S, uint64_t* sketches, int32_t* lens) {
+    if (!c || !offsets || nseq < 0 || !sketches || !lens) return fail(RK_ERR_ARG, "bad arguments");
+    if (S < 1 || S > RK_MAX_SKETCH) return fail(RK_ERR_LIMIT, "sketch size %d outside [1,%d]", S, RK_MAX_SKETCH);
+    GeneralCfg cfg;
+    RKCHK(check_ks(ks, nks, &cfg.ks));
+    cfg.S = S;
+    GeneralOut go; go.sketches = sketches; go.lens = lens;
+    return general_run(c, bases, nullptr, offsets, nseq, cfg, go);
+}
+
+// ---- references --------------------------------------------------------------------------------
+static int build_index(rk_ctx* c) {
+    struct Pair { uint64_t h; uint32_t ref; };
+    const int R = c->nref, S = c->S;
+    if (R > 0xFFFFF) return fail(RK_ERR_LIMIT, "more than 2^20-1 references");
+    std::vector<Pair> pairs;
+    for (int r = 0; r < R; ++r)
+        for (int j = 0; j < c->h_lens[(size_t)r]; ++j) {
+            uint64_t h = c->h_sk[(size_t)r * S + j];
+            if (h != 0) pairs.push_back(Pair{h, (uint32_t)r});
+        }
+    std::sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) { return a.h != b.h ? a.h < b.h : a.ref < b.ref; });
+    size_t distinct = 0;
+    for (size_t i = 0; i < pairs.size(); ++i) if (i == 0 || pairs[i].h != pairs[i - 1].h) ++distinct;
+    uint32_t size = 1024;
+    while ((size_t)size < distinct * 2 + 1) size <<= 1;
+    std::vector<uint64_t> keys(size, 0);
+    std::vector<uint32_t> vals(size, 0);
+    std::vector<uint32_t> post;
+    post.push_back(0);
+    const uint32_t mask = size - 1;
+    size_t i = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> grp;
+    while (i < pairs.size()) {
+        size_t j = i;
+        grp.clear();
+        while (j < pairs.size() && pairs[j].h == pairs[i].h) {
+            size_t k = j; while (k < pairs.size() && pairs[k].h == pairs[i].h && pairs[k].ref == pairs[j].ref) ++k;
+            grp.emplace_back(pairs[j].ref, (uint32_t)(k - j));
+            j = k;
+        }
+        uint32_t v;
+        if (grp.size() == 1 && grp[0].second <= 0x7FFu) v = grp[0].first | (grp[0].second << 20);
+        else {
+            if (post.size() + 1 + 2 * grp.size() >= 0x7fffffffull) return fail(RK_ERR_LIMIT, "postings overflow");
+            v = 0x80000000u | (uint32_t)post.size();
+            post.push_back((uint32_t)grp.size());
+            for (auto& g : grp) { post.push_back(g.first); post.push_back(g.second); }
+        }
+        uint32_t s = index_slot(pairs[i].h, mask);
+        while (keys[s] != 0) s = (s + 1) & mask;
+        keys[s] = pairs[i].h; vals[s] = v;
+        i = j;
+    }
+    RKCHK(c->d_keys.reserve((size_t)size * 8));
+    RKCHK(c->d_vals.reserve((size_t)size * 4));
+    RKCHK(c->d_post.reserve(post.size() * 4));
+    HIPCHK(hipMemcpy(c->d_keys.p, keys.data(), (size_t)size * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_vals.p, vals.data(), (size_t)size * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_post.p, post.data(), post.size() * 4, hipMemcpyHostToDevice));
+    c->ix.keys = c->d_keys.as<uint64_t>(); c->ix.vals = c->d_vals.as<uint32_t>(); c->ix.post = c->d_post.as<uint32_t>();
+    c->ix.mask = mask; c->ix.nref = R;
+    c->have_refs = true;
+    return RK_OK;
+}
+
+extern "C" int rk_set_reference_sketches(rk_ctx* c, const uint64_t* sketches, const int32_t* lens, int nref,
+                                         const int* ks, int nks, int S) {
+    if (!c || !sketches || !lens || nref < 1) return fail(RK_ERR_ARG, "bad arguments (need >= 1 reference)");
+    if (S < 1 || S > RK_MAX_SKETCH) return fail(RK_ERR_LIMIT, "sketch size %d outside [1,%d]", S, RK_MAX_SKETCH);
+    RKCHK(set_dev(c));
+    RKCHK(check_ks(ks, nks, &c->ks));
+    c->nref = nref; c->S = S;
+    c->h_sk.assign(sketches, sketches + (size_t)nref * S);
+    c->h_lens.assign(lens, lens + nref);
+    for (int r = 0; r < nref; ++r)
+        if (lens[r] < 0 || lens[r] > S) return fail(RK_ERR_ARG, "sketch length %d of reference %d outside [0,%d]", lens[r], r, S);
+    return build_index(c);
+}
+
+extern "C" int rk_set_references(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int nref,
+                                 const int* ks, int nks, int S, int max_samples, uint64_t counter_slots) {
+    if (!c || !offsets || nref < 1) return fail(RK_ERR_ARG, "bad arguments (need >= 1 reference; rkmh.cpp:848 is undefined for 0)");
+    if (S < 1 || S > RK_MAX_SKETCH) return fail(RK_ERR_LIMIT, "sketch size %d outside [1,%d]", S, RK_MAX_SKETCH);
+    GeneralCfg cfg;
+    RKCHK(check_ks(ks, nks, &cfg.ks));
+    cfg.S = S;
+    std::vector<uint64_t> sk((size_t)nref * S);
+    std::vector<int32_t> lens((size_t)nref);
+    GeneralOut go; go.sketches = sk.data(); go.lens = lens.data();
+    rk_counter* cnt = nullptr;
+    if (max_samples >= 0) {
+        // -I path (rkmh.cpp:828-838): pass 1 counts every k-mer occurrence, pass 2 sketches with the range filter
+        RKCHK(rk_counter_create(c, counter_slots ? counter_slots : 200000000ull, &cnt));
+        GeneralCfg c1 = cfg; c1.inc_counter = cnt;
+        GeneralOut none;
+        int r = general_run(c, bases, nullptr, offsets, nref, c1, none);
+        if (r != RK_OK) { rk_counter_destroy(cnt); return r; }
+        cfg.filt_counter = cnt; cfg.filter_mode = FILTER_RANGE; cfg.fmin = 0; cfg.fmax = max_samples;
+    }
+    int r = general_run(c, bases, nullptr, offsets, nref, cfg, go);
+    if (cnt) rk_counter_destroy(cnt);
+    if (r != RK_OK) return r;
+    return rk_set_reference_sketches(c, sk.data(), lens.data(), nref, ks, nks, S);
+}
+
+extern "C" int rk_get_reference_sketches(rk_ctx* c, uint64_t* sketches, int32_t* lens) {
+    if (!c || !sketches || !lens) return fail(RK_ERR_ARG, "bad arguments");
+    if (!c->have_refs) return fail(RK_ERR_STATE, "no references set");
+    memcpy(sketches, c->h_sk.data(), c->h_sk.size() * 8);
+    memcpy(lens, c->h_lens.data(), c->h_lens.size() * 4);
+    return RK_OK;
+}
+extern "C" int rk_num_references(const rk_ctx* c) { return c ? c->nref : 0; }
+
+extern "C" int rk_set_depth_filter(rk_ctx* c, rk_counter* counter, int min_kmer_occ) {
+    if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
+    c->depth = counter; c->min_occ = min_kmer_occ;
+    return RK_OK;
+}
+
+// ---- the hot loop -------------------------------------------------------------------------------
+static int pick_maxlen(uint32_t max_read_len) {
+    int m = (int)((max_read_len + 63u) & ~63u);
+    if (m < 64) m = 64;
+    if (m > FUSED_MAXLEN) m = FUSED_MAXLEN;
+    return m;
+}
+
+static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nreads, void* d_out4,
+                        uint32_t max_read_len, int mode, rk_counter* count_into, hipStream_t st) {
+    if (nreads > 0xfffffff0ll) return fail(RK_ERR_LIMIT, "more than 2^32-16 reads in one device batch");
+    if (((uintptr_t)d_bases & 3) != 0) return fail(RK_ERR_ARG, "d_bases must be 4-byte aligned");
+    int32_t* counter = nullptr; uint64_t slots = 1; int min_occ = 0;
+    if (mode == 1) { counter = count_into->d; slots = count_into->slots; }
+    else if (c->depth) { counter = c->depth->d; slots = c->depth->slots; min_occ = c->min_occ; }
+    HIPCHK(launch_classify_fused((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
+                                 counter, slots, min_occ, mode, (int32_t*)d_out4, c->pol, pick_maxlen(max_read_len), st));
+    return RK_OK;
+}
+
+static int device_max_len(rk_ctx* c, const void* d_offs, int64_t nreads, hipStream_t st, uint32_t* out) {
+    RKCHK(c->w_misc.reserve(16));
+    HIPCHK(launch_max_len((const uint32_t*)d_offs, (uint32_t)nreads, c->w_misc.as<uint32_t>(), st));
+    HIPCHK(hipMemcpyAsync(out, c->w_misc.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return RK_OK;
+}
+
+// reroute reads the fused kernel flagged (max_id == -2) through the general path; offsets = u64 host offsets
+static int reroute_flagged(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, int32_t* out4) {
+    std::vector<int64_t> idx;
+    for (int64_t i = 0; i < nreads; ++i) if (out4[i * 4] == -2) idx.push_back(i);
+    if (idx.empty()) return RK_OK;
+    std::vector<uint64_t> offs(idx.size() + 1, 0);
+    for (size_t j = 0; j < idx.size(); ++j) offs[j + 1] = offs[j] + (offsets[idx[j] + 1] - offsets[idx[j]]);
+    std::vector<uint8_t> sub((size_t)offs.back() + 8);
+    for (size_t j = 0; j < idx.size(); ++j) memcpy(sub.data() + offs[j], bases + offsets[idx[j]], (size_t)(offs[j + 1] - offs[j]));
+    std::vector<int32_t> res(idx.size() * 4);
+    GeneralCfg cfg; cfg.ks = c->ks; cfg.S = c->S; cfg.classify = true;
+    if (c->depth) { cfg.filt_counter = c->depth; cfg.filter_mode = FILTER_MASK_MIN; cfg.fmin = c->min_occ; }
+    GeneralOut go; go.out4 = res.data();
+    RKCHK(general_run(c, sub.data(), nullptr, offs.data(), (int64_t)idx.size(), cfg, go));
+    for (size_t j = 0; j < idx.size(); ++j) memcpy(out4 + idx[j] * 4, res.data() + j * 4, 16);
+    return RK_OK;
+}
+
+extern "C" int rk_classify_batch_device(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nreads,
+                                        void* d_out4, uint32_t max_read_len, void* hip_stream) {
+    if (!c || nreads < 0 || (nreads > 0 && (!d_bases || !d_offs || !d_out4))) return fail(RK_ERR_ARG, "bad arguments");
+    if (!c->have_refs) return fail(RK_ERR_STATE, "classify before rk_set_references");
+    RKCHK(set_dev(c));
+    if (nreads == 0) return RK_OK;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->st;
+    // the resident-input entry point serves reads the fused kernel can take (len <= FUSED_MAXLEN and all
+    // hashes inside the sketch); anything else is flagged -2 in d_out4 for the caller (rk_classify_batch
+    // reroutes those through the general path itself).
+    if (max_read_len == 0) RKCHK(device_max_len(c, d_offs, nreads, st, &max_read_len));
+    return fused_device(c, d_bases, d_offs, nreads, d_out4, max_read_len, 0, nullptr, st);
+}
+
+extern "C" int rk_count_batch_device(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nreads,
+                                     rk_counter* counter, void* hip_stream) {
+    if (!c || !counter || nreads < 0 || (nreads > 0 && (!d_bases || !d_offs))) return fail(RK_ERR_ARG, "bad arguments");
+    RKCHK(set_dev(c));
+    if (nreads == 0) return RK_OK;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->st;
+    uint32_t ml = 0;
+    RKCHK(device_max_len(c, d_offs, nreads, st, &ml));
+    if (ml > (uint32_t)FUSED_MAXLEN) return fail(RK_ERR_LIMIT, "rk_count_batch_device: reads longer than %d need rk_count_batch", FUSED_MAXLEN);
+    if (c->ks.n == 0) return fail(RK_ERR_STATE, "k-mer sizes unknown: call rk_set_references first");
+    return fused_device(c, d_bases, d_offs, nreads, nullptr, ml, 1, counter, st);
+}
+
+// double-buffered host pipeline around the fused kernel. mode 0 classify, mode 1 count.
+static int host_pipeline(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, int32_t* out4,
+                         int mode, rk_counter* count_into) {
+    RKCHK(set_dev(c));
+    const int64_t MAX_READS = 1 << 21;
+    const uint64_t MAX_BASES = 1ull << 29;
+    int64_t i0 = 0;
+    int which = 0;
+    auto drain = [&](Slot& s) -> int {
+        if (!s.busy) return RK_OK;
+        HIPCHK(hipEventSynchronize(s.done));
+        if (mode == 0) memcpy(out4 + s.first * 4, s.h_out.p, (size_t)s.n * 16);
+        s.busy = false;
+        return RK_OK;
+    };
+    while (i0 < nreads) {
+        int64_t i1 = i0;
+        uint64_t cb = 0;
+        uint32_t maxlen = 0;
+        while (i1 < nreads && i1 - i0 < MAX_READS) {
+            uint64_t len = offsets[i1 + 1] - offsets[i1];
+            if (i1 > i0 && cb + len > MAX_BASES) break;
+            if (len > 0xffffffffull - cb) return fail(RK_ERR_LIMIT, "read %lld too long for a 32-bit batch", (long long)i1);
+            cb += len; if (len > maxlen) maxlen = (uint32_t)len; ++i1;
+        }
+        const int64_t cn = i1 - i0;
+        Slot& s = c->slot[which];
+        RKCHK(drain(s));
+        RKCHK(s.h_bases.reserve(cb + 64)); RKCHK(s.h_offs.reserve((size_t)(cn + 1) * 4)); RKCHK(s.h_out.reserve((size_t)cn * 16));
+        RKCHK(s.d_bases.reserve(cb + 64)); RKCHK(s.d_offs.reserve((size_t)(cn + 1) * 4)); RKCHK(s.d_out.reserve((size_t)cn * 16));
+        const uint64_t b0 = offsets[i0];
+        memcpy(s.h_bases.p, bases + b0, cb);
+        uint32_t* ho = s.h_offs.as<uint32_t>();
+        for (int64_t i = 0; i <= cn; ++i) ho[i] = (uint32_t)(offsets[i0 + i] - b0);
+        HIPCHK(hipMemcpyAsync(s.d_bases.p, s.h_bases.p, cb, hipMemcpyHostToDevice, s.st));
+        HIPCHK(hipMemcpyAsync(s.d_offs.p, s.h_offs.p, (size_t)(cn + 1) * 4, hipMemcpyHostToDevice, s.st));
+        RKCHK(fused_device(c, s.d_bases.p, s.d_offs.p, cn, s.d_out.p, maxlen, mode, count_into, s.st));
+        if (mode == 0) HIPCHK(hipMemcpyAsync(s.h_out.p, s.d_out.p, (size_t)cn * 16, hipMemcpyDeviceToHost, s.st));
+        HIPCHK(hipEventRecord(s.done, s.st));
+        s.first = i0; s.n = cn; s.busy = true;
+        which ^= 1;
+        i0 = i1;
+    }
+    RKCHK(drain(c->slot[0]));
+    RKCHK(drain(c->slot[1]));
+    return RK_OK;
+}
+
+extern "C" int rk_classify_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, int32_t* out4) {
+    if (!c || !offsets || nreads < 0 || (nreads > 0 && !out4)) return fail(RK_ERR_ARG, "bad arguments");
+    if (!c->have_refs) return fail(RK_ERR_STATE, "classify before rk_set_references");
+    if (nreads == 0) return RK_OK;
+    RKCHK(host_pipeline(c, bases, offsets, nreads, out4, 0, nullptr));
+    return reroute_flagged(c, bases, offsets, nreads, out4);
+}
+
+extern "C" int rk_count_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, rk_counter* counter) {
+    if (!c || !offsets || nreads < 0 || !counter) return fail(RK_ERR_ARG, "bad arguments");
+    if (c->ks.n == 0) return fail(RK_ERR_STATE, "k-mer sizes unknown: call rk_set_references first");
+    if (nreads == 0) return RK_OK;
+    // reads longer than the fused kernel's limit go through the tile hasher
+    bool any_long = false;
+    for (int64_t i = 0; i < nreads; ++i) if (offsets[i + 1] - offsets[i] > (uint64_t)FUSED_MAXLEN) { any_long = true; break; }
+    if (!any_long) return host_pipeline(c, bases, offsets, nreads, nullptr, 1, counter);
+    GeneralCfg cfg; cfg.ks = c->ks; cfg.inc_counter = counter;
+    GeneralOut none;
+    return general_run(c, bases, nullptr, offsets, nreads, cfg, none);
+}
+
+extern "C" int rk_format_stream_line(char* dst, size_t cap, const char* ref_name, const char* read_name,
+                                     int max_shared, int diff, int min_num, int sketch_size, int min_matches, int min_diff) {
+    // src/rkmh.cpp:887-892
+    const bool diff_filter = diff > min_diff;
+    const bool depth_filter = min_num <= min_matches;
+    const bool match_filter = max_shared < min_matches;
+    int n = snprintf(dst, cap, "%s\t%s\t%d\t%d%s\t%s\t%s\n", ref_name, read_name, max_shared, sketch_size,
+                     depth_filter ? "FAIL:DEPTH" : "", match_filter ? "FAIL:MATCHES" : "", diff_filter ? "" : "FAIL:DIFF");
+    if (n < 0 || (size_t)n >= cap) return fail(RK_ERR_ARG, "line buffer too small");
+    return n;
+}

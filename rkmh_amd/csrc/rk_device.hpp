@@ -1,0 +1,249 @@
+// rk_device.hpp -- gfx950 device building blocks shared by the rkmh_amd kernels.
+//
+// Replaces (on the device) what mkmh::calc_hashes does per k-mer for the call sites
+// /root/reference/src/rkmh.cpp:821,860: canonical MurmurHash3_x64_128 (seed 42) of a k-mer window,
+// 0 for any window holding a non-ACGT base.  Windows are read from an LDS copy of the upper-cased
+// sequence and of its reverse complement, so a hash costs two unaligned LDS window reads
+// (aligned ds_read_b32 + v_alignbyte_b32) and two murmur evaluations -- no per-window complementing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rk {
+
+struct DevPolicy {
+    int32_t fold;
+    int32_t drop_last_window;
+    int32_t counter_counts_zero;
+    int32_t mask_strict_less;
+    int32_t freq_max_inclusive;
+    uint32_t seed;
+};
+
+constexpr uint64_t MM_C1 = 0x87c37b91114253d5ULL;
+constexpr uint64_t MM_C2 = 0x4cf5ad432745937fULL;
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t fmix64(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33; return k;
+}
+__device__ __forceinline__ void mm_block(uint64_t& h1, uint64_t& h2, uint64_t k1, uint64_t k2) {
+    k1 *= MM_C1; k1 = rotl64(k1, 31); k1 *= MM_C2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 *= MM_C2; k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+}
+// finalisation + the 128->64 fold (policy U1)
+__device__ __forceinline__ uint64_t mm_finish(uint64_t h1, uint64_t h2, uint32_t len, int fold) {
+    h1 ^= len; h2 ^= len;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2;
+    if (fold == 0) return (h1 << 32) | (h1 >> 32);   // ((u64)w[0] << 32) | w[1]
+    if (fold == 1) return h1;                        // *(u64*)w
+    h2 += h1;                                        // ((u64)w[2] << 32) | w[1]
+    return (h2 << 32) | (h1 >> 32);
+}
+
+// bytes [a, a+4) of a little-endian dword array, a = 4*idx + sh
+__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+
+// MurmurHash3_x64_128 of the k bytes starting at byte offset `a` of the LDS dword array w32.
+// The array must be readable for 8 dwords past the window (buffers are padded).
+template <int KT>
+__device__ __forceinline__ uint64_t murmur_window(const uint32_t* w32, uint32_t a, int k_rt, uint32_t seed, int fold) {
+    const int k = KT ? KT : k_rt;
+    uint32_t idx = a >> 2;
+    const uint32_t sh = a & 3;
+    uint64_t h1 = seed, h2 = seed;
+    uint32_t prev = w32[idx];
+    const int nblocks = k >> 4;
+    for (int b = 0; b < nblocks; ++b) {
+        uint32_t w1 = w32[idx + 1], w2 = w32[idx + 2], w3 = w32[idx + 3], w4 = w32[idx + 4];
+        uint32_t s0 = alignbyte(w1, prev, sh), s1 = alignbyte(w2, w1, sh);
+        uint32_t s2 = alignbyte(w3, w2, sh), s3 = alignbyte(w4, w3, sh);
+        mm_block(h1, h2, (uint64_t)s0 | ((uint64_t)s1 << 32), (uint64_t)s2 | ((uint64_t)s3 << 32));
+        prev = w4; idx += 4;
+    }
+    const int rem = k & 15;
+    if (rem) {
+        uint32_t w1 = w32[idx + 1], w2 = w32[idx + 2], w3 = w32[idx + 3], w4 = w32[idx + 4];
+        uint32_t t[4] = {alignbyte(w1, prev, sh), alignbyte(w2, w1, sh), alignbyte(w3, w2, sh), alignbyte(w4, w3, sh)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int nv = rem - 4 * q;
+            uint32_t m = nv >= 4 ? 0xffffffffu : (nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u));
+            t[q] &= m;
+        }
+        uint64_t k1 = (uint64_t)t[0] | ((uint64_t)t[1] << 32);
+        uint64_t k2 = (uint64_t)t[2] | ((uint64_t)t[3] << 32);
+        if (rem > 8) { k2 *= MM_C2; k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2; }
+        k1 *= MM_C1; k1 = rotl64(k1, 31); k1 *= MM_C2; h1 ^= k1;
+    }
+    return mm_finish(h1, h2, (uint32_t)k, fold);
+}
+
+// ---- per-dword (4 bases) SWAR helpers -------------------------------------------------------
+// mkmh::to_upper quirk: every (signed) char > 91 gets -32 (bytes >= 128 are negative => untouched)
+__device__ __forceinline__ uint32_t upper4(uint32_t x) {
+    uint32_t t = (x & 0x7f7f7f7fu) + 0x24242424u;   // bit7 <=> low7 >= 92
+    uint32_t m = t & ~x & 0x80808080u;
+    return x - (m >> 2);
+}
+// complement of upper-case A/C/G/T bytes (other bytes: don't care, their windows are never hashed)
+__device__ __forceinline__ uint32_t comp4(uint32_t x) {
+    uint32_t m = (x >> 1) & 0x01010101u;            // bit1: 0 for A,T  1 for C,G
+    return x ^ 0x15151515u ^ (m | (m << 4));        // A<->T: ^0x15, C<->G: ^0x04
+}
+// 4-bit mask: bit q set <=> byte q is NOT one of 'A','C','G','T'
+__device__ __forceinline__ uint32_t invalid4(uint32_t x) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t b = (x >> (8 * q)) & 0xffu;
+        uint32_t ok = ((b >> 5) == 2u) ? ((0x0010008Au >> (b & 31u)) & 1u) : 0u;
+        r |= (ok ^ 1u) << q;
+    }
+    return r;
+}
+
+// LDS image of one staged sequence piece.
+//   fwd  : dword array; the piece's first base sits at byte offset FWD_PAD + d (d = global misalignment)
+//   rc   : dword array; reverse complement string, byte 0 = complement of the LAST base
+//   inv  : bit (FWD_PAD + d + t) set <=> base t invalid (bits indexed by fwd byte position)
+constexpr int FWD_PAD = 4;   // bytes in front of the fwd image so that p-3 reads stay in bounds
+constexpr int TAIL_PAD = 40; // bytes readable past either string (murmur_window over-read)
+
+__host__ __device__ constexpr int stage_lds_dwords(int max_bases) {
+    // fwd + rc + inv
+    return ((FWD_PAD + 3 + max_bases + TAIL_PAD + 3) / 4) + ((max_bases + TAIL_PAD + 3) / 4) +
+           ((FWD_PAD + 3 + max_bases + 31) / 32 + 2);
+}
+
+struct Staged {
+    uint32_t* fwd;
+    uint32_t* rc;
+    uint32_t* inv;
+    uint32_t fbase; // byte offset of base 0 inside fwd
+    uint32_t nbases;
+};
+
+// Cooperative staging by a group of G threads (tid in [0,G)), G a multiple of 8 and all threads of
+// the group call it.  `sync` is __syncthreads (block groups) -- for one-wave groups the block IS the wave.
+template <typename SyncFn>
+__device__ __forceinline__ Staged stage_piece(const uint8_t* __restrict__ bases, uint64_t start, uint32_t nbases,
+                                              uint32_t* lds, int max_bases, int tid, int G, SyncFn sync) {
+    Staged s;
+    const int fwd_dw = (FWD_PAD + 3 + max_bases + TAIL_PAD + 3) / 4;
+    const int rc_dw = (max_bases + TAIL_PAD + 3) / 4;
+    s.fwd = lds;
+    s.rc = lds + fwd_dw;
+    s.inv = s.rc + rc_dw;
+    const uint32_t d = (uint32_t)(start & 3);
+    s.fbase = FWD_PAD + d;
+    s.nbases = nbases;
+    const uint32_t* g32 = reinterpret_cast<const uint32_t*>(bases) + (start >> 2);
+    const uint32_t ndw = (d + nbases + 3) >> 2;       // global dwords covering the piece
+    // fwd dword j (j>=1) holds global dword j-1 (FWD_PAD = 4 bytes = 1 dword)
+    for (uint32_t j0 = 0; j0 < ndw + 1; j0 += G) {
+        uint32_t j = j0 + tid;                         // fwd dword index
+        uint32_t x = 0;
+        if (j >= 1 && j <= ndw) x = upper4(g32[j - 1]);
+        uint32_t nib = invalid4(x);
+        if (j <= ndw) s.fwd[j] = x;
+        uint32_t n = nib << (4 * (tid & 7));
+        n |= __shfl_xor((int)n, 1);
+        n |= __shfl_xor((int)n, 2);
+        n |= __shfl_xor((int)n, 4);
+        if ((tid & 7) == 0) s.inv[j >> 3] = n;
+    }
+    sync();
+    // rc dword q covers rc bytes 4q..4q+3 = complement of fwd bytes p+3..p, p = fbase + nbases - 4 - 4q
+    const uint32_t nrc = (nbases + 3) >> 2;
+    for (uint32_t q = tid; q < nrc; q += G) {
+        int32_t p = (int32_t)(s.fbase + nbases) - 4 - 4 * (int32_t)q; // >= FWD_PAD + d - 3 >= 1
+        uint32_t idx = (uint32_t)p >> 2, sh = (uint32_t)p & 3;
+        uint32_t v = alignbyte(s.fwd[idx + 1], s.fwd[idx], sh);
+        s.rc[q] = __builtin_bswap32(comp4(v));
+    }
+    sync();
+    return s;
+}
+
+// all k bases of window i valid?  (bits fbase+i .. fbase+i+k-1 of inv all zero)
+template <int KT>
+__device__ __forceinline__ bool window_valid(const Staged& s, uint32_t i, int k_rt) {
+    const int k = KT ? KT : k_rt;
+    uint32_t bit = s.fbase + i;
+    uint32_t idx = bit >> 5, sh = bit & 31;
+    int left = k;
+    uint32_t lo = s.inv[idx];
+    uint32_t acc = 0;
+    while (left > 0) {
+        uint32_t hi = s.inv[idx + 1];
+        uint32_t x = __builtin_amdgcn_alignbit(hi, lo, sh); // 32 bits starting at `bit`
+        uint32_t m = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+        acc |= x & m;
+        lo = hi; ++idx; left -= 32;
+    }
+    return acc == 0;
+}
+
+// canonical hash of window i (k-mer size k) of a staged piece
+template <int KT>
+__device__ __forceinline__ uint64_t canonical_window(const Staged& s, uint32_t i, int k_rt, const DevPolicy& pol) {
+    const int k = KT ? KT : k_rt;
+    if (!window_valid<KT>(s, i, k)) return 0;
+    uint64_t f = murmur_window<KT>(s.fwd, s.fbase + i, k, pol.seed, pol.fold);
+    uint64_t r = murmur_window<KT>(s.rc, s.nbases - (uint32_t)k - i, k, pol.seed, pol.fold);
+    return f < r ? f : r;
+}
+
+__host__ __device__ __forceinline__ int num_windows(int len, int k, int drop_last) {
+    int n = drop_last ? len - k : len - k + 1;
+    return n > 0 ? n : 0;
+}
+
+// ---- resident reference index (open addressing, keys = distinct sketch hashes) ---------------
+struct RefIndex {
+    const uint64_t* keys;   // [mask+1], 0 = empty
+    const uint32_t* vals;   // [mask+1]: bit31=0 -> inline single posting (ref | mult<<20); bit31=1 -> offset into post
+    const uint32_t* post;   // [off] = count, then count x (ref, mult)
+    uint32_t mask;
+    int32_t nref;
+};
+constexpr uint32_t IDX_NOT_FOUND = 0xffffffffu;
+
+__host__ __device__ __forceinline__ uint32_t index_slot(uint64_t h, uint32_t mask) {
+    uint32_t x = (uint32_t)h ^ (uint32_t)(h >> 32);
+    x *= 0x9E3779B1u;
+    x ^= x >> 15;
+    return x & mask;
+}
+__device__ __forceinline__ uint32_t index_find(const RefIndex& ix, uint64_t h) {
+    uint32_t s = index_slot(h, ix.mask);
+    while (true) {
+        uint64_t key = ix.keys[s];
+        if (key == h) return s;
+        if (key == 0) return IDX_NOT_FOUND;
+        s = (s + 1) & ix.mask;
+    }
+}
+
+// 64-bit (value, index) wave reductions via shuffles
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+
+} // namespace rk

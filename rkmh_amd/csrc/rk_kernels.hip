@@ -1,0 +1,366 @@
+// rk_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the rkmh classify/stream hot path.
+//
+// What each kernel replaces in the reference (paths relative to /root/reference):
+//   k_hash_tiles       mkmh::calc_hashes over arbitrary-length sequences       src/rkmh.cpp:821,831,909,2101
+//   k_sort_intersect   mkmh::minhashes (+ mask_by_frequency / minhashes_frequency_filter) and, for
+//                      long reads, the intersection loop + argmax               src/rkmh.cpp:822,835,863,916-934
+//   k_classify_fused   the whole per-read loop body for reads whose windows all fit the sketch
+//                      (to_upper, calc_hashes, minhashes, R x hash_intersection_size, argmax/diff)
+//                                                                               src/rkmh.cpp:856-888
+//   k_intersect_pair   mkmh::hash_intersection_size for one pair                src/rkmh.cpp:869
+//
+// Integer hashing work: no MFMA.  The design points are coalesced dword loads of the bases, LDS-staged
+// forward + reverse-complement strings, wave ballots for compaction, LDS atomics for the per-reference
+// counters and a hash-table index of all reference sketches that stays L2/MALL resident.
+#include "rk_kernels.hpp"
+
+namespace rk {
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_to_upper(uint8_t* d, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        signed char c = (signed char)d[i];
+        d[i] = (uint8_t)(((int)c - 91) > 0 ? c - 32 : c);
+    }
+}
+hipError_t launch_to_upper(uint8_t* d, uint64_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint32_t grid = (uint32_t)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_to_upper, dim3(grid), dim3(256), 0, st, d, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// calc_hashes: one block per tile (grid-stride), tile = <= HASH_TILE_WIN windows of one sequence.
+template <int KT>
+__global__ __launch_bounds__(256) void k_hash_tiles(const uint8_t* __restrict__ bases, const TileDesc* __restrict__ tiles,
+                                                    uint32_t ntiles, uint64_t* __restrict__ out, int32_t* counter,
+                                                    uint64_t slots, DevPolicy pol) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[stage_lds_dwords(HASH_TILE_MAXB)];
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const TileDesc td = tiles[t];
+        if (KT != 0 && td.k != (uint32_t)KT) continue; // other k handled by the generic instance
+        if (KT == 0 && td.k == 16) continue;
+        __syncthreads(); // previous tile's readers are done
+        Staged s = stage_piece(bases, td.base_off, td.nbases, lds, HASH_TILE_MAXB, threadIdx.x, 256,
+                               [] { __syncthreads(); });
+        for (uint32_t i = threadIdx.x; i < td.nwin; i += 256) {
+            uint64_t h = canonical_window<KT>(s, i, (int)td.k, pol);
+            out[td.out_off + i] = h;
+            if (counter && (pol.counter_counts_zero || h != 0)) atomicAdd(&counter[h % slots], 1);
+        }
+    }
+}
+hipError_t launch_hash_tiles(const uint8_t* bases, const TileDesc* tiles, uint32_t ntiles, uint64_t* out,
+                             int32_t* counter, uint64_t slots, const DevPolicy& pol, hipStream_t st) {
+    if (ntiles == 0) return hipSuccess;
+    uint32_t grid = ntiles < 8192 ? ntiles : 8192;
+    hipLaunchKernelGGL(k_hash_tiles<16>, dim3(grid), dim3(256), 0, st, bases, tiles, ntiles, out, counter, slots, pol);
+    hipLaunchKernelGGL(k_hash_tiles<0>, dim3(grid), dim3(256), 0, st, bases, tiles, ntiles, out, counter, slots, pol);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared tail of both classify kernels: per-reference counters in LDS -> argmax/diff of rkmh.cpp:874-883
+// (first index attaining the max wins; diff = max - max(earlier entries), -1 when there is none).
+__device__ __forceinline__ void wave_argmax_diff(const int* sh, int R, int lane, int& max_id, int& max_shared, int& diff) {
+    int best = -1, besti = 0x7fffffff;
+    for (int j = lane; j < R; j += 64) {
+        int v = sh[j];
+        if (v > best) { best = v; besti = j; }
+    }
+    int gmax = wave_max_i32(best);
+    int gid = wave_min_i32(best == gmax ? besti : 0x7fffffff);
+    int prev = -1;
+    for (int j = lane; j < gid; j += 64) { int v = sh[j]; prev = v > prev ? v : prev; }
+    prev = wave_max_i32(prev);
+    max_id = gid; max_shared = gmax; diff = gmax - prev;
+}
+
+__device__ __forceinline__ void accumulate_posting(const RefIndex& ix, uint32_t slot, uint32_t rank, int* sh) {
+    uint32_t v = ix.vals[slot];
+    if (!(v >> 31)) {
+        uint32_t ref = v & 0xFFFFFu, mult = (v >> 20) & 0x7FFu;
+        if (rank < mult) atomicAdd(&sh[ref], 1);
+    } else {
+        uint32_t off = v & 0x7fffffffu;
+        uint32_t cnt = ix.post[off];
+        for (uint32_t c = 0; c < cnt; ++c) {
+            uint32_t ref = ix.post[off + 1 + 2 * c], mult = ix.post[off + 2 + 2 * c];
+            if (rank < mult) atomicAdd(&sh[ref], 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// minhashes (+filters) and optional intersection: one block per sequence, bitonic sort in LDS.
+__global__ void k_sort_intersect(SortArgs a, RefIndex ix, int has_ix, DevPolicy pol) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sm[];
+    uint64_t* v = sm;
+    int* sh = reinterpret_cast<int*>(sm + a.P);          // [nref] counters, then one int: number of zeros
+    int& s_nz = sh[has_ix ? ix.nref : 0];
+    const int tid = threadIdx.x, T = blockDim.x;
+    const uint32_t P = a.P;
+    for (uint32_t li = blockIdx.x; li < a.nlist; li += gridDim.x) {
+        const uint32_t id = a.seq_ids[li];
+        const uint64_t seg = a.seg_off[id];
+        const uint32_t n = (uint32_t)(a.seg_off[id + 1] - seg);
+        __syncthreads();
+        for (uint32_t t = tid; t < P; t += T) {
+            uint64_t h = ~0ull;
+            if (t < n) {
+                h = a.hashes[seg + t];
+                if (a.filter_mode == FILTER_MASK_MIN) {            // mask_by_frequency, rkmh.cpp:916
+                    int c = a.counter[h % a.slots];
+                    if (pol.mask_strict_less ? (c < a.fmin) : (c <= a.fmin)) h = 0;
+                } else if (a.filter_mode == FILTER_RANGE && h != 0) { // minhashes_frequency_filter, rkmh.cpp:835
+                    int c = a.counter[h % a.slots];
+                    bool keep = pol.freq_max_inclusive ? (c >= a.fmin && c <= a.fmax) : (c >= a.fmin && c < a.fmax);
+                    if (!keep) h = 0;
+                }
+            }
+            v[t] = h;
+        }
+        if (tid == 0) s_nz = 0;
+        __syncthreads();
+        for (uint32_t size = 2; size <= P; size <<= 1) {
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t t = tid; t < (P >> 1); t += T) {
+                    uint32_t lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+                    uint32_t hi = lo | stride;
+                    bool asc = ((lo & size) == 0);
+                    uint64_t x = v[lo], y = v[hi];
+                    if ((x > y) == asc) { v[lo] = y; v[hi] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        // zeros sort first: nz = number of zero entries among the n real ones
+        for (uint32_t t = tid; t < n; t += T)
+            if (v[t] == 0 && (t + 1 == n || v[t + 1] != 0)) s_nz = (int)(t + 1);
+        __syncthreads();
+        const uint32_t nz = (uint32_t)s_nz;
+        const uint32_t m = (n - nz) < (uint32_t)a.S ? (n - nz) : (uint32_t)a.S;
+        if (a.write_back)
+            for (uint32_t t = tid; t < n; t += T) a.hashes[seg + t] = v[t];
+        if (a.sketches) {
+            uint64_t* sk = a.sketches + (uint64_t)id * (uint64_t)a.S;
+            for (uint32_t t = tid; t < (uint32_t)a.S; t += T) sk[t] = t < m ? v[nz + t] : 0ull;
+        }
+        if (a.lens && tid == 0) a.lens[id] = (int32_t)m;
+        if (has_ix && a.out4) {
+            for (int j = tid; j < ix.nref; j += T) sh[j] = 0;
+            __syncthreads();
+            for (uint32_t t = tid; t < m; t += T) {
+                uint64_t h = v[nz + t];
+                uint32_t u = t;
+                while (u > 0 && v[nz + u - 1] == h) --u;   // rank among equal sketch entries (multiset merge)
+                uint32_t slot = index_find(ix, h);
+                if (slot != IDX_NOT_FOUND) accumulate_posting(ix, slot, t - u, sh);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                int mi, ms, df;
+                wave_argmax_diff(sh, ix.nref, tid, mi, ms, df);
+                if (tid == 0) {
+                    int4 r = make_int4(mi, ms, df, (int)m);
+                    reinterpret_cast<int4*>(a.out4)[id] = r;
+                }
+            }
+        }
+    }
+}
+hipError_t launch_sort_intersect(const SortArgs& a, const RefIndex* ix, const DevPolicy& pol, hipStream_t st) {
+    if (a.nlist == 0) return hipSuccess;
+    int T = (int)(a.P / 2);
+    if (T < 64) T = 64;
+    if (T > 1024) T = 1024;
+    RefIndex z{};
+    const RefIndex& use = ix ? *ix : z;
+    size_t lds = (size_t)a.P * 8 + (ix ? (size_t)ix->nref * 4 : 0) + 16; // counters + s_nz
+    uint32_t grid = a.nlist < 65535 ? a.nlist : 65535;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_intersect),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_sort_intersect, dim3(grid), dim3(T), lds, st, a, use, ix ? 1 : 0, pol);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// hash_intersection_size for one pair of ascending arrays (leading zeros skipped, both advance on
+// equality => sum over values of min(mult_a, mult_b)).  One block, binary searches into b.
+__global__ __launch_bounds__(256) void k_intersect_pair(const uint64_t* __restrict__ a, int na,
+                                                        const uint64_t* __restrict__ b, int nb, int* out) {
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    int local = 0;
+    for (int t = threadIdx.x; t < na; t += 256) {
+        uint64_t h = a[t];
+        if (h == 0) continue;
+        int u = t;
+        while (u > 0 && a[u - 1] == h) --u;
+        int rank = t - u;
+        int lo = 0, hi = nb;                 // lower_bound
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (b[mid] < h) lo = mid + 1; else hi = mid; }
+        int first = lo;
+        hi = nb;                             // upper_bound
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (b[mid] <= h) lo = mid + 1; else hi = mid; }
+        if (rank < lo - first) ++local;
+    }
+    atomicAdd(&total, local);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = total;
+}
+hipError_t launch_intersect_pair(const uint64_t* a, int na, const uint64_t* b, int nb, int* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_intersect_pair, dim3(1), dim3(256), 0, st, a, na, b, nb, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fused per-read kernel (v1): one wave per read, persistent over reads.
+//   stage read (upper-case, reverse complement, validity bits) -> hash every window -> optional -M mask
+//   -> look every non-zero hash up in the resident reference index -> per-reference LDS counters
+//   (multiset semantics via the occurrence rank of repeated hits) -> argmax/diff -> one int4 per read.
+// Eligible reads: len <= maxlen and (number of non-zero hashes) <= S, i.e. the sketch is ALL hashes and
+// the sort of minhashes() cannot change the intersection sizes.  Others get max_id = -2 (host reroutes).
+template <int KT, int MODE>
+__global__ __launch_bounds__(64) void k_classify_fused(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
+                                                       uint32_t nreads, KsArr ks, int S, RefIndex ix, int32_t* counter,
+                                                       uint64_t slots, int min_occ, int32_t* out4, DevPolicy pol, int maxlen) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* stage = smem;
+    uint32_t* hits = smem + stage_lds_dwords(maxlen);     // [maxlen * ks.n] slots of the hashes that hit
+    int* sh = reinterpret_cast<int*>(hits + maxlen * ks.n);
+    const int lane = threadIdx.x;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
+        const uint32_t start = offs[r];
+        const uint32_t len = offs[r + 1] - start;
+        if (len > (uint32_t)maxlen) {
+            if (MODE == 0 && lane == 0) reinterpret_cast<int4*>(out4)[r] = make_int4(-2, 0, 0, 0);
+            continue;
+        }
+        __syncthreads();
+        Staged s = stage_piece(bases, start, len, stage, maxlen, lane, 64, [] { __syncthreads(); });
+        if (MODE == 0)
+            for (int j = lane; j < ix.nref; j += 64) sh[j] = 0;
+        uint32_t H = 0;
+        int nnz = 0;
+        for (int kk = 0; kk < ks.n; ++kk) {
+            const int k = KT ? KT : ks.k[kk];
+            const uint32_t nw = (uint32_t)num_windows((int)len, k, pol.drop_last_window);
+            for (uint32_t i0 = 0; i0 < nw; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                uint64_t h = 0;
+                if (i < nw) h = canonical_window<KT>(s, i, k, pol);
+                if (MODE == 1) {
+                    if (i < nw && (pol.counter_counts_zero || h != 0)) atomicAdd(&counter[h % slots], 1);
+                    continue;
+                }
+                if (counter && i < nw) {                          // mask_by_frequency, rkmh.cpp:916
+                    int c = counter[h % slots];
+                    if (pol.mask_strict_less ? (c < min_occ) : (c <= min_occ)) h = 0;
+                }
+                nnz += __popcll(__ballot(h != 0));
+                uint32_t slot = IDX_NOT_FOUND;
+                if (h != 0) slot = index_find(ix, h);
+                const bool hit = slot != IDX_NOT_FOUND;
+                const uint64_t bm = __ballot(hit);
+                if (hit) hits[H + __popcll(bm & lt_mask)] = slot;
+                H += (uint32_t)__popcll(bm);
+            }
+        }
+        if (MODE == 1) continue;
+        if (nnz > S) {
+            if (lane == 0) reinterpret_cast<int4*>(out4)[r] = make_int4(-2, 0, 0, 0);
+            continue;
+        }
+        __syncthreads();
+        for (uint32_t t0 = 0; t0 < H; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            if (t < H) {
+                const uint32_t slot = hits[t];
+                uint32_t rank = 0;
+                for (uint32_t u = 0; u < t; ++u) rank += (hits[u] == slot) ? 1u : 0u;
+                accumulate_posting(ix, slot, rank, sh);
+            }
+        }
+        __syncthreads();
+        int mi, ms, df;
+        wave_argmax_diff(sh, ix.nref, lane, mi, ms, df);
+        if (lane == 0) reinterpret_cast<int4*>(out4)[r] = make_int4(mi, ms, df, nnz);
+    }
+}
+
+hipError_t launch_classify_fused(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
+                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
+                                 int32_t* out4, const DevPolicy& pol, int maxlen, hipStream_t st) {
+    if (nreads == 0) return hipSuccess;
+    size_t lds = ((size_t)stage_lds_dwords(maxlen) + (size_t)maxlen * ks.n + (size_t)(ix.nref > 0 ? ix.nref : 0)) * 4 + 16;
+    uint32_t grid = 256 * 16;
+    if (grid > nreads) grid = nreads;
+    const bool k16 = (ks.n == 1 && ks.k[0] == 16);
+#define RK_LAUNCH(KT, MODE)                                                                                         \
+    do {                                                                                                            \
+        if (lds > 64 * 1024) {                                                                                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_classify_fused<KT, MODE>),           \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+            if (e != hipSuccess) return e;                                                                          \
+        }                                                                                                           \
+        hipLaunchKernelGGL((k_classify_fused<KT, MODE>), dim3(grid), dim3(64), lds, st, bases, offs, nreads, ks, S,  \
+                           ix, counter, slots, min_occ, out4, pol, maxlen);                                         \
+    } while (0)
+    if (mode == 0) { if (k16) RK_LAUNCH(16, 0); else RK_LAUNCH(0, 0); }
+    else           { if (k16) RK_LAUNCH(16, 1); else RK_LAUNCH(0, 1); }
+#undef RK_LAUNCH
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_max_len(const uint32_t* __restrict__ offs, uint32_t nreads, uint32_t* d_max) {
+    uint32_t m = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nreads; i += gridDim.x * 256) {
+        uint32_t l = offs[i + 1] - offs[i];
+        m = l > m ? l : m;
+    }
+    m = (uint32_t)wave_max_i32((int)m);
+    if ((threadIdx.x & 63) == 0) atomicMax(d_max, m);
+}
+hipError_t launch_max_len(const uint32_t* offs, uint32_t nreads, uint32_t* d_max, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(d_max, 0, 4, st);
+    if (e != hipSuccess) return e;
+    if (nreads == 0) return hipSuccess;
+    uint32_t grid = (nreads + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_max_len, dim3(grid), dim3(256), 0, st, offs, nreads, d_max);
+    return hipGetLastError();
+}
+
+// mask_by_frequency (rkmh.cpp:916): order-preserving, in place
+__global__ __launch_bounds__(256) void k_mask_by_frequency(uint64_t* h, uint64_t n, const int32_t* __restrict__ counter,
+                                                           uint64_t slots, int min_occ, int strict) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int c = counter[h[i] % slots];
+    if (strict ? (c < min_occ) : (c <= min_occ)) h[i] = 0;
+}
+hipError_t launch_mask_by_frequency(uint64_t* h, uint64_t n, const int32_t* counter, uint64_t slots, int min_occ,
+                                    const DevPolicy& pol, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mask_by_frequency, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, h, n, counter, slots, min_occ,
+                       pol.mask_strict_less);
+    return hipGetLastError();
+}
+
+__global__ void k_counter_inc(int32_t* counter, uint64_t slots, uint64_t key) { atomicAdd(&counter[key % slots], 1); }
+hipError_t launch_counter_inc(int32_t* counter, uint64_t slots, uint64_t key, hipStream_t st) {
+    hipLaunchKernelGGL(k_counter_inc, dim3(1), dim3(1), 0, st, counter, slots, key);
+    return hipGetLastError();
+}
+
+} // namespace rk

@@ -1,0 +1,60 @@
+// rk_kernels.hpp -- launcher declarations (host side) for the gfx950 kernels in rk_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rk_device.hpp"
+
+namespace rk {
+
+constexpr int MAX_KS = 8;
+constexpr int MAX_K = 64;
+constexpr int HASH_TILE_WIN = 2048;             // windows per hash tile
+constexpr int HASH_TILE_MAXB = HASH_TILE_WIN + MAX_K;
+constexpr int FUSED_MAXLEN = 1024;              // longest read taken by the fused classify kernel
+constexpr int SORT_MAX_P = 16384;               // largest in-LDS sort (128 KiB of u64)
+
+struct KsArr { int32_t n; int32_t k[MAX_KS]; };
+
+// one piece of one sequence to hash with one k
+struct TileDesc {
+    uint64_t base_off;  // byte offset of the tile's first base in `bases`
+    uint64_t out_off;   // index of the tile's first hash in `out`
+    uint32_t nbases;    // bases staged (= nwin + k - 1)
+    uint32_t nwin;      // windows hashed
+    uint32_t k;
+    uint32_t pad;
+};
+
+enum { FILTER_NONE = 0, FILTER_MASK_MIN = 1, FILTER_RANGE = 2 };
+
+struct SortArgs {
+    uint64_t* hashes;          // all hashes (segments per sequence)
+    const uint64_t* seg_off;   // [nseq+1]
+    const uint32_t* seq_ids;   // sequences handled by this launch
+    uint32_t nlist;
+    uint32_t P;                // power of two >= longest segment in the list
+    int32_t S;
+    int32_t write_back;        // write the sorted segment back into `hashes` (minhashes sorts in place)
+    uint64_t* sketches;        // nullable: [nseq * S] zero padded
+    int32_t* lens;             // nullable
+    int32_t* out4;             // nullable: classify results (needs ix)
+    const int32_t* counter;    // nullable
+    uint64_t slots;
+    int32_t filter_mode, fmin, fmax;
+};
+
+hipError_t launch_to_upper(uint8_t* d, uint64_t n, hipStream_t st);
+hipError_t launch_hash_tiles(const uint8_t* bases, const TileDesc* tiles, uint32_t ntiles, uint64_t* out,
+                             int32_t* counter, uint64_t slots, const DevPolicy& pol, hipStream_t st);
+hipError_t launch_sort_intersect(const SortArgs& a, const RefIndex* ix, const DevPolicy& pol, hipStream_t st);
+hipError_t launch_intersect_pair(const uint64_t* a, int na, const uint64_t* b, int nb, int* out, hipStream_t st);
+// mode 0: classify (out4 written); mode 1: count only (counter incremented)
+hipError_t launch_classify_fused(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
+                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
+                                 int32_t* out4, const DevPolicy& pol, int maxlen, hipStream_t st);
+hipError_t launch_max_len(const uint32_t* offs, uint32_t nreads, uint32_t* d_max, hipStream_t st);
+hipError_t launch_mask_by_frequency(uint64_t* h, uint64_t n, const int32_t* counter, uint64_t slots, int min_occ,
+                                    const DevPolicy& pol, hipStream_t st);
+hipError_t launch_counter_inc(int32_t* counter, uint64_t slots, uint64_t key, hipStream_t st);
+
+} // namespace rk

@@ -1,0 +1,294 @@
+// rkmh_main.cpp -- the `rkmh` command line on top of librkmh_amd.so (C ABI in include/rkmh_amd.h).
+//
+// Drop-in for the sub-commands of /root/reference/src/rkmh.cpp that sit on the classify/stream hot path:
+//   stream / classify   main_stream   (src/rkmh.cpp:584-989; classify forwards to it, :2744-2747)
+//   hash                main_hash     (src/rkmh.cpp:1931-2116)
+// Same flags (option tables src/rkmh.cpp:626-650 and :1963-1983), same stdout line formats
+// (src/rkmh.cpp:892), but the per-read OpenMP loop is replaced by batches handed to the GPU while a
+// second host thread parses the next batch.  Output order = input order (the reference's order is
+// nondeterministic under -t > 1, src/rkmh.cpp:893).
+#include <getopt.h>
+
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rkmh_amd.h"
+
+static void die(const char* what) {
+    fprintf(stderr, "rkmh: %s: %s\n", what, rk_last_error());
+    exit(1);
+}
+#define CK(call) do { if ((call) != RK_OK) die(#call); } while (0)
+
+static void print_help() {
+    fprintf(stderr,
+            "rkmh (MI355X build): MinHash read classification on AMD Instinct GPUs\n"
+            "Usage: rkmh <command> [options]\n"
+            "  classify / stream   classify reads against a set of references\n"
+            "  hash                print the k-mer hashes of every sequence\n"
+            "Run a command without options for its help text.\n");
+}
+static void help_stream() {
+    fprintf(stderr,
+            "rkmh stream|classify -r <refs.fa> -f <reads.fq> [-k <k>]... [-s <sketch>] [options]\n"
+            "  -r/--reference <file>   reference FASTA/FASTQ(.gz); repeatable\n"
+            "  -f/--fasta <file>       read FASTA/FASTQ(.gz); repeatable\n"
+            "  -k/--kmer <k>           k-mer size; repeatable (default 16)\n"
+            "  -s/--sketch-size <s>    sketch size (default 1000)\n"
+            "  -t/--threads <n>        accepted for compatibility (the per-read loop runs on the GPU)\n"
+            "  -M/--min-kmer-occurence <n>  drop read k-mers seen fewer than n times across all reads\n"
+            "  -I/--max-samples <n>    drop reference k-mers counted more than n times across references\n"
+            "  -N/--min-matches <n>    flag FAIL:DEPTH / FAIL:MATCHES\n"
+            "  -D/--min-diff <n>       flag FAIL:DIFF\n"
+            "  --device <id>           GPU to use (default 0)\n");
+}
+static void help_hash() {
+    fprintf(stderr,
+            "rkmh hash -f <seqs.fa|fq> [-k <k>]...\n"
+            "  prints one line per sequence: name, then every k-mer hash, tab separated\n");
+}
+
+struct Opts {
+    std::vector<const char*> refs, reads;
+    std::vector<int> ks;
+    int sketch = 1000, threads = 1, min_occ = -1, min_matches = -1, min_diff = 0, max_samples = 100000;
+    bool read_depth = false, ref_depth = false;
+    int device = 0;
+};
+
+// bounded queue of parsed batches
+struct Queue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<rk_seqset> q;
+    bool done = false;
+    std::string err;
+    void push(const rk_seqset& s) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return q.size() < 2; });
+        q.push_back(s);
+        cv.notify_all();
+    }
+    bool pop(rk_seqset* s) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !q.empty() || done; });
+        if (q.empty()) return false;
+        *s = q.front();
+        q.pop_front();
+        cv.notify_all();
+        return true;
+    }
+    void finish() { std::lock_guard<std::mutex> l(m); done = true; cv.notify_all(); }
+};
+
+static void emit_lines(const rk_seqset& refs, const rk_seqset& reads, const int32_t* out4, const Opts& o, std::string& buf) {
+    buf.clear();
+    char line[8192];
+    for (int64_t i = 0; i < reads.nseq; ++i) {
+        const int32_t* r = out4 + i * 4;
+        const char* refn = refs.names + refs.name_offsets[r[0]];
+        const char* readn = reads.names + reads.name_offsets[i];
+        int n = rk_format_stream_line(line, sizeof line, refn, readn, r[1], r[2], r[3], o.sketch, o.min_matches, o.min_diff);
+        if (n < 0) { // very long names
+            std::string big(strlen(refn) + strlen(readn) + 128, '\0');
+            n = rk_format_stream_line(&big[0], big.size(), refn, readn, r[1], r[2], r[3], o.sketch, o.min_matches, o.min_diff);
+            if (n < 0) die("rk_format_stream_line");
+            buf.append(big.data(), (size_t)n);
+        } else buf.append(line, (size_t)n);
+    }
+    fwrite(buf.data(), 1, buf.size(), stdout);
+}
+
+static int main_stream(int argc, char** argv) {
+    Opts o;
+    if (argc <= 2) { help_stream(); exit(1); }
+    static struct option long_options[] = {
+        {"help", no_argument, 0, 'h'},           {"kmer", required_argument, 0, 'k'},
+        {"fasta", required_argument, 0, 'f'},    {"reference", required_argument, 0, 'r'},
+        {"sketch-size", required_argument, 0, 's'}, {"ref-sketch", required_argument, 0, 'S'},
+        {"threads", required_argument, 0, 't'},  {"min-kmer-occurence", required_argument, 0, 'M'},
+        {"min-matches", required_argument, 0, 'N'}, {"min-diff", required_argument, 0, 'D'},
+        {"max-samples", required_argument, 0, 'I'}, {"pre-reads", required_argument, 0, 'F'},
+        {"pre-references", required_argument, 0, 'R'}, {"read-kmer-map-file", required_argument, 0, 'p'},
+        {"ref-kmer-map-file", required_argument, 0, 'q'}, {"in-stream", no_argument, 0, 'i'},
+        {"output-reads", no_argument, 0, 'z'},   {"merge-sketch", no_argument, 0, 'm'},
+        {"device", required_argument, 0, 1000},  {0, 0, 0, 0}};
+    optind = 2;
+    int c;
+    while ((c = getopt_long(argc, argv, "zmhdk:f:r:s:S:t:M:N:I:R:F:p:q:iD:", long_options, nullptr)) != -1) {
+        switch (c) {
+            case 'm': case 'i': case 'z': break;                 // parsed and ignored, rkmh.cpp:656-658,709-714
+            case 'F': case 'R': case 'p': case 'q': case 'S': break; // parsed, bodies empty in the reference (:659-670,:697-700)
+            case 't': o.threads = atoi(optarg); break;
+            case 'r': o.refs.push_back(optarg); break;
+            case 'f': o.reads.push_back(optarg); break;
+            case 'k': o.ks.push_back(atoi(optarg)); break;
+            case 'N': o.min_matches = atoi(optarg); break;
+            case 'D': o.min_diff = atoi(optarg); break;
+            case 's': o.sketch = atoi(optarg); break;
+            case 'M': o.min_occ = atoi(optarg); o.read_depth = true; break;
+            case 'I': o.max_samples = atoi(optarg); o.ref_depth = true; break;
+            case 1000: o.device = atoi(optarg); break;
+            case '?': case 'h': default: print_help(); exit(1);
+        }
+    }
+    if (o.ks.empty()) {
+        fprintf(stderr, "No kmer size(s) provided. Will use a default kmer size of 16.\n"); // rkmh.cpp:729
+        o.ks.push_back(16);
+    }
+    if (o.refs.empty()) { fprintf(stderr, "rkmh: at least one -r reference file is required\n"); exit(1); }
+
+    rk_ctx* ctx = nullptr;
+    CK(rk_ctx_create(o.device, nullptr, &ctx));
+    rk_seqset refs;
+    CK(rk_parse_files(o.refs.data(), (int)o.refs.size(), &refs));
+    if (refs.nseq < 1) { fprintf(stderr, "rkmh: no reference sequences found\n"); exit(1); }
+    CK(rk_set_references(ctx, refs.bases, refs.offsets, (int)refs.nseq, o.ks.data(), (int)o.ks.size(), o.sketch,
+                         o.ref_depth ? o.max_samples : -1, 0));
+    std::string buf;
+    std::vector<int32_t> out4;
+    if (o.read_depth) {
+        // two passes over ALL reads (rkmh.cpp:904-948): the reference holds them in RAM, so do we
+        rk_seqset reads;
+        CK(rk_parse_files(o.reads.data(), (int)o.reads.size(), &reads));
+        rk_counter* cnt = nullptr;
+        CK(rk_counter_create(ctx, 200000000ull, &cnt)); // rkmh.cpp:739
+        CK(rk_count_batch(ctx, reads.bases, reads.offsets, reads.nseq, cnt));
+        CK(rk_set_depth_filter(ctx, cnt, o.min_occ));
+        out4.resize((size_t)reads.nseq * 4);
+        CK(rk_classify_batch(ctx, reads.bases, reads.offsets, reads.nseq, out4.data()));
+        emit_lines(refs, reads, out4.data(), o, buf);
+        rk_counter_destroy(cnt);
+        rk_seqset_free(&reads);
+    } else {
+        Queue q;
+        std::thread producer([&] {
+            for (const char* path : o.reads) {
+                rk_reader* rd = nullptr;
+                if (rk_reader_open(path, &rd) != RK_OK) { q.err = rk_last_error(); break; }
+                for (;;) {
+                    rk_seqset s;
+                    if (rk_reader_next(rd, 1 << 20, 1ull << 28, &s) != RK_OK) { q.err = rk_last_error(); break; }
+                    if (s.nseq == 0) { rk_seqset_free(&s); break; }
+                    q.push(s);
+                }
+                rk_reader_close(rd);
+                if (!q.err.empty()) break;
+            }
+            q.finish();
+        });
+        rk_seqset s;
+        while (q.pop(&s)) {
+            out4.resize((size_t)s.nseq * 4);
+            CK(rk_classify_batch(ctx, s.bases, s.offsets, s.nseq, out4.data()));
+            emit_lines(refs, s, out4.data(), o, buf);
+            rk_seqset_free(&s);
+        }
+        producer.join();
+        if (!q.err.empty()) { fprintf(stderr, "rkmh: %s\n", q.err.c_str()); exit(1); }
+    }
+    fflush(stdout);
+    rk_seqset_free(&refs);
+    rk_ctx_destroy(ctx);
+    return 0;
+}
+
+static int main_hash(int argc, char** argv) {
+    std::vector<const char*> files;
+    std::vector<int> ks;
+    int device = 0;
+    bool print_kmers = false;
+    if (argc <= 2) { help_hash(); exit(1); }
+    static struct option long_options[] = {
+        {"help", no_argument, 0, 'h'},        {"kmer", required_argument, 0, 'k'},
+        {"fasta", required_argument, 0, 'f'}, {"sketch-size", required_argument, 0, 's'},
+        {"threads", required_argument, 0, 't'}, {"min-kmer-occurence", required_argument, 0, 'M'},
+        {"max-samples", required_argument, 0, 'I'}, {"output", required_argument, 0, 'o'},
+        {"device", required_argument, 0, 1000}, {0, 0, 0, 0}};
+    optind = 2;
+    int c;
+    bool use_freqs = false;
+    while ((c = getopt_long(argc, argv, "ThcwKk:f:s:t:mM:I:o:", long_options, nullptr)) != -1) {
+        switch (c) {
+            case 'f': files.push_back(optarg); break;
+            case 'k': ks.push_back(atoi(optarg)); break;
+            case 'K': print_kmers = true; break;
+            case 'M': case 'I': use_freqs = true; break;       // accepted; nothing is printed (rkmh.cpp:2047,2109-2111)
+            case 'T': case 'c': case 'w': case 'm': case 's': case 't': case 'o': break; // accepted and ignored
+            case 1000: device = atoi(optarg); break;
+            case '?': case 'h': default: print_help(); exit(1);
+        }
+    }
+    if (ks.empty()) {
+        fprintf(stderr, "No kmer size(s) provided. Will use a default kmer size of 16.\n");
+        ks.push_back(16);
+    }
+    if (files.empty()) { fprintf(stderr, "rkmh: -f <file> is required\n"); exit(1); }
+    if (use_freqs) return 0;
+    rk_ctx* ctx = nullptr;
+    if (!print_kmers) CK(rk_ctx_create(device, nullptr, &ctx));
+    rk_reader* rd = nullptr;
+    CK(rk_reader_open(files[0], &rd)); // only input_files[0] is used, rkmh.cpp:2064,2085
+    std::string buf;
+    for (;;) {
+        rk_seqset s;
+        CK(rk_reader_next(rd, 1000, 1ull << 28, &s)); // 1000-record buffers, rkmh.cpp:2085-2094
+        if (s.nseq == 0) { rk_seqset_free(&s); break; }
+        buf.clear();
+        if (print_kmers) {
+            for (int64_t i = 0; i < s.nseq; ++i) {
+                buf += s.names + s.name_offsets[i];
+                const uint8_t* seq = s.bases + s.offsets[i];
+                int64_t len = (int64_t)(s.offsets[i + 1] - s.offsets[i]);
+                for (int k : ks)
+                    for (int64_t w = 0; w + k < len; ++w) { // len-k windows (policy U3)
+                        buf += '\t';
+                        for (int j = 0; j < k; ++j) {
+                            signed char ch = (signed char)seq[w + j];
+                            buf += (char)(((int)ch - 91) > 0 ? ch - 32 : ch);
+                        }
+                    }
+                buf += '\n';
+            }
+        } else {
+            std::vector<uint64_t> ho((size_t)s.nseq + 1);
+            uint64_t* h = nullptr;
+            CK(rk_hash_batch(ctx, s.bases, s.offsets, s.nseq, ks.data(), (int)ks.size(), &h, ho.data()));
+            char num[32];
+            for (int64_t i = 0; i < s.nseq; ++i) {
+                buf += s.names + s.name_offsets[i];
+                for (uint64_t j = ho[(size_t)i]; j < ho[(size_t)i + 1]; ++j) {
+                    int n = snprintf(num, sizeof num, "\t%llu", (unsigned long long)h[j]);
+                    buf.append(num, (size_t)n);
+                }
+                buf += '\n';
+            }
+            rk_free(h);
+        }
+        fwrite(buf.data(), 1, buf.size(), stdout);
+        rk_seqset_free(&s);
+    }
+    rk_reader_close(rd);
+    if (ctx) rk_ctx_destroy(ctx);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc <= 1) { print_help(); exit(1); }
+    std::string cmd = argv[1];
+    if (cmd == "stream") return main_stream(argc, argv);
+    if (cmd == "classify") {
+        fprintf(stderr, "CLASSIFY COMMAND IS TEMPORARILY UNAVAILABLE: TRY rkmh stream INSTEAD.\n"); // rkmh.cpp:2746
+        return main_stream(argc, argv);
+    }
+    if (cmd == "hash") return main_hash(argc, argv);
+    print_help();
+    exit(1);
+}

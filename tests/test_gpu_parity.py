@@ -1,0 +1,311 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs --
+bit-exact hashes, sketches and per-read (max_id, max_shared, diff, min_num)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import golden, rand_dna
+
+pytestmark = pytest.mark.gpu
+
+
+def _pad(b):
+    out = np.zeros(len(b) + 16, dtype=np.uint8)
+    out[: len(b)] = b
+    return out
+
+
+@pytest.fixture(scope="module")
+def pave(orc, data_dir):
+    recs = orc.kseq_parse_file(os.path.join(data_dir, "all_pave_ref.fa.gz"))
+    rb, ro = orc.pack([r[1] for r in recs])
+    return [r[0] for r in recs], _pad(rb), ro
+
+
+def test_extension_is_loaded_from_tree():
+    import rkmh_amd
+    rkmh_amd.load_library()
+    maps = open("/proc/self/maps").read()
+    assert "rkmh_amd/lib/librkmh_amd.so" in maps
+
+
+@pytest.mark.parametrize("fold", [0, 1, 2])
+@pytest.mark.parametrize("drop", [0, 1])
+def test_calc_hashes_bit_exact_all_policies(orc, fold, drop):
+    import rkmh_amd
+    c = rkmh_amd.Context(0, fold=fold, drop_last_window=drop)
+    pol = orc.default_policy(fold=fold, drop_last_window=drop)
+    rng = np.random.default_rng(100 + fold * 2 + drop)
+    for k in (1, 3, 8, 12, 15, 16, 17, 20, 24, 31, 32, 33, 48, 64):
+        for n in (0, k - 1, k, k + 1, 70, 257, 5000):
+            if n < 0:
+                continue
+            s = rand_dna(rng, n, b"ACGTACGTACGTACGTacgtN")
+            want = orc.calc_hashes(orc.to_upper(s), [k], pol)
+            got = c.calc_hashes(s, [k])
+            assert got.dtype == np.uint64 and len(got) == len(want)
+            assert (got == want).all(), (k, n)
+    c.close()
+
+
+def test_calc_hash_single_kmer(ctx, orc):
+    for kmer in (b"ACGTACGTACGT", b"ACGTACGTACGTACGT", b"GATTACAGATTACAGATTAC", b"ACGTNCGTACGTACGT", b"A", b"acgtacgtacgtacgt"):
+        assert ctx.calc_hash(kmer) == orc.calc_hash(orc.to_upper(kmer))
+
+
+def test_to_upper(ctx, orc):
+    s = bytes(range(1, 128)) * 3
+    assert ctx.to_upper(s) == orc.to_upper(s)
+
+
+def test_multi_k_and_long_sequence_tiles(ctx, orc, pave):
+    _, rb, ro = pave
+    seq = bytes(rb[: int(ro[3])])  # ~23 kb: several 2048-window tiles, lower case + IUPAC
+    for ks in ([16], [12, 16, 20], [31], [7, 33]):
+        want = orc.calc_hashes(orc.to_upper(seq), ks)
+        got = ctx.calc_hashes(seq, ks)
+        assert (got == want).all(), ks
+
+
+def test_unaligned_starts(ctx, orc):
+    rng = np.random.default_rng(5)
+    seqs = [rand_dna(rng, int(n), b"ACGTN" * 3 + b"ACGT" * 10) for n in rng.integers(0, 300, size=200)]
+    bases, offs = orc.pack(seqs)
+    h, ho = ctx.hash_batch(_pad(bases), offs, [16])
+    for i, s in enumerate(seqs):
+        assert (h[int(ho[i]): int(ho[i + 1])] == orc.calc_hashes(s, [16])).all(), i
+
+
+def test_minhashes_and_intersection_mirrors(ctx, orc):
+    rng = np.random.default_rng(9)
+    for n, S in ((0, 10), (1, 10), (50, 10), (200, 1000), (3000, 1000), (16384, 2000)):
+        h = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+        h[rng.random(n) < 0.1] = 0
+        if n > 10:
+            h[5] = h[6] = h[7]  # duplicates survive (no dedup)
+        mins, srt = ctx.minhashes(h, S)
+        assert (mins == orc.minhashes(h, S)).all()
+        assert (srt == np.sort(h)).all()
+    a = np.sort(rng.integers(1, 500, size=300, dtype=np.uint64))
+    b = np.sort(rng.integers(1, 500, size=1000, dtype=np.uint64))
+    assert ctx.hash_intersection_size(a, b) == orc.hash_intersection_size(a, b)
+    assert ctx.hash_intersection_size(np.array([0, 0, 5, 5, 5], np.uint64), np.array([0, 5, 5], np.uint64)) == 2
+    assert ctx.hash_intersection_size(np.zeros(0, np.uint64), b) == 0
+
+
+def test_counter_mirror(ctx, orc):
+    import rkmh_amd
+    cnt = rkmh_amd.Counter(ctx, slots=1009)
+    s = b"ACGTTGCAAGGCTTAACCGGTTAAGGCCATATATATATATGCGCGCGC" * 3
+    h = ctx.calc_hashes(s, [8], counter=cnt)
+    want = {}
+    for v in orc.calc_hashes(s, [8]):
+        want[int(v) % 1009] = want.get(int(v) % 1009, 0) + 1
+    for v in set(int(x) for x in h):
+        assert cnt.get(v) == want[v % 1009]
+    cnt.increment(12345)
+    assert cnt.get(12345) == want.get(12345 % 1009, 0) + 1
+    masked = ctx.mask_by_frequency(h, cnt, 4)
+    assert (masked == np.array([v if cnt.get(int(v)) >= 4 else 0 for v in h], dtype=np.uint64)).all()
+    mins, _ = ctx.minhashes(h, 20, counter=cnt, min_count=0, max_count=3)
+    keep = np.array([v for v in np.sort(h) if v != 0 and cnt.get(int(v)) <= 3], dtype=np.uint64)[:20]
+    assert (mins == keep).all()
+    cnt.destroy()
+
+
+def test_ref_sketches_bit_exact(ctx, orc, pave):
+    _, rb, ro = pave
+    for ks, S in (([16], 1000), ([12], 1000), ([20], 2000), ([12, 16], 500)):
+        want_sk, want_ln = orc.sketch_refs(rb, ro, ks, S, threads=4)
+        sk, ln = ctx.sketch_batch(rb, ro, ks, S)
+        assert (ln == want_ln).all()
+        assert (sk == want_sk).all()
+
+
+def _classify_both(ctx, orc, rb, ro, qb, qo, ks, S, **kw):
+    ctx.set_references(rb, ro, ks, S)
+    sk, ln = ctx.get_reference_sketches()
+    want = orc.classify_stream(qb, qo, ks, S, sk, ln, threads=8, **kw)
+    got = ctx.classify(qb, qo)
+    return got, want
+
+
+@pytest.mark.parametrize("tag", ["c1_hpv16_minion25", "zika_z1", "c2mini_pave", "c2mini_pave_k12_k16"])
+def test_classify_matches_golden_and_oracle(ctx, orc, golden_dir, data_dir, tag):
+    from rkmh_amd import synth
+    g = golden(golden_dir, tag)
+    refs = orc.kseq_parse_file(os.path.join(data_dir, g["ref_file"]))
+    rb, ro = orc.pack([r[1] for r in refs])
+    rb = _pad(rb)
+    rn = [r[0].decode() for r in refs]
+    if "reads_file" in g:
+        reads = orc.kseq_parse_file(os.path.join(data_dir, g["reads_file"]))
+        qn = [r[0].decode() for r in reads]
+        qb, qo = orc.pack([r[1] for r in reads])
+        qb = _pad(qb)
+    else:
+        qb, qo = synth.generate_reads(rb, ro, 0, 1000)
+        qn = [n.decode() for n in synth.read_names(0, 1000)]
+    got, want = _classify_both(ctx, orc, rb, ro, qb, qo, g["ks"], g["sketch_size"])
+    assert (got == want).all()
+    rows = [[qn[i], rn[got[i, 0]], int(got[i, 1]), int(got[i, 2]), int(got[i, 3])] for i in range(len(qn))]
+    assert rows == g["rows"]
+
+
+def test_depth_filter_path_matches_golden(ctx, orc, golden_dir, pave):
+    import rkmh_amd
+    from rkmh_amd import synth
+    g = golden(golden_dir, "c2mini_pave_M2")
+    rn, rb, ro = pave
+    qb, qo = synth.generate_reads(rb, ro, 0, 1000)
+    ctx.set_references(rb, ro, g["ks"], g["sketch_size"])
+    cnt = rkmh_amd.Counter(ctx, slots=g["kwargs"]["counter_slots"])
+    ctx.count_batch(qb, qo, cnt)
+    ctx.set_depth_filter(cnt, g["kwargs"]["min_kmer_occ"])
+    try:
+        got = ctx.classify(qb, qo)
+    finally:
+        ctx.set_depth_filter(None, 0)
+    rows = [[int(got[i, 1]), int(got[i, 2]), int(got[i, 3])] for i in range(1000)]
+    assert rows == [r[2:] for r in g["rows"]]
+    assert [rn[got[i, 0]].decode() for i in range(1000)] == [r[1] for r in g["rows"]]
+    cnt.destroy()
+
+
+def test_max_samples_reference_path(ctx, orc, pave):
+    _, rb, ro = pave
+    n = 40
+    ctx.set_references(rb, ro[: n + 1], [16], 1000, max_samples=1, counter_slots=5000011)
+    sk, ln = ctx.get_reference_sketches()
+    wsk, wln = orc.sketch_refs(rb, ro[: n + 1], [16], 1000, threads=4, max_samples=1, counter_slots=5000011)
+    assert (ln == wln).all() and (sk == wsk).all()
+
+
+def test_edge_cases(ctx, orc):
+    rng = np.random.default_rng(21)
+    refs = [rand_dna(rng, 600) for _ in range(5)]
+    refs.append(refs[1])                     # exact duplicate reference -> ties, first wins
+    refs.append(b"A" * 300)                  # homopolymer: one hash repeated (multiset semantics)
+    reads = [
+        b"", b"ACGT", refs[0][:16], refs[0][:17], refs[1][100:250], refs[2][5:155].lower(),
+        b"N" * 150, refs[3][:70] + b"N" + refs[3][71:150], b"A" * 150, b"A" * 40, refs[4][:1024], refs[4][:600],
+        rand_dna(rng, 150), (refs[0][:100] + refs[2][:100]), b"ACGT" * 40,
+    ]
+    rb, ro = orc.pack(refs)
+    qb, qo = orc.pack(reads)
+    for ks, S in (([16], 1000), ([16], 50), ([12], 1000), ([8, 16], 100), ([16], 1)):
+        got, want = _classify_both(ctx, orc, _pad(rb), ro, _pad(qb), qo, ks, S)
+        assert (got == want).all(), (ks, S, got, want)
+
+
+def test_long_reads_take_general_path(ctx, orc, pave):
+    """Reads longer than the fused kernel's limit and sketches smaller than the read (bottom-S matters)."""
+    _, rb, ro = pave
+    rng = np.random.default_rng(4)
+    reads = []
+    for i in range(40):
+        r = int(rng.integers(0, 182))
+        L = int(rng.integers(200, 6000))
+        st = int(rng.integers(0, int(ro[r + 1] - ro[r]) - L))
+        reads.append(bytes(rb[int(ro[r]) + st: int(ro[r]) + st + L]))
+    reads += [reads[0][:150], reads[1][:100]]  # mixed with fused-eligible ones
+    qb, qo = orc.pack(reads)
+    got, want = _classify_both(ctx, orc, rb, ro, _pad(qb), qo, [16], 1000)
+    assert (got == want).all()
+    got, want = _classify_both(ctx, orc, rb, ro, _pad(qb), qo, [16], 64)  # S < windows even for 150 bp reads
+    assert (got == want).all()
+
+
+def test_resident_input_entry_point(ctx, orc, pave):
+    import torch
+    from rkmh_amd import synth
+    _, rb, ro = pave
+    qb, qo = synth.generate_reads_fast(rb, ro, 5000, 25000)
+    ctx.set_references(rb, ro, [16], 1000)
+    sk, ln = ctx.get_reference_sketches()
+    want = orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=8)
+    d_b = torch.from_numpy(qb).cuda()
+    d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).cuda()  # uint32 values, bit pattern kept
+    d_out = torch.empty((20000, 4), dtype=torch.int32, device="cuda")
+    for mrl in (150, 0):
+        d_out.zero_()
+        ctx.classify_device(d_b.data_ptr(), d_o.data_ptr(), 20000, d_out.data_ptr(), max_read_len=mrl,
+                            stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert (d_out.cpu().numpy() == want).all()
+
+
+def test_full_size_properties(ctx, orc, pave):
+    """C2 at full size (1M reads): properties that need no CPU pass over everything."""
+    from rkmh_amd import synth
+    _, rb, ro = pave
+    n = 1000000
+    qb, qo = synth.generate_reads_fast(rb, ro, 0, n)
+    ctx.set_references(rb, ro, [16], 1000)
+    out = ctx.classify(qb, qo)
+    assert out.shape == (n, 4)
+    assert (out[:, 0] >= 0).all() and (out[:, 0] < 182).all()
+    assert (out[:, 3] <= 134).all() and (out[:, 3] >= 0).all()
+    assert (out[:, 1] >= 0).all() and (out[:, 1] <= out[:, 3]).all()
+    assert (out[:, 2] >= 0).all() and (out[:, 2] <= out[:, 1] + 1).all()
+    # idempotence + sharding invariance: any slice classified alone gives the same rows
+    for lo, hi in ((0, 1000), (123457, 130001), (n - 777, n)):
+        sub = ctx.classify(np.concatenate([qb[lo * 150: hi * 150], np.zeros(16, np.uint8)]), qo[: hi - lo + 1])
+        assert (sub == out[lo:hi]).all()
+    # a bounded random sample against the oracle
+    sk, ln = ctx.get_reference_sketches()
+    idx = np.random.default_rng(1).integers(0, n - 2000, size=5)
+    for lo in idx:
+        lo = int(lo)
+        want = orc.classify_stream(qb[lo * 150: (lo + 2000) * 150], qo[:2001], [16], 1000, sk, ln, threads=8)
+        assert (out[lo: lo + 2000] == want).all()
+    # most reads come back to a reference that shares >= 5 sketch hashes (1 % error reads of 150 bp)
+    assert (out[:, 1] >= 5).mean() > 0.9
+
+
+def test_cli_stream_and_hash_output(ctx, orc, root, data_dir, golden_dir, tmp_path):
+    exe = os.path.join(root, "bin", "rkmh")
+    g = golden(golden_dir, "c1_hpv16_minion25")
+    r = subprocess.run([exe, "classify", "-r", os.path.join(data_dir, "hpv_16.fa.gz"), "-f",
+                        os.path.join(data_dir, "minION25.fq.gz"), "-k", "12", "-s", "1000"], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert b"CLASSIFY COMMAND IS TEMPORARILY UNAVAILABLE" in r.stderr
+    want = "".join(orc.stream_line(x[1], x[0], x[2], x[3], x[4], 1000) for x in g["rows"])
+    assert r.stdout.decode() == want
+    # stream with flags + default k notice
+    g = golden(golden_dir, "zika_z1")
+    r = subprocess.run([exe, "stream", "-r", os.path.join(data_dir, "zika.refs.fa.gz"), "-f",
+                        os.path.join(data_dir, "z1.fq.gz"), "-N", "2", "-D", "1", "-t", "4"], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert b"No kmer size(s) provided. Will use a default kmer size of 16." in r.stderr
+    want = "".join(orc.stream_line(x[1], x[0], x[2], x[3], x[4], 1000, min_matches=2, min_diff=1) for x in g["rows"])
+    assert r.stdout.decode() == want
+    # -M path through the CLI (counter = 200M slots as rkmh.cpp:739)
+    from rkmh_amd import synth, api
+    refs = api.parse_files([os.path.join(data_dir, "all_pave_ref.fa.gz")])
+    qb, qo = synth.generate_reads(refs["bases"], refs["offsets"], 0, 300)
+    names = synth.read_names(0, 300)
+    fq = tmp_path / "r.fq"
+    synth.write_fastq(str(fq), qb, qo, names)
+    r = subprocess.run([exe, "stream", "-r", os.path.join(data_dir, "all_pave_ref.fa.gz"), "-f", str(fq), "-k", "16",
+                        "-M", "2"], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    rb, ro = refs["bases"], refs["offsets"]
+    sk, ln = orc.sketch_refs(rb, ro, [16], 1000, threads=4)
+    o4 = orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=4, min_kmer_occ=2)
+    want = "".join(orc.stream_line(refs["names"][o4[i, 0]].decode(), names[i].decode(), o4[i, 1], o4[i, 2], o4[i, 3], 1000)
+                   for i in range(300))
+    assert r.stdout.decode() == want
+    # hash sub-command: name then every hash
+    r = subprocess.run([exe, "hash", "-f", os.path.join(data_dir, "hpv_16.fa.gz"), "-k", "12"], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    rec = orc.kseq_parse_file(os.path.join(data_dir, "hpv_16.fa.gz"))[0]
+    h = orc.calc_hashes(orc.to_upper(rec[1]), [12])
+    assert r.stdout.decode() == rec[0].decode() + "".join("\t%d" % v for v in h) + "\n"
+    # no arguments -> help on stderr, exit 1
+    r = subprocess.run([exe], capture_output=True)
+    assert r.returncode == 1 and r.stdout == b"" and b"Usage" in r.stderr
+    r = subprocess.run([exe, "stream"], capture_output=True)
+    assert r.returncode == 1

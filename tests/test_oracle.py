@@ -1,0 +1,162 @@
+"""CPU-only: pins the oracle (oracle/rk_oracle.c) -- murmur3 against independent known-answer vectors,
+the mkmh restatements against straightforward Python definitions, and the committed golden files."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import golden, rand_dna
+
+
+def test_murmur3_known_answers(orc, golden_dir):
+    vec = json.load(open(os.path.join(golden_dir, "murmur3_kat.json")))["vectors"]
+    assert len(vec) > 50
+    for v in vec:
+        assert orc.murmur3_x64_128(bytes.fromhex(v["key_hex"]), v["seed"]) == (v["h1"], v["h2"])
+    # the two vectors quoted in SURVEY.md section 8c
+    assert orc.murmur3_x64_128(b"hello", 0) == (0xcbd8a7b341bd9b02, 0x5b1e906a48ae1d19)
+    assert orc.murmur3_x64_128(b"ACGTACGTACGTACGT", 42) == (4706917051267373191, 12844982669895470291)
+
+
+def _rc(s):
+    return bytes({65: 84, 84: 65, 67: 71, 71: 67}.get(c, c) for c in reversed(s))
+
+
+def _fold(h1, h2, fold):
+    w = [h1 & 0xffffffff, h1 >> 32, h2 & 0xffffffff, h2 >> 32]
+    return {0: (w[0] << 32) | w[1], 1: h1, 2: (w[2] << 32) | w[1]}[fold]
+
+
+@pytest.mark.parametrize("fold", [0, 1, 2])
+@pytest.mark.parametrize("drop", [0, 1])
+def test_calc_hashes_definition(orc, fold, drop):
+    rng = np.random.default_rng(7)
+    pol = orc.default_policy(fold=fold, drop_last_window=drop)
+    for k in (5, 12, 16, 20, 31, 33):
+        s = rand_dna(rng, 90, b"ACGTACGTACGTN")
+        h = orc.calc_hashes(s, [k], pol)
+        n = len(s) - k + (0 if drop else 1)
+        assert len(h) == n
+        for i in range(n):
+            w = s[i:i + k]
+            if any(c not in b"ACGT" for c in w):
+                assert h[i] == 0
+            else:
+                f = _fold(*orc.murmur3_x64_128(w, 42), fold)
+                r = _fold(*orc.murmur3_x64_128(_rc(w), 42), fold)
+                assert int(h[i]) == min(f, r)
+                assert orc.calc_hash(w, pol) == min(f, r)
+
+
+def test_multi_k_concatenates(orc):
+    s = b"ACGTTGCAAGGCTTAACCGGTTAAGGCC"
+    a, b = orc.calc_hashes(s, [4]), orc.calc_hashes(s, [7])
+    assert (orc.calc_hashes(s, [4, 7]) == np.concatenate([a, b])).all()
+
+
+def test_short_sequence_is_empty(orc):
+    assert len(orc.calc_hashes(b"ACGT", [16])) == 0
+    assert len(orc.calc_hashes(b"", [16])) == 0
+    assert len(orc.calc_hashes(b"ACGTACGTACGTACGT", [16])) == 0  # len-k windows (policy U3)
+    assert len(orc.calc_hashes(b"ACGTACGTACGTACGT", [16], orc.default_policy(drop_last_window=0))) == 1
+
+
+def test_to_upper_quirk(orc):
+    assert orc.to_upper(b"acgtnACGTN") == b"ACGTNACGTN"
+    assert orc.to_upper(b"[\\]^_`{|}~") == b"[<=>?@[\\]^"  # every char > 91 gets -32 (mkmh quirk)
+    assert orc.to_upper(bytes([200, 255])) == bytes([200, 255])
+
+
+def test_minhashes_definition(orc):
+    rng = np.random.default_rng(3)
+    h = rng.integers(1, 50, size=200, dtype=np.uint64)
+    h[::7] = 0
+    for S in (1, 10, 150, 500):
+        want = np.sort(h[h != 0])[:S]
+        assert (orc.minhashes(h, S) == want).all()
+    assert len(orc.minhashes(np.zeros(5, np.uint64), 10)) == 0
+    assert len(orc.minhashes(np.zeros(0, np.uint64), 10)) == 0
+
+
+def test_intersection_is_multiset_merge(orc):
+    f = orc.hash_intersection_size
+    assert f([1, 2, 3], [2, 3, 4]) == 2
+    assert f([5, 5], [5]) == 1
+    assert f([5], [5, 5]) == 1
+    assert f([5, 5, 5], [5, 5]) == 2
+    assert f([0, 0, 5], [0, 5]) == 1  # leading zeros skipped
+    assert f([], [1]) == 0
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        a = np.sort(rng.integers(1, 40, size=60, dtype=np.uint64))
+        b = np.sort(rng.integers(1, 40, size=80, dtype=np.uint64))
+        want = sum(min((a == v).sum(), (b == v).sum()) for v in np.unique(a))
+        assert f(a, b) == want
+
+
+def test_argmax_diff_rules(orc):
+    f = orc.argmax_diff
+    assert f([0, 0, 0]) == (0, 0, 1)          # all zero: first ref, diff = 0 - (-1)
+    assert f([3, 5, 5, 1]) == (1, 5, 2)       # first max wins; later equal score does not change diff
+    assert f([5, 3, 5]) == (0, 5, 6)
+    assert f([1, 2, 3]) == (2, 3, 1)
+    assert f([2, 2]) == (0, 2, 3)
+
+
+def test_stream_line_format(orc):
+    assert orc.stream_line("R", "q", 5, 2, 100, 1000) == "R\tq\t5\t1000\t\t\n"
+    assert orc.stream_line("R", "q", 5, 0, 100, 1000) == "R\tq\t5\t1000\t\tFAIL:DIFF\n"
+    assert orc.stream_line("R", "q", 5, 2, 100, 1000, min_matches=200) == "R\tq\t5\t1000FAIL:DEPTH\tFAIL:MATCHES\t\n"
+
+
+def test_counter_and_depth_path(orc):
+    # -M path equals "mask then classify" computed by hand
+    rng = np.random.default_rng(11)
+    refs = [rand_dna(rng, 400) for _ in range(3)]
+    reads = [refs[i % 3][10 * i:10 * i + 80] for i in range(12)] + [rand_dna(rng, 80)]
+    rb, ro = orc.pack(refs)
+    qb, qo = orc.pack(reads)
+    sk, ln = orc.sketch_refs(rb, ro, [11], 50)
+    out = orc.classify_stream(qb, qo, [11], 50, sk, ln, min_kmer_occ=2, counter_slots=10007)
+    counts = {}
+    allh = [orc.calc_hashes(r, [11]) for r in reads]
+    for h in allh:
+        for v in h:
+            counts[int(v) % 10007] = counts.get(int(v) % 10007, 0) + 1
+    for i, h in enumerate(allh):
+        m = np.array([v if counts[int(v) % 10007] >= 2 else 0 for v in h], dtype=np.uint64)
+        mins = orc.minhashes(m, 50)
+        shared = [orc.hash_intersection_size(mins, sk[j, :ln[j]]) for j in range(3)]
+        assert tuple(out[i]) == orc.argmax_diff(shared) + (len(mins),)
+
+
+@pytest.mark.parametrize("tag", ["c1_hpv16_minion25", "zika_z1", "c2mini_pave", "c2mini_pave_k12_k16", "c2mini_pave_M2"])
+def test_golden_files_match_oracle(orc, golden_dir, data_dir, tag):
+    """The committed goldens are what the oracle produces today (regression pin)."""
+    g = golden(golden_dir, tag)
+    refs = orc.kseq_parse_file(os.path.join(data_dir, g["ref_file"]))
+    if "reads_file" in g:
+        reads = orc.kseq_parse_file(os.path.join(data_dir, g["reads_file"]))
+        qn = [r[0].decode() for r in reads]
+        qb, qo = orc.pack([r[1] for r in reads])
+    else:
+        from rkmh_amd import synth
+        rb0, ro0 = orc.pack([r[1] for r in refs])
+        qb, qo = synth.generate_reads(rb0, ro0, 0, 1000)
+        qn = [n.decode() for n in synth.read_names(0, 1000)]
+    rb, ro = orc.pack([r[1] for r in refs])
+    rn = [r[0].decode() for r in refs]
+    sk, ln = orc.sketch_refs(rb, ro, g["ks"], g["sketch_size"], threads=4)
+    assert [int(x) for x in ln] == g["ref_sketch_lens"]
+    assert [int(x) for x in sk[0, :8]] == g["first_sketch_hashes"]["ref0"]
+    out = orc.classify_stream(qb, qo, g["ks"], g["sketch_size"], sk, ln, threads=4, **g["kwargs"])
+    rows = [[qn[i], rn[out[i, 0]], int(out[i, 1]), int(out[i, 2]), int(out[i, 3])] for i in range(len(qn))]
+    assert rows == g["rows"]
+
+
+def test_c1_expectation(golden_dir):
+    """C1 gives 25 lines, all naming HPV16."""
+    g = golden(golden_dir, "c1_hpv16_minion25")
+    assert len(g["rows"]) == 25
+    assert all("HPV16" in r[1] for r in g["rows"])
