@@ -83,6 +83,19 @@ _SIGS = {
 }
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as /opt/rocm's).
+    If librkmh_amd.so pulled in the system copy first, a later `import torch` would bring a second runtime
+    that finds no GPU.  So when torch is installed, its runtime is loaded first and the library binds to it."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """Loads librkmh_amd.so (built in-tree by `make` / __graft_entry__.build()). No fallback."""
     global _LIB
@@ -91,6 +104,7 @@ def load_library():
         if not os.path.exists(path):
             raise RkmhError("%s is missing: build it with `make` (hipcc --offload-arch=gfx950). "
                             "rkmh_amd has no CPU fallback." % path)
+        _preload_torch_hip_runtime()
         lib = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)  # AttributeError if the ABI drifted
