@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- reads classified/sec of the rkmh classify/stream hot path on N MI355X (BASELINE.json metric).
+
+Workload (config C2 of SURVEY.md section 8d, per GPU): 1,000,000 synthetic 150 bp reads drawn from the 182
+references of data/all_pave_ref.fa (1 % substitutions, strand flips, 1/1000 reads with an N), k=16, s=1000.
+A "step" = one pass of the hot path (rk_classify_batch_device: upper-case, hash, sketch, intersect against
+every reference, argmax/diff) over the rank's resident batch.  Reads are sharded over ranks (weak scaling:
+every rank owns --reads reads of the global set); reference sketches are built on rank 0 and broadcast over
+RCCL once before the timed region.  Inputs are resident in HBM when the timed region starts.
+
+One JSON line on rank 0 with the contract fields plus `roofline` (HBM bound; algorithmic bytes = 170 B per
+read: 150 B bases + 4 B offset + 16 B result) and, at N=1, `cpu_baseline` (the oracle = literal restatement
+of src/rkmh.cpp:845-898 with OpenMP, timed on this box's host cores on a bounded sample of the same reads,
+and used to check the GPU rows bit-for-bit).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+B_READ = 170.0          # algorithmic bytes per 150 bp read (ASCII input): 150 + 4 + 16
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 disables)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    a = ap.parse_args()
+
+    import rkmh_amd
+    from rkmh_amd import api, dist as rdist, synth
+
+    rank, local, world = rdist.init()
+    if world != a.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ctx = rkmh_amd.Context(local)
+
+    ks, S, L = [16], 1000, 150
+    refs = api.parse_files([os.path.join(ROOT, "tests", "golden", "data", "all_pave_ref.fa.gz")])
+    rb, ro, R = refs["bases"], refs["offsets"], refs["nseq"]
+    if rank == 0:
+        ctx.set_references(rb, ro, ks, S)                 # sketched on this GPU
+        sk, ln = ctx.get_reference_sketches()
+    else:
+        sk = ln = None
+    sk, ln = rdist.broadcast_sketches(sk, ln, R, S, src=0, device=dev)   # RCCL over xGMI, once
+    if rank != 0:
+        ctx.set_reference_sketches(sk, ln, ks, S)
+
+    n = a.reads
+    lo = rank * n
+    qb, qo = synth.generate_reads_fast(rb, ro, lo, lo + n, read_len=L, threads=min(32, os.cpu_count() or 1))
+    d_b = torch.from_numpy(qb).to(dev)
+    d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev)
+    d_out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    tstream = torch.cuda.Stream(device=dev)          # the kernels AND the timing events go on this stream
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+
+    def step():
+        ctx.classify_device(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=L, stream=stream)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(el.item())
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))   # HIP events on the launch stream
+
+    out = d_out.cpu().numpy()
+    if (out[:, 0] < 0).any():
+        raise SystemExit("fused path flagged reads for rerouting: the benchmark batch must be fused-eligible")
+
+    if rank == 0:
+        value = world * n * a.steps / elapsed
+        achieved = B_READ * n / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get("reads_per_launch") == n:
+                    traffic = j.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "reads classified/sec", "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "stream (C2): %d synthetic %d bp reads per GPU vs data/all_pave_ref.fa (%d refs), k=16 s=1000"
+                                   % (n, L, R), "reads_per_gpu": n, "read_len": L, "k": 16, "sketch_size": S,
+                       "references": R, "parallelism": "reads sharded over %d rank(s); ref sketches RCCL-broadcast once" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_classify_fused", "kernel_ms": kern_ms, "bytes_per_read": B_READ},
+        }
+        if world == 1 and a.cpu_seconds > 0:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle  # CPU baseline + checker only
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            thr = a.cpu_threads or min(oracle.max_threads(), avail)
+            probe = min(n, 4 * thr)
+            t = time.perf_counter()
+            oracle.classify_stream(qb, qo[: probe + 1], ks, S, sk, ln, threads=thr)
+            rate = probe / max(time.perf_counter() - t, 1e-6)
+            m = int(max(min(n, rate * a.cpu_seconds), min(n, 1000)))
+            t = time.perf_counter()
+            want = oracle.classify_stream(qb, qo[: m + 1], ks, S, sk, ln, threads=thr)
+            dt = time.perf_counter() - t
+            if not (want == out[:m]).all():
+                raise SystemExit("PARITY FAILURE: GPU rows differ from the CPU oracle")
+            t = time.perf_counter()
+            m1 = max(min(m, int(m / thr * 4)), 1)
+            oracle.classify_stream(qb, qo[: m1 + 1], ks, S, sk, ln, threads=1)
+            dt1 = time.perf_counter() - t
+            res["cpu_baseline"] = {"value": m / dt, "unit": "reads/s", "cores": thr, "kind": "port",
+                                   "sample": "first %d reads of the same batch, OpenMP x%d, refs pre-sketched; %.1f s" % (m, thr, dt),
+                                   "single_thread_value": m1 / dt1, "parity": "GPU rows bit-exact on the %d sampled reads" % m}
+        print(json.dumps(res))
+        sys.stdout.flush()
+    ctx.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

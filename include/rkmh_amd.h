@@ -65,6 +65,8 @@ int rk_device_count(void);
 int rk_ctx_create(int device, const rk_policy* policy, rk_ctx** out);
 void rk_ctx_destroy(rk_ctx* ctx);
 int rk_ctx_synchronize(rk_ctx* ctx);
+/* The context's own non-blocking hipStream_t (what the host-buffer entry points enqueue on). */
+void* rk_ctx_stream(rk_ctx* ctx);
 void rk_free(void* p);
 
 /* ------------------------------------------------------------------------------------------------
@@ -148,7 +150,8 @@ int rk_classify_batch(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets
  * up to the next multiple of 4 past the last base; d_offsets_u32: uint32 [nreads+1] byte offsets into
  * d_bases; d_out4: int32 [nreads*4].  max_read_len: upper bound of the read lengths in the batch (sizes the
  * per-wave LDS image; 0 => determined by a device reduction, which costs one stream sync).
- * hip_stream: a hipStream_t (NULL => the context's stream).  Asynchronous: returns after enqueueing.
+ * hip_stream: the hipStream_t to enqueue on (NULL = HIP's null stream; rk_ctx_stream() = the context's own).
+ * Asynchronous: returns after enqueueing.
  * Reads the fused kernel cannot take (longer than 1024 bases, or more non-zero hashes than the sketch
  * size) come back with max_id = -2; rk_classify_batch reroutes those itself. */
 int rk_classify_batch_device(rk_ctx* ctx, const void* d_bases, const void* d_offsets_u32, int64_t nreads,

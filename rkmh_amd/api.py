@@ -45,6 +45,7 @@ _SIGS = {
     "rk_ctx_create": (C.c_int, [C.c_int, C.POINTER(Policy), C.POINTER(C.c_void_p)]),
     "rk_ctx_destroy": (None, [C.c_void_p]),
     "rk_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "rk_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "rk_free": (None, [C.c_void_p]),
     "rk_to_upper": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "rk_calc_hashes": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _ip, C.c_int, C.POINTER(_u64p), _ip]),
@@ -397,11 +398,21 @@ class Context:
         _chk(self._lib.rk_classify_batch(self._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), n, _p(out, C.c_int32)))
         return out
 
-    def classify_device(self, d_bases_ptr, d_offsets_ptr, nreads, d_out_ptr, max_read_len=0, stream=0):
-        """Same with inputs resident in HBM (raw device pointers, e.g. torch tensors' data_ptr())."""
+    @property
+    def stream(self):
+        return int(self._lib.rk_ctx_stream(self._h) or 0)
+
+    def classify_device(self, d_bases_ptr, d_offsets_ptr, nreads, d_out_ptr, max_read_len=0, stream=None):
+        """Same with inputs resident in HBM (raw device pointers, e.g. torch tensors' data_ptr()).
+        stream: a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream; 0 = null stream);
+        None = the context's own stream."""
+        if stream is None:
+            stream = self.stream
         _chk(self._lib.rk_classify_batch_device(self._h, C.c_void_p(d_bases_ptr), C.c_void_p(d_offsets_ptr), nreads,
                                                 C.c_void_p(d_out_ptr), max_read_len, C.c_void_p(stream)))
 
-    def count_device(self, d_bases_ptr, d_offsets_ptr, nreads, counter, stream=0):
+    def count_device(self, d_bases_ptr, d_offsets_ptr, nreads, counter, stream=None):
+        if stream is None:
+            stream = self.stream
         _chk(self._lib.rk_count_batch_device(self._h, C.c_void_p(d_bases_ptr), C.c_void_p(d_offsets_ptr), nreads,
                                              counter._h, C.c_void_p(stream)))

@@ -154,6 +154,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (c->st) { e = hipStreamDestroy(c->st); (void)e; }
     delete c;
 }
+extern "C" void* rk_ctx_stream(rk_ctx* c) { return c ? (void*)c->st : nullptr; }
 extern "C" int rk_ctx_synchronize(rk_ctx* c) {
     if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
     RKCHK(set_dev(c));
@@ -681,7 +682,7 @@ extern "C" int rk_classify_batch_device(rk_ctx* c, const void* d_bases, const vo
     if (!c->have_refs) return fail(RK_ERR_STATE, "classify before rk_set_references");
     RKCHK(set_dev(c));
     if (nreads == 0) return RK_OK;
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->st;
+    hipStream_t st = (hipStream_t)hip_stream;
     // the resident-input entry point serves reads the fused kernel can take (len <= FUSED_MAXLEN and all
     // hashes inside the sketch); anything else is flagged -2 in d_out4 for the caller (rk_classify_batch
     // reroutes those through the general path itself).
@@ -694,7 +695,7 @@ extern "C" int rk_count_batch_device(rk_ctx* c, const void* d_bases, const void*
     if (!c || !counter || nreads < 0 || (nreads > 0 && (!d_bases || !d_offs))) return fail(RK_ERR_ARG, "bad arguments");
     RKCHK(set_dev(c));
     if (nreads == 0) return RK_OK;
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->st;
+    hipStream_t st = (hipStream_t)hip_stream;
     uint32_t ml = 0;
     RKCHK(device_max_len(c, d_offs, nreads, st, &ml));
     if (ml > (uint32_t)FUSED_MAXLEN) return fail(RK_ERR_LIMIT, "rk_count_batch_device: reads longer than %d need rk_count_batch", FUSED_MAXLEN);

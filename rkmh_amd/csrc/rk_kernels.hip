@@ -13,6 +13,7 @@
 // forward + reverse-complement strings, wave ballots for compaction, LDS atomics for the per-reference
 // counters and a hash-table index of all reference sketches that stays L2/MALL resident.
 #include "rk_kernels.hpp"
+#include <cstdlib>
 
 namespace rk {
 
@@ -302,7 +303,8 @@ hipError_t launch_classify_fused(const uint8_t* bases, const uint32_t* offs, uin
                                  int32_t* out4, const DevPolicy& pol, int maxlen, hipStream_t st) {
     if (nreads == 0) return hipSuccess;
     size_t lds = ((size_t)stage_lds_dwords(maxlen) + (size_t)maxlen * ks.n + (size_t)(ix.nref > 0 ? ix.nref : 0)) * 4 + 16;
-    uint32_t grid = 256 * 16;
+    uint32_t grid = 256 * 32;   // one wave per block: 32 waves per CU = 8 per SIMD
+    if (const char* g = getenv("RKMH_FUSED_GRID")) grid = (uint32_t)atoi(g);
     if (grid > nreads) grid = nreads;
     const bool k16 = (ks.n == 1 && ks.k[0] == 16);
 #define RK_LAUNCH(KT, MODE)                                                                                         \

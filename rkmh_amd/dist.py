@@ -1,0 +1,70 @@
+"""One process per GPU over torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+
+The classify path shards by reads -- each rank owns a contiguous block of the global read set and never
+talks to the others after start-up.  The only exchanges are:
+  * broadcast of the reference sketches uint64[R][S] + int32 lens[R] from the rank that sketched them;
+  * (-M path only) an all-reduce(sum) of the HASHTCounter table between pass 1 and pass 2.
+"""
+import os
+
+import numpy as np
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    import torch
+    import torch.distributed as dist
+    rank, local, world = env_rank()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_bounds(n_total, rank, world):
+    """Contiguous block [lo, hi) of rank (GPU g gets reads [g*N/G, (g+1)*N/G))."""
+    return n_total * rank // world, n_total * (rank + 1) // world
+
+
+def broadcast_sketches(sketches, lens, nref, sketch_size, src=0, device=None):
+    """Rank `src` passes (sketches [R,S] uint64, lens [R] int32); the others pass None. Returns numpy arrays."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return sketches, lens
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    if dist.get_rank() == src:
+        t_sk = torch.from_numpy(np.ascontiguousarray(sketches).view(np.int64)).to(dev)
+        t_ln = torch.from_numpy(np.ascontiguousarray(lens)).to(dev)
+    else:
+        t_sk = torch.empty((nref, sketch_size), dtype=torch.int64, device=dev)
+        t_ln = torch.empty((nref,), dtype=torch.int32, device=dev)
+    dist.broadcast(t_sk, src=src)
+    dist.broadcast(t_ln, src=src)
+    return t_sk.cpu().numpy().view(np.uint64), t_ln.cpu().numpy()
+
+
+def allreduce_counter(t_counts):
+    """Sum the per-rank HASHTCounter tables in place (torch int32 tensor that the rk_counter wraps)."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t_counts, op=dist.ReduceOp.SUM)
+    return t_counts
+
+
+def gather_rows(rows, dst=0):
+    """Gather per-rank result blocks (numpy [n_i,4] int32) on `dst` in rank order (= global read order)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return rows
+    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(rows, out, dst=dst)
+    return np.concatenate(out, axis=0) if out is not None else None
