@@ -102,7 +102,7 @@ struct rk_ctx {
     KsArr ks{};
     std::vector<uint64_t> h_sk;
     std::vector<int32_t> h_lens;
-    DevBuf d_keys, d_vals, d_post;
+    DevBuf d_fpb, d_keys, d_vals, d_post;
     RefIndex ix{};
     bool have_refs = false;
     // -M
@@ -143,7 +143,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
-    for (DevBuf* b : {&c->d_keys, &c->d_vals, &c->d_post, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+    for (DevBuf* b : {&c->d_fpb, &c->d_keys, &c->d_vals, &c->d_post, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
@@ -533,13 +533,16 @@ static int build_index(rk_ctx* c) {
     std::sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) { return a.h != b.h ? a.h < b.h : a.ref < b.ref; });
     size_t distinct = 0;
     for (size_t i = 0; i < pairs.size(); ++i) if (i == 0 || pairs[i].h != pairs[i - 1].h) ++distinct;
-    uint32_t size = 1024;
-    while ((size_t)size < distinct * 2 + 1) size <<= 1;
+    // bucketed table: 4 slots per bucket, ~1.25 keys per bucket on average (load ~0.31)
+    uint32_t nb = 256, lg = 8;
+    while ((size_t)nb * 5 < distinct * 4 + 4) { nb <<= 1; ++lg; }
+    const uint32_t size = nb * 4;
+    std::vector<uint32_t> fpb(size, 0);
     std::vector<uint64_t> keys(size, 0);
     std::vector<uint32_t> vals(size, 0);
     std::vector<uint32_t> post;
     post.push_back(0);
-    const uint32_t mask = size - 1;
+    const uint32_t bmask = nb - 1, bshift = 32 - lg;
     size_t i = 0;
     std::vector<std::pair<uint32_t, uint32_t>> grp;
     while (i < pairs.size()) {
@@ -558,19 +561,26 @@ static int build_index(rk_ctx* c) {
             post.push_back((uint32_t)grp.size());
             for (auto& g : grp) { post.push_back(g.first); post.push_back(g.second); }
         }
-        uint32_t s = index_slot(pairs[i].h, mask);
-        while (keys[s] != 0) s = (s + 1) & mask;
-        keys[s] = pairs[i].h; vals[s] = v;
+        uint32_t b = index_bucket(pairs[i].h, bshift);
+        for (;;) {
+            uint32_t q = 0;
+            while (q < 4 && fpb[4 * b + q] != 0) ++q;
+            if (q < 4) { fpb[4 * b + q] = index_fp(pairs[i].h); keys[4 * b + q] = pairs[i].h; vals[4 * b + q] = v; break; }
+            b = (b + 1) & bmask;
+        }
         i = j;
     }
+    RKCHK(c->d_fpb.reserve((size_t)size * 4));
     RKCHK(c->d_keys.reserve((size_t)size * 8));
     RKCHK(c->d_vals.reserve((size_t)size * 4));
     RKCHK(c->d_post.reserve(post.size() * 4));
+    HIPCHK(hipMemcpy(c->d_fpb.p, fpb.data(), (size_t)size * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_keys.p, keys.data(), (size_t)size * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_vals.p, vals.data(), (size_t)size * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_post.p, post.data(), post.size() * 4, hipMemcpyHostToDevice));
-    c->ix.keys = c->d_keys.as<uint64_t>(); c->ix.vals = c->d_vals.as<uint32_t>(); c->ix.post = c->d_post.as<uint32_t>();
-    c->ix.mask = mask; c->ix.nref = R;
+    c->ix.fpb = c->d_fpb.as<uint4>(); c->ix.keys = c->d_keys.as<uint64_t>(); c->ix.vals = c->d_vals.as<uint32_t>();
+    c->ix.post = c->d_post.as<uint32_t>();
+    c->ix.bmask = bmask; c->ix.bshift = bshift; c->ix.nref = R;
     c->have_refs = true;
     return RK_OK;
 }
@@ -645,8 +655,14 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     int32_t* counter = nullptr; uint64_t slots = 1; int min_occ = 0;
     if (mode == 1) { counter = count_into->d; slots = count_into->slots; }
     else if (c->depth) { counter = c->depth->d; slots = c->depth->slots; min_occ = c->min_occ; }
-    HIPCHK(launch_classify_fused((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
-                                 counter, slots, min_occ, mode, (int32_t*)d_out4, c->pol, pick_maxlen(max_read_len), st));
+    static const bool force_v1 = getenv("RKMH_FUSED_V1") != nullptr;
+    uint32_t ml = max_read_len < 1 ? 1 : (max_read_len > (uint32_t)FUSED_MAXLEN ? (uint32_t)FUSED_MAXLEN : max_read_len);
+    if (!force_v1 && classify_tile_supported(mode == 0 ? c->ix.nref : 0))
+        HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
+                                    counter, slots, min_occ, mode, (int32_t*)d_out4, c->pol, (int)ml, st));
+    else
+        HIPCHK(launch_classify_fused((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
+                                     counter, slots, min_occ, mode, (int32_t*)d_out4, c->pol, pick_maxlen(max_read_len), st));
     return RK_OK;
 }
 

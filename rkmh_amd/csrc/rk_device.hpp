@@ -159,7 +159,7 @@ __device__ __forceinline__ Staged stage_piece(const uint8_t* __restrict__ bases,
         n |= __shfl_xor((int)n, 1);
         n |= __shfl_xor((int)n, 2);
         n |= __shfl_xor((int)n, 4);
-        if ((tid & 7) == 0) s.inv[j >> 3] = n;
+        if ((tid & 7) == 0 && (j >> 3) <= (ndw >> 3)) s.inv[j >> 3] = n;  // never past the word holding dword ndw
     }
     sync();
     // rc dword q covers rc bytes 4q..4q+3 = complement of fwd bytes p+3..p, p = fbase + nbases - 4 - 4q
@@ -208,29 +208,39 @@ __host__ __device__ __forceinline__ int num_windows(int len, int k, int drop_las
     return n > 0 ? n : 0;
 }
 
-// ---- resident reference index (open addressing, keys = distinct sketch hashes) ---------------
+// ---- resident reference index ------------------------------------------------------------------
+// All distinct hashes of all reference sketches in one bucketed hash table that stays L2 resident:
+//   fpb  : one 16-byte bucket = 4 x 32-bit fingerprints (0 = empty; slots of a bucket fill in order)
+//   keys : the full 64-bit hash per slot (read only to confirm a fingerprint match)
+//   vals : per slot, bit31=0 -> single posting inline (ref | mult<<20); bit31=1 -> offset into post
+//   post : [off] = count, then count x (ref, mult)
+// A lookup that misses (about 7 of 8 read k-mers) costs exactly one 16-byte load.
 struct RefIndex {
-    const uint64_t* keys;   // [mask+1], 0 = empty
-    const uint32_t* vals;   // [mask+1]: bit31=0 -> inline single posting (ref | mult<<20); bit31=1 -> offset into post
-    const uint32_t* post;   // [off] = count, then count x (ref, mult)
-    uint32_t mask;
+    const uint4* fpb;
+    const uint64_t* keys;
+    const uint32_t* vals;
+    const uint32_t* post;
+    uint32_t bmask;   // buckets - 1
+    uint32_t bshift;  // 32 - log2(buckets)
     int32_t nref;
 };
 constexpr uint32_t IDX_NOT_FOUND = 0xffffffffu;
 
-__host__ __device__ __forceinline__ uint32_t index_slot(uint64_t h, uint32_t mask) {
-    uint32_t x = (uint32_t)h ^ (uint32_t)(h >> 32);
-    x *= 0x9E3779B1u;
-    x ^= x >> 15;
-    return x & mask;
+__host__ __device__ __forceinline__ uint32_t index_fp(uint64_t h) { return (uint32_t)h | 0x80000000u; }
+__host__ __device__ __forceinline__ uint32_t index_bucket(uint64_t h, uint32_t bshift) {
+    return bshift >= 32 ? 0u : (((uint32_t)(h >> 32) ^ ((uint32_t)h >> 31)) * 0x9E3779B1u) >> bshift;
 }
 __device__ __forceinline__ uint32_t index_find(const RefIndex& ix, uint64_t h) {
-    uint32_t s = index_slot(h, ix.mask);
-    while (true) {
-        uint64_t key = ix.keys[s];
-        if (key == h) return s;
-        if (key == 0) return IDX_NOT_FOUND;
-        s = (s + 1) & ix.mask;
+    const uint32_t fp = index_fp(h);
+    uint32_t b = index_bucket(h, ix.bshift);
+    for (;;) {
+        const uint4 f = ix.fpb[b];
+        if (f.x == fp && ix.keys[4 * b + 0] == h) return 4 * b + 0;
+        if (f.y == fp && ix.keys[4 * b + 1] == h) return 4 * b + 1;
+        if (f.z == fp && ix.keys[4 * b + 2] == h) return 4 * b + 2;
+        if (f.w == fp && ix.keys[4 * b + 3] == h) return 4 * b + 3;
+        if (f.w == 0) return IDX_NOT_FOUND;   // bucket not full => the key was never pushed further
+        b = (b + 1) & ix.bmask;
     }
 }
 
