@@ -35,8 +35,11 @@ __device__ __forceinline__ void mm_block(uint64_t& h1, uint64_t& h2, uint64_t k1
     k2 *= MM_C2; k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2;
     h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
 }
-// finalisation + the 128->64 fold (policy U1)
-__device__ __forceinline__ uint64_t mm_finish(uint64_t h1, uint64_t h2, uint32_t len, int fold) {
+// finalisation + the 128->64 fold (policy U1).  FOLD >= 0 fixes the fold at compile time (no branches
+// between the forward and reverse-complement hash chains, so the scheduler can interleave them).
+template <int FOLD = -1>
+__device__ __forceinline__ uint64_t mm_finish(uint64_t h1, uint64_t h2, uint32_t len, int fold_rt) {
+    const int fold = FOLD >= 0 ? FOLD : fold_rt;
     h1 ^= len; h2 ^= len;
     h1 += h2; h2 += h1;
     h1 = fmix64(h1); h2 = fmix64(h2);
@@ -54,7 +57,7 @@ __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t
 
 // MurmurHash3_x64_128 of the k bytes starting at byte offset `a` of the LDS dword array w32.
 // The array must be readable for 8 dwords past the window (buffers are padded).
-template <int KT>
+template <int KT, int FOLD = -1>
 __device__ __forceinline__ uint64_t murmur_window(const uint32_t* w32, uint32_t a, int k_rt, uint32_t seed, int fold) {
     const int k = KT ? KT : k_rt;
     uint32_t idx = a >> 2;
@@ -84,7 +87,7 @@ __device__ __forceinline__ uint64_t murmur_window(const uint32_t* w32, uint32_t 
         if (rem > 8) { k2 *= MM_C2; k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2; }
         k1 *= MM_C1; k1 = rotl64(k1, 31); k1 *= MM_C2; h1 ^= k1;
     }
-    return mm_finish(h1, h2, (uint32_t)k, fold);
+    return mm_finish<FOLD>(h1, h2, (uint32_t)k, fold);
 }
 
 // ---- per-dword (4 bases) SWAR helpers -------------------------------------------------------
