@@ -105,6 +105,7 @@ struct rk_ctx {
     DevBuf d_fpb, d_keys, d_vals, d_post;
     RefIndex ix{};
     bool have_refs = false;
+    double density = 1.0; // fraction of a reference's k-mers that its sketch keeps (largest over references)
     // -M
     rk_counter* depth = nullptr;
     int min_occ = 0;
@@ -581,6 +582,14 @@ static int build_index(rk_ctx* c) {
     c->ix.fpb = c->d_fpb.as<uint4>(); c->ix.keys = c->d_keys.as<uint64_t>(); c->ix.vals = c->d_vals.as<uint32_t>();
     c->ix.post = c->d_post.as<uint32_t>();
     c->ix.bmask = bmask; c->ix.bshift = bshift; c->ix.nref = R;
+    // a full bottom-S sketch of uniform hashes keeps the fraction (largest kept hash / 2^64) of the k-mers
+    c->density = 0.0;
+    for (int r = 0; r < R; ++r) {
+        const int len = c->h_lens[(size_t)r];
+        double d = 1.0;
+        if (len == S && len > 0) d = (double)c->h_sk[(size_t)r * S + (size_t)len - 1] / 18446744073709551616.0;
+        if (d > c->density) c->density = d;
+    }
     c->have_refs = true;
     return RK_OK;
 }
@@ -657,9 +666,11 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     else if (c->depth) { counter = c->depth->d; slots = c->depth->slots; min_occ = c->min_occ; }
     static const bool force_v1 = getenv("RKMH_FUSED_V1") != nullptr;
     uint32_t ml = max_read_len < 1 ? 1 : (max_read_len > (uint32_t)FUSED_MAXLEN ? (uint32_t)FUSED_MAXLEN : max_read_len);
-    if (!force_v1 && classify_tile_supported(mode == 0 ? c->ix.nref : 0))
+    int expect = 0; // hits an error-free read is expected to score: sizes the kernel's per-read hit multiset
+    for (int j = 0; j < c->ks.n; ++j) expect += (int)(c->density * (double)num_windows((int)ml, c->ks.k[j], c->pol.drop_last_window)) + 1;
+    if (!force_v1 && classify_tile_supported(mode == 0 ? c->ix.nref : 0, (int)ml))
         HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
-                                    counter, slots, min_occ, mode, (int32_t*)d_out4, c->pol, (int)ml, st));
+                                    counter, slots, min_occ, mode, (int32_t*)d_out4, c->pol, (int)ml, expect, st));
     else
         HIPCHK(launch_classify_fused((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
                                      counter, slots, min_occ, mode, (int32_t*)d_out4, c->pol, pick_maxlen(max_read_len), st));

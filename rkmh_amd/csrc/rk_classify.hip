@@ -7,22 +7,25 @@
 // sort cannot change any intersection size and is skipped).  Other reads are flagged max_id = -2 and
 // rerouted by the host through k_hash_tiles + k_sort_intersect.
 //
-// Work decomposition (one 256-thread workgroup = one TILE of T consecutive reads):
-//   phase 0  the tile's bases are ONE contiguous byte range of the batch: stage it with coalesced dword
-//            loads into LDS as an upper-cased forward image, a reverse-complement image and a validity
-//            bitmap; per-read tables; a bitmap of the byte positions that start no hashable window
-//            (read tails, windows holding a non-ACGT base).
-//   phase 1  the tile's byte positions are flattened over the 256 threads; the hot loop is branch-free:
-//            two unaligned LDS window reads, both murmur3 chains in one basic block, one 16-byte bucket
-//            load from the L2-resident reference index whose latency hides behind the NEXT position's
-//            hashing.  Fingerprint matches (about 1 window in 8) are pushed to an LDS queue with one
-//            wave-aggregated atomic.
-//   phase 1b the queue is drained with every lane busy: full-key verification, postings accumulated into
-//            per-read 16-bit LDS counters; since counts only grow, an LDS atomicMax of (count, -ref) per
-//            increment leaves (max_shared, first max_id) behind without any scan.  An exact per-read
-//            LDS hash set flags reads that hit the same sketch hash twice (multiset semantics).
-//   phase 2  16 lanes per read: best earlier score for `diff` (DPP row reduction over the counters),
-//            the exact multiset recount for flagged reads, one int4 per read, counters re-zeroed.
+// Work decomposition: ONE WAVE = one tile of T consecutive reads (T = 4 for 150 bp reads); a workgroup is a
+// single wave, so nothing ever waits at a workgroup barrier and the 8 waves a SIMD holds drift apart into
+// different phases -- latency-bound phases of one wave hide under the hashing of the others.
+//   phase 0  the tile's bases are ONE contiguous byte range of the batch.  They (and the tile's offsets)
+//            were prefetched into registers while the previous tile was hashed; they are written to LDS as
+//            an upper-cased forward image, a reverse-complement image and a validity bitmap, plus a bitmap
+//            of the byte positions that start no hashable window (read tails, windows with a non-ACGT base).
+//   phase 1  the tile's byte positions are flattened over the 64 lanes; the hot loop is branch-free: two
+//            unaligned LDS window reads, both murmur3 chains in one basic block, one 16-byte bucket load
+//            from the L2-resident reference index whose latency hides behind the NEXT position's hashing.
+//            Fingerprint matches (about 1 window in 8) go to a wave-private LDS queue (ballot + popcount,
+//            no atomics).
+//   drain    when the queue holds more than a wave's worth (and at the end) it is emptied with every lane
+//            busy: full-key verification, exact occurrence rank of the sketch hash within the read (LDS
+//            multiset: the merge of rkmh.cpp:869 counts min(multiplicities)), postings added to per-read
+//            16-bit LDS counters; since counts only grow, an LDS atomicMax of (count, -ref) per increment
+//            leaves (max_shared, first max_id) behind without any scan.
+//   phase 2  16 lanes per read (4 reads = one wave): best earlier score for `diff` (DPP row reduction over
+//            the counters), one int4 per read, counters re-zeroed.
 // Integer work only (no MFMA).
 #include "rk_kernels.hpp"
 
@@ -30,42 +33,42 @@
 
 namespace rk {
 
-constexpr int TILE_THREADS = 256;
-constexpr int GROUPS = TILE_THREADS / 16; // phase-2 lane groups
-constexpr int DSET = 128;                 // per-read exact hit multiset (slot + occurrence count), open addressing
+constexpr int WAVE = 64;
+constexpr int PF = 6; // prefetched base dwords per lane: tile bytes <= PF*64*4 - 8
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
-// reductions over a 16-lane DPP row; every lane of the row ends with the result
-__device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {
-    uint32_t t;
-    t = (uint32_t)dpp_i32<0xB1>((int)v); v = t > v ? t : v;   // quad_perm [1,0,3,2]
-    t = (uint32_t)dpp_i32<0x4E>((int)v); v = t > v ? t : v;   // quad_perm [2,3,0,1]
-    t = (uint32_t)dpp_i32<0x141>((int)v); v = t > v ? t : v;  // row_half_mirror
-    t = (uint32_t)dpp_i32<0x140>((int)v); v = t > v ? t : v;  // row_mirror
-    return v;
-}
+// max over a 16-lane DPP row; every lane of the row ends with the result
 __device__ __forceinline__ int row_max_i32(int v) {
     int t;
-    t = dpp_i32<0xB1>(v); v = t > v ? t : v;
-    t = dpp_i32<0x4E>(v); v = t > v ? t : v;
-    t = dpp_i32<0x141>(v); v = t > v ? t : v;
-    t = dpp_i32<0x140>(v); v = t > v ? t : v;
+    t = dpp_i32<0xB1>(v); v = t > v ? t : v;   // quad_perm [1,0,3,2]
+    t = dpp_i32<0x4E>(v); v = t > v ? t : v;   // quad_perm [2,3,0,1]
+    t = dpp_i32<0x141>(v); v = t > v ? t : v;  // row_half_mirror
+    t = dpp_i32<0x140>(v); v = t > v ? t : v;  // row_mirror
     return v;
 }
 
+// Orders this wave's LDS traffic for cross-lane hand-offs.  A workgroup is one wave: LDS instructions of a
+// wave execute in order, so no hardware wait is needed -- only the compiler must not move accesses across.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct TileGeom {
-    int32_t T;            // reads per tile (<= 64)
-    int32_t cap_bytes;    // staged bytes per tile
-    int32_t qcap;         // candidate queue entries
-    int32_t cwords;       // 16-bit counter words per read = (nref + 1) / 2
-    int32_t dbg;          // ablation switches for profiling (RKMH_DBG; 0 in production)
+    int32_t T;          // reads per tile (<= 16)
+    int32_t cap_bytes;  // staged bytes per tile
+    int32_t qcap;       // candidate queue entries (>= 128)
+    int32_t cwords;     // 16-bit counter words per read = (nref + 1) / 2
+    int32_t dset;       // slots of the per-read hit multiset (power of two)
+    int32_t dbg;        // ablation switches for profiling (RKMH_DBG; 0 in production)
 };
 
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
 __host__ __device__ inline size_t tile_lds_bytes(const TileGeom& g) {
-    return ((size_t)stage_lds_dwords(g.cap_bytes) + 6 * (size_t)(g.T + 1) + 2 * (size_t)tile_map_words(g.cap_bytes) +
-            4 * (size_t)g.qcap + (size_t)g.T * (size_t)(g.cwords + DSET) + 8) * 4;
+    return ((size_t)((stage_lds_dwords(g.cap_bytes) + 1) & ~1) + 4 * (size_t)g.qcap + 5 * (size_t)(g.T + 1) + 8 +
+            2 * (size_t)tile_map_words(g.cap_bytes) + (size_t)g.T * (size_t)(g.cwords + g.dset)) * 4;
 }
 
 // for every posting (ref, mult) of an index value
@@ -99,14 +102,25 @@ __device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uin
     }
 }
 
+// The bucket load of the software-pipelined lookup is issued through inline asm so that hipcc does not count
+// it: left to itself the compiler drains vmcnt at the loop header and exposes the full L2 latency every
+// iteration.  Form (ii) of the guide: "=v" load, then a wait statement naming the destination "+v" right
+// before the first consumer.  Over-waiting by compiler-inserted waits is harmless (loads return in order).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bucket_load_async(const uint4* p, u32x4& f) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void bucket_wait(u32x4& f) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : : "memory"); }
+
+// MODE 0: classify; MODE 1: count pass of -M (rkmh.cpp:904-910); MODE 2: classify with the -M mask (rkmh.cpp:916)
 template <int KT, int MODE, int FOLD>
-__global__ __launch_bounds__(TILE_THREADS) void k_classify_tile(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
-                                                                uint32_t nreads, KsArr ks, int S, RefIndex ix, int32_t* counter,
-                                                                uint64_t slots, int min_occ, int32_t* out4, DevPolicy pol,
-                                                                TileGeom geo) {
+__global__ __launch_bounds__(WAVE, 8) void k_classify_tile(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
+                                                           uint32_t nreads, KsArr ks, int S, RefIndex ix, int32_t* counter,
+                                                           uint64_t slots, int min_occ, int32_t* out4, DevPolicy pol, TileGeom geo) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int T = geo.T;
-    const int QCAP = geo.qcap;
+    const uint32_t QCAP = (uint32_t)geo.qcap;
+    const uint32_t DS = (uint32_t)geo.dset;
     uint32_t* stage = smem;
     uint32_t* qh32 = stage + ((stage_lds_dwords(geo.cap_bytes) + 1) & ~1); // [2*QCAP] candidate hashes (8-byte aligned)
     uint64_t* qh = reinterpret_cast<uint64_t*>(qh32);
@@ -116,75 +130,154 @@ __global__ __launch_bounds__(TILE_THREADS) void k_classify_tile(const uint8_t* _
     uint32_t* nwin = rstart + (T + 1);                           // [T+1] windows of read t (all k)
     uint32_t* nzero = nwin + (T + 1);                            // [T+1] zero hashes per read
     uint32_t* best = nzero + (T + 1);                            // [T+1] max over increments of (count << 16 | 0xFFFF - ref)
-    uint32_t* flags = best + (T + 1);                            // [T+1] read needs the exact multiset recount
-    uint32_t* misc = flags + (T + 1);                            // [0..3] per-wave queue lengths, [4] tile has invalid bases, [5] queue overflowed
-    uint32_t* bad = misc + 8;                                     // bit p set <=> no hashable window starts at tile byte p
+    uint32_t* flags = best + (T + 1);                            // [T+1] read must go through the general path
+    uint32_t* misc = flags + (T + 1);                            // [0] tile has invalid bases
+    uint32_t* bad = misc + 8;                                    // bit p set <=> no hashable window starts at tile byte p
     uint32_t* tmap = bad + tile_map_words(geo.cap_bytes);        // read index holding tile byte 32*c
     uint32_t* c16 = tmap + tile_map_words(geo.cap_bytes);        // [T][cwords] packed 16-bit per-reference counters
-    uint32_t* dset = c16 + T * geo.cwords;                       // [T][DSET] slots already hit by the read (+1; 0 = empty)
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    uint32_t* dset = c16 + T * geo.cwords;                       // [T][DS] multiset of the slots the read has hit
+    const int lane = threadIdx.x;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const int wave = tid >> 6;
-    const uint32_t QW = (uint32_t)QCAP / 4u; // every wave owns a quarter of the queue: pushes need no atomics
 
-    if (MODE == 0) // counters are re-zeroed by phase 2 after use
-        for (int i = tid; i < T * geo.cwords; i += TILE_THREADS) c16[i] = 0;
+    if (MODE != 1) { // counters are re-zeroed by phase 2 after use
+        for (int i = lane; i < T * geo.cwords; i += WAVE) c16[i] = 0;
+    }
     const uint32_t ntiles = (nreads + (uint32_t)T - 1) / (uint32_t)T;
+
+    // Software prefetch across tiles: while tile i is hashed, the offsets and the raw base dwords of this wave's
+    // next tile travel into registers, so phase 0 of the next tile touches no global memory.
+    uint32_t pf[PF];
+    uint32_t cur_a = 0, cur_b = 0, cur_o = 0; // tile byte range [a,b) in the batch, this lane's read offset
+    auto tile_reads = [&](uint32_t tl) -> int {
+        const uint32_t r = tl * (uint32_t)T;
+        return (int)((nreads - r) < (uint32_t)T ? (nreads - r) : (uint32_t)T);
+    };
+    auto load_offsets = [&](uint32_t tl, uint32_t& a_, uint32_t& b_, uint32_t& o_) {
+        const uint32_t r = tl * (uint32_t)T;
+        const int n = tile_reads(tl);
+        a_ = offs[r];
+        b_ = offs[r + (uint32_t)n];
+        o_ = offs[r + (uint32_t)(lane <= n ? lane : n)];
+    };
+    auto load_bases = [&](uint32_t a_, uint32_t b_) {
+        const uint32_t* g32 = reinterpret_cast<const uint32_t*>(bases) + (a_ >> 2);
+        uint32_t ndw = ((a_ & 3u) + (b_ - a_) + 3u) >> 2;
+        if (b_ - a_ > (uint32_t)geo.cap_bytes) ndw = 0; // oversized tile: rerouted, nothing to stage
+#pragma unroll
+        for (int q = 0; q < PF; ++q) { // register q of a lane = fwd-image dword jf = 64q + lane = global dword jf - 1
+            const uint32_t jf = (uint32_t)q * WAVE + (uint32_t)lane;
+            pf[q] = (jf >= 1 && jf <= ndw) ? g32[jf - 1] : 0u;
+        }
+    };
+    if (blockIdx.x < ntiles) { load_offsets(blockIdx.x, cur_a, cur_b, cur_o); load_bases(cur_a, cur_b); }
+
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t r0 = tile * (uint32_t)T;
-        const int Tn = (int)((nreads - r0) < (uint32_t)T ? (nreads - r0) : (uint32_t)T);
-        __syncthreads(); // previous tile fully consumed
-        // ---- phase 0 -------------------------------------------------------------------------------
-        const uint32_t tstart = offs[r0];
-        if (tid <= Tn) {
-            const uint32_t o0 = offs[r0 + tid];
-            rstart[tid] = o0 - tstart;
-            if (tid < Tn) {
-                const int len = (int)(offs[r0 + tid + 1] - o0);
+        const int Tn = tile_reads(tile);
+        const uint32_t tstart = cur_a;
+        const uint32_t B = cur_b - cur_a;
+        const uint32_t ntile = tile + gridDim.x;
+        uint32_t nxt_a = 0, nxt_b = 0, nxt_o = 0;
+        if (ntile < ntiles) load_offsets(ntile, nxt_a, nxt_b, nxt_o); // lands during phase 0
+        wave_sync(); // previous tile fully consumed
+        if (B > (uint32_t)geo.cap_bytes) { // a read longer than the hint: the host reroutes the tile
+            if (MODE != 1 && lane < Tn) reinterpret_cast<int4*>(out4)[r0 + lane] = make_int4(-2, 0, 0, 0);
+            cur_a = nxt_a; cur_b = nxt_b; cur_o = nxt_o;
+            if (ntile < ntiles) load_bases(cur_a, cur_b);
+            continue;
+        }
+        // ---- phase 0, interval 1: everything that needs only registers ------------------------------
+        Staged s;
+        {
+            const int fwd_dw = (FWD_PAD + 3 + geo.cap_bytes + TAIL_PAD + 3) / 4;
+            const int rc_dw = (geo.cap_bytes + TAIL_PAD + 3) / 4;
+            s.fwd = stage; s.rc = stage + fwd_dw; s.inv = s.rc + rc_dw;
+            s.fbase = FWD_PAD + (tstart & 3u); s.nbases = B;
+        }
+        const uint32_t o_next = (uint32_t)__shfl_down((int)cur_o, 1); // offset of read lane+1
+        if (lane <= Tn) {
+            rstart[lane] = cur_o - tstart;
+            if (lane < Tn) {
+                const int len = (int)(o_next - cur_o);
                 uint32_t nw = 0;
                 if (KT) nw = (uint32_t)num_windows(len, KT, pol.drop_last_window);
                 else for (int j = 0; j < ks.n; ++j) nw += (uint32_t)num_windows(len, ks.k[j], pol.drop_last_window);
-                nwin[tid] = nw; nzero[tid] = 0; best[tid] = 0; flags[tid] = 0;
+                nwin[lane] = nw; nzero[lane] = 0; best[lane] = 0; flags[lane] = 0;
             }
         }
-        if (tid < 8) misc[tid] = 0;
-        if (MODE == 0)
-            for (int i = tid; i < Tn * DSET; i += TILE_THREADS) dset[i] = 0;
-        __syncthreads();
-        const uint32_t B = rstart[Tn];
-        if (B > (uint32_t)geo.cap_bytes) { // a read longer than the hint: the host reroutes the tile
-            if (MODE == 0 && tid < Tn) reinterpret_cast<int4*>(out4)[r0 + tid] = make_int4(-2, 0, 0, 0);
-            continue;
+        if (lane == 0) misc[0] = 0;
+        const uint32_t bad_words = (B + 31) / 32 + 1;
+        for (uint32_t i = lane; i < bad_words; i += WAVE) bad[i] = 0;
+        if (MODE != 1)
+            for (uint32_t i = lane; i < (uint32_t)Tn * DS; i += WAVE) dset[i] = 0;
+        const uint32_t ndw = ((tstart & 3u) + B + 3u) >> 2; // global dwords covering the tile
+#pragma unroll
+        for (int q = 0; q < PF; ++q) { // upper-cased forward image + 4 validity bits per dword (8 lanes = one bitmap word)
+            if ((uint32_t)q * WAVE <= ndw) { // wave-uniform
+                const uint32_t jf = (uint32_t)q * WAVE + (uint32_t)lane;
+                const uint32_t x = (jf >= 1 && jf <= ndw) ? upper4(pf[q]) : 0u;
+                if (jf <= ndw) s.fwd[jf] = x;
+                uint32_t n = invalid4(x) << (4 * (lane & 7));
+                n |= (uint32_t)__shfl_xor((int)n, 1);
+                n |= (uint32_t)__shfl_xor((int)n, 2);
+                n |= (uint32_t)__shfl_xor((int)n, 4);
+                if ((lane & 7) == 0 && (jf >> 3) <= (ndw >> 3)) s.inv[jf >> 3] = n;
+            }
         }
-        Staged s = stage_piece(bases, tstart, B, stage, geo.cap_bytes, tid, TILE_THREADS, [] { __syncthreads(); });
+        cur_a = nxt_a; cur_b = nxt_b; cur_o = nxt_o;
+        wave_sync();
+        // ---- phase 0, interval 2: reverse-complement image, read tails, chunk map, validity summary ----
+        {
+            const uint32_t nrc = (B + 3) >> 2;
+            for (uint32_t q = lane; q < nrc; q += WAVE) {
+                const int32_t pp_ = (int32_t)(s.fbase + B) - 4 - 4 * (int32_t)q;
+                const uint32_t idx = (uint32_t)pp_ >> 2, sh = (uint32_t)pp_ & 3;
+                s.rc[q] = __builtin_bswap32(comp4(alignbyte(s.fwd[idx + 1], s.fwd[idx], sh)));
+            }
+        }
+        auto mark_tails = [&](int k) { // the last (len - windows) positions of every read start no window
+            if (lane < Tn) {
+                const uint32_t rs = rstart[lane], re = rstart[lane + 1];
+                uint32_t pos = rs + (uint32_t)num_windows((int)(re - rs), k, pol.drop_last_window);
+                while (pos < re) {
+                    const uint32_t lo = pos & 31, n = (32 - lo) < (re - pos) ? (32 - lo) : (re - pos);
+                    atomicOr(&bad[pos >> 5], (n == 32 ? ~0u : ((1u << n) - 1u)) << lo);
+                    pos += n;
+                }
+            }
+        };
+        mark_tails(KT ? KT : ks.k[0]);
         { // does any real base of the tile fail the ACGT test?
             uint32_t any = 0;
             const uint32_t lo_bit = s.fbase, hi_bit = s.fbase + B;
-            for (uint32_t wd = tid; wd * 32 < hi_bit; wd += TILE_THREADS) {
+            for (uint32_t wd = lane; wd * 32 < hi_bit; wd += WAVE) {
                 uint32_t m = s.inv[wd];
                 const uint32_t b0 = wd * 32;
                 if (b0 < lo_bit) m &= ~0u << (lo_bit - b0);
                 if (b0 + 32 > hi_bit) m &= ~0u >> (b0 + 32 - hi_bit);
                 any |= m;
             }
-            if (any) misc[4] = 1;
+            if (any) misc[0] = 1;
         }
-        for (uint32_t c = tid; c * 32 < B; c += TILE_THREADS) { // chunk map: last read starting at or before byte 32c
+        for (uint32_t c = lane; c * 32 < B; c += WAVE) { // chunk map: last read starting at or before byte 32c
             const uint32_t pos = c * 32;
             int lo = 0, hi = Tn - 1;
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (rstart[mid] <= pos) lo = mid; else hi = mid - 1; }
             tmap[c] = (uint32_t)lo;
         }
-        __syncthreads();
-        const bool has_invalid = misc[4] != 0;
+        wave_sync();
+        if (ntile < ntiles) load_bases(cur_a, cur_b); // the next tile's bases travel while this tile is hashed
+        const bool has_invalid = misc[0] != 0;
         auto read_of = [&](uint32_t p) -> int {
             int t = (int)tmap[p >> 5];
             while (p >= rstart[t + 1]) ++t;
             return t;
         };
-        // one verified candidate: dedup set, postings -> counters, running best.  rec >= 0: queue entry to rewrite
-        auto take_candidate = [&](uint64_t h, uint32_t p, uint32_t hint, int rec) {
+
+        // one candidate window: verify the full key, find the occurrence rank of this sketch hash within the read
+        // (exact LDS multiset: entry = (slot + 1) | (occurrences - 1) << 27), add the postings the multiset merge of
+        // rkmh.cpp:869 would count, keep the running (max_shared, first max_id) of the read
+        auto take_candidate = [&](uint64_t h, uint32_t p, uint32_t hint) {
             uint32_t slot = 0, v = 0;
             bool found = false;
             if (hint != IDX_NOT_FOUND) { // the one slot whose fingerprint matched: key and value in one round trip
@@ -194,18 +287,15 @@ __global__ __launch_bounds__(TILE_THREADS) void k_classify_tile(const uint8_t* _
                 found = key == h;
             }
             if (!found) found = index_lookup(ix, h, slot, v);
-            (void)rec;
             if (!found) return;
             const int t = read_of(p);
-            // occurrence rank of this sketch hash within the read (multiset merge, rkmh.cpp:869): exact LDS multiset,
-            // entry = (slot + 1) | occurrences-1 << 27
             uint32_t rank = 0;
             {
-                uint32_t* ds = dset + t * DSET;
+                uint32_t* ds = dset + (uint32_t)t * DS;
                 const uint32_t key = slot + 1u;
-                uint32_t idx = (slot * 0x9E3779B1u) >> (32 - 7);
-                int probe = 0;
-                for (; probe < DSET; ++probe) {
+                uint32_t idx = ((slot * 0x9E3779B1u) >> 16) & (DS - 1);
+                uint32_t probe = 0;
+                for (; probe < DS; ++probe) {
                     const uint32_t old = atomicCAS(&ds[idx], 0u, key);
                     if (old == 0u) break;
                     if ((old & 0x07FFFFFFu) == key) {
@@ -214,135 +304,119 @@ __global__ __launch_bounds__(TILE_THREADS) void k_classify_tile(const uint8_t* _
                         if (rank >= 30u) flags[t] = 1; // count field about to overflow: general path
                         break;
                     }
-                    idx = (idx + 1) & (DSET - 1);
+                    idx = (idx + 1) & (DS - 1);
                 }
-                if (probe == DSET) { flags[t] = 1; return; } // more distinct hits than the set holds: general path
+                if (probe == DS) { flags[t] = 1; return; } // more distinct hits than the set holds: general path
             }
             uint32_t* ct = c16 + t * geo.cwords;
             for_postings(ix, v, [&](uint32_t ref, uint32_t mult) {
                 if (rank < mult) {
                     const uint32_t sh = (ref & 1u) * 16u;
                     const uint32_t old = atomicAdd(&ct[ref >> 1], 1u << sh);
-                    const uint32_t c = ((old >> sh) & 0xFFFFu) + 1u;
-                    atomicMax(&best[t], (c << 16) | (0xFFFFu - ref));
+                    const uint32_t cnt = ((old >> sh) & 0xFFFFu) + 1u;
+                    atomicMax(&best[t], (cnt << 16) | (0xFFFFu - ref));
                 }
             });
         };
-        const uint32_t bad_words = (B + 31) / 32 + 1;
-        const uint32_t nIt = (B + TILE_THREADS - 1) / TILE_THREADS;
 
         // ---- phase 1: one pass over the tile's byte positions per k-mer size ----------------------
-        uint32_t qcount = 0; // this wave's queue length (wave-uniform)
+        uint32_t qcount = 0; // queue length (wave-uniform)
+        const uint32_t nIt = (B + WAVE - 1) / WAVE;
         for (int kk = 0; kk < (KT ? 1 : ks.n); ++kk) {
             const int k = KT ? KT : ks.k[kk];
-            if (kk) __syncthreads(); // previous k done with `bad`
-            for (uint32_t i = tid; i < bad_words; i += TILE_THREADS) bad[i] = 0;
-            __syncthreads();
-            if (tid < Tn) { // the last (len - windows) positions of every read start no window
-                const uint32_t rs = rstart[tid], re = rstart[tid + 1];
-                uint32_t pos = rs + (uint32_t)num_windows((int)(re - rs), k, pol.drop_last_window);
-                while (pos < re) {
-                    const uint32_t lo = pos & 31, n = (32 - lo) < (re - pos) ? (32 - lo) : (re - pos);
-                    atomicOr(&bad[pos >> 5], (n == 32 ? ~0u : ((1u << n) - 1u)) << lo);
-                    pos += n;
-                }
+            if (kk) { // later k-mer sizes rebuild the start bitmap
+                wave_sync();
+                for (uint32_t i = lane; i < bad_words; i += WAVE) bad[i] = 0;
+                wave_sync();
+                mark_tails(k);
+                wave_sync();
             }
-            __syncthreads();
-            if (MODE == 0 && has_invalid) { // windows holding a non-ACGT base hash to 0: count them, then skip them
-                for (uint32_t p = tid; p < B; p += TILE_THREADS) {
+            if (MODE != 1 && has_invalid) { // windows holding a non-ACGT base hash to 0: count them, then skip them
+                for (uint32_t p = lane; p < B; p += WAVE) {
                     if (!((bad[p >> 5] >> (p & 31)) & 1u) && !window_valid<KT>(s, p, k)) {
                         atomicOr(&bad[p >> 5], 1u << (p & 31));
                         atomicAdd(&nzero[read_of(p)], 1u);
                     }
                 }
-                __syncthreads();
+                wave_sync();
             }
-            uint4 fb = make_uint4(0, 0, 0, 0); // bucket fetched for the previous position (lookup in flight)
+            u32x4 fb = {0u, 0u, 0u, 0u}; // bucket fetched for the previous position (lookup in flight)
             uint64_t hp = 0;
             uint32_t pp = 0;
-            for (uint32_t it = 0; it <= nIt; ++it) {
-                const uint32_t p = it * TILE_THREADS + tid;
-                uint64_t h = 0;
-                if (it < nIt) {
-                    const bool ok = p < B && !((bad[p >> 5] >> (p & 31)) & 1u);
-                    const uint32_t pc = ok ? p : 0u; // keep the LDS addresses in range for idle lanes
-                    if (MODE == 1 && has_invalid && !window_valid<KT>(s, pc, k)) h = 0;
-                    else if (geo.dbg & 4) {
-                        h = ((uint64_t)(s.fwd[(s.fbase + pc) >> 2] * 0x9E3779B1u) << 32) | (s.rc[(B - (uint32_t)k - pc) >> 2] * 0x85EBCA6Bu);
-                    } else {
-                        const uint64_t f = murmur_window<KT, FOLD>(s.fwd, s.fbase + pc, k, pol.seed, pol.fold);
-                        const uint64_t r = murmur_window<KT, FOLD>(s.rc, B - (uint32_t)k - pc, k, pol.seed, pol.fold);
-                        h = f < r ? f : r;
+            uint32_t it = 0;
+            for (;;) {
+                // run positions until the queue may not take another wave of candidates (or the tile is done);
+                // step nIt only examines the last lookup
+                for (; it <= nIt && (MODE == 1 || qcount + WAVE <= QCAP); ++it) {
+                    const uint32_t p = it * WAVE + (uint32_t)lane;
+                    uint64_t h = 0;
+                    if (it < nIt) {
+                        const bool ok = p < B && !((bad[p >> 5] >> (p & 31)) & 1u);
+                        const uint32_t pc = ok ? p : 0u; // keep the LDS addresses in range for idle lanes
+                        if (MODE == 1 && has_invalid && !window_valid<KT>(s, pc, k)) h = 0;
+                        else if (geo.dbg & 4) {
+                            h = ((uint64_t)(s.fwd[(s.fbase + pc) >> 2] * 0x9E3779B1u) << 32) | (s.rc[(B - (uint32_t)k - pc) >> 2] * 0x85EBCA6Bu);
+                        } else {
+                            const uint64_t f = murmur_window<KT, FOLD>(s.fwd, s.fbase + pc, k, pol.seed, pol.fold);
+                            const uint64_t r = murmur_window<KT, FOLD>(s.rc, B - (uint32_t)k - pc, k, pol.seed, pol.fold);
+                            h = f < r ? f : r;
+                        }
+                        if (MODE == 1) {
+                            if (ok && (pol.counter_counts_zero || h != 0)) atomicAdd(&counter[h % slots], 1);
+                            continue;
+                        }
+                        h = ok ? h : 0;
+                        if (MODE == 2 && ok) { // mask_by_frequency, rkmh.cpp:916
+                            const int c = counter[h % slots];
+                            if (pol.mask_strict_less ? (c < min_occ) : (c <= min_occ)) h = 0;
+                        }
+                        if (ok && h == 0) atomicAdd(&nzero[read_of(p)], 1u);
                     }
-                    if (MODE == 1) {
-                        if (ok && (pol.counter_counts_zero || h != 0)) atomicAdd(&counter[h % slots], 1);
-                        continue;
+                    if (MODE == 1) continue;
+                    // examine the lookup issued one step ago: fingerprint matches / full buckets are queued
+                    bucket_wait(fb);
+                    if (!(geo.dbg & 1)) {
+                        const uint32_t fp = index_fp(hp);
+                        const uint32_t mm = (fb.x == fp ? 1u : 0u) | (fb.y == fp ? 2u : 0u) | (fb.z == fp ? 4u : 0u) | (fb.w == fp ? 8u : 0u);
+                        const bool cand = hp != 0 && (mm != 0 || fb.w != 0);
+                        const uint64_t m = __ballot(cand);
+                        if (cand) {
+                            const uint32_t hint = (mm != 0 && (mm & (mm - 1u)) == 0)
+                                                      ? 4u * index_bucket(hp, ix.bshift) + ((uint32_t)__ffs((int)mm) - 1u) : IDX_NOT_FOUND;
+                            const uint32_t q = qcount + (uint32_t)__popcll(m & lt_mask);
+                            qh[q] = hp; qp[q] = pp; qs[q] = hint;
+                        }
+                        qcount += (uint32_t)__popcll(m);
                     }
-                    h = ok ? h : 0;
-                    if (counter && ok) { // mask_by_frequency, rkmh.cpp:916
-                        const int c = counter[h % slots];
-                        if (pol.mask_strict_less ? (c < min_occ) : (c <= min_occ)) h = 0;
-                    }
-                    if (ok && h == 0) atomicAdd(&nzero[read_of(p)], 1u);
+                    if (geo.dbg & 8) { if (h == 0x1234567ull) nzero[0] = 1; } else
+                    if (h != 0) bucket_load_async(ix.fpb + index_bucket(h, ix.bshift), fb); // lands while the next position is hashed
+                    hp = h;
+                    pp = p;
                 }
-                // consume the lookup issued one iteration ago: fingerprint matches / full buckets are queued
-                if (!(geo.dbg & 1)) {
-                    const uint32_t fp = index_fp(hp);
-                    const uint32_t mm = (fb.x == fp ? 1u : 0u) | (fb.y == fp ? 2u : 0u) | (fb.z == fp ? 4u : 0u) | (fb.w == fp ? 8u : 0u);
-                    const bool cand = hp != 0 && (mm != 0 || fb.w != 0);
-                    const uint64_t m = __ballot(cand);
-                    if (cand) {
-                        const uint32_t hint = (mm != 0 && (mm & (mm - 1u)) == 0)
-                                                  ? 4u * index_bucket(hp, ix.bshift) + ((uint32_t)__ffs((int)mm) - 1u) : IDX_NOT_FOUND;
-                        const uint32_t e = qcount + (uint32_t)__popcll(m & lt_mask);
-                        if (e < QW) { const uint32_t q = (uint32_t)wave * QW + e; qh[q] = hp; qp[q] = pp; qs[q] = hint; }
-                        else take_candidate(hp, pp, hint, -1); // queue full: handle in place
-                    }
-                    qcount += (uint32_t)__popcll(m);
-                }
-                if (geo.dbg & 8) { if (h == 0x1234567ull) nzero[0] = 1; } else
-                if (h != 0) fb = ix.fpb[index_bucket(h, ix.bshift)]; // issue; lands while the next position is hashed
-                hp = h;
-                pp = p;
+                if (MODE == 1) break;
+                // drain: every lane takes queued candidates
+                wave_sync();
+                if (!(geo.dbg & 32))
+                    for (uint32_t e = lane; e < qcount; e += WAVE) take_candidate(qh[e], qp[e], qs[e]);
+                qcount = 0;
+                wave_sync();
+                if (it > nIt) break;
             }
         }
         if (MODE == 1) continue;
-        if (lane == 0) misc[wave] = qcount < QW ? qcount : QW;
-        __syncthreads();
-        // ---- phase 1b: drain the candidate queue, every lane busy ----------------------------------
-        const uint32_t qc0 = misc[0], qc1 = misc[1], qc2 = misc[2], qc3 = misc[3];
-        const uint32_t qn = qc0 + qc1 + qc2 + qc3;
-        auto qindex = [&](uint32_t e) -> uint32_t { // e-th queued candidate -> position in the segmented queue
-            if (e < qc0) return e;
-            e -= qc0;
-            if (e < qc1) return QW + e;
-            e -= qc1;
-            if (e < qc2) return 2 * QW + e;
-            return 3 * QW + (e - qc2);
-        };
-        for (uint32_t e = tid; e < qn && !(geo.dbg & 32); e += TILE_THREADS) {
-            const uint32_t q = qindex(e);
-            take_candidate(qh[q], qp[q], qs[q], (int)q);
-        }
-        __syncthreads();
 
         // ---- phase 2: 16 lanes per read -----------------------------------------------------------
         {
-            const int g = tid >> 4, sl = tid & 15;
-            for (int t = g; t < Tn; t += GROUPS) {
+            const int g = lane >> 4, sl = lane & 15;
+            for (int t = g; t < Tn; t += WAVE / 16) {
                 uint32_t* ct = c16 + t * geo.cwords;
                 const int nmins = (int)nwin[t] - (int)nzero[t];
-                bool reroute = nmins > S; // bottom-S selection matters: general path
-                uint32_t bk = best[t];
-                if ((geo.dbg & 2) && !reroute) {
+                // bottom-S selection matters, or the hit multiset overflowed: exact answer comes from the general path
+                const bool reroute = nmins > S || flags[t] != 0;
+                const uint32_t bk = best[t];
+                if (reroute || (geo.dbg & 2)) {
                     for (int w = sl; w < geo.cwords; w += 16) ct[w] = 0;
-                    if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(0, (int)(bk >> 16), 0, nmins);
-                    continue;
-                }
-                if (flags[t]) reroute = true; // hit multiset overflowed: exact answer comes from the general path
-                if (reroute) {
-                    for (int w = sl; w < geo.cwords; w += 16) ct[w] = 0;
-                    if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(-2, 0, 0, 0);
+                    if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = reroute ? make_int4(-2, 0, 0, 0) : make_int4(0, (int)(bk >> 16), 0, nmins);
                     continue;
                 }
                 // first max wins (rkmh.cpp:878); diff = max - best EARLIER score (untouched refs score 0; none => -1)
@@ -356,7 +430,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_classify_tile(const uint8_t* _
                     if (2 * w + 1 < max_id && c1 > prev) prev = c1;
                 }
                 prev = row_max_i32(prev);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                wave_sync();
                 for (int w = sl; w < geo.cwords; w += 16) ct[w] = 0;
                 if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(max_id, max_shared, max_shared - prev, nmins);
             }
@@ -364,42 +438,45 @@ __global__ __launch_bounds__(TILE_THREADS) void k_classify_tile(const uint8_t* _
     }
 }
 
-static TileGeom make_geom(int maxlen, int nref) {
+static TileGeom make_geom(int maxlen, int nref, int expect_hits) {
     TileGeom g;
     if (maxlen < 1) maxlen = 1;
-    int T = 4800 / maxlen;
+    int T = 640 / maxlen; // ~600 bytes per wave: 8+ hashing steps per tile
     if (const char* e = getenv("RKMH_TILE_T")) T = atoi(e);
-    if (T > 32) T = 32;
-    if (T < 4) T = 4;
+    if (T > 16) T = 16;
+    if (T < 1) T = 1;
+    while (T > 1 && T * maxlen > PF * WAVE * 4 - 8) --T;
     g.T = T;
     g.cap_bytes = T * maxlen;
-    g.qcap = ((g.cap_bytes / 4) + 255) & ~255; // about a quarter of the windows may be candidates before in-place handling
+    g.qcap = 128;
     if (const char* e = getenv("RKMH_TILE_QCAP")) g.qcap = atoi(e);
     g.cwords = (nref + 1) / 2;
+    int ds = 64;
+    while (ds < 3 * expect_hits && ds < 1024) ds <<= 1;
+    if (const char* e = getenv("RKMH_TILE_DSET")) ds = atoi(e);
+    g.dset = ds;
     g.dbg = 0;
     if (const char* e = getenv("RKMH_DBG")) g.dbg = atoi(e);
     return g;
 }
 
-// T x nref 16-bit counters must fit beside the tile in LDS; reference ids must fit 16 bits
-bool classify_tile_supported(int nref) { return nref <= 2048; }
+// T x nref 16-bit counters must fit beside the tile in LDS; reference ids must fit 16 bits;
+// one tile (>= 1 read of maxlen bytes) must fit the prefetch registers
+bool classify_tile_supported(int nref, int maxlen) { return nref <= 2048 && maxlen <= PF * WAVE * 4 - 8; }
 
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
-                                int32_t* out4, const DevPolicy& pol, int maxlen, hipStream_t st) {
+                                int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st) {
     if (nreads == 0) return hipSuccess;
-    TileGeom geo = make_geom(maxlen, mode == 0 ? ix.nref : 0);
-    if (mode != 0) geo.qcap = 0;
-    while (tile_lds_bytes(geo) > 64 * 1024 && geo.T > 4) { // keep at least two workgroups per CU
-        geo.T /= 2;
-        geo.cap_bytes = geo.T * maxlen;
-        if (mode == 0) geo.qcap = ((geo.cap_bytes / 4) + 255) & ~255;
-    }
+    TileGeom geo = make_geom(maxlen, mode == 1 ? 0 : ix.nref, mode == 1 ? 0 : expect_hits);
+    if (mode == 1) { geo.qcap = 0; geo.dset = 0; }
+    while (tile_lds_bytes(geo) > 20 * 1024 && geo.T > 1) { geo.T -= 1; geo.cap_bytes = geo.T * maxlen; } // >= 8 waves per CU
     const size_t lds = tile_lds_bytes(geo);
     const uint32_t ntiles = (nreads + (uint32_t)geo.T - 1) / (uint32_t)geo.T;
-    uint32_t grid = ntiles;
-    if (const char* g = getenv("RKMH_TILE_GRID")) { uint32_t v = (uint32_t)atoi(g); if (v && v < grid) grid = v; }
+    uint32_t grid = ntiles < 8192u ? ntiles : 8192u; // 32 persistent waves per CU, each prefetching its next tile
+    if (const char* g = getenv("RKMH_TILE_GRID")) { uint32_t v = (uint32_t)atoi(g); if (v && v < ntiles) grid = v; }
     const bool k16 = (ks.n == 1 && ks.k[0] == 16);
+    const int kmode = mode == 1 ? 1 : (counter ? 2 : 0);
 #define RK_LAUNCH(KT, MODE, FOLD)                                                                                    \
     do {                                                                                                             \
         if (lds > 64 * 1024) {                                                                                       \
@@ -407,18 +484,20 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
             if (e != hipSuccess) return e;                                                                           \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_classify_tile<KT, MODE, FOLD>), dim3(grid), dim3(TILE_THREADS), lds, st, bases, offs,   \
-                           nreads, ks, S, ix, counter, slots, min_occ, out4, pol, geo);                              \
+        hipLaunchKernelGGL((k_classify_tile<KT, MODE, FOLD>), dim3(grid), dim3(WAVE), lds, st, bases, offs, nreads,   \
+                           ks, S, ix, counter, slots, min_occ, out4, pol, geo);                                      \
     } while (0)
-#define RK_LAUNCH_F(KT, MODE)                                                                                        \
+#define RK_LAUNCH_M(KT, FOLD)                                                                                        \
     do {                                                                                                             \
-        if (pol.fold == 0) RK_LAUNCH(KT, MODE, 0);                                                                   \
-        else if (pol.fold == 1) RK_LAUNCH(KT, MODE, 1);                                                              \
-        else RK_LAUNCH(KT, MODE, 2);                                                                                 \
+        if (kmode == 0) RK_LAUNCH(KT, 0, FOLD);                                                                      \
+        else if (kmode == 1) RK_LAUNCH(KT, 1, FOLD);                                                                 \
+        else RK_LAUNCH(KT, 2, FOLD);                                                                                 \
     } while (0)
-    if (mode == 0) { if (k16) RK_LAUNCH_F(16, 0); else RK_LAUNCH_F(0, 0); }
-    else           { if (k16) RK_LAUNCH_F(16, 1); else RK_LAUNCH_F(0, 1); }
-#undef RK_LAUNCH_F
+    if (!k16) RK_LAUNCH_M(0, -1);             // any k / several k: runtime fold
+    else if (pol.fold == 0) RK_LAUNCH_M(16, 0);
+    else if (pol.fold == 1) RK_LAUNCH_M(16, 1);
+    else RK_LAUNCH_M(16, 2);
+#undef RK_LAUNCH_M
 #undef RK_LAUNCH
     return hipGetLastError();
 }

@@ -52,11 +52,11 @@ hipError_t launch_intersect_pair(const uint64_t* a, int na, const uint64_t* b, i
 hipError_t launch_classify_fused(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                  const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
                                  int32_t* out4, const DevPolicy& pol, int maxlen, hipStream_t st);
-// tile-per-workgroup fused kernel (rk_classify.hip); same contract as launch_classify_fused
-bool classify_tile_supported(int nref);
+// wave-per-tile fused kernel (rk_classify.hip); expect_hits sizes the per-read hit multiset
+bool classify_tile_supported(int nref, int maxlen);
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
-                                int32_t* out4, const DevPolicy& pol, int maxlen, hipStream_t st);
+                                int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st);
 hipError_t launch_max_len(const uint32_t* offs, uint32_t nreads, uint32_t* d_max, hipStream_t st);
 hipError_t launch_mask_by_frequency(uint64_t* h, uint64_t n, const int32_t* counter, uint64_t slots, int min_occ,
                                     const DevPolicy& pol, hipStream_t st);
