@@ -650,13 +650,6 @@ extern "C" int rk_set_depth_filter(rk_ctx* c, rk_counter* counter, int min_kmer_
 }
 
 // ---- the hot loop -------------------------------------------------------------------------------
-static int pick_maxlen(uint32_t max_read_len) {
-    int m = (int)((max_read_len + 63u) & ~63u);
-    if (m < 64) m = 64;
-    if (m > FUSED_MAXLEN) m = FUSED_MAXLEN;
-    return m;
-}
-
 static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nreads, void* d_out4,
                         uint32_t max_read_len, int mode, rk_counter* count_into, hipStream_t st) {
     if (nreads > 0xfffffff0ll) return fail(RK_ERR_LIMIT, "more than 2^32-16 reads in one device batch");
@@ -664,16 +657,16 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     int32_t* counter = nullptr; uint64_t slots = 1; int min_occ = 0;
     if (mode == 1) { counter = count_into->d; slots = count_into->slots; }
     else if (c->depth) { counter = c->depth->d; slots = c->depth->slots; min_occ = c->min_occ; }
-    static const bool force_v1 = getenv("RKMH_FUSED_V1") != nullptr;
     uint32_t ml = max_read_len < 1 ? 1 : (max_read_len > (uint32_t)FUSED_MAXLEN ? (uint32_t)FUSED_MAXLEN : max_read_len);
     int expect = 0; // hits an error-free read is expected to score: sizes the kernel's per-read hit multiset
     for (int j = 0; j < c->ks.n; ++j) expect += (int)(c->density * (double)num_windows((int)ml, c->ks.k[j], c->pol.drop_last_window)) + 1;
-    if (!force_v1 && classify_tile_supported(mode == 0 ? c->ix.nref : 0, (int)ml))
+    if (classify_tile_supported(mode == 0 ? c->ix.nref : 0, (int)ml))
         HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
                                     counter, slots, min_occ, mode, (int32_t*)d_out4, c->pol, (int)ml, expect, st));
+    else if (mode == 0)
+        HIPCHK(launch_fill_reroute((int32_t*)d_out4, (uint32_t)nreads, st)); // e.g. more than 2048 references: general path
     else
-        HIPCHK(launch_classify_fused((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
-                                     counter, slots, min_occ, mode, (int32_t*)d_out4, c->pol, pick_maxlen(max_read_len), st));
+        return fail(RK_ERR_LIMIT, "count pass: batch not supported by the fused kernel");
     return RK_OK;
 }
 

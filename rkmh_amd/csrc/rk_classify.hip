@@ -114,7 +114,7 @@ __device__ __forceinline__ void bucket_wait(u32x4& f) { asm volatile("s_waitcnt 
 
 // MODE 0: classify; MODE 1: count pass of -M (rkmh.cpp:904-910); MODE 2: classify with the -M mask (rkmh.cpp:916)
 template <int KT, int MODE, int FOLD>
-__global__ __launch_bounds__(WAVE, 8) void k_classify_tile(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
+__global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
                                                            uint32_t nreads, KsArr ks, int S, RefIndex ix, int32_t* counter,
                                                            uint64_t slots, int min_occ, int32_t* out4, DevPolicy pol, TileGeom geo) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];

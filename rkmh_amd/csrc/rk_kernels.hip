@@ -4,9 +4,7 @@
 //   k_hash_tiles       mkmh::calc_hashes over arbitrary-length sequences       src/rkmh.cpp:821,831,909,2101
 //   k_sort_intersect   mkmh::minhashes (+ mask_by_frequency / minhashes_frequency_filter) and, for
 //                      long reads, the intersection loop + argmax               src/rkmh.cpp:822,835,863,916-934
-//   k_classify_fused   the whole per-read loop body for reads whose windows all fit the sketch
-//                      (to_upper, calc_hashes, minhashes, R x hash_intersection_size, argmax/diff)
-//                                                                               src/rkmh.cpp:856-888
+//   (the fused per-read kernel k_classify_tile lives in rk_classify.hip)
 //   k_intersect_pair   mkmh::hash_intersection_size for one pair                src/rkmh.cpp:869
 //
 // Integer hashing work: no MFMA.  The design points are coalesced dword loads of the bases, LDS-staged
@@ -223,103 +221,14 @@ hipError_t launch_intersect_pair(const uint64_t* a, int na, const uint64_t* b, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// The fused per-read kernel (v1): one wave per read, persistent over reads.
-//   stage read (upper-case, reverse complement, validity bits) -> hash every window -> optional -M mask
-//   -> look every non-zero hash up in the resident reference index -> per-reference LDS counters
-//   (multiset semantics via the occurrence rank of repeated hits) -> argmax/diff -> one int4 per read.
-// Eligible reads: len <= maxlen and (number of non-zero hashes) <= S, i.e. the sketch is ALL hashes and
-// the sort of minhashes() cannot change the intersection sizes.  Others get max_id = -2 (host reroutes).
-template <int KT, int MODE>
-__global__ __launch_bounds__(64) void k_classify_fused(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
-                                                       uint32_t nreads, KsArr ks, int S, RefIndex ix, int32_t* counter,
-                                                       uint64_t slots, int min_occ, int32_t* out4, DevPolicy pol, int maxlen) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* stage = smem;
-    uint32_t* hits = smem + stage_lds_dwords(maxlen);     // [maxlen * ks.n] slots of the hashes that hit
-    int* sh = reinterpret_cast<int*>(hits + maxlen * ks.n);
-    const int lane = threadIdx.x;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
-        const uint32_t start = offs[r];
-        const uint32_t len = offs[r + 1] - start;
-        if (len > (uint32_t)maxlen) {
-            if (MODE == 0 && lane == 0) reinterpret_cast<int4*>(out4)[r] = make_int4(-2, 0, 0, 0);
-            continue;
-        }
-        __syncthreads();
-        Staged s = stage_piece(bases, start, len, stage, maxlen, lane, 64, [] { __syncthreads(); });
-        if (MODE == 0)
-            for (int j = lane; j < ix.nref; j += 64) sh[j] = 0;
-        uint32_t H = 0;
-        int nnz = 0;
-        for (int kk = 0; kk < ks.n; ++kk) {
-            const int k = KT ? KT : ks.k[kk];
-            const uint32_t nw = (uint32_t)num_windows((int)len, k, pol.drop_last_window);
-            for (uint32_t i0 = 0; i0 < nw; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                uint64_t h = 0;
-                if (i < nw) h = canonical_window<KT>(s, i, k, pol);
-                if (MODE == 1) {
-                    if (i < nw && (pol.counter_counts_zero || h != 0)) atomicAdd(&counter[h % slots], 1);
-                    continue;
-                }
-                if (counter && i < nw) {                          // mask_by_frequency, rkmh.cpp:916
-                    int c = counter[h % slots];
-                    if (pol.mask_strict_less ? (c < min_occ) : (c <= min_occ)) h = 0;
-                }
-                nnz += __popcll(__ballot(h != 0));
-                uint32_t slot = IDX_NOT_FOUND;
-                if (h != 0) slot = index_find(ix, h);
-                const bool hit = slot != IDX_NOT_FOUND;
-                const uint64_t bm = __ballot(hit);
-                if (hit) hits[H + __popcll(bm & lt_mask)] = slot;
-                H += (uint32_t)__popcll(bm);
-            }
-        }
-        if (MODE == 1) continue;
-        if (nnz > S) {
-            if (lane == 0) reinterpret_cast<int4*>(out4)[r] = make_int4(-2, 0, 0, 0);
-            continue;
-        }
-        __syncthreads();
-        for (uint32_t t0 = 0; t0 < H; t0 += 64) {
-            const uint32_t t = t0 + lane;
-            if (t < H) {
-                const uint32_t slot = hits[t];
-                uint32_t rank = 0;
-                for (uint32_t u = 0; u < t; ++u) rank += (hits[u] == slot) ? 1u : 0u;
-                accumulate_posting(ix, slot, rank, sh);
-            }
-        }
-        __syncthreads();
-        int mi, ms, df;
-        wave_argmax_diff(sh, ix.nref, lane, mi, ms, df);
-        if (lane == 0) reinterpret_cast<int4*>(out4)[r] = make_int4(mi, ms, df, nnz);
-    }
+// marks every read "reroute through the general path" (used when the fused kernel cannot take the batch)
+__global__ __launch_bounds__(256) void k_fill_reroute(int32_t* out4, uint32_t nreads) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nreads) reinterpret_cast<int4*>(out4)[i] = make_int4(-2, 0, 0, 0);
 }
-
-hipError_t launch_classify_fused(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
-                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
-                                 int32_t* out4, const DevPolicy& pol, int maxlen, hipStream_t st) {
+hipError_t launch_fill_reroute(int32_t* out4, uint32_t nreads, hipStream_t st) {
     if (nreads == 0) return hipSuccess;
-    size_t lds = ((size_t)stage_lds_dwords(maxlen) + (size_t)maxlen * ks.n + (size_t)(ix.nref > 0 ? ix.nref : 0)) * 4 + 16;
-    uint32_t grid = 256 * 32;   // one wave per block: 32 waves per CU = 8 per SIMD
-    if (const char* g = getenv("RKMH_FUSED_GRID")) grid = (uint32_t)atoi(g);
-    if (grid > nreads) grid = nreads;
-    const bool k16 = (ks.n == 1 && ks.k[0] == 16);
-#define RK_LAUNCH(KT, MODE)                                                                                         \
-    do {                                                                                                            \
-        if (lds > 64 * 1024) {                                                                                      \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_classify_fused<KT, MODE>),           \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-            if (e != hipSuccess) return e;                                                                          \
-        }                                                                                                           \
-        hipLaunchKernelGGL((k_classify_fused<KT, MODE>), dim3(grid), dim3(64), lds, st, bases, offs, nreads, ks, S,  \
-                           ix, counter, slots, min_occ, out4, pol, maxlen);                                         \
-    } while (0)
-    if (mode == 0) { if (k16) RK_LAUNCH(16, 0); else RK_LAUNCH(0, 0); }
-    else           { if (k16) RK_LAUNCH(16, 1); else RK_LAUNCH(0, 1); }
-#undef RK_LAUNCH
+    hipLaunchKernelGGL(k_fill_reroute, dim3((nreads + 255) / 256), dim3(256), 0, st, out4, nreads);
     return hipGetLastError();
 }
 

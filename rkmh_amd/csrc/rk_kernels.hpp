@@ -10,7 +10,7 @@ constexpr int MAX_KS = 8;
 constexpr int MAX_K = 64;
 constexpr int HASH_TILE_WIN = 2048;             // windows per hash tile
 constexpr int HASH_TILE_MAXB = HASH_TILE_WIN + MAX_K;
-constexpr int FUSED_MAXLEN = 1024;              // longest read taken by the fused classify kernel
+constexpr int FUSED_MAXLEN = 1528;              // longest read taken by the fused classify kernel (prefetch registers)
 constexpr int SORT_MAX_P = 16384;               // largest in-LDS sort (128 KiB of u64)
 
 struct KsArr { int32_t n; int32_t k[MAX_KS]; };
@@ -48,10 +48,8 @@ hipError_t launch_hash_tiles(const uint8_t* bases, const TileDesc* tiles, uint32
                              int32_t* counter, uint64_t slots, const DevPolicy& pol, hipStream_t st);
 hipError_t launch_sort_intersect(const SortArgs& a, const RefIndex* ix, const DevPolicy& pol, hipStream_t st);
 hipError_t launch_intersect_pair(const uint64_t* a, int na, const uint64_t* b, int nb, int* out, hipStream_t st);
+hipError_t launch_fill_reroute(int32_t* out4, uint32_t nreads, hipStream_t st);
 // mode 0: classify (out4 written); mode 1: count only (counter incremented)
-hipError_t launch_classify_fused(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
-                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
-                                 int32_t* out4, const DevPolicy& pol, int maxlen, hipStream_t st);
 // wave-per-tile fused kernel (rk_classify.hip); expect_hits sizes the per-read hit multiset
 bool classify_tile_supported(int nref, int maxlen);
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,

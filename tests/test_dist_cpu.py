@@ -1,0 +1,82 @@
+"""CPU-only, world_size 2 over gloo: the multi-GPU plumbing of the classify path (rkmh_amd/dist.py) --
+shard bounds, the reference-sketch broadcast, the -M counter all-reduce and the ordered gather of result rows."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from rkmh_amd import dist as rdist
+    r, lr, w = rdist.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    # 1. contiguous read shards cover [0, N) exactly once
+    N = 1000003
+    lo, hi = rdist.shard_bounds(N, rank, world)
+    # 2. sketches built on rank 0 reach everyone bit-exact (uint64 incl. values >= 2^63)
+    R, S = 7, 50
+    rng = np.random.default_rng(5)
+    sk0 = rng.integers(0, np.iinfo(np.uint64).max, size=(R, S), dtype=np.uint64)
+    ln0 = rng.integers(0, S + 1, size=R).astype(np.int32)
+    sk, ln = rdist.broadcast_sketches(sk0 if rank == 0 else None, ln0 if rank == 0 else None, R, S, src=0)
+    ok_b = bool((sk == sk0).all() and (ln == ln0).all() and sk.dtype == np.uint64)
+    # 3. -M: per-rank counter tables sum to the global table
+    t = torch.full((1000,), rank + 1, dtype=torch.int32)
+    rdist.allreduce_counter(t)
+    ok_c = bool((t == sum(range(1, world + 1))).all())
+    # 4. result rows come back in global read order
+    rows = np.full((hi - lo, 4), rank, dtype=np.int32)
+    rows[:, 1] = np.arange(lo, hi)
+    allrows = rdist.gather_rows(rows, dst=0)
+    ok_g = True
+    if rank == 0:
+        ok_g = allrows.shape == (N, 4) and bool((allrows[:, 1] == np.arange(N)).all())
+    else:
+        ok_g = allrows is None
+    q.put((rank, lo, hi, ok_b, ok_c, ok_g))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_plumbing_over_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == 1000003
+    for r in res:
+        assert r[3] and r[4] and r[5], r
+
+
+def test_shard_bounds_cover_everything():
+    sys.path.insert(0, ROOT)
+    from rkmh_amd import dist as rdist
+    for n in (0, 1, 7, 100, 1000003):
+        for w in (1, 2, 3, 8):
+            b = [rdist.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1

@@ -309,3 +309,59 @@ def test_cli_stream_and_hash_output(ctx, orc, root, data_dir, golden_dir, tmp_pa
     assert r.returncode == 1 and r.stdout == b"" and b"Usage" in r.stderr
     r = subprocess.run([exe, "stream"], capture_output=True)
     assert r.returncode == 1
+
+
+def test_python_cli_single_rank(orc, root, data_dir, golden_dir):
+    """python -m rkmh_amd.cli (the torch.distributed form) at world size 1: same lines as the golden, incl. -M."""
+    import sys
+    g = golden(golden_dir, "zika_z1")
+    r = subprocess.run([sys.executable, "-m", "rkmh_amd.cli", "stream", "-r", os.path.join(data_dir, "zika.refs.fa.gz"), "-f",
+                        os.path.join(data_dir, "z1.fq.gz"), "-k", "16"], capture_output=True, cwd=root)
+    assert r.returncode == 0, r.stderr
+    want = "".join(orc.stream_line(x[1], x[0], x[2], x[3], x[4], 1000) for x in g["rows"])
+    assert r.stdout.decode() == want
+    r = subprocess.run([sys.executable, "-m", "rkmh_amd.cli", "stream", "-r", os.path.join(data_dir, "zika.refs.fa.gz"), "-f",
+                        os.path.join(data_dir, "z1.fq.gz"), "-k", "16", "-M", "2"], capture_output=True, cwd=root)
+    assert r.returncode == 0, r.stderr
+    refs = orc.kseq_parse_file(os.path.join(data_dir, "zika.refs.fa.gz"))
+    reads = orc.kseq_parse_file(os.path.join(data_dir, "z1.fq.gz"))
+    rb, ro = orc.pack([x[1] for x in refs])
+    qb, qo = orc.pack([x[1] for x in reads])
+    sk, ln = orc.sketch_refs(rb, ro, [16], 1000, threads=4)
+    o4 = orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=4, min_kmer_occ=2)
+    want = "".join(orc.stream_line(refs[o4[i, 0]][0].decode(), reads[i][0].decode(), o4[i, 1], o4[i, 2], o4[i, 3], 1000)
+                   for i in range(len(reads)))
+    assert r.stdout.decode() == want
+
+
+def test_many_references_reroute(ctx, orc):
+    """More references than the fused kernel's LDS counters hold: every read takes the general path."""
+    rng = np.random.default_rng(77)
+    refs = [rand_dna(rng, 220) for _ in range(2100)]
+    reads = [refs[int(i)][20:170] for i in rng.integers(0, 2100, size=60)] + [rand_dna(rng, 150)]
+    rb, ro = orc.pack(refs)
+    qb, qo = orc.pack(reads)
+    got, want = _classify_both(ctx, orc, _pad(rb), ro, _pad(qb), qo, [16], 1000)
+    assert (got == want).all()
+    assert (got[:60, 1] > 100).all()
+
+
+def test_depth_filter_with_long_reads(ctx, orc, pave):
+    """-M path where some reads exceed the fused kernel's length limit (count + classify through the tile hasher)."""
+    import rkmh_amd
+    _, rb, ro = pave
+    reads = [bytes(rb[int(ro[i]) + 100: int(ro[i]) + 100 + L]) for i, L in ((0, 150), (1, 3000), (2, 150), (0, 2000), (5, 150))] * 3
+    qb, qo = orc.pack(reads)
+    qb = _pad(qb)
+    ctx.set_references(rb, ro, [16], 1000)
+    sk, ln = ctx.get_reference_sketches()
+    cnt = rkmh_amd.Counter(ctx, slots=1000003)
+    ctx.count_batch(qb, qo, cnt)
+    ctx.set_depth_filter(cnt, 3)
+    try:
+        got = ctx.classify(qb, qo)
+    finally:
+        ctx.set_depth_filter(None, 0)
+    want = orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=4, min_kmer_occ=3, counter_slots=1000003)
+    assert (got == want).all()
+    cnt.destroy()
