@@ -555,7 +555,9 @@ static int build_index(rk_ctx* c) {
             j = k;
         }
         uint32_t v;
-        if (grp.size() == 1 && grp[0].second <= 0x7FFu) v = grp[0].first | (grp[0].second << 20);
+        if (grp.size() == 1 && grp[0].second <= 0x1FFu) v = grp[0].first | (grp[0].second << 20);
+        else if (grp.size() == 2 && grp[0].second == 1 && grp[1].second == 1 && grp[0].first < 2048 && grp[1].first < 2048)
+            v = (1u << 29) | grp[0].first | (grp[1].first << 11);
         else {
             if (post.size() + 1 + 2 * grp.size() >= 0x7fffffffull) return fail(RK_ERR_LIMIT, "postings overflow");
             v = 0x80000000u | (uint32_t)post.size();

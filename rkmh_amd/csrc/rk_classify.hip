@@ -68,14 +68,17 @@ struct TileGeom {
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
 __host__ __device__ inline size_t tile_lds_bytes(const TileGeom& g) {
     return ((size_t)((stage_lds_dwords(g.cap_bytes) + 1) & ~1) + 4 * (size_t)g.qcap + 5 * (size_t)(g.T + 1) + 8 +
-            2 * (size_t)tile_map_words(g.cap_bytes) + (size_t)g.T * (size_t)(g.cwords + g.dset)) * 4;
+            2 * (size_t)tile_map_words(g.cap_bytes) + 2 * 64 +
+            (size_t)g.T * (size_t)(g.cwords + g.dset)) * 4;
 }
 
 // for every posting (ref, mult) of an index value
 template <typename F>
 __device__ __forceinline__ void for_postings(const RefIndex& ix, uint32_t v, F f) {
-    if (!(v >> 31)) f(v & 0xFFFFFu, (v >> 20) & 0x7FFu);
-    else {
+    if (!(v >> 31)) {
+        if (((v >> 29) & 3u) == 0u) f(v & 0xFFFFFu, (v >> 20) & 0x1FFu);
+        else { f(v & 0x7FFu, 1u); f((v >> 11) & 0x7FFu, 1u); }
+    } else {
         const uint32_t off = v & 0x7fffffffu;
         const uint32_t cnt = ix.post[off];
         for (uint32_t c = 0; c < cnt; ++c) f(ix.post[off + 1 + 2 * c], ix.post[off + 2 + 2 * c]);
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
     uint32_t* tmap = bad + tile_map_words(geo.cap_bytes);        // read index holding tile byte 32*c
     uint32_t* c16 = tmap + tile_map_words(geo.cap_bytes);        // [T][cwords] packed 16-bit per-reference counters
     uint32_t* dset = c16 + T * geo.cwords;                       // [T][DS] multiset of the slots the read has hit
+    uint32_t* mq = dset + T * DS;                                // [64][2] hits with several postings (drain)
     const int lane = threadIdx.x;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
 
     // Software prefetch across tiles: while tile i is hashed, the offsets and the raw base dwords of this wave's
     // next tile travel into registers, so phase 0 of the next tile touches no global memory.
-    uint32_t pf[PF];
+    uint32_t pf[PF] = {0u, 0u, 0u, 0u, 0u, 0u};
     uint32_t cur_a = 0, cur_b = 0, cur_o = 0; // tile byte range [a,b) in the batch, this lane's read offset
     auto tile_reads = [&](uint32_t tl) -> int {
         const uint32_t r = tl * (uint32_t)T;
@@ -159,15 +163,24 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
         b_ = offs[r + (uint32_t)n];
         o_ = offs[r + (uint32_t)(lane <= n ? lane : n)];
     };
+    // The base prefetch is issued through inline asm (loads hipcc does not count): otherwise the compiler, seeing
+    // loads pending at the hashing loop's header, drains vmcnt inside every iteration and with it the pipelined
+    // bucket lookup.  Addresses are clamped into the tile (out-of-range lanes are zeroed when the image is built).
     auto load_bases = [&](uint32_t a_, uint32_t b_) {
         const uint32_t* g32 = reinterpret_cast<const uint32_t*>(bases) + (a_ >> 2);
         uint32_t ndw = ((a_ & 3u) + (b_ - a_) + 3u) >> 2;
         if (b_ - a_ > (uint32_t)geo.cap_bytes) ndw = 0; // oversized tile: rerouted, nothing to stage
 #pragma unroll
         for (int q = 0; q < PF; ++q) { // register q of a lane = fwd-image dword jf = 64q + lane = global dword jf - 1
-            const uint32_t jf = (uint32_t)q * WAVE + (uint32_t)lane;
-            pf[q] = (jf >= 1 && jf <= ndw) ? g32[jf - 1] : 0u;
+            if ((uint32_t)q * WAVE <= ndw) { // wave-uniform
+                const uint32_t jf = (uint32_t)q * WAVE + (uint32_t)lane;
+                const uint32_t j = jf >= 1 ? (jf <= ndw ? jf - 1 : (ndw ? ndw - 1 : 0u)) : 0u;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(pf[q]) : "v"(g32 + j) : "memory");
+            }
         }
+    };
+    auto wait_bases = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]) : : "memory");
     };
     if (blockIdx.x < ntiles) { load_offsets(blockIdx.x, cur_a, cur_b, cur_o); load_bases(cur_a, cur_b); }
 
@@ -206,11 +219,14 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
             }
         }
         if (lane == 0) misc[0] = 0;
+        const uint32_t ulen = (uint32_t)__shfl((int)(o_next - cur_o), 0);                 // length of read 0
+        const bool uniform = __ballot(lane < Tn && (o_next - cur_o) != ulen) == 0ull;     // every read of the tile as long
         const uint32_t bad_words = (B + 31) / 32 + 1;
         for (uint32_t i = lane; i < bad_words; i += WAVE) bad[i] = 0;
         if (MODE != 1)
             for (uint32_t i = lane; i < (uint32_t)Tn * DS; i += WAVE) dset[i] = 0;
         const uint32_t ndw = ((tstart & 3u) + B + 3u) >> 2; // global dwords covering the tile
+        wait_bases();
 #pragma unroll
         for (int q = 0; q < PF; ++q) { // upper-cased forward image + 4 validity bits per dword (8 lanes = one bitmap word)
             if ((uint32_t)q * WAVE <= ndw) { // wave-uniform
@@ -274,10 +290,18 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
             return t;
         };
 
+        // +1 for reference `ref` of read t; the monotone counters make (max_shared, first max_id) a running atomicMax
+        auto add_posting = [&](int t, uint32_t ref) {
+            const uint32_t sh = (ref & 1u) * 16u;
+            const uint32_t old = atomicAdd(&c16[t * geo.cwords + (int)(ref >> 1)], 1u << sh);
+            const uint32_t cnt = ((old >> sh) & 0xFFFFu) + 1u;
+            atomicMax(&best[t], (cnt << 16) | (0xFFFFu - ref));
+        };
         // one candidate window: verify the full key, find the occurrence rank of this sketch hash within the read
-        // (exact LDS multiset: entry = (slot + 1) | (occurrences - 1) << 27), add the postings the multiset merge of
-        // rkmh.cpp:869 would count, keep the running (max_shared, first max_id) of the read
-        auto take_candidate = [&](uint64_t h, uint32_t p, uint32_t hint) {
+        // (exact LDS multiset: entry = (slot + 1) | (occurrences - 1) << 27) and add the postings the multiset merge of
+        // rkmh.cpp:869 would count.  A hit with several postings is returned (read << 8 | rank, postings offset) for
+        // the 16-lanes-per-hit pass instead of looping here with 63 lanes idle.
+        auto take_candidate = [&](uint64_t h, uint32_t p, uint32_t hint, uint32_t& m_tr, uint32_t& m_off) -> bool {
             uint32_t slot = 0, v = 0;
             bool found = false;
             if (hint != IDX_NOT_FOUND) { // the one slot whose fingerprint matched: key and value in one round trip
@@ -287,7 +311,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                 found = key == h;
             }
             if (!found) found = index_lookup(ix, h, slot, v);
-            if (!found) return;
+            if (!found) return false;
             const int t = read_of(p);
             uint32_t rank = 0;
             {
@@ -306,22 +330,48 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                     }
                     idx = (idx + 1) & (DS - 1);
                 }
-                if (probe == DS) { flags[t] = 1; return; } // more distinct hits than the set holds: general path
+                if (probe == DS) { flags[t] = 1; return false; } // more distinct hits than the set holds: general path
             }
-            uint32_t* ct = c16 + t * geo.cwords;
-            for_postings(ix, v, [&](uint32_t ref, uint32_t mult) {
-                if (rank < mult) {
-                    const uint32_t sh = (ref & 1u) * 16u;
-                    const uint32_t old = atomicAdd(&ct[ref >> 1], 1u << sh);
-                    const uint32_t cnt = ((old >> sh) & 0xFFFFu) + 1u;
-                    atomicMax(&best[t], (cnt << 16) | (0xFFFFu - ref));
+            if (!(v >> 31)) { // one posting (with multiplicity) or two single postings, stored inline
+                if (((v >> 29) & 3u) == 0u) {
+                    if (rank < ((v >> 20) & 0x1FFu)) add_posting(t, v & 0xFFFFFu);
+                } else if (rank == 0) {
+                    add_posting(t, v & 0x7FFu);
+                    add_posting(t, (v >> 11) & 0x7FFu);
                 }
-            });
+                return false;
+            }
+            m_tr = ((uint32_t)t << 8) | rank;
+            m_off = v & 0x7fffffffu;
+            return true;
+        };
+        auto drain_queue = [&](uint32_t qn) {
+            for (uint32_t e0 = 0; e0 < qn; e0 += WAVE) {
+                const uint32_t e = e0 + (uint32_t)lane;
+                uint32_t m_tr = 0, m_off = 0;
+                bool multi = false;
+                if (e < qn) multi = take_candidate(qh[e], qp[e], qs[e], m_tr, m_off);
+                const uint64_t mm = __ballot(multi);
+                if (mm) { // hits with several postings: 16 lanes walk one hit's posting list, 4 hits at a time
+                    if (multi) { const uint32_t j = (uint32_t)__popcll(mm & lt_mask); mq[2 * j] = m_tr; mq[2 * j + 1] = m_off; }
+                    wave_sync();
+                    const uint32_t nm = (uint32_t)__popcll(mm);
+                    const int g = lane >> 4, sl = lane & 15;
+                    for (uint32_t j = (uint32_t)g; j < nm; j += WAVE / 16) {
+                        const uint32_t tr = mq[2 * j], off = mq[2 * j + 1];
+                        const uint32_t cnt = ix.post[off];
+                        for (uint32_t c = (uint32_t)sl; c < cnt; c += 16) {
+                            const uint32_t ref = ix.post[off + 1 + 2 * c], mult = ix.post[off + 2 + 2 * c];
+                            if ((tr & 0xFFu) < mult) add_posting((int)(tr >> 8), ref);
+                        }
+                    }
+                    wave_sync();
+                }
+            }
         };
 
         // ---- phase 1: one pass over the tile's byte positions per k-mer size ----------------------
         uint32_t qcount = 0; // queue length (wave-uniform)
-        const uint32_t nIt = (B + WAVE - 1) / WAVE;
         for (int kk = 0; kk < (KT ? 1 : ks.n); ++kk) {
             const int k = KT ? KT : ks.k[kk];
             if (kk) { // later k-mer sizes rebuild the start bitmap
@@ -340,6 +390,14 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                 }
                 wave_sync();
             }
+            // Tiles whose reads all have the same length (the common case for short-read data) and hold no invalid
+            // base need no start bitmap: compact window index w -> read t = w / nw, position p = w + t * (len - nw),
+            // so no lane idles on read tails (k-1 positions per read).  Other tiles walk all byte positions.
+            const uint32_t nw_u = (uint32_t)num_windows((int)ulen, k, pol.drop_last_window);
+            const bool compact = uniform && !has_invalid && nw_u > 0;
+            const uint32_t nW = compact ? nw_u * (uint32_t)Tn : B;
+            const float rcp_nw = compact ? 1.0f / (float)nw_u : 0.0f;
+            const uint32_t nIt = (nW + WAVE - 1) / WAVE;
             u32x4 fb = {0u, 0u, 0u, 0u}; // bucket fetched for the previous position (lookup in flight)
             uint64_t hp = 0;
             uint32_t pp = 0;
@@ -348,10 +406,20 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                 // run positions until the queue may not take another wave of candidates (or the tile is done);
                 // step nIt only examines the last lookup
                 for (; it <= nIt && (MODE == 1 || qcount + WAVE <= QCAP); ++it) {
-                    const uint32_t p = it * WAVE + (uint32_t)lane;
+                    const uint32_t w = it * WAVE + (uint32_t)lane;
+                    uint32_t p = w;
                     uint64_t h = 0;
                     if (it < nIt) {
-                        const bool ok = p < B && !((bad[p >> 5] >> (p & 31)) & 1u);
+                        bool ok;
+                        if (compact) { // wave-uniform
+                            uint32_t t = (uint32_t)((float)w * rcp_nw);
+                            t -= (t * nw_u > w) ? 1u : 0u;        // float rounding can be off by one either way
+                            t += ((t + 1u) * nw_u <= w) ? 1u : 0u;
+                            p = w + t * (ulen - nw_u);
+                            ok = w < nW;
+                        } else {
+                            ok = p < B && !((bad[p >> 5] >> (p & 31)) & 1u);
+                        }
                         const uint32_t pc = ok ? p : 0u; // keep the LDS addresses in range for idle lanes
                         if (MODE == 1 && has_invalid && !window_valid<KT>(s, pc, k)) h = 0;
                         else if (geo.dbg & 4) {
@@ -396,8 +464,10 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                 if (MODE == 1) break;
                 // drain: every lane takes queued candidates
                 wave_sync();
-                if (!(geo.dbg & 32))
-                    for (uint32_t e = lane; e < qcount; e += WAVE) take_candidate(qh[e], qp[e], qs[e]);
+                if (!(geo.dbg & 32)) drain_queue(qcount);
+                // tell hipcc that no load of the drain is pending any more: otherwise it drains vmcnt inside every
+                // hashing step (a vals/keys destination register is reused there) and with it the pipelined lookup
+                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
                 qcount = 0;
                 wave_sync();
                 if (it > nIt) break;

@@ -215,7 +215,8 @@ __host__ __device__ __forceinline__ int num_windows(int len, int k, int drop_las
 // All distinct hashes of all reference sketches in one bucketed hash table that stays L2 resident:
 //   fpb  : one 16-byte bucket = 4 x 32-bit fingerprints (0 = empty; slots of a bucket fill in order)
 //   keys : the full 64-bit hash per slot (read only to confirm a fingerprint match)
-//   vals : per slot, bit31=0 -> single posting inline (ref | mult<<20); bit31=1 -> offset into post
+//   vals : per slot, bit31=1 -> offset into post; else bits 30:29 = 0: one posting inline (ref | mult<<20, mult<512),
+//          1: two postings of multiplicity 1 inline (ref1 | ref2<<11, both < 2048)
 //   post : [off] = count, then count x (ref, mult)
 // A lookup that misses (about 7 of 8 read k-mers) costs exactly one 16-byte load.
 struct RefIndex {

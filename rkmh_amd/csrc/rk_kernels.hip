@@ -81,8 +81,13 @@ __device__ __forceinline__ void wave_argmax_diff(const int* sh, int R, int lane,
 __device__ __forceinline__ void accumulate_posting(const RefIndex& ix, uint32_t slot, uint32_t rank, int* sh) {
     uint32_t v = ix.vals[slot];
     if (!(v >> 31)) {
-        uint32_t ref = v & 0xFFFFFu, mult = (v >> 20) & 0x7FFu;
-        if (rank < mult) atomicAdd(&sh[ref], 1);
+        if (((v >> 29) & 3u) == 0u) {
+            uint32_t ref = v & 0xFFFFFu, mult = (v >> 20) & 0x1FFu;
+            if (rank < mult) atomicAdd(&sh[ref], 1);
+        } else if (rank == 0) {
+            atomicAdd(&sh[v & 0x7FFu], 1);
+            atomicAdd(&sh[(v >> 11) & 0x7FFu], 1);
+        }
     } else {
         uint32_t off = v & 0x7fffffffu;
         uint32_t cnt = ix.post[off];
