@@ -33,8 +33,15 @@
 
 namespace rk {
 
+// Ablation switches used to attribute kernel time to its parts: build with
+// -DRK_ABLATE=1 and set RKMH_DBG (1 no queueing, 2 no phase 2, 4 cheap hash, 8 no bucket loads, 32 no drain).
+#ifndef RK_ABLATE
+#define RK_ABLATE 0
+#endif
+#define RK_DBG(bit) (RK_ABLATE && (geo.dbg & (bit)))
+
 constexpr int WAVE = 64;
-constexpr int PF = 6; // prefetched base dwords per lane: tile bytes <= PF*64*4 - 8
+constexpr int PF_MAX = 6; // prefetched base dwords per lane: tile bytes <= PF*64*4 - 8 (template parameter PF = 2 or 6)
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
@@ -62,7 +69,7 @@ struct TileGeom {
     int32_t qcap;       // candidate queue entries (>= 128)
     int32_t cwords;     // 16-bit counter words per read = (nref + 1) / 2
     int32_t dset;       // slots of the per-read hit multiset (power of two)
-    int32_t dbg;        // ablation switches for profiling (RKMH_DBG; 0 in production)
+    int32_t dbg;        // ablation switches (only read when built with -DRK_ABLATE=1)
 };
 
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
@@ -116,7 +123,7 @@ __device__ __forceinline__ void bucket_load_async(const uint4* p, u32x4& f) {
 __device__ __forceinline__ void bucket_wait(u32x4& f) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : : "memory"); }
 
 // MODE 0: classify; MODE 1: count pass of -M (rkmh.cpp:904-910); MODE 2: classify with the -M mask (rkmh.cpp:916)
-template <int KT, int MODE, int FOLD>
+template <int KT, int MODE, int FOLD, int PF>
 __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
                                                            uint32_t nreads, KsArr ks, int S, RefIndex ix, int32_t* counter,
                                                            uint64_t slots, int min_occ, int32_t* out4, DevPolicy pol, TileGeom geo) {
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
     uint32_t* stage = smem;
     uint32_t* qh32 = stage + ((stage_lds_dwords(geo.cap_bytes) + 1) & ~1); // [2*QCAP] candidate hashes (8-byte aligned)
     uint64_t* qh = reinterpret_cast<uint64_t*>(qh32);
-    uint32_t* qp = qh32 + 2 * QCAP;                              // [QCAP] tile byte position of the candidate window
+    uint32_t* qp = qh32 + 2 * QCAP;                              // [QCAP] read (within the tile) of the candidate window
     uint32_t* qs = qp + QCAP;                                    // [QCAP] slot whose fingerprint matched (or NONE)
     uint32_t* rstart = qs + QCAP;                                // [T+1] byte offset of read t inside the tile
     uint32_t* nwin = rstart + (T + 1);                           // [T+1] windows of read t (all k)
@@ -150,7 +157,9 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
 
     // Software prefetch across tiles: while tile i is hashed, the offsets and the raw base dwords of this wave's
     // next tile travel into registers, so phase 0 of the next tile touches no global memory.
-    uint32_t pf[PF] = {0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t pf[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) pf[q] = 0u;
     uint32_t cur_a = 0, cur_b = 0, cur_o = 0; // tile byte range [a,b) in the batch, this lane's read offset
     auto tile_reads = [&](uint32_t tl) -> int {
         const uint32_t r = tl * (uint32_t)T;
@@ -180,7 +189,8 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
         }
     };
     auto wait_bases = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]) : : "memory");
+        if constexpr (PF == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]) : : "memory");
     };
     if (blockIdx.x < ntiles) { load_offsets(blockIdx.x, cur_a, cur_b, cur_o); load_bases(cur_a, cur_b); }
 
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
         // (exact LDS multiset: entry = (slot + 1) | (occurrences - 1) << 27) and add the postings the multiset merge of
         // rkmh.cpp:869 would count.  A hit with several postings is returned (read << 8 | rank, postings offset) for
         // the 16-lanes-per-hit pass instead of looping here with 63 lanes idle.
-        auto take_candidate = [&](uint64_t h, uint32_t p, uint32_t hint, uint32_t& m_tr, uint32_t& m_off) -> bool {
+        auto take_candidate = [&](uint64_t h, int t, uint32_t hint, uint32_t& m_tr, uint32_t& m_off) -> bool {
             uint32_t slot = 0, v = 0;
             bool found = false;
             if (hint != IDX_NOT_FOUND) { // the one slot whose fingerprint matched: key and value in one round trip
@@ -312,7 +322,6 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
             }
             if (!found) found = index_lookup(ix, h, slot, v);
             if (!found) return false;
-            const int t = read_of(p);
             uint32_t rank = 0;
             {
                 uint32_t* ds = dset + (uint32_t)t * DS;
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                 const uint32_t e = e0 + (uint32_t)lane;
                 uint32_t m_tr = 0, m_off = 0;
                 bool multi = false;
-                if (e < qn) multi = take_candidate(qh[e], qp[e], qs[e], m_tr, m_off);
+                if (e < qn) multi = take_candidate(qh[e], (int)qp[e], qs[e], m_tr, m_off);
                 const uint64_t mm = __ballot(multi);
                 if (mm) { // hits with several postings: 16 lanes walk one hit's posting list, 4 hits at a time
                     if (multi) { const uint32_t j = (uint32_t)__popcll(mm & lt_mask); mq[2 * j] = m_tr; mq[2 * j + 1] = m_off; }
@@ -400,29 +409,30 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
             const uint32_t nIt = (nW + WAVE - 1) / WAVE;
             u32x4 fb = {0u, 0u, 0u, 0u}; // bucket fetched for the previous position (lookup in flight)
             uint64_t hp = 0;
-            uint32_t pp = 0;
+            uint32_t tp = 0; // read of the previous position
             uint32_t it = 0;
             for (;;) {
                 // run positions until the queue may not take another wave of candidates (or the tile is done);
                 // step nIt only examines the last lookup
                 for (; it <= nIt && (MODE == 1 || qcount + WAVE <= QCAP); ++it) {
                     const uint32_t w = it * WAVE + (uint32_t)lane;
-                    uint32_t p = w;
+                    uint32_t p = w, t = 0;
                     uint64_t h = 0;
                     if (it < nIt) {
                         bool ok;
                         if (compact) { // wave-uniform
-                            uint32_t t = (uint32_t)((float)w * rcp_nw);
+                            t = (uint32_t)((float)w * rcp_nw);
                             t -= (t * nw_u > w) ? 1u : 0u;        // float rounding can be off by one either way
                             t += ((t + 1u) * nw_u <= w) ? 1u : 0u;
                             p = w + t * (ulen - nw_u);
                             ok = w < nW;
                         } else {
                             ok = p < B && !((bad[p >> 5] >> (p & 31)) & 1u);
+                            if (ok) t = (uint32_t)read_of(p);
                         }
                         const uint32_t pc = ok ? p : 0u; // keep the LDS addresses in range for idle lanes
                         if (MODE == 1 && has_invalid && !window_valid<KT>(s, pc, k)) h = 0;
-                        else if (geo.dbg & 4) {
+                        else if RK_DBG(4) {
                             h = ((uint64_t)(s.fwd[(s.fbase + pc) >> 2] * 0x9E3779B1u) << 32) | (s.rc[(B - (uint32_t)k - pc) >> 2] * 0x85EBCA6Bu);
                         } else {
                             const uint64_t f = murmur_window<KT, FOLD>(s.fwd, s.fbase + pc, k, pol.seed, pol.fold);
@@ -438,12 +448,12 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                             const int c = counter[h % slots];
                             if (pol.mask_strict_less ? (c < min_occ) : (c <= min_occ)) h = 0;
                         }
-                        if (ok && h == 0) atomicAdd(&nzero[read_of(p)], 1u);
+                        if (ok && h == 0) atomicAdd(&nzero[t], 1u);
                     }
                     if (MODE == 1) continue;
                     // examine the lookup issued one step ago: fingerprint matches / full buckets are queued
                     bucket_wait(fb);
-                    if (!(geo.dbg & 1)) {
+                    if (!RK_DBG(1)) {
                         const uint32_t fp = index_fp(hp);
                         const uint32_t mm = (fb.x == fp ? 1u : 0u) | (fb.y == fp ? 2u : 0u) | (fb.z == fp ? 4u : 0u) | (fb.w == fp ? 8u : 0u);
                         const bool cand = hp != 0 && (mm != 0 || fb.w != 0);
@@ -452,25 +462,33 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                             const uint32_t hint = (mm != 0 && (mm & (mm - 1u)) == 0)
                                                       ? 4u * index_bucket(hp, ix.bshift) + ((uint32_t)__ffs((int)mm) - 1u) : IDX_NOT_FOUND;
                             const uint32_t q = qcount + (uint32_t)__popcll(m & lt_mask);
-                            qh[q] = hp; qp[q] = pp; qs[q] = hint;
+                            qh[q] = hp; qp[q] = tp; qs[q] = hint;
                         }
                         qcount += (uint32_t)__popcll(m);
                     }
-                    if (geo.dbg & 8) { if (h == 0x1234567ull) nzero[0] = 1; } else
+                    if RK_DBG(8) { if (h == 0x1234567ull) nzero[0] = 1; } else
                     if (h != 0) bucket_load_async(ix.fpb + index_bucket(h, ix.bshift), fb); // lands while the next position is hashed
                     hp = h;
-                    pp = p;
+                    tp = t;
                 }
                 if (MODE == 1) break;
                 // drain: every lane takes queued candidates
                 wave_sync();
-                if (!(geo.dbg & 32)) drain_queue(qcount);
+                const bool last = it > nIt;
+                const uint32_t qn = last ? qcount : (qcount & ~(uint32_t)(WAVE - 1)); // mid-tile: whole waves of candidates only
+                if (!RK_DBG(32)) drain_queue(qn);
                 // tell hipcc that no load of the drain is pending any more: otherwise it drains vmcnt inside every
                 // hashing step (a vals/keys destination register is reused there) and with it the pipelined lookup
                 __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-                qcount = 0;
                 wave_sync();
-                if (it > nIt) break;
+                if (last) { qcount = 0; break; }
+                const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
+                uint64_t ch = 0; uint32_t ct_ = 0, cs = 0;
+                if ((uint32_t)lane < rem) { ch = qh[qn + lane]; ct_ = qp[qn + lane]; cs = qs[qn + lane]; }
+                wave_sync();
+                if ((uint32_t)lane < rem) { qh[lane] = ch; qp[lane] = ct_; qs[lane] = cs; }
+                qcount = rem;
+                wave_sync();
             }
         }
         if (MODE == 1) continue;
@@ -484,7 +502,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                 // bottom-S selection matters, or the hit multiset overflowed: exact answer comes from the general path
                 const bool reroute = nmins > S || flags[t] != 0;
                 const uint32_t bk = best[t];
-                if (reroute || (geo.dbg & 2)) {
+                if (reroute || RK_DBG(2)) {
                     for (int w = sl; w < geo.cwords; w += 16) ct[w] = 0;
                     if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = reroute ? make_int4(-2, 0, 0, 0) : make_int4(0, (int)(bk >> 16), 0, nmins);
                     continue;
@@ -511,11 +529,12 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
 static TileGeom make_geom(int maxlen, int nref, int expect_hits) {
     TileGeom g;
     if (maxlen < 1) maxlen = 1;
-    int T = 640 / maxlen; // ~600 bytes per wave: 8+ hashing steps per tile
+    int T = 500 / maxlen; // ~450 bytes per wave: the tile's candidates then fit one dense drain (measured best at 150 bp)
+    if (T < 2) T = 2;
     if (const char* e = getenv("RKMH_TILE_T")) T = atoi(e);
     if (T > 16) T = 16;
     if (T < 1) T = 1;
-    while (T > 1 && T * maxlen > PF * WAVE * 4 - 8) --T;
+    while (T > 1 && T * maxlen > PF_MAX * WAVE * 4 - 8) --T;
     g.T = T;
     g.cap_bytes = T * maxlen;
     g.qcap = 128;
@@ -532,7 +551,7 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits) {
 
 // T x nref 16-bit counters must fit beside the tile in LDS; reference ids must fit 16 bits;
 // one tile (>= 1 read of maxlen bytes) must fit the prefetch registers
-bool classify_tile_supported(int nref, int maxlen) { return nref <= 2048 && maxlen <= PF * WAVE * 4 - 8; }
+bool classify_tile_supported(int nref, int maxlen) { return nref <= 2048 && maxlen <= PF_MAX * WAVE * 4 - 8; }
 
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
@@ -550,17 +569,22 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     if (const char* e = getenv("RKMH_TILE_TPB")) tpb = atoi(e) > 0 ? atoi(e) : 3;
     const bool k16 = (ks.n == 1 && ks.k[0] == 16);
     const int kmode = mode == 1 ? 1 : (counter ? 2 : 0);
-#define RK_LAUNCH(KT, MODE, FOLD)                                                                                    \
+#define RK_LAUNCH_P(KT, MODE, FOLD, PF)                                                                                    \
     do {                                                                                                             \
         if (lds > 64 * 1024) {                                                                                       \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_classify_tile<KT, MODE, FOLD>),       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_classify_tile<KT, MODE, FOLD, PF>),       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
             if (e != hipSuccess) return e;                                                                           \
         }                                                                                                            \
         uint32_t grid = (ntiles + (uint32_t)tpb - 1) / (uint32_t)tpb;                                                \
         if (const char* g = getenv("RKMH_TILE_GRID")) { uint32_t v = (uint32_t)atoi(g); if (v && v < ntiles) grid = v; } \
-        hipLaunchKernelGGL((k_classify_tile<KT, MODE, FOLD>), dim3(grid), dim3(WAVE), lds, st, bases, offs, nreads,   \
+        hipLaunchKernelGGL((k_classify_tile<KT, MODE, FOLD, PF>), dim3(grid), dim3(WAVE), lds, st, bases, offs, nreads,   \
                            ks, S, ix, counter, slots, min_occ, out4, pol, geo);                                      \
+    } while (0)
+#define RK_LAUNCH(KT, MODE, FOLD)                                                                                    \
+    do {                                                                                                             \
+        if (geo.cap_bytes <= 2 * WAVE * 4 - 8) RK_LAUNCH_P(KT, MODE, FOLD, 2);                                       \
+        else RK_LAUNCH_P(KT, MODE, FOLD, 6);                                                                         \
     } while (0)
 #define RK_LAUNCH_M(KT, FOLD)                                                                                        \
     do {                                                                                                             \
@@ -574,6 +598,7 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     else RK_LAUNCH_M(16, 2);
 #undef RK_LAUNCH_M
 #undef RK_LAUNCH
+#undef RK_LAUNCH_P
     return hipGetLastError();
 }
 
