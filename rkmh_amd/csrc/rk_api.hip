@@ -110,7 +110,7 @@ struct rk_ctx {
     rk_counter* depth = nullptr;
     int min_occ = 0;
     // workspaces for the general path
-    DevBuf w_bases, w_tiles, w_hashes, w_segoff, w_ids, w_sk, w_lens, w_out, w_misc;
+    DevBuf w_bases, w_tiles, w_hashes, w_segoff, w_ids, w_sk, w_lens, w_out, w_misc, w_sel, w_selstate;
     Slot slot[2];
 };
 
@@ -145,7 +145,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
     for (DevBuf* b : {&c->d_fpb, &c->d_keys, &c->d_vals, &c->d_post, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
-                      &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc}) b->release();
+                      &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
         s.d_bases.release(); s.d_offs.release(); s.d_out.release();
@@ -205,6 +205,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
     std::vector<TileDesc> tiles;
     std::vector<uint64_t> seg;
     std::vector<std::vector<uint32_t>> classes(32);
+    std::vector<uint32_t> long_seqs;
     uint64_t hash_cursor = 0; // position in out.hashes
     int64_t i0 = 0;
     while (i0 < n) {
@@ -213,6 +214,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
         uint64_t cb = 0, ch = 0;
         tiles.clear(); seg.clear(); seg.push_back(0);
         for (auto& v : classes) v.clear();
+        long_seqs.clear();
         const uint64_t base0 = offsets[i0];
         while (i1 < n) {
             uint64_t len = offsets[i1 + 1] - offsets[i1];
@@ -221,8 +223,8 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
             else for (int j = 0; j < cfg.ks.n; ++j) nh += (uint64_t)num_windows((int)len, cfg.ks.k[j], c->pol.drop_last_window);
             if (len > 0x7fffffffull) return fail(RK_ERR_LIMIT, "sequence %lld longer than 2^31-1", (long long)i1);
             if (i1 > i0 && (cb + len > MAX_CHUNK_BASES || ch + nh > MAX_CHUNK_HASHES)) break;
-            if (need_sort && nh > (uint64_t)SORT_MAX_P)
-                return fail(RK_ERR_LIMIT, "sequence %lld has %llu hashes; the in-LDS sketcher handles <= %d (radix-select path not built yet)",
+            if (need_sort && nh > (uint64_t)SORT_MAX_P && out.write_back_sorted)
+                return fail(RK_ERR_LIMIT, "sequence %lld has %llu hashes; in-place sorting handles <= %d",
                             (long long)i1, (unsigned long long)nh, SORT_MAX_P);
             // tiles
             uint64_t o = seg.back();
@@ -244,9 +246,12 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
             }
             seg.push_back(o);
             if (need_sort) {
-                uint32_t P = next_pow2((uint32_t)nh);
-                int cls = 0; while ((64u << cls) < P) ++cls;
-                classes[cls].push_back((uint32_t)(i1 - i0));
+                if (nh > (uint64_t)SORT_MAX_P) long_seqs.push_back((uint32_t)(i1 - i0)); // radix select, then sort <= S candidates
+                else {
+                    uint32_t P = next_pow2((uint32_t)nh);
+                    int cls = 0; while ((64u << cls) < P) ++cls;
+                    classes[cls].push_back((uint32_t)(i1 - i0));
+                }
             }
             cb += len; ch += nh; ++i1;
         }
@@ -299,6 +304,30 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
                 a.slots = cfg.filt_counter ? cfg.filt_counter->slots : 1;
                 a.filter_mode = cfg.filter_mode; a.fmin = cfg.fmin; a.fmax = cfg.fmax;
                 HIPCHK(launch_sort_intersect(a, cfg.classify ? &c->ix : nullptr, c->pol, c->st));
+            }
+            if (!long_seqs.empty()) { // sequences longer than the LDS sorter: exact bottom-S by radix select first
+                RKCHK(c->w_sel.reserve((size_t)S * 8 + 64));
+                RKCHK(c->w_selstate.reserve(16 * 4 + 8192 * 4));
+                uint32_t* st_ = c->w_selstate.as<uint32_t>();
+                for (uint32_t li : long_seqs) {
+                    uint32_t* d_id = c->w_ids.as<uint32_t>() + id_cursor;
+                    HIPCHK(hipMemcpyAsync(d_id, &li, 4, hipMemcpyHostToDevice, c->st));
+                    id_cursor += 1;
+                    const uint64_t n_h = seg[li + 1] - seg[li];
+                    HIPCHK(launch_select_bottom(c->w_hashes.as<uint64_t>() + seg[li], n_h, S,
+                                                cfg.filt_counter ? cfg.filt_counter->d : nullptr, cfg.filt_counter ? cfg.filt_counter->slots : 1,
+                                                cfg.filter_mode, cfg.fmin, cfg.fmax, c->pol, st_, st_ + 16, c->w_sel.as<uint64_t>(), c->st));
+                    SortArgs a{};
+                    a.hashes = c->w_hashes.as<uint64_t>(); a.seg_off = c->w_segoff.as<uint64_t>();
+                    a.seq_ids = d_id; a.nlist = 1; a.P = next_pow2((uint32_t)S); a.S = S; a.write_back = 0;
+                    a.sketches = out.sketches ? c->w_sk.as<uint64_t>() : nullptr;
+                    a.lens = out.lens ? c->w_lens.as<int32_t>() : nullptr;
+                    a.out4 = out.out4 ? c->w_out.as<int32_t>() : nullptr;
+                    a.filter_mode = FILTER_NONE;
+                    a.sel_hashes = c->w_sel.as<uint64_t>(); a.sel_len = st_ + 8;
+                    HIPCHK(launch_sort_intersect(a, cfg.classify ? &c->ix : nullptr, c->pol, c->st));
+                    HIPCHK(hipStreamSynchronize(c->st)); // w_sel / state are reused by the next long sequence
+                }
             }
             // the ids vectors must outlive the async copies
             HIPCHK(hipStreamSynchronize(c->st));

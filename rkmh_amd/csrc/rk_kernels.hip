@@ -109,14 +109,17 @@ __global__ void k_sort_intersect(SortArgs a, RefIndex ix, int has_ix, DevPolicy 
     const uint32_t P = a.P;
     for (uint32_t li = blockIdx.x; li < a.nlist; li += gridDim.x) {
         const uint32_t id = a.seq_ids[li];
-        const uint64_t seg = a.seg_off[id];
-        const uint32_t n = (uint32_t)(a.seg_off[id + 1] - seg);
+        const bool sel = a.sel_len != nullptr;
+        const uint64_t seg = sel ? 0 : a.seg_off[id];
+        const uint32_t n = sel ? a.sel_len[0] : (uint32_t)(a.seg_off[id + 1] - seg);
+        const uint64_t* src = sel ? a.sel_hashes : a.hashes;
         __syncthreads();
         for (uint32_t t = tid; t < P; t += T) {
             uint64_t h = ~0ull;
             if (t < n) {
-                h = a.hashes[seg + t];
-                if (a.filter_mode == FILTER_MASK_MIN) {            // mask_by_frequency, rkmh.cpp:916
+                h = src[seg + t];
+                if (sel) {
+                } else if (a.filter_mode == FILTER_MASK_MIN) {            // mask_by_frequency, rkmh.cpp:916
                     int c = a.counter[h % a.slots];
                     if (pol.mask_strict_less ? (c < a.fmin) : (c <= a.fmin)) h = 0;
                 } else if (a.filter_mode == FILTER_RANGE && h != 0) { // minhashes_frequency_filter, rkmh.cpp:835
@@ -191,6 +194,125 @@ hipError_t launch_sort_intersect(const SortArgs& a, const RefIndex* ix, const De
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_sort_intersect, dim3(grid), dim3(T), lds, st, a, use, ix ? 1 : 0, pol);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Radix select for sequences with more hashes than the LDS sorter holds (chromosome-scale references).
+// state dwords: [0,1] prefix (u64, high bits decided so far)  [2] remaining rank inside the prefix bucket
+//               [3] count strictly below the prefix  [4] take_all flag  [5] compaction cursor  [8] candidates out
+constexpr int SEL_BITS = 13;
+constexpr int SEL_BINS = 1 << SEL_BITS;
+__device__ __forceinline__ uint64_t sel_filter(uint64_t h, const int32_t* counter, uint64_t slots, int mode, int fmin, int fmax,
+                                               const DevPolicy& pol) {
+    if (mode == FILTER_MASK_MIN) {
+        int c = counter[h % slots];
+        if (pol.mask_strict_less ? (c < fmin) : (c <= fmin)) h = 0;
+    } else if (mode == FILTER_RANGE && h != 0) {
+        int c = counter[h % slots];
+        bool keep = pol.freq_max_inclusive ? (c >= fmin && c <= fmax) : (c >= fmin && c < fmax);
+        if (!keep) h = 0;
+    }
+    return h;
+}
+// digit d (0..4) covers bits [shift, shift+width): 13,13,13,13,12 bits from the top
+__device__ __forceinline__ void sel_digit(int d, int& shift, int& width) {
+    width = d < 4 ? SEL_BITS : 64 - 4 * SEL_BITS;
+    shift = d < 4 ? 64 - SEL_BITS * (d + 1) : 0;
+}
+__global__ __launch_bounds__(256) void k_sel_hist(const uint64_t* __restrict__ h, uint64_t n, const int32_t* counter, uint64_t slots,
+                                                  int mode, int fmin, int fmax, DevPolicy pol, const uint32_t* state, uint32_t* hist,
+                                                  int d) {
+    __shared__ uint32_t lh[SEL_BINS];
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256) lh[i] = 0;
+    __syncthreads();
+    int shift, width;
+    sel_digit(d, shift, width);
+    const uint64_t prefix = ((uint64_t)state[1] << 32) | state[0];
+    const bool take_all = state[4] != 0;
+    if (!take_all) {
+        for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+            const uint64_t v = sel_filter(h[i], counter, slots, mode, fmin, fmax, pol);
+            if (v == 0) continue;
+            if (d > 0 && (v >> (shift + width)) != prefix) continue;
+            atomicAdd(&lh[(uint32_t)(v >> shift) & ((1u << width) - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+__global__ __launch_bounds__(1024) void k_sel_scan(uint32_t* state, uint32_t* hist, int d, int S) {
+    __shared__ uint32_t part[1024];
+    int shift, width;
+    sel_digit(d, shift, width);
+    const int bins = 1 << width, per = SEL_BINS / 1024; // 8 bins per thread
+    const int tid = threadIdx.x;
+    if (d == 0 && tid == 0) state[2] = (uint32_t)S; // everything else was zeroed by the launcher
+    __syncthreads();
+    uint32_t loc[8], sum = 0;
+    for (int j = 0; j < per; ++j) { int b = tid * per + j; loc[j] = b < bins ? hist[b] : 0; sum += loc[j]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { // inclusive scan of the per-thread sums
+        uint32_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t total = part[1023];
+    const uint32_t remaining = state[2];
+    __syncthreads();
+    if (state[4] == 0) {
+        if (d == 0 && total < remaining) { if (tid == 0) state[4] = 1; } // fewer kept hashes than S: take them all
+        else {
+            uint32_t before = part[tid] - sum; // kept hashes in bins before this thread's
+            for (int j = 0; j < per; ++j) {
+                if (before < remaining && before + loc[j] >= remaining) { // the S-th smallest lies in this bin
+                    const uint64_t prefix = (((uint64_t)state[1] << 32) | state[0]);
+                    const uint64_t np = d == 0 ? (uint64_t)(tid * per + j) : ((prefix << width) | (uint64_t)(tid * per + j));
+                    state[0] = (uint32_t)np; state[1] = (uint32_t)(np >> 32);
+                    state[2] = remaining - before;
+                    state[3] += before;
+                }
+                before += loc[j];
+            }
+        }
+    }
+    for (int j = 0; j < per; ++j) hist[tid * per + j] = 0; // ready for the next digit
+}
+__global__ __launch_bounds__(256) void k_sel_compact(const uint64_t* __restrict__ h, uint64_t n, const int32_t* counter, uint64_t slots,
+                                                     int mode, int fmin, int fmax, DevPolicy pol, uint32_t* state, uint64_t* out) {
+    const uint64_t T = ((uint64_t)state[1] << 32) | state[0]; // the S-th smallest kept hash
+    const bool take_all = state[4] != 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t v = sel_filter(h[i], counter, slots, mode, fmin, fmax, pol);
+        if (v != 0 && (take_all || v < T)) out[atomicAdd(&state[5], 1u)] = v;
+    }
+    if (blockIdx.x == 0 && !take_all) { // state[2] copies of the threshold value complete the bottom-S multiset
+        const uint32_t base = state[3], copies = state[2];
+        for (uint32_t j = threadIdx.x; j < copies; j += 256) out[base + j] = T;
+    }
+}
+__global__ void k_sel_finish(uint32_t* state) { state[8] = state[4] ? state[5] : state[3] + state[2]; }
+
+hipError_t launch_select_bottom(const uint64_t* hashes, uint64_t n, int S, const int32_t* counter, uint64_t slots,
+                                int filter_mode, int fmin, int fmax, const DevPolicy& pol, uint32_t* sel_state,
+                                uint32_t* hist, uint64_t* sel_out, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(hist, 0, SEL_BINS * 4, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(sel_state, 0, 16 * 4, st); // the first histogram pass already reads the take-all flag
+    if (e != hipSuccess) return e;
+    uint32_t grid = (uint32_t)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    for (int d = 0; d < 5; ++d) {
+        hipLaunchKernelGGL(k_sel_hist, dim3(grid), dim3(256), 0, st, hashes, n, counter, slots, filter_mode, fmin, fmax, pol,
+                           (const uint32_t*)sel_state, hist, d);
+        hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, st, sel_state, hist, d, S);
+    }
+    // the compaction writes values < T through the cursor (which ends at state[3]) and the copies of T behind them
+    hipLaunchKernelGGL(k_sel_compact, dim3(grid), dim3(256), 0, st, hashes, n, counter, slots, filter_mode, fmin, fmax, pol,
+                       sel_state, sel_out);
+    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(1), 0, st, sel_state);
     return hipGetLastError();
 }
 

@@ -41,12 +41,22 @@ struct SortArgs {
     const int32_t* counter;    // nullable
     uint64_t slots;
     int32_t filter_mode, fmin, fmax;
+    // optional: sort a pre-selected candidate buffer instead of the sequence's own segment (radix-select path);
+    // sel_len[0] = number of candidates on the device, filters were already applied
+    const uint64_t* sel_hashes;
+    const uint32_t* sel_len;
 };
 
 hipError_t launch_to_upper(uint8_t* d, uint64_t n, hipStream_t st);
 hipError_t launch_hash_tiles(const uint8_t* bases, const TileDesc* tiles, uint32_t ntiles, uint64_t* out,
                              int32_t* counter, uint64_t slots, const DevPolicy& pol, hipStream_t st);
 hipError_t launch_sort_intersect(const SortArgs& a, const RefIndex* ix, const DevPolicy& pol, hipStream_t st);
+// bottom-S candidates of one LONG sequence (more hashes than the in-LDS sorter holds): exact radix select of the
+// S-th smallest kept hash (13-bit digits), then compaction into sel_out[<= S]; sel_state is 16 dwords of scratch,
+// hist 8192 dwords.  sel_state[8] receives the number of candidates.
+hipError_t launch_select_bottom(const uint64_t* hashes, uint64_t n, int S, const int32_t* counter, uint64_t slots,
+                                int filter_mode, int fmin, int fmax, const DevPolicy& pol, uint32_t* sel_state,
+                                uint32_t* hist, uint64_t* sel_out, hipStream_t st);
 hipError_t launch_intersect_pair(const uint64_t* a, int na, const uint64_t* b, int nb, int* out, hipStream_t st);
 hipError_t launch_fill_reroute(int32_t* out4, uint32_t nreads, hipStream_t st);
 // mode 0: classify (out4 written); mode 1: count only (counter incremented)

@@ -365,3 +365,34 @@ def test_depth_filter_with_long_reads(ctx, orc, pave):
     want = orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=4, min_kmer_occ=3, counter_slots=1000003)
     assert (got == want).all()
     cnt.destroy()
+
+
+def test_long_sequences_radix_select(ctx, orc, pave):
+    """Sequences with more hashes than the LDS sorter holds (> 16384): exact bottom-S by radix select."""
+    import rkmh_amd
+    _, rb, ro = pave
+    rng = np.random.default_rng(12)
+    big = bytes(rb[: int(ro[40])])                 # ~300 kb of concatenated HPV genomes (lower case + IUPAC)
+    rnd = rand_dna(rng, 200000, b"ACGT")
+    low = (b"ACGTTGCA" * 4000)                     # highly repetitive: many equal hashes around the threshold
+    tiny = rand_dna(rng, 20000, b"ACGT")           # 19984 hashes: just above the limit
+    seqs = [big, rnd, low, tiny, rnd[:9000]]
+    bases, offs = orc.pack(seqs)
+    bases = _pad(bases)
+    for ks, S in (([16], 1000), ([20], 2000), ([12, 16], 16384), ([16], 7)):
+        want_sk, want_ln = orc.sketch_refs(bases, offs, ks, S, threads=4)
+        sk, ln = ctx.sketch_batch(bases, offs, ks, S)
+        assert (ln == want_ln).all(), (ks, S, ln, want_ln)
+        assert (sk == want_sk).all(), (ks, S)
+    # as references (+ the -I filter) and as long reads
+    ctx.set_references(bases, offs, [16], 1000, max_samples=3, counter_slots=5000011)
+    sk, ln = ctx.get_reference_sketches()
+    wsk, wln = orc.sketch_refs(bases, offs, [16], 1000, threads=4, max_samples=3, counter_slots=5000011)
+    assert (ln == wln).all() and (sk == wsk).all()
+    ctx.set_references(rb, ro, [16], 1000)
+    sk, ln = ctx.get_reference_sketches()
+    reads = [big[1000:60000], rnd[:30000], big[5:155]]
+    qb, qo = orc.pack(reads)
+    got = ctx.classify(_pad(qb), qo)
+    want = orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=4)
+    assert (got == want).all()
