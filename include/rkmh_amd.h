@@ -124,6 +124,9 @@ int rk_sketch_batch(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, 
  * (src/rkmh.cpp:828-838) with a counter of counter_slots (0 => 200000000, src/rkmh.cpp:742). */
 int rk_set_references(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, int nref,
                       const int* ks, int nks, int sketch_size, int max_samples, uint64_t counter_slots);
+/* How the -I counter is filled by the next rk_set_references: 0 = once per k-mer occurrence (main_stream,
+ * src/rkmh.cpp:831), 1 = once per distinct hash per reference (main_filter's hash_sequences, src/rkmh.cpp:348-355). */
+int rk_set_reference_count_mode(rk_ctx* ctx, int mode);
 /* Import already-built sketches (after an RCCL broadcast from the rank that sketched them). */
 int rk_set_reference_sketches(rk_ctx* ctx, const uint64_t* sketches, const int32_t* lens, int nref,
                               const int* ks, int nks, int sketch_size);

@@ -120,7 +120,7 @@ def pack(seqs):
     return bases, offs
 
 
-def sketch_refs(bases, offsets, ks, S, policy=None, threads=1, max_samples=None, counter_slots=200000000):
+def sketch_refs(bases, offsets, ks, S, policy=None, threads=1, max_samples=None, counter_slots=200000000, distinct=False):
     policy = policy or default_policy()
     ks = np.asarray(ks, dtype=np.int32)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -133,7 +133,7 @@ def sketch_refs(bases, offsets, ks, S, policy=None, threads=1, max_samples=None,
                               _p(sk, C.c_uint64), _p(ln, C.c_int32), C.byref(policy), threads)
     else:
         lib().rko_sketch_refs_maxsamples(_p(bases, C.c_char), _p(offsets, C.c_uint64), nref, _p(ks, C.c_int),
-                                         len(ks), S, int(max_samples), C.c_uint64(counter_slots),
+                                         len(ks), S, int(max_samples), C.c_uint64(counter_slots), 1 if distinct else 0,
                                          _p(sk, C.c_uint64), _p(ln, C.c_int32), C.byref(policy), threads)
     return sk, ln
 
@@ -260,3 +260,34 @@ def stream_line(ref_name, read_name, max_shared, diff, min_num, sketch_size, min
     return "%s\t%s\t%d\t%d%s\t%s\t%s\n" % (
         ref_name, read_name, max_shared, sketch_size, "FAIL:DEPTH" if depth_filter else "",
         "FAIL:MATCHES" if match_filter else "", "" if diff_filter else "FAIL:DIFF")
+
+
+# ---------------------------------------------------------------------------------------------
+# main_filter (/root/reference/src/rkmh.cpp:996-1424) on top of the stream rows.  The sketches are the same
+# (mask by counter, bottom-S); only the decision differs: classify_and_count_diff_filter
+# (/root/reference/src/equiv.hpp:324-353) starts from max_shared = prev_best = 0 with an empty sample name.
+# ---------------------------------------------------------------------------------------------
+def filter_decision(row, min_matches=-1, min_diff=0):
+    """row = (max_id, max_shared, diff, min_num) of the stream loop -> (ref_index or None, shared, diff_ok, passes)."""
+    max_id, max_shared, diff, nmins = (int(x) for x in row)
+    if max_shared <= 0:
+        ref, shared, d = None, 0, 0
+    else:
+        ref, shared = max_id, max_shared
+        d = diff - (1 if max_id == 0 else 0)   # stream's scan starts at -1, filter's at 0
+    diff_ok = d > min_diff
+    depth_filter = nmins <= 0
+    match_filter = shared < min_matches
+    return ref, shared, diff_ok, (not depth_filter) and (not match_filter) and diff_ok
+
+
+def filter_record(name: bytes, seq_upper: bytes, qual: bytes) -> bytes:
+    """stdout of a passing read, rkmh.cpp:1299-1302"""
+    return b">" + name + b"\n" + seq_upper + b"\n+\n" + qual + b"\n"
+
+
+def filter_stdin_line(name, ref_name, shared, union, nmins, diff_ok, min_matches=-1):
+    """-i mode, rkmh.cpp:1397-1399"""
+    return "Sample: %s\tResult: %s\t%d\t%d\t%s\t%s\t%s\n" % (
+        name, ref_name, shared, union, "FAIL:DEPTH" if nmins <= 0 else "",
+        "FAIL:MATCHES" if shared < min_matches else "", "" if diff_ok else "FAIL:DIFF")

@@ -134,6 +134,8 @@ void rko_calc_hashes(const char* seq, int len, const int* ks, int nks,
     *out = h; *n = total;
 }
 
+static int cmp_u64(const void* a, const void* b);
+
 rko_counter* rko_counter_new(uint64_t slots) {
     rko_counter* c = (rko_counter*)malloc(sizeof(rko_counter));
     c->slots = slots;
@@ -250,7 +252,7 @@ void rko_sketch_refs(const char* bases, const uint64_t* offsets, int nref,
 
 /* -I path: src/rkmh.cpp:828-838 (counter incremented per k-mer occurrence: SURVEY Appendix C.7) */
 void rko_sketch_refs_maxsamples(const char* bases, const uint64_t* offsets, int nref,
-                                const int* ks, int nks, int S, int max_samples, uint64_t counter_slots,
+                                const int* ks, int nks, int S, int max_samples, uint64_t counter_slots, int distinct,
                                 uint64_t* sketches, int32_t* sketch_lens, const rko_policy* p, int threads) {
     (void)threads;
     rko_counter* c = rko_counter_new(counter_slots);
@@ -261,7 +263,17 @@ void rko_sketch_refs_maxsamples(const char* bases, const uint64_t* offsets, int 
         int len = (int)(offsets[i + 1] - offsets[i]);
         /* refs were upper-cased by parse_fastas (rkmh.cpp:252) */
         char* s = upper_copy(bases + offsets[i], len);
-        rko_calc_hashes_counted(s, len, ks, nks, &hs[i], &ns[i], c, p);
+        if (!distinct) rko_calc_hashes_counted(s, len, ks, nks, &hs[i], &ns[i], c, p);
+        else {
+            /* main_filter's hash_sequences, src/rkmh.cpp:343-355: std::set of the sample's hashes, one increment per member */
+            rko_calc_hashes(s, len, ks, nks, &hs[i], &ns[i], p);
+            uint64_t* tmp = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(ns[i] > 0 ? ns[i] : 1));
+            memcpy(tmp, hs[i], sizeof(uint64_t) * (size_t)ns[i]);
+            if (ns[i] > 0) qsort(tmp, (size_t)ns[i], sizeof(uint64_t), cmp_u64);
+            for (int j = 0; j < ns[i]; j++)
+                if (j == 0 || tmp[j] != tmp[j - 1]) rko_counter_increment(c, tmp[j]);
+            free(tmp);
+        }
         free(s);
     }
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic)

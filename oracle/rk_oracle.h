@@ -111,9 +111,10 @@ void rko_classify_stream_depth(const char* bases, const uint64_t* offsets, int64
                                int min_kmer_occ, uint64_t counter_slots,
                                int32_t* out4, const rko_policy* p, int threads);
 
-/* -I ref path rkmh.cpp:828-838 */
+/* -I ref path rkmh.cpp:828-838 (distinct = 0: counter per k-mer occurrence) and main_filter's variant
+ * rkmh.cpp:343-355 + 1211-1231 (distinct = 1: once per distinct hash per reference) */
 void rko_sketch_refs_maxsamples(const char* bases, const uint64_t* offsets, int nref,
-                                const int* ks, int nks, int S, int max_samples, uint64_t counter_slots,
+                                const int* ks, int nks, int S, int max_samples, uint64_t counter_slots, int distinct,
                                 uint64_t* sketches, int32_t* sketch_lens, const rko_policy* p, int threads);
 
 int rko_max_threads(void);

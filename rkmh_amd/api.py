@@ -66,6 +66,7 @@ _SIGS = {
     "rk_hash_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, _ip, C.c_int, C.POINTER(_u64p), _u64p]),
     "rk_sketch_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, _ip, C.c_int, C.c_int, _u64p, _i32p]),
     "rk_set_references": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.c_uint64]),
+    "rk_set_reference_count_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "rk_set_reference_sketches": (C.c_int, [C.c_void_p, _u64p, _i32p, C.c_int, _ip, C.c_int, C.c_int]),
     "rk_get_reference_sketches": (C.c_int, [C.c_void_p, _u64p, _i32p]),
     "rk_num_references": (C.c_int, [C.c_void_p]),
@@ -359,8 +360,9 @@ class Context:
                                        sketch_size, _p(sk, C.c_uint64), _p(ln, C.c_int32)))
         return sk, ln
 
-    def set_references(self, bases, offsets, ks, sketch_size, max_samples=None, counter_slots=0):
+    def set_references(self, bases, offsets, ks, sketch_size, max_samples=None, counter_slots=0, count_distinct=False):
         ks = _ks(ks)
+        _chk(self._lib.rk_set_reference_count_mode(self._h, 1 if count_distinct else 0))
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         _chk(self._lib.rk_set_references(self._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), len(offsets) - 1,
                                          _p(ks, C.c_int), len(ks), sketch_size,

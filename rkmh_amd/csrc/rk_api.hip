@@ -110,7 +110,8 @@ struct rk_ctx {
     rk_counter* depth = nullptr;
     int min_occ = 0;
     // workspaces for the general path
-    DevBuf w_bases, w_tiles, w_hashes, w_segoff, w_ids, w_sk, w_lens, w_out, w_misc, w_sel, w_selstate;
+    DevBuf w_bases, w_tiles, w_hashes, w_segoff, w_ids, w_sk, w_lens, w_out, w_misc, w_sel, w_selstate, w_table;
+    int ref_count_mode = 0; // -I counter fill: 0 per k-mer occurrence (stream), 1 once per distinct hash per reference (filter)
     Slot slot[2];
 };
 
@@ -145,7 +146,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
     for (DevBuf* b : {&c->d_fpb, &c->d_keys, &c->d_vals, &c->d_post, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
-                      &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate}) b->release();
+                      &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
         s.d_bases.release(); s.d_offs.release(); s.d_out.release();
@@ -186,6 +187,7 @@ struct GeneralCfg {
     KsArr ks;
     int S = 0;
     rk_counter* inc_counter = nullptr; // increment while hashing (6-arg calc_hashes)
+    rk_counter* distinct_counter = nullptr; // increment once per distinct hash per sequence (filter, rkmh.cpp:348-355)
     const rk_counter* filt_counter = nullptr;
     int filter_mode = FILTER_NONE, fmin = 0, fmax = 0;
     bool single_kmer = false;          // calc_hash(string): exactly one window of len bases per sequence
@@ -280,6 +282,17 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
                                  c->pol, c->st));
         if (out.hashes && !out.write_back_sorted && ch)
             HIPCHK(hipMemcpyAsync(out.hashes + hash_cursor, c->w_hashes.p, ch * 8, hipMemcpyDeviceToHost, c->st));
+        if (cfg.distinct_counter) {
+            for (int64_t q = 0; q < cn; ++q) {
+                const uint64_t n_h = seg[(size_t)q + 1] - seg[(size_t)q];
+                if (n_h == 0) continue;
+                uint64_t tsize = 1024;
+                while (tsize < 2 * n_h) tsize <<= 1;
+                RKCHK(c->w_table.reserve((tsize + 1) * 8));
+                HIPCHK(launch_count_distinct(c->w_hashes.as<uint64_t>() + seg[(size_t)q], n_h, c->w_table.as<uint64_t>(), tsize,
+                                             cfg.distinct_counter->d, cfg.distinct_counter->slots, c->st));
+            }
+        }
         if (need_sort) {
             const int S = cfg.S;
             if (out.sketches) RKCHK(c->w_sk.reserve((size_t)cn * S * 8));
@@ -653,7 +666,8 @@ extern "C" int rk_set_references(rk_ctx* c, const uint8_t* bases, const uint64_t
     if (max_samples >= 0) {
         // -I path (rkmh.cpp:828-838): pass 1 counts every k-mer occurrence, pass 2 sketches with the range filter
         RKCHK(rk_counter_create(c, counter_slots ? counter_slots : 200000000ull, &cnt));
-        GeneralCfg c1 = cfg; c1.inc_counter = cnt;
+        GeneralCfg c1 = cfg;
+        if (c->ref_count_mode == 1) c1.distinct_counter = cnt; else c1.inc_counter = cnt;
         GeneralOut none;
         int r = general_run(c, bases, nullptr, offsets, nref, c1, none);
         if (r != RK_OK) { rk_counter_destroy(cnt); return r; }
@@ -673,6 +687,12 @@ extern "C" int rk_get_reference_sketches(rk_ctx* c, uint64_t* sketches, int32_t*
     return RK_OK;
 }
 extern "C" int rk_num_references(const rk_ctx* c) { return c ? c->nref : 0; }
+
+extern "C" int rk_set_reference_count_mode(rk_ctx* c, int mode) {
+    if (!c || (mode != 0 && mode != 1)) return fail(RK_ERR_ARG, "mode must be 0 or 1");
+    c->ref_count_mode = mode;
+    return RK_OK;
+}
 
 extern "C" int rk_set_depth_filter(rk_ctx* c, rk_counter* counter, int min_kmer_occ) {
     if (!c) return fail(RK_ERR_ARG, "ctx is NULL");

@@ -395,6 +395,36 @@ hipError_t launch_mask_by_frequency(uint64_t* h, uint64_t n, const int32_t* coun
     return hipGetLastError();
 }
 
+// set<hash_t> sample_set(hashes...) ; for (x : sample_set) counter.increment(x)   (rkmh.cpp:348-355)
+// key 0 (the invalid-k-mer sentinel, a member of the set like any other value) is tracked by a flag word.
+__global__ __launch_bounds__(256) void k_count_distinct(const uint64_t* __restrict__ h, uint64_t n, unsigned long long* table,
+                                                        uint64_t tmask, int32_t* counter, uint64_t slots, unsigned int* zero_seen) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t v = h[i];
+        if (v == 0) {
+            if (atomicExch(zero_seen, 1u) == 0u) atomicAdd(&counter[0], 1);
+            continue;
+        }
+        uint64_t s = (v * 0x9E3779B97F4A7C15ull) >> 20 & tmask;
+        for (;;) {
+            const unsigned long long old = atomicCAS(&table[s], 0ull, (unsigned long long)v);
+            if (old == 0ull) { atomicAdd(&counter[v % slots], 1); break; }
+            if (old == v) break;
+            s = (s + 1) & tmask;
+        }
+    }
+}
+hipError_t launch_count_distinct(const uint64_t* hashes, uint64_t n, uint64_t* table, uint64_t tsize, int32_t* counter,
+                                 uint64_t slots, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(table, 0, (tsize + 1) * 8, st); // last word = the zero-seen flag
+    if (e != hipSuccess) return e;
+    uint32_t grid = (uint32_t)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_count_distinct, dim3(grid), dim3(256), 0, st, hashes, n, reinterpret_cast<unsigned long long*>(table),
+                       tsize - 1, counter, slots, reinterpret_cast<unsigned int*>(table + tsize));
+    return hipGetLastError();
+}
+
 __global__ void k_counter_inc(int32_t* counter, uint64_t slots, uint64_t key) { atomicAdd(&counter[key % slots], 1); }
 hipError_t launch_counter_inc(int32_t* counter, uint64_t slots, uint64_t key, hipStream_t st) {
     hipLaunchKernelGGL(k_counter_inc, dim3(1), dim3(1), 0, st, counter, slots, key);

@@ -68,6 +68,10 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
 hipError_t launch_max_len(const uint32_t* offs, uint32_t nreads, uint32_t* d_max, hipStream_t st);
 hipError_t launch_mask_by_frequency(uint64_t* h, uint64_t n, const int32_t* counter, uint64_t slots, int min_occ,
                                     const DevPolicy& pol, hipStream_t st);
+// increments counter[h % slots] once per DISTINCT hash of one sample (filter's hash_sequences, rkmh.cpp:348-355):
+// exact set semantics through a scratch open-addressing table of tsize (power of two, >= 2n) u64 slots, zeroed here
+hipError_t launch_count_distinct(const uint64_t* hashes, uint64_t n, uint64_t* table, uint64_t tsize, int32_t* counter,
+                                 uint64_t slots, hipStream_t st);
 hipError_t launch_counter_inc(int32_t* counter, uint64_t slots, uint64_t key, hipStream_t st);
 
 } // namespace rk

@@ -2,6 +2,7 @@
 //
 // Drop-in for the sub-commands of /root/reference/src/rkmh.cpp that sit on the classify/stream hot path:
 //   stream / classify   main_stream   (src/rkmh.cpp:584-989; classify forwards to it, :2744-2747)
+//   filter              main_filter   (src/rkmh.cpp:996-1424)
 //   hash                main_hash     (src/rkmh.cpp:1931-2116)
 // Same flags (option tables src/rkmh.cpp:626-650 and :1963-1983), same stdout line formats
 // (src/rkmh.cpp:892), but the per-read OpenMP loop is replaced by batches handed to the GPU while a
@@ -32,6 +33,7 @@ static void print_help() {
             "rkmh (MI355X build): MinHash read classification on AMD Instinct GPUs\n"
             "Usage: rkmh <command> [options]\n"
             "  classify / stream   classify reads against a set of references\n"
+            "  filter              print the reads that match a reference (or classify reads arriving on STDIN)\n"
             "  hash                print the k-mer hashes of every sequence\n"
             "Run a command without options for its help text.\n");
 }
@@ -200,6 +202,146 @@ static int main_stream(int argc, char** argv) {
     return 0;
 }
 
+// filter: main_filter, src/rkmh.cpp:996-1424.  Same sketches as stream; the decision is
+// classify_and_count_diff_filter (src/equiv.hpp:324-353): scan from max_shared = prev_best = 0, empty sample name.
+struct FilterDecision { int ref; int shared; bool diff_ok; };
+static FilterDecision filter_decide(const int32_t* r, int min_diff) {
+    FilterDecision d;
+    if (r[1] <= 0) { d.ref = -1; d.shared = 0; d.diff_ok = 0 > min_diff; return d; }
+    d.ref = r[0]; d.shared = r[1];
+    const int diff = r[2] - (r[0] == 0 ? 1 : 0); // the stream scan starts at -1, this one at 0
+    d.diff_ok = diff > min_diff;
+    return d;
+}
+static void help_filter() {
+    fprintf(stderr,
+            "rkmh filter -r <refs.fa> -f <reads.fq> [-k <k>]... [-s <sketch>] [-M n] [-I n] [-N n] [-D n] [-i]\n"
+            "  prints the reads (as >name / SEQ / + / QUAL) whose best reference passes the match and diff filters;\n"
+            "  -i then classifies reads arriving on STDIN and prints one 'Sample: ... Result: ...' line each\n");
+}
+
+static int main_filter(int argc, char** argv) {
+    Opts o;
+    bool in_stream = false;
+    if (argc <= 2) { help_filter(); exit(1); }
+    static struct option long_options[] = {
+        {"help", no_argument, 0, 'h'},           {"kmer", required_argument, 0, 'k'},
+        {"fasta", required_argument, 0, 'f'},    {"reference", required_argument, 0, 'r'},
+        {"sketch-size", required_argument, 0, 's'}, {"ref-sketch", required_argument, 0, 'S'},
+        {"threads", required_argument, 0, 't'},  {"min-kmer-occurence", required_argument, 0, 'M'},
+        {"min-matches", required_argument, 0, 'N'}, {"min-diff", required_argument, 0, 'D'},
+        {"max-samples", required_argument, 0, 'I'}, {"pre-reads", required_argument, 0, 'F'},
+        {"pre-references", required_argument, 0, 'R'}, {"read-kmer-map-file", required_argument, 0, 'p'},
+        {"ref-kmer-map-file", required_argument, 0, 'q'}, {"in-stream", no_argument, 0, 'i'},
+        {"device", required_argument, 0, 1000},  {0, 0, 0, 0}};
+    optind = 2;
+    int c;
+    while ((c = getopt_long(argc, argv, "hdk:f:r:s:S:t:M:N:I:R:F:p:q:iD:", long_options, nullptr)) != -1) {
+        switch (c) {
+            case 'F': case 'R': case 'p': case 'q': case 'S': break; // parsed, bodies empty (rkmh.cpp:1139-1151)
+            case 't': o.threads = atoi(optarg); break;
+            case 'r': o.refs.push_back(optarg); break;
+            case 'f': o.reads.push_back(optarg); break;
+            case 'k': o.ks.push_back(atoi(optarg)); break;
+            case 'N': o.min_matches = atoi(optarg); break;
+            case 'D': o.min_diff = atoi(optarg); break;
+            case 's': o.sketch = atoi(optarg); break;
+            case 'M': o.min_occ = atoi(optarg); o.read_depth = true; break;
+            case 'I': o.max_samples = atoi(optarg); o.ref_depth = true; break;
+            case 'i': in_stream = true; break;
+            case 1000: o.device = atoi(optarg); break;
+            case '?': case 'h': default: print_help(); exit(1);
+        }
+    }
+    if (o.ks.empty()) {
+        fprintf(stderr, "No kmer size(s) provided. Will use a default kmer size of 16.\n");
+        o.ks.push_back(16);
+    }
+    if (o.refs.empty()) { fprintf(stderr, "rkmh: at least one -r reference file is required\n"); exit(1); }
+    rk_ctx* ctx = nullptr;
+    CK(rk_ctx_create(o.device, nullptr, &ctx));
+    rk_seqset refs;
+    CK(rk_parse_files(o.refs.data(), (int)o.refs.size(), &refs));
+    if (refs.nseq < 1) { fprintf(stderr, "rkmh: no reference sequences found\n"); exit(1); }
+    // reference sketches: the sample-count filter applies when max_samples < 100000 (rkmh.cpp:1211); its counter is
+    // filled once per distinct hash per reference and only when -I was given (rkmh.cpp:1193, :348-355); 10 M slots (:1188)
+    CK(rk_set_reference_count_mode(ctx, 1));
+    const bool ref_filter = o.max_samples < 100000;
+    CK(rk_set_references(ctx, refs.bases, refs.offsets, (int)refs.nseq, o.ks.data(), (int)o.ks.size(), o.sketch,
+                         ref_filter ? o.max_samples : -1, 10000000ull));
+    std::vector<int32_t> ref_lens((size_t)refs.nseq);
+    {
+        std::vector<uint64_t> sk((size_t)refs.nseq * (size_t)o.sketch);
+        CK(rk_get_reference_sketches(ctx, sk.data(), ref_lens.data()));
+    }
+    rk_counter* cnt = nullptr;
+    CK(rk_counter_create(ctx, 10000000ull, &cnt)); // read_hash_counter, rkmh.cpp:1187
+    std::string buf;
+    std::vector<int32_t> out4;
+    if (!o.reads.empty()) {
+        rk_seqset reads;
+        CK(rk_parse_files(o.reads.data(), (int)o.reads.size(), &reads));
+        if (o.read_depth) {
+            CK(rk_count_batch(ctx, reads.bases, reads.offsets, reads.nseq, cnt)); // rkmh.cpp:321-338
+            CK(rk_set_depth_filter(ctx, cnt, o.min_occ));                          // keep get(h) >= min_kmer_occ, :1260
+        }
+        out4.resize((size_t)reads.nseq * 4);
+        CK(rk_classify_batch(ctx, reads.bases, reads.offsets, reads.nseq, out4.data()));
+        for (int64_t i = 0; i < reads.nseq; ++i) {
+            const int32_t* r = &out4[(size_t)i * 4];
+            const FilterDecision d = filter_decide(r, o.min_diff);
+            const bool depth_filter = r[3] <= 0, match_filter = d.shared < o.min_matches; // rkmh.cpp:1292-1293
+            if (depth_filter || match_filter || !d.diff_ok) continue;
+            buf += '>';
+            buf += reads.names + reads.name_offsets[i];
+            buf += '\n';
+            for (uint64_t j = reads.offsets[i]; j < reads.offsets[i + 1]; ++j) {
+                signed char ch = (signed char)reads.bases[j];
+                buf += (char)(((int)ch - 91) > 0 ? ch - 32 : ch); // to_upper as parse_fastas applies it (rkmh.cpp:280)
+            }
+            buf += "\n+\n";
+            if (reads.quals) buf.append(reads.quals + reads.offsets[i], (size_t)(reads.offsets[i + 1] - reads.offsets[i]));
+            buf += '\n';
+            if (buf.size() > (1u << 22)) { fwrite(buf.data(), 1, buf.size(), stdout); buf.clear(); }
+        }
+        fwrite(buf.data(), 1, buf.size(), stdout);
+        buf.clear();
+        rk_seqset_free(&reads);
+    }
+    if (in_stream) { // rkmh.cpp:1329-1408: reads from STDIN are classified, one line each
+        CK(rk_set_depth_filter(ctx, o.min_occ > 0 ? cnt : nullptr, o.min_occ)); // :1365
+        rk_reader* rd = nullptr;
+        CK(rk_reader_open("-", &rd));
+        char line[8192];
+        for (;;) {
+            rk_seqset s;
+            CK(rk_reader_next(rd, 1 << 18, 1ull << 27, &s));
+            if (s.nseq == 0) { rk_seqset_free(&s); break; }
+            out4.resize((size_t)s.nseq * 4);
+            CK(rk_classify_batch(ctx, s.bases, s.offsets, s.nseq, out4.data()));
+            for (int64_t i = 0; i < s.nseq; ++i) {
+                const int32_t* r = &out4[(size_t)i * 4];
+                const FilterDecision d = filter_decide(r, o.min_diff);
+                const int uni = d.ref < 0 ? 0 : (r[3] < ref_lens[(size_t)d.ref] ? r[3] : ref_lens[(size_t)d.ref]);
+                int n = snprintf(line, sizeof line, "Sample: %s\tResult: %s\t%d\t%d\t%s\t%s\t%s\n", s.names + s.name_offsets[i],
+                                 d.ref < 0 ? "" : refs.names + refs.name_offsets[d.ref], d.shared, uni, r[3] <= 0 ? "FAIL:DEPTH" : "",
+                                 d.shared < o.min_matches ? "FAIL:MATCHES" : "", d.diff_ok ? "" : "FAIL:DIFF");
+                if (n > 0) buf.append(line, (size_t)(n < (int)sizeof line ? n : (int)sizeof line - 1));
+            }
+            fwrite(buf.data(), 1, buf.size(), stdout);
+            buf.clear();
+            rk_seqset_free(&s);
+        }
+        rk_reader_close(rd);
+    }
+    fflush(stdout);
+    CK(rk_set_depth_filter(ctx, nullptr, 0));
+    rk_counter_destroy(cnt);
+    rk_seqset_free(&refs);
+    rk_ctx_destroy(ctx);
+    return 0;
+}
+
 static int main_hash(int argc, char** argv) {
     std::vector<const char*> files;
     std::vector<int> ks;
@@ -289,6 +431,7 @@ int main(int argc, char** argv) {
         return main_stream(argc, argv);
     }
     if (cmd == "hash") return main_hash(argc, argv);
+    if (cmd == "filter") return main_filter(argc, argv);
     print_help();
     exit(1);
 }

@@ -396,3 +396,62 @@ def test_long_sequences_radix_select(ctx, orc, pave):
     got = ctx.classify(_pad(qb), qo)
     want = orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=4)
     assert (got == want).all()
+
+
+def _filter_expect(orc, refs, reads, ks, S, min_occ=None, max_samples=None, min_matches=-1, min_diff=0):
+    rb, ro = orc.pack([orc.to_upper(x[1]) for x in refs])
+    qb, qo = orc.pack([x[1] for x in reads])
+    if max_samples is not None and max_samples < 100000:
+        sk, ln = orc.sketch_refs(rb, ro, ks, S, threads=4, max_samples=max_samples, counter_slots=10000000, distinct=True)
+    else:
+        sk, ln = orc.sketch_refs(rb, ro, ks, S, threads=4)
+    kw = {} if min_occ is None else dict(min_kmer_occ=min_occ, counter_slots=10000000)
+    rows = orc.classify_stream(qb, qo, ks, S, sk, ln, threads=4, **kw)
+    return rows, ln
+
+
+def test_cli_filter(orc, root, data_dir, tmp_path):
+    """rkmh filter (main_filter, rkmh.cpp:996-1424): passing reads in file mode, 'Sample:' lines in -i mode."""
+    from rkmh_amd import synth, api
+    exe = os.path.join(root, "bin", "rkmh")
+    refs = orc.kseq_parse_file(os.path.join(data_dir, "all_pave_ref.fa.gz"))[:60]
+    ref_fa = tmp_path / "refs.fa"
+    ref_fa.write_bytes(b"".join(b">" + r[0] + b" some comment\n" + r[1] + b"\n" for r in refs))
+    R = api.parse_files([str(ref_fa)])
+    qb, qo = synth.generate_reads(R["bases"], R["offsets"], 0, 400)
+    names = synth.read_names(0, 400)
+    rng = np.random.default_rng(3)
+    seqs = [bytes(qb[int(qo[i]): int(qo[i + 1])]) for i in range(400)]
+    for i in range(0, 400, 7):                       # some reads that match nothing, some lower case
+        seqs[i] = rand_dna(rng, 150)
+    seqs[5] = seqs[5].lower()
+    quals = [bytes(rng.integers(33, 74, size=150).astype(np.uint8).tolist()) for _ in range(400)]
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(b"".join(b"@" + names[i] + b"\n" + seqs[i] + b"\n+\n" + quals[i] + b"\n" for i in range(400)))
+    reads = [(names[i], seqs[i], quals[i]) for i in range(400)]
+    for flags, kw in (([], {}), (["-N", "8", "-D", "2"], dict(min_matches=8, min_diff=2)),
+                      (["-M", "2", "-N", "3"], dict(min_occ=2, min_matches=3)),
+                      (["-I", "2", "-D", "1"], dict(max_samples=2, min_diff=1))):
+        r = subprocess.run([exe, "filter", "-r", str(ref_fa), "-f", str(fq), "-k", "16", "-s", "1000"] + flags, capture_output=True)
+        assert r.returncode == 0, r.stderr
+        rows, _ = _filter_expect(orc, refs, reads, [16], 1000, min_occ=kw.get("min_occ"), max_samples=kw.get("max_samples"))
+        want = b""
+        npass = 0
+        for i in range(400):
+            ref, shared, diff_ok, ok = orc.filter_decision(rows[i], kw.get("min_matches", -1), kw.get("min_diff", 0))
+            if ok:
+                want += orc.filter_record(names[i], orc.to_upper(seqs[i]), quals[i])
+                npass += 1
+        assert 0 < npass < 400, (flags, npass)
+        assert r.stdout == want, flags
+    # -i: classify what arrives on STDIN (no -f): one line per read
+    r = subprocess.run([exe, "filter", "-r", str(ref_fa), "-k", "16", "-N", "4", "-i"], input=fq.read_bytes(), capture_output=True)
+    assert r.returncode == 0, r.stderr
+    rows, ln = _filter_expect(orc, refs, reads, [16], 1000)
+    want = ""
+    for i in range(400):
+        ref, shared, diff_ok, ok = orc.filter_decision(rows[i], 4, 0)
+        uni = 0 if ref is None else min(int(rows[i][3]), int(ln[ref]))
+        want += orc.filter_stdin_line(names[i].decode(), "" if ref is None else refs[ref][0].decode(), shared, uni, int(rows[i][3]),
+                                      diff_ok, min_matches=4)
+    assert r.stdout.decode() == want
