@@ -4,13 +4,15 @@ ARCH := gfx950
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result
 CSRC := rkmh_amd/csrc
 LIB := rkmh_amd/lib/librkmh_amd.so
-OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_api.o $(CSRC)/rk_parse.o $(CSRC)/rk_synth.o
+OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_call.o $(CSRC)/rk_api.o $(CSRC)/rk_parse.o $(CSRC)/rk_synth.o
 
 all: $(LIB) bin/rkmh oracle
 
 $(CSRC)/rk_kernels.o: $(CSRC)/rk_kernels.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/rk_classify.o: $(CSRC)/rk_classify.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/rk_call.o: $(CSRC)/rk_call.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/rk_api.o: $(CSRC)/rk_api.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp include/rkmh_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

@@ -160,6 +160,26 @@ int rk_classify_batch(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets
 int rk_classify_batch_device(rk_ctx* ctx, const void* d_bases, const void* d_offsets_u32, int64_t nreads,
                              void* d_out4, uint32_t max_read_len, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * `call` (main_call, src/rkmh.cpp:1455-1904): k-mer depth map of the reads, sliding-window mean depth along the
+ * references (window NOT reset between references, as a single-threaded run of src/rkmh.cpp:1769-1791), and at
+ * every position whose depth is below half that mean the 3k SNP and k one-base-deletion k-mers are hashed and
+ * looked up; every candidate passing the tests of :1814 / :1853 comes back as one record (rk_free the array).
+ * The caller aggregates records into VCF rows (KC/MD/RD/OD, :1821-1829) -- see rkmh_main.cpp. */
+typedef struct rk_call_record {
+    int32_t ref;        /* reference index */
+    int32_t pos;        /* j + alt_pos + 1 (src/rkmh.cpp:1815, :1855) */
+    int32_t alt_depth;  /* depth of the rescue k-mer */
+    int32_t avg_d;      /* truncated window mean at the position */
+    int32_t depth;      /* depth of the original k-mer */
+    uint8_t orig, alt;  /* reference base, alternative base ('-' for a deletion) */
+    uint8_t kind;       /* 0 SNP, 1 deletion */
+    uint8_t pad;
+} rk_call_record;
+int rk_call(rk_ctx* ctx, const uint8_t* ref_bases, const uint64_t* ref_offsets, int nref,
+            const uint8_t* read_bases, const uint64_t* read_offsets, int64_t nreads, int k, int window_len,
+            rk_call_record** out, int64_t* nout);
+
 /* Formats one stdout line of stream/classify exactly as src/rkmh.cpp:887-893. Returns bytes written
  * (excluding NUL) or a negative error if cap is too small. */
 int rk_format_stream_line(char* dst, size_t cap, const char* ref_name, const char* read_name,

@@ -291,3 +291,64 @@ def filter_stdin_line(name, ref_name, shared, union, nmins, diff_ok, min_matches
     return "Sample: %s\tResult: %s\t%d\t%d\t%s\t%s\t%s\n" % (
         name, ref_name, shared, union, "FAIL:DEPTH" if nmins <= 0 else "",
         "FAIL:MATCHES" if shared < min_matches else "", "" if diff_ok else "FAIL:DIFF")
+
+
+# ---------------------------------------------------------------------------------------------
+# main_call (/root/reference/src/rkmh.cpp:1455-1904), single-threaded semantics, restated literally
+# (pure Python: small inputs only).  Returns the VCF text the reference prints with default flags.
+# ---------------------------------------------------------------------------------------------
+CALL_HEADER = ("##fileformat=VCF4.2\n##source=rkmh\n##reference=%s\n"
+               "##INFO=<ID=KD,Number=1,Type=Integer,Description=\"Number of times call for specific kmer appears\">\n"
+               "##INFO=<ID=MD,Number=1,Type=Integer,Description=\"Maximum depth found for the rescue kmer.\">\n"
+               "##INFO=<ID=RD,Number=1,Type=Integer,Description=\"Average depth in region\">"
+               "##INFO=<ID=OD,Number=1,Type=Integer,Description=\"Depth of original kmer at site before modification.\">\n")
+_SNP_ALTS = {ord("A"): b"CTG", ord("C"): b"TGA", ord("T"): b"CGA", ord("G"): b"ACT"}   # rkmh.cpp:1634-1637
+
+
+def call_rows(ref_names, ref_seqs, read_seqs, k, window_len=100, policy=None):
+    """ref_seqs / read_seqs: raw bytes (upper-cased here as rkmh.cpp:1609,1614 do). -> sorted list of VCF row strings."""
+    from collections import Counter
+    policy = policy or default_policy()
+    depth_map = Counter()
+    for r in read_seqs:                                            # rkmh.cpp:1613-1622
+        for h in calc_hashes(to_upper(r), [k], policy):
+            depth_map[int(h)] += 1
+    cc, cmax, cavg, corig = {}, {}, {}, {}
+    d_window = []                                                  # thread-private, NOT reset between refs (:1769)
+    for name, raw in zip(ref_names, ref_seqs):
+        seq = to_upper(raw)
+        hashes = calc_hashes(seq, [k], policy)
+        for j in range(len(hashes)):
+            depth = depth_map.get(int(hashes[j]), 0)
+            d_window.append(depth)
+            if len(d_window) > window_len:
+                d_window.pop(0)
+            avg_d = int(float(sum(d_window)) / float(len(d_window)))   # double -> int, :1791
+            if depth < 0.5 * avg_d:                                # :1801
+                ref = bytearray(seq[j:j + k])
+                d_alt = seq[j - 1:j + k] if j > 0 else b""
+                for alt_pos in range(k):                           # SNPs, :1807-1840
+                    orig = ref[alt_pos]
+                    for x in _SNP_ALTS.get(orig, b""):
+                        alt = bytearray(ref)
+                        alt[alt_pos] = x
+                        alt_depth = depth_map.get(calc_hash(bytes(alt), policy), 0)
+                        if (alt_depth >= 0.1 * avg_d) & (alt_depth > depth):
+                            key = "%s\t%d\t.\t%s\t%s" % (name, j + alt_pos + 1, chr(orig), chr(x))
+                            cc[key] = cc.get(key, 0) + 1
+                            cavg[key] = max(avg_d, cavg.get(key, 0))
+                            corig[key] = max(corig.get(key, 0), depth)
+                            cmax[key] = max(cmax.get(key, 0), alt_depth)
+                if j > 0:                                          # deletions, :1847-1865
+                    for alt_pos in range(1, len(d_alt)):
+                        orig = d_alt[alt_pos]
+                        mod = d_alt[:alt_pos] + d_alt[alt_pos + 1:]
+                        alt_depth = depth_map.get(calc_hash(mod, policy), 0)
+                        if alt_depth > 0.9 * avg_d:
+                            key = "%s\t%d\t.\t%s\t-" % (name, j + alt_pos + 1, chr(orig))
+                            cc[key] = cc.get(key, 0) + 1
+                            cavg[key] = max(cavg.get(key, 0), avg_d)
+                            corig[key] = max(corig.get(key, 0), depth)
+                            cmax[key] = max(cmax.get(key, 0), alt_depth)
+    return ["%s\t99\tPASS\tKC=%d;MD=%d;RD=%d;OD=%d\n" % (key, cc[key], cmax[key], cavg[key], corig[key])
+            for key in sorted(cc, key=lambda s: s.encode())]     # std::map<string,...>: byte-wise order

@@ -25,6 +25,11 @@ class Policy(C.Structure):
                 ("mask_strict_less", C.c_int32), ("freq_max_inclusive", C.c_int32), ("seed", C.c_uint32)]
 
 
+class CallRecord(C.Structure):
+    _fields_ = [("ref", C.c_int32), ("pos", C.c_int32), ("alt_depth", C.c_int32), ("avg_d", C.c_int32), ("depth", C.c_int32),
+                ("orig", C.c_uint8), ("alt", C.c_uint8), ("kind", C.c_uint8), ("pad", C.c_uint8)]
+
+
 class SeqSet(C.Structure):
     _fields_ = [("nseq", C.c_int64), ("bases", C.POINTER(C.c_uint8)), ("offsets", C.POINTER(C.c_uint64)),
                 ("names", C.POINTER(C.c_char)), ("name_offsets", C.POINTER(C.c_uint64)),
@@ -75,6 +80,7 @@ _SIGS = {
     "rk_count_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "rk_classify_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, _i32p]),
     "rk_classify_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rk_call": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int, _u8p, _u64p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.POINTER(CallRecord)), C.POINTER(C.c_int64)]),
     "rk_format_stream_line": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rk_parse_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.POINTER(SeqSet)]),
     "rk_seqset_free": (None, [C.POINTER(SeqSet)]),
@@ -403,6 +409,20 @@ class Context:
     @property
     def stream(self):
         return int(self._lib.rk_ctx_stream(self._h) or 0)
+
+    def call(self, ref_bases, ref_offsets, read_bases, read_offsets, k, window_len=100):
+        """main_call's candidate records (rkmh.cpp:1772-1865): list of dicts, one per passing SNP / deletion k-mer."""
+        ref_offsets = np.ascontiguousarray(ref_offsets, dtype=np.uint64)
+        read_offsets = np.ascontiguousarray(read_offsets, dtype=np.uint64)
+        out = C.POINTER(CallRecord)()
+        n = C.c_int64()
+        _chk(self._lib.rk_call(self._h, _p(ref_bases, C.c_uint8), _p(ref_offsets, C.c_uint64), len(ref_offsets) - 1,
+                               _p(read_bases, C.c_uint8), _p(read_offsets, C.c_uint64), len(read_offsets) - 1, k, window_len,
+                               C.byref(out), C.byref(n)))
+        recs = [dict(ref=out[i].ref, pos=out[i].pos, alt_depth=out[i].alt_depth, avg_d=out[i].avg_d, depth=out[i].depth,
+                     orig=chr(out[i].orig), alt=chr(out[i].alt), kind=out[i].kind) for i in range(n.value)]
+        self._lib.rk_free(out)
+        return recs
 
     def classify_device(self, d_bases_ptr, d_offsets_ptr, nreads, d_out_ptr, max_read_len=0, stream=None):
         """Same with inputs resident in HBM (raw device pointers, e.g. torch tensors' data_ptr()).

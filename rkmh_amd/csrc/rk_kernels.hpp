@@ -47,6 +47,25 @@ struct SortArgs {
     const uint32_t* sel_len;
 };
 
+// ---- `call` sub-command (rk_call.hip) ----
+struct DepthTable {            // exact hash -> occurrence count map in HBM (read_hash_to_depth, rkmh.cpp:1619-1621)
+    uint64_t* keys;            // [mask+1], 0 = empty
+    uint32_t* counts;          // [mask+1]
+    uint32_t* zero_count;      // occurrences of hash 0 (the invalid-k-mer sentinel is a key like any other)
+    uint64_t mask;
+};
+struct CallRecord {            // one candidate that passed the depth tests of rkmh.cpp:1814 / :1853
+    int32_t ref, pos, alt_depth, avg_d, depth;
+    uint8_t orig, alt, kind, pad;   // kind 0 = SNP, 1 = deletion (alt = '-')
+};
+hipError_t launch_depth_insert(const uint64_t* h, uint64_t n, const DepthTable& t, hipStream_t st);
+hipError_t launch_depth_lookup(const uint64_t* h, uint64_t n, const DepthTable& t, int32_t* depth, hipStream_t st);
+hipError_t launch_exclusive_scan(const int32_t* in, uint64_t n, int64_t* out, int64_t* scratch, hipStream_t st);
+hipError_t launch_call_enumerate(const uint8_t* ref_upper, const uint64_t* ref_off, const uint64_t* win_off, int nref,
+                                 uint64_t nwin_total, const int32_t* depth, const int64_t* prefix, int k, int window_len,
+                                 const DepthTable& t, const DevPolicy& pol, CallRecord* out, uint32_t* out_count, uint32_t out_cap,
+                                 hipStream_t st);
+
 hipError_t launch_to_upper(uint8_t* d, uint64_t n, hipStream_t st);
 hipError_t launch_hash_tiles(const uint8_t* bases, const TileDesc* tiles, uint32_t ntiles, uint64_t* out,
                              int32_t* counter, uint64_t slots, const DevPolicy& pol, hipStream_t st);

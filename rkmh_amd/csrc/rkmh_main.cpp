@@ -3,6 +3,7 @@
 // Drop-in for the sub-commands of /root/reference/src/rkmh.cpp that sit on the classify/stream hot path:
 //   stream / classify   main_stream   (src/rkmh.cpp:584-989; classify forwards to it, :2744-2747)
 //   filter              main_filter   (src/rkmh.cpp:996-1424)
+//   call                main_call     (src/rkmh.cpp:1455-1904)
 //   hash                main_hash     (src/rkmh.cpp:1931-2116)
 // Same flags (option tables src/rkmh.cpp:626-650 and :1963-1983), same stdout line formats
 // (src/rkmh.cpp:892), but the per-read OpenMP loop is replaced by batches handed to the GPU while a
@@ -34,6 +35,7 @@ static void print_help() {
             "Usage: rkmh <command> [options]\n"
             "  classify / stream   classify reads against a set of references\n"
             "  filter              print the reads that match a reference (or classify reads arriving on STDIN)\n"
+            "  call                call SNPs / 1-bp deletions from k-mer depth along a reference\n"
             "  hash                print the k-mer hashes of every sequence\n"
             "Run a command without options for its help text.\n");
 }
@@ -342,6 +344,94 @@ static int main_filter(int argc, char** argv) {
     return 0;
 }
 
+// call: main_call, src/rkmh.cpp:1455-1904.  The GPU returns one record per candidate k-mer that passed the depth
+// tests; the VCF rows are the records aggregated by (ref, pos, orig, alt) exactly as rkmh.cpp:1821-1829 / :1856-1863.
+static void help_call() {
+    fprintf(stderr,
+            "rkmh call -r <ref.fa> -f <reads.fq> [-k <k>] [-w <window>]\n"
+            "  calls SNPs and 1-bp deletions from the k-mer depth of the reads along the reference (VCF-like rows)\n");
+}
+#include <map>
+static int main_call(int argc, char** argv) {
+    std::vector<const char*> refs, reads;
+    std::vector<int> ks;
+    int window_len = 100, device = 0;
+    bool show_depth = false;
+    if (argc <= 2) { help_call(); exit(1); }
+    static struct option long_options[] = {
+        {"help", no_argument, 0, 'h'},        {"kmer", required_argument, 0, 'k'},
+        {"fasta", required_argument, 0, 'f'}, {"reference", required_argument, 0, 'r'},
+        {"sketch", required_argument, 0, 's'}, {"threads", required_argument, 0, 't'},
+        {"window-len", required_argument, 0, 'w'}, {"show-depth", no_argument, 0, 'd'},
+        {"device", required_argument, 0, 1000}, {0, 0, 0, 0}};
+    optind = 2;
+    int c;
+    while ((c = getopt_long(argc, argv, "hdk:f:r:s:t:w:", long_options, nullptr)) != -1) {
+        switch (c) {
+            case 'r': refs.push_back(optarg); break;
+            case 'f': reads.push_back(optarg); break;
+            case 'k': ks.push_back(atoi(optarg)); break;
+            case 'w': window_len = atoi(optarg); break;
+            case 'd': show_depth = true; break;             // sets show_depth, clears output_vcf: prints nothing (Appendix A.3)
+            case 's': case 't': break;                        // parsed, unused
+            case 1000: device = atoi(optarg); break;
+            case '?': case 'h': default: print_help(); exit(1);
+        }
+    }
+    if (ks.empty()) {
+        fprintf(stderr, "No kmer size(s) provided. Will use a default kmer size of 16.\n");
+        ks.push_back(16);
+    } else if (ks.size() > 1) {                               // rkmh.cpp:1543-1552
+        fprintf(stderr, "Only a single kmer size may be used for calling.\nSizes provided: ");
+        for (int k : ks) fprintf(stderr, "%d ", k);
+        fprintf(stderr, "\nPlease choose a single kmer size.\n");
+        exit(1);
+    }
+    fprintf(stderr, "Parsing sequences...\n");
+    if (refs.empty()) {
+        fprintf(stderr, "No references were provided. Please provide at least one reference file in fasta/fastq format.\n");
+        help_call(); exit(1);
+    }
+    if (reads.empty()) {
+        fprintf(stderr, "No reads were provided. Please provide at least one read file in fasta/fastq format.\n");
+        help_call(); exit(1);
+    }
+    rk_seqset R, Q;
+    CK(rk_parse_files(refs.data(), (int)refs.size(), &R));
+    CK(rk_parse_files(reads.data(), (int)reads.size(), &Q));
+    if (R.nseq < 1) { fprintf(stderr, "rkmh: no reference sequences found\n"); exit(1); }
+    if (R.nseq > 1) fprintf(stderr, "WARNING: more than one ref provided. VCF will not be correct\n");
+    if (show_depth) return 0;
+    rk_ctx* ctx = nullptr;
+    CK(rk_ctx_create(device, nullptr, &ctx));
+    rk_call_record* rec = nullptr;
+    int64_t nrec = 0;
+    CK(rk_call(ctx, R.bases, R.offsets, (int)R.nseq, Q.bases, Q.offsets, Q.nseq, ks[0], window_len, &rec, &nrec));
+    printf("##fileformat=VCF4.2\n##source=rkmh\n##reference=%s\n"
+           "##INFO=<ID=KD,Number=1,Type=Integer,Description=\"Number of times call for specific kmer appears\">\n"
+           "##INFO=<ID=MD,Number=1,Type=Integer,Description=\"Maximum depth found for the rescue kmer.\">\n"
+           "##INFO=<ID=RD,Number=1,Type=Integer,Description=\"Average depth in region\">"
+           "##INFO=<ID=OD,Number=1,Type=Integer,Description=\"Depth of original kmer at site before modification.\">\n", refs[0]);
+    struct Agg { int kc = 0, md = 0, rd = 0, od = 0; };
+    std::map<std::string, Agg> rows; // lexicographic key order, as the reference's std::map (rkmh.cpp:1885)
+    char key[4096];
+    for (int64_t i = 0; i < nrec; ++i) {
+        const rk_call_record& r = rec[i];
+        snprintf(key, sizeof key, "%s\t%d\t.\t%c\t%c", R.names + R.name_offsets[r.ref], r.pos, (char)r.orig, (char)r.alt);
+        Agg& a = rows[key];
+        a.kc += 1;
+        if (r.alt_depth > a.md) a.md = r.alt_depth;
+        if (r.avg_d > a.rd) a.rd = r.avg_d;
+        if (r.depth > a.od) a.od = r.depth;
+    }
+    for (auto& kv : rows) printf("%s\t99\tPASS\tKC=%d;MD=%d;RD=%d;OD=%d\n", kv.first.c_str(), kv.second.kc, kv.second.md, kv.second.rd, kv.second.od);
+    fflush(stdout);
+    rk_free(rec);
+    rk_seqset_free(&R); rk_seqset_free(&Q);
+    rk_ctx_destroy(ctx);
+    return 0;
+}
+
 static int main_hash(int argc, char** argv) {
     std::vector<const char*> files;
     std::vector<int> ks;
@@ -432,6 +522,7 @@ int main(int argc, char** argv) {
     }
     if (cmd == "hash") return main_hash(argc, argv);
     if (cmd == "filter") return main_filter(argc, argv);
+    if (cmd == "call") return main_call(argc, argv);
     print_help();
     exit(1);
 }

@@ -455,3 +455,63 @@ def test_cli_filter(orc, root, data_dir, tmp_path):
         want += orc.filter_stdin_line(names[i].decode(), "" if ref is None else refs[ref][0].decode(), shared, uni, int(rows[i][3]),
                                       diff_ok, min_matches=4)
     assert r.stdout.decode() == want
+
+
+def _call_fixture(orc, data_dir, tmp_path, cov=40, seed=5):
+    """C5-like input: reads drawn from HPV16 carrying planted SNPs and 1-bp deletions, 0.5 % substitution noise."""
+    rec = orc.kseq_parse_file(os.path.join(data_dir, "hpv_16.fa.gz"))[0]
+    ref = bytearray(orc.to_upper(rec[1]))
+    rng = np.random.default_rng(seed)
+    mut = bytearray(ref)
+    for pos, alt in ((500, b"A"), (1200, b"C"), (2503, b"G"), (4000, b"T"), (6100, b"A")):
+        mut[pos] = alt[0] if mut[pos] != alt[0] else b"ACGT"[(b"ACGT".index(alt) + 1) % 4]
+    for pos in (7000, 3100):
+        del mut[pos]
+    n = cov * len(ref) // 150
+    reads = []
+    for _ in range(n):
+        st = int(rng.integers(0, len(mut) - 150))
+        r = bytearray(mut[st:st + 150])
+        for j in np.nonzero(rng.random(150) < 0.005)[0]:
+            r[j] = b"ACGT"[int(rng.integers(0, 4))]
+        if rng.random() < 0.5:
+            r = bytearray(bytes(r).translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1])
+        reads.append(bytes(r))
+    fa = tmp_path / "ref.fa"
+    fa.write_bytes(b">" + rec[0] + b"\n" + rec[1] + b"\n")
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads)))
+    return rec, reads, fa, fq
+
+
+def test_call_matches_oracle(ctx, orc, root, data_dir, tmp_path):
+    """rkmh call (main_call, rkmh.cpp:1455-1904): VCF rows identical to the literal single-threaded restatement."""
+    exe = os.path.join(root, "bin", "rkmh")
+    rec, reads, fa, fq = _call_fixture(orc, data_dir, tmp_path)
+    for k, w in ((12, 100), (16, 30)):
+        r = subprocess.run([exe, "call", "-r", str(fa), "-f", str(fq), "-k", str(k), "-w", str(w)], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert b"Parsing sequences..." in r.stderr
+        rows = orc.call_rows([rec[0].decode()], [rec[1]], reads, k, w)
+        want = orc.CALL_HEADER % str(fa) + "".join(rows)
+        assert r.stdout.decode() == want, (k, w)
+        assert len(rows) >= 5
+    # the planted variants are found (sanity of the workload, not of parity)
+    assert any("\t501\t" in x or "\t1201\t" in x for x in rows)
+    # two references: the depth window carries over from one to the next (Appendix C.9); records through the C ABI
+    refs2 = [(b"partA", rec[1][:3000]), (b"partB", rec[1][2500:6000])]
+    rb, ro = orc.pack([x[1] for x in refs2])
+    qb, qo = orc.pack(reads)
+    got = ctx.call(_pad(rb), ro, _pad(qb), qo, 12, 50)
+    agg = {}
+    for g in got:
+        key = "%s\t%d\t.\t%s\t%s" % (refs2[g["ref"]][0].decode(), g["pos"], g["orig"], g["alt"])
+        a = agg.setdefault(key, [0, 0, 0, 0])
+        a[0] += 1; a[1] = max(a[1], g["alt_depth"]); a[2] = max(a[2], g["avg_d"]); a[3] = max(a[3], g["depth"])
+    mine = ["%s\t99\tPASS\tKC=%d;MD=%d;RD=%d;OD=%d\n" % (k_, *agg[k_]) for k_ in sorted(agg, key=lambda s: s.encode())]
+    assert mine == orc.call_rows([x[0].decode() for x in refs2], [x[1] for x in refs2], reads, 12, 50)
+    # argument checks of the CLI
+    r = subprocess.run([exe, "call", "-r", str(fa), "-f", str(fq), "-k", "12", "-k", "16"], capture_output=True)
+    assert r.returncode == 1 and b"Only a single kmer size may be used for calling." in r.stderr
+    r = subprocess.run([exe, "call", "-r", str(fa), "-f", str(fq), "-k", "12", "-d"], capture_output=True)
+    assert r.returncode == 0 and r.stdout == b""
