@@ -37,6 +37,7 @@ static void print_help() {
             "  filter              print the reads that match a reference (or classify reads arriving on STDIN)\n"
             "  call                call SNPs / 1-bp deletions from k-mer depth along a reference\n"
             "  hash                print the k-mer hashes of every sequence\n"
+            "  sketch              write MinHash sketches as JSON (load them with stream -R)\n"
             "Run a command without options for its help text.\n");
 }
 static void help_stream() {
@@ -110,8 +111,12 @@ static void emit_lines(const rk_seqset& refs, const rk_seqset& reads, const int3
     fwrite(buf.data(), 1, buf.size(), stdout);
 }
 
+struct LoadedSketches { std::vector<std::string> names; std::vector<uint64_t> sk; std::vector<int32_t> lens; std::vector<int> ks; int S = 0; };
+static bool load_sketch_json(const char* path, LoadedSketches& L);
+
 static int main_stream(int argc, char** argv) {
     Opts o;
+    const char* pre_refs = nullptr;
     if (argc <= 2) { help_stream(); exit(1); }
     static struct option long_options[] = {
         {"help", no_argument, 0, 'h'},           {"kmer", required_argument, 0, 'k'},
@@ -129,7 +134,8 @@ static int main_stream(int argc, char** argv) {
     while ((c = getopt_long(argc, argv, "zmhdk:f:r:s:S:t:M:N:I:R:F:p:q:iD:", long_options, nullptr)) != -1) {
         switch (c) {
             case 'm': case 'i': case 'z': break;                 // parsed and ignored, rkmh.cpp:656-658,709-714
-            case 'F': case 'R': case 'p': case 'q': case 'S': break; // parsed, bodies empty in the reference (:659-670,:697-700)
+            case 'R': pre_refs = optarg; break;               // pre-hashed references: parsed but unimplemented in the reference (:662-664)
+            case 'F': case 'p': case 'q': case 'S': break; // parsed, bodies empty in the reference (:659-670,:697-700)
             case 't': o.threads = atoi(optarg); break;
             case 'r': o.refs.push_back(optarg); break;
             case 'f': o.reads.push_back(optarg); break;
@@ -143,19 +149,36 @@ static int main_stream(int argc, char** argv) {
             case '?': case 'h': default: print_help(); exit(1);
         }
     }
+    LoadedSketches pre;
+    if (pre_refs) {
+        if (!load_sketch_json(pre_refs, pre)) { fprintf(stderr, "rkmh: cannot load sketches from %s\n", pre_refs); exit(1); }
+        o.ks = pre.ks; o.sketch = pre.S;
+    }
     if (o.ks.empty()) {
         fprintf(stderr, "No kmer size(s) provided. Will use a default kmer size of 16.\n"); // rkmh.cpp:729
         o.ks.push_back(16);
     }
-    if (o.refs.empty()) { fprintf(stderr, "rkmh: at least one -r reference file is required\n"); exit(1); }
+    if (o.refs.empty() && !pre_refs) { fprintf(stderr, "rkmh: at least one -r reference file (or -R sketches) is required\n"); exit(1); }
 
     rk_ctx* ctx = nullptr;
     CK(rk_ctx_create(o.device, nullptr, &ctx));
     rk_seqset refs;
-    CK(rk_parse_files(o.refs.data(), (int)o.refs.size(), &refs));
-    if (refs.nseq < 1) { fprintf(stderr, "rkmh: no reference sequences found\n"); exit(1); }
-    CK(rk_set_references(ctx, refs.bases, refs.offsets, (int)refs.nseq, o.ks.data(), (int)o.ks.size(), o.sketch,
-                         o.ref_depth ? o.max_samples : -1, 0));
+    memset(&refs, 0, sizeof refs);
+    std::string pre_names;
+    std::vector<uint64_t> pre_noff;
+    if (pre_refs) { // names come from the JSON file; emit_lines only needs names + name_offsets
+        pre_noff.push_back(0);
+        for (auto& nm : pre.names) { pre_names += nm; pre_names += '\0'; pre_noff.push_back(pre_names.size()); }
+        refs.nseq = (int64_t)pre.names.size();
+        refs.names = &pre_names[0];
+        refs.name_offsets = pre_noff.data();
+        CK(rk_set_reference_sketches(ctx, pre.sk.data(), pre.lens.data(), (int)pre.lens.size(), o.ks.data(), (int)o.ks.size(), o.sketch));
+    } else {
+        CK(rk_parse_files(o.refs.data(), (int)o.refs.size(), &refs));
+        if (refs.nseq < 1) { fprintf(stderr, "rkmh: no reference sequences found\n"); exit(1); }
+        CK(rk_set_references(ctx, refs.bases, refs.offsets, (int)refs.nseq, o.ks.data(), (int)o.ks.size(), o.sketch,
+                             o.ref_depth ? o.max_samples : -1, 0));
+    }
     std::string buf;
     std::vector<int32_t> out4;
     if (o.read_depth) {
@@ -199,7 +222,7 @@ static int main_stream(int argc, char** argv) {
         if (!q.err.empty()) { fprintf(stderr, "rkmh: %s\n", q.err.c_str()); exit(1); }
     }
     fflush(stdout);
-    rk_seqset_free(&refs);
+    if (!pre_refs) rk_seqset_free(&refs);
     rk_ctx_destroy(ctx);
     return 0;
 }
@@ -432,6 +455,153 @@ static int main_call(int argc, char** argv) {
     return 0;
 }
 
+// ---- JSON sketches (the schema of dump_hash_json, src/rkmh.cpp:489-525; dead code in the reference, kept here as the
+// interchange format SURVEY.md section 8f ranks next).  Keys are emitted in the alphabetical order nlohmann::json uses.
+static void json_escape(std::string& out, const char* s) {
+    for (; *s; ++s) {
+        unsigned char ch = (unsigned char)*s;
+        if (ch == '"' || ch == '\\') { out += '\\'; out += (char)ch; }
+        else if (ch < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", ch); out += b; }
+        else out += (char)ch;
+    }
+}
+static void help_sketch() {
+    fprintf(stderr,
+            "rkmh sketch -f <seqs.fa|fq> [-k <k>]... [-s <sketch>] [-o <out.json>]\n"
+            "  writes a JSON array with one MinHash sketch per sequence (schema of the reference's dump_hash_json);\n"
+            "  `rkmh stream -R <out.json>` loads it instead of sketching references again\n");
+}
+static int main_sketch(int argc, char** argv) {
+    std::vector<const char*> files;
+    std::vector<int> ks;
+    int S = 1000, device = 0;
+    const char* outp = nullptr;
+    if (argc <= 2) { help_sketch(); exit(1); }
+    optind = 2;
+    int c;
+    static struct option long_options[] = {{"help", no_argument, 0, 'h'}, {"kmer", required_argument, 0, 'k'},
+        {"fasta", required_argument, 0, 'f'}, {"reference", required_argument, 0, 'r'}, {"sketch-size", required_argument, 0, 's'},
+        {"output", required_argument, 0, 'o'}, {"device", required_argument, 0, 1000}, {0, 0, 0, 0}};
+    while ((c = getopt_long(argc, argv, "hk:f:r:s:o:t:", long_options, nullptr)) != -1) {
+        switch (c) {
+            case 'f': case 'r': files.push_back(optarg); break;
+            case 'k': ks.push_back(atoi(optarg)); break;
+            case 's': S = atoi(optarg); break;
+            case 'o': outp = optarg; break;
+            case 't': break;
+            case 1000: device = atoi(optarg); break;
+            default: help_sketch(); exit(1);
+        }
+    }
+    if (ks.empty()) { fprintf(stderr, "No kmer size(s) provided. Will use a default kmer size of 16.\n"); ks.push_back(16); }
+    if (files.empty()) { fprintf(stderr, "rkmh: -f <file> is required\n"); exit(1); }
+    rk_ctx* ctx = nullptr;
+    CK(rk_ctx_create(device, nullptr, &ctx));
+    rk_seqset s;
+    CK(rk_parse_files(files.data(), (int)files.size(), &s));
+    std::vector<uint64_t> sk((size_t)s.nseq * (size_t)S);
+    std::vector<int32_t> lens((size_t)s.nseq);
+    CK(rk_sketch_batch(ctx, s.bases, s.offsets, s.nseq, ks.data(), (int)ks.size(), S, sk.data(), lens.data()));
+    FILE* fo = outp ? fopen(outp, "w") : stdout;
+    if (!fo) { fprintf(stderr, "rkmh: cannot write %s\n", outp); exit(1); }
+    std::string kstr;
+    for (size_t i = 0; i < ks.size(); ++i) { kstr += std::to_string(ks[i]); if (i + 1 < ks.size()) kstr += ' '; }
+    std::string o = "[";
+    char num[32];
+    for (int64_t i = 0; i < s.nseq; ++i) {
+        std::string name;
+        json_escape(name, s.names + s.name_offsets[i]);
+        if (i) o += ',';
+        o += "{\"alphabet\":\"ATGC\",\"canonical\":\"true\",\"hashBits\":64,\"hashSeed\":42,\"hashType\":\"MurmurHash3_x64_128\",\"kmer\":\"" + kstr +
+             "\",\"name\":\"" + name + "\",\"preserveCase\":\"false\",\"seqLen\":" + std::to_string(s.offsets[i + 1] - s.offsets[i]) +
+             ",\"sketches\":{\"comment\":\"\",\"hashes\":[";
+        for (int j = 0; j < lens[(size_t)i]; ++j) {
+            int n = snprintf(num, sizeof num, j ? ",%llu" : "%llu", (unsigned long long)sk[(size_t)i * S + j]);
+            o.append(num, (size_t)n);
+        }
+        o += "],\"length\":" + std::to_string(S) + ",\"name\":\"" + name + "\"}}";
+        if (o.size() > (1u << 22)) { fwrite(o.data(), 1, o.size(), fo); o.clear(); }
+    }
+    o += "]\n";
+    fwrite(o.data(), 1, o.size(), fo);
+    if (fo != stdout) fclose(fo);
+    rk_seqset_free(&s);
+    rk_ctx_destroy(ctx);
+    return 0;
+}
+
+// minimal reader for the files written above (tolerates whitespace; no general JSON support is claimed)
+static bool json_find(const std::string& t, size_t from, size_t to, const char* key, size_t& vpos) {
+    std::string pat = std::string("\"") + key + "\"";
+    size_t p = t.find(pat, from);
+    if (p == std::string::npos || p >= to) return false;
+    p = t.find(':', p + pat.size());
+    if (p == std::string::npos || p >= to) return false;
+    ++p;
+    while (p < to && isspace((unsigned char)t[p])) ++p;
+    vpos = p;
+    return true;
+}
+static std::string json_string_at(const std::string& t, size_t p) {
+    std::string r;
+    if (t[p] != '"') return r;
+    for (++p; p < t.size() && t[p] != '"'; ++p) {
+        if (t[p] == '\\' && p + 1 < t.size()) { ++p; r += t[p]; } else r += t[p];
+    }
+    return r;
+}
+static bool load_sketch_json(const char* path, LoadedSketches& L) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    std::string t;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) t.append(buf, n);
+    fclose(f);
+    // objects are delimited by their "sketches":{...}} tail; walk by the "alphabet" key that opens each object
+    size_t pos = 0;
+    std::vector<std::vector<uint64_t>> all;
+    while ((pos = t.find("\"alphabet\"", pos)) != std::string::npos) {
+        size_t next = t.find("\"alphabet\"", pos + 10);
+        size_t end = next == std::string::npos ? t.size() : next;
+        size_t v;
+        if (!json_find(t, pos, end, "kmer", v)) return false;
+        std::vector<int> ks;
+        { std::string kk = json_string_at(t, v); char* e = &kk[0]; while (*e) { while (*e == ' ') ++e; if (!*e) break; ks.push_back((int)strtol(e, &e, 10)); } }
+        if (L.ks.empty()) L.ks = ks; else if (ks != L.ks) return false;
+        if (!json_find(t, pos, end, "name", v)) return false;
+        L.names.push_back(json_string_at(t, v));
+        size_t sp;
+        if (!json_find(t, pos, end, "sketches", sp)) return false;
+        if (!json_find(t, sp, end, "length", v)) return false;
+        int S = (int)strtol(t.c_str() + v, nullptr, 10);
+        if (L.S == 0) L.S = S; else if (S != L.S) return false;
+        if (!json_find(t, sp, end, "hashes", v)) return false;
+        std::vector<uint64_t> h;
+        const char* q = t.c_str() + v;
+        if (*q != '[') return false;
+        ++q;
+        for (;;) {
+            while (*q && (isspace((unsigned char)*q) || *q == ',')) ++q;
+            if (*q == ']' || !*q) break;
+            char* e;
+            h.push_back(strtoull(q, &e, 10));
+            if (e == q) return false;
+            q = e;
+        }
+        all.push_back(h);
+        pos = end;
+    }
+    if (all.empty() || L.S <= 0) return false;
+    L.sk.assign(all.size() * (size_t)L.S, 0);
+    for (size_t i = 0; i < all.size(); ++i) {
+        if ((int)all[i].size() > L.S) return false;
+        L.lens.push_back((int32_t)all[i].size());
+        for (size_t j = 0; j < all[i].size(); ++j) L.sk[i * (size_t)L.S + j] = all[i][j];
+    }
+    return true;
+}
+
 static int main_hash(int argc, char** argv) {
     std::vector<const char*> files;
     std::vector<int> ks;
@@ -523,6 +693,7 @@ int main(int argc, char** argv) {
     if (cmd == "hash") return main_hash(argc, argv);
     if (cmd == "filter") return main_filter(argc, argv);
     if (cmd == "call") return main_call(argc, argv);
+    if (cmd == "sketch") return main_sketch(argc, argv);
     print_help();
     exit(1);
 }

@@ -515,3 +515,28 @@ def test_call_matches_oracle(ctx, orc, root, data_dir, tmp_path):
     assert r.returncode == 1 and b"Only a single kmer size may be used for calling." in r.stderr
     r = subprocess.run([exe, "call", "-r", str(fa), "-f", str(fq), "-k", "12", "-d"], capture_output=True)
     assert r.returncode == 0 and r.stdout == b""
+
+
+def test_json_sketches_roundtrip(orc, root, data_dir, golden_dir, tmp_path):
+    """rkmh sketch -> JSON (schema of dump_hash_json, rkmh.cpp:489-525) -> rkmh stream -R: same lines as sketching anew."""
+    import json
+    exe = os.path.join(root, "bin", "rkmh")
+    js = tmp_path / "refs.json"
+    r = subprocess.run([exe, "sketch", "-f", os.path.join(data_dir, "zika.refs.fa.gz"), "-k", "16", "-s", "1000", "-o", str(js)],
+                       capture_output=True)
+    assert r.returncode == 0, r.stderr
+    doc = json.load(open(js))
+    refs = orc.kseq_parse_file(os.path.join(data_dir, "zika.refs.fa.gz"))
+    rb, ro = orc.pack([x[1] for x in refs])
+    sk, ln = orc.sketch_refs(rb, ro, [16], 1000, threads=4)
+    assert len(doc) == len(refs)
+    for i, d in enumerate(doc):
+        assert list(d.keys()) == ["alphabet", "canonical", "hashBits", "hashSeed", "hashType", "kmer", "name", "preserveCase", "seqLen", "sketches"]
+        assert d["name"] == refs[i][0].decode() and d["kmer"] == "16" and d["hashSeed"] == 42 and d["hashBits"] == 64
+        assert d["hashType"] == "MurmurHash3_x64_128" and d["alphabet"] == "ATGC" and d["seqLen"] == len(refs[i][1])
+        assert d["sketches"]["length"] == 1000 and d["sketches"]["hashes"] == [int(x) for x in sk[i, :ln[i]]]
+    g = golden(golden_dir, "zika_z1")
+    r = subprocess.run([exe, "stream", "-R", str(js), "-f", os.path.join(data_dir, "z1.fq.gz")], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    want = "".join(orc.stream_line(x[1], x[0], x[2], x[3], x[4], 1000) for x in g["rows"])
+    assert r.stdout.decode() == want
