@@ -197,8 +197,10 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t r0 = tile * (uint32_t)T;
         const int Tn = tile_reads(tile);
-        const uint32_t tstart = cur_a;
-        const uint32_t B = cur_b - cur_a;
+        // wave-uniform values are moved to SGPRs explicitly: hipcc cannot prove that values loaded from one address by
+        // every lane are uniform, and keeps loop counters derived from them in VGPRs with exec-mask loop control
+        const uint32_t tstart = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur_a);
+        const uint32_t B = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur_b - cur_a));
         const uint32_t ntile = tile + gridDim.x;
         uint32_t nxt_a = 0, nxt_b = 0, nxt_o = 0;
         if (ntile < ntiles) load_offsets(ntile, nxt_a, nxt_b, nxt_o); // lands during phase 0
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
             }
         }
         if (lane == 0) misc[0] = 0;
-        const uint32_t ulen = (uint32_t)__shfl((int)(o_next - cur_o), 0);                 // length of read 0
+        const uint32_t ulen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(o_next - cur_o)); // length of read 0
         const bool uniform = __ballot(lane < Tn && (o_next - cur_o) != ulen) == 0ull;     // every read of the tile as long
         const uint32_t bad_words = (B + 31) / 32 + 1;
         for (uint32_t i = lane; i < bad_words; i += WAVE) bad[i] = 0;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
         }
         wave_sync();
         if (ntile < ntiles) load_bases(cur_a, cur_b); // the next tile's bases travel while this tile is hashed
-        const bool has_invalid = misc[0] != 0;
+        const bool has_invalid = __builtin_amdgcn_readfirstlane((int)misc[0]) != 0;
         auto read_of = [&](uint32_t p) -> int {
             int t = (int)tmap[p >> 5];
             while (p >= rstart[t + 1]) ++t;
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                             const uint32_t q = qcount + (uint32_t)__popcll(m & lt_mask);
                             qh[q] = hp; qp[q] = tp; qs[q] = hint;
                         }
-                        qcount += (uint32_t)__popcll(m);
+                        qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
                     }
                     if RK_DBG(8) { if (h == 0x1234567ull) nzero[0] = 1; } else
                     if (h != 0) bucket_load_async(ix.fpb + index_bucket(h, ix.bshift), fb); // lands while the next position is hashed

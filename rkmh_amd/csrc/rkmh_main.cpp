@@ -23,6 +23,16 @@
 
 #include "../../include/rkmh_amd.h"
 
+#include <chrono>
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static const bool g_timing = getenv("RKMH_TIMING") != nullptr; // stage timings on stderr
+static void tick(const char* what, double& t0) {
+    if (!g_timing) return;
+    const double t = now_s();
+    fprintf(stderr, "[rkmh timing] %-28s %.3f s\n", what, t - t0);
+    t0 = t;
+}
+
 static void die(const char* what) {
     fprintf(stderr, "rkmh: %s: %s\n", what, rk_last_error());
     exit(1);
@@ -160,8 +170,10 @@ static int main_stream(int argc, char** argv) {
     }
     if (o.refs.empty() && !pre_refs) { fprintf(stderr, "rkmh: at least one -r reference file (or -R sketches) is required\n"); exit(1); }
 
+    double t0 = now_s();
     rk_ctx* ctx = nullptr;
     CK(rk_ctx_create(o.device, nullptr, &ctx));
+    tick("context", t0);
     rk_seqset refs;
     memset(&refs, 0, sizeof refs);
     std::string pre_names;
@@ -179,8 +191,10 @@ static int main_stream(int argc, char** argv) {
         CK(rk_set_references(ctx, refs.bases, refs.offsets, (int)refs.nseq, o.ks.data(), (int)o.ks.size(), o.sketch,
                              o.ref_depth ? o.max_samples : -1, 0));
     }
+    tick("references", t0);
     std::string buf;
     std::vector<int32_t> out4;
+    double t_cls = 0, t_emit = 0, t_wait = 0;
     if (o.read_depth) {
         // two passes over ALL reads (rkmh.cpp:904-948): the reference holds them in RAM, so do we
         rk_seqset reads;
@@ -212,12 +226,19 @@ static int main_stream(int argc, char** argv) {
             q.finish();
         });
         rk_seqset s;
-        while (q.pop(&s)) {
+        for (;;) {
+            double a = now_s();
+            if (!q.pop(&s)) break;
+            double b = now_s();
             out4.resize((size_t)s.nseq * 4);
             CK(rk_classify_batch(ctx, s.bases, s.offsets, s.nseq, out4.data()));
+            double c2 = now_s();
             emit_lines(refs, s, out4.data(), o, buf);
             rk_seqset_free(&s);
+            double d = now_s();
+            t_wait += b - a; t_cls += c2 - b; t_emit += d - c2;
         }
+        if (g_timing) fprintf(stderr, "[rkmh timing] wait-for-parser %.3f s, classify %.3f s, format+write %.3f s\n", t_wait, t_cls, t_emit);
         producer.join();
         if (!q.err.empty()) { fprintf(stderr, "rkmh: %s\n", q.err.c_str()); exit(1); }
     }
