@@ -234,7 +234,6 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
         const uint32_t ulen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(o_next - cur_o)); // length of read 0
         const bool uniform = __ballot(lane < Tn && (o_next - cur_o) != ulen) == 0ull;     // every read of the tile as long
         const uint32_t bad_words = (B + 31) / 32 + 1;
-        for (uint32_t i = lane; i < bad_words; i += WAVE) bad[i] = 0;
         if (MODE != 1)
             for (uint32_t i = lane; i < (uint32_t)Tn * DS; i += WAVE) dset[i] = 0;
         const uint32_t ndw = ((tstart & 3u) + B + 3u) >> 2; // global dwords covering the tile
@@ -274,7 +273,6 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                 }
             }
         };
-        mark_tails(KT ? KT : ks.k[0]);
         { // does any real base of the tile fail the ACGT test?
             uint32_t any = 0;
             const uint32_t lo_bit = s.fbase, hi_bit = s.fbase + B;
@@ -287,15 +285,24 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
             }
             if (any) misc[0] = 1;
         }
-        for (uint32_t c = lane; c * 32 < B; c += WAVE) { // chunk map: last read starting at or before byte 32c
-            const uint32_t pos = c * 32;
-            int lo = 0, hi = Tn - 1;
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (rstart[mid] <= pos) lo = mid; else hi = mid - 1; }
-            tmap[c] = (uint32_t)lo;
-        }
         wave_sync();
-        if (ntile < ntiles) load_bases(cur_a, cur_b); // the next tile's bases travel while this tile is hashed
         const bool has_invalid = __builtin_amdgcn_readfirstlane((int)misc[0]) != 0;
+        // "plain" tiles (all reads equally long, no invalid base: the common case) need neither the start bitmap nor
+        // the position -> read map; the others build both now
+        const bool plain = uniform && !has_invalid;
+        if (!plain) {
+            for (uint32_t i = lane; i < bad_words; i += WAVE) bad[i] = 0;
+            for (uint32_t c = lane; c * 32 < B; c += WAVE) { // chunk map: last read starting at or before byte 32c
+                const uint32_t pos = c * 32;
+                int lo = 0, hi = Tn - 1;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (rstart[mid] <= pos) lo = mid; else hi = mid - 1; }
+                tmap[c] = (uint32_t)lo;
+            }
+            wave_sync();
+            mark_tails(KT ? KT : ks.k[0]);
+            wave_sync();
+        }
+        if (ntile < ntiles) load_bases(cur_a, cur_b); // the next tile's bases travel while this tile is hashed
         auto read_of = [&](uint32_t p) -> int {
             int t = (int)tmap[p >> 5];
             while (p >= rstart[t + 1]) ++t;
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
         uint32_t qcount = 0; // queue length (wave-uniform)
         for (int kk = 0; kk < (KT ? 1 : ks.n); ++kk) {
             const int k = KT ? KT : ks.k[kk];
-            if (kk) { // later k-mer sizes rebuild the start bitmap
+            if (kk && !plain) { // later k-mer sizes rebuild the start bitmap
                 wave_sync();
                 for (uint32_t i = lane; i < bad_words; i += WAVE) bad[i] = 0;
                 wave_sync();
@@ -405,9 +412,9 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
             // base need no start bitmap: compact window index w -> read t = w / nw, position p = w + t * (len - nw),
             // so no lane idles on read tails (k-1 positions per read).  Other tiles walk all byte positions.
             const uint32_t nw_u = (uint32_t)num_windows((int)ulen, k, pol.drop_last_window);
-            const bool compact = uniform && !has_invalid && nw_u > 0;
+            const bool compact = plain; // nw_u == 0 (reads shorter than k): no window at all
             const uint32_t nW = compact ? nw_u * (uint32_t)Tn : B;
-            const float rcp_nw = compact ? 1.0f / (float)nw_u : 0.0f;
+            const float rcp_nw = (compact && nw_u) ? 1.0f / (float)nw_u : 0.0f;
             const uint32_t nIt = (nW + WAVE - 1) / WAVE;
             u32x4 fb = {0u, 0u, 0u, 0u}; // bucket fetched for the previous position (lookup in flight)
             uint64_t hp = 0;
