@@ -74,7 +74,7 @@ struct TileGeom {
 
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
 __host__ __device__ inline size_t tile_lds_bytes(const TileGeom& g) {
-    return ((size_t)((stage_lds_dwords(g.cap_bytes) + 1) & ~1) + 4 * (size_t)g.qcap + 5 * (size_t)(g.T + 1) + 8 +
+    return ((size_t)((stage_lds_dwords(g.cap_bytes) + 1) & ~1) + 3 * (size_t)g.qcap + 5 * (size_t)(g.T + 1) + 8 +
             2 * (size_t)tile_map_words(g.cap_bytes) + 2 * 64 +
             (size_t)g.T * (size_t)(g.cwords + g.dset)) * 4;
 }
@@ -135,8 +135,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
     uint32_t* qh32 = stage + ((stage_lds_dwords(geo.cap_bytes) + 1) & ~1); // [2*QCAP] candidate hashes (8-byte aligned)
     uint64_t* qh = reinterpret_cast<uint64_t*>(qh32);
     uint32_t* qp = qh32 + 2 * QCAP;                              // [QCAP] read (within the tile) of the candidate window
-    uint32_t* qs = qp + QCAP;                                    // [QCAP] slot whose fingerprint matched (or NONE)
-    uint32_t* rstart = qs + QCAP;                                // [T+1] byte offset of read t inside the tile
+    uint32_t* rstart = qp + QCAP;                                // [T+1] byte offset of read t inside the tile
     uint32_t* nwin = rstart + (T + 1);                           // [T+1] windows of read t (all k)
     uint32_t* nzero = nwin + (T + 1);                            // [T+1] zero hashes per read
     uint32_t* best = nzero + (T + 1);                            // [T+1] max over increments of (count << 16 | 0xFFFF - ref)
@@ -320,17 +319,9 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
         // (exact LDS multiset: entry = (slot + 1) | (occurrences - 1) << 27) and add the postings the multiset merge of
         // rkmh.cpp:869 would count.  A hit with several postings is returned (read << 8 | rank, postings offset) for
         // the 16-lanes-per-hit pass instead of looping here with 63 lanes idle.
-        auto take_candidate = [&](uint64_t h, int t, uint32_t hint, uint32_t& m_tr, uint32_t& m_off) -> bool {
+        auto take_candidate = [&](uint64_t h, int t, uint32_t& m_tr, uint32_t& m_off) -> bool {
             uint32_t slot = 0, v = 0;
-            bool found = false;
-            if (hint != IDX_NOT_FOUND) { // the one slot whose fingerprint matched: key and value in one round trip
-                const uint64_t key = ix.keys[hint];
-                v = ix.vals[hint];
-                slot = hint;
-                found = key == h;
-            }
-            if (!found) found = index_lookup(ix, h, slot, v);
-            if (!found) return false;
+            if (!index_lookup(ix, h, slot, v)) return false; // re-reads the bucket (L1/L2 hit), then key + value together
             uint32_t rank = 0;
             {
                 uint32_t* ds = dset + (uint32_t)t * DS;
@@ -368,7 +359,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                 const uint32_t e = e0 + (uint32_t)lane;
                 uint32_t m_tr = 0, m_off = 0;
                 bool multi = false;
-                if (e < qn) multi = take_candidate(qh[e], (int)qp[e], qs[e], m_tr, m_off);
+                if (e < qn) multi = take_candidate(qh[e], (int)qp[e], m_tr, m_off);
                 const uint64_t mm = __ballot(multi);
                 if (mm) { // hits with several postings: 16 lanes walk one hit's posting list, 4 hits at a time
                     if (multi) { const uint32_t j = (uint32_t)__popcll(mm & lt_mask); mq[2 * j] = m_tr; mq[2 * j + 1] = m_off; }
@@ -464,14 +455,11 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                     bucket_wait(fb);
                     if (!RK_DBG(1)) {
                         const uint32_t fp = index_fp(hp);
-                        const uint32_t mm = (fb.x == fp ? 1u : 0u) | (fb.y == fp ? 2u : 0u) | (fb.z == fp ? 4u : 0u) | (fb.w == fp ? 8u : 0u);
-                        const bool cand = hp != 0 && (mm != 0 || fb.w != 0);
+                        const bool cand = hp != 0 && (fb.x == fp || fb.y == fp || fb.z == fp || fb.w == fp || fb.w != 0);
                         const uint64_t m = __ballot(cand);
                         if (cand) {
-                            const uint32_t hint = (mm != 0 && (mm & (mm - 1u)) == 0)
-                                                      ? 4u * index_bucket(hp, ix.bshift) + ((uint32_t)__ffs((int)mm) - 1u) : IDX_NOT_FOUND;
                             const uint32_t q = qcount + (uint32_t)__popcll(m & lt_mask);
-                            qh[q] = hp; qp[q] = tp; qs[q] = hint;
+                            qh[q] = hp; qp[q] = tp;
                         }
                         qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
                     }
@@ -492,10 +480,10 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                 wave_sync();
                 if (last) { qcount = 0; break; }
                 const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
-                uint64_t ch = 0; uint32_t ct_ = 0, cs = 0;
-                if ((uint32_t)lane < rem) { ch = qh[qn + lane]; ct_ = qp[qn + lane]; cs = qs[qn + lane]; }
+                uint64_t ch = 0; uint32_t ct_ = 0;
+                if ((uint32_t)lane < rem) { ch = qh[qn + lane]; ct_ = qp[qn + lane]; }
                 wave_sync();
-                if ((uint32_t)lane < rem) { qh[lane] = ch; qp[lane] = ct_; qs[lane] = cs; }
+                if ((uint32_t)lane < rem) { qh[lane] = ch; qp[lane] = ct_; }
                 qcount = rem;
                 wave_sync();
             }
