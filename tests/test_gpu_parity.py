@@ -540,3 +540,83 @@ def test_json_sketches_roundtrip(orc, root, data_dir, golden_dir, tmp_path):
     assert r.returncode == 0, r.stderr
     want = "".join(orc.stream_line(x[1], x[0], x[2], x[3], x[4], 1000) for x in g["rows"])
     assert r.stdout.decode() == want
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_randomized_differential(orc, seed):
+    """Random ragged batches (lengths 0..1700, lower case, N runs, repeats, shared and duplicated references, 1-3 k-mer
+    sizes, tiny to large sketches, every fold / window policy, with and without -M) against the oracle."""
+    import rkmh_amd
+    rng = np.random.default_rng(1000 + seed)
+    fold = int(rng.integers(0, 3))
+    drop = int(rng.integers(0, 2))
+    nk = int(rng.integers(1, 4))
+    ks = sorted(set(int(x) for x in rng.choice([8, 11, 12, 15, 16, 17, 20, 24, 31, 32, 33], size=nk, replace=False)))
+    if seed % 3 == 0:
+        ks = [16]
+    S = int(rng.choice([1, 5, 40, 200, 1000, 3000]))
+    nref = int(rng.integers(1, 40))
+    base = rand_dna(rng, 3000)
+    refs = []
+    for i in range(nref):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            r = rand_dna(rng, int(rng.integers(50, 4000)))
+        elif kind == 1:                                       # mutated copy of a shared ancestor: shared sketch hashes
+            r = bytearray(base[: int(rng.integers(500, 3000))])
+            for j in np.nonzero(rng.random(len(r)) < 0.02)[0]:
+                r[j] = b"ACGT"[int(rng.integers(0, 4))]
+            r = bytes(r)
+        elif kind == 2:                                       # low complexity: repeated hashes inside one sketch
+            unit = rand_dna(rng, int(rng.integers(1, 40)))
+            r = (unit * (3000 // len(unit) + 1))[: int(rng.integers(100, 3000))]
+        else:
+            r = refs[int(rng.integers(0, len(refs)))] if refs else base
+        refs.append(r)
+    reads = []
+    nreads = int(rng.integers(50, 400))
+    uniform_len = int(rng.choice([0, 0, 100, 150, 251]))     # some batches of equal-length reads (the fast tile path)
+    for i in range(nreads):
+        src = refs[int(rng.integers(0, nref))]
+        L = uniform_len if uniform_len else int(rng.choice([0, 3, 15, 16, 17, 60, 150, 150, 150, 300, 800, 1528, 1529, 1700]))
+        if rng.random() < 0.15 or len(src) < L + 1:
+            r = bytearray(rand_dna(rng, L))
+        else:
+            st = int(rng.integers(0, len(src) - L + 1))
+            r = bytearray(src[st:st + L])
+        for j in np.nonzero(rng.random(len(r)) < 0.01)[0]:
+            r[j] = b"ACGT"[int(rng.integers(0, 4))]
+        if rng.random() < 0.1 and len(r) > 20:
+            a = int(rng.integers(0, len(r) - 5))
+            r[a:a + int(rng.integers(1, 5))] = b"N" * 1
+        if rng.random() < 0.1:
+            r = bytearray(bytes(r).lower())
+        if rng.random() < 0.05 and len(r) > 40:               # a read with an internal repeat: duplicate k-mers
+            r = bytearray(bytes(r[:40]) * (len(r) // 40 + 1))[: len(r)]
+        reads.append(bytes(r))
+    rb, ro = orc.pack(refs)
+    qb, qo = orc.pack(reads)
+    c = rkmh_amd.Context(0, fold=fold, drop_last_window=drop)
+    pol = orc.default_policy(fold=fold, drop_last_window=drop)
+    try:
+        c.set_references(_pad(rb), ro, ks, S)
+        sk, ln = c.get_reference_sketches()
+        wsk, wln = orc.sketch_refs(rb, ro, ks, S, pol, threads=4)
+        assert (ln == wln).all() and (sk == wsk).all()
+        got = c.classify(_pad(qb), qo)
+        want = orc.classify_stream(qb, qo, ks, S, sk, ln, pol, threads=4)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, (seed, ks, S, fold, drop, bad[:5], got[bad[:5]], want[bad[:5]], [len(reads[i]) for i in bad[:5]])
+        if seed % 2 == 0:                                     # -M path on the same batch
+            slots = 100003
+            cnt = rkmh_amd.Counter(c, slots=slots)
+            c.count_batch(_pad(qb), qo, cnt)
+            c.set_depth_filter(cnt, 2)
+            got = c.classify(_pad(qb), qo)
+            c.set_depth_filter(None, 0)
+            want = orc.classify_stream(qb, qo, ks, S, sk, ln, pol, threads=4, min_kmer_occ=2, counter_slots=slots)
+            bad = np.nonzero((got != want).any(axis=1))[0]
+            assert len(bad) == 0, ("-M", seed, ks, S, bad[:5], got[bad[:5]], want[bad[:5]])
+            cnt.destroy()
+    finally:
+        c.close()
