@@ -100,6 +100,11 @@ void rk_counter_destroy(rk_counter* c);
 int rk_counter_clear(rk_counter* c);
 int rk_counter_increment(rk_counter* c, uint64_t key);
 int rk_counter_get(const rk_counter* c, uint64_t key, int32_t* out);
+/* Counter (de)serialisation (the -p/-q flags the reference parses but leaves unimplemented, src/rkmh.cpp:665-670,
+ * :744-769; docs/todo.md:1).  File = "RKHT1\n", u64 slots, u64 nnz, then nnz x (u32 slot, i32 count), little endian.
+ * rk_counter_load requires a counter with the same number of slots and REPLACES its contents. */
+int rk_counter_save(rk_counter* c, const char* path);
+int rk_counter_load(rk_counter* c, const char* path);
 void* rk_counter_device_ptr(rk_counter* c);
 uint64_t rk_counter_slots(const rk_counter* c);
 

@@ -66,6 +66,8 @@ _SIGS = {
     "rk_counter_clear": (C.c_int, [C.c_void_p]),
     "rk_counter_increment": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rk_counter_get": (C.c_int, [C.c_void_p, C.c_uint64, _i32p]),
+    "rk_counter_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rk_counter_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rk_counter_device_ptr": (C.c_void_p, [C.c_void_p]),
     "rk_counter_slots": (C.c_uint64, [C.c_void_p]),
     "rk_hash_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, _ip, C.c_int, C.POINTER(_u64p), _u64p]),
@@ -242,6 +244,12 @@ class Counter:
 
     def clear(self):
         _chk(self._lib.rk_counter_clear(self._h))
+
+    def save(self, path):
+        _chk(self._lib.rk_counter_save(self._h, os.fsencode(path)))
+
+    def load(self, path):
+        _chk(self._lib.rk_counter_load(self._h, os.fsencode(path)))
 
     @property
     def slots(self):

@@ -536,6 +536,52 @@ extern "C" int rk_counter_get(const rk_counter* k, uint64_t key, int32_t* out) {
     HIPCHK(hipMemcpy(out, k->d + (key % k->slots), 4, hipMemcpyDeviceToHost));
     return RK_OK;
 }
+extern "C" int rk_counter_save(rk_counter* k, const char* path) {
+    if (!k || !path) return fail(RK_ERR_ARG, "bad arguments");
+    if (k->slots > 0xffffffffull) return fail(RK_ERR_LIMIT, "counter too large to serialise (slot index is 32 bit)");
+    RKCHK(set_dev(k->ctx));
+    std::vector<int32_t> h((size_t)k->slots);
+    HIPCHK(hipMemcpy(h.data(), k->d, k->slots * 4, hipMemcpyDeviceToHost));
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(RK_ERR_IO, "cannot write %s", path);
+    uint64_t nnz = 0;
+    for (int32_t v : h) nnz += v != 0;
+    bool ok = fwrite("RKHT1\n", 1, 6, f) == 6 && fwrite(&k->slots, 8, 1, f) == 1 && fwrite(&nnz, 8, 1, f) == 1;
+    std::vector<uint32_t> rec;
+    rec.reserve(1 << 16);
+    for (size_t i = 0; ok && i < h.size(); ++i) {
+        if (h[i] == 0) continue;
+        rec.push_back((uint32_t)i); rec.push_back((uint32_t)h[i]);
+        if (rec.size() >= (1 << 16)) { ok = fwrite(rec.data(), 4, rec.size(), f) == rec.size(); rec.clear(); }
+    }
+    if (ok && !rec.empty()) ok = fwrite(rec.data(), 4, rec.size(), f) == rec.size();
+    ok = (fclose(f) == 0) && ok;
+    return ok ? RK_OK : fail(RK_ERR_IO, "short write to %s", path);
+}
+extern "C" int rk_counter_load(rk_counter* k, const char* path) {
+    if (!k || !path) return fail(RK_ERR_ARG, "bad arguments");
+    RKCHK(set_dev(k->ctx));
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(RK_ERR_IO, "cannot read %s", path);
+    char magic[6];
+    uint64_t slots = 0, nnz = 0;
+    bool ok = fread(magic, 1, 6, f) == 6 && memcmp(magic, "RKHT1\n", 6) == 0 && fread(&slots, 8, 1, f) == 1 && fread(&nnz, 8, 1, f) == 1;
+    if (!ok) { fclose(f); return fail(RK_ERR_IO, "%s is not a counter file", path); }
+    if (slots != k->slots) { fclose(f); return fail(RK_ERR_ARG, "%s holds %llu slots, the counter has %llu", path, (unsigned long long)slots, (unsigned long long)k->slots); }
+    std::vector<int32_t> h((size_t)slots, 0);
+    std::vector<uint32_t> rec(1 << 16);
+    uint64_t left = nnz * 2;
+    while (ok && left) {
+        size_t want = left < rec.size() ? (size_t)left : rec.size();
+        ok = fread(rec.data(), 4, want, f) == want;
+        for (size_t i = 0; ok && i + 1 < want; i += 2) { if (rec[i] >= slots) { ok = false; break; } h[rec[i]] = (int32_t)rec[i + 1]; }
+        left -= want;
+    }
+    fclose(f);
+    if (!ok) return fail(RK_ERR_IO, "%s is truncated or corrupt", path);
+    HIPCHK(hipMemcpy(k->d, h.data(), slots * 4, hipMemcpyHostToDevice));
+    return RK_OK;
+}
 extern "C" void* rk_counter_device_ptr(rk_counter* k) { return k ? k->d : nullptr; }
 extern "C" uint64_t rk_counter_slots(const rk_counter* k) { return k ? k->slots : 0; }
 

@@ -127,6 +127,7 @@ static bool load_sketch_json(const char* path, LoadedSketches& L);
 static int main_stream(int argc, char** argv) {
     Opts o;
     const char* pre_refs = nullptr;
+    const char* read_map = nullptr;
     if (argc <= 2) { help_stream(); exit(1); }
     static struct option long_options[] = {
         {"help", no_argument, 0, 'h'},           {"kmer", required_argument, 0, 'k'},
@@ -145,7 +146,8 @@ static int main_stream(int argc, char** argv) {
         switch (c) {
             case 'm': case 'i': case 'z': break;                 // parsed and ignored, rkmh.cpp:656-658,709-714
             case 'R': pre_refs = optarg; break;               // pre-hashed references: parsed but unimplemented in the reference (:662-664)
-            case 'F': case 'p': case 'q': case 'S': break; // parsed, bodies empty in the reference (:659-670,:697-700)
+            case 'p': read_map = optarg; break;               // read k-mer depth map: commented out in the reference (:665-667, :744-758)
+            case 'F': case 'q': case 'S': break; // parsed, bodies empty in the reference (:659-670,:697-700)
             case 't': o.threads = atoi(optarg); break;
             case 'r': o.refs.push_back(optarg); break;
             case 'f': o.reads.push_back(optarg); break;
@@ -201,7 +203,13 @@ static int main_stream(int argc, char** argv) {
         CK(rk_parse_files(o.reads.data(), (int)o.reads.size(), &reads));
         rk_counter* cnt = nullptr;
         CK(rk_counter_create(ctx, 200000000ull, &cnt)); // rkmh.cpp:739
-        CK(rk_count_batch(ctx, reads.bases, reads.offsets, reads.nseq, cnt));
+        // -p <file>: reuse a saved depth map (pass 1 is skipped) or save this run's for the next one
+        FILE* probe = read_map ? fopen(read_map, "rb") : nullptr;
+        if (probe) { fclose(probe); CK(rk_counter_load(cnt, read_map)); }
+        else {
+            CK(rk_count_batch(ctx, reads.bases, reads.offsets, reads.nseq, cnt));
+            if (read_map) CK(rk_counter_save(cnt, read_map));
+        }
         CK(rk_set_depth_filter(ctx, cnt, o.min_occ));
         out4.resize((size_t)reads.nseq * 4);
         CK(rk_classify_batch(ctx, reads.bases, reads.offsets, reads.nseq, out4.data()));

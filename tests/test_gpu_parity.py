@@ -620,3 +620,28 @@ def test_randomized_differential(orc, seed):
             cnt.destroy()
     finally:
         c.close()
+
+
+def test_counter_serialisation(ctx, orc, root, data_dir, tmp_path):
+    """Depth-map save/load (the -p flag the reference leaves unimplemented): a second run that loads the map prints the same lines."""
+    import rkmh_amd
+    cnt = rkmh_amd.Counter(ctx, slots=100003)
+    h = ctx.calc_hashes(b"ACGTTGCAAGGCTTAACCGGTTAAGGCCATATATATATATGCGCGCGC" * 4, [8], counter=cnt)
+    f = tmp_path / "c.bin"
+    cnt.save(str(f))
+    other = rkmh_amd.Counter(ctx, slots=100003)
+    other.load(str(f))
+    for v in set(int(x) for x in h):
+        assert other.get(v) == cnt.get(v) > 0
+    wrong = rkmh_amd.Counter(ctx, slots=99991)
+    with pytest.raises(rkmh_amd.RkmhError):
+        wrong.load(str(f))
+    for c in (cnt, other, wrong):
+        c.destroy()
+    exe = os.path.join(root, "bin", "rkmh")
+    args = [exe, "stream", "-r", os.path.join(data_dir, "zika.refs.fa.gz"), "-f", os.path.join(data_dir, "z1.fq.gz"), "-k", "16", "-M", "2",
+            "-p", str(tmp_path / "depth.map")]
+    a = subprocess.run(args, capture_output=True)
+    assert a.returncode == 0 and (tmp_path / "depth.map").exists(), a.stderr
+    b = subprocess.run(args, capture_output=True)   # second run loads the map instead of counting
+    assert b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 1000
