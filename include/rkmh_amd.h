@@ -206,9 +206,14 @@ int rk_parse_files(const char* const* paths, int npaths, rk_seqset* out);
 void rk_seqset_free(rk_seqset* s);
 /* Streaming form (the build's replacement of KSEQ_Reader::get_next_buffer, src/rkmh.cpp:951-959, 2085-2094):
  * up to max_records records / max_bases bases per call (0 = unlimited); out->nseq == 0 at end of input.
- * path "-" reads STDIN. */
+ * path "-" reads STDIN.  Uncompressed input read with max_records == 0 or >= 65536 goes through the
+ * block-parallel scanner (RKMH_PARSE_THREADS, default 8): a batch is then a whole block of about
+ * max_records records, so both limits are approximate there; any input that is not strictly
+ * line-structured falls back to the sequential kseq-grammar scanner with identical results. */
 typedef struct rk_reader rk_reader;
 int rk_reader_open(const char* path, rk_reader** out);
+#define RK_READER_NO_QUALS 1 /* do not keep quality strings (stream/classify never read them) */
+void rk_reader_set_options(rk_reader* r, int flags);
 int rk_reader_next(rk_reader* r, int64_t max_records, uint64_t max_bases, rk_seqset* out);
 void rk_reader_close(rk_reader* r);
 

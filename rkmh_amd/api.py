@@ -88,6 +88,7 @@ _SIGS = {
     "rk_seqset_free": (None, [C.POINTER(SeqSet)]),
     "rk_reader_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "rk_reader_next": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(SeqSet)]),
+    "rk_reader_set_options": (None, [C.c_void_p, C.c_int]),
     "rk_reader_close": (None, [C.c_void_p]),
     "rk_synth_reads": (C.c_int, [_u8p, _u64p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, _u8p, C.c_int]),
 }
@@ -186,10 +187,12 @@ def parse_files(paths):
 class Reader:
     """Streaming FASTA/FASTQ(.gz) reader (batches ready for Context.classify)."""
 
-    def __init__(self, path):
+    def __init__(self, path, keep_quals=True):
         self._lib = load_library()
         self._h = C.c_void_p()
         _chk(self._lib.rk_reader_open(os.fsencode(path), C.byref(self._h)))
+        if not keep_quals:
+            self._lib.rk_reader_set_options(self._h, 1)
 
     def next_batch(self, max_records=1 << 20, max_bases=1 << 28):
         ss = SeqSet()

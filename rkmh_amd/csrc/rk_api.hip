@@ -894,16 +894,37 @@ extern "C" int rk_count_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* o
     return general_run(c, bases, nullptr, offsets, nreads, cfg, none);
 }
 
+static inline char* put_int(char* w, int v) {
+    char tmp[12];
+    int n = 0;
+    unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *w++ = '-';
+    while (n) *w++ = tmp[--n];
+    return w;
+}
+
 extern "C" int rk_format_stream_line(char* dst, size_t cap, const char* ref_name, const char* read_name,
                                      int max_shared, int diff, int min_num, int sketch_size, int min_matches, int min_diff) {
-    // src/rkmh.cpp:887-892
+    // src/rkmh.cpp:887-892: ref \t read \t max_shared \t sketch_size<depth filter> \t <match filter> \t <diff filter> \n
     const bool diff_filter = diff > min_diff;
     const bool depth_filter = min_num <= min_matches;
     const bool match_filter = max_shared < min_matches;
-    int n = snprintf(dst, cap, "%s\t%s\t%d\t%d%s\t%s\t%s\n", ref_name, read_name, max_shared, sketch_size,
-                     depth_filter ? "FAIL:DEPTH" : "", match_filter ? "FAIL:MATCHES" : "", diff_filter ? "" : "FAIL:DIFF");
-    if (n < 0 || (size_t)n >= cap) return fail(RK_ERR_ARG, "line buffer too small");
-    return n;
+    const size_t ln = strlen(ref_name), lq = strlen(read_name);
+    if (ln + lq + 64 >= cap) return fail(RK_ERR_ARG, "line buffer too small");
+    char* w = dst;
+    memcpy(w, ref_name, ln); w += ln; *w++ = '\t';
+    memcpy(w, read_name, lq); w += lq; *w++ = '\t';
+    w = put_int(w, max_shared); *w++ = '\t';
+    w = put_int(w, sketch_size);
+    if (depth_filter) { memcpy(w, "FAIL:DEPTH", 10); w += 10; }
+    *w++ = '\t';
+    if (match_filter) { memcpy(w, "FAIL:MATCHES", 12); w += 12; }
+    *w++ = '\t';
+    if (!diff_filter) { memcpy(w, "FAIL:DIFF", 9); w += 9; }
+    *w++ = '\n';
+    *w = '\0';
+    return (int)(w - dst);
 }
 
 // ---- call ------------------------------------------------------------------------------------------

@@ -10,12 +10,18 @@
 // Bases are NOT upper-cased here: the device does that while staging (rkmh.cpp:252 / :856).
 #include "../../include/rkmh_amd.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -63,6 +69,15 @@ struct Batch {
     bool init() { return offsets.push(0) && name_offsets.push(0); }
 };
 
+struct Piece {
+    Grow<uint8_t> bases;
+    Grow<uint64_t> ends;      // cumulative base count after each record (piece-local)
+    Grow<char> names;
+    Grow<uint64_t> name_ends; // cumulative name bytes (with the NULs) after each record
+    Grow<char> quals;
+    bool bad = false, oom = false;
+};
+
 } // namespace
 
 struct rk_reader {
@@ -73,8 +88,45 @@ struct rk_reader {
     int last_char = 0;
     bool finished = false;
 
+    // --- block-parallel front end (plain, well-formed files only; see next_block) ---
+    bool par_ok = false;       // still in block-parallel mode
+    bool skip_quals = false;   // RK_READER_NO_QUALS
+    int nthreads = 1;
+    const unsigned char* map = nullptr; // regular uncompressed file: the whole file, mmap'd
+    size_t map_size = 0, map_pos = 0;
+    std::vector<unsigned char> blk;     // pipes: current block; starts with the tail of the previous one
+    bool blk_eof = false;
+    const unsigned char* pend_ptr = nullptr; // after a fallback the sequential scanner is fed from here first
+    size_t pend_len = 0, pend_pos = 0;
+    bool pending = false, pend_then_eof = false;
+    double bytes_per_rec = 0;
+    size_t max_block = 384u << 20; // RKMH_PARSE_BLOCK_KB
+    size_t min_par = 1u << 20;     // blocks smaller than this are scanned by one thread
+    std::vector<Piece> pieces;     // per-worker scratch, reused across blocks
+
+    void to_sequential() {
+        par_ok = false;
+        pending = true;
+        pend_pos = 0;
+        if (map) { pend_ptr = map + map_pos; pend_len = map_size - map_pos; pend_then_eof = true; }
+        else { pend_ptr = blk.data(); pend_len = blk.size(); pend_then_eof = blk_eof; }
+    }
+
     inline bool fill() {
-        if (eof) return false;
+        if (pending) {
+            size_t n = pend_len - pend_pos;
+            if (n > buf.size()) n = buf.size();
+            if (n) {
+                memcpy(buf.data(), pend_ptr + pend_pos, n);
+                pend_pos += n;
+                beg = 0; end = n;
+                return true;
+            }
+            pending = false;
+            std::vector<unsigned char>().swap(blk);
+            if (pend_then_eof) eof = true;
+        }
+        if (eof || !fp) return false;
         int r = gzread(fp, buf.data(), (unsigned)buf.size());
         beg = 0;
         end = r > 0 ? (size_t)r : 0;
@@ -85,6 +137,8 @@ struct rk_reader {
         if (beg >= end && !fill()) return -1;
         return buf[beg++];
     }
+
+    int next_block(Batch& b, int64_t max_records);
 
     // one record appended to b. returns 1 record read, 0 clean EOF, -2 truncated, -3 out of memory
     int next(Batch& b) {
@@ -156,15 +210,17 @@ struct rk_reader {
             if (c == -1) { b.bases.n = seq0; b.names.n = name0; return -2; }
             const size_t q0 = b.quals.n;
             size_t ql = 0;
-            if (b.quals_ok && !b.quals.reserve(q0 + slen + 1)) return -3;
+            if (skip_quals) b.quals_ok = false;
+            const bool keep_q = b.quals_ok;
+            if (keep_q && !b.quals.reserve(q0 + slen + 1)) return -3;
             for (;;) {
                 c = getc();
                 if (c == -1 || !(ql < slen)) break;
-                if (c >= 33 && c <= 127) { if (b.quals_ok) b.quals.p[q0 + ql] = (char)c; ++ql; }
+                if (c >= 33 && c <= 127) { if (keep_q) b.quals.p[q0 + ql] = (char)c; ++ql; }
             }
             last_char = 0;
             if (ql != slen) { b.bases.n = seq0; b.names.n = name0; return -2; }
-            if (b.quals_ok) b.quals.n = q0 + slen;
+            if (keep_q) b.quals.n = q0 + slen;
         } else {
             b.quals_ok = false;
         }
@@ -174,6 +230,281 @@ struct rk_reader {
         return 1;
     }
 };
+
+// ---------------------------------------------------------------------------------------------------
+// Block-parallel front end.  kseq's grammar is inherently sequential (a quality string is read by count,
+// '@' may be data), so the parallel path only accepts input on which that grammar provably coincides with
+// the line-oriented one: every FASTQ record is exactly four lines (header, one sequence line of keeper
+// bytes, a '+' line, a quality line of exactly as many bytes 33..127), every FASTA sequence line holds only
+// keeper bytes.  A block is cut at validated record starts, the pieces are scanned by worker threads under
+// those strict rules, and ANY deviation anywhere in the block hands the untouched block back to the
+// sequential scanner above (and disables this path for the rest of the file), so the result is always the
+// one kseq_read (kseq.hpp:170-208) would produce.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+inline const unsigned char* find_nl(const unsigned char* p, const unsigned char* e) {
+    return p < e ? (const unsigned char*)memchr(p, '\n', (size_t)(e - p)) : nullptr;
+}
+
+// true when [p, e) are all keeper bytes (class 1)
+inline bool all_keepers(const unsigned char* p, const unsigned char* e) {
+    unsigned acc = 0; // arithmetic form of seqcls == 1 so the loop vectorises
+    for (; p < e; ++p) {
+        const unsigned c = *p;
+        acc |= (unsigned)((c - 33u) > 93u) | (unsigned)(c == '>') | (unsigned)(c == '+') | (unsigned)(c == '@');
+    }
+    return acc == 0;
+}
+inline bool all_quals(const unsigned char* p, const unsigned char* e) {
+    unsigned acc = 0;
+    for (; p < e; ++p) acc |= (unsigned)((unsigned)(*p - 33u) > 94u);
+    return acc == 0;
+}
+
+inline bool push_name(Piece& o, const unsigned char* p, const unsigned char* nl) {
+    const unsigned char* q = p;
+    while (q < nl && !T.space[*q]) ++q;
+    if (!o.names.append((const char*)p, (size_t)(q - p)) || !o.names.push('\0')) return false;
+    return o.name_ends.push((uint64_t)o.names.n);
+}
+
+void parse_fastq_piece(const unsigned char* p, const unsigned char* e, bool want_quals, Piece& o) {
+    while (p < e) {
+        while (p < e && (*p == '\n' || *p == '\r')) ++p;
+        if (p >= e) break;
+        if (*p != '@') { o.bad = true; return; }
+        ++p;
+        const unsigned char* nl = find_nl(p, e);
+        if (!nl) { o.bad = true; return; }
+        if (!push_name(o, p, nl)) { o.oom = true; return; }
+        p = nl + 1;
+        nl = find_nl(p, e);
+        if (!nl) { o.bad = true; return; }
+        const unsigned char* se = nl;
+        if (se > p && se[-1] == '\r') --se;
+        const size_t slen = (size_t)(se - p);
+        if (!all_keepers(p, se)) { o.bad = true; return; }
+        if (!o.bases.append(p, slen) || !o.ends.push((uint64_t)o.bases.n)) { o.oom = true; return; }
+        p = nl + 1;
+        if (p >= e || *p != '+') { o.bad = true; return; }
+        nl = find_nl(p, e);
+        if (!nl) { o.bad = true; return; }
+        p = nl + 1;
+        nl = find_nl(p, e);
+        const unsigned char* qe = nl ? nl : e;
+        const unsigned char* qend = qe;
+        if (qend > p && qend[-1] == '\r') --qend;
+        if ((size_t)(qend - p) != slen || !all_quals(p, qend)) { o.bad = true; return; }
+        if (want_quals && !o.quals.append((const char*)p, slen)) { o.oom = true; return; }
+        p = nl ? nl + 1 : e;
+    }
+}
+
+void parse_fasta_piece(const unsigned char* p, const unsigned char* e, Piece& o) {
+    while (p < e) {
+        while (p < e && (*p == '\n' || *p == '\r')) ++p;
+        if (p >= e) break;
+        if (*p != '>') { o.bad = true; return; }
+        ++p;
+        const unsigned char* nl = find_nl(p, e);
+        if (!nl) { o.bad = true; return; }
+        if (!push_name(o, p, nl)) { o.oom = true; return; }
+        p = nl + 1;
+        while (p < e && *p != '>') {
+            nl = find_nl(p, e);
+            const unsigned char* le = nl ? nl : e;
+            const unsigned char* se = le;
+            if (se > p && se[-1] == '\r') --se;
+            if (!all_keepers(p, se)) { o.bad = true; return; }
+            if (!o.bases.append(p, (size_t)(se - p))) { o.oom = true; return; }
+            p = nl ? nl + 1 : e;
+        }
+        if (!o.ends.push((uint64_t)o.bases.n)) { o.oom = true; return; }
+    }
+}
+
+// first record start at or after `from` (line-aligned); for FASTQ the line two below must begin with '+',
+// which a quality line that happens to begin with '@' can never satisfy (its +2 line is a sequence line).
+const unsigned char* find_record_start(const unsigned char* base, const unsigned char* from,
+                                       const unsigned char* e, bool fastq) {
+    const unsigned char* p = from;
+    if (p > base && p[-1] != '\n') {
+        const unsigned char* nl = find_nl(p, e);
+        if (!nl) return nullptr;
+        p = nl + 1;
+    }
+    while (p < e) {
+        if (fastq) {
+            if (*p == '@') {
+                const unsigned char* l1 = find_nl(p, e);
+                if (!l1) return nullptr;
+                const unsigned char* l2 = find_nl(l1 + 1, e);
+                if (!l2 || l2 + 1 >= e) return nullptr;
+                if (l2[1] == '+') return p;
+            }
+        } else if (*p == '>') {
+            return p;
+        }
+        const unsigned char* nl = find_nl(p, e);
+        if (!nl) return nullptr;
+        p = nl + 1;
+    }
+    return nullptr;
+}
+
+// last record start in (base, e): records before it are complete inside the block
+const unsigned char* find_last_record_start(const unsigned char* base, const unsigned char* e, bool fastq) {
+    size_t win = 1u << 16;
+    const size_t total = (size_t)(e - base);
+    for (;;) {
+        const unsigned char* from = total > win ? e - win : base + 1;
+        const unsigned char* best = nullptr;
+        const unsigned char* p = from;
+        for (;;) {
+            const unsigned char* q = find_record_start(base, p, e, fastq);
+            if (!q) break;
+            best = q;
+            p = q + 1;
+        }
+        if (best && best > base) return best;
+        if (win >= total) return nullptr;
+        win *= 16;
+    }
+}
+
+} // namespace
+
+// Appends the records of the next block to b.  1 = block consumed (more may follow), 0 = end of input,
+// -1 = input is not strictly line-structured: the block was handed back to the sequential scanner,
+// -3 = out of memory.
+int rk_reader::next_block(Batch& b, int64_t max_records) {
+    size_t target = bytes_per_rec > 0 && max_records > 0 ? (size_t)(bytes_per_rec * (double)max_records) : (64u << 20);
+    if (target < (4u << 20)) target = 4u << 20;
+    if (target > max_block) target = max_block;
+    bool fastq = false;
+    size_t cut = 0;
+    const unsigned char* base = nullptr;
+    for (;;) {
+        size_t avail;
+        bool at_eof;
+        if (map) {
+            avail = map_size - map_pos;
+            at_eof = avail <= target;
+            if (!at_eof) avail = target;
+            base = map + map_pos;
+        } else {
+            while (!blk_eof && blk.size() < target) { // top the block up to `target` bytes
+                size_t have = blk.size();
+                size_t want = target - have;
+                if (want > (1u << 30)) want = 1u << 30;
+                blk.resize(have + want);
+                int r = gzread(fp, blk.data() + have, (unsigned)want);
+                size_t got = r > 0 ? (size_t)r : 0;
+                blk.resize(have + got);
+                if (got < want) blk_eof = true;
+            }
+            avail = blk.size();
+            at_eof = blk_eof;
+            base = blk.data();
+        }
+        if (avail == 0) return 0;
+        const unsigned char* e = base + avail;
+        const unsigned char* p = base;
+        while (p < e && (*p == '\n' || *p == '\r')) ++p;
+        if (p >= e) {
+            if (at_eof) { if (map) map_pos = map_size; else blk.clear(); return 0; }
+            target *= 2;
+            continue;
+        }
+        if (*p != '@' && *p != '>') { to_sequential(); return -1; }
+        fastq = *p == '@';
+        if (at_eof) { cut = avail; break; }
+        const unsigned char* last = find_last_record_start(base, e, fastq);
+        if (last) { cut = (size_t)(last - base); break; }
+        target *= 2; // a single record longer than the block: look further
+    }
+    int nt = nthreads;
+    if (cut < min_par) nt = 1;
+    std::vector<size_t> starts((size_t)nt + 1);
+    starts[0] = 0;
+    starts[(size_t)nt] = cut;
+    for (int i = 1; i < nt; ++i) {
+        size_t from = cut / (size_t)nt * (size_t)i;
+        if (from < starts[(size_t)i - 1]) from = starts[(size_t)i - 1];
+        const unsigned char* q = find_record_start(base, base + from, base + cut, fastq);
+        starts[(size_t)i] = q ? (size_t)(q - base) : cut;
+    }
+    if (pieces.size() < (size_t)nt) pieces.resize((size_t)nt);
+    const bool want_quals = fastq && b.quals_ok && !skip_quals;
+    auto work = [&](int i) {
+        Piece& pc = pieces[(size_t)i];
+        pc.bases.n = pc.ends.n = pc.names.n = pc.name_ends.n = pc.quals.n = 0;
+        pc.bad = pc.oom = false;
+        const unsigned char* s = base + starts[(size_t)i];
+        const unsigned char* t = base + starts[(size_t)i + 1];
+        if (fastq) parse_fastq_piece(s, t, want_quals, pc);
+        else parse_fasta_piece(s, t, pc);
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < nt; ++i) th.emplace_back(work, i);
+        work(0);
+        for (auto& t : th) t.join();
+    }
+    for (int i = 0; i < nt; ++i) {
+        if (pieces[(size_t)i].oom) return -3;
+        if (pieces[(size_t)i].bad) { to_sequential(); return -1; }
+    }
+    // merge: prefix sums, then every worker copies its own piece into place
+    std::vector<size_t> rec0((size_t)nt + 1), base0((size_t)nt + 1), name0((size_t)nt + 1);
+    rec0[0] = (size_t)b.nseq; base0[0] = b.bases.n; name0[0] = b.names.n;
+    for (int i = 0; i < nt; ++i) {
+        rec0[(size_t)i + 1] = rec0[(size_t)i] + pieces[(size_t)i].ends.n;
+        base0[(size_t)i + 1] = base0[(size_t)i] + pieces[(size_t)i].bases.n;
+        name0[(size_t)i + 1] = name0[(size_t)i] + pieces[(size_t)i].names.n;
+    }
+    const size_t nrec = rec0[(size_t)nt], nb = base0[(size_t)nt], nn = name0[(size_t)nt];
+    const size_t q_before = b.quals.n;
+    if (!b.bases.reserve(nb + 64) || !b.offsets.reserve(nrec + 1) || !b.names.reserve(nn + 1) ||
+        !b.name_offsets.reserve(nrec + 1))
+        return -3;
+    if (want_quals && !b.quals.reserve(q_before + (nb - base0[0]) + 1)) return -3;
+    auto place = [&](int i) {
+        Piece& pc = pieces[(size_t)i];
+        if (pc.bases.n) memcpy(b.bases.p + base0[(size_t)i], pc.bases.p, pc.bases.n);
+        if (pc.names.n) memcpy(b.names.p + name0[(size_t)i], pc.names.p, pc.names.n);
+        if (want_quals && pc.quals.n)
+            memcpy(b.quals.p + q_before + (base0[(size_t)i] - base0[0]), pc.quals.p, pc.quals.n);
+        uint64_t* off = b.offsets.p + rec0[(size_t)i] + 1;
+        uint64_t* noff = b.name_offsets.p + rec0[(size_t)i] + 1;
+        for (size_t j = 0; j < pc.ends.n; ++j) {
+            off[j] = (uint64_t)base0[(size_t)i] + pc.ends.p[j];
+            noff[j] = (uint64_t)name0[(size_t)i] + pc.name_ends.p[j];
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < nt; ++i) th.emplace_back(place, i);
+        place(0);
+        for (auto& t : th) t.join();
+    }
+    b.bases.n = nb; b.names.n = nn;
+    b.offsets.n = nrec + 1; b.name_offsets.n = nrec + 1;
+    if (want_quals) b.quals.n = q_before + (nb - base0[0]);
+    const size_t got = nrec - (size_t)b.nseq;
+    if (got && !want_quals) b.quals_ok = false;
+    if (got) bytes_per_rec = (double)cut / (double)got;
+    b.nseq = (int64_t)nrec;
+    if (map) {
+        map_pos += cut;
+    } else { // keep the unfinished tail for the next call
+        const size_t tail = blk.size() - cut;
+        if (tail) memmove(blk.data(), blk.data() + cut, tail);
+        blk.resize(tail);
+    }
+    return 1;
+}
 
 extern "C" void rk__set_error(const char* msg); // rk_api.hip
 static int perr(int code, const std::string& m) { rk__set_error(m.c_str()); return code; }
@@ -195,19 +526,56 @@ extern "C" {
 
 int rk_reader_open(const char* path, rk_reader** out) {
     if (!path || !out) return perr(RK_ERR_ARG, "bad arguments");
-    gzFile fp = strcmp(path, "-") == 0 ? gzdopen(0, "r") : gzopen(path, "r");
-    if (!fp) return perr(RK_ERR_IO, std::string("cannot open ") + path);
-    gzbuffer(fp, 1 << 20);
     rk_reader* r = new rk_reader();
-    r->fp = fp;
     r->buf.resize(4u << 20);
+    {
+        const char* e = getenv("RKMH_PARSE_THREADS");
+        long v = e ? atol(e) : 0;
+        r->nthreads = (int)(v > 0 ? (v > 64 ? 64 : v) : 8);
+    }
+    if (const char* e = getenv("RKMH_PARSE_BLOCK_KB")) { // testing knob: small blocks exercise cut/carry/merge
+        long v = atol(e);
+        if (v > 0) { r->max_block = (size_t)v << 10; r->min_par = r->max_block / 8; }
+    }
+    bool plain = false;
+    if (strcmp(path, "-") != 0) { // regular uncompressed file: map it, no read() copies at all
+        int fd = open(path, O_RDONLY);
+        if (fd < 0) { delete r; return perr(RK_ERR_IO, std::string("cannot open ") + path); }
+        struct stat st;
+        unsigned char magic[2] = {0, 0};
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) >= 1 &&
+            !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                r->map = (const unsigned char*)m;
+                r->map_size = (size_t)st.st_size;
+                plain = true;
+            }
+        }
+        close(fd);
+    }
+    if (!r->map) {
+        gzFile fp = strcmp(path, "-") == 0 ? gzdopen(0, "r") : gzopen(path, "r");
+        if (!fp) { delete r; return perr(RK_ERR_IO, std::string("cannot open ") + path); }
+        gzbuffer(fp, 1 << 20);
+        r->fp = fp;
+        plain = gzdirect(fp) != 0;
+    }
+    r->par_ok = plain && r->nthreads > 1;
+    if (!r->par_ok && r->map) r->to_sequential();
     *out = r;
     return RK_OK;
+}
+
+void rk_reader_set_options(rk_reader* r, int flags) {
+    if (r) r->skip_quals = (flags & RK_READER_NO_QUALS) != 0;
 }
 
 void rk_reader_close(rk_reader* r) {
     if (!r) return;
     if (r->fp) gzclose(r->fp);
+    if (r->map) munmap((void*)r->map, r->map_size);
     delete r;
 }
 
@@ -221,6 +589,14 @@ int rk_reader_next(rk_reader* r, int64_t max_records, uint64_t max_bases, rk_seq
     while (!r->finished) {
         if (max_records > 0 && b.nseq >= max_records) break;
         if (max_bases > 0 && b.bases.n >= max_bases) break;
+        if (r->par_ok && max_records > 0 && max_records < 65536) r->to_sequential(); // small exact batches
+        if (r->par_ok) { // block-parallel: limits are soft (a whole block is appended at a time)
+            int rb = r->next_block(b, max_records);
+            if (rb == -3) return perr(RK_ERR_NOMEM, "out of memory");
+            if (rb == 0) { r->finished = true; break; }
+            if (rb == 1) break;
+            continue; // -1: fell back to the sequential scanner
+        }
         int rc = r->next(b);
         if (rc == -3) return perr(RK_ERR_NOMEM, "out of memory");
         if (rc <= 0) { r->finished = true; break; } // EOF, or truncated record: ends the file (rkmh.cpp:251)
@@ -238,8 +614,9 @@ int rk_parse_files(const char* const* paths, int npaths, rk_seqset* out) {
         int rc = rk_reader_open(paths[i], &r);
         if (rc != RK_OK) return rc;
         for (;;) {
-            int k = r->next(b);
+            int k = r->par_ok ? r->next_block(b, 0) : r->next(b);
             if (k == -3) { rk_reader_close(r); return perr(RK_ERR_NOMEM, "out of memory"); }
+            if (k == -1) continue;
             if (k <= 0) break;
         }
         rk_reader_close(r);

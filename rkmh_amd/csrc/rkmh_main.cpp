@@ -78,35 +78,38 @@ struct Opts {
     int device = 0;
 };
 
-// bounded queue of parsed batches
-struct Queue {
+// bounded queue between pipeline stages (parser -> classify -> format/write)
+template <typename V> struct QueueT {
     std::mutex m;
     std::condition_variable cv;
-    std::deque<rk_seqset> q;
+    std::deque<V> q;
     bool done = false;
     std::string err;
-    void push(const rk_seqset& s) {
+    void push(V s) {
         std::unique_lock<std::mutex> l(m);
         cv.wait(l, [&] { return q.size() < 2; });
-        q.push_back(s);
+        q.push_back(std::move(s));
         cv.notify_all();
     }
-    bool pop(rk_seqset* s) {
+    bool pop(V* s) {
         std::unique_lock<std::mutex> l(m);
         cv.wait(l, [&] { return !q.empty() || done; });
         if (q.empty()) return false;
-        *s = q.front();
+        *s = std::move(q.front());
         q.pop_front();
         cv.notify_all();
         return true;
     }
     void finish() { std::lock_guard<std::mutex> l(m); done = true; cv.notify_all(); }
 };
+typedef QueueT<rk_seqset> Queue;
+struct Classified { rk_seqset reads; std::vector<int32_t> out4; };
 
-static void emit_lines(const rk_seqset& refs, const rk_seqset& reads, const int32_t* out4, const Opts& o, std::string& buf) {
+static void format_range(const rk_seqset& refs, const rk_seqset& reads, const int32_t* out4, const Opts& o,
+                         int64_t lo, int64_t hi, std::string& buf) {
     buf.clear();
     char line[8192];
-    for (int64_t i = 0; i < reads.nseq; ++i) {
+    for (int64_t i = lo; i < hi; ++i) {
         const int32_t* r = out4 + i * 4;
         const char* refn = refs.names + refs.name_offsets[r[0]];
         const char* readn = reads.names + reads.name_offsets[i];
@@ -118,7 +121,27 @@ static void emit_lines(const rk_seqset& refs, const rk_seqset& reads, const int3
             buf.append(big.data(), (size_t)n);
         } else buf.append(line, (size_t)n);
     }
-    fwrite(buf.data(), 1, buf.size(), stdout);
+}
+
+// TSV lines in read order (rkmh.cpp:889-897); big batches are formatted by a few threads, written in order
+static void emit_lines(const rk_seqset& refs, const rk_seqset& reads, const int32_t* out4, const Opts& o, std::string& buf) {
+    const int nt = reads.nseq >= 65536 ? 6 : 1;
+    if (nt == 1) {
+        format_range(refs, reads, out4, o, 0, reads.nseq, buf);
+        fwrite(buf.data(), 1, buf.size(), stdout);
+        return;
+    }
+    static std::vector<std::string> parts;
+    parts.resize((size_t)nt);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            format_range(refs, reads, out4, o, reads.nseq * t / nt, reads.nseq * (t + 1) / nt, parts[(size_t)t]);
+        });
+    for (int t = 0; t < nt; ++t) {
+        th[(size_t)t].join();
+        fwrite(parts[(size_t)t].data(), 1, parts[(size_t)t].size(), stdout);
+    }
 }
 
 struct LoadedSketches { std::vector<std::string> names; std::vector<uint64_t> sk; std::vector<int32_t> lens; std::vector<int> ks; int S = 0; };
@@ -222,6 +245,7 @@ static int main_stream(int argc, char** argv) {
             for (const char* path : o.reads) {
                 rk_reader* rd = nullptr;
                 if (rk_reader_open(path, &rd) != RK_OK) { q.err = rk_last_error(); break; }
+                rk_reader_set_options(rd, RK_READER_NO_QUALS); // stream never looks at qualities
                 for (;;) {
                     rk_seqset s;
                     if (rk_reader_next(rd, 1 << 20, 1ull << 28, &s) != RK_OK) { q.err = rk_last_error(); break; }
@@ -233,20 +257,31 @@ static int main_stream(int argc, char** argv) {
             }
             q.finish();
         });
-        rk_seqset s;
+        QueueT<Classified> done_q;
+        std::thread writer([&] { // lines leave in read order: one writer, batches in queue order
+            Classified c;
+            std::string wbuf;
+            while (done_q.pop(&c)) {
+                double a = now_s();
+                emit_lines(refs, c.reads, c.out4.data(), o, wbuf);
+                rk_seqset_free(&c.reads);
+                t_emit += now_s() - a;
+            }
+        });
         for (;;) {
             double a = now_s();
-            if (!q.pop(&s)) break;
+            Classified c;
+            if (!q.pop(&c.reads)) break;
             double b = now_s();
-            out4.resize((size_t)s.nseq * 4);
-            CK(rk_classify_batch(ctx, s.bases, s.offsets, s.nseq, out4.data()));
+            c.out4.resize((size_t)c.reads.nseq * 4);
+            CK(rk_classify_batch(ctx, c.reads.bases, c.reads.offsets, c.reads.nseq, c.out4.data()));
             double c2 = now_s();
-            emit_lines(refs, s, out4.data(), o, buf);
-            rk_seqset_free(&s);
-            double d = now_s();
-            t_wait += b - a; t_cls += c2 - b; t_emit += d - c2;
+            done_q.push(std::move(c));
+            t_wait += b - a; t_cls += c2 - b;
         }
-        if (g_timing) fprintf(stderr, "[rkmh timing] wait-for-parser %.3f s, classify %.3f s, format+write %.3f s\n", t_wait, t_cls, t_emit);
+        done_q.finish();
+        writer.join();
+        if (g_timing) fprintf(stderr, "[rkmh timing] wait-for-parser %.3f s, classify %.3f s, format+write %.3f s (overlapped)\n", t_wait, t_cls, t_emit);
         producer.join();
         if (!q.err.empty()) { fprintf(stderr, "rkmh: %s\n", q.err.c_str()); exit(1); }
     }

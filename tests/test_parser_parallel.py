@@ -1,0 +1,121 @@
+"""Block-parallel FASTA/FASTQ front end (rk_parse.cpp next_block) against the kseq-grammar restatement in
+oracle/oracle.py (kseq.hpp:170-208) and against the sequential scanner, on well-formed and hostile inputs.
+CPU only: the parser is host code."""
+import os
+
+import numpy as np
+import pytest
+
+from rkmh_amd import api
+
+
+def _records(ss):
+    out = []
+    for i in range(len(ss["names"])):
+        s = bytes(ss["bases"][int(ss["offsets"][i]):int(ss["offsets"][i + 1])])
+        q = ss["quals"][i] if ss.get("quals") is not None else None
+        out.append((ss["names"][i], s, q))
+    return out
+
+
+def _oracle_records(orc, data):
+    recs = orc.kseq_parse_bytes(data)
+    have_q = len(recs) > 0 and all(r[2] is not None for r in recs)
+    return [(r[0], r[1], r[2] if have_q else None) for r in recs]
+
+
+def _parse(path, threads, block_kb):
+    os.environ["RKMH_PARSE_THREADS"] = str(threads)
+    os.environ["RKMH_PARSE_BLOCK_KB"] = str(block_kb)
+    try:
+        whole = _records(api.parse_files([path]))
+        rd = api.Reader(path)
+        batched = []
+        while True:
+            b = rd.next_batch(max_records=1 << 16, max_bases=1 << 28)
+            if b is None:
+                break
+            batched.extend(_records(b))
+        rd.close()
+        return whole, batched
+    finally:
+        del os.environ["RKMH_PARSE_THREADS"]
+        del os.environ["RKMH_PARSE_BLOCK_KB"]
+
+
+def _fastq(rng, n, crlf=False, at_quals=False, lens=(20, 200)):
+    nl = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n):
+        L = int(rng.integers(lens[0], lens[1]))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTNacgt", np.uint8), L))
+        q = bytearray(rng.integers(33, 127, L, dtype=np.uint8).tobytes())
+        if at_quals and L and i % 3 == 0:
+            q[0] = ord("@")
+        if at_quals and L > 1 and i % 5 == 0:
+            q[0] = ord("+")
+        out.append(b"@r%d some comment" % i + nl + seq + nl + b"+" + nl + bytes(q) + nl)
+    return b"".join(out)
+
+
+def _fasta(rng, n, width=60):
+    out = []
+    for i in range(n):
+        L = int(rng.integers(0, 3000))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), L))
+        out.append(b">ref%d desc\n" % i)
+        for j in range(0, L, width):
+            out.append(seq[j:j + width] + b"\n")
+        if i % 7 == 0:
+            out.append(b"\n")
+    return b"".join(out)
+
+
+CASES = {
+    "fastq_plain": lambda r: _fastq(r, 4000),
+    "fastq_at_quals": lambda r: _fastq(r, 4000, at_quals=True),
+    "fastq_crlf": lambda r: _fastq(r, 3000, crlf=True, at_quals=True),
+    "fastq_no_final_newline": lambda r: _fastq(r, 3000)[:-1],
+    "fastq_truncated_qual": lambda r: _fastq(r, 3000)[:-40],
+    "fastq_truncated_in_header": lambda r: _fastq(r, 2000) + b"@last",
+    "fastq_multiline": lambda r: _fastq(r, 1500) + b"@ml\nACGT\nACGT\n+\nIIIIIIII\n" + _fastq(r, 1500),
+    "fastq_junk_between": lambda r: _fastq(r, 1500) + b"junk line\n" + _fastq(r, 1500),
+    "fastq_spaces_in_seq": lambda r: _fastq(r, 1500) + b"@sp\nAC GT\n+\nIIII\n" + _fastq(r, 1500),
+    "fastq_short_qual": lambda r: _fastq(r, 1500) + b"@sq\nACGTACGT\n+\nIII\n" + _fastq(r, 1500, at_quals=True),
+    "fastq_long_qual": lambda r: _fastq(r, 1500) + b"@lq\nACGT\n+\nIIII@II\n" + _fastq(r, 1500),
+    "fastq_empty_seq": lambda r: _fastq(r, 1000) + b"@e\n\n+\n\n" + _fastq(r, 1000),
+    "fasta_multiline": lambda r: _fasta(r, 400),
+    "fasta_plus_inside": lambda r: _fasta(r, 200) + b">odd\nACGT+ACGT\nACGT\n" + _fasta(r, 200),
+    "fasta_gt_inside": lambda r: _fasta(r, 200) + b">odd\nACGT>x\nACGT\n" + _fasta(r, 200),
+    "mixed_fasta_fastq": lambda r: _fasta(r, 150) + _fastq(r, 1500) + _fasta(r, 100),
+    "leading_blank_lines": lambda r: b"\n\n" + _fastq(r, 2000),
+    "leading_junk": lambda r: b"# comment\n" + _fastq(r, 2000),
+    "empty": lambda r: b"",
+    "only_newlines": lambda r: b"\n\n\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_parallel_parser_matches_kseq_grammar(orc, tmp_path, name):
+    rng = np.random.default_rng(abs(hash(name)) % (1 << 31))
+    data = CASES[name](rng)
+    path = str(tmp_path / (name + ".txt"))
+    with open(path, "wb") as f:
+        f.write(data)
+    want = _oracle_records(orc, data)
+    for threads, block_kb in ((1, 64), (4, 64), (8, 200), (8, 1 << 20)):
+        whole, batched = _parse(path, threads, block_kb)
+        assert whole == want, (name, threads, block_kb, "parse_files")
+        # quality strings are all-or-nothing per batch (rk_seqset.quals), so batches compare names + bases
+        assert [r[:2] for r in batched] == [r[:2] for r in want], (name, threads, block_kb, "reader")
+
+
+def test_parallel_parser_big_default_settings(orc, tmp_path):
+    """Default knobs (8 threads, large blocks) on a file big enough to split across every worker."""
+    rng = np.random.default_rng(5)
+    data = _fastq(rng, 60000, at_quals=True, lens=(100, 200))
+    path = str(tmp_path / "big.fq")
+    with open(path, "wb") as f:
+        f.write(data)
+    got = _records(api.parse_files([path]))
+    assert got == _oracle_records(orc, data)
