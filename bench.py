@@ -62,6 +62,8 @@ def main():
     rank, local, world = rdist.init()
     if world != a.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
+    if os.environ.get("RKMH_BENCH_ONE_DEVICE"):   # plumbing test: several ranks on one GPU (with RKMH_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ctx = rkmh_amd.Context(local)
@@ -74,7 +76,8 @@ def main():
         sk, ln = ctx.get_reference_sketches()
     else:
         sk = ln = None
-    sk, ln = rdist.broadcast_sketches(sk, ln, R, S, src=0, device=dev)   # RCCL over xGMI, once
+    sk, ln = rdist.broadcast_sketches(sk, ln, R, S, src=0,                 # RCCL over xGMI, once
+                                      device=dev if os.environ.get("RKMH_DIST_BACKEND", "nccl") == "nccl" else "cpu")
     if rank != 0:
         ctx.set_reference_sketches(sk, ln, ks, S)
 
@@ -109,7 +112,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
-    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    el = torch.tensor([t1 - t0], dtype=torch.float64,
+                      device=dev if (world == 1 or torch.distributed.get_backend() == "nccl") else "cpu")
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el.item())
