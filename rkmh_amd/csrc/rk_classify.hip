@@ -74,7 +74,7 @@ struct TileGeom {
 
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
 __host__ __device__ inline size_t tile_lds_bytes(const TileGeom& g) {
-    return ((size_t)((stage_lds_dwords(g.cap_bytes) + 1) & ~1) + 3 * (size_t)g.qcap + 5 * (size_t)(g.T + 1) + 8 +
+    return ((size_t)((stage_lds_dwords(g.cap_bytes) + 3) & ~3) + 4 * (size_t)g.qcap + 5 * (size_t)(g.T + 1) + 8 +
             2 * (size_t)tile_map_words(g.cap_bytes) + 2 * 64 +
             (size_t)g.T * (size_t)(g.cwords + g.dset)) * 4;
 }
@@ -117,8 +117,9 @@ __device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uin
 // iteration.  Form (ii) of the guide: "=v" load, then a wait statement naming the destination "+v" right
 // before the first consumer.  Over-waiting by compiler-inserted waits is harmless (loads return in order).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void bucket_load_async(const uint4* p, u32x4& f) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f) : "v"(p) : "memory");
+__device__ __forceinline__ void bucket_load_async(const uint4* base, uint32_t byte_off, u32x4& f) {
+    // saddr form: wave-uniform table base in SGPRs + 32-bit byte offset per lane (no 64-bit address arithmetic)
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f) : "v"(byte_off), "s"(base) : "memory");
 }
 __device__ __forceinline__ void bucket_wait(u32x4& f) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : : "memory"); }
 
@@ -132,10 +133,9 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
     const uint32_t QCAP = (uint32_t)geo.qcap;
     const uint32_t DS = (uint32_t)geo.dset;
     uint32_t* stage = smem;
-    uint32_t* qh32 = stage + ((stage_lds_dwords(geo.cap_bytes) + 1) & ~1); // [2*QCAP] candidate hashes (8-byte aligned)
-    uint64_t* qh = reinterpret_cast<uint64_t*>(qh32);
-    uint32_t* qp = qh32 + 2 * QCAP;                              // [QCAP] read (within the tile) of the candidate window
-    uint32_t* rstart = qp + QCAP;                                // [T+1] byte offset of read t inside the tile
+    // candidate queue: one 16-byte entry per window {hash lo, hash hi, read within the tile, -} (one ds_write_b128)
+    uint4* qe = reinterpret_cast<uint4*>(stage + ((stage_lds_dwords(geo.cap_bytes) + 3) & ~3));
+    uint32_t* rstart = reinterpret_cast<uint32_t*>(qe + QCAP);   // [T+1] byte offset of read t inside the tile
     uint32_t* nwin = rstart + (T + 1);                           // [T+1] windows of read t (all k)
     uint32_t* nzero = nwin + (T + 1);                            // [T+1] zero hashes per read
     uint32_t* best = nzero + (T + 1);                            // [T+1] max over increments of (count << 16 | 0xFFFF - ref)
@@ -288,7 +288,14 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
         const bool has_invalid = __builtin_amdgcn_readfirstlane((int)misc[0]) != 0;
         // "plain" tiles (all reads equally long, no invalid base: the common case) need neither the start bitmap nor
         // the position -> read map; the others build both now
-        const bool plain = uniform && !has_invalid;
+        // ... and at least one window per read
+        uint32_t nw_min;
+        if (KT) nw_min = (uint32_t)num_windows((int)ulen, KT, pol.drop_last_window);
+        else {
+            nw_min = ~0u;
+            for (int j = 0; j < ks.n; ++j) { const uint32_t v = (uint32_t)num_windows((int)ulen, ks.k[j], pol.drop_last_window); nw_min = v < nw_min ? v : nw_min; }
+        }
+        const bool plain = uniform && !has_invalid && nw_min >= 1u;
         if (!plain) {
             for (uint32_t i = lane; i < bad_words; i += WAVE) bad[i] = 0;
             for (uint32_t c = lane; c * 32 < B; c += WAVE) { // chunk map: last read starting at or before byte 32c
@@ -359,7 +366,10 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                 const uint32_t e = e0 + (uint32_t)lane;
                 uint32_t m_tr = 0, m_off = 0;
                 bool multi = false;
-                if (e < qn) multi = take_candidate(qh[e], (int)qp[e], m_tr, m_off);
+                if (e < qn) {
+                    const uint4 ce = qe[e];
+                    multi = take_candidate(((uint64_t)ce.y << 32) | ce.x, (int)ce.z, m_tr, m_off);
+                }
                 const uint64_t mm = __ballot(multi);
                 if (mm) { // hits with several postings: 16 lanes walk one hit's posting list, 4 hits at a time
                     if (multi) { const uint32_t j = (uint32_t)__popcll(mm & lt_mask); mq[2 * j] = m_tr; mq[2 * j + 1] = m_off; }
@@ -403,10 +413,15 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
             // base need no start bitmap: compact window index w -> read t = w / nw, position p = w + t * (len - nw),
             // so no lane idles on read tails (k-1 positions per read).  Other tiles walk all byte positions.
             const uint32_t nw_u = (uint32_t)num_windows((int)ulen, k, pol.drop_last_window);
-            const bool compact = plain; // nw_u == 0 (reads shorter than k): no window at all
+            const bool compact = plain;
             const uint32_t nW = compact ? nw_u * (uint32_t)Tn : B;
-            const float rcp_nw = (compact && nw_u) ? 1.0f / (float)nw_u : 0.0f;
             const uint32_t nIt = (nW + WAVE - 1) / WAVE;
+            // compact mapping state of this lane, advanced by 64 windows per step without any division: window
+            // w = it * 64 + lane lies in read ct_ (as its window cwl) and starts at tile byte cp
+            const uint32_t dtail = ulen - nw_u;           // positions at the end of a read that start no window
+            uint32_t ct_ = 0, cwl = (uint32_t)lane, cp = (uint32_t)lane;
+            if (compact)
+                while (cwl >= nw_u) { cwl -= nw_u; ct_ += 1; cp += dtail; } // reads with fewer than 64 windows
             u32x4 fb = {0u, 0u, 0u, 0u}; // bucket fetched for the previous position (lookup in flight)
             uint64_t hp = 0;
             uint32_t tp = 0; // read of the previous position
@@ -415,56 +430,60 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                 // run positions until the queue may not take another wave of candidates (or the tile is done);
                 // step nIt only examines the last lookup
                 for (; it <= nIt && (MODE == 1 || qcount + WAVE <= QCAP); ++it) {
-                    const uint32_t w = it * WAVE + (uint32_t)lane;
-                    uint32_t p = w, t = 0;
+                    uint32_t t = 0;
                     uint64_t h = 0;
                     if (it < nIt) {
                         bool ok;
+                        uint32_t p;
                         if (compact) { // wave-uniform
-                            t = (uint32_t)((float)w * rcp_nw);
-                            t -= (t * nw_u > w) ? 1u : 0u;        // float rounding can be off by one either way
-                            t += ((t + 1u) * nw_u <= w) ? 1u : 0u;
-                            p = w + t * (ulen - nw_u);
-                            ok = w < nW;
+                            t = ct_; p = cp;
+                            ok = t < (uint32_t)Tn;
+                            cwl += WAVE; cp += WAVE;
+                            if (cwl >= nw_u) { // one read boundary per step, more only for reads with fewer than 64 windows
+                                cwl -= nw_u; ct_ += 1; cp += dtail;
+                                while (cwl >= nw_u) { cwl -= nw_u; ct_ += 1; cp += dtail; }
+                            }
                         } else {
+                            p = it * WAVE + (uint32_t)lane;
                             ok = p < B && !((bad[p >> 5] >> (p & 31)) & 1u);
                             if (ok) t = (uint32_t)read_of(p);
                         }
-                        const uint32_t pc = ok ? p : 0u; // keep the LDS addresses in range for idle lanes
-                        if (MODE == 1 && has_invalid && !window_valid<KT>(s, pc, k)) h = 0;
-                        else if RK_DBG(4) {
-                            h = ((uint64_t)(s.fwd[(s.fbase + pc) >> 2] * 0x9E3779B1u) << 32) | (s.rc[(B - (uint32_t)k - pc) >> 2] * 0x85EBCA6Bu);
-                        } else {
-                            const uint64_t f = murmur_window<KT, FOLD>(s.fwd, s.fbase + pc, k, pol.seed, pol.fold);
-                            const uint64_t r = murmur_window<KT, FOLD>(s.rc, B - (uint32_t)k - pc, k, pol.seed, pol.fold);
-                            h = f < r ? f : r;
+                        if (ok) { // idle lanes (read tails, the end of the tile) keep h = 0 and are never looked up
+                            if (MODE == 1 && has_invalid && !window_valid<KT>(s, p, k)) h = 0;
+                            else if RK_DBG(4) {
+                                h = ((uint64_t)(s.fwd[(s.fbase + p) >> 2] * 0x9E3779B1u) << 32) | (s.rc[(B - (uint32_t)k - p) >> 2] * 0x85EBCA6Bu);
+                            } else {
+                                const uint64_t f = murmur_window<KT, FOLD>(s.fwd, s.fbase + p, k, pol.seed, pol.fold);
+                                const uint64_t r = murmur_window<KT, FOLD>(s.rc, B - (uint32_t)k - p, k, pol.seed, pol.fold);
+                                h = f < r ? f : r;
+                            }
+                            if (MODE == 1) {
+                                if (pol.counter_counts_zero || h != 0) atomicAdd(&counter[h % slots], 1);
+                            } else {
+                                if (MODE == 2) { // mask_by_frequency, rkmh.cpp:916
+                                    const int c = counter[h % slots];
+                                    if (pol.mask_strict_less ? (c < min_occ) : (c <= min_occ)) h = 0;
+                                }
+                                if (h == 0) atomicAdd(&nzero[t], 1u);
+                            }
                         }
-                        if (MODE == 1) {
-                            if (ok && (pol.counter_counts_zero || h != 0)) atomicAdd(&counter[h % slots], 1);
-                            continue;
-                        }
-                        h = ok ? h : 0;
-                        if (MODE == 2 && ok) { // mask_by_frequency, rkmh.cpp:916
-                            const int c = counter[h % slots];
-                            if (pol.mask_strict_less ? (c < min_occ) : (c <= min_occ)) h = 0;
-                        }
-                        if (ok && h == 0) atomicAdd(&nzero[t], 1u);
                     }
                     if (MODE == 1) continue;
                     // examine the lookup issued one step ago: fingerprint matches / full buckets are queued
                     bucket_wait(fb);
                     if (!RK_DBG(1)) {
                         const uint32_t fp = index_fp(hp);
-                        const bool cand = hp != 0 && (fb.x == fp || fb.y == fp || fb.z == fp || fb.w == fp || fb.w != 0);
-                        const uint64_t m = __ballot(cand);
+                        // bitwise, not short-circuit: straight-line compares whose lane mask IS the ballot
+                        const bool cand = (hp != 0) & ((fb.x == fp) | (fb.y == fp) | (fb.z == fp) | (fb.w == fp) | (fb.w != 0));
+                        const uint64_t m = __builtin_amdgcn_ballot_w64(cand);
                         if (cand) {
-                            const uint32_t q = qcount + (uint32_t)__popcll(m & lt_mask);
-                            qh[q] = hp; qp[q] = tp;
+                            const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            qe[q] = make_uint4((uint32_t)hp, (uint32_t)(hp >> 32), tp, 0u);
                         }
                         qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
                     }
                     if RK_DBG(8) { if (h == 0x1234567ull) nzero[0] = 1; } else
-                    if (h != 0) bucket_load_async(ix.fpb + index_bucket(h, ix.bshift), fb); // lands while the next position is hashed
+                    if (h != 0) bucket_load_async(ix.fpb, index_bucket_nz(h, ix.bshift) << 4, fb); // lands while the next position is hashed
                     hp = h;
                     tp = t;
                 }
@@ -480,10 +499,10 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                 wave_sync();
                 if (last) { qcount = 0; break; }
                 const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
-                uint64_t ch = 0; uint32_t ct_ = 0;
-                if ((uint32_t)lane < rem) { ch = qh[qn + lane]; ct_ = qp[qn + lane]; }
+                uint4 ce = make_uint4(0u, 0u, 0u, 0u);
+                if ((uint32_t)lane < rem) ce = qe[qn + lane];
                 wave_sync();
-                if ((uint32_t)lane < rem) { qh[lane] = ch; qp[lane] = ct_; }
+                if ((uint32_t)lane < rem) qe[lane] = ce;
                 qcount = rem;
                 wave_sync();
             }

@@ -234,6 +234,10 @@ __host__ __device__ __forceinline__ uint32_t index_fp(uint64_t h) { return (uint
 __host__ __device__ __forceinline__ uint32_t index_bucket(uint64_t h, uint32_t bshift) {
     return bshift >= 32 ? 0u : (((uint32_t)(h >> 32) ^ ((uint32_t)h >> 31)) * 0x9E3779B1u) >> bshift;
 }
+// built indexes always have >= 256 buckets (bshift <= 24): no degenerate-table check in the hot loop
+__device__ __forceinline__ uint32_t index_bucket_nz(uint64_t h, uint32_t bshift) {
+    return (((uint32_t)(h >> 32) ^ ((uint32_t)h >> 31)) * 0x9E3779B1u) >> bshift;
+}
 __device__ __forceinline__ uint32_t index_find(const RefIndex& ix, uint64_t h) {
     const uint32_t fp = index_fp(h);
     uint32_t b = index_bucket(h, ix.bshift);
