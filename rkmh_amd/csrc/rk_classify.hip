@@ -438,11 +438,6 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                         if (compact) { // wave-uniform
                             t = ct_; p = cp;
                             ok = t < (uint32_t)Tn;
-                            cwl += WAVE; cp += WAVE;
-                            if (cwl >= nw_u) { // one read boundary per step, more only for reads with fewer than 64 windows
-                                cwl -= nw_u; ct_ += 1; cp += dtail;
-                                while (cwl >= nw_u) { cwl -= nw_u; ct_ += 1; cp += dtail; }
-                            }
                         } else {
                             p = it * WAVE + (uint32_t)lane;
                             ok = p < B && !((bad[p >> 5] >> (p & 31)) & 1u);
@@ -467,14 +462,23 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                                 if (h == 0) atomicAdd(&nzero[t], 1u);
                             }
                         }
+                        if (compact) { // advance the mapping after its use (in place, no register copies)
+                            cwl += WAVE; cp += WAVE;
+                            if (cwl >= nw_u) { // one read boundary per step, more only for reads with fewer than 64 windows
+                                cwl -= nw_u; ct_ += 1; cp += dtail;
+                                while (cwl >= nw_u) { cwl -= nw_u; ct_ += 1; cp += dtail; }
+                            }
+                        }
                     }
                     if (MODE == 1) continue;
                     // examine the lookup issued one step ago: fingerprint matches / full buckets are queued
                     bucket_wait(fb);
                     if (!RK_DBG(1)) {
                         const uint32_t fp = index_fp(hp);
-                        // bitwise, not short-circuit: straight-line compares whose lane mask IS the ballot
-                        const bool cand = (hp != 0) & ((fb.x == fp) | (fb.y == fp) | (fb.z == fp) | (fb.w == fp) | (fb.w != 0));
+                        // bitwise, not short-circuit: straight-line compares.  fb.w == fp is covered by fb.w != 0 (fp has bit 31
+                        // set).  Lanes without a window carry hp = 0 and looked up bucket(0) like everyone else: hash 0 is never
+                        // in the index (zero hashes are dropped from sketches), so at worst the drain rejects a few of them.
+                        const bool cand = (fb.x == fp) | (fb.y == fp) | (fb.z == fp) | (fb.w != 0);
                         const uint64_t m = __builtin_amdgcn_ballot_w64(cand);
                         if (cand) {
                             const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
                         qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
                     }
                     if RK_DBG(8) { if (h == 0x1234567ull) nzero[0] = 1; } else
-                    if (h != 0) bucket_load_async(ix.fpb, index_bucket_nz(h, ix.bshift) << 4, fb); // lands while the next position is hashed
+                    bucket_load_async(ix.fpb, index_bucket_nz(h, ix.bshift) << 4, fb); // lands while the next position is hashed
                     hp = h;
                     tp = t;
                 }

@@ -56,26 +56,29 @@ __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t
 }
 
 // MurmurHash3_x64_128 of the k bytes starting at byte offset `a` of the LDS dword array w32.
-// The array must be readable for 8 dwords past the window (buffers are padded).
+// The array must be readable for 16 bytes past the window (buffers are padded).
+// Windows are fetched with UNALIGNED 16-byte LDS reads: gfx950 runs with unaligned DS access enabled (hipcc itself
+// emits one ds_read_b128 for an align-1 vector load; verified on MI355X by tools/ubench_unaligned_lds.hip), so no
+// dword-aligned reads + v_alignbyte funnel is needed.
+typedef uint32_t rk_u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed)) rk_unaligned16 { rk_u32x4 v; };
+__device__ __forceinline__ rk_u32x4 lds_load16_unaligned(const uint32_t* w32, uint32_t byte_off) {
+    return reinterpret_cast<const rk_unaligned16*>(reinterpret_cast<const uint8_t*>(w32) + byte_off)->v;
+}
 template <int KT, int FOLD = -1>
 __device__ __forceinline__ uint64_t murmur_window(const uint32_t* w32, uint32_t a, int k_rt, uint32_t seed, int fold) {
     const int k = KT ? KT : k_rt;
-    uint32_t idx = a >> 2;
-    const uint32_t sh = a & 3;
     uint64_t h1 = seed, h2 = seed;
-    uint32_t prev = w32[idx];
     const int nblocks = k >> 4;
     for (int b = 0; b < nblocks; ++b) {
-        uint32_t w1 = w32[idx + 1], w2 = w32[idx + 2], w3 = w32[idx + 3], w4 = w32[idx + 4];
-        uint32_t s0 = alignbyte(w1, prev, sh), s1 = alignbyte(w2, w1, sh);
-        uint32_t s2 = alignbyte(w3, w2, sh), s3 = alignbyte(w4, w3, sh);
-        mm_block(h1, h2, (uint64_t)s0 | ((uint64_t)s1 << 32), (uint64_t)s2 | ((uint64_t)s3 << 32));
-        prev = w4; idx += 4;
+        const rk_u32x4 w = lds_load16_unaligned(w32, a);
+        mm_block(h1, h2, (uint64_t)w.x | ((uint64_t)w.y << 32), (uint64_t)w.z | ((uint64_t)w.w << 32));
+        a += 16;
     }
     const int rem = k & 15;
     if (rem) {
-        uint32_t w1 = w32[idx + 1], w2 = w32[idx + 2], w3 = w32[idx + 3], w4 = w32[idx + 4];
-        uint32_t t[4] = {alignbyte(w1, prev, sh), alignbyte(w2, w1, sh), alignbyte(w3, w2, sh), alignbyte(w4, w3, sh)};
+        const rk_u32x4 w = lds_load16_unaligned(w32, a);
+        uint32_t t[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int nv = rem - 4 * q;
