@@ -1,7 +1,7 @@
 # Builds the product: librkmh_amd.so (HIP kernels + C ABI, gfx950 only) and the rkmh CLI.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH := gfx950
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result $(EXTRA_HIPFLAGS)
 CSRC := rkmh_amd/csrc
 LIB := rkmh_amd/lib/librkmh_amd.so
 OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_call.o $(CSRC)/rk_api.o $(CSRC)/rk_parse.o $(CSRC)/rk_synth.o

@@ -41,6 +41,11 @@ namespace rk {
 #define RK_DBG(bit) (RK_ABLATE && (geo.dbg & (bit)))
 
 constexpr int WAVE = 64;
+// Occupancy target: the kernel is sensitive to it (5 -> 6 waves/SIMD = +11 % measured), so registers and LDS are
+// both budgeted for it: VGPRs <= 512 / waves, LDS per single-wave workgroup <= 160 KB / (4 * waves).
+#ifndef RK_WAVES_PER_SIMD
+#define RK_WAVES_PER_SIMD 7
+#endif
 constexpr int PF_MAX = 6; // prefetched base dwords per lane: tile bytes <= PF*64*4 - 8 (template parameter PF = 2 or 6)
 
 template <int CTRL>
@@ -75,7 +80,7 @@ struct TileGeom {
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
 __host__ __device__ inline size_t tile_lds_bytes(const TileGeom& g) {
     return ((size_t)((stage_lds_dwords(g.cap_bytes) + 3) & ~3) + 4 * (size_t)g.qcap + 5 * (size_t)(g.T + 1) + 8 +
-            2 * (size_t)tile_map_words(g.cap_bytes) + 2 * 64 +
+            2 * (size_t)tile_map_words(g.cap_bytes) +
             (size_t)g.T * (size_t)(g.cwords + g.dset)) * 4;
 }
 
@@ -125,7 +130,7 @@ __device__ __forceinline__ void bucket_wait(u32x4& f) { asm volatile("s_waitcnt 
 
 // MODE 0: classify; MODE 1: count pass of -M (rkmh.cpp:904-910); MODE 2: classify with the -M mask (rkmh.cpp:916)
 template <int KT, int MODE, int FOLD, int PF>
-__global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
+__global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
                                                            uint32_t nreads, KsArr ks, int S, RefIndex ix, int32_t* counter,
                                                            uint64_t slots, int min_occ, int32_t* out4, DevPolicy pol, TileGeom geo) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -145,7 +150,9 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
     uint32_t* tmap = bad + tile_map_words(geo.cap_bytes);        // read index holding tile byte 32*c
     uint32_t* c16 = tmap + tile_map_words(geo.cap_bytes);        // [T][cwords] packed 16-bit per-reference counters
     uint32_t* dset = c16 + T * geo.cwords;                       // [T][DS] multiset of the slots the read has hit
-    uint32_t* mq = dset + T * DS;                                // [64][2] hits with several postings (drain)
+    // [64][2] hits with several postings (drain).  Aliases the first 32 queue entries: a drain step has its 64
+    // entries in registers before it writes here, and entries left for later sit at index >= 64.
+    uint32_t* mq = reinterpret_cast<uint32_t*>(qe);
     const int lane = threadIdx.x;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
@@ -189,6 +196,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
     };
     auto wait_bases = [&]() {
         if constexpr (PF == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]) : : "memory");
+        else if constexpr (PF == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]) : : "memory");
     };
     if (blockIdx.x < ntiles) { load_offsets(blockIdx.x, cur_a, cur_b, cur_o); load_bases(cur_a, cur_b); }
@@ -322,6 +330,10 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
             const uint32_t cnt = ((old >> sh) & 0xFFFFu) + 1u;
             atomicMax(&best[t], (cnt << 16) | (0xFFFFu - ref));
         };
+        // one candidate window: verify the full key, find the occurrence rank of this sketch hash within the read
+        // (exact LDS multiset: entry = (slot + 1) | (occurrences - 1) << 27) and add the postings the multiset merge of
+        // rkmh.cpp:869 would count.  A hit with several postings is returned (read << 8 | rank, postings offset) for
+        // the 16-lanes-per-hit pass instead of looping here with 63 lanes idle.
         // one candidate window: verify the full key, find the occurrence rank of this sketch hash within the read
         // (exact LDS multiset: entry = (slot + 1) | (occurrences - 1) << 27) and add the postings the multiset merge of
         // rkmh.cpp:869 would count.  A hit with several postings is returned (read << 8 | rank, postings offset) for
@@ -546,17 +558,13 @@ __global__ __launch_bounds__(WAVE, 6) void k_classify_tile(const uint8_t* __rest
     }
 }
 
-static TileGeom make_geom(int maxlen, int nref, int expect_hits) {
+// LDS budget of one single-wave workgroup for 6 waves per SIMD (24 per CU, 512-byte allocation granules).  The kernel
+// saturates VALU issue at 6 waves/SIMD and loses ~11 % at 5 (measured), so tiles never grow past this.
+constexpr size_t LDS_BUDGET_6_WAVES = 6656;
+
+static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_read) {
     TileGeom g;
     if (maxlen < 1) maxlen = 1;
-    int T = 500 / maxlen; // ~450 bytes per wave: the tile's candidates then fit one dense drain (measured best at 150 bp)
-    if (T < 2) T = 2;
-    if (const char* e = getenv("RKMH_TILE_T")) T = atoi(e);
-    if (T > 16) T = 16;
-    if (T < 1) T = 1;
-    while (T > 1 && T * maxlen > PF_MAX * WAVE * 4 - 8) --T;
-    g.T = T;
-    g.cap_bytes = T * maxlen;
     g.qcap = 128;
     if (const char* e = getenv("RKMH_TILE_QCAP")) g.qcap = atoi(e);
     g.cwords = (nref + 1) / 2;
@@ -566,6 +574,28 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits) {
     g.dset = ds;
     g.dbg = 0;
     if (const char* e = getenv("RKMH_DBG")) g.dbg = atoi(e);
+    // Reads per tile: the hashing loop walks T * win_per_read windows 64 at a time, so T is chosen for the best fill of
+    // its last step (150 bp, k=16: T=3 fills 89.7 %, T=4 93.1 %) among the sizes that keep the occupancy target and
+    // the short prefetch (<= 3 dwords per lane).
+    auto fits = [&](int T, size_t budget) {
+        g.T = T; g.cap_bytes = T * maxlen;
+        return T * maxlen <= PF_MAX * WAVE * 4 - 8 && tile_lds_bytes(g) <= budget;
+    };
+    int best = 1;
+    double best_fill = -1.0;
+    if (win_per_read < 1) win_per_read = 1;
+    for (int T = 1; T <= 16; ++T) {
+        if (T > 1 && (!fits(T, LDS_BUDGET_6_WAVES) || T * maxlen > 3 * WAVE * 4 - 8)) break;
+        const int nw = T * win_per_read;
+        const double fill = (double)nw / (double)(((nw + WAVE - 1) / WAVE) * WAVE);
+        if (fill >= best_fill - 0.005) { best = T; if (fill > best_fill) best_fill = fill; }
+    }
+    if (const char* e = getenv("RKMH_TILE_T")) best = atoi(e);
+    if (best > 16) best = 16;
+    if (best < 1) best = 1;
+    while (best > 1 && best * maxlen > PF_MAX * WAVE * 4 - 8) --best;
+    g.T = best;
+    g.cap_bytes = best * maxlen;
     return g;
 }
 
@@ -577,16 +607,18 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st) {
     if (nreads == 0) return hipSuccess;
-    TileGeom geo = make_geom(maxlen, mode == 1 ? 0 : ix.nref, mode == 1 ? 0 : expect_hits);
+    TileGeom geo = make_geom(maxlen, mode == 1 ? 0 : ix.nref, mode == 1 ? 0 : expect_hits,
+                             num_windows(maxlen, ks.k[0], pol.drop_last_window));
     if (mode == 1) { geo.qcap = 0; geo.dset = 0; }
     while (tile_lds_bytes(geo) > 20 * 1024 && geo.T > 1) { geo.T -= 1; geo.cap_bytes = geo.T * maxlen; } // >= 8 waves per CU
     const size_t lds = tile_lds_bytes(geo);
     const uint32_t ntiles = (nreads + (uint32_t)geo.T - 1) / (uint32_t)geo.T;
-    // Short-lived waves: each single-wave workgroup walks a handful of tiles (the first one cold, the others
-    // prefetched) and retires, so the hardware dispatcher keeps balancing the CUs; measured on MI355X: 4 tiles per
-    // workgroup beats both one tile per workgroup (no prefetch, +39 %) and chip-resident persistent waves (+17 %).
-    int tpb = 3;
-    if (const char* e = getenv("RKMH_TILE_TPB")) tpb = atoi(e) > 0 ? atoi(e) : 3;
+    // Short-lived waves: each single-wave workgroup walks a couple of tiles (the first one cold, the next prefetched)
+    // and retires, so the hardware dispatcher keeps balancing the CUs.  Measured on MI355X with the current kernel
+    // (T=4): 1 or 2 tiles per workgroup are within noise of each other, 3 is -1 %, 6 is -4 %, chip-resident persistent
+    // waves were -17 % (tail imbalance); 2 keeps the cross-tile prefetch useful when the batch streams from HBM.
+    int tpb = 2;
+    if (const char* e = getenv("RKMH_TILE_TPB")) tpb = atoi(e) > 0 ? atoi(e) : 2;
     const bool k16 = (ks.n == 1 && ks.k[0] == 16);
     const int kmode = mode == 1 ? 1 : (counter ? 2 : 0);
 #define RK_LAUNCH_P(KT, MODE, FOLD, PF)                                                                                    \
@@ -604,6 +636,7 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
 #define RK_LAUNCH(KT, MODE, FOLD)                                                                                    \
     do {                                                                                                             \
         if (geo.cap_bytes <= 2 * WAVE * 4 - 8) RK_LAUNCH_P(KT, MODE, FOLD, 2);                                       \
+        else if (geo.cap_bytes <= 3 * WAVE * 4 - 8) RK_LAUNCH_P(KT, MODE, FOLD, 3);                                  \
         else RK_LAUNCH_P(KT, MODE, FOLD, 6);                                                                         \
     } while (0)
 #define RK_LAUNCH_M(KT, FOLD)                                                                                        \

@@ -29,11 +29,17 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
     k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL;
     k ^= k >> 33; return k;
 }
+// x * 5 as (x << 2) + x in ONE v_lshl_add_u64 (hipcc otherwise spends two v_mad_u64_u32 and a move on it)
+__device__ __forceinline__ uint64_t mul5(uint64_t x) {
+    uint64_t r;
+    asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 __device__ __forceinline__ void mm_block(uint64_t& h1, uint64_t& h2, uint64_t k1, uint64_t k2) {
     k1 *= MM_C1; k1 = rotl64(k1, 31); k1 *= MM_C2; h1 ^= k1;
-    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = mul5(h1) + 0x52dce729;
     k2 *= MM_C2; k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2;
-    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = mul5(h2) + 0x38495ab5;
 }
 // finalisation + the 128->64 fold (policy U1).  FOLD >= 0 fixes the fold at compile time (no branches
 // between the forward and reverse-complement hash chains, so the scheduler can interleave them).
@@ -63,6 +69,16 @@ __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t
 typedef uint32_t rk_u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed)) rk_unaligned16 { rk_u32x4 v; };
 __device__ __forceinline__ rk_u32x4 lds_load16_unaligned(const uint32_t* w32, uint32_t byte_off) {
+#ifdef RK_HACK_ALIGNED_WINDOWS // timing experiment only (wrong hashes): what do the unaligned LDS reads cost?
+    rk_u32x4 hv = reinterpret_cast<const rk_unaligned16*>(reinterpret_cast<const uint8_t*>(w32) + (byte_off & ~15u))->v;
+    hv.x ^= byte_off * 0x9E3779B1u;
+    return hv;
+#endif
+#ifdef RK_HACK_RANDOM_WINDOWS // companion experiment: unaligned reads, same hash perturbation
+    rk_u32x4 hv = reinterpret_cast<const rk_unaligned16*>(reinterpret_cast<const uint8_t*>(w32) + byte_off)->v;
+    hv.x ^= byte_off * 0x9E3779B1u;
+    return hv;
+#endif
     return reinterpret_cast<const rk_unaligned16*>(reinterpret_cast<const uint8_t*>(w32) + byte_off)->v;
 }
 template <int KT, int FOLD = -1>
