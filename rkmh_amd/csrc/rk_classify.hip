@@ -237,36 +237,51 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 nwin[lane] = nw; nzero[lane] = 0; best[lane] = 0; flags[lane] = 0;
             }
         }
-        if (lane == 0) misc[0] = 0;
         const uint32_t ulen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(o_next - cur_o)); // length of read 0
         const bool uniform = __ballot(lane < Tn && (o_next - cur_o) != ulen) == 0ull;     // every read of the tile as long
         const uint32_t bad_words = (B + 31) / 32 + 1;
         if (MODE != 1)
             for (uint32_t i = lane; i < (uint32_t)Tn * DS; i += WAVE) dset[i] = 0;
         const uint32_t ndw = ((tstart & 3u) + B + 3u) >> 2; // global dwords covering the tile
+        // byte masks of the tile's first and last global dword (bytes of neighbouring tiles are not ours to judge)
+        const uint32_t m_first = ~0u << (8u * (tstart & 3u));
+        const uint32_t endb = ((tstart & 3u) + B) & 3u;
+        const uint32_t m_last = endb ? (~0u >> (8u * (4u - endb))) : ~0u;
+        uint32_t anyinv = 0;
         wait_bases();
 #pragma unroll
-        for (int q = 0; q < PF; ++q) { // upper-cased forward image + 4 validity bits per dword (8 lanes = one bitmap word)
+        for (int q = 0; q < PF; ++q) { // upper-cased forward image; does any base of the tile fail the ACGT test?
             if ((uint32_t)q * WAVE <= ndw) { // wave-uniform
                 const uint32_t jf = (uint32_t)q * WAVE + (uint32_t)lane;
-                const uint32_t x = (jf >= 1 && jf <= ndw) ? upper4(pf[q]) : 0u;
+                const bool in = jf >= 1 && jf <= ndw;
+                const uint32_t x = in ? upper4(pf[q]) : 0u;
                 if (jf <= ndw) s.fwd[jf] = x;
+                uint32_t m = in ? ~0u : 0u;
+                if (jf == 1) m &= m_first;
+                if (jf == ndw) m &= m_last;
+                anyinv |= acgt_mismatch4(x) & m;
+            }
+        }
+        cur_a = nxt_a; cur_b = nxt_b; cur_o = nxt_o;
+        const bool has_invalid = __ballot(anyinv != 0u) != 0ull;
+        wave_sync();
+        // ---- phase 0, interval 2: reverse-complement image; for the rare tile with a non-ACGT base the validity bitmap ----
+        {
+            const uint32_t nrc = (B + 3) >> 2;
+            for (uint32_t q = lane; q < nrc; q += WAVE) { // rc dword q = reversed complement of fwd bytes [fbase+B-4-4q, +4)
+                const uint32_t pp_ = s.fbase + B - 4u - 4u * q; // >= fbase - 3: the pad dword in front absorbs it
+                s.rc[q] = revcomp4(lds_load4_unaligned(s.fwd, pp_));
+            }
+        }
+        if (has_invalid) { // 4 validity bits per dword, 8 lanes = one bitmap word (bits indexed by fwd byte position)
+            for (uint32_t j0 = 0; j0 <= ndw; j0 += WAVE) {
+                const uint32_t jf = j0 + (uint32_t)lane;
+                const uint32_t x = jf <= ndw ? s.fwd[jf] : 0u;
                 uint32_t n = invalid4(x) << (4 * (lane & 7));
                 n |= (uint32_t)__shfl_xor((int)n, 1);
                 n |= (uint32_t)__shfl_xor((int)n, 2);
                 n |= (uint32_t)__shfl_xor((int)n, 4);
                 if ((lane & 7) == 0 && (jf >> 3) <= (ndw >> 3)) s.inv[jf >> 3] = n;
-            }
-        }
-        cur_a = nxt_a; cur_b = nxt_b; cur_o = nxt_o;
-        wave_sync();
-        // ---- phase 0, interval 2: reverse-complement image, read tails, chunk map, validity summary ----
-        {
-            const uint32_t nrc = (B + 3) >> 2;
-            for (uint32_t q = lane; q < nrc; q += WAVE) {
-                const int32_t pp_ = (int32_t)(s.fbase + B) - 4 - 4 * (int32_t)q;
-                const uint32_t idx = (uint32_t)pp_ >> 2, sh = (uint32_t)pp_ & 3;
-                s.rc[q] = __builtin_bswap32(comp4(alignbyte(s.fwd[idx + 1], s.fwd[idx], sh)));
             }
         }
         auto mark_tails = [&](int k) { // the last (len - windows) positions of every read start no window
@@ -280,20 +295,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 }
             }
         };
-        { // does any real base of the tile fail the ACGT test?
-            uint32_t any = 0;
-            const uint32_t lo_bit = s.fbase, hi_bit = s.fbase + B;
-            for (uint32_t wd = lane; wd * 32 < hi_bit; wd += WAVE) {
-                uint32_t m = s.inv[wd];
-                const uint32_t b0 = wd * 32;
-                if (b0 < lo_bit) m &= ~0u << (lo_bit - b0);
-                if (b0 + 32 > hi_bit) m &= ~0u >> (b0 + 32 - hi_bit);
-                any |= m;
-            }
-            if (any) misc[0] = 1;
-        }
         wave_sync();
-        const bool has_invalid = __builtin_amdgcn_readfirstlane((int)misc[0]) != 0;
         // "plain" tiles (all reads equally long, no invalid base: the common case) need neither the start bitmap nor
         // the position -> read map; the others build both now
         // ... and at least one window per read

@@ -121,6 +121,23 @@ __device__ __forceinline__ uint32_t comp4(uint32_t x) {
     uint32_t m = (x >> 1) & 0x01010101u;            // bit1: 0 for A,T  1 for C,G
     return x ^ 0x15151515u ^ (m | (m << 4));        // A<->T: ^0x15, C<->G: ^0x04
 }
+// Letter tables indexed by bits 2:1 of an upper-case base (A=0, C=1, T=2, G=3): one v_perm_b32 looks four bases up.
+// acgt_mismatch4: byte q is non-zero <=> byte q of x is NOT one of 'A','C','G','T'.
+__device__ __forceinline__ uint32_t acgt_mismatch4(uint32_t x) {
+    const uint32_t sel = (x >> 1) & 0x03030303u;
+    return x ^ __builtin_amdgcn_perm(0x47544341u, 0x47544341u, sel); // "ACTG"
+}
+// reverse complement of four upper-case bases (bytes that are not A/C/G/T: don't care, their windows are never hashed)
+__device__ __forceinline__ uint32_t revcomp4(uint32_t x) {
+    const uint32_t sel = (x >> 1) & 0x03030303u;
+    const uint32_t c = __builtin_amdgcn_perm(0x43414754u, 0x43414754u, sel); // "TGAC": A->T, C->G, T->A, G->C
+    return __builtin_bswap32(c);
+}
+// one dword at any byte offset of an LDS dword array (unaligned DS access, see murmur_window below)
+struct __attribute__((packed)) rk_unaligned4 { uint32_t v; };
+__device__ __forceinline__ uint32_t lds_load4_unaligned(const uint32_t* w32, uint32_t byte_off) {
+    return reinterpret_cast<const rk_unaligned4*>(reinterpret_cast<const uint8_t*>(w32) + byte_off)->v;
+}
 // 4-bit mask: bit q set <=> byte q is NOT one of 'A','C','G','T'
 __device__ __forceinline__ uint32_t invalid4(uint32_t x) {
     uint32_t r = 0;
