@@ -8,17 +8,20 @@
 // rerouted by the host through k_hash_tiles + k_sort_intersect.
 //
 // Work decomposition: ONE WAVE = one tile of T consecutive reads (T = 4 for 150 bp reads); a workgroup is a
-// single wave, so nothing ever waits at a workgroup barrier and the 8 waves a SIMD holds drift apart into
-// different phases -- latency-bound phases of one wave hide under the hashing of the others.
+// single wave, so nothing ever waits at a workgroup barrier and the 6 waves a SIMD holds drift apart into
+// different phases -- latency-bound phases of one wave hide under the hashing of the others.  The kernel is
+// bound by VALU issue (PMC: > 90 % of the issue slots), so every design decision below is about wave-level
+// instruction count; occupancy only has to stay at 6 waves/SIMD (registers <= 80, LDS <= 6.5 KB per tile).
 //   phase 0  the tile's bases are ONE contiguous byte range of the batch.  They (and the tile's offsets)
 //            were prefetched into registers while the previous tile was hashed; they are written to LDS as
-//            an upper-cased forward image, a reverse-complement image and a validity bitmap, plus a bitmap
-//            of the byte positions that start no hashable window (read tails, windows with a non-ACGT base).
-//   phase 1  the tile's byte positions are flattened over the 64 lanes; the hot loop is branch-free: two
-//            unaligned LDS window reads, both murmur3 chains in one basic block, one 16-byte bucket load
-//            from the L2-resident reference index whose latency hides behind the NEXT position's hashing.
-//            Fingerprint matches (about 1 window in 8) go to a wave-private LDS queue (ballot + popcount,
-//            no atomics).
+//            an upper-cased forward image and a reverse-complement image (v_perm_b32 letter tables).  A ballot
+//            says whether any base fails the ACGT test; only such tiles (and tiles of ragged reads) build the
+//            validity bitmap and the bitmap of byte positions that start no hashable window.
+//   phase 1  the tile's windows are flattened over the 64 lanes (division-free running mapping window -> read,
+//            position); the hot loop body is one basic block: two UNALIGNED 16-byte LDS reads (the two strands'
+//            windows, no alignment funnel), both murmur3 chains, one 16-byte bucket load (saddr form) from the
+//            reference index whose latency hides behind the NEXT window's hashing.  Fingerprint matches (about
+//            1 window in 8) go to a wave-private LDS queue of 16-byte entries (ballot + mbcnt, no atomics).
 //   drain    when the queue holds more than a wave's worth (and at the end) it is emptied with every lane
 //            busy: full-key verification, exact occurrence rank of the sketch hash within the read (LDS
 //            multiset: the merge of rkmh.cpp:869 counts min(multiplicities)), postings added to per-read
@@ -44,7 +47,7 @@ constexpr int WAVE = 64;
 // Occupancy target: the kernel is sensitive to it (5 -> 6 waves/SIMD = +11 % measured), so registers and LDS are
 // both budgeted for it: VGPRs <= 512 / waves, LDS per single-wave workgroup <= 160 KB / (4 * waves).
 #ifndef RK_WAVES_PER_SIMD
-#define RK_WAVES_PER_SIMD 7
+#define RK_WAVES_PER_SIMD 6
 #endif
 constexpr int PF_MAX = 6; // prefetched base dwords per lane: tile bytes <= PF*64*4 - 8 (template parameter PF = 2 or 6)
 
