@@ -661,7 +661,8 @@ static int build_index(rk_ctx* c) {
         for (;;) {
             uint32_t q = 0;
             while (q < 4 && fpb[4 * b + q] != 0) ++q;
-            if (q < 4) { fpb[4 * b + q] = index_fp(pairs[i].h); keys[4 * b + q] = pairs[i].h; vals[4 * b + q] = v; break; }
+            if (q < 4) { fpb[4 * b + q] |= index_fp(pairs[i].h); keys[4 * b + q] = pairs[i].h; vals[4 * b + q] = v; break; }
+            fpb[4 * b] |= IDX_OVF; // the key goes further down the chain: lookups must follow
             b = (b + 1) & bmask;
         }
         i = j;

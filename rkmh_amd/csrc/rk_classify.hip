@@ -37,7 +37,8 @@
 namespace rk {
 
 // Ablation switches used to attribute kernel time to its parts: build with
-// -DRK_ABLATE=1 and set RKMH_DBG (1 no queueing, 2 no phase 2, 4 cheap hash, 8 no bucket loads, 32 no drain).
+// -DRK_ABLATE=1 and set RKMH_DBG (1 no queueing, 2 no phase 2, 4 cheap hash, 8 no bucket loads, 32 no drain,
+// 64 no hit multiset, 128 no counter updates, 256 no index verification in the drain).
 #ifndef RK_ABLATE
 #define RK_ABLATE 0
 #endif
@@ -106,7 +107,7 @@ __device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uin
     uint32_t b = index_bucket(h, ix.bshift);
     for (;;) {
         const uint4 f = ix.fpb[b];
-        uint32_t m = (f.x == fp ? 1u : 0u) | (f.y == fp ? 2u : 0u) | (f.z == fp ? 4u : 0u) | (f.w == fp ? 8u : 0u);
+        uint32_t m = ((f.x & ~IDX_OVF) == fp ? 1u : 0u) | (f.y == fp ? 2u : 0u) | (f.z == fp ? 4u : 0u) | (f.w == fp ? 8u : 0u);
         while (m) {
             const uint32_t q = (uint32_t)__ffs((int)m) - 1u;
             m &= m - 1u;
@@ -115,7 +116,7 @@ __device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uin
             const uint32_t v = ix.vals[s];
             if (key == h) { slot = s; val = v; return true; }
         }
-        if (f.w == 0) return false;
+        if (!(f.x & IDX_OVF)) return false;
         b = (b + 1) & ix.bmask;
     }
 }
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
 
         // +1 for reference `ref` of read t; the monotone counters make (max_shared, first max_id) a running atomicMax
         auto add_posting = [&](int t, uint32_t ref) {
+            if RK_DBG(128) return;
             const uint32_t sh = (ref & 1u) * 16u;
             const uint32_t old = atomicAdd(&c16[t * geo.cwords + (int)(ref >> 1)], 1u << sh);
             const uint32_t cnt = ((old >> sh) & 0xFFFFu) + 1u;
@@ -345,9 +347,10 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         // the 16-lanes-per-hit pass instead of looping here with 63 lanes idle.
         auto take_candidate = [&](uint64_t h, int t, uint32_t& m_tr, uint32_t& m_off) -> bool {
             uint32_t slot = 0, v = 0;
+            if RK_DBG(256) { slot = (uint32_t)h & 0xFFFFu; v = (uint32_t)(h >> 40) % 180u | (1u << 20); } else
             if (!index_lookup(ix, h, slot, v)) return false; // re-reads the bucket (L1/L2 hit), then key + value together
             uint32_t rank = 0;
-            {
+            if (!RK_DBG(64)) {
                 uint32_t* ds = dset + (uint32_t)t * DS;
                 const uint32_t key = slot + 1u;
                 uint32_t idx = ((slot * 0x9E3779B1u) >> 16) & (DS - 1);
@@ -492,10 +495,11 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                     bucket_wait(fb);
                     if (!RK_DBG(1)) {
                         const uint32_t fp = index_fp(hp);
-                        // bitwise, not short-circuit: straight-line compares.  fb.w == fp is covered by fb.w != 0 (fp has bit 31
-                        // set).  Lanes without a window carry hp = 0 and looked up bucket(0) like everyone else: hash 0 is never
-                        // in the index (zero hashes are dropped from sketches), so at worst the drain rejects a few of them.
-                        const bool cand = (fb.x == fp) | (fb.y == fp) | (fb.z == fp) | (fb.w != 0);
+                        // bitwise, not short-circuit: straight-line compares.  A bucket whose overflow flag (sign bit of slot 0)
+                        // is set makes every window that lands in it a candidate (its slot-0 compare fails by design, the drain
+                        // sorts it out): 0.08 % of the windows.  Lanes without a window carry hp = 0 and looked up bucket(0)
+                        // like everyone else: hash 0 is never in the index, so at worst the drain rejects a few of them.
+                        const bool cand = (fb.x == fp) | (fb.y == fp) | (fb.z == fp) | (fb.w == fp) | ((int32_t)fb.x < 0);
                         const uint64_t m = __builtin_amdgcn_ballot_w64(cand);
                         if (cand) {
                             const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));

@@ -266,7 +266,12 @@ struct RefIndex {
 };
 constexpr uint32_t IDX_NOT_FOUND = 0xffffffffu;
 
-__host__ __device__ __forceinline__ uint32_t index_fp(uint64_t h) { return (uint32_t)h | 0x80000000u; }
+// fingerprint = 30 hash bits + the "occupied" bit 30 (never 0).  Bit 31 of a bucket's slot-0 word is the bucket's
+// OVERFLOW flag: some key that hashed here (or passed through here) was stored further down the chain.  Only then
+// does a lookup that found no fingerprint match have to look at the next bucket -- "bucket is full" alone does not
+// say so, and with ~0.7 keys per bucket it is 7 times more frequent than a real overflow.
+constexpr uint32_t IDX_OVF = 0x80000000u;
+__host__ __device__ __forceinline__ uint32_t index_fp(uint64_t h) { return ((uint32_t)h & 0x3fffffffu) | 0x40000000u; }
 __host__ __device__ __forceinline__ uint32_t index_bucket(uint64_t h, uint32_t bshift) {
     return bshift >= 32 ? 0u : (((uint32_t)(h >> 32) ^ ((uint32_t)h >> 31)) * 0x9E3779B1u) >> bshift;
 }
@@ -279,11 +284,11 @@ __device__ __forceinline__ uint32_t index_find(const RefIndex& ix, uint64_t h) {
     uint32_t b = index_bucket(h, ix.bshift);
     for (;;) {
         const uint4 f = ix.fpb[b];
-        if (f.x == fp && ix.keys[4 * b + 0] == h) return 4 * b + 0;
+        if ((f.x & ~IDX_OVF) == fp && ix.keys[4 * b + 0] == h) return 4 * b + 0;
         if (f.y == fp && ix.keys[4 * b + 1] == h) return 4 * b + 1;
         if (f.z == fp && ix.keys[4 * b + 2] == h) return 4 * b + 2;
         if (f.w == fp && ix.keys[4 * b + 3] == h) return 4 * b + 3;
-        if (f.w == 0) return IDX_NOT_FOUND;   // bucket not full => the key was never pushed further
+        if (!(f.x & IDX_OVF)) return IDX_NOT_FOUND;   // nothing was ever pushed past this bucket
         b = (b + 1) & ix.bmask;
     }
 }
