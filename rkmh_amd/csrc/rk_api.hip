@@ -102,7 +102,7 @@ struct rk_ctx {
     KsArr ks{};
     std::vector<uint64_t> h_sk;
     std::vector<int32_t> h_lens;
-    DevBuf d_fpb, d_keys, d_vals, d_post;
+    DevBuf d_fpb, d_kv, d_post;
     RefIndex ix{};
     bool have_refs = false;
     double density = 1.0; // fraction of a reference's k-mers that its sketch keeps (largest over references)
@@ -145,7 +145,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
-    for (DevBuf* b : {&c->d_fpb, &c->d_keys, &c->d_vals, &c->d_post, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+    for (DevBuf* b : {&c->d_fpb, &c->d_kv, &c->d_post, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
@@ -632,8 +632,7 @@ static int build_index(rk_ctx* c) {
     while ((size_t)nb * 5 < distinct * 4 + 4) { nb <<= 1; ++lg; }
     const uint32_t size = nb * 4;
     std::vector<uint32_t> fpb(size, 0);
-    std::vector<uint64_t> keys(size, 0);
-    std::vector<uint32_t> vals(size, 0);
+    std::vector<uint32_t> kv((size_t)size * 4, 0); // {key lo, key hi, value, 0} per slot
     std::vector<uint32_t> post;
     post.push_back(0);
     const uint32_t bmask = nb - 1, bshift = 32 - lg;
@@ -661,21 +660,24 @@ static int build_index(rk_ctx* c) {
         for (;;) {
             uint32_t q = 0;
             while (q < 4 && fpb[4 * b + q] != 0) ++q;
-            if (q < 4) { fpb[4 * b + q] |= index_fp(pairs[i].h); keys[4 * b + q] = pairs[i].h; vals[4 * b + q] = v; break; }
+            if (q < 4) {
+                const size_t sl = (size_t)4 * b + q;
+                fpb[sl] |= index_fp(pairs[i].h);
+                kv[4 * sl] = (uint32_t)pairs[i].h; kv[4 * sl + 1] = (uint32_t)(pairs[i].h >> 32); kv[4 * sl + 2] = v;
+                break;
+            }
             fpb[4 * b] |= IDX_OVF; // the key goes further down the chain: lookups must follow
             b = (b + 1) & bmask;
         }
         i = j;
     }
     RKCHK(c->d_fpb.reserve((size_t)size * 4));
-    RKCHK(c->d_keys.reserve((size_t)size * 8));
-    RKCHK(c->d_vals.reserve((size_t)size * 4));
+    RKCHK(c->d_kv.reserve((size_t)size * 16));
     RKCHK(c->d_post.reserve(post.size() * 4));
     HIPCHK(hipMemcpy(c->d_fpb.p, fpb.data(), (size_t)size * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->d_keys.p, keys.data(), (size_t)size * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->d_vals.p, vals.data(), (size_t)size * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_kv.p, kv.data(), (size_t)size * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_post.p, post.data(), post.size() * 4, hipMemcpyHostToDevice));
-    c->ix.fpb = c->d_fpb.as<uint4>(); c->ix.keys = c->d_keys.as<uint64_t>(); c->ix.vals = c->d_vals.as<uint32_t>();
+    c->ix.fpb = c->d_fpb.as<uint4>(); c->ix.kv = c->d_kv.as<uint4>();
     c->ix.post = c->d_post.as<uint32_t>();
     c->ix.bmask = bmask; c->ix.bshift = bshift; c->ix.nref = R;
     // a full bottom-S sketch of uniform hashes keeps the fraction (largest kept hash / 2^64) of the k-mers

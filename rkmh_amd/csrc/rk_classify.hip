@@ -112,9 +112,8 @@ __device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uin
             const uint32_t q = (uint32_t)__ffs((int)m) - 1u;
             m &= m - 1u;
             const uint32_t s = 4 * b + q;
-            const uint64_t key = ix.keys[s];
-            const uint32_t v = ix.vals[s];
-            if (key == h) { slot = s; val = v; return true; }
+            const uint4 e = ix.kv[s]; // key and value in one 16-byte fetch
+            if (e.x == (uint32_t)h && e.y == (uint32_t)(h >> 32)) { slot = s; val = e.z; return true; }
         }
         if (!(f.x & IDX_OVF)) return false;
         b = (b + 1) & ix.bmask;
