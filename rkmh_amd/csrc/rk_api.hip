@@ -102,7 +102,7 @@ struct rk_ctx {
     KsArr ks{};
     std::vector<uint64_t> h_sk;
     std::vector<int32_t> h_lens;
-    DevBuf d_fpb, d_kv, d_post;
+    DevBuf d_fpb, d_base, d_kv, d_post;
     RefIndex ix{};
     bool have_refs = false;
     double density = 1.0; // fraction of a reference's k-mers that its sketch keeps (largest over references)
@@ -145,7 +145,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
-    for (DevBuf* b : {&c->d_fpb, &c->d_kv, &c->d_post, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
@@ -672,12 +672,26 @@ static int build_index(rk_ctx* c) {
         i = j;
     }
     RKCHK(c->d_fpb.reserve((size_t)size * 4));
-    RKCHK(c->d_kv.reserve((size_t)size * 16));
+    // compact the key/value entries: key id = (keys stored in earlier buckets) + position in the bucket
+    std::vector<uint32_t> base((size_t)nb + 1, 0);
+    for (uint32_t b = 0; b < nb; ++b) {
+        uint32_t q = 0;
+        while (q < 4 && fpb[(size_t)4 * b + q] != 0) ++q;
+        base[(size_t)b + 1] = base[b] + q;
+    }
+    const size_t nkeys = base[nb];
+    std::vector<uint32_t> dense((nkeys + 1) * 4, 0);
+    for (uint32_t b = 0; b < nb; ++b)
+        for (uint32_t q = 0; q < base[(size_t)b + 1] - base[b]; ++q)
+            memcpy(&dense[((size_t)base[b] + q) * 4], &kv[((size_t)4 * b + q) * 4], 16);
+    RKCHK(c->d_base.reserve(((size_t)nb + 1) * 4));
+    HIPCHK(hipMemcpy(c->d_base.p, base.data(), ((size_t)nb + 1) * 4, hipMemcpyHostToDevice));
+    RKCHK(c->d_kv.reserve((nkeys + 1) * 16));
     RKCHK(c->d_post.reserve(post.size() * 4));
     HIPCHK(hipMemcpy(c->d_fpb.p, fpb.data(), (size_t)size * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->d_kv.p, kv.data(), (size_t)size * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_kv.p, dense.data(), (nkeys + 1) * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_post.p, post.data(), post.size() * 4, hipMemcpyHostToDevice));
-    c->ix.fpb = c->d_fpb.as<uint4>(); c->ix.kv = c->d_kv.as<uint4>();
+    c->ix.fpb = c->d_fpb.as<uint4>(); c->ix.base = c->d_base.as<uint32_t>(); c->ix.kv = c->d_kv.as<uint4>();
     c->ix.post = c->d_post.as<uint32_t>();
     c->ix.bmask = bmask; c->ix.bshift = bshift; c->ix.nref = R;
     // a full bottom-S sketch of uniform hashes keeps the fraction (largest kept hash / 2^64) of the k-mers

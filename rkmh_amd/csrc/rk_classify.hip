@@ -101,18 +101,20 @@ __device__ __forceinline__ void for_postings(const RefIndex& ix, uint32_t v, F f
     }
 }
 
-// full lookup: fingerprint scan, then key and value of a matching slot are fetched together
+// full lookup: fingerprint scan (+ the bucket's first key id), then key and value of a matching key are fetched together;
+// `slot` returns the key id (a dense number unique to the sketch hash)
 __device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uint32_t& slot, uint32_t& val) {
     const uint32_t fp = index_fp(h);
     uint32_t b = index_bucket(h, ix.bshift);
     for (;;) {
         const uint4 f = ix.fpb[b];
+        const uint32_t id0 = ix.base[b]; // fetched in the same round as the fingerprints
         uint32_t m = ((f.x & ~IDX_OVF) == fp ? 1u : 0u) | (f.y == fp ? 2u : 0u) | (f.z == fp ? 4u : 0u) | (f.w == fp ? 8u : 0u);
         while (m) {
             const uint32_t q = (uint32_t)__ffs((int)m) - 1u;
             m &= m - 1u;
-            const uint32_t s = 4 * b + q;
-            const uint4 e = ix.kv[s]; // key and value in one 16-byte fetch
+            const uint32_t s = id0 + q;
+            const uint4 e = ix.kv[s]; // key and value in one 16-byte fetch from the dense (L2-resident) key array
             if (e.x == (uint32_t)h && e.y == (uint32_t)(h >> 32)) { slot = s; val = e.z; return true; }
         }
         if (!(f.x & IDX_OVF)) return false;

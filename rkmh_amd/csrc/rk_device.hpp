@@ -250,14 +250,17 @@ __host__ __device__ __forceinline__ int num_windows(int len, int k, int drop_las
 // ---- resident reference index ------------------------------------------------------------------
 // All distinct hashes of all reference sketches in one bucketed hash table that stays L2 resident:
 //   fpb  : one 16-byte bucket = 4 x 32-bit fingerprints (0 = empty; slots of a bucket fill in order)
-//   kv   : per slot {full 64-bit hash (read only to confirm a fingerprint match), value, pad} in one 16-byte entry
-//   value: per slot, bit31=1 -> offset into post; else bits 30:29 = 0: one posting inline (ref | mult<<20, mult<512),
+//   base : per bucket, keys stored before it; key id = base[bucket] + position in the bucket (slots fill in order)
+//   kv   : per key id {full 64-bit hash (read only to confirm a fingerprint match), value, pad} in one 16-byte entry
+//   value: per key, bit31=1 -> offset into post; else bits 30:29 = 0: one posting inline (ref | mult<<20, mult<512),
 //          1: two postings of multiplicity 1 inline (ref1 | ref2<<11, both < 2048)
 //   post : [off] = count, then count x (ref, mult)
 // A lookup that misses (about 7 of 8 read k-mers) costs exactly one 16-byte load.
 struct RefIndex {
     const uint4* fpb;
-    const uint4* kv;      // per slot {key lo, key hi, value, 0}: one 16-byte line fetch verifies a hit AND brings its postings
+    const uint32_t* base; // per bucket: number of keys stored in the buckets before it => key id = base[bucket] + slot in bucket
+    const uint4* kv;      // per key id {key lo, key hi, value, 0}, DENSE (no holes): a 16-byte fetch verifies a hit and brings its
+                          // postings, and the whole array (16 B x distinct sketch hashes) is small enough to live in L2
     const uint32_t* post;
     uint32_t bmask;   // buckets - 1
     uint32_t bshift;  // 32 - log2(buckets)
@@ -278,8 +281,8 @@ __host__ __device__ __forceinline__ uint32_t index_bucket(uint64_t h, uint32_t b
 __device__ __forceinline__ uint32_t index_bucket_nz(uint64_t h, uint32_t bshift) {
     return (((uint32_t)(h >> 32) ^ ((uint32_t)h >> 31)) * 0x9E3779B1u) >> bshift;
 }
-__device__ __forceinline__ uint64_t index_key(const RefIndex& ix, uint32_t slot) {
-    const uint2 k = *reinterpret_cast<const uint2*>(&ix.kv[slot]);
+__device__ __forceinline__ uint64_t index_key(const RefIndex& ix, uint32_t id) {
+    const uint2 k = *reinterpret_cast<const uint2*>(&ix.kv[id]);
     return ((uint64_t)k.y << 32) | k.x;
 }
 __device__ __forceinline__ uint32_t index_find(const RefIndex& ix, uint64_t h) {
@@ -287,10 +290,11 @@ __device__ __forceinline__ uint32_t index_find(const RefIndex& ix, uint64_t h) {
     uint32_t b = index_bucket(h, ix.bshift);
     for (;;) {
         const uint4 f = ix.fpb[b];
-        if ((f.x & ~IDX_OVF) == fp && index_key(ix, 4 * b + 0) == h) return 4 * b + 0;
-        if (f.y == fp && index_key(ix, 4 * b + 1) == h) return 4 * b + 1;
-        if (f.z == fp && index_key(ix, 4 * b + 2) == h) return 4 * b + 2;
-        if (f.w == fp && index_key(ix, 4 * b + 3) == h) return 4 * b + 3;
+        const uint32_t id0 = ix.base[b];
+        if ((f.x & ~IDX_OVF) == fp && index_key(ix, id0 + 0) == h) return id0 + 0;
+        if (f.y == fp && index_key(ix, id0 + 1) == h) return id0 + 1;
+        if (f.z == fp && index_key(ix, id0 + 2) == h) return id0 + 2;
+        if (f.w == fp && index_key(ix, id0 + 3) == h) return id0 + 3;
         if (!(f.x & IDX_OVF)) return IDX_NOT_FOUND;   // nothing was ever pushed past this bucket
         b = (b + 1) & ix.bmask;
     }
