@@ -655,7 +655,10 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
         else if (kmode == 1) RK_LAUNCH(KT, 1, FOLD);                                                                 \
         else RK_LAUNCH(KT, 2, FOLD);                                                                                 \
     } while (0)
-    if (!k16) RK_LAUNCH_M(0, -1);             // any k / several k: runtime fold
+    // single k of 12 or 20 (the reference's other documented settings): window length known at compile time, runtime fold
+    if (ks.n == 1 && ks.k[0] == 12) RK_LAUNCH_M(12, -1);
+    else if (ks.n == 1 && ks.k[0] == 20) RK_LAUNCH_M(20, -1);
+    else if (!k16) RK_LAUNCH_M(0, -1);        // any k / several k: runtime fold
     else if (pol.fold == 0) RK_LAUNCH_M(16, 0);
     else if (pol.fold == 1) RK_LAUNCH_M(16, 1);
     else RK_LAUNCH_M(16, 2);
