@@ -76,7 +76,8 @@ struct TileGeom {
     int32_t T;          // reads per tile (<= 16)
     int32_t cap_bytes;  // staged bytes per tile
     int32_t qcap;       // candidate queue entries (>= 128)
-    int32_t cwords;     // 16-bit counter words per read = (nref + 1) / 2
+    int32_t cwords;     // counter words per read = ceil(nref / counters per word)
+    int32_t clg;        // log2(counters per 32-bit word): 1 = 16-bit counters, 2 = 8-bit (reads with <= 255 windows)
     int32_t dset;       // slots of the per-read hit multiset (power of two)
     int32_t dbg;        // ablation switches (only read when built with -DRK_ABLATE=1)
 };
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
     uint32_t* mq = reinterpret_cast<uint32_t*>(qe);
     const int lane = threadIdx.x;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t clg = (uint32_t)geo.clg, cper_m1 = (1u << clg) - 1u, cbits = 32u >> clg, cmask = (1u << cbits) - 1u;
 
     if (MODE != 1) { // counters are re-zeroed by phase 2 after use
         for (int i = lane; i < T * geo.cwords; i += WAVE) c16[i] = 0;
@@ -333,9 +335,11 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         // +1 for reference `ref` of read t; the monotone counters make (max_shared, first max_id) a running atomicMax
         auto add_posting = [&](int t, uint32_t ref) {
             if RK_DBG(128) return;
-            const uint32_t sh = (ref & 1u) * 16u;
-            const uint32_t old = atomicAdd(&c16[t * geo.cwords + (int)(ref >> 1)], 1u << sh);
-            const uint32_t cnt = ((old >> sh) & 0xFFFFu) + 1u;
+            // packed counters: 16 bits each, or 8 bits when no read of the batch has more than 255 windows (a count never
+            // exceeds the number of windows, so no field can carry into its neighbour)
+            const uint32_t sh = (ref & cper_m1) * cbits;
+            const uint32_t old = atomicAdd(&c16[t * geo.cwords + (int)(ref >> clg)], 1u << sh);
+            const uint32_t cnt = ((old >> sh) & cmask) + 1u;
             atomicMax(&best[t], (cnt << 16) | (0xFFFFu - ref));
         };
         // one candidate window: verify the full key, find the occurrence rank of this sketch hash within the read
@@ -553,11 +557,13 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 const int max_id = bk ? (int)(0xFFFFu - (bk & 0xFFFFu)) : 0;
                 const int max_shared = (int)(bk >> 16);
                 int prev = max_id > 0 ? 0 : -1;
-                for (int w = sl; 2 * w < max_id; w += 16) {
-                    const uint32_t x = ct[w];
-                    const int c0 = (int)(x & 0xFFFFu), c1 = (int)(x >> 16);
-                    if (c0 > prev) prev = c0;                       // ref 2w < max_id
-                    if (2 * w + 1 < max_id && c1 > prev) prev = c1;
+                for (int w = sl; (w << clg) < max_id; w += 16) {
+                    uint32_t x = ct[w];
+                    for (uint32_t j = 0; j <= cper_m1; ++j) { // counters of references (w << clg) + j < max_id
+                        const int cj = (int)(x & cmask);
+                        x >>= cbits;
+                        if ((int)((uint32_t)(w << clg) + j) < max_id && cj > prev) prev = cj;
+                    }
                 }
                 prev = row_max_i32(prev);
                 wave_sync();
@@ -572,12 +578,14 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
 // saturates VALU issue at 6 waves/SIMD and loses ~11 % at 5 (measured), so tiles never grow past this.
 constexpr size_t LDS_BUDGET_6_WAVES = 6656;
 
-static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_read) {
+static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_read, int win_total) {
     TileGeom g;
     if (maxlen < 1) maxlen = 1;
     g.qcap = 128;
     if (const char* e = getenv("RKMH_TILE_QCAP")) g.qcap = atoi(e);
-    g.cwords = (nref + 1) / 2;
+    g.clg = win_total <= 255 ? 2 : 1;
+    if (const char* e = getenv("RKMH_TILE_C16")) { if (atoi(e) > 0) g.clg = 1; } // A/B knob: 1 = always 16-bit counters
+    g.cwords = (nref + (1 << g.clg) - 1) >> g.clg;
     int ds = 64;
     while (ds < 3 * expect_hits && ds < 1024) ds <<= 1;
     if (const char* e = getenv("RKMH_TILE_DSET")) ds = atoi(e);
@@ -591,15 +599,22 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
         g.T = T; g.cap_bytes = T * maxlen;
         return T * maxlen <= PF_MAX * WAVE * 4 - 8 && tile_lds_bytes(g) <= budget;
     };
-    int best = 1;
-    double best_fill = -1.0;
     if (win_per_read < 1) win_per_read = 1;
+    double fill[17] = {0};
+    int tmax = 1;
+    double best_fill = -1.0;
     for (int T = 1; T <= 16; ++T) {
         if (T > 1 && (!fits(T, LDS_BUDGET_6_WAVES) || T * maxlen > 3 * WAVE * 4 - 8)) break;
         const int nw = T * win_per_read;
-        const double fill = (double)nw / (double)(((nw + WAVE - 1) / WAVE) * WAVE);
-        if (fill >= best_fill - 0.005) { best = T; if (fill > best_fill) best_fill = fill; }
+        fill[T] = (double)nw / (double)(((nw + WAVE - 1) / WAVE) * WAVE);
+        if (fill[T] > best_fill) best_fill = fill[T];
+        tmax = T;
     }
+    // the smallest tile within 2.5 % of the best fill: beyond that, bigger tiles measured slower (150 bp: T=5 fills
+    // 95.2 % against 93.1 % for T=4 and is 0.7 % slower; T=6 4 % slower)
+    int best = 1;
+    for (int T = 1; T <= tmax; ++T)
+        if (fill[T] >= best_fill - 0.025) { best = T; break; }
     if (const char* e = getenv("RKMH_TILE_T")) best = atoi(e);
     if (best > 16) best = 16;
     if (best < 1) best = 1;
@@ -617,8 +632,10 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st) {
     if (nreads == 0) return hipSuccess;
+    int win_total = 0; // most windows any read of the batch can have (all k): bounds every per-reference count
+    for (int j = 0; j < ks.n; ++j) win_total += num_windows(maxlen, ks.k[j], pol.drop_last_window);
     TileGeom geo = make_geom(maxlen, mode == 1 ? 0 : ix.nref, mode == 1 ? 0 : expect_hits,
-                             num_windows(maxlen, ks.k[0], pol.drop_last_window));
+                             num_windows(maxlen, ks.k[0], pol.drop_last_window), win_total);
     if (mode == 1) { geo.qcap = 0; geo.dset = 0; }
     while (tile_lds_bytes(geo) > 20 * 1024 && geo.T > 1) { geo.T -= 1; geo.cap_bytes = geo.T * maxlen; } // >= 8 waves per CU
     const size_t lds = tile_lds_bytes(geo);

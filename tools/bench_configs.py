@@ -13,7 +13,7 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 
 
-def run(tag, refs_b, refs_o, ks, S, n, L, depth=None, steps=10):
+def run(tag, refs_b, refs_o, ks, S, n, L, depth=None, steps=50):
     ctx = rkmh_amd.Context(0)
     t = time.time()
     ctx.set_references(refs_b, refs_o, ks, S)
@@ -33,7 +33,7 @@ def run(tag, refs_b, refs_o, ks, S, n, L, depth=None, steps=10):
     def step():
         ctx.classify_device(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=L, stream=st.cuda_stream)
 
-    for _ in range(2):
+    for _ in range(10):
         step()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
