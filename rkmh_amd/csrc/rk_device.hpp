@@ -3,8 +3,9 @@
 // Replaces (on the device) what mkmh::calc_hashes does per k-mer for the call sites
 // /root/reference/src/rkmh.cpp:821,860: canonical MurmurHash3_x64_128 (seed 42) of a k-mer window,
 // 0 for any window holding a non-ACGT base.  Windows are read from an LDS copy of the upper-cased
-// sequence and of its reverse complement, so a hash costs two unaligned LDS window reads
-// (aligned ds_read_b32 + v_alignbyte_b32) and two murmur evaluations -- no per-window complementing.
+// sequence and of its reverse complement, so a hash costs two unaligned 16-byte LDS window reads
+// (ds_read_b128 at any byte address: gfx950 runs with unaligned DS access) and two murmur evaluations --
+// no per-window complementing.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,10 +57,6 @@ __device__ __forceinline__ uint64_t mm_finish(uint64_t h1, uint64_t h2, uint32_t
     return (h2 << 32) | (h1 >> 32);
 }
 
-// bytes [a, a+4) of a little-endian dword array, a = 4*idx + sh
-__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
-    return __builtin_amdgcn_alignbyte(hi, lo, sh);
-}
 
 // MurmurHash3_x64_128 of the k bytes starting at byte offset `a` of the LDS dword array w32.
 // The array must be readable for 16 bytes past the window (buffers are padded).
@@ -115,11 +112,6 @@ __device__ __forceinline__ uint32_t upper4(uint32_t x) {
     uint32_t t = (x & 0x7f7f7f7fu) + 0x24242424u;   // bit7 <=> low7 >= 92
     uint32_t m = t & ~x & 0x80808080u;
     return x - (m >> 2);
-}
-// complement of upper-case A/C/G/T bytes (other bytes: don't care, their windows are never hashed)
-__device__ __forceinline__ uint32_t comp4(uint32_t x) {
-    uint32_t m = (x >> 1) & 0x01010101u;            // bit1: 0 for A,T  1 for C,G
-    return x ^ 0x15151515u ^ (m | (m << 4));        // A<->T: ^0x15, C<->G: ^0x04
 }
 // Letter tables indexed by bits 2:1 of an upper-case base (A=0, C=1, T=2, G=3): one v_perm_b32 looks four bases up.
 // acgt_mismatch4: byte q is non-zero <=> byte q of x is NOT one of 'A','C','G','T'.
@@ -204,10 +196,8 @@ __device__ __forceinline__ Staged stage_piece(const uint8_t* __restrict__ bases,
     // rc dword q covers rc bytes 4q..4q+3 = complement of fwd bytes p+3..p, p = fbase + nbases - 4 - 4q
     const uint32_t nrc = (nbases + 3) >> 2;
     for (uint32_t q = tid; q < nrc; q += G) {
-        int32_t p = (int32_t)(s.fbase + nbases) - 4 - 4 * (int32_t)q; // >= FWD_PAD + d - 3 >= 1
-        uint32_t idx = (uint32_t)p >> 2, sh = (uint32_t)p & 3;
-        uint32_t v = alignbyte(s.fwd[idx + 1], s.fwd[idx], sh);
-        s.rc[q] = __builtin_bswap32(comp4(v));
+        const uint32_t p = s.fbase + nbases - 4u - 4u * q; // >= FWD_PAD + d - 3 >= 1
+        s.rc[q] = revcomp4(lds_load4_unaligned(s.fwd, p));
     }
     sync();
     return s;
