@@ -200,6 +200,31 @@ struct GeneralCfg {
 static uint32_t next_pow2(uint32_t x) { uint32_t p = 64; while (p < x) p <<= 1; return p; }
 
 // d_bases: device pointer to the batch's bases when already resident (else nullptr => upload from `bases`)
+// Host -> device copy of a pageable buffer through the context's two pinned staging buffers (the same ones the fused
+// host pipeline uses): the CPU fills one while the DMA engine drains the other.  hipMemcpyAsync straight from pageable
+// memory runs at a fraction of the link rate and blocks the caller for the whole transfer.
+static int upload_staged(rk_ctx* c, void* dst, const uint8_t* src, size_t bytes, hipStream_t st) {
+    const size_t CH = 16u << 20;
+    if (bytes <= (1u << 20)) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); return RK_OK; }
+    for (int i = 0; i < 2; ++i) {
+        if (c->slot[i].busy) { HIPCHK(hipEventSynchronize(c->slot[i].done)); c->slot[i].busy = false; }
+        RKCHK(c->slot[i].h_bases.reserve(CH));
+    }
+    int which = 0;
+    bool used[2] = {false, false};
+    for (size_t off = 0; off < bytes; off += CH) {
+        const size_t nb = bytes - off < CH ? bytes - off : CH;
+        Slot& sl = c->slot[which];
+        if (used[which]) HIPCHK(hipEventSynchronize(sl.done)); // its previous chunk has left the pinned buffer
+        memcpy(sl.h_bases.p, src + off, nb);
+        HIPCHK(hipMemcpyAsync((uint8_t*)dst + off, sl.h_bases.p, nb, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(sl.done, st));
+        used[which] = true;
+        which ^= 1;
+    }
+    return RK_OK;
+}
+
 static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_in, const uint64_t* offsets, int64_t n,
                        const GeneralCfg& cfg, const GeneralOut& out) {
     RKCHK(set_dev(c));
@@ -266,7 +291,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
         if (d_bases_in) d_bases = d_bases_in + base0;
         else {
             RKCHK(c->w_bases.reserve(cb + 64));
-            if (cb) HIPCHK(hipMemcpyAsync(c->w_bases.p, bases + base0, cb, hipMemcpyHostToDevice, c->st));
+            if (cb) RKCHK(upload_staged(c, c->w_bases.p, bases + base0, cb, c->st));
             d_bases = c->w_bases.as<uint8_t>();
         }
         if (((uintptr_t)d_bases & 3) != 0) {
@@ -894,6 +919,40 @@ extern "C" int rk_classify_batch(rk_ctx* c, const uint8_t* bases, const uint64_t
     if (!c || !offsets || nreads < 0 || (nreads > 0 && !out4)) return fail(RK_ERR_ARG, "bad arguments");
     if (!c->have_refs) return fail(RK_ERR_STATE, "classify before rk_set_references");
     if (nreads == 0) return RK_OK;
+    // Reads the fused kernel is certain to hand back (longer than it stages, or with more windows than the sketch keeps,
+    // so that bottom-S selection matters) go to the general path directly instead of being uploaded and hashed twice.
+    // This only routes: the fused kernel still flags whatever it cannot answer exactly.
+    auto general_only = [&](int64_t i) {
+        const uint64_t len = offsets[i + 1] - offsets[i];
+        if (len > (uint64_t)FUSED_MAXLEN) return true;
+        uint64_t nw = 0;
+        for (int j = 0; j < c->ks.n; ++j) nw += (uint64_t)num_windows((int)len, c->ks.k[j], c->pol.drop_last_window);
+        return nw > (uint64_t)c->S;
+    };
+    int64_t ngen = 0;
+    for (int64_t i = 0; i < nreads; ++i) ngen += general_only(i) ? 1 : 0;
+    if (ngen == nreads || !classify_tile_supported(c->ix.nref, 1)) { // e.g. a nanopore batch: one pass through the general path
+        GeneralCfg cfg; cfg.ks = c->ks; cfg.S = c->S; cfg.classify = true;
+        if (c->depth) { cfg.filt_counter = c->depth; cfg.filter_mode = FILTER_MASK_MIN; cfg.fmin = c->min_occ; }
+        GeneralOut go; go.out4 = out4;
+        return general_run(c, bases, nullptr, offsets, nreads, cfg, go);
+    }
+    if (ngen * 8 > nreads) { // mixed batch: the short reads are gathered for the fused kernel, the rest marked for the general path
+        std::vector<int64_t> idx;
+        idx.reserve((size_t)(nreads - ngen));
+        for (int64_t i = 0; i < nreads; ++i) {
+            if (general_only(i)) out4[i * 4] = -2;
+            else idx.push_back(i);
+        }
+        std::vector<uint64_t> offs(idx.size() + 1, 0);
+        for (size_t j = 0; j < idx.size(); ++j) offs[j + 1] = offs[j] + (offsets[idx[j] + 1] - offsets[idx[j]]);
+        std::vector<uint8_t> sub((size_t)offs.back() + 64);
+        for (size_t j = 0; j < idx.size(); ++j) memcpy(sub.data() + offs[j], bases + offsets[idx[j]], (size_t)(offs[j + 1] - offs[j]));
+        std::vector<int32_t> res(idx.size() * 4);
+        RKCHK(host_pipeline(c, sub.data(), offs.data(), (int64_t)idx.size(), res.data(), 0, nullptr));
+        for (size_t j = 0; j < idx.size(); ++j) memcpy(out4 + idx[j] * 4, res.data() + j * 4, 16);
+        return reroute_flagged(c, bases, offsets, nreads, out4);
+    }
     RKCHK(host_pipeline(c, bases, offsets, nreads, out4, 0, nullptr));
     return reroute_flagged(c, bases, offsets, nreads, out4);
 }
