@@ -235,7 +235,8 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
     std::vector<TileDesc> tiles;
     std::vector<uint64_t> seg;
     std::vector<std::vector<uint32_t>> classes(32);
-    std::vector<uint32_t> long_seqs;
+    std::vector<uint32_t> long_seqs, presel;
+    const uint64_t PRESEL_MAX_HASHES = 1ull << 22; // one block streams its sequence a few times: fine up to a few million hashes
     uint64_t hash_cursor = 0; // position in out.hashes
     int64_t i0 = 0;
     while (i0 < n) {
@@ -330,15 +331,10 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
             if (out.out4) RKCHK(c->w_out.reserve((size_t)cn * 16));
             RKCHK(c->w_ids.reserve((size_t)cn * 4));
             size_t id_cursor = 0;
-            for (int cls = 0; cls < 32; ++cls) {
-                auto& ids = classes[cls];
-                if (ids.empty()) continue;
-                uint32_t* d_ids = c->w_ids.as<uint32_t>() + id_cursor;
-                HIPCHK(hipMemcpyAsync(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->st));
-                id_cursor += ids.size();
+            auto sort_args = [&](uint32_t* d_ids, uint32_t count, uint32_t P) {
                 SortArgs a{};
                 a.hashes = c->w_hashes.as<uint64_t>(); a.seg_off = c->w_segoff.as<uint64_t>();
-                a.seq_ids = d_ids; a.nlist = (uint32_t)ids.size(); a.P = 64u << cls; a.S = S;
+                a.seq_ids = d_ids; a.nlist = count; a.P = P; a.S = S;
                 a.write_back = out.write_back_sorted ? 1 : 0;
                 a.sketches = out.sketches ? c->w_sk.as<uint64_t>() : nullptr;
                 a.lens = out.lens ? c->w_lens.as<int32_t>() : nullptr;
@@ -346,6 +342,37 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
                 a.counter = cfg.filt_counter ? cfg.filt_counter->d : nullptr;
                 a.slots = cfg.filt_counter ? cfg.filt_counter->slots : 1;
                 a.filter_mode = cfg.filter_mode; a.fmin = cfg.fmin; a.fmax = cfg.fmax;
+                return a;
+            };
+            // Sequences with far more hashes than the sketch keeps (long reads, genomes up to a few million k-mers) are not
+            // sorted whole: their block radix-selects the bottom S first and sorts only those.
+            const uint32_t Psel = std::max<uint32_t>(64u, next_pow2((uint32_t)S));
+            const bool can_presel = !out.write_back_sorted && Psel <= (uint32_t)SORT_MAX_P;
+            presel.clear();
+            for (int cls = 0; cls < 32; ++cls) {
+                auto& ids = classes[cls];
+                if (ids.empty()) continue;
+                if (can_presel && (64u << cls) > Psel) { presel.insert(presel.end(), ids.begin(), ids.end()); continue; }
+                uint32_t* d_ids = c->w_ids.as<uint32_t>() + id_cursor;
+                HIPCHK(hipMemcpyAsync(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->st));
+                id_cursor += ids.size();
+                SortArgs a = sort_args(d_ids, (uint32_t)ids.size(), 64u << cls);
+                HIPCHK(launch_sort_intersect(a, cfg.classify ? &c->ix : nullptr, c->pol, c->st));
+            }
+            if (can_presel) { // long sequences of moderate size take the same route; only the huge ones need the multi-block select
+                size_t keep = 0;
+                for (uint32_t li : long_seqs) {
+                    if (seg[li + 1] - seg[li] <= PRESEL_MAX_HASHES) presel.push_back(li);
+                    else long_seqs[keep++] = li;
+                }
+                long_seqs.resize(keep);
+            }
+            if (!presel.empty()) {
+                uint32_t* d_ids = c->w_ids.as<uint32_t>() + id_cursor;
+                HIPCHK(hipMemcpyAsync(d_ids, presel.data(), presel.size() * 4, hipMemcpyHostToDevice, c->st));
+                id_cursor += presel.size();
+                SortArgs a = sort_args(d_ids, (uint32_t)presel.size(), Psel);
+                a.preselect = 1;
                 HIPCHK(launch_sort_intersect(a, cfg.classify ? &c->ix : nullptr, c->pol, c->st));
             }
             if (!long_seqs.empty()) { // sequences longer than the LDS sorter: exact bottom-S by radix select first

@@ -105,28 +105,125 @@ __global__ void k_sort_intersect(SortArgs a, RefIndex ix, int has_ix, DevPolicy 
     uint64_t* v = sm;
     int* sh = reinterpret_cast<int*>(sm + a.P);          // [nref] counters, then one int: number of zeros
     int& s_nz = sh[has_ix ? ix.nref : 0];
+    // pre-selection scratch (only when a.preselect): histogram, threshold bucket, a few scalars
+    uint32_t* hist = reinterpret_cast<uint32_t*>(sh + (has_ix ? ix.nref : 0) + 4);
+    uint64_t* side = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(hist + (1 << PRESEL_BITS) + 8 + 1024 + 64) + 7) & ~(uintptr_t)7);
+    uint32_t* ps = hist + (1 << PRESEL_BITS);            // [0] taken so far [1] side count [2] bin [3] below [4] bucket count
+    uint32_t* csum = ps + 8;                             // [<= 1024] per-thread partial sums, then [64] per-lane sums
     const int tid = threadIdx.x, T = blockDim.x;
     const uint32_t P = a.P;
+    auto filtered = [&](uint64_t h) -> uint64_t {
+        if (a.filter_mode == FILTER_MASK_MIN) {            // mask_by_frequency, rkmh.cpp:916
+            int c = a.counter[h % a.slots];
+            if (pol.mask_strict_less ? (c < a.fmin) : (c <= a.fmin)) h = 0;
+        } else if (a.filter_mode == FILTER_RANGE && h != 0) { // minhashes_frequency_filter, rkmh.cpp:835
+            int c = a.counter[h % a.slots];
+            bool keep = pol.freq_max_inclusive ? (c >= a.fmin && c <= a.fmax) : (c >= a.fmin && c < a.fmax);
+            if (!keep) h = 0;
+        }
+        return h;
+    };
     for (uint32_t li = blockIdx.x; li < a.nlist; li += gridDim.x) {
         const uint32_t id = a.seq_ids[li];
         const bool sel = a.sel_len != nullptr;
         const uint64_t seg = sel ? 0 : a.seg_off[id];
         const uint32_t n = sel ? a.sel_len[0] : (uint32_t)(a.seg_off[id + 1] - seg);
         const uint64_t* src = sel ? a.sel_hashes : a.hashes;
+        uint32_t n_sort = n; // entries of v that belong to the sequence
         __syncthreads();
+        if (a.preselect && n > P) {
+            // ---- exact bottom-S of the non-zero (filtered) hashes by most-significant-digit radix select ----
+            // invariant: every hash < lo is taken (there are S - need of them); the answer's remaining `need` elements
+            // are the smallest ones of the bucket [lo, lo + 2^shift)
+            uint64_t lo = 0;
+            uint32_t shift = 64, need = (uint32_t)a.S;
+            bool take_all = false;
+            for (;;) {
+                const uint32_t bits = shift >= (uint32_t)PRESEL_BITS ? (uint32_t)PRESEL_BITS : shift;
+                const uint32_t nbins = 1u << bits;
+                const uint32_t dsh = shift - bits;
+                for (uint32_t b = tid; b < nbins; b += T) hist[b] = 0;
+                __syncthreads();
+                for (uint32_t t = tid; t < n; t += T) {
+                    const uint64_t h = filtered(src[seg + t]);
+                    if (h != 0 && (shift == 64 || (h >> shift) == (lo >> shift))) atomicAdd(&hist[(uint32_t)(h >> dsh) & (nbins - 1)], 1u);
+                }
+                __syncthreads();
+                // bin where the running count reaches `need`: per-thread chunk sums, then one wave scans the chunks
+                const uint32_t per = (nbins + (uint32_t)T - 1) / (uint32_t)T;
+                {
+                    uint32_t sum = 0;
+                    for (uint32_t j = 0; j < per; ++j) { const uint32_t b = (uint32_t)tid * per + j; if (b < nbins) sum += hist[b]; }
+                    csum[tid] = sum;
+                }
+                __syncthreads();
+                // two-level scan: 64 lanes sum T/64 chunk sums each, lane 0 walks the 64 lane sums, then one lane's
+                // chunks, then one chunk's bins -- a few dozen dependent steps instead of thousands
+                const uint32_t cpl = ((uint32_t)T + 63u) / 64u; // chunks per lane
+                if (tid < 64) {
+                    uint32_t sum = 0;
+                    for (uint32_t j = 0; j < cpl; ++j) { const uint32_t c = (uint32_t)tid * cpl + j; if (c < (uint32_t)T) sum += csum[c]; }
+                    csum[1024 + tid] = sum;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t acc = 0, lane_ = 0;
+                    for (; lane_ < 64; ++lane_) { if (acc + csum[1024 + lane_] >= need) break; acc += csum[1024 + lane_]; }
+                    if (lane_ == 64) { ps[2] = nbins; ps[3] = acc; ps[4] = 0; } // fewer than `need` left: take everything
+                    else {
+                        uint32_t chunk = lane_ * cpl;
+                        for (;; ++chunk) { if (acc + csum[chunk] >= need) break; acc += csum[chunk]; }
+                        uint32_t b = chunk * per;
+                        for (;; ++b) { if (acc + hist[b] >= need) break; acc += hist[b]; }
+                        ps[2] = b; ps[3] = acc; ps[4] = hist[b];
+                    }
+                }
+                __syncthreads();
+                const uint32_t bin = ps[2], below = ps[3], bcount = ps[4];
+                __syncthreads();
+                if (bin == nbins) { take_all = true; break; }
+                need -= below;
+                lo |= (uint64_t)bin << dsh;
+                shift = dsh;
+                if (shift == 0 || bcount <= (uint32_t)PRESEL_SIDE) break;
+            }
+            // collect: everything below the bucket, and the bucket itself on the side
+            if (tid == 0) { ps[0] = 0; ps[1] = 0; }
+            __syncthreads();
+            for (uint32_t t = tid; t < n; t += T) {
+                const uint64_t h = filtered(src[seg + t]);
+                if (h == 0) continue;
+                if (take_all || h < lo) { const uint32_t pos = atomicAdd(&ps[0], 1u); if (pos < P) v[pos] = h; }
+                else if (shift == 0 ? h == lo : (h >> shift) == (lo >> shift)) {
+                    const uint32_t pos = atomicAdd(&ps[1], 1u);
+                    if (pos < (uint32_t)PRESEL_SIDE) side[pos] = h;
+                }
+            }
+            __syncthreads();
+            uint32_t taken = ps[0];
+            if (!take_all) {
+                if (shift == 0) { // the bucket is one value repeated: `need` copies of it
+                    for (uint32_t t = tid; t < need; t += T) v[taken + t] = lo;
+                } else { // <= PRESEL_SIDE elements: rank sort, the `need` smallest complete the selection
+                    const uint32_t ns = ps[1];
+                    for (uint32_t i = tid; i < ns; i += T) {
+                        const uint64_t x = side[i];
+                        uint32_t r = 0;
+                        for (uint32_t j = 0; j < ns; ++j) { const uint64_t y = side[j]; r += (y < x || (y == x && j < i)) ? 1u : 0u; }
+                        if (r < need) v[taken + r] = x;
+                    }
+                }
+                taken += need;
+            }
+            __syncthreads();
+            for (uint32_t t = taken + tid; t < P; t += T) v[t] = ~0ull;
+            n_sort = taken;
+        } else
         for (uint32_t t = tid; t < P; t += T) {
             uint64_t h = ~0ull;
             if (t < n) {
                 h = src[seg + t];
-                if (sel) {
-                } else if (a.filter_mode == FILTER_MASK_MIN) {            // mask_by_frequency, rkmh.cpp:916
-                    int c = a.counter[h % a.slots];
-                    if (pol.mask_strict_less ? (c < a.fmin) : (c <= a.fmin)) h = 0;
-                } else if (a.filter_mode == FILTER_RANGE && h != 0) { // minhashes_frequency_filter, rkmh.cpp:835
-                    int c = a.counter[h % a.slots];
-                    bool keep = pol.freq_max_inclusive ? (c >= a.fmin && c <= a.fmax) : (c >= a.fmin && c < a.fmax);
-                    if (!keep) h = 0;
-                }
+                if (!sel) h = filtered(h);
             }
             v[t] = h;
         }
@@ -145,11 +242,11 @@ __global__ void k_sort_intersect(SortArgs a, RefIndex ix, int has_ix, DevPolicy 
             }
         }
         // zeros sort first: nz = number of zero entries among the n real ones
-        for (uint32_t t = tid; t < n; t += T)
-            if (v[t] == 0 && (t + 1 == n || v[t + 1] != 0)) s_nz = (int)(t + 1);
+        for (uint32_t t = tid; t < n_sort; t += T)
+            if (v[t] == 0 && (t + 1 == n_sort || v[t + 1] != 0)) s_nz = (int)(t + 1);
         __syncthreads();
         const uint32_t nz = (uint32_t)s_nz;
-        const uint32_t m = (n - nz) < (uint32_t)a.S ? (n - nz) : (uint32_t)a.S;
+        const uint32_t m = (n_sort - nz) < (uint32_t)a.S ? (n_sort - nz) : (uint32_t)a.S;
         if (a.write_back)
             for (uint32_t t = tid; t < n; t += T) a.hashes[seg + t] = v[t];
         if (a.sketches) {
@@ -187,6 +284,7 @@ hipError_t launch_sort_intersect(const SortArgs& a, const RefIndex* ix, const De
     RefIndex z{};
     const RefIndex& use = ix ? *ix : z;
     size_t lds = (size_t)a.P * 8 + (ix ? (size_t)ix->nref * 4 : 0) + 16; // counters + s_nz
+    if (a.preselect) lds += ((size_t)(1 << PRESEL_BITS) + 8 + 1024 + 64) * 4 + (size_t)PRESEL_SIDE * 8 + 16;
     uint32_t grid = a.nlist < 65535 ? a.nlist : 65535;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_intersect),

@@ -45,7 +45,13 @@ struct SortArgs {
     // sel_len[0] = number of candidates on the device, filters were already applied
     const uint64_t* sel_hashes;
     const uint32_t* sel_len;
+    // optional: sequences with many more hashes than S are not sorted whole; the block first radix-selects the bottom
+    // S non-zero hashes of its sequence (12-bit digits, histogram in LDS) straight from global memory and sorts those
+    // (P is then next_pow2(S), not the segment length).  Exact for any multiset, including heavy duplicates.
+    uint32_t preselect;
 };
+constexpr int PRESEL_BITS = 12;                 // digit width of the in-block radix select
+constexpr int PRESEL_SIDE = 1024;               // threshold-bucket elements resolved by rank sort
 
 // ---- `call` sub-command (rk_call.hip) ----
 struct DepthTable {            // exact hash -> occurrence count map in HBM (read_hash_to_depth, rkmh.cpp:1619-1621)

@@ -218,6 +218,34 @@ def test_long_reads_take_general_path(ctx, orc, pave):
     assert (got == want).all()
 
 
+def test_bottom_s_preselection_with_duplicate_heavy_sequences(ctx, orc):
+    """The in-block radix pre-selection (sequences with more hashes than the sketch keeps) on multisets that stress
+    it: one hash repeated thousands of times (homopolymer: the threshold bucket never shrinks, all 64 bits get
+    decided), short tandem repeats (a handful of distinct hashes, each hundreds of times), N runs, mixed with random
+    sequence; as references (sketches) and as reads (classification), for sketch sizes around the bucket limits."""
+    rng = np.random.default_rng(77)
+    base = rand_dna(rng, 9000)
+    seqs = [
+        b"A" * 5000,                                   # one hash, 4984 copies
+        b"AC" * 2500,                                  # two hashes
+        b"ACG" * 1700, b"ACGTT" * 1100,                # 3 / 5 distinct hashes
+        b"A" * 3000 + base[:3000],                     # duplicates below/above random hashes
+        base[:4000] + b"N" * 700 + base[4000:7000],    # zero hashes in the middle
+        (b"ACGTTGCAAC" * 30 + base[:200]) * 12,        # repeats mixed with unique stretches
+        base, base[:2100], base[:1100], base[::-1][:3333],
+    ]
+    rb, ro = orc.pack(seqs)
+    reads = seqs + [base[100:250], b"A" * 150, base[500:1650]]
+    qb, qo = orc.pack(reads)
+    for ks, S in (([16], 1000), ([16], 1), ([16], 7), ([16], 300), ([16], 1024), ([16], 2000), ([12], 1000), ([8, 16], 1500)):
+        ctx.set_references(_pad(rb), ro, ks, S)
+        sk, ln = ctx.get_reference_sketches()
+        wsk, wln = orc.sketch_refs(rb, ro, ks, S)
+        assert (ln == wln).all() and (sk == wsk).all(), (ks, S)
+        got, want = _classify_both(ctx, orc, _pad(rb), ro, _pad(qb), qo, ks, S)
+        assert (got == want).all(), (ks, S, got, want)
+
+
 def test_resident_input_entry_point(ctx, orc, pave):
     import torch
     from rkmh_amd import synth
