@@ -80,6 +80,8 @@ struct TileGeom {
     int32_t clg;        // log2(counters per 32-bit word): 1 = 16-bit counters, 2 = 8-bit (reads with <= 255 windows)
     int32_t dset;       // slots of the per-read hit multiset (power of two)
     int32_t dbg;        // ablation switches (only read when built with -DRK_ABLATE=1)
+    int32_t tpb;        // consecutive tiles per workgroup
+    int32_t xcd;        // 1: workgroups that share an XCD (blockIdx % 8, round-robin dispatch) take neighbouring tiles
 };
 
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
@@ -206,16 +208,23 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         else if constexpr (PF == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]) : : "memory");
     };
-    if (blockIdx.x < ntiles) { load_offsets(blockIdx.x, cur_a, cur_b, cur_o); load_bases(cur_a, cur_b); }
+    // XCD-aware tile ownership: the dispatcher deals workgroups round-robin over the 8 XCDs, each with its own L2.
+    // Workgroup b is given the tiles of "virtual" workgroup (b % 8) * ceil(grid / 8) + b / 8, so the workgroups of one
+    // XCD walk one contiguous eighth of the batch and the cache lines that straddle two tiles are fetched into one L2.
+    uint32_t vb = blockIdx.x;
+    if (geo.xcd) { const uint32_t per = (gridDim.x + 7u) >> 3; vb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3); }
+    const uint32_t tile0 = vb * (uint32_t)geo.tpb;
+    const uint32_t tile_end = (tile0 + (uint32_t)geo.tpb) < ntiles ? (tile0 + (uint32_t)geo.tpb) : ntiles;
+    if (tile0 < ntiles) { load_offsets(tile0, cur_a, cur_b, cur_o); load_bases(cur_a, cur_b); }
 
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (uint32_t tile = tile0; tile < tile_end; ++tile) {
         const uint32_t r0 = tile * (uint32_t)T;
         const int Tn = tile_reads(tile);
         // wave-uniform values are moved to SGPRs explicitly: hipcc cannot prove that values loaded from one address by
         // every lane are uniform, and keeps loop counters derived from them in VGPRs with exec-mask loop control
         const uint32_t tstart = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur_a);
         const uint32_t B = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur_b - cur_a));
-        const uint32_t ntile = tile + gridDim.x;
+        const uint32_t ntile = tile + 1u < tile_end ? tile + 1u : ntiles; // this workgroup's next tile (none: ntiles)
         uint32_t nxt_a = 0, nxt_b = 0, nxt_o = 0;
         if (ntile < ntiles) load_offsets(ntile, nxt_a, nxt_b, nxt_o); // lands during phase 0
         wave_sync(); // previous tile fully consumed
@@ -646,6 +655,9 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     // waves were -17 % (tail imbalance); 2 keeps the cross-tile prefetch useful when the batch streams from HBM.
     int tpb = 2;
     if (const char* e = getenv("RKMH_TILE_TPB")) tpb = atoi(e) > 0 ? atoi(e) : 2;
+    geo.tpb = tpb;
+    geo.xcd = 1;
+    if (const char* e = getenv("RKMH_TILE_XCD")) geo.xcd = atoi(e) != 0;
     const bool k16 = (ks.n == 1 && ks.k[0] == 16);
     const int kmode = mode == 1 ? 1 : (counter ? 2 : 0);
 #define RK_LAUNCH_P(KT, MODE, FOLD, PF)                                                                                    \
@@ -656,7 +668,7 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
             if (e != hipSuccess) return e;                                                                           \
         }                                                                                                            \
         uint32_t grid = (ntiles + (uint32_t)tpb - 1) / (uint32_t)tpb;                                                \
-        if (const char* g = getenv("RKMH_TILE_GRID")) { uint32_t v = (uint32_t)atoi(g); if (v && v < ntiles) grid = v; } \
+        grid = (grid + 7u) & ~7u; /* whole rounds of the 8 XCDs: the virtual ids then cover [0, grid) exactly */      \
         hipLaunchKernelGGL((k_classify_tile<KT, MODE, FOLD, PF>), dim3(grid), dim3(WAVE), lds, st, bases, offs, nreads,   \
                            ks, S, ix, counter, slots, min_occ, out4, pol, geo);                                      \
     } while (0)

@@ -4,12 +4,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rkmh_amd import api, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 refs = api.parse_files([os.path.join(ROOT, "tests/golden/data/all_pave_ref.fa.gz")])
-qb, qo = synth.generate_reads_fast(refs["bases"], refs["offsets"], 0, n, threads=16)
-path = "/tmp/reads_%d.fq" % n
+qb, qo = synth.generate_reads_fast(refs["bases"], refs["offsets"], 0, n, read_len=L, threads=16)
+path = "/tmp/reads_%d_%d.fq" % (n, L)
 t = time.time()
 with open(path, "wb") as f:
-    L = 150
     qual = b"+" * L
     chunk = []
     for i in range(n):
@@ -32,7 +32,7 @@ import rkmh_amd
 ctx = rkmh_amd.Context(0)
 ctx.set_references(refs["bases"], refs["offsets"], [16], 1000)
 m = min(n, 2000000)
-res = ctx.classify(qb[:m * 150 + 16], qo[:m + 1])
+res = ctx.classify(qb[:m * L + 16], qo[:m + 1])
 bad = 0
 with open("/tmp/out.tsv", "rb") as f:
     for i in range(m):
