@@ -467,6 +467,35 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                     uint32_t t = 0;
                     uint64_t h = 0;
                     if (it < nIt) {
+                        // what happens to a window's canonical hash: the -M count / mask, the zero-hash tally of its read
+                        auto account = [&](uint64_t& hh, uint32_t tt) {
+                            if (MODE == 1) {
+                                if (pol.counter_counts_zero || hh != 0) atomicAdd(&counter[hh % slots], 1);
+                            } else {
+                                if (MODE == 2) { // mask_by_frequency, rkmh.cpp:916
+                                    const int c = counter[hh % slots];
+                                    if (pol.mask_strict_less ? (c < min_occ) : (c <= min_occ)) hh = 0;
+                                }
+                                if (hh == 0) atomicAdd(&nzero[tt], 1u);
+                            }
+                        };
+                        const bool split = compact && it + 1 == nIt && nW - it * WAVE <= 32u && !RK_DBG(4) && !(geo.dbg & 1024); // wave-uniform (RKMH_DBG=1024: A/B off)
+                        if (split) {
+                            // The tile's last <= 32 windows: lanes l and l + 32 take window l together -- the low half hashes
+                            // the forward strand, the high half the reverse complement, one exchange gives both the minimum.
+                            // The step then issues one murmur per lane instead of two for a mostly idle wave.
+                            const int l2 = lane & 31;
+                            t = (uint32_t)__shfl((int)ct_, l2);
+                            const uint32_t p = (uint32_t)__shfl((int)cp, l2);
+                            if (t < (uint32_t)Tn) { // same for both lanes of a pair
+                                const bool low = lane < 32;
+                                const uint32_t* img = low ? s.fwd : s.rc;
+                                const uint32_t off = low ? s.fbase + p : B - (uint32_t)k - p;
+                                const uint64_t own = murmur_window<KT, FOLD>(img, off, k, pol.seed, pol.fold);
+                                const uint64_t oth = (uint64_t)__shfl_xor((long long)own, 32);
+                                if (low) { h = own < oth ? own : oth; account(h, t); }
+                            }
+                        } else {
                         bool ok;
                         uint32_t p;
                         if (compact) { // wave-uniform
@@ -486,15 +515,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                                 const uint64_t r = murmur_window<KT, FOLD>(s.rc, B - (uint32_t)k - p, k, pol.seed, pol.fold);
                                 h = f < r ? f : r;
                             }
-                            if (MODE == 1) {
-                                if (pol.counter_counts_zero || h != 0) atomicAdd(&counter[h % slots], 1);
-                            } else {
-                                if (MODE == 2) { // mask_by_frequency, rkmh.cpp:916
-                                    const int c = counter[h % slots];
-                                    if (pol.mask_strict_less ? (c < min_occ) : (c <= min_occ)) h = 0;
-                                }
-                                if (h == 0) atomicAdd(&nzero[t], 1u);
-                            }
+                            account(h, t);
                         }
                         if (compact) { // advance the mapping after its use (in place, no register copies)
                             cwl += WAVE; cp += WAVE;
@@ -502,6 +523,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                                 cwl -= nw_u; ct_ += 1; cp += dtail;
                                 while (cwl >= nw_u) { cwl -= nw_u; ct_ += 1; cp += dtail; }
                             }
+                        }
                         }
                     }
                     if (MODE == 1) continue;
