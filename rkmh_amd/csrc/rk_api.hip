@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace rk;
@@ -200,6 +201,26 @@ struct GeneralCfg {
 static uint32_t next_pow2(uint32_t x) { uint32_t p = 64; while (p < x) p <<= 1; return p; }
 
 // d_bases: device pointer to the batch's bases when already resident (else nullptr => upload from `bases`)
+// memcpy into a pinned staging buffer with a few threads: one core copies ~14 GB/s, the link takes several times that
+static void par_memcpy(void* dst, const void* src, size_t n) {
+    static const int nt = []() {
+        const char* e = getenv("RKMH_COPY_THREADS");
+        int v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : (v > 16 ? 16 : v);
+    }();
+    if (n < (8u << 20) || nt == 1) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((n / (size_t)nt) + 4095) & ~(size_t)4095;
+    for (int i = 1; i < nt; ++i) {
+        const size_t off = per * (size_t)i;
+        if (off >= n) break;
+        const size_t len = n - off < per ? n - off : per;
+        th.emplace_back([=] { memcpy((char*)dst + off, (const char*)src + off, len); });
+    }
+    memcpy(dst, src, per < n ? per : n);
+    for (auto& t : th) t.join();
+}
+
 // Host -> device copy of a pageable buffer through the context's two pinned staging buffers (the same ones the fused
 // host pipeline uses): the CPU fills one while the DMA engine drains the other.  hipMemcpyAsync straight from pageable
 // memory runs at a fraction of the link rate and blocks the caller for the whole transfer.
@@ -216,7 +237,7 @@ static int upload_staged(rk_ctx* c, void* dst, const uint8_t* src, size_t bytes,
         const size_t nb = bytes - off < CH ? bytes - off : CH;
         Slot& sl = c->slot[which];
         if (used[which]) HIPCHK(hipEventSynchronize(sl.done)); // its previous chunk has left the pinned buffer
-        memcpy(sl.h_bases.p, src + off, nb);
+        par_memcpy(sl.h_bases.p, src + off, nb);
         HIPCHK(hipMemcpyAsync((uint8_t*)dst + off, sl.h_bases.p, nb, hipMemcpyHostToDevice, st));
         HIPCHK(hipEventRecord(sl.done, st));
         used[which] = true;
@@ -925,7 +946,7 @@ static int host_pipeline(rk_ctx* c, const uint8_t* bases, const uint64_t* offset
         RKCHK(s.h_bases.reserve(cb + 64)); RKCHK(s.h_offs.reserve((size_t)(cn + 1) * 4)); RKCHK(s.h_out.reserve((size_t)cn * 16));
         RKCHK(s.d_bases.reserve(cb + 64)); RKCHK(s.d_offs.reserve((size_t)(cn + 1) * 4)); RKCHK(s.d_out.reserve((size_t)cn * 16));
         const uint64_t b0 = offsets[i0];
-        memcpy(s.h_bases.p, bases + b0, cb);
+        par_memcpy(s.h_bases.p, bases + b0, cb);
         uint32_t* ho = s.h_offs.as<uint32_t>();
         for (int64_t i = 0; i <= cn; ++i) ho[i] = (uint32_t)(offsets[i0 + i] - b0);
         HIPCHK(hipMemcpyAsync(s.d_bases.p, s.h_bases.p, cb, hipMemcpyHostToDevice, s.st));
