@@ -105,22 +105,42 @@ template <typename V> struct QueueT {
 typedef QueueT<rk_seqset> Queue;
 struct Classified { rk_seqset reads; std::vector<int32_t> out4; };
 
+static inline char* put_int(char* w, int v) {
+    char tmp[12];
+    int n = 0;
+    unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *w++ = '-';
+    while (n) *w++ = tmp[--n];
+    return w;
+}
+
+// Lines of reads [lo, hi) in the format of rk_format_stream_line (rkmh.cpp:887-892), written straight into one buffer:
+// name lengths come from the offset arrays, no per-line strlen / temporary / append.
 static void format_range(const rk_seqset& refs, const rk_seqset& reads, const int32_t* out4, const Opts& o,
                          int64_t lo, int64_t hi, std::string& buf) {
-    buf.clear();
-    char line[8192];
+    size_t maxref = 0;
+    for (int64_t r = 0; r < refs.nseq; ++r) maxref = std::max<size_t>(maxref, (size_t)(refs.name_offsets[r + 1] - refs.name_offsets[r]));
+    const size_t need = (size_t)(reads.name_offsets[hi] - reads.name_offsets[lo]) + (size_t)(hi - lo) * (maxref + 64);
+    if (buf.size() < need) buf.resize(need);
+    char* const w0 = &buf[0];
+    char* w = w0;
     for (int64_t i = lo; i < hi; ++i) {
         const int32_t* r = out4 + i * 4;
-        const char* refn = refs.names + refs.name_offsets[r[0]];
-        const char* readn = reads.names + reads.name_offsets[i];
-        int n = rk_format_stream_line(line, sizeof line, refn, readn, r[1], r[2], r[3], o.sketch, o.min_matches, o.min_diff);
-        if (n < 0) { // very long names
-            std::string big(strlen(refn) + strlen(readn) + 128, '\0');
-            n = rk_format_stream_line(&big[0], big.size(), refn, readn, r[1], r[2], r[3], o.sketch, o.min_matches, o.min_diff);
-            if (n < 0) die("rk_format_stream_line");
-            buf.append(big.data(), (size_t)n);
-        } else buf.append(line, (size_t)n);
+        const size_t ln = (size_t)(refs.name_offsets[r[0] + 1] - refs.name_offsets[r[0]]) - 1; // offsets include the NUL
+        const size_t lq = (size_t)(reads.name_offsets[i + 1] - reads.name_offsets[i]) - 1;
+        memcpy(w, refs.names + refs.name_offsets[r[0]], ln); w += ln; *w++ = '\t';
+        memcpy(w, reads.names + reads.name_offsets[i], lq); w += lq; *w++ = '\t';
+        w = put_int(w, r[1]); *w++ = '\t';
+        w = put_int(w, o.sketch);
+        if (r[3] <= o.min_matches) { memcpy(w, "FAIL:DEPTH", 10); w += 10; }
+        *w++ = '\t';
+        if (r[1] < o.min_matches) { memcpy(w, "FAIL:MATCHES", 12); w += 12; }
+        *w++ = '\t';
+        if (!(r[2] > o.min_diff)) { memcpy(w, "FAIL:DIFF", 9); w += 9; }
+        *w++ = '\n';
     }
+    buf.resize((size_t)(w - w0));
 }
 
 // TSV lines in read order (rkmh.cpp:889-897); big batches are formatted by a few threads, written in order
