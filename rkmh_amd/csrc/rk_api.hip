@@ -257,7 +257,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
     std::vector<uint64_t> seg;
     std::vector<std::vector<uint32_t>> classes(32);
     std::vector<uint32_t> long_seqs, presel;
-    const uint64_t PRESEL_MAX_HASHES = 1ull << 22; // one block streams its sequence a few times: fine up to a few million hashes
+    const uint64_t PRESEL_MAX_HASHES = 1ull << 18; // one block streams its sequence a few times; beyond this the multi-block select is faster (measured: 3 M hashes 4 ms vs 0.7 ms)
     uint64_t hash_cursor = 0; // position in out.hashes
     int64_t i0 = 0;
     while (i0 < n) {
