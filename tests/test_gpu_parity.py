@@ -246,6 +246,43 @@ def test_bottom_s_preselection_with_duplicate_heavy_sequences(ctx, orc):
         assert (got == want).all(), (ks, S, got, want)
 
 
+def test_c3_like_all_bundled_references(ctx, orc, data_dir):
+    """SURVEY 8(d) C3 in miniature: every bundled FASTA concatenated (~270 viral references, many of them near
+    duplicates of each other => ties and two-posting index values) against synthetic 150 bp reads, k=16, s=1000,
+    through the host entry point and the resident one, plus a batch mixing short and long reads."""
+    import torch
+    from rkmh_amd import synth
+    seqs = []
+    for f in ("all_pave_ref.fa.gz", "zika.refs.fa.gz", "dengue.fa.gz", "new_refs.fa.gz", "hpv_16.fa.gz",
+              "zika.fa.gz", "yellow_fever.fa.gz", "hpv_16_allFasta.fa.gz"):
+        seqs += [r[1] for r in orc.kseq_parse_file(os.path.join(data_dir, f))]
+    assert len(seqs) > 250
+    rb, ro = orc.pack(seqs)
+    rb = _pad(rb)
+    qb, qo = synth.generate_reads_fast(rb, ro, 0, 30000)
+    got, want = _classify_both(ctx, orc, rb, ro, qb, qo, [16], 1000)
+    assert (got == want).all()
+    d_b = torch.from_numpy(qb).cuda()
+    d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).cuda()
+    d_out = torch.empty((30000, 4), dtype=torch.int32, device="cuda")
+    ctx.classify_device(d_b.data_ptr(), d_o.data_ptr(), 30000, d_out.data_ptr(), max_read_len=150,
+                        stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (d_out.cpu().numpy() == want).all()
+    # a mixed batch: short reads interleaved with reads far longer than the sketch (routing + gather/scatter)
+    rng = np.random.default_rng(9)
+    mixed = []
+    for i in range(600):
+        r = int(rng.integers(0, len(seqs)))
+        L = 150 if i % 3 else int(rng.integers(1200, 5000))
+        L = min(L, len(seqs[r]))
+        st = int(rng.integers(0, len(seqs[r]) - L + 1))
+        mixed.append(seqs[r][st:st + L])
+    mb, mo = orc.pack(mixed)
+    got, want = _classify_both(ctx, orc, rb, ro, _pad(mb), mo, [16], 1000)
+    assert (got == want).all()
+
+
 def test_resident_input_entry_point(ctx, orc, pave):
     import torch
     from rkmh_amd import synth
