@@ -127,12 +127,18 @@ def main():
         value = world * n * a.steps / elapsed
         achieved = B_READ * n / (kern_ms * 1e-3) / 1e9
         traffic = None
+        valu = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 if j.get("reads_per_launch") == n:
                     traffic = j.get("hbm_bytes_per_launch")
+                    if j.get("valu_insts_per_launch"):
+                        # the binding resource: wave64 VALU instructions issue one per 4 cycles per SIMD (1024 SIMDs, 2.4 GHz)
+                        valu = {"insts_per_read": j["valu_insts_per_launch"] / n,
+                                "issue_frac": j["valu_insts_per_launch"] * 4.0 / (1024 * kern_ms * 1e-3 * 2.4e9),
+                                "source": "SQ_INSTS_VALU (profiles/pmc_latest.json) x 4 cycles / (1024 SIMDs x live kernel_ms x 2.4 GHz)"}
             except Exception:
                 traffic = None
         res = {
@@ -144,7 +150,7 @@ def main():
                        "references": R, "parallelism": "reads sharded over %d rank(s); ref sketches RCCL-broadcast once" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_classify_tile", "kernel_ms": kern_ms, "bytes_per_read": B_READ},
+                         "kernel": "k_classify_tile", "kernel_ms": kern_ms, "bytes_per_read": B_READ, "valu": valu},
         }
         if world == 1 and a.cpu_seconds > 0:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
