@@ -250,7 +250,10 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 uint32_t nw = 0;
                 if (KT) nw = (uint32_t)num_windows(len, KT, pol.drop_last_window);
                 else for (int j = 0; j < ks.n; ++j) nw += (uint32_t)num_windows(len, ks.k[j], pol.drop_last_window);
-                nwin[lane] = nw; nzero[lane] = 0; best[lane] = 0; flags[lane] = 0;
+                nwin[lane] = nw; nzero[lane] = 0; best[lane] = 0;
+                // a read with more windows than a packed counter can count (only possible when the caller's length hint was
+                // too small for this read: 8-bit counters are chosen for hints of <= 255 windows) takes the general path
+                flags[lane] = nw > cmask ? 1u : 0u;
             }
         }
         const uint32_t ulen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(o_next - cur_o)); // length of read 0

@@ -283,6 +283,39 @@ def test_c3_like_all_bundled_references(ctx, orc, data_dir):
     assert (got == want).all()
 
 
+def test_resident_entry_point_with_too_small_length_hint(ctx, orc):
+    """rk_classify_batch_device trusts max_read_len for its tile geometry (and for the width of its packed counters).
+    A batch that breaks the promise must never be answered wrongly: every row is either exact or flagged -2."""
+    import torch
+    rng = np.random.default_rng(5)
+    refs = [rand_dna(rng, 450) for _ in range(5)]          # shorter than the sketch: every k-mer is a sketch hash
+    # period-20 tandem repeat: a 400 bp read scores 380 on it with only 20 distinct hashes (each 19 times), i.e. neither the
+    # hit multiset (64 keys, 30 occurrences) nor anything else but the 8-bit counter itself would notice
+    refs.append(rand_dna(rng, 20) * 24)
+    reads = []
+    for i in range(400):
+        r = refs[i % 6]
+        reads += [r[:400], r[100:150], r[200:250], r[300:350]] if i % 2 else [r[50:100], r[:430], r[10:60], r[5:45]]
+    rb, ro = orc.pack(refs)
+    qb, qo = orc.pack(reads)
+    qb = _pad(qb)
+    got, want = _classify_both(ctx, orc, _pad(rb), ro, qb, qo, [16], 1000)   # host entry point measures the lengths itself
+    assert (got == want).all()
+    n = len(reads)
+    d_b = torch.from_numpy(qb).cuda()
+    d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).cuda()
+    d_out = torch.empty((n, 4), dtype=torch.int32, device="cuda")
+    for hint in (150, 120, 200):
+        d_out.zero_()
+        ctx.classify_device(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=hint,
+                            stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out = d_out.cpu().numpy()
+        ok = (out[:, 0] == -2) | (out == want).all(axis=1)
+        assert ok.all(), (hint, np.nonzero(~ok)[0][:10], out[~ok][:5], want[~ok][:5])
+        assert (out[:, 0] != -2).any()
+
+
 def test_resident_input_entry_point(ctx, orc, pave):
     import torch
     from rkmh_amd import synth
