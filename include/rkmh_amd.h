@@ -164,6 +164,10 @@ int rk_classify_batch(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets
  * size) come back with max_id = -2; rk_classify_batch reroutes those itself. */
 int rk_classify_batch_device(rk_ctx* ctx, const void* d_bases, const void* d_offsets_u32, int64_t nreads,
                              void* d_out4, uint32_t max_read_len, void* hip_stream);
+/* As above, but rows the fused kernel cannot answer (long reads, reads with more windows than the sketch keeps) are
+ * answered by the general kernels on the resident bases instead of being flagged; synchronises hip_stream. */
+int rk_classify_batch_device_all(rk_ctx* ctx, const void* d_bases, const void* d_offsets_u32, int64_t nreads,
+                                 void* d_out4, uint32_t max_read_len, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * `call` (main_call, src/rkmh.cpp:1455-1904): k-mer depth map of the reads, sliding-window mean depth along the

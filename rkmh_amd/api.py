@@ -82,6 +82,7 @@ _SIGS = {
     "rk_count_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "rk_classify_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, _i32p]),
     "rk_classify_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rk_classify_batch_device_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "rk_call": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int, _u8p, _u64p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.POINTER(CallRecord)), C.POINTER(C.c_int64)]),
     "rk_format_stream_line": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rk_parse_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.POINTER(SeqSet)]),
@@ -443,6 +444,14 @@ class Context:
             stream = self.stream
         _chk(self._lib.rk_classify_batch_device(self._h, C.c_void_p(d_bases_ptr), C.c_void_p(d_offsets_ptr), nreads,
                                                 C.c_void_p(d_out_ptr), max_read_len, C.c_void_p(stream)))
+
+    def classify_device_all(self, d_bases_ptr, d_offsets_ptr, nreads, d_out_ptr, max_read_len=0, stream=None):
+        """classify_device without flagged rows: reads the fused kernel hands back are answered by the general kernels
+        on the resident bases (synchronises the stream)."""
+        if stream is None:
+            stream = self.stream
+        _chk(self._lib.rk_classify_batch_device_all(self._h, C.c_void_p(d_bases_ptr), C.c_void_p(d_offsets_ptr), nreads,
+                                                    C.c_void_p(d_out_ptr), max_read_len, C.c_void_p(stream)))
 
     def count_device(self, d_bases_ptr, d_offsets_ptr, nreads, counter, stream=None):
         if stream is None:

@@ -196,6 +196,9 @@ struct GeneralCfg {
     int filter_mode = FILTER_NONE, fmin = 0, fmax = 0;
     bool single_kmer = false;          // calc_hash(string): exactly one window of len bases per sequence
     bool classify = false;
+    // resident batches only (d_bases_in != nullptr): sequence i starts at byte abs_starts[i] of d_bases_in and `offsets`
+    // is just the prefix sum of the lengths -- lets a scattered subset of a resident batch run without gathering bases
+    const uint64_t* abs_starts = nullptr;
 };
 
 static uint32_t next_pow2(uint32_t x) { uint32_t p = 64; while (p < x) p <<= 1; return p; }
@@ -280,7 +283,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
                             (long long)i1, (unsigned long long)nh, SORT_MAX_P);
             // tiles
             uint64_t o = seg.back();
-            uint64_t rel = offsets[i1] - base0;
+            uint64_t rel = cfg.abs_starts ? cfg.abs_starts[i1] : offsets[i1] - base0;
             if (cfg.single_kmer) {
                 if (len < 1 || len > RK_MAX_K) return fail(RK_ERR_LIMIT, "k-mer length %llu outside [1,%d]", (unsigned long long)len, RK_MAX_K);
                 tiles.push_back(TileDesc{rel, o, (uint32_t)len, 1u, (uint32_t)len, 0u});
@@ -310,7 +313,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
         const int64_t cn = i1 - i0;
         // ---- upload
         const uint8_t* d_bases;
-        if (d_bases_in) d_bases = d_bases_in + base0;
+        if (d_bases_in) d_bases = cfg.abs_starts ? d_bases_in : d_bases_in + base0;
         else {
             RKCHK(c->w_bases.reserve(cb + 64));
             if (cb) RKCHK(upload_staged(c, c->w_bases.p, bases + base0, cb, c->st));
@@ -900,6 +903,43 @@ extern "C" int rk_classify_batch_device(rk_ctx* c, const void* d_bases, const vo
     // reroutes those through the general path itself).
     if (max_read_len == 0) RKCHK(device_max_len(c, d_offs, nreads, st, &max_read_len));
     return fused_device(c, d_bases, d_offs, nreads, d_out4, max_read_len, 0, nullptr, st);
+}
+
+// Same contract as rk_classify_batch_device, but no row is left flagged: rows the fused kernel hands back (long reads,
+// reads with more windows than the sketch keeps, ...) are answered by the general kernels on the resident bases -- only
+// the 4-byte offsets and the flagged rows cross PCIe.  Synchronises `hip_stream` (it has to look at the flags).
+extern "C" int rk_classify_batch_device_all(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nreads,
+                                            void* d_out4, uint32_t max_read_len, void* hip_stream) {
+    RKCHK(rk_classify_batch_device(c, d_bases, d_offs, nreads, d_out4, max_read_len, hip_stream));
+    if (nreads == 0) return RK_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    std::vector<int32_t> rows((size_t)nreads * 4);
+    std::vector<uint32_t> offs32((size_t)nreads + 1);
+    HIPCHK(hipMemcpyAsync(rows.data(), d_out4, (size_t)nreads * 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(offs32.data(), d_offs, ((size_t)nreads + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint32_t> idx;
+    for (int64_t i = 0; i < nreads; ++i) if (rows[(size_t)i * 4] == -2) idx.push_back((uint32_t)i);
+    if (idx.empty()) return RK_OK;
+    const size_t m = idx.size();
+    std::vector<uint64_t> lens_ps(m + 1, 0), starts(m);
+    for (size_t j = 0; j < m; ++j) {
+        starts[j] = offs32[idx[j]];
+        lens_ps[j + 1] = lens_ps[j] + (uint64_t)(offs32[(size_t)idx[j] + 1] - offs32[idx[j]]);
+    }
+    std::vector<int32_t> res(m * 4);
+    GeneralCfg cfg; cfg.ks = c->ks; cfg.S = c->S; cfg.classify = true; cfg.abs_starts = starts.data();
+    if (c->depth) { cfg.filt_counter = c->depth; cfg.filter_mode = FILTER_MASK_MIN; cfg.fmin = c->min_occ; }
+    GeneralOut go; go.out4 = res.data();
+    RKCHK(general_run(c, nullptr, (const uint8_t*)d_bases, lens_ps.data(), (int64_t)m, cfg, go));
+    // scatter the answers into the caller's result buffer
+    RKCHK(c->w_ids.reserve(m * 4));
+    RKCHK(c->w_out.reserve(m * 16));
+    HIPCHK(hipMemcpyAsync(c->w_ids.p, idx.data(), m * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->w_out.p, res.data(), m * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(launch_scatter_rows(c->w_out.as<int32_t>(), c->w_ids.as<uint32_t>(), (uint32_t)m, (int32_t*)d_out4, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return RK_OK;
 }
 
 extern "C" int rk_count_batch_device(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nreads,

@@ -451,6 +451,15 @@ __global__ __launch_bounds__(256) void k_fill_reroute(int32_t* out4, uint32_t nr
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < nreads) reinterpret_cast<int4*>(out4)[i] = make_int4(-2, 0, 0, 0);
 }
+__global__ __launch_bounds__(256) void k_scatter_rows(const int32_t* rows, const uint32_t* ids, uint32_t m, int32_t* out4) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m) reinterpret_cast<int4*>(out4)[ids[i]] = reinterpret_cast<const int4*>(rows)[i];
+}
+hipError_t launch_scatter_rows(const int32_t* rows, const uint32_t* ids, uint32_t m, int32_t* out4, hipStream_t st) {
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_rows, dim3((m + 255) / 256), dim3(256), 0, st, rows, ids, m, out4);
+    return hipGetLastError();
+}
 hipError_t launch_fill_reroute(int32_t* out4, uint32_t nreads, hipStream_t st) {
     if (nreads == 0) return hipSuccess;
     hipLaunchKernelGGL(k_fill_reroute, dim3((nreads + 255) / 256), dim3(256), 0, st, out4, nreads);

@@ -216,6 +216,17 @@ def test_long_reads_take_general_path(ctx, orc, pave):
     assert (got == want).all()
     got, want = _classify_both(ctx, orc, rb, ro, _pad(qb), qo, [16], 64)  # S < windows even for 150 bp reads
     assert (got == want).all()
+    # the complete resident entry point: same batch living in HBM, nothing left flagged
+    import torch
+    for S in (1000, 64):
+        got, want = _classify_both(ctx, orc, rb, ro, _pad(qb), qo, [16], S)
+        n = len(reads)
+        d_b = torch.from_numpy(_pad(qb)).cuda()
+        d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).cuda()
+        d_out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+        ctx.classify_device_all(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=0,
+                                stream=torch.cuda.current_stream().cuda_stream)
+        assert (d_out.cpu().numpy() == want).all(), S
 
 
 def test_bottom_s_preselection_with_duplicate_heavy_sequences(ctx, orc):
