@@ -48,8 +48,11 @@ def usable_cpus():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--spinup-seconds", type=float, default=0.3,
+                    help="untimed launches before the warm-up steps until the GPU clocks have ramped (a 1 ms kernel measured "
+                         "during the first ~50 ms after idle runs 4-12 %% slower); 0 disables")
     ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 disables)")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -98,6 +101,12 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    if a.spinup_seconds > 0:          # clock ramp: not part of the W warm-up steps, not timed
+        t_sp = time.perf_counter()
+        while time.perf_counter() - t_sp < a.spinup_seconds:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -147,7 +156,8 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "stream (C2): %d synthetic %d bp reads per GPU vs data/all_pave_ref.fa (%d refs), k=16 s=1000"
                                    % (n, L, R), "reads_per_gpu": n, "read_len": L, "k": 16, "sketch_size": S,
-                       "references": R, "parallelism": "reads sharded over %d rank(s); ref sketches RCCL-broadcast once" % world},
+                       "references": R, "parallelism": "reads sharded over %d rank(s); ref sketches RCCL-broadcast once" % world,
+                       "spinup_seconds": a.spinup_seconds},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_classify_tile", "kernel_ms": kern_ms, "bytes_per_read": B_READ, "valu": valu},
