@@ -538,8 +538,13 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                         // is set makes every window that lands in it a candidate (its slot-0 compare fails by design, the drain
                         // sorts it out): 0.08 % of the windows.  Lanes without a window carry hp = 0 and looked up bucket(0)
                         // like everyone else: hash 0 is never in the index, so at worst the drain rejects a few of them.
-                        const bool cand = (fb.x == fp) | (fb.y == fp) | (fb.z == fp) | (fb.w == fp) | ((int32_t)fb.x < 0);
-                        const uint64_t m = __builtin_amdgcn_ballot_w64(cand);
+                        // one ballot per compare (each IS the compare's lane mask), OR-ed on the scalar unit; inverse_ballot turns
+                        // the mask back into the branch predicate without the v_cndmask + v_cmp round trip hipcc emits for
+                        // ballot(a | b)
+                        const uint64_t m = __builtin_amdgcn_ballot_w64(fb.x == fp) | __builtin_amdgcn_ballot_w64(fb.y == fp) |
+                                           __builtin_amdgcn_ballot_w64(fb.z == fp) | __builtin_amdgcn_ballot_w64(fb.w == fp) |
+                                           __builtin_amdgcn_ballot_w64((int32_t)fb.x < 0);
+                        const bool cand = __builtin_amdgcn_inverse_ballot_w64(m);
                         if (cand) {
                             const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                             qe[q] = make_uint4((uint32_t)hp, (uint32_t)(hp >> 32), tp, 0u);
