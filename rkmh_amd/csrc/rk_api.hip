@@ -732,7 +732,7 @@ static int build_index(rk_ctx* c) {
             post.push_back((uint32_t)grp.size());
             for (auto& g : grp) { post.push_back(g.first); post.push_back(g.second); }
         }
-        uint32_t b = index_bucket(pairs[i].h, bshift);
+        uint32_t b = index_bucket(pairs[i].h, bmask);
         for (;;) {
             uint32_t q = 0;
             while (q < 4 && fpb[4 * b + q] != 0) ++q;

@@ -108,7 +108,7 @@ __device__ __forceinline__ void for_postings(const RefIndex& ix, uint32_t v, F f
 // `slot` returns the key id (a dense number unique to the sketch hash)
 __device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uint32_t& slot, uint32_t& val) {
     const uint32_t fp = index_fp(h);
-    uint32_t b = index_bucket(h, ix.bshift);
+    uint32_t b = index_bucket(h, ix.bmask);
     for (;;) {
         const uint4 f = ix.fpb[b];
         const uint32_t id0 = ix.base[b]; // fetched in the same round as the fingerprints
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                         qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
                     }
                     if RK_DBG(8) { if (h == 0x1234567ull) nzero[0] = 1; } else
-                    bucket_load_async(ix.fpb, index_bucket_nz(h, ix.bshift) << 4, fb); // lands while the next position is hashed
+                    bucket_load_async(ix.fpb, index_bucket(h, ix.bmask) << 4, fb); // lands while the next position is hashed
                     hp = h;
                     tp = t;
                 }

@@ -264,12 +264,11 @@ constexpr uint32_t IDX_NOT_FOUND = 0xffffffffu;
 // say so, and with ~0.7 keys per bucket it is 7 times more frequent than a real overflow.
 constexpr uint32_t IDX_OVF = 0x80000000u;
 __host__ __device__ __forceinline__ uint32_t index_fp(uint64_t h) { return ((uint32_t)h & 0x3fffffffu) | 0x40000000u; }
-__host__ __device__ __forceinline__ uint32_t index_bucket(uint64_t h, uint32_t bshift) {
-    return bshift >= 32 ? 0u : (((uint32_t)(h >> 32) ^ ((uint32_t)h >> 31)) * 0x9E3779B1u) >> bshift;
-}
-// built indexes always have >= 256 buckets (bshift <= 24): no degenerate-table check in the hot loop
-__device__ __forceinline__ uint32_t index_bucket_nz(uint64_t h, uint32_t bshift) {
-    return (((uint32_t)(h >> 32) ^ ((uint32_t)h >> 31)) * 0x9E3779B1u) >> bshift;
+// bucket = the LOW bits of the hash's high word (the fingerprint takes the low word's bits).  Murmur output is already
+// uniform, so no further mixing is spent in the hot loop -- but the keys are bottom-S sketch hashes, i.e. the SMALLEST
+// hashes of their sequences, so the top bits of the 64-bit value are heavily biased and must not be used.
+__host__ __device__ __forceinline__ uint32_t index_bucket(uint64_t h, uint32_t bmask) {
+    return (uint32_t)(h >> 32) & bmask;
 }
 __device__ __forceinline__ uint64_t index_key(const RefIndex& ix, uint32_t id) {
     const uint2 k = *reinterpret_cast<const uint2*>(&ix.kv[id]);
@@ -277,7 +276,7 @@ __device__ __forceinline__ uint64_t index_key(const RefIndex& ix, uint32_t id) {
 }
 __device__ __forceinline__ uint32_t index_find(const RefIndex& ix, uint64_t h) {
     const uint32_t fp = index_fp(h);
-    uint32_t b = index_bucket(h, ix.bshift);
+    uint32_t b = index_bucket(h, ix.bmask);
     for (;;) {
         const uint4 f = ix.fpb[b];
         const uint32_t id0 = ix.base[b];
