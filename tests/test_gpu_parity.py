@@ -651,7 +651,7 @@ def test_json_sketches_roundtrip(orc, root, data_dir, golden_dir, tmp_path):
     assert r.stdout.decode() == want
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RKMH_TEST_SEEDS", "48"))))   # soak: RKMH_TEST_SEEDS=2000
 def test_randomized_differential(orc, seed):
     """Random ragged batches (lengths 0..1700, lower case, N runs, repeats, shared and duplicated references, 1-3 k-mer
     sizes, tiny to large sketches, every fold / window policy, with and without -M) against the oracle."""
