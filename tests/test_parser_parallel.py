@@ -119,3 +119,40 @@ def test_parallel_parser_big_default_settings(orc, tmp_path):
         f.write(data)
     got = _records(api.parse_files([path]))
     assert got == _oracle_records(orc, data)
+
+
+def test_parallel_parser_fuzz(orc, tmp_path):
+    """Well-formed FASTQ/FASTA files with a few random structural mutations (inserted/deleted/overwritten '@', '>', '+',
+    newlines, CRLF, blanks, arbitrary bytes, truncation), tiny blocks so that cuts and fallbacks land everywhere;
+    RKMH_TEST_FUZZ=12000 for a soak (12 400 inputs x 3 settings passed when this was written)."""
+    rng = np.random.default_rng(2024)
+    tokens = [b"@", b">", b"+", b"\n", b"\r\n", b" ", b"\t", b"\n\n"]
+
+    def mutate(data, k):
+        b = bytearray(data)
+        for _ in range(k):
+            if not b:
+                break
+            op, pos = int(rng.integers(0, 4)), int(rng.integers(0, len(b)))
+            tok = tokens[int(rng.integers(0, len(tokens)))] if rng.random() < 0.7 else bytes([int(rng.integers(0, 256))])
+            if op == 0:
+                b[pos:pos] = tok
+            elif op == 1:
+                del b[pos:pos + int(rng.integers(1, 8))]
+            elif op == 2:
+                b[pos:pos + len(tok)] = tok
+            else:
+                b = b[:pos]
+        return bytes(b)
+
+    path = str(tmp_path / "fuzz.txt")
+    for it in range(int(os.environ.get("RKMH_TEST_FUZZ", "120"))):
+        base = _fastq(rng, int(rng.integers(50, 500)), lens=(0, 120), at_quals=bool(it % 2)) if rng.random() < 0.6 \
+            else _fasta(rng, int(rng.integers(20, 150)))
+        data = mutate(base, int(rng.integers(0, 6)))
+        with open(path, "wb") as f:
+            f.write(data)
+        want = [r[:2] for r in _oracle_records(orc, data)]
+        for threads, block_kb in ((4, 4), (8, 16), (3, 64)):
+            whole, _ = _parse(path, threads, block_kb)
+            assert [r[:2] for r in whole] == want, (it, threads, block_kb)
