@@ -651,6 +651,11 @@ def test_json_sketches_roundtrip(orc, root, data_dir, golden_dir, tmp_path):
     assert r.stdout.decode() == want
 
 
+# RKMH_TEST_LONG=1 mixes in reads of 5-20 kb (general path: radix pre-selection, tile hasher) for soak runs
+_RAND_LENS = [0, 3, 15, 16, 17, 60, 150, 150, 150, 300, 800, 1528, 1529, 1700] + \
+    ([5000, 9000, 20000] if os.environ.get("RKMH_TEST_LONG") else [])
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RKMH_TEST_SEEDS", "48"))))   # soak: RKMH_TEST_SEEDS=2000
 def test_randomized_differential(orc, seed):
     """Random ragged batches (lengths 0..1700, lower case, N runs, repeats, shared and duplicated references, 1-3 k-mer
@@ -687,7 +692,7 @@ def test_randomized_differential(orc, seed):
     uniform_len = int(rng.choice([0, 0, 100, 150, 251]))     # some batches of equal-length reads (the fast tile path)
     for i in range(nreads):
         src = refs[int(rng.integers(0, nref))]
-        L = uniform_len if uniform_len else int(rng.choice([0, 3, 15, 16, 17, 60, 150, 150, 150, 300, 800, 1528, 1529, 1700]))
+        L = uniform_len if uniform_len else int(rng.choice(_RAND_LENS))
         if rng.random() < 0.15 or len(src) < L + 1:
             r = bytearray(rand_dna(rng, L))
         else:
