@@ -53,7 +53,7 @@ template <typename V> struct Grow { // malloc-backed growable array handed over 
         return true;
     }
     bool push(V v) { if (n == cap && !reserve(n + 1)) return false; p[n++] = v; return true; }
-    bool append(const V* s, size_t k) { if (!reserve(n + k)) return false; memcpy(p + n, s, k * sizeof(V)); n += k; return true; }
+    bool append(const V* s, size_t k) { if (k == 0) return true; if (!reserve(n + k)) return false; memcpy(p + n, s, k * sizeof(V)); n += k; return true; }
     V* release() { V* r = p; p = nullptr; n = cap = 0; return r; }
     ~Grow() { free(p); }
 };
