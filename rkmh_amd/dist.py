@@ -11,7 +11,10 @@ import numpy as np
 
 
 def env_rank():
-    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RKMH_ONE_DEVICE"):   # plumbing tests: several ranks share GPU 0 (use with RKMH_DIST_BACKEND=gloo)
+        local = 0
+    return int(os.environ.get("RANK", "0")), local, int(os.environ.get("WORLD_SIZE", "1"))
 
 
 def init(backend=None):
