@@ -75,6 +75,7 @@ struct Piece {
     Grow<char> names;
     Grow<uint64_t> name_ends; // cumulative name bytes (with the NULs) after each record
     Grow<char> quals;
+    size_t lead = 0;          // FASTA pieces that start inside a record: bases that continue the previous piece's last record
     bool bad = false, oom = false;
 };
 
@@ -138,7 +139,13 @@ struct rk_reader {
         return buf[beg++];
     }
 
-    int next_block(Batch& b, int64_t max_records);
+    // open-cut parsing restarts the file from byte 0 with the sequential scanner on any irregularity (a block may have
+    // begun inside a record, which the sequential scanner cannot resume): the batch's state at the start of the file
+    bool f_saved = false, f_quals_ok = true;
+    size_t f_nseq = 0, f_bases = 0, f_names = 0, f_quals = 0;
+    bool blk_at_ls = true;     // pipes: the byte after the previous block's cut begins a line
+    bool rec_open = false;     // a FASTA header has been seen: a block / piece may begin with sequence data of that record
+    int next_block(Batch& b, int64_t max_records, bool open_cuts = false);
 
     // one record appended to b. returns 1 record read, 0 clean EOF, -2 truncated, -3 out of memory
     int next(Batch& b) {
@@ -301,27 +308,47 @@ void parse_fastq_piece(const unsigned char* p, const unsigned char* e, bool want
     }
 }
 
-void parse_fasta_piece(const unsigned char* p, const unsigned char* e, Piece& o) {
+// FASTA piece [p, e).  A piece may begin INSIDE a record (cuts may fall anywhere outside a header line, so that a
+// chromosome-sized record is shared by all workers): bases before the piece's first header line are its `lead`, the
+// continuation of the record that was open when the piece began.  at_ls: p is the first byte of a line.  need_header:
+// nothing is open yet (start of the file), so anything but blank lines before the first header is an irregularity.
+void parse_fasta_piece(const unsigned char* p, const unsigned char* e, bool at_ls, bool need_header, Piece& o) {
+    bool opened = false; // a header was seen in this piece
+    o.lead = 0;
     while (p < e) {
-        while (p < e && (*p == '\n' || *p == '\r')) ++p;
-        if (p >= e) break;
-        if (*p != '>') { o.bad = true; return; }
-        ++p;
-        const unsigned char* nl = find_nl(p, e);
-        if (!nl) { o.bad = true; return; }
-        if (!push_name(o, p, nl)) { o.oom = true; return; }
-        p = nl + 1;
-        while (p < e && *p != '>') {
-            nl = find_nl(p, e);
-            const unsigned char* le = nl ? nl : e;
-            const unsigned char* se = le;
-            if (se > p && se[-1] == '\r') --se;
-            if (!all_keepers(p, se)) { o.bad = true; return; }
-            if (!o.bases.append(p, (size_t)(se - p))) { o.oom = true; return; }
-            p = nl ? nl + 1 : e;
+        if (at_ls && *p == '>') {
+            if (opened) { if (!o.ends.push((uint64_t)o.bases.n)) { o.oom = true; return; } }
+            else o.lead = o.bases.n;
+            ++p;
+            const unsigned char* nl = find_nl(p, e);
+            if (!nl) { o.bad = true; return; } // the file ends inside a header line: leave it to the sequential scanner
+            if (!push_name(o, p, nl)) { o.oom = true; return; }
+            p = nl + 1;
+            opened = true;
+            continue;
         }
-        if (!o.ends.push((uint64_t)o.bases.n)) { o.oom = true; return; }
+        if (!opened && need_header) { // before the very first header only blank lines are regular
+            if (*p == '\n' || *p == '\r') { at_ls = *p == '\n'; ++p; continue; }
+            o.bad = true; return;
+        }
+        const unsigned char* nl = find_nl(p, e);
+        const unsigned char* se = nl ? nl : e;
+        if (nl && se > p && se[-1] == '\r') --se;
+        if (!all_keepers(p, se)) { o.bad = true; return; }
+        if (!o.bases.append(p, (size_t)(se - p))) { o.oom = true; return; }
+        p = nl ? nl + 1 : e;
+        at_ls = nl != nullptr;
     }
+    if (opened) { if (!o.ends.push((uint64_t)o.bases.n)) { o.oom = true; return; } }
+    else o.lead = o.bases.n;
+}
+
+// a legal FASTA cut at or before `pos`: anywhere except inside a header line (then the start of that line)
+size_t fasta_cut(const unsigned char* base, size_t pos) {
+    if (pos == 0) return 0;
+    const unsigned char* nl = (const unsigned char*)memrchr(base, '\n', pos);
+    const size_t ls = nl ? (size_t)(nl - base) + 1 : 0;
+    return base[ls] == '>' ? ls : pos;
 }
 
 // first record start at or after `from` (line-aligned); for FASTQ the line two below must begin with '+',
@@ -378,10 +405,27 @@ const unsigned char* find_last_record_start(const unsigned char* base, const uns
 // Appends the records of the next block to b.  1 = block consumed (more may follow), 0 = end of input,
 // -1 = input is not strictly line-structured: the block was handed back to the sequential scanner,
 // -3 = out of memory.
-int rk_reader::next_block(Batch& b, int64_t max_records) {
+int rk_reader::next_block(Batch& b, int64_t max_records, bool open_cuts) {
+    // open_cuts (whole-file parsing of a mapped file into ONE batch): FASTA blocks and pieces may end inside a record
+    if (!map) open_cuts = false;
+    if (open_cuts && !f_saved) {
+        f_saved = true; f_quals_ok = b.quals_ok;
+        f_nseq = (size_t)b.nseq; f_bases = b.bases.n; f_names = b.names.n; f_quals = b.quals.n;
+    }
+    auto irregular = [&]() -> int { // hand the input to the sequential scanner
+        if (open_cuts) { // ... from the first byte of the file, dropping what this file contributed so far
+            b.nseq = (int64_t)f_nseq; b.bases.n = f_bases; b.names.n = f_names; b.quals.n = f_quals; b.quals_ok = f_quals_ok;
+            b.offsets.n = f_nseq + 1; b.name_offsets.n = f_nseq + 1;
+            map_pos = 0; rec_open = false;
+        }
+        to_sequential();
+        return -1;
+    };
     size_t target = bytes_per_rec > 0 && max_records > 0 ? (size_t)(bytes_per_rec * (double)max_records) : (64u << 20);
+    if (open_cuts) target = max_block;
     if (target < (4u << 20)) target = 4u << 20;
     if (target > max_block) target = max_block;
+    bool fasta_open = false; // this block uses the open-record FASTA rules
     bool fastq = false;
     size_t cut = 0;
     const unsigned char* base = nullptr;
@@ -417,8 +461,22 @@ int rk_reader::next_block(Batch& b, int64_t max_records) {
             target *= 2;
             continue;
         }
-        if (*p != '@' && *p != '>') { to_sequential(); return -1; }
+        if (open_cuts && rec_open) { // continuing a FASTA file: the block may begin with sequence data
+            fastq = false; fasta_open = true;
+            cut = at_eof ? avail : fasta_cut(base, avail);
+            if (cut > 0) break;
+            target *= 2; // a header line longer than the block
+            continue;
+        }
+        if (*p != '@' && *p != '>') return irregular();
         fastq = *p == '@';
+        if (!fastq && open_cuts) {
+            fasta_open = true;
+            cut = at_eof ? avail : fasta_cut(base, avail);
+            if (cut > 0) break;
+            target *= 2;
+            continue;
+        }
         if (at_eof) { cut = avail; break; }
         const unsigned char* last = find_last_record_start(base, e, fastq);
         if (last) { cut = (size_t)(last - base); break; }
@@ -432,6 +490,11 @@ int rk_reader::next_block(Batch& b, int64_t max_records) {
     for (int i = 1; i < nt; ++i) {
         size_t from = cut / (size_t)nt * (size_t)i;
         if (from < starts[(size_t)i - 1]) from = starts[(size_t)i - 1];
+        if (fasta_open) {
+            size_t c = fasta_cut(base, from);
+            starts[(size_t)i] = c < starts[(size_t)i - 1] ? starts[(size_t)i - 1] : c;
+            continue;
+        }
         const unsigned char* q = find_record_start(base, base + from, base + cut, fastq);
         starts[(size_t)i] = q ? (size_t)(q - base) : cut;
     }
@@ -443,8 +506,15 @@ int rk_reader::next_block(Batch& b, int64_t max_records) {
         pc.bad = pc.oom = false;
         const unsigned char* s = base + starts[(size_t)i];
         const unsigned char* t = base + starts[(size_t)i + 1];
+        // upper bounds up front (untouched pages cost nothing): no geometric regrowth copies of 100 MB sequence lines
+        const size_t span = (size_t)(t - s);
+        if (!pc.bases.reserve(fastq ? span / 2 + 64 : span + 64) || (want_quals && !pc.quals.reserve(span / 2 + 64))) { pc.oom = true; return; }
         if (fastq) parse_fastq_piece(s, t, want_quals, pc);
-        else parse_fasta_piece(s, t, pc);
+        else {
+            const bool at_ls = s == base ? (fasta_open ? (map ? (map_pos == 0 || s[-1] == '\n') : blk_at_ls) : true) : s[-1] == '\n';
+            parse_fasta_piece(s, t, at_ls, /*need_header=*/i == 0 && !(fasta_open && rec_open), pc);
+            if (!fasta_open && pc.lead) pc.bad = true; // closed-cut blocks begin at a record start by construction
+        }
     };
     {
         std::vector<std::thread> th;
@@ -454,7 +524,7 @@ int rk_reader::next_block(Batch& b, int64_t max_records) {
     }
     for (int i = 0; i < nt; ++i) {
         if (pieces[(size_t)i].oom) return -3;
-        if (pieces[(size_t)i].bad) { to_sequential(); return -1; }
+        if (pieces[(size_t)i].bad) return irregular();
     }
     // merge: prefix sums, then every worker copies its own piece into place
     std::vector<size_t> rec0((size_t)nt + 1), base0((size_t)nt + 1), name0((size_t)nt + 1);
@@ -488,6 +558,16 @@ int rk_reader::next_block(Batch& b, int64_t max_records) {
         for (int i = 1; i < nt; ++i) th.emplace_back(place, i);
         place(0);
         for (auto& t : th) t.join();
+    }
+    if (fasta_open) { // a piece's leading bases belong to the record that was open when the piece began
+        for (int i = 0; i < nt; ++i) {
+            const size_t lead = pieces[(size_t)i].lead;
+            if (!lead) continue;
+            if (rec0[(size_t)i] == 0) return irregular(); // sequence data before any header (cannot happen: need_header)
+            b.offsets.p[rec0[(size_t)i]] = (uint64_t)base0[(size_t)i] + lead;
+        }
+        if (nrec > 0) rec_open = true;
+        if (!map) blk_at_ls = cut > 0 && base[cut - 1] == '\n';
     }
     b.bases.n = nb; b.names.n = nn;
     b.offsets.n = nrec + 1; b.name_offsets.n = nrec + 1;
@@ -614,7 +694,7 @@ int rk_parse_files(const char* const* paths, int npaths, rk_seqset* out) {
         int rc = rk_reader_open(paths[i], &r);
         if (rc != RK_OK) return rc;
         for (;;) {
-            int k = r->par_ok ? r->next_block(b, 0) : r->next(b);
+            int k = r->par_ok ? r->next_block(b, 0, /*open_cuts=*/true) : r->next(b);
             if (k == -3) { rk_reader_close(r); return perr(RK_ERR_NOMEM, "out of memory"); }
             if (k == -1) continue;
             if (k <= 0) break;

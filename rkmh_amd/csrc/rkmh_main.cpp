@@ -367,11 +367,14 @@ static int main_filter(int argc, char** argv) {
         o.ks.push_back(16);
     }
     if (o.refs.empty()) { fprintf(stderr, "rkmh: at least one -r reference file is required\n"); exit(1); }
+    double t0 = now_s();
     rk_ctx* ctx = nullptr;
     CK(rk_ctx_create(o.device, nullptr, &ctx));
+    tick("context", t0);
     rk_seqset refs;
     CK(rk_parse_files(o.refs.data(), (int)o.refs.size(), &refs));
     if (refs.nseq < 1) { fprintf(stderr, "rkmh: no reference sequences found\n"); exit(1); }
+    tick("parse references", t0);
     // reference sketches: the sample-count filter applies when max_samples < 100000 (rkmh.cpp:1211); its counter is
     // filled once per distinct hash per reference and only when -I was given (rkmh.cpp:1193, :348-355); 10 M slots (:1188)
     CK(rk_set_reference_count_mode(ctx, 1));
@@ -383,6 +386,7 @@ static int main_filter(int argc, char** argv) {
         std::vector<uint64_t> sk((size_t)refs.nseq * (size_t)o.sketch);
         CK(rk_get_reference_sketches(ctx, sk.data(), ref_lens.data()));
     }
+    tick("sketch references", t0);
     rk_counter* cnt = nullptr;
     CK(rk_counter_create(ctx, 10000000ull, &cnt)); // read_hash_counter, rkmh.cpp:1187
     std::string buf;
@@ -390,12 +394,14 @@ static int main_filter(int argc, char** argv) {
     if (!o.reads.empty()) {
         rk_seqset reads;
         CK(rk_parse_files(o.reads.data(), (int)o.reads.size(), &reads));
+        tick("parse reads", t0);
         if (o.read_depth) {
             CK(rk_count_batch(ctx, reads.bases, reads.offsets, reads.nseq, cnt)); // rkmh.cpp:321-338
             CK(rk_set_depth_filter(ctx, cnt, o.min_occ));                          // keep get(h) >= min_kmer_occ, :1260
         }
         out4.resize((size_t)reads.nseq * 4);
         CK(rk_classify_batch(ctx, reads.bases, reads.offsets, reads.nseq, out4.data()));
+        tick("count + classify", t0);
         for (int64_t i = 0; i < reads.nseq; ++i) {
             const int32_t* r = &out4[(size_t)i * 4];
             const FilterDecision d = filter_decide(r, o.min_diff);
@@ -415,6 +421,7 @@ static int main_filter(int argc, char** argv) {
         }
         fwrite(buf.data(), 1, buf.size(), stdout);
         buf.clear();
+        tick("emit", t0);
         rk_seqset_free(&reads);
     }
     if (in_stream) { // rkmh.cpp:1329-1408: reads from STDIN are classified, one line each

@@ -90,6 +90,14 @@ CASES = {
     "mixed_fasta_fastq": lambda r: _fasta(r, 150) + _fastq(r, 1500) + _fasta(r, 100),
     "leading_blank_lines": lambda r: b"\n\n" + _fastq(r, 2000),
     "leading_junk": lambda r: b"# comment\n" + _fastq(r, 2000),
+    "fasta_giant_single_line_records": lambda r: b"".join(b">chr%d some description\n" % i + bytes(r.choice(np.frombuffer(b"ACGTN", np.uint8), int(r.integers(1000, 300000)))) + b"\n" for i in range(7)),
+    "fasta_giant_wrapped_crlf": lambda r: _fasta(r, 40, width=70).replace(b"\n", b"\r\n"),
+    "fasta_long_headers": lambda r: b"".join(b">" + b"h" * int(r.integers(1, 9000)) + b" x\n" + b"ACGT" * int(r.integers(0, 3000)) + b"\n" for _ in range(60)),
+    "fasta_ends_in_header": lambda r: _fasta(r, 100) + b">last_header_without_newline",
+    "fasta_lone_gt": lambda r: _fasta(r, 100) + b">\n" + _fasta(r, 20),
+    "fasta_no_final_newline": lambda r: _fasta(r, 120)[:-1],
+    "fasta_plus_in_giant_record": lambda r: b">a\n" + b"ACGT" * 40000 + b"+" + b"ACGT" * 40000 + b"\n>b\nAC\n",
+    "fasta_junk_first": lambda r: b"junk\n" + _fasta(r, 100),
     "empty": lambda r: b"",
     "only_newlines": lambda r: b"\n\n\n",
 }

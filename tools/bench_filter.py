@@ -37,7 +37,8 @@ with open(fq, "wb") as f:
 print("inputs: genome %d Mb (%.0f MB fasta), %d reads (%.0f MB fastq) generated in %.0f s" % (gmb, os.path.getsize(fa) / 1e6, n, os.path.getsize(fq) / 1e6, time.time() - t), flush=True)
 for args in (["-k", "20", "-s", "2000"], ["-k", "20", "-s", "2000", "-M", "2"]):
     t = time.time()
-    r = subprocess.run([os.path.join(ROOT, "bin/rkmh"), "filter", "-r", fa, "-f", fq] + args, stdout=open("/tmp/filter.out", "wb"), stderr=subprocess.PIPE)
+    r = subprocess.run([os.path.join(ROOT, "bin/rkmh"), "filter", "-r", fa, "-f", fq] + args, stdout=open("/tmp/filter.out", "wb"), stderr=subprocess.PIPE, env=dict(os.environ, RKMH_TIMING="1"))
+    print(r.stderr.decode()[-700:])
     dt = time.time() - t
     kept = sum(1 for l in open("/tmp/filter.out", "rb") if l.startswith(b">"))
     print("rkmh filter %s: rc %d, %.2f s wall = %.2f M reads/s end to end; %d reads pass" % (" ".join(args), r.returncode, dt, n / dt / 1e6, kept), flush=True)
