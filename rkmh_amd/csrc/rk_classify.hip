@@ -430,6 +430,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         uint32_t qcount = 0; // queue length (wave-uniform)
         for (int kk = 0; kk < (KT ? 1 : ks.n); ++kk) {
             const int k = KT ? KT : ks.k[kk];
+            const TailMasks tmasks = make_tail_masks(k);
             if (kk && !plain) { // later k-mer sizes rebuild the start bitmap
                 wave_sync();
                 for (uint32_t i = lane; i < bad_words; i += WAVE) bad[i] = 0;
@@ -514,9 +515,13 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                             else if RK_DBG(4) {
                                 h = ((uint64_t)(s.fwd[(s.fbase + p) >> 2] * 0x9E3779B1u) << 32) | (s.rc[(B - (uint32_t)k - p) >> 2] * 0x85EBCA6Bu);
                             } else {
-                                const uint64_t f = murmur_window<KT, FOLD>(s.fwd, s.fbase + p, k, pol.seed, pol.fold);
-                                const uint64_t r = murmur_window<KT, FOLD>(s.rc, B - (uint32_t)k - p, k, pol.seed, pol.fold);
-                                h = f < r ? f : r;
+                                if constexpr (KT == 0) { // run-time k: both strands through one block loop, uniform tail masks
+                                    h = canonical_rt(s.fwd, s.fbase + p, s.rc, B - (uint32_t)k - p, k, tmasks, pol.seed, pol.fold);
+                                } else {
+                                    const uint64_t f = murmur_window<KT, FOLD>(s.fwd, s.fbase + p, k, pol.seed, pol.fold);
+                                    const uint64_t r = murmur_window<KT, FOLD>(s.rc, B - (uint32_t)k - p, k, pol.seed, pol.fold);
+                                    h = f < r ? f : r;
+                                }
                             }
                             account(h, t);
                         }
@@ -714,9 +719,11 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
         else if (kmode == 1) RK_LAUNCH(KT, 1, FOLD);                                                                 \
         else RK_LAUNCH(KT, 2, FOLD);                                                                                 \
     } while (0)
-    // single k of 12 or 20 (the reference's other documented settings): window length known at compile time, runtime fold
+    // single k of 12, 20 (the reference's other documented settings), 21 or 31: window length known at compile time, runtime fold
     if (ks.n == 1 && ks.k[0] == 12) RK_LAUNCH_M(12, -1);
     else if (ks.n == 1 && ks.k[0] == 20) RK_LAUNCH_M(20, -1);
+    else if (ks.n == 1 && ks.k[0] == 21) RK_LAUNCH_M(21, -1);   // Mash / sourmash defaults
+    else if (ks.n == 1 && ks.k[0] == 31) RK_LAUNCH_M(31, -1);
     else if (!k16) RK_LAUNCH_M(0, -1);        // any k / several k: runtime fold
     else if (pol.fold == 0) RK_LAUNCH_M(16, 0);
     else if (pol.fold == 1) RK_LAUNCH_M(16, 1);

@@ -106,6 +106,50 @@ __device__ __forceinline__ uint64_t murmur_window(const uint32_t* w32, uint32_t 
     return mm_finish<FOLD>(h1, h2, (uint32_t)k, fold);
 }
 
+// Canonical hash of a window whose length is only known at run time: both strands advance through ONE loop over the
+// 16-byte blocks (the two chains interleave, half the loop control of two separate calls) and the tail is masked with
+// wave-uniform masks prepared once per kernel (TailMasks) instead of per-window shift arithmetic.
+struct TailMasks { uint32_t m[4]; uint32_t rem; };
+__device__ __forceinline__ TailMasks make_tail_masks(int k) {
+    TailMasks t;
+    t.rem = (uint32_t)k & 15u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int nv = (int)t.rem - 4 * q;
+        t.m[q] = nv >= 4 ? 0xffffffffu : (nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u));
+    }
+    return t;
+}
+__device__ __forceinline__ uint64_t canonical_rt(const uint32_t* fwd, uint32_t af, const uint32_t* rc, uint32_t ar, int k,
+                                                 const TailMasks& tm, uint32_t seed, int fold) {
+    uint64_t f1 = seed, f2 = seed, r1 = seed, r2 = seed;
+    const int nblocks = k >> 4;
+    for (int b = 0; b < nblocks; ++b) {
+        const rk_u32x4 wf = lds_load16_unaligned(fwd, af);
+        const rk_u32x4 wr = lds_load16_unaligned(rc, ar);
+        mm_block(f1, f2, (uint64_t)wf.x | ((uint64_t)wf.y << 32), (uint64_t)wf.z | ((uint64_t)wf.w << 32));
+        mm_block(r1, r2, (uint64_t)wr.x | ((uint64_t)wr.y << 32), (uint64_t)wr.z | ((uint64_t)wr.w << 32));
+        af += 16; ar += 16;
+    }
+    if (tm.rem) {
+        const rk_u32x4 wf = lds_load16_unaligned(fwd, af);
+        const rk_u32x4 wr = lds_load16_unaligned(rc, ar);
+        uint64_t fk1 = (uint64_t)(wf.x & tm.m[0]) | ((uint64_t)(wf.y & tm.m[1]) << 32);
+        uint64_t rk1 = (uint64_t)(wr.x & tm.m[0]) | ((uint64_t)(wr.y & tm.m[1]) << 32);
+        if (tm.rem > 8) {
+            uint64_t fk2 = (uint64_t)(wf.z & tm.m[2]) | ((uint64_t)(wf.w & tm.m[3]) << 32);
+            uint64_t rk2 = (uint64_t)(wr.z & tm.m[2]) | ((uint64_t)(wr.w & tm.m[3]) << 32);
+            fk2 *= MM_C2; fk2 = rotl64(fk2, 33); fk2 *= MM_C1; f2 ^= fk2;
+            rk2 *= MM_C2; rk2 = rotl64(rk2, 33); rk2 *= MM_C1; r2 ^= rk2;
+        }
+        fk1 *= MM_C1; fk1 = rotl64(fk1, 31); fk1 *= MM_C2; f1 ^= fk1;
+        rk1 *= MM_C1; rk1 = rotl64(rk1, 31); rk1 *= MM_C2; r1 ^= rk1;
+    }
+    const uint64_t f = mm_finish<-1>(f1, f2, (uint32_t)k, fold);
+    const uint64_t r = mm_finish<-1>(r1, r2, (uint32_t)k, fold);
+    return f < r ? f : r;
+}
+
 // ---- per-dword (4 bases) SWAR helpers -------------------------------------------------------
 // mkmh::to_upper quirk: every (signed) char > 91 gets -32 (bytes >= 128 are negative => untouched)
 __device__ __forceinline__ uint32_t upper4(uint32_t x) {

@@ -71,7 +71,9 @@ run("1000 synthetic references", p1000[0], p1000[1], [16], 1000, 1000000, 150)
 run("k=20 s=2000 (filter config)", rb, ro, [20], 2000, 1000000, 150)
 run("k=20 s=1000", rb, ro, [20], 1000, 1000000, 150)
 run("k=16 s=2000", rb, ro, [16], 2000, 1000000, 150)
-run("k=21 s=1000 (runtime-k kernel)", rb, ro, [21], 1000, 1000000, 150)
+run("k=21 s=1000", rb, ro, [21], 1000, 1000000, 150)
+run("k=31 s=1000", rb, ro, [31], 1000, 1000000, 150)
+run("k=24 s=1000 (runtime-k kernel)", rb, ro, [24], 1000, 1000000, 150)
 run("k=12", rb, ro, [12], 1000, 1000000, 150)
 run("multi-k 12,14,16", rb, ro, [12, 14, 16], 1000, 1000000, 150)
 run("-M 2 (count pass + masked classify)", rb, ro, [16], 1000, 1000000, 150, depth=2)
