@@ -327,6 +327,44 @@ def test_resident_entry_point_with_too_small_length_hint(ctx, orc):
         assert (out[:, 0] != -2).any()
 
 
+def test_two_contexts_from_two_host_threads(orc, pave):
+    """The reference calls mkmh concurrently from OpenMP threads; here the rule is one rk_ctx per host thread.  Two threads,
+    each with its own context on the same GPU, classify different batches (short and long reads) at the same time."""
+    import threading
+    import rkmh_amd
+    from rkmh_amd import synth
+    _, rb, ro = pave
+    jobs = []
+    for j, (lo, n, L) in enumerate(((0, 30000, 150), (70000, 4000, 2500))):
+        qb, qo = synth.generate_reads_fast(rb, ro, lo, lo + n, read_len=L)
+        jobs.append((qb, qo))
+    ref_ctx = rkmh_amd.Context(0)
+    ref_ctx.set_references(rb, ro, [16], 1000)
+    sk, ln = ref_ctx.get_reference_sketches()
+    wants = [orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=8) for qb, qo in jobs]
+    errors = []
+
+    def run(j):
+        try:
+            c = rkmh_amd.Context(0)
+            c.set_reference_sketches(sk, ln, [16], 1000)
+            for _ in range(4):
+                got = c.classify(jobs[j][0], jobs[j][1])
+                if not (got == wants[j]).all():
+                    errors.append((j, "mismatch"))
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((j, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(j,)) for j in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    ref_ctx.close()
+    assert not errors, errors
+
+
 def test_resident_input_entry_point(ctx, orc, pave):
     import torch
     from rkmh_amd import synth
