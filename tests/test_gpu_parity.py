@@ -365,6 +365,37 @@ def test_two_contexts_from_two_host_threads(orc, pave):
     assert not errors, errors
 
 
+def test_error_paths_of_the_c_abi(orc, pave):
+    """Limits and misuse come back as error codes + rk_last_error text (the reference aborts or has undefined behaviour);
+    the context stays usable afterwards."""
+    import rkmh_amd
+    _, rb, ro = pave
+    c = rkmh_amd.Context(0)
+    qb, qo = orc.pack([bytes(rb[:150]), bytes(rb[200:350])])
+    qb = _pad(qb)
+    with pytest.raises(rkmh_amd.RkmhError, match="rk_set_references"):
+        c.classify(qb, qo)                                   # classify before references
+    with pytest.raises(rkmh_amd.RkmhError):
+        c.set_references(rb, ro, [65], 1000)                 # k > RK_MAX_K
+    with pytest.raises(rkmh_amd.RkmhError):
+        c.set_references(rb, ro, [0], 1000)                  # k < 1
+    with pytest.raises(rkmh_amd.RkmhError):
+        c.set_references(rb, ro, list(range(8, 17)), 1000)   # more than RK_MAX_KS k-mer sizes
+    with pytest.raises(rkmh_amd.RkmhError):
+        c.set_references(rb, ro, [16], 16385)                # sketch > RK_MAX_SKETCH
+    with pytest.raises(rkmh_amd.RkmhError):
+        c.set_references(rb, ro, [16], 0)
+    with pytest.raises(rkmh_amd.RkmhError):
+        c.set_references(rb, ro[:1], [16], 1000)             # zero references (UB in the reference, rkmh.cpp:848)
+    with pytest.raises(rkmh_amd.RkmhError):
+        c.hash_batch(qb, qo, [70])
+    # still alive and exact
+    c.set_references(rb, ro, [16], 1000)
+    sk, ln = c.get_reference_sketches()
+    assert (c.classify(qb, qo) == orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=1)).all()
+    c.close()
+
+
 def test_resident_input_entry_point(ctx, orc, pave):
     import torch
     from rkmh_amd import synth
