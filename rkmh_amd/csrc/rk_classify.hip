@@ -25,7 +25,7 @@
 //   drain    when the queue holds more than a wave's worth (and at the end) it is emptied with every lane
 //            busy: full-key verification, exact occurrence rank of the sketch hash within the read (LDS
 //            multiset: the merge of rkmh.cpp:869 counts min(multiplicities)), postings added to per-read
-//            16-bit LDS counters; since counts only grow, an LDS atomicMax of (count, -ref) per increment
+//            packed LDS counters (8 bits when no read has more than 255 windows, else 16); since counts only grow, an LDS atomicMax of (count, -ref) per increment
 //            leaves (max_shared, first max_id) behind without any scan.
 //   phase 2  16 lanes per read (4 reads = one wave): best earlier score for `diff` (DPP row reduction over
 //            the counters), one int4 per read, counters re-zeroed.
@@ -38,7 +38,8 @@ namespace rk {
 
 // Ablation switches used to attribute kernel time to its parts: build with
 // -DRK_ABLATE=1 and set RKMH_DBG (1 no queueing, 2 no phase 2, 4 cheap hash, 8 no bucket loads, 32 no drain,
-// 64 no hit multiset, 128 no counter updates, 256 no index verification in the drain).
+// 64 no hit multiset, 128 no counter updates, 256 no index verification in the drain).  Always available:
+// RKMH_DBG=1024 turns the split-strand last step off (A/B), RKMH_TILE_* override the tile geometry.
 #ifndef RK_ABLATE
 #define RK_ABLATE 0
 #endif
