@@ -1,7 +1,9 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs --
 bit-exact hashes, sketches and per-read (max_id, max_shared, diff, min_num)."""
+import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -394,6 +396,26 @@ def test_error_paths_of_the_c_abi(orc, pave):
     sk, ln = c.get_reference_sketches()
     assert (c.classify(qb, qo) == orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=1)).all()
     c.close()
+
+
+def test_bench_json_contract(root):
+    """bench.py prints ONE JSON line with the driver's fields, the roofline object and (N=1) the CPU baseline."""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "30000", "--steps", "3", "--warmup", "1",
+                        "--cpu-seconds", "0.5", "--spinup-seconds", "0"], capture_output=True, cwd=root)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[k], t), (k, d[k])
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "bit-exact" in cb["parity"]
 
 
 def test_resident_input_entry_point(ctx, orc, pave):
