@@ -160,7 +160,7 @@ int rk_classify_batch(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets
  * per-wave LDS image; 0 => determined by a device reduction, which costs one stream sync).
  * hip_stream: the hipStream_t to enqueue on (NULL = HIP's null stream; rk_ctx_stream() = the context's own).
  * Asynchronous: returns after enqueueing.
- * Reads the fused kernel cannot take (longer than 1528 bases, more than 2048 references, or more non-zero hashes than the sketch
+ * Reads the fused kernel cannot take (longer than 1528 bases, more than 16384 references, or more non-zero hashes than the sketch
  * size) come back with max_id = -2; rk_classify_batch reroutes those itself. */
 int rk_classify_batch_device(rk_ctx* ctx, const void* d_bases, const void* d_offsets_u32, int64_t nreads,
                              void* d_out4, uint32_t max_read_len, void* hip_stream);

@@ -859,7 +859,7 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
         HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
                                     counter, slots, min_occ, mode, (int32_t*)d_out4, c->pol, (int)ml, expect, st));
     else if (mode == 0)
-        HIPCHK(launch_fill_reroute((int32_t*)d_out4, (uint32_t)nreads, st)); // e.g. more than 2048 references: general path
+        HIPCHK(launch_fill_reroute((int32_t*)d_out4, (uint32_t)nreads, st)); // e.g. more than 16384 references: general path
     else
         return fail(RK_ERR_LIMIT, "count pass: batch not supported by the fused kernel");
     return RK_OK;

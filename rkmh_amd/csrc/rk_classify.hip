@@ -79,6 +79,8 @@ struct TileGeom {
     int32_t qcap;       // candidate queue entries (>= 128)
     int32_t cwords;     // counter words per read = ceil(nref / counters per word)
     int32_t clg;        // log2(counters per 32-bit word): 1 = 16-bit counters, 2 = 8-bit (reads with <= 255 windows)
+    int32_t csparse;    // 1: the per-read counters are a small open-addressing map ref -> count (many references) and
+                        //    cwords is its size (power of two); entry = (ref + 1) << 11 | count
     int32_t dset;       // slots of the per-read hit multiset (power of two)
     int32_t dbg;        // ablation switches (only read when built with -DRK_ABLATE=1)
     int32_t tpb;        // consecutive tiles per workgroup
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 nwin[lane] = nw; nzero[lane] = 0; best[lane] = 0;
                 // a read with more windows than a packed counter can count (only possible when the caller's length hint was
                 // too small for this read: 8-bit counters are chosen for hints of <= 255 windows) takes the general path
-                flags[lane] = nw > cmask ? 1u : 0u;
+                flags[lane] = nw > (geo.csparse ? 0x7FFu : cmask) ? 1u : 0u;
             }
         }
         const uint32_t ulen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(o_next - cur_o)); // length of read 0
@@ -350,9 +352,24 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
             if RK_DBG(128) return;
             // packed counters: 16 bits each, or 8 bits when no read of the batch has more than 255 windows (a count never
             // exceeds the number of windows, so no field can carry into its neighbour)
-            const uint32_t sh = (ref & cper_m1) * cbits;
-            const uint32_t old = atomicAdd(&c16[t * geo.cwords + (int)(ref >> clg)], 1u << sh);
-            const uint32_t cnt = ((old >> sh) & cmask) + 1u;
+            uint32_t cnt;
+            if (geo.csparse) { // wave-uniform: large reference panels keep (ref, count) pairs of the references a read really hits
+                uint32_t* row = c16 + t * geo.cwords;
+                const uint32_t M1 = (uint32_t)geo.cwords - 1u, key = ref + 1u;
+                uint32_t idx = ((ref * 0x9E3779B1u) >> 16) & M1, probe = 0;
+                cnt = 0;
+                for (; probe <= M1; ++probe) {
+                    const uint32_t old = atomicCAS(&row[idx], 0u, (key << 11) | 1u);
+                    if (old == 0u) { cnt = 1u; break; }
+                    if ((old >> 11) == key) { cnt = (atomicAdd(&row[idx], 1u) & 0x7FFu) + 1u; break; }
+                    idx = (idx + 1u) & M1;
+                }
+                if (probe > M1) { flags[t] = 1; return; } // the read hits more references than the map holds: general path
+            } else {
+                const uint32_t sh = (ref & cper_m1) * cbits;
+                const uint32_t old = atomicAdd(&c16[t * geo.cwords + (int)(ref >> clg)], 1u << sh);
+                cnt = ((old >> sh) & cmask) + 1u;
+            }
             atomicMax(&best[t], (cnt << 16) | (0xFFFFu - ref));
         };
         // one candidate window: verify the full key, find the occurrence rank of this sketch hash within the read
@@ -602,6 +619,13 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 const int max_id = bk ? (int)(0xFFFFu - (bk & 0xFFFFu)) : 0;
                 const int max_shared = (int)(bk >> 16);
                 int prev = max_id > 0 ? 0 : -1;
+                if (geo.csparse) {
+                    for (int w = sl; w < geo.cwords; w += 16) {
+                        const uint32_t x = ct[w];
+                        const int r_ = (int)(x >> 11) - 1, cj = (int)(x & 0x7FFu);
+                        if (x != 0u && r_ < max_id && cj > prev) prev = cj;
+                    }
+                } else
                 for (int w = sl; (w << clg) < max_id; w += 16) {
                     uint32_t x = ct[w];
                     for (uint32_t j = 0; j <= cper_m1; ++j) { // counters of references (w << clg) + j < max_id
@@ -631,6 +655,12 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
     g.clg = win_total <= 255 ? 2 : 1;
     if (const char* e = getenv("RKMH_TILE_C16")) { if (atoi(e) > 0) g.clg = 1; } // A/B knob: 1 = always 16-bit counters
     g.cwords = (nref + (1 << g.clg) - 1) >> g.clg;
+    g.csparse = 0;
+    // Many references: a dense counter row per read would eat the LDS budget (and reference ids beyond 2048 would not
+    // fit at all), so the row becomes a 128-entry map of the references the read actually hits.
+    int sparse_min = 129; // dense rows up to 128 words (512 B) stay dense
+    if (const char* e = getenv("RKMH_TILE_SPARSE")) sparse_min = atoi(e) > 0 ? 1 : (1 << 30);
+    if (nref > 0 && g.cwords >= sparse_min) { g.csparse = 1; g.cwords = 128; }
     int ds = 64;
     while (ds < 3 * expect_hits && ds < 1024) ds <<= 1;
     if (const char* e = getenv("RKMH_TILE_DSET")) ds = atoi(e);
@@ -669,9 +699,9 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
     return g;
 }
 
-// T x nref 16-bit counters must fit beside the tile in LDS; reference ids must fit 16 bits;
+// reference ids must fit the 16 bits they get in the running (count, -ref) maximum; large panels count sparsely;
 // one tile (>= 1 read of maxlen bytes) must fit the prefetch registers
-bool classify_tile_supported(int nref, int maxlen) { return nref <= 2048 && maxlen <= PF_MAX * WAVE * 4 - 8; }
+bool classify_tile_supported(int nref, int maxlen) { return nref <= 16384 && maxlen <= PF_MAX * WAVE * 4 - 8; }
 
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,

@@ -534,16 +534,53 @@ def test_python_cli_single_rank(orc, root, data_dir, golden_dir):
     assert r.stdout.decode() == want
 
 
-def test_many_references_reroute(ctx, orc):
-    """More references than the fused kernel's LDS counters hold: every read takes the general path."""
+def test_many_references_sparse_counters(ctx, orc):
+    """Large panels: per-read counters become a 128-entry map of the references a read really hits (any number of
+    references up to 16384 on the fused path).  Unrelated references, families of near-identical references (a read hits
+    dozens of them: ties, diff against earlier members), families larger than the map (overflow => general path),
+    duplicated references, through both entry points; and a panel beyond the fused limit."""
+    import torch
     rng = np.random.default_rng(77)
-    refs = [rand_dna(rng, 220) for _ in range(2100)]
-    reads = [refs[int(i)][20:170] for i in rng.integers(0, 2100, size=60)] + [rand_dna(rng, 150)]
+    refs = [rand_dna(rng, 220) for _ in range(2100)]                   # unrelated, short: every k-mer is a sketch hash
+    fam = rand_dna(rng, 900)
+    for j in range(90):                                                 # a family of 90 near-identical references
+        r = bytearray(fam)
+        for q in rng.integers(0, 900, size=6):
+            r[q] = b"ACGT"[int(rng.integers(0, 4))]
+        refs.insert(int(rng.integers(0, len(refs))), bytes(r))
+    big = rand_dna(rng, 700)
+    refs += [big] * 150                                                 # 150 identical references: more than the map holds
+    reads = [refs[int(i)][20:170] for i in rng.integers(0, len(refs), size=300)]
+    reads += [fam[i:i + 150] for i in range(0, 700, 50)] + [big[100:250], rand_dna(rng, 150), b"A" * 150]
     rb, ro = orc.pack(refs)
     qb, qo = orc.pack(reads)
-    got, want = _classify_both(ctx, orc, _pad(rb), ro, _pad(qb), qo, [16], 1000)
+    rbp, qbp = _pad(rb), _pad(qb)
+    for ks, S in (([16], 1000), ([16], 120), ([12, 16], 1000)):
+        got, want = _classify_both(ctx, orc, rbp, ro, qbp, qo, ks, S)
+        assert (got == want).all(), (ks, S, np.nonzero((got != want).any(axis=1))[0][:5])
+    assert (got[:300, 1] > 50).all()
+    # resident entry point: exact or flagged, and the unrelated-reference reads are answered by the fused kernel itself
+    ctx.set_references(rbp, ro, [16], 1000)
+    sk, ln = ctx.get_reference_sketches()
+    want = orc.classify_stream(qbp, qo, [16], 1000, sk, ln, threads=8)
+    n = len(reads)
+    d_b = torch.from_numpy(qbp).cuda()
+    d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).cuda()
+    d_out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    ctx.classify_device(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=150,
+                        stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    ok = (out[:, 0] == -2) | (out == want).all(axis=1)
+    assert ok.all()
+    assert (out[:, 0] != -2).mean() > 0.8
+    # beyond the fused limit: everything through the general path
+    refs2 = [rand_dna(rng, 60) for _ in range(17000)]
+    reads2 = [refs2[int(i)][5:55] for i in rng.integers(0, 17000, size=40)]
+    rb2, ro2 = orc.pack(refs2)
+    qb2, qo2 = orc.pack(reads2)
+    got, want = _classify_both(ctx, orc, _pad(rb2), ro2, _pad(qb2), qo2, [16], 1000)
     assert (got == want).all()
-    assert (got[:60, 1] > 100).all()
 
 
 def test_depth_filter_with_long_reads(ctx, orc, pave):

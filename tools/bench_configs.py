@@ -68,6 +68,8 @@ p300 = synth.synthetic_panel(300)
 run("300 synthetic ~7.6 kb references", p300[0], p300[1], [16], 1000, 1000000, 150)
 p1000 = synth.synthetic_panel(1000)
 run("1000 synthetic references", p1000[0], p1000[1], [16], 1000, 1000000, 150)
+p4000 = synth.synthetic_panel(4000)
+run("4000 synthetic references", p4000[0], p4000[1], [16], 1000, 1000000, 150)
 run("k=20 s=2000 (filter config)", rb, ro, [20], 2000, 1000000, 150)
 run("k=20 s=1000", rb, ro, [20], 1000, 1000000, 150)
 run("k=16 s=2000", rb, ro, [16], 2000, 1000000, 150)
