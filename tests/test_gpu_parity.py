@@ -798,11 +798,16 @@ def test_randomized_differential(orc, seed):
         ks = [16]
     S = int(rng.choice([1, 5, 40, 200, 1000, 3000]))
     nref = int(rng.integers(1, 40))
+    many = seed % 10 == 7                                     # a large panel: the sparse-counter form of the fused kernel
+    if many:
+        nref = int(rng.integers(520, 1400))
     base = rand_dna(rng, 3000)
     refs = []
     for i in range(nref):
         kind = rng.integers(0, 4)
-        if kind == 0:
+        if many and kind != 3:
+            r = rand_dna(rng, int(rng.integers(40, 260))) if kind else base[: int(rng.integers(100, 400))]
+        elif kind == 0:
             r = rand_dna(rng, int(rng.integers(50, 4000)))
         elif kind == 1:                                       # mutated copy of a shared ancestor: shared sketch hashes
             r = bytearray(base[: int(rng.integers(500, 3000))])
