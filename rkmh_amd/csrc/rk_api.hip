@@ -703,11 +703,13 @@ static int build_index(rk_ctx* c) {
     std::sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) { return a.h != b.h ? a.h < b.h : a.ref < b.ref; });
     size_t distinct = 0;
     for (size_t i = 0; i < pairs.size(); ++i) if (i == 0 || pairs[i].h != pairs[i - 1].h) ++distinct;
-    // bucketed table: 4 slots per bucket, ~1.25 keys per bucket on average (load ~0.31)
+    // bucketed table: 8 slots per bucket, at most 2.5 keys per bucket on average (P(more than 8) ~ 0.1 %)
     uint32_t nb = 256, lg = 8;
-    while ((size_t)nb * 5 < distinct * 4 + 4) { nb <<= 1; ++lg; }
-    const uint32_t size = nb * 4;
-    std::vector<uint32_t> fpb(size, 0);
+    size_t load_pct = 250;
+    if (const char* e = getenv("RKMH_INDEX_LOAD")) { long v = atol(e); if (v >= 10 && v <= 700) load_pct = (size_t)v; }
+    while ((size_t)nb * load_pct < distinct * 100 + 100) { nb <<= 1; ++lg; }
+    const uint32_t size = nb * IDX_SLOTS;
+    std::vector<uint16_t> fpb(size, 0);
     std::vector<uint32_t> kv((size_t)size * 4, 0); // {key lo, key hi, value, 0} per slot
     std::vector<uint32_t> post;
     post.push_back(0);
@@ -735,36 +737,36 @@ static int build_index(rk_ctx* c) {
         uint32_t b = index_bucket(pairs[i].h, bmask);
         for (;;) {
             uint32_t q = 0;
-            while (q < 4 && fpb[4 * b + q] != 0) ++q;
-            if (q < 4) {
-                const size_t sl = (size_t)4 * b + q;
-                fpb[sl] |= index_fp(pairs[i].h);
+            while (q < (uint32_t)IDX_SLOTS && fpb[(size_t)IDX_SLOTS * b + q] != 0) ++q;
+            if (q < (uint32_t)IDX_SLOTS) {
+                const size_t sl = (size_t)IDX_SLOTS * b + q;
+                fpb[sl] |= (uint16_t)index_fp(pairs[i].h);
                 kv[4 * sl] = (uint32_t)pairs[i].h; kv[4 * sl + 1] = (uint32_t)(pairs[i].h >> 32); kv[4 * sl + 2] = v;
                 break;
             }
-            fpb[4 * b] |= IDX_OVF; // the key goes further down the chain: lookups must follow
+            fpb[(size_t)IDX_SLOTS * b] |= (uint16_t)IDX_OVF; // the key goes further down the chain: lookups must follow
             b = (b + 1) & bmask;
         }
         i = j;
     }
-    RKCHK(c->d_fpb.reserve((size_t)size * 4));
+    RKCHK(c->d_fpb.reserve((size_t)size * 2));
     // compact the key/value entries: key id = (keys stored in earlier buckets) + position in the bucket
     std::vector<uint32_t> base((size_t)nb + 1, 0);
     for (uint32_t b = 0; b < nb; ++b) {
         uint32_t q = 0;
-        while (q < 4 && fpb[(size_t)4 * b + q] != 0) ++q;
+        while (q < (uint32_t)IDX_SLOTS && fpb[(size_t)IDX_SLOTS * b + q] != 0) ++q;
         base[(size_t)b + 1] = base[b] + q;
     }
     const size_t nkeys = base[nb];
     std::vector<uint32_t> dense((nkeys + 1) * 4, 0);
     for (uint32_t b = 0; b < nb; ++b)
         for (uint32_t q = 0; q < base[(size_t)b + 1] - base[b]; ++q)
-            memcpy(&dense[((size_t)base[b] + q) * 4], &kv[((size_t)4 * b + q) * 4], 16);
+            memcpy(&dense[((size_t)base[b] + q) * 4], &kv[((size_t)IDX_SLOTS * b + q) * 4], 16);
     RKCHK(c->d_base.reserve(((size_t)nb + 1) * 4));
     HIPCHK(hipMemcpy(c->d_base.p, base.data(), ((size_t)nb + 1) * 4, hipMemcpyHostToDevice));
     RKCHK(c->d_kv.reserve((nkeys + 1) * 16));
     RKCHK(c->d_post.reserve(post.size() * 4));
-    HIPCHK(hipMemcpy(c->d_fpb.p, fpb.data(), (size_t)size * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_fpb.p, fpb.data(), (size_t)size * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_kv.p, dense.data(), (nkeys + 1) * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_post.p, post.data(), post.size() * 4, hipMemcpyHostToDevice));
     c->ix.fpb = c->d_fpb.as<uint4>(); c->ix.base = c->d_base.as<uint32_t>(); c->ix.kv = c->d_kv.as<uint4>();

@@ -115,7 +115,7 @@ __device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uin
     for (;;) {
         const uint4 f = ix.fpb[b];
         const uint32_t id0 = ix.base[b]; // fetched in the same round as the fingerprints
-        uint32_t m = ((f.x & ~IDX_OVF) == fp ? 1u : 0u) | (f.y == fp ? 2u : 0u) | (f.z == fp ? 4u : 0u) | (f.w == fp ? 8u : 0u);
+        uint32_t m = index_match_mask(f, fp);
         while (m) {
             const uint32_t q = (uint32_t)__ffs((int)m) - 1u;
             m &= m - 1u;
@@ -557,16 +557,18 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                     bucket_wait(fb);
                     if (!RK_DBG(1)) {
                         const uint32_t fp = index_fp(hp);
-                        // bitwise, not short-circuit: straight-line compares.  A bucket whose overflow flag (sign bit of slot 0)
-                        // is set makes every window that lands in it a candidate (its slot-0 compare fails by design, the drain
-                        // sorts it out): 0.08 % of the windows.  Lanes without a window carry hp = 0 and looked up bucket(0)
+                        // eight halfword compares (SDWA word selects, one VALU each).  A bucket whose overflow flag (bit 15 of slot
+                        // 0) is set makes every window that lands in it a candidate (its slot-0 compare fails by design, the drain
+                        // sorts it out): ~0.1 % of the windows.  Lanes without a window carry hp = 0 and looked up bucket(0)
                         // like everyone else: hash 0 is never in the index, so at worst the drain rejects a few of them.
                         // one ballot per compare (each IS the compare's lane mask), OR-ed on the scalar unit; inverse_ballot turns
                         // the mask back into the branch predicate without the v_cndmask + v_cmp round trip hipcc emits for
                         // ballot(a | b)
-                        const uint64_t m = __builtin_amdgcn_ballot_w64(fb.x == fp) | __builtin_amdgcn_ballot_w64(fb.y == fp) |
-                                           __builtin_amdgcn_ballot_w64(fb.z == fp) | __builtin_amdgcn_ballot_w64(fb.w == fp) |
-                                           __builtin_amdgcn_ballot_w64((int32_t)fb.x < 0);
+                        const uint64_t m = __builtin_amdgcn_ballot_w64((fb.x & 0xffffu) == fp) | __builtin_amdgcn_ballot_w64((fb.x >> 16) == fp) |
+                                           __builtin_amdgcn_ballot_w64((fb.y & 0xffffu) == fp) | __builtin_amdgcn_ballot_w64((fb.y >> 16) == fp) |
+                                           __builtin_amdgcn_ballot_w64((fb.z & 0xffffu) == fp) | __builtin_amdgcn_ballot_w64((fb.z >> 16) == fp) |
+                                           __builtin_amdgcn_ballot_w64((fb.w & 0xffffu) == fp) | __builtin_amdgcn_ballot_w64((fb.w >> 16) == fp) |
+                                           __builtin_amdgcn_ballot_w64((fb.x & IDX_OVF) != 0u);
                         const bool cand = __builtin_amdgcn_inverse_ballot_w64(m);
                         if (cand) {
                             const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));

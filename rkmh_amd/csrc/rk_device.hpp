@@ -282,14 +282,17 @@ __host__ __device__ __forceinline__ int num_windows(int len, int k, int drop_las
 }
 
 // ---- resident reference index ------------------------------------------------------------------
-// All distinct hashes of all reference sketches in one bucketed hash table that stays L2 resident:
-//   fpb  : one 16-byte bucket = 4 x 32-bit fingerprints (0 = empty; slots of a bucket fill in order)
-//   base : per bucket, keys stored before it; key id = base[bucket] + position in the bucket (slots fill in order)
+// All distinct hashes of all reference sketches in one bucketed hash table sized to stay L2 resident:
+//   fpb  : one 16-byte bucket = 8 x 16-bit fingerprints (0 = empty; slots of a bucket fill in order)
+//   base : per bucket, keys stored before it; key id = base[bucket] + position in the bucket
 //   kv   : per key id {full 64-bit hash (read only to confirm a fingerprint match), value, pad} in one 16-byte entry
 //   value: per key, bit31=1 -> offset into post; else bits 30:29 = 0: one posting inline (ref | mult<<20, mult<512),
 //          1: two postings of multiplicity 1 inline (ref1 | ref2<<11, both < 2048)
 //   post : [off] = count, then count x (ref, mult)
-// A lookup that misses (about 7 of 8 read k-mers) costs exactly one 16-byte load.
+// A lookup that misses (about 7 of 8 read k-mers) costs exactly one 16-byte load.  Eight narrow fingerprints per
+// bucket instead of four wide ones halve the table for the same number of keys (1 MB at C2, 2 MB for ~300 references
+// against the 4 MB L2 of an XCD -- measured: a 4 MB table costs 20-25 % of the kernel, an 8 MB one doubles its time)
+// and make bucket overflow (> 8 keys where the mean is <= 2.5) a 0.1 % event.
 struct RefIndex {
     const uint4* fpb;
     const uint32_t* base; // per bucket: number of keys stored in the buckets before it => key id = base[bucket] + slot in bucket
@@ -301,18 +304,26 @@ struct RefIndex {
     int32_t nref;
 };
 constexpr uint32_t IDX_NOT_FOUND = 0xffffffffu;
+constexpr int IDX_SLOTS = 8;
 
-// fingerprint = 30 hash bits + the "occupied" bit 30 (never 0).  Bit 31 of a bucket's slot-0 word is the bucket's
+// fingerprint = 14 hash bits + the "occupied" bit 14 (never 0).  Bit 15 of a bucket's slot-0 halfword is the bucket's
 // OVERFLOW flag: some key that hashed here (or passed through here) was stored further down the chain.  Only then
-// does a lookup that found no fingerprint match have to look at the next bucket -- "bucket is full" alone does not
-// say so, and with ~0.7 keys per bucket it is 7 times more frequent than a real overflow.
-constexpr uint32_t IDX_OVF = 0x80000000u;
-__host__ __device__ __forceinline__ uint32_t index_fp(uint64_t h) { return ((uint32_t)h & 0x3fffffffu) | 0x40000000u; }
+// does a lookup that found no fingerprint match have to look at the next bucket.  (A false fingerprint match -- 2.5
+// keys x 2^-14 per lookup -- only costs a verification in the drain: exactness comes from the 64-bit key compare.)
+constexpr uint32_t IDX_OVF = 0x8000u;
+__host__ __device__ __forceinline__ uint32_t index_fp(uint64_t h) { return ((uint32_t)h & 0x3fffu) | 0x4000u; }
 // bucket = the LOW bits of the hash's high word (the fingerprint takes the low word's bits).  Murmur output is already
 // uniform, so no further mixing is spent in the hot loop -- but the keys are bottom-S sketch hashes, i.e. the SMALLEST
 // hashes of their sequences, so the top bits of the 64-bit value are heavily biased and must not be used.
 __host__ __device__ __forceinline__ uint32_t index_bucket(uint64_t h, uint32_t bmask) {
     return (uint32_t)(h >> 32) & bmask;
+}
+// 8-bit mask of the bucket's slots whose fingerprint equals fp (slot 0's overflow flag ignored)
+__device__ __forceinline__ uint32_t index_match_mask(const uint4& f, uint32_t fp) {
+    return (((f.x & 0x7fffu) == fp) ? 1u : 0u) | (((f.x >> 16) == fp) ? 2u : 0u) |
+           (((f.y & 0xffffu) == fp) ? 4u : 0u) | (((f.y >> 16) == fp) ? 8u : 0u) |
+           (((f.z & 0xffffu) == fp) ? 16u : 0u) | (((f.z >> 16) == fp) ? 32u : 0u) |
+           (((f.w & 0xffffu) == fp) ? 64u : 0u) | (((f.w >> 16) == fp) ? 128u : 0u);
 }
 __device__ __forceinline__ uint64_t index_key(const RefIndex& ix, uint32_t id) {
     const uint2 k = *reinterpret_cast<const uint2*>(&ix.kv[id]);
@@ -324,10 +335,12 @@ __device__ __forceinline__ uint32_t index_find(const RefIndex& ix, uint64_t h) {
     for (;;) {
         const uint4 f = ix.fpb[b];
         const uint32_t id0 = ix.base[b];
-        if ((f.x & ~IDX_OVF) == fp && index_key(ix, id0 + 0) == h) return id0 + 0;
-        if (f.y == fp && index_key(ix, id0 + 1) == h) return id0 + 1;
-        if (f.z == fp && index_key(ix, id0 + 2) == h) return id0 + 2;
-        if (f.w == fp && index_key(ix, id0 + 3) == h) return id0 + 3;
+        uint32_t m = index_match_mask(f, fp);
+        while (m) {
+            const uint32_t q = (uint32_t)__ffs((int)m) - 1u;
+            m &= m - 1u;
+            if (index_key(ix, id0 + q) == h) return id0 + q;
+        }
         if (!(f.x & IDX_OVF)) return IDX_NOT_FOUND;   // nothing was ever pushed past this bucket
         b = (b + 1) & ix.bmask;
     }
