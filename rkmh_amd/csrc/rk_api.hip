@@ -758,18 +758,18 @@ static int build_index(rk_ctx* c) {
         base[(size_t)b + 1] = base[b] + q;
     }
     const size_t nkeys = base[nb];
-    std::vector<uint32_t> dense((nkeys + 2) * 3, 0);
+    std::vector<uint32_t> dense((nkeys + 1) * 4, 0);
     for (uint32_t b = 0; b < nb; ++b)
         for (uint32_t q = 0; q < base[(size_t)b + 1] - base[b]; ++q)
-            memcpy(&dense[((size_t)base[b] + q) * 3], &kv[((size_t)IDX_SLOTS * b + q) * 4], 12);
+            memcpy(&dense[((size_t)base[b] + q) * 4], &kv[((size_t)IDX_SLOTS * b + q) * 4], 16);
     RKCHK(c->d_base.reserve(((size_t)nb + 1) * 4));
     HIPCHK(hipMemcpy(c->d_base.p, base.data(), ((size_t)nb + 1) * 4, hipMemcpyHostToDevice));
-    RKCHK(c->d_kv.reserve((nkeys + 2) * 12));
+    RKCHK(c->d_kv.reserve((nkeys + 1) * 16));
     RKCHK(c->d_post.reserve(post.size() * 4));
     HIPCHK(hipMemcpy(c->d_fpb.p, fpb.data(), (size_t)size * 2, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->d_kv.p, dense.data(), (nkeys + 2) * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_kv.p, dense.data(), (nkeys + 1) * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_post.p, post.data(), post.size() * 4, hipMemcpyHostToDevice));
-    c->ix.fpb = c->d_fpb.as<uint4>(); c->ix.base = c->d_base.as<uint32_t>(); c->ix.kv = c->d_kv.as<uint32_t>();
+    c->ix.fpb = c->d_fpb.as<uint4>(); c->ix.base = c->d_base.as<uint32_t>(); c->ix.kv = c->d_kv.as<uint4>();
     c->ix.post = c->d_post.as<uint32_t>();
     c->ix.bmask = bmask; c->ix.bshift = bshift; c->ix.nref = R;
     // a full bottom-S sketch of uniform hashes keeps the fraction (largest kept hash / 2^64) of the k-mers

@@ -120,9 +120,8 @@ __device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uin
             const uint32_t q = (uint32_t)__ffs((int)m) - 1u;
             m &= m - 1u;
             const uint32_t s = id0 + q;
-            const uint32_t* ep = ix.kv + 3u * s; // key and value in one 12-byte fetch from the dense (L2-resident) key array
-            const uint32_t e0 = ep[0], e1 = ep[1], e2 = ep[2];
-            if (e0 == (uint32_t)h && e1 == (uint32_t)(h >> 32)) { slot = s; val = e2; return true; }
+            const uint4 e = ix.kv[s]; // key and value in one 16-byte fetch from the dense (L2-resident) key array
+            if (e.x == (uint32_t)h && e.y == (uint32_t)(h >> 32)) { slot = s; val = e.z; return true; }
         }
         if (!(f.x & IDX_OVF)) return false;
         b = (b + 1) & ix.bmask;

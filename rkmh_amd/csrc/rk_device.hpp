@@ -285,7 +285,7 @@ __host__ __device__ __forceinline__ int num_windows(int len, int k, int drop_las
 // All distinct hashes of all reference sketches in one bucketed hash table sized to stay L2 resident:
 //   fpb  : one 16-byte bucket = 8 x 16-bit fingerprints (0 = empty; slots of a bucket fill in order)
 //   base : per bucket, keys stored before it; key id = base[bucket] + position in the bucket
-//   kv   : per key id {full 64-bit hash (read only to confirm a fingerprint match), value} in one 12-byte entry
+//   kv   : per key id {full 64-bit hash (read only to confirm a fingerprint match), value, pad} in one 16-byte entry
 //   value: per key, bit31=1 -> offset into post; else bits 30:29 = 0: one posting inline (ref | mult<<20, mult<512),
 //          1: two postings of multiplicity 1 inline (ref1 | ref2<<11, both < 2048)
 //   post : [off] = count, then count x (ref, mult)
@@ -296,8 +296,8 @@ __host__ __device__ __forceinline__ int num_windows(int len, int k, int drop_las
 struct RefIndex {
     const uint4* fpb;
     const uint32_t* base; // per bucket: number of keys stored in the buckets before it => key id = base[bucket] + slot in bucket
-    const uint32_t* kv;   // per key id {key lo, key hi, value}: 12 bytes, DENSE (no holes, no padding): one 12-byte fetch verifies
-                          // a hit and brings its postings, and the whole array (12 B x distinct sketch hashes) lives in L2
+    const uint4* kv;      // per key id {key lo, key hi, value, 0}, DENSE (no holes): a 16-byte fetch verifies a hit and brings its
+                          // postings, and the whole array (16 B x distinct sketch hashes) is small enough to live in L2
     const uint32_t* post;
     uint32_t bmask;   // buckets - 1
     uint32_t bshift;  // 32 - log2(buckets)
@@ -326,8 +326,8 @@ __device__ __forceinline__ uint32_t index_match_mask(const uint4& f, uint32_t fp
            (((f.w & 0xffffu) == fp) ? 64u : 0u) | (((f.w >> 16) == fp) ? 128u : 0u);
 }
 __device__ __forceinline__ uint64_t index_key(const RefIndex& ix, uint32_t id) {
-    const uint32_t* e = ix.kv + 3u * id;
-    return ((uint64_t)e[1] << 32) | e[0];
+    const uint2 k = *reinterpret_cast<const uint2*>(&ix.kv[id]);
+    return ((uint64_t)k.y << 32) | k.x;
 }
 __device__ __forceinline__ uint32_t index_find(const RefIndex& ix, uint64_t h) {
     const uint32_t fp = index_fp(h);

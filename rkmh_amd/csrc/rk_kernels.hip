@@ -79,7 +79,7 @@ __device__ __forceinline__ void wave_argmax_diff(const int* sh, int R, int lane,
 }
 
 __device__ __forceinline__ void accumulate_posting(const RefIndex& ix, uint32_t slot, uint32_t rank, int* sh) {
-    uint32_t v = ix.kv[3u * slot + 2u];
+    uint32_t v = ix.kv[slot].z;
     if (!(v >> 31)) {
         if (((v >> 29) & 3u) == 0u) {
             uint32_t ref = v & 0xFFFFFu, mult = (v >> 20) & 0x1FFu;
