@@ -10,8 +10,14 @@ all: $(LIB) bin/rkmh oracle
 
 $(CSRC)/rk_kernels.o: $(CSRC)/rk_kernels.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(CSRC)/rk_classify.o: $(CSRC)/rk_classify.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+# The fused kernel issues its prefetches through inline asm; the ISA of THIS compile is checked for uses of a register
+# that an asm-issued load may still be writing (tools/lint_async_loads.py).  A finding fails the build.
+$(CSRC)/rk_classify.o: $(CSRC)/rk_classify.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp tools/lint_async_loads.py
+	@mkdir -p build/isa
+	cd build/isa && $(HIPCC) $(HIPFLAGS) -save-temps -c $(CURDIR)/$< -o $(CURDIR)/$@.tmp
+	@cd build/isa && rm -f *.bc *.hipi *.out *.resolution.txt *.hipfb *host-x86_64*.s *.o
+	python3 tools/lint_async_loads.py build/isa/rk_classify-hip-amdgcn-amd-amdhsa-$(ARCH).s || { rm -f $@.tmp; exit 1; }
+	mv $@.tmp $@
 $(CSRC)/rk_call.o: $(CSRC)/rk_call.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/rk_api.o: $(CSRC)/rk_api.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp include/rkmh_amd.h

@@ -222,21 +222,21 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
 
     for (uint32_t tile = tile0; tile < tile_end; ++tile) {
         const uint32_t r0 = tile * (uint32_t)T;
-        const int Tn = tile_reads(tile);
         // wave-uniform values are moved to SGPRs explicitly: hipcc cannot prove that values loaded from one address by
         // every lane are uniform, and keeps loop counters derived from them in VGPRs with exec-mask loop control
         const uint32_t tstart = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur_a);
-        const uint32_t B = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur_b - cur_a));
+        const uint32_t B_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur_b - cur_a));
         const uint32_t ntile = tile + 1u < tile_end ? tile + 1u : ntiles; // this workgroup's next tile (none: ntiles)
         uint32_t nxt_a = 0, nxt_b = 0, nxt_o = 0;
         if (ntile < ntiles) load_offsets(ntile, nxt_a, nxt_b, nxt_o); // lands during phase 0
         wave_sync(); // previous tile fully consumed
-        if (B > (uint32_t)geo.cap_bytes) { // a read longer than the hint: the host reroutes the tile
-            if (MODE != 1 && lane < Tn) reinterpret_cast<int4*>(out4)[r0 + lane] = make_int4(-2, 0, 0, 0);
-            cur_a = nxt_a; cur_b = nxt_b; cur_o = nxt_o;
-            if (ntile < ntiles) load_bases(cur_a, cur_b);
-            continue;
-        }
+        // A tile holding a read longer than the caller's hint is rerouted by the host (rows of -2; the count pass skips it).
+        // Here it becomes an EMPTY tile (no reads, no bytes) that runs through the body like any other: a branch around the
+        // body would fork the path between the asm-issued prefetch and its wait (see the end of the loop body).
+        const bool oversized = B_all > (uint32_t)geo.cap_bytes;
+        if (MODE != 1 && oversized && lane < tile_reads(tile)) reinterpret_cast<int4*>(out4)[r0 + lane] = make_int4(-2, 0, 0, 0);
+        const int Tn = oversized ? 0 : tile_reads(tile);
+        const uint32_t B = oversized ? 0u : B_all;
         // ---- phase 0, interval 1: everything that needs only registers ------------------------------
         Staged s;
         {
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 wave_sync();
             }
         }
-        if (MODE == 1) continue;
+        if (MODE == 1) { wait_bases(); continue; } // see the end of the loop body
 
         // ---- phase 2: 16 lanes per read -----------------------------------------------------------
         {
@@ -642,6 +642,12 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(max_id, max_shared, max_shared - prev, nmins);
             }
         }
+        // The prefetch registers cross the back edge of this loop.  hipcc does not know that an asm-issued load is still
+        // writing them, and may resolve the loop-carried value with a register copy at the end of the body: a copy taken
+        // before the data has landed reads the previous tile's bases (seen in the count pass of -M, whose hashing loop
+        // holds no other wait, as a one-in-thousands wrong count).  Retiring the loads HERE makes the loop-carried value
+        // the output of this statement, so any such copy follows it.  tools/lint_async_loads.py checks the ISA for this.
+        wait_bases();
     }
 }
 

@@ -1,0 +1,60 @@
+"""tools/lint_async_loads.py: the build-time ISA check behind the inline-asm prefetches of the fused kernel."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("lint_async_loads", os.path.join(ROOT, "tools", "lint_async_loads.py"))
+lint = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(lint)
+
+HEAD = "_Z6kernelv:\n"
+LOAD = "\t;;#ASMSTART\n\tglobal_load_dword v5, v[2:3], off\n\t;;#ASMEND\n"
+WAIT = "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n"
+
+
+def run(body):
+    ks = list(lint.kernels((HEAD + body + "\ts_endpgm\n").split("\n")))
+    assert len(ks) == 1
+    return lint.analyse(*ks[0])
+
+
+def test_copy_of_a_register_in_flight_is_reported():
+    res = run(LOAD + "\tv_add_u32_e32 v1, v2, v3\n\tv_mov_b32_e32 v9, v5\n" + WAIT + "\tv_mov_b32_e32 v8, v5\n")
+    assert [c for _, c, _, _ in res] == ["v_mov_b32_e32 v9, v5"]
+
+
+def test_use_after_the_wait_is_clean():
+    assert run(LOAD + "\tv_add_u32_e32 v1, v2, v3\n" + WAIT + "\tv_mov_b32_e32 v9, v5\n") == []
+
+
+def test_loop_carried_copy_on_the_back_edge():
+    # load in the loop body, copy in the latch, wait only at the top of the next iteration: the -M count-pass bug
+    body = (".LBB0_1:\n" + WAIT + "\tv_and_b32_e32 v4, 3, v6\n" + "\t;;#ASMSTART\n\tglobal_load_dword v7, v[2:3], off\n\t;;#ASMEND\n"
+            "\tv_add_u32_e32 v1, v2, v3\n\tv_mov_b32_e32 v6, v7\n\ts_cbranch_scc1 .LBB0_1\n")
+    res = run(body)
+    assert len(res) == 1 and res[0][1] == "v_mov_b32_e32 v6, v7" and res[0][2] == [7]
+
+
+def test_overwrite_of_a_register_in_flight_is_reported():
+    assert len(run(LOAD + "\tv_mov_b32_e32 v5, 0\n" + WAIT)) == 1
+
+
+def test_dead_high_half_of_a_mad_addend_is_accepted():
+    body = LOAD + "\tv_mad_u64_u32 v[10:11], s[4:5], v1, s6, v[4:5]\n\tv_mov_b32_e32 v11, 0\n" + WAIT
+    assert run(body) == []
+    body = LOAD + "\tv_mad_u64_u32 v[10:11], s[4:5], v1, s6, v[4:5]\n\tv_add_u32_e32 v12, v11, v1\n" + WAIT
+    assert len(run(body)) == 1
+
+
+def test_shipped_kernel_isa_is_clean():
+    """The .s kept by the Makefile's compile of rk_classify.hip (build/isa/, same compile as the shipped object)."""
+    s = os.path.join(ROOT, "build", "isa", "rk_classify-hip-amdgcn-amd-amdhsa-gfx950.s")
+    if not os.path.exists(s):
+        pytest.skip("no build/isa (run make)")
+    n = 0
+    for name, body in lint.kernels(open(s).read().split("\n")):
+        n += 1
+        assert lint.analyse(name, body) == [], name
+    assert n >= 72

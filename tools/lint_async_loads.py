@@ -1,0 +1,206 @@
+"""Build-time check of the inline-asm prefetches (rk_classify.hip: load_bases / bucket_load_async).
+
+Those loads are issued through `asm volatile` so that hipcc does not count them (it would otherwise drain vmcnt inside
+the hashing loop).  The price: hipcc does not know the destination VGPRs are in flight, so nothing stops its register
+allocator from placing a copy (v_mov of a loop-carried value) or any other use of such a register between the load and
+the `s_waitcnt vmcnt(0)` that retires it -- the copy would then read the register's OLD contents, depending on timing.
+
+This script walks the control-flow graph of every kernel in a `hipcc -save-temps` .s file and reports each instruction
+that reads or writes a VGPR while an asm-issued load into it may still be outstanding (forward may-analysis; only
+`s_waitcnt vmcnt(0)` retires loads).  Exit status 1 when anything is found.
+
+    python tools/lint_async_loads.py build/rk_classify-hip-amdgcn-amd-amdhsa-gfx950.s
+"""
+import re
+import sys
+
+REG1 = re.compile(r"\bv(\d+)\b")
+REGN = re.compile(r"\bv\[(\d+):(\d+)\]")
+
+
+def regs_of(text):
+    out = set()
+    for m in REGN.finditer(text):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in REG1.finditer(text):
+        out.add(int(m.group(1)))
+    return out
+
+
+def kernels(lines):
+    cur, name = None, None
+    for l in lines:
+        m = re.match(r"^(_Z\w+):", l)
+        if m and cur is None:
+            name, cur = m.group(1), []
+            continue
+        if cur is not None:
+            cur.append(l)
+            if "s_endpgm" in l:
+                yield name, cur
+                cur = None
+
+
+def analyse(name, body):
+    # instruction list with flags
+    ins = []      # (text, in_asm)
+    lab_of = []
+    labels = {}
+    cur_label = "entry"
+    in_asm = False
+    for l in body:
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):", t)
+        if m:
+            labels[m.group(1)] = len(ins)
+            cur_label = m.group(1)
+            continue
+        c = t.split(";")[0].strip()
+        if not c or c.startswith("."):
+            continue
+        ins.append((c, in_asm))
+        lab_of.append(cur_label)
+    n = len(ins)
+    succ = [[] for _ in range(n)]
+    for i, (c, _) in enumerate(ins):
+        op = c.split()[0]
+        if op == "s_endpgm":
+            continue
+        if op == "s_branch":
+            succ[i].append(labels[c.split()[1]])
+            continue
+        if op.startswith("s_cbranch"):
+            succ[i].append(labels[c.split()[1]])
+        if i + 1 < n:
+            succ[i].append(i + 1)
+    state_in = [None] * n
+    state_in[0] = frozenset()
+    work = [0]
+    found = {}
+    while work:
+        i = work.pop()
+        st = set(state_in[i])
+        c, asm = ins[i]
+        op = c.split()[0]
+        used = regs_of(c)
+        if asm and op.startswith("global_load"):
+            dest = regs_of(c.split()[1].rstrip(","))
+            src = used - dest
+            if st & src:
+                found[i] = (c, sorted(st & src))
+            st |= dest
+        elif op == "s_waitcnt" and "vmcnt(0)" in c:
+            st.clear()
+        else:
+            if st & used and not dont_care_high_half(ins, succ, i, st):
+                found[i] = (c, sorted(st & used))
+        fs = frozenset(st)
+        for j in succ[i]:
+            if state_in[j] is None or not fs <= state_in[j]:
+                state_in[j] = fs if state_in[j] is None else (state_in[j] | fs)
+                work.append(j)
+    res = []
+    for i, (c, r) in sorted(found.items()):
+        res.append((i, c, r, witness(ins, succ, lab_of, i, r)))
+    return res
+
+
+def dont_care_high_half(ins, succ, i, inflight):
+    """hipcc computes a 32-bit multiply-add with `v_mad_u64_u32 v[d:d+1], a, b, v[x:x+1]` and leaves the addend's high half
+    x+1 undefined -- whichever register follows x, possibly one in flight.  Harmless when the result's high half d+1 is
+    dead: accepted if d+1 is overwritten before it is read, within the straight-line code that follows."""
+    c = ins[i][0]
+    m = re.match(r"v_mad_u64_u32 v\[(\d+):(\d+)\], (.*), v\[(\d+):(\d+)\]$", c)
+    if not m:
+        return False
+    d_hi, x_hi = int(m.group(2)), int(m.group(5))
+    others = regs_of(m.group(3)) | {int(m.group(1)), d_hi, int(m.group(4))}
+    if (set(inflight) & regs_of(c)) != {x_hi} or x_hi in others:
+        return False
+    # is d_hi read before it is written on any path from here?
+    seen, stack = set(), list(succ[i])
+    while stack:
+        j = stack.pop()
+        if j in seen:
+            continue
+        seen.add(j)
+        cj = ins[j][0]
+        op = cj.split()[0]
+        parts = cj.split(None, 1)
+        if len(parts) == 2 and not op.startswith("s_"):
+            ops = parts[1].split(", ")
+            writes = op.startswith("v_") or op.startswith("ds_read") or op.startswith("global_load") or op.startswith("ds_bpermute")
+            dest = regs_of(ops[0]) if writes else set()
+            srcs = regs_of(", ".join(ops[1:])) if writes else regs_of(parts[1])
+            if op.startswith("v_cmp") or op.startswith("v_readlane") or op.startswith("v_readfirstlane"):
+                dest, srcs = set(), regs_of(parts[1])
+            if d_hi in srcs:
+                return False
+            if d_hi in dest:
+                continue
+        stack.extend(succ[j])
+    return True
+
+
+def witness(ins, succ, lab_of, hit, regs):
+    """Shortest wait-free path from an asm load of one of `regs` to instruction `hit`, as a list of block labels."""
+    from collections import deque
+    for ld, (c, asm) in enumerate(ins):
+        if not (asm and c.split()[0].startswith("global_load")):
+            continue
+        if not (regs_of(c.split()[1].rstrip(",")) & set(regs)):
+            continue
+        prev = {ld: None}
+        dq = deque([ld])
+        while dq:
+            i = dq.popleft()
+            if i == hit and prev[i] is not None:
+                break
+            for j in succ[i]:
+                cj = ins[j][0]
+                if j in prev and j != hit:
+                    continue
+                if cj.startswith("s_waitcnt") and "vmcnt(0)" in cj:
+                    continue
+                if j not in prev or (j == hit and j == ld):
+                    prev[j] = i
+                    dq.append(j)
+        if hit in prev and prev[hit] is not None:
+            path, x, seen = [], hit, set()
+            while x is not None and x not in seen:
+                seen.add(x)
+                path.append(x)
+                x = prev[x]
+            blocks = []
+            for x in reversed(path):
+                if not blocks or blocks[-1] != lab_of[x]:
+                    blocks.append(lab_of[x])
+            return "load #%d -> %s" % (ld, " ".join(blocks))
+    return "?"
+
+
+def main():
+    lines = open(sys.argv[1]).read().split("\n")
+    bad = 0
+    nk = 0
+    for name, body in kernels(lines):
+        nk += 1
+        res = analyse(name, body)
+        if res:
+            bad += 1
+            m = re.search(r"I(Li\w+?)EEv", name)
+            print("%s: %d hazard(s)" % (name[:70], len(res)))
+            for i, c, r, w in res[:8]:
+                print("    #%d  %-50s in flight: %s   [%s]" % (i, c, ",".join("v%d" % x for x in r), w))
+    print("%d kernels checked, %d with a use of an in-flight register" % (nk, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
