@@ -784,7 +784,11 @@ _RAND_LENS = [0, 3, 15, 16, 17, 60, 150, 150, 150, 300, 800, 1528, 1529, 1700] +
     ([5000, 9000, 20000] if os.environ.get("RKMH_TEST_LONG") else [])
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RKMH_TEST_SEEDS", "48"))))   # soak: RKMH_TEST_SEEDS=2000
+# soak: RKMH_TEST_SEEDS=2000 [RKMH_TEST_SEED_BASE=100000 for inputs no earlier run has seen]
+_SEED_BASE = int(os.environ.get("RKMH_TEST_SEED_BASE", "0"))
+
+
+@pytest.mark.parametrize("seed", range(_SEED_BASE, _SEED_BASE + int(os.environ.get("RKMH_TEST_SEEDS", "48"))))
 def test_randomized_differential(orc, seed):
     """Random ragged batches (lengths 0..1700, lower case, N runs, repeats, shared and duplicated references, 1-3 k-mer
     sizes, tiny to large sketches, every fold / window policy, with and without -M) against the oracle."""
