@@ -90,6 +90,13 @@ int rk_minhashes_frequency_filter(rk_ctx* ctx, uint64_t* h, int n, int sketch_si
                                   const rk_counter* counter, int min_count, int max_count);
 /* mkmh::hash_intersection_size(const hash_t*, int, const hash_t*, int, int&)  src/rkmh.cpp:869,922 */
 int rk_hash_intersection_size(rk_ctx* ctx, const uint64_t* a, int na, const uint64_t* b, int nb, int* out);
+/* mkmh::hash_intersection(hash_t*, int start, int len, hash_t*, int start, int len, int sketch_size) -> tuple<hash_t*, int>
+ * as called from src/equiv.hpp:308,340,364 (the comment at equiv.hpp:303-305 names the arguments (ptr, len, start); the CALLS
+ * pass (ptr, start, len) and that order is kept).  The matching hashes of a[a_start, a_start+a_len) and b[...], ascending,
+ * both sides advancing on equality as in rk_hash_intersection_size, at most sketch_size of them.  *out is allocated by
+ * the callee (the reference's callers delete[] it, equiv.hpp:317,349); release it with rk_free. */
+int rk_hash_intersection(rk_ctx* ctx, const uint64_t* a, int a_start, int a_len, const uint64_t* b, int b_start, int b_len,
+                         int sketch_size, uint64_t** out, int* n);
 
 /* HASHTCounter (ctor src/rkmh.cpp:739,742,1187; increment :335; get :1218,1260): int32 slots in HBM,
  * slot = key % slots.  rk_counter_wrap adopts caller-owned DEVICE memory (e.g. a torch tensor, so

@@ -104,6 +104,16 @@ def hash_intersection_size(a: np.ndarray, b: np.ndarray) -> int:
     return out.value
 
 
+def hash_intersection(a, a_start, a_len, b, b_start, b_len, S) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out, n = C.POINTER(C.c_uint64)(), C.c_int()
+    lib().rko_hash_intersection(_p(a, C.c_uint64), a_start, a_len, _p(b, C.c_uint64), b_start, b_len, S, C.byref(out), C.byref(n))
+    r = np.ctypeslib.as_array(out, shape=(max(n.value, 1),))[: n.value].copy()
+    lib().rko_free(out)
+    return r.astype(np.uint64)
+
+
 def argmax_diff(shared):
     s = np.ascontiguousarray(shared, dtype=np.int32)
     a, b, c = C.c_int(), C.c_int(), C.c_int()

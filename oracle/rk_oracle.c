@@ -205,6 +205,24 @@ void rko_hash_intersection_size(const uint64_t* a, int na, const uint64_t* b, in
     *out = r;
 }
 
+/* A5f: equiv.hpp:308,340,364 (the callers read get<1> as the count and delete[] get<0>) */
+void rko_hash_intersection(const uint64_t* a, int a_start, int a_len, const uint64_t* b, int b_start, int b_len, int S,
+                           uint64_t** out, int* n) {
+    const uint64_t* x = a + a_start;
+    const uint64_t* y = b + b_start;
+    int cap = S < a_len ? S : a_len;
+    uint64_t* r = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(cap > 0 ? cap : 1));
+    int i = 0, j = 0, c = 0;
+    while (i < a_len && x[i] == 0) i++;
+    while (j < b_len && y[j] == 0) j++;
+    while (i < a_len && j < b_len && c < cap) {
+        if (x[i] == y[j]) { r[c++] = x[i]; i++; j++; }
+        else if (x[i] > y[j]) j++;
+        else i++;
+    }
+    *out = r; *n = c;
+}
+
 /* A6: src/rkmh.cpp:874-883 */
 void rko_argmax_diff(const int* shared, int R, int* max_id, int* max_shared, int* diff) {
     int ms = -1, mi = 0, d = 0;

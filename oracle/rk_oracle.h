@@ -86,6 +86,11 @@ void rko_minhashes_frequency_filter(uint64_t* h, int n, int S, uint64_t** out, i
 /* A5: hash_intersection_size (rkmh.cpp:869,922): two-pointer merge, both advance on equality (U7) */
 void rko_hash_intersection_size(const uint64_t* a, int na, const uint64_t* b, int nb, int* out);
 
+/* A5f: the 7-argument hash_intersection filter's helpers call (equiv.hpp:308,340,364; argument order as CALLED: array,
+ * start, length -- U7b): the same merge, materialising the matches (ascending, at most S); *out is malloc'd. */
+void rko_hash_intersection(const uint64_t* a, int a_start, int a_len, const uint64_t* b, int b_start, int b_len, int S,
+                           uint64_t** out, int* n);
+
 /* A6: argmax + diff exactly as the sequential scan rkmh.cpp:874-883 */
 void rko_argmax_diff(const int* shared, int R, int* max_id, int* max_shared, int* diff);
 

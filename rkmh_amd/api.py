@@ -60,6 +60,7 @@ _SIGS = {
     "rk_mask_by_frequency": (C.c_int, [C.c_void_p, _u64p, C.c_int, C.c_void_p, C.c_int]),
     "rk_minhashes_frequency_filter": (C.c_int, [C.c_void_p, _u64p, C.c_int, C.c_int, C.POINTER(_u64p), _ip, C.c_void_p, C.c_int, C.c_int]),
     "rk_hash_intersection_size": (C.c_int, [C.c_void_p, _u64p, C.c_int, _u64p, C.c_int, _ip]),
+    "rk_hash_intersection": (C.c_int, [C.c_void_p, _u64p, C.c_int, C.c_int, _u64p, C.c_int, C.c_int, C.c_int, C.POINTER(_u64p), _ip]),
     "rk_counter_create": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "rk_counter_wrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "rk_counter_destroy": (None, [C.c_void_p]),
@@ -353,6 +354,19 @@ class Context:
         out = C.c_int()
         _chk(self._lib.rk_hash_intersection_size(self._h, _p(a, C.c_uint64), len(a), _p(b, C.c_uint64), len(b), C.byref(out)))
         return out.value
+
+    def hash_intersection(self, a, a_start, a_len, b, b_start, b_len, sketch_size):
+        """mkmh's 7-argument hash_intersection (equiv.hpp:308,340,364): the matches themselves (<= sketch_size)."""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        if a_start < 0 or b_start < 0 or a_start + a_len > len(a) or b_start + b_len > len(b):
+            raise ValueError("range outside the array")
+        out, n = _u64p(), C.c_int()
+        _chk(self._lib.rk_hash_intersection(self._h, _p(a, C.c_uint64), a_start, a_len, _p(b, C.c_uint64), b_start, b_len,
+                                            sketch_size, C.byref(out), C.byref(n)))
+        r = np.ctypeslib.as_array(out, shape=(max(n.value, 1),))[: n.value].copy()
+        self._lib.rk_free(out)
+        return r
 
     # ---- outer boundary (batches) ------------------------------------------------------------
     def hash_batch(self, bases, offsets, ks):

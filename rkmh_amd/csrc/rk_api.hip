@@ -570,6 +570,33 @@ extern "C" int rk_hash_intersection_size(rk_ctx* c, const uint64_t* a, int na, c
     return RK_OK;
 }
 
+// mkmh::hash_intersection with 7 arguments, as filter's classify_* helpers call it (equiv.hpp:308, 340, 364): (array, start,
+// length) twice, then the sketch size, which bounds the result.  Callee-allocated result, released with rk_free.
+extern "C" int rk_hash_intersection(rk_ctx* c, const uint64_t* a, int a_start, int a_len, const uint64_t* b, int b_start, int b_len,
+                                    int S, uint64_t** out, int* n) {
+    if (!c || !out || !n || a_start < 0 || b_start < 0 || a_len < 0 || b_len < 0 || S < 0 || (!a && a_len) || (!b && b_len))
+        return fail(RK_ERR_ARG, "bad arguments");
+    *out = nullptr; *n = 0;
+    RKCHK(set_dev(c));
+    const int cap = S < a_len ? S : a_len;
+    RKCHK(c->w_hashes.reserve((size_t)(a_len + b_len + cap + 2) * 8));
+    RKCHK(c->w_lens.reserve(4));
+    uint64_t* da = c->w_hashes.as<uint64_t>();
+    uint64_t* db = da + a_len;
+    uint64_t* dout = db + b_len;
+    if (a_len) HIPCHK(hipMemcpyAsync(da, a + a_start, (size_t)a_len * 8, hipMemcpyHostToDevice, c->st));
+    if (b_len) HIPCHK(hipMemcpyAsync(db, b + b_start, (size_t)b_len * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(launch_intersect_pair_emit(da, a_len, db, b_len, cap, dout, c->w_lens.as<int>(), c->st));
+    int cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, c->w_lens.p, 4, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    uint64_t* r = (uint64_t*)malloc((size_t)(cnt > 0 ? cnt : 1) * 8);
+    if (!r) return fail(RK_ERR_NOMEM, "malloc");
+    if (cnt) HIPCHK(hipMemcpy(r, dout, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    *out = r; *n = cnt;
+    return RK_OK;
+}
+
 // ---- HASHTCounter ------------------------------------------------------------------------------
 extern "C" int rk_counter_create(rk_ctx* c, uint64_t slots, rk_counter** out) {
     if (!c || !out || slots == 0) return fail(RK_ERR_ARG, "bad arguments");

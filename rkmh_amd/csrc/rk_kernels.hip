@@ -445,6 +445,46 @@ hipError_t launch_intersect_pair(const uint64_t* a, int na, const uint64_t* b, i
     return hipGetLastError();
 }
 
+// mkmh::hash_intersection (7 arguments, equiv.hpp:308,340,364): the matches themselves, ascending, at most `cap` of them.
+// Same multiset rule as k_intersect_pair (occurrence `rank` of a hash in a matches while b holds more than `rank` copies);
+// the block compacts 256 elements of a per round with wave ballots.
+__global__ __launch_bounds__(256) void k_intersect_pair_emit(const uint64_t* __restrict__ a, int na, const uint64_t* __restrict__ b,
+                                                             int nb, int cap, uint64_t* __restrict__ out, int* n_out) {
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int running = 0;
+    for (int base = 0; base < na; base += 256) {
+        const int t = base + (int)threadIdx.x;
+        bool hit = false;
+        uint64_t h = 0;
+        if (t < na && (h = a[t]) != 0) {
+            int u = t;
+            while (u > 0 && a[u - 1] == h) --u;
+            const int rank = t - u;
+            int lo = 0, hi = nb;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (b[mid] < h) lo = mid + 1; else hi = mid; }
+            const int first = lo;
+            hi = nb;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (b[mid] <= h) lo = mid + 1; else hi = mid; }
+            hit = rank < lo - first;
+        }
+        const uint64_t m = __ballot(hit);
+        if (lane == 0) wsum[w] = __popcll(m);
+        __syncthreads();
+        int before = running;
+        for (int j = 0; j < w; ++j) before += wsum[j];
+        const int pos = before + __popcll(m & ((1ull << lane) - 1ull));
+        if (hit && pos < cap) out[pos] = h;
+        running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = running < cap ? running : cap;
+}
+hipError_t launch_intersect_pair_emit(const uint64_t* a, int na, const uint64_t* b, int nb, int cap, uint64_t* out, int* n_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_intersect_pair_emit, dim3(1), dim3(256), 0, st, a, na, b, nb, cap, out, n_out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // marks every read "reroute through the general path" (used when the fused kernel cannot take the batch)
 __global__ __launch_bounds__(256) void k_fill_reroute(int32_t* out4, uint32_t nreads) {

@@ -83,6 +83,7 @@ hipError_t launch_select_bottom(const uint64_t* hashes, uint64_t n, int S, const
                                 int filter_mode, int fmin, int fmax, const DevPolicy& pol, uint32_t* sel_state,
                                 uint32_t* hist, uint64_t* sel_out, hipStream_t st);
 hipError_t launch_intersect_pair(const uint64_t* a, int na, const uint64_t* b, int nb, int* out, hipStream_t st);
+hipError_t launch_intersect_pair_emit(const uint64_t* a, int na, const uint64_t* b, int nb, int cap, uint64_t* out, int* n_out, hipStream_t st);
 hipError_t launch_fill_reroute(int32_t* out4, uint32_t nreads, hipStream_t st);
 hipError_t launch_scatter_rows(const int32_t* rows, const uint32_t* ids, uint32_t m, int32_t* out4, hipStream_t st);
 // mode 0: classify (out4 written); mode 1: count only (counter incremented)

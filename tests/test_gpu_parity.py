@@ -95,6 +95,19 @@ def test_minhashes_and_intersection_mirrors(ctx, orc):
     assert ctx.hash_intersection_size(a, b) == orc.hash_intersection_size(a, b)
     assert ctx.hash_intersection_size(np.array([0, 0, 5, 5, 5], np.uint64), np.array([0, 5, 5], np.uint64)) == 2
     assert ctx.hash_intersection_size(np.zeros(0, np.uint64), b) == 0
+    # the materialising 7-argument form filter's helpers call (equiv.hpp:308,340,364)
+    for a0, al, b0, bl, cap in ((0, 300, 0, 1000, 1000), (7, 200, 100, 600, 1000), (0, 300, 0, 1000, 5), (10, 0, 0, 1000, 10), (0, 300, 1000, 0, 10)):
+        got = ctx.hash_intersection(a, a0, al, b, b0, bl, cap)
+        assert (got == orc.hash_intersection(a, a0, al, b, b0, bl, cap)).all() and len(got) == len(orc.hash_intersection(a, a0, al, b, b0, bl, cap))
+    big_a = np.sort(rng.integers(1, 3000, size=5000, dtype=np.uint64))
+    big_b = np.sort(rng.integers(1, 3000, size=7000, dtype=np.uint64))
+    got = ctx.hash_intersection(big_a, 0, 5000, big_b, 0, 7000, 5000)
+    want = orc.hash_intersection(big_a, 0, 5000, big_b, 0, 7000, 5000)
+    assert len(got) == len(want) == ctx.hash_intersection_size(big_a, big_b) and (got == want).all()
+    z = ctx.hash_intersection(np.array([0, 0, 5, 5, 5], np.uint64), 0, 5, np.array([0, 5, 5], np.uint64), 0, 3, 10)
+    assert list(z) == [5, 5]
+    with pytest.raises(ValueError):
+        ctx.hash_intersection(a, 0, 301, b, 0, 10, 10)
 
 
 def test_counter_mirror(ctx, orc):

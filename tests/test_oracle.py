@@ -79,6 +79,27 @@ def test_minhashes_definition(orc):
     assert len(orc.minhashes(np.zeros(0, np.uint64), 10)) == 0
 
 
+def test_materialised_intersection(orc):
+    """A5f, the 7-argument hash_intersection of filter (equiv.hpp:308,340,364): (array, start, length) x 2, sketch size."""
+    f = orc.hash_intersection
+    assert list(f([9, 1, 2, 3], 1, 3, [2, 3, 4, 7], 0, 3, 10)) == [2, 3]
+    assert list(f([5, 5, 5], 0, 3, [5, 5], 0, 2, 10)) == [5, 5]
+    assert list(f([5, 5, 5], 0, 3, [5, 5], 0, 2, 1)) == [5]            # at most sketch_size matches
+    assert list(f([0, 0, 5], 0, 3, [0, 5], 0, 2, 10)) == [5]
+    assert list(f([1, 2], 0, 0, [1, 2], 0, 2, 10)) == []
+    rng = np.random.default_rng(6)
+    for _ in range(20):
+        a = np.sort(rng.integers(1, 40, size=60, dtype=np.uint64))
+        b = np.sort(rng.integers(1, 40, size=80, dtype=np.uint64))
+        a0, b0 = int(rng.integers(0, 20)), int(rng.integers(0, 20))
+        al, bl = int(rng.integers(0, 40)), int(rng.integers(0, 60))
+        got = f(a, a0, al, b, b0, bl, 1000)
+        sa, sb = a[a0:a0 + al], b[b0:b0 + bl]
+        want = [v for v in np.unique(sa) for _ in range(min((sa == v).sum(), (sb == v).sum()))]
+        assert list(got) == want
+        assert len(got) == orc.hash_intersection_size(sa, sb)
+
+
 def test_intersection_is_multiset_merge(orc):
     f = orc.hash_intersection_size
     assert f([1, 2, 3], [2, 3, 4]) == 2
