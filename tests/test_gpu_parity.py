@@ -886,6 +886,87 @@ def test_randomized_differential(orc, seed):
         c.close()
 
 
+def test_count_pass_is_repeatable_under_load(data_dir):
+    """The -M count pass at the reference's table size (HASHTCounter(200 000 000), rkmh.cpp:739) on 1 M short reads: the
+    memory pipe is full of atomics, which is when the tile prefetch of the fused kernel used to land late (a register
+    copy taken before its `s_waitcnt`: every repetition then produced a different table).  The table must be the same
+    in every repetition and equal the one derived from rk_hash_batch (general hashing kernel, no atomics)."""
+    import torch
+    import rkmh_amd
+    from rkmh_amd import api, synth
+    n, L, slots = 1000000, 100, 200000000
+    dev = torch.device("cuda", 0)
+    c = rkmh_amd.Context(0)
+    try:
+        refs = api.parse_files([os.path.join(data_dir, "all_pave_ref.fa.gz")])
+        rb, ro = refs["bases"], refs["offsets"]
+        c.set_references(rb, ro, [16], 1000)
+        qb, qo = synth.generate_reads_fast(rb, ro, 0, n, read_len=L, threads=8)
+        d_b = torch.from_numpy(qb).to(dev)
+        d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev)
+        table = torch.zeros(slots, dtype=torch.int32, device=dev)
+        cnt = rkmh_amd.Counter(c, slots=slots, device_ptr=table.data_ptr())
+        h, ho = c.hash_batch(_pad(qb), qo, [16])
+        assert len(h) == int(ho[-1]) == n * (L - 16)
+        want = torch.bincount(torch.from_numpy((h % np.uint64(slots)).astype(np.int64)).to(dev), minlength=slots).to(torch.int32)
+        for rep in range(6):
+            table.zero_()
+            torch.cuda.synchronize()
+            c.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt)
+            c.synchronize()
+            ndiff = int((table != want).sum().item())
+            assert ndiff == 0, (rep, ndiff)
+        cnt.destroy()
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("ks,depth,L", [([16], True, 150), ([15], False, 150), ([12, 16], False, 100), ([15], True, 100), ([21], True, 150)])
+def test_every_kernel_form_at_scale(orc, data_dir, ks, depth, L):
+    """300 k reads through the fused kernel's other instantiations -- run-time k, several k, the masked (-M) form with a
+    200 M-slot table -- against the oracle, three launches each.  (Randomized batches are a few hundred reads: too
+    short-lived for timing-dependent faults, which is how the stale tile prefetch of the count pass stayed rare there.)"""
+    import torch
+    import rkmh_amd
+    from rkmh_amd import api, synth
+    n, S, slots = 300000, 1000, 200000000
+    dev = torch.device("cuda", 0)
+    c = rkmh_amd.Context(0)
+    try:
+        refs = api.parse_files([os.path.join(data_dir, "all_pave_ref.fa.gz")])
+        rb, ro = refs["bases"], refs["offsets"]
+        c.set_references(rb, ro, ks, S)
+        sk, ln = c.get_reference_sketches()
+        qb, qo = synth.generate_reads_fast(rb, ro, 0, n, read_len=L, threads=8)
+        pol = orc.default_policy()
+        want = orc.classify_stream(qb, qo, ks, S, sk, ln, pol, threads=orc.max_threads(),
+                                   **({"min_kmer_occ": 2, "counter_slots": slots} if depth else {}))
+        d_b = torch.from_numpy(qb).to(dev)
+        d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev)
+        d_out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        cnt = None
+        if depth:
+            table = torch.zeros(slots, dtype=torch.int32, device=dev)
+            cnt = rkmh_amd.Counter(c, slots=slots, device_ptr=table.data_ptr())
+        for rep in range(3):
+            if depth:
+                table.zero_()
+                torch.cuda.synchronize()
+                c.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt)
+                c.set_depth_filter(cnt, 2)
+            d_out.zero_()
+            c.classify_device_all(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=L)
+            c.synchronize()
+            got = d_out.cpu().numpy()
+            bad = np.nonzero((got != want).any(axis=1))[0]
+            assert len(bad) == 0, (rep, len(bad), bad[:5], got[bad[:5]], want[bad[:5]])
+        if depth:
+            c.set_depth_filter(None, 0)
+            cnt.destroy()
+    finally:
+        c.close()
+
+
 def test_counter_serialisation(ctx, orc, root, data_dir, tmp_path):
     """Depth-map save/load (the -p flag the reference leaves unimplemented): a second run that loads the map prints the same lines."""
     import rkmh_amd
