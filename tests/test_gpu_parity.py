@@ -967,6 +967,59 @@ def test_every_kernel_form_at_scale(orc, data_dir, ks, depth, L):
         c.close()
 
 
+def test_other_paths_at_scale(ctx, orc, pave):
+    """The paths the randomized batches only exercise with a handful of reads, at sizes that keep the GPU busy for
+    milliseconds, every row against the oracle: the host entry point (slot pipeline, pinned staging) on 300 k short
+    reads; 4 000 long reads (3-9 kb: tile hasher, radix pre-selection, sort + intersect); a 700-reference panel
+    (sparse per-read counters) on 40 k reads."""
+    from rkmh_amd import synth
+    _, rb, ro = pave
+    T = orc.max_threads()
+    ctx.set_references(rb, ro, [16], 1000)
+    sk, ln = ctx.get_reference_sketches()
+    n = 300000
+    qb, qo = synth.generate_reads_fast(rb, ro, 5000000, 5000000 + n)
+    want = orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=T)
+    for rep in range(2):
+        got = ctx.classify(_pad(qb), qo)
+        assert (got == want).all(), rep
+    # long reads
+    rng = np.random.default_rng(12)
+    reads = []
+    for i in range(4000):
+        r = int(rng.integers(0, 182))
+        rl = int(ro[r + 1] - ro[r])
+        L = min(int(rng.integers(3000, 9000)), rl)
+        st = int(rng.integers(0, rl - L + 1))
+        x = bytearray(rb[int(ro[r]) + st: int(ro[r]) + st + L])
+        for j in np.nonzero(rng.random(L) < 0.08)[0]:               # nanopore-like error rate
+            x[j] = b"ACGT"[int(rng.integers(0, 4))]
+        reads.append(bytes(x))
+    lb, lo_ = orc.pack(reads)
+    want = orc.classify_stream(lb, lo_, [16], 1000, sk, ln, threads=T)
+    for rep in range(2):
+        got = ctx.classify(_pad(lb), lo_)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, (rep, len(bad), got[bad[:3]], want[bad[:3]])
+    # a large panel: 700 references derived from the bundled ones (mutated copies), 40 k reads
+    prefs = []
+    for i in range(700):
+        r = i % 182
+        x = bytearray(rb[int(ro[r]): int(ro[r + 1])][:3000])
+        for j in np.nonzero(rng.random(len(x)) < 0.03 * (i // 182))[0]:
+            x[j] = b"ACGT"[int(rng.integers(0, 4))]
+        prefs.append(bytes(x))
+    pb, po = orc.pack(prefs)
+    ctx.set_references(_pad(pb), po, [16], 1000)
+    psk, pln = ctx.get_reference_sketches()
+    qb, qo = synth.generate_reads_fast(pb, po, 0, 40000)
+    want = orc.classify_stream(qb, qo, [16], 1000, psk, pln, threads=T)
+    for rep in range(2):
+        got = ctx.classify(_pad(qb), qo)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, (rep, len(bad), got[bad[:3]], want[bad[:3]])
+
+
 def test_counter_serialisation(ctx, orc, root, data_dir, tmp_path):
     """Depth-map save/load (the -p flag the reference leaves unimplemented): a second run that loads the map prints the same lines."""
     import rkmh_amd
