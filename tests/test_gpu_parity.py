@@ -707,6 +707,52 @@ def test_cli_filter(orc, root, data_dir, tmp_path):
     assert r.stdout.decode() == want
 
 
+def test_cli_filter_and_stream_at_scale(orc, root, data_dir, tmp_path):
+    """bin/rkmh filter -M / -I and stream -M on 150 k reads (many pipeline batches, a loaded count pass): stdout
+    identical to the oracle's decisions, twice."""
+    from rkmh_amd import synth, api
+    exe = os.path.join(root, "bin", "rkmh")
+    n = 150000
+    refs = orc.kseq_parse_file(os.path.join(data_dir, "all_pave_ref.fa.gz"))[:60]
+    ref_fa = tmp_path / "refs.fa"
+    ref_fa.write_bytes(b"".join(b">" + r[0] + b"\n" + r[1] + b"\n" for r in refs))
+    R = api.parse_files([str(ref_fa)])
+    qb, qo = synth.generate_reads_fast(R["bases"], R["offsets"], 0, n)
+    names = synth.read_names(0, n)
+    seqs = [bytes(qb[i * 150: (i + 1) * 150]) for i in range(n)]
+    rng = np.random.default_rng(8)
+    for i in range(0, n, 11):
+        seqs[i] = rand_dna(rng, 150)
+    q = b"I" * 150
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(b"".join(b"@" + names[i] + b"\n" + seqs[i] + b"\n+\n" + q + b"\n" for i in range(n)))
+    reads = [(names[i], seqs[i], q) for i in range(n)]
+    for flags, kw in ((["-M", "2", "-N", "3"], dict(min_occ=2, min_matches=3)), (["-I", "2", "-D", "1"], dict(max_samples=2, min_diff=1))):
+        rows, _ = _filter_expect(orc, refs, reads, [16], 1000, min_occ=kw.get("min_occ"), max_samples=kw.get("max_samples"))
+        parts = []
+        for i in range(n):
+            ref, shared, diff_ok, ok = orc.filter_decision(rows[i], kw.get("min_matches", -1), kw.get("min_diff", 0))
+            if ok:
+                parts.append(orc.filter_record(names[i], orc.to_upper(seqs[i]), q))
+        want = b"".join(parts)
+        assert 0 < len(parts) < n
+        for rep in range(2):
+            r = subprocess.run([exe, "filter", "-r", str(ref_fa), "-f", str(fq), "-k", "16", "-s", "1000"] + flags, capture_output=True)
+            assert r.returncode == 0, r.stderr
+            assert r.stdout == want, (flags, rep, len(r.stdout), len(want))
+    # stream -M 2 (200 M-slot table as in the reference): the lines in input order
+    rb, ro = orc.pack([orc.to_upper(x[1]) for x in refs])
+    qb2, qo2 = orc.pack(seqs)
+    sk, ln = orc.sketch_refs(rb, ro, [16], 1000, threads=4)
+    rows = orc.classify_stream(qb2, qo2, [16], 1000, sk, ln, threads=orc.max_threads(), min_kmer_occ=2, counter_slots=200000000)
+    want = "".join(orc.stream_line(refs[int(rw[0])][0].decode(), names[i].decode(), int(rw[1]), int(rw[2]), int(rw[3]), 1000)
+                   for i, rw in enumerate(rows))
+    for rep in range(2):
+        r = subprocess.run([exe, "stream", "-r", str(ref_fa), "-f", str(fq), "-k", "16", "-s", "1000", "-M", "2"], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.decode() == want, (rep, len(r.stdout), len(want))
+
+
 def _call_fixture(orc, data_dir, tmp_path, cov=40, seed=5):
     """C5-like input: reads drawn from HPV16 carrying planted SNPs and 1-bp deletions, 0.5 % substitution noise."""
     rec = orc.kseq_parse_file(os.path.join(data_dir, "hpv_16.fa.gz"))[0]
