@@ -813,6 +813,20 @@ def test_call_matches_oracle(ctx, orc, root, data_dir, tmp_path):
     assert r.returncode == 0 and r.stdout == b""
 
 
+def test_call_at_c5_scale(orc, root, data_dir, tmp_path):
+    """C5: 1000x coverage of HPV16 (52 k reads of 150 bp) with planted SNPs and deletions, -k 12: the VCF
+    rows of bin/rkmh call equal the literal restatement of main_call, twice (the depth map is filled by atomics)."""
+    exe = os.path.join(root, "bin", "rkmh")
+    rec, reads, fa, fq = _call_fixture(orc, data_dir, tmp_path, cov=1000, seed=9)
+    rows = orc.call_rows([rec[0].decode()], [rec[1]], reads, 12, 100)
+    want = orc.CALL_HEADER % str(fa) + "".join(rows)
+    assert len(rows) >= 5 and len(reads) > 50000
+    for rep in range(2):
+        r = subprocess.run([exe, "call", "-r", str(fa), "-f", str(fq), "-k", "12"], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.decode() == want, rep
+
+
 def test_json_sketches_roundtrip(orc, root, data_dir, golden_dir, tmp_path):
     """rkmh sketch -> JSON (schema of dump_hash_json, rkmh.cpp:489-525) -> rkmh stream -R: same lines as sketching anew."""
     import json
