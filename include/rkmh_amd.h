@@ -103,7 +103,7 @@ int rk_hash_intersection(rk_ctx* ctx, const uint64_t* a, int a_start, int a_len,
  * that the table can be all-reduced over RCCL between pass 1 and pass 2 of the -M path). */
 int rk_counter_create(rk_ctx* ctx, uint64_t slots, rk_counter** out);
 int rk_counter_wrap(rk_ctx* ctx, void* d_counts_int32, uint64_t slots, rk_counter** out);
-void rk_counter_destroy(rk_counter* c);
+void rk_counter_destroy(rk_counter* c);   /* allowed after rk_ctx_destroy of its context; every other call is not */
 int rk_counter_clear(rk_counter* c);
 int rk_counter_increment(rk_counter* c, uint64_t key);
 int rk_counter_get(const rk_counter* c, uint64_t key, int32_t* out);

@@ -83,6 +83,7 @@ struct rk_counter {
     int32_t* d;
     uint64_t slots;
     bool owned;
+    int device; // copy of ctx->device: destroying a counter after its context must not touch the freed context
 };
 
 struct Slot { // one half of the double-buffered classify pipeline
@@ -606,17 +607,17 @@ extern "C" int rk_counter_create(rk_ctx* c, uint64_t slots, rk_counter** out) {
     if (e != hipSuccess) return fail(RK_ERR_NOMEM, "hipMalloc(%llu) for counter: %s", (unsigned long long)(slots * 4), hipGetErrorString(e));
     HIPCHK(hipMemsetAsync(d, 0, slots * 4, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
-    *out = new rk_counter{c, (int32_t*)d, slots, true};
+    *out = new rk_counter{c, (int32_t*)d, slots, true, c->device};
     return RK_OK;
 }
 extern "C" int rk_counter_wrap(rk_ctx* c, void* d, uint64_t slots, rk_counter** out) {
     if (!c || !out || !d || slots == 0) return fail(RK_ERR_ARG, "bad arguments");
-    *out = new rk_counter{c, (int32_t*)d, slots, false};
+    *out = new rk_counter{c, (int32_t*)d, slots, false, c->device};
     return RK_OK;
 }
 extern "C" void rk_counter_destroy(rk_counter* k) {
     if (!k) return;
-    if (k->owned) { hipError_t e = hipSetDevice(k->ctx->device); (void)e; e = hipFree(k->d); (void)e; }
+    if (k->owned) { hipError_t e = hipSetDevice(k->device); (void)e; e = hipFree(k->d); (void)e; }
     delete k;
 }
 extern "C" int rk_counter_clear(rk_counter* k) {
