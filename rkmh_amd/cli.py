@@ -1,10 +1,13 @@
-"""`python -m rkmh_amd.cli stream|classify ...` -- the multi-GPU form of the rkmh stream/classify command.
+"""`python -m rkmh_amd.cli stream|classify|filter ...` -- the multi-GPU form of the rkmh stream/classify/filter commands.
 
 Same flags and stdout as main_stream (/root/reference/src/rkmh.cpp:584-989; option table :626-650; line
 format :892).  Launched plainly it uses one GPU; launched under torch.distributed.run it is one process per
 GPU: rank 0 sketches the references and broadcasts the sketches over RCCL, every rank classifies a contiguous
 block of the reads, the -M path all-reduces the k-mer counter between its two passes
-(rkmh.cpp:904-948), and rank 0 prints the lines in input order.  (The single-GPU C++ binary is bin/rkmh.)
+(rkmh.cpp:904-948), and rank 0 prints the lines in input order.  `filter` (main_filter, rkmh.cpp:996-1424, file mode)
+shards the same way: 10 M-slot counters (:1187-1188), the decision of classify_and_count_diff_filter (equiv.hpp:324-353)
+on the gathered rows, passing reads printed by rank 0 in input order.  (The single-GPU C++ binary is bin/rkmh; `filter -i`,
+`call` and `hash` exist only there: a 52 k-read `call` takes 0.2 s on one GPU.)
 """
 import getopt
 import sys
@@ -17,7 +20,13 @@ HELP = """rkmh stream|classify -r <refs.fa> -f <reads.fq> [-k <k>]... [-s <sketc
 """
 
 
-def main_stream(argv):
+def _upper(a):
+    """to_upper as parse_fastas applies it (rkmh.cpp:280): signed chars above 91 lose 32."""
+    x = np.ascontiguousarray(a, dtype=np.uint8).view(np.int8)
+    return np.where(x > 91, x - 32, x).astype(np.int8).view(np.uint8).tobytes()
+
+
+def main_stream(argv, filter_mode=False):
     if len(argv) <= 2:
         sys.stderr.write(HELP)
         return 1
@@ -31,6 +40,7 @@ def main_stream(argv):
         return 1
     refs, reads, ks = [], [], []
     sketch, min_occ, min_matches, min_diff, max_samples = 1000, None, -1, 0, None
+    in_stream = False
     for o, a in opts:
         if o in ("-r", "--reference"): refs.append(a)
         elif o in ("-f", "--fasta"): reads.append(a)
@@ -40,6 +50,7 @@ def main_stream(argv):
         elif o in ("-I", "--max-samples"): max_samples = int(a)
         elif o in ("-N", "--min-matches"): min_matches = int(a)
         elif o in ("-D", "--min-diff"): min_diff = int(a)
+        elif o in ("-i", "--in-stream"): in_stream = True
         elif o in ("-h", "--help", "-d"):
             sys.stderr.write(HELP)
             return 1
@@ -49,6 +60,9 @@ def main_stream(argv):
     if not refs:
         sys.stderr.write("rkmh: at least one -r reference file is required\n")
         return 1
+    if filter_mode and (in_stream or not reads):
+        sys.stderr.write("rkmh_amd.cli filter: file mode only (-f); for -i use bin/rkmh filter\n")
+        return 1
     rank, local, world = rdist.init()
     ctx = api.Context(local)
     R = api.parse_files(refs)
@@ -56,7 +70,11 @@ def main_stream(argv):
         sys.stderr.write("rkmh: no reference sequences found\n")
         return 1
     if rank == 0:
-        ctx.set_references(R["bases"], R["offsets"], ks, sketch, max_samples=max_samples)
+        if filter_mode:   # the sample-count filter applies when max_samples < 100000 (rkmh.cpp:1211); 10 M slots (:1188),
+            ms = max_samples if (max_samples is not None and max_samples < 100000) else None   # filled once per distinct hash
+            ctx.set_references(R["bases"], R["offsets"], ks, sketch, max_samples=ms, counter_slots=10000000, count_distinct=True)
+        else:
+            ctx.set_references(R["bases"], R["offsets"], ks, sketch, max_samples=max_samples)
         sk, ln = ctx.get_reference_sketches()
     else:
         sk = ln = None
@@ -72,7 +90,7 @@ def main_stream(argv):
     counter = None
     if min_occ is not None:
         import torch
-        slots = 200000000  # rkmh.cpp:739
+        slots = 10000000 if filter_mode else 200000000  # rkmh.cpp:1187 / :739
         dev = "cuda:%d" % local
         t = torch.zeros(slots, dtype=torch.int32, device=dev)
         counter = api.Counter(ctx, slots=slots, device_ptr=t.data_ptr())
@@ -84,7 +102,23 @@ def main_stream(argv):
         ctx.set_depth_filter(counter, min_occ)
     rows = ctx.classify(bases, offs)
     allrows = rdist.gather_rows(rows, dst=0)
-    if rank == 0:
+    if rank == 0 and filter_mode:
+        out = sys.stdout.buffer
+        qoff, qbases, quals = Q["offsets"], Q["bases"], Q.get("quals")
+        for i in range(Q["nseq"]):
+            r = allrows[i]
+            # classify_and_count_diff_filter scans from max_shared = prev_best = 0 (the stream scan starts at -1)
+            if int(r[1]) <= 0:
+                shared, diff_ok = 0, 0 > min_diff
+            else:
+                shared, diff_ok = int(r[1]), (int(r[2]) - (1 if int(r[0]) == 0 else 0)) > min_diff
+            if int(r[3]) <= 0 or shared < min_matches or not diff_ok:      # rkmh.cpp:1292-1298
+                continue
+            a, b = int(qoff[i]), int(qoff[i + 1])
+            out.write(b">" + Q["names"][i] + b"\n" + _upper(qbases[a:b]) + b"\n+\n" +
+                      (quals[i] if quals is not None else b"") + b"\n")   # rkmh.cpp:1299-1302
+        out.flush()
+    elif rank == 0:
         out = sys.stdout.buffer
         for i in range(Q["nseq"]):
             r = allrows[i]
@@ -100,9 +134,11 @@ def main_stream(argv):
 
 def main(argv=None):
     argv = list(sys.argv if argv is None else argv)
-    if len(argv) <= 1 or argv[1] not in ("stream", "classify"):
-        sys.stderr.write("Usage: python -m rkmh_amd.cli stream|classify [options]   (hash: use bin/rkmh)\n")
+    if len(argv) <= 1 or argv[1] not in ("stream", "classify", "filter"):
+        sys.stderr.write("Usage: python -m rkmh_amd.cli stream|classify|filter [options]   (call, hash, filter -i: use bin/rkmh)\n")
         return 1
+    if argv[1] == "filter":
+        return main_stream(argv, filter_mode=True)
     if argv[1] == "classify":
         sys.stderr.write("CLASSIFY COMMAND IS TEMPORARILY UNAVAILABLE: TRY rkmh stream INSTEAD.\n")
     return main_stream(argv)

@@ -694,6 +694,11 @@ def test_cli_filter(orc, root, data_dir, tmp_path):
                 npass += 1
         assert 0 < npass < 400, (flags, npass)
         assert r.stdout == want, flags
+        import sys                                    # the torch.distributed form of the command, world size 1
+        r = subprocess.run([sys.executable, "-m", "rkmh_amd.cli", "filter", "-r", str(ref_fa), "-f", str(fq), "-k", "16", "-s", "1000"] + flags,
+                           capture_output=True, cwd=root)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == want, ("python cli", flags)
     # -i: classify what arrives on STDIN (no -f): one line per read
     r = subprocess.run([exe, "filter", "-r", str(ref_fa), "-k", "16", "-N", "4", "-i"], input=fq.read_bytes(), capture_output=True)
     assert r.returncode == 0, r.stderr
