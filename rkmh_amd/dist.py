@@ -64,10 +64,27 @@ def allreduce_counter(t_counts):
 
 
 def gather_rows(rows, dst=0):
-    """Gather per-rank result blocks (numpy [n_i,4] int32) on `dst` in rank order (= global read order)."""
+    """Gather per-rank result blocks (numpy [n_i,4] int32) on `dst` in rank order (= global read order).
+    Tensor collectives only (all_gather of the block sizes, gather of blocks padded to the largest): no pickling of
+    gigabyte-sized results, and the same code under RCCL (device tensors) and gloo (host tensors)."""
+    import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return rows
-    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
-    dist.gather_object(rows, out, dst=dst)
-    return np.concatenate(out, axis=0) if out is not None else None
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
+    t_n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, t_n)
+    sizes = [int(x.item()) for x in sizes]
+    cap = max(max(sizes), 1)
+    buf = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    if rows.shape[0]:
+        buf[: rows.shape[0]] = torch.from_numpy(rows).to(dev)
+    if rank == dst:
+        outs = [torch.empty_like(buf) for _ in range(world)]
+        dist.gather(buf, outs, dst=dst)
+        return np.concatenate([outs[r][: sizes[r]].cpu().numpy() for r in range(world)], axis=0)
+    dist.gather(buf, None, dst=dst)
+    return None
