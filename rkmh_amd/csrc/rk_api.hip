@@ -104,7 +104,7 @@ struct rk_ctx {
     KsArr ks{};
     std::vector<uint64_t> h_sk;
     std::vector<int32_t> h_lens;
-    DevBuf d_fpb, d_base, d_kv, d_post;
+    DevBuf d_fpb, d_base, d_kv, d_post, d_pre;
     RefIndex ix{};
     bool have_refs = false;
     double density = 1.0; // fraction of a reference's k-mers that its sketch keeps (largest over references)
@@ -147,7 +147,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
-    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
@@ -800,6 +800,23 @@ static int build_index(rk_ctx* c) {
     c->ix.fpb = c->d_fpb.as<uint4>(); c->ix.base = c->d_base.as<uint32_t>(); c->ix.kv = c->d_kv.as<uint4>();
     c->ix.post = c->d_post.as<uint32_t>();
     c->ix.bmask = bmask; c->ix.bshift = bshift; c->ix.nref = R;
+    // First-level filter in front of the bucket table (RKMH_PREFILTER=0 turns it off for A/B runs): RKMH_PRE_BITS bits per
+    // key (default 16), two bits set per key, at most RKMH_PRE_MAXKB (default 2048) KB so that it stays in an XCD's L2.
+    c->ix.pre = nullptr; c->ix.pmask = 0;
+    int pre_mode = 1;
+    if (const char* e = getenv("RKMH_PREFILTER")) pre_mode = atoi(e);
+    if (pre_mode > 0) {
+        size_t bits_per_key = 16, max_words = (size_t)2048 * 256;
+        if (const char* e = getenv("RKMH_PRE_BITS")) { long v = atol(e); if (v >= 2 && v <= 256) bits_per_key = (size_t)v; }
+        if (const char* e = getenv("RKMH_PRE_MAXKB")) { long v = atol(e); if (v >= 16 && v <= (1 << 20)) max_words = (size_t)v * 256; }
+        uint32_t pwords = 1u << 12;
+        while ((size_t)pwords * 32 < distinct * bits_per_key && (size_t)pwords * 2 <= max_words) pwords <<= 1;
+        std::vector<uint32_t> pre(pwords, 0);
+        for (size_t q = 0; q < pairs.size(); ++q) pre[index_pre_word(pairs[q].h, pwords - 1)] |= index_pre_bits(pairs[q].h);
+        RKCHK(c->d_pre.reserve((size_t)pwords * 4));
+        HIPCHK(hipMemcpy(c->d_pre.p, pre.data(), (size_t)pwords * 4, hipMemcpyHostToDevice));
+        c->ix.pre = c->d_pre.as<uint32_t>(); c->ix.pmask = pwords - 1;
+    }
     // a full bottom-S sketch of uniform hashes keeps the fraction (largest kept hash / 2^64) of the k-mers
     c->density = 0.0;
     for (int r = 0; r < R; ++r) {

@@ -138,13 +138,21 @@ __device__ __forceinline__ void bucket_load_async(const uint4* base, uint32_t by
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f) : "v"(byte_off), "s"(base) : "memory");
 }
 __device__ __forceinline__ void bucket_wait(u32x4& f) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : : "memory"); }
+// the same for one word of the first-level filter (RefIndex::pre)
+__device__ __forceinline__ void word_load_async(const uint32_t* base, uint32_t byte_off, uint32_t& f) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(f) : "v"(byte_off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void word_wait(uint32_t& f) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : : "memory"); }
 
 // MODE 0: classify; MODE 1: count pass of -M (rkmh.cpp:904-910); MODE 2: classify with the -M mask (rkmh.cpp:916)
-template <int KT, int MODE, int FOLD, int PF>
+// MODE_ 3 / 4: MODE 0 / 2 with the first-level filter of large panels (RefIndex::pre) in front of the bucket table
+template <int KT, int MODE_, int FOLD, int PF>
 __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
                                                            uint32_t nreads, KsArr ks, int S, RefIndex ix, int32_t* counter,
                                                            uint64_t slots, int min_occ, int32_t* out4, DevPolicy pol, TileGeom geo) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr bool PRE = MODE_ >= 3;
+    constexpr int MODE = MODE_ == 3 ? 0 : (MODE_ == 4 ? 2 : MODE_);
     const int T = geo.T;
     const uint32_t QCAP = (uint32_t)geo.qcap;
     const uint32_t DS = (uint32_t)geo.dset;
@@ -479,6 +487,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
             if (compact)
                 while (cwl >= nw_u) { cwl -= nw_u; ct_ += 1; cp += dtail; } // reads with fewer than 64 windows
             u32x4 fb = {0u, 0u, 0u, 0u}; // bucket fetched for the previous position (lookup in flight)
+            uint32_t fw = 0;             // ... or its word of the first-level filter (large panels)
             uint64_t hp = 0;
             uint32_t tp = 0; // read of the previous position
             uint32_t it = 0;
@@ -554,6 +563,21 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                     }
                     if (MODE == 1) continue;
                     // examine the lookup issued one step ago: fingerprint matches / full buckets are queued
+                    if constexpr (PRE) { // large panel: the filter word decides what the drain will look up in the table
+                        word_wait(fw);
+                        const uint32_t bm = index_pre_bits(hp);
+                        const bool cand = (fw & bm) == bm;
+                        const uint64_t m = __ballot(cand);
+                        if (cand) {
+                            const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            qe[q] = make_uint4((uint32_t)hp, (uint32_t)(hp >> 32), tp, 0u);
+                        }
+                        qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
+                        word_load_async(ix.pre, index_pre_word(h, ix.pmask) << 2, fw);
+                        hp = h;
+                        tp = t;
+                        continue;
+                    }
                     bucket_wait(fb);
                     if (!RK_DBG(1)) {
                         const uint32_t fp = index_fp(hp);
@@ -754,9 +778,11 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     } while (0)
 #define RK_LAUNCH_M(KT, FOLD)                                                                                        \
     do {                                                                                                             \
-        if (kmode == 0) RK_LAUNCH(KT, 0, FOLD);                                                                      \
-        else if (kmode == 1) RK_LAUNCH(KT, 1, FOLD);                                                                 \
-        else RK_LAUNCH(KT, 2, FOLD);                                                                                 \
+        if (kmode == 1) RK_LAUNCH(KT, 1, FOLD);                                                                      \
+        else if (kmode == 0 && !ix.pre) RK_LAUNCH(KT, 0, FOLD);                                                      \
+        else if (kmode == 0) RK_LAUNCH(KT, 3, FOLD);                                                                 \
+        else if (!ix.pre) RK_LAUNCH(KT, 2, FOLD);                                                                    \
+        else RK_LAUNCH(KT, 4, FOLD);                                                                                 \
     } while (0)
     // single k of 12, 20 (the reference's other documented settings), 21 or 31: window length known at compile time, runtime fold
     if (ks.n == 1 && ks.k[0] == 12) RK_LAUNCH_M(12, -1);

@@ -302,7 +302,19 @@ struct RefIndex {
     uint32_t bmask;   // buckets - 1
     uint32_t bshift;  // 32 - log2(buckets)
     int32_t nref;
+    // Optional first-level filter for large panels (nullptr = none): one bit pair per key in a <= 2 MB bit array that stays
+    // in an XCD's L2 when the bucket table (16 B per 2.5 keys) no longer does.  The hashing loop then tests the filter word
+    // and only windows that pass go to the queue; the drain looks them up in the table as it always did.
+    const uint32_t* pre;
+    uint32_t pmask;   // filter words - 1
 };
+// filter word and bit pair of a hash: the word from the low bits of the high hash word (like the bucket), the two bits
+// from bits 14..23 of the low word (bits 0..13 are the fingerprint)
+__host__ __device__ __forceinline__ uint32_t index_pre_word(uint64_t h, uint32_t pmask) { return (uint32_t)(h >> 32) & pmask; }
+__host__ __device__ __forceinline__ uint32_t index_pre_bits(uint64_t h) {
+    const uint32_t lo = (uint32_t)h;
+    return (1u << ((lo >> 14) & 31u)) | (1u << ((lo >> 19) & 31u));
+}
 constexpr uint32_t IDX_NOT_FOUND = 0xffffffffu;
 constexpr int IDX_SLOTS = 8;
 

@@ -111,19 +111,15 @@ def analyse(name, body):
     return res
 
 
-def dont_care_high_half(ins, succ, i, inflight):
-    """hipcc computes a 32-bit multiply-add with `v_mad_u64_u32 v[d:d+1], a, b, v[x:x+1]` and leaves the addend's high half
-    x+1 undefined -- whichever register follows x, possibly one in flight.  Harmless when the result's high half d+1 is
-    dead: accepted if d+1 is overwritten before it is read, within the straight-line code that follows."""
-    c = ins[i][0]
-    m = re.match(r"v_mad_u64_u32 v\[(\d+):(\d+)\], (.*), v\[(\d+):(\d+)\]$", c)
-    if not m:
+MAD = re.compile(r"v_mad_u64_u32 v\[(\d+):(\d+)\], (.*), v\[(\d+):(\d+)\]$")
+
+
+def value_is_dead(ins, succ, i, reg, depth=0):
+    """True when the value instruction i leaves in VGPR `reg` is never used: on every path it is overwritten before it
+    is read -- where a read as the (undefined) high half of another v_mad_u64_u32 addend only passes the question on to
+    that instruction's own high result."""
+    if depth > 6:
         return False
-    d_hi, x_hi = int(m.group(2)), int(m.group(5))
-    others = regs_of(m.group(3)) | {int(m.group(1)), d_hi, int(m.group(4))}
-    if (set(inflight) & regs_of(c)) != {x_hi} or x_hi in others:
-        return False
-    # is d_hi read before it is written on any path from here?
     seen, stack = set(), list(succ[i])
     while stack:
         j = stack.pop()
@@ -140,12 +136,33 @@ def dont_care_high_half(ins, succ, i, inflight):
             srcs = regs_of(", ".join(ops[1:])) if writes else regs_of(parts[1])
             if op.startswith("v_cmp") or op.startswith("v_readlane") or op.startswith("v_readfirstlane"):
                 dest, srcs = set(), regs_of(parts[1])
-            if d_hi in srcs:
-                return False
-            if d_hi in dest:
+            if reg in srcs:
+                m = MAD.match(cj)
+                if m and int(m.group(5)) == reg and reg not in (regs_of(m.group(3)) | {int(m.group(4))}):
+                    if not value_is_dead(ins, succ, j, int(m.group(2)), depth + 1):
+                        return False
+                    if reg in dest:
+                        continue
+                else:
+                    return False
+            if reg in dest:
                 continue
         stack.extend(succ[j])
     return True
+
+
+def dont_care_high_half(ins, succ, i, inflight):
+    """hipcc computes a 32-bit multiply-add with `v_mad_u64_u32 v[d:d+1], a, b, v[x:x+1]` and leaves the addend's high half
+    x+1 undefined -- whichever register follows x, possibly one in flight.  Harmless when the result's high half d+1 is
+    dead (never read before it is overwritten, on any path)."""
+    m = MAD.match(ins[i][0])
+    if not m:
+        return False
+    d_hi, x_hi = int(m.group(2)), int(m.group(5))
+    others = regs_of(m.group(3)) | {int(m.group(1)), d_hi, int(m.group(4))}
+    if (set(inflight) & regs_of(ins[i][0])) != {x_hi} or x_hi in others:
+        return False
+    return value_is_dead(ins, succ, i, d_hi)
 
 
 def witness(ins, succ, lab_of, hit, regs):
