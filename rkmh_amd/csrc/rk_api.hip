@@ -800,13 +800,16 @@ static int build_index(rk_ctx* c) {
     c->ix.fpb = c->d_fpb.as<uint4>(); c->ix.base = c->d_base.as<uint32_t>(); c->ix.kv = c->d_kv.as<uint4>();
     c->ix.post = c->d_post.as<uint32_t>();
     c->ix.bmask = bmask; c->ix.bshift = bshift; c->ix.nref = R;
-    // First-level filter in front of the bucket table (RKMH_PREFILTER=0 turns it off for A/B runs): RKMH_PRE_BITS bits per
-    // key (default 16), two bits set per key, at most RKMH_PRE_MAXKB (default 2048) KB so that it stays in an XCD's L2.
+    // First-level filter in front of the bucket table (RKMH_PREFILTER=0 turns it off for A/B runs): two bits set per key,
+    // 32 bits per key where that fits in 1 MB -- measured at C2 (163 k keys): 256 KB 0.976 ms, 512 KB 0.959, 1 MB 0.953,
+    // 2 MB 0.997 (the filter then crowds the reads and the table out of the 4 MB L2); at 10^6 keys 1 MB beats 2 MB (1.07 vs
+    // 1.12 ms) although one window in twenty then passes by chance; only beyond 2 * 10^6 keys does 2 MB win (4 * 10^6
+    // keys: 1 MB 2.28 ms, 2 MB 1.77, 4 MB 1.99).  RKMH_PRE_BITS / RKMH_PRE_MAXKB override both numbers.
     c->ix.pre = nullptr; c->ix.pmask = 0;
     int pre_mode = 1;
     if (const char* e = getenv("RKMH_PREFILTER")) pre_mode = atoi(e);
     if (pre_mode > 0) {
-        size_t bits_per_key = 16, max_words = (size_t)2048 * 256;
+        size_t bits_per_key = 32, max_words = (size_t)(distinct > 2000000 ? 2048 : 1024) * 256;
         if (const char* e = getenv("RKMH_PRE_BITS")) { long v = atol(e); if (v >= 2 && v <= 256) bits_per_key = (size_t)v; }
         if (const char* e = getenv("RKMH_PRE_MAXKB")) { long v = atol(e); if (v >= 16 && v <= (1 << 20)) max_words = (size_t)v * 256; }
         uint32_t pwords = 1u << 12;

@@ -758,6 +758,11 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     if (const char* e = getenv("RKMH_TILE_XCD")) geo.xcd = atoi(e) != 0;
     const bool k16 = (ks.n == 1 && ks.k[0] == 16);
     const int kmode = mode == 1 ? 1 : (counter ? 2 : 0);
+    // The masked (-M) form waits for a random read of the 800 MB counter table in every step: it is bound by memory requests,
+    // not by VALU issue, and the filter word is one more request per window (C2: 2.86 ms without, 3.10 ms with).  It pays
+    // only once the bucket table itself has left L2.
+    bool pre_masked = ((size_t)ix.bmask + 1) * 16 > ((size_t)3 << 20);
+    if (const char* e = getenv("RKMH_PRE_MASKED")) pre_masked = atoi(e) != 0; // tests force either form
 #define RK_LAUNCH_P(KT, MODE, FOLD, PF)                                                                                    \
     do {                                                                                                             \
         if (lds > 64 * 1024) {                                                                                       \
@@ -781,7 +786,7 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
         if (kmode == 1) RK_LAUNCH(KT, 1, FOLD);                                                                      \
         else if (kmode == 0 && !ix.pre) RK_LAUNCH(KT, 0, FOLD);                                                      \
         else if (kmode == 0) RK_LAUNCH(KT, 3, FOLD);                                                                 \
-        else if (!ix.pre) RK_LAUNCH(KT, 2, FOLD);                                                                    \
+        else if (!ix.pre || !pre_masked) RK_LAUNCH(KT, 2, FOLD);                                                     \
         else RK_LAUNCH(KT, 4, FOLD);                                                                                 \
     } while (0)
     // single k of 12, 20 (the reference's other documented settings), 21 or 31: window length known at compile time, runtime fold

@@ -1083,6 +1083,23 @@ def test_other_paths_at_scale(ctx, orc, pave):
         got = ctx.classify(_pad(qb), qo)
         bad = np.nonzero((got != want).any(axis=1))[0]
         assert len(bad) == 0, (rep, len(bad), got[bad[:3]], want[bad[:3]])
+    # the same panel with -M 2, through both masked kernel forms (with and without the first-level filter)
+    import rkmh_amd
+    slots = 10000000
+    want = orc.classify_stream(qb, qo, [16], 1000, psk, pln, threads=T, min_kmer_occ=2, counter_slots=slots)
+    cnt = rkmh_amd.Counter(ctx, slots=slots)
+    ctx.count_batch(_pad(qb), qo, cnt)
+    ctx.set_depth_filter(cnt, 2)
+    try:
+        for force in ("1", "0"):
+            os.environ["RKMH_PRE_MASKED"] = force
+            got = ctx.classify(_pad(qb), qo)
+            bad = np.nonzero((got != want).any(axis=1))[0]
+            assert len(bad) == 0, (force, len(bad), got[bad[:3]], want[bad[:3]])
+    finally:
+        os.environ.pop("RKMH_PRE_MASKED", None)
+        ctx.set_depth_filter(None, 0)
+        cnt.destroy()
 
 
 def test_counter_serialisation(ctx, orc, root, data_dir, tmp_path):
