@@ -24,7 +24,16 @@ struct DevPolicy {
 constexpr uint64_t MM_C1 = 0x87c37b91114253d5ULL;
 constexpr uint64_t MM_C2 = 0x4cf5ad432745937fULL;
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+// 64-bit rotate by a compile-time amount as two v_alignbit_b32 (hipcc builds most of these rotates from 64-bit shifts and
+// ORs, three to four instructions each); r = 33 is the half swap (free: register naming) followed by a rotate by 1
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (r >= 32) { const uint32_t t = lo; lo = hi; hi = t; r -= 32; }
+    if (r == 0) return ((uint64_t)hi << 32) | lo;
+    const uint32_t nh = __builtin_amdgcn_alignbit(hi, lo, 32 - r);
+    const uint32_t nl = __builtin_amdgcn_alignbit(lo, hi, 32 - r);
+    return ((uint64_t)nh << 32) | nl;
+}
 __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdULL;
     k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL;
