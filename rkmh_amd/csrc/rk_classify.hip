@@ -545,9 +545,15 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                                 if constexpr (KT == 0) { // run-time k: both strands through one block loop, uniform tail masks
                                     h = canonical_rt(s.fwd, s.fbase + p, s.rc, B - (uint32_t)k - p, k, tmasks, pol.seed, pol.fold);
                                 } else {
+                                    if constexpr (FOLD == 0) { // the half swap of fold 0 happens inside the minimum
+                                        const uint64_t f = murmur_window<KT, 3>(s.fwd, s.fbase + p, k, pol.seed, 0);
+                                        const uint64_t r = murmur_window<KT, 3>(s.rc, B - (uint32_t)k - p, k, pol.seed, 0);
+                                        h = min_swapped(f, r);
+                                    } else {
                                     const uint64_t f = murmur_window<KT, FOLD>(s.fwd, s.fbase + p, k, pol.seed, pol.fold);
                                     const uint64_t r = murmur_window<KT, FOLD>(s.rc, B - (uint32_t)k - p, k, pol.seed, pol.fold);
                                     h = f < r ? f : r;
+                                    }
                                 }
                             }
                             account(h, t);

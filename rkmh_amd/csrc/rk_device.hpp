@@ -26,13 +26,21 @@ constexpr uint64_t MM_C2 = 0x4cf5ad432745937fULL;
 
 // 64-bit rotate by a compile-time amount as two v_alignbit_b32 (hipcc builds most of these rotates from 64-bit shifts and
 // ORs, three to four instructions each); r = 33 is the half swap (free: register naming) followed by a rotate by 1
+// The halves are joined by a vector bitcast, not by (hi << 32) | lo: hipcc turns that OR into a 64-bit ADD of {lo, 0} and
+// {0, hi}, fuses it with the addition that follows the rotate, and pays a v_mov and an extra v_lshl_add_u64 for it.
+typedef uint32_t rk_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint64_t join64(uint32_t lo, uint32_t hi) {
+    const rk_u32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint64_t, v);
+}
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) {
-    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const rk_u32x2 v = __builtin_bit_cast(rk_u32x2, x);
+    uint32_t lo = v.x, hi = v.y;
     if (r >= 32) { const uint32_t t = lo; lo = hi; hi = t; r -= 32; }
-    if (r == 0) return ((uint64_t)hi << 32) | lo;
+    if (r == 0) return join64(lo, hi);
     const uint32_t nh = __builtin_amdgcn_alignbit(hi, lo, 32 - r);
     const uint32_t nl = __builtin_amdgcn_alignbit(lo, hi, 32 - r);
-    return ((uint64_t)nh << 32) | nl;
+    return join64(nl, nh);
 }
 __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdULL;
@@ -51,6 +59,15 @@ __device__ __forceinline__ void mm_block(uint64_t& h1, uint64_t& h2, uint64_t k1
     k2 *= MM_C2; k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2;
     h2 = rotl64(h2, 31); h2 += h1; h2 = mul5(h2) + 0x38495ab5;
 }
+// First block of a hash: h1 = h2 = seed are wave-uniform, so "h1 += h2" folds into the constant of the multiply-add that
+// follows ((h1 + seed) * 5 + c = h1 * 5 + (5 * seed + c)): one 64-bit add less per strand.
+__device__ __forceinline__ void mm_block_first(uint64_t& h1, uint64_t& h2, uint32_t seed, uint64_t k1, uint64_t k2) {
+    k1 *= MM_C1; k1 = rotl64(k1, 31); k1 *= MM_C2;
+    h1 = rotl64(k1 ^ (uint64_t)seed, 27);
+    h1 = mul5(h1) + ((uint64_t)seed * 5u + 0x52dce729u);
+    k2 *= MM_C2; k2 = rotl64(k2, 33); k2 *= MM_C1;
+    h2 = rotl64(k2 ^ (uint64_t)seed, 31); h2 += h1; h2 = mul5(h2) + 0x38495ab5;
+}
 // finalisation + the 128->64 fold (policy U1).  FOLD >= 0 fixes the fold at compile time (no branches
 // between the forward and reverse-complement hash chains, so the scheduler can interleave them).
 template <int FOLD = -1>
@@ -60,12 +77,22 @@ __device__ __forceinline__ uint64_t mm_finish(uint64_t h1, uint64_t h2, uint32_t
     h1 += h2; h2 += h1;
     h1 = fmix64(h1); h2 = fmix64(h2);
     h1 += h2;
+    if (FOLD == 3) return h1;                        // fold 0 with the half swap left to min_swapped()
     if (fold == 0) return (h1 << 32) | (h1 >> 32);   // ((u64)w[0] << 32) | w[1]
     if (fold == 1) return h1;                        // *(u64*)w
     h2 += h1;                                        // ((u64)w[2] << 32) | w[1]
     return (h2 << 32) | (h1 >> 32);
 }
 
+
+// Canonical hash under fold 0 (the half-swapped h1) from the two UNSWAPPED h1 values: the smaller of swap(f), swap(r).
+// Comparing and selecting the halves directly saves the two v_mov per strand that materialising swap() into an aligned
+// register pair for v_cmp_lt_u64 costs.
+__device__ __forceinline__ uint64_t min_swapped(uint64_t f, uint64_t r) {
+    const rk_u32x2 a = __builtin_bit_cast(rk_u32x2, f), b = __builtin_bit_cast(rk_u32x2, r);
+    const bool lt = a.x < b.x || (a.x == b.x && a.y < b.y); // .x (low half of h1) is the high half of the folded value
+    return join64(lt ? a.y : b.y, lt ? a.x : b.x);
+}
 
 // MurmurHash3_x64_128 of the k bytes starting at byte offset `a` of the LDS dword array w32.
 // The array must be readable for 16 bytes past the window (buffers are padded).
@@ -94,7 +121,8 @@ __device__ __forceinline__ uint64_t murmur_window(const uint32_t* w32, uint32_t 
     const int nblocks = k >> 4;
     for (int b = 0; b < nblocks; ++b) {
         const rk_u32x4 w = lds_load16_unaligned(w32, a);
-        mm_block(h1, h2, (uint64_t)w.x | ((uint64_t)w.y << 32), (uint64_t)w.z | ((uint64_t)w.w << 32));
+        if (b == 0) mm_block_first(h1, h2, seed, join64(w.x, w.y), join64(w.z, w.w));
+        else mm_block(h1, h2, join64(w.x, w.y), join64(w.z, w.w));
         a += 16;
     }
     const int rem = k & 15;
