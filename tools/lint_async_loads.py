@@ -112,6 +112,19 @@ def analyse(name, body):
 
 
 MAD = re.compile(r"v_mad_u64_u32 v\[(\d+):(\d+)\], (.*), v\[(\d+):(\d+)\]$")
+MOV64 = re.compile(r"v_mov_b64_e32 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\]$")
+
+
+def high_half_passthrough(c):
+    """(dest high register, source high register, other registers) of an instruction that only forwards the high half of a
+    64-bit source into the high half of its result: v_mad_u64_u32's addend, v_mov_b64's source."""
+    m = MAD.match(c)
+    if m:
+        return int(m.group(2)), int(m.group(5)), regs_of(m.group(3)) | {int(m.group(1)), int(m.group(2)), int(m.group(4))}
+    m = MOV64.match(c)
+    if m:
+        return int(m.group(2)), int(m.group(4)), {int(m.group(1)), int(m.group(2)), int(m.group(3))}
+    return None
 
 
 def value_is_dead(ins, succ, i, reg, depth=0):
@@ -137,9 +150,9 @@ def value_is_dead(ins, succ, i, reg, depth=0):
             if op.startswith("v_cmp") or op.startswith("v_readlane") or op.startswith("v_readfirstlane"):
                 dest, srcs = set(), regs_of(parts[1])
             if reg in srcs:
-                m = MAD.match(cj)
-                if m and int(m.group(5)) == reg and reg not in (regs_of(m.group(3)) | {int(m.group(4))}):
-                    if not value_is_dead(ins, succ, j, int(m.group(2)), depth + 1):
+                hp = high_half_passthrough(cj)
+                if hp and hp[1] == reg and reg not in (hp[2] - {hp[0]}):
+                    if not value_is_dead(ins, succ, j, hp[0], depth + 1):
                         return False
                     if reg in dest:
                         continue
@@ -155,11 +168,10 @@ def dont_care_high_half(ins, succ, i, inflight):
     """hipcc computes a 32-bit multiply-add with `v_mad_u64_u32 v[d:d+1], a, b, v[x:x+1]` and leaves the addend's high half
     x+1 undefined -- whichever register follows x, possibly one in flight.  Harmless when the result's high half d+1 is
     dead (never read before it is overwritten, on any path)."""
-    m = MAD.match(ins[i][0])
-    if not m:
+    hp = high_half_passthrough(ins[i][0])
+    if not hp:
         return False
-    d_hi, x_hi = int(m.group(2)), int(m.group(5))
-    others = regs_of(m.group(3)) | {int(m.group(1)), d_hi, int(m.group(4))}
+    d_hi, x_hi, others = hp
     if (set(inflight) & regs_of(ins[i][0])) != {x_hi} or x_hi in others:
         return False
     return value_is_dead(ins, succ, i, d_hi)
