@@ -9,8 +9,9 @@
 //
 // Work decomposition: ONE WAVE = one tile of T consecutive reads (T = 4 for 150 bp reads); a workgroup is a
 // single wave, so nothing ever waits at a workgroup barrier and the 6 waves a SIMD holds drift apart into
-// different phases -- latency-bound phases of one wave hide under the hashing of the others.  The kernel is
-// bound by VALU issue (PMC: > 90 % of the issue slots), so every design decision below is about wave-level
+// different phases -- latency-bound phases of one wave hide under the hashing of the others (measured: workgroups
+// that all start together and stay in step are 17 % slower).  The kernel is bound by VALU issue (PMC: 92 % of the
+// issue slots, next to an LDS pipeline that is 62 % busy), so every design decision below is about wave-level
 // instruction count; occupancy only has to stay at 6 waves/SIMD (registers <= 80, LDS <= 6.5 KB per tile).
 //   phase 0  the tile's bases are ONE contiguous byte range of the batch.  They (and the tile's offsets)
 //            were prefetched into registers while the previous tile was hashed; they are written to LDS as
@@ -19,11 +20,14 @@
 //            validity bitmap and the bitmap of byte positions that start no hashable window.
 //   phase 1  the tile's windows are flattened over the 64 lanes (division-free running mapping window -> read,
 //            position); the hot loop body is one basic block: two UNALIGNED 16-byte LDS reads (the two strands'
-//            windows, no alignment funnel), both murmur3 chains, one 16-byte bucket load (saddr form) from the
-//            reference index whose latency hides behind the NEXT window's hashing.  Fingerprint matches (about
-//            1 window in 8) go to a wave-private LDS queue of 16-byte entries (ballot + mbcnt, no atomics).
+//            windows, no alignment funnel), both murmur3 chains, one 4-byte load (saddr form) of the window's word
+//            of the first-level filter -- an L2-resident bit array in which every sketch hash sets two bits --
+//            whose latency hides behind the NEXT window's hashing.  Windows that pass (every hit, about 1 window
+//            in 8, plus a fraction of a percent) go to a wave-private LDS queue of 16-byte entries (ballot +
+//            mbcnt, no atomics).  (RKMH_PREFILTER=0, and the masked -M form while the bucket table fits L2, load and
+//            test the 16-byte fingerprint bucket of the reference index instead.)
 //   drain    when the queue holds more than a wave's worth (and at the end) it is emptied with every lane
-//            busy: full-key verification, exact occurrence rank of the sketch hash within the read (LDS
+//            busy: lookup in the bucket table (fingerprints, then the 64-bit key: exactness comes from here), exact occurrence rank of the sketch hash within the read (LDS
 //            multiset: the merge of rkmh.cpp:869 counts min(multiplicities)), postings added to per-read
 //            packed LDS counters (8 bits when no read has more than 255 windows, else 16); since counts only grow, an LDS atomicMax of (count, -ref) per increment
 //            leaves (max_shared, first max_id) behind without any scan.
