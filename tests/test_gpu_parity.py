@@ -951,7 +951,8 @@ def test_randomized_differential(orc, seed):
         c.close()
 
 
-def test_count_pass_is_repeatable_under_load(data_dir):
+@pytest.mark.parametrize("ragged", [False, True])
+def test_count_pass_is_repeatable_under_load(data_dir, ragged):
     """The -M count pass at the reference's table size (HASHTCounter(200 000 000), rkmh.cpp:739) on 1 M short reads: the
     memory pipe is full of atomics, which is when the tile prefetch of the fused kernel used to land late (a register
     copy taken before its `s_waitcnt`: every repetition then produced a different table).  The table must be the same
@@ -967,12 +968,14 @@ def test_count_pass_is_repeatable_under_load(data_dir):
         rb, ro = refs["bases"], refs["offsets"]
         c.set_references(rb, ro, [16], 1000)
         qb, qo = synth.generate_reads_fast(rb, ro, 0, n, read_len=L, threads=8)
-        d_b = torch.from_numpy(qb).to(dev)
+        if ragged:   # unequal lengths (20..100, some shorter than k), lower case and N runs: the bitmap-walking form of the pass
+            qb, qo = _ragged(qb, n, L, seed=3)
+        d_b = torch.from_numpy(_pad(qb)).to(dev)
         d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev)
         table = torch.zeros(slots, dtype=torch.int32, device=dev)
         cnt = rkmh_amd.Counter(c, slots=slots, device_ptr=table.data_ptr())
         h, ho = c.hash_batch(_pad(qb), qo, [16])
-        assert len(h) == int(ho[-1]) == n * (L - 16)
+        assert len(h) == int(ho[-1]) and (ragged or len(h) == n * (L - 16))
         want = torch.bincount(torch.from_numpy((h % np.uint64(slots)).astype(np.int64)).to(dev), minlength=slots).to(torch.int32)
         for rep in range(6):
             table.zero_()
@@ -986,7 +989,24 @@ def test_count_pass_is_repeatable_under_load(data_dir):
         c.close()
 
 
-@pytest.mark.parametrize("ks,depth,L", [([16], True, 150), ([15], False, 150), ([12, 16], False, 100), ([15], True, 100), ([21], True, 150)])
+def _ragged(qb, n, L, seed, lo=20):
+    """Cuts equal-length synthetic reads to unequal lengths (lo..L, 1 % shorter than any k), adds N runs and lower case."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(lo, L + 1, size=n)
+    short = rng.random(n) < 0.01
+    lens[short] = rng.integers(0, 12, size=int(short.sum()))
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    idx = np.repeat(np.arange(n, dtype=np.int64) * L - offs[:-1], lens) + np.arange(offs[-1], dtype=np.int64)
+    b = qb[idx].copy()
+    b[rng.random(len(b)) < 0.002] = ord("N")
+    low = rng.random(len(b)) < 0.01
+    b[low] = b[low] | 0x20
+    return b, offs.astype(np.uint64)
+
+
+@pytest.mark.parametrize("ks,depth,L", [([16], True, 150), ([15], False, 150), ([12, 16], False, 100), ([15], True, 100), ([21], True, 150),
+                                        ([16], False, -150), ([16], True, -150), ([20], True, -100)])
 def test_every_kernel_form_at_scale(orc, data_dir, ks, depth, L):
     """300 k reads through the fused kernel's other instantiations -- run-time k, several k, the masked (-M) form with a
     200 M-slot table -- against the oracle, three launches each.  (Randomized batches are a few hundred reads: too
@@ -1002,7 +1022,12 @@ def test_every_kernel_form_at_scale(orc, data_dir, ks, depth, L):
         rb, ro = refs["bases"], refs["offsets"]
         c.set_references(rb, ro, ks, S)
         sk, ln = c.get_reference_sketches()
+        ragged = L < 0                       # negative L: reads of unequal length up to |L| (tiles walk byte positions)
+        L = abs(L)
         qb, qo = synth.generate_reads_fast(rb, ro, 0, n, read_len=L, threads=8)
+        if ragged:
+            qb, qo = _ragged(qb, n, L, seed=L + len(ks), lo=60)
+            qb = _pad(qb)
         pol = orc.default_policy()
         want = orc.classify_stream(qb, qo, ks, S, sk, ln, pol, threads=orc.max_threads(),
                                    **({"min_kmer_occ": 2, "counter_slots": slots} if depth else {}))
