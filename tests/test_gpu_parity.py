@@ -1091,6 +1091,21 @@ def test_other_paths_at_scale(ctx, orc, pave):
         got = ctx.classify(_pad(lb), lo_)
         bad = np.nonzero((got != want).any(axis=1))[0]
         assert len(bad) == 0, (rep, len(bad), got[bad[:3]], want[bad[:3]])
+    # the same long reads with -M 2 (count pass and mask on the general kernels)
+    import rkmh_amd
+    lslots = 10000000
+    lwant = orc.classify_stream(lb, lo_, [16], 1000, sk, ln, threads=T, min_kmer_occ=2, counter_slots=lslots)
+    lcnt = rkmh_amd.Counter(ctx, slots=lslots)
+    try:
+        ctx.count_batch(_pad(lb), lo_, lcnt)
+        ctx.set_depth_filter(lcnt, 2)
+        for rep in range(2):
+            got = ctx.classify(_pad(lb), lo_)
+            bad = np.nonzero((got != lwant).any(axis=1))[0]
+            assert len(bad) == 0, ("long -M", rep, len(bad), got[bad[:3]], lwant[bad[:3]])
+    finally:
+        ctx.set_depth_filter(None, 0)
+        lcnt.destroy()
     # a large panel: 700 references derived from the bundled ones (mutated copies), 40 k reads
     prefs = []
     for i in range(700):
