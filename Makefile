@@ -3,6 +3,8 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH := gfx950
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result $(EXTRA_HIPFLAGS)
 CSRC := rkmh_amd/csrc
+# instantiations of the fused kernel the ISA lint must find (it fails closed below that): 8 k variants x 5 modes x 3 prefetch depths
+MIN_TILE_KERNELS ?= 120
 LIB := rkmh_amd/lib/librkmh_amd.so
 OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_call.o $(CSRC)/rk_api.o $(CSRC)/rk_parse.o $(CSRC)/rk_synth.o
 
@@ -16,7 +18,7 @@ $(CSRC)/rk_classify.o: $(CSRC)/rk_classify.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk
 	@mkdir -p build/isa
 	cd build/isa && $(HIPCC) $(HIPFLAGS) -save-temps -c $(CURDIR)/$< -o $(CURDIR)/$@.tmp
 	@cd build/isa && rm -f *.bc *.hipi *.out *.resolution.txt *.hipfb *host-x86_64*.s *.o
-	python3 tools/lint_async_loads.py build/isa/rk_classify-hip-amdgcn-amd-amdhsa-$(ARCH).s || { rm -f $@.tmp; exit 1; }
+	python3 tools/lint_async_loads.py --min-tile-kernels $(MIN_TILE_KERNELS) build/isa/rk_classify-hip-amdgcn-amd-amdhsa-$(ARCH).s || { rm -f $@.tmp; exit 1; }
 	mv $@.tmp $@
 $(CSRC)/rk_call.o: $(CSRC)/rk_call.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

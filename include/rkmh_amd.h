@@ -107,11 +107,22 @@ void rk_counter_destroy(rk_counter* c);   /* allowed after rk_ctx_destroy of its
 int rk_counter_clear(rk_counter* c);
 int rk_counter_increment(rk_counter* c, uint64_t key);
 int rk_counter_get(const rk_counter* c, uint64_t key, int32_t* out);
-/* Counter (de)serialisation (the -p/-q flags the reference parses but leaves unimplemented, src/rkmh.cpp:665-670,
- * :744-769; docs/todo.md:1).  File = "RKHT1\n", u64 slots, u64 nnz, then nnz x (u32 slot, i32 count), little endian.
- * rk_counter_load requires a counter with the same number of slots and REPLACES its contents. */
+/* Counter (de)serialisation (what the reference's commented-out read_hash_counter.write_to_binary / deserialize would do,
+ * src/rkmh.cpp:744-769, :911-913; docs/todo.md:1).  File = "RKHT2\n", u64 slots, u64 nnz, u32 tag_len, tag, then
+ * nnz x (u32 slot, i32 count), little endian ("RKHT1\n" files of round 1, without the tag field, load as untagged).
+ * rk_counter_load* require a counter with the same number of slots and REPLACE its contents.  A file saved with a
+ * provenance tag only loads through rk_counter_load_tagged with the identical tag (RK_ERR_ARG otherwise); an untagged
+ * file only loads through rk_counter_load. */
 int rk_counter_save(rk_counter* c, const char* path);
 int rk_counter_load(rk_counter* c, const char* path);
+int rk_counter_save_tagged(rk_counter* c, const char* path, const void* tag, uint32_t tag_len);
+int rk_counter_load_tagged(rk_counter* c, const char* path, const void* tag, uint32_t tag_len);
+/* Provenance tag of a READ depth map (pass 1 of -M, src/rkmh.cpp:904-910): k list, seed, fold, window and zero-counting
+ * policy of the context, and a fingerprint of the read set (count, total bases, hashes of the lengths and of up to
+ * 2 MiB of bases).  Host-side. */
+#define RK_DEPTH_TAG_BYTES 128
+int rk_depth_map_tag(const rk_ctx* ctx, const int* ks, int nks, const uint8_t* bases, const uint64_t* offsets,
+                     int64_t nseq, uint8_t tag[RK_DEPTH_TAG_BYTES]);
 void* rk_counter_device_ptr(rk_counter* c);
 uint64_t rk_counter_slots(const rk_counter* c);
 

@@ -69,6 +69,9 @@ _SIGS = {
     "rk_counter_get": (C.c_int, [C.c_void_p, C.c_uint64, _i32p]),
     "rk_counter_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rk_counter_load": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rk_counter_save_tagged": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32]),
+    "rk_counter_load_tagged": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32]),
+    "rk_depth_map_tag": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rk_counter_device_ptr": (C.c_void_p, [C.c_void_p]),
     "rk_counter_slots": (C.c_uint64, [C.c_void_p]),
     "rk_hash_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, _ip, C.c_int, C.POINTER(_u64p), _u64p]),
@@ -250,11 +253,19 @@ class Counter:
     def clear(self):
         _chk(self._lib.rk_counter_clear(self._h))
 
-    def save(self, path):
-        _chk(self._lib.rk_counter_save(self._h, os.fsencode(path)))
+    def save(self, path, tag=None):
+        """tag: bytes from Context.depth_map_tag (provenance of a read-depth map) or None for an untagged file."""
+        if tag is None:
+            _chk(self._lib.rk_counter_save(self._h, os.fsencode(path)))
+        else:
+            _chk(self._lib.rk_counter_save_tagged(self._h, os.fsencode(path), C.c_char_p(bytes(tag)), len(tag)))
 
-    def load(self, path):
-        _chk(self._lib.rk_counter_load(self._h, os.fsencode(path)))
+    def load(self, path, tag=None):
+        """Refuses (RkmhError) a file whose provenance tag differs from `tag` (tagged vs untagged included)."""
+        if tag is None:
+            _chk(self._lib.rk_counter_load(self._h, os.fsencode(path)))
+        else:
+            _chk(self._lib.rk_counter_load_tagged(self._h, os.fsencode(path), C.c_char_p(bytes(tag)), len(tag)))
 
     @property
     def slots(self):
@@ -423,6 +434,14 @@ class Context:
     def count_batch(self, bases, offsets, counter):
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         _chk(self._lib.rk_count_batch(self._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), len(offsets) - 1, counter._h))
+
+    def depth_map_tag(self, ks, bases, offsets) -> bytes:
+        """Provenance tag of the read-depth map these reads produce under this context's policy (for Counter.save/load)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        kk = (C.c_int * len(ks))(*ks)
+        tag = (C.c_uint8 * 128)()
+        _chk(self._lib.rk_depth_map_tag(self._h, kk, len(ks), _p(bases, C.c_uint8), _p(offsets, C.c_uint64), len(offsets) - 1, tag))
+        return bytes(tag)
 
     def classify(self, bases, offsets) -> np.ndarray:
         """main_stream's per-read loop for a host batch -> int32 [n,4] (max_id, max_shared, diff, min_num)."""

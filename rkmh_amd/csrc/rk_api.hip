@@ -112,7 +112,7 @@ struct rk_ctx {
     rk_counter* depth = nullptr;
     int min_occ = 0;
     // workspaces for the general path
-    DevBuf w_bases, w_tiles, w_hashes, w_segoff, w_ids, w_sk, w_lens, w_out, w_misc, w_sel, w_selstate, w_table;
+    DevBuf w_bases, w_tiles, w_hashes, w_segoff, w_ids, w_sk, w_lens, w_out, w_misc, w_sel, w_selstate, w_table, w_gcount;
     int ref_count_mode = 0; // -I counter fill: 0 per k-mer occurrence (stream), 1 once per distinct hash per reference (filter)
     Slot slot[2];
 };
@@ -148,7 +148,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
     for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
-                      &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table}) b->release();
+                      &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
         s.d_bases.release(); s.d_offs.release(); s.d_out.release();
@@ -356,6 +356,17 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
             if (out.out4) RKCHK(c->w_out.reserve((size_t)cn * 16));
             RKCHK(c->w_ids.reserve((size_t)cn * 4));
             size_t id_cursor = 0;
+            // panels whose per-reference counter row does not fit the LDS beside the largest sort buffer count in global rows
+            int32_t* gcount = nullptr;
+            uint32_t gcount_rows = 0;
+            if (cfg.classify && out.out4) {
+                // with classification every launch sorts at most next_pow2(S) values (longer sequences are pre-selected)
+                gcount_rows = sort_intersect_global_rows(std::max<uint32_t>(64u, next_pow2((uint32_t)S)), c->ix.nref);
+                if (gcount_rows) {
+                    RKCHK(c->w_gcount.reserve((size_t)gcount_rows * (size_t)c->ix.nref * 4));
+                    gcount = c->w_gcount.as<int32_t>();
+                }
+            }
             auto sort_args = [&](uint32_t* d_ids, uint32_t count, uint32_t P) {
                 SortArgs a{};
                 a.hashes = c->w_hashes.as<uint64_t>(); a.seg_off = c->w_segoff.as<uint64_t>();
@@ -367,6 +378,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
                 a.counter = cfg.filt_counter ? cfg.filt_counter->d : nullptr;
                 a.slots = cfg.filt_counter ? cfg.filt_counter->slots : 1;
                 a.filter_mode = cfg.filter_mode; a.fmin = cfg.fmin; a.fmax = cfg.fmax;
+                if (cfg.classify && out.out4) { a.gcount = gcount; a.gcount_rows = gcount_rows; }
                 return a;
             };
             // Sequences with far more hashes than the sketch keeps (long reads, genomes up to a few million k-mers) are not
@@ -419,6 +431,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
                     a.lens = out.lens ? c->w_lens.as<int32_t>() : nullptr;
                     a.out4 = out.out4 ? c->w_out.as<int32_t>() : nullptr;
                     a.filter_mode = FILTER_NONE;
+                    if (cfg.classify && out.out4) { a.gcount = gcount; a.gcount_rows = gcount_rows; }
                     a.sel_hashes = c->w_sel.as<uint64_t>(); a.sel_len = st_ + 8;
                     HIPCHK(launch_sort_intersect(a, cfg.classify ? &c->ix : nullptr, c->pol, c->st));
                     HIPCHK(hipStreamSynchronize(c->st)); // w_sel / state are reused by the next long sequence
@@ -640,8 +653,13 @@ extern "C" int rk_counter_get(const rk_counter* k, uint64_t key, int32_t* out) {
     HIPCHK(hipMemcpy(out, k->d + (key % k->slots), 4, hipMemcpyDeviceToHost));
     return RK_OK;
 }
-extern "C" int rk_counter_save(rk_counter* k, const char* path) {
-    if (!k || !path) return fail(RK_ERR_ARG, "bad arguments");
+// Depth-map files.  "RKHT2\n", u64 slots, u64 nnz, u32 tag_len, tag bytes, then nnz x (u32 slot, i32 count).  The tag is an
+// opaque provenance record (rk_depth_map_tag: k list, hash policy, fingerprint of the read set); a file saved with a tag
+// only loads when the caller presents the identical tag, so a map counted from other reads or under another hashing policy is
+// refused instead of silently producing wrong masks.  "RKHT1\n" files (round 1: no tag field) still load as untagged.
+static int counter_save_impl(rk_counter* k, const char* path, const void* tag, uint32_t tag_len) {
+    if (!k || !path || (tag_len && !tag)) return fail(RK_ERR_ARG, "bad arguments");
+    if (tag_len > 4096) return fail(RK_ERR_ARG, "tag too long");
     if (k->slots > 0xffffffffull) return fail(RK_ERR_LIMIT, "counter too large to serialise (slot index is 32 bit)");
     RKCHK(set_dev(k->ctx));
     std::vector<int32_t> h((size_t)k->slots);
@@ -650,7 +668,8 @@ extern "C" int rk_counter_save(rk_counter* k, const char* path) {
     if (!f) return fail(RK_ERR_IO, "cannot write %s", path);
     uint64_t nnz = 0;
     for (int32_t v : h) nnz += v != 0;
-    bool ok = fwrite("RKHT1\n", 1, 6, f) == 6 && fwrite(&k->slots, 8, 1, f) == 1 && fwrite(&nnz, 8, 1, f) == 1;
+    bool ok = fwrite("RKHT2\n", 1, 6, f) == 6 && fwrite(&k->slots, 8, 1, f) == 1 && fwrite(&nnz, 8, 1, f) == 1 &&
+              fwrite(&tag_len, 4, 1, f) == 1 && (tag_len == 0 || fwrite(tag, 1, tag_len, f) == tag_len);
     std::vector<uint32_t> rec;
     rec.reserve(1 << 16);
     for (size_t i = 0; ok && i < h.size(); ++i) {
@@ -662,15 +681,26 @@ extern "C" int rk_counter_save(rk_counter* k, const char* path) {
     ok = (fclose(f) == 0) && ok;
     return ok ? RK_OK : fail(RK_ERR_IO, "short write to %s", path);
 }
-extern "C" int rk_counter_load(rk_counter* k, const char* path) {
-    if (!k || !path) return fail(RK_ERR_ARG, "bad arguments");
+static int counter_load_impl(rk_counter* k, const char* path, const void* tag, uint32_t tag_len) {
+    if (!k || !path || (tag_len && !tag)) return fail(RK_ERR_ARG, "bad arguments");
     RKCHK(set_dev(k->ctx));
     FILE* f = fopen(path, "rb");
     if (!f) return fail(RK_ERR_IO, "cannot read %s", path);
     char magic[6];
     uint64_t slots = 0, nnz = 0;
-    bool ok = fread(magic, 1, 6, f) == 6 && memcmp(magic, "RKHT1\n", 6) == 0 && fread(&slots, 8, 1, f) == 1 && fread(&nnz, 8, 1, f) == 1;
+    uint32_t flen = 0;
+    bool ok = fread(magic, 1, 6, f) == 6;
+    const bool v1 = ok && memcmp(magic, "RKHT1\n", 6) == 0, v2 = ok && memcmp(magic, "RKHT2\n", 6) == 0;
+    ok = (v1 || v2) && fread(&slots, 8, 1, f) == 1 && fread(&nnz, 8, 1, f) == 1 && (v1 || fread(&flen, 4, 1, f) == 1) && flen <= 4096;
+    std::vector<uint8_t> ftag(flen);
+    if (ok && flen) ok = fread(ftag.data(), 1, flen, f) == flen;
     if (!ok) { fclose(f); return fail(RK_ERR_IO, "%s is not a counter file", path); }
+    if (flen != tag_len || (flen && memcmp(ftag.data(), tag, flen) != 0)) {
+        fclose(f);
+        if (flen == 0) return fail(RK_ERR_ARG, "%s carries no provenance tag: refusing to use it as the depth map of these reads", path);
+        if (tag_len == 0) return fail(RK_ERR_ARG, "%s carries a provenance tag: load it with rk_counter_load_tagged", path);
+        return fail(RK_ERR_ARG, "%s was counted from other reads, k-mer sizes or hashing policy than this run (provenance tag mismatch): refusing to load it", path);
+    }
     if (slots != k->slots) { fclose(f); return fail(RK_ERR_ARG, "%s holds %llu slots, the counter has %llu", path, (unsigned long long)slots, (unsigned long long)k->slots); }
     std::vector<int32_t> h((size_t)slots, 0);
     std::vector<uint32_t> rec(1 << 16);
@@ -684,6 +714,45 @@ extern "C" int rk_counter_load(rk_counter* k, const char* path) {
     fclose(f);
     if (!ok) return fail(RK_ERR_IO, "%s is truncated or corrupt", path);
     HIPCHK(hipMemcpy(k->d, h.data(), slots * 4, hipMemcpyHostToDevice));
+    return RK_OK;
+}
+extern "C" int rk_counter_save(rk_counter* k, const char* path) { return counter_save_impl(k, path, nullptr, 0); }
+extern "C" int rk_counter_load(rk_counter* k, const char* path) { return counter_load_impl(k, path, nullptr, 0); }
+extern "C" int rk_counter_save_tagged(rk_counter* k, const char* path, const void* tag, uint32_t tag_len) {
+    return counter_save_impl(k, path, tag, tag_len);
+}
+extern "C" int rk_counter_load_tagged(rk_counter* k, const char* path, const void* tag, uint32_t tag_len) {
+    return counter_load_impl(k, path, tag, tag_len);
+}
+// Provenance of a read-depth map: everything that decides which slot a read's k-mers increment (k list, seed, fold, window and
+// zero-counting policy) plus a fingerprint of the read set (count, total bases, FNV-1a over the read lengths and over up to
+// 2 x 1 MiB of bases from both ends of the batch).
+extern "C" int rk_depth_map_tag(const rk_ctx* c, const int* ks, int nks, const uint8_t* bases, const uint64_t* offsets,
+                                int64_t nseq, uint8_t tag[RK_DEPTH_TAG_BYTES]) {
+    if (!c || !ks || nks < 1 || nks > RK_MAX_KS || !offsets || nseq < 0 || !tag || (nseq > 0 && !bases)) return fail(RK_ERR_ARG, "bad arguments");
+    auto fnv = [](uint64_t h, const void* p, size_t n) {
+        const uint8_t* b = (const uint8_t*)p;
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+        return h;
+    };
+    struct Tag { char magic[8]; int32_t fold, drop_last, counts_zero; uint32_t seed; int32_t nks; int32_t ks[RK_MAX_KS]; int64_t nseq; uint64_t total, hlen, hbases; } t;
+    static_assert(sizeof(Tag) <= RK_DEPTH_TAG_BYTES, "tag layout");
+    memset(&t, 0, sizeof t);
+    memcpy(t.magic, "rkdepth1", 8);
+    t.fold = c->pol.fold; t.drop_last = c->pol.drop_last_window; t.counts_zero = c->pol.counter_counts_zero; t.seed = c->pol.seed;
+    t.nks = nks;
+    for (int i = 0; i < nks; ++i) t.ks[i] = ks[i];
+    t.nseq = nseq;
+    t.total = offsets[nseq] - offsets[0];
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (int64_t i = 0; i < nseq; ++i) { const uint64_t len = offsets[i + 1] - offsets[i]; h = fnv(h, &len, 8); }
+    t.hlen = h;
+    const uint64_t span = t.total < (1ull << 20) ? t.total : (1ull << 20);
+    h = 0xcbf29ce484222325ull;
+    if (span) { h = fnv(h, bases + offsets[0], (size_t)span); h = fnv(h, bases + offsets[nseq] - span, (size_t)span); }
+    t.hbases = h;
+    memset(tag, 0, RK_DEPTH_TAG_BYTES);
+    memcpy(tag, &t, sizeof t);
     return RK_OK;
 }
 extern "C" void* rk_counter_device_ptr(rk_counter* k) { return k ? k->d : nullptr; }

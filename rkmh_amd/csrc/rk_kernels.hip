@@ -103,10 +103,13 @@ __device__ __forceinline__ void accumulate_posting(const RefIndex& ix, uint32_t 
 __global__ void k_sort_intersect(SortArgs a, RefIndex ix, int has_ix, DevPolicy pol) {
     extern __shared__ __attribute__((aligned(16))) uint64_t sm[];
     uint64_t* v = sm;
-    int* sh = reinterpret_cast<int*>(sm + a.P);          // [nref] counters, then one int: number of zeros
-    int& s_nz = sh[has_ix ? ix.nref : 0];
+    // [nref] counters (in LDS, or this block's row of a.gcount for panels too large for it), then one int: number of zeros
+    int* lsh = reinterpret_cast<int*>(sm + a.P);
+    const int nl = (has_ix && !a.gcount) ? ix.nref : 0;
+    int* sh = a.gcount ? a.gcount + (size_t)blockIdx.x * (size_t)ix.nref : lsh;
+    int& s_nz = lsh[nl];
     // pre-selection scratch (only when a.preselect): histogram, threshold bucket, a few scalars
-    uint32_t* hist = reinterpret_cast<uint32_t*>(sh + (has_ix ? ix.nref : 0) + 4);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lsh + nl + 4);
     uint64_t* side = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(hist + (1 << PRESEL_BITS) + 8 + 1024 + 64) + 7) & ~(uintptr_t)7);
     uint32_t* ps = hist + (1 << PRESEL_BITS);            // [0] taken so far [1] side count [2] bin [3] below [4] bucket count
     uint32_t* csum = ps + 8;                             // [<= 1024] per-thread partial sums, then [64] per-lane sums
@@ -276,6 +279,17 @@ __global__ void k_sort_intersect(SortArgs a, RefIndex ix, int has_ix, DevPolicy 
         }
     }
 }
+static size_t sort_intersect_lds(uint32_t P, size_t counters, bool preselect) {
+    size_t lds = (size_t)P * 8 + counters * 4 + 16; // sort buffer + counters + s_nz
+    if (preselect) lds += ((size_t)(1 << PRESEL_BITS) + 8 + 1024 + 64) * 4 + (size_t)PRESEL_SIDE * 8 + 16;
+    return lds;
+}
+constexpr size_t LDS_PER_WORKGROUP = 160 * 1024; // gfx950
+uint32_t sort_intersect_global_rows(uint32_t P, int nref) {
+    if (nref <= 0 || sort_intersect_lds(P, (size_t)nref, true) <= LDS_PER_WORKGROUP) return 0;
+    const size_t rows = ((size_t)256 << 20) / ((size_t)nref * 4); // <= 256 MB of counter rows
+    return (uint32_t)(rows < 64 ? 64 : (rows > 4096 ? 4096 : rows));
+}
 hipError_t launch_sort_intersect(const SortArgs& a, const RefIndex* ix, const DevPolicy& pol, hipStream_t st) {
     if (a.nlist == 0) return hipSuccess;
     int T = (int)(a.P / 2);
@@ -283,9 +297,10 @@ hipError_t launch_sort_intersect(const SortArgs& a, const RefIndex* ix, const De
     if (T > 1024) T = 1024;
     RefIndex z{};
     const RefIndex& use = ix ? *ix : z;
-    size_t lds = (size_t)a.P * 8 + (ix ? (size_t)ix->nref * 4 : 0) + 16; // counters + s_nz
-    if (a.preselect) lds += ((size_t)(1 << PRESEL_BITS) + 8 + 1024 + 64) * 4 + (size_t)PRESEL_SIDE * 8 + 16;
+    const size_t lds = sort_intersect_lds(a.P, (ix && !a.gcount) ? (size_t)ix->nref : 0, a.preselect != 0);
+    if (lds > LDS_PER_WORKGROUP) return hipErrorInvalidValue; // callers size SortArgs::gcount with sort_intersect_global_rows
     uint32_t grid = a.nlist < 65535 ? a.nlist : 65535;
+    if (a.gcount && grid > a.gcount_rows) grid = a.gcount_rows;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_intersect),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -49,7 +49,14 @@ struct SortArgs {
     // S non-zero hashes of its sequence (12-bit digits, histogram in LDS) straight from global memory and sorts those
     // (P is then next_pow2(S), not the segment length).  Exact for any multiset, including heavy duplicates.
     uint32_t preselect;
+    // optional: per-reference counter rows in GLOBAL memory, [gcount_rows][nref] int32 (panels whose counter row does not fit
+    // the LDS next to the sort buffer, see sort_intersect_global_rows); the launch then uses at most gcount_rows blocks
+    int32_t* gcount;
+    uint32_t gcount_rows;
 };
+// 0 when one block's per-reference counters fit the LDS beside its sort buffer, else the number of global counter rows
+// (= blocks) the caller must provide in SortArgs::gcount
+uint32_t sort_intersect_global_rows(uint32_t P, int nref);
 constexpr int PRESEL_BITS = 12;                 // digit width of the in-block radix select
 constexpr int PRESEL_SIDE = 1024;               // threshold-bucket elements resolved by rank sort
 

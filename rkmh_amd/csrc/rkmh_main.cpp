@@ -62,6 +62,10 @@ static void help_stream() {
             "  -I/--max-samples <n>    drop reference k-mers counted more than n times across references\n"
             "  -N/--min-matches <n>    flag FAIL:DEPTH / FAIL:MATCHES\n"
             "  -D/--min-diff <n>       flag FAIL:DIFF\n"
+            "  -p/-q/-F <file>, -S <n>, -i, -z, -m   parsed and ignored, as in the reference\n"
+            "  -R <sketches.json>      reference sketches written by `rkmh sketch` instead of -r\n"
+            "  --depth-map-cache <file>  (with -M) save the read-depth map of this run, or reuse the file if it was saved\n"
+            "                          from the same reads, k-mer sizes and hashing policy (anything else is refused)\n"
             "  --device <id>           GPU to use (default 0)\n");
 }
 static void help_hash() {
@@ -182,15 +186,17 @@ static int main_stream(int argc, char** argv) {
         {"pre-references", required_argument, 0, 'R'}, {"read-kmer-map-file", required_argument, 0, 'p'},
         {"ref-kmer-map-file", required_argument, 0, 'q'}, {"in-stream", no_argument, 0, 'i'},
         {"output-reads", no_argument, 0, 'z'},   {"merge-sketch", no_argument, 0, 'm'},
-        {"device", required_argument, 0, 1000},  {0, 0, 0, 0}};
+        {"device", required_argument, 0, 1000},  {"depth-map-cache", required_argument, 0, 1001}, {0, 0, 0, 0}};
     optind = 2;
     int c;
     while ((c = getopt_long(argc, argv, "zmhdk:f:r:s:S:t:M:N:I:R:F:p:q:iD:", long_options, nullptr)) != -1) {
         switch (c) {
             case 'm': case 'i': case 'z': break;                 // parsed and ignored, rkmh.cpp:656-658,709-714
             case 'R': pre_refs = optarg; break;               // pre-hashed references: parsed but unimplemented in the reference (:662-664)
-            case 'p': read_map = optarg; break;               // read k-mer depth map: commented out in the reference (:665-667, :744-758)
-            case 'F': case 'q': case 'S': break; // parsed, bodies empty in the reference (:659-670,:697-700)
+            // -p/-q (k-mer map files): the reference parses them and does nothing (bodies commented out, :665-670, :744-769);
+            // so do we -- no file is read or written.  The reusable depth map is this build's own, explicit option below.
+            case 'F': case 'p': case 'q': case 'S': break; // parsed, bodies empty in the reference (:659-670,:697-700)
+            case 1001: read_map = optarg; break;              // --depth-map-cache FILE (not a reference flag): see the -M block
             case 't': o.threads = atoi(optarg); break;
             case 'r': o.refs.push_back(optarg); break;
             case 'f': o.reads.push_back(optarg); break;
@@ -246,12 +252,16 @@ static int main_stream(int argc, char** argv) {
         CK(rk_parse_files(o.reads.data(), (int)o.reads.size(), &reads));
         rk_counter* cnt = nullptr;
         CK(rk_counter_create(ctx, 200000000ull, &cnt)); // rkmh.cpp:739
-        // -p <file>: reuse a saved depth map (pass 1 is skipped) or save this run's for the next one
+        // --depth-map-cache FILE: reuse a saved depth map (pass 1 is skipped) or save this run's for the next one.  The file
+        // records what it was counted from (k list, hashing policy, fingerprint of the read set); a file that does not match
+        // THIS run is refused with a diagnostic rather than used (CK exits).
+        uint8_t tag[RK_DEPTH_TAG_BYTES];
+        if (read_map) CK(rk_depth_map_tag(ctx, o.ks.data(), (int)o.ks.size(), reads.bases, reads.offsets, reads.nseq, tag));
         FILE* probe = read_map ? fopen(read_map, "rb") : nullptr;
-        if (probe) { fclose(probe); CK(rk_counter_load(cnt, read_map)); }
+        if (probe) { fclose(probe); CK(rk_counter_load_tagged(cnt, read_map, tag, sizeof tag)); }
         else {
             CK(rk_count_batch(ctx, reads.bases, reads.offsets, reads.nseq, cnt));
-            if (read_map) CK(rk_counter_save(cnt, read_map));
+            if (read_map) CK(rk_counter_save_tagged(cnt, read_map, tag, sizeof tag));
         }
         CK(rk_set_depth_filter(ctx, cnt, o.min_occ));
         out4.resize((size_t)reads.nseq * 4);

@@ -57,4 +57,21 @@ def test_shipped_kernel_isa_is_clean():
     for name, body in lint.kernels(open(s).read().split("\n")):
         n += 1
         assert lint.analyse(name, body) == [], name
-    assert n >= 72
+    assert n >= 120
+
+
+def test_gate_fails_closed_on_input_it_cannot_read():
+    """No kernel found, too few k_classify_tile instantiations, or a k_classify_tile without asm-issued loads: exit status 2."""
+    sink = []
+    assert lint.check_file([], out=sink.append) == 2
+    assert lint.check_file("some text\nwithout kernels\n".split("\n"), out=sink.append) == 2
+    tile = "_ZN2rk15k_classify_tileILi16ELi0ELi0ELi3EEEvPKh:\n"
+    clean = (tile + LOAD + WAIT + "\tv_mov_b32_e32 v9, v5\n\ts_endpgm\n").split("\n")
+    assert lint.check_file(clean, min_tile_kernels=1, out=sink.append) == 0
+    assert lint.check_file(clean, min_tile_kernels=2, out=sink.append) == 2
+    # markers no longer recognised => the prefetch looks like a tracked load => the gate must refuse, not pass
+    unmarked = (tile + "\tglobal_load_dword v5, v[2:3], off\n\tv_mov_b32_e32 v9, v5\n\ts_endpgm\n").split("\n")
+    assert lint.check_file(unmarked, min_tile_kernels=1, out=sink.append) == 2
+    hazard = (tile + LOAD + "\tv_mov_b32_e32 v9, v5\n" + WAIT + "\ts_endpgm\n").split("\n")
+    assert lint.check_file(hazard, min_tile_kernels=1, out=sink.append) == 1
+    assert any("refusing to pass" in x for x in sink)

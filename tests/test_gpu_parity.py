@@ -1143,7 +1143,8 @@ def test_other_paths_at_scale(ctx, orc, pave):
 
 
 def test_counter_serialisation(ctx, orc, root, data_dir, tmp_path):
-    """Depth-map save/load (the -p flag the reference leaves unimplemented): a second run that loads the map prints the same lines."""
+    """Depth-map save/load.  -p itself stays a no-op as in the reference; the build's own --depth-map-cache saves/reuses a map and
+    refuses one whose recorded provenance (reads, k list, hashing policy) does not match the run."""
     import rkmh_amd
     cnt = rkmh_amd.Counter(ctx, slots=100003)
     h = ctx.calc_hashes(b"ACGTTGCAAGGCTTAACCGGTTAAGGCCATATATATATATGCGCGCGC" * 4, [8], counter=cnt)
@@ -1159,9 +1160,81 @@ def test_counter_serialisation(ctx, orc, root, data_dir, tmp_path):
     for c in (cnt, other, wrong):
         c.destroy()
     exe = os.path.join(root, "bin", "rkmh")
-    args = [exe, "stream", "-r", os.path.join(data_dir, "zika.refs.fa.gz"), "-f", os.path.join(data_dir, "z1.fq.gz"), "-k", "16", "-M", "2",
-            "-p", str(tmp_path / "depth.map")]
+    base = [exe, "stream", "-r", os.path.join(data_dir, "zika.refs.fa.gz"), "-f", os.path.join(data_dir, "z1.fq.gz"), "-k", "16", "-M", "2"]
+    plain = subprocess.run(base, capture_output=True)
+    assert plain.returncode == 0 and len(plain.stdout) > 1000
+    # -p is parsed and ignored, as in the reference (rkmh.cpp:665-667, body commented out): no file appears, same lines
+    ign = subprocess.run(base + ["-p", str(tmp_path / "ignored.map")], capture_output=True)
+    assert ign.returncode == 0 and ign.stdout == plain.stdout and not (tmp_path / "ignored.map").exists()
+    # the build's own cache flag: first run saves, second run loads instead of counting
+    args = base + ["--depth-map-cache", str(tmp_path / "depth.map")]
     a = subprocess.run(args, capture_output=True)
     assert a.returncode == 0 and (tmp_path / "depth.map").exists(), a.stderr
-    b = subprocess.run(args, capture_output=True)   # second run loads the map instead of counting
-    assert b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 1000
+    b = subprocess.run(args, capture_output=True)
+    assert b.returncode == 0 and a.stdout == b.stdout == plain.stdout
+    # a map counted from OTHER reads, or with another k, is refused with a diagnostic instead of being used
+    import gzip
+    recs = gzip.open(os.path.join(data_dir, "z1.fq.gz"), "rb").read().split(b"\n")
+    (tmp_path / "half.fq").write_bytes(b"\n".join(recs[:4 * 400]) + b"\n")
+    other_reads = [x if x != os.path.join(data_dir, "z1.fq.gz") else str(tmp_path / "half.fq") for x in args]
+    r = subprocess.run(other_reads, capture_output=True)
+    assert r.returncode != 0 and b"provenance" in r.stderr, r.stderr
+    other_k = [x if x != "16" else "14" for x in args]
+    r = subprocess.run(other_k, capture_output=True)
+    assert r.returncode != 0 and b"provenance" in r.stderr, r.stderr
+    # library level: tagged files need the identical tag; untagged and tagged do not mix
+    qb = np.frombuffer(b"ACGTTGCAAGGCTTAACCGGTTAAGGCCATATATATATATGCGCGCGC" * 4, dtype=np.uint8)
+    qo = np.array([0, 96, 192], dtype=np.uint64)
+    tag = ctx.depth_map_tag([8], qb, qo)
+    assert tag != ctx.depth_map_tag([9], qb, qo) and tag != ctx.depth_map_tag([8], qb, np.array([0, 95, 192], dtype=np.uint64))
+    cnt = rkmh_amd.Counter(ctx, slots=100003)
+    cnt.increment(12345)
+    cnt.save(str(tmp_path / "t.bin"), tag=tag)
+    cnt.load(str(tmp_path / "t.bin"), tag=tag)
+    assert cnt.get(12345) == 1
+    with pytest.raises(rkmh_amd.RkmhError):
+        cnt.load(str(tmp_path / "t.bin"))
+    with pytest.raises(rkmh_amd.RkmhError):
+        cnt.load(str(tmp_path / "t.bin"), tag=ctx.depth_map_tag([9], qb, qo))
+    with pytest.raises(rkmh_amd.RkmhError):
+        cnt.load(str(f), tag=tag)   # f is the untagged file from above
+    # round-1 files ("RKHT1", no tag field) still load as untagged
+    v1 = tmp_path / "v1.bin"
+    import struct
+    v1.write_bytes(b"RKHT1\n" + struct.pack("<QQ", 100003, 1) + struct.pack("<Ii", 7, 5))
+    cnt.load(str(v1))
+    assert cnt.get(7) == 5 and cnt.get(12345) == 0
+    cnt.destroy()
+
+
+def test_panel_too_large_for_lds_counters(orc):
+    """45 000 references: beyond the fused kernel (16 384) and beyond what one block's LDS holds as a dense counter row,
+    so the general path counts in global rows (SortArgs::gcount).  Short and long reads, every row against the oracle."""
+    import rkmh_amd
+    T = min(16, os.cpu_count() or 1)
+    rng = np.random.default_rng(77)
+    nref, S = 45000, 16
+    genome = rand_dna(rng, 60 * nref + 200, b"ACGT")
+    refs = [genome[60 * i: 60 * i + 90] for i in range(nref)]      # neighbours overlap by 30 bases: shared hashes, ties
+    rb, ro = orc.pack(refs)
+    reads = []
+    for i in range(300):
+        a = int(rng.integers(0, len(genome) - 700))
+        n = int(rng.choice([40, 150, 600]))
+        reads.append(genome[a: a + n])
+    reads += [b"", b"ACGT", b"N" * 50]
+    qb, qo = orc.pack(reads)
+    c = rkmh_amd.Context(0)
+    try:
+        c.set_references(_pad(rb), ro, [16], S)
+        sk, ln = c.get_reference_sketches()
+        wsk, wln = orc.sketch_refs(rb, ro, [16], S, threads=T)
+        assert (sk == wsk).all() and (ln == wln).all()
+        want = orc.classify_stream(qb, qo, [16], S, wsk, wln, threads=T)
+        for rep in range(2):
+            got = c.classify(_pad(qb), qo)
+            bad = np.nonzero((got != want).any(axis=1))[0]
+            assert len(bad) == 0, (rep, len(bad), got[bad[:3]], want[bad[:3]])
+        assert (want[:, 1] > 0).sum() > 200
+    finally:
+        c.close()

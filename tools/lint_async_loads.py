@@ -214,21 +214,62 @@ def witness(ins, succ, lab_of, hit, regs):
     return "?"
 
 
-def main():
-    lines = open(sys.argv[1]).read().split("\n")
-    bad = 0
-    nk = 0
+def asm_loads(body):
+    """Number of global loads issued from inline asm in one kernel body (the loads hipcc does not track)."""
+    n, in_asm = 0, False
+    for l in body:
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
+        elif in_asm and t.startswith("global_load"):
+            n += 1
+    return n
+
+
+def check_file(lines, min_tile_kernels=0, out=print):
+    """Returns the exit status: 0 clean, 1 hazards, 2 the input does not look like what this gate protects (fails CLOSED:
+    no kernels, fewer k_classify_tile instantiations than expected, or a k_classify_tile without any asm-issued load --
+    i.e. the symbol regex, the -save-temps layout or the ASMSTART markers stopped matching)."""
+    bad = nk = ntile = nloads = 0
+    blind = []
     for name, body in kernels(lines):
         nk += 1
+        la = asm_loads(body)
+        nloads += la
+        if "k_classify_tile" in name:
+            ntile += 1
+            if la == 0:
+                blind.append(name)
         res = analyse(name, body)
         if res:
             bad += 1
-            m = re.search(r"I(Li\w+?)EEv", name)
-            print("%s: %d hazard(s)" % (name[:70], len(res)))
+            out("%s: %d hazard(s)" % (name[:70], len(res)))
             for i, c, r, w in res[:8]:
-                print("    #%d  %-50s in flight: %s   [%s]" % (i, c, ",".join("v%d" % x for x in r), w))
-    print("%d kernels checked, %d with a use of an in-flight register" % (nk, bad))
+                out("    #%d  %-50s in flight: %s   [%s]" % (i, c, ",".join("v%d" % x for x in r), w))
+    out("%d kernels checked (%d k_classify_tile, %d asm-issued loads), %d with a use of an in-flight register" % (nk, ntile, nloads, bad))
+    if nk == 0:
+        out("lint_async_loads: NO kernel found in the input -- refusing to pass (symbol regex or file layout changed?)")
+        return 2
+    if ntile < min_tile_kernels:
+        out("lint_async_loads: %d k_classify_tile instantiations, expected at least %d -- refusing to pass" % (ntile, min_tile_kernels))
+        return 2
+    if blind:
+        out("lint_async_loads: %d k_classify_tile kernel(s) without any asm-issued global_load (e.g. %s) -- the ASMSTART markers "
+            "were not recognised or the prefetch is gone; refusing to pass" % (len(blind), blind[0][:70]))
+        return 2
     return 1 if bad else 0
+
+
+def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("isa")
+    ap.add_argument("--min-tile-kernels", type=int, default=0,
+                    help="fail unless at least this many k_classify_tile instantiations were analysed")
+    a = ap.parse_args()
+    return check_file(open(a.isa).read().split("\n"), a.min_tile_kernels)
 
 
 if __name__ == "__main__":
