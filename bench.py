@@ -148,14 +148,15 @@ def main():
                     traffic = j.get("hbm_bytes_per_launch")
                     if j.get("valu_insts_per_launch"):
                         # the binding resource: a wave64 VALU instruction occupies its SIMD's issue port for 4 cycles
-                        props = torch.cuda.get_device_properties(dev)
-                        simds = 4 * props.multi_processor_count
-                        ghz = props.clock_rate / 1e6     # peak engine clock (kHz -> GHz); the kernel holds ~99 % of it
+                        props = api.device_props(local)
+                        simds = 4 * props["compute_units"]
+                        ghz = props["clock_khz"] / 1e6   # peak engine clock (kHz -> GHz); the kernel holds ~99 % of it
                         valu = {"insts_per_read": j["valu_insts_per_launch"] / n,
                                 "issue_frac": j["valu_insts_per_launch"] * 4.0 / (simds * kern_ms * 1e-3 * ghz * 1e9),
                                 "source": "offline estimate: SQ_INSTS_VALU of %s x 4 cycles / (%d SIMDs x live kernel_ms x %.2f GHz peak clock)"
                                           % (j.get("source", "profiles/pmc_latest.json").split(" ")[0], simds, ghz)}
-            except Exception:
+            except (OSError, ValueError, KeyError) as e:   # unreadable / malformed file: no offline figures, and say so
+                sys.stderr.write("bench.py: ignoring profiles/pmc_latest.json (%s)\n" % e)
                 traffic = None
                 valu = None
         res = {

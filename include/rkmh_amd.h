@@ -60,6 +60,9 @@ typedef struct rk_counter rk_counter;
 const char* rk_last_error(void);
 const char* rk_version(void);
 int rk_device_count(void);
+/* Compute units, peak engine clock (kHz), L2 bytes (one XCD's) and HBM bytes of a device (hipGetDeviceProperties); any
+ * out pointer may be NULL.  Used by bench.py to turn instruction counts into issue-slot fractions on the actual part. */
+int rk_device_props(int device, int32_t* compute_units, int32_t* clock_khz, int64_t* l2_bytes, int64_t* hbm_bytes);
 
 /* One context = one GPU (one process per GPU in multi-GPU runs). policy may be NULL (defaults). */
 int rk_ctx_create(int device, const rk_policy* policy, rk_ctx** out);

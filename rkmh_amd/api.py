@@ -67,6 +67,7 @@ _SIGS = {
     "rk_counter_clear": (C.c_int, [C.c_void_p]),
     "rk_counter_increment": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rk_counter_get": (C.c_int, [C.c_void_p, C.c_uint64, _i32p]),
+    "rk_device_props": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rk_counter_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rk_counter_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rk_counter_save_tagged": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32]),
@@ -228,6 +229,14 @@ def format_stream_line(ref_name, read_name, max_shared, diff, min_num, sketch_si
     if n < 0:
         _chk(n)
     return buf.raw[:n]
+
+
+def device_props(device=0) -> dict:
+    """{'compute_units', 'clock_khz', 'l2_bytes', 'hbm_bytes'} of a GPU (hipGetDeviceProperties)."""
+    lib = load_library()
+    cu, khz, l2, hbm = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+    _chk(lib.rk_device_props(device, C.byref(cu), C.byref(khz), C.byref(l2), C.byref(hbm)))
+    return {"compute_units": cu.value, "clock_khz": khz.value, "l2_bytes": l2.value, "hbm_bytes": hbm.value}
 
 
 class Counter:

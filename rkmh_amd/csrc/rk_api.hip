@@ -119,6 +119,17 @@ struct rk_ctx {
 
 static int set_dev(rk_ctx* c) { HIPCHK(hipSetDevice(c->device)); return RK_OK; }
 
+extern "C" int rk_device_props(int device, int32_t* compute_units, int32_t* clock_khz, int64_t* l2_bytes, int64_t* hbm_bytes) {
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, device);
+    if (e != hipSuccess) return fail(RK_ERR_HIP, "hipGetDeviceProperties(%d): %s", device, hipGetErrorString(e));
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (clock_khz) *clock_khz = p.clockRate;
+    if (l2_bytes) *l2_bytes = p.l2CacheSize;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return RK_OK;
+}
+
 extern "C" int rk_ctx_create(int device, const rk_policy* policy, rk_ctx** out) {
     if (!out) return fail(RK_ERR_ARG, "out is NULL");
     *out = nullptr;

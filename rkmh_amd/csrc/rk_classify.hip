@@ -89,6 +89,8 @@ struct TileGeom {
     int32_t dbg;        // ablation switches (only read when built with -DRK_ABLATE=1)
     int32_t tpb;        // consecutive tiles per workgroup
     int32_t xcd;        // 1: workgroups that share an XCD (blockIdx % 8, round-robin dispatch) take neighbouring tiles
+    int32_t magic_nw;   // windows (first k) of a read of the hinted length, and ...
+    uint32_t magic;     // ... ceil(2^32 / magic_nw): the compact window -> read division of tiles made of such reads
 };
 
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
             nw_min = ~0u;
             for (int j = 0; j < ks.n; ++j) { const uint32_t v = (uint32_t)num_windows((int)ulen, ks.k[j], pol.drop_last_window); nw_min = v < nw_min ? v : nw_min; }
         }
-        const bool plain = uniform && !has_invalid && nw_min >= 1u;
+        const bool plain = uniform && !has_invalid && nw_min >= 2u; // >= 2: the compact mapping divides by the window count
         if (!plain) {
             for (uint32_t i = lane; i < bad_words; i += WAVE) bad[i] = 0;
             for (uint32_t c = lane; c * 32 < B; c += WAVE) { // chunk map: last read starting at or before byte 32c
@@ -484,12 +486,16 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
             const bool compact = plain;
             const uint32_t nW = compact ? nw_u * (uint32_t)Tn : B;
             const uint32_t nIt = (nW + WAVE - 1) / WAVE;
-            // compact mapping state of this lane, advanced by 64 windows per step without any division: window
-            // w = it * 64 + lane lies in read ct_ (as its window cwl) and starts at tile byte cp
+            // compact mapping without any state: window w = it * 64 + lane lies in read t = w / nw_u and starts at tile byte
+            // p = w + t * dtail.  The division is one v_mul_hi_u32 by a per-tile magic constant (exact while w * nw_u < 2^32:
+            // w < 16 reads x 1528 windows), so a step spends 3 VALU on the mapping instead of a running (read, window, position)
+            // triple with a compare-and-wrap per step.
             const uint32_t dtail = ulen - nw_u;           // positions at the end of a read that start no window
-            uint32_t ct_ = 0, cwl = (uint32_t)lane, cp = (uint32_t)lane;
-            if (compact)
-                while (cwl >= nw_u) { cwl -= nw_u; ct_ += 1; cp += dtail; } // reads with fewer than 64 windows
+            // magic = ceil(2^32 / nw_u) (nw_u >= 2 for plain tiles); the host supplies it for reads of the hinted length, so
+            // only tiles of another length pay for an integer division (once per tile)
+            uint32_t magic = 0;
+            if (compact) magic = nw_u == (uint32_t)geo.magic_nw ? (uint32_t)geo.magic
+                                                                : (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu / nw_u + 1u));
             u32x4 fb = {0u, 0u, 0u, 0u}; // bucket fetched for the previous position (lookup in flight)
             uint32_t fw = 0;             // ... or its word of the first-level filter (large panels)
             uint64_t hp = 0;
@@ -519,10 +525,10 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                             // The tile's last <= 32 windows: lanes l and l + 32 take window l together -- the low half hashes
                             // the forward strand, the high half the reverse complement, one exchange gives both the minimum.
                             // The step then issues one murmur per lane instead of two for a mostly idle wave.
-                            const int l2 = lane & 31;
-                            t = (uint32_t)__shfl((int)ct_, l2);
-                            const uint32_t p = (uint32_t)__shfl((int)cp, l2);
-                            if (t < (uint32_t)Tn) { // same for both lanes of a pair
+                            const uint32_t w = it * WAVE + (uint32_t)(lane & 31);
+                            t = __umulhi(w, magic);
+                            const uint32_t p = w + __umul24(t, dtail);
+                            if (w < nW) { // same for both lanes of a pair
                                 const bool low = lane < 32;
                                 const uint32_t* img = low ? s.fwd : s.rc;
                                 const uint32_t off = low ? s.fbase + p : B - (uint32_t)k - p;
@@ -534,8 +540,10 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                         bool ok;
                         uint32_t p;
                         if (compact) { // wave-uniform
-                            t = ct_; p = cp;
-                            ok = t < (uint32_t)Tn;
+                            const uint32_t w = it * WAVE + (uint32_t)lane;
+                            t = __umulhi(w, magic);
+                            p = w + __umul24(t, dtail);
+                            ok = w < nW;
                         } else {
                             p = it * WAVE + (uint32_t)lane;
                             ok = p < B && !((bad[p >> 5] >> (p & 31)) & 1u);
@@ -561,13 +569,6 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                                 }
                             }
                             account(h, t);
-                        }
-                        if (compact) { // advance the mapping after its use (in place, no register copies)
-                            cwl += WAVE; cp += WAVE;
-                            if (cwl >= nw_u) { // one read boundary per step, more only for reads with fewer than 64 windows
-                                cwl -= nw_u; ct_ += 1; cp += dtail;
-                                while (cwl >= nw_u) { cwl -= nw_u; ct_ += 1; cp += dtail; }
-                            }
                         }
                         }
                     }
@@ -766,6 +767,8 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     geo.tpb = tpb;
     geo.xcd = 1;
     if (const char* e = getenv("RKMH_TILE_XCD")) geo.xcd = atoi(e) != 0;
+    geo.magic_nw = num_windows(maxlen, ks.k[0], pol.drop_last_window);
+    geo.magic = geo.magic_nw >= 2 ? 0xFFFFFFFFu / (uint32_t)geo.magic_nw + 1u : 0u;
     const bool k16 = (ks.n == 1 && ks.k[0] == 16);
     const int kmode = mode == 1 ? 1 : (counter ? 2 : 0);
     // The masked (-M) form waits for a random read of the 800 MB counter table in every step: it is bound by memory requests,
