@@ -431,6 +431,22 @@ def test_bench_json_contract(root):
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "bit-exact" in cb["oracle_check"]
 
 
+def test_bench_two_ranks_launched_like_the_driver(root):
+    """The driver's N>1 launch line (torch.distributed.run, one rank per GPU) with both ranks on GPU 0 and gloo instead of RCCL
+    (a one-GPU box): rank 0 prints ONE line, n_gpus = 2, value = reads of BOTH ranks over the slowest rank's time, no CPU baseline."""
+    env = dict(os.environ, RKMH_BENCH_ONE_DEVICE="1", RKMH_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--reads", "40000", "--steps", "4",
+                        "--warmup", "1", "--spinup-seconds", "0"], capture_output=True, cwd=root, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 40000 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6
+    assert d["config"]["reads_per_gpu"] == 40000 and "2 rank" in d["config"]["parallelism"]
+
+
 def test_resident_input_entry_point(ctx, orc, pave):
     import torch
     from rkmh_amd import synth
