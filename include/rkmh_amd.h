@@ -190,6 +190,18 @@ int rk_classify_batch_device(rk_ctx* ctx, const void* d_bases, const void* d_off
 int rk_classify_batch_device_all(rk_ctx* ctx, const void* d_bases, const void* d_offsets_u32, int64_t nreads,
                                  void* d_out4, uint32_t max_read_len, void* hip_stream);
 
+/* hpv16's per-read loop (main_hpv16, src/rkmh.cpp:2656-2719).  The references set with rk_set_reference_sketches are hash
+ * LISTS here, not bottom-s sketches: first the argmax_refs HPV type references (all hashes of each, :2546-2547), then the
+ * lineage- and sublineage-specific k-mer sets (:2568-2650); sketch_size = the longest list.  Per read: calc_hashes (all -k),
+ * mask_by_frequency when a depth filter is set (:2663), sort (:2666); out4 = (max_id, max_shared, diff, non-zero hashes) over
+ * the first argmax_refs references with the strict-> first-max rule of :2675-2678; tail_counts[i][nref - argmax_refs] = the
+ * intersection size against each remaining reference (what sort_by_similarity ranks, :2688, :2700).  With reference lists
+ * of DISTINCT values the intersection is the number of distinct non-zero read hashes present in the list
+ * (hash_set_intersection_size; absent from /root/reference, policy U13 of DESIGN.md).  No bottom-s: a read with more hashes
+ * than sketch_size is refused (RK_ERR_LIMIT).  Host buffers; runs the general kernels (k_hash_tiles + k_sort_intersect). */
+int rk_classify_groups_batch(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, int argmax_refs,
+                             int32_t* out4, int32_t* tail_counts);
+
 /* ------------------------------------------------------------------------------------------------
  * `call` (main_call, src/rkmh.cpp:1455-1904): k-mer depth map of the reads, sliding-window mean depth along the
  * references (window NOT reset between references, as a single-threaded run of src/rkmh.cpp:1769-1791), and at

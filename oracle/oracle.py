@@ -362,3 +362,99 @@ def call_rows(ref_names, ref_seqs, read_seqs, k, window_len=100, policy=None):
                             cmax[key] = max(cmax.get(key, 0), alt_depth)
     return ["%s\t99\tPASS\tKC=%d;MD=%d;RD=%d;OD=%d\n" % (key, cc[key], cmax[key], cavg[key], corig[key])
             for key in sorted(cc, key=lambda s: s.encode())]     # std::map<string,...>: byte-wise order
+
+
+# ---- hpv16 (main_hpv16, /root/reference/src/rkmh.cpp:2366-2723) --------------------------------------------------------
+# Two more mkmh functions absent from /root/reference appear on this path; what they do is restated from their call sites
+# and isolated as named policies (UNVERIFIED, switchable -- DESIGN.md section 0):
+#   U13 hash_set_intersection_size(alpha, alen, beta, blen, shared)   call rkmh.cpp:2673
+#       = number of DISTINCT NON-ZERO values present in both ascending arrays ("set" as opposed to the multiset merge of
+#         hash_intersection_size; 0 is the invalid-k-mer sentinel everywhere else in the reference, rkmh.cpp:1218,1260).
+#   U14 sort_by_similarity(alpha, len, names, n, ref_hashes, ref_lens, out_names, out_sims, out_intersections)   :2688, :2700
+#       = per reference i: inter_i = U13(alpha, ref_i); sim_i = inter_i / (double) DEN; all three output vectors ordered by
+#         sim descending, ties in reference order (stable).  DEN: HPV16_SIM_DEN = "ref" (size of the reference list; a list of
+#         size 0 gives sim 0) or "read" (len, the read's hash count).
+HPV16_SIM_DEN = "ref"
+
+
+def hash_set_intersection_size(a, b) -> int:
+    a = np.asarray(a, dtype=np.uint64)
+    b = np.asarray(b, dtype=np.uint64)
+    return int(len(np.intersect1d(a[a != 0], b[b != 0])))  # intersect1d works on the unique values of both
+
+
+def sort_by_similarity(h, names, ref_hashes, sim_den=None):
+    den = sim_den or HPV16_SIM_DEN
+    inter = [hash_set_intersection_size(h, r) for r in ref_hashes]
+    sims = []
+    for x, r in zip(inter, ref_hashes):
+        d = len(r) if den == "ref" else len(h)
+        sims.append(float(x) / float(d) if d > 0 else 0.0)
+    order = sorted(range(len(names)), key=lambda i: -sims[i])   # Python's sort is stable: ties keep reference order
+    return [names[i] for i in order], [sims[i] for i in order], [inter[i] for i in order]
+
+
+def _specific_sets(keys, hashes):
+    """rkmh.cpp:2560-2596 / :2614-2645: union of the hashes of every sequence of a (sub)lineage as a std::set, then the
+    chain of std::set_difference against every OTHER (sub)lineage in map order.  Returns (names in map order, sorted arrays)."""
+    groups = {}
+    for k, h in zip(keys, hashes):
+        groups.setdefault(k, set()).update(int(x) for x in h)
+    names = sorted(groups)            # std::map<char,...> / std::map<string,...> iterate in key order
+    out = []
+    for x in names:
+        xdiff = set(groups[x])
+        for y in names:
+            if y != x:
+                xdiff -= groups[y]
+        out.append(np.array(sorted(xdiff), dtype=np.uint64))
+    return names, out
+
+
+def hpv16(type_names, type_seqs, sub_names, sub_seqs, read_names, read_seqs, ks, policy=None, min_kmer_occ=None,
+          counter_slots=800000000, sim_den=None):
+    """Returns (stdout lines, text of lineage_specific_hashes.<k>.tst, stderr table lines).  Sequences are upper-cased here as
+    parse_fastas does (rkmh.cpp:227); names are the first header token."""
+    policy = policy or default_policy()
+    k0 = [int(ks[0])]
+    type_hashes = [np.sort(calc_hashes(to_upper(s), k0, policy)) for s in type_seqs]     # :2546 + the in-place sort of minhashes :2547
+    sub_hashes = [calc_hashes(to_upper(s), k0, policy) for s in sub_seqs]                 # :2553
+    lin_names, lin_hashes = _specific_sets([chr(n[0]) for n in sub_names], sub_hashes)    # key[0], :2561
+    sublin_names, sublin_hashes = _specific_sets([n[:2].decode() for n in sub_names], sub_hashes)  # substr(0,2), :2615
+    tst = "".join("%s\t%s\n" % (n, "".join("%d\t" % int(x) for x in h)) for n, h in zip(lin_names, lin_hashes))   # :2598-2611
+    err = ["Lineage specific kmer table created:"] + ["\t%s\t%d" % (n, len(h)) for n, h in zip(lin_names, lin_hashes)]
+    err += ["Sublineage specific kmer table created:"] + ["\t%s\t%d" % (n, len(h)) for n, h in zip(sublin_names, sublin_hashes)]
+    reads_h = [calc_hashes(to_upper(s), ks, policy) for s in read_seqs]                   # :2661 (every -k)
+    if min_kmer_occ is not None:                                                          # :2524-2528 + :2663
+        table = {}
+        for h in reads_h:
+            for x in h:
+                if policy.counter_counts_zero or x != 0:
+                    s = int(x) % counter_slots
+                    table[s] = table.get(s, 0) + 1
+        masked = []
+        for h in reads_h:
+            h = h.copy()
+            for i, x in enumerate(h):
+                c = table.get(int(x) % counter_slots, 0)
+                if (c < min_kmer_occ) if policy.mask_strict_less else (c <= min_kmer_occ):
+                    h[i] = 0
+            masked.append(h)
+        reads_h = masked
+    lines = []
+    for name, h in zip(read_names, reads_h):
+        h = np.sort(h)                                                                    # :2666
+        max_shared, max_id = -1, 0
+        for j, th in enumerate(type_hashes):                                              # :2669-2679
+            shared = hash_set_intersection_size(h, th)
+            if shared > max_shared:
+                max_shared, max_id = shared, j
+        ln, ls, li = sort_by_similarity(h, lin_names, lin_hashes, sim_den)
+        sn, ss, si = sort_by_similarity(h, sublin_names, sublin_hashes, sim_den)
+        st = "%s\t%s\t%d/%d\t" % (name.decode(), type_names[max_id].decode(), max_shared, len(h))
+        st += "".join("%s:%s;" % (a, "%g" % b) for a, b in zip(ln, ls)) + "\t"            # ostream << double = %g, precision 6
+        st += "".join("%s:%s;" % (a, "%g" % b) for a, b in zip(sn, ss)) + "\t"
+        st += "".join("%d;" % x for x in li) + "\t"
+        st += "".join("%d;" % x for x in si) + "\n"
+        lines.append(st)
+    return lines, tst, err

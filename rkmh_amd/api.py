@@ -67,6 +67,7 @@ _SIGS = {
     "rk_counter_clear": (C.c_int, [C.c_void_p]),
     "rk_counter_increment": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rk_counter_get": (C.c_int, [C.c_void_p, C.c_uint64, _i32p]),
+    "rk_classify_groups_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "rk_device_props": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rk_counter_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rk_counter_load": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -459,6 +460,16 @@ class Context:
         out = np.zeros((n, 4), dtype=np.int32)
         _chk(self._lib.rk_classify_batch(self._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), n, _p(out, C.c_int32)))
         return out
+
+    def classify_groups(self, bases, offsets, argmax_refs):
+        """hpv16's per-read loop: (out4 [n,4] over the first argmax_refs references, counts [n, nref - argmax_refs] of the rest)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        out = np.zeros((n, 4), dtype=np.int32)
+        tail = np.zeros((n, max(int(self._lib.rk_num_references(self._h)) - argmax_refs, 0)), dtype=np.int32)
+        _chk(self._lib.rk_classify_groups_batch(self._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), n, argmax_refs,
+                                                _p(out, C.c_int32), _p(tail, C.c_int32) if tail.size else None))
+        return out, tail
 
     @property
     def stream(self):

@@ -112,7 +112,7 @@ struct rk_ctx {
     rk_counter* depth = nullptr;
     int min_occ = 0;
     // workspaces for the general path
-    DevBuf w_bases, w_tiles, w_hashes, w_segoff, w_ids, w_sk, w_lens, w_out, w_misc, w_sel, w_selstate, w_table, w_gcount;
+    DevBuf w_bases, w_tiles, w_hashes, w_segoff, w_ids, w_sk, w_lens, w_out, w_misc, w_sel, w_selstate, w_table, w_gcount, w_tail;
     int ref_count_mode = 0; // -I counter fill: 0 per k-mer occurrence (stream), 1 once per distinct hash per reference (filter)
     Slot slot[2];
 };
@@ -159,7 +159,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
     for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
-                      &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount}) b->release();
+                      &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount, &c->w_tail}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
         s.d_bases.release(); s.d_offs.release(); s.d_out.release();
@@ -195,6 +195,7 @@ struct GeneralOut {
     int32_t* lens = nullptr;         // host [n]
     int32_t* out4 = nullptr;         // host [n*4]
     bool write_back_sorted = false;  // hashes out = sorted segments (minhashes in-place semantics)
+    int32_t* tail_counts = nullptr;  // host [n * (nref - argmax_n)] (cfg.argmax_n > 0)
 };
 struct GeneralCfg {
     KsArr ks;
@@ -208,6 +209,8 @@ struct GeneralCfg {
     int filter_mode = FILTER_NONE, fmin = 0, fmax = 0;
     bool single_kmer = false;          // calc_hash(string): exactly one window of len bases per sequence
     bool classify = false;
+    int argmax_n = 0;                  // > 0: argmax over the first argmax_n references only, counts of the rest -> tail_counts
+    bool keep_all = false;             // every hash takes part (no bottom-S): sequences with more hashes than S are refused
     // resident batches only (d_bases_in != nullptr): sequence i starts at byte abs_starts[i] of d_bases_in and `offsets`
     // is just the prefix sum of the lengths -- lets a scattered subset of a resident batch run without gathering bases
     const uint64_t* abs_starts = nullptr;
@@ -289,6 +292,9 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
             if (cfg.single_kmer) nh = 1;
             else for (int j = 0; j < cfg.ks.n; ++j) nh += (uint64_t)num_windows((int)len, cfg.ks.k[j], c->pol.drop_last_window);
             if (len > 0x7fffffffull) return fail(RK_ERR_LIMIT, "sequence %lld longer than 2^31-1", (long long)i1);
+            if (cfg.keep_all && nh > (uint64_t)cfg.S)
+                return fail(RK_ERR_LIMIT, "sequence %lld has %llu hashes; without bottom-s selection at most %d take part", (long long)i1,
+                            (unsigned long long)nh, cfg.S);
             if (i1 > i0 && (cb + len > MAX_CHUNK_BASES || ch + nh > MAX_CHUNK_HASHES)) break;
             if (need_sort && nh > (uint64_t)SORT_MAX_P && out.write_back_sorted)
                 return fail(RK_ERR_LIMIT, "sequence %lld has %llu hashes; in-place sorting handles <= %d",
@@ -365,6 +371,8 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
             if (out.sketches) RKCHK(c->w_sk.reserve((size_t)cn * S * 8));
             if (out.lens) RKCHK(c->w_lens.reserve((size_t)cn * 4));
             if (out.out4) RKCHK(c->w_out.reserve((size_t)cn * 16));
+            const size_t ntail = (cfg.classify && cfg.argmax_n > 0 && out.tail_counts) ? (size_t)(c->ix.nref - cfg.argmax_n) : 0;
+            if (ntail) RKCHK(c->w_tail.reserve((size_t)cn * ntail * 4));
             RKCHK(c->w_ids.reserve((size_t)cn * 4));
             size_t id_cursor = 0;
             // panels whose per-reference counter row does not fit the LDS beside the largest sort buffer count in global rows
@@ -390,6 +398,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
                 a.slots = cfg.filt_counter ? cfg.filt_counter->slots : 1;
                 a.filter_mode = cfg.filter_mode; a.fmin = cfg.fmin; a.fmax = cfg.fmax;
                 if (cfg.classify && out.out4) { a.gcount = gcount; a.gcount_rows = gcount_rows; }
+                if (cfg.classify) { a.argmax_n = cfg.argmax_n; a.tail_counts = ntail ? c->w_tail.as<int32_t>() : nullptr; }
                 return a;
             };
             // Sequences with far more hashes than the sketch keeps (long reads, genomes up to a few million k-mers) are not
@@ -443,6 +452,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
                     a.out4 = out.out4 ? c->w_out.as<int32_t>() : nullptr;
                     a.filter_mode = FILTER_NONE;
                     if (cfg.classify && out.out4) { a.gcount = gcount; a.gcount_rows = gcount_rows; }
+                    if (cfg.classify) { a.argmax_n = cfg.argmax_n; a.tail_counts = ntail ? c->w_tail.as<int32_t>() : nullptr; }
                     a.sel_hashes = c->w_sel.as<uint64_t>(); a.sel_len = st_ + 8;
                     HIPCHK(launch_sort_intersect(a, cfg.classify ? &c->ix : nullptr, c->pol, c->st));
                     HIPCHK(hipStreamSynchronize(c->st)); // w_sel / state are reused by the next long sequence
@@ -455,6 +465,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
             if (out.sketches) HIPCHK(hipMemcpyAsync(out.sketches + (size_t)i0 * S, c->w_sk.p, (size_t)cn * S * 8, hipMemcpyDeviceToHost, c->st));
             if (out.lens) HIPCHK(hipMemcpyAsync(out.lens + i0, c->w_lens.p, (size_t)cn * 4, hipMemcpyDeviceToHost, c->st));
             if (out.out4) HIPCHK(hipMemcpyAsync(out.out4 + (size_t)i0 * 4, c->w_out.p, (size_t)cn * 16, hipMemcpyDeviceToHost, c->st));
+            if (ntail) HIPCHK(hipMemcpyAsync(out.tail_counts + (size_t)i0 * ntail, c->w_tail.p, (size_t)cn * ntail * 4, hipMemcpyDeviceToHost, c->st));
         }
         HIPCHK(hipStreamSynchronize(c->st));
         hash_cursor += ch;
@@ -1019,6 +1030,22 @@ static int reroute_flagged(rk_ctx* c, const uint8_t* bases, const uint64_t* offs
     RKCHK(general_run(c, sub.data(), nullptr, offs.data(), (int64_t)idx.size(), cfg, go));
     for (size_t j = 0; j < idx.size(); ++j) memcpy(out4 + idx[j] * 4, res.data() + j * 4, 16);
     return RK_OK;
+}
+
+// hpv16's per-read loop (src/rkmh.cpp:2656-2719): every hash of the read takes part (calc_hashes + mask + sort, no bottom-s);
+// argmax over the first argmax_refs references (the HPV types, :2669-2679), raw intersection sizes against the others (the
+// lineage- and sublineage-specific k-mer sets that sort_by_similarity ranks, :2688-2704).
+extern "C" int rk_classify_groups_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, int argmax_refs,
+                                        int32_t* out4, int32_t* tail_counts) {
+    if (!c || !offsets || nreads < 0 || (nreads > 0 && (!out4 || !bases))) return fail(RK_ERR_ARG, "bad arguments");
+    if (!c->have_refs) return fail(RK_ERR_STATE, "classify before rk_set_references");
+    if (argmax_refs < 1 || argmax_refs > c->ix.nref) return fail(RK_ERR_ARG, "argmax_refs %d outside [1,%d]", argmax_refs, c->ix.nref);
+    if (argmax_refs < c->ix.nref && !tail_counts && nreads > 0) return fail(RK_ERR_ARG, "tail_counts is NULL");
+    GeneralCfg cfg; cfg.ks = c->ks; cfg.S = c->S; cfg.classify = true; cfg.keep_all = true;
+    cfg.argmax_n = argmax_refs < c->ix.nref ? argmax_refs : 0;
+    if (c->depth) { cfg.filt_counter = c->depth; cfg.filter_mode = FILTER_MASK_MIN; cfg.fmin = c->min_occ; }
+    GeneralOut go; go.out4 = out4; go.tail_counts = cfg.argmax_n ? tail_counts : nullptr;
+    return general_run(c, bases, nullptr, offsets, nreads, cfg, go);
 }
 
 extern "C" int rk_classify_batch_device(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nreads,

@@ -268,13 +268,18 @@ __global__ void k_sort_intersect(SortArgs a, RefIndex ix, int has_ix, DevPolicy 
                 if (slot != IDX_NOT_FOUND) accumulate_posting(ix, slot, t - u, sh);
             }
             __syncthreads();
+            const int R_arg = a.argmax_n > 0 ? a.argmax_n : ix.nref;
             if (tid < 64) {
                 int mi, ms, df;
-                wave_argmax_diff(sh, ix.nref, tid, mi, ms, df);
+                wave_argmax_diff(sh, R_arg, tid, mi, ms, df);
                 if (tid == 0) {
                     int4 r = make_int4(mi, ms, df, (int)m);
                     reinterpret_cast<int4*>(a.out4)[id] = r;
                 }
+            }
+            if (a.tail_counts) { // raw counts of the references that take no part in the argmax (lineage / sublineage sets)
+                const int nt = ix.nref - R_arg;
+                for (int j = tid; j < nt; j += T) a.tail_counts[(size_t)id * (size_t)nt + j] = sh[R_arg + j];
             }
         }
     }

@@ -53,6 +53,10 @@ struct SortArgs {
     // the LDS next to the sort buffer, see sort_intersect_global_rows); the launch then uses at most gcount_rows blocks
     int32_t* gcount;
     uint32_t gcount_rows;
+    // optional (hpv16, rkmh.cpp:2656-2719): the argmax/diff only looks at the first argmax_n references (0 = all of them) and
+    // the raw shared counts of the others are written to tail_counts[seq id][nref - argmax_n]
+    int32_t argmax_n;
+    int32_t* tail_counts;
 };
 // 0 when one block's per-reference counters fit the LDS beside its sort buffer, else the number of global counter rows
 // (= blocks) the caller must provide in SortArgs::gcount

@@ -47,6 +47,7 @@ static void print_help() {
             "  filter              print the reads that match a reference (or classify reads arriving on STDIN)\n"
             "  call                call SNPs / 1-bp deletions from k-mer depth along a reference\n"
             "  hash                print the k-mer hashes of every sequence\n"
+            "  hpv16               HPV type and HPV16 lineage / sublineage k-mer matches of every read\n"
             "  sketch              write MinHash sketches as JSON (load them with stream -R)\n"
             "Run a command without options for its help text.\n");
 }
@@ -783,6 +784,196 @@ static int main_hash(int argc, char** argv) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// hpv16 (main_hpv16, src/rkmh.cpp:2366-2723): HPV type of every read (set intersection of ALL its k-mer hashes with all hashes
+// of each type reference), and its similarity to the k-mers specific to each HPV16 lineage / sublineage.
+// Two mkmh functions on this path are absent from the reference snapshot (hash_set_intersection_size :2673, sort_by_similarity
+// :2688/:2700); what they are taken to do is stated in DESIGN.md (policies U13/U14) and restated in oracle/oracle.py::hpv16.
+#include <algorithm>
+#include <set>
+static void help_hpv16() {
+    fprintf(stderr,
+            "rkmh hpv16 -f <reads.fq> [-R <dir>] [-k <k>]... [-t <n>] [-M <n>]\n"
+            "  classifies every read to an HPV type (<dir>/all_pave_ref.fa) and reports its k-mer matches to the\n"
+            "  HPV16 lineages / sublineages of <dir>/new_refs.fa; <dir> defaults to ./data (as the reference: run it from the\n"
+            "  rkmh directory).  Also writes lineage_specific_hashes.<k>.tst into the working directory.\n"
+            "  -s/-N/-D are accepted and unused, as in the reference.  --device <id>: GPU to use.\n");
+}
+static int main_hpv16(int argc, char** argv) {
+    std::vector<const char*> read_files;
+    std::string refpath = "data";                       // :2369
+    std::vector<int> ks;
+    int min_kmer_occ = 0, device = 0;
+    bool do_read_depth = false;
+    if (argc <= 2) { help_hpv16(); exit(1); }           // :2386-2389 (prints the classify help there)
+    static struct option long_options[] = {             // :2393-2405
+        {"help", no_argument, 0, 'h'},           {"kmer", no_argument, 0, 'k'},
+        {"fasta", required_argument, 0, 'f'},    {"reference", required_argument, 0, 'r'},
+        {"sketch", required_argument, 0, 's'},   {"threads", required_argument, 0, 't'},
+        {"min-kmer-occurence", required_argument, 0, 'M'}, {"min-matches", required_argument, 0, 'N'},
+        {"min-diff", required_argument, 0, 'D'}, {"max-samples", required_argument, 0, 'I'},
+        {"device", required_argument, 0, 1000},  {0, 0, 0, 0}};
+    optind = 2;
+    int c;
+    while ((c = getopt_long(argc, argv, "hk:f:R:s:t:M:N:D:", long_options, nullptr)) != -1) {
+        switch (c) {
+            case 't': case 's': case 'N': case 'D': break;          // parsed; nothing downstream reads them (:2411, :2428, :2435-2440)
+            case 'f': read_files.push_back(optarg); break;
+            case 'R': refpath = optarg; break;
+            case 'k': if (optarg) ks.push_back(atoi(optarg)); break; // (--kmer is declared no_argument there too: unusable)
+            case 'M': min_kmer_occ = atoi(optarg); do_read_depth = true; break;
+            case 1000: device = atoi(optarg); break;
+            case '?': case 'h': print_help(); exit(1);
+            default: print_help(); abort();                          // --reference / --max-samples: declared, no case (:2441-2443)
+        }
+    }
+    if (ks.empty()) {
+        fprintf(stderr, "NO KMER SIZE PROVIDED. USING A DEFAULT KMER SIZE OF 16\n");   // :2449
+        ks.push_back(16);
+    }
+    auto existing = [](const std::string& p) -> std::string {      // bundled test data is kept gzipped
+        FILE* f = fopen(p.c_str(), "rb");
+        if (f) { fclose(f); return p; }
+        f = fopen((p + ".gz").c_str(), "rb");
+        if (f) { fclose(f); return p + ".gz"; }
+        fprintf(stderr, "rkmh hpv16: cannot open %s (pass the directory holding all_pave_ref.fa and new_refs.fa with -R)\n", p.c_str());
+        exit(1);
+    };
+    const std::string type_file = existing(refpath + "/all_pave_ref.fa"), sub_file = existing(refpath + "/new_refs.fa");   // :2453-2456
+    double t0 = now_s();
+    rk_ctx* ctx = nullptr;
+    CK(rk_ctx_create(device, nullptr, &ctx));
+    rk_policy pol;
+    rk_default_policy(&pol);
+    rk_seqset types, subs, reads;
+    const char* p1[1] = {type_file.c_str()};
+    const char* p2[1] = {sub_file.c_str()};
+    CK(rk_parse_files(p1, 1, &types));
+    CK(rk_parse_files(p2, 1, &subs));
+    if (types.nseq < 1 || subs.nseq < 1) { fprintf(stderr, "rkmh hpv16: no sequences in the reference files\n"); exit(1); }
+    memset(&reads, 0, sizeof reads);
+    if (!read_files.empty()) CK(rk_parse_files(read_files.data(), (int)read_files.size(), &reads));
+    tick("parse", t0);
+    // all hashes (first -k only, :2546 and :2553) of the type and of the lineage/sublineage references, on the GPU
+    const int k0 = ks[0];
+    uint64_t *th = nullptr, *sh = nullptr;
+    std::vector<uint64_t> tho((size_t)types.nseq + 1), sho((size_t)subs.nseq + 1);
+    CK(rk_hash_batch(ctx, types.bases, types.offsets, types.nseq, &k0, 1, &th, tho.data()));
+    CK(rk_hash_batch(ctx, subs.bases, subs.offsets, subs.nseq, &k0, 1, &sh, sho.data()));
+    // lineage- and sublineage-specific k-mers: union per (sub)lineage, minus every other one (:2560-2650), in std::map order
+    auto specific = [&](int key_len, std::vector<std::string>& names, std::vector<std::vector<uint64_t>>& lists) {
+        std::map<std::string, std::set<uint64_t>> groups;
+        for (int64_t i = 0; i < subs.nseq; ++i) {
+            std::string key(subs.names + subs.name_offsets[i]);
+            key = key.substr(0, (size_t)key_len);                    // subtype_keys[i][0] / substr(0, 2)
+            groups[key].insert(sh + sho[(size_t)i], sh + sho[(size_t)i + 1]);
+        }
+        for (auto& x : groups) {
+            std::vector<uint64_t> xdiff(x.second.begin(), x.second.end()), diff;
+            for (auto& y : groups) {
+                if (y.first == x.first) continue;
+                diff.clear();
+                std::set_difference(xdiff.begin(), xdiff.end(), y.second.begin(), y.second.end(), std::back_inserter(diff));
+                xdiff.swap(diff);
+            }
+            names.push_back(x.first);
+            lists.push_back(xdiff);                                  // ascending (mkmh::sort of a sorted range, :2592)
+        }
+    };
+    std::vector<std::string> lin_names, sublin_names;
+    std::vector<std::vector<uint64_t>> lin_lists, sublin_lists;
+    specific(1, lin_names, lin_lists);
+    {   // :2598-2611
+        FILE* ofi = fopen(("lineage_specific_hashes." + std::to_string(k0) + ".tst").c_str(), "w");
+        fprintf(stderr, "Lineage specific kmer table created:\n");
+        for (size_t i = 0; i < lin_names.size(); ++i) {
+            fprintf(stderr, "\t%s\t%zu\n", lin_names[i].c_str(), lin_lists[i].size());
+            if (ofi) {
+                fprintf(ofi, "%s\t", lin_names[i].c_str());
+                for (uint64_t x : lin_lists[i]) fprintf(ofi, "%llu\t", (unsigned long long)x);
+                fprintf(ofi, "\n");
+            }
+        }
+        if (ofi) fclose(ofi);
+    }
+    specific(2, sublin_names, sublin_lists);
+    fprintf(stderr, "Sublineage specific kmer table created:\n");   // :2647-2650
+    for (size_t i = 0; i < sublin_names.size(); ++i) fprintf(stderr, "\t%s\t%zu\n", sublin_names[i].c_str(), sublin_lists[i].size());
+    // reference lists for the device: distinct non-zero values, ascending (set semantics of hash_set_intersection_size, U13)
+    const int ntype = (int)types.nseq, nlin = (int)lin_names.size(), nsub = (int)sublin_names.size(), nref = ntype + nlin + nsub;
+    const int S = RK_MAX_SKETCH;   // list capacity = most hashes a read may have here (no bottom-s on this path)
+    std::vector<uint64_t> lists((size_t)nref * (size_t)S, 0);
+    std::vector<int32_t> lens((size_t)nref, 0);
+    std::vector<size_t> full_len((size_t)nref, 0);                   // reflens as the reference passes them to sort_by_similarity
+    auto put = [&](int r, std::vector<uint64_t> v) {
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        if (!v.empty() && v[0] == 0) v.erase(v.begin());
+        if (v.size() > (size_t)S) { fprintf(stderr, "rkmh hpv16: reference %d has %zu distinct k-mers (limit %d)\n", r, v.size(), S); exit(1); }
+        memcpy(&lists[(size_t)r * S], v.data(), v.size() * 8);
+        lens[(size_t)r] = (int32_t)v.size();
+    };
+    for (int i = 0; i < ntype; ++i) put(i, std::vector<uint64_t>(th + tho[(size_t)i], th + tho[(size_t)i + 1]));
+    for (int i = 0; i < nlin; ++i) { put(ntype + i, lin_lists[(size_t)i]); full_len[(size_t)(ntype + i)] = lin_lists[(size_t)i].size(); }
+    for (int i = 0; i < nsub; ++i) { put(ntype + nlin + i, sublin_lists[(size_t)i]); full_len[(size_t)(ntype + nlin + i)] = sublin_lists[(size_t)i].size(); }
+    rk_free(th); rk_free(sh);
+    CK(rk_set_reference_sketches(ctx, lists.data(), lens.data(), nref, ks.data(), (int)ks.size(), S));   // reads are hashed with EVERY -k (:2661)
+    tick("tables", t0);
+    rk_counter* cnt = nullptr;
+    if (do_read_depth) {                                             // :2514-2530, then mask_by_frequency per read (:2663)
+        CK(rk_counter_create(ctx, 800000000ull, &cnt));
+        CK(rk_count_batch(ctx, reads.bases, reads.offsets, reads.nseq, cnt));
+        CK(rk_set_depth_filter(ctx, cnt, min_kmer_occ));
+    }
+    std::vector<int32_t> out4((size_t)reads.nseq * 4), tail((size_t)reads.nseq * (size_t)(nlin + nsub));
+    if (reads.nseq > 0) CK(rk_classify_groups_batch(ctx, reads.bases, reads.offsets, reads.nseq, ntype, out4.data(), tail.data()));
+    tick("classify", t0);
+    const bool den_read = getenv("RKMH_HPV16_SIM") && !strcmp(getenv("RKMH_HPV16_SIM"), "read");   // U14: similarity denominator
+    std::string buf;
+    char num[64];
+    std::vector<int> order;
+    std::vector<double> sims;
+    auto ranked = [&](const int32_t* cnts, int first, int n, int hashnum, const std::vector<std::string>& names, std::string& a, std::string& b) {
+        // sort_by_similarity (U14): intersection / list size, descending, ties in reference order
+        order.resize((size_t)n); sims.resize((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            order[(size_t)i] = i;
+            const double den = den_read ? (double)hashnum : (double)full_len[(size_t)(first + i)];
+            sims[(size_t)i] = den > 0 ? (double)cnts[i] / den : 0.0;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sims[(size_t)x] > sims[(size_t)y]; });
+        for (int i : order) {
+            a += names[(size_t)i]; a += ':';
+            snprintf(num, sizeof num, "%g", sims[(size_t)i]);        // ostream << double
+            a += num; a += ';';
+            b += std::to_string(cnts[i]); b += ';';
+        }
+    };
+    for (int64_t i = 0; i < reads.nseq; ++i) {
+        const int64_t len = (int64_t)(reads.offsets[i + 1] - reads.offsets[i]);
+        int64_t hashnum = 0;
+        for (int k : ks) { const int64_t nw = pol.drop_last_window ? len - k : len - k + 1; if (nw > 0) hashnum += nw; }
+        const int32_t* r = &out4[(size_t)i * 4];
+        const int32_t* t = &tail[(size_t)i * (size_t)(nlin + nsub)];
+        buf += reads.names + reads.name_offsets[i]; buf += '\t';
+        buf += types.names + types.name_offsets[r[0]]; buf += '\t';
+        buf += std::to_string(r[1]); buf += '/'; buf += std::to_string(hashnum); buf += '\t';
+        std::string la, lb, sa, sb;
+        ranked(t, ntype, nlin, (int)hashnum, lin_names, la, lb);
+        ranked(t + nlin, ntype + nlin, nsub, (int)hashnum, sublin_names, sa, sb);
+        buf += la; buf += '\t'; buf += sa; buf += '\t'; buf += lb; buf += '\t'; buf += sb; buf += '\n';
+        if (buf.size() > (1u << 22)) { fwrite(buf.data(), 1, buf.size(), stdout); buf.clear(); }
+    }
+    fwrite(buf.data(), 1, buf.size(), stdout);
+    tick("emit", t0);
+    if (cnt) rk_counter_destroy(cnt);
+    rk_seqset_free(&types); rk_seqset_free(&subs);
+    if (!read_files.empty()) rk_seqset_free(&reads);
+    rk_ctx_destroy(ctx);
+    return 0;
+}
+
+
 int main(int argc, char** argv) {
     if (argc <= 1) { print_help(); exit(1); }
     std::string cmd = argv[1];
@@ -795,6 +986,7 @@ int main(int argc, char** argv) {
     if (cmd == "filter") return main_filter(argc, argv);
     if (cmd == "call") return main_call(argc, argv);
     if (cmd == "sketch") return main_sketch(argc, argv);
+    if (cmd == "hpv16") return main_hpv16(argc, argv);
     print_help();
     exit(1);
 }

@@ -1254,3 +1254,104 @@ def test_panel_too_large_for_lds_counters(orc):
         assert (want[:, 1] > 0).sum() > 200
     finally:
         c.close()
+
+
+def _hpv16_inputs(orc, data_dir, n_synth=300, seed=5):
+    types = orc.kseq_parse_file(os.path.join(data_dir, "all_pave_ref.fa.gz"))
+    subs = orc.kseq_parse_file(os.path.join(data_dir, "new_refs.fa.gz"))
+    rng = np.random.default_rng(seed)
+    reads = []
+    for i in range(n_synth):   # reads drawn from the HPV16 sublineage genomes (1 % substitutions, either strand, some with an N)
+        name, seq = subs[int(rng.integers(0, len(subs)))][:2]
+        seq = orc.to_upper(seq)
+        L = int(rng.choice([60, 150, 250, 400]))
+        a = int(rng.integers(0, len(seq) - L))
+        r = bytearray(seq[a: a + L])
+        for p in np.nonzero(rng.random(L) < 0.01)[0]:
+            r[p] = b"ACGT"[int(rng.integers(0, 4))]
+        if i % 50 == 7:
+            r[int(rng.integers(0, L))] = ord("N")
+        if i % 9 == 0:
+            r = bytearray(bytes(r).lower())
+        if rng.random() < 0.5:
+            r = bytearray(bytes(r)[::-1].translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca")))
+        reads.append((b"s%04d_%s" % (i, name), bytes(r)))
+    reads += [(b"empty", b""), (b"short", b"ACGTACGT"), (b"polyA", b"A" * 80)]
+    return types, subs, reads
+
+
+@pytest.mark.parametrize("ks,extra", [([16], []), ([12, 16], []), ([16], ["-M", "2"])])
+def test_hpv16_command_against_the_oracle(orc, root, data_dir, tmp_path, ks, extra):
+    """bin/rkmh hpv16 (rkmh.cpp:2366-2723) == oracle.hpv16 byte for byte: stdout, the lineage .tst file, the stderr tables.
+    Reads: synthetic HPV16 sublineage reads (incl. lower case, N, other strand), the reference's own nanopore reads (long), and
+    reads of an unrelated virus (no matches at all)."""
+    types, subs, reads = _hpv16_inputs(orc, data_dir)
+    reads += [r[:2] for r in orc.kseq_parse_file(os.path.join(data_dir, "minION25.fq.gz"))[:6]]
+    reads += [r[:2] for r in orc.kseq_parse_file(os.path.join(data_dir, "z1.fq.gz"))[:40]]
+    fq = tmp_path / "reads.fa"
+    fq.write_bytes(b"".join(b">" + n + b"\n" + s + b"\n" for n, s in reads))
+    args = [os.path.join(root, "bin", "rkmh"), "hpv16", "-f", str(fq), "-R", data_dir]
+    for k in ks:
+        args += ["-k", str(k)]
+    r = subprocess.run(args + extra, capture_output=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    mo = 2 if extra else None
+    want, tst, err = orc.hpv16([t[0] for t in types], [t[1] for t in types], [t[0] for t in subs], [t[1] for t in subs],
+                               [x[0] for x in reads], [x[1] for x in reads], ks, min_kmer_occ=mo)
+    got = r.stdout.decode().splitlines(keepends=True)
+    assert len(got) == len(want) == len(reads)
+    for g, w in zip(got, want):
+        assert g == w
+    assert (tmp_path / ("lineage_specific_hashes.%d.tst" % ks[0])).read_text() == tst
+    assert [l for l in r.stderr.decode().splitlines() if l.startswith("\t") or "kmer table created" in l] == err
+    # the workload means something: most synthetic reads name HPV16 and match their own lineage best
+    hits = [w.split("\t") for w in want[:300]]
+    assert sum(1 for h in hits if h[1].startswith(b"gi|333031".decode()) or "HPV16" in h[1]) > 250
+    assert sum(1 for h, (n, _) in zip(hits, reads[:300]) if h[3].split(":")[0] == n.decode().split("_")[1][0]) > 150
+
+
+def test_classify_groups_entry_point(orc, data_dir):
+    """rk_classify_groups_batch: argmax over the first references only, raw set-intersection counts for the rest; a read with more
+    hashes than the list capacity is refused instead of being bottom-s truncated."""
+    import rkmh_amd
+    rng = np.random.default_rng(3)
+    genome = rand_dna(rng, 6000, b"ACGT")
+    lists_src = [genome[0:2000], genome[1500:3500], genome[3000:5000], genome[4000:6000], genome[500:900]]
+    k, S = 16, 4096
+    lists = np.zeros((len(lists_src), S), dtype=np.uint64)
+    lens = np.zeros(len(lists_src), dtype=np.int32)
+    full = []
+    for i, s in enumerate(lists_src):
+        h = np.unique(orc.calc_hashes(s, [k]))
+        h = h[h != 0]
+        lists[i, : len(h)] = h
+        lens[i] = len(h)
+        full.append(h)
+    reads = [genome[a: a + n] for a, n in ((100, 300), (1600, 200), (1600, 200), (4100, 1000), (0, 20), (5000, 700))] + [b"ACGT" * 50, b""]
+    qb, qo = orc.pack(reads)
+    c = rkmh_amd.Context(0)
+    try:
+        c.set_reference_sketches(lists, lens, [k], S)
+        out, tail = c.classify_groups(_pad(qb), qo, 3)
+        for i, r in enumerate(reads):
+            h = np.sort(orc.calc_hashes(orc.to_upper(r), [k]))
+            cnt = [orc.hash_set_intersection_size(h, f) for f in full]
+            best = int(np.argmax(cnt[:3])) if len(h) else 0
+            assert out[i, 0] == best and out[i, 1] == cnt[best] and out[i, 3] == int((h != 0).sum()), (i, out[i], cnt)
+            assert list(tail[i]) == cnt[3:], (i, tail[i], cnt)
+        with pytest.raises(rkmh_amd.RkmhError):
+            c.classify_groups(_pad(np.frombuffer(rand_dna(rng, 5000, b"ACGT"), dtype=np.uint8)), np.array([0, 5000], dtype=np.uint64), 3)
+    finally:
+        c.close()
+
+
+def test_hpv16_cli_matches_committed_golden(root, data_dir, golden_dir, tmp_path):
+    """bin/rkmh hpv16 on the reference's bundled nanopore reads == tests/golden/hpv16_minion25.json (stdout, stderr tables, .tst)."""
+    import hashlib
+    g = json.load(open(os.path.join(golden_dir, "hpv16_minion25.json")))
+    r = subprocess.run([os.path.join(root, "bin", "rkmh"), "hpv16", "-f", os.path.join(data_dir, g["reads_file"]), "-R", data_dir, "-k", "16"],
+                       capture_output=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout.decode().splitlines(keepends=True) == g["stdout_lines"]
+    assert [l for l in r.stderr.decode().splitlines() if l.startswith("\t") or "kmer table created" in l] == g["stderr_tables"]
+    assert hashlib.sha256((tmp_path / "lineage_specific_hashes.16.tst").read_bytes()).hexdigest() == g["tst_sha256"]

@@ -181,3 +181,38 @@ def test_c1_expectation(golden_dir):
     g = golden(golden_dir, "c1_hpv16_minion25")
     assert len(g["rows"]) == 25
     assert all("HPV16" in r[1] for r in g["rows"])
+
+
+def test_hash_set_intersection_size_policy_u13(orc):
+    """U13 (mkmh function absent from the reference; call site rkmh.cpp:2673): distinct non-zero values present in both arrays."""
+    a = np.array([0, 0, 3, 3, 5, 9, 9, 9, 12], dtype=np.uint64)
+    b = np.array([0, 3, 4, 9, 9, 13], dtype=np.uint64)
+    assert orc.hash_set_intersection_size(a, b) == 2            # {3, 9}: duplicates count once, 0 never
+    assert orc.hash_intersection_size(a[2:], b[1:]) == 3        # the multiset merge of the stream path counts 9 twice
+    assert orc.hash_set_intersection_size(a, np.zeros(0, np.uint64)) == 0
+
+
+def test_sort_by_similarity_policy_u14(orc):
+    """U14 (absent; call sites rkmh.cpp:2688, :2700): similarity = intersection / list size, descending, ties in list order."""
+    h = np.array([1, 2, 3, 4, 5, 6], dtype=np.uint64)
+    refs = [np.array([1, 2, 9, 10], dtype=np.uint64), np.array([3, 4, 5, 11, 12, 13, 14, 15], dtype=np.uint64),
+            np.array([6, 20], dtype=np.uint64), np.zeros(0, np.uint64), np.array([1, 30], dtype=np.uint64)]
+    names, sims, inter = orc.sort_by_similarity(h, ["a", "b", "c", "d", "e"], refs, "ref")
+    assert names == ["a", "c", "e", "b", "d"] and inter == [2, 1, 1, 3, 0] and sims == [0.5, 0.5, 0.5, 0.375, 0.0]
+    names, sims, inter = orc.sort_by_similarity(h, ["a", "b", "c", "d", "e"], refs, "read")
+    assert names == ["b", "a", "c", "e", "d"] and inter == [3, 2, 1, 1, 0]
+
+
+def test_hpv16_golden_matches_oracle(orc, golden_dir, data_dir):
+    """oracle.hpv16 (restatement of rkmh.cpp:2366-2723) on the reference's bundled files == the committed golden."""
+    import hashlib
+    g = json.load(open(os.path.join(golden_dir, "hpv16_minion25.json")))
+    types = orc.kseq_parse_file(os.path.join(data_dir, "all_pave_ref.fa.gz"))
+    subs = orc.kseq_parse_file(os.path.join(data_dir, "new_refs.fa.gz"))
+    reads = orc.kseq_parse_file(os.path.join(data_dir, g["reads_file"]))
+    lines, tst, err = orc.hpv16([t[0] for t in types], [t[1] for t in types], [t[0] for t in subs], [t[1] for t in subs],
+                                [r[0] for r in reads], [r[1] for r in reads], g["ks"], sim_den=g["sim_den"])
+    assert lines == g["stdout_lines"] and err == g["stderr_tables"]
+    assert hashlib.sha256(tst.encode()).hexdigest() == g["tst_sha256"] and tst[:80] == g["tst_first_80"]
+    # every one of the reference's own HPV16 nanopore reads names the HPV16 type reference
+    assert all("HPV16" in l.split("\t")[1] for l in lines)
