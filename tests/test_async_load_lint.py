@@ -75,3 +75,13 @@ def test_gate_fails_closed_on_input_it_cannot_read():
     hazard = (tile + LOAD + "\tv_mov_b32_e32 v9, v5\n" + WAIT + "\ts_endpgm\n").split("\n")
     assert lint.check_file(hazard, min_tile_kernels=1, out=sink.append) == 1
     assert any("refusing to pass" in x for x in sink)
+
+
+def test_blocks_placed_after_the_exit_block_are_analysed():
+    """hipcc may lay basic blocks out AFTER s_endpgm; a kernel body runs to its .Lfunc_end label, so a hazard there is found."""
+    text = ("_ZN2rk15k_classify_tileILi16ELi0ELi0ELi3EEEvPKh:\n" + LOAD + "\ts_cbranch_scc0 .LBB0_2\n" + WAIT +
+            "\ts_endpgm\n.LBB0_2:\n\tv_mov_b32_e32 v9, v5\n" + WAIT + "\ts_endpgm\n.Lfunc_end0:\n")
+    ks = list(lint.kernels(text.split("\n")))
+    assert len(ks) == 1
+    res = lint.analyse(*ks[0])
+    assert [c for _, c, _, _ in res] == ["v_mov_b32_e32 v9, v5"]

@@ -28,6 +28,8 @@ def regs_of(text):
 
 
 def kernels(lines):
+    """(symbol, body lines) of every function.  A body runs to the function's .Lfunc_end label, NOT to its first s_endpgm:
+    hipcc may place basic blocks after the exit block."""
     cur, name = None, None
     for l in lines:
         m = re.match(r"^(_Z\w+):", l)
@@ -35,10 +37,14 @@ def kernels(lines):
             name, cur = m.group(1), []
             continue
         if cur is not None:
-            cur.append(l)
-            if "s_endpgm" in l:
-                yield name, cur
+            if re.match(r"^\.Lfunc_end\d+:", l):
+                if any("s_endpgm" in x for x in cur):
+                    yield name, cur
                 cur = None
+                continue
+            cur.append(l)
+    if cur is not None and any("s_endpgm" in x for x in cur):   # text without the end label (the unit tests)
+        yield name, cur
 
 
 def analyse(name, body):
