@@ -104,7 +104,8 @@ struct rk_ctx {
     KsArr ks{};
     std::vector<uint64_t> h_sk;
     std::vector<int32_t> h_lens;
-    DevBuf d_fpb, d_base, d_kv, d_post, d_pre;
+    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_kpre, d_kmap;
+    uint32_t kpre_inserted = 0; // k-mers the enumeration put into the k-mer-space filter (diagnostic)
     RefIndex ix{};
     bool have_refs = false;
     double density = 1.0; // fraction of a reference's k-mers that its sketch keeps (largest over references)
@@ -158,7 +159,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
-    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_kpre, &c->d_kmap, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount, &c->w_tail}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
@@ -910,6 +911,84 @@ static int build_index(rk_ctx* c) {
         RKCHK(c->d_pre.reserve((size_t)pwords * 4));
         HIPCHK(hipMemcpy(c->d_pre.p, pre.data(), (size_t)pwords * 4, hipMemcpyHostToDevice));
         c->ix.pre = c->d_pre.as<uint32_t>(); c->ix.pmask = pwords - 1;
+    }
+    // k-mer-space filter (single k of 12 or 16, the sizes the fused kernel has a packed-k-mer form for): every k-mer of the 4^k
+    // universe whose canonical hash is a key (or 0), found by exhaustive enumeration on the device -- see k_enum_kmers.
+    // Sized like the hash-space filter (32 bits per key, 2 set).  RKMH_KMER_PREFILTER=0 turns it off (A/B runs, tests).
+    c->ix.kpre = nullptr; c->ix.kpshift = 0; c->ix.kpk = 0; c->ix.kmap = nullptr; c->ix.kmap_m = 0; c->kpre_inserted = 0;
+    int kpre_mode = pre_mode > 0 ? 1 : 0;
+    if (const char* e = getenv("RKMH_KMER_PREFILTER")) kpre_mode = atoi(e);
+    if (kpre_mode > 0 && c->ks.n == 1 && (c->ks.k[0] == 12 || c->ks.k[0] == 16)) {
+        size_t bits_per_key = 32, max_words = (size_t)1024 * 256;
+        if (const char* e = getenv("RKMH_KPRE_BITS")) { long v = atol(e); if (v >= 2 && v <= 256) bits_per_key = (size_t)v; }
+        if (const char* e = getenv("RKMH_KPRE_MAXKB")) { long v = atol(e); if (v >= 16 && v <= (1 << 20)) max_words = (size_t)v * 256; }
+        uint32_t kwords = 1u << 12, klg = 12;
+        while ((size_t)kwords * 32 < distinct * bits_per_key && (size_t)kwords * 2 <= max_words) { kwords <<= 1; ++klg; }
+        RKCHK(c->d_kpre.reserve((size_t)kwords * 4 + 16));
+        HIPCHK(hipMemsetAsync(c->d_kpre.p, 0, (size_t)kwords * 4 + 16, c->st));
+        uint32_t* stats = c->d_kpre.as<uint32_t>() + kwords;
+        // the k-mers found come back as a list (one per strand pair): normally exactly one per key, plus any k-mer that collides
+        // with a key or hashes to 0 -- a handful at most, so twice the keys is ample room; more than that disables this form
+        const uint32_t list_cap = (uint32_t)std::min<size_t>(2 * distinct + 4096, 0x3fffffffu);
+        DevBuf d_list;
+        RKCHK(d_list.reserve((size_t)list_cap * 8));
+        RefIndex probe = c->ix;
+        probe.kpre = nullptr; probe.kmap = nullptr;
+        hipError_t le = launch_enum_kmers(probe, c->pol, c->ks.k[0], c->d_kpre.as<uint32_t>(), klg - 5, stats, d_list.as<uint2>(), list_cap, c->st);
+        uint32_t found = 0;
+        if (le == hipSuccess) le = hipMemcpyAsync(&found, stats, 4, hipMemcpyDeviceToHost, c->st);
+        if (le == hipSuccess) le = hipStreamSynchronize(c->st);
+        std::vector<uint32_t> list((size_t)std::min<uint32_t>(found, list_cap) * 2);
+        if (le == hipSuccess && !list.empty()) le = hipMemcpy(list.data(), d_list.p, list.size() * 4, hipMemcpyDeviceToHost);
+        d_list.release();
+        if (le != hipSuccess) return fail(RK_ERR_HIP, "k-mer enumeration: %s", hipGetErrorString(le));
+        c->kpre_inserted = found;
+        bool ok = found <= list_cap;
+        // exact map k-mer -> index value: bucketed cuckoo (2 cells per 16-byte bucket, 2 candidate buckets, load ~0.8).  Built only
+        // when every key has exactly one preimage (found == keys + zero-hash k-mers with no two entries sharing a key id): the
+        // cell number then identifies the key for the per-read multiset.  Anything else leaves the hash-space kernels in charge.
+        std::vector<uint32_t> cells;
+        uint32_t m = 0;
+        if (ok) {
+            std::vector<uint8_t> seen(nkeys + 1, 0);
+            for (uint32_t i = 0; ok && i < found; ++i) {
+                const uint32_t slot = list[2 * (size_t)i + 1];
+                if (slot == IDX_NOT_FOUND) continue;
+                if (slot >= nkeys || seen[slot]) ok = false; // two different k-mers with the same 64-bit canonical hash
+                else seen[slot] = 1;
+            }
+        }
+        if (ok) {
+            m = (uint32_t)((double)found / 1.6) + 64;
+            cells.assign((size_t)m * 4, KMAP_EMPTY);
+            uint32_t rnd = 0x12345u;
+            for (uint32_t i = 0; ok && i < found; ++i) {
+                uint32_t key = list[2 * (size_t)i], slot = list[2 * (size_t)i + 1];
+                uint32_t val = slot == IDX_NOT_FOUND ? KMAP_ZERO : dense[(size_t)slot * 4 + 2];
+                uint32_t bkt = kmap_cell1(key, m);
+                bool placed = false;
+                for (int kick = 0; kick < 2000 && !placed; ++kick) {
+                    const uint32_t b1 = kmap_cell1(key, m), b2 = kmap_cell2(key, m);
+                    for (uint32_t cand : {b1, b2}) {
+                        uint32_t* e = &cells[(size_t)cand * 4];
+                        if (e[0] == KMAP_EMPTY) { e[0] = key; e[1] = val; placed = true; break; }
+                        if (e[2] == KMAP_EMPTY) { e[2] = key; e[3] = val; placed = true; break; }
+                    }
+                    if (placed) break;
+                    rnd = rnd * 1664525u + 1013904223u;   // evict a random cell of the bucket other than the one we just came from
+                    bkt = (bkt == b1) ? b2 : b1;
+                    uint32_t* e = &cells[(size_t)bkt * 4 + ((rnd >> 16) & 1u) * 2];
+                    std::swap(e[0], key); std::swap(e[1], val);
+                }
+                if (!placed) ok = false;
+            }
+        }
+        if (ok) {
+            RKCHK(c->d_kmap.reserve(cells.size() * 4 + 16));
+            HIPCHK(hipMemcpy(c->d_kmap.p, cells.data(), cells.size() * 4, hipMemcpyHostToDevice));
+            c->ix.kmap = c->d_kmap.as<uint4>(); c->ix.kmap_m = m;
+            c->ix.kpre = c->d_kpre.as<uint32_t>(); c->ix.kpshift = klg - 5; c->ix.kpk = (uint32_t)c->ks.k[0]; // 32 words per line
+        }
     }
     // a full bottom-S sketch of uniform hashes keeps the fraction (largest kept hash / 2^64) of the k-mers
     c->density = 0.0;

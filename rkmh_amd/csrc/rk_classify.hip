@@ -42,7 +42,9 @@ namespace rk {
 
 // Ablation switches used to attribute kernel time to its parts: build with
 // -DRK_ABLATE=1 and set RKMH_DBG (1 no queueing, 2 no phase 2, 4 cheap hash, 8 no bucket loads, 32 no drain,
-// 64 no hit multiset, 128 no counter updates, 256 no index verification in the drain).  Always available:
+// 64 no hit multiset, 128 no counter updates, 256 no index verification in the drain; MODE_ 5 timing experiments with WRONG
+// results: 2048 all filter probes of a wave in one cache line, 8192 / 16384 groups of 4 / 8 lanes share a line, 4096 nothing reaches
+// the drain).  Always available:
 // RKMH_DBG=1024 turns the split-strand last step off (A/B), RKMH_TILE_* override the tile geometry.
 #ifndef RK_ABLATE
 #define RK_ABLATE 0
@@ -54,6 +56,10 @@ constexpr int WAVE = 64;
 // both budgeted for it: VGPRs <= 512 / waves, LDS per single-wave workgroup <= 160 KB / (4 * waves).
 #ifndef RK_WAVES_PER_SIMD
 #define RK_WAVES_PER_SIMD 6
+#endif
+// MODE_ 5 kernels compute no hash in their common path and wait on memory instead: they are latency-bound and want more waves
+#ifndef RK_KPRE_WAVES_PER_SIMD
+#define RK_KPRE_WAVES_PER_SIMD 6
 #endif
 constexpr int PF_MAX = 6; // prefetched base dwords per lane: tile bytes <= PF*64*4 - 8 (template parameter PF = 2 or 6)
 
@@ -89,13 +95,18 @@ struct TileGeom {
     int32_t dbg;        // ablation switches (only read when built with -DRK_ABLATE=1)
     int32_t tpb;        // consecutive tiles per workgroup
     int32_t xcd;        // 1: workgroups that share an XCD (blockIdx % 8, round-robin dispatch) take neighbouring tiles
+    int32_t kpre;       // 1: MODE_ 5 kernels (k-mer-space filter): packed 2-bit images, 4-byte queue entries (position | read << 16)
     int32_t magic_nw;   // windows (first k) of a read of the hinted length, and ...
     uint32_t magic;     // ... ceil(2^32 / magic_nw): the compact window -> read division of tiles made of such reads
 };
 
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
+// packed 2-bit image of one strand of a tile: 16 bases per dword, + the dword a window's 64-bit read may touch past the end
+__host__ __device__ inline int tile_pk_dwords(int cap_bytes) { return cap_bytes / 16 + 3; }
 __host__ __device__ inline size_t tile_lds_bytes(const TileGeom& g) {
-    return ((size_t)((stage_lds_dwords(g.cap_bytes) + 3) & ~3) + 4 * (size_t)g.qcap + 5 * (size_t)(g.T + 1) + 8 +
+    // queue region: 16-byte entries {hash, read}, or (kpre) two packed images + 4-byte entries + the 128-dword multi-posting list
+    const size_t q_dw = g.kpre ? 2 * (size_t)tile_pk_dwords(g.cap_bytes) + (size_t)g.qcap + 128 : 4 * (size_t)g.qcap;
+    return ((size_t)((stage_lds_dwords(g.cap_bytes) + 3) & ~3) + q_dw + 5 * (size_t)(g.T + 1) + 8 +
             2 * (size_t)tile_map_words(g.cap_bytes) +
             (size_t)g.T * (size_t)(g.cwords + g.dset)) * 4;
 }
@@ -148,24 +159,64 @@ __device__ __forceinline__ void bucket_wait(u32x4& f) { asm volatile("s_waitcnt 
 __device__ __forceinline__ void word_load_async(const uint32_t* base, uint32_t byte_off, uint32_t& f) {
     asm volatile("global_load_dword %0, %1, %2" : "=v"(f) : "v"(byte_off), "s"(base) : "memory");
 }
+// The same load with five wait states in front.  The "s" base of the saddr form may be re-materialised by hipcc with
+// v_readlane_b32 (SGPR values parked in VGPR lanes under register pressure) right before the statement; a VALU write of an SGPR
+// needs 5 wait states before a VMEM instruction reads it, and the hazard recogniser does not look inside inline asm -- seen as
+// a GPU memory fault (stale base) in the chunked loop of MODE_ 5.  tools/lint_async_loads.py checks every asm-issued saddr load
+// of the shipped ISA for this.
+__device__ __forceinline__ void word_load_async_ws(const uint32_t* base, uint32_t byte_off, uint32_t& f) {
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(f) : "v"(byte_off), "s"(base) : "memory");
+}
 __device__ __forceinline__ void word_wait(uint32_t& f) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : : "memory"); }
+
+// the k <= 16 bases starting at base p of a packed 2-bit image (16 bases per dword): one 8-byte LDS read + one funnel shift
+struct __attribute__((packed, aligned(4))) rk_pair4 { uint32_t x, y; };
+template <int KT>
+__device__ __forceinline__ uint32_t packed_window(const uint32_t* pk, uint32_t p) {
+    const rk_pair4 w = *reinterpret_cast<const rk_pair4*>(reinterpret_cast<const uint8_t*>(pk) + ((p >> 2) & ~3u));
+    uint32_t v = __builtin_amdgcn_alignbit(w.y, w.x, (p << 1) & 31u);
+    if (KT < 16) v &= (1u << (2 * KT)) - 1u;
+    return v;
+}
+// four upper-case bases (one dword) -> their four 2-bit codes in one byte
+__device__ __forceinline__ uint32_t pack4(uint32_t x) {
+    const uint32_t c = (x >> 1) & 0x03030303u;
+    const uint32_t t = c | (c >> 6);
+    return (t | (t >> 12)) & 0xffu;
+}
 
 // MODE 0: classify; MODE 1: count pass of -M (rkmh.cpp:904-910); MODE 2: classify with the -M mask (rkmh.cpp:916)
 // MODE_ 3 / 4: MODE 0 / 2 with the first-level filter of large panels (RefIndex::pre) in front of the bucket table
+// MODE_ 5: MODE 0 for a single k of 12 or 16 with the k-mer-space filter (RefIndex::kpre).  The loop over the windows of a plain
+//          tile no longer hashes: it extracts the packed 2-bit k-mer of both strands (one 8-byte LDS read + one funnel shift each),
+//          takes the smaller, and tests two bits of a filter that holds EVERY k-mer of the 4^k universe whose canonical hash is a
+//          key of the index or is 0 (filled by exhaustive enumeration when the references are set: k_enum_kmers).  A window that
+//          fails provably has a non-zero hash that is in no sketch -- it can change neither a count nor the number of non-zero
+//          hashes -- and is not hashed at all.  Windows that pass (every hit + a fraction of a percent) are queued by position and
+//          hashed in the drain, 64 at a time with every lane busy, then looked up exactly as before.  Tiles that are not plain
+//          (ragged, or holding a non-ACGT base) run the MODE_ 3 loop; their candidates are queued by position too.
 template <int KT, int MODE_, int FOLD, int PF>
-__global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
+__global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAVES_PER_SIMD)) void k_classify_tile(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
                                                            uint32_t nreads, KsArr ks, int S, RefIndex ix, int32_t* counter,
                                                            uint64_t slots, int min_occ, int32_t* out4, DevPolicy pol, TileGeom geo) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr bool PRE = MODE_ >= 3;
-    constexpr int MODE = MODE_ == 3 ? 0 : (MODE_ == 4 ? 2 : MODE_);
+    constexpr bool KPRE = MODE_ == 5;
+    static_assert(!KPRE || (KT >= 1 && KT <= 16), "the k-mer-space filter packs a k-mer into 32 bits");
+    constexpr int MODE = (MODE_ == 3 || MODE_ == 5) ? 0 : (MODE_ == 4 ? 2 : MODE_);
     const int T = geo.T;
     const uint32_t QCAP = (uint32_t)geo.qcap;
     const uint32_t DS = (uint32_t)geo.dset;
     uint32_t* stage = smem;
     // candidate queue: one 16-byte entry per window {hash lo, hash hi, read within the tile, -} (one ds_write_b128)
     uint4* qe = reinterpret_cast<uint4*>(stage + ((stage_lds_dwords(geo.cap_bytes) + 3) & ~3));
-    uint32_t* rstart = reinterpret_cast<uint32_t*>(qe + QCAP);   // [T+1] byte offset of read t inside the tile
+    // MODE_ 5 lays the same region out as: packed image of the forward string, of the reverse-complement string, the queue
+    // of 4-byte entries (tile byte position | read << 16), the multi-posting list
+    const int pkdw = tile_pk_dwords(geo.cap_bytes);
+    uint32_t* pk_f = reinterpret_cast<uint32_t*>(qe);
+    uint32_t* pk_r = pk_f + pkdw;
+    uint32_t* q32 = pk_r + pkdw;
+    uint32_t* rstart = KPRE ? q32 + QCAP + 128 : reinterpret_cast<uint32_t*>(qe + QCAP);   // [T+1] byte offset of read t inside the tile
     uint32_t* nwin = rstart + (T + 1);                           // [T+1] windows of read t (all k)
     uint32_t* nzero = nwin + (T + 1);                            // [T+1] zero hashes per read
     uint32_t* best = nzero + (T + 1);                            // [T+1] max over increments of (count << 16 | 0xFFFF - ref)
@@ -177,7 +228,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
     uint32_t* dset = c16 + T * geo.cwords;                       // [T][DS] multiset of the slots the read has hit
     // [64][2] hits with several postings (drain).  Aliases the first 32 queue entries: a drain step has its 64
     // entries in registers before it writes here, and entries left for later sit at index >= 64.
-    uint32_t* mq = reinterpret_cast<uint32_t*>(qe);
+    uint32_t* mq = KPRE ? q32 + QCAP : reinterpret_cast<uint32_t*>(qe);
     const int lane = threadIdx.x;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t clg = (uint32_t)geo.clg, cper_m1 = (1u << clg) - 1u, cbits = 32u >> clg, cmask = (1u << cbits) - 1u;
@@ -354,7 +405,18 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
             mark_tails(KT ? KT : ks.k[0]);
             wave_sync();
         }
-        if (ntile < ntiles) load_bases(cur_a, cur_b); // the next tile's bases travel while this tile is hashed
+        if constexpr (KPRE) { // packed 2-bit images of both strings: byte q = bases [4q, 4q + 4) (every tile: the drain resolves candidates by k-mer)
+            const uint32_t nq = (B + 3) >> 2;
+            for (uint32_t q = lane; q < 4u * (uint32_t)pkdw; q += WAVE) {
+                uint32_t bf = 0, br = 0;
+                if (q < nq) { bf = pack4(lds_load4_unaligned(s.fwd, s.fbase + 4u * q)); br = pack4(s.rc[q]); }
+                reinterpret_cast<uint8_t*>(pk_f)[q] = (uint8_t)bf;
+                reinterpret_cast<uint8_t*>(pk_r)[q] = (uint8_t)br;
+            }
+            wave_sync();
+        }
+        // the next tile's bases travel while this tile is hashed (MODE_ 5 kernels request them after their hashing loop instead)
+        if constexpr (!KPRE) { if (ntile < ntiles) load_bases(cur_a, cur_b); }
         auto read_of = [&](uint32_t p) -> int {
             int t = (int)tmap[p >> 5];
             while (p >= rstart[t + 1]) ++t;
@@ -394,10 +456,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         // (exact LDS multiset: entry = (slot + 1) | (occurrences - 1) << 27) and add the postings the multiset merge of
         // rkmh.cpp:869 would count.  A hit with several postings is returned (read << 8 | rank, postings offset) for
         // the 16-lanes-per-hit pass instead of looping here with 63 lanes idle.
-        auto take_candidate = [&](uint64_t h, int t, uint32_t& m_tr, uint32_t& m_off) -> bool {
-            uint32_t slot = 0, v = 0;
-            if RK_DBG(256) { slot = (uint32_t)h & 0xFFFFu; v = (uint32_t)(h >> 40) % 180u | (1u << 20); } else
-            if (!index_lookup(ix, h, slot, v)) return false; // re-reads the bucket (L1/L2 hit), then key + value together
+        auto apply_hit = [&](uint32_t slot, uint32_t v, int t, uint32_t& m_tr, uint32_t& m_off) -> bool {
             uint32_t rank = 0;
             if (!RK_DBG(64)) {
                 uint32_t* ds = dset + (uint32_t)t * DS;
@@ -430,14 +489,43 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
             m_off = v & 0x7fffffffu;
             return true;
         };
+        auto take_candidate = [&](uint64_t h, int t, uint32_t& m_tr, uint32_t& m_off) -> bool {
+            uint32_t slot = 0, v = 0;
+            if RK_DBG(256) { slot = (uint32_t)h & 0xFFFFu; v = (uint32_t)(h >> 40) % 180u | (1u << 20); } else
+            if (!index_lookup(ix, h, slot, v)) return false; // re-reads the bucket (L1/L2 hit), then key + value together
+            return apply_hit(slot, v, t, m_tr, m_off);
+        };
+        const bool drain_counts_zero = KPRE && plain;
         auto drain_queue = [&](uint32_t qn) {
             for (uint32_t e0 = 0; e0 < qn; e0 += WAVE) {
                 const uint32_t e = e0 + (uint32_t)lane;
                 uint32_t m_tr = 0, m_off = 0;
                 bool multi = false;
                 if (e < qn) {
+                    if constexpr (KPRE) {
+                        // queued by position and resolved by K-MER: the packed canonical k-mer is looked up in the exact map the
+                        // enumeration produced (two independent 16-byte loads, four 32-bit compares) -- no hash is computed
+                        const uint32_t ce = q32[e];
+                        const uint32_t p = ce & 0xFFFFu, t = ce >> 16;
+                        const uint32_t vf = packed_window<KT>(pk_f, p), vr = packed_window<KT>(pk_r, B - (uint32_t)KT - p);
+                        const uint32_t key = vf < vr ? vf : vr;
+                        const uint32_t b1 = kmap_cell1(key, ix.kmap_m), b2 = kmap_cell2(key, ix.kmap_m);
+                        const uint4 c1 = ix.kmap[b1], c2 = ix.kmap[b2];
+                        uint32_t val = 0, id = KMAP_EMPTY;
+                        if (c1.x == key) { val = c1.y; id = 2u * b1; }
+                        else if (c1.z == key) { val = c1.w; id = 2u * b1 + 1u; }
+                        else if (c2.x == key) { val = c2.y; id = 2u * b2; }
+                        else if (c2.z == key) { val = c2.w; id = 2u * b2 + 1u; }
+                        if (id != KMAP_EMPTY) { // else: a false positive of the bit filter
+                            // a k-mer whose canonical hash is 0: plain tiles count their zero hashes here (every such k-mer is
+                            // in the map); the other tiles counted every window in their hashing loop
+                            if (val == KMAP_ZERO) { if (drain_counts_zero) atomicAdd(&nzero[t], 1u); }
+                            else multi = apply_hit(id, val, (int)t, m_tr, m_off);
+                        }
+                    } else {
                     const uint4 ce = qe[e];
                     multi = take_candidate(((uint64_t)ce.y << 32) | ce.x, (int)ce.z, m_tr, m_off);
+                    }
                 }
                 const uint64_t mm = __ballot(multi);
                 if (mm) { // hits with several postings: 16 lanes walk one hit's posting list, 4 hits at a time
@@ -500,13 +588,92 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
             uint32_t fw = 0;             // ... or its word of the first-level filter (large panels)
             uint64_t hp = 0;
             uint32_t tp = 0; // read of the previous position
+            uint32_t pp = 0; // ... and its tile byte position (MODE_ 5 queues positions)
             uint32_t it = 0;
+            // (MODE_ 5) drains whole waves of candidates mid-tile, everything at the end
+            auto drain_now = [&](bool last) {
+                wave_sync();
+                const uint32_t qn = last ? qcount : (qcount & ~(uint32_t)(WAVE - 1)); // mid-tile: whole waves of candidates only
+                if (!RK_DBG(32)) drain_queue(qn);
+                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no load of the drain is pending
+                wave_sync();
+                if (last) { qcount = 0; return; }
+                const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
+                uint32_t ce = 0u;
+                if ((uint32_t)lane < rem) ce = q32[qn + lane];
+                wave_sync();
+                if ((uint32_t)lane < rem) q32[lane] = ce;
+                qcount = rem;
+                wave_sync();
+            };
+            bool tile_done = false;
+            if constexpr (KPRE) {
+                if (compact) { // wave-uniform
+                    // MODE_ 5, plain tile.  No hashing in this loop: packed k-mer of both strands -> the smaller -> one filter word.
+                    // A step is ~30 VALU, far too little to hide an L2 round trip, so the steps run in chunks of KCH: the filter
+                    // words of a whole chunk are requested back to back, ONE wait retires them, then the chunk is examined.
+                    constexpr int KCH = 5;
+                    // Nothing is in flight here at run time.  The statement is for the STATIC control-flow graph: hipcc's structurizer
+                    // threads this branch and the other loop form through shared "Flow" blocks, which creates (infeasible) paths
+                    // from that loop's asm-issued filter load to this code; with the load's register retired here, every such
+                    // path passes a wait before the register can be handed to anything else (tools/lint_async_loads.py).
+                    word_wait(fw);
+                    for (uint32_t c0 = 0; c0 < nIt; c0 += KCH) {
+                        const uint32_t len = nIt - c0 < (uint32_t)KCH ? nIt - c0 : (uint32_t)KCH;
+                        uint32_t xv[KCH], fwv[KCH];
+#pragma unroll
+                        for (int j = 0; j < KCH; ++j) { xv[j] = 0u; fwv[j] = 0u; }
+#pragma unroll
+                        for (int j = 0; j < KCH; ++j) {
+                            if ((uint32_t)j < len) { // wave-uniform
+                                const uint32_t w = (c0 + (uint32_t)j) * WAVE + (uint32_t)lane;
+                                uint32_t x = 0u, off = 0u;
+                                if (w < nW) {
+                                    const uint32_t t_ = __umulhi(w, magic);
+                                    const uint32_t p_ = w + __umul24(t_, dtail);
+                                    const uint32_t vf = packed_window<KT>(pk_f, p_);
+                                    const uint32_t vr = packed_window<KT>(pk_r, B - (uint32_t)KT - p_);
+                                    x = kpre_mix(vf < vr ? vf : vr);
+                                    off = kpre_word_off(vf, vr, p_ & 3u, KT, x, ix.kpshift);
+                                }
+                                if RK_DBG(2048) off &= 0x7Cu;   // TIMING EXPERIMENT (wrong results): every probe of the wave in one cache line
+                                if RK_DBG(8192) off = ((uint32_t)__shfl((int)off, lane & ~3) & ~0x7Fu) | (off & 0x7Cu);  // ... groups of 4 lanes share a line
+                                if RK_DBG(16384) off = ((uint32_t)__shfl((int)off, lane & ~7) & ~0x7Fu) | (off & 0x7Cu); // ... groups of 8
+                                xv[j] = x;
+                                word_load_async_ws(ix.kpre, off, fwv[j]);
+                            }
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(fwv[0]), "+v"(fwv[1]), "+v"(fwv[2]), "+v"(fwv[3]), "+v"(fwv[4]) : : "memory");
+                        static_assert(KCH == 5, "the wait statement names the chunk's registers");
+#pragma unroll
+                        for (int j = 0; j < KCH; ++j) {
+                            if ((uint32_t)j < len) {
+                                if (qcount + WAVE > QCAP) drain_now(false);
+                                const uint32_t w = (c0 + (uint32_t)j) * WAVE + (uint32_t)lane;
+                                const uint32_t bm = kpre_bits(xv[j]);
+                                bool cand = w < nW && (fwv[j] & bm) == bm;
+                                if RK_DBG(4096) cand = false;   // TIMING EXPERIMENT (wrong results): probes only, nothing reaches the drain
+                                const uint64_t m = __ballot(cand);
+                                if (cand) {
+                                    const uint32_t t_ = __umulhi(w, magic);
+                                    const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                                    q32[q] = (w + __umul24(t_, dtail)) | (t_ << 16);
+                                }
+                                qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
+                            }
+                        }
+                    }
+                    tile_done = true;
+                }
+            }
+            if (!tile_done)
             for (;;) {
                 // run positions until the queue may not take another wave of candidates (or the tile is done);
                 // step nIt only examines the last lookup
                 for (; it <= nIt && (MODE == 1 || qcount + WAVE <= QCAP); ++it) {
                     uint32_t t = 0;
                     uint64_t h = 0;
+                    uint32_t pcur = 0;
                     if (it < nIt) {
                         // what happens to a window's canonical hash: the -M count / mask, the zero-hash tally of its read
                         auto account = [&](uint64_t& hh, uint32_t tt) {
@@ -549,6 +716,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                             ok = p < B && !((bad[p >> 5] >> (p & 31)) & 1u);
                             if (ok) t = (uint32_t)read_of(p);
                         }
+                        pcur = p;
                         if (ok) { // idle lanes (read tails, the end of the tile) keep h = 0 and are never looked up
                             if (MODE == 1 && has_invalid && !window_valid<KT>(s, p, k)) h = 0;
                             else if RK_DBG(4) {
@@ -581,12 +749,14 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                         const uint64_t m = __ballot(cand);
                         if (cand) {
                             const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            qe[q] = make_uint4((uint32_t)hp, (uint32_t)(hp >> 32), tp, 0u);
+                            if constexpr (KPRE) q32[q] = pp | (tp << 16); // tiles that are not plain: queued by position as well
+                            else qe[q] = make_uint4((uint32_t)hp, (uint32_t)(hp >> 32), tp, 0u);
                         }
                         qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
                         word_load_async(ix.pre, index_pre_word(h, ix.pmask) << 2, fw);
                         hp = h;
                         tp = t;
+                        pp = pcur;
                         continue;
                     }
                     bucket_wait(fb);
@@ -620,20 +790,41 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 // drain: every lane takes queued candidates
                 wave_sync();
                 const bool last = it > nIt;
+                // MODE_ 5: the final drain is shared with the chunked form, below.  The last step's filter word is never examined:
+                // it is retired HERE, in the block that leaves the loop, so no edge out of this loop has a load in flight
+                if constexpr (KPRE) { if (last) { word_wait(fw); break; } }
                 const uint32_t qn = last ? qcount : (qcount & ~(uint32_t)(WAVE - 1)); // mid-tile: whole waves of candidates only
                 if (!RK_DBG(32)) drain_queue(qn);
                 // tell hipcc that no load of the drain is pending any more: otherwise it drains vmcnt inside every
                 // hashing step (a vals/keys destination register is reused there) and with it the pipelined lookup
                 __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
                 wave_sync();
+                // the last step's filter word is never examined: retire that asm-issued load HERE, tied to its register, so that no
+                // later code (the next tile may run the other loop form) can be given the register while the load is in flight
+                if constexpr (PRE) { if (last) word_wait(fw); }
                 if (last) { qcount = 0; break; }
                 const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
+                if constexpr (KPRE) {
+                    uint32_t ce = 0u;
+                    if ((uint32_t)lane < rem) ce = q32[qn + lane];
+                    wave_sync();
+                    if ((uint32_t)lane < rem) q32[lane] = ce;
+                } else {
                 uint4 ce = make_uint4(0u, 0u, 0u, 0u);
                 if ((uint32_t)lane < rem) ce = qe[qn + lane];
                 wave_sync();
                 if ((uint32_t)lane < rem) qe[lane] = ce;
+                }
                 qcount = rem;
                 wave_sync();
+            }
+            if constexpr (KPRE) {
+                // Both loop forms end here with their last candidates still queued and no load in flight.  Only now -- issued in
+                // phase 0, its HBM latency would sit in front of every chunk's wait -- are the next tile's bases requested, from
+                // this ONE call site (two sites would make hipcc merge the prefetch registers with copies of registers that are
+                // still in flight); they land during the final drain and phase 2.
+                if (ntile < ntiles) load_bases(cur_a, cur_b);
+                drain_now(true);
             }
         }
         if (MODE == 1) { wait_bases(); continue; } // see the end of the loop body
@@ -690,8 +881,9 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
 // saturates VALU issue at 6 waves/SIMD and loses ~11 % at 5 (measured), so tiles never grow past this.
 constexpr size_t LDS_BUDGET_6_WAVES = 6656;
 
-static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_read, int win_total) {
+static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_read, int win_total, int kpre) {
     TileGeom g;
+    g.kpre = kpre;
     if (maxlen < 1) maxlen = 1;
     g.qcap = 128;
     if (const char* e = getenv("RKMH_TILE_QCAP")) g.qcap = atoi(e);
@@ -752,8 +944,11 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     if (nreads == 0) return hipSuccess;
     int win_total = 0; // most windows any read of the batch can have (all k): bounds every per-reference count
     for (int j = 0; j < ks.n; ++j) win_total += num_windows(maxlen, ks.k[j], pol.drop_last_window);
+    // the k-mer-space filter form: plain classification (no -M counter) with the single k the filter was enumerated for
+    const bool use_kpre = mode == 0 && !counter && ix.kpre && ix.kmap && ix.pre && ks.n == 1 && (uint32_t)ks.k[0] == ix.kpk &&
+                          (ks.k[0] == 12 || ks.k[0] == 16);
     TileGeom geo = make_geom(maxlen, mode == 1 ? 0 : ix.nref, mode == 1 ? 0 : expect_hits,
-                             num_windows(maxlen, ks.k[0], pol.drop_last_window), win_total);
+                             num_windows(maxlen, ks.k[0], pol.drop_last_window), win_total, use_kpre ? 1 : 0);
     if (mode == 1) { geo.qcap = 0; geo.dset = 0; }
     while (tile_lds_bytes(geo) > 20 * 1024 && geo.T > 1) { geo.T -= 1; geo.cap_bytes = geo.T * maxlen; } // >= 8 waves per CU
     const size_t lds = tile_lds_bytes(geo);
@@ -803,7 +998,11 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
         else RK_LAUNCH(KT, 4, FOLD);                                                                                 \
     } while (0)
     // single k of 12, 20 (the reference's other documented settings), 21 or 31: window length known at compile time, runtime fold
-    if (ks.n == 1 && ks.k[0] == 12) RK_LAUNCH_M(12, -1);
+    if (use_kpre && ks.k[0] == 12) RK_LAUNCH(12, 5, -1);
+    else if (use_kpre && pol.fold == 0) RK_LAUNCH(16, 5, 0);
+    else if (use_kpre && pol.fold == 1) RK_LAUNCH(16, 5, 1);
+    else if (use_kpre) RK_LAUNCH(16, 5, 2);
+    else if (ks.n == 1 && ks.k[0] == 12) RK_LAUNCH_M(12, -1);
     else if (ks.n == 1 && ks.k[0] == 20) RK_LAUNCH_M(20, -1);
     else if (ks.n == 1 && ks.k[0] == 21) RK_LAUNCH_M(21, -1);   // Mash / sourmash defaults
     else if (ks.n == 1 && ks.k[0] == 31) RK_LAUNCH_M(31, -1);

@@ -94,6 +94,70 @@ __device__ __forceinline__ uint64_t min_swapped(uint64_t f, uint64_t r) {
     return join64(lt ? a.y : b.y, lt ? a.x : b.x);
 }
 
+// 2-bit base code of an upper-case base: (ascii >> 1) & 3  =>  A=0, C=1, T=2, G=3; complement = code ^ 2.
+// Packed k-mer: base i of the string in bits [2i, 2i+2).
+__host__ __device__ __forceinline__ uint32_t kpre_mix(uint32_t key) { return key * 0x9E3779B1u; }
+__host__ __device__ __forceinline__ uint32_t kpre_bits(uint32_t x) { return (1u << ((x >> 4) & 31u)) | (1u << ((x >> 9) & 31u)); }
+// Where a window probes the filter.  The kernel is bound by L2 REQUESTS (one per distinct 128-byte line a wave touches), so the
+// line is chosen by something four neighbouring windows of a read have in common: windows p = 4g + j (j = 0..3) all contain the
+// (k-3)-mer at read positions [4g + 3, 4g + k), which sits at offset 3 - j of window j.  line = hash of the smaller of that
+// substring and its reverse complement (strand-symmetric); the word inside the line comes from the k-mer's own mix x.  A key is
+// therefore entered under its four possible alignments (j = 0..3, which also covers its occurrence on the other strand).
+//   vf / vr: packed window and packed reverse-complement window;  j = position & 3;  kplines = lines - 1 (power of two)
+__host__ __device__ __forceinline__ uint32_t kpre_word_off(uint32_t vf, uint32_t vr, uint32_t j, int k, uint32_t x, uint32_t kplg) {
+    const uint32_t msk = (1u << (2 * (k - 3))) - 1u;                    // k <= 16: at most 26 bits
+    const uint32_t a = (vf >> (2u * (3u - j))) & msk, b = (vr >> (2u * j)) & msk;
+    const uint32_t c = (a < b ? a : b) * 0x85EBCA6Bu;
+    return ((c >> (32u - kplg)) << 7) | ((x >> 25) << 2 & 0x7Cu);       // byte offset: line * 128 + word-in-line * 4
+}
+// reverse complement of a packed k-mer (k <= 16)
+__host__ __device__ __forceinline__ uint32_t packed_revcomp(uint32_t v, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r = __builtin_bitreverse32(v);
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
+#endif
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);  // 2-bit groups in reverse order, bits of a group in order
+    if (k < 16) r >>= 2 * (16 - k);
+    const uint32_t m = k < 16 ? ((1u << (2 * k)) - 1u) : 0xffffffffu;
+    return (r ^ 0xAAAAAAAAu) & m;
+}
+
+// MurmurHash3_x64_128 of a k-mer of k <= 16 bytes held in four dwords (little-endian byte order, bytes beyond k zero)
+template <int FOLD = -1>
+__device__ __forceinline__ uint64_t murmur_regs16(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int k, uint32_t seed, int fold) {
+    uint64_t h1 = seed, h2 = seed;
+    if (k == 16) mm_block_first(h1, h2, seed, join64(w0, w1), join64(w2, w3));
+    else { // tail only, as in murmur_window
+        uint64_t k1 = join64(w0, w1), k2 = join64(w2, w3);
+        if (k > 8) { k2 *= MM_C2; k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2; }
+        k1 *= MM_C1; k1 = rotl64(k1, 31); k1 *= MM_C2; h1 ^= k1;
+    }
+    return mm_finish<FOLD>(h1, h2, (uint32_t)k, fold);
+}
+// the four ASCII bases 'A','C','T','G' of the 2-bit codes in byte `d` of a packed k-mer
+__device__ __forceinline__ uint32_t packed_to_ascii4(uint32_t v, int d) {
+    const uint32_t b = (v >> (8 * d)) & 0xffu;
+    const uint32_t sel = (b & 3u) | ((b & 0xCu) << 6) | ((b & 0x30u) << 12) | ((b & 0xC0u) << 18);
+    return __builtin_amdgcn_perm(0x47544341u, 0x47544341u, sel); // code 0..3 -> "ACTG"
+}
+// canonical hash (min over both strands of the folded value) of a packed k-mer, k <= 16
+__device__ __forceinline__ uint64_t canonical_packed(uint32_t v, int k, uint32_t seed, int fold) {
+    const uint32_t rv = packed_revcomp(v, k);
+    uint32_t f[4], r[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int nv = k - 4 * d; // bytes of this dword that belong to the k-mer
+        const uint32_t m = nv >= 4 ? 0xffffffffu : (nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u));
+        f[d] = packed_to_ascii4(v, d) & m;
+        r[d] = packed_to_ascii4(rv, d) & m;
+    }
+    const uint64_t hf = murmur_regs16<-1>(f[0], f[1], f[2], f[3], k, seed, fold);
+    const uint64_t hr = murmur_regs16<-1>(r[0], r[1], r[2], r[3], k, seed, fold);
+    return hf < hr ? hf : hr;
+}
+
 // MurmurHash3_x64_128 of the k bytes starting at byte offset `a` of the LDS dword array w32.
 // The array must be readable for 16 bytes past the window (buffers are padded).
 // Windows are fetched with UNALIGNED 16-byte LDS reads: gfx950 runs with unaligned DS access enabled (hipcc itself
@@ -344,7 +408,29 @@ struct RefIndex {
     // and only windows that pass go to the queue; the drain looks them up in the table as it always did.
     const uint32_t* pre;
     uint32_t pmask;   // filter words - 1
+    // Optional k-mer-space filter (nullptr = none; single k <= 16 only): a bit array addressed by the PACKED 2-bit k-mer
+    // (smaller of the window and its reverse complement as 32-bit numbers) in which every k-mer of the whole 4^k universe whose
+    // canonical hash is a key of this index -- or is 0 -- has its two bits set.  It is filled by exhaustive enumeration
+    // (k_enum_kmers), so it has no false negatives BY CONSTRUCTION: a window that fails the test provably hashes to a non-zero
+    // value that is in no sketch, and the fused kernel does not hash it at all (k_classify_tile, MODE_ 5).
+    const uint32_t* kpre;
+    uint32_t kpshift; // log2(filter LINES of 128 bytes)
+    uint32_t kpk;     // the k it was enumerated for
+    // ... and the exact map behind it: every k-mer the enumeration found, as {packed canonical k-mer, index value} cells in a
+    // bucketed cuckoo hash: 16-byte buckets of two cells, two candidate buckets per k-mer, load ~0.8 (1.6 MB at C2: it must
+    // share the L2 with the filter; 0xFFFFFFFF = empty cell: never a canonical k-mer).  A candidate window is resolved by its
+    // K-MER -- two independent 16-byte loads and four 32-bit compares -- so MODE_ 5 kernels compute no hash at all: the
+    // enumeration hashed the whole universe once.  The cell number is the key's identity for the per-read hit multiset (the map
+    // is only built when every index key has exactly one preimage, which the enumeration checks; otherwise the hash-space
+    // kernels serve the panel).  value = KMAP_ZERO marks a k-mer whose canonical hash is 0.
+    const uint4* kmap;
+    uint32_t kmap_m;  // buckets
 };
+constexpr uint32_t KMAP_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t KMAP_ZERO = 0xFFFFFFFEu; // not a valid index value (bit 31 set => postings offset < 2^31 - 1)
+__host__ __device__ __forceinline__ uint32_t kmap_cell1(uint32_t key, uint32_t m) { return (uint32_t)(((uint64_t)(key * 0x9E3779B1u) * m) >> 32); }
+__host__ __device__ __forceinline__ uint32_t kmap_cell2(uint32_t key, uint32_t m) { return (uint32_t)(((uint64_t)((key ^ (key >> 15)) * 0x85EBCA6Bu) * m) >> 32); }
+
 // filter word and bit pair of a hash: the word from the low bits of the high hash word (like the bucket), the two bits
 // from bits 14..23 of the low word (bits 0..13 are the fingerprint)
 __host__ __device__ __forceinline__ uint32_t index_pre_word(uint64_t h, uint32_t pmask) { return (uint32_t)(h >> 32) & pmask; }

@@ -85,3 +85,19 @@ def test_blocks_placed_after_the_exit_block_are_analysed():
     assert len(ks) == 1
     res = lint.analyse(*ks[0])
     assert [c for _, c, _, _ in res] == ["v_mov_b32_e32 v9, v5"]
+
+
+def test_sgpr_base_written_by_valu_right_before_an_asm_load():
+    """gfx9: a VALU write of an SGPR (v_readlane: hipcc re-materialising a parked pointer) needs 5 wait states before a VMEM
+    instruction reads it, and nobody inserts them for a load inside inline asm -- seen as a GPU memory fault.  s_nop 4 in the asm fixes it."""
+    bad = ("\tv_readlane_b32 s14, v79, 4\n\tv_readlane_b32 s15, v79, 5\n\t;;#ASMSTART\n\tglobal_load_dword v5, v6, s[14:15]\n\t;;#ASMEND\n" + WAIT)
+    ks = list(lint.kernels((HEAD + bad + "\ts_endpgm\n").split("\n")))
+    found = lint.sgpr_hazards(ks[0][1])
+    assert len(found) == 2 and found[0][1] == [14] and found[1][1] == [15]
+    good = bad.replace("\tglobal_load_dword v5, v6, s[14:15]", "\ts_nop 4\n\tglobal_load_dword v5, v6, s[14:15]")
+    ks = list(lint.kernels((HEAD + good + "\ts_endpgm\n").split("\n")))
+    assert lint.sgpr_hazards(ks[0][1]) == []
+    sink = []
+    tile = "_ZN2rk15k_classify_tileILi16ELi5ELi0ELi3EEEvPKh:\n"
+    assert lint.check_file((tile + bad + "\ts_endpgm\n").split("\n"), min_tile_kernels=1, out=sink.append) == 1
+    assert lint.check_file((tile + good + "\ts_endpgm\n").split("\n"), min_tile_kernels=1, out=sink.append) == 0

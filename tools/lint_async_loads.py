@@ -234,6 +234,49 @@ def asm_loads(body):
     return n
 
 
+def sgpr_hazards(body):
+    """Asm-issued saddr-form loads (`global_load_* vD, vOff, s[a:b]`) whose base SGPRs were written by a VALU instruction
+    (v_readlane / v_readfirstlane / v_cmp ... writing SGPRs) fewer than 5 wait states earlier.  gfx9: "VALU writes SGPR ->
+    VMEM reads that SGPR" needs 5 wait states; hipcc's hazard recogniser does not look inside inline asm.  s_nop N counts N+1
+    wait states, any other instruction 1.  Straight-line scan per basic block (a label resets the window: conservative enough,
+    a branch target is never reached within 5 states of a v_readlane in this code, and a miss here only loses a diagnostic)."""
+    res = []
+    recent = []  # (sgpr numbers written by VALU, wait states since)
+    in_asm = False
+    for l in body:
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if re.match(r"^\.LBB\d+_\d+:", t):
+            recent = []
+            continue
+        c = t.split(";")[0].strip()
+        if not c or c.startswith("."):
+            continue
+        op = c.split()[0]
+        if in_asm and op.startswith("global_load") and re.search(r",\s*s\[(\d+):(\d+)\]", c):
+            m = re.search(r",\s*s\[(\d+):(\d+)\]", c)
+            base = set(range(int(m.group(1)), int(m.group(2)) + 1))
+            for regs, age in recent:
+                if regs & base and age < 5:
+                    res.append((c, sorted(regs & base), age))
+        states = 1
+        m = re.match(r"^s_nop\s+(\d+)", c)
+        if m:
+            states = int(m.group(1)) + 1
+        recent = [(r, a + states) for r, a in recent if a + states < 8]
+        if op.startswith("v_readlane") or op.startswith("v_readfirstlane"):
+            d = c.split()[1].rstrip(",")
+            m = re.match(r"^s(\d+)$", d)
+            if m:
+                recent.append(({int(m.group(1))}, 0))
+    return res
+
+
 def check_file(lines, min_tile_kernels=0, out=print):
     """Returns the exit status: 0 clean, 1 hazards, 2 the input does not look like what this gate protects (fails CLOSED:
     no kernels, fewer k_classify_tile instantiations than expected, or a k_classify_tile without any asm-issued load --
@@ -248,13 +291,19 @@ def check_file(lines, min_tile_kernels=0, out=print):
             ntile += 1
             if la == 0:
                 blind.append(name)
+        sh = sgpr_hazards(body)
+        if sh:
+            bad += 1
+            out("%s: %d asm load(s) reading an SGPR base too soon after a VALU wrote it" % (name[:70], len(sh)))
+            for c, regs, age in sh[:8]:
+                out("    %-50s s%s written %d wait state(s) earlier (needs 5)" % (c, ",s".join(str(r) for r in regs), age))
         res = analyse(name, body)
         if res:
             bad += 1
             out("%s: %d hazard(s)" % (name[:70], len(res)))
             for i, c, r, w in res[:8]:
                 out("    #%d  %-50s in flight: %s   [%s]" % (i, c, ",".join("v%d" % x for x in r), w))
-    out("%d kernels checked (%d k_classify_tile, %d asm-issued loads), %d with a use of an in-flight register" % (nk, ntile, nloads, bad))
+    out("%d kernels checked (%d k_classify_tile, %d asm-issued loads), %d finding(s): uses of an in-flight register / SGPR bases read too soon" % (nk, ntile, nloads, bad))
     if nk == 0:
         out("lint_async_loads: NO kernel found in the input -- refusing to pass (symbol regex or file layout changed?)")
         return 2
