@@ -160,6 +160,12 @@ int rk_set_reference_sketches(rk_ctx* ctx, const uint64_t* sketches, const int32
 int rk_get_reference_sketches(rk_ctx* ctx, uint64_t* sketches, int32_t* lens);
 int rk_num_references(const rk_ctx* ctx);
 
+/* Which form of the fused kernel plain classification (no -M) will use for the references now set: returns 1 when the
+ * k-mer-space form is active (single k of 12 or 16: the 4^k k-mer universe was enumerated and every k-mer whose canonical hash
+ * is a sketch hash -- or 0 -- is known, so windows are filtered and resolved by k-mer and never hashed), 0 for the hash-space
+ * form, negative on error.  *kmers_found (may be NULL) = k-mers the enumeration found (one per strand pair). */
+int rk_kmer_form(const rk_ctx* ctx, uint32_t* kmers_found);
+
 /* Read-depth filter (-M, src/rkmh.cpp:701-704): when set, classify masks hashes whose counter
  * value is below min_kmer_occ (mask_by_frequency, :916) before sketching.  NULL disables. */
 int rk_set_depth_filter(rk_ctx* ctx, rk_counter* counter, int min_kmer_occ);

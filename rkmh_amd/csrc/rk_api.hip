@@ -953,6 +953,7 @@ static int build_index(rk_ctx* c) {
         // cell number then identifies the key for the per-read multiset.  Anything else leaves the hash-space kernels in charge.
         std::vector<uint32_t> cells;
         uint32_t m = 0;
+        if (getenv("RKMH_KMAP_FORCE_DUP")) ok = false; // tests: behave as if two k-mers shared a key (the map is not built)
         if (ok) {
             std::vector<uint8_t> seen(nkeys + 1, 0);
             for (uint32_t i = 0; ok && i < found; ++i) {
@@ -1060,6 +1061,13 @@ extern "C" int rk_set_reference_count_mode(rk_ctx* c, int mode) {
     if (!c || (mode != 0 && mode != 1)) return fail(RK_ERR_ARG, "mode must be 0 or 1");
     c->ref_count_mode = mode;
     return RK_OK;
+}
+
+extern "C" int rk_kmer_form(const rk_ctx* c, uint32_t* kmers_found) {
+    if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
+    if (!c->have_refs) return fail(RK_ERR_STATE, "no references set");
+    if (kmers_found) *kmers_found = c->kpre_inserted;
+    return (c->ix.kpre && c->ix.kmap) ? 1 : 0;
 }
 
 extern "C" int rk_set_depth_filter(rk_ctx* c, rk_counter* counter, int min_kmer_occ) {

@@ -1355,3 +1355,103 @@ def test_hpv16_cli_matches_committed_golden(root, data_dir, golden_dir, tmp_path
     assert r.stdout.decode().splitlines(keepends=True) == g["stdout_lines"]
     assert [l for l in r.stderr.decode().splitlines() if l.startswith("\t") or "kmer table created" in l] == g["stderr_tables"]
     assert hashlib.sha256((tmp_path / "lineage_specific_hashes.16.tst").read_bytes()).hexdigest() == g["tst_sha256"]
+
+
+@pytest.mark.parametrize("k,fold,drop", [(16, 0, 1), (16, 1, 1), (16, 2, 0), (16, 0, 0), (12, 0, 1), (12, 1, 0)])
+def test_kmer_space_form_every_policy(orc, pave, k, fold, drop):
+    """The k-mer-space form of the fused kernel (MODE_ 5: windows filtered and resolved by packed k-mer, no hashing) for every
+    fold / window policy and both k it exists for: active, and every row equal to the oracle on 150 bp reads (plain tiles),
+    reads of unequal length with N / lower case (the other loop form inside the same kernel) and reads shorter than k."""
+    import rkmh_amd
+    from rkmh_amd import synth
+    _, rb, ro = pave
+    T = min(16, os.cpu_count() or 1)
+    pol = orc.default_policy(fold=fold, drop_last_window=drop)
+    c = rkmh_amd.Context(0, fold=fold, drop_last_window=drop)
+    try:
+        c.set_references(rb, ro, [k], 1000)
+        active, found = c.kmer_form()
+        assert active and found > 100000
+        sk, ln = c.get_reference_sketches()
+        wsk, wln = orc.sketch_refs(rb, ro, [k], 1000, policy=pol, threads=T)
+        assert (sk == wsk).all() and (ln == wln).all()
+        qb, qo = synth.generate_reads_fast(rb, ro, 7000, 7000 + 60000)
+        want = orc.classify_stream(qb, qo, [k], 1000, wsk, wln, policy=pol, threads=T)
+        got = c.classify(_pad(qb), qo)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, (len(bad), got[bad[:3]], want[bad[:3]])
+        rng = np.random.default_rng(k * 10 + fold)
+        reads = []
+        for i in range(3000):
+            L = int(rng.integers(0, 170))
+            a = int(rng.integers(0, len(rb) - 400))
+            r = bytearray(bytes(rb[a: a + L]))
+            if i % 7 == 0 and L > 3:
+                r[int(rng.integers(0, L))] = ord("N")
+            reads.append(bytes(r))
+        qb2, qo2 = orc.pack(reads)
+        want = orc.classify_stream(qb2, qo2, [k], 1000, wsk, wln, policy=pol, threads=T)
+        got = c.classify(_pad(qb2), qo2)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, (len(bad), got[bad[:3]], want[bad[:3]])
+    finally:
+        c.close()
+
+
+def test_kmer_space_form_with_imported_sketches_and_keys_without_a_preimage(orc):
+    """The enumeration works from the sketch HASHES alone: imported sketches (the multi-GPU broadcast, -R files) get the k-mer-space
+    form too, and a sketch hash that no k-mer of the universe produces (random 64-bit values here) simply never matches --
+    exactly what the oracle's merge says."""
+    import rkmh_amd
+    rng = np.random.default_rng(11)
+    genome = rand_dna(rng, 30000, b"ACGT")
+    refs = [genome[i * 5000: i * 5000 + 6000] for i in range(5)]
+    S = 512
+    sk = np.zeros((len(refs) + 1, S), dtype=np.uint64)
+    ln = np.zeros(len(refs) + 1, dtype=np.int32)
+    for i, r in enumerate(refs):
+        m = orc.minhashes(orc.calc_hashes(r, [16]), S)
+        m[::3] = np.sort(rng.integers(1, 2**63, size=len(m[::3]), dtype=np.uint64))   # a third of the entries: no preimage
+        m = np.sort(m)
+        sk[i, : len(m)] = m
+        ln[i] = len(m)
+    fake = np.sort(rng.integers(1, 2**63, size=S, dtype=np.uint64))                    # a reference made of nothing real
+    sk[-1] = fake
+    ln[-1] = S
+    reads = [genome[a: a + 150] for a in rng.integers(0, len(genome) - 150, size=5000)]
+    qb, qo = orc.pack(reads)
+    c = rkmh_amd.Context(0)
+    try:
+        c.set_reference_sketches(sk, ln, [16], S)
+        active, found = c.kmer_form()
+        real = len(np.unique(np.concatenate([orc.calc_hashes(r, [16]) for r in refs])))
+        assert active and 0 < found < real   # only keys that ARE some k-mer's hash were found
+        want = orc.classify_stream(qb, qo, [16], S, sk, ln, threads=8)
+        got = c.classify(_pad(qb), qo)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, (len(bad), got[bad[:3]], want[bad[:3]])
+        assert (want[:, 1] > 0).mean() > 0.5 and (want[:, 0] != len(refs)).all()
+    finally:
+        c.close()
+
+
+def test_kmer_space_form_steps_aside_when_the_map_cannot_be_built(orc, pave):
+    """If two k-mers ever shared a sketch hash the exact k-mer map is not built and the hash-space kernels serve the panel (forced
+    here through RKMH_KMAP_FORCE_DUP): same rows."""
+    import rkmh_amd
+    from rkmh_amd import synth
+    _, rb, ro = pave
+    qb, qo = synth.generate_reads_fast(rb, ro, 100, 20100)
+    rows = []
+    for force in (False, True):
+        if force:
+            os.environ["RKMH_KMAP_FORCE_DUP"] = "1"
+        try:
+            c = rkmh_amd.Context(0)
+            c.set_references(rb, ro, [16], 1000)
+            assert c.kmer_form()[0] == (not force)
+            rows.append(c.classify(_pad(qb), qo))
+            c.close()
+        finally:
+            os.environ.pop("RKMH_KMAP_FORCE_DUP", None)
+    assert (rows[0] == rows[1]).all()
