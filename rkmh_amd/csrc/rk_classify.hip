@@ -104,8 +104,8 @@ __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes 
 // packed 2-bit image of one strand of a tile: 16 bases per dword, + the dword a window's 64-bit read may touch past the end
 __host__ __device__ inline int tile_pk_dwords(int cap_bytes) { return cap_bytes / 16 + 3; }
 __host__ __device__ inline size_t tile_lds_bytes(const TileGeom& g) {
-    // queue region: 16-byte entries {hash, read}, or (kpre) two packed images + 4-byte entries + the 128-dword multi-posting list
-    const size_t q_dw = g.kpre ? 2 * (size_t)tile_pk_dwords(g.cap_bytes) + (size_t)g.qcap + 128 : 4 * (size_t)g.qcap;
+    // queue region: 16-byte entries {hash, read}, or (kpre) two packed images + 8-byte entries {k-mer, read} + the 128-dword multi-posting list
+    const size_t q_dw = g.kpre ? 2 * (size_t)tile_pk_dwords(g.cap_bytes) + 2 * (size_t)g.qcap + 128 : 4 * (size_t)g.qcap;
     return ((size_t)((stage_lds_dwords(g.cap_bytes) + 3) & ~3) + q_dw + 5 * (size_t)(g.T + 1) + 8 +
             2 * (size_t)tile_map_words(g.cap_bytes) +
             (size_t)g.T * (size_t)(g.cwords + g.dset)) * 4;
@@ -211,12 +211,12 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
     // candidate queue: one 16-byte entry per window {hash lo, hash hi, read within the tile, -} (one ds_write_b128)
     uint4* qe = reinterpret_cast<uint4*>(stage + ((stage_lds_dwords(geo.cap_bytes) + 3) & ~3));
     // MODE_ 5 lays the same region out as: packed image of the forward string, of the reverse-complement string, the queue
-    // of 4-byte entries (tile byte position | read << 16), the multi-posting list
+    // of 8-byte entries {canonical packed k-mer, read}, the multi-posting list
     const int pkdw = tile_pk_dwords(geo.cap_bytes);
     uint32_t* pk_f = reinterpret_cast<uint32_t*>(qe);
     uint32_t* pk_r = pk_f + pkdw;
-    uint32_t* q32 = pk_r + pkdw;
-    uint32_t* rstart = KPRE ? q32 + QCAP + 128 : reinterpret_cast<uint32_t*>(qe + QCAP);   // [T+1] byte offset of read t inside the tile
+    uint2* q64 = reinterpret_cast<uint2*>(pk_r + pkdw + ((2 * pkdw) & 1));   // 8-byte aligned: {canonical packed k-mer, read}
+    uint32_t* rstart = KPRE ? reinterpret_cast<uint32_t*>(q64 + QCAP) + 128 : reinterpret_cast<uint32_t*>(qe + QCAP);   // [T+1] byte offset of read t inside the tile
     uint32_t* nwin = rstart + (T + 1);                           // [T+1] windows of read t (all k)
     uint32_t* nzero = nwin + (T + 1);                            // [T+1] zero hashes per read
     uint32_t* best = nzero + (T + 1);                            // [T+1] max over increments of (count << 16 | 0xFFFF - ref)
@@ -228,9 +228,10 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
     uint32_t* dset = c16 + T * geo.cwords;                       // [T][DS] multiset of the slots the read has hit
     // [64][2] hits with several postings (drain).  Aliases the first 32 queue entries: a drain step has its 64
     // entries in registers before it writes here, and entries left for later sit at index >= 64.
-    uint32_t* mq = KPRE ? q32 + QCAP : reinterpret_cast<uint32_t*>(qe);
+    uint32_t* mq = KPRE ? reinterpret_cast<uint32_t*>(q64 + QCAP) : reinterpret_cast<uint32_t*>(qe);
     const int lane = threadIdx.x;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t kp_sr = 2u * ((uint32_t)lane & 3u), kp_sf = 6u - kp_sr; // MODE_ 5: this lane's alignment in the filter (see kpre_word_off_s)
     const uint32_t clg = (uint32_t)geo.clg, cper_m1 = (1u << clg) - 1u, cbits = 32u >> clg, cmask = (1u << cbits) - 1u;
 
     if (MODE != 1) { // counters are re-zeroed by phase 2 after use
@@ -503,12 +504,10 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                 bool multi = false;
                 if (e < qn) {
                     if constexpr (KPRE) {
-                        // queued by position and resolved by K-MER: the packed canonical k-mer is looked up in the exact map the
+                        // queued as {canonical packed k-mer, read} and resolved by K-MER: the k-mer is looked up in the exact map the
                         // enumeration produced (two independent 16-byte loads, four 32-bit compares) -- no hash is computed
-                        const uint32_t ce = q32[e];
-                        const uint32_t p = ce & 0xFFFFu, t = ce >> 16;
-                        const uint32_t vf = packed_window<KT>(pk_f, p), vr = packed_window<KT>(pk_r, B - (uint32_t)KT - p);
-                        const uint32_t key = vf < vr ? vf : vr;
+                        const uint2 ce = q64[e];
+                        const uint32_t key = ce.x, t = ce.y;
                         const uint32_t b1 = kmap_cell1(key, ix.kmap_m), b2 = kmap_cell2(key, ix.kmap_m);
                         const uint4 c1 = ix.kmap[b1], c2 = ix.kmap[b2];
                         uint32_t val = 0, id = KMAP_EMPTY;
@@ -599,10 +598,10 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                 wave_sync();
                 if (last) { qcount = 0; return; }
                 const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
-                uint32_t ce = 0u;
-                if ((uint32_t)lane < rem) ce = q32[qn + lane];
+                uint2 ce = make_uint2(0u, 0u);
+                if ((uint32_t)lane < rem) ce = q64[qn + lane];
                 wave_sync();
-                if ((uint32_t)lane < rem) q32[lane] = ce;
+                if ((uint32_t)lane < rem) q64[lane] = ce;
                 qcount = rem;
                 wave_sync();
             };
@@ -620,44 +619,53 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                     word_wait(fw);
                     for (uint32_t c0 = 0; c0 < nIt; c0 += KCH) {
                         const uint32_t len = nIt - c0 < (uint32_t)KCH ? nIt - c0 : (uint32_t)KCH;
-                        uint32_t xv[KCH], fwv[KCH];
+                        uint32_t xv[KCH], offv[KCH], fwv[KCH];
 #pragma unroll
-                        for (int j = 0; j < KCH; ++j) { xv[j] = 0u; fwv[j] = 0u; }
-#pragma unroll
-                        for (int j = 0; j < KCH; ++j) {
+                        for (int j = 0; j < KCH; ++j) { // canonical k-mer and filter word address of every window of the chunk
+                            uint32_t key = 0u, off = 0u;
                             if ((uint32_t)j < len) { // wave-uniform
                                 const uint32_t w = (c0 + (uint32_t)j) * WAVE + (uint32_t)lane;
-                                uint32_t x = 0u, off = 0u;
                                 if (w < nW) {
                                     const uint32_t t_ = __umulhi(w, magic);
                                     const uint32_t p_ = w + __umul24(t_, dtail);
                                     const uint32_t vf = packed_window<KT>(pk_f, p_);
                                     const uint32_t vr = packed_window<KT>(pk_r, B - (uint32_t)KT - p_);
-                                    x = kpre_mix(vf < vr ? vf : vr);
-                                    off = kpre_word_off(vf, vr, p_ & 3u, KT, x, ix.kpshift);
+                                    key = vf < vr ? vf : vr;
+                                    off = kpre_word_off_s(vf, vr, kp_sf, kp_sr, KT, kpre_mix(key), ix.kpshift);
+                                    if RK_DBG(2048) off &= 0x7Cu;   // TIMING EXPERIMENT (wrong results): every probe of the wave in one cache line
                                 }
-                                if RK_DBG(2048) off &= 0x7Cu;   // TIMING EXPERIMENT (wrong results): every probe of the wave in one cache line
-                                if RK_DBG(8192) off = ((uint32_t)__shfl((int)off, lane & ~3) & ~0x7Fu) | (off & 0x7Cu);  // ... groups of 4 lanes share a line
-                                if RK_DBG(16384) off = ((uint32_t)__shfl((int)off, lane & ~7) & ~0x7Fu) | (off & 0x7Cu); // ... groups of 8
-                                xv[j] = x;
-                                word_load_async_ws(ix.kpre, off, fwv[j]);
                             }
+                            xv[j] = key; offv[j] = off;
                         }
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(fwv[0]), "+v"(fwv[1]), "+v"(fwv[2]), "+v"(fwv[3]), "+v"(fwv[4]) : : "memory");
-                        static_assert(KCH == 5, "the wait statement names the chunk's registers");
+                        // The chunk's filter words: five loads issued back to back and retired by the wait in ONE asm statement, so
+                        // hipcc cannot place anything -- in particular no copy of a destination register -- between issue and wait
+                        // (it did, once the register pressure changed; tools/lint_async_loads.py caught it).  Outputs are early-
+                        // clobber: a load may land while a later one is still being issued.  s_nop 4: the "s" base may have been
+                        // re-materialised by a VALU v_readlane right before (see word_load_async_ws).  Steps past the tile's end
+                        // load word 0 and are ignored.
+                        static_assert(KCH == 5, "the asm statement names the chunk's registers");
+                        asm volatile("s_nop 4\n\t"
+                                     "global_load_dword %0, %5, %10\n\t"
+                                     "global_load_dword %1, %6, %10\n\t"
+                                     "global_load_dword %2, %7, %10\n\t"
+                                     "global_load_dword %3, %8, %10\n\t"
+                                     "global_load_dword %4, %9, %10\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(fwv[0]), "=&v"(fwv[1]), "=&v"(fwv[2]), "=&v"(fwv[3]), "=&v"(fwv[4])
+                                     : "v"(offv[0]), "v"(offv[1]), "v"(offv[2]), "v"(offv[3]), "v"(offv[4]), "s"(ix.kpre)
+                                     : "memory");
 #pragma unroll
                         for (int j = 0; j < KCH; ++j) {
                             if ((uint32_t)j < len) {
                                 if (qcount + WAVE > QCAP) drain_now(false);
                                 const uint32_t w = (c0 + (uint32_t)j) * WAVE + (uint32_t)lane;
-                                const uint32_t bm = kpre_bits(xv[j]);
+                                const uint32_t bm = kpre_bits(kpre_mix(xv[j]));
                                 bool cand = w < nW && (fwv[j] & bm) == bm;
                                 if RK_DBG(4096) cand = false;   // TIMING EXPERIMENT (wrong results): probes only, nothing reaches the drain
                                 const uint64_t m = __ballot(cand);
                                 if (cand) {
-                                    const uint32_t t_ = __umulhi(w, magic);
                                     const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                                    q32[q] = (w + __umul24(t_, dtail)) | (t_ << 16);
+                                    q64[q] = make_uint2(xv[j], __umulhi(w, magic));
                                 }
                                 qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
                             }
@@ -749,7 +757,10 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                         const uint64_t m = __ballot(cand);
                         if (cand) {
                             const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            if constexpr (KPRE) q32[q] = pp | (tp << 16); // tiles that are not plain: queued by position as well
+                            if constexpr (KPRE) { // tiles that are not plain: queued as {k-mer, read} as well
+                                const uint32_t vf = packed_window<KT>(pk_f, pp), vr = packed_window<KT>(pk_r, B - (uint32_t)KT - pp);
+                                q64[q] = make_uint2(vf < vr ? vf : vr, tp);
+                            }
                             else qe[q] = make_uint4((uint32_t)hp, (uint32_t)(hp >> 32), tp, 0u);
                         }
                         qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
@@ -805,10 +816,10 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                 if (last) { qcount = 0; break; }
                 const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
                 if constexpr (KPRE) {
-                    uint32_t ce = 0u;
-                    if ((uint32_t)lane < rem) ce = q32[qn + lane];
+                    uint2 ce = make_uint2(0u, 0u);
+                    if ((uint32_t)lane < rem) ce = q64[qn + lane];
                     wave_sync();
-                    if ((uint32_t)lane < rem) q32[lane] = ce;
+                    if ((uint32_t)lane < rem) q64[lane] = ce;
                 } else {
                 uint4 ce = make_uint4(0u, 0u, 0u, 0u);
                 if ((uint32_t)lane < rem) ce = qe[qn + lane];

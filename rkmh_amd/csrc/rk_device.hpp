@@ -104,11 +104,18 @@ __host__ __device__ __forceinline__ uint32_t kpre_bits(uint32_t x) { return (1u 
 // substring and its reverse complement (strand-symmetric); the word inside the line comes from the k-mer's own mix x.  A key is
 // therefore entered under its four possible alignments (j = 0..3, which also covers its occurrence on the other strand).
 //   vf / vr: packed window and packed reverse-complement window;  j = position & 3;  kplines = lines - 1 (power of two)
-__host__ __device__ __forceinline__ uint32_t kpre_word_off(uint32_t vf, uint32_t vr, uint32_t j, int k, uint32_t x, uint32_t kplg) {
+// sf = 2 * (3 - j), sr = 2 * j: the shifts that bring the shared substring of alignment j to bit 0 of the window / of its
+// reverse complement.  ANY j in 0..3 finds a key (all four are entered); which one a lane uses only decides how well a wave's
+// probes coalesce, so the fused kernel takes j = lane & 3 -- per-lane constants -- which is the alignment of four consecutive
+// windows whenever a lane quad lies inside one read.
+__host__ __device__ __forceinline__ uint32_t kpre_word_off_s(uint32_t vf, uint32_t vr, uint32_t sf, uint32_t sr, int k, uint32_t x, uint32_t kplg) {
     const uint32_t msk = (1u << (2 * (k - 3))) - 1u;                    // k <= 16: at most 26 bits
-    const uint32_t a = (vf >> (2u * (3u - j))) & msk, b = (vr >> (2u * j)) & msk;
+    const uint32_t a = (vf >> sf) & msk, b = (vr >> sr) & msk;
     const uint32_t c = (a < b ? a : b) * 0x85EBCA6Bu;
     return ((c >> (32u - kplg)) << 7) | ((x >> 25) << 2 & 0x7Cu);       // byte offset: line * 128 + word-in-line * 4
+}
+__host__ __device__ __forceinline__ uint32_t kpre_word_off(uint32_t vf, uint32_t vr, uint32_t j, int k, uint32_t x, uint32_t kplg) {
+    return kpre_word_off_s(vf, vr, 2u * (3u - j), 2u * j, k, x, kplg);
 }
 // reverse complement of a packed k-mer (k <= 16)
 __host__ __device__ __forceinline__ uint32_t packed_revcomp(uint32_t v, int k) {
