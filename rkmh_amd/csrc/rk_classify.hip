@@ -102,7 +102,9 @@ struct TileGeom {
 
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
 // packed 2-bit image of one strand of a tile: 16 bases per dword, + the dword a window's 64-bit read may touch past the end
-__host__ __device__ inline int tile_pk_dwords(int cap_bytes) { return cap_bytes / 16 + 3; }
+// ... and, for the forward string, 16 positions of padding in front (position of tile base b = 16 + fbase + b): the words of the
+// reverse-complement image are cut from it at positions that may precede the tile by up to 15
+__host__ __device__ inline int tile_pk_dwords(int cap_bytes) { return cap_bytes / 16 + 4; }
 __host__ __device__ inline size_t tile_lds_bytes(const TileGeom& g) {
     // queue region: 16-byte entries {hash, read}, or (kpre) two packed images + 8-byte entries {k-mer, read} + the 128-dword multi-posting list
     const size_t q_dw = g.kpre ? 2 * (size_t)tile_pk_dwords(g.cap_bytes) + 2 * (size_t)g.qcap + 128 : 4 * (size_t)g.qcap;
@@ -343,7 +345,11 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                 const uint32_t jf = (uint32_t)q * WAVE + (uint32_t)lane;
                 const bool in = jf >= 1 && jf <= ndw;
                 const uint32_t x = in ? upper4(pf[q]) : 0u;
-                if (jf <= ndw) s.fwd[jf] = x;
+                if constexpr (KPRE) { // packed forward image straight from the registers: fwd-image dword jf = packed byte 4 + jf
+                    if (jf <= ndw) reinterpret_cast<uint8_t*>(pk_f)[4u + jf] = (uint8_t)pack4(x);
+                } else {
+                    if (jf <= ndw) s.fwd[jf] = x;
+                }
                 uint32_t m = in ? ~0u : 0u;
                 if (jf == 1) m &= m_first;
                 if (jf == ndw) m &= m_last;
@@ -352,9 +358,29 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
         }
         cur_a = nxt_a; cur_b = nxt_b; cur_o = nxt_o;
         const bool has_invalid = __ballot(anyinv != 0u) != 0ull;
+        // "plain" tiles (all reads equally long, no invalid base, at least two windows per read: the common case) need neither the
+        // start bitmap nor the position -> read map -- and, in MODE_ 5 kernels, no byte images at all: nothing is hashed
+        uint32_t nw_min;
+        if (KT) nw_min = (uint32_t)num_windows((int)ulen, KT, pol.drop_last_window);
+        else {
+            nw_min = ~0u;
+            for (int j = 0; j < ks.n; ++j) { const uint32_t v = (uint32_t)num_windows((int)ulen, ks.k[j], pol.drop_last_window); nw_min = v < nw_min ? v : nw_min; }
+        }
+        const bool plain = uniform && !has_invalid && nw_min >= 2u; // >= 2: the compact mapping divides by the window count
+        if constexpr (KPRE) {
+            if (!plain) { // the other loop form hashes: it needs the upper-cased byte image after all (the registers still hold the tile)
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+                    if ((uint32_t)q * WAVE <= ndw) {
+                        const uint32_t jf = (uint32_t)q * WAVE + (uint32_t)lane;
+                        if (jf <= ndw) s.fwd[jf] = (jf >= 1) ? upper4(pf[q]) : 0u;
+                    }
+                }
+            }
+        }
         wave_sync();
         // ---- phase 0, interval 2: reverse-complement image; for the rare tile with a non-ACGT base the validity bitmap ----
-        {
+        if (!KPRE || !plain) {
             const uint32_t nrc = (B + 3) >> 2;
             for (uint32_t q = lane; q < nrc; q += WAVE) { // rc dword q = reversed complement of fwd bytes [fbase+B-4-4q, +4)
                 const uint32_t pp_ = s.fbase + B - 4u - 4u * q; // >= fbase - 3: the pad dword in front absorbs it
@@ -384,16 +410,6 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
             }
         };
         wave_sync();
-        // "plain" tiles (all reads equally long, no invalid base: the common case) need neither the start bitmap nor
-        // the position -> read map; the others build both now
-        // ... and at least one window per read
-        uint32_t nw_min;
-        if (KT) nw_min = (uint32_t)num_windows((int)ulen, KT, pol.drop_last_window);
-        else {
-            nw_min = ~0u;
-            for (int j = 0; j < ks.n; ++j) { const uint32_t v = (uint32_t)num_windows((int)ulen, ks.k[j], pol.drop_last_window); nw_min = v < nw_min ? v : nw_min; }
-        }
-        const bool plain = uniform && !has_invalid && nw_min >= 2u; // >= 2: the compact mapping divides by the window count
         if (!plain) {
             for (uint32_t i = lane; i < bad_words; i += WAVE) bad[i] = 0;
             for (uint32_t c = lane; c * 32 < B; c += WAVE) { // chunk map: last read starting at or before byte 32c
@@ -406,14 +422,11 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
             mark_tails(KT ? KT : ks.k[0]);
             wave_sync();
         }
-        if constexpr (KPRE) { // packed 2-bit images of both strings: byte q = bases [4q, 4q + 4) (every tile: the drain resolves candidates by k-mer)
-            const uint32_t nq = (B + 3) >> 2;
-            for (uint32_t q = lane; q < 4u * (uint32_t)pkdw; q += WAVE) {
-                uint32_t bf = 0, br = 0;
-                if (q < nq) { bf = pack4(lds_load4_unaligned(s.fwd, s.fbase + 4u * q)); br = pack4(s.rc[q]); }
-                reinterpret_cast<uint8_t*>(pk_f)[q] = (uint8_t)bf;
-                reinterpret_cast<uint8_t*>(pk_r)[q] = (uint8_t)br;
-            }
+        const uint32_t pkoff = 16u + s.fbase; // MODE_ 5: packed position of tile base 0 in pk_f
+        if constexpr (KPRE) { // packed reverse-complement image, 16 bases per word, cut from the packed forward image
+            const uint32_t nrw = (B + 15u) >> 4;
+            for (uint32_t j = lane; j < nrw; j += WAVE) // word j = rc positions [16j, 16j + 16) = forward positions [B - 16j - 16, B - 16j)
+                pk_r[j] = packed_revcomp(packed_window<16>(pk_f, pkoff + B - 16u * (j + 1u)), 16);
             wave_sync();
         }
         // the next tile's bases travel while this tile is hashed (MODE_ 5 kernels request them after their hashing loop instead)
@@ -628,7 +641,7 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                                 if (w < nW) {
                                     const uint32_t t_ = __umulhi(w, magic);
                                     const uint32_t p_ = w + __umul24(t_, dtail);
-                                    const uint32_t vf = packed_window<KT>(pk_f, p_);
+                                    const uint32_t vf = packed_window<KT>(pk_f, pkoff + p_);
                                     const uint32_t vr = packed_window<KT>(pk_r, B - (uint32_t)KT - p_);
                                     key = vf < vr ? vf : vr;
                                     off = kpre_word_off_s(vf, vr, kp_sf, kp_sr, KT, kpre_mix(key), ix.kpshift);
@@ -758,7 +771,7 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                         if (cand) {
                             const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                             if constexpr (KPRE) { // tiles that are not plain: queued as {k-mer, read} as well
-                                const uint32_t vf = packed_window<KT>(pk_f, pp), vr = packed_window<KT>(pk_r, B - (uint32_t)KT - pp);
+                                const uint32_t vf = packed_window<KT>(pk_f, pkoff + pp), vr = packed_window<KT>(pk_r, B - (uint32_t)KT - pp);
                                 q64[q] = make_uint2(vf < vr ? vf : vr, tp);
                             }
                             else qe[q] = make_uint4((uint32_t)hp, (uint32_t)(hp >> 32), tp, 0u);
