@@ -766,7 +766,11 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                     if constexpr (PRE) { // large panel: the filter word decides what the drain will look up in the table
                         word_wait(fw);
                         const uint32_t bm = index_pre_bits(hp);
-                        const bool cand = (fw & bm) == bm;
+                        // MODE_ 5 queues a lane's K-MER, so a lane without a window (hp = 0: read tails, the end of the tile) must
+                        // not be queued even if the filter word of hash 0 happens to pass: in the hash-queue form that entry was
+                        // looked up as hash 0 and found nothing; here it would be the k-mer at that lane's position, for read 0
+                        // (found by the randomized soak: over-counts on the first read of tiles of unequal reads under len-k)
+                        const bool cand = (fw & bm) == bm && (!KPRE || hp != 0);
                         const uint64_t m = __ballot(cand);
                         if (cand) {
                             const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));

@@ -882,7 +882,12 @@ _RAND_LENS = [0, 3, 15, 16, 17, 60, 150, 150, 150, 300, 800, 1528, 1529, 1700] +
 _SEED_BASE = int(os.environ.get("RKMH_TEST_SEED_BASE", "0"))
 
 
-@pytest.mark.parametrize("seed", range(_SEED_BASE, _SEED_BASE + int(os.environ.get("RKMH_TEST_SEEDS", "48"))))
+# seeds that once failed (kept forever): 500118 = k-mer-space form, tiles of unequal reads under len-k: lanes without a window were
+# queued with the k-mer at their position (a read's dropped last window is a real sketch k-mer) and counted for read 0
+_REGRESSION_SEEDS = [500118]
+
+
+@pytest.mark.parametrize("seed", list(range(_SEED_BASE, _SEED_BASE + int(os.environ.get("RKMH_TEST_SEEDS", "48")))) + _REGRESSION_SEEDS)
 def test_randomized_differential(orc, seed):
     """Random ragged batches (lengths 0..1700, lower case, N runs, repeats, shared and duplicated references, 1-3 k-mer
     sizes, tiny to large sketches, every fold / window policy, with and without -M) against the oracle."""
@@ -1455,3 +1460,35 @@ def test_kmer_space_form_steps_aside_when_the_map_cannot_be_built(orc, pave):
         finally:
             os.environ.pop("RKMH_KMAP_FORCE_DUP", None)
     assert (rows[0] == rows[1]).all()
+
+
+def test_idle_lanes_never_reach_the_drain_as_kmers(orc, pave):
+    """Regression (k-mer-space form, the loop form for tiles that are not plain): with a SATURATED hash-space filter every lane
+    passes it, including lanes that hold no window.  Such a lane must not be queued: its entry would be the k-mer at the lane's
+    position -- under len-k the dropped last window of a read is a real sketch k-mer -- counted for read 0 of the tile."""
+    import rkmh_amd
+    _, rb, ro = pave
+    T = min(16, os.cpu_count() or 1)
+    rng = np.random.default_rng(8)
+    reads = []
+    for i in range(4000):   # error-free reads cut from the references (their last window hits with high probability), lengths 99 / 100
+        r = int(rng.integers(0, len(ro) - 1))
+        L = 100 - (i % 2)
+        a = int(rng.integers(int(ro[r]), int(ro[r + 1]) - L))
+        reads.append(orc.to_upper(bytes(rb[a: a + L])))
+    qb, qo = orc.pack(reads)
+    os.environ["RKMH_PRE_MAXKB"] = "16"          # 131072 filter bits for 163 k keys x 2 bits: ~92 % of the bits set
+    try:
+        for drop in (1, 0):
+            c = rkmh_amd.Context(0, drop_last_window=drop)
+            pol = orc.default_policy(drop_last_window=drop)
+            c.set_references(rb, ro, [16], 1000)
+            assert c.kmer_form()[0]
+            sk, ln = c.get_reference_sketches()
+            want = orc.classify_stream(qb, qo, [16], 1000, sk, ln, policy=pol, threads=T)
+            got = c.classify(_pad(qb), qo)
+            bad = np.nonzero((got != want).any(axis=1))[0]
+            assert len(bad) == 0, (drop, len(bad), bad[:8], got[bad[:4]], want[bad[:4]])
+            c.close()
+    finally:
+        os.environ.pop("RKMH_PRE_MAXKB", None)
