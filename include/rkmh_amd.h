@@ -165,6 +165,9 @@ int rk_num_references(const rk_ctx* ctx);
  * is a sketch hash -- or 0 -- is known, so windows are filtered and resolved by k-mer and never hashed), 0 for the hash-space
  * form, negative on error.  *kmers_found (may be NULL) = k-mers the enumeration found (one per strand pair). */
 int rk_kmer_form(const rk_ctx* ctx, uint32_t* kmers_found);
+/* Whether the NEXT rk_set_references / rk_set_reference_sketches may build the k-mer-space form (default 1).  A caller that only
+ * uses the general kernels on these references (hpv16's rk_classify_groups_batch) saves the enumeration by passing 0. */
+int rk_set_kmer_form(rk_ctx* ctx, int enable);
 
 /* Read-depth filter (-M, src/rkmh.cpp:701-704): when set, classify masks hashes whose counter
  * value is below min_kmer_occ (mask_by_frequency, :916) before sketching.  NULL disables. */

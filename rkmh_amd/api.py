@@ -69,6 +69,7 @@ _SIGS = {
     "rk_counter_get": (C.c_int, [C.c_void_p, C.c_uint64, _i32p]),
     "rk_classify_groups_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "rk_kmer_form": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "rk_set_kmer_form": (C.c_int, [C.c_void_p, C.c_int]),
     "rk_device_props": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rk_counter_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rk_counter_load": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -461,6 +462,10 @@ class Context:
         out = np.zeros((n, 4), dtype=np.int32)
         _chk(self._lib.rk_classify_batch(self._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), n, _p(out, C.c_int32)))
         return out
+
+    def set_kmer_form(self, enable):
+        """Allow (default) or forbid the k-mer-space form for the references set next."""
+        _chk(self._lib.rk_set_kmer_form(self._h, 1 if enable else 0))
 
     def kmer_form(self):
         """(active, k-mers found by the enumeration): is the k-mer-space form of the fused kernel in use for these references?"""

@@ -106,6 +106,7 @@ struct rk_ctx {
     std::vector<int32_t> h_lens;
     DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_kpre, d_kmap;
     uint32_t kpre_inserted = 0; // k-mers the enumeration put into the k-mer-space filter (diagnostic)
+    bool kmer_form_allowed = true; // rk_set_kmer_form
     RefIndex ix{};
     bool have_refs = false;
     double density = 1.0; // fraction of a reference's k-mers that its sketch keeps (largest over references)
@@ -922,7 +923,7 @@ static int build_index(rk_ctx* c) {
     // per-window probe goes to a 1-2 MB bit array whatever the panel, are faster (measured: 1000 references 1.55 vs 1.06 ms).
     size_t kpre_max_keys = 6000000;
     if (const char* e = getenv("RKMH_KPRE_MAXKEYS")) { long v = atol(e); if (v >= 0) kpre_max_keys = (size_t)v; }
-    if (kpre_mode > 0 && c->ks.n == 1 && (c->ks.k[0] == 12 || c->ks.k[0] == 16) && distinct <= kpre_max_keys) {
+    if (kpre_mode > 0 && c->kmer_form_allowed && c->ks.n == 1 && (c->ks.k[0] == 12 || c->ks.k[0] == 16) && distinct <= kpre_max_keys) {
         size_t bits_per_key = 32, max_words = (size_t)16384 * 256;
         if (const char* e = getenv("RKMH_KPRE_BITS")) { long v = atol(e); if (v >= 2 && v <= 256) bits_per_key = (size_t)v; }
         if (const char* e = getenv("RKMH_KPRE_MAXKB")) { long v = atol(e); if (v >= 16 && v <= (1 << 20)) max_words = (size_t)v * 256; }
@@ -1063,6 +1064,11 @@ extern "C" int rk_set_reference_count_mode(rk_ctx* c, int mode) {
     return RK_OK;
 }
 
+extern "C" int rk_set_kmer_form(rk_ctx* c, int enable) {
+    if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
+    c->kmer_form_allowed = enable != 0;
+    return RK_OK;
+}
 extern "C" int rk_kmer_form(const rk_ctx* c, uint32_t* kmers_found) {
     if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
     if (!c->have_refs) return fail(RK_ERR_STATE, "no references set");

@@ -917,6 +917,7 @@ static int main_hpv16(int argc, char** argv) {
     for (int i = 0; i < nlin; ++i) { put(ntype + i, lin_lists[(size_t)i]); full_len[(size_t)(ntype + i)] = lin_lists[(size_t)i].size(); }
     for (int i = 0; i < nsub; ++i) { put(ntype + nlin + i, sublin_lists[(size_t)i]); full_len[(size_t)(ntype + nlin + i)] = sublin_lists[(size_t)i].size(); }
     rk_free(th); rk_free(sh);
+    CK(rk_set_kmer_form(ctx, 0));   // these "references" are only used through the general kernels: no need to enumerate the k-mer universe
     CK(rk_set_reference_sketches(ctx, lists.data(), lens.data(), nref, ks.data(), (int)ks.size(), S));   // reads are hashed with EVERY -k (:2661)
     tick("tables", t0);
     rk_counter* cnt = nullptr;
