@@ -161,7 +161,7 @@ int rk_get_reference_sketches(rk_ctx* ctx, uint64_t* sketches, int32_t* lens);
 int rk_num_references(const rk_ctx* ctx);
 
 /* Which form of the fused kernel plain classification (no -M) will use for the references now set: returns 1 when the
- * k-mer-space form is active (single k of 12 or 16: the 4^k k-mer universe was enumerated and every k-mer whose canonical hash
+ * k-mer-space form is active (single k from 8 to 16: the 4^k k-mer universe was enumerated and every k-mer whose canonical hash
  * is a sketch hash -- or 0 -- is known, so windows are filtered and resolved by k-mer and never hashed), 0 for the hash-space
  * form, negative on error.  *kmers_found (may be NULL) = k-mers the enumeration found (one per strand pair). */
 int rk_kmer_form(const rk_ctx* ctx, uint32_t* kmers_found);

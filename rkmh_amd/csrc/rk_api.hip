@@ -913,7 +913,7 @@ static int build_index(rk_ctx* c) {
         HIPCHK(hipMemcpy(c->d_pre.p, pre.data(), (size_t)pwords * 4, hipMemcpyHostToDevice));
         c->ix.pre = c->d_pre.as<uint32_t>(); c->ix.pmask = pwords - 1;
     }
-    // k-mer-space filter (single k of 12 or 16, the sizes the fused kernel has a packed-k-mer form for): every k-mer of the 4^k
+    // k-mer-space filter (single k of 8..16, the sizes the fused kernel has a packed-k-mer form for): every k-mer of the 4^k
     // universe whose canonical hash is a key (or 0), found by exhaustive enumeration on the device -- see k_enum_kmers.
     // Sized like the hash-space filter (32 bits per key, 2 set).  RKMH_KMER_PREFILTER=0 turns it off (A/B runs, tests).
     c->ix.kpre = nullptr; c->ix.kpshift = 0; c->ix.kpk = 0; c->ix.kmap = nullptr; c->ix.kmap_m = 0; c->kpre_inserted = 0;
@@ -923,7 +923,7 @@ static int build_index(rk_ctx* c) {
     // per-window probe goes to a 1-2 MB bit array whatever the panel, are faster (measured: 1000 references 1.55 vs 1.06 ms).
     size_t kpre_max_keys = 6000000;
     if (const char* e = getenv("RKMH_KPRE_MAXKEYS")) { long v = atol(e); if (v >= 0) kpre_max_keys = (size_t)v; }
-    if (kpre_mode > 0 && c->kmer_form_allowed && c->ks.n == 1 && (c->ks.k[0] == 12 || c->ks.k[0] == 16) && distinct <= kpre_max_keys) {
+    if (kpre_mode > 0 && c->kmer_form_allowed && c->ks.n == 1 && c->ks.k[0] >= KPRE_MIN_K && c->ks.k[0] <= 16 && distinct <= kpre_max_keys) {
         size_t bits_per_key = 32, max_words = (size_t)16384 * 256;
         if (const char* e = getenv("RKMH_KPRE_BITS")) { long v = atol(e); if (v >= 2 && v <= 256) bits_per_key = (size_t)v; }
         if (const char* e = getenv("RKMH_KPRE_MAXKB")) { long v = atol(e); if (v >= 16 && v <= (1 << 20)) max_words = (size_t)v * 256; }

@@ -189,7 +189,7 @@ __device__ __forceinline__ uint32_t pack4(uint32_t x) {
 
 // MODE 0: classify; MODE 1: count pass of -M (rkmh.cpp:904-910); MODE 2: classify with the -M mask (rkmh.cpp:916)
 // MODE_ 3 / 4: MODE 0 / 2 with the first-level filter of large panels (RefIndex::pre) in front of the bucket table
-// MODE_ 5: MODE 0 for a single k of 12 or 16 with the k-mer-space filter (RefIndex::kpre).  The loop over the windows of a plain
+// MODE_ 5: MODE 0 for a single k from 8 to 16 with the k-mer-space filter (RefIndex::kpre).  The loop over the windows of a plain
 //          tile no longer hashes: it extracts the packed 2-bit k-mer of both strands (one 8-byte LDS read + one funnel shift each),
 //          takes the smaller, and tests two bits of a filter that holds EVERY k-mer of the 4^k universe whose canonical hash is a
 //          key of the index or is 0 (filled by exhaustive enumeration when the references are set: k_enum_kmers).  A window that
@@ -974,7 +974,7 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     for (int j = 0; j < ks.n; ++j) win_total += num_windows(maxlen, ks.k[j], pol.drop_last_window);
     // the k-mer-space filter form: plain classification (no -M counter) with the single k the filter was enumerated for
     const bool use_kpre = mode == 0 && !counter && ix.kpre && ix.kmap && ix.pre && ks.n == 1 && (uint32_t)ks.k[0] == ix.kpk &&
-                          (ks.k[0] == 12 || ks.k[0] == 16);
+                          ks.k[0] >= KPRE_MIN_K && ks.k[0] <= 16;
     TileGeom geo = make_geom(maxlen, mode == 1 ? 0 : ix.nref, mode == 1 ? 0 : expect_hits,
                              num_windows(maxlen, ks.k[0], pol.drop_last_window), win_total, use_kpre ? 1 : 0);
     if (mode == 1) { geo.qcap = 0; geo.dset = 0; }
@@ -1026,7 +1026,14 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
         else RK_LAUNCH(KT, 4, FOLD);                                                                                 \
     } while (0)
     // single k of 12, 20 (the reference's other documented settings), 21 or 31: window length known at compile time, runtime fold
-    if (use_kpre && ks.k[0] == 12) RK_LAUNCH(12, 5, -1);
+    if (use_kpre && ks.k[0] == 8) RK_LAUNCH(8, 5, -1);
+    else if (use_kpre && ks.k[0] == 9) RK_LAUNCH(9, 5, -1);
+    else if (use_kpre && ks.k[0] == 10) RK_LAUNCH(10, 5, -1);
+    else if (use_kpre && ks.k[0] == 11) RK_LAUNCH(11, 5, -1);
+    else if (use_kpre && ks.k[0] == 12) RK_LAUNCH(12, 5, -1);
+    else if (use_kpre && ks.k[0] == 13) RK_LAUNCH(13, 5, -1);
+    else if (use_kpre && ks.k[0] == 14) RK_LAUNCH(14, 5, -1);
+    else if (use_kpre && ks.k[0] == 15) RK_LAUNCH(15, 5, -1);
     else if (use_kpre && pol.fold == 0) RK_LAUNCH(16, 5, 0);
     else if (use_kpre && pol.fold == 1) RK_LAUNCH(16, 5, 1);
     else if (use_kpre) RK_LAUNCH(16, 5, 2);

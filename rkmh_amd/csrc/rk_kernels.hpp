@@ -104,6 +104,7 @@ hipError_t launch_scatter_rows(const int32_t* rows, const uint32_t* ids, uint32_
 // mode 0: classify (out4 written); mode 1: count only (counter incremented)
 // wave-per-tile fused kernel (rk_classify.hip); expect_hits sizes the per-read hit multiset
 bool classify_tile_supported(int nref, int maxlen);
+constexpr int KPRE_MIN_K = 8; // the k-mer-space form of the fused kernel exists for a single k in [KPRE_MIN_K, 16]
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st);

@@ -1362,7 +1362,8 @@ def test_hpv16_cli_matches_committed_golden(root, data_dir, golden_dir, tmp_path
     assert hashlib.sha256((tmp_path / "lineage_specific_hashes.16.tst").read_bytes()).hexdigest() == g["tst_sha256"]
 
 
-@pytest.mark.parametrize("k,fold,drop", [(16, 0, 1), (16, 1, 1), (16, 2, 0), (16, 0, 0), (12, 0, 1), (12, 1, 0)])
+@pytest.mark.parametrize("k,fold,drop", [(16, 0, 1), (16, 1, 1), (16, 2, 0), (16, 0, 0), (12, 0, 1), (12, 1, 0), (8, 0, 1), (9, 2, 0),
+                                         (10, 0, 1), (11, 1, 1), (13, 0, 0), (14, 2, 1), (15, 0, 1)])
 def test_kmer_space_form_every_policy(orc, pave, k, fold, drop):
     """The k-mer-space form of the fused kernel (MODE_ 5: windows filtered and resolved by packed k-mer, no hashing) for every
     fold / window policy and both k it exists for: active, and every row equal to the oracle on 150 bp reads (plain tiles),
@@ -1376,7 +1377,7 @@ def test_kmer_space_form_every_policy(orc, pave, k, fold, drop):
     try:
         c.set_references(rb, ro, [k], 1000)
         active, found = c.kmer_form()
-        assert active and found > 100000
+        assert active and found > (100000 if k >= 12 else 1000)   # (4^8 / 2 k-mers exist at k = 8)
         sk, ln = c.get_reference_sketches()
         wsk, wln = orc.sketch_refs(rb, ro, [k], 1000, policy=pol, threads=T)
         assert (sk == wsk).all() and (ln == wln).all()
