@@ -105,10 +105,15 @@ __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes 
 // ... and, for the forward string, 16 positions of padding in front (position of tile base b = 16 + fbase + b): the words of the
 // reverse-complement image are cut from it at positions that may precede the tile by up to 15
 __host__ __device__ inline int tile_pk_dwords(int cap_bytes) { return cap_bytes / 16 + 4; }
+// MODE_ 5 kernels stage no byte images at all (plain tiles hash nothing, the other tiles hash from the packed image): of the staged
+// region only the validity bitmap remains (bit = fwd byte position, as in stage_lds_dwords)
+__host__ __device__ inline int tile_stage_dwords(const TileGeom& g) {
+    return g.kpre ? (FWD_PAD + 3 + g.cap_bytes + 31) / 32 + 2 : stage_lds_dwords(g.cap_bytes);
+}
 __host__ __device__ inline size_t tile_lds_bytes(const TileGeom& g) {
     // queue region: 16-byte entries {hash, read}, or (kpre) two packed images + 8-byte entries {k-mer, read} + the 128-dword multi-posting list
     const size_t q_dw = g.kpre ? 2 * (size_t)tile_pk_dwords(g.cap_bytes) + 2 * (size_t)g.qcap + 128 : 4 * (size_t)g.qcap;
-    return ((size_t)((stage_lds_dwords(g.cap_bytes) + 3) & ~3) + q_dw + 5 * (size_t)(g.T + 1) + 8 +
+    return ((size_t)((tile_stage_dwords(g) + 3) & ~3) + q_dw + 5 * (size_t)(g.T + 1) + 8 +
             2 * (size_t)tile_map_words(g.cap_bytes) +
             (size_t)g.T * (size_t)(g.cwords + g.dset)) * 4;
 }
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
     const uint32_t DS = (uint32_t)geo.dset;
     uint32_t* stage = smem;
     // candidate queue: one 16-byte entry per window {hash lo, hash hi, read within the tile, -} (one ds_write_b128)
-    uint4* qe = reinterpret_cast<uint4*>(stage + ((stage_lds_dwords(geo.cap_bytes) + 3) & ~3));
+    uint4* qe = reinterpret_cast<uint4*>(stage + ((tile_stage_dwords(geo) + 3) & ~3));
     // MODE_ 5 lays the same region out as: packed image of the forward string, of the reverse-complement string, the queue
     // of 8-byte entries {canonical packed k-mer, read}, the multi-posting list
     const int pkdw = tile_pk_dwords(geo.cap_bytes);
@@ -311,6 +316,7 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
             const int fwd_dw = (FWD_PAD + 3 + geo.cap_bytes + TAIL_PAD + 3) / 4;
             const int rc_dw = (geo.cap_bytes + TAIL_PAD + 3) / 4;
             s.fwd = stage; s.rc = stage + fwd_dw; s.inv = s.rc + rc_dw;
+            if constexpr (KPRE) { s.fwd = nullptr; s.rc = nullptr; s.inv = stage; } // no byte images in these kernels
             s.fbase = FWD_PAD + (tstart & 3u); s.nbases = B;
         }
         const uint32_t o_next = (uint32_t)__shfl_down((int)cur_o, 1); // offset of read lane+1
@@ -367,26 +373,31 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
             for (int j = 0; j < ks.n; ++j) { const uint32_t v = (uint32_t)num_windows((int)ulen, ks.k[j], pol.drop_last_window); nw_min = v < nw_min ? v : nw_min; }
         }
         const bool plain = uniform && !has_invalid && nw_min >= 2u; // >= 2: the compact mapping divides by the window count
-        if constexpr (KPRE) {
-            if (!plain) { // the other loop form hashes: it needs the upper-cased byte image after all (the registers still hold the tile)
-#pragma unroll
-                for (int q = 0; q < PF; ++q) {
-                    if ((uint32_t)q * WAVE <= ndw) {
-                        const uint32_t jf = (uint32_t)q * WAVE + (uint32_t)lane;
-                        if (jf <= ndw) s.fwd[jf] = (jf >= 1) ? upper4(pf[q]) : 0u;
-                    }
-                }
-            }
-        }
         wave_sync();
         // ---- phase 0, interval 2: reverse-complement image; for the rare tile with a non-ACGT base the validity bitmap ----
-        if (!KPRE || !plain) {
+        if constexpr (!KPRE) {
             const uint32_t nrc = (B + 3) >> 2;
             for (uint32_t q = lane; q < nrc; q += WAVE) { // rc dword q = reversed complement of fwd bytes [fbase+B-4-4q, +4)
                 const uint32_t pp_ = s.fbase + B - 4u - 4u * q; // >= fbase - 3: the pad dword in front absorbs it
                 s.rc[q] = revcomp4(lds_load4_unaligned(s.fwd, pp_));
             }
         }
+        if constexpr (KPRE) {
+            if (has_invalid) { // the same bitmap, from the prefetched dwords (still in registers: the next tile is requested after the loop)
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+                    if ((uint32_t)q * WAVE <= ndw) { // wave-uniform
+                        const uint32_t jf = (uint32_t)q * WAVE + (uint32_t)lane;
+                        const uint32_t x = (jf >= 1 && jf <= ndw) ? upper4(pf[q]) : 0u;
+                        uint32_t n = invalid4(x) << (4 * (lane & 7));
+                        n |= (uint32_t)__shfl_xor((int)n, 1);
+                        n |= (uint32_t)__shfl_xor((int)n, 2);
+                        n |= (uint32_t)__shfl_xor((int)n, 4);
+                        if ((lane & 7) == 0 && (jf >> 3) <= (ndw >> 3)) s.inv[jf >> 3] = n;
+                    }
+                }
+            }
+        } else
         if (has_invalid) { // 4 validity bits per dword, 8 lanes = one bitmap word (bits indexed by fwd byte position)
             for (uint32_t j0 = 0; j0 <= ndw; j0 += WAVE) {
                 const uint32_t jf = j0 + (uint32_t)lane;
@@ -742,6 +753,8 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                             if (MODE == 1 && has_invalid && !window_valid<KT>(s, p, k)) h = 0;
                             else if RK_DBG(4) {
                                 h = ((uint64_t)(s.fwd[(s.fbase + p) >> 2] * 0x9E3779B1u) << 32) | (s.rc[(B - (uint32_t)k - p) >> 2] * 0x85EBCA6Bu);
+                            } else if constexpr (KPRE) { // no byte images here: the window is expanded from the packed image in registers
+                                h = canonical_packed(packed_window<KT>(pk_f, pkoff + p), KT, pol.seed, pol.fold);
                             } else {
                                 if constexpr (KT == 0) { // run-time k: both strands through one block loop, uniform tail masks
                                     h = canonical_rt(s.fwd, s.fbase + p, s.rc, B - (uint32_t)k - p, k, tmasks, pol.seed, pol.fold);
@@ -942,7 +955,7 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
     int tmax = 1;
     double best_fill = -1.0;
     for (int T = 1; T <= 16; ++T) {
-        if (T > 1 && (!fits(T, LDS_BUDGET_6_WAVES) || T * maxlen > 3 * WAVE * 4 - 8)) break;
+        if (T > 1 && (!fits(T, LDS_BUDGET_6_WAVES) || T * maxlen > (kpre ? PF_MAX : 3) * WAVE * 4 - 8)) break;
         const int nw = T * win_per_read;
         fill[T] = (double)nw / (double)(((nw + WAVE - 1) / WAVE) * WAVE);
         if (fill[T] > best_fill) best_fill = fill[T];
