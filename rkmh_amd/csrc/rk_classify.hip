@@ -955,7 +955,7 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
     int tmax = 1;
     double best_fill = -1.0;
     for (int T = 1; T <= 16; ++T) {
-        if (T > 1 && (!fits(T, LDS_BUDGET_6_WAVES) || T * maxlen > (kpre ? PF_MAX : 3) * WAVE * 4 - 8)) break;
+        if (T > 1 && (!fits(T, LDS_BUDGET_6_WAVES) || T * maxlen > 3 * WAVE * 4 - 8)) break;
         const int nw = T * win_per_read;
         fill[T] = (double)nw / (double)(((nw + WAVE - 1) / WAVE) * WAVE);
         if (fill[T] > best_fill) best_fill = fill[T];
@@ -966,6 +966,10 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
     int best = 1;
     for (int T = 1; T <= tmax; ++T)
         if (fill[T] >= best_fill - 0.025) { best = T; break; }
+    // the k-mer-space form: a step is a fifth of a hashing step, so the fill of the last one hardly matters and the per-tile
+    // bookkeeping does -- the largest tile within the short prefetch (measured at 150 bp: T = 4 and 5 0.518 ms, 6..8 with the
+    // long prefetch 0.53-0.55, 9-10 0.57)
+    if (kpre) best = tmax;
     if (const char* e = getenv("RKMH_TILE_T")) best = atoi(e);
     if (best > 16) best = 16;
     if (best < 1) best = 1;
