@@ -169,7 +169,11 @@ def main():
                        "spinup_seconds": a.spinup_seconds},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_classify_tile", "kernel_ms": kern_ms, "bytes_per_read": B_READ, "valu": valu},
+                         "kernel": "k_classify_tile", "kernel_ms": kern_ms, "bytes_per_read": B_READ, "valu": valu,
+                         # which form of the fused kernel ran: "k-mer-space" = reads are filtered and matched by packed k-mer after the
+                         # whole 4^k k-mer universe was hashed once when the references were set; "hash-space" = every
+                         # window is hashed in the kernel
+                         "kernel_form": "k-mer-space" if ctx.kmer_form()[0] else "hash-space"},
         }
         if world == 1 and a.cpu_seconds > 0:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
