@@ -1493,3 +1493,42 @@ def test_idle_lanes_never_reach_the_drain_as_kmers(orc, pave):
             c.close()
     finally:
         os.environ.pop("RKMH_PRE_MAXKB", None)
+
+
+def test_enumeration_finds_exactly_the_preimages(orc, pave):
+    """k_enum_kmers against an independent enumeration by the oracle at k = 8 (65 536 k-mers): the number of strand pairs whose
+    canonical hash is a key of the index (or 0) must be exactly what the GPU reports -- for sketched references and for imported
+    sketches in which half the hashes were replaced by values no 8-mer produces."""
+    import itertools
+    import rkmh_amd
+    _, rb, ro = pave
+    k, S = 8, 300
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    canon_hash = {}
+    for t in itertools.product(b"ACGT", repeat=k):
+        s = bytes(t)
+        r = s.translate(comp)[::-1]
+        if s <= r:
+            canon_hash[s] = orc.calc_hash(s)          # the oracle's canonical hash of the pair {s, revcomp(s)}
+    assert len(canon_hash) == (4 ** k + 4 ** (k // 2)) // 2   # pairs + palindromes
+    c = rkmh_amd.Context(0)
+    try:
+        c.set_references(rb, ro, [k], S)
+        sk, ln = c.get_reference_sketches()
+        keys = set(int(x) for i in range(len(ln)) for x in sk[i, : ln[i]])
+        want = sum(1 for h in canon_hash.values() if h in keys or h == 0)
+        active, found = c.kmer_form()
+        assert active and found == want and want > 1000
+        rng = np.random.default_rng(4)
+        sk2 = sk.copy()
+        for i in range(len(ln)):
+            m = sk2[i, : ln[i]]
+            m[::2] = rng.integers(1, 2**63, size=len(m[::2]), dtype=np.uint64)
+            sk2[i, : ln[i]] = np.sort(m)
+        c.set_reference_sketches(sk2, ln, [k], S)
+        keys2 = set(int(x) for i in range(len(ln)) for x in sk2[i, : ln[i]])
+        want2 = sum(1 for h in canon_hash.values() if h in keys2 or h == 0)
+        active, found = c.kmer_form()
+        assert active and found == want2 and 0 < want2 < want
+    finally:
+        c.close()
