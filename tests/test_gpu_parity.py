@@ -1381,6 +1381,12 @@ def test_kmer_space_form_every_policy(orc, pave, k, fold, drop):
         sk, ln = c.get_reference_sketches()
         wsk, wln = orc.sketch_refs(rb, ro, [k], 1000, policy=pol, threads=T)
         assert (sk == wsk).all() and (ln == wln).all()
+        # every sketch hash of a real sequence has its source k-mer as a preimage, so found >= distinct keys; equality says that the
+        # WHOLE 4^k universe holds no second k-mer hashing to any key (and none hashing to 0) -- true for this panel at every k >= 12
+        distinct = len(np.unique(sk[sk != 0]))
+        assert found >= distinct
+        if k >= 12:
+            assert found == distinct, (found, distinct)
         qb, qo = synth.generate_reads_fast(rb, ro, 7000, 7000 + 60000)
         want = orc.classify_stream(qb, qo, [k], 1000, wsk, wln, policy=pol, threads=T)
         got = c.classify(_pad(qb), qo)
