@@ -34,6 +34,16 @@
 //   phase 2  16 lanes per read (4 reads = one wave): best earlier score for `diff` (DPP row reduction over
 //            the counters), one int4 per read, counters re-zeroed.
 // Integer work only (no MFMA).
+//
+// Two forms of phase 1 / drain live in this file (template parameter MODE_):
+//   hash-space (MODE_ 0-4, described above): every window is hashed in the kernel.  Bound twice over on MI355X: 92 % of the
+//            VALU issue slots AND the L2 request rate (one scattered 4-byte filter probe per window).
+//   k-mer-space (MODE_ 5, single k from 8 to 16, no -M): NO window of a plain tile is hashed.  When the references are set,
+//            k_enum_kmers (rk_kernels.hip) hashes the whole 4^k k-mer universe once and records every k-mer whose canonical hash
+//            is a sketch hash or 0; the kernel then extracts packed 2-bit k-mers, probes a filter whose cache line is chosen by what
+//            four neighbouring windows share, and resolves the few candidates by k-mer in an exact map -- bit-identical to the
+//            hash-defined result by construction (see the comment at MODE_ 5 below and DESIGN.md section 3.1b).  This is the
+//            form the headline configuration runs.
 #include "rk_kernels.hpp"
 
 #include <cstdlib>
