@@ -936,6 +936,7 @@ static int build_index(rk_ctx* c) {
         // with a key or hashes to 0 -- a handful at most, so twice the keys is ample room; more than that disables this form
         const uint32_t list_cap = (uint32_t)std::min<size_t>(2 * distinct + 4096, 0x3fffffffu);
         DevBuf d_list;
+        struct Release { DevBuf& b; ~Release() { b.release(); } } release_list{d_list}; // freed on every path out of this block
         RKCHK(d_list.reserve((size_t)list_cap * 8));
         RefIndex probe = c->ix;
         probe.kpre = nullptr; probe.kmap = nullptr;
