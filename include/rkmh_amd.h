@@ -170,7 +170,9 @@ int rk_kmer_form(const rk_ctx* ctx, uint32_t* kmers_found);
 int rk_set_kmer_form(rk_ctx* ctx, int enable);
 
 /* Read-depth filter (-M, src/rkmh.cpp:701-704): when set, classify masks hashes whose counter
- * value is below min_kmer_occ (mask_by_frequency, :916) before sketching.  NULL disables. */
+ * value is below min_kmer_occ (mask_by_frequency, :916) before sketching.  NULL disables.
+ * The table is read as it is AT THIS CALL (the fused kernel uses a one-bit-per-slot snapshot of the comparison): set the
+ * filter after pass 1 (rk_count_batch*, and after any all-reduce of the table), and again if the table changes later. */
 int rk_set_depth_filter(rk_ctx* ctx, rk_counter* counter, int min_kmer_occ);
 
 /* Pass 1 of the -M path (src/rkmh.cpp:904-910): hash every read and increment the counter. */

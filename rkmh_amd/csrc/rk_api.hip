@@ -104,7 +104,7 @@ struct rk_ctx {
     KsArr ks{};
     std::vector<uint64_t> h_sk;
     std::vector<int32_t> h_lens;
-    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_kpre, d_kmap;
+    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_kpre, d_kmap, d_keepbits;
     uint32_t kpre_inserted = 0; // k-mers the enumeration put into the k-mer-space filter (diagnostic)
     bool kmer_form_allowed = true; // rk_set_kmer_form
     RefIndex ix{};
@@ -160,7 +160,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
-    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_kpre, &c->d_kmap, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_kpre, &c->d_kmap, &c->d_keepbits, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount, &c->w_tail}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
@@ -1080,6 +1080,14 @@ extern "C" int rk_kmer_form(const rk_ctx* c, uint32_t* kmers_found) {
 extern "C" int rk_set_depth_filter(rk_ctx* c, rk_counter* counter, int min_kmer_occ) {
     if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
     c->depth = counter; c->min_occ = min_kmer_occ;
+    if (counter) {
+        // the fused kernel's masked forms read one KEEP bit per slot instead of the 4-byte count (k_keep_bits): a snapshot of
+        // the table as it is NOW -- the -M flow sets the filter after pass 1 (and after the all-reduce in multi-GPU runs)
+        RKCHK(set_dev(c));
+        RKCHK(c->d_keepbits.reserve(((counter->slots + 31) / 32) * 4 + 16));
+        HIPCHK(launch_keep_bits(counter->d, counter->slots, min_kmer_occ, c->pol, c->d_keepbits.as<uint32_t>(), c->st));
+        HIPCHK(hipStreamSynchronize(c->st));
+    }
     return RK_OK;
 }
 
@@ -1090,7 +1098,7 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     if (((uintptr_t)d_bases & 3) != 0) return fail(RK_ERR_ARG, "d_bases must be 4-byte aligned");
     int32_t* counter = nullptr; uint64_t slots = 1; int min_occ = 0;
     if (mode == 1) { counter = count_into->d; slots = count_into->slots; }
-    else if (c->depth) { counter = c->depth->d; slots = c->depth->slots; min_occ = c->min_occ; }
+    else if (c->depth) { counter = c->d_keepbits.as<int32_t>(); slots = c->depth->slots; min_occ = c->min_occ; } // the keep bitmap, see rk_set_depth_filter
     uint32_t ml = max_read_len < 1 ? 1 : (max_read_len > (uint32_t)FUSED_MAXLEN ? (uint32_t)FUSED_MAXLEN : max_read_len);
     int expect = 0; // hits an error-free read is expected to score: sizes the kernel's per-read hit multiset
     for (int j = 0; j < c->ks.n; ++j) expect += (int)(c->density * (double)num_windows((int)ml, c->ks.k[j], c->pol.drop_last_window)) + 1;

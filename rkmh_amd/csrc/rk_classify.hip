@@ -105,6 +105,7 @@ struct TileGeom {
     int32_t dbg;        // ablation switches (only read when built with -DRK_ABLATE=1)
     int32_t tpb;        // consecutive tiles per workgroup
     int32_t xcd;        // 1: workgroups that share an XCD (blockIdx % 8, round-robin dispatch) take neighbouring tiles
+    uint64_t slots_m;   // floor((2^64 - 1) / slots) of the -M counter table: hash % slots by Barrett reduction (mod_slots)
     int32_t kpre;       // 1: MODE_ 5 kernels (k-mer-space filter): packed 2-bit images, 4-byte queue entries (position | read << 16)
     int32_t magic_nw;   // windows (first k) of a read of the hinted length, and ...
     uint32_t magic;     // ... ceil(2^32 / magic_nw): the compact window -> read division of tiles made of such reads
@@ -185,6 +186,16 @@ __device__ __forceinline__ void word_load_async_ws(const uint32_t* base, uint32_
     asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(f) : "v"(byte_off), "s"(base) : "memory");
 }
 __device__ __forceinline__ void word_wait(uint32_t& f) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : : "memory"); }
+
+// h % slots for the -M table (HASHTCounter slot, rkmh.cpp:739) without a 64-bit division: m = floor((2^64 - 1) / slots) comes
+// from the host; q = mulhi(h, m) is the quotient or one less (h * m / 2^64 lies in (h / slots - 1, h / slots]), so one conditional
+// subtraction finishes it.  Exact for every h and every slots >= 1 (2 * slots < 2^64).  ~20 VALU instead of ~55.
+__device__ __forceinline__ uint64_t mod_slots(uint64_t h, uint64_t slots, uint64_t m) {
+    const uint64_t q = __umul64hi(h, m);
+    uint64_t r = h - q * slots;
+    if (r >= slots) r -= slots;
+    return r;
+}
 
 // the k <= 16 bases starting at base p of a packed 2-bit image (16 bases per dword): one 8-byte LDS read + one funnel shift
 struct __attribute__((packed, aligned(4))) rk_pair4 { uint32_t x, y; };
@@ -720,11 +731,15 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                         // what happens to a window's canonical hash: the -M count / mask, the zero-hash tally of its read
                         auto account = [&](uint64_t& hh, uint32_t tt) {
                             if (MODE == 1) {
-                                if (pol.counter_counts_zero || hh != 0) atomicAdd(&counter[hh % slots], 1);
+                                if (pol.counter_counts_zero || hh != 0) atomicAdd(&counter[mod_slots(hh, slots, geo.slots_m)], 1);
                             } else {
                                 if (MODE == 2) { // mask_by_frequency, rkmh.cpp:916
-                                    const int c = counter[hh % slots];
-                                    if (pol.mask_strict_less ? (c < min_occ) : (c <= min_occ)) hh = 0;
+                                    // `counter` is the KEEP bitmap here (rk_set_depth_filter: bit s = the count of slot s passes the
+                                    // threshold): 1 bit per slot instead of 4 bytes -- 25 MB for the reference's 200 M slots, which
+                                    // the Infinity Cache holds, where the table itself (800 MB) is a random HBM access per window
+                                    const uint64_t slot = mod_slots(hh, slots, geo.slots_m);
+                                    const uint32_t wbits = reinterpret_cast<const uint32_t*>(counter)[slot >> 5];
+                                    if (!((wbits >> ((uint32_t)slot & 31u)) & 1u)) hh = 0;
                                 }
                                 if (hh == 0) atomicAdd(&nzero[tt], 1u);
                             }
@@ -1017,6 +1032,7 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     geo.tpb = tpb;
     geo.xcd = 1;
     if (const char* e = getenv("RKMH_TILE_XCD")) geo.xcd = atoi(e) != 0;
+    geo.slots_m = slots ? ~0ull / slots : 0;
     geo.magic_nw = num_windows(maxlen, ks.k[0], pol.drop_last_window);
     geo.magic = geo.magic_nw >= 2 ? 0xFFFFFFFFu / (uint32_t)geo.magic_nw + 1u : 0u;
     const bool k16 = (ks.n == 1 && ks.k[0] == 16);
@@ -1024,6 +1040,9 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     // The masked (-M) form waits for a random read of the 800 MB counter table in every step: it is bound by memory requests,
     // not by VALU issue, and the filter word is one more request per window (C2: 2.86 ms without, 3.10 ms with).  It pays
     // only once the bucket table itself has left L2.
+    // (Round 2: the count is read as one keep bit per slot -- 25 MB instead of 800 MB -- which took this form from 2.86 to 2.58 ms;
+    // pipelining that lookup one step ahead, in the filter-word form, was measured SLOWER, 2.89 ms: the pass is bound by the
+    // rate of random accesses that miss the L2, about 5 * 10^10 per second here, not by latency or instructions.)
     bool pre_masked = ((size_t)ix.bmask + 1) * 16 > ((size_t)3 << 20);
     if (const char* e = getenv("RKMH_PRE_MASKED")) pre_masked = atoi(e) != 0; // tests force either form
 #define RK_LAUNCH_P(KT, MODE, FOLD, PF)                                                                                    \

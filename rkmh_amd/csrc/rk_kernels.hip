@@ -316,6 +316,34 @@ hipError_t launch_sort_intersect(const SortArgs& a, const RefIndex* ix, const De
 }
 
 // ------------------------------------------------------------------------------------------------
+// mask_by_frequency (rkmh.cpp:916) keeps a hash when its slot's count passes the threshold.  Once the table is final that
+// comparison is a property of the SLOT: one bit per slot (bit = keep), built in one streaming pass over the table.
+__global__ __launch_bounds__(256) void k_keep_bits(const int32_t* __restrict__ counter, uint64_t slots, int min_occ, int strict_less,
+                                                   uint32_t* __restrict__ bits, uint64_t nwords) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = 0;
+        const uint64_t s0 = w * 32;
+#pragma unroll 8
+        for (uint32_t b = 0; b < 32; ++b) {
+            const uint64_t sidx = s0 + b;
+            if (sidx < slots) {
+                const int c = counter[sidx];
+                const bool masked = strict_less ? (c < min_occ) : (c <= min_occ);
+                v |= (masked ? 0u : 1u) << b;
+            }
+        }
+        bits[w] = v;
+    }
+}
+hipError_t launch_keep_bits(const int32_t* counter, uint64_t slots, int min_occ, const DevPolicy& pol, uint32_t* bits, hipStream_t st) {
+    const uint64_t nwords = (slots + 31) / 32;
+    uint64_t blocks = (nwords + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(k_keep_bits, dim3((uint32_t)blocks), dim3(256), 0, st, counter, slots, min_occ, pol.mask_strict_less, bits, nwords);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Exhaustive enumeration behind the k-mer-space filter (RefIndex::kpre): EVERY k-mer of the 4^k universe (k <= 16) is hashed
 // exactly as calc_hashes would hash it as a window; those whose canonical hash is a key of the index -- the true preimages of
 // the sketch hashes and any other k-mer that happens to collide with one -- and those hashing to 0 set their two bits.  The

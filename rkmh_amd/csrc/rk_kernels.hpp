@@ -93,6 +93,8 @@ hipError_t launch_sort_intersect(const SortArgs& a, const RefIndex* ix, const De
 hipError_t launch_select_bottom(const uint64_t* hashes, uint64_t n, int S, const int32_t* counter, uint64_t slots,
                                 int filter_mode, int fmin, int fmax, const DevPolicy& pol, uint32_t* sel_state,
                                 uint32_t* hist, uint64_t* sel_out, hipStream_t st);
+// bits[s / 32] bit (s % 32) = the count of slot s passes mask_by_frequency's threshold (one streaming pass over the table)
+hipError_t launch_keep_bits(const int32_t* counter, uint64_t slots, int min_occ, const DevPolicy& pol, uint32_t* bits, hipStream_t st);
 // fills RefIndex::kpre (zeroed by the caller) by hashing all 4^k k-mers; stats[0] = k-mers found (one per strand pair), the first
 // list_cap of them in list[] as (packed canonical k-mer, key id or IDX_NOT_FOUND for a zero hash)
 hipError_t launch_enum_kmers(const RefIndex& ix, const DevPolicy& pol, int k, uint32_t* kpre, uint32_t kpshift, uint32_t* stats,

@@ -43,6 +43,17 @@ const Tables T;
 template <typename V> struct Grow { // malloc-backed growable array handed over to C callers
     V* p = nullptr;
     size_t n = 0, cap = 0;
+    // Owns p: movable, never copied.  (It used to have only the implicit, shallow copy: std::vector<Piece>::resize relocating live
+    // pieces -- a later block using more workers than an earlier one -- left the new elements pointing at buffers the old ones had
+    // freed, and the next reserve() was a double free.  Seen as a rare abort of the parser tests; found with AddressSanitizer.)
+    Grow() = default;
+    Grow(const Grow&) = delete;
+    Grow& operator=(const Grow&) = delete;
+    Grow(Grow&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    Grow& operator=(Grow&& o) noexcept {
+        if (this != &o) { free(p); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; }
+        return *this;
+    }
     bool reserve(size_t want) {
         if (want <= cap) return true;
         size_t nc = cap ? cap : 1024;
