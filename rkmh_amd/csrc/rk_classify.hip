@@ -85,6 +85,15 @@ __device__ __forceinline__ int row_max_i32(int v) {
     return v;
 }
 
+// max over an aligned group of 8 lanes (half a DPP row)
+__device__ __forceinline__ int half_row_max_i32(int v) {
+    int t;
+    t = dpp_i32<0xB1>(v); v = t > v ? t : v;   // quad_perm [1,0,3,2]
+    t = dpp_i32<0x4E>(v); v = t > v ? t : v;   // quad_perm [2,3,0,1]
+    t = dpp_i32<0x141>(v); v = t > v ? t : v;  // row_half_mirror
+    return v;
+}
+
 // Orders this wave's LDS traffic for cross-lane hand-offs.  A workgroup is one wave: LDS instructions of a
 // wave execute in order, so no hardware wait is needed -- only the compiler must not move accesses across.
 __device__ __forceinline__ void wave_sync() {
@@ -895,17 +904,19 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
         }
         if (MODE == 1) { wait_bases(); continue; } // see the end of the loop body
 
-        // ---- phase 2: 16 lanes per read -----------------------------------------------------------
+        // ---- phase 2: 16 lanes per read, or 8 when the tile holds more than four (one pass for up to eight reads: with 16, the fifth
+        //      read of a five-read tile was a pass of its own with 48 lanes idle) -----------------------
         {
-            const int g = lane >> 4, sl = lane & 15;
-            for (int t = g; t < Tn; t += WAVE / 16) {
+            const int lsh = Tn > 4 ? 3 : 4, LPR = 1 << lsh; // wave-uniform
+            const int g = lane >> lsh, sl = lane & (LPR - 1);
+            for (int t = g; t < Tn; t += WAVE >> lsh) {
                 uint32_t* ct = c16 + t * geo.cwords;
                 const int nmins = (int)nwin[t] - (int)nzero[t];
                 // bottom-S selection matters, or the hit multiset overflowed: exact answer comes from the general path
                 const bool reroute = nmins > S || flags[t] != 0;
                 const uint32_t bk = best[t];
                 if (reroute || RK_DBG(2)) {
-                    for (int w = sl; w < geo.cwords; w += 16) ct[w] = 0;
+                    for (int w = sl; w < geo.cwords; w += LPR) ct[w] = 0;
                     if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = reroute ? make_int4(-2, 0, 0, 0) : make_int4(0, (int)(bk >> 16), 0, nmins);
                     continue;
                 }
@@ -914,13 +925,13 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                 const int max_shared = (int)(bk >> 16);
                 int prev = max_id > 0 ? 0 : -1;
                 if (geo.csparse) {
-                    for (int w = sl; w < geo.cwords; w += 16) {
+                    for (int w = sl; w < geo.cwords; w += LPR) {
                         const uint32_t x = ct[w];
                         const int r_ = (int)(x >> 11) - 1, cj = (int)(x & 0x7FFu);
                         if (x != 0u && r_ < max_id && cj > prev) prev = cj;
                     }
                 } else
-                for (int w = sl; (w << clg) < max_id; w += 16) {
+                for (int w = sl; (w << clg) < max_id; w += LPR) {
                     uint32_t x = ct[w];
                     for (uint32_t j = 0; j <= cper_m1; ++j) { // counters of references (w << clg) + j < max_id
                         const int cj = (int)(x & cmask);
@@ -928,9 +939,9 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                         if ((int)((uint32_t)(w << clg) + j) < max_id && cj > prev) prev = cj;
                     }
                 }
-                prev = row_max_i32(prev);
+                prev = LPR == 16 ? row_max_i32(prev) : half_row_max_i32(prev);
                 wave_sync();
-                for (int w = sl; w < geo.cwords; w += 16) ct[w] = 0;
+                for (int w = sl; w < geo.cwords; w += LPR) ct[w] = 0;
                 if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(max_id, max_shared, max_shared - prev, nmins);
             }
         }
