@@ -1538,3 +1538,36 @@ def test_enumeration_finds_exactly_the_preimages(orc, pave):
         assert active and found == want2 and 0 < want2 < want
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("slots", [1, 2, 3, 65537, 99999989, 1 << 20])
+def test_depth_filter_with_unusual_table_sizes(orc, pave, slots):
+    """-M end to end (count pass + keep bitmap + masked classify) for table sizes that stress hash % slots (mod_slots: Barrett
+    reduction with a host-supplied reciprocal -- 1 slot, tiny, a Fermat prime, a large prime, a power of two), both masked kernel
+    forms, against the oracle with the same table size."""
+    import rkmh_amd
+    from rkmh_amd import synth
+    _, rb, ro = pave
+    T = min(16, os.cpu_count() or 1)
+    qb, qo = synth.generate_reads_fast(rb, ro, 31000, 31000 + 6000)
+    c = rkmh_amd.Context(0)
+    try:
+        c.set_references(rb, ro, [16], 1000)
+        sk, ln = c.get_reference_sketches()
+        for min_occ in (2, 40):
+            want = orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=T, min_kmer_occ=min_occ, counter_slots=slots)
+            cnt = rkmh_amd.Counter(c, slots=slots)
+            c.count_batch(_pad(qb), qo, cnt)
+            c.set_depth_filter(cnt, min_occ)
+            try:
+                for force in ("0", "1"):
+                    os.environ["RKMH_PRE_MASKED"] = force
+                    got = c.classify(_pad(qb), qo)
+                    bad = np.nonzero((got != want).any(axis=1))[0]
+                    assert len(bad) == 0, (slots, min_occ, force, len(bad), got[bad[:3]], want[bad[:3]])
+            finally:
+                os.environ.pop("RKMH_PRE_MASKED", None)
+                c.set_depth_filter(None, 0)
+                cnt.destroy()
+    finally:
+        c.close()
