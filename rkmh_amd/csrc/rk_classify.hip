@@ -312,6 +312,7 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
     auto wait_bases = [&]() {
         if constexpr (PF == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]) : : "memory");
         else if constexpr (PF == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]) : : "memory");
+        else if constexpr (PF == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]) : : "memory");
     };
     // XCD-aware tile ownership: the dispatcher deals workgroups round-robin over the 8 XCDs, each with its own L2.
@@ -987,11 +988,16 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
         return T * maxlen <= PF_MAX * WAVE * 4 - 8 && tile_lds_bytes(g) <= budget;
     };
     if (win_per_read < 1) win_per_read = 1;
+    // prefetch dwords per lane the k-mer-space form may use when choosing its tile: 4 (six 150 bp reads per tile: 0.481 ms
+    // against 0.507 for five with 3 dwords -- the second drain round is fuller and phase 2 takes eight reads in one pass).
+    // RKMH_KPRE_PF=3 for A/B runs.
+    int kpre_pf = 4;
+    if (const char* e = getenv("RKMH_KPRE_PF")) kpre_pf = atoi(e) == 3 ? 3 : 4;
     double fill[17] = {0};
     int tmax = 1;
     double best_fill = -1.0;
     for (int T = 1; T <= 16; ++T) {
-        if (T > 1 && (!fits(T, LDS_BUDGET_6_WAVES) || T * maxlen > 3 * WAVE * 4 - 8)) break;
+        if (T > 1 && (!fits(T, LDS_BUDGET_6_WAVES) || T * maxlen > (kpre ? kpre_pf : 3) * WAVE * 4 - 8)) break;
         const int nw = T * win_per_read;
         fill[T] = (double)nw / (double)(((nw + WAVE - 1) / WAVE) * WAVE);
         if (fill[T] > best_fill) best_fill = fill[T];
@@ -1003,8 +1009,8 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
     for (int T = 1; T <= tmax; ++T)
         if (fill[T] >= best_fill - 0.025) { best = T; break; }
     // the k-mer-space form: a step is a fifth of a hashing step, so the fill of the last one hardly matters and the per-tile
-    // bookkeeping does -- the largest tile within the short prefetch (measured at 150 bp: T = 4 and 5 0.518 ms, 6..8 with the
-    // long prefetch 0.53-0.55, 9-10 0.57)
+    // bookkeeping does -- the largest tile within a prefetch of 4 dwords per lane (measured at 150 bp: T = 4 and 5 0.518 ms, 6..8
+    // with the 6-dword prefetch 0.53-0.55, 9-10 0.57; then, with a 4-dword prefetch instantiated, T = 6 0.481)
     if (kpre) best = tmax;
     if (const char* e = getenv("RKMH_TILE_T")) best = atoi(e);
     if (best > 16) best = 16;
@@ -1074,6 +1080,14 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
         else if (geo.cap_bytes <= 3 * WAVE * 4 - 8) RK_LAUNCH_P(KT, MODE, FOLD, 3);                                  \
         else RK_LAUNCH_P(KT, MODE, FOLD, 6);                                                                         \
     } while (0)
+/* the k-mer-space form also exists with four prefetch dwords per lane (tiles of up to 1016 bytes: six 150 bp reads) */
+#define RK_LAUNCH5(KT, FOLD)                                                                                          \
+    do {                                                                                                             \
+        if (geo.cap_bytes <= 2 * WAVE * 4 - 8) RK_LAUNCH_P(KT, 5, FOLD, 2);                                          \
+        else if (geo.cap_bytes <= 3 * WAVE * 4 - 8) RK_LAUNCH_P(KT, 5, FOLD, 3);                                     \
+        else if (geo.cap_bytes <= 4 * WAVE * 4 - 8) RK_LAUNCH_P(KT, 5, FOLD, 4);                                     \
+        else RK_LAUNCH_P(KT, 5, FOLD, 6);                                                                            \
+    } while (0)
 #define RK_LAUNCH_M(KT, FOLD)                                                                                        \
     do {                                                                                                             \
         if (kmode == 1) RK_LAUNCH(KT, 1, FOLD);                                                                      \
@@ -1083,17 +1097,17 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
         else RK_LAUNCH(KT, 4, FOLD);                                                                                 \
     } while (0)
     // single k of 12, 20 (the reference's other documented settings), 21 or 31: window length known at compile time, runtime fold
-    if (use_kpre && ks.k[0] == 8) RK_LAUNCH(8, 5, -1);
-    else if (use_kpre && ks.k[0] == 9) RK_LAUNCH(9, 5, -1);
-    else if (use_kpre && ks.k[0] == 10) RK_LAUNCH(10, 5, -1);
-    else if (use_kpre && ks.k[0] == 11) RK_LAUNCH(11, 5, -1);
-    else if (use_kpre && ks.k[0] == 12) RK_LAUNCH(12, 5, -1);
-    else if (use_kpre && ks.k[0] == 13) RK_LAUNCH(13, 5, -1);
-    else if (use_kpre && ks.k[0] == 14) RK_LAUNCH(14, 5, -1);
-    else if (use_kpre && ks.k[0] == 15) RK_LAUNCH(15, 5, -1);
-    else if (use_kpre && pol.fold == 0) RK_LAUNCH(16, 5, 0);
-    else if (use_kpre && pol.fold == 1) RK_LAUNCH(16, 5, 1);
-    else if (use_kpre) RK_LAUNCH(16, 5, 2);
+    if (use_kpre && ks.k[0] == 8) RK_LAUNCH5(8, -1);
+    else if (use_kpre && ks.k[0] == 9) RK_LAUNCH5(9, -1);
+    else if (use_kpre && ks.k[0] == 10) RK_LAUNCH5(10, -1);
+    else if (use_kpre && ks.k[0] == 11) RK_LAUNCH5(11, -1);
+    else if (use_kpre && ks.k[0] == 12) RK_LAUNCH5(12, -1);
+    else if (use_kpre && ks.k[0] == 13) RK_LAUNCH5(13, -1);
+    else if (use_kpre && ks.k[0] == 14) RK_LAUNCH5(14, -1);
+    else if (use_kpre && ks.k[0] == 15) RK_LAUNCH5(15, -1);
+    else if (use_kpre && pol.fold == 0) RK_LAUNCH5(16, 0);
+    else if (use_kpre && pol.fold == 1) RK_LAUNCH5(16, 1);
+    else if (use_kpre) RK_LAUNCH5(16, 2);
     else if (ks.n == 1 && ks.k[0] == 12) RK_LAUNCH_M(12, -1);
     else if (ks.n == 1 && ks.k[0] == 20) RK_LAUNCH_M(20, -1);
     else if (ks.n == 1 && ks.k[0] == 21) RK_LAUNCH_M(21, -1);   // Mash / sourmash defaults
@@ -1102,6 +1116,7 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     else if (pol.fold == 0) RK_LAUNCH_M(16, 0);
     else if (pol.fold == 1) RK_LAUNCH_M(16, 1);
     else RK_LAUNCH_M(16, 2);
+#undef RK_LAUNCH5
 #undef RK_LAUNCH_M
 #undef RK_LAUNCH
 #undef RK_LAUNCH_P
