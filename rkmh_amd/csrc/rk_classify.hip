@@ -1011,7 +1011,8 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
     // the k-mer-space form: a step is a fifth of a hashing step, so the fill of the last one hardly matters and the per-tile
     // bookkeeping does -- the largest tile within a prefetch of 4 dwords per lane (measured at 150 bp: T = 4 and 5 0.518 ms, 6..8
     // with the 6-dword prefetch 0.53-0.55, 9-10 0.57; then, with a 4-dword prefetch instantiated, T = 6 0.481)
-    if (kpre) best = tmax;
+    // ... but never more than eight reads: that is what phase 2 takes in one pass (100 bp reads: T = 8 0.333 ms, T = 9-10 0.37)
+    if (kpre) best = tmax < 8 ? tmax : 8;
     if (const char* e = getenv("RKMH_TILE_T")) best = atoi(e);
     if (best > 16) best = 16;
     if (best < 1) best = 1;
