@@ -9,7 +9,7 @@ L = int(sys.argv[1]); n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 refs = api.parse_files([os.path.join(ROOT, "tests", "golden", "data", "all_pave_ref.fa.gz")])
 rb, ro = refs["bases"], refs["offsets"]
 dev = torch.device("cuda", 0)
-c = rkmh_amd.Context(0); c.set_references(rb, ro, [16], 1000)
+c = rkmh_amd.Context(0); K = int(os.environ.get("BENCH_K", "16")); c.set_references(rb, ro, [K], 1000)
 qb, qo = synth.generate_reads_fast(rb, ro, 0, n, read_len=L, threads=16)
 d_b = torch.from_numpy(qb).to(dev); d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev)
 d_out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
