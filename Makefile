@@ -6,7 +6,7 @@ CSRC := rkmh_amd/csrc
 # instantiations of the fused kernel the ISA lint must find (it fails closed below that): 5 hash-space k variants + run-time k (x 5 modes) and the k-mer-space form for k = 8..16, x 3 prefetch depths
 MIN_TILE_KERNELS ?= 160
 LIB := rkmh_amd/lib/librkmh_amd.so
-OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_call.o $(CSRC)/rk_api.o $(CSRC)/rk_parse.o $(CSRC)/rk_synth.o
+OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_kmer.o $(CSRC)/rk_call.o $(CSRC)/rk_api.o $(CSRC)/rk_parse.o $(CSRC)/rk_synth.o
 
 all: $(LIB) bin/rkmh oracle
 
@@ -20,6 +20,11 @@ $(CSRC)/rk_classify.o: $(CSRC)/rk_classify.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk
 	@cd build/isa && rm -f *.bc *.hipi *.out *.resolution.txt *.hipfb *host-x86_64*.s *.o
 	python3 tools/lint_async_loads.py --min-tile-kernels $(MIN_TILE_KERNELS) build/isa/rk_classify-hip-amdgcn-amd-amdhsa-$(ARCH).s || { rm -f $@.tmp; exit 1; }
 	mv $@.tmp $@
+# the k-mer-space kernel: its ISA is kept next to the fused kernel's (tools/isa_blocks.py, instruction counts in DESIGN.md)
+$(CSRC)/rk_kmer.o: $(CSRC)/rk_kmer.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp
+	@mkdir -p build/isa_kmer
+	cd build/isa_kmer && $(HIPCC) $(HIPFLAGS) -save-temps -c $(CURDIR)/$< -o $(CURDIR)/$@
+	@cd build/isa_kmer && rm -f *.bc *.hipi *.out *.resolution.txt *.hipfb *host-x86_64*.s *.o
 $(CSRC)/rk_call.o: $(CSRC)/rk_call.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/rk_api.o: $(CSRC)/rk_api.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp include/rkmh_amd.h

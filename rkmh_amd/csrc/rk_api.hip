@@ -104,7 +104,7 @@ struct rk_ctx {
     KsArr ks{};
     std::vector<uint64_t> h_sk;
     std::vector<int32_t> h_lens;
-    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_kpre, d_kmap, d_keepbits;
+    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_kpre, d_kmap, d_kf4, d_keepbits;
     uint32_t kpre_inserted = 0; // k-mers the enumeration put into the k-mer-space filter (diagnostic)
     bool kmer_form_allowed = true; // rk_set_kmer_form
     RefIndex ix{};
@@ -160,7 +160,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
-    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_kpre, &c->d_kmap, &c->d_keepbits, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_kpre, &c->d_kmap, &c->d_kf4, &c->d_keepbits, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount, &c->w_tail}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
@@ -917,6 +917,7 @@ static int build_index(rk_ctx* c) {
     // universe whose canonical hash is a key (or 0), found by exhaustive enumeration on the device -- see k_enum_kmers.
     // Sized like the hash-space filter (32 bits per key, 2 set).  RKMH_KMER_PREFILTER=0 turns it off (A/B runs, tests).
     c->ix.kpre = nullptr; c->ix.kpshift = 0; c->ix.kpk = 0; c->ix.kmap = nullptr; c->ix.kmap_m = 0; c->kpre_inserted = 0;
+    c->ix.kf4 = nullptr; c->ix.kf4_lg = 0;
     int kpre_mode = pre_mode > 0 ? 1 : 0;
     if (const char* e = getenv("RKMH_KMER_PREFILTER")) kpre_mode = atoi(e);
     // Only for panels whose filter + map stay L2-resident (an XCD's L2 is 4 MB): beyond that the hash-space kernels, whose
@@ -991,6 +992,26 @@ static int build_index(rk_ctx* c) {
             }
         }
         if (ok) {
+            // group filter of k_classify_kmer (kf4_sector in rk_device.hpp): every found k-mer in both orientations under its four
+            // alignments, two bits each in dword j of the 16-byte sector its alignment-j core selects; sized for ~10 entries per
+            // sector (about 5 of a dword's 32 bits set: one window in ~45 of those that hit nothing passes by chance)
+            const int k = c->ks.k[0];
+            uint32_t lg = 8;
+            static const long kf4_entries = getenv("RKMH_KF4_ENTRIES") ? atol(getenv("RKMH_KF4_ENTRIES")) : 10;
+            while (((size_t)1 << lg) * (size_t)(kf4_entries > 0 ? kf4_entries : 10) < (size_t)found * 8 && lg < 24) ++lg;
+            std::vector<uint32_t> f4((size_t)4 << lg, 0u);
+            const uint32_t cm = kf4_core_mask(k);
+            for (uint32_t i = 0; i < found; ++i) {
+                const uint32_t v = list[2 * (size_t)i], rv = packed_revcomp(v, k);
+                for (int o = 0; o < (rv == v ? 1 : 2); ++o) {
+                    const uint32_t X = o ? rv : v, bits = kf4_bits(X);
+                    for (uint32_t j = 0; j < 4; ++j)
+                        f4[(size_t)kf4_sector((X >> (2 * (3 - j))) & cm, lg) * 4 + j] |= bits;
+                }
+            }
+            RKCHK(c->d_kf4.reserve(f4.size() * 4));
+            HIPCHK(hipMemcpy(c->d_kf4.p, f4.data(), f4.size() * 4, hipMemcpyHostToDevice));
+            c->ix.kf4 = c->d_kf4.as<uint4>(); c->ix.kf4_lg = lg;
             RKCHK(c->d_kmap.reserve(cells.size() * 4 + 16));
             HIPCHK(hipMemcpy(c->d_kmap.p, cells.data(), cells.size() * 4, hipMemcpyHostToDevice));
             c->ix.kmap = c->d_kmap.as<uint4>(); c->ix.kmap_m = m;
@@ -1102,7 +1123,13 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     uint32_t ml = max_read_len < 1 ? 1 : (max_read_len > (uint32_t)FUSED_MAXLEN ? (uint32_t)FUSED_MAXLEN : max_read_len);
     int expect = 0; // hits an error-free read is expected to score: sizes the kernel's per-read hit multiset
     for (int j = 0; j < c->ks.n; ++j) expect += (int)(c->density * (double)num_windows((int)ml, c->ks.k[j], c->pol.drop_last_window)) + 1;
-    if (classify_tile_supported(mode == 0 ? c->ix.nref : 0, (int)ml))
+    // plain classification with the single k the exact k-mer map was enumerated for: the k-mer-space kernel (rk_kmer.hip)
+    static const bool kmer_v2 = !(getenv("RKMH_KMER_V2") && atoi(getenv("RKMH_KMER_V2")) == 0); // 0: the MODE_ 5 form of k_classify_tile (A/B)
+    if (mode == 0 && !counter && kmer_v2 && c->ix.kf4 && c->ix.kmap && c->ks.n == 1 && (uint32_t)c->ks.k[0] == c->ix.kpk &&
+        classify_kmer_supported(c->ix.nref, (int)ml, c->ks.k[0]))
+        HIPCHK(launch_classify_kmer((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks.k[0], c->S, c->ix,
+                                    (int32_t*)d_out4, c->pol, (int)ml, expect, st));
+    else if (classify_tile_supported(mode == 0 ? c->ix.nref : 0, (int)ml))
         HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
                                     counter, slots, min_occ, mode, (int32_t*)d_out4, c->pol, (int)ml, expect, st));
     else if (mode == 0)

@@ -117,6 +117,21 @@ __host__ __device__ __forceinline__ uint32_t kpre_word_off_s(uint32_t vf, uint32
 __host__ __device__ __forceinline__ uint32_t kpre_word_off(uint32_t vf, uint32_t vr, uint32_t j, int k, uint32_t x, uint32_t kplg) {
     return kpre_word_off_s(vf, vr, 2u * (3u - j), 2u * j, k, x, kplg);
 }
+// ---- forward-strand group filter of the k-mer-space kernel (rk_kmer.hip) --------------------------------------------------------
+// One lane of that kernel examines FOUR consecutive windows of a read (a "group": read positions 4g .. 4g+3), which it reads from
+// the packed image as one super-window of k + 3 bases.  All four windows contain the (k-3)-mer at super-window offset 3 (the
+// "core"), so one 16-byte SECTOR of the filter, chosen by the core, serves the whole group: dword j of the sector holds the bit
+// pairs of every found k-mer X whose alignment-j core (X >> 2 * (3 - j)) maps to the sector.  Keys are entered in BOTH orientations
+// (X and its reverse complement), so the window loop never forms a reverse complement; the drain canonicalises the few candidates.
+__host__ __device__ __forceinline__ uint32_t kf4_core_mask(int k) { return k > 3 ? (1u << (2 * (k - 3))) - 1u : 0u; }
+__host__ __device__ __forceinline__ uint32_t kf4_sector(uint32_t core, uint32_t lg) { return lg ? (core * 0x85EBCA6Bu) >> (32u - lg) : 0u; }
+// the two bits of a k-mer inside its dword: the TOP ten bits of x * odd constant (mod 2^32), which every bit of x reaches -- a
+// window that differs from a found k-mer only in a base outside the core (a sequencing error in the flank) lands in the same
+// sector and must not land on the same bits (the middle bits of the 64-bit product, one instruction cheaper, fail that for the
+// low bases of x: they only reach bit 32 and up through a carry)
+__host__ __device__ __forceinline__ uint32_t kf4_h(uint32_t x) { return x * 0x9E3779B1u; }
+__host__ __device__ __forceinline__ uint32_t kf4_bits(uint32_t x) { const uint32_t h = kf4_h(x); return (1u << (h >> 27)) | (1u << ((h >> 22) & 31u)); }
+
 // reverse complement of a packed k-mer (k <= 16)
 __host__ __device__ __forceinline__ uint32_t packed_revcomp(uint32_t v, int k) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -432,6 +447,9 @@ struct RefIndex {
     // kernels serve the panel).  value = KMAP_ZERO marks a k-mer whose canonical hash is 0.
     const uint4* kmap;
     uint32_t kmap_m;  // buckets
+    // forward-strand group filter of k_classify_kmer (rk_kmer.hip; see kf4_sector above): 2^kf4_lg sectors of 16 bytes
+    const uint4* kf4;
+    uint32_t kf4_lg;
 };
 constexpr uint32_t KMAP_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t KMAP_ZERO = 0xFFFFFFFEu; // not a valid index value (bit 31 set => postings offset < 2^31 - 1)
