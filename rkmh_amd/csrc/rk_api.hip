@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 using namespace rk;
@@ -104,7 +105,7 @@ struct rk_ctx {
     KsArr ks{};
     std::vector<uint64_t> h_sk;
     std::vector<int32_t> h_lens;
-    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_kpre, d_kmap, d_kf4, d_keepbits;
+    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_kpre, d_kmap, d_kf4, d_km1, d_km1v, d_keepbits;
     uint32_t kpre_inserted = 0; // k-mers the enumeration put into the k-mer-space filter (diagnostic)
     bool kmer_form_allowed = true; // rk_set_kmer_form
     RefIndex ix{};
@@ -160,7 +161,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
-    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_kpre, &c->d_kmap, &c->d_kf4, &c->d_keepbits, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_kpre, &c->d_kmap, &c->d_kf4, &c->d_km1, &c->d_km1v, &c->d_keepbits, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount, &c->w_tail}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
@@ -917,7 +918,7 @@ static int build_index(rk_ctx* c) {
     // universe whose canonical hash is a key (or 0), found by exhaustive enumeration on the device -- see k_enum_kmers.
     // Sized like the hash-space filter (32 bits per key, 2 set).  RKMH_KMER_PREFILTER=0 turns it off (A/B runs, tests).
     c->ix.kpre = nullptr; c->ix.kpshift = 0; c->ix.kpk = 0; c->ix.kmap = nullptr; c->ix.kmap_m = 0; c->kpre_inserted = 0;
-    c->ix.kf4 = nullptr; c->ix.kf4_lg = 0;
+    c->ix.kf4 = nullptr; c->ix.kf4_lg = 0; c->ix.km1 = nullptr; c->ix.km1_b = 0; c->ix.km1_vals = nullptr;
     int kpre_mode = pre_mode > 0 ? 1 : 0;
     if (const char* e = getenv("RKMH_KMER_PREFILTER")) kpre_mode = atoi(e);
     // Only for panels whose filter + map stay L2-resident (an XCD's L2 is 4 MB): beyond that the hash-space kernels, whose
@@ -1007,6 +1008,60 @@ static int build_index(rk_ctx* c) {
                     const uint32_t X = o ? rv : v, bits = kf4_bits(X);
                     for (uint32_t j = 0; j < 4; ++j)
                         f4[(size_t)kf4_sector((X >> (2 * (3 - j))) & cm, lg) * 4 + j] |= bits;
+                }
+            }
+            // single-probe exact map (KM1_C in rk_device.hpp).  A displaced key may only move to the next bucket; if that one is full
+            // too the table doubles.  More compound values than the 15-bit id space names leave the hash-space kernels in charge.
+            {
+                static const double km1_load = getenv("RKMH_KM1_LOAD") ? atof(getenv("RKMH_KM1_LOAD")) : 0.35;
+                std::vector<uint32_t> vals;
+                std::unordered_map<uint32_t, uint32_t> val_id;
+                std::vector<uint32_t> vid(found);
+                bool fits = true;
+                for (uint32_t i = 0; i < found && fits; ++i) {
+                    const uint32_t slot = list[2 * (size_t)i + 1];
+                    if (slot == IDX_NOT_FOUND) { vid[i] = KM1_VID_ZERO; continue; }
+                    const uint32_t val = dense[(size_t)slot * 4 + 2];
+                    if (!(val >> 31) && ((val >> 29) & 3u) == 0u && ((val >> 20) & 0x1FFu) == 1u && (val & 0xFFFFFu) < KM1_VID_TABLE) { vid[i] = val & 0xFFFFFu; continue; }
+                    auto it = val_id.find(val);
+                    if (it == val_id.end()) {
+                        if (KM1_VID_TABLE + vals.size() >= KM1_VID_ZERO) { fits = false; break; }
+                        it = val_id.emplace(val, (uint32_t)(KM1_VID_TABLE + vals.size())).first;
+                        vals.push_back(val);
+                    }
+                    vid[i] = it->second;
+                }
+                uint32_t b = 17;
+                while (b < 28 && (double)found > km1_load * 4.0 * (double)((size_t)1 << b)) ++b;
+                std::vector<uint32_t> c1;
+                for (; fits && b <= 28; ++b) {
+                    const uint32_t nbk = 1u << b, rmask = (1u << (32 - b)) - 1u;
+                    c1.assign((size_t)nbk * 4, KM1_CELL_EMPTY);
+                    bool placed_all = true;
+                    for (uint32_t i = 0; i < found && placed_all; ++i) {
+                        const uint32_t y = list[2 * (size_t)i] * KM1_C;
+                        uint32_t bk = y >> (32 - b);
+                        const uint32_t rem = y & rmask;
+                        bool placed = false;
+                        for (int hop = 0; hop < 2 && !placed; ++hop) {
+                            uint32_t* e = &c1[(size_t)bk * 4];
+                            for (int q = 0; q < 4 && !placed; ++q)
+                                if ((e[q] & 0x7FFFu) == KM1_VID_EMPTY && (e[q] >> 16) == 0xFFFFu) {
+                                    e[q] = (e[q] & 0x8000u) | ((rem | (hop ? 0x8000u : 0u)) << 16) | vid[i];
+                                    placed = true;
+                                }
+                            if (!placed) { e[3] |= 0x8000u; bk = (bk + 1) & (nbk - 1); } // full: later lookups that miss here try the next bucket
+                        }
+                        placed_all = placed;
+                    }
+                    if (placed_all) break;
+                }
+                if (fits && b <= 28) { // else: the MODE_ 5 form of k_classify_tile serves the panel
+                    RKCHK(c->d_km1.reserve(c1.size() * 4));
+                    HIPCHK(hipMemcpy(c->d_km1.p, c1.data(), c1.size() * 4, hipMemcpyHostToDevice));
+                    RKCHK(c->d_km1v.reserve(vals.size() * 4 + 16));
+                    if (!vals.empty()) HIPCHK(hipMemcpy(c->d_km1v.p, vals.data(), vals.size() * 4, hipMemcpyHostToDevice));
+                    c->ix.km1 = c->d_km1.as<uint4>(); c->ix.km1_b = b; c->ix.km1_vals = c->d_km1v.as<uint32_t>();
                 }
             }
             RKCHK(c->d_kf4.reserve(f4.size() * 4));
@@ -1125,7 +1180,7 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     for (int j = 0; j < c->ks.n; ++j) expect += (int)(c->density * (double)num_windows((int)ml, c->ks.k[j], c->pol.drop_last_window)) + 1;
     // plain classification with the single k the exact k-mer map was enumerated for: the k-mer-space kernel (rk_kmer.hip)
     static const bool kmer_v2 = !(getenv("RKMH_KMER_V2") && atoi(getenv("RKMH_KMER_V2")) == 0); // 0: the MODE_ 5 form of k_classify_tile (A/B)
-    if (mode == 0 && !counter && kmer_v2 && c->ix.kf4 && c->ix.kmap && c->ks.n == 1 && (uint32_t)c->ks.k[0] == c->ix.kpk &&
+    if (mode == 0 && !counter && kmer_v2 && c->ix.kf4 && c->ix.km1 && c->ks.n == 1 && (uint32_t)c->ks.k[0] == c->ix.kpk &&
         classify_kmer_supported(c->ix.nref, (int)ml, c->ks.k[0]))
         HIPCHK(launch_classify_kmer((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks.k[0], c->S, c->ix,
                                     (int32_t*)d_out4, c->pol, (int)ml, expect, st));

@@ -124,7 +124,7 @@ __host__ __device__ __forceinline__ uint32_t kpre_word_off(uint32_t vf, uint32_t
 // pairs of every found k-mer X whose alignment-j core (X >> 2 * (3 - j)) maps to the sector.  Keys are entered in BOTH orientations
 // (X and its reverse complement), so the window loop never forms a reverse complement; the drain canonicalises the few candidates.
 __host__ __device__ __forceinline__ uint32_t kf4_core_mask(int k) { return k > 3 ? (1u << (2 * (k - 3))) - 1u : 0u; }
-__host__ __device__ __forceinline__ uint32_t kf4_sector(uint32_t core, uint32_t lg) { return lg ? (core * 0x85EBCA6Bu) >> (32u - lg) : 0u; }
+__host__ __device__ __forceinline__ uint32_t kf4_sector(uint32_t core, uint32_t lg) { return (core * 0x85EBCA6Bu) >> (32u - lg); } // 1 <= lg <= 31
 // the two bits of a k-mer inside its dword: the TOP ten bits of x * odd constant (mod 2^32), which every bit of x reaches -- a
 // window that differs from a found k-mer only in a base outside the core (a sequencing error in the flank) lands in the same
 // sector and must not land on the same bits (the middle bits of the 64-bit product, one instruction cheaper, fail that for the
@@ -450,7 +450,19 @@ struct RefIndex {
     // forward-strand group filter of k_classify_kmer (rk_kmer.hip; see kf4_sector above): 2^kf4_lg sectors of 16 bytes
     const uint4* kf4;
     uint32_t kf4_lg;
+    const uint4* km1;      // single-probe exact map (see KM1_C above), 2^km1_b buckets
+    uint32_t km1_b;
+    const uint32_t* km1_vals;
 };
+// ... and the single-probe form of that map the k-mer-space kernel (rk_kmer.hip) resolves its candidates in: one 16-byte bucket of
+// four 4-byte cells per lookup.  y = key * odd constant is a bijection on 32 bits, so (bucket = top km1_b bits of y, remainder =
+// the other 32 - km1_b <= 15 bits) IS the key: a cell holds the remainder (high half; bit 15 = the cell's key belongs to the
+// PREVIOUS bucket, which was full) and a 15-bit value id (low half; bit 15 of the bucket's last cell = a key of this bucket was
+// displaced into the next one).  Value ids below KM1_VID_TABLE are a single posting of multiplicity 1 (the id is the reference);
+// KM1_VID_ZERO marks a k-mer whose canonical hash is 0; other ids index km1_vals, which holds index values in the RefIndex::kv format.
+constexpr uint32_t KM1_C = 0x9E3779B1u;
+constexpr uint32_t KM1_VID_TABLE = 16384u, KM1_VID_ZERO = 0x7FFEu, KM1_VID_EMPTY = 0x7FFFu;
+constexpr uint32_t KM1_CELL_EMPTY = 0xFFFF0000u | KM1_VID_EMPTY; // remainder field 0xFFFF: no remainder (<= 15 bits + displaced bit... see below) equals it
 constexpr uint32_t KMAP_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t KMAP_ZERO = 0xFFFFFFFEu; // not a valid index value (bit 31 set => postings offset < 2^31 - 1)
 __host__ __device__ __forceinline__ uint32_t kmap_cell1(uint32_t key, uint32_t m) { return (uint32_t)(((uint64_t)(key * 0x9E3779B1u) * m) >> 32); }

@@ -16,31 +16,46 @@
 //   * tiles of unequal reads and tiles with non-ACGT bases stay in k-mer space too (a window holding an invalid base hashes to 0 by
 //     definition -- counted from a validity bitmap -- and read boundaries only change the group -> read mapping): the kernel
 //     contains no murmur code at all.
-//   * the drain canonicalises a candidate (bit reverse), resolves it by k-mer in the exact cuckoo map (kmap), and uses the k-mer
-//     itself as identity in the per-read hit set; two drain rounds' lookups are in flight together.
+//   * the drain canonicalises a candidate (bit reverse), resolves it by k-mer with ONE 16-byte load of the exact map (km1), and uses the k-mer
+//     itself as identity in the per-read hit multiset; two drain rounds' lookups are in flight together.
+//   * the LDS layout is static (compile-time offsets: no address arithmetic on a run-time base, no SGPRs for the sub-arrays).
 // Work decomposition as before: ONE WAVE = one tile of T consecutive reads, a workgroup is a single wave (no barriers).
 #include "rk_kernels.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace rk {
 
 namespace {
 
 constexpr int KW = 64;
-constexpr int KM_MAX_T = 8;        // reads per tile (phase 2 takes eight reads in one pass; the group -> read search is unrolled for it)
-constexpr int KM_MQ = 32;          // deferred multi-posting hits per tile (more are walked by their own lane)
-constexpr int KM_CH = 4;           // steps (64 groups = 256 windows each) whose filter sectors are requested together
-constexpr int KM_QCAP = 64 + 4 * KW; // candidate queue entries (4 bytes each): a step adds at most 256 to a remainder of < 64
-#ifndef RK_KMER_WAVES
-#define RK_KMER_WAVES 6
+constexpr int KM_MAX_T = 8;          // reads per tile (phase 2 takes eight reads in one pass; the group -> read search is unrolled for it)
+constexpr int KM_MQ = 32;            // deferred multi-posting hits per drain (more are walked by their own lane)
+#ifndef RK_KMER_ABL
+#define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values
 #endif
+#ifndef RK_KMER_DR
+#define RK_KMER_DR 2 // drain rounds whose map lookups are in flight together
+#endif
+#ifndef RK_KMER_CH
+#define RK_KMER_CH 2
+#endif
+constexpr int KM_CH = RK_KMER_CH;     // steps (64 groups = 256 windows each) whose filter sectors are requested together
+constexpr int KM_QCAP = 64 + 4 * KW; // candidate queue entries (4 bytes each): a step adds at most 256 to a remainder of < 64
+constexpr int KM_LDS_SMALL = 5120;   // static LDS of the common instantiation: 32 single-wave workgroups per CU (8 per SIMD)
+constexpr int KM_LDS_BIG = 20480;    // ... of the one for large hit multisets / counter rows (8 per CU)
+#ifndef RK_KMER_WAVES
+#define RK_KMER_WAVES 7
+#endif
+
+// per-read reference counters: packed 8-bit (no read has more than 255 windows), packed 16-bit, or a 128-entry map ref -> count
+enum { CM_DENSE8 = 0, CM_DENSE16 = 1, CM_SPARSE = 2 };
 
 struct KmerGeom {
     int32_t T;         // reads per tile
-    int32_t cap_bytes; // largest tile (bytes) that fits the staged quads: NQ * 1024 - 15
-    int32_t cwords, clg, csparse; // per-read reference counters, as in k_classify_tile
-    int32_t dset;      // slots of the per-read hit set (power of two)
+    int32_t cwords;    // counter words per read
+    int32_t dset;      // slots of the per-read hit multiset (power of two)
     int32_t tpb, xcd;
     int32_t L;         // hinted read length ...
     int32_t gpr;       // ... its groups per read = ceil(windows / 4) ...
@@ -50,11 +65,23 @@ struct KmerGeom {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(1))) km_pair1 { uint32_t x, y; };
 
-__host__ __device__ inline int km_pk_dwords(int nq) { return nq * 64 + 2; }
-__host__ __device__ inline int km_inv_dwords(int nq) { return nq * 32 + 2; }
-__host__ __device__ inline size_t km_lds_bytes(const KmerGeom& g, int nq) {
-    return ((size_t)km_pk_dwords(nq) + km_inv_dwords(nq) + (size_t)KM_QCAP + 2 * KM_MQ + 4 * (KM_MAX_T + 1) + 3 * KM_MAX_T +
-            (size_t)g.T * (size_t)(g.cwords + g.dset)) * 4;
+// static LDS layout (dwords)
+template <int NQ>
+struct KmLds {
+    static constexpr int PK = 0;                              // packed 2-bit image of the staged quads + two zero dwords (position P = byte P of the quads)
+    static constexpr int INV = PK + NQ * 64 + 2;              // bit P set <=> base P is not ACGT (built only for tiles that hold one)
+    static constexpr int Q = INV + NQ * 32 + 2;               // candidate queue: P | read << 12 | (window within the read) << 15
+    static constexpr int MQ = Q + KM_QCAP;                    // [KM_MQ][2] deferred hits with a posting list: read | rank << 8, list offset
+    static constexpr int RI = MQ + 2 * KM_MQ;                 // [9] uint4 {start position, windows, first group, -} of read t
+    static constexpr int NZ = RI + 4 * (KM_MAX_T + 1);        // [8] zero hashes of read t
+    static constexpr int BEST = NZ + KM_MAX_T;                // [8] max over increments of (count << 16 | 0xFFFF - ref)
+    static constexpr int FLAGS = BEST + KM_MAX_T;             // [8] read must take the general path
+    static constexpr int CNT = FLAGS + KM_MAX_T;              // [T][cwords] per-reference counters, then [T][dset] hit multisets
+    static_assert(RI % 4 == 0, "rinfo is read with 16-byte LDS loads");
+    static_assert(CNT % 4 == 0, "the multisets are cleared with 16-byte LDS stores");
+};
+inline size_t km_lds_bytes(const KmerGeom& g, int nq) {
+    return ((size_t)(nq == 1 ? KmLds<1>::CNT : KmLds<2>::CNT) + (size_t)g.T * (size_t)(g.cwords + g.dset)) * 4;
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -102,32 +129,34 @@ __device__ __forceinline__ uint32_t km_nonzero4(uint32_t m) {
     return ((y >> 7) * 0x01020408u) >> 24;
 }
 
-template <int KT, int NQ>
-__global__ __launch_bounds__(KW, RK_KMER_WAVES) void k_classify_kmer(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
-                                                                     uint32_t nreads, int S, RefIndex ix, int32_t* __restrict__ out4,
-                                                                     DevPolicy pol, KmerGeom geo) {
+template <int KT, int NQ, int CMODE, bool BIG>
+__global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
+                                                                              uint32_t nreads, int S, RefIndex ix, int32_t* __restrict__ out4,
+                                                                              DevPolicy pol, KmerGeom geo) {
     static_assert(KT >= 4 && KT <= 16, "a k-mer packs into 32 bits; the core is the (k-3)-mer");
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    using L = KmLds<NQ>;
+    __shared__ __attribute__((aligned(16))) uint32_t smem[(BIG ? KM_LDS_BIG : KM_LDS_SMALL) / 4];
     constexpr uint32_t KMASK = KT == 16 ? 0xffffffffu : ((1u << (2 * KT)) - 1u);
     constexpr uint32_t CMASK = (1u << (2 * (KT - 3))) - 1u;
     constexpr uint32_t KBITS = (1u << KT) - 1u; // KT validity bits
+    constexpr uint32_t PAD_P = NQ * 1024;       // position of the image's zero padding: where lanes without a group look
+    constexpr uint32_t clg = CMODE == CM_DENSE8 ? 2 : 1, cbits = 32u >> clg, cmask = (1u << cbits) - 1u;
+    uint32_t* const pk = smem + L::PK;
+    uint32_t* const inv = smem + L::INV;
+    uint32_t* const q = smem + L::Q;
+    uint32_t* const mq = smem + L::MQ;
+    uint4* const rinfo = reinterpret_cast<uint4*>(smem + L::RI);
+    uint32_t* const nzero = smem + L::NZ;
+    uint32_t* const best = smem + L::BEST;
+    uint32_t* const flags = smem + L::FLAGS;
+    uint32_t* const cnt = smem + L::CNT;
     const int T = geo.T;
-    constexpr uint32_t QCAP = (uint32_t)KM_QCAP;
-    const uint32_t DS = (uint32_t)geo.dset;
-    uint32_t* pk = smem;                                          // packed 2-bit image of the staged quads (position P = byte P of the quads)
-    uint32_t* inv = pk + km_pk_dwords(NQ);                        // bit P set <=> base P is not ACGT (built only for tiles that hold one)
-    uint32_t* q = inv + km_inv_dwords(NQ);                        // candidate queue: P | read << 11 | (window within the read) << 15
-    uint32_t* mq = q + QCAP;                                      // [KM_MQ][2] deferred hits with a posting list: read, list offset
-    uint4* rinfo = reinterpret_cast<uint4*>(mq + 2 * KM_MQ);      // [T+1] {start position, windows, first group, -} of read t (16-byte aligned: all sizes above are even... see launcher)
-    uint32_t* nzero = reinterpret_cast<uint32_t*>(rinfo + (KM_MAX_T + 1)); // [T] zero hashes of read t
-    uint32_t* best = nzero + KM_MAX_T;                            // [T] max over increments of (count << 16 | 0xFFFF - ref)
-    uint32_t* flags = best + KM_MAX_T;                            // [T] read must take the general path
-    uint32_t* cnt = flags + KM_MAX_T;                             // [T][cwords] packed per-reference counters
-    uint32_t* dset = cnt + T * geo.cwords;                        // [T][DS] k-mers (+1) the read has hit
+    const uint32_t CW = (uint32_t)geo.cwords, DS = (uint32_t)geo.dset;
+    uint32_t* const dset = cnt + (uint32_t)T * CW;
+    const uint32_t ds_shift = 32u - (uint32_t)__builtin_ctz(DS);
     const int lane = threadIdx.x;
-    const uint32_t clg = (uint32_t)geo.clg, cper_m1 = (1u << clg) - 1u, cbits = 32u >> clg, cmask = (1u << cbits) - 1u;
 
-    for (int i = lane; i < T * geo.cwords; i += KW) cnt[i] = 0; // re-zeroed by phase 2 after use
+    for (uint32_t i = lane; i < ((uint32_t)T * CW) >> 2; i += KW) reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0u, 0u, 0u, 0u); // re-zeroed by phase 2 after use
     const uint32_t ntiles = (nreads + (uint32_t)T - 1) / (uint32_t)T;
     const uintptr_t gb = reinterpret_cast<uintptr_t>(bases);
     // readable byte range of the batch: [bases, bases + offs[nreads] + 4) (the ABI asks for 4 bytes of slack), whole dwords
@@ -153,7 +182,7 @@ __global__ __launch_bounds__(KW, RK_KMER_WAVES) void k_classify_kmer(const uint8
         const uintptr_t base16 = first & ~(uintptr_t)15;
         const uint32_t nbytes = (uint32_t)(first - base16) + (b_ - a_);
         uint32_t nq = (nbytes + 15u) >> 4;
-        if (nbytes > (uint32_t)(NQ * 1024)) nq = 0; // oversized tile: rerouted, nothing to stage
+        if (nq > (uint32_t)(NQ * KW)) nq = NQ * KW; // oversized tile: the reads that lie inside the staged quads are served, the others rerouted
         const bool safe = base16 >= gb && base16 + 16u * (uintptr_t)nq <= safe_hi; // wave-uniform
 #pragma unroll
         for (int r = 0; r < NQ; ++r) {
@@ -195,14 +224,20 @@ __global__ __launch_bounds__(KW, RK_KMER_WAVES) void k_classify_kmer(const uint8
         wave_sync(); // previous tile fully consumed
         const uint32_t mis = (uint32_t)((gb + ta) & 15u);       // position of the tile's first base inside quad 0
         const uint32_t nbytes = mis + (tb - ta);
-        const bool oversized = nbytes > (uint32_t)(NQ * 1024);
-        if (oversized && lane < tile_reads(tile)) reinterpret_cast<int4*>(out4)[r0 + lane] = make_int4(-2, 0, 0, 0);
-        const int Tn = oversized ? 0 : tile_reads(tile);
-        const uint32_t nq = oversized ? 0u : (nbytes + 15u) >> 4;
-
-        // ---- phase 0: per-read bookkeeping (lane t = read t), packed image, validity ballot ---------------------------------
         const uint32_t o_next = (uint32_t)__shfl_down((int)cur_o, 1);
         const uint32_t len = o_next - cur_o;
+        // A tile longer than the staged quads (only possible when the caller's length hint was too small): the reads that end
+        // inside the quads -- a prefix of the tile -- are served, the others are handed back (rows of -2).
+        int Tn = tile_reads(tile);
+        uint32_t nq = (nbytes + 15u) >> 4;
+        if (nbytes > (uint32_t)(NQ * 1024)) { // wave-uniform, rare
+            const int Tn0 = Tn;
+            Tn = __popcll(__ballot(lane < Tn0 && o_next - ta + mis <= (uint32_t)(NQ * 1024)));
+            if (lane >= Tn && lane < Tn0) reinterpret_cast<int4*>(out4)[r0 + lane] = make_int4(-2, 0, 0, 0);
+            nq = NQ * KW;
+        }
+
+        // ---- phase 0: per-read bookkeeping (lane t = read t), packed image, validity ballot ---------------------------------
         uint32_t nw = 0, ng = 0;
         if (lane < Tn) { nw = (uint32_t)num_windows((int)len, KT, pol.drop_last_window); ng = (nw + 3u) >> 2; }
         uint32_t gs = ng; // inclusive prefix of the group counts over the tile's reads (lanes 0..7)
@@ -212,15 +247,18 @@ __global__ __launch_bounds__(KW, RK_KMER_WAVES) void k_classify_kmer(const uint8
         const uint32_t NG = (uint32_t)__builtin_amdgcn_readlane((int)gs, KM_MAX_T - 1); // groups of the tile
         if (lane <= KM_MAX_T) { // entries past the tile's last read: no windows, first group = NG
             rinfo[lane] = make_uint4(cur_o - ta + mis, nw, gs - ng, 0u);
-            if (lane < Tn) {
+            if (lane < KM_MAX_T) {
                 nzero[lane] = 0; best[lane] = 0;
                 // more windows than a packed counter can count (only possible when the caller's length hint was too small)
-                flags[lane] = nw > (geo.csparse ? 0x7FFu : cmask) ? 1u : 0u;
+                flags[lane] = nw > (CMODE == CM_SPARSE ? 0x7FFu : cmask) ? 1u : 0u;
             }
         }
         const uint32_t ulen = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
         const bool same_len = __ballot(lane < Tn && len != ulen) == 0ull;
-        for (uint32_t i = lane; i < (uint32_t)Tn * DS; i += KW) dset[i] = 0;
+        { // clear the hit multisets: 16 bytes per lane and store
+            uint4* d4 = reinterpret_cast<uint4*>(dset);
+            for (uint32_t i = lane; i < ((uint32_t)Tn * DS) >> 2; i += KW) d4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
         uint32_t mism = 0;
 #pragma unroll
         for (int r = 0; r < NQ; ++r) {
@@ -250,31 +288,34 @@ __global__ __launch_bounds__(KW, RK_KMER_WAVES) void k_classify_kmer(const uint8
         const bool uniform = same_len && gpr_u >= 2u; // >= 2: the magic division needs a divisor > 1
         uint32_t magic = 0;
         if (uniform) magic = ulen == (uint32_t)geo.L ? geo.magic : (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu / gpr_u + 1u));
-        // +1 for reference `ref` of read t; the monotone counters make (max_shared, first max_id) a running atomicMax
-        auto add_posting = [&](uint32_t t, uint32_t ref) {
+
+        // +1 for reference `ref` of read t, whose counter row starts crow_b bytes into cnt; the monotone counters make
+        // (max_shared, first max_id) a running atomicMax
+        auto add_posting = [&](uint32_t t, uint32_t crow_b, uint32_t ref) {
             uint32_t c;
-            if (geo.csparse) { // wave-uniform: large panels keep (ref, count) pairs of the references a read really hits
-                uint32_t* row = cnt + t * (uint32_t)geo.cwords;
-                const uint32_t M1 = (uint32_t)geo.cwords - 1u, key = ref + 1u;
+            if constexpr (CMODE == CM_SPARSE) { // large panels keep (ref, count) pairs of the references a read really hits
+                uint32_t* crow = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(cnt) + crow_b);
+                const uint32_t M1 = CW - 1u, key = ref + 1u;
                 uint32_t idx = ((ref * 0x9E3779B1u) >> 16) & M1, probe = 0;
                 c = 0;
                 for (; probe <= M1; ++probe) {
-                    const uint32_t old = atomicCAS(&row[idx], 0u, (key << 11) | 1u);
+                    const uint32_t old = atomicCAS(&crow[idx], 0u, (key << 11) | 1u);
                     if (old == 0u) { c = 1u; break; }
-                    if ((old >> 11) == key) { c = (atomicAdd(&row[idx], 1u) & 0x7FFu) + 1u; break; }
+                    if ((old >> 11) == key) { c = (atomicAdd(&crow[idx], 1u) & 0x7FFu) + 1u; break; }
                     idx = (idx + 1u) & M1;
                 }
                 if (probe > M1) { flags[t] = 1; return; } // the read hits more references than the map holds: general path
             } else {
-                const uint32_t sh = (ref & cper_m1) * cbits;
-                const uint32_t old = atomicAdd(&cnt[t * (uint32_t)geo.cwords + (ref >> clg)], 1u << sh);
-                c = ((old >> sh) & cmask) + 1u;
+                const uint32_t sh = (ref << (5 - clg)) & (32u - cbits);           // bit position of the counter inside its word
+                const uint32_t woff = (ref >> clg) << 2;                          // byte offset of the word inside the row
+                const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(cnt) + crow_b + woff), 1u << sh);
+                c = __builtin_amdgcn_ubfe(old, sh, cbits) + 1u;
             }
-            atomicMax(&best[t], (c << 16) | (0xFFFFu - ref));
+            atomicMax(&best[t], (c << 16) + (0xFFFFu - ref));
         };
         auto walk_list = [&](uint32_t t, uint32_t rank, uint32_t off) { // the postings of a list this occurrence counts for
             const uint32_t n = ix.post[off];
-            for (uint32_t c = 0; c < n; ++c) if (rank < ix.post[off + 2 + 2 * c]) add_posting(t, ix.post[off + 1 + 2 * c]);
+            for (uint32_t c = 0; c < n; ++c) if (rank < ix.post[off + 2 + 2 * c]) add_posting(t, __umul24(t, CW * 4u), ix.post[off + 1 + 2 * c]);
         };
         uint32_t mqn = 0; // deferred list hits (wave-uniform)
         auto process_mq = [&]() { // 16 lanes walk one hit's posting list, 4 hits at a time
@@ -282,42 +323,49 @@ __global__ __launch_bounds__(KW, RK_KMER_WAVES) void k_classify_kmer(const uint8
             const uint32_t g = (uint32_t)lane >> 4, sl = (uint32_t)lane & 15u;
             for (uint32_t j = g; j < mqn; j += KW / 16) {
                 const uint32_t tr = mq[2 * j], off = mq[2 * j + 1];
-                const uint32_t n = ix.post[off];
-                for (uint32_t c = sl; c < n; c += 16) if ((tr >> 8) < ix.post[off + 2 + 2 * c]) add_posting(tr & 0xFFu, ix.post[off + 1 + 2 * c]);
+                const uint32_t n = ix.post[off], t = tr & 0xFFu;
+                for (uint32_t c = sl; c < n; c += 16) if ((tr >> 8) < ix.post[off + 2 + 2 * c]) add_posting(t, __umul24(t, CW * 4u), ix.post[off + 1 + 2 * c]);
             }
             wave_sync();
             mqn = 0;
         };
-        // one candidate of the queue: canonical k-mer, its read, its two buckets of the exact map (loads in flight on return)
-        struct Cand { uint32_t key, t; bool ok; uint4 c1, c2; };
+        // one candidate of the queue: canonical k-mer, its read, its bucket of the exact map (load in flight on return)
+        struct Cand { uint32_t key, t, y; uint4 c; };
+        const uint32_t km_sh = 32u - ix.km1_b, km_rmask = (1u << km_sh) - 1u;
         auto lookup = [&](uint32_t e, uint32_t qn) -> Cand {
             Cand c;
-            c.key = 0; c.t = 0; c.ok = false;
-            c.c1 = make_uint4(KMAP_EMPTY, 0u, KMAP_EMPTY, 0u); c.c2 = c.c1;
-            if (e < qn) {
-                const uint32_t ent = q[e];
-                const uint32_t P = ent & 2047u, t = (ent >> 11) & 15u, o = ent >> 15;
-                const km_pair1 w = *reinterpret_cast<const km_pair1*>(reinterpret_cast<const uint8_t*>(pk) + (P >> 2));
-                const uint32_t x = __builtin_amdgcn_alignbit(w.y, w.x, (P & 3u) << 1) & KMASK;
-                const uint32_t r = packed_revcomp(x, KT);
-                c.key = x < r ? x : r;
-                c.t = t;
-                c.ok = o < rinfo[t].y; // the last group of a read may reach past its last window
-                c.c1 = ix.kmap[kmap_cell1(c.key, ix.kmap_m)];
-                c.c2 = ix.kmap[kmap_cell2(c.key, ix.kmap_m)];
-            }
+            uint32_t ent = PAD_P | (0x1FFFFu << 15); // past the queue's end: the all-A k-mer of the padding, never a window of its read
+            if (e < qn) ent = q[e];
+            const uint32_t P = ent & 4095u, t = (ent >> 12) & 7u, o = ent >> 15;
+            const km_pair1 w = *reinterpret_cast<const km_pair1*>(reinterpret_cast<const uint8_t*>(pk) + (P >> 2));
+            const uint32_t x = __builtin_amdgcn_alignbit(w.y, w.x, (P & 3u) << 1) & KMASK;
+            const uint32_t r = packed_revcomp(x, KT);
+            c.key = x < r ? x : r;
+            c.t = o < rinfo[t].y ? t : 0xFFFFFFFFu; // the last group of a read may reach past its last window
+            c.y = c.key * KM1_C;
+            c.c = ix.km1[c.y >> km_sh];
             return c;
         };
+        // the cell of the bucket whose remainder field equals want (KM1_CELL_EMPTY: none)
+        auto match_cell = [&](const uint4& b, uint32_t want) -> uint32_t {
+            return (b.x >> 16) == want ? b.x : ((b.y >> 16) == want ? b.y : ((b.z >> 16) == want ? b.z : ((b.w >> 16) == want ? b.w : KM1_CELL_EMPTY)));
+        };
         auto apply = [&](const Cand& c) {
-            uint32_t val = KMAP_EMPTY; // KMAP_EMPTY is no index value (bit 31 set => postings offset < 2^31 - 1)
+            const uint32_t want = c.y & km_rmask;
+            uint32_t cell = match_cell(c.c, want);
+            // a miss in a bucket that displaced a key into the next one: that bucket may hold this key (tagged as displaced)
+            const bool again = (cell & 0x7FFFu) == KM1_VID_EMPTY && (c.c.w & 0x8000u) != 0u && c.t != 0xFFFFFFFFu;
+            if (!(RK_KMER_ABL & 16) && __ballot(again)) {
+                if (again) cell = match_cell(ix.km1[((c.y >> km_sh) + 1u) & ((1u << ix.km1_b) - 1u)], want | 0x8000u);
+            }
+            const uint32_t vid = cell & 0x7FFFu;
+            uint32_t val = vid | (1u << 20); // a single posting of multiplicity 1, in the RefIndex::kv value format
+            const bool hit = vid != KM1_VID_EMPTY && c.t != 0xFFFFFFFFu; // else: a false positive of the bit filter, or a window past its read's last
+            if (!(RK_KMER_ABL & 32) && hit && vid >= KM1_VID_TABLE && vid != KM1_VID_ZERO) val = ix.km1_vals[vid - KM1_VID_TABLE]; // compound value (a few KB: L1-resident)
             uint32_t rank = 0;
-            if (c.c1.x == c.key) val = c.c1.y;
-            else if (c.c1.z == c.key) val = c.c1.w;
-            else if (c.c2.x == c.key) val = c.c2.y;
-            else if (c.c2.z == c.key) val = c.c2.w;
             bool multi = false;
-            if (c.ok && val != KMAP_EMPTY) { // else: a false positive of the bit filter, or a window past its read's last
-                if (val == KMAP_ZERO) atomicAdd(&nzero[c.t], 1u); // a k-mer whose canonical hash is 0
+            if ((RK_KMER_ABL & 2) ? (val == 0x12345u) : hit) {
+                if (vid == KM1_VID_ZERO) atomicAdd(&nzero[c.t], 1u); // a k-mer whose canonical hash is 0
                 else {
                     // hit MULTISET of the read: the canonical k-mer (+1: never 0xFFFFFFFF) is the key's identity, every occurrence
                     // adds one more entry, and the entries passed on the way to the free slot are this occurrence's rank.  The merge
@@ -325,19 +373,22 @@ __global__ __launch_bounds__(KW, RK_KMER_WAVES) void k_classify_kmer(const uint8
                     // counts for a posting iff rank < its multiplicity.
                     uint32_t* ds = dset + c.t * DS;
                     const uint32_t id = c.key + 1u;
-                    uint32_t idx = (c.key * 0x9E3779B1u) >> (32u - (uint32_t)__builtin_ctz(DS));
-                    bool done = false;
-                    for (uint32_t probe = 0; probe < DS && !done; ++probe) {
-                        const uint32_t old = atomicCAS(&ds[idx], 0u, id);
-                        if (old == 0u) done = true;
-                        else { rank += old == id ? 1u : 0u; idx = (idx + 1u) & (DS - 1u); }
+                    uint32_t idx = (c.key * 0x9E3779B1u) >> ds_shift;
+                    uint32_t old = atomicCAS(&ds[idx], 0u, id);
+                    uint32_t probes = 1;
+                    while (old != 0u && probes < DS) { // the wave leaves this loop when its last lane has found a free slot
+                        rank += old == id ? 1u : 0u;
+                        idx = (idx + 1u) & (DS - 1u);
+                        old = atomicCAS(&ds[idx], 0u, id);
+                        ++probes;
                     }
-                    if (!done) flags[c.t] = 1; // more hits than the set holds: general path
+                    if (old != 0u) flags[c.t] = 1; // more hits than the set holds: general path
                     else if (!(val >> 31)) { // one posting (with multiplicity) or two single postings, stored inline
                         const bool two = ((val >> 29) & 3u) != 0u;
                         if (rank < (two ? 1u : ((val >> 20) & 0x1FFu))) {
-                            add_posting(c.t, val & (two ? 0x7FFu : 0xFFFFFu));
-                            if (two) add_posting(c.t, (val >> 11) & 0x7FFu);
+                            const uint32_t crow_b = __umul24(c.t, CW * 4u);
+                            add_posting(c.t, crow_b, val & (two ? 0x7FFu : 0xFFFFFu));
+                            if (two) add_posting(c.t, crow_b, (val >> 11) & 0x7FFu);
                         }
                     } else multi = true;
                 }
@@ -354,6 +405,7 @@ __global__ __launch_bounds__(KW, RK_KMER_WAVES) void k_classify_kmer(const uint8
             }
         };
         auto drain = [&](uint32_t qn) {
+#if RK_KMER_DR == 2
             for (uint32_t e0 = 0; e0 < qn; e0 += 2 * KW) { // two rounds of lookups in flight
                 const bool two = e0 + KW < qn;
                 const Cand a = lookup(e0 + (uint32_t)lane, qn);
@@ -362,85 +414,89 @@ __global__ __launch_bounds__(KW, RK_KMER_WAVES) void k_classify_kmer(const uint8
                 apply(a);
                 if (two) apply(b);
             }
+#else
+            for (uint32_t e0 = 0; e0 < qn; e0 += KW) apply(lookup(e0 + (uint32_t)lane, qn));
+#endif
             if (mqn) process_mq();
         };
 
         // ---- window phase: 64 groups (256 windows) per step, KM_CH steps' filter sectors requested together ---------------------
         const uint32_t nsteps = (NG + KW - 1) / KW;
-        const uint32_t rs0 = mis;
         uint32_t qcount = 0;
         uint32_t step = 0;
         for (;;) {
+            // issue: every lane computes; a lane without a group looks at the image's zero padding (the all-A k-mer) and tags its
+            // candidates, should the filter pass that k-mer, with a window number no read has -- the drain drops them
             uint32_t wl[KM_CH], wh[KM_CH], e0v[KM_CH];
             u32x4 fw[KM_CH];
 #pragma unroll
             for (int s = 0; s < KM_CH; ++s) {
-                wl[s] = 0; wh[s] = 0; e0v[s] = 0xFFFFFFFFu; fw[s] = u32x4{0u, 0u, 0u, 0u};
-                if (step + (uint32_t)s < nsteps) { // wave-uniform
-                    const uint32_t G = (step + (uint32_t)s) * KW + (uint32_t)lane;
-                    if (G < NG) {
-                        uint32_t t, g, rs;
-                        if (uniform) { // wave-uniform
-                            t = __umulhi(G, magic);
-                            g = G - t * gpr_u;
-                            rs = rs0 + t * ulen;
-                        } else {
-                            t = 0; // the last read whose first group is <= G (rinfo[i].z of reads past the tile's last is NG)
+                const uint32_t G = (step + (uint32_t)s) * KW + (uint32_t)lane;
+                uint32_t t, g, rs;
+                if (uniform) { // wave-uniform
+                    t = __umulhi(G, magic);
+                    g = G - __umul24(t, gpr_u);
+                    rs = mis + __umul24(t, ulen);
+                } else {
+                    t = 0; // the last read whose first group is <= G (rinfo[i].z of reads past the tile's last is NG)
 #pragma unroll
-                            for (int i = 1; i < KM_MAX_T; ++i) t += G >= rinfo[i].z ? 1u : 0u;
-                            const uint4 ri = rinfo[t];
-                            g = G - ri.z;
-                            rs = ri.x;
-                        }
-                        const uint32_t P0 = rs + 4u * g;
-                        const km_pair1 w = *reinterpret_cast<const km_pair1*>(reinterpret_cast<const uint8_t*>(pk) + (P0 >> 2));
-                        const uint32_t sh = (P0 & 3u) << 1;
-                        wl[s] = __builtin_amdgcn_alignbit(w.y, w.x, sh);
-                        wh[s] = w.y >> sh;
-                        e0v[s] = P0 | (t << 11) | (g << 17);
-                        const uint32_t core = (__builtin_amdgcn_alignbit(wh[s], wl[s], 6)) & CMASK;
-                        fw[s] = reinterpret_cast<const u32x4*>(ix.kf4)[kf4_sector(core, ix.kf4_lg)];
-                    }
+                    for (int i = 1; i < KM_MAX_T; ++i) t += G >= rinfo[i].z ? 1u : 0u;
+                    const uint4 ri = rinfo[t];
+                    g = G - ri.z;
+                    rs = ri.x;
                 }
+                const bool act = G < NG;
+                const uint32_t P0 = act ? rs + 4u * g : PAD_P;
+                e0v[s] = act ? (P0 | (t << 12) | (g << 17)) : (PAD_P | (0x1FFFCu << 15));
+                const km_pair1 w = *reinterpret_cast<const km_pair1*>(reinterpret_cast<const uint8_t*>(pk) + (P0 >> 2));
+                const uint32_t sh = (P0 & 3u) << 1;
+                wl[s] = __builtin_amdgcn_alignbit(w.y, w.x, sh);
+                wh[s] = w.y >> sh;
+                const uint32_t core = KT == 16 ? wl[s] >> 6 : (wl[s] >> 6) & CMASK; // k = 16: the 13-mer is all of bits 6..31
+                fw[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(ix.kf4) + ((uint64_t)kf4_sector(core, ix.kf4_lg) << 4));
             }
+            // test + push.  has_invalid (a tile with a non-ACGT base, rare) runs its own copy of the code.
             bool stop = false;
             uint32_t done = 0;
+            auto test_step = [&](int s, auto inv_tag) {
+                constexpr bool INV = decltype(inv_tag)::value;
+                uint32_t ib = 0, nz = 0, nwt = 0, t_ = 0;
+                bool act = true;
+                if constexpr (INV) {
+                    const uint32_t P0 = e0v[s] & 4095u;
+                    act = P0 != PAD_P;
+                    t_ = (e0v[s] >> 12) & 7u;
+                    if (act) { ib = __builtin_amdgcn_alignbit(inv[(P0 >> 5) + 1], inv[P0 >> 5], P0 & 31u); nwt = rinfo[t_].y; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t x = j == 0 ? wl[s] : __builtin_amdgcn_alignbit(wh[s], wl[s], 2 * j);
+                    if (KT < 16) x &= KMASK;
+                    const uint32_t h = kf4_h(x);
+                    const uint32_t f = j == 0 ? fw[s].x : (j == 1 ? fw[s].y : (j == 2 ? fw[s].z : fw[s].w));
+                    bool cand = (__builtin_amdgcn_ubfe(f, h >> 27, 1u) & __builtin_amdgcn_ubfe(f, h >> 22, 1u)) != 0u;
+                    if constexpr (INV) {
+                        if (act && ((ib >> j) & KBITS) != 0u) { // a window holding a non-ACGT base hashes to 0 (if it is a window of the read)
+                            cand = false;
+                            if ((e0v[s] >> 15) + (uint32_t)j < nwt) ++nz;
+                        }
+                    }
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(cand);
+                    // inverse_ballot turns the mask back into the branch predicate (no second compare for the exec mask)
+                    if (__builtin_amdgcn_inverse_ballot_w64(m)) q[qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = e0v[s] + (uint32_t)j * 0x8001u;
+                    qcount += (uint32_t)__builtin_popcountll(m);
+                }
+                if constexpr (INV) { if (nz) atomicAdd(&nzero[t_], nz); }
+            };
 #pragma unroll
             for (int s = 0; s < KM_CH; ++s) {
                 if (step + (uint32_t)s < nsteps && !stop) { // wave-uniform
-                    if (qcount + 4u * KW > QCAP) stop = true;
+                    if (qcount + 4u * KW > (uint32_t)KM_QCAP) stop = true;
                     else {
                         ++done;
-                        { // lanes without a group carry an all-zero sector: none of their windows passes, and every lane takes part
-                          // in the ballots that advance the (wave-uniform) queue length
-                            const bool active = e0v[s] != 0xFFFFFFFFu;
-                            uint32_t ib = 0, nz = 0, nwt = 0;
-                            if (has_invalid && active) { // has_invalid: wave-uniform, rare
-                                const uint32_t P0 = e0v[s] & 2047u;
-                                ib = __builtin_amdgcn_alignbit(inv[(P0 >> 5) + 1], inv[P0 >> 5], P0 & 31u);
-                                nwt = rinfo[(e0v[s] >> 11) & 15u].y;
-                            }
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const uint32_t x = (j == 0 ? wl[s] : __builtin_amdgcn_alignbit(wh[s], wl[s], 2 * j)) & KMASK;
-                                const uint32_t h = kf4_h(x);
-                                const uint32_t f = j == 0 ? fw[s].x : (j == 1 ? fw[s].y : (j == 2 ? fw[s].z : fw[s].w));
-                                bool cand = (((f >> (h >> 27)) & (f >> ((h >> 22) & 31u))) & 1u) != 0u;
-                                if (has_invalid) {
-                                    if (active && ((ib >> j) & KBITS) != 0u) { // a window holding a non-ACGT base hashes to 0 (if it is a window of the read)
-                                        cand = false;
-                                        if ((e0v[s] >> 15) + (uint32_t)j < nwt) ++nz;
-                                    }
-                                }
-                                const uint64_t m = __ballot(cand);
-                                if (cand) {
-                                    const uint32_t qi = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                                    q[qi] = e0v[s] + (uint32_t)j * 0x8001u;
-                                }
-                                qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
-                            }
-                            if (has_invalid && nz) atomicAdd(&nzero[(e0v[s] >> 11) & 15u], nz);
-                        }
+                        if (RK_KMER_ABL & 1) { if (wl[s] == 0x12345u && fw[s].x == 77u) q[qcount++] = e0v[s]; }
+                        else if (has_invalid) test_step(s, std::true_type{});
+                        else test_step(s, std::false_type{});
                     }
                 }
             }
@@ -450,7 +506,7 @@ __global__ __launch_bounds__(KW, RK_KMER_WAVES) void k_classify_kmer(const uint8
             if (last && ntile < ntiles) fetch_tile(cur_a, cur_b);
             wave_sync();
             const uint32_t qn = last ? qcount : (qcount & ~(uint32_t)(KW - 1)); // mid-tile: whole waves of candidates only
-            drain(qn);
+            if (!(RK_KMER_ABL & 4)) drain(qn);
             wave_sync();
             if (last) break;
             const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
@@ -466,14 +522,14 @@ __global__ __launch_bounds__(KW, RK_KMER_WAVES) void k_classify_kmer(const uint8
         {
             const int lsh = Tn > 4 ? 3 : 4, LPR = 1 << lsh; // wave-uniform
             const int g = lane >> lsh, sl = lane & (LPR - 1);
-            for (int t = g; t < Tn; t += KW >> lsh) {
-                uint32_t* ct = cnt + t * geo.cwords;
+            for (int t = g; t < ((RK_KMER_ABL & 8) ? 0 : Tn); t += KW >> lsh) {
+                uint32_t* ct = cnt + (uint32_t)t * CW;
                 const int nmins = (int)rinfo[t].y - (int)nzero[t];
-                // bottom-S selection matters, or the hit set overflowed: exact answer comes from the general path
+                // bottom-S selection matters, or the hit multiset overflowed: exact answer comes from the general path
                 const bool reroute = nmins > S || flags[t] != 0;
                 const uint32_t bk = best[t];
                 if (reroute) {
-                    for (int w = sl; w < geo.cwords; w += LPR) ct[w] = 0;
+                    for (uint32_t w = sl; w < CW >> 2; w += LPR) reinterpret_cast<uint4*>(ct)[w] = make_uint4(0u, 0u, 0u, 0u);
                     if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(-2, 0, 0, 0);
                     continue;
                 }
@@ -481,56 +537,93 @@ __global__ __launch_bounds__(KW, RK_KMER_WAVES) void k_classify_kmer(const uint8
                 const int max_id = bk ? (int)(0xFFFFu - (bk & 0xFFFFu)) : 0;
                 const int max_shared = (int)(bk >> 16);
                 int prev = max_id > 0 ? 0 : -1;
-                if (geo.csparse) {
-                    for (int w = sl; w < geo.cwords; w += LPR) {
+                if constexpr (CMODE == CM_SPARSE) {
+                    for (uint32_t w = sl; w < CW; w += LPR) {
                         const uint32_t x = ct[w];
                         const int r_ = (int)(x >> 11) - 1, cj = (int)(x & 0x7FFu);
                         if (x != 0u && r_ < max_id && cj > prev) prev = cj;
                     }
-                } else
-                for (int w = sl; (w << clg) < max_id; w += LPR) {
-                    uint32_t x = ct[w];
-                    for (uint32_t j = 0; j <= cper_m1; ++j) { // counters of references (w << clg) + j < max_id
-                        const int cj = (int)(x & cmask);
-                        x >>= cbits;
-                        if ((int)((uint32_t)(w << clg) + j) < max_id && cj > prev) prev = cj;
+                } else if (max_id > 0) {
+                    // counters of references below max_id: whole words up to the one that holds reference max_id - 1, of which only
+                    // the low fields count
+                    const int wb = (max_id - 1) >> clg;
+                    const uint32_t kb = (uint32_t)max_id - ((uint32_t)wb << clg);              // 1 .. counters per word
+                    const uint32_t mb = 0xFFFFFFFFu >> (32u - kb * cbits);
+                    uint32_t acc = 0;
+                    for (int w = sl; w <= wb; w += LPR) {
+                        const uint32_t x = ct[w] & (w == wb ? mb : 0xFFFFFFFFu);
+                        if constexpr (CMODE == CM_DENSE8) {
+                            const uint32_t m01 = (x & 0xFFu) > ((x >> 8) & 0xFFu) ? (x & 0xFFu) : ((x >> 8) & 0xFFu);
+                            const uint32_t m23 = ((x >> 16) & 0xFFu) > (x >> 24) ? ((x >> 16) & 0xFFu) : (x >> 24);
+                            const uint32_t m = m01 > m23 ? m01 : m23;
+                            acc = acc > m ? acc : m;
+                        } else {
+                            const uint32_t m = (x & 0xFFFFu) > (x >> 16) ? (x & 0xFFFFu) : (x >> 16);
+                            acc = acc > m ? acc : m;
+                        }
                     }
+                    prev = (int)acc > prev ? (int)acc : prev;
                 }
                 prev = LPR == 16 ? row_max_i32(prev) : half_row_max_i32(prev);
                 wave_sync();
-                for (int w = sl; w < geo.cwords; w += LPR) ct[w] = 0;
+                for (uint32_t w = sl; w < CW >> 2; w += LPR) reinterpret_cast<uint4*>(ct)[w] = make_uint4(0u, 0u, 0u, 0u); // rows are whole 16-byte units
                 if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(max_id, max_shared, max_shared - prev, nmins);
             }
         }
     }
 }
 
-// LDS budget of one single-wave workgroup for 8 waves per SIMD (32 per CU of 160 KB)
-constexpr size_t KM_LDS_BUDGET = 5120;
-
-KmerGeom make_kmer_geom(int maxlen, int nref, int expect_hits, int nw_per_read, int win_total, int nq) {
-    KmerGeom g;
+bool make_kmer_geom(KmerGeom& g, int maxlen, int nref, int expect_hits, int nw_per_read, int nq, int& cmode, bool& big) {
     if (maxlen < 1) maxlen = 1;
-    g.cap_bytes = nq * 1024 - 15;
-    g.clg = win_total <= 255 ? 2 : 1;
-    g.cwords = (nref + (1 << g.clg) - 1) >> g.clg;
-    g.csparse = 0;
-    if (nref > 0 && g.cwords >= 129) { g.csparse = 1; g.cwords = 128; }
+    cmode = nw_per_read <= 255 ? CM_DENSE8 : CM_DENSE16;
+    const int clg = cmode == CM_DENSE8 ? 2 : 1;
+    g.cwords = (nref + (1 << clg) - 1) >> clg;
+    // Many references: a dense counter row per read would eat the LDS budget (and reference ids beyond 2048 would not fit at all),
+    // so the row becomes a 128-entry map of the references the read actually hits.
+    if (nref > 0 && g.cwords >= 129) { cmode = CM_SPARSE; g.cwords = 128; }
+    g.cwords = (g.cwords + 3) & ~3; // rows stay 16-byte aligned
     int ds = 64;
     while (ds < 3 * expect_hits && ds < 1024) ds <<= 1;
     g.dset = ds;
-    int T = g.cap_bytes / maxlen;
+    int T = (nq * 1024 - 15) / maxlen;
     if (T > KM_MAX_T) T = KM_MAX_T;
     if (T < 1) T = 1;
     static const int forced_t = getenv("RKMH_KMER_T") ? atoi(getenv("RKMH_KMER_T")) : 0;
     if (forced_t > 0 && forced_t < T) T = forced_t;
     g.T = T;
-    while (g.T > 1 && km_lds_bytes(g, nq) > KM_LDS_BUDGET) g.T -= 1;
+    big = false;
+    // the small layout if at least half the reads the staged quads could hold fit it, else the large one
+    while (g.T > 1 && km_lds_bytes(g, nq) > (size_t)KM_LDS_SMALL) g.T -= 1;
+    if (km_lds_bytes(g, nq) > (size_t)KM_LDS_SMALL || 2 * g.T < T) {
+        big = true;
+        g.T = T;
+        while (g.T > 1 && km_lds_bytes(g, nq) > (size_t)KM_LDS_BIG) g.T -= 1;
+        if (km_lds_bytes(g, nq) > (size_t)KM_LDS_BIG) return false;
+    }
     g.tpb = 2; g.xcd = 1;
     g.L = maxlen;
     g.gpr = (nw_per_read + 3) >> 2;
     g.magic = g.gpr >= 2 ? 0xFFFFFFFFu / (uint32_t)g.gpr + 1u : 0u;
-    return g;
+    return true;
+}
+
+template <int KT>
+hipError_t launch_k(int nq, int cmode, bool big, dim3 grid, hipStream_t st, const uint8_t* bases, const uint32_t* offs, uint32_t nreads,
+                    int S, const RefIndex& ix, int32_t* out4, const DevPolicy& pol, const KmerGeom& geo) {
+#define RK_KM_GO(NQ, CM, BIG) hipLaunchKernelGGL((k_classify_kmer<KT, NQ, CM, BIG>), grid, dim3(KW), 0, st, bases, offs, nreads, S, ix, out4, pol, geo)
+#define RK_KM_CM(NQ, BIG)                                                                                    \
+    do {                                                                                                     \
+        if (cmode == CM_DENSE8) RK_KM_GO(NQ, CM_DENSE8, BIG);                                                \
+        else if (cmode == CM_DENSE16) RK_KM_GO(NQ, CM_DENSE16, BIG);                                         \
+        else RK_KM_GO(NQ, CM_SPARSE, BIG);                                                                   \
+    } while (0)
+    if (nq == 1 && !big) RK_KM_CM(1, false);
+    else if (nq == 1) RK_KM_CM(1, true);
+    else if (!big) RK_KM_CM(2, false);
+    else RK_KM_CM(2, true);
+#undef RK_KM_CM
+#undef RK_KM_GO
+    return hipGetLastError();
 }
 
 } // namespace
@@ -545,40 +638,26 @@ hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint
     if (nreads == 0) return hipSuccess;
     const int nq = maxlen <= 1024 - 15 ? 1 : 2;
     const int nw = num_windows(maxlen, k, pol.drop_last_window);
-    KmerGeom geo = make_kmer_geom(maxlen, ix.nref, expect_hits, nw, nw, nq);
+    KmerGeom geo;
+    int cmode = 0;
+    bool big = false;
+    if (!make_kmer_geom(geo, maxlen, ix.nref, expect_hits, nw, nq, cmode, big)) return hipErrorInvalidConfiguration;
     static const int tpb_env = getenv("RKMH_TILE_TPB") ? atoi(getenv("RKMH_TILE_TPB")) : 0;
     static const int xcd_env = getenv("RKMH_TILE_XCD") ? atoi(getenv("RKMH_TILE_XCD")) : -1;
     if (tpb_env > 0) geo.tpb = tpb_env;
     if (xcd_env >= 0) geo.xcd = xcd_env != 0;
-    const size_t lds = km_lds_bytes(geo, nq);
     const uint32_t ntiles = (nreads + (uint32_t)geo.T - 1) / (uint32_t)geo.T;
     uint32_t grid = (ntiles + (uint32_t)geo.tpb - 1) / (uint32_t)geo.tpb;
     grid = (grid + 7u) & ~7u; // whole rounds of the 8 XCDs: the virtual ids then cover [0, grid) exactly
-#define RK_KM_LAUNCH(KT, NQ)                                                                                                   \
-    do {                                                                                                                       \
-        if (lds > 64 * 1024) {                                                                                                 \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_classify_kmer<KT, NQ>),                         \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-            if (e != hipSuccess) return e;                                                                                     \
-        }                                                                                                                      \
-        hipLaunchKernelGGL((k_classify_kmer<KT, NQ>), dim3(grid), dim3(KW), lds, st, bases, offs, nreads, S, ix, out4, pol, geo); \
-    } while (0)
-#define RK_KM_K(KT) do { if (nq == 1) RK_KM_LAUNCH(KT, 1); else RK_KM_LAUNCH(KT, 2); } while (0)
+#define RK_KM_K(KT) case KT: return launch_k<KT>(nq, cmode, big, dim3(grid), st, bases, offs, nreads, S, ix, out4, pol, geo)
     switch (k) {
-        case 8: RK_KM_K(8); break;
-        case 9: RK_KM_K(9); break;
-        case 10: RK_KM_K(10); break;
-        case 11: RK_KM_K(11); break;
-        case 12: RK_KM_K(12); break;
-        case 13: RK_KM_K(13); break;
-        case 14: RK_KM_K(14); break;
-        case 15: RK_KM_K(15); break;
-        case 16: RK_KM_K(16); break;
+#ifndef RK_KMER_FAST_BUILD // tools/kmer_variants.sh: timing experiments compile the k = 16 kernels only
+        RK_KM_K(8); RK_KM_K(9); RK_KM_K(10); RK_KM_K(11); RK_KM_K(12); RK_KM_K(13); RK_KM_K(14); RK_KM_K(15);
+#endif
+        RK_KM_K(16);
         default: return hipErrorInvalidValue;
     }
 #undef RK_KM_K
-#undef RK_KM_LAUNCH
-    return hipGetLastError();
 }
 
 } // namespace rk
