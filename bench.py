@@ -8,10 +8,14 @@ every reference, argmax/diff) over the rank's resident batch.  Reads are sharded
 every rank owns --reads reads of the global set); reference sketches are built on rank 0 and broadcast over
 RCCL once before the timed region.  Inputs are resident in HBM when the timed region starts.
 
+The timed steps rotate over --batches (default 4) DISTINCT resident batches of --reads reads each (4 x 170 MB = 680 MB, more than
+the 256 MiB Infinity Cache), so no step finds its input cached from the step before: the bases really stream from HBM.
+
 One JSON line on rank 0 with the contract fields plus `roofline` (HBM bound; algorithmic bytes = 170 B per
 read: 150 B bases + 4 B offset + 16 B result) and, at N=1, `cpu_baseline` (the oracle = literal restatement
 of src/rkmh.cpp:845-898 with OpenMP, timed on this box's host cores on a bounded sample of the same reads,
-and used to check the GPU rows bit-for-bit).
+and used to check the GPU rows bit-for-bit), `host_path` (rk_classify_batch from pageable host memory: PCIe inclusive) and `e2e`
+(bin/rkmh stream on a generated FASTQ: parser + PCIe + kernel + TSV, wall clock of the whole process).  Neither is `value`.
 """
 import argparse
 import json
@@ -45,6 +49,63 @@ def usable_cpus():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def e2e_stream(n, L, rb, ro, synth):
+    """bin/rkmh stream on a generated FASTQ in /tmp: wall clock of the whole process (start-up, context, reference sketches,
+    parser, host pipeline, kernel, TSV formatting and writing).  Returns the `e2e` object of the bench line."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "bin", "rkmh")
+    ref = os.path.join(ROOT, "tests", "golden", "data", "all_pave_ref.fa.gz")
+    tmp = tempfile.mkdtemp(prefix="rkmh_e2e_")
+    fq, tsv = os.path.join(tmp, "reads.fq"), os.path.join(tmp, "out.tsv")
+    try:
+        with open(fq, "wb") as f:
+            for lo in range(0, n, 1000000):          # fixed-width records, built 1 M at a time: "@r%09d\n" seq "\n+\n" qual "\n"
+                m = min(1000000, n - lo)
+                qb, _ = synth.generate_reads_fast(rb, ro, lo, lo + m, read_len=L, threads=min(32, os.cpu_count() or 1))
+                rec = np.empty((m, 11 + L + 3 + L + 1), dtype=np.uint8)
+                rec[:, 0] = ord("@"); rec[:, 1] = ord("r"); rec[:, 11 + L] = 10; rec[:, 10] = 10
+                idx = np.arange(lo, lo + m, dtype=np.int64)
+                for d in range(9):
+                    rec[:, 9 - d] = 48 + (idx // 10 ** d) % 10
+                rec[:, 11:11 + L] = qb[: m * L].reshape(m, L)
+                rec[:, 12 + L] = ord("+"); rec[:, 13 + L] = 10
+                rec[:, 14 + L:14 + 2 * L] = ord("I"); rec[:, 14 + 2 * L] = 10
+                f.write(rec.tobytes())
+        size = os.path.getsize(fq)
+        best = None
+        for rep in range(2):                          # the second run finds the file in the page cache, as a pipeline's input would be
+            t = time.perf_counter()
+            r = subprocess.run([exe, "stream", "-r", ref, "-f", fq, "-k", "16", "-s", "1000"], stdout=open(tsv, "wb"), stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t
+            if r.returncode != 0:
+                return {"error": r.stderr.decode()[-300:]}
+            best = dt if best is None else min(best, dt)
+        lines = sum(1 for _ in open(tsv, "rb"))
+        return {"value": n / best, "unit": "reads/s", "reads": n, "fastq_bytes": size, "wall_s": best, "output_lines": lines,
+                "note": "bin/rkmh stream -k 16 -s 1000 on a generated FASTQ, whole process: start-up + reference sketches + parser + PCIe + kernel + TSV"}
+    finally:
+        for x in (fq, tsv):
+            try:
+                os.remove(x)
+            except OSError:
+                pass
+        try:
+            os.rmdir(tmp)
+        except OSError:
+            pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,7 +117,9 @@ def main():
     ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 disables)")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--host-path", action="store_true", help="also time rk_classify_batch from pageable host memory (PCIe-inclusive)")
+    ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the timed steps rotate over (>= 4 x 170 MB defeats the 256 MiB Infinity Cache)")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive rk_classify_batch figure (N=1 only)")
+    ap.add_argument("--e2e-reads", type=int, default=4000000, help="reads of the generated FASTQ for the bin/rkmh stream end-to-end figure (0 disables; N=1 only)")
     a = ap.parse_args()
 
     import rkmh_amd
@@ -85,17 +148,25 @@ def main():
         ctx.set_reference_sketches(sk, ln, ks, S)
 
     n = a.reads
-    lo = rank * n
-    qb, qo = synth.generate_reads_fast(rb, ro, lo, lo + n, read_len=L, threads=min(32, os.cpu_count() or 1))
-    d_b = torch.from_numpy(qb).to(dev)
-    d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev)
-    d_out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    nb = max(1, a.batches)
+    lo = rank * n * nb          # every rank owns nb consecutive batches of n reads of the global read set
+    d_bs, d_os, d_outs, qbs, qos = [], [], [], [], []
+    for b in range(nb):
+        qb, qo = synth.generate_reads_fast(rb, ro, lo + b * n, lo + (b + 1) * n, read_len=L, threads=min(32, os.cpu_count() or 1))
+        qbs.append(qb); qos.append(qo)
+        d_bs.append(torch.from_numpy(qb).to(dev))
+        d_os.append(torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev))
+        d_outs.append(torch.zeros((n, 4), dtype=torch.int32, device=dev))
+    qb, qo = qbs[0], qos[0]
     tstream = torch.cuda.Stream(device=dev)          # the kernels AND the timing events go on this stream
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
+    step_no = [0]
 
     def step():
-        ctx.classify_device(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=L, stream=stream)
+        b = step_no[0] % nb
+        step_no[0] += 1
+        ctx.classify_device(d_bs[b].data_ptr(), d_os[b].data_ptr(), n, d_outs[b].data_ptr(), max_read_len=L, stream=stream)
 
     def barrier():
         if world > 1:
@@ -128,8 +199,9 @@ def main():
     elapsed = float(el.item())
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))   # HIP events on the launch stream
 
-    out = d_out.cpu().numpy()
-    if (out[:, 0] < 0).any():
+    outs = [d.cpu().numpy() for d in d_outs]
+    out = outs[0]
+    if any((o[:, 0] < 0).any() for o in outs):
         raise SystemExit("fused path flagged reads for rerouting: the benchmark batch must be fused-eligible")
 
     if rank == 0:
@@ -169,7 +241,8 @@ def main():
                        "spinup_seconds": a.spinup_seconds},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_classify_tile", "kernel_ms": kern_ms, "bytes_per_read": B_READ, "valu": valu,
+                         "kernel": "k_classify_kmer" if ctx.kmer_form()[0] else "k_classify_tile", "kernel_ms": kern_ms,
+                         "bytes_per_read": B_READ, "valu": valu,
                          # which form of the fused kernel ran: "k-mer-space" = reads are filtered and matched by packed k-mer after the
                          # whole 4^k k-mer universe was hashed once when the references were set; "hash-space" = every
                          # window is hashed in the kernel
@@ -193,17 +266,26 @@ def main():
             m1 = max(min(m, int(m / thr * 4)), 1)
             oracle.classify_stream(qb, qo[: m1 + 1], ks, S, sk, ln, threads=1)
             dt1 = time.perf_counter() - t
-            res["cpu_baseline"] = {"value": m / dt, "unit": "reads/s", "cores": thr, "kind": "port",
+            res["cpu_baseline"] = {"value": m / dt, "unit": "reads/s", "cores": thr, "kind": "port", "cpu_model": cpu_model(),
                                    "sample": "first %d reads of the same batch, OpenMP x%d, refs pre-sketched; %.1f s" % (m, thr, dt),
                                    "single_thread_value": m1 / dt1,
                                    "oracle_check": "GPU rows bit-exact vs the CPU oracle on the %d sampled reads (oracle-consistent; the mkmh policies "
                                                    "are unpinned by any reference artefact, DESIGN.md section 0)" % m}
-        if a.host_path:
+        if world == 1 and not a.no_host_path:
+            # PCIe-inclusive: the same batches from PAGEABLE host memory through rk_classify_batch (pinned staging, H2D, kernel,
+            # D2H overlapped chunk by chunk).  Never the reported value.
+            hb = np.concatenate([x[: n * L] for x in qbs] + [np.zeros(16, np.uint8)])
+            ho = np.arange(nb * n + 1, dtype=np.uint64) * np.uint64(L)
+            ctx.classify(hb[: n * L + 16], ho[: n + 1])          # warm-up: staging buffers, first-touch
             t = time.perf_counter()
-            hout = ctx.classify(qb, qo)
+            hout = ctx.classify(hb, ho)
             dt = time.perf_counter() - t
-            assert (hout == out).all()
-            res["host_path"] = {"value": n / dt, "unit": "reads/s", "note": "rk_classify_batch from pageable host memory: pinned staging + H2D + kernel + D2H"}
+            if not all((hout[b * n:(b + 1) * n] == outs[b]).all() for b in range(nb)):
+                raise SystemExit("host path rows differ from the resident path")
+            res["host_path"] = {"value": nb * n / dt, "unit": "reads/s", "gbytes_per_s_h2d": nb * n * (L + 4) / dt / 1e9, "reads": nb * n,
+                                "note": "rk_classify_batch from pageable host memory: staging + H2D + kernel + D2H, PCIe inclusive"}
+        if world == 1 and a.e2e_reads > 0:
+            res["e2e"] = e2e_stream(a.e2e_reads, L, rb, ro, synth)
         print(json.dumps(res))
         sys.stdout.flush()
     ctx.close()

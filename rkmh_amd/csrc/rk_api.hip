@@ -105,8 +105,8 @@ struct rk_ctx {
     KsArr ks{};
     std::vector<uint64_t> h_sk;
     std::vector<int32_t> h_lens;
-    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_kpre, d_kmap, d_kf4, d_km1, d_km1v, d_keepbits;
-    uint32_t kpre_inserted = 0; // k-mers the enumeration put into the k-mer-space filter (diagnostic)
+    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_kf4, d_km1, d_km1v, d_keepbits;
+    uint32_t kpre_inserted = 0; // k-mers the enumeration found for the k-mer-space structures (diagnostic)
     bool kmer_form_allowed = true; // rk_set_kmer_form
     RefIndex ix{};
     bool have_refs = false;
@@ -161,7 +161,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
-    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_kpre, &c->d_kmap, &c->d_kf4, &c->d_km1, &c->d_km1v, &c->d_keepbits, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_kf4, &c->d_km1, &c->d_km1v, &c->d_keepbits, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount, &c->w_tail}) b->release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
@@ -914,50 +914,37 @@ static int build_index(rk_ctx* c) {
         HIPCHK(hipMemcpy(c->d_pre.p, pre.data(), (size_t)pwords * 4, hipMemcpyHostToDevice));
         c->ix.pre = c->d_pre.as<uint32_t>(); c->ix.pmask = pwords - 1;
     }
-    // k-mer-space filter (single k of 8..16, the sizes the fused kernel has a packed-k-mer form for): every k-mer of the 4^k
-    // universe whose canonical hash is a key (or 0), found by exhaustive enumeration on the device -- see k_enum_kmers.
-    // Sized like the hash-space filter (32 bits per key, 2 set).  RKMH_KMER_PREFILTER=0 turns it off (A/B runs, tests).
-    c->ix.kpre = nullptr; c->ix.kpshift = 0; c->ix.kpk = 0; c->ix.kmap = nullptr; c->ix.kmap_m = 0; c->kpre_inserted = 0;
+    // k-mer-space structures (a single k of 8..16): every k-mer of the 4^k universe whose canonical hash is a key (or 0), found by
+    // exhaustive enumeration on the device -- see k_enum_kmers -- goes into the group filter and the exact map of k_classify_kmer
+    // (rk_kmer.hip).  RKMH_KMER_PREFILTER=0 turns them off (A/B runs, tests).
+    c->ix.kpk = 0; c->kpre_inserted = 0;
     c->ix.kf4 = nullptr; c->ix.kf4_lg = 0; c->ix.km1 = nullptr; c->ix.km1_b = 0; c->ix.km1_vals = nullptr;
-    int kpre_mode = pre_mode > 0 ? 1 : 0;
-    if (const char* e = getenv("RKMH_KMER_PREFILTER")) kpre_mode = atoi(e);
-    // Only for panels whose filter + map stay L2-resident (an XCD's L2 is 4 MB): beyond that the hash-space kernels, whose
-    // per-window probe goes to a 1-2 MB bit array whatever the panel, are faster (measured: 1000 references 1.55 vs 1.06 ms).
-    size_t kpre_max_keys = 6000000;
-    if (const char* e = getenv("RKMH_KPRE_MAXKEYS")) { long v = atol(e); if (v >= 0) kpre_max_keys = (size_t)v; }
-    if (kpre_mode > 0 && c->kmer_form_allowed && c->ks.n == 1 && c->ks.k[0] >= KPRE_MIN_K && c->ks.k[0] <= 16 && distinct <= kpre_max_keys) {
-        size_t bits_per_key = 32, max_words = (size_t)16384 * 256;
-        if (const char* e = getenv("RKMH_KPRE_BITS")) { long v = atol(e); if (v >= 2 && v <= 256) bits_per_key = (size_t)v; }
-        if (const char* e = getenv("RKMH_KPRE_MAXKB")) { long v = atol(e); if (v >= 16 && v <= (1 << 20)) max_words = (size_t)v * 256; }
-        uint32_t kwords = 1u << 12, klg = 12;
-        while ((size_t)kwords * 32 < distinct * bits_per_key && (size_t)kwords * 2 <= max_words) { kwords <<= 1; ++klg; }
-        RKCHK(c->d_kpre.reserve((size_t)kwords * 4 + 16));
-        HIPCHK(hipMemsetAsync(c->d_kpre.p, 0, (size_t)kwords * 4 + 16, c->st));
-        uint32_t* stats = c->d_kpre.as<uint32_t>() + kwords;
+    static const int kmer_env = getenv("RKMH_KMER_PREFILTER") ? atoi(getenv("RKMH_KMER_PREFILTER")) : -1;
+    const int kmer_mode = kmer_env >= 0 ? kmer_env : (pre_mode > 0 ? 1 : 0);
+    static const long kmer_max_keys_env = getenv("RKMH_KPRE_MAXKEYS") ? atol(getenv("RKMH_KPRE_MAXKEYS")) : -1;
+    const size_t kmer_max_keys = kmer_max_keys_env >= 0 ? (size_t)kmer_max_keys_env : 6000000;
+    if (kmer_mode > 0 && c->kmer_form_allowed && c->ks.n == 1 && c->ks.k[0] >= KPRE_MIN_K && c->ks.k[0] <= 16 && distinct <= kmer_max_keys) {
+        const int k = c->ks.k[0];
         // the k-mers found come back as a list (one per strand pair): normally exactly one per key, plus any k-mer that collides
         // with a key or hashes to 0 -- a handful at most, so twice the keys is ample room; more than that disables this form
         const uint32_t list_cap = (uint32_t)std::min<size_t>(2 * distinct + 4096, 0x3fffffffu);
-        DevBuf d_list;
-        struct Release { DevBuf& b; ~Release() { b.release(); } } release_list{d_list}; // freed on every path out of this block
+        DevBuf d_list, d_stats;
+        struct Release { DevBuf& a; DevBuf& b; ~Release() { a.release(); b.release(); } } release_list{d_list, d_stats}; // freed on every path out
         RKCHK(d_list.reserve((size_t)list_cap * 8));
-        RefIndex probe = c->ix;
-        probe.kpre = nullptr; probe.kmap = nullptr;
-        hipError_t le = launch_enum_kmers(probe, c->pol, c->ks.k[0], c->d_kpre.as<uint32_t>(), klg - 5, stats, d_list.as<uint2>(), list_cap, c->st);
+        RKCHK(d_stats.reserve(16));
+        HIPCHK(hipMemsetAsync(d_stats.p, 0, 16, c->st));
+        hipError_t le = launch_enum_kmers(c->ix, c->pol, k, d_stats.as<uint32_t>(), d_list.as<uint2>(), list_cap, c->st);
         uint32_t found = 0;
-        if (le == hipSuccess) le = hipMemcpyAsync(&found, stats, 4, hipMemcpyDeviceToHost, c->st);
+        if (le == hipSuccess) le = hipMemcpyAsync(&found, d_stats.p, 4, hipMemcpyDeviceToHost, c->st);
         if (le == hipSuccess) le = hipStreamSynchronize(c->st);
         std::vector<uint32_t> list((size_t)std::min<uint32_t>(found, list_cap) * 2);
         if (le == hipSuccess && !list.empty()) le = hipMemcpy(list.data(), d_list.p, list.size() * 4, hipMemcpyDeviceToHost);
-        d_list.release();
         if (le != hipSuccess) return fail(RK_ERR_HIP, "k-mer enumeration: %s", hipGetErrorString(le));
         c->kpre_inserted = found;
+        // Built only when every key has exactly one preimage (found == keys + zero-hash k-mers with no two entries sharing a key id):
+        // the k-mer then identifies the key in the per-read hit multiset.  Anything else leaves the hash-space kernels in charge.
         bool ok = found <= list_cap;
-        // exact map k-mer -> index value: bucketed cuckoo (2 cells per 16-byte bucket, 2 candidate buckets, load ~0.8).  Built only
-        // when every key has exactly one preimage (found == keys + zero-hash k-mers with no two entries sharing a key id): the
-        // cell number then identifies the key for the per-read multiset.  Anything else leaves the hash-space kernels in charge.
-        std::vector<uint32_t> cells;
-        uint32_t m = 0;
-        if (getenv("RKMH_KMAP_FORCE_DUP")) ok = false; // tests: behave as if two k-mers shared a key (the map is not built)
+        if (getenv("RKMH_KMAP_FORCE_DUP")) ok = false; // tests: behave as if two k-mers shared a key (nothing is built)
         if (ok) {
             std::vector<uint8_t> seen(nkeys + 1, 0);
             for (uint32_t i = 0; ok && i < found; ++i) {
@@ -968,35 +955,9 @@ static int build_index(rk_ctx* c) {
             }
         }
         if (ok) {
-            m = (uint32_t)((double)found / 1.6) + 64;
-            cells.assign((size_t)m * 4, KMAP_EMPTY);
-            uint32_t rnd = 0x12345u;
-            for (uint32_t i = 0; ok && i < found; ++i) {
-                uint32_t key = list[2 * (size_t)i], slot = list[2 * (size_t)i + 1];
-                uint32_t val = slot == IDX_NOT_FOUND ? KMAP_ZERO : dense[(size_t)slot * 4 + 2];
-                uint32_t bkt = kmap_cell1(key, m);
-                bool placed = false;
-                for (int kick = 0; kick < 2000 && !placed; ++kick) {
-                    const uint32_t b1 = kmap_cell1(key, m), b2 = kmap_cell2(key, m);
-                    for (uint32_t cand : {b1, b2}) {
-                        uint32_t* e = &cells[(size_t)cand * 4];
-                        if (e[0] == KMAP_EMPTY) { e[0] = key; e[1] = val; placed = true; break; }
-                        if (e[2] == KMAP_EMPTY) { e[2] = key; e[3] = val; placed = true; break; }
-                    }
-                    if (placed) break;
-                    rnd = rnd * 1664525u + 1013904223u;   // evict a random cell of the bucket other than the one we just came from
-                    bkt = (bkt == b1) ? b2 : b1;
-                    uint32_t* e = &cells[(size_t)bkt * 4 + ((rnd >> 16) & 1u) * 2];
-                    std::swap(e[0], key); std::swap(e[1], val);
-                }
-                if (!placed) ok = false;
-            }
-        }
-        if (ok) {
             // group filter of k_classify_kmer (kf4_sector in rk_device.hpp): every found k-mer in both orientations under its four
             // alignments, two bits each in dword j of the 16-byte sector its alignment-j core selects; sized for ~10 entries per
             // sector (about 5 of a dword's 32 bits set: one window in ~45 of those that hit nothing passes by chance)
-            const int k = c->ks.k[0];
             uint32_t lg = 8;
             static const long kf4_entries = getenv("RKMH_KF4_ENTRIES") ? atol(getenv("RKMH_KF4_ENTRIES")) : 10;
             while (((size_t)1 << lg) * (size_t)(kf4_entries > 0 ? kf4_entries : 10) < (size_t)found * 8 && lg < 24) ++lg;
@@ -1010,53 +971,53 @@ static int build_index(rk_ctx* c) {
                         f4[(size_t)kf4_sector((X >> (2 * (3 - j))) & cm, lg) * 4 + j] |= bits;
                 }
             }
-            // single-probe exact map (KM1_C in rk_device.hpp).  A displaced key may only move to the next bucket; if that one is full
-            // too the table doubles.  More compound values than the 15-bit id space names leave the hash-space kernels in charge.
+            // exact map (KM1_C in rk_device.hpp).  A displaced key may only move to the next bucket; if that one is full too, or the
+            // value ids do not fit the cell, the table doubles (shorter remainders leave more bits for the id).
             {
                 static const double km1_load = getenv("RKMH_KM1_LOAD") ? atof(getenv("RKMH_KM1_LOAD")) : 0.35;
                 std::vector<uint32_t> vals;
                 std::unordered_map<uint32_t, uint32_t> val_id;
                 std::vector<uint32_t> vid(found);
-                bool fits = true;
-                for (uint32_t i = 0; i < found && fits; ++i) {
+                const uint32_t VID_ZERO = 0xFFFFFFFEu; // placeholder, mapped to the layout's id below
+                for (uint32_t i = 0; i < found; ++i) {
                     const uint32_t slot = list[2 * (size_t)i + 1];
-                    if (slot == IDX_NOT_FOUND) { vid[i] = KM1_VID_ZERO; continue; }
+                    if (slot == IDX_NOT_FOUND) { vid[i] = VID_ZERO; continue; }
                     const uint32_t val = dense[(size_t)slot * 4 + 2];
-                    if (!(val >> 31) && ((val >> 29) & 3u) == 0u && ((val >> 20) & 0x1FFu) == 1u && (val & 0xFFFFFu) < KM1_VID_TABLE) { vid[i] = val & 0xFFFFFu; continue; }
+                    if (!(val >> 31) && ((val >> 29) & 3u) == 0u && ((val >> 20) & 0x1FFu) == 1u) { vid[i] = val & 0xFFFFFu; continue; } // one posting, once: the reference
                     auto it = val_id.find(val);
-                    if (it == val_id.end()) {
-                        if (KM1_VID_TABLE + vals.size() >= KM1_VID_ZERO) { fits = false; break; }
-                        it = val_id.emplace(val, (uint32_t)(KM1_VID_TABLE + vals.size())).first;
-                        vals.push_back(val);
-                    }
+                    if (it == val_id.end()) { it = val_id.emplace(val, (uint32_t)(R + vals.size())).first; vals.push_back(val); }
                     vid[i] = it->second;
                 }
-                uint32_t b = 17;
-                while (b < 28 && (double)found > km1_load * 4.0 * (double)((size_t)1 << b)) ++b;
+                const uint32_t kbits = 2u * (uint32_t)k;
+                uint32_t b = kbits < 17u ? kbits : 17u;
+                while (b < kbits && b < 28 && (double)found > km1_load * 4.0 * (double)((size_t)1 << b)) ++b;
                 std::vector<uint32_t> c1;
-                for (; fits && b <= 28; ++b) {
-                    const uint32_t nbk = 1u << b, rmask = (1u << (32 - b)) - 1u;
-                    c1.assign((size_t)nbk * 4, KM1_CELL_EMPTY);
+                bool built = false;
+                for (; b <= kbits && b <= 28 && !built; ++b) {
+                    const uint32_t r = kbits - b, vb = km1_vbits(k, b), vmask = (1u << vb) - 1u;
+                    if ((uint64_t)R + vals.size() + 2 > (uint64_t)vmask) continue; // ids need more bits: a longer bucket index frees them
+                    const uint32_t nbk = 1u << b, rmask = r ? (1u << r) - 1u : 0u;
+                    c1.assign((size_t)nbk * 4, ~(1u << vb)); // empty: tag and id all ones, flag clear
                     bool placed_all = true;
                     for (uint32_t i = 0; i < found && placed_all; ++i) {
-                        const uint32_t y = list[2 * (size_t)i] * KM1_C;
-                        uint32_t bk = y >> (32 - b);
-                        const uint32_t rem = y & rmask;
+                        const uint32_t y = km1_y(list[2 * (size_t)i], k);
+                        uint32_t bk = r ? y >> r : y;
+                        const uint32_t rem = y & rmask, id = vid[i] == VID_ZERO ? vmask - 1u : vid[i];
                         bool placed = false;
                         for (int hop = 0; hop < 2 && !placed; ++hop) {
                             uint32_t* e = &c1[(size_t)bk * 4];
                             for (int q = 0; q < 4 && !placed; ++q)
-                                if ((e[q] & 0x7FFFu) == KM1_VID_EMPTY && (e[q] >> 16) == 0xFFFFu) {
-                                    e[q] = (e[q] & 0x8000u) | ((rem | (hop ? 0x8000u : 0u)) << 16) | vid[i];
+                                if ((e[q] & vmask) == vmask) { // empty (no key carries the all-ones id)
+                                    e[q] = ((rem | (hop ? 1u << r : 0u)) << (vb + 1)) | id;
                                     placed = true;
                                 }
-                            if (!placed) { e[3] |= 0x8000u; bk = (bk + 1) & (nbk - 1); } // full: later lookups that miss here try the next bucket
+                            if (!placed) { e[3] |= 1u << vb; bk = (bk + 1) & (nbk - 1); } // full: later lookups that miss here try the next bucket
                         }
                         placed_all = placed;
                     }
-                    if (placed_all) break;
+                    if (placed_all) { built = true; break; }
                 }
-                if (fits && b <= 28) { // else: the MODE_ 5 form of k_classify_tile serves the panel
+                if (built) { // else: the hash-space kernels serve the panel
                     RKCHK(c->d_km1.reserve(c1.size() * 4));
                     HIPCHK(hipMemcpy(c->d_km1.p, c1.data(), c1.size() * 4, hipMemcpyHostToDevice));
                     RKCHK(c->d_km1v.reserve(vals.size() * 4 + 16));
@@ -1067,10 +1028,8 @@ static int build_index(rk_ctx* c) {
             RKCHK(c->d_kf4.reserve(f4.size() * 4));
             HIPCHK(hipMemcpy(c->d_kf4.p, f4.data(), f4.size() * 4, hipMemcpyHostToDevice));
             c->ix.kf4 = c->d_kf4.as<uint4>(); c->ix.kf4_lg = lg;
-            RKCHK(c->d_kmap.reserve(cells.size() * 4 + 16));
-            HIPCHK(hipMemcpy(c->d_kmap.p, cells.data(), cells.size() * 4, hipMemcpyHostToDevice));
-            c->ix.kmap = c->d_kmap.as<uint4>(); c->ix.kmap_m = m;
-            c->ix.kpre = c->d_kpre.as<uint32_t>(); c->ix.kpshift = klg - 5; c->ix.kpk = (uint32_t)c->ks.k[0]; // 32 words per line
+            if (c->ix.km1) c->ix.kpk = (uint32_t)k;
+            else { c->ix.kf4 = nullptr; c->ix.kf4_lg = 0; }
         }
     }
     // a full bottom-S sketch of uniform hashes keeps the fraction (largest kept hash / 2^64) of the k-mers
@@ -1150,7 +1109,7 @@ extern "C" int rk_kmer_form(const rk_ctx* c, uint32_t* kmers_found) {
     if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
     if (!c->have_refs) return fail(RK_ERR_STATE, "no references set");
     if (kmers_found) *kmers_found = c->kpre_inserted;
-    return (c->ix.kpre && c->ix.kmap) ? 1 : 0;
+    return (c->ix.kf4 && c->ix.km1) ? 1 : 0;
 }
 
 extern "C" int rk_set_depth_filter(rk_ctx* c, rk_counter* counter, int min_kmer_occ) {
@@ -1160,6 +1119,9 @@ extern "C" int rk_set_depth_filter(rk_ctx* c, rk_counter* counter, int min_kmer_
         // the fused kernel's masked forms read one KEEP bit per slot instead of the 4-byte count (k_keep_bits): a snapshot of
         // the table as it is NOW -- the -M flow sets the filter after pass 1 (and after the all-reduce in multi-GPU runs)
         RKCHK(set_dev(c));
+        // pass 1 (rk_count_batch_device) is asynchronous on the CALLER's stream, an all-reduce may run on yet another one: the
+        // snapshot must see the finished table, so the whole device is drained first (once per -M run: not a hot path)
+        HIPCHK(hipDeviceSynchronize());
         RKCHK(c->d_keepbits.reserve(((counter->slots + 31) / 32) * 4 + 16));
         HIPCHK(launch_keep_bits(counter->d, counter->slots, min_kmer_occ, c->pol, c->d_keepbits.as<uint32_t>(), c->st));
         HIPCHK(hipStreamSynchronize(c->st));
@@ -1179,8 +1141,7 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     int expect = 0; // hits an error-free read is expected to score: sizes the kernel's per-read hit multiset
     for (int j = 0; j < c->ks.n; ++j) expect += (int)(c->density * (double)num_windows((int)ml, c->ks.k[j], c->pol.drop_last_window)) + 1;
     // plain classification with the single k the exact k-mer map was enumerated for: the k-mer-space kernel (rk_kmer.hip)
-    static const bool kmer_v2 = !(getenv("RKMH_KMER_V2") && atoi(getenv("RKMH_KMER_V2")) == 0); // 0: the MODE_ 5 form of k_classify_tile (A/B)
-    if (mode == 0 && !counter && kmer_v2 && c->ix.kf4 && c->ix.km1 && c->ks.n == 1 && (uint32_t)c->ks.k[0] == c->ix.kpk &&
+    if (mode == 0 && !counter && c->ix.kf4 && c->ix.km1 && c->ks.n == 1 && (uint32_t)c->ks.k[0] == c->ix.kpk &&
         classify_kmer_supported(c->ix.nref, (int)ml, c->ks.k[0]))
         HIPCHK(launch_classify_kmer((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks.k[0], c->S, c->ix,
                                     (int32_t*)d_out4, c->pol, (int)ml, expect, st));

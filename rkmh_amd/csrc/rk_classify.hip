@@ -35,15 +35,9 @@
 //            the counters), one int4 per read, counters re-zeroed.
 // Integer work only (no MFMA).
 //
-// Two forms of phase 1 / drain live in this file (template parameter MODE_):
-//   hash-space (MODE_ 0-4, described above): every window is hashed in the kernel.  Bound twice over on MI355X: 92 % of the
-//            VALU issue slots AND the L2 request rate (one scattered 4-byte filter probe per window).
-//   k-mer-space (MODE_ 5, single k from 8 to 16, no -M): NO window of a plain tile is hashed.  When the references are set,
-//            k_enum_kmers (rk_kernels.hip) hashes the whole 4^k k-mer universe once and records every k-mer whose canonical hash
-//            is a sketch hash or 0; the kernel then extracts packed 2-bit k-mers, probes a filter whose cache line is chosen by what
-//            four neighbouring windows share, and resolves the few candidates by k-mer in an exact map -- bit-identical to the
-//            hash-defined result by construction (see the comment at MODE_ 5 below and DESIGN.md section 3.1b).  This is the
-//            form the headline configuration runs.
+// Every window is hashed in this kernel (the hash-space form).  It serves -M (both passes), several k, and k outside 8..16; plain
+// classification with a single k from 8 to 16 runs the k-mer-space kernel of rk_kmer.hip, which hashes nothing.  Bound twice over on
+// MI355X: 92 % of the VALU issue slots AND the L2 request rate (one scattered 4-byte filter probe per window).
 #include "rk_kernels.hpp"
 
 #include <cstdlib>
@@ -52,10 +46,8 @@ namespace rk {
 
 // Ablation switches used to attribute kernel time to its parts: build with
 // -DRK_ABLATE=1 and set RKMH_DBG (1 no queueing, 2 no phase 2, 4 cheap hash, 8 no bucket loads, 32 no drain,
-// 64 no hit multiset, 128 no counter updates, 256 no index verification in the drain; MODE_ 5 timing experiments with WRONG
-// results: 2048 all filter probes of a wave in one cache line, 8192 / 16384 groups of 4 / 8 lanes share a line, 4096 nothing reaches
-// the drain).  Always available:
-// RKMH_DBG=1024 turns the split-strand last step off (A/B), RKMH_TILE_* override the tile geometry.
+// 64 no hit multiset, 128 no counter updates, 256 no index verification in the drain).  Always available:
+// RKMH_DBG=1024 turns the split-strand last step off (A/B), RKMH_TILE_* override the tile geometry (read once per process).
 #ifndef RK_ABLATE
 #define RK_ABLATE 0
 #endif
@@ -67,11 +59,7 @@ constexpr int WAVE = 64;
 #ifndef RK_WAVES_PER_SIMD
 #define RK_WAVES_PER_SIMD 6
 #endif
-// MODE_ 5 kernels compute no hash in their common path and wait on memory instead: they are latency-bound and want more waves
-#ifndef RK_KPRE_WAVES_PER_SIMD
-#define RK_KPRE_WAVES_PER_SIMD 6
-#endif
-constexpr int PF_MAX = 6; // prefetched base dwords per lane: tile bytes <= PF*64*4 - 8 (template parameter PF = 2 or 6)
+constexpr int PF_MAX = 6; // prefetched base dwords per lane: tile bytes <= PF*64*4 - 8 (template parameter PF = 2, 3 or 6)
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
@@ -115,24 +103,14 @@ struct TileGeom {
     int32_t tpb;        // consecutive tiles per workgroup
     int32_t xcd;        // 1: workgroups that share an XCD (blockIdx % 8, round-robin dispatch) take neighbouring tiles
     uint64_t slots_m;   // floor((2^64 - 1) / slots) of the -M counter table: hash % slots by Barrett reduction (mod_slots)
-    int32_t kpre;       // 1: MODE_ 5 kernels (k-mer-space filter): packed 2-bit images, 4-byte queue entries (position | read << 16)
     int32_t magic_nw;   // windows (first k) of a read of the hinted length, and ...
     uint32_t magic;     // ... ceil(2^32 / magic_nw): the compact window -> read division of tiles made of such reads
 };
 
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
-// packed 2-bit image of one strand of a tile: 16 bases per dword, + the dword a window's 64-bit read may touch past the end
-// ... and, for the forward string, 16 positions of padding in front (position of tile base b = 16 + fbase + b): the words of the
-// reverse-complement image are cut from it at positions that may precede the tile by up to 15
-__host__ __device__ inline int tile_pk_dwords(int cap_bytes) { return cap_bytes / 16 + 4; }
-// MODE_ 5 kernels stage no byte images at all (plain tiles hash nothing, the other tiles hash from the packed image): of the staged
-// region only the validity bitmap remains (bit = fwd byte position, as in stage_lds_dwords)
-__host__ __device__ inline int tile_stage_dwords(const TileGeom& g) {
-    return g.kpre ? (FWD_PAD + 3 + g.cap_bytes + 31) / 32 + 2 : stage_lds_dwords(g.cap_bytes);
-}
+__host__ __device__ inline int tile_stage_dwords(const TileGeom& g) { return stage_lds_dwords(g.cap_bytes); }
 __host__ __device__ inline size_t tile_lds_bytes(const TileGeom& g) {
-    // queue region: 16-byte entries {hash, read}, or (kpre) two packed images + 8-byte entries {k-mer, read} + the 128-dword multi-posting list
-    const size_t q_dw = g.kpre ? 2 * (size_t)tile_pk_dwords(g.cap_bytes) + 2 * (size_t)g.qcap + 128 : 4 * (size_t)g.qcap;
+    const size_t q_dw = 4 * (size_t)g.qcap; // queue region: 16-byte entries {hash, read}
     return ((size_t)((tile_stage_dwords(g) + 3) & ~3) + q_dw + 5 * (size_t)(g.T + 1) + 8 +
             2 * (size_t)tile_map_words(g.cap_bytes) +
             (size_t)g.T * (size_t)(g.cwords + g.dset)) * 4;
@@ -186,14 +164,6 @@ __device__ __forceinline__ void bucket_wait(u32x4& f) { asm volatile("s_waitcnt 
 __device__ __forceinline__ void word_load_async(const uint32_t* base, uint32_t byte_off, uint32_t& f) {
     asm volatile("global_load_dword %0, %1, %2" : "=v"(f) : "v"(byte_off), "s"(base) : "memory");
 }
-// The same load with five wait states in front.  The "s" base of the saddr form may be re-materialised by hipcc with
-// v_readlane_b32 (SGPR values parked in VGPR lanes under register pressure) right before the statement; a VALU write of an SGPR
-// needs 5 wait states before a VMEM instruction reads it, and the hazard recogniser does not look inside inline asm -- seen as
-// a GPU memory fault (stale base) in the chunked loop of MODE_ 5.  tools/lint_async_loads.py checks every asm-issued saddr load
-// of the shipped ISA for this.
-__device__ __forceinline__ void word_load_async_ws(const uint32_t* base, uint32_t byte_off, uint32_t& f) {
-    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(f) : "v"(byte_off), "s"(base) : "memory");
-}
 __device__ __forceinline__ void word_wait(uint32_t& f) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : : "memory"); }
 
 // h % slots for the -M table (HASHTCounter slot, rkmh.cpp:739) without a 64-bit division: m = floor((2^64 - 1) / slots) comes
@@ -206,54 +176,22 @@ __device__ __forceinline__ uint64_t mod_slots(uint64_t h, uint64_t slots, uint64
     return r;
 }
 
-// the k <= 16 bases starting at base p of a packed 2-bit image (16 bases per dword): one 8-byte LDS read + one funnel shift
-struct __attribute__((packed, aligned(4))) rk_pair4 { uint32_t x, y; };
-template <int KT>
-__device__ __forceinline__ uint32_t packed_window(const uint32_t* pk, uint32_t p) {
-    const rk_pair4 w = *reinterpret_cast<const rk_pair4*>(reinterpret_cast<const uint8_t*>(pk) + ((p >> 2) & ~3u));
-    uint32_t v = __builtin_amdgcn_alignbit(w.y, w.x, (p << 1) & 31u);
-    if (KT < 16) v &= (1u << (2 * KT)) - 1u;
-    return v;
-}
-// four upper-case bases (one dword) -> their four 2-bit codes in one byte
-__device__ __forceinline__ uint32_t pack4(uint32_t x) {
-    const uint32_t c = (x >> 1) & 0x03030303u;
-    const uint32_t t = c | (c >> 6);
-    return (t | (t >> 12)) & 0xffu;
-}
-
 // MODE 0: classify; MODE 1: count pass of -M (rkmh.cpp:904-910); MODE 2: classify with the -M mask (rkmh.cpp:916)
 // MODE_ 3 / 4: MODE 0 / 2 with the first-level filter of large panels (RefIndex::pre) in front of the bucket table
-// MODE_ 5: MODE 0 for a single k from 8 to 16 with the k-mer-space filter (RefIndex::kpre).  The loop over the windows of a plain
-//          tile no longer hashes: it extracts the packed 2-bit k-mer of both strands (one 8-byte LDS read + one funnel shift each),
-//          takes the smaller, and tests two bits of a filter that holds EVERY k-mer of the 4^k universe whose canonical hash is a
-//          key of the index or is 0 (filled by exhaustive enumeration when the references are set: k_enum_kmers).  A window that
-//          fails provably has a non-zero hash that is in no sketch -- it can change neither a count nor the number of non-zero
-//          hashes -- and is not hashed at all.  Windows that pass (every hit + a fraction of a percent) are queued by position and
-//          hashed in the drain, 64 at a time with every lane busy, then looked up exactly as before.  Tiles that are not plain
-//          (ragged, or holding a non-ACGT base) run the MODE_ 3 loop; their candidates are queued by position too.
 template <int KT, int MODE_, int FOLD, int PF>
-__global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAVES_PER_SIMD)) void k_classify_tile(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
+__global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
                                                            uint32_t nreads, KsArr ks, int S, RefIndex ix, int32_t* counter,
                                                            uint64_t slots, int min_occ, int32_t* out4, DevPolicy pol, TileGeom geo) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr bool PRE = MODE_ >= 3;
-    constexpr bool KPRE = MODE_ == 5;
-    static_assert(!KPRE || (KT >= 1 && KT <= 16), "the k-mer-space filter packs a k-mer into 32 bits");
-    constexpr int MODE = (MODE_ == 3 || MODE_ == 5) ? 0 : (MODE_ == 4 ? 2 : MODE_);
+    constexpr int MODE = MODE_ == 3 ? 0 : (MODE_ == 4 ? 2 : MODE_);
     const int T = geo.T;
     const uint32_t QCAP = (uint32_t)geo.qcap;
     const uint32_t DS = (uint32_t)geo.dset;
     uint32_t* stage = smem;
     // candidate queue: one 16-byte entry per window {hash lo, hash hi, read within the tile, -} (one ds_write_b128)
     uint4* qe = reinterpret_cast<uint4*>(stage + ((tile_stage_dwords(geo) + 3) & ~3));
-    // MODE_ 5 lays the same region out as: packed image of the forward string, of the reverse-complement string, the queue
-    // of 8-byte entries {canonical packed k-mer, read}, the multi-posting list
-    const int pkdw = tile_pk_dwords(geo.cap_bytes);
-    uint32_t* pk_f = reinterpret_cast<uint32_t*>(qe);
-    uint32_t* pk_r = pk_f + pkdw;
-    uint2* q64 = reinterpret_cast<uint2*>(pk_r + pkdw + ((2 * pkdw) & 1));   // 8-byte aligned: {canonical packed k-mer, read}
-    uint32_t* rstart = KPRE ? reinterpret_cast<uint32_t*>(q64 + QCAP) + 128 : reinterpret_cast<uint32_t*>(qe + QCAP);   // [T+1] byte offset of read t inside the tile
+    uint32_t* rstart = reinterpret_cast<uint32_t*>(qe + QCAP);   // [T+1] byte offset of read t inside the tile
     uint32_t* nwin = rstart + (T + 1);                           // [T+1] windows of read t (all k)
     uint32_t* nzero = nwin + (T + 1);                            // [T+1] zero hashes per read
     uint32_t* best = nzero + (T + 1);                            // [T+1] max over increments of (count << 16 | 0xFFFF - ref)
@@ -265,10 +203,9 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
     uint32_t* dset = c16 + T * geo.cwords;                       // [T][DS] multiset of the slots the read has hit
     // [64][2] hits with several postings (drain).  Aliases the first 32 queue entries: a drain step has its 64
     // entries in registers before it writes here, and entries left for later sit at index >= 64.
-    uint32_t* mq = KPRE ? reinterpret_cast<uint32_t*>(q64 + QCAP) : reinterpret_cast<uint32_t*>(qe);
+    uint32_t* mq = reinterpret_cast<uint32_t*>(qe);
     const int lane = threadIdx.x;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const uint32_t kp_sr = 2u * ((uint32_t)lane & 3u), kp_sf = 6u - kp_sr; // MODE_ 5: this lane's alignment in the filter (see kpre_word_off_s)
     const uint32_t clg = (uint32_t)geo.clg, cper_m1 = (1u << clg) - 1u, cbits = 32u >> clg, cmask = (1u << cbits) - 1u;
 
     if (MODE != 1) { // counters are re-zeroed by phase 2 after use
@@ -312,7 +249,6 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
     auto wait_bases = [&]() {
         if constexpr (PF == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]) : : "memory");
         else if constexpr (PF == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]) : : "memory");
-        else if constexpr (PF == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]) : : "memory");
     };
     // XCD-aware tile ownership: the dispatcher deals workgroups round-robin over the 8 XCDs, each with its own L2.
@@ -347,7 +283,6 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
             const int fwd_dw = (FWD_PAD + 3 + geo.cap_bytes + TAIL_PAD + 3) / 4;
             const int rc_dw = (geo.cap_bytes + TAIL_PAD + 3) / 4;
             s.fwd = stage; s.rc = stage + fwd_dw; s.inv = s.rc + rc_dw;
-            if constexpr (KPRE) { s.fwd = nullptr; s.rc = nullptr; s.inv = stage; } // no byte images in these kernels
             s.fbase = FWD_PAD + (tstart & 3u); s.nbases = B;
         }
         const uint32_t o_next = (uint32_t)__shfl_down((int)cur_o, 1); // offset of read lane+1
@@ -382,11 +317,7 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                 const uint32_t jf = (uint32_t)q * WAVE + (uint32_t)lane;
                 const bool in = jf >= 1 && jf <= ndw;
                 const uint32_t x = in ? upper4(pf[q]) : 0u;
-                if constexpr (KPRE) { // packed forward image straight from the registers: fwd-image dword jf = packed byte 4 + jf
-                    if (jf <= ndw) reinterpret_cast<uint8_t*>(pk_f)[4u + jf] = (uint8_t)pack4(x);
-                } else {
-                    if (jf <= ndw) s.fwd[jf] = x;
-                }
+                if (jf <= ndw) s.fwd[jf] = x;
                 uint32_t m = in ? ~0u : 0u;
                 if (jf == 1) m &= m_first;
                 if (jf == ndw) m &= m_last;
@@ -396,7 +327,7 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
         cur_a = nxt_a; cur_b = nxt_b; cur_o = nxt_o;
         const bool has_invalid = __ballot(anyinv != 0u) != 0ull;
         // "plain" tiles (all reads equally long, no invalid base, at least two windows per read: the common case) need neither the
-        // start bitmap nor the position -> read map -- and, in MODE_ 5 kernels, no byte images at all: nothing is hashed
+        // start bitmap nor the position -> read map
         uint32_t nw_min;
         if (KT) nw_min = (uint32_t)num_windows((int)ulen, KT, pol.drop_last_window);
         else {
@@ -406,29 +337,13 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
         const bool plain = uniform && !has_invalid && nw_min >= 2u; // >= 2: the compact mapping divides by the window count
         wave_sync();
         // ---- phase 0, interval 2: reverse-complement image; for the rare tile with a non-ACGT base the validity bitmap ----
-        if constexpr (!KPRE) {
+        {
             const uint32_t nrc = (B + 3) >> 2;
             for (uint32_t q = lane; q < nrc; q += WAVE) { // rc dword q = reversed complement of fwd bytes [fbase+B-4-4q, +4)
                 const uint32_t pp_ = s.fbase + B - 4u - 4u * q; // >= fbase - 3: the pad dword in front absorbs it
                 s.rc[q] = revcomp4(lds_load4_unaligned(s.fwd, pp_));
             }
         }
-        if constexpr (KPRE) {
-            if (has_invalid) { // the same bitmap, from the prefetched dwords (still in registers: the next tile is requested after the loop)
-#pragma unroll
-                for (int q = 0; q < PF; ++q) {
-                    if ((uint32_t)q * WAVE <= ndw) { // wave-uniform
-                        const uint32_t jf = (uint32_t)q * WAVE + (uint32_t)lane;
-                        const uint32_t x = (jf >= 1 && jf <= ndw) ? upper4(pf[q]) : 0u;
-                        uint32_t n = invalid4(x) << (4 * (lane & 7));
-                        n |= (uint32_t)__shfl_xor((int)n, 1);
-                        n |= (uint32_t)__shfl_xor((int)n, 2);
-                        n |= (uint32_t)__shfl_xor((int)n, 4);
-                        if ((lane & 7) == 0 && (jf >> 3) <= (ndw >> 3)) s.inv[jf >> 3] = n;
-                    }
-                }
-            }
-        } else
         if (has_invalid) { // 4 validity bits per dword, 8 lanes = one bitmap word (bits indexed by fwd byte position)
             for (uint32_t j0 = 0; j0 <= ndw; j0 += WAVE) {
                 const uint32_t jf = j0 + (uint32_t)lane;
@@ -464,15 +379,8 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
             mark_tails(KT ? KT : ks.k[0]);
             wave_sync();
         }
-        const uint32_t pkoff = 16u + s.fbase; // MODE_ 5: packed position of tile base 0 in pk_f
-        if constexpr (KPRE) { // packed reverse-complement image, 16 bases per word, cut from the packed forward image
-            const uint32_t nrw = (B + 15u) >> 4;
-            for (uint32_t j = lane; j < nrw; j += WAVE) // word j = rc positions [16j, 16j + 16) = forward positions [B - 16j - 16, B - 16j)
-                pk_r[j] = packed_revcomp(packed_window<16>(pk_f, pkoff + B - 16u * (j + 1u)), 16);
-            wave_sync();
-        }
-        // the next tile's bases travel while this tile is hashed (MODE_ 5 kernels request them after their hashing loop instead)
-        if constexpr (!KPRE) { if (ntile < ntiles) load_bases(cur_a, cur_b); }
+        // the next tile's bases travel while this tile is hashed
+        if (ntile < ntiles) load_bases(cur_a, cur_b);
         auto read_of = [&](uint32_t p) -> int {
             int t = (int)tmap[p >> 5];
             while (p >= rstart[t + 1]) ++t;
@@ -504,10 +412,6 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
             }
             atomicMax(&best[t], (cnt << 16) | (0xFFFFu - ref));
         };
-        // one candidate window: verify the full key, find the occurrence rank of this sketch hash within the read
-        // (exact LDS multiset: entry = (slot + 1) | (occurrences - 1) << 27) and add the postings the multiset merge of
-        // rkmh.cpp:869 would count.  A hit with several postings is returned (read << 8 | rank, postings offset) for
-        // the 16-lanes-per-hit pass instead of looping here with 63 lanes idle.
         // one candidate window: verify the full key, find the occurrence rank of this sketch hash within the read
         // (exact LDS multiset: entry = (slot + 1) | (occurrences - 1) << 27) and add the postings the multiset merge of
         // rkmh.cpp:869 would count.  A hit with several postings is returned (read << 8 | rank, postings offset) for
@@ -551,35 +455,14 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
             if (!index_lookup(ix, h, slot, v)) return false; // re-reads the bucket (L1/L2 hit), then key + value together
             return apply_hit(slot, v, t, m_tr, m_off);
         };
-        const bool drain_counts_zero = KPRE && plain;
         auto drain_queue = [&](uint32_t qn) {
             for (uint32_t e0 = 0; e0 < qn; e0 += WAVE) {
                 const uint32_t e = e0 + (uint32_t)lane;
                 uint32_t m_tr = 0, m_off = 0;
                 bool multi = false;
                 if (e < qn) {
-                    if constexpr (KPRE) {
-                        // queued as {canonical packed k-mer, read} and resolved by K-MER: the k-mer is looked up in the exact map the
-                        // enumeration produced (two independent 16-byte loads, four 32-bit compares) -- no hash is computed
-                        const uint2 ce = q64[e];
-                        const uint32_t key = ce.x, t = ce.y;
-                        const uint32_t b1 = kmap_cell1(key, ix.kmap_m), b2 = kmap_cell2(key, ix.kmap_m);
-                        const uint4 c1 = ix.kmap[b1], c2 = ix.kmap[b2];
-                        uint32_t val = 0, id = KMAP_EMPTY;
-                        if (c1.x == key) { val = c1.y; id = 2u * b1; }
-                        else if (c1.z == key) { val = c1.w; id = 2u * b1 + 1u; }
-                        else if (c2.x == key) { val = c2.y; id = 2u * b2; }
-                        else if (c2.z == key) { val = c2.w; id = 2u * b2 + 1u; }
-                        if (id != KMAP_EMPTY) { // else: a false positive of the bit filter
-                            // a k-mer whose canonical hash is 0: plain tiles count their zero hashes here (every such k-mer is
-                            // in the map); the other tiles counted every window in their hashing loop
-                            if (val == KMAP_ZERO) { if (drain_counts_zero) atomicAdd(&nzero[t], 1u); }
-                            else multi = apply_hit(id, val, (int)t, m_tr, m_off);
-                        }
-                    } else {
                     const uint4 ce = qe[e];
                     multi = take_candidate(((uint64_t)ce.y << 32) | ce.x, (int)ce.z, m_tr, m_off);
-                    }
                 }
                 const uint64_t mm = __ballot(multi);
                 if (mm) { // hits with several postings: 16 lanes walk one hit's posting list, 4 hits at a time
@@ -642,101 +525,13 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
             uint32_t fw = 0;             // ... or its word of the first-level filter (large panels)
             uint64_t hp = 0;
             uint32_t tp = 0; // read of the previous position
-            uint32_t pp = 0; // ... and its tile byte position (MODE_ 5 queues positions)
             uint32_t it = 0;
-            // (MODE_ 5) drains whole waves of candidates mid-tile, everything at the end
-            auto drain_now = [&](bool last) {
-                wave_sync();
-                const uint32_t qn = last ? qcount : (qcount & ~(uint32_t)(WAVE - 1)); // mid-tile: whole waves of candidates only
-                if (!RK_DBG(32)) drain_queue(qn);
-                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no load of the drain is pending
-                wave_sync();
-                if (last) { qcount = 0; return; }
-                const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
-                uint2 ce = make_uint2(0u, 0u);
-                if ((uint32_t)lane < rem) ce = q64[qn + lane];
-                wave_sync();
-                if ((uint32_t)lane < rem) q64[lane] = ce;
-                qcount = rem;
-                wave_sync();
-            };
-            bool tile_done = false;
-            if constexpr (KPRE) {
-                if (compact) { // wave-uniform
-                    // MODE_ 5, plain tile.  No hashing in this loop: packed k-mer of both strands -> the smaller -> one filter word.
-                    // A step is ~30 VALU, far too little to hide an L2 round trip, so the steps run in chunks of KCH: the filter
-                    // words of a whole chunk are requested back to back, ONE wait retires them, then the chunk is examined.
-                    constexpr int KCH = 5;
-                    // Nothing is in flight here at run time.  The statement is for the STATIC control-flow graph: hipcc's structurizer
-                    // threads this branch and the other loop form through shared "Flow" blocks, which creates (infeasible) paths
-                    // from that loop's asm-issued filter load to this code; with the load's register retired here, every such
-                    // path passes a wait before the register can be handed to anything else (tools/lint_async_loads.py).
-                    word_wait(fw);
-                    for (uint32_t c0 = 0; c0 < nIt; c0 += KCH) {
-                        const uint32_t len = nIt - c0 < (uint32_t)KCH ? nIt - c0 : (uint32_t)KCH;
-                        uint32_t xv[KCH], offv[KCH], fwv[KCH];
-#pragma unroll
-                        for (int j = 0; j < KCH; ++j) { // canonical k-mer and filter word address of every window of the chunk
-                            uint32_t key = 0u, off = 0u;
-                            if ((uint32_t)j < len) { // wave-uniform
-                                const uint32_t w = (c0 + (uint32_t)j) * WAVE + (uint32_t)lane;
-                                if (w < nW) {
-                                    const uint32_t t_ = __umulhi(w, magic);
-                                    const uint32_t p_ = w + __umul24(t_, dtail);
-                                    const uint32_t vf = packed_window<KT>(pk_f, pkoff + p_);
-                                    const uint32_t vr = packed_window<KT>(pk_r, B - (uint32_t)KT - p_);
-                                    key = vf < vr ? vf : vr;
-                                    off = kpre_word_off_s(vf, vr, kp_sf, kp_sr, KT, kpre_mix(key), ix.kpshift);
-                                    if RK_DBG(2048) off &= 0x7Cu;   // TIMING EXPERIMENT (wrong results): every probe of the wave in one cache line
-                                }
-                            }
-                            xv[j] = key; offv[j] = off;
-                        }
-                        // The chunk's filter words: five loads issued back to back and retired by the wait in ONE asm statement, so
-                        // hipcc cannot place anything -- in particular no copy of a destination register -- between issue and wait
-                        // (it did, once the register pressure changed; tools/lint_async_loads.py caught it).  Outputs are early-
-                        // clobber: a load may land while a later one is still being issued.  s_nop 4: the "s" base may have been
-                        // re-materialised by a VALU v_readlane right before (see word_load_async_ws).  Steps past the tile's end
-                        // load word 0 and are ignored.
-                        static_assert(KCH == 5, "the asm statement names the chunk's registers");
-                        asm volatile("s_nop 4\n\t"
-                                     "global_load_dword %0, %5, %10\n\t"
-                                     "global_load_dword %1, %6, %10\n\t"
-                                     "global_load_dword %2, %7, %10\n\t"
-                                     "global_load_dword %3, %8, %10\n\t"
-                                     "global_load_dword %4, %9, %10\n\t"
-                                     "s_waitcnt vmcnt(0)"
-                                     : "=&v"(fwv[0]), "=&v"(fwv[1]), "=&v"(fwv[2]), "=&v"(fwv[3]), "=&v"(fwv[4])
-                                     : "v"(offv[0]), "v"(offv[1]), "v"(offv[2]), "v"(offv[3]), "v"(offv[4]), "s"(ix.kpre)
-                                     : "memory");
-#pragma unroll
-                        for (int j = 0; j < KCH; ++j) {
-                            if ((uint32_t)j < len) {
-                                if (qcount + WAVE > QCAP) drain_now(false);
-                                const uint32_t w = (c0 + (uint32_t)j) * WAVE + (uint32_t)lane;
-                                const uint32_t bm = kpre_bits(kpre_mix(xv[j]));
-                                bool cand = w < nW && (fwv[j] & bm) == bm;
-                                if RK_DBG(4096) cand = false;   // TIMING EXPERIMENT (wrong results): probes only, nothing reaches the drain
-                                const uint64_t m = __ballot(cand);
-                                if (cand) {
-                                    const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                                    q64[q] = make_uint2(xv[j], __umulhi(w, magic));
-                                }
-                                qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
-                            }
-                        }
-                    }
-                    tile_done = true;
-                }
-            }
-            if (!tile_done)
             for (;;) {
                 // run positions until the queue may not take another wave of candidates (or the tile is done);
                 // step nIt only examines the last lookup
                 for (; it <= nIt && (MODE == 1 || qcount + WAVE <= QCAP); ++it) {
                     uint32_t t = 0;
                     uint64_t h = 0;
-                    uint32_t pcur = 0;
                     if (it < nIt) {
                         // what happens to a window's canonical hash: the -M count / mask, the zero-hash tally of its read
                         auto account = [&](uint64_t& hh, uint32_t tt) {
@@ -783,13 +578,10 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                             ok = p < B && !((bad[p >> 5] >> (p & 31)) & 1u);
                             if (ok) t = (uint32_t)read_of(p);
                         }
-                        pcur = p;
                         if (ok) { // idle lanes (read tails, the end of the tile) keep h = 0 and are never looked up
                             if (MODE == 1 && has_invalid && !window_valid<KT>(s, p, k)) h = 0;
                             else if RK_DBG(4) {
                                 h = ((uint64_t)(s.fwd[(s.fbase + p) >> 2] * 0x9E3779B1u) << 32) | (s.rc[(B - (uint32_t)k - p) >> 2] * 0x85EBCA6Bu);
-                            } else if constexpr (KPRE) { // no byte images here: the window is expanded from the packed image in registers
-                                h = canonical_packed(packed_window<KT>(pk_f, pkoff + p), KT, pol.seed, pol.fold);
                             } else {
                                 if constexpr (KT == 0) { // run-time k: both strands through one block loop, uniform tail masks
                                     h = canonical_rt(s.fwd, s.fbase + p, s.rc, B - (uint32_t)k - p, k, tmasks, pol.seed, pol.fold);
@@ -814,25 +606,16 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                     if constexpr (PRE) { // large panel: the filter word decides what the drain will look up in the table
                         word_wait(fw);
                         const uint32_t bm = index_pre_bits(hp);
-                        // MODE_ 5 queues a lane's K-MER, so a lane without a window (hp = 0: read tails, the end of the tile) must
-                        // not be queued even if the filter word of hash 0 happens to pass: in the hash-queue form that entry was
-                        // looked up as hash 0 and found nothing; here it would be the k-mer at that lane's position, for read 0
-                        // (found by the randomized soak: over-counts on the first read of tiles of unequal reads under len-k)
-                        const bool cand = (fw & bm) == bm && (!KPRE || hp != 0);
+                        const bool cand = (fw & bm) == bm;
                         const uint64_t m = __ballot(cand);
                         if (cand) {
                             const uint32_t q = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            if constexpr (KPRE) { // tiles that are not plain: queued as {k-mer, read} as well
-                                const uint32_t vf = packed_window<KT>(pk_f, pkoff + pp), vr = packed_window<KT>(pk_r, B - (uint32_t)KT - pp);
-                                q64[q] = make_uint2(vf < vr ? vf : vr, tp);
-                            }
-                            else qe[q] = make_uint4((uint32_t)hp, (uint32_t)(hp >> 32), tp, 0u);
+                            qe[q] = make_uint4((uint32_t)hp, (uint32_t)(hp >> 32), tp, 0u);
                         }
                         qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
                         word_load_async(ix.pre, index_pre_word(h, ix.pmask) << 2, fw);
                         hp = h;
                         tp = t;
-                        pp = pcur;
                         continue;
                     }
                     bucket_wait(fb);
@@ -866,9 +649,6 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                 // drain: every lane takes queued candidates
                 wave_sync();
                 const bool last = it > nIt;
-                // MODE_ 5: the final drain is shared with the chunked form, below.  The last step's filter word is never examined:
-                // it is retired HERE, in the block that leaves the loop, so no edge out of this loop has a load in flight
-                if constexpr (KPRE) { if (last) { word_wait(fw); break; } }
                 const uint32_t qn = last ? qcount : (qcount & ~(uint32_t)(WAVE - 1)); // mid-tile: whole waves of candidates only
                 if (!RK_DBG(32)) drain_queue(qn);
                 // tell hipcc that no load of the drain is pending any more: otherwise it drains vmcnt inside every
@@ -880,27 +660,12 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
                 if constexpr (PRE) { if (last) word_wait(fw); }
                 if (last) { qcount = 0; break; }
                 const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
-                if constexpr (KPRE) {
-                    uint2 ce = make_uint2(0u, 0u);
-                    if ((uint32_t)lane < rem) ce = q64[qn + lane];
-                    wave_sync();
-                    if ((uint32_t)lane < rem) q64[lane] = ce;
-                } else {
                 uint4 ce = make_uint4(0u, 0u, 0u, 0u);
                 if ((uint32_t)lane < rem) ce = qe[qn + lane];
                 wave_sync();
                 if ((uint32_t)lane < rem) qe[lane] = ce;
-                }
                 qcount = rem;
                 wave_sync();
-            }
-            if constexpr (KPRE) {
-                // Both loop forms end here with their last candidates still queued and no load in flight.  Only now -- issued in
-                // phase 0, its HBM latency would sit in front of every chunk's wait -- are the next tile's bases requested, from
-                // this ONE call site (two sites would make hipcc merge the prefetch registers with copies of registers that are
-                // still in flight); they land during the final drain and phase 2.
-                if (ntile < ntiles) load_bases(cur_a, cur_b);
-                drain_now(true);
             }
         }
         if (MODE == 1) { wait_bases(); continue; } // see the end of the loop body
@@ -959,27 +724,42 @@ __global__ __launch_bounds__(WAVE, (MODE_ == 5 ? RK_KPRE_WAVES_PER_SIMD : RK_WAV
 // saturates VALU issue at 6 waves/SIMD and loses ~11 % at 5 (measured), so tiles never grow past this.
 constexpr size_t LDS_BUDGET_6_WAVES = 6656;
 
-static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_read, int win_total, int kpre) {
+// The RKMH_* knobs (A/B runs, the geometry sweeps of the test suite) are read ONCE per process: a launch costs no getenv.
+struct TileKnobs {
+    int qcap = 0, c16 = 0, sparse = 0, dset = 0, dbg = 0, tile_t = 0, tpb = 0, xcd = -1, pre_masked = -1;
+    TileKnobs() {
+        auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        qcap = num("RKMH_TILE_QCAP", 0);
+        c16 = num("RKMH_TILE_C16", 0);
+        sparse = getenv("RKMH_TILE_SPARSE") ? (num("RKMH_TILE_SPARSE", 0) > 0 ? 1 : -1) : 0;
+        dset = num("RKMH_TILE_DSET", 0);
+        dbg = num("RKMH_DBG", 0);
+        tile_t = num("RKMH_TILE_T", 0);
+        tpb = num("RKMH_TILE_TPB", 0);
+        xcd = num("RKMH_TILE_XCD", -1);
+        pre_masked = num("RKMH_PRE_MASKED", -1);
+    }
+};
+static const TileKnobs& knobs() { static const TileKnobs k; return k; }
+
+static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_read, int win_total) {
+    const TileKnobs& kn = knobs();
     TileGeom g;
-    g.kpre = kpre;
     if (maxlen < 1) maxlen = 1;
-    g.qcap = 128;
-    if (const char* e = getenv("RKMH_TILE_QCAP")) g.qcap = atoi(e);
+    g.qcap = kn.qcap > 0 ? kn.qcap : 128;
     g.clg = win_total <= 255 ? 2 : 1;
-    if (const char* e = getenv("RKMH_TILE_C16")) { if (atoi(e) > 0) g.clg = 1; } // A/B knob: 1 = always 16-bit counters
+    if (kn.c16 > 0) g.clg = 1; // A/B knob: always 16-bit counters
     g.cwords = (nref + (1 << g.clg) - 1) >> g.clg;
     g.csparse = 0;
     // Many references: a dense counter row per read would eat the LDS budget (and reference ids beyond 2048 would not
     // fit at all), so the row becomes a 128-entry map of the references the read actually hits.
-    int sparse_min = 129; // dense rows up to 128 words (512 B) stay dense
-    if (const char* e = getenv("RKMH_TILE_SPARSE")) sparse_min = atoi(e) > 0 ? 1 : (1 << 30);
+    const int sparse_min = kn.sparse > 0 ? 1 : (kn.sparse < 0 ? (1 << 30) : 129); // dense rows up to 128 words (512 B) stay dense
     if (nref > 0 && g.cwords >= sparse_min) { g.csparse = 1; g.cwords = 128; }
     int ds = 64;
     while (ds < 3 * expect_hits && ds < 1024) ds <<= 1;
-    if (const char* e = getenv("RKMH_TILE_DSET")) ds = atoi(e);
+    if (kn.dset > 0) ds = kn.dset;
     g.dset = ds;
-    g.dbg = 0;
-    if (const char* e = getenv("RKMH_DBG")) g.dbg = atoi(e);
+    g.dbg = kn.dbg;
     // Reads per tile: the hashing loop walks T * win_per_read windows 64 at a time, so T is chosen for the best fill of
     // its last step (150 bp, k=16: T=3 fills 89.7 %, T=4 93.1 %) among the sizes that keep the occupancy target and
     // the short prefetch (<= 3 dwords per lane).
@@ -988,16 +768,11 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
         return T * maxlen <= PF_MAX * WAVE * 4 - 8 && tile_lds_bytes(g) <= budget;
     };
     if (win_per_read < 1) win_per_read = 1;
-    // prefetch dwords per lane the k-mer-space form may use when choosing its tile: 4 (six 150 bp reads per tile: 0.481 ms
-    // against 0.507 for five with 3 dwords -- the second drain round is fuller and phase 2 takes eight reads in one pass).
-    // RKMH_KPRE_PF=3 for A/B runs.
-    int kpre_pf = 4;
-    if (const char* e = getenv("RKMH_KPRE_PF")) kpre_pf = atoi(e) == 3 ? 3 : 4;
     double fill[17] = {0};
     int tmax = 1;
     double best_fill = -1.0;
     for (int T = 1; T <= 16; ++T) {
-        if (T > 1 && (!fits(T, LDS_BUDGET_6_WAVES) || T * maxlen > (kpre ? kpre_pf : 3) * WAVE * 4 - 8)) break;
+        if (T > 1 && (!fits(T, LDS_BUDGET_6_WAVES) || T * maxlen > 3 * WAVE * 4 - 8)) break;
         const int nw = T * win_per_read;
         fill[T] = (double)nw / (double)(((nw + WAVE - 1) / WAVE) * WAVE);
         if (fill[T] > best_fill) best_fill = fill[T];
@@ -1008,12 +783,7 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
     int best = 1;
     for (int T = 1; T <= tmax; ++T)
         if (fill[T] >= best_fill - 0.025) { best = T; break; }
-    // the k-mer-space form: a step is a fifth of a hashing step, so the fill of the last one hardly matters and the per-tile
-    // bookkeeping does -- the largest tile within a prefetch of 4 dwords per lane (measured at 150 bp: T = 4 and 5 0.518 ms, 6..8
-    // with the 6-dword prefetch 0.53-0.55, 9-10 0.57; then, with a 4-dword prefetch instantiated, T = 6 0.481)
-    // ... but never more than eight reads: that is what phase 2 takes in one pass (100 bp reads: T = 8 0.333 ms, T = 9-10 0.37)
-    if (kpre) best = tmax < 8 ? tmax : 8;
-    if (const char* e = getenv("RKMH_TILE_T")) best = atoi(e);
+    if (kn.tile_t > 0) best = kn.tile_t;
     if (best > 16) best = 16;
     if (best < 1) best = 1;
     while (best > 1 && best * maxlen > PF_MAX * WAVE * 4 - 8) --best;
@@ -1030,13 +800,11 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st) {
     if (nreads == 0) return hipSuccess;
+    const TileKnobs& kn = knobs();
     int win_total = 0; // most windows any read of the batch can have (all k): bounds every per-reference count
     for (int j = 0; j < ks.n; ++j) win_total += num_windows(maxlen, ks.k[j], pol.drop_last_window);
-    // the k-mer-space filter form: plain classification (no -M counter) with the single k the filter was enumerated for
-    const bool use_kpre = mode == 0 && !counter && ix.kpre && ix.kmap && ix.pre && ks.n == 1 && (uint32_t)ks.k[0] == ix.kpk &&
-                          ks.k[0] >= KPRE_MIN_K && ks.k[0] <= 16;
     TileGeom geo = make_geom(maxlen, mode == 1 ? 0 : ix.nref, mode == 1 ? 0 : expect_hits,
-                             num_windows(maxlen, ks.k[0], pol.drop_last_window), win_total, use_kpre ? 1 : 0);
+                             num_windows(maxlen, ks.k[0], pol.drop_last_window), win_total);
     if (mode == 1) { geo.qcap = 0; geo.dset = 0; }
     while (tile_lds_bytes(geo) > 20 * 1024 && geo.T > 1) { geo.T -= 1; geo.cap_bytes = geo.T * maxlen; } // >= 8 waves per CU
     const size_t lds = tile_lds_bytes(geo);
@@ -1045,24 +813,22 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     // and retires, so the hardware dispatcher keeps balancing the CUs.  Measured on MI355X with the current kernel
     // (T=4): 1 or 2 tiles per workgroup are within noise of each other, 3 is -1 %, 6 is -4 %, chip-resident persistent
     // waves were -17 % (tail imbalance); 2 keeps the cross-tile prefetch useful when the batch streams from HBM.
-    int tpb = 2;
-    if (const char* e = getenv("RKMH_TILE_TPB")) tpb = atoi(e) > 0 ? atoi(e) : 2;
+    const int tpb = kn.tpb > 0 ? kn.tpb : 2;
     geo.tpb = tpb;
-    geo.xcd = 1;
-    if (const char* e = getenv("RKMH_TILE_XCD")) geo.xcd = atoi(e) != 0;
+    geo.xcd = kn.xcd >= 0 ? (kn.xcd != 0) : 1;
     geo.slots_m = slots ? ~0ull / slots : 0;
     geo.magic_nw = num_windows(maxlen, ks.k[0], pol.drop_last_window);
     geo.magic = geo.magic_nw >= 2 ? 0xFFFFFFFFu / (uint32_t)geo.magic_nw + 1u : 0u;
     const bool k16 = (ks.n == 1 && ks.k[0] == 16);
     const int kmode = mode == 1 ? 1 : (counter ? 2 : 0);
-    // The masked (-M) form waits for a random read of the 800 MB counter table in every step: it is bound by memory requests,
+    // The masked (-M) form waits for a random read of the keep bitmap in every step: it is bound by memory requests,
     // not by VALU issue, and the filter word is one more request per window (C2: 2.86 ms without, 3.10 ms with).  It pays
     // only once the bucket table itself has left L2.
     // (Round 2: the count is read as one keep bit per slot -- 25 MB instead of 800 MB -- which took this form from 2.86 to 2.58 ms;
     // pipelining that lookup one step ahead, in the filter-word form, was measured SLOWER, 2.89 ms: the pass is bound by the
     // rate of random accesses that miss the L2, about 5 * 10^10 per second here, not by latency or instructions.)
     bool pre_masked = ((size_t)ix.bmask + 1) * 16 > ((size_t)3 << 20);
-    if (const char* e = getenv("RKMH_PRE_MASKED")) pre_masked = atoi(e) != 0; // tests force either form
+    if (kn.pre_masked >= 0) pre_masked = kn.pre_masked != 0; // tests force either form
 #define RK_LAUNCH_P(KT, MODE, FOLD, PF)                                                                                    \
     do {                                                                                                             \
         if (lds > 64 * 1024) {                                                                                       \
@@ -1081,14 +847,6 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
         else if (geo.cap_bytes <= 3 * WAVE * 4 - 8) RK_LAUNCH_P(KT, MODE, FOLD, 3);                                  \
         else RK_LAUNCH_P(KT, MODE, FOLD, 6);                                                                         \
     } while (0)
-/* the k-mer-space form also exists with four prefetch dwords per lane (tiles of up to 1016 bytes: six 150 bp reads) */
-#define RK_LAUNCH5(KT, FOLD)                                                                                          \
-    do {                                                                                                             \
-        if (geo.cap_bytes <= 2 * WAVE * 4 - 8) RK_LAUNCH_P(KT, 5, FOLD, 2);                                          \
-        else if (geo.cap_bytes <= 3 * WAVE * 4 - 8) RK_LAUNCH_P(KT, 5, FOLD, 3);                                     \
-        else if (geo.cap_bytes <= 4 * WAVE * 4 - 8) RK_LAUNCH_P(KT, 5, FOLD, 4);                                     \
-        else RK_LAUNCH_P(KT, 5, FOLD, 6);                                                                            \
-    } while (0)
 #define RK_LAUNCH_M(KT, FOLD)                                                                                        \
     do {                                                                                                             \
         if (kmode == 1) RK_LAUNCH(KT, 1, FOLD);                                                                      \
@@ -1098,18 +856,7 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
         else RK_LAUNCH(KT, 4, FOLD);                                                                                 \
     } while (0)
     // single k of 12, 20 (the reference's other documented settings), 21 or 31: window length known at compile time, runtime fold
-    if (use_kpre && ks.k[0] == 8) RK_LAUNCH5(8, -1);
-    else if (use_kpre && ks.k[0] == 9) RK_LAUNCH5(9, -1);
-    else if (use_kpre && ks.k[0] == 10) RK_LAUNCH5(10, -1);
-    else if (use_kpre && ks.k[0] == 11) RK_LAUNCH5(11, -1);
-    else if (use_kpre && ks.k[0] == 12) RK_LAUNCH5(12, -1);
-    else if (use_kpre && ks.k[0] == 13) RK_LAUNCH5(13, -1);
-    else if (use_kpre && ks.k[0] == 14) RK_LAUNCH5(14, -1);
-    else if (use_kpre && ks.k[0] == 15) RK_LAUNCH5(15, -1);
-    else if (use_kpre && pol.fold == 0) RK_LAUNCH5(16, 0);
-    else if (use_kpre && pol.fold == 1) RK_LAUNCH5(16, 1);
-    else if (use_kpre) RK_LAUNCH5(16, 2);
-    else if (ks.n == 1 && ks.k[0] == 12) RK_LAUNCH_M(12, -1);
+    if (ks.n == 1 && ks.k[0] == 12) RK_LAUNCH_M(12, -1);
     else if (ks.n == 1 && ks.k[0] == 20) RK_LAUNCH_M(20, -1);
     else if (ks.n == 1 && ks.k[0] == 21) RK_LAUNCH_M(21, -1);   // Mash / sourmash defaults
     else if (ks.n == 1 && ks.k[0] == 31) RK_LAUNCH_M(31, -1);
@@ -1117,7 +864,6 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     else if (pol.fold == 0) RK_LAUNCH_M(16, 0);
     else if (pol.fold == 1) RK_LAUNCH_M(16, 1);
     else RK_LAUNCH_M(16, 2);
-#undef RK_LAUNCH5
 #undef RK_LAUNCH_M
 #undef RK_LAUNCH
 #undef RK_LAUNCH_P

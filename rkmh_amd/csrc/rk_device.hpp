@@ -96,27 +96,6 @@ __device__ __forceinline__ uint64_t min_swapped(uint64_t f, uint64_t r) {
 
 // 2-bit base code of an upper-case base: (ascii >> 1) & 3  =>  A=0, C=1, T=2, G=3; complement = code ^ 2.
 // Packed k-mer: base i of the string in bits [2i, 2i+2).
-__host__ __device__ __forceinline__ uint32_t kpre_mix(uint32_t key) { return key * 0x9E3779B1u; }
-__host__ __device__ __forceinline__ uint32_t kpre_bits(uint32_t x) { return (1u << ((x >> 4) & 31u)) | (1u << ((x >> 9) & 31u)); }
-// Where a window probes the filter.  The kernel is bound by L2 REQUESTS (one per distinct 128-byte line a wave touches), so the
-// line is chosen by something four neighbouring windows of a read have in common: windows p = 4g + j (j = 0..3) all contain the
-// (k-3)-mer at read positions [4g + 3, 4g + k), which sits at offset 3 - j of window j.  line = hash of the smaller of that
-// substring and its reverse complement (strand-symmetric); the word inside the line comes from the k-mer's own mix x.  A key is
-// therefore entered under its four possible alignments (j = 0..3, which also covers its occurrence on the other strand).
-//   vf / vr: packed window and packed reverse-complement window;  j = position & 3;  kplines = lines - 1 (power of two)
-// sf = 2 * (3 - j), sr = 2 * j: the shifts that bring the shared substring of alignment j to bit 0 of the window / of its
-// reverse complement.  ANY j in 0..3 finds a key (all four are entered); which one a lane uses only decides how well a wave's
-// probes coalesce, so the fused kernel takes j = lane & 3 -- per-lane constants -- which is the alignment of four consecutive
-// windows whenever a lane quad lies inside one read.
-__host__ __device__ __forceinline__ uint32_t kpre_word_off_s(uint32_t vf, uint32_t vr, uint32_t sf, uint32_t sr, int k, uint32_t x, uint32_t kplg) {
-    const uint32_t msk = (1u << (2 * (k - 3))) - 1u;                    // k <= 16: at most 26 bits
-    const uint32_t a = (vf >> sf) & msk, b = (vr >> sr) & msk;
-    const uint32_t c = (a < b ? a : b) * 0x85EBCA6Bu;
-    return ((c >> (32u - kplg)) << 7) | ((x >> 25) << 2 & 0x7Cu);       // byte offset: line * 128 + word-in-line * 4
-}
-__host__ __device__ __forceinline__ uint32_t kpre_word_off(uint32_t vf, uint32_t vr, uint32_t j, int k, uint32_t x, uint32_t kplg) {
-    return kpre_word_off_s(vf, vr, 2u * (3u - j), 2u * j, k, x, kplg);
-}
 // ---- forward-strand group filter of the k-mer-space kernel (rk_kmer.hip) --------------------------------------------------------
 // One lane of that kernel examines FOUR consecutive windows of a read (a "group": read positions 4g .. 4g+3), which it reads from
 // the packed image as one super-window of k + 3 bases.  All four windows contain the (k-3)-mer at super-window offset 3 (the
@@ -430,23 +409,12 @@ struct RefIndex {
     // and only windows that pass go to the queue; the drain looks them up in the table as it always did.
     const uint32_t* pre;
     uint32_t pmask;   // filter words - 1
-    // Optional k-mer-space filter (nullptr = none; single k <= 16 only): a bit array addressed by the PACKED 2-bit k-mer
-    // (smaller of the window and its reverse complement as 32-bit numbers) in which every k-mer of the whole 4^k universe whose
-    // canonical hash is a key of this index -- or is 0 -- has its two bits set.  It is filled by exhaustive enumeration
-    // (k_enum_kmers), so it has no false negatives BY CONSTRUCTION: a window that fails the test provably hashes to a non-zero
-    // value that is in no sketch, and the fused kernel does not hash it at all (k_classify_tile, MODE_ 5).
-    const uint32_t* kpre;
-    uint32_t kpshift; // log2(filter LINES of 128 bytes)
-    uint32_t kpk;     // the k it was enumerated for
-    // ... and the exact map behind it: every k-mer the enumeration found, as {packed canonical k-mer, index value} cells in a
-    // bucketed cuckoo hash: 16-byte buckets of two cells, two candidate buckets per k-mer, load ~0.8 (1.6 MB at C2: it must
-    // share the L2 with the filter; 0xFFFFFFFF = empty cell: never a canonical k-mer).  A candidate window is resolved by its
-    // K-MER -- two independent 16-byte loads and four 32-bit compares -- so MODE_ 5 kernels compute no hash at all: the
-    // enumeration hashed the whole universe once.  The cell number is the key's identity for the per-read hit multiset (the map
-    // is only built when every index key has exactly one preimage, which the enumeration checks; otherwise the hash-space
-    // kernels serve the panel).  value = KMAP_ZERO marks a k-mer whose canonical hash is 0.
-    const uint4* kmap;
-    uint32_t kmap_m;  // buckets
+    // Optional k-mer-space structures (nullptr = none; a single k from 8 to 16 only), built from the EXHAUSTIVE enumeration of the
+    // 4^k k-mer universe (k_enum_kmers): every k-mer whose canonical hash is a key of this index -- or is 0 -- is in them, so they
+    // have no false negatives BY CONSTRUCTION: a window that fails the filter provably hashes to a non-zero value that is in no
+    // sketch, and k_classify_kmer does not hash it at all.  They are only built when every index key has exactly one preimage
+    // (the enumeration checks); otherwise the hash-space kernels serve the panel.
+    uint32_t kpk;     // the k they were enumerated for
     // forward-strand group filter of k_classify_kmer (rk_kmer.hip; see kf4_sector above): 2^kf4_lg sectors of 16 bytes
     const uint4* kf4;
     uint32_t kf4_lg;
@@ -454,20 +422,16 @@ struct RefIndex {
     uint32_t km1_b;
     const uint32_t* km1_vals;
 };
-// ... and the single-probe form of that map the k-mer-space kernel (rk_kmer.hip) resolves its candidates in: one 16-byte bucket of
-// four 4-byte cells per lookup.  y = key * odd constant is a bijection on 32 bits, so (bucket = top km1_b bits of y, remainder =
-// the other 32 - km1_b <= 15 bits) IS the key: a cell holds the remainder (high half; bit 15 = the cell's key belongs to the
-// PREVIOUS bucket, which was full) and a 15-bit value id (low half; bit 15 of the bucket's last cell = a key of this bucket was
-// displaced into the next one).  Value ids below KM1_VID_TABLE are a single posting of multiplicity 1 (the id is the reference);
-// KM1_VID_ZERO marks a k-mer whose canonical hash is 0; other ids index km1_vals, which holds index values in the RefIndex::kv format.
+// The exact map the k-mer-space kernel (rk_kmer.hip) resolves its candidates in: every k-mer the enumeration found, one 16-byte
+// bucket of four 4-byte cells per lookup.  y = (key * odd constant) mod 4^k is a bijection on the 2k-bit k-mers, so (bucket = top
+// km1_b bits of y, remainder = the other r = 2k - km1_b bits) IS the key.  A cell, from the top: the tag (r + 1 bits: the
+// remainder, above it 1 = this key belongs to the PREVIOUS bucket, which was full), one flag bit (in the bucket's last cell: a key
+// of this bucket was displaced into the next one) and the value id (vb = 30 - r bits).  Value ids below the number of references
+// are a single posting of multiplicity 1 (the id is the reference); km1_vid_zero marks a k-mer whose canonical hash is 0; other
+// ids index km1_vals (offset by the number of references), which holds index values in the RefIndex::kv format; all ones = empty.
 constexpr uint32_t KM1_C = 0x9E3779B1u;
-constexpr uint32_t KM1_VID_TABLE = 16384u, KM1_VID_ZERO = 0x7FFEu, KM1_VID_EMPTY = 0x7FFFu;
-constexpr uint32_t KM1_CELL_EMPTY = 0xFFFF0000u | KM1_VID_EMPTY; // remainder field 0xFFFF: no remainder (<= 15 bits + displaced bit... see below) equals it
-constexpr uint32_t KMAP_EMPTY = 0xFFFFFFFFu;
-constexpr uint32_t KMAP_ZERO = 0xFFFFFFFEu; // not a valid index value (bit 31 set => postings offset < 2^31 - 1)
-__host__ __device__ __forceinline__ uint32_t kmap_cell1(uint32_t key, uint32_t m) { return (uint32_t)(((uint64_t)(key * 0x9E3779B1u) * m) >> 32); }
-__host__ __device__ __forceinline__ uint32_t kmap_cell2(uint32_t key, uint32_t m) { return (uint32_t)(((uint64_t)((key ^ (key >> 15)) * 0x85EBCA6Bu) * m) >> 32); }
-
+__host__ __device__ __forceinline__ uint32_t km1_y(uint32_t key, int k) { return k >= 16 ? key * KM1_C : (key * KM1_C) & ((1u << (2 * k)) - 1u); }
+__host__ __device__ __forceinline__ uint32_t km1_vbits(int k, uint32_t b) { return 30u - ((uint32_t)(2 * k) - b); }
 // filter word and bit pair of a hash: the word from the low bits of the high hash word (like the bucket), the two bits
 // from bits 14..23 of the low word (bits 0..13 are the fingerprint)
 __host__ __device__ __forceinline__ uint32_t index_pre_word(uint64_t h, uint32_t pmask) { return (uint32_t)(h >> 32) & pmask; }

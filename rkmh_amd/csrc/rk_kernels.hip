@@ -344,14 +344,14 @@ hipError_t launch_keep_bits(const int32_t* counter, uint64_t slots, int min_occ,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Exhaustive enumeration behind the k-mer-space filter (RefIndex::kpre): EVERY k-mer of the 4^k universe (k <= 16) is hashed
+// Exhaustive enumeration behind the k-mer-space kernel (rk_kmer.hip): EVERY k-mer of the 4^k universe (k <= 16) is hashed
 // exactly as calc_hashes would hash it as a window; those whose canonical hash is a key of the index -- the true preimages of
-// the sketch hashes and any other k-mer that happens to collide with one -- and those hashing to 0 set their two bits.  The
-// fused kernel's decision "this window cannot matter" is therefore a theorem about this index, not a probabilistic filter.
-// 4^16 k-mers take ~25 ms on MI355X (two murmurs + one 4-byte read of the hash-space filter each; the bucket table is only
-// touched by the few that pass).
-__global__ __launch_bounds__(256) void k_enum_kmers(RefIndex ix, DevPolicy pol, int k, uint64_t total, uint32_t* kpre, uint32_t kpshift,
-                                                    uint32_t* stats, uint2* list, uint32_t list_cap) {
+// the sketch hashes and any other k-mer that happens to collide with one -- and those hashing to 0 are listed.  The host builds
+// the group filter (kf4) and the exact map (km1) from the list, so that kernel's decision "this window cannot matter" is a
+// theorem about this index, not a probabilistic filter.  4^16 k-mers take ~25 ms on MI355X (two murmurs + one 4-byte read of
+// the hash-space filter each; the bucket table is only touched by the few that pass).
+__global__ __launch_bounds__(256) void k_enum_kmers(RefIndex ix, DevPolicy pol, int k, uint64_t total, uint32_t* stats, uint2* list,
+                                                    uint32_t list_cap) {
     for (uint64_t v64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v64 < total; v64 += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t v = (uint32_t)v64;
         const uint32_t rv = packed_revcomp(v, k);
@@ -366,19 +366,16 @@ __global__ __launch_bounds__(256) void k_enum_kmers(RefIndex ix, DevPolicy pol, 
             slot = index_find(ix, h);
             if (slot == IDX_NOT_FOUND) continue;
         }
-        const uint32_t x = kpre_mix(v);
-        for (uint32_t j = 0; j < 4; ++j) // the four alignments a read can present this k-mer (or its reverse complement) in
-            atomicOr(&kpre[kpre_word_off(v, rv, j, k, x, kpshift) >> 2], kpre_bits(x));
         const uint32_t pos = atomicAdd(stats, 1u);
         if (pos < list_cap) list[pos] = make_uint2(v, slot); // slot = IDX_NOT_FOUND: the k-mer hashes to 0
     }
 }
-hipError_t launch_enum_kmers(const RefIndex& ix, const DevPolicy& pol, int k, uint32_t* kpre, uint32_t kpshift, uint32_t* stats,
-                             uint2* list, uint32_t list_cap, hipStream_t st) {
+hipError_t launch_enum_kmers(const RefIndex& ix, const DevPolicy& pol, int k, uint32_t* stats, uint2* list, uint32_t list_cap,
+                             hipStream_t st) {
     const uint64_t total = 1ull << (2 * k);
     uint64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_enum_kmers, dim3((uint32_t)blocks), dim3(256), 0, st, ix, pol, k, total, kpre, kpshift, stats, list, list_cap);
+    hipLaunchKernelGGL(k_enum_kmers, dim3((uint32_t)blocks), dim3(256), 0, st, ix, pol, k, total, stats, list, list_cap);
     return hipGetLastError();
 }
 

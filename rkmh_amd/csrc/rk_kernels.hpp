@@ -95,10 +95,10 @@ hipError_t launch_select_bottom(const uint64_t* hashes, uint64_t n, int S, const
                                 uint32_t* hist, uint64_t* sel_out, hipStream_t st);
 // bits[s / 32] bit (s % 32) = the count of slot s passes mask_by_frequency's threshold (one streaming pass over the table)
 hipError_t launch_keep_bits(const int32_t* counter, uint64_t slots, int min_occ, const DevPolicy& pol, uint32_t* bits, hipStream_t st);
-// fills RefIndex::kpre (zeroed by the caller) by hashing all 4^k k-mers; stats[0] = k-mers found (one per strand pair), the first
-// list_cap of them in list[] as (packed canonical k-mer, key id or IDX_NOT_FOUND for a zero hash)
-hipError_t launch_enum_kmers(const RefIndex& ix, const DevPolicy& pol, int k, uint32_t* kpre, uint32_t kpshift, uint32_t* stats,
-                             uint2* list, uint32_t list_cap, hipStream_t st);
+// hashes all 4^k k-mers; stats[0] = k-mers found (one per strand pair), the first list_cap of them in list[] as (packed canonical
+// k-mer, key id or IDX_NOT_FOUND for a zero hash)
+hipError_t launch_enum_kmers(const RefIndex& ix, const DevPolicy& pol, int k, uint32_t* stats, uint2* list, uint32_t list_cap,
+                             hipStream_t st);
 hipError_t launch_intersect_pair(const uint64_t* a, int na, const uint64_t* b, int nb, int* out, hipStream_t st);
 hipError_t launch_intersect_pair_emit(const uint64_t* a, int na, const uint64_t* b, int nb, int cap, uint64_t* out, int* n_out, hipStream_t st);
 hipError_t launch_fill_reroute(int32_t* out4, uint32_t nreads, hipStream_t st);
@@ -106,12 +106,12 @@ hipError_t launch_scatter_rows(const int32_t* rows, const uint32_t* ids, uint32_
 // mode 0: classify (out4 written); mode 1: count only (counter incremented)
 // wave-per-tile fused kernel (rk_classify.hip); expect_hits sizes the per-read hit multiset
 bool classify_tile_supported(int nref, int maxlen);
-constexpr int KPRE_MIN_K = 8; // the k-mer-space form of the fused kernel exists for a single k in [KPRE_MIN_K, 16]
+constexpr int KPRE_MIN_K = 8; // the k-mer-space kernel (rk_kmer.hip) exists for a single k in [KPRE_MIN_K, 16]
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st);
 // the k-mer-space kernel (rk_kmer.hip): plain classification with the single k (KPRE_MIN_K..16) the exact k-mer map and the group
-// filter (RefIndex::kmap / kf4) were built for
+// filter (RefIndex::km1 / kf4) were built for
 bool classify_kmer_supported(int nref, int maxlen, int k);
 hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, int k, int S, const RefIndex& ix,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st);

@@ -331,7 +331,8 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         };
         // one candidate of the queue: canonical k-mer, its read, its bucket of the exact map (load in flight on return)
         struct Cand { uint32_t key, t, y; uint4 c; };
-        const uint32_t km_sh = 32u - ix.km1_b, km_rmask = (1u << km_sh) - 1u;
+        const uint32_t km_r = 2u * KT - ix.km1_b, km_vb1 = 31u - km_r;      // remainder bits; value id bits + the flag bit
+        const uint32_t km_vmask = (1u << (km_vb1 - 1u)) - 1u, km_rmask = (1u << km_r) - 1u, nref = (uint32_t)ix.nref;
         auto lookup = [&](uint32_t e, uint32_t qn) -> Cand {
             Cand c;
             uint32_t ent = PAD_P | (0x1FFFFu << 15); // past the queue's end: the all-A k-mer of the padding, never a window of its read
@@ -342,30 +343,32 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             const uint32_t r = packed_revcomp(x, KT);
             c.key = x < r ? x : r;
             c.t = o < rinfo[t].y ? t : 0xFFFFFFFFu; // the last group of a read may reach past its last window
-            c.y = c.key * KM1_C;
-            c.c = ix.km1[c.y >> km_sh];
+            c.y = km1_y(c.key, KT);
+            c.c = ix.km1[c.y >> km_r];
             return c;
         };
-        // the cell of the bucket whose remainder field equals want (KM1_CELL_EMPTY: none)
-        auto match_cell = [&](const uint4& b, uint32_t want) -> uint32_t {
-            return (b.x >> 16) == want ? b.x : ((b.y >> 16) == want ? b.y : ((b.z >> 16) == want ? b.z : ((b.w >> 16) == want ? b.w : KM1_CELL_EMPTY)));
+        // the cell of the bucket whose tag equals the one in wantsh (all ones: none)
+        auto match_cell = [&](const uint4& b, uint32_t wantsh) -> uint32_t {
+            const uint32_t lim = 1u << km_vb1;
+            return (b.x ^ wantsh) < lim ? b.x : ((b.y ^ wantsh) < lim ? b.y : ((b.z ^ wantsh) < lim ? b.z : ((b.w ^ wantsh) < lim ? b.w : 0xFFFFFFFFu)));
         };
         auto apply = [&](const Cand& c) {
-            const uint32_t want = c.y & km_rmask;
-            uint32_t cell = match_cell(c.c, want);
+            const uint32_t wantsh = (c.y & km_rmask) << km_vb1;   // the remainder (low km_r bits of y) in the tag position, "not displaced"
+            uint32_t cell = match_cell(c.c, wantsh);
             // a miss in a bucket that displaced a key into the next one: that bucket may hold this key (tagged as displaced)
-            const bool again = (cell & 0x7FFFu) == KM1_VID_EMPTY && (c.c.w & 0x8000u) != 0u && c.t != 0xFFFFFFFFu;
+            const bool again = (cell & km_vmask) == km_vmask && ((c.c.w >> (km_vb1 - 1u)) & 1u) != 0u && c.t != 0xFFFFFFFFu;
             if (!(RK_KMER_ABL & 16) && __ballot(again)) {
-                if (again) cell = match_cell(ix.km1[((c.y >> km_sh) + 1u) & ((1u << ix.km1_b) - 1u)], want | 0x8000u);
+                if (again) cell = match_cell(ix.km1[((c.y >> km_r) + 1u) & ((1u << ix.km1_b) - 1u)], wantsh | 0x80000000u);
             }
-            const uint32_t vid = cell & 0x7FFFu;
+            const uint32_t vid = cell & km_vmask;
             uint32_t val = vid | (1u << 20); // a single posting of multiplicity 1, in the RefIndex::kv value format
-            const bool hit = vid != KM1_VID_EMPTY && c.t != 0xFFFFFFFFu; // else: a false positive of the bit filter, or a window past its read's last
-            if (!(RK_KMER_ABL & 32) && hit && vid >= KM1_VID_TABLE && vid != KM1_VID_ZERO) val = ix.km1_vals[vid - KM1_VID_TABLE]; // compound value (a few KB: L1-resident)
+            const bool hit = vid != km_vmask && c.t != 0xFFFFFFFFu; // else: a false positive of the bit filter, or a window past its read's last
+            const bool zero = vid == km_vmask - 1u;
+            if (!(RK_KMER_ABL & 32) && hit && vid >= nref && !zero) val = ix.km1_vals[vid - nref]; // compound value (a few KB: L1-resident)
             uint32_t rank = 0;
             bool multi = false;
             if ((RK_KMER_ABL & 2) ? (val == 0x12345u) : hit) {
-                if (vid == KM1_VID_ZERO) atomicAdd(&nzero[c.t], 1u); // a k-mer whose canonical hash is 0
+                if (zero) atomicAdd(&nzero[c.t], 1u); // a k-mer whose canonical hash is 0
                 else {
                     // hit MULTISET of the read: the canonical k-mer (+1: never 0xFFFFFFFF) is the key's identity, every occurrence
                     // adds one more entry, and the entries passed on the way to the free slot are this occurrence's rank.  The merge

@@ -1571,3 +1571,121 @@ def test_depth_filter_with_unusual_table_sizes(orc, pave, slots):
                 cnt.destroy()
     finally:
         c.close()
+
+
+def test_depth_filter_after_a_count_pass_on_another_stream(ctx, orc, pave):
+    """rk_count_batch_device is asynchronous on the CALLER's stream; rk_set_depth_filter snapshots the table into a keep bitmap.
+    The snapshot must see the finished pass 1 even when that ran on a stream the context does not own: the
+    masked classification right after it equals the oracle's two-pass result, with the reference's 200 M-slot table so the
+    count pass is long enough to still be running when the filter is set."""
+    import torch
+    import rkmh_amd
+    from rkmh_amd import synth
+    _, rb, ro = pave
+    n = 300000
+    qb, qo = synth.generate_reads_fast(rb, ro, 0, n)
+    ctx.set_references(rb, ro, [20], 1000)     # k = 20: the masked hash-space kernels
+    sk, ln = ctx.get_reference_sketches()
+    want = orc.classify_stream(qb, qo, [20], 1000, sk, ln, threads=orc.max_threads(), min_kmer_occ=2, counter_slots=200000000)
+    d_b = torch.from_numpy(qb).cuda()
+    d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).cuda()
+    d_out = torch.empty((n, 4), dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        cnt = rkmh_amd.Counter(ctx, slots=200000000)
+        ctx.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt, stream=side.cuda_stream)   # no synchronisation here, on purpose
+        ctx.set_depth_filter(cnt, 2)
+        try:
+            ctx.classify_device_all(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=150, stream=side.cuda_stream)
+            side.synchronize()
+            got = d_out.cpu().numpy()
+        finally:
+            ctx.set_depth_filter(None, 0)
+            cnt.destroy()
+        assert (got == want).all(), (rep, np.nonzero((got != want).any(axis=1))[0][:10])
+
+
+def test_c4_filter_k20_s2000_against_megabase_references(orc, root, data_dir, tmp_path):
+    """BASELINE config 4 in miniature (`filter`, k = 20, s = 2000, with and without -M 2, large references): 24
+    synthetic 1.5 Mb sequences + the HPV16 variant genomes as references, 60 000 reads -- 90 % drawn from the synthetic genome,
+    10 % HPV16 reads and reads that match nothing -- through bin/rkmh filter; stdout byte-identical to the oracle's restatement of
+    classify_and_count_diff_filter (equiv.hpp:324-353) over the rows of the stream loop, 10 M-slot counters as rkmh.cpp:1187-1188."""
+    from rkmh_amd import synth
+    exe = os.path.join(root, "bin", "rkmh")
+    rng = np.random.default_rng(44)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    chrom, nchrom, n = 1500000, 24, 60000
+    refs = [(b"chr%d" % (c + 1), acgt[rng.integers(0, 4, size=chrom, dtype=np.uint8)].tobytes()) for c in range(nchrom)]
+    hpv = [(r[0], r[1]) for r in orc.kseq_parse_file(os.path.join(data_dir, "hpv_16_allFasta.fa.gz"))]
+    refs += hpv
+    ref_fa = tmp_path / "genome.fa"
+    with open(ref_fa, "wb") as f:
+        for name, seq in refs:
+            f.write(b">" + name + b"\n")
+            for i in range(0, len(seq), 60000):     # multi-line FASTA records
+                f.write(seq[i:i + 60000] + b"\n")
+    gb, go = orc.pack([r[1] for r in refs[:nchrom]])
+    hb, ho = orc.pack([orc.to_upper(r[1]) for r in hpv])
+    nh = n // 10
+    q1, _ = synth.generate_reads_fast(_pad(gb), go, 0, n - nh)
+    q2, _ = synth.generate_reads_fast(_pad(hb), ho, 0, nh)
+    seqs = [bytes(q1[i * 150:(i + 1) * 150]) for i in range(n - nh)] + [bytes(q2[i * 150:(i + 1) * 150]) for i in range(nh)]
+    for i in range(0, n, 13):
+        seqs[i] = rand_dna(rng, 150)              # reads that match nothing
+    seqs[7] = seqs[7].lower()
+    order = rng.permutation(n)
+    seqs = [seqs[i] for i in order]
+    names = [b"m%07d" % i for i in range(n)]
+    q = b"I" * 150
+    fq = tmp_path / "mixed.fq"
+    fq.write_bytes(b"".join(b"@" + names[i] + b"\n" + seqs[i] + b"\n+\n" + q + b"\n" for i in range(n)))
+    # the oracle: reference sketches once, then the stream rows with and without the depth mask
+    rb, ro = orc.pack([orc.to_upper(x[1]) for x in refs])
+    qb, qo = orc.pack(seqs)
+    sk, ln = orc.sketch_refs(rb, ro, [20], 2000, threads=orc.max_threads())
+    assert int(ln.min()) == 2000
+    for flags, kw, mm in (([], {}, -1), (["-M", "2", "-N", "5"], dict(min_kmer_occ=2, counter_slots=10000000), 5)):
+        rows = orc.classify_stream(qb, qo, [20], 2000, sk, ln, threads=orc.max_threads(), **kw)
+        parts = [orc.filter_record(names[i], orc.to_upper(seqs[i]), q) for i in range(n) if orc.filter_decision(rows[i], mm, 0)[3]]
+        assert n // 20 < len(parts) < n, (flags, len(parts))
+        r = subprocess.run([exe, "filter", "-r", str(ref_fa), "-f", str(fq), "-k", "20", "-s", "2000"] + flags, capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == b"".join(parts), (flags, len(r.stdout), sum(map(len, parts)))
+
+
+def test_c3_sized_resident_shard(ctx, orc, data_dir):
+    """BASELINE config 3, one GPU's share: 12.5 M synthetic 150 bp reads (a 1.9 GB resident shard) against every bundled
+    reference (~270 viral genomes, k = 16, s = 1000) in ONE rk_classify_batch_device call; 60 000 rows sampled across the whole
+    shard equal the oracle, no row is handed back, and the launch is repeatable."""
+    import torch
+    from rkmh_amd import synth
+    seqs = []
+    for f in ("all_pave_ref.fa.gz", "zika.refs.fa.gz", "dengue.fa.gz", "new_refs.fa.gz", "hpv_16.fa.gz",
+              "zika.fa.gz", "yellow_fever.fa.gz", "hpv_16_allFasta.fa.gz"):
+        seqs += [r[1] for r in orc.kseq_parse_file(os.path.join(data_dir, f))]
+    rb, ro = orc.pack(seqs)
+    rb = _pad(rb)
+    n = 12500000
+    qb, qo = synth.generate_reads_fast(rb, ro, 0, n, threads=min(16, os.cpu_count() or 1))
+    ctx.set_references(rb, ro, [16], 1000)
+    assert ctx.kmer_form()[0]
+    sk, ln = ctx.get_reference_sketches()
+    d_b = torch.from_numpy(qb).cuda()
+    d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).cuda()
+    d_out = torch.empty((n, 4), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.classify_device(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=150, stream=st)
+    torch.cuda.synchronize()
+    first = d_out.cpu().numpy()
+    assert not (first[:, 0] == -2).any()
+    d_out.zero_()
+    ctx.classify_device(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=150, stream=st)
+    torch.cuda.synchronize()
+    assert (d_out.cpu().numpy() == first).all()
+    rng = np.random.default_rng(12)
+    blocks = np.sort(rng.choice(n // 1000, size=60, replace=False))          # sixty runs of 1000 consecutive reads
+    for b in blocks:
+        lo = int(b) * 1000
+        sub_o = qo[lo:lo + 1001] - qo[lo]
+        want = orc.classify_stream(qb[int(qo[lo]):int(qo[lo + 1000]) + 8], sub_o, [16], 1000, sk, ln, threads=orc.max_threads())
+        assert (first[lo:lo + 1000] == want).all(), lo

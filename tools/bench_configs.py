@@ -28,6 +28,7 @@ def run(tag, refs_b, refs_o, ks, S, n, L, depth=None, steps=50):
     if depth is not None:
         cnt = api.Counter(ctx, 200000000)
         ctx.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt, stream=st.cuda_stream)
+        st.synchronize()   # pass 1 must be complete before the keep bitmap is derived (rk_set_depth_filter also drains the device itself)
         ctx.set_depth_filter(cnt, depth)
 
     def step():
