@@ -57,7 +57,7 @@ def test_shipped_kernel_isa_is_clean():
     for name, body in lint.kernels(open(s).read().split("\n")):
         n += 1
         assert lint.analyse(name, body) == [], name
-    assert n >= 160
+    assert n >= 120   # MIN_TILE_KERNELS of the Makefile: k = 12, 16 (x 3 folds), 20, 21, 31, run-time k; x 5 modes x 3 prefetch depths
 
 
 def test_gate_fails_closed_on_input_it_cannot_read():
