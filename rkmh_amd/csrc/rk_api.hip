@@ -971,10 +971,10 @@ static int build_index(rk_ctx* c) {
                         f4[(size_t)kf4_sector((X >> (2 * (3 - j))) & cm, lg) * 4 + j] |= bits;
                 }
             }
-            // exact map (KM1_C in rk_device.hpp).  A displaced key may only move to the next bucket; if that one is full too, or the
-            // value ids do not fit the cell, the table doubles (shorter remainders leave more bits for the id).
+            // exact map (KM1_C in rk_device.hpp).  A key whose bucket is full moves on by up to 2^KM1_HB - 1 buckets; if that is not
+            // enough, or the value ids do not fit the cell, the table doubles (shorter remainders leave more bits for the id).
             {
-                static const double km1_load = getenv("RKMH_KM1_LOAD") ? atof(getenv("RKMH_KM1_LOAD")) : 0.35;
+                static const double km1_load = getenv("RKMH_KM1_LOAD") ? atof(getenv("RKMH_KM1_LOAD")) : 0.65;
                 std::vector<uint32_t> vals;
                 std::unordered_map<uint32_t, uint32_t> val_id;
                 std::vector<uint32_t> vid(found);
@@ -989,7 +989,7 @@ static int build_index(rk_ctx* c) {
                     vid[i] = it->second;
                 }
                 const uint32_t kbits = 2u * (uint32_t)k;
-                uint32_t b = kbits < 17u ? kbits : 17u;
+                uint32_t b = kbits < 12u ? kbits : 12u;
                 while (b < kbits && b < 28 && (double)found > km1_load * 4.0 * (double)((size_t)1 << b)) ++b;
                 std::vector<uint32_t> c1;
                 bool built = false;
@@ -1004,11 +1004,11 @@ static int build_index(rk_ctx* c) {
                         uint32_t bk = r ? y >> r : y;
                         const uint32_t rem = y & rmask, id = vid[i] == VID_ZERO ? vmask - 1u : vid[i];
                         bool placed = false;
-                        for (int hop = 0; hop < 2 && !placed; ++hop) {
+                        for (uint32_t hop = 0; hop < (1u << KM1_HB) && !placed; ++hop) {
                             uint32_t* e = &c1[(size_t)bk * 4];
                             for (int q = 0; q < 4 && !placed; ++q)
                                 if ((e[q] & vmask) == vmask) { // empty (no key carries the all-ones id)
-                                    e[q] = ((rem | (hop ? 1u << r : 0u)) << (vb + 1)) | id;
+                                    e[q] = ((rem | (hop << r)) << (vb + 1)) | id;
                                     placed = true;
                                 }
                             if (!placed) { e[3] |= 1u << vb; bk = (bk + 1) & (nbk - 1); } // full: later lookups that miss here try the next bucket

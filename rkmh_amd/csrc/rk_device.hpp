@@ -424,14 +424,17 @@ struct RefIndex {
 };
 // The exact map the k-mer-space kernel (rk_kmer.hip) resolves its candidates in: every k-mer the enumeration found, one 16-byte
 // bucket of four 4-byte cells per lookup.  y = (key * odd constant) mod 4^k is a bijection on the 2k-bit k-mers, so (bucket = top
-// km1_b bits of y, remainder = the other r = 2k - km1_b bits) IS the key.  A cell, from the top: the tag (r + 1 bits: the
-// remainder, above it 1 = this key belongs to the PREVIOUS bucket, which was full), one flag bit (in the bucket's last cell: a key
-// of this bucket was displaced into the next one) and the value id (vb = 30 - r bits).  Value ids below the number of references
-// are a single posting of multiplicity 1 (the id is the reference); km1_vid_zero marks a k-mer whose canonical hash is 0; other
-// ids index km1_vals (offset by the number of references), which holds index values in the RefIndex::kv format; all ones = empty.
+// km1_b bits of y, remainder = the other r = 2k - km1_b bits) IS the key.  A cell, from the top: the tag (KM1_HB + r bits: how many
+// buckets past its own the key was stored -- its own was full -- then the remainder), one flag bit (in the bucket's last cell: a
+// key that wanted this bucket, or passed through it, lies further on) and the value id (vb = 31 - KM1_HB - r bits).  Value ids
+// below the number of references are a single posting of multiplicity 1 (the id is the reference); all ones - 1 marks a k-mer
+// whose canonical hash is 0; other ids index km1_vals (offset by the number of references), which holds index values in the
+// RefIndex::kv format; all ones = empty.  At the load the table is built for (~0.6: 1 MB for the 161 k k-mers of the 182-genome
+// panel, so that it shares an XCD's 4 MB L2 with the 2 MB filter) nine lookups in ten end in the first bucket.
 constexpr uint32_t KM1_C = 0x9E3779B1u;
+constexpr uint32_t KM1_HB = 3;                       // hop bits: a key lies at most 7 buckets past its own
 __host__ __device__ __forceinline__ uint32_t km1_y(uint32_t key, int k) { return k >= 16 ? key * KM1_C : (key * KM1_C) & ((1u << (2 * k)) - 1u); }
-__host__ __device__ __forceinline__ uint32_t km1_vbits(int k, uint32_t b) { return 30u - ((uint32_t)(2 * k) - b); }
+__host__ __device__ __forceinline__ uint32_t km1_vbits(int k, uint32_t b) { return 31u - KM1_HB - ((uint32_t)(2 * k) - b); }
 // filter word and bit pair of a hash: the word from the low bits of the high hash word (like the bucket), the two bits
 // from bits 14..23 of the low word (bits 0..13 are the fingerprint)
 __host__ __device__ __forceinline__ uint32_t index_pre_word(uint64_t h, uint32_t pmask) { return (uint32_t)(h >> 32) & pmask; }

@@ -35,6 +35,9 @@ constexpr int KM_MQ = 32;            // deferred multi-posting hits per drain (m
 #ifndef RK_KMER_ABL
 #define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values
 #endif
+#ifndef RK_KMER_NT
+#define RK_KMER_NT 1 // the bases are read once: streaming loads keep them from evicting the filter and the map from L2
+#endif
 #ifndef RK_KMER_DR
 #define RK_KMER_DR 2 // drain rounds whose map lookups are in flight together
 #endif
@@ -46,7 +49,7 @@ constexpr int KM_QCAP = 64 + 4 * KW; // candidate queue entries (4 bytes each): 
 constexpr int KM_LDS_SMALL = 5120;   // static LDS of the common instantiation: 32 single-wave workgroups per CU (8 per SIMD)
 constexpr int KM_LDS_BIG = 20480;    // ... of the one for large hit multisets / counter rows (8 per CU)
 #ifndef RK_KMER_WAVES
-#define RK_KMER_WAVES 7
+#define RK_KMER_WAVES 8
 #endif
 
 // per-read reference counters: packed 8-bit (no read has more than 255 windows), packed 16-bit, or a 128-entry map ref -> count
@@ -56,7 +59,7 @@ struct KmerGeom {
     int32_t T;         // reads per tile
     int32_t cwords;    // counter words per read
     int32_t dset;      // slots of the per-read hit multiset (power of two)
-    int32_t tpb, xcd;
+    int32_t xcd;
     int32_t L;         // hinted read length ...
     int32_t gpr;       // ... its groups per read = ceil(windows / 4) ...
     uint32_t magic;    // ... and ceil(2^32 / gpr): the group -> read division of tiles made of such reads
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
     const uint32_t ds_shift = 32u - (uint32_t)__builtin_ctz(DS);
     const int lane = threadIdx.x;
 
-    for (uint32_t i = lane; i < ((uint32_t)T * CW) >> 2; i += KW) reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0u, 0u, 0u, 0u); // re-zeroed by phase 2 after use
+    for (uint32_t i = lane; i < ((uint32_t)T * CW) >> 2; i += KW) reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0u, 0u, 0u, 0u);
     const uint32_t ntiles = (nreads + (uint32_t)T - 1) / (uint32_t)T;
     const uintptr_t gb = reinterpret_cast<uintptr_t>(bases);
     // readable byte range of the batch: [bases, bases + offs[nreads] + 4) (the ABI asks for 4 bytes of slack), whole dwords
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             u32x4 v = {0u, 0u, 0u, 0u};
             if (qi < nq) {
                 const uintptr_t qa = base16 + 16u * (uintptr_t)qi;
-                if (safe) v = *reinterpret_cast<const u32x4*>(qa);
+                if (safe) v = RK_KMER_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(qa)) : *reinterpret_cast<const u32x4*>(qa);
                 else {
                     uint32_t d[4];
 #pragma unroll
@@ -205,23 +208,20 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         }
     };
 
-    uint32_t vb = blockIdx.x;
-    if (geo.xcd) { const uint32_t per = (gridDim.x + 7u) >> 3; vb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3); }
-    const uint32_t tile0 = vb * (uint32_t)geo.tpb;
-    const uint32_t tile_end = (tile0 + (uint32_t)geo.tpb) < ntiles ? (tile0 + (uint32_t)geo.tpb) : ntiles;
+    // One tile per workgroup (measured with batches streaming from HBM: 1 tile 0.381 ms, 2 tiles with the second one's bases
+    // prefetched 0.383, 4 tiles 0.392, 8 tiles 0.402 -- short-lived waves let the dispatcher balance the CUs, and the other waves of
+    // the SIMD hide a fresh wave's two cold loads).  XCD-aware ownership: the dispatcher deals workgroups round-robin over the 8
+    // XCDs, so workgroup b takes tile (b % 8) * ceil(grid / 8) + b / 8 and each XCD's L2 sees one contiguous eighth of the batch.
+    uint32_t tile = blockIdx.x;
+    if (geo.xcd) { const uint32_t per = (gridDim.x + 7u) >> 3; tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3); }
+    if (tile >= ntiles) return;
     uint32_t cur_a = 0, cur_b = 0, cur_o = 0;
-#pragma unroll
-    for (int r = 0; r < NQ; ++r) pf[r] = u32x4{0u, 0u, 0u, 0u};
-    if (tile0 < ntiles) { load_offsets(tile0, cur_a, cur_b, cur_o); fetch_tile(cur_a, cur_b); }
-
-    for (uint32_t tile = tile0; tile < tile_end; ++tile) {
+    load_offsets(tile, cur_a, cur_b, cur_o);
+    fetch_tile(cur_a, cur_b);
+    {
         const uint32_t r0 = tile * (uint32_t)T;
         const uint32_t ta = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur_a);
         const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur_b);
-        const uint32_t ntile = tile + 1u < tile_end ? tile + 1u : ntiles;
-        uint32_t nxt_a = 0, nxt_b = 0, nxt_o = 0;
-        if (ntile < ntiles) load_offsets(ntile, nxt_a, nxt_b, nxt_o);
-        wave_sync(); // previous tile fully consumed
         const uint32_t mis = (uint32_t)((gb + ta) & 15u);       // position of the tile's first base inside quad 0
         const uint32_t nbytes = mis + (tb - ta);
         const uint32_t o_next = (uint32_t)__shfl_down((int)cur_o, 1);
@@ -280,7 +280,6 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             }
             if (lane < 2) inv[NQ * 32 + lane] = 0;
         }
-        cur_a = nxt_a; cur_b = nxt_b; cur_o = nxt_o;
         wave_sync();
 
         // group -> read mapping: tiles of equally long reads divide by a magic constant, the others search the group starts
@@ -331,7 +330,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         };
         // one candidate of the queue: canonical k-mer, its read, its bucket of the exact map (load in flight on return)
         struct Cand { uint32_t key, t, y; uint4 c; };
-        const uint32_t km_r = 2u * KT - ix.km1_b, km_vb1 = 31u - km_r;      // remainder bits; value id bits + the flag bit
+        const uint32_t km_r = 2u * KT - ix.km1_b, km_vb1 = 32u - KM1_HB - km_r;      // remainder bits; value id bits + the flag bit
         const uint32_t km_vmask = (1u << (km_vb1 - 1u)) - 1u, km_rmask = (1u << km_r) - 1u, nref = (uint32_t)ix.nref;
         auto lookup = [&](uint32_t e, uint32_t qn) -> Cand {
             Cand c;
@@ -355,10 +354,17 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         auto apply = [&](const Cand& c) {
             const uint32_t wantsh = (c.y & km_rmask) << km_vb1;   // the remainder (low km_r bits of y) in the tag position, "not displaced"
             uint32_t cell = match_cell(c.c, wantsh);
-            // a miss in a bucket that displaced a key into the next one: that bucket may hold this key (tagged as displaced)
-            const bool again = (cell & km_vmask) == km_vmask && ((c.c.w >> (km_vb1 - 1u)) & 1u) != 0u && c.t != 0xFFFFFFFFu;
-            if (!(RK_KMER_ABL & 16) && __ballot(again)) {
-                if (again) cell = match_cell(ix.km1[((c.y >> km_r) + 1u) & ((1u << ix.km1_b) - 1u)], wantsh | 0x80000000u);
+            // a miss in a bucket that sent a key further on: that key may be this one, stored up to 7 buckets past its own and tagged
+            // with the distance (about one lookup in ten takes this path once; the wave leaves when its last lane is done)
+            bool again = (cell & km_vmask) == km_vmask && ((c.c.w >> (km_vb1 - 1u)) & 1u) != 0u && c.t != 0xFFFFFFFFu;
+            if (!(RK_KMER_ABL & 16)) {
+                for (uint32_t hop = 1; hop < (1u << KM1_HB) && __ballot(again); ++hop) {
+                    if (again) {
+                        const uint4 nb = ix.km1[((c.y >> km_r) + hop) & ((1u << ix.km1_b) - 1u)];
+                        cell = match_cell(nb, wantsh | (hop << (32u - KM1_HB)));
+                        again = (cell & km_vmask) == km_vmask && ((nb.w >> (km_vb1 - 1u)) & 1u) != 0u;
+                    }
+                }
             }
             const uint32_t vid = cell & km_vmask;
             uint32_t val = vid | (1u << 20); // a single posting of multiplicity 1, in the RefIndex::kv value format
@@ -505,8 +511,6 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             }
             step += done;
             const bool last = step >= nsteps;
-            // the next tile's bases are requested once this tile's filter traffic is over: they land during the drain and phase 2
-            if (last && ntile < ntiles) fetch_tile(cur_a, cur_b);
             wave_sync();
             const uint32_t qn = last ? qcount : (qcount & ~(uint32_t)(KW - 1)); // mid-tile: whole waves of candidates only
             if (!(RK_KMER_ABL & 4)) drain(qn);
@@ -532,7 +536,6 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                 const bool reroute = nmins > S || flags[t] != 0;
                 const uint32_t bk = best[t];
                 if (reroute) {
-                    for (uint32_t w = sl; w < CW >> 2; w += LPR) reinterpret_cast<uint4*>(ct)[w] = make_uint4(0u, 0u, 0u, 0u);
                     if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(-2, 0, 0, 0);
                     continue;
                 }
@@ -568,8 +571,6 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                     prev = (int)acc > prev ? (int)acc : prev;
                 }
                 prev = LPR == 16 ? row_max_i32(prev) : half_row_max_i32(prev);
-                wave_sync();
-                for (uint32_t w = sl; w < CW >> 2; w += LPR) reinterpret_cast<uint4*>(ct)[w] = make_uint4(0u, 0u, 0u, 0u); // rows are whole 16-byte units
                 if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(max_id, max_shared, max_shared - prev, nmins);
             }
         }
@@ -603,7 +604,7 @@ bool make_kmer_geom(KmerGeom& g, int maxlen, int nref, int expect_hits, int nw_p
         while (g.T > 1 && km_lds_bytes(g, nq) > (size_t)KM_LDS_BIG) g.T -= 1;
         if (km_lds_bytes(g, nq) > (size_t)KM_LDS_BIG) return false;
     }
-    g.tpb = 2; g.xcd = 1;
+    g.xcd = 1;
     g.L = maxlen;
     g.gpr = (nw_per_read + 3) >> 2;
     g.magic = g.gpr >= 2 ? 0xFFFFFFFFu / (uint32_t)g.gpr + 1u : 0u;
@@ -645,12 +646,10 @@ hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint
     int cmode = 0;
     bool big = false;
     if (!make_kmer_geom(geo, maxlen, ix.nref, expect_hits, nw, nq, cmode, big)) return hipErrorInvalidConfiguration;
-    static const int tpb_env = getenv("RKMH_TILE_TPB") ? atoi(getenv("RKMH_TILE_TPB")) : 0;
     static const int xcd_env = getenv("RKMH_TILE_XCD") ? atoi(getenv("RKMH_TILE_XCD")) : -1;
-    if (tpb_env > 0) geo.tpb = tpb_env;
     if (xcd_env >= 0) geo.xcd = xcd_env != 0;
     const uint32_t ntiles = (nreads + (uint32_t)geo.T - 1) / (uint32_t)geo.T;
-    uint32_t grid = (ntiles + (uint32_t)geo.tpb - 1) / (uint32_t)geo.tpb;
+    uint32_t grid = ntiles;
     grid = (grid + 7u) & ~7u; // whole rounds of the 8 XCDs: the virtual ids then cover [0, grid) exactly
 #define RK_KM_K(KT) case KT: return launch_k<KT>(nq, cmode, big, dim3(grid), st, bases, offs, nreads, S, ix, out4, pol, geo)
     switch (k) {

@@ -17,14 +17,14 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 vals = {}
 kernel = None
 for line in open(src):
-    m = re.match(r"^\s+(.*k_classify_tile.*?)\s{2,}(\w+)\s+n=(\d+)\s+mean=(\S+)", line)
+    m = re.match(r"^\s+(.*k_classify_(?:kmer|tile).*?)\s{2,}(\w+)\s+n=(\d+)\s+mean=(\S+)", line)
     if m:
         kernel = kernel or m.group(1)
         vals[m.group(2)] = float(m.group(4))
 need = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")
 missing = [k for k in need if k not in vals]
 if missing:
-    sys.exit("make_pmc_json: %s has no %s for k_classify_tile" % (src, ", ".join(missing)))
+    sys.exit("make_pmc_json: %s has no %s for the classify kernel" % (src, ", ".join(missing)))
 out = {
     "source": "%s (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_* in separate passes, bench.py --steps 20)" % os.path.relpath(src, ROOT),
     "kernel": kernel,
