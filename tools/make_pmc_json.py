@@ -17,7 +17,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 vals = {}
 kernel = None
 for line in open(src):
-    m = re.match(r"^\s+(.*k_classify_(?:kmer|tile).*?)\s{2,}(\w+)\s+n=(\d+)\s+mean=(\S+)", line)
+    m = re.match(r"^\s+(.*k_classify_(?:kmer|tile).*)\s(\w+)\s+n=(\d+)\s+mean=(\S+)", line)
     if m:
         kernel = kernel or m.group(1)
         vals[m.group(2)] = float(m.group(4))
