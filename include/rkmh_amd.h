@@ -71,6 +71,11 @@ int rk_ctx_synchronize(rk_ctx* ctx);
 /* The context's own non-blocking hipStream_t (what the host-buffer entry points enqueue on). */
 void* rk_ctx_stream(rk_ctx* ctx);
 void rk_free(void* p);
+/* Page-locked host memory (hipHostMalloc).  rk_classify_batch / rk_count_batch read page-locked `bases` by DMA where they lie and
+ * write page-locked `out4` in place -- no staging copy on either side (the reference has no analogue: its reads never leave the
+ * host, src/rkmh.cpp:845-898); pageable buffers keep working through the library's own pinned staging buffers. */
+int rk_host_alloc(size_t bytes, void** out);
+void rk_host_free(void* p);
 
 /* ------------------------------------------------------------------------------------------------
  * INNER boundary: one-sequence mirrors of the mkmh calls (replaces, file:line of the call site):

@@ -52,6 +52,8 @@ _SIGS = {
     "rk_ctx_synchronize": (C.c_int, [C.c_void_p]),
     "rk_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "rk_free": (None, [C.c_void_p]),
+    "rk_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rk_host_free": (None, [C.c_void_p]),
     "rk_to_upper": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "rk_calc_hashes": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _ip, C.c_int, C.POINTER(_u64p), _ip]),
     "rk_calc_hashes_counted": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _ip, C.c_int, C.POINTER(_u64p), _ip, C.c_void_p]),
@@ -179,6 +181,32 @@ def _seqset_to_py(ss):
         q = C.string_at(ss.quals, nb)
         quals = [q[int(offs[i]): int(offs[i + 1])] for i in range(n)]
     return {"bases": bases, "offsets": offs, "names": names, "quals": quals, "nseq": n}
+
+
+class PinnedArray:
+    """A numpy view of page-locked host memory from rk_host_alloc (freed when the object dies): the host entry points read and
+    write such buffers by DMA where they lie."""
+
+    def __init__(self, shape, dtype):
+        lib = load_library()
+        self._lib = lib
+        self._ptr = C.c_void_p()
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        _chk(lib.rk_host_alloc(max(nbytes, 1), C.byref(self._ptr)))
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(self._ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                self._lib.rk_host_free(self._ptr)
+                self._ptr = None
+        except Exception:
+            pass
+
+
+def pinned_array(shape, dtype):
+    return PinnedArray(shape, dtype)
 
 
 def parse_files(paths):
@@ -455,11 +483,13 @@ class Context:
         _chk(self._lib.rk_depth_map_tag(self._h, kk, len(ks), _p(bases, C.c_uint8), _p(offsets, C.c_uint64), len(offsets) - 1, tag))
         return bytes(tag)
 
-    def classify(self, bases, offsets) -> np.ndarray:
-        """main_stream's per-read loop for a host batch -> int32 [n,4] (max_id, max_shared, diff, min_num)."""
+    def classify(self, bases, offsets, out=None) -> np.ndarray:
+        """main_stream's per-read loop for a host batch -> int32 [n,4] (max_id, max_shared, diff, min_num).
+        Page-locked arrays (pinned_array) are read / written by DMA in place; anything else goes through staging buffers."""
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
-        out = np.zeros((n, 4), dtype=np.int32)
+        if out is None:
+            out = np.zeros((n, 4), dtype=np.int32)
         _chk(self._lib.rk_classify_batch(self._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), n, _p(out, C.c_int32)))
         return out
 

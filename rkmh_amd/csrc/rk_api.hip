@@ -6,6 +6,7 @@
 #include "rk_kernels.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -46,7 +47,8 @@ extern "C" int rk_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
-extern "C" void rk_free(void* p) { free(p); }
+extern "C" void rk__pool_forget(void* p); // rk_parse.cpp: big parser buffers are tracked for recycling
+extern "C" void rk_free(void* p) { rk__pool_forget(p); free(p); }
 
 // growable device buffer
 struct DevBuf {
@@ -223,23 +225,42 @@ static uint32_t next_pow2(uint32_t x) { uint32_t p = 64; while (p < x) p <<= 1; 
 
 // d_bases: device pointer to the batch's bases when already resident (else nullptr => upload from `bases`)
 // memcpy into a pinned staging buffer with a few threads: one core copies ~14 GB/s, the link takes several times that
-static void par_memcpy(void* dst, const void* src, size_t n) {
+static int host_threads() { // workers for the host-side copies and per-read loops (RKMH_COPY_THREADS; default: up to 8 of the CPUs granted)
     static const int nt = []() {
         const char* e = getenv("RKMH_COPY_THREADS");
-        int v = e ? atoi(e) : 4;
-        return v < 1 ? 1 : (v > 16 ? 16 : v);
+        int v = e ? atoi(e) : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+        return v < 1 ? 1 : (v > 32 ? 32 : v);
     }();
-    if (n < (8u << 20) || nt == 1) { memcpy(dst, src, n); return; }
+    return nt;
+}
+// f(begin, end) over [0, n) in contiguous pieces on host_threads() threads (the caller's thread takes the first piece)
+template <typename F>
+static void par_for(size_t n, size_t min_piece, F f) {
+    const int nt = host_threads();
+    if (n < 2 * min_piece || nt == 1) { f((size_t)0, n); return; }
+    size_t pieces = std::min<size_t>((size_t)nt, n / min_piece);
+    const size_t per = (n + pieces - 1) / pieces;
     std::vector<std::thread> th;
-    const size_t per = ((n / (size_t)nt) + 4095) & ~(size_t)4095;
-    for (int i = 1; i < nt; ++i) {
-        const size_t off = per * (size_t)i;
-        if (off >= n) break;
-        const size_t len = n - off < per ? n - off : per;
-        th.emplace_back([=] { memcpy((char*)dst + off, (const char*)src + off, len); });
+    for (size_t i = 1; i < pieces; ++i) {
+        const size_t lo = per * i, hi = std::min(n, lo + per);
+        if (lo >= hi) break;
+        th.emplace_back([=] { f(lo, hi); });
     }
-    memcpy(dst, src, per < n ? per : n);
+    f((size_t)0, std::min(n, per));
     for (auto& t : th) t.join();
+}
+static void par_memcpy(void* dst, const void* src, size_t n) {
+    par_for(n, (size_t)4 << 20, [=](size_t lo, size_t hi) { memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
+}
+// is [p, p + bytes) page-locked host memory the DMA engines can read directly (rk_host_alloc, hipHostMalloc, hipHostRegister)?
+static bool is_pinned_host(const void* p, size_t bytes) {
+    if (!p || bytes == 0) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a.type != hipMemoryTypeHost) return false;
+    hipPointerAttribute_t b;
+    if (hipPointerGetAttributes(&b, (const char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return b.type == hipMemoryTypeHost;
 }
 
 // Host -> device copy of a pageable buffer through the context's two pinned staging buffers (the same ones the fused
@@ -1262,43 +1283,74 @@ extern "C" int rk_count_batch_device(rk_ctx* c, const void* d_bases, const void*
 }
 
 // double-buffered host pipeline around the fused kernel. mode 0 classify, mode 1 count.
+// Page-locked inputs (rk_host_alloc / hipHostMalloc: what the FASTQ front end fills) are read by the DMA engine where they lie;
+// pageable ones go through the context's pinned staging buffers, copied by host_threads() threads while the previous chunk is on
+// the link.  Results land directly in out4 when that is page-locked.  *flagged receives the number of rows the kernel handed back.
 static int host_pipeline(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, int32_t* out4,
-                         int mode, rk_counter* count_into) {
+                         int mode, rk_counter* count_into, int64_t* flagged = nullptr) {
     RKCHK(set_dev(c));
     const int64_t MAX_READS = 1 << 21;
     const uint64_t MAX_BASES = 1ull << 29;
-    int64_t i0 = 0;
+    const bool src_pinned = nreads > 0 && is_pinned_host(bases + offsets[0], (size_t)(offsets[nreads] - offsets[0]) + 4);
+    const bool out_pinned = mode == 0 && nreads > 0 && is_pinned_host(out4, (size_t)nreads * 16);
+    int64_t i0 = 0, nflag = 0;
     int which = 0;
     auto drain = [&](Slot& s) -> int {
         if (!s.busy) return RK_OK;
         HIPCHK(hipEventSynchronize(s.done));
-        if (mode == 0) memcpy(out4 + s.first * 4, s.h_out.p, (size_t)s.n * 16);
+        if (mode == 0) {
+            int32_t* dst = out4 + s.first * 4;
+            const int32_t* src = out_pinned ? dst : s.h_out.as<int32_t>();
+            std::vector<int64_t> part((size_t)host_threads() + 1, 0);
+            std::atomic<int> slot_no{0};
+            par_for((size_t)s.n, (size_t)1 << 17, [&](size_t lo, size_t hi) { // copy out (unless the DMA wrote in place) and count the rows handed back
+                if (!out_pinned) memcpy(dst + lo * 4, src + lo * 4, (hi - lo) * 16);
+                int64_t k = 0;
+                for (size_t i = lo; i < hi; ++i) k += src[i * 4] == -2;
+                part[(size_t)slot_no.fetch_add(1) % part.size()] += k;
+            });
+            for (int64_t k : part) nflag += k;
+        }
         s.busy = false;
         return RK_OK;
     };
     while (i0 < nreads) {
-        int64_t i1 = i0;
-        uint64_t cb = 0;
-        uint32_t maxlen = 0;
-        while (i1 < nreads && i1 - i0 < MAX_READS) {
-            uint64_t len = offsets[i1 + 1] - offsets[i1];
-            if (i1 > i0 && cb + len > MAX_BASES) break;
-            if (len > 0xffffffffull - cb) return fail(RK_ERR_LIMIT, "read %lld too long for a 32-bit batch", (long long)i1);
-            cb += len; if (len > maxlen) maxlen = (uint32_t)len; ++i1;
+        // a chunk: at most MAX_READS reads / MAX_BASES bases (offsets are monotone: the end is found by bisection, the longest read
+        // by a parallel scan)
+        int64_t i1 = std::min(nreads, i0 + MAX_READS);
+        const uint64_t b0 = offsets[i0];
+        if (offsets[i1] - b0 > MAX_BASES) {
+            int64_t lo = i0 + 1, hi = i1;
+            while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (offsets[mid] - b0 <= MAX_BASES) lo = mid; else hi = mid - 1; }
+            i1 = lo;
         }
         const int64_t cn = i1 - i0;
+        const uint64_t cb = offsets[i1] - b0;
+        if (cb > 0xfffffff0ull) return fail(RK_ERR_LIMIT, "read %lld too long for a 32-bit batch", (long long)i0);
         Slot& s = c->slot[which];
         RKCHK(drain(s));
-        RKCHK(s.h_bases.reserve(cb + 64)); RKCHK(s.h_offs.reserve((size_t)(cn + 1) * 4)); RKCHK(s.h_out.reserve((size_t)cn * 16));
+        RKCHK(s.h_offs.reserve((size_t)(cn + 1) * 4));
+        if (!src_pinned) RKCHK(s.h_bases.reserve(cb + 64));
+        if (!out_pinned && mode == 0) RKCHK(s.h_out.reserve((size_t)cn * 16));
         RKCHK(s.d_bases.reserve(cb + 64)); RKCHK(s.d_offs.reserve((size_t)(cn + 1) * 4)); RKCHK(s.d_out.reserve((size_t)cn * 16));
-        const uint64_t b0 = offsets[i0];
-        par_memcpy(s.h_bases.p, bases + b0, cb);
         uint32_t* ho = s.h_offs.as<uint32_t>();
-        for (int64_t i = 0; i <= cn; ++i) ho[i] = (uint32_t)(offsets[i0 + i] - b0);
-        HIPCHK(hipMemcpyAsync(s.d_bases.p, s.h_bases.p, cb, hipMemcpyHostToDevice, s.st));
+        std::atomic<uint32_t> maxlen_a{0};
+        par_for((size_t)cn + 1, (size_t)1 << 17, [&](size_t lo, size_t hi) { // 32-bit offsets relative to the chunk + the longest read
+            uint32_t ml = 0;
+            for (size_t i = lo; i < hi; ++i) {
+                ho[i] = (uint32_t)(offsets[(size_t)i0 + i] - b0);
+                if (i < (size_t)cn) { const uint64_t len = offsets[(size_t)i0 + i + 1] - offsets[(size_t)i0 + i]; if (len > ml) ml = (uint32_t)std::min<uint64_t>(len, 0xffffffffull); }
+            }
+            uint32_t cur = maxlen_a.load();
+            while (ml > cur && !maxlen_a.compare_exchange_weak(cur, ml)) {}
+        });
+        const uint32_t maxlen = maxlen_a.load();
+        const void* hsrc = bases + b0;
+        if (!src_pinned) { par_memcpy(s.h_bases.p, bases + b0, cb); hsrc = s.h_bases.p; }
+        HIPCHK(hipMemcpyAsync(s.d_bases.p, hsrc, cb, hipMemcpyHostToDevice, s.st));
         HIPCHK(hipMemcpyAsync(s.d_offs.p, s.h_offs.p, (size_t)(cn + 1) * 4, hipMemcpyHostToDevice, s.st));
         RKCHK(fused_device(c, s.d_bases.p, s.d_offs.p, cn, s.d_out.p, maxlen, mode, count_into, s.st));
-        if (mode == 0) HIPCHK(hipMemcpyAsync(s.h_out.p, s.d_out.p, (size_t)cn * 16, hipMemcpyDeviceToHost, s.st));
+        if (mode == 0) HIPCHK(hipMemcpyAsync(out_pinned ? (void*)(out4 + i0 * 4) : s.h_out.p, s.d_out.p, (size_t)cn * 16, hipMemcpyDeviceToHost, s.st));
         HIPCHK(hipEventRecord(s.done, s.st));
         s.first = i0; s.n = cn; s.busy = true;
         which ^= 1;
@@ -1306,8 +1358,19 @@ static int host_pipeline(rk_ctx* c, const uint8_t* bases, const uint64_t* offset
     }
     RKCHK(drain(c->slot[0]));
     RKCHK(drain(c->slot[1]));
+    if (flagged) *flagged = nflag;
     return RK_OK;
 }
+
+// page-locked host memory for callers that want rk_classify_batch / rk_count_batch to run at link speed (no staging copy)
+extern "C" int rk_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(RK_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; return fail(RK_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    return RK_OK;
+}
+extern "C" void rk_host_free(void* p) { if (p) { hipError_t e = hipHostFree(p); (void)e; } }
 
 extern "C" int rk_classify_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, int32_t* out4) {
     if (!c || !offsets || nreads < 0 || (nreads > 0 && !out4)) return fail(RK_ERR_ARG, "bad arguments");
@@ -1323,8 +1386,13 @@ extern "C" int rk_classify_batch(rk_ctx* c, const uint8_t* bases, const uint64_t
         for (int j = 0; j < c->ks.n; ++j) nw += (uint64_t)num_windows((int)len, c->ks.k[j], c->pol.drop_last_window);
         return nw > (uint64_t)c->S;
     };
-    int64_t ngen = 0;
-    for (int64_t i = 0; i < nreads; ++i) ngen += general_only(i) ? 1 : 0;
+    std::atomic<int64_t> ngen_a{0};
+    par_for((size_t)nreads, (size_t)1 << 17, [&](size_t lo, size_t hi) {
+        int64_t k = 0;
+        for (size_t i = lo; i < hi; ++i) k += general_only((int64_t)i) ? 1 : 0;
+        ngen_a += k;
+    });
+    const int64_t ngen = ngen_a.load();
     if (ngen == nreads || !classify_tile_supported(c->ix.nref, 1)) { // e.g. a nanopore batch: one pass through the general path
         GeneralCfg cfg; cfg.ks = c->ks; cfg.S = c->S; cfg.classify = true;
         if (c->depth) { cfg.filt_counter = c->depth; cfg.filter_mode = FILTER_MASK_MIN; cfg.fmin = c->min_occ; }
@@ -1347,8 +1415,9 @@ extern "C" int rk_classify_batch(rk_ctx* c, const uint8_t* bases, const uint64_t
         for (size_t j = 0; j < idx.size(); ++j) memcpy(out4 + idx[j] * 4, res.data() + j * 4, 16);
         return reroute_flagged(c, bases, offsets, nreads, out4);
     }
-    RKCHK(host_pipeline(c, bases, offsets, nreads, out4, 0, nullptr));
-    return reroute_flagged(c, bases, offsets, nreads, out4);
+    int64_t nflag = 0;
+    RKCHK(host_pipeline(c, bases, offsets, nreads, out4, 0, nullptr, &nflag));
+    return nflag ? reroute_flagged(c, bases, offsets, nreads, out4) : RK_OK; // the pipeline counted the rows the kernel handed back
 }
 
 extern "C" int rk_count_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, rk_counter* counter) {
