@@ -113,6 +113,12 @@ int rk_counter_create(rk_ctx* ctx, uint64_t slots, rk_counter** out);
 int rk_counter_wrap(rk_ctx* ctx, void* d_counts_int32, uint64_t slots, rk_counter** out);
 void rk_counter_destroy(rk_counter* c);   /* allowed after rk_ctx_destroy of its context; every other call is not */
 int rk_counter_clear(rk_counter* c);
+/* dst += src and dst = src, element-wise, for two tables of equal size that may belong to contexts on DIFFERENT devices: the
+ * reduce / broadcast of a -M run that spreads its reads over several GPUs inside one process (bin/rkmh --devices).  The
+ * reference's OpenMP threads share one HASHTCounter (src/rkmh.cpp:739, :909); one table per device summed after pass 1 gives the
+ * same counts.  Both calls synchronise the two contexts' streams. */
+int rk_counter_add(rk_counter* dst, const rk_counter* src);
+int rk_counter_copy(rk_counter* dst, const rk_counter* src);
 int rk_counter_increment(rk_counter* c, uint64_t key);
 int rk_counter_get(const rk_counter* c, uint64_t key, int32_t* out);
 /* Counter (de)serialisation (what the reference's commented-out read_hash_counter.write_to_binary / deserialize would do,

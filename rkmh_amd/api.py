@@ -52,6 +52,8 @@ _SIGS = {
     "rk_ctx_synchronize": (C.c_int, [C.c_void_p]),
     "rk_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "rk_free": (None, [C.c_void_p]),
+    "rk_counter_add": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rk_counter_copy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rk_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "rk_host_free": (None, [C.c_void_p]),
     "rk_to_upper": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),

@@ -686,6 +686,38 @@ extern "C" int rk_counter_clear(rk_counter* k) {
     HIPCHK(hipStreamSynchronize(k->ctx->st));
     return RK_OK;
 }
+// dst += src (element-wise) and dst = src for two tables of the same size that may live on different devices / contexts: the
+// reduce and broadcast steps of a multi-device -M run inside one process (one rk_ctx per device; the reference's OpenMP threads
+// share ONE HASHTCounter instead, src/rkmh.cpp:739,909).  A table on another device is brought over in 64 MB pieces.
+static int counter_combine(rk_counter* dst, const rk_counter* src, bool add) {
+    if (!dst || !src) return fail(RK_ERR_ARG, "counter is NULL");
+    if (dst->slots != src->slots) return fail(RK_ERR_ARG, "counters of %llu and %llu slots", (unsigned long long)dst->slots, (unsigned long long)src->slots);
+    if (dst == src || dst->d == src->d) return add ? fail(RK_ERR_ARG, "rk_counter_add of a table to itself") : RK_OK;
+    RKCHK(set_dev(src->ctx));
+    HIPCHK(hipStreamSynchronize(src->ctx->st)); // whatever filled src on its own context's stream is complete
+    RKCHK(set_dev(dst->ctx));
+    hipStream_t st = dst->ctx->st;
+    if (!add) { HIPCHK(hipMemcpyAsync(dst->d, src->d, src->slots * 4, hipMemcpyDefault, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
+    if (dst->device == src->device) { HIPCHK(launch_counter_add(dst->d, src->d, dst->slots, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
+    const uint64_t CH = (uint64_t)16 << 20; // slots per piece (64 MB)
+    DevBuf tmp[2];
+    int rc = RK_OK;
+    for (int i = 0; i < 2 && rc == RK_OK; ++i) rc = tmp[i].reserve(std::min<uint64_t>(CH, dst->slots) * 4);
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2 && rc == RK_OK; ++i) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(RK_ERR_HIP, "hipEventCreate failed");
+    int which = 0;
+    for (uint64_t off = 0; off < dst->slots && rc == RK_OK; off += CH, which ^= 1) {
+        const uint64_t n = std::min<uint64_t>(CH, dst->slots - off);
+        hipError_t e = hipMemcpyAsync(tmp[which].p, src->d + off, n * 4, hipMemcpyDefault, st);
+        if (e == hipSuccess) e = launch_counter_add(dst->d + off, tmp[which].as<int32_t>(), n, st);
+        if (e != hipSuccess) rc = fail(RK_ERR_HIP, "rk_counter_add: %s", hipGetErrorString(e));
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == RK_OK) rc = fail(RK_ERR_HIP, "rk_counter_add: synchronize failed");
+    for (int i = 0; i < 2; ++i) { if (ev[i]) { hipError_t e = hipEventDestroy(ev[i]); (void)e; } tmp[i].release(); }
+    return rc;
+}
+extern "C" int rk_counter_add(rk_counter* dst, const rk_counter* src) { return counter_combine(dst, src, true); }
+extern "C" int rk_counter_copy(rk_counter* dst, const rk_counter* src) { return counter_combine(dst, src, false); }
 extern "C" int rk_counter_increment(rk_counter* k, uint64_t key) {
     if (!k) return fail(RK_ERR_ARG, "counter is NULL");
     RKCHK(set_dev(k->ctx));

@@ -657,6 +657,25 @@ hipError_t launch_count_distinct(const uint64_t* hashes, uint64_t n, uint64_t* t
 }
 
 __global__ void k_counter_inc(int32_t* counter, uint64_t slots, uint64_t key) { atomicAdd(&counter[key % slots], 1); }
+// dst[i] += src[i]: the sum of two devices' (or two passes') depth tables -- the all-reduce step of a multi-device -M run
+__global__ __launch_bounds__(256) void k_counter_add(int32_t* __restrict__ dst, const int32_t* __restrict__ src, uint64_t n) {
+    const uint64_t n4 = n >> 2;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) {
+        int4 a = reinterpret_cast<int4*>(dst)[i];
+        const int4 b = reinterpret_cast<const int4*>(src)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        reinterpret_cast<int4*>(dst)[i] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] += src[(n4 << 2) + threadIdx.x];
+}
+hipError_t launch_counter_add(int32_t* dst, const int32_t* src, uint64_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = ((n >> 2) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_counter_add, dim3((uint32_t)blocks), dim3(256), 0, st, dst, src, n);
+    return hipGetLastError();
+}
 hipError_t launch_counter_inc(int32_t* counter, uint64_t slots, uint64_t key, hipStream_t st) {
     hipLaunchKernelGGL(k_counter_inc, dim3(1), dim3(1), 0, st, counter, slots, key);
     return hipGetLastError();

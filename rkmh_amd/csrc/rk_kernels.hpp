@@ -123,5 +123,6 @@ hipError_t launch_mask_by_frequency(uint64_t* h, uint64_t n, const int32_t* coun
 hipError_t launch_count_distinct(const uint64_t* hashes, uint64_t n, uint64_t* table, uint64_t tsize, int32_t* counter,
                                  uint64_t slots, hipStream_t st);
 hipError_t launch_counter_inc(int32_t* counter, uint64_t slots, uint64_t key, hipStream_t st);
+hipError_t launch_counter_add(int32_t* dst, const int32_t* src, uint64_t n, hipStream_t st); // dst[i] += src[i]; both 16-byte aligned
 
 } // namespace rk

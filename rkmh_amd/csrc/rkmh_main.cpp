@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -67,7 +69,10 @@ static void help_stream() {
             "  -R <sketches.json>      reference sketches written by `rkmh sketch` instead of -r\n"
             "  --depth-map-cache <file>  (with -M) save the read-depth map of this run, or reuse the file if it was saved\n"
             "                          from the same reads, k-mer sizes and hashing policy (anything else is refused)\n"
-            "  --device <id>           GPU to use (default 0)\n");
+            "  --device <id>           GPU to use (default 0)\n"
+            "  --devices <a,b,..|all>  spread the reads over several GPUs of this node (stream, filter): one host thread and one\n"
+            "                          context per device, reference sketches built on the first and imported by the others, -M depth\n"
+            "                          tables summed after pass 1; output order and content are those of a single-device run\n");
 }
 static void help_hash() {
     fprintf(stderr,
@@ -81,7 +86,21 @@ struct Opts {
     int sketch = 1000, threads = 1, min_occ = -1, min_matches = -1, min_diff = 0, max_samples = 100000;
     bool read_depth = false, ref_depth = false;
     int device = 0;
+    std::vector<int> devices; // --devices a,b,...: reads are spread over these GPUs (one host thread + rk_ctx each); empty = --device
 };
+static std::vector<int> parse_devices(const char* arg) {
+    std::vector<int> d;
+    if (!strcmp(arg, "all")) { const int n = rk_device_count(); for (int i = 0; i < n; ++i) d.push_back(i); return d; }
+    for (const char* p = arg; *p;) {
+        char* e = nullptr;
+        const long v = strtol(p, &e, 10);
+        if (e == p || v < 0) { fprintf(stderr, "rkmh: bad --devices list '%s'\n", arg); exit(1); }
+        d.push_back((int)v);
+        p = *e == ',' ? e + 1 : e;
+        if (*e && *e != ',') { fprintf(stderr, "rkmh: bad --devices list '%s'\n", arg); exit(1); }
+    }
+    return d;
+}
 
 // bounded queue between pipeline stages (parser -> classify -> format/write)
 template <typename V> struct QueueT {
@@ -89,10 +108,11 @@ template <typename V> struct QueueT {
     std::condition_variable cv;
     std::deque<V> q;
     bool done = false;
+    size_t cap = 2;
     std::string err;
     void push(V s) {
         std::unique_lock<std::mutex> l(m);
-        cv.wait(l, [&] { return q.size() < 2; });
+        cv.wait(l, [&] { return q.size() < cap; });
         q.push_back(std::move(s));
         cv.notify_all();
     }
@@ -108,7 +128,8 @@ template <typename V> struct QueueT {
     void finish() { std::lock_guard<std::mutex> l(m); done = true; cv.notify_all(); }
 };
 typedef QueueT<rk_seqset> Queue;
-struct Classified { rk_seqset reads; std::vector<int32_t> out4; };
+struct Classified { rk_seqset reads; std::vector<int32_t> out4; int64_t seq = 0; };
+struct Numbered { rk_seqset reads; int64_t seq = 0; };
 
 static inline char* put_int(char* w, int v) {
     char tmp[12];
@@ -172,6 +193,76 @@ static void emit_lines(const rk_seqset& refs, const rk_seqset& reads, const int3
 struct LoadedSketches { std::vector<std::string> names; std::vector<uint64_t> sk; std::vector<int32_t> lens; std::vector<int> ks; int S = 0; };
 static bool load_sketch_json(const char* path, LoadedSketches& L);
 
+// The devices of one run (--devices): context 0 builds the reference sketches (rk_set_references on its GPU), the others import
+// them (rk_set_reference_sketches: a few MB through the host), all in parallel threads -- the in-process form of the one-rank-per-
+// GPU layout of rkmh_amd/cli.py, and the GPU analogue of the reference's -t OpenMP threads (rkmh.cpp:734, :813-898).
+struct DeviceGroup {
+    std::vector<rk_ctx*> ctx;
+    void create(const Opts& o) {
+        std::vector<int> ids = o.devices.empty() ? std::vector<int>{o.device} : o.devices;
+        ctx.assign(ids.size(), nullptr);
+        std::vector<std::thread> th;
+        std::vector<std::string> err(ids.size());
+        for (size_t i = 0; i < ids.size(); ++i)
+            th.emplace_back([&, i] { if (rk_ctx_create(ids[i], nullptr, &ctx[i]) != RK_OK) err[i] = rk_last_error(); });
+        for (auto& t : th) t.join();
+        for (auto& e : err) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
+    }
+    // after the references were set on ctx[0]: the same sketches on every other context
+    void share_references(const Opts& o) {
+        if (ctx.size() < 2) return;
+        const int R = rk_num_references(ctx[0]);
+        std::vector<uint64_t> sk((size_t)R * (size_t)o.sketch);
+        std::vector<int32_t> lens((size_t)R);
+        CK(rk_get_reference_sketches(ctx[0], sk.data(), lens.data()));
+        std::vector<std::thread> th;
+        std::vector<std::string> err(ctx.size());
+        for (size_t i = 1; i < ctx.size(); ++i)
+            th.emplace_back([&, i] {
+                if (rk_set_reference_sketches(ctx[i], sk.data(), lens.data(), R, o.ks.data(), (int)o.ks.size(), o.sketch) != RK_OK) err[i] = rk_last_error();
+            });
+        for (auto& t : th) t.join();
+        for (auto& e : err) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
+    }
+    void destroy() { for (rk_ctx* c : ctx) rk_ctx_destroy(c); ctx.clear(); }
+    size_t size() const { return ctx.size(); }
+};
+// reads [lo, hi) of a parsed set as a batch of their own (offsets stay absolute: the entry points only use differences and offsets[0])
+static inline int64_t share_lo(int64_t n, size_t d, size_t nd) { return n * (int64_t)d / (int64_t)nd; }
+
+// Two passes over ALL reads on several devices (rkmh.cpp:904-948): device d counts and classifies reads [n d / D, n (d+1) / D);
+// the depth tables are summed onto device 0 and copied back between the passes, so every device masks with the counts of the WHOLE
+// read set, exactly as the reference's threads do with their shared counter.  cnt[0] holds the full table on return.
+static void two_pass_on_group(DeviceGroup& g, const rk_seqset& reads, uint64_t slots, int min_occ, std::vector<rk_counter*>& cnt,
+                              bool pass1, int32_t* out4) {
+    const size_t D = g.size();
+    std::vector<std::string> err(D);
+    auto run = [&](const std::function<int(size_t)>& f) {
+        std::vector<std::thread> th;
+        for (size_t d = 0; d < D; ++d) th.emplace_back([&, d] { if (f(d) != RK_OK) err[d] = rk_last_error(); });
+        for (auto& t : th) t.join();
+        for (auto& e : err) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
+    };
+    if (cnt.empty()) {
+        cnt.assign(D, nullptr);
+        run([&](size_t d) { return rk_counter_create(g.ctx[d], slots, &cnt[d]); });
+    }
+    if (pass1) {
+        run([&](size_t d) {
+            const int64_t lo = share_lo(reads.nseq, d, D), hi = share_lo(reads.nseq, d + 1, D);
+            return rk_count_batch(g.ctx[d], reads.bases, reads.offsets + lo, hi - lo, cnt[d]);
+        });
+        for (size_t d = 1; d < D; ++d) CK(rk_counter_add(cnt[0], cnt[d]));
+    }
+    for (size_t d = 1; d < D; ++d) CK(rk_counter_copy(cnt[d], cnt[0]));
+    run([&](size_t d) {
+        const int64_t lo = share_lo(reads.nseq, d, D), hi = share_lo(reads.nseq, d + 1, D);
+        int r = rk_set_depth_filter(g.ctx[d], cnt[d], min_occ);
+        if (r == RK_OK) r = rk_classify_batch(g.ctx[d], reads.bases, reads.offsets + lo, hi - lo, out4 + lo * 4);
+        return r;
+    });
+}
+
 static int main_stream(int argc, char** argv) {
     Opts o;
     const char* pre_refs = nullptr;
@@ -187,7 +278,8 @@ static int main_stream(int argc, char** argv) {
         {"pre-references", required_argument, 0, 'R'}, {"read-kmer-map-file", required_argument, 0, 'p'},
         {"ref-kmer-map-file", required_argument, 0, 'q'}, {"in-stream", no_argument, 0, 'i'},
         {"output-reads", no_argument, 0, 'z'},   {"merge-sketch", no_argument, 0, 'm'},
-        {"device", required_argument, 0, 1000},  {"depth-map-cache", required_argument, 0, 1001}, {0, 0, 0, 0}};
+        {"device", required_argument, 0, 1000},  {"depth-map-cache", required_argument, 0, 1001},
+        {"devices", required_argument, 0, 1002}, {0, 0, 0, 0}};
     optind = 2;
     int c;
     while ((c = getopt_long(argc, argv, "zmhdk:f:r:s:S:t:M:N:I:R:F:p:q:iD:", long_options, nullptr)) != -1) {
@@ -208,6 +300,7 @@ static int main_stream(int argc, char** argv) {
             case 'M': o.min_occ = atoi(optarg); o.read_depth = true; break;
             case 'I': o.max_samples = atoi(optarg); o.ref_depth = true; break;
             case 1000: o.device = atoi(optarg); break;
+            case 1002: o.devices = parse_devices(optarg); break;
             case '?': case 'h': default: print_help(); exit(1);
         }
     }
@@ -223,8 +316,9 @@ static int main_stream(int argc, char** argv) {
     if (o.refs.empty() && !pre_refs) { fprintf(stderr, "rkmh: at least one -r reference file (or -R sketches) is required\n"); exit(1); }
 
     double t0 = now_s();
-    rk_ctx* ctx = nullptr;
-    CK(rk_ctx_create(o.device, nullptr, &ctx));
+    DeviceGroup group;
+    group.create(o);
+    rk_ctx* ctx = group.ctx[0];
     tick("context", t0);
     rk_seqset refs;
     memset(&refs, 0, sizeof refs);
@@ -243,6 +337,7 @@ static int main_stream(int argc, char** argv) {
         CK(rk_set_references(ctx, refs.bases, refs.offsets, (int)refs.nseq, o.ks.data(), (int)o.ks.size(), o.sketch,
                              o.ref_depth ? o.max_samples : -1, 0));
     }
+    group.share_references(o);
     tick("references", t0);
     std::string buf;
     std::vector<int32_t> out4;
@@ -251,37 +346,55 @@ static int main_stream(int argc, char** argv) {
         // two passes over ALL reads (rkmh.cpp:904-948): the reference holds them in RAM, so do we
         rk_seqset reads;
         CK(rk_parse_files(o.reads.data(), (int)o.reads.size(), &reads));
-        rk_counter* cnt = nullptr;
-        CK(rk_counter_create(ctx, 200000000ull, &cnt)); // rkmh.cpp:739
+        std::vector<rk_counter*> cnts(group.size(), nullptr);
+        CK(rk_counter_create(ctx, 200000000ull, &cnts[0])); // rkmh.cpp:739
+        for (size_t d = 1; d < group.size(); ++d) CK(rk_counter_create(group.ctx[d], 200000000ull, &cnts[d]));
+        rk_counter* cnt = cnts[0];
         // --depth-map-cache FILE: reuse a saved depth map (pass 1 is skipped) or save this run's for the next one.  The file
         // records what it was counted from (k list, hashing policy, fingerprint of the read set); a file that does not match
         // THIS run is refused with a diagnostic rather than used (CK exits).
         uint8_t tag[RK_DEPTH_TAG_BYTES];
         if (read_map) CK(rk_depth_map_tag(ctx, o.ks.data(), (int)o.ks.size(), reads.bases, reads.offsets, reads.nseq, tag));
         FILE* probe = read_map ? fopen(read_map, "rb") : nullptr;
-        if (probe) { fclose(probe); CK(rk_counter_load_tagged(cnt, read_map, tag, sizeof tag)); }
-        else {
-            CK(rk_count_batch(ctx, reads.bases, reads.offsets, reads.nseq, cnt));
-            if (read_map) CK(rk_counter_save_tagged(cnt, read_map, tag, sizeof tag));
-        }
-        CK(rk_set_depth_filter(ctx, cnt, o.min_occ));
         out4.resize((size_t)reads.nseq * 4);
-        CK(rk_classify_batch(ctx, reads.bases, reads.offsets, reads.nseq, out4.data()));
+        if (probe) {
+            fclose(probe);
+            CK(rk_counter_load_tagged(cnt, read_map, tag, sizeof tag));
+            two_pass_on_group(group, reads, 200000000ull, o.min_occ, cnts, false, out4.data());
+        } else if (read_map) { // pass 1 alone first: the summed table is saved before the masked pass
+            std::vector<std::string> err(group.size());
+            std::vector<std::thread> th;
+            for (size_t d = 0; d < group.size(); ++d)
+                th.emplace_back([&, d] {
+                    const int64_t lo = share_lo(reads.nseq, d, group.size()), hi = share_lo(reads.nseq, d + 1, group.size());
+                    if (rk_count_batch(group.ctx[d], reads.bases, reads.offsets + lo, hi - lo, cnts[d]) != RK_OK) err[d] = rk_last_error();
+                });
+            for (auto& t : th) t.join();
+            for (auto& e : err) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
+            for (size_t d = 1; d < group.size(); ++d) CK(rk_counter_add(cnt, cnts[d]));
+            CK(rk_counter_save_tagged(cnt, read_map, tag, sizeof tag));
+            two_pass_on_group(group, reads, 200000000ull, o.min_occ, cnts, false, out4.data());
+        } else two_pass_on_group(group, reads, 200000000ull, o.min_occ, cnts, true, out4.data());
         emit_lines(refs, reads, out4.data(), o, buf);
-        rk_counter_destroy(cnt);
+        for (rk_counter* k : cnts) rk_counter_destroy(k);
         rk_seqset_free(&reads);
     } else {
-        Queue q;
+        // parser -> (one classify thread per device) -> writer.  Batches are numbered by the parser; the writer puts them back in
+        // input order, so the output does not depend on how many devices took part or on which one was faster.
+        QueueT<Numbered> q;
+        q.cap = 2 * group.size();
         std::thread producer([&] {
+            int64_t seq = 0;
             for (const char* path : o.reads) {
                 rk_reader* rd = nullptr;
                 if (rk_reader_open(path, &rd) != RK_OK) { q.err = rk_last_error(); break; }
                 rk_reader_set_options(rd, RK_READER_NO_QUALS); // stream never looks at qualities
                 for (;;) {
-                    rk_seqset s;
-                    if (rk_reader_next(rd, 1 << 20, 1ull << 28, &s) != RK_OK) { q.err = rk_last_error(); break; }
-                    if (s.nseq == 0) { rk_seqset_free(&s); break; }
-                    q.push(s);
+                    Numbered nb;
+                    if (rk_reader_next(rd, 1 << 20, 1ull << 28, &nb.reads) != RK_OK) { q.err = rk_last_error(); break; }
+                    if (nb.reads.nseq == 0) { rk_seqset_free(&nb.reads); break; }
+                    nb.seq = seq++;
+                    q.push(nb);
                 }
                 rk_reader_close(rd);
                 if (!q.err.empty()) break;
@@ -289,36 +402,56 @@ static int main_stream(int argc, char** argv) {
             q.finish();
         });
         QueueT<Classified> done_q;
-        std::thread writer([&] { // lines leave in read order: one writer, batches in queue order
+        done_q.cap = 2 * group.size() + 2;
+        std::thread writer([&] { // lines leave in read order: one writer, batches by number
             Classified c;
             std::string wbuf;
+            std::map<int64_t, Classified> waiting;
+            int64_t next = 0;
             while (done_q.pop(&c)) {
-                double a = now_s();
-                emit_lines(refs, c.reads, c.out4.data(), o, wbuf);
-                rk_seqset_free(&c.reads);
-                t_emit += now_s() - a;
+                waiting.emplace(c.seq, std::move(c));
+                for (auto it = waiting.find(next); it != waiting.end(); it = waiting.find(next)) {
+                    double a = now_s();
+                    emit_lines(refs, it->second.reads, it->second.out4.data(), o, wbuf);
+                    rk_seqset_free(&it->second.reads);
+                    t_emit += now_s() - a;
+                    waiting.erase(it);
+                    ++next;
+                }
             }
         });
-        for (;;) {
-            double a = now_s();
-            Classified c;
-            if (!q.pop(&c.reads)) break;
-            double b = now_s();
-            c.out4.resize((size_t)c.reads.nseq * 4);
-            CK(rk_classify_batch(ctx, c.reads.bases, c.reads.offsets, c.reads.nseq, c.out4.data()));
-            double c2 = now_s();
-            done_q.push(std::move(c));
-            t_wait += b - a; t_cls += c2 - b;
-        }
+        std::mutex tm;
+        std::vector<std::string> werr(group.size());
+        auto work = [&](size_t d) {
+            for (;;) {
+                double a = now_s();
+                Numbered nb;
+                if (!q.pop(&nb)) break;
+                double b = now_s();
+                Classified c;
+                c.reads = nb.reads; c.seq = nb.seq;
+                c.out4.resize((size_t)c.reads.nseq * 4);
+                if (rk_classify_batch(group.ctx[d], c.reads.bases, c.reads.offsets, c.reads.nseq, c.out4.data()) != RK_OK) { werr[d] = rk_last_error(); break; }
+                double c2 = now_s();
+                done_q.push(std::move(c));
+                std::lock_guard<std::mutex> l(tm);
+                t_wait += b - a; t_cls += c2 - b;
+            }
+        };
+        std::vector<std::thread> workers;
+        for (size_t d = 1; d < group.size(); ++d) workers.emplace_back(work, d);
+        work(0);
+        for (auto& t : workers) t.join();
+        for (auto& e : werr) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
         done_q.finish();
         writer.join();
-        if (g_timing) fprintf(stderr, "[rkmh timing] wait-for-parser %.3f s, classify %.3f s, format+write %.3f s (overlapped)\n", t_wait, t_cls, t_emit);
+        if (g_timing) fprintf(stderr, "[rkmh timing] wait-for-parser %.3f s, classify %.3f s, format+write %.3f s (overlapped; summed over %zu device(s))\n", t_wait, t_cls, t_emit, group.size());
         producer.join();
         if (!q.err.empty()) { fprintf(stderr, "rkmh: %s\n", q.err.c_str()); exit(1); }
     }
     fflush(stdout);
     if (!pre_refs) rk_seqset_free(&refs);
-    rk_ctx_destroy(ctx);
+    group.destroy();
     return 0;
 }
 
@@ -353,7 +486,7 @@ static int main_filter(int argc, char** argv) {
         {"max-samples", required_argument, 0, 'I'}, {"pre-reads", required_argument, 0, 'F'},
         {"pre-references", required_argument, 0, 'R'}, {"read-kmer-map-file", required_argument, 0, 'p'},
         {"ref-kmer-map-file", required_argument, 0, 'q'}, {"in-stream", no_argument, 0, 'i'},
-        {"device", required_argument, 0, 1000},  {0, 0, 0, 0}};
+        {"device", required_argument, 0, 1000}, {"devices", required_argument, 0, 1002}, {0, 0, 0, 0}};
     optind = 2;
     int c;
     while ((c = getopt_long(argc, argv, "hdk:f:r:s:S:t:M:N:I:R:F:p:q:iD:", long_options, nullptr)) != -1) {
@@ -370,6 +503,7 @@ static int main_filter(int argc, char** argv) {
             case 'I': o.max_samples = atoi(optarg); o.ref_depth = true; break;
             case 'i': in_stream = true; break;
             case 1000: o.device = atoi(optarg); break;
+            case 1002: o.devices = parse_devices(optarg); break;
             case '?': case 'h': default: print_help(); exit(1);
         }
     }
@@ -379,8 +513,9 @@ static int main_filter(int argc, char** argv) {
     }
     if (o.refs.empty()) { fprintf(stderr, "rkmh: at least one -r reference file is required\n"); exit(1); }
     double t0 = now_s();
-    rk_ctx* ctx = nullptr;
-    CK(rk_ctx_create(o.device, nullptr, &ctx));
+    DeviceGroup group;
+    group.create(o);
+    rk_ctx* ctx = group.ctx[0];
     tick("context", t0);
     rk_seqset refs;
     CK(rk_parse_files(o.refs.data(), (int)o.refs.size(), &refs));
@@ -397,21 +532,33 @@ static int main_filter(int argc, char** argv) {
         std::vector<uint64_t> sk((size_t)refs.nseq * (size_t)o.sketch);
         CK(rk_get_reference_sketches(ctx, sk.data(), ref_lens.data()));
     }
+    group.share_references(o);
     tick("sketch references", t0);
-    rk_counter* cnt = nullptr;
-    CK(rk_counter_create(ctx, 10000000ull, &cnt)); // read_hash_counter, rkmh.cpp:1187
+    std::vector<rk_counter*> cnts(group.size(), nullptr);
+    for (size_t d = 0; d < group.size(); ++d) CK(rk_counter_create(group.ctx[d], 10000000ull, &cnts[d])); // read_hash_counter, rkmh.cpp:1187
+    rk_counter* cnt = cnts[0];
     std::string buf;
     std::vector<int32_t> out4;
     if (!o.reads.empty()) {
         rk_seqset reads;
         CK(rk_parse_files(o.reads.data(), (int)o.reads.size(), &reads));
         tick("parse reads", t0);
-        if (o.read_depth) {
-            CK(rk_count_batch(ctx, reads.bases, reads.offsets, reads.nseq, cnt)); // rkmh.cpp:321-338
-            CK(rk_set_depth_filter(ctx, cnt, o.min_occ));                          // keep get(h) >= min_kmer_occ, :1260
-        }
         out4.resize((size_t)reads.nseq * 4);
-        CK(rk_classify_batch(ctx, reads.bases, reads.offsets, reads.nseq, out4.data()));
+        if (o.read_depth) {
+            // count (rkmh.cpp:321-338), then keep get(h) >= min_kmer_occ (:1260); the reads are spread over the devices, the
+            // depth tables summed in between
+            two_pass_on_group(group, reads, 10000000ull, o.min_occ, cnts, true, out4.data());
+        } else {
+            std::vector<std::string> err(group.size());
+            std::vector<std::thread> th;
+            for (size_t d = 0; d < group.size(); ++d)
+                th.emplace_back([&, d] {
+                    const int64_t lo = share_lo(reads.nseq, d, group.size()), hi = share_lo(reads.nseq, d + 1, group.size());
+                    if (rk_classify_batch(group.ctx[d], reads.bases, reads.offsets + lo, hi - lo, out4.data() + lo * 4) != RK_OK) err[d] = rk_last_error();
+                });
+            for (auto& t : th) t.join();
+            for (auto& e : err) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
+        }
         tick("count + classify", t0);
         for (int64_t i = 0; i < reads.nseq; ++i) {
             const int32_t* r = &out4[(size_t)i * 4];
@@ -462,10 +609,10 @@ static int main_filter(int argc, char** argv) {
         rk_reader_close(rd);
     }
     fflush(stdout);
-    CK(rk_set_depth_filter(ctx, nullptr, 0));
-    rk_counter_destroy(cnt);
+    for (size_t d = 0; d < group.size(); ++d) CK(rk_set_depth_filter(group.ctx[d], nullptr, 0));
+    for (rk_counter* k : cnts) rk_counter_destroy(k);
     rk_seqset_free(&refs);
-    rk_ctx_destroy(ctx);
+    group.destroy();
     return 0;
 }
 

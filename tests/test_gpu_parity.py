@@ -1689,3 +1689,45 @@ def test_c3_sized_resident_shard(ctx, orc, data_dir):
         sub_o = qo[lo:lo + 1001] - qo[lo]
         want = orc.classify_stream(qb[int(qo[lo]):int(qo[lo + 1000]) + 8], sub_o, [16], 1000, sk, ln, threads=orc.max_threads())
         assert (first[lo:lo + 1000] == want).all(), lo
+
+
+def test_cli_devices_matches_single_device(orc, root, data_dir, tmp_path):
+    """bin/rkmh --devices (several GPUs inside one process: one host thread + rk_ctx per device, sketches built once and imported,
+    -M depth tables summed between the passes, batches written back in input order).  On a one-GPU box the same device is listed
+    twice or three times: stdout must be byte-identical to the single-device run for stream, stream -M, filter -M and filter -I,
+    on a FASTQ large enough for several parser batches."""
+    from rkmh_amd import synth, api
+    exe = os.path.join(root, "bin", "rkmh")
+    n = 2300000          # > two parser batches of 2^20 records
+    refs = orc.kseq_parse_file(os.path.join(data_dir, "all_pave_ref.fa.gz"))[:60]
+    ref_fa = tmp_path / "refs.fa"
+    ref_fa.write_bytes(b"".join(b">" + r[0] + b"\n" + r[1] + b"\n" for r in refs))
+    R = api.parse_files([str(ref_fa)])
+    qb, _ = synth.generate_reads_fast(R["bases"], R["offsets"], 0, n)
+    rec = np.empty((n, 11 + 150 + 3 + 150 + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r"); rec[:, 10] = 10; rec[:, 161] = 10
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(8):
+        rec[:, 9 - d] = 48 + (idx // 10 ** d) % 10
+    rec[:, 2] = 48
+    rec[:, 11:161] = qb[: n * 150].reshape(n, 150)
+    rec[:, 162] = ord("+"); rec[:, 163] = 10; rec[:, 164:314] = ord("I"); rec[:, 314] = 10
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(rec.tobytes())
+    small = tmp_path / "small.fq"
+    small.write_bytes(rec[:200000].tobytes())
+
+    def run(args):
+        r = subprocess.run([exe] + args, capture_output=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout
+    base = ["-r", str(ref_fa), "-k", "16", "-s", "1000"]
+    one = run(["stream"] + base + ["-f", str(fq)])
+    assert one.count(b"\n") == n
+    assert run(["stream"] + base + ["-f", str(fq), "--devices", "0,0"]) == one
+    assert run(["stream"] + base + ["-f", str(fq), "--devices", "0,0,0"]) == one
+    for cmd, flags in (("stream", ["-M", "2"]), ("filter", ["-M", "2", "-N", "3"]), ("filter", ["-I", "2", "-D", "1"]), ("filter", [])):
+        single = run([cmd] + base + ["-f", str(small)] + flags)
+        assert len(single) > 0
+        assert run([cmd] + base + ["-f", str(small)] + flags + ["--devices", "0,0"]) == single, (cmd, flags)
+        assert run([cmd] + base + ["-f", str(small)] + flags + ["--devices", "0,0,0"]) == single, (cmd, flags)
