@@ -816,7 +816,7 @@ extern "C" int rk_depth_map_tag(const rk_ctx* c, const int* ks, int nks, const u
     struct Tag { char magic[8]; int32_t fold, drop_last, counts_zero; uint32_t seed; int32_t nks; int32_t ks[RK_MAX_KS]; int64_t nseq; uint64_t total, hlen, hbases; } t;
     static_assert(sizeof(Tag) <= RK_DEPTH_TAG_BYTES, "tag layout");
     memset(&t, 0, sizeof t);
-    memcpy(t.magic, "rkdepth1", 8);
+    memcpy(t.magic, "rkdepth2", 8); // 2: the fingerprint covers every base (1 sampled both ends)
     t.fold = c->pol.fold; t.drop_last = c->pol.drop_last_window; t.counts_zero = c->pol.counter_counts_zero; t.seed = c->pol.seed;
     t.nks = nks;
     for (int i = 0; i < nks; ++i) t.ks[i] = ks[i];
@@ -825,10 +825,28 @@ extern "C" int rk_depth_map_tag(const rk_ctx* c, const int* ks, int nks, const u
     uint64_t h = 0xcbf29ce484222325ull;
     for (int64_t i = 0; i < nseq; ++i) { const uint64_t len = offsets[i + 1] - offsets[i]; h = fnv(h, &len, 8); }
     t.hlen = h;
-    const uint64_t span = t.total < (1ull << 20) ? t.total : (1ull << 20);
-    h = 0xcbf29ce484222325ull;
-    if (span) { h = fnv(h, bases + offsets[0], (size_t)span); h = fnv(h, bases + offsets[nseq] - span, (size_t)span); }
-    t.hbases = h;
+    // EVERY base takes part (a read set edited in the middle, same lengths, must not look like the one the map was counted from):
+    // 64-bit multiply-rotate hash over 8-byte words, 4 MB pieces hashed in parallel and combined in order
+    {
+        const uint8_t* b0 = bases + offsets[0];
+        const size_t total = (size_t)t.total, PIECE = (size_t)4 << 20, npieces = (total + PIECE - 1) / PIECE;
+        std::vector<uint64_t> ph(npieces, 0);
+        par_for(npieces, 1, [&](size_t lo, size_t hi) {
+            for (size_t p = lo; p < hi; ++p) {
+                const uint8_t* q = b0 + p * PIECE;
+                const size_t n = std::min(PIECE, total - p * PIECE);
+                uint64_t x = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+                size_t i = 0;
+                for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, q + i, 8); x = (x ^ w) * 0xff51afd7ed558ccdull; x = (x << 29) | (x >> 35); }
+                uint64_t w = 0;
+                if (i < n) { memcpy(&w, q + i, n - i); x = (x ^ w) * 0xff51afd7ed558ccdull; x = (x << 29) | (x >> 35); }
+                ph[p] = x;
+            }
+        });
+        h = 0xcbf29ce484222325ull;
+        for (uint64_t x : ph) h = fnv(h, &x, 8);
+        t.hbases = h;
+    }
     memset(tag, 0, RK_DEPTH_TAG_BYTES);
     memcpy(tag, &t, sizeof t);
     return RK_OK;

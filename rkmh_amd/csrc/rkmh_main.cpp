@@ -944,7 +944,8 @@ static void help_hpv16() {
             "  classifies every read to an HPV type (<dir>/all_pave_ref.fa) and reports its k-mer matches to the\n"
             "  HPV16 lineages / sublineages of <dir>/new_refs.fa; <dir> defaults to ./data (as the reference: run it from the\n"
             "  rkmh directory).  Also writes lineage_specific_hashes.<k>.tst into the working directory.\n"
-            "  -s/-N/-D are accepted and unused, as in the reference.  --device <id>: GPU to use.\n");
+            "  -s/-N/-D are accepted and unused, as in the reference.  --device <id>: GPU to use.\n"
+            "  Reads of any length are accepted; those with more than 16384 k-mers (all -k together) are answered one at a time.\n");
 }
 static int main_hpv16(int argc, char** argv) {
     std::vector<const char*> read_files;
@@ -1074,7 +1075,59 @@ static int main_hpv16(int argc, char** argv) {
         CK(rk_set_depth_filter(ctx, cnt, min_kmer_occ));
     }
     std::vector<int32_t> out4((size_t)reads.nseq * 4), tail((size_t)reads.nseq * (size_t)(nlin + nsub));
-    if (reads.nseq > 0) CK(rk_classify_groups_batch(ctx, reads.bases, reads.offsets, reads.nseq, ntype, out4.data(), tail.data()));
+    // The batched path keeps every hash of a read in the in-LDS sorter (RK_MAX_SKETCH values).  A longer read (a nanopore or
+    // rolling-circle read of more than ~16 kb, or ~8 kb with two -k) is answered one at a time instead: hashed on the GPU
+    // (rk_hash_batch, any length), masked (-M), then intersected with every list on the host exactly as :2666-2704 does -- the
+    // reference handles reads of any length, so does this.
+    auto hashes_of = [&](int64_t i) -> int64_t {
+        const int64_t len = (int64_t)(reads.offsets[i + 1] - reads.offsets[i]);
+        int64_t hn = 0;
+        for (int k : ks) { const int64_t nw = pol.drop_last_window ? len - k : len - k + 1; if (nw > 0) hn += nw; }
+        return hn;
+    };
+    std::vector<int64_t> longs, normal;
+    for (int64_t i = 0; i < reads.nseq; ++i) (hashes_of(i) > (int64_t)S ? longs : normal).push_back(i);
+    if (longs.empty()) {
+        if (reads.nseq > 0) CK(rk_classify_groups_batch(ctx, reads.bases, reads.offsets, reads.nseq, ntype, out4.data(), tail.data()));
+    } else {
+        fprintf(stderr, "rkmh hpv16: %zu read(s) with more than %d k-mers are classified one at a time\n", longs.size(), S);
+        if (!normal.empty()) { // the other reads as a batch of their own
+            std::vector<uint64_t> off(normal.size() + 1, 0);
+            for (size_t j = 0; j < normal.size(); ++j) off[j + 1] = off[j] + (reads.offsets[normal[j] + 1] - reads.offsets[normal[j]]);
+            std::vector<uint8_t> sub((size_t)off.back() + 64);
+            for (size_t j = 0; j < normal.size(); ++j) memcpy(sub.data() + off[j], reads.bases + reads.offsets[normal[j]], (size_t)(off[j + 1] - off[j]));
+            std::vector<int32_t> o4(normal.size() * 4), tl(normal.size() * (size_t)(nlin + nsub));
+            CK(rk_classify_groups_batch(ctx, sub.data(), off.data(), (int64_t)normal.size(), ntype, o4.data(), tl.data()));
+            for (size_t j = 0; j < normal.size(); ++j) {
+                memcpy(&out4[(size_t)normal[j] * 4], &o4[j * 4], 16);
+                memcpy(&tail[(size_t)normal[j] * (size_t)(nlin + nsub)], &tl[j * (size_t)(nlin + nsub)], sizeof(int32_t) * (size_t)(nlin + nsub));
+            }
+        }
+        for (int64_t i : longs) {
+            uint64_t* h = nullptr;
+            uint64_t ho[2] = {0, 0};
+            const uint64_t one[2] = {0, reads.offsets[i + 1] - reads.offsets[i]};
+            CK(rk_hash_batch(ctx, reads.bases + reads.offsets[i], one, 1, ks.data(), (int)ks.size(), &h, ho));
+            if (cnt) CK(rk_mask_by_frequency(ctx, h, (int)ho[1], cnt, min_kmer_occ));
+            std::vector<uint64_t> v(h, h + ho[1]);
+            rk_free(h);
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+            if (!v.empty() && v[0] == 0) v.erase(v.begin());
+            auto isect = [&](int r) { // distinct non-zero values in both ascending arrays (U13)
+                const uint64_t* a = &lists[(size_t)r * S];
+                const int na = lens[(size_t)r];
+                int n = 0, x = 0; size_t y = 0;
+                while (x < na && y < v.size()) { if (a[x] == v[y]) { ++n; ++x; ++y; } else if (a[x] < v[y]) ++x; else ++y; }
+                return n;
+            };
+            int best = 0, best_id = 0, prev = -1;                                   // first maximum wins (:2669-2679)
+            for (int r = 0; r < ntype; ++r) { const int c2 = isect(r); if (c2 > best) { prev = best; best = c2; best_id = r; } }
+            int32_t* o = &out4[(size_t)i * 4];
+            o[0] = best_id; o[1] = best; o[2] = best - prev; o[3] = (int32_t)v.size();
+            for (int r = 0; r < nlin + nsub; ++r) tail[(size_t)i * (size_t)(nlin + nsub) + (size_t)r] = isect(ntype + r);
+        }
+    }
     tick("classify", t0);
     const bool den_read = getenv("RKMH_HPV16_SIM") && !strcmp(getenv("RKMH_HPV16_SIM"), "read");   // U14: similarity denominator
     std::string buf;

@@ -1208,6 +1208,14 @@ def test_counter_serialisation(ctx, orc, root, data_dir, tmp_path):
     qo = np.array([0, 96, 192], dtype=np.uint64)
     tag = ctx.depth_map_tag([8], qb, qo)
     assert tag != ctx.depth_map_tag([9], qb, qo) and tag != ctx.depth_map_tag([8], qb, np.array([0, 95, 192], dtype=np.uint64))
+    # the fingerprint covers EVERY base: one substitution in the middle of a 40 MB read set with unchanged lengths is another read set
+    big = np.frombuffer(rand_dna(np.random.default_rng(77), 40000000), dtype=np.uint8).copy()
+    bo = np.arange(0, 40000001, 100, dtype=np.uint64)
+    t_big = ctx.depth_map_tag([16], big, bo)
+    assert t_big == ctx.depth_map_tag([16], big.copy(), bo)
+    edited = big.copy()
+    edited[20000001] = ord("A") if edited[20000001] != ord("A") else ord("C")
+    assert t_big != ctx.depth_map_tag([16], edited, bo)
     cnt = rkmh_amd.Counter(ctx, slots=100003)
     cnt.increment(12345)
     cnt.save(str(tmp_path / "t.bin"), tag=tag)
@@ -1293,6 +1301,8 @@ def test_hpv16_command_against_the_oracle(orc, root, data_dir, tmp_path, ks, ext
     types, subs, reads = _hpv16_inputs(orc, data_dir)
     reads += [r[:2] for r in orc.kseq_parse_file(os.path.join(data_dir, "minION25.fq.gz"))[:6]]
     reads += [r[:2] for r in orc.kseq_parse_file(os.path.join(data_dir, "z1.fq.gz"))[:40]]
+    # a rolling-circle read: three copies of an HPV16 genome (23.7 kb: more k-mers than the batched path's sorter holds)
+    reads.append((b"rolling_circle", orc.to_upper(subs[0][1]) * 3))
     fq = tmp_path / "reads.fa"
     fq.write_bytes(b"".join(b">" + n + b"\n" + s + b"\n" for n, s in reads))
     args = [os.path.join(root, "bin", "rkmh"), "hpv16", "-f", str(fq), "-R", data_dir]
