@@ -351,21 +351,20 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             const uint32_t lim = 1u << km_vb1;
             return (b.x ^ wantsh) < lim ? b.x : ((b.y ^ wantsh) < lim ? b.y : ((b.z ^ wantsh) < lim ? b.z : ((b.w ^ wantsh) < lim ? b.w : 0xFFFFFFFFu)));
         };
-        auto apply = [&](const Cand& c) {
-            const uint32_t wantsh = (c.y & km_rmask) << km_vb1;   // the remainder (low km_r bits of y) in the tag position, "not displaced"
-            uint32_t cell = match_cell(c.c, wantsh);
-            // a miss in a bucket that sent a key further on: that key may be this one, stored up to 7 buckets past its own and tagged
-            // with the distance (about one lookup in ten takes this path once; the wave leaves when its last lane is done)
-            bool again = (cell & km_vmask) == km_vmask && ((c.c.w >> (km_vb1 - 1u)) & 1u) != 0u && c.t != 0xFFFFFFFFu;
-            if (!(RK_KMER_ABL & 16)) {
-                for (uint32_t hop = 1; hop < (1u << KM1_HB) && __ballot(again); ++hop) {
-                    if (again) {
-                        const uint4 nb = ix.km1[((c.y >> km_r) + hop) & ((1u << ix.km1_b) - 1u)];
-                        cell = match_cell(nb, wantsh | (hop << (32u - KM1_HB)));
-                        again = (cell & km_vmask) == km_vmask && ((nb.w >> (km_vb1 - 1u)) & 1u) != 0u;
-                    }
-                }
+        // first bucket: the cell, and whether the search must go on (a miss in a bucket that sent a key further on: that key may be
+        // this one, stored up to 7 buckets past its own and tagged with the distance)
+        auto first_match = [&](const Cand& c, uint32_t& cell, bool& again) {
+            cell = match_cell(c.c, (c.y & km_rmask) << km_vb1);
+            again = (cell & km_vmask) == km_vmask && ((c.c.w >> (km_vb1 - 1u)) & 1u) != 0u && c.t != 0xFFFFFFFFu;
+        };
+        auto next_match = [&](const Cand& c, uint32_t hop, uint32_t& cell, bool& again) {
+            if (again) {
+                const uint4 nb = ix.km1[((c.y >> km_r) + hop) & ((1u << ix.km1_b) - 1u)];
+                cell = match_cell(nb, ((c.y & km_rmask) << km_vb1) | (hop << (32u - KM1_HB)));
+                again = (cell & km_vmask) == km_vmask && ((nb.w >> (km_vb1 - 1u)) & 1u) != 0u;
             }
+        };
+        auto apply = [&](const Cand& c, uint32_t cell) {
             const uint32_t vid = cell & km_vmask;
             uint32_t val = vid | (1u << 20); // a single posting of multiplicity 1, in the RefIndex::kv value format
             const bool hit = vid != km_vmask && c.t != 0xFFFFFFFFu; // else: a false positive of the bit filter, or a window past its read's last
@@ -414,18 +413,22 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             }
         };
         auto drain = [&](uint32_t qn) {
-#if RK_KMER_DR == 2
             for (uint32_t e0 = 0; e0 < qn; e0 += 2 * KW) { // two rounds of lookups in flight
                 const bool two = e0 + KW < qn;
                 const Cand a = lookup(e0 + (uint32_t)lane, qn);
                 Cand b = a;
                 if (two) b = lookup(e0 + KW + (uint32_t)lane, qn);
-                apply(a);
-                if (two) apply(b);
+                uint32_t ca, cb = 0xFFFFFFFFu;
+                bool ga, gb = false;
+                first_match(a, ca, ga);
+                if (two) first_match(b, cb, gb);
+                // the searches that go on (about one lookup in ten, once) are continued for both rounds together: one more memory
+                // round trip per hop for the tile, not per round; the wave leaves when its last lane is done
+                if (!(RK_KMER_ABL & 16))
+                    for (uint32_t hop = 1; hop < (1u << KM1_HB) && __ballot(ga || gb); ++hop) { next_match(a, hop, ca, ga); next_match(b, hop, cb, gb); }
+                apply(a, ca);
+                if (two) apply(b, cb);
             }
-#else
-            for (uint32_t e0 = 0; e0 < qn; e0 += KW) apply(lookup(e0 + (uint32_t)lane, qn));
-#endif
             if (mqn) process_mq();
         };
 
