@@ -241,9 +241,10 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         uint32_t nw = 0, ng = 0;
         if (lane < Tn) { nw = (uint32_t)num_windows((int)len, KT, pol.drop_last_window); ng = (nw + 3u) >> 2; }
         uint32_t gs = ng; // inclusive prefix of the group counts over the tile's reads (lanes 0..7)
-        { uint32_t t1 = (uint32_t)__shfl_up((int)gs, 1); if (lane >= 1) gs += t1;
-          t1 = (uint32_t)__shfl_up((int)gs, 2); if (lane >= 2) gs += t1;
-          t1 = (uint32_t)__shfl_up((int)gs, 4); if (lane >= 4) gs += t1; }
+        // (DPP row shifts: lanes 0..7 lie in one 16-lane row, a lane without a source reads 0)
+        gs += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gs, 0x111, 0xf, 0xf, true); // row_shr:1
+        gs += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gs, 0x112, 0xf, 0xf, true); // row_shr:2
+        gs += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gs, 0x114, 0xf, 0xf, true); // row_shr:4
         const uint32_t NG = (uint32_t)__builtin_amdgcn_readlane((int)gs, KM_MAX_T - 1); // groups of the tile
         if (lane <= KM_MAX_T) { // entries past the tile's last read: no windows, first group = NG
             rinfo[lane] = make_uint4(cur_o - ta + mis, nw, gs - ng, 0u);

@@ -10,6 +10,7 @@
 // second host thread parses the next batch.  Output order = input order (the reference's order is
 // nondeterministic under -t > 1, src/rkmh.cpp:893).
 #include <getopt.h>
+#include <unistd.h>
 
 #include <condition_variable>
 #include <cstdio>
@@ -315,6 +316,31 @@ static int main_stream(int argc, char** argv) {
     }
     if (o.refs.empty() && !pre_refs) { fprintf(stderr, "rkmh: at least one -r reference file (or -R sketches) is required\n"); exit(1); }
 
+    // The FASTQ front end starts NOW (streaming path): while the GPU contexts come up and the references are sketched -- a few
+    // tenths of a second -- the parser is already filling its first batches.
+    QueueT<Numbered> q;
+    q.cap = 4;
+    std::thread producer;
+    if (!o.read_depth)
+        producer = std::thread([&] {
+            int64_t seq = 0;
+            for (const char* path : o.reads) {
+                rk_reader* rd = nullptr;
+                if (rk_reader_open(path, &rd) != RK_OK) { q.err = rk_last_error(); break; }
+                rk_reader_set_options(rd, RK_READER_NO_QUALS); // stream never looks at qualities
+                for (;;) {
+                    Numbered nb;
+                    if (rk_reader_next(rd, 1 << 20, 1ull << 28, &nb.reads) != RK_OK) { q.err = rk_last_error(); break; }
+                    if (nb.reads.nseq == 0) { rk_seqset_free(&nb.reads); break; }
+                    nb.seq = seq++;
+                    q.push(nb);
+                }
+                rk_reader_close(rd);
+                if (!q.err.empty()) break;
+            }
+            q.finish();
+        });
+
     double t0 = now_s();
     DeviceGroup group;
     group.create(o);
@@ -381,26 +407,7 @@ static int main_stream(int argc, char** argv) {
     } else {
         // parser -> (one classify thread per device) -> writer.  Batches are numbered by the parser; the writer puts them back in
         // input order, so the output does not depend on how many devices took part or on which one was faster.
-        QueueT<Numbered> q;
-        q.cap = 2 * group.size();
-        std::thread producer([&] {
-            int64_t seq = 0;
-            for (const char* path : o.reads) {
-                rk_reader* rd = nullptr;
-                if (rk_reader_open(path, &rd) != RK_OK) { q.err = rk_last_error(); break; }
-                rk_reader_set_options(rd, RK_READER_NO_QUALS); // stream never looks at qualities
-                for (;;) {
-                    Numbered nb;
-                    if (rk_reader_next(rd, 1 << 20, 1ull << 28, &nb.reads) != RK_OK) { q.err = rk_last_error(); break; }
-                    if (nb.reads.nseq == 0) { rk_seqset_free(&nb.reads); break; }
-                    nb.seq = seq++;
-                    q.push(nb);
-                }
-                rk_reader_close(rd);
-                if (!q.err.empty()) break;
-            }
-            q.finish();
-        });
+        if (q.cap < 2 * group.size()) { std::lock_guard<std::mutex> l(q.m); q.cap = 2 * group.size(); q.cv.notify_all(); }
         QueueT<Classified> done_q;
         done_q.cap = 2 * group.size() + 2;
         std::thread writer([&] { // lines leave in read order: one writer, batches by number
@@ -450,9 +457,12 @@ static int main_stream(int argc, char** argv) {
         if (!q.err.empty()) { fprintf(stderr, "rkmh: %s\n", q.err.c_str()); exit(1); }
     }
     fflush(stdout);
+    tick("main loop + flush", t0);
     if (!pre_refs) rk_seqset_free(&refs);
     group.destroy();
-    return 0;
+    tick("teardown", t0);
+    fflush(stdout); fflush(stderr);
+    _exit(0); // everything is written: skip the HIP runtime's and the loader's exit handlers (~0.1-0.2 s of a 1 s run)
 }
 
 // filter: main_filter, src/rkmh.cpp:996-1424.  Same sketches as stream; the decision is
