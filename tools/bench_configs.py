@@ -82,4 +82,9 @@ run("multi-k 12,14,16", rb, ro, [12, 14, 16], 1000, 1000000, 150)
 run("-M 2 (count pass + masked classify)", rb, ro, [16], 1000, 1000000, 150, depth=2)
 run("100 bp reads", rb, ro, [16], 1000, 1000000, 100)
 run("250 bp reads", rb, ro, [16], 1000, 1000000, 250)
+run("1000 bp reads (200 k)", rb, ro, [16], 1000, 200000, 1000)
+run("k=10", rb, ro, [10], 1000, 1000000, 150)
+run("k=15", rb, ro, [15], 1000, 1000000, 150)
+p2000 = synth.synthetic_panel(2000)
+run("2000 synthetic references", p2000[0], p2000[1], [16], 1000, 1000000, 150)
 run("1000 bp reads (fused, T=1)", rb, ro, [16], 1000, 200000, 1000)
