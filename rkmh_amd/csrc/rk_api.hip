@@ -107,7 +107,9 @@ struct rk_ctx {
     KsArr ks{};
     std::vector<uint64_t> h_sk;
     std::vector<int32_t> h_lens;
-    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_kf4, d_km1, d_km1v, d_keepbits;
+    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_keepbits;
+    DevBuf d_kf4[KM_MAX_KS], d_km1[KM_MAX_KS], d_km1v[KM_MAX_KS]; // k-mer-space structures, one set per k-mer size
+    KmerSets ksets{};
     uint32_t kpre_inserted = 0; // k-mers the enumeration found for the k-mer-space structures (diagnostic)
     bool kmer_form_allowed = true; // rk_set_kmer_form
     RefIndex ix{};
@@ -163,8 +165,9 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
-    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_kf4, &c->d_km1, &c->d_km1v, &c->d_keepbits, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_keepbits, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount, &c->w_tail}) b->release();
+    for (int j = 0; j < KM_MAX_KS; ++j) { c->d_kf4[j].release(); c->d_km1[j].release(); c->d_km1v[j].release(); }
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
         s.d_bases.release(); s.d_offs.release(); s.d_out.release();
@@ -985,17 +988,23 @@ static int build_index(rk_ctx* c) {
         HIPCHK(hipMemcpy(c->d_pre.p, pre.data(), (size_t)pwords * 4, hipMemcpyHostToDevice));
         c->ix.pre = c->d_pre.as<uint32_t>(); c->ix.pmask = pwords - 1;
     }
-    // k-mer-space structures (a single k of 8..16): every k-mer of the 4^k universe whose canonical hash is a key (or 0), found by
-    // exhaustive enumeration on the device -- see k_enum_kmers -- goes into the group filter and the exact map of k_classify_kmer
-    // (rk_kmer.hip).  RKMH_KMER_PREFILTER=0 turns them off (A/B runs, tests).
+    // k-mer-space structures (every k-mer size of the run from 8 to 16): every k-mer of the 4^k universe whose canonical hash is a key
+    // (or 0), found by exhaustive enumeration on the device -- see k_enum_kmers -- goes into the group filter and the exact map of
+    // k_classify_kmer (rk_kmer.hip), one pair per size.  RKMH_KMER_PREFILTER=0 turns them off (A/B runs, tests).
     c->ix.kpk = 0; c->kpre_inserted = 0;
     c->ix.kf4 = nullptr; c->ix.kf4_lg = 0; c->ix.km1 = nullptr; c->ix.km1_b = 0; c->ix.km1_vals = nullptr;
+    memset(&c->ksets, 0, sizeof c->ksets);
     static const int kmer_env = getenv("RKMH_KMER_PREFILTER") ? atoi(getenv("RKMH_KMER_PREFILTER")) : -1;
     const int kmer_mode = kmer_env >= 0 ? kmer_env : (pre_mode > 0 ? 1 : 0);
     static const long kmer_max_keys_env = getenv("RKMH_KPRE_MAXKEYS") ? atol(getenv("RKMH_KPRE_MAXKEYS")) : -1;
     const size_t kmer_max_keys = kmer_max_keys_env >= 0 ? (size_t)kmer_max_keys_env : 6000000;
-    if (kmer_mode > 0 && c->kmer_form_allowed && c->ks.n == 1 && c->ks.k[0] >= KPRE_MIN_K && c->ks.k[0] <= 16 && distinct <= kmer_max_keys) {
-        const int k = c->ks.k[0];
+    bool all_k_ok = kmer_mode > 0 && c->kmer_form_allowed && c->ks.n >= 1 && c->ks.n <= KM_MAX_KS && distinct <= kmer_max_keys;
+    for (int j = 0; j < c->ks.n; ++j) all_k_ok = all_k_ok && c->ks.k[j] >= KPRE_MIN_K && c->ks.k[j] <= 16;
+    for (int j = 0; j + 1 < c->ks.n; ++j) for (int i = j + 1; i < c->ks.n; ++i) all_k_ok = all_k_ok && c->ks.k[j] != c->ks.k[i]; // a size given twice hashes twice: hash-space path
+    std::vector<uint8_t> seen(all_k_ok ? nkeys + 1 : 0, 0); // across the sizes: a key found by two k-mers of ANY sizes disables the form
+    int built = 0;
+    for (int kidx = 0; all_k_ok && kidx < c->ks.n; ++kidx) {
+        const int k = c->ks.k[kidx];
         // the k-mers found come back as a list (one per strand pair): normally exactly one per key, plus any k-mer that collides
         // with a key or hashes to 0 -- a handful at most, so twice the keys is ample room; more than that disables this form
         const uint32_t list_cap = (uint32_t)std::min<size_t>(2 * distinct + 4096, 0x3fffffffu);
@@ -1011,13 +1020,12 @@ static int build_index(rk_ctx* c) {
         std::vector<uint32_t> list((size_t)std::min<uint32_t>(found, list_cap) * 2);
         if (le == hipSuccess && !list.empty()) le = hipMemcpy(list.data(), d_list.p, list.size() * 4, hipMemcpyDeviceToHost);
         if (le != hipSuccess) return fail(RK_ERR_HIP, "k-mer enumeration: %s", hipGetErrorString(le));
-        c->kpre_inserted = found;
+        c->kpre_inserted += found;
         // Built only when every key has exactly one preimage (found == keys + zero-hash k-mers with no two entries sharing a key id):
         // the k-mer then identifies the key in the per-read hit multiset.  Anything else leaves the hash-space kernels in charge.
         bool ok = found <= list_cap;
         if (getenv("RKMH_KMAP_FORCE_DUP")) ok = false; // tests: behave as if two k-mers shared a key (nothing is built)
         if (ok) {
-            std::vector<uint8_t> seen(nkeys + 1, 0);
             for (uint32_t i = 0; ok && i < found; ++i) {
                 const uint32_t slot = list[2 * (size_t)i + 1];
                 if (slot == IDX_NOT_FOUND) continue;
@@ -1089,20 +1097,28 @@ static int build_index(rk_ctx* c) {
                     if (placed_all) { built = true; break; }
                 }
                 if (built) { // else: the hash-space kernels serve the panel
-                    RKCHK(c->d_km1.reserve(c1.size() * 4));
-                    HIPCHK(hipMemcpy(c->d_km1.p, c1.data(), c1.size() * 4, hipMemcpyHostToDevice));
-                    RKCHK(c->d_km1v.reserve(vals.size() * 4 + 16));
-                    if (!vals.empty()) HIPCHK(hipMemcpy(c->d_km1v.p, vals.data(), vals.size() * 4, hipMemcpyHostToDevice));
-                    c->ix.km1 = c->d_km1.as<uint4>(); c->ix.km1_b = b; c->ix.km1_vals = c->d_km1v.as<uint32_t>();
+                    DevBuf& d_km1 = c->d_km1[(size_t)kidx];
+                    DevBuf& d_km1v = c->d_km1v[(size_t)kidx];
+                    RKCHK(d_km1.reserve(c1.size() * 4));
+                    HIPCHK(hipMemcpy(d_km1.p, c1.data(), c1.size() * 4, hipMemcpyHostToDevice));
+                    RKCHK(d_km1v.reserve(vals.size() * 4 + 16));
+                    if (!vals.empty()) HIPCHK(hipMemcpy(d_km1v.p, vals.data(), vals.size() * 4, hipMemcpyHostToDevice));
+                    c->ksets.km1[kidx] = d_km1.as<uint4>(); c->ksets.km1_b[kidx] = b; c->ksets.km1_vals[kidx] = d_km1v.as<uint32_t>();
                 }
             }
-            RKCHK(c->d_kf4.reserve(f4.size() * 4));
-            HIPCHK(hipMemcpy(c->d_kf4.p, f4.data(), f4.size() * 4, hipMemcpyHostToDevice));
-            c->ix.kf4 = c->d_kf4.as<uint4>(); c->ix.kf4_lg = lg;
-            if (c->ix.km1) c->ix.kpk = (uint32_t)k;
-            else { c->ix.kf4 = nullptr; c->ix.kf4_lg = 0; }
+            DevBuf& d_kf4 = c->d_kf4[(size_t)kidx];
+            RKCHK(d_kf4.reserve(f4.size() * 4));
+            HIPCHK(hipMemcpy(d_kf4.p, f4.data(), f4.size() * 4, hipMemcpyHostToDevice));
+            if (c->ksets.km1[kidx]) { c->ksets.kf4[kidx] = d_kf4.as<uint4>(); c->ksets.kf4_lg[kidx] = lg; c->ksets.k[kidx] = k; ++built; }
+            else ok = false;
         }
+        if (!ok) break; // one size without its structures: the hash-space kernels serve the run
     }
+    if (built == c->ks.n && built > 0) { // every size has its filter and map
+        c->ksets.n = built;
+        c->ix.kf4 = c->ksets.kf4[0]; c->ix.kf4_lg = c->ksets.kf4_lg[0]; c->ix.km1 = c->ksets.km1[0]; c->ix.km1_b = c->ksets.km1_b[0];
+        c->ix.km1_vals = c->ksets.km1_vals[0]; c->ix.kpk = (uint32_t)c->ksets.k[0];
+    } else memset(&c->ksets, 0, sizeof c->ksets);
     // a full bottom-S sketch of uniform hashes keeps the fraction (largest kept hash / 2^64) of the k-mers
     c->density = 0.0;
     for (int r = 0; r < R; ++r) {
@@ -1180,7 +1196,7 @@ extern "C" int rk_kmer_form(const rk_ctx* c, uint32_t* kmers_found) {
     if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
     if (!c->have_refs) return fail(RK_ERR_STATE, "no references set");
     if (kmers_found) *kmers_found = c->kpre_inserted;
-    return (c->ix.kf4 && c->ix.km1) ? 1 : 0;
+    return c->ksets.n >= 1 ? 1 : 0;
 }
 
 extern "C" int rk_set_depth_filter(rk_ctx* c, rk_counter* counter, int min_kmer_occ) {
@@ -1212,9 +1228,8 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     int expect = 0; // hits an error-free read is expected to score: sizes the kernel's per-read hit multiset
     for (int j = 0; j < c->ks.n; ++j) expect += (int)(c->density * (double)num_windows((int)ml, c->ks.k[j], c->pol.drop_last_window)) + 1;
     // plain classification with the single k the exact k-mer map was enumerated for: the k-mer-space kernel (rk_kmer.hip)
-    if (mode == 0 && !counter && c->ix.kf4 && c->ix.km1 && c->ks.n == 1 && (uint32_t)c->ks.k[0] == c->ix.kpk &&
-        classify_kmer_supported(c->ix.nref, (int)ml, c->ks.k[0]))
-        HIPCHK(launch_classify_kmer((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks.k[0], c->S, c->ix,
+    if (mode == 0 && !counter && c->ksets.n == c->ks.n && c->ksets.n >= 1 && classify_kmer_supported(c->ix.nref, (int)ml, c->ks.k[0]))
+        HIPCHK(launch_classify_kmer((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ksets, c->S, c->ix,
                                     (int32_t*)d_out4, c->pol, (int)ml, expect, st));
     else if (classify_tile_supported(mode == 0 ? c->ix.nref : 0, (int)ml))
         HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,

@@ -435,6 +435,17 @@ constexpr uint32_t KM1_C = 0x9E3779B1u;
 constexpr uint32_t KM1_HB = 3;                       // hop bits: a key lies at most 7 buckets past its own
 __host__ __device__ __forceinline__ uint32_t km1_y(uint32_t key, int k) { return k >= 16 ? key * KM1_C : (key * KM1_C) & ((1u << (2 * k)) - 1u); }
 __host__ __device__ __forceinline__ uint32_t km1_vbits(int k, uint32_t b) { return 31u - KM1_HB - ((uint32_t)(2 * k) - b); }
+// the k-mer-space structures of EVERY k of a run with several k-mer sizes (each from 8 to 16): the multi-k form of k_classify_kmer
+// walks a tile once per k (hashes of all k count towards the same per-read sketch comparison, U5) with that k's filter and map
+constexpr int KM_MAX_KS = 8;
+struct KmerSets {
+    int32_t n;
+    int32_t k[KM_MAX_KS];
+    const uint4* kf4[KM_MAX_KS];
+    const uint4* km1[KM_MAX_KS];
+    const uint32_t* km1_vals[KM_MAX_KS];
+    uint32_t kf4_lg[KM_MAX_KS], km1_b[KM_MAX_KS];
+};
 // filter word and bit pair of a hash: the word from the low bits of the high hash word (like the bucket), the two bits
 // from bits 14..23 of the low word (bits 0..13 are the fingerprint)
 __host__ __device__ __forceinline__ uint32_t index_pre_word(uint64_t h, uint32_t pmask) { return (uint32_t)(h >> 32) & pmask; }

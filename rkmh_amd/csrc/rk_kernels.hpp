@@ -110,10 +110,10 @@ constexpr int KPRE_MIN_K = 8; // the k-mer-space kernel (rk_kmer.hip) exists for
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st);
-// the k-mer-space kernel (rk_kmer.hip): plain classification with the single k (KPRE_MIN_K..16) the exact k-mer map and the group
-// filter (RefIndex::km1 / kf4) were built for
+// the k-mer-space kernel (rk_kmer.hip): plain classification with k-mer sizes from KPRE_MIN_K to 16 whose exact k-mer maps and group
+// filters were built (KmerSets: one per size; a single size runs the compile-time-k kernels, several the run-time-k one)
 bool classify_kmer_supported(int nref, int maxlen, int k);
-hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, int k, int S, const RefIndex& ix,
+hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KmerSets& ksets, int S, const RefIndex& ix,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st);
 hipError_t launch_max_len(const uint32_t* offs, uint32_t nreads, uint32_t* d_max, hipStream_t st);
 hipError_t launch_mask_by_frequency(uint64_t* h, uint64_t n, const int32_t* counter, uint64_t slots, int min_occ,

@@ -61,8 +61,8 @@ struct KmerGeom {
     int32_t dset;      // slots of the per-read hit multiset (power of two)
     int32_t xcd;
     int32_t L;         // hinted read length ...
-    int32_t gpr;       // ... its groups per read = ceil(windows / 4) ...
-    uint32_t magic;    // ... and ceil(2^32 / gpr): the group -> read division of tiles made of such reads
+    int32_t gpr[KM_MAX_KS];    // ... its groups per read = ceil(windows / 4), per k-mer size ...
+    uint32_t magic[KM_MAX_KS]; // ... and ceil(2^32 / gpr): the group -> read division of tiles made of such reads
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -79,7 +79,8 @@ struct KmLds {
     static constexpr int NZ = RI + 4 * (KM_MAX_T + 1);        // [8] zero hashes of read t
     static constexpr int BEST = NZ + KM_MAX_T;                // [8] max over increments of (count << 16 | 0xFFFF - ref)
     static constexpr int FLAGS = BEST + KM_MAX_T;             // [8] read must take the general path
-    static constexpr int CNT = FLAGS + KM_MAX_T;              // [T][cwords] per-reference counters, then [T][dset] hit multisets
+    static constexpr int NWT = FLAGS + KM_MAX_T;              // [8] windows of read t, all k-mer sizes together
+    static constexpr int CNT = NWT + KM_MAX_T;                // [T][cwords] per-reference counters, then [T][dset] hit multisets
     static_assert(RI % 4 == 0, "rinfo is read with 16-byte LDS loads");
     static_assert(CNT % 4 == 0, "the multisets are cleared with 16-byte LDS stores");
 };
@@ -134,14 +135,12 @@ __device__ __forceinline__ uint32_t km_nonzero4(uint32_t m) {
 
 template <int KT, int NQ, int CMODE, bool BIG>
 __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
-                                                                              uint32_t nreads, int S, RefIndex ix, int32_t* __restrict__ out4,
-                                                                              DevPolicy pol, KmerGeom geo) {
-    static_assert(KT >= 4 && KT <= 16, "a k-mer packs into 32 bits; the core is the (k-3)-mer");
+                                                                              uint32_t nreads, int S, RefIndex ix, KmerSets ksets,
+                                                                              int32_t* __restrict__ out4, DevPolicy pol, KmerGeom geo) {
+    // KT = 0: several k-mer sizes (ksets.k[], each from 8 to 16), one pass over the tile's windows per size
+    static_assert(KT == 0 || (KT >= 4 && KT <= 16), "a k-mer packs into 32 bits; the core is the (k-3)-mer");
     using L = KmLds<NQ>;
     __shared__ __attribute__((aligned(16))) uint32_t smem[(BIG ? KM_LDS_BIG : KM_LDS_SMALL) / 4];
-    constexpr uint32_t KMASK = KT == 16 ? 0xffffffffu : ((1u << (2 * KT)) - 1u);
-    constexpr uint32_t CMASK = (1u << (2 * (KT - 3))) - 1u;
-    constexpr uint32_t KBITS = (1u << KT) - 1u; // KT validity bits
     constexpr uint32_t PAD_P = NQ * 1024;       // position of the image's zero padding: where lanes without a group look
     constexpr uint32_t clg = CMODE == CM_DENSE8 ? 2 : 1, cbits = 32u >> clg, cmask = (1u << cbits) - 1u;
     uint32_t* const pk = smem + L::PK;
@@ -152,6 +151,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
     uint32_t* const nzero = smem + L::NZ;
     uint32_t* const best = smem + L::BEST;
     uint32_t* const flags = smem + L::FLAGS;
+    uint32_t* const nwtot = smem + L::NWT;
     uint32_t* const cnt = smem + L::CNT;
     const int T = geo.T;
     const uint32_t CW = (uint32_t)geo.cwords, DS = (uint32_t)geo.dset;
@@ -238,28 +238,20 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         }
 
         // ---- phase 0: per-read bookkeeping (lane t = read t), packed image, validity ballot ---------------------------------
-        uint32_t nw = 0, ng = 0;
-        if (lane < Tn) { nw = (uint32_t)num_windows((int)len, KT, pol.drop_last_window); ng = (nw + 3u) >> 2; }
-        uint32_t gs = ng; // inclusive prefix of the group counts over the tile's reads (lanes 0..7)
-        // (DPP row shifts: lanes 0..7 lie in one 16-lane row, a lane without a source reads 0)
-        gs += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gs, 0x111, 0xf, 0xf, true); // row_shr:1
-        gs += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gs, 0x112, 0xf, 0xf, true); // row_shr:2
-        gs += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gs, 0x114, 0xf, 0xf, true); // row_shr:4
-        const uint32_t NG = (uint32_t)__builtin_amdgcn_readlane((int)gs, KM_MAX_T - 1); // groups of the tile
-        if (lane <= KM_MAX_T) { // entries past the tile's last read: no windows, first group = NG
-            rinfo[lane] = make_uint4(cur_o - ta + mis, nw, gs - ng, 0u);
-            if (lane < KM_MAX_T) {
-                nzero[lane] = 0; best[lane] = 0;
-                // more windows than a packed counter can count (only possible when the caller's length hint was too small)
-                flags[lane] = nw > (CMODE == CM_SPARSE ? 0x7FFu : cmask) ? 1u : 0u;
-            }
+        constexpr int NKC = KT ? 1 : KM_MAX_KS;
+        const int NK = KT ? 1 : ksets.n; // k-mer sizes: the tile's windows are walked once per size
+        uint32_t nw_all = 0;             // windows of this lane's read, all sizes together
+        if (lane < Tn) {
+#pragma unroll
+            for (int j = 0; j < NKC; ++j) if (j < NK) nw_all += (uint32_t)num_windows((int)len, KT ? KT : ksets.k[j], pol.drop_last_window);
+        }
+        if (lane < KM_MAX_T) {
+            nzero[lane] = 0; best[lane] = 0; nwtot[lane] = nw_all;
+            // more windows than a packed counter can count (only possible when the caller's length hint was too small)
+            flags[lane] = nw_all > (CMODE == CM_SPARSE ? 0x7FFu : cmask) ? 1u : 0u;
         }
         const uint32_t ulen = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
         const bool same_len = __ballot(lane < Tn && len != ulen) == 0ull;
-        { // clear the hit multisets: 16 bytes per lane and store
-            uint4* d4 = reinterpret_cast<uint4*>(dset);
-            for (uint32_t i = lane; i < ((uint32_t)Tn * DS) >> 2; i += KW) d4[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
         uint32_t mism = 0;
 #pragma unroll
         for (int r = 0; r < NQ; ++r) {
@@ -281,13 +273,37 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             }
             if (lane < 2) inv[NQ * 32 + lane] = 0;
         }
+        for (int kk = 0; kk < NK; ++kk) {
+        // ---- one k-mer size: its windows, its filter and map; the per-read counters, zero counts and running best carry over ----
+        const int k = KT ? KT : ksets.k[kk];
+        const uint32_t KMASK = k == 16 ? 0xffffffffu : ((1u << (2 * k)) - 1u);
+        const uint32_t CMASK = (1u << (2 * (k - 3))) - 1u;
+        const uint32_t KBITS = (1u << k) - 1u; // k validity bits
+        const uint4* const kf4p = KT ? ix.kf4 : ksets.kf4[kk];
+        const uint4* const km1p = KT ? ix.km1 : ksets.km1[kk];
+        const uint32_t* const km1v = KT ? ix.km1_vals : ksets.km1_vals[kk];
+        const uint32_t kf4_lg = KT ? ix.kf4_lg : ksets.kf4_lg[kk], km1_b = KT ? ix.km1_b : ksets.km1_b[kk];
+        wave_sync(); // the previous size's pass is over (first pass: the image is staged)
+        uint32_t nw = 0, ng = 0;
+        if (lane < Tn) { nw = (uint32_t)num_windows((int)len, k, pol.drop_last_window); ng = (nw + 3u) >> 2; }
+        uint32_t gs = ng; // inclusive prefix of the group counts over the tile's reads (lanes 0..7)
+        // (DPP row shifts: lanes 0..7 lie in one 16-lane row, a lane without a source reads 0)
+        gs += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gs, 0x111, 0xf, 0xf, true); // row_shr:1
+        gs += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gs, 0x112, 0xf, 0xf, true); // row_shr:2
+        gs += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gs, 0x114, 0xf, 0xf, true); // row_shr:4
+        const uint32_t NG = (uint32_t)__builtin_amdgcn_readlane((int)gs, KM_MAX_T - 1); // groups of the tile
+        if (lane <= KM_MAX_T) rinfo[lane] = make_uint4(cur_o - ta + mis, nw, gs - ng, 0u); // entries past the tile's last read: no windows, first group = NG
+        { // clear the hit multisets (repeats only exist within one k-mer size: different sizes never share a hash): 16 bytes per lane and store
+            uint4* d4 = reinterpret_cast<uint4*>(dset);
+            for (uint32_t i = lane; i < ((uint32_t)Tn * DS) >> 2; i += KW) d4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
         wave_sync();
 
         // group -> read mapping: tiles of equally long reads divide by a magic constant, the others search the group starts
-        const uint32_t nw_u = (uint32_t)num_windows((int)ulen, KT, pol.drop_last_window), gpr_u = (nw_u + 3u) >> 2;
+        const uint32_t nw_u = (uint32_t)num_windows((int)ulen, k, pol.drop_last_window), gpr_u = (nw_u + 3u) >> 2;
         const bool uniform = same_len && gpr_u >= 2u; // >= 2: the magic division needs a divisor > 1
         uint32_t magic = 0;
-        if (uniform) magic = ulen == (uint32_t)geo.L ? geo.magic : (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu / gpr_u + 1u));
+        if (uniform) magic = ulen == (uint32_t)geo.L ? geo.magic[kk] : (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu / gpr_u + 1u));
 
         // +1 for reference `ref` of read t, whose counter row starts crow_b bytes into cnt; the monotone counters make
         // (max_shared, first max_id) a running atomicMax
@@ -331,7 +347,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         };
         // one candidate of the queue: canonical k-mer, its read, its bucket of the exact map (load in flight on return)
         struct Cand { uint32_t key, t, y; uint4 c; };
-        const uint32_t km_r = 2u * KT - ix.km1_b, km_vb1 = 32u - KM1_HB - km_r;      // remainder bits; value id bits + the flag bit
+        const uint32_t km_r = 2u * (uint32_t)k - km1_b, km_vb1 = 32u - KM1_HB - km_r;      // remainder bits; value id bits + the flag bit
         const uint32_t km_vmask = (1u << (km_vb1 - 1u)) - 1u, km_rmask = (1u << km_r) - 1u, nref = (uint32_t)ix.nref;
         auto lookup = [&](uint32_t e, uint32_t qn) -> Cand {
             Cand c;
@@ -340,11 +356,11 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             const uint32_t P = ent & 4095u, t = (ent >> 12) & 7u, o = ent >> 15;
             const km_pair1 w = *reinterpret_cast<const km_pair1*>(reinterpret_cast<const uint8_t*>(pk) + (P >> 2));
             const uint32_t x = __builtin_amdgcn_alignbit(w.y, w.x, (P & 3u) << 1) & KMASK;
-            const uint32_t r = packed_revcomp(x, KT);
+            const uint32_t r = packed_revcomp(x, k);
             c.key = x < r ? x : r;
             c.t = o < rinfo[t].y ? t : 0xFFFFFFFFu; // the last group of a read may reach past its last window
-            c.y = km1_y(c.key, KT);
-            c.c = ix.km1[c.y >> km_r];
+            c.y = km1_y(c.key, k);
+            c.c = km1p[c.y >> km_r];
             return c;
         };
         // the cell of the bucket whose tag equals the one in wantsh (all ones: none)
@@ -360,7 +376,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         };
         auto next_match = [&](const Cand& c, uint32_t hop, uint32_t& cell, bool& again) {
             if (again) {
-                const uint4 nb = ix.km1[((c.y >> km_r) + hop) & ((1u << ix.km1_b) - 1u)];
+                const uint4 nb = km1p[((c.y >> km_r) + hop) & ((1u << km1_b) - 1u)];
                 cell = match_cell(nb, ((c.y & km_rmask) << km_vb1) | (hop << (32u - KM1_HB)));
                 again = (cell & km_vmask) == km_vmask && ((nb.w >> (km_vb1 - 1u)) & 1u) != 0u;
             }
@@ -370,7 +386,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             uint32_t val = vid | (1u << 20); // a single posting of multiplicity 1, in the RefIndex::kv value format
             const bool hit = vid != km_vmask && c.t != 0xFFFFFFFFu; // else: a false positive of the bit filter, or a window past its read's last
             const bool zero = vid == km_vmask - 1u;
-            if (!(RK_KMER_ABL & 32) && hit && vid >= nref && !zero) val = ix.km1_vals[vid - nref]; // compound value (a few KB: L1-resident)
+            if (!(RK_KMER_ABL & 32) && hit && vid >= nref && !zero) val = km1v[vid - nref]; // compound value (a few KB: L1-resident)
             uint32_t rank = 0;
             bool multi = false;
             if ((RK_KMER_ABL & 2) ? (val == 0x12345u) : hit) {
@@ -465,8 +481,8 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                 const uint32_t sh = (P0 & 3u) << 1;
                 wl[s] = __builtin_amdgcn_alignbit(w.y, w.x, sh);
                 wh[s] = w.y >> sh;
-                const uint32_t core = KT == 16 ? wl[s] >> 6 : (wl[s] >> 6) & CMASK; // k = 16: the 13-mer is all of bits 6..31
-                fw[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(ix.kf4) + ((uint64_t)kf4_sector(core, ix.kf4_lg) << 4));
+                const uint32_t core = k == 16 ? wl[s] >> 6 : (wl[s] >> 6) & CMASK; // k = 16: the 13-mer is all of bits 6..31
+                fw[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(kf4p) + ((uint64_t)kf4_sector(core, kf4_lg) << 4));
             }
             // test + push.  has_invalid (a tile with a non-ACGT base, rare) runs its own copy of the code.
             bool stop = false;
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint32_t x = j == 0 ? wl[s] : __builtin_amdgcn_alignbit(wh[s], wl[s], 2 * j);
-                    if (KT < 16) x &= KMASK;
+                    if (k < 16) x &= KMASK;
                     const uint32_t h = kf4_h(x);
                     const uint32_t f = j == 0 ? fw[s].x : (j == 1 ? fw[s].y : (j == 2 ? fw[s].z : fw[s].w));
                     bool cand = (__builtin_amdgcn_ubfe(f, h >> 27, 1u) & __builtin_amdgcn_ubfe(f, h >> 22, 1u)) != 0u;
@@ -529,13 +545,16 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             wave_sync();
         }
 
+        } // k-mer sizes
+        wave_sync();
+
         // ---- phase 2: 16 lanes per read, or 8 when the tile holds more than four ------------------------------------------------
         {
             const int lsh = Tn > 4 ? 3 : 4, LPR = 1 << lsh; // wave-uniform
             const int g = lane >> lsh, sl = lane & (LPR - 1);
             for (int t = g; t < ((RK_KMER_ABL & 8) ? 0 : Tn); t += KW >> lsh) {
                 uint32_t* ct = cnt + (uint32_t)t * CW;
-                const int nmins = (int)rinfo[t].y - (int)nzero[t];
+                const int nmins = (int)nwtot[t] - (int)nzero[t];
                 // bottom-S selection matters, or the hit multiset overflowed: exact answer comes from the general path
                 const bool reroute = nmins > S || flags[t] != 0;
                 const uint32_t bk = best[t];
@@ -581,9 +600,10 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
     }
 }
 
-bool make_kmer_geom(KmerGeom& g, int maxlen, int nref, int expect_hits, int nw_per_read, int nq, int& cmode, bool& big) {
+// win_total: windows of a read of the hinted length, all k-mer sizes together (bounds every per-reference count)
+bool make_kmer_geom(KmerGeom& g, int maxlen, int nref, int expect_hits, int win_total, const int* nw_k, int nk, int nq, int& cmode, bool& big) {
     if (maxlen < 1) maxlen = 1;
-    cmode = nw_per_read <= 255 ? CM_DENSE8 : CM_DENSE16;
+    cmode = win_total <= 255 ? CM_DENSE8 : CM_DENSE16;
     const int clg = cmode == CM_DENSE8 ? 2 : 1;
     g.cwords = (nref + (1 << clg) - 1) >> clg;
     // Many references: a dense counter row per read would eat the LDS budget (and reference ids beyond 2048 would not fit at all),
@@ -610,15 +630,17 @@ bool make_kmer_geom(KmerGeom& g, int maxlen, int nref, int expect_hits, int nw_p
     }
     g.xcd = 1;
     g.L = maxlen;
-    g.gpr = (nw_per_read + 3) >> 2;
-    g.magic = g.gpr >= 2 ? 0xFFFFFFFFu / (uint32_t)g.gpr + 1u : 0u;
+    for (int j = 0; j < KM_MAX_KS; ++j) {
+        g.gpr[j] = j < nk ? (nw_k[j] + 3) >> 2 : 0;
+        g.magic[j] = g.gpr[j] >= 2 ? 0xFFFFFFFFu / (uint32_t)g.gpr[j] + 1u : 0u;
+    }
     return true;
 }
 
 template <int KT>
 hipError_t launch_k(int nq, int cmode, bool big, dim3 grid, hipStream_t st, const uint8_t* bases, const uint32_t* offs, uint32_t nreads,
-                    int S, const RefIndex& ix, int32_t* out4, const DevPolicy& pol, const KmerGeom& geo) {
-#define RK_KM_GO(NQ, CM, BIG) hipLaunchKernelGGL((k_classify_kmer<KT, NQ, CM, BIG>), grid, dim3(KW), 0, st, bases, offs, nreads, S, ix, out4, pol, geo)
+                    int S, const RefIndex& ix, const KmerSets& ksets, int32_t* out4, const DevPolicy& pol, const KmerGeom& geo) {
+#define RK_KM_GO(NQ, CM, BIG) hipLaunchKernelGGL((k_classify_kmer<KT, NQ, CM, BIG>), grid, dim3(KW), 0, st, bases, offs, nreads, S, ix, ksets, out4, pol, geo)
 #define RK_KM_CM(NQ, BIG)                                                                                    \
     do {                                                                                                     \
         if (cmode == CM_DENSE8) RK_KM_GO(NQ, CM_DENSE8, BIG);                                                \
@@ -641,22 +663,26 @@ bool classify_kmer_supported(int nref, int maxlen, int k) {
     return nref <= 16384 && maxlen <= 2 * 1024 - 15 && k >= KPRE_MIN_K && k <= 16;
 }
 
-hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, int k, int S, const RefIndex& ix,
+// ksets: the structures of every k-mer size of the run (n = 1: the compile-time-k kernels, whose structures are ix.kf4 / km1 too)
+hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KmerSets& ksets, int S, const RefIndex& ix,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st) {
     if (nreads == 0) return hipSuccess;
+    if (ksets.n < 1 || ksets.n > KM_MAX_KS) return hipErrorInvalidValue;
     const int nq = maxlen <= 1024 - 15 ? 1 : 2;
-    const int nw = num_windows(maxlen, k, pol.drop_last_window);
+    int nw_k[KM_MAX_KS] = {0}, win_total = 0;
+    for (int j = 0; j < ksets.n; ++j) { nw_k[j] = num_windows(maxlen, ksets.k[j], pol.drop_last_window); win_total += nw_k[j]; }
     KmerGeom geo;
     int cmode = 0;
     bool big = false;
-    if (!make_kmer_geom(geo, maxlen, ix.nref, expect_hits, nw, nq, cmode, big)) return hipErrorInvalidConfiguration;
+    if (!make_kmer_geom(geo, maxlen, ix.nref, expect_hits, win_total, nw_k, ksets.n, nq, cmode, big)) return hipErrorInvalidConfiguration;
     static const int xcd_env = getenv("RKMH_TILE_XCD") ? atoi(getenv("RKMH_TILE_XCD")) : -1;
     if (xcd_env >= 0) geo.xcd = xcd_env != 0;
     const uint32_t ntiles = (nreads + (uint32_t)geo.T - 1) / (uint32_t)geo.T;
     uint32_t grid = ntiles;
     grid = (grid + 7u) & ~7u; // whole rounds of the 8 XCDs: the virtual ids then cover [0, grid) exactly
-#define RK_KM_K(KT) case KT: return launch_k<KT>(nq, cmode, big, dim3(grid), st, bases, offs, nreads, S, ix, out4, pol, geo)
-    switch (k) {
+    if (ksets.n > 1) return launch_k<0>(nq, cmode, big, dim3(grid), st, bases, offs, nreads, S, ix, ksets, out4, pol, geo);
+#define RK_KM_K(KT) case KT: return launch_k<KT>(nq, cmode, big, dim3(grid), st, bases, offs, nreads, S, ix, ksets, out4, pol, geo)
+    switch (ksets.k[0]) {
 #ifndef RK_KMER_FAST_BUILD // tools/kmer_variants.sh: timing experiments compile the k = 16 kernels only
         RK_KM_K(8); RK_KM_K(9); RK_KM_K(10); RK_KM_K(11); RK_KM_K(12); RK_KM_K(13); RK_KM_K(14); RK_KM_K(15);
 #endif
