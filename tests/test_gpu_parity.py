@@ -1027,7 +1027,9 @@ def _ragged(qb, n, L, seed, lo=20):
 
 
 @pytest.mark.parametrize("ks,depth,L", [([16], True, 150), ([15], False, 150), ([12, 16], False, 100), ([15], True, 100), ([21], True, 150),
-                                        ([16], False, -150), ([16], True, -150), ([20], True, -100)])
+                                        ([16], False, -150), ([16], True, -150), ([20], True, -100),
+                                        ([12, 20], False, 100),          # several k, one of them outside 8..16: the hash-space multi-k kernel
+                                        ([12, 14, 16], False, -150)])    # several k in k-mer space, reads of unequal length
 def test_every_kernel_form_at_scale(orc, data_dir, ks, depth, L):
     """300 k reads through the fused kernel's other instantiations -- run-time k, several k, the masked (-M) form with a
     200 M-slot table -- against the oracle, three launches each.  (Randomized batches are a few hundred reads: too
@@ -1413,6 +1415,50 @@ def test_kmer_space_form_every_policy(orc, pave, k, fold, drop):
             reads.append(bytes(r))
         qb2, qo2 = orc.pack(reads)
         want = orc.classify_stream(qb2, qo2, [k], 1000, wsk, wln, policy=pol, threads=T)
+        got = c.classify(_pad(qb2), qo2)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, (len(bad), got[bad[:3]], want[bad[:3]])
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("ks,fold,drop", [([12, 16], 0, 1), ([8, 16], 1, 0), ([12, 14, 16], 0, 1), ([9, 10, 11, 12, 13, 14, 15, 16], 2, 1), ([16, 10], 0, 0)])
+def test_kmer_space_form_several_k(orc, pave, ks, fold, drop):
+    """Several k-mer sizes, each from 8 to 16 (the reference's `-k 12 -k 16` usage, rkmh.cpp:680-682): one filter + map per size, the
+    tile's windows walked once per size over the same per-read counters.  Active, and every row equal to the oracle on 150 bp reads,
+    on reads of unequal length with N / lower case and reads shorter than the sizes, for several fold / window policies and for the
+    largest number of sizes the ABI takes."""
+    import rkmh_amd
+    from rkmh_amd import synth
+    _, rb, ro = pave
+    T = min(16, os.cpu_count() or 1)
+    pol = orc.default_policy(fold=fold, drop_last_window=drop)
+    c = rkmh_amd.Context(0, fold=fold, drop_last_window=drop)
+    try:
+        c.set_references(rb, ro, ks, 1000)
+        active, found = c.kmer_form()
+        assert active and found > 1000
+        sk, ln = c.get_reference_sketches()
+        wsk, wln = orc.sketch_refs(rb, ro, ks, 1000, policy=pol, threads=T)
+        assert (sk == wsk).all() and (ln == wln).all()
+        qb, qo = synth.generate_reads_fast(rb, ro, 9000, 9000 + 40000)
+        want = orc.classify_stream(qb, qo, ks, 1000, wsk, wln, policy=pol, threads=T)
+        got = c.classify(_pad(qb), qo)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, (len(bad), got[bad[:3]], want[bad[:3]])
+        rng = np.random.default_rng(len(ks) * 10 + fold)
+        reads = []
+        for i in range(3000):
+            L = int(rng.integers(0, 170))
+            a = int(rng.integers(0, len(rb) - 400))
+            r = bytearray(bytes(rb[a: a + L]))
+            if i % 7 == 0 and L > 3:
+                r[int(rng.integers(0, L))] = ord("N")
+            if i % 11 == 0:
+                r = bytearray(bytes(r).lower())
+            reads.append(bytes(r))
+        qb2, qo2 = orc.pack(reads)
+        want = orc.classify_stream(qb2, qo2, ks, 1000, wsk, wln, policy=pol, threads=T)
         got = c.classify(_pad(qb2), qo2)
         bad = np.nonzero((got != want).any(axis=1))[0]
         assert len(bad) == 0, (len(bad), got[bad[:3]], want[bad[:3]])
