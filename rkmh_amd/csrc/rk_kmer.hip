@@ -33,7 +33,7 @@ constexpr int KW = 64;
 constexpr int KM_MAX_T = 8;          // reads per tile (phase 2 takes eight reads in one pass; the group -> read search is unrolled for it)
 constexpr int KM_MQ = 32;            // deferred multi-posting hits per drain (more are walked by their own lane)
 #ifndef RK_KMER_ABL
-#define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values
+#define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length
 #endif
 #ifndef RK_KMER_NT
 #define RK_KMER_NT 1 // the bases are read once: streaming loads keep them from evicting the filter and the map from L2
@@ -172,6 +172,10 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
     auto load_offsets = [&](uint32_t tl, uint32_t& a_, uint32_t& b_, uint32_t& o_) {
         const uint32_t r = tl * (uint32_t)T;
         const int n = tile_reads(tl);
+        if (RK_KMER_ABL & 64) { // timing experiment: reads of exactly geo.L bases starting at offset 0 -- no dependent offset load
+            a_ = r * (uint32_t)geo.L; b_ = (r + (uint32_t)n) * (uint32_t)geo.L; o_ = (r + (uint32_t)(lane <= n ? lane : n)) * (uint32_t)geo.L;
+            return;
+        }
         a_ = offs[r];
         b_ = offs[r + (uint32_t)n];
         o_ = offs[r + (uint32_t)(lane <= n ? lane : n)];
