@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -87,7 +88,18 @@ struct rk_counter {
     uint64_t slots;
     bool owned;
     int device; // copy of ctx->device: destroying a counter after its context must not touch the freed context
+    // the slot-partitioned count pass (rk_count.hip) adds to the table with plain read-modify-writes: passes into one table are
+    // chained (each waits for `last` on its stream), and they share the scratch arrays
+    DevBuf ws;
+    hipEvent_t last = nullptr;
+    bool last_set = false;
+    std::mutex mu;
 };
+// every other reader / writer of a table first waits for the count passes enqueued so far
+static int counter_settle(const rk_counter* k) {
+    if (k && k->last_set) HIPCHK(hipEventSynchronize(k->last));
+    return RK_OK;
+}
 
 struct Slot { // one half of the double-buffered classify pipeline
     PinBuf h_bases, h_offs, h_out;
@@ -669,22 +681,31 @@ extern "C" int rk_counter_create(rk_ctx* c, uint64_t slots, rk_counter** out) {
     if (e != hipSuccess) return fail(RK_ERR_NOMEM, "hipMalloc(%llu) for counter: %s", (unsigned long long)(slots * 4), hipGetErrorString(e));
     HIPCHK(hipMemsetAsync(d, 0, slots * 4, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
-    *out = new rk_counter{c, (int32_t*)d, slots, true, c->device};
+    rk_counter* k = new rk_counter();
+    k->ctx = c; k->d = (int32_t*)d; k->slots = slots; k->owned = true; k->device = c->device;
+    *out = k;
     return RK_OK;
 }
 extern "C" int rk_counter_wrap(rk_ctx* c, void* d, uint64_t slots, rk_counter** out) {
     if (!c || !out || !d || slots == 0) return fail(RK_ERR_ARG, "bad arguments");
-    *out = new rk_counter{c, (int32_t*)d, slots, false, c->device};
+    rk_counter* k = new rk_counter();
+    k->ctx = c; k->d = (int32_t*)d; k->slots = slots; k->owned = false; k->device = c->device;
+    *out = k;
     return RK_OK;
 }
 extern "C" void rk_counter_destroy(rk_counter* k) {
     if (!k) return;
-    if (k->owned) { hipError_t e = hipSetDevice(k->device); (void)e; e = hipFree(k->d); (void)e; }
+    hipError_t e = hipSetDevice(k->device); (void)e;
+    if (k->last_set) { e = hipEventSynchronize(k->last); (void)e; }
+    if (k->last) { e = hipEventDestroy(k->last); (void)e; }
+    k->ws.release();
+    if (k->owned) { e = hipFree(k->d); (void)e; }
     delete k;
 }
 extern "C" int rk_counter_clear(rk_counter* k) {
     if (!k) return fail(RK_ERR_ARG, "counter is NULL");
     RKCHK(set_dev(k->ctx));
+    RKCHK(counter_settle(k));
     HIPCHK(hipMemsetAsync(k->d, 0, k->slots * 4, k->ctx->st));
     HIPCHK(hipStreamSynchronize(k->ctx->st));
     return RK_OK;
@@ -697,8 +718,10 @@ static int counter_combine(rk_counter* dst, const rk_counter* src, bool add) {
     if (dst->slots != src->slots) return fail(RK_ERR_ARG, "counters of %llu and %llu slots", (unsigned long long)dst->slots, (unsigned long long)src->slots);
     if (dst == src || dst->d == src->d) return add ? fail(RK_ERR_ARG, "rk_counter_add of a table to itself") : RK_OK;
     RKCHK(set_dev(src->ctx));
+    RKCHK(counter_settle(src));
     HIPCHK(hipStreamSynchronize(src->ctx->st)); // whatever filled src on its own context's stream is complete
     RKCHK(set_dev(dst->ctx));
+    RKCHK(counter_settle(dst));
     hipStream_t st = dst->ctx->st;
     if (!add) { HIPCHK(hipMemcpyAsync(dst->d, src->d, src->slots * 4, hipMemcpyDefault, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
     if (dst->device == src->device) { HIPCHK(launch_counter_add(dst->d, src->d, dst->slots, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
@@ -724,6 +747,7 @@ extern "C" int rk_counter_copy(rk_counter* dst, const rk_counter* src) { return 
 extern "C" int rk_counter_increment(rk_counter* k, uint64_t key) {
     if (!k) return fail(RK_ERR_ARG, "counter is NULL");
     RKCHK(set_dev(k->ctx));
+    RKCHK(counter_settle(k));
     HIPCHK(launch_counter_inc(k->d, k->slots, key, k->ctx->st));
     HIPCHK(hipStreamSynchronize(k->ctx->st));
     return RK_OK;
@@ -731,6 +755,7 @@ extern "C" int rk_counter_increment(rk_counter* k, uint64_t key) {
 extern "C" int rk_counter_get(const rk_counter* k, uint64_t key, int32_t* out) {
     if (!k || !out) return fail(RK_ERR_ARG, "bad arguments");
     RKCHK(set_dev(k->ctx));
+    RKCHK(counter_settle(k));
     HIPCHK(hipMemcpy(out, k->d + (key % k->slots), 4, hipMemcpyDeviceToHost));
     return RK_OK;
 }
@@ -743,6 +768,7 @@ static int counter_save_impl(rk_counter* k, const char* path, const void* tag, u
     if (tag_len > 4096) return fail(RK_ERR_ARG, "tag too long");
     if (k->slots > 0xffffffffull) return fail(RK_ERR_LIMIT, "counter too large to serialise (slot index is 32 bit)");
     RKCHK(set_dev(k->ctx));
+    RKCHK(counter_settle(k));
     std::vector<int32_t> h((size_t)k->slots);
     HIPCHK(hipMemcpy(h.data(), k->d, k->slots * 4, hipMemcpyDeviceToHost));
     FILE* f = fopen(path, "wb");
@@ -765,6 +791,7 @@ static int counter_save_impl(rk_counter* k, const char* path, const void* tag, u
 static int counter_load_impl(rk_counter* k, const char* path, const void* tag, uint32_t tag_len) {
     if (!k || !path || (tag_len && !tag)) return fail(RK_ERR_ARG, "bad arguments");
     RKCHK(set_dev(k->ctx));
+    RKCHK(counter_settle(k));
     FILE* f = fopen(path, "rb");
     if (!f) return fail(RK_ERR_IO, "cannot read %s", path);
     char magic[6];
@@ -1217,8 +1244,40 @@ extern "C" int rk_set_depth_filter(rk_ctx* c, rk_counter* counter, int min_kmer_
 }
 
 // ---- the hot loop -------------------------------------------------------------------------------
+// The -M count pass in its slot-partitioned form (rk_count.hip): worth its fixed cost (six launches, two passes over a slot
+// array) for batches of millions of windows into tables that do not fit a few workgroups' LDS; RKMH_COUNT_BINS=1 / 0 forces it
+// on (any size: the tests) / off (one device atomic per window, 2.6e10/s)
+static int count_bins_env() {
+    const char* e = getenv("RKMH_COUNT_BINS"); // read per pass (a few launches each): tests switch it inside one process
+    return e && *e ? atoi(e) : -1;
+}
+static int count_partitioned(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nreads, uint32_t ml, int expect,
+                             rk_counter* k, uint64_t total_bases, hipStream_t st, bool* done) {
+    *done = false;
+    const int env = count_bins_env();
+    if (env == 0 || total_bases == 0 || !classify_tile_supported(0, (int)ml)) return RK_OK;
+    const uint64_t stride = (total_bases + 3) & ~3ull;
+    CountPlan pl;
+    if (stride >= (1ull << 31) || !count_plan(k->slots, stride * (uint64_t)c->ks.n, &pl)) return RK_OK;
+    if (env < 0 && (pl.n < ((uint64_t)4 << 20) || pl.nsub < 256)) return RK_OK;
+    std::lock_guard<std::mutex> lock(k->mu);
+    if (!k->last) HIPCHK(hipEventCreateWithFlags(&k->last, hipEventDisableTiming));
+    if (k->last_set) HIPCHK(hipStreamWaitEvent(st, k->last, 0)); // the previous pass into this table: scratch and sub-ranges are its
+    const size_t need = count_plan_scratch_bytes(pl);
+    if (need > k->ws.cap) { HIPCHK(hipDeviceSynchronize()); RKCHK(k->ws.reserve(need)); } // nothing may still be reading the old arrays
+    const CountScratch sc = count_plan_carve(pl, k->ws.p);
+    HIPCHK(launch_count_prepare(pl, sc, st));
+    HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix, k->d, k->slots, 0, 1,
+                                (int32_t*)sc.flat, c->pol, (int)ml, expect, st, (uint32_t)stride));
+    HIPCHK(launch_count_bins(pl, sc, k->d, st));
+    HIPCHK(hipEventRecord(k->last, st));
+    k->last_set = true;
+    *done = true;
+    return RK_OK;
+}
+
 static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nreads, void* d_out4,
-                        uint32_t max_read_len, int mode, rk_counter* count_into, hipStream_t st) {
+                        uint32_t max_read_len, int mode, rk_counter* count_into, hipStream_t st, uint64_t total_bases = 0) {
     if (nreads > 0xfffffff0ll) return fail(RK_ERR_LIMIT, "more than 2^32-16 reads in one device batch");
     if (((uintptr_t)d_bases & 3) != 0) return fail(RK_ERR_ARG, "d_bases must be 4-byte aligned");
     int32_t* counter = nullptr; uint64_t slots = 1; int min_occ = 0;
@@ -1227,13 +1286,20 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     uint32_t ml = max_read_len < 1 ? 1 : (max_read_len > (uint32_t)FUSED_MAXLEN ? (uint32_t)FUSED_MAXLEN : max_read_len);
     int expect = 0; // hits an error-free read is expected to score: sizes the kernel's per-read hit multiset
     for (int j = 0; j < c->ks.n; ++j) expect += (int)(c->density * (double)num_windows((int)ml, c->ks.k[j], c->pol.drop_last_window)) + 1;
+    if (mode == 1) {
+        bool done = false;
+        RKCHK(count_partitioned(c, d_bases, d_offs, nreads, ml, expect, count_into, total_bases, st, &done));
+        if (done) return RK_OK;
+        // atomic form: other passes into this table may still be adding with plain stores
+        if (count_into->last_set) HIPCHK(hipStreamWaitEvent(st, count_into->last, 0));
+    }
     // plain classification with the single k the exact k-mer map was enumerated for: the k-mer-space kernel (rk_kmer.hip)
     if (mode == 0 && !counter && c->ksets.n == c->ks.n && c->ksets.n >= 1 && classify_kmer_supported(c->ix.nref, (int)ml, c->ks.k[0]))
         HIPCHK(launch_classify_kmer((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ksets, c->S, c->ix,
                                     (int32_t*)d_out4, c->pol, (int)ml, expect, st));
     else if (classify_tile_supported(mode == 0 ? c->ix.nref : 0, (int)ml))
         HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
-                                    counter, slots, min_occ, mode, (int32_t*)d_out4, c->pol, (int)ml, expect, st));
+                                    counter, slots, min_occ, mode, mode == 1 ? nullptr : (int32_t*)d_out4, c->pol, (int)ml, expect, st)); // (a count pass given an array there writes slots to it)
     else if (mode == 0)
         HIPCHK(launch_fill_reroute((int32_t*)d_out4, (uint32_t)nreads, st)); // e.g. more than 16384 references: general path
     else
@@ -1241,10 +1307,11 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     return RK_OK;
 }
 
-static int device_max_len(rk_ctx* c, const void* d_offs, int64_t nreads, hipStream_t st, uint32_t* out) {
+static int device_max_len(rk_ctx* c, const void* d_offs, int64_t nreads, hipStream_t st, uint32_t* out, uint32_t* end_off = nullptr) {
     RKCHK(c->w_misc.reserve(16));
     HIPCHK(launch_max_len((const uint32_t*)d_offs, (uint32_t)nreads, c->w_misc.as<uint32_t>(), st));
     HIPCHK(hipMemcpyAsync(out, c->w_misc.p, 4, hipMemcpyDeviceToHost, st));
+    if (end_off) HIPCHK(hipMemcpyAsync(end_off, (const uint32_t*)d_offs + nreads, 4, hipMemcpyDeviceToHost, st)); // one past the last base
     HIPCHK(hipStreamSynchronize(st));
     return RK_OK;
 }
@@ -1340,11 +1407,11 @@ extern "C" int rk_count_batch_device(rk_ctx* c, const void* d_bases, const void*
     RKCHK(set_dev(c));
     if (nreads == 0) return RK_OK;
     hipStream_t st = (hipStream_t)hip_stream;
-    uint32_t ml = 0;
-    RKCHK(device_max_len(c, d_offs, nreads, st, &ml));
+    uint32_t ml = 0, end_off = 0;
+    RKCHK(device_max_len(c, d_offs, nreads, st, &ml, &end_off));
     if (ml > (uint32_t)FUSED_MAXLEN) return fail(RK_ERR_LIMIT, "rk_count_batch_device: reads longer than %d need rk_count_batch", FUSED_MAXLEN);
     if (c->ks.n == 0) return fail(RK_ERR_STATE, "k-mer sizes unknown: call rk_set_references first");
-    return fused_device(c, d_bases, d_offs, nreads, nullptr, ml, 1, counter, st);
+    return fused_device(c, d_bases, d_offs, nreads, nullptr, ml, 1, counter, st, end_off);
 }
 
 // double-buffered host pipeline around the fused kernel. mode 0 classify, mode 1 count.
@@ -1414,7 +1481,7 @@ static int host_pipeline(rk_ctx* c, const uint8_t* bases, const uint64_t* offset
         if (!src_pinned) { par_memcpy(s.h_bases.p, bases + b0, cb); hsrc = s.h_bases.p; }
         HIPCHK(hipMemcpyAsync(s.d_bases.p, hsrc, cb, hipMemcpyHostToDevice, s.st));
         HIPCHK(hipMemcpyAsync(s.d_offs.p, s.h_offs.p, (size_t)(cn + 1) * 4, hipMemcpyHostToDevice, s.st));
-        RKCHK(fused_device(c, s.d_bases.p, s.d_offs.p, cn, s.d_out.p, maxlen, mode, count_into, s.st));
+        RKCHK(fused_device(c, s.d_bases.p, s.d_offs.p, cn, s.d_out.p, maxlen, mode, count_into, s.st, cb));
         if (mode == 0) HIPCHK(hipMemcpyAsync(out_pinned ? (void*)(out4 + i0 * 4) : s.h_out.p, s.d_out.p, (size_t)cn * 16, hipMemcpyDeviceToHost, s.st));
         HIPCHK(hipEventRecord(s.done, s.st));
         s.first = i0; s.n = cn; s.busy = true;
@@ -1493,6 +1560,7 @@ extern "C" int rk_count_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* o
     bool any_long = false;
     for (int64_t i = 0; i < nreads; ++i) if (offsets[i + 1] - offsets[i] > (uint64_t)FUSED_MAXLEN) { any_long = true; break; }
     if (!any_long) return host_pipeline(c, bases, offsets, nreads, nullptr, 1, counter);
+    RKCHK(counter_settle(counter));
     GeneralCfg cfg; cfg.ks = c->ks; cfg.inc_counter = counter;
     GeneralOut none;
     return general_run(c, bases, nullptr, offsets, nreads, cfg, none);

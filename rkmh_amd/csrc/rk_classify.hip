@@ -103,6 +103,7 @@ struct TileGeom {
     int32_t tpb;        // consecutive tiles per workgroup
     int32_t xcd;        // 1: workgroups that share an XCD (blockIdx % 8, round-robin dispatch) take neighbouring tiles
     uint64_t slots_m;   // floor((2^64 - 1) / slots) of the -M counter table: hash % slots by Barrett reduction (mod_slots)
+    uint32_t slot_stride; // count pass that emits slots instead of counting (out4 = the flat array): entries per k-mer size
     int32_t magic_nw;   // windows (first k) of a read of the hinted length, and ...
     uint32_t magic;     // ... ceil(2^32 / magic_nw): the compact window -> read division of tiles made of such reads
 };
@@ -534,9 +535,15 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                     uint64_t h = 0;
                     if (it < nIt) {
                         // what happens to a window's canonical hash: the -M count / mask, the zero-hash tally of its read
-                        auto account = [&](uint64_t& hh, uint32_t tt) {
+                        auto account = [&](uint64_t& hh, uint32_t tt, uint32_t pp) {
                             if (MODE == 1) {
-                                if (pol.counter_counts_zero || hh != 0) atomicAdd(&counter[mod_slots(hh, slots, geo.slots_m)], 1);
+                                if (pol.counter_counts_zero || hh != 0) {
+                                    const uint64_t slot = mod_slots(hh, slots, geo.slots_m);
+                                    // slot-partitioned count (rk_count.hip): the window's slot goes to the flat array, indexed by
+                                    // the byte position of the window (tails keep the sentinel); no atomic here
+                                    if (out4) reinterpret_cast<uint32_t*>(out4)[(size_t)kk * geo.slot_stride + tstart + pp] = (uint32_t)slot;
+                                    else atomicAdd(&counter[slot], 1);
+                                }
                             } else {
                                 if (MODE == 2) { // mask_by_frequency, rkmh.cpp:916
                                     // `counter` is the KEEP bitmap here (rk_set_depth_filter: bit s = the count of slot s passes the
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                                 const uint32_t off = low ? s.fbase + p : B - (uint32_t)k - p;
                                 const uint64_t own = murmur_window<KT, FOLD>(img, off, k, pol.seed, pol.fold);
                                 const uint64_t oth = (uint64_t)__shfl_xor((long long)own, 32);
-                                if (low) { h = own < oth ? own : oth; account(h, t); }
+                                if (low) { h = own < oth ? own : oth; account(h, t, p); }
                             }
                         } else {
                         bool ok;
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                                     }
                                 }
                             }
-                            account(h, t);
+                            account(h, t, p);
                         }
                         }
                     }
@@ -798,7 +805,8 @@ bool classify_tile_supported(int nref, int maxlen) { return nref <= 16384 && max
 
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
-                                int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st) {
+                                int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st,
+                                uint32_t slot_stride) {
     if (nreads == 0) return hipSuccess;
     const TileKnobs& kn = knobs();
     int win_total = 0; // most windows any read of the batch can have (all k): bounds every per-reference count
@@ -817,6 +825,7 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     geo.tpb = tpb;
     geo.xcd = kn.xcd >= 0 ? (kn.xcd != 0) : 1;
     geo.slots_m = slots ? ~0ull / slots : 0;
+    geo.slot_stride = slot_stride;
     geo.magic_nw = num_windows(maxlen, ks.k[0], pol.drop_last_window);
     geo.magic = geo.magic_nw >= 2 ? 0xFFFFFFFFu / (uint32_t)geo.magic_nw + 1u : 0u;
     const bool k16 = (ks.n == 1 && ks.k[0] == 16);

@@ -109,7 +109,8 @@ bool classify_tile_supported(int nref, int maxlen);
 constexpr int KPRE_MIN_K = 8; // the k-mer-space kernel (rk_kmer.hip) exists for a single k in [KPRE_MIN_K, 16]
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
-                                int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st);
+                                int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st,
+                                uint32_t slot_stride = 0);
 // the k-mer-space kernel (rk_kmer.hip): plain classification with k-mer sizes from KPRE_MIN_K to 16 whose exact k-mer maps and group
 // filters were built (KmerSets: one per size; a single size runs the compile-time-k kernels, several the run-time-k one)
 bool classify_kmer_supported(int nref, int maxlen, int k);
@@ -123,6 +124,23 @@ hipError_t launch_mask_by_frequency(uint64_t* h, uint64_t n, const int32_t* coun
 hipError_t launch_count_distinct(const uint64_t* hashes, uint64_t n, uint64_t* table, uint64_t tsize, int32_t* counter,
                                  uint64_t slots, hipStream_t st);
 hipError_t launch_counter_inc(int32_t* counter, uint64_t slots, uint64_t key, hipStream_t st);
+// ---- the count pass without global atomics (rk_count.hip) ----
+constexpr int CB_THREADS = 1024;
+constexpr int CB_CHUNK = 16384;           // slots counting-sorted per step (64 KB of LDS)
+constexpr int CB_SUB_LG = 15;             // log2(slots per sub-range) = counters held in LDS (128 KB)
+constexpr int CB_MAX_BINS = 1024;
+constexpr uint32_t CB_NONE = 0xFFFFFFFFu; // "no window at this position"
+struct CountPlan {
+    uint64_t slots, n, span; // table size; entries of the slot array (multiple of 4); entries per span (multiple of CB_CHUNK)
+    uint32_t nsub, R, nb, magicR, G; // sub-ranges of 2^15 slots; sub-ranges per bin; bins; ceil(2^32 / R); spans
+};
+struct CountScratch { uint32_t *flat, *binned, *hist, *off, *total, *bin_start; };
+// false: this table / batch stays on the atomic form (>= 2^32 - 1 slots, >= 2^31 entries)
+bool count_plan(uint64_t slots, uint64_t n_entries, CountPlan* out);
+size_t count_plan_scratch_bytes(const CountPlan& pl);
+CountScratch count_plan_carve(const CountPlan& pl, void* ws);
+hipError_t launch_count_prepare(const CountPlan& pl, const CountScratch& s, hipStream_t st); // before the slot-emitting launch_classify_tile
+hipError_t launch_count_bins(const CountPlan& pl, const CountScratch& s, int32_t* counter, hipStream_t st); // after it
 hipError_t launch_counter_add(int32_t* dst, const int32_t* src, uint64_t n, hipStream_t st); // dst[i] += src[i]; both 16-byte aligned
 
 } // namespace rk

@@ -1010,6 +1010,71 @@ def test_count_pass_is_repeatable_under_load(data_dir, ragged):
         c.close()
 
 
+@pytest.mark.parametrize("slots,ks,ragged,unaligned", [(200000000, [16], False, False), (70000001, [20], True, False), (5000011, [12, 16], True, True),
+                                                        (1009, [16], False, False), (32768 * 1024 + 5, [15], True, True)])
+def test_count_pass_slot_partitioned_equals_atomic(data_dir, slots, ks, ragged, unaligned):
+    """Pass 1 of -M (rkmh.cpp:904-910) in its two device forms: one global atomic per window (RKMH_COUNT_BINS=0) and the
+    slot-partitioned form that counts in LDS and adds to the table with plain stores (rk_count.hip; RKMH_COUNT_BINS=1 forces it at
+    any size).  Both tables must equal the bincount of rk_hash_batch's hashes modulo the table size: one sub-range only (1009 slots),
+    one sub-range per bin, several per bin (200 M slots: 6), an exact multiple + 5 (a bin whose last sub-range is 5 slots), a table
+    that is only 4-byte aligned, several k-mer sizes, reads of unequal length with N runs and reads shorter than k.  Two batches
+    are counted into the same table from two streams without synchronising in between: the passes are chained by the library."""
+    import torch
+    import rkmh_amd
+    from rkmh_amd import api, synth
+    n, L = 150000, 100
+    dev = torch.device("cuda", 0)
+    c = rkmh_amd.Context(0)
+    try:
+        refs = api.parse_files([os.path.join(data_dir, "all_pave_ref.fa.gz")])
+        rb, ro = refs["bases"], refs["offsets"]
+        c.set_references(rb, ro, ks, 1000)
+        batches = []
+        for seed in (0, 1):
+            qb, qo = synth.generate_reads_fast(rb, ro, seed * n, (seed + 1) * n, read_len=L, threads=8)
+            if ragged:
+                qb, qo = _ragged(qb, n, L, seed=3 + seed)
+            batches.append((qb, qo))
+        want = torch.zeros(slots, dtype=torch.int64, device=dev)
+        for qb, qo in batches:
+            h, ho = c.hash_batch(_pad(qb), qo, ks)
+            want += torch.bincount(torch.from_numpy((h % np.uint64(slots)).astype(np.int64)).to(dev), minlength=slots)
+        want = want.to(torch.int32)
+        store = torch.zeros(slots + 4, dtype=torch.int32, device=dev)
+        table = store[1:slots + 1] if unaligned else store[:slots]
+        assert (table.data_ptr() % 16 != 0) == unaligned
+        cnt = rkmh_amd.Counter(c, slots=slots, device_ptr=table.data_ptr())
+        dbs = [(torch.from_numpy(_pad(qb)).to(dev), torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev)) for qb, qo in batches]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        try:
+            for form in ("1", "0", "1"):
+                os.environ["RKMH_COUNT_BINS"] = form
+                store.zero_()
+                torch.cuda.synchronize()
+                for (d_b, d_o), st in zip(dbs, streams):
+                    c.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt, stream=st.cuda_stream)
+                torch.cuda.synchronize()
+                ndiff = int((table != want).sum().item())
+                assert ndiff == 0, (form, ndiff)
+                assert int(store[0].item()) == 0 or not unaligned
+                assert int(store[slots + (1 if unaligned else 0):].abs().sum().item()) == 0   # nothing written past the table
+            # mixed: a partitioned pass followed at once by an atomic one on another stream
+            store.zero_()
+            torch.cuda.synchronize()
+            os.environ["RKMH_COUNT_BINS"] = "1"
+            c.count_device(dbs[0][0].data_ptr(), dbs[0][1].data_ptr(), n, cnt, stream=streams[0].cuda_stream)
+            os.environ["RKMH_COUNT_BINS"] = "0"
+            c.count_device(dbs[1][0].data_ptr(), dbs[1][1].data_ptr(), n, cnt, stream=streams[1].cuda_stream)
+            torch.cuda.synchronize()
+            assert int((table != want).sum().item()) == 0
+        finally:
+            os.environ.pop("RKMH_COUNT_BINS", None)
+        cnt.destroy()
+    finally:
+        c.close()
+
+
 def _ragged(qb, n, L, seed, lo=20):
     """Cuts equal-length synthetic reads to unequal lengths (lo..L, 1 % shorter than any k), adds N runs and lower case."""
     rng = np.random.default_rng(seed)

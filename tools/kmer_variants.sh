@@ -10,7 +10,7 @@ for v in "$@"; do
   cf=""; envs=""
   for w in $v; do case $w in ENV:*) envs="$envs ${w#ENV:}";; *) cf="$cf $w";; esac; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DRK_KMER_FAST_BUILD $cf -c rkmh_amd/csrc/rk_kmer.hip -o rkmh_amd/csrc/rk_kmer.o 2>&1 | grep -i "error" 
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o rkmh_amd/lib/librkmh_amd.so rkmh_amd/csrc/rk_kernels.o rkmh_amd/csrc/rk_classify.o rkmh_amd/csrc/rk_kmer.o rkmh_amd/csrc/rk_call.o rkmh_amd/csrc/rk_api.o rkmh_amd/csrc/rk_parse.o rkmh_amd/csrc/rk_synth.o -lz -lpthread
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o rkmh_amd/lib/librkmh_amd.so rkmh_amd/csrc/rk_kernels.o rkmh_amd/csrc/rk_classify.o rkmh_amd/csrc/rk_kmer.o rkmh_amd/csrc/rk_count.o rkmh_amd/csrc/rk_call.o rkmh_amd/csrc/rk_api.o rkmh_amd/csrc/rk_parse.o rkmh_amd/csrc/rk_synth.o -lz -lpthread
   r=$(env $envs python3 bench.py --steps 100 --warmup 20 --cpu-seconds 0 --no-host-path --e2e-reads 0 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('%.4f ms' % d['roofline']['kernel_ms'])")
   valu=""
   if [ -n "$KMER_PMC" ]; then
