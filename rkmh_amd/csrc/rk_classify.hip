@@ -790,6 +790,19 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
     int best = 1;
     for (int T = 1; T <= tmax; ++T)
         if (fill[T] >= best_fill - 0.025) { best = T; break; }
+    // A small tile that fills its steps well still pays the per-tile work (staging, phase 2, the prefetch ramp: about 2.2 steps'
+    // worth, measured) once per FEW reads: k = 22 .. 30 at 150 bp (<= 128 windows per read: one read fills two steps to 99 %) ran
+    // one read per tile at 1.67 ms per 1 M reads; four per tile take 1.05 ms.  So a fill-chosen tile below four reads is re-examined
+    // with that cost, tiles beyond four reads carrying the ~4 % per read they measured slower by.
+    if (best < 4) {
+        auto cost = [&](int T) {
+            const int nw = T * win_per_read;
+            return ((double)((nw + WAVE - 1) / WAVE) + 2.2) / (double)T * (1.0 + 0.04 * (double)(T > 4 ? T - 4 : 0));
+        };
+        int alt = best;
+        for (int T = best + 1; T <= tmax && T <= 8; ++T) if (cost(T) < cost(alt)) alt = T;
+        if (cost(alt) < 0.95 * cost(best)) best = alt;
+    }
     if (kn.tile_t > 0) best = kn.tile_t;
     if (best > 16) best = 16;
     if (best < 1) best = 1;
@@ -864,6 +877,11 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
         else if (!ix.pre || !pre_masked) RK_LAUNCH(KT, 2, FOLD);                                                     \
         else RK_LAUNCH(KT, 4, FOLD);                                                                                 \
     } while (0)
+#ifdef RK_TILE_ONLY_K // experiment builds (tools/classify_variants.sh): one compile-time k, seconds to compile
+    if (ks.n != 1 || ks.k[0] != RK_TILE_ONLY_K) return hipErrorInvalidValue;
+    RK_LAUNCH_M(RK_TILE_ONLY_K, -1);
+    return hipGetLastError();
+#endif
     // single k of 12, 20 (the reference's other documented settings), 21 or 31: window length known at compile time, runtime fold
     if (ks.n == 1 && ks.k[0] == 12) RK_LAUNCH_M(12, -1);
     else if (ks.n == 1 && ks.k[0] == 20) RK_LAUNCH_M(20, -1);

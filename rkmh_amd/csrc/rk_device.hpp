@@ -222,25 +222,43 @@ __device__ __forceinline__ TailMasks make_tail_masks(int k) {
     }
     return t;
 }
-__device__ __forceinline__ uint64_t canonical_rt(const uint32_t* fwd, uint32_t af, const uint32_t* rc, uint32_t ar, int k,
+// NB >= 0: the number of whole 16-byte blocks is known at compile time (the block loop unrolls and the first block takes the
+// constant-folded form); NB < 0: any number of blocks
+template <int NB>
+__device__ __forceinline__ uint64_t canonical_nb(const uint32_t* fwd, uint32_t af, const uint32_t* rc, uint32_t ar, int k,
                                                  const TailMasks& tm, uint32_t seed, int fold) {
     uint64_t f1 = seed, f2 = seed, r1 = seed, r2 = seed;
-    const int nblocks = k >> 4;
-    for (int b = 0; b < nblocks; ++b) {
-        const rk_u32x4 wf = lds_load16_unaligned(fwd, af);
-        const rk_u32x4 wr = lds_load16_unaligned(rc, ar);
-        mm_block(f1, f2, (uint64_t)wf.x | ((uint64_t)wf.y << 32), (uint64_t)wf.z | ((uint64_t)wf.w << 32));
-        mm_block(r1, r2, (uint64_t)wr.x | ((uint64_t)wr.y << 32), (uint64_t)wr.z | ((uint64_t)wr.w << 32));
-        af += 16; ar += 16;
+    if constexpr (NB >= 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const rk_u32x4 wf = lds_load16_unaligned(fwd, af);
+            const rk_u32x4 wr = lds_load16_unaligned(rc, ar);
+            if (b == 0) {
+                mm_block_first(f1, f2, seed, join64(wf.x, wf.y), join64(wf.z, wf.w));
+                mm_block_first(r1, r2, seed, join64(wr.x, wr.y), join64(wr.z, wr.w));
+            } else {
+                mm_block(f1, f2, join64(wf.x, wf.y), join64(wf.z, wf.w));
+                mm_block(r1, r2, join64(wr.x, wr.y), join64(wr.z, wr.w));
+            }
+            af += 16; ar += 16;
+        }
+    } else {
+        for (int b = 0; b < (k >> 4); ++b) {
+            const rk_u32x4 wf = lds_load16_unaligned(fwd, af);
+            const rk_u32x4 wr = lds_load16_unaligned(rc, ar);
+            mm_block(f1, f2, join64(wf.x, wf.y), join64(wf.z, wf.w));
+            mm_block(r1, r2, join64(wr.x, wr.y), join64(wr.z, wr.w));
+            af += 16; ar += 16;
+        }
     }
     if (tm.rem) {
         const rk_u32x4 wf = lds_load16_unaligned(fwd, af);
         const rk_u32x4 wr = lds_load16_unaligned(rc, ar);
-        uint64_t fk1 = (uint64_t)(wf.x & tm.m[0]) | ((uint64_t)(wf.y & tm.m[1]) << 32);
-        uint64_t rk1 = (uint64_t)(wr.x & tm.m[0]) | ((uint64_t)(wr.y & tm.m[1]) << 32);
+        uint64_t fk1 = join64(wf.x & tm.m[0], wf.y & tm.m[1]);
+        uint64_t rk1 = join64(wr.x & tm.m[0], wr.y & tm.m[1]);
         if (tm.rem > 8) {
-            uint64_t fk2 = (uint64_t)(wf.z & tm.m[2]) | ((uint64_t)(wf.w & tm.m[3]) << 32);
-            uint64_t rk2 = (uint64_t)(wr.z & tm.m[2]) | ((uint64_t)(wr.w & tm.m[3]) << 32);
+            uint64_t fk2 = join64(wf.z & tm.m[2], wf.w & tm.m[3]);
+            uint64_t rk2 = join64(wr.z & tm.m[2], wr.w & tm.m[3]);
             fk2 *= MM_C2; fk2 = rotl64(fk2, 33); fk2 *= MM_C1; f2 ^= fk2;
             rk2 *= MM_C2; rk2 = rotl64(rk2, 33); rk2 *= MM_C1; r2 ^= rk2;
         }
@@ -250,6 +268,15 @@ __device__ __forceinline__ uint64_t canonical_rt(const uint32_t* fwd, uint32_t a
     const uint64_t f = mm_finish<-1>(f1, f2, (uint32_t)k, fold);
     const uint64_t r = mm_finish<-1>(r1, r2, (uint32_t)k, fold);
     return f < r ? f : r;
+}
+__device__ __forceinline__ uint64_t canonical_rt(const uint32_t* fwd, uint32_t af, const uint32_t* rc, uint32_t ar, int k,
+                                                 const TailMasks& tm, uint32_t seed, int fold) {
+    // k is wave-uniform: one scalar branch picks the unrolled form of the common sizes (k = 16 .. 31: one block, 32 .. 47: two)
+    const int nb = k >> 4;
+    if (nb == 1) return canonical_nb<1>(fwd, af, rc, ar, k, tm, seed, fold);
+    if (nb == 2) return canonical_nb<2>(fwd, af, rc, ar, k, tm, seed, fold);
+    if (nb == 0) return canonical_nb<0>(fwd, af, rc, ar, k, tm, seed, fold);
+    return canonical_nb<-1>(fwd, af, rc, ar, k, tm, seed, fold);
 }
 
 // ---- per-dword (4 bases) SWAR helpers -------------------------------------------------------

@@ -598,14 +598,22 @@ __global__ __launch_bounds__(256) void k_max_len(const uint32_t* __restrict__ of
         m = l > m ? l : m;
     }
     m = (uint32_t)wave_max_i32((int)m);
-    if ((threadIdx.x & 63) == 0) atomicMax(d_max, m);
+    // one atomic per block, and only from blocks that would raise the value: atomics on ONE address are served one at a time
+    // (8192 of them took 96 us for 1 M reads)
+    __shared__ uint32_t wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) m = wm[i] > m ? wm[i] : m;
+        if (m > __hip_atomic_load(d_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d_max, m);
+    }
 }
 hipError_t launch_max_len(const uint32_t* offs, uint32_t nreads, uint32_t* d_max, hipStream_t st) {
     hipError_t e = hipMemsetAsync(d_max, 0, 4, st);
     if (e != hipSuccess) return e;
     if (nreads == 0) return hipSuccess;
     uint32_t grid = (nreads + 255) / 256;
-    if (grid > 2048) grid = 2048;
+    if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(k_max_len, dim3(grid), dim3(256), 0, st, offs, nreads, d_max);
     return hipGetLastError();
 }

@@ -126,7 +126,10 @@ hipError_t launch_count_distinct(const uint64_t* hashes, uint64_t n, uint64_t* t
 hipError_t launch_counter_inc(int32_t* counter, uint64_t slots, uint64_t key, hipStream_t st);
 // ---- the count pass without global atomics (rk_count.hip) ----
 constexpr int CB_THREADS = 1024;
-constexpr int CB_CHUNK = 16384;           // slots counting-sorted per step (64 KB of LDS)
+#ifndef RK_CB_CHUNK
+#define RK_CB_CHUNK 16384
+#endif
+constexpr int CB_CHUNK = RK_CB_CHUNK;     // slots counting-sorted per step (64 KB of LDS); a multiple of 4096
 constexpr int CB_SUB_LG = 15;             // log2(slots per sub-range) = counters held in LDS (128 KB)
 constexpr int CB_MAX_BINS = 1024;
 constexpr uint32_t CB_NONE = 0xFFFFFFFFu; // "no window at this position"

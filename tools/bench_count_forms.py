@@ -1,5 +1,5 @@
 """The -M count pass (pass 1, rkmh.cpp:904-910) in its two device forms, 1 M reads of 150 bp, tables of several sizes.
-Usage: python tools/bench_count_forms.py [k ...]"""
+Usage: [SLOTS=200000000,...] [FORMS=0,1] [REPS=10] python tools/bench_count_forms.py [k ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,9 +16,9 @@ st = torch.cuda.Stream()
 reps = int(os.environ.get("REPS", "10"))
 for k in [int(a) for a in sys.argv[1:]] or [16, 20]:
     ctx.set_references(rb, ro, [k], 1000)
-    for slots in (200000000, 25000000, 10000000):
+    for slots in [int(x) for x in os.environ.get("SLOTS", "200000000,25000000,10000000").split(",")]:
         row = []
-        for form in ("0", "1"):
+        for form in os.environ.get("FORMS", "0,1").split(","):
             os.environ["RKMH_COUNT_BINS"] = form
             cnt = api.Counter(ctx, slots)
             for _ in range(3):
@@ -33,5 +33,5 @@ for k in [int(a) for a in sys.argv[1:]] or [16, 20]:
             st.synchronize()
             row.append(e0.elapsed_time(e1) / reps)
             cnt.destroy()
-        print("k=%d slots=%-10d: atomic form %.3f ms, slot-partitioned form %.3f ms per 1 M reads" % (k, slots, row[0], row[1]), flush=True)
+        print("k=%d slots=%-10d: %s ms per 1 M reads (forms %s; 0 = one atomic per window, 1 = slot-partitioned)" % (k, slots, ", ".join("%.3f" % r for r in row), os.environ.get("FORMS", "0,1")), flush=True)
 os.environ.pop("RKMH_COUNT_BINS", None)
