@@ -186,7 +186,11 @@ int rk_set_kmer_form(rk_ctx* ctx, int enable);
  * filter after pass 1 (rk_count_batch*, and after any all-reduce of the table), and again if the table changes later. */
 int rk_set_depth_filter(rk_ctx* ctx, rk_counter* counter, int min_kmer_occ);
 
-/* Pass 1 of the -M path (src/rkmh.cpp:904-910): hash every read and increment the counter. */
+/* Pass 1 of the -M path (src/rkmh.cpp:904-910): hash every read and increment the counter.
+ * Passes into ONE counter are ordered by the library (each waits on its stream for the previous one: large batches add their
+ * counts with plain stores, not atomics), whatever streams they are given; rk_counter_get / _clear / _add / _copy / _save /
+ * _increment and rk_set_depth_filter wait for the passes enqueued so far.  A caller that reads the table through
+ * rk_counter_device_ptr() synchronises with the pass's stream itself, as before. */
 int rk_count_batch(rk_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, rk_counter* counter);
 int rk_count_batch_device(rk_ctx* ctx, const void* d_bases, const void* d_offsets_u32, int64_t nreads,
                           rk_counter* counter, void* hip_stream);
