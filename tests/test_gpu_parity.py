@@ -968,6 +968,25 @@ def test_randomized_differential(orc, seed):
             bad = np.nonzero((got != want).any(axis=1))[0]
             assert len(bad) == 0, ("-M", seed, ks, S, bad[:5], got[bad[:5]], want[bad[:5]])
             cnt.destroy()
+        if seed % 4 == 0:                                     # pass 1 in both device forms (rk_count.hip): identical tables
+            import torch
+            slots = int(rng.choice([1, 97, 32768, 32769, 100003, 5000000]))
+            tabs = []
+            try:
+                for form in ("0", "1"):
+                    os.environ["RKMH_COUNT_BINS"] = form
+                    t = torch.zeros(slots + 8, dtype=torch.int32, device="cuda")
+                    cnt = rkmh_amd.Counter(c, slots=slots, device_ptr=t.data_ptr() + 4 * (seed % 8 // 4))
+                    c.count_batch(_pad(qb), qo, cnt)
+                    c.count_batch(_pad(qb), qo, cnt)          # twice: the second pass adds to a table that is not zero
+                    cnt.destroy()
+                    tabs.append(t.cpu().numpy())
+            finally:
+                os.environ.pop("RKMH_COUNT_BINS", None)
+            assert (tabs[0] == tabs[1]).all(), ("count forms", seed, ks, slots, int((tabs[0] != tabs[1]).sum()))
+            h, _ = c.hash_batch(_pad(qb), qo, ks)
+            off = seed % 8 // 4
+            assert int(tabs[0][off:off + slots].sum()) == 2 * len(h) and tabs[0][:off].sum() == 0 and tabs[0][off + slots:].sum() == 0
     finally:
         c.close()
 
