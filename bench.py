@@ -94,9 +94,17 @@ def e2e_stream(n, L, rb, ro, synth):
             if best is None or dt < best:
                 best, stages = dt, [l for l in r.stderr.decode().splitlines() if l.startswith("[rkmh timing]")]
         lines = sum(1 for _ in open(tsv, "rb"))
-        return {"value": n / best, "unit": "reads/s", "reads": n, "fastq_bytes": size, "wall_s": best, "output_lines": lines,
-                "stages": [l[len("[rkmh timing] "):].strip() for l in stages],
-                "note": "bin/rkmh stream -k 16 -s 1000 on a generated FASTQ, whole process: start-up + reference sketches + parser + PCIe + kernel + TSV"}
+        res = {"value": n / best, "unit": "reads/s", "reads": n, "fastq_bytes": size, "wall_s": best, "output_lines": lines,
+               "stages": [l[len("[rkmh timing] "):].strip() for l in stages],
+               "note": "bin/rkmh stream -k 16 -s 1000 on a generated FASTQ, whole process: start-up + reference sketches + parser + PCIe + kernel + TSV"}
+        # the same file four times over (-f x 4): what a longer input does to the fixed start-up / tear-down share, and the marginal
+        # rate of the pipeline ((4 - 1) n reads in the extra time)
+        t = time.perf_counter()
+        r = subprocess.run([exe, "stream", "-r", ref] + ["-f", fq] * 4 + ["-k", "16", "-s", "1000"], stdout=open(tsv, "wb"), stderr=subprocess.PIPE)
+        dt4 = time.perf_counter() - t
+        if r.returncode == 0 and dt4 > best:
+            res["x4"] = {"reads": 4 * n, "wall_s": dt4, "value": 4 * n / dt4, "marginal_reads_per_s": 3 * n / (dt4 - best)}
+        return res
     finally:
         for x in (fq, tsv):
             try:
