@@ -91,13 +91,16 @@ struct rk_counter {
     // the slot-partitioned count pass (rk_count.hip) adds to the table with plain read-modify-writes: passes into one table are
     // chained (each waits for `last` on its stream), and they share the scratch arrays
     DevBuf ws;
-    hipEvent_t last = nullptr;
+    hipEvent_t last = nullptr;        // the latest slot-partitioned pass (plain stores): every later pass waits for it
     bool last_set = false;
+    hipEvent_t last_atomic = nullptr; // the latest atomic-form pass: only a slot-partitioned pass has to wait for it
+    bool last_atomic_set = false;
     std::mutex mu;
 };
 // every other reader / writer of a table first waits for the count passes enqueued so far
 static int counter_settle(const rk_counter* k) {
     if (k && k->last_set) HIPCHK(hipEventSynchronize(k->last));
+    if (k && k->last_atomic_set) HIPCHK(hipEventSynchronize(k->last_atomic));
     return RK_OK;
 }
 
@@ -697,7 +700,9 @@ extern "C" void rk_counter_destroy(rk_counter* k) {
     if (!k) return;
     hipError_t e = hipSetDevice(k->device); (void)e;
     if (k->last_set) { e = hipEventSynchronize(k->last); (void)e; }
+    if (k->last_atomic_set) { e = hipEventSynchronize(k->last_atomic); (void)e; }
     if (k->last) { e = hipEventDestroy(k->last); (void)e; }
+    if (k->last_atomic) { e = hipEventDestroy(k->last_atomic); (void)e; }
     k->ws.release();
     if (k->owned) { e = hipFree(k->d); (void)e; }
     delete k;
@@ -1263,6 +1268,7 @@ static int count_partitioned(rk_ctx* c, const void* d_bases, const void* d_offs,
     std::lock_guard<std::mutex> lock(k->mu);
     if (!k->last) HIPCHK(hipEventCreateWithFlags(&k->last, hipEventDisableTiming));
     if (k->last_set) HIPCHK(hipStreamWaitEvent(st, k->last, 0)); // the previous pass into this table: scratch and sub-ranges are its
+    if (k->last_atomic_set) HIPCHK(hipStreamWaitEvent(st, k->last_atomic, 0)); // atomics still landing would race with the plain adds
     const size_t need = count_plan_scratch_bytes(pl);
     if (need > k->ws.cap) { HIPCHK(hipDeviceSynchronize()); RKCHK(k->ws.reserve(need)); } // nothing may still be reading the old arrays
     const CountScratch sc = count_plan_carve(pl, k->ws.p);
@@ -1291,19 +1297,26 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
         RKCHK(count_partitioned(c, d_bases, d_offs, nreads, ml, expect, count_into, total_bases, st, &done));
         if (done) return RK_OK;
         // atomic form: other passes into this table may still be adding with plain stores
+        std::lock_guard<std::mutex> lock(count_into->mu);
         if (count_into->last_set) HIPCHK(hipStreamWaitEvent(st, count_into->last, 0));
+        if (!classify_tile_supported(0, (int)ml)) return fail(RK_ERR_LIMIT, "count pass: batch not supported by the fused kernel");
+        HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
+                                    counter, slots, min_occ, 1, nullptr, c->pol, (int)ml, expect, st)); // (given an array there, it would write slots to it)
+        // atomic passes may overlap each other; a later slot-partitioned pass must not overlap this one
+        if (!count_into->last_atomic) HIPCHK(hipEventCreateWithFlags(&count_into->last_atomic, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(count_into->last_atomic, st));
+        count_into->last_atomic_set = true;
+        return RK_OK;
     }
     // plain classification with the single k the exact k-mer map was enumerated for: the k-mer-space kernel (rk_kmer.hip)
-    if (mode == 0 && !counter && c->ksets.n == c->ks.n && c->ksets.n >= 1 && classify_kmer_supported(c->ix.nref, (int)ml, c->ks.k[0]))
+    if (!counter && c->ksets.n == c->ks.n && c->ksets.n >= 1 && classify_kmer_supported(c->ix.nref, (int)ml, c->ks.k[0]))
         HIPCHK(launch_classify_kmer((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ksets, c->S, c->ix,
                                     (int32_t*)d_out4, c->pol, (int)ml, expect, st));
-    else if (classify_tile_supported(mode == 0 ? c->ix.nref : 0, (int)ml))
+    else if (classify_tile_supported(c->ix.nref, (int)ml))
         HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
-                                    counter, slots, min_occ, mode, mode == 1 ? nullptr : (int32_t*)d_out4, c->pol, (int)ml, expect, st)); // (a count pass given an array there writes slots to it)
-    else if (mode == 0)
-        HIPCHK(launch_fill_reroute((int32_t*)d_out4, (uint32_t)nreads, st)); // e.g. more than 16384 references: general path
+                                    counter, slots, min_occ, 0, (int32_t*)d_out4, c->pol, (int)ml, expect, st));
     else
-        return fail(RK_ERR_LIMIT, "count pass: batch not supported by the fused kernel");
+        HIPCHK(launch_fill_reroute((int32_t*)d_out4, (uint32_t)nreads, st)); // e.g. more than 16384 references: general path
     return RK_OK;
 }
 

@@ -1087,6 +1087,15 @@ def test_count_pass_slot_partitioned_equals_atomic(data_dir, slots, ks, ragged, 
             c.count_device(dbs[1][0].data_ptr(), dbs[1][1].data_ptr(), n, cnt, stream=streams[1].cuda_stream)
             torch.cuda.synchronize()
             assert int((table != want).sum().item()) == 0
+            # ... and the other way round: atomics still landing when the plain adds would start
+            store.zero_()
+            torch.cuda.synchronize()
+            os.environ["RKMH_COUNT_BINS"] = "0"
+            c.count_device(dbs[0][0].data_ptr(), dbs[0][1].data_ptr(), n, cnt, stream=streams[0].cuda_stream)
+            os.environ["RKMH_COUNT_BINS"] = "1"
+            c.count_device(dbs[1][0].data_ptr(), dbs[1][1].data_ptr(), n, cnt, stream=streams[1].cuda_stream)
+            torch.cuda.synchronize()
+            assert int((table != want).sum().item()) == 0
         finally:
             os.environ.pop("RKMH_COUNT_BINS", None)
         cnt.destroy()
