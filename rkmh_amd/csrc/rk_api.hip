@@ -281,6 +281,28 @@ static bool is_pinned_host(const void* p, size_t bytes) {
     return b.type == hipMemoryTypeHost;
 }
 
+// Page-locks a caller's pageable buffer for the duration of one call (hipHostRegister of memory that is already touched takes
+// 2-3 ms per 256 MB on the MI355X host, measured: tools/ubench/host_register.hip -- a tenth of the staging copy it replaces), so the
+// DMA engines read / write it in place.  Fails quietly (read-only mappings, a page shared with another registration, a platform
+// limit): the caller then takes the staging path.  RKMH_HOST_REGISTER=0 disables.
+struct ScopedHostRegister {
+    void* base = nullptr;
+    bool ok = false;
+    static bool enabled() {
+        static const bool on = [] { const char* e = getenv("RKMH_HOST_REGISTER"); return !(e && *e == '0'); }();
+        return on;
+    }
+    ScopedHostRegister(const void* p, size_t bytes, size_t min_bytes) {
+        if (!p || bytes < min_bytes || !enabled()) return;
+        const uintptr_t lo = (uintptr_t)p & ~(uintptr_t)4095, hi = ((uintptr_t)p + bytes + 4095) & ~(uintptr_t)4095;
+        if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterPortable) == hipSuccess) { base = (void*)lo; ok = true; }
+        else (void)hipGetLastError();
+    }
+    ~ScopedHostRegister() { if (ok) { hipError_t e = hipHostUnregister(base); (void)e; } }
+    ScopedHostRegister(const ScopedHostRegister&) = delete;
+    ScopedHostRegister& operator=(const ScopedHostRegister&) = delete;
+};
+
 // Host -> device copy of a pageable buffer through the context's two pinned staging buffers (the same ones the fused
 // host pipeline uses): the CPU fills one while the DMA engine drains the other.  hipMemcpyAsync straight from pageable
 // memory runs at a fraction of the link rate and blocks the caller for the whole transfer.
@@ -1436,8 +1458,13 @@ static int host_pipeline(rk_ctx* c, const uint8_t* bases, const uint64_t* offset
     RKCHK(set_dev(c));
     const int64_t MAX_READS = 1 << 21;
     const uint64_t MAX_BASES = 1ull << 29;
-    const bool src_pinned = nreads > 0 && is_pinned_host(bases + offsets[0], (size_t)(offsets[nreads] - offsets[0]) + 4);
-    const bool out_pinned = mode == 0 && nreads > 0 && is_pinned_host(out4, (size_t)nreads * 16);
+    bool src_pinned = nreads > 0 && is_pinned_host(bases + offsets[0], (size_t)(offsets[nreads] - offsets[0]) + 4);
+    bool out_pinned = mode == 0 && nreads > 0 && is_pinned_host(out4, (size_t)nreads * 16);
+    // pageable buffers of some size are page-locked for this call instead of being copied through the staging buffers
+    ScopedHostRegister reg_src(nreads > 0 && !src_pinned ? bases + offsets[0] : nullptr, nreads > 0 ? (size_t)(offsets[nreads] - offsets[0]) + 4 : 0, (size_t)8 << 20);
+    ScopedHostRegister reg_out(mode == 0 && nreads > 0 && !out_pinned ? out4 : nullptr, (size_t)nreads * 16, (size_t)4 << 20);
+    src_pinned = src_pinned || reg_src.ok;
+    out_pinned = out_pinned || reg_out.ok;
     int64_t i0 = 0, nflag = 0;
     int which = 0;
     auto drain = [&](Slot& s) -> int {

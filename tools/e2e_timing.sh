@@ -27,8 +27,13 @@ with open("/tmp/e2e_reads.fq", "wb") as f:
         f.write(rec.tobytes())
 print("generated", n, "reads in %.1f s" % (time.time() - t))
 PY
-for rep in 1 2; do
-  time env RKMH_TIMING=1 bin/rkmh stream -r tests/golden/data/all_pave_ref.fa.gz -f /tmp/e2e_reads.fq -k 16 -s 1000 > /tmp/e2e_out.tsv
+# E2E_VARIANTS="NAME=V,NAME2=V2 NAME=W ...": one timed pair of runs per entry (comma-separated environment settings)
+for v in ${E2E_VARIANTS:-default}; do
+  echo "== $v"
+  envs=$(echo $v | tr ',' ' '); [ "$v" = default ] && envs=""
+  for rep in 1 2; do
+    /usr/bin/time -f "wall %e s user %U s sys %S s" env RKMH_TIMING=1 $envs bin/rkmh stream -r tests/golden/data/all_pave_ref.fa.gz -f /tmp/e2e_reads.fq -k 16 -s 1000 > /tmp/e2e_out.tsv
+  done
 done
 wc -l /tmp/e2e_out.tsv; nproc; cat /sys/fs/cgroup/cpu.max
 rm -f /tmp/e2e_reads.fq /tmp/e2e_out.tsv
