@@ -11,11 +11,13 @@
 #include "../../include/rkmh_amd.h"
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -680,6 +682,33 @@ static int hand_over(Batch& b, rk_seqset* out) {
 
 extern "C" {
 
+// CPUs this process may actually use: the affinity mask and the cgroup quota (a 256-thread host that grants a container 16 CPUs
+// reports 256 from hardware_concurrency)
+static int granted_cpus() {
+    static const int n = [] {
+        long v = (long)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const long a = CPU_COUNT(&set); if (a > 0 && (v <= 0 || a < v)) v = a; }
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0};
+            long period = 0;
+            if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+                const long c = (atol(q) + period - 1) / period;
+                if (c > 0 && (v <= 0 || c < v)) v = c;
+            }
+            fclose(f);
+        } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { // cgroup v1
+            long quota = -1, period = 0;
+            if (fscanf(g, "%ld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%ld", &period) != 1) period = 0; fclose(h); }
+            if (quota > 0 && period > 0) { const long c = (quota + period - 1) / period; if (v <= 0 || c < v) v = c; }
+        }
+        return (int)(v > 0 ? v : 8);
+    }();
+    return n;
+}
+
 int rk_reader_open(const char* path, rk_reader** out) {
     if (!path || !out) return perr(RK_ERR_ARG, "bad arguments");
     rk_reader* r = new rk_reader();
@@ -687,7 +716,10 @@ int rk_reader_open(const char* path, rk_reader** out) {
     {
         const char* e = getenv("RKMH_PARSE_THREADS");
         long v = e ? atol(e) : 0;
-        r->nthreads = (int)(v > 0 ? (v > 64 ? 64 : v) : 8);
+        // default: three quarters of the CPUs granted, 4 .. 16 (the classify and formatting threads of a stream run need the
+        // rest; measured on 16 CPUs: 16 M reads' main loop 0.38 s with 8 parser threads, 0.32 s with 12, 0.34 s with 16)
+        const long dflt = std::min<long>(16, std::max<long>(4, (long)granted_cpus() * 3 / 4));
+        r->nthreads = (int)(v > 0 ? (v > 64 ? 64 : v) : dflt);
     }
     if (const char* e = getenv("RKMH_PARSE_BLOCK_KB")) { // testing knob: small blocks exercise cut/carry/merge
         long v = atol(e);

@@ -129,7 +129,28 @@ template <typename V> struct QueueT {
     void finish() { std::lock_guard<std::mutex> l(m); done = true; cv.notify_all(); }
 };
 typedef QueueT<rk_seqset> Queue;
-struct Classified { rk_seqset reads; std::vector<int32_t> out4; int64_t seq = 0; };
+// Result rows of the streaming path live in a few recycled page-locked buffers (rk_host_alloc): a fresh 16 MB vector per batch is
+// zero-filled and page-faulted by the host each time, and the library would have to page-lock or stage it (8 of the 14 ms a
+// 1 M-read batch spent in its classify stage)
+struct OutPool {
+    std::mutex m;
+    std::vector<std::pair<int32_t*, size_t>> free_; // (buffer, rows it holds)
+    int32_t* get(size_t rows, size_t* cap) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].second >= rows) { int32_t* p = free_[i].first; *cap = free_[i].second; free_.erase(free_.begin() + (long)i); return p; }
+        }
+        size_t want = rows + rows / 4 + 4096;
+        void* p = nullptr;
+        if (rk_host_alloc(want * 16, &p) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); exit(1); }
+        *cap = want;
+        return (int32_t*)p;
+    }
+    void put(int32_t* p, size_t cap) { if (p) { std::lock_guard<std::mutex> l(m); free_.emplace_back(p, cap); } }
+    ~OutPool() { for (auto& f : free_) rk_host_free(f.first); }
+};
+struct Classified { rk_seqset reads; int32_t* out4 = nullptr; size_t out_cap = 0; int64_t seq = 0; };
 struct Numbered { rk_seqset reads; int64_t seq = 0; };
 
 static inline char* put_int(char* w, int v) {
@@ -410,6 +431,7 @@ static int main_stream(int argc, char** argv) {
         if (q.cap < 2 * group.size()) { std::lock_guard<std::mutex> l(q.m); q.cap = 2 * group.size(); q.cv.notify_all(); }
         QueueT<Classified> done_q;
         done_q.cap = 2 * group.size() + 2;
+        OutPool out_pool;
         std::thread writer([&] { // lines leave in read order: one writer, batches by number
             Classified c;
             std::string wbuf;
@@ -419,7 +441,8 @@ static int main_stream(int argc, char** argv) {
                 waiting.emplace(c.seq, std::move(c));
                 for (auto it = waiting.find(next); it != waiting.end(); it = waiting.find(next)) {
                     double a = now_s();
-                    emit_lines(refs, it->second.reads, it->second.out4.data(), o, wbuf);
+                    emit_lines(refs, it->second.reads, it->second.out4, o, wbuf);
+                    out_pool.put(it->second.out4, it->second.out_cap);
                     rk_seqset_free(&it->second.reads);
                     t_emit += now_s() - a;
                     waiting.erase(it);
@@ -437,8 +460,8 @@ static int main_stream(int argc, char** argv) {
                 double b = now_s();
                 Classified c;
                 c.reads = nb.reads; c.seq = nb.seq;
-                c.out4.resize((size_t)c.reads.nseq * 4);
-                if (rk_classify_batch(group.ctx[d], c.reads.bases, c.reads.offsets, c.reads.nseq, c.out4.data()) != RK_OK) { werr[d] = rk_last_error(); break; }
+                c.out4 = out_pool.get((size_t)c.reads.nseq, &c.out_cap);
+                if (rk_classify_batch(group.ctx[d], c.reads.bases, c.reads.offsets, c.reads.nseq, c.out4) != RK_OK) { werr[d] = rk_last_error(); break; }
                 double c2 = now_s();
                 done_q.push(std::move(c));
                 std::lock_guard<std::mutex> l(tm);

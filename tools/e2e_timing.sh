@@ -32,7 +32,7 @@ for v in ${E2E_VARIANTS:-default}; do
   echo "== $v"
   envs=$(echo $v | tr ',' ' '); [ "$v" = default ] && envs=""
   for rep in 1 2; do
-    /usr/bin/time -f "wall %e s user %U s sys %S s" env RKMH_TIMING=1 $envs bin/rkmh stream -r tests/golden/data/all_pave_ref.fa.gz -f /tmp/e2e_reads.fq -k 16 -s 1000 > /tmp/e2e_out.tsv
+    time env RKMH_TIMING=1 $envs bin/rkmh stream -r tests/golden/data/all_pave_ref.fa.gz -f /tmp/e2e_reads.fq -k 16 -s 1000 > /tmp/e2e_out.tsv
   done
 done
 wc -l /tmp/e2e_out.tsv; nproc; cat /sys/fs/cgroup/cpu.max
