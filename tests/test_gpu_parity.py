@@ -1103,6 +1103,56 @@ def test_count_pass_slot_partitioned_equals_atomic(data_dir, slots, ks, ragged, 
         c.close()
 
 
+def test_count_pass_slot_partitioned_degenerate_batches(ctx, pave):
+    """The slot-partitioned count pass on batches that stress its binning: no window at all (every read shorter than k), every
+    window the same k-mer (poly-A reads: one slot receives 1.7 M increments, one bin receives every entry, the LDS rank counters of
+    the counting sort run up to the chunk size), and two k-mers alternating.  Tables equal the atomic form's and the closed form."""
+    import torch
+    import rkmh_amd
+    _, rb, ro = pave
+    ctx.set_references(rb, ro, [16], 1000)
+    slots = 50000017
+    dev = torch.device("cuda", 0)
+
+    def run(reads):
+        qb = np.frombuffer(b"".join(reads), np.uint8)
+        qo = np.zeros(len(reads) + 1, np.int64)
+        np.cumsum([len(r) for r in reads], out=qo[1:])
+        d_b = torch.from_numpy(_pad(qb)).to(dev)
+        d_o = torch.from_numpy(qo).to(torch.int32).to(dev)
+        tabs = []
+        for form in ("0", "1"):
+            os.environ["RKMH_COUNT_BINS"] = form
+            t = torch.zeros(slots, dtype=torch.int32, device=dev)
+            cnt = rkmh_amd.Counter(ctx, slots=slots, device_ptr=t.data_ptr())
+            ctx.count_device(d_b.data_ptr(), d_o.data_ptr(), len(reads), cnt)
+            torch.cuda.synchronize()
+            cnt.destroy()
+            tabs.append(t)
+        assert bool((tabs[0] == tabs[1]).all())
+        return tabs[1]
+
+    try:
+        t = run([b"ACGTACGTACG"] * 5000 + [b""] * 10 + [b"ACGTTGCAACGTTGC"] * 100)      # 11 and 15 bases: no 16-mer
+        assert int(t.sum().item()) == 0
+        n, L = 20000, 100
+        t = run([b"A" * L] * n)
+        nw = int(ctx.calc_hashes(b"A" * L, [16]).shape[0])
+        h = int(ctx.calc_hashes(b"A" * 16 + b"C", [16])[0]) if nw else 0
+        assert nw in (84, 85) and int(t.sum().item()) == n * nw and int(t.max().item()) == n * nw
+        assert int(t[int(np.uint64(ctx.calc_hashes(b"A" * L, [16])[0]) % np.uint64(slots))].item()) == n * nw and h != 0
+        t = run([b"AC" * 50] * n)                                                           # two k-mers (ACAC.., CACA..), canonical forms
+        hs = ctx.calc_hashes(b"AC" * 50, [16])
+        want = {}
+        for v in hs:
+            want[int(np.uint64(v) % np.uint64(slots))] = want.get(int(np.uint64(v) % np.uint64(slots)), 0) + n
+        assert int(t.sum().item()) == n * len(hs)
+        for sl, c in want.items():
+            assert int(t[sl].item()) == c
+    finally:
+        os.environ.pop("RKMH_COUNT_BINS", None)
+
+
 def _ragged(qb, n, L, seed, lo=20):
     """Cuts equal-length synthetic reads to unequal lengths (lo..L, 1 % shorter than any k), adds N runs and lower case."""
     rng = np.random.default_rng(seed)
