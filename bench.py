@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the timed steps rotate over (>= 4 x 170 MB defeats the 256 MiB Infinity Cache)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive rk_classify_batch figure (N=1 only)")
+    ap.add_argument("--no-depth-filter", action="store_true", help="skip the -M figures (count pass + masked classify at 200 M slots; N=1 only)")
     ap.add_argument("--e2e-reads", type=int, default=16000000, help="reads of the generated FASTQ for the bin/rkmh stream end-to-end figure (0 disables; N=1 only)")
     a = ap.parse_args()
 
@@ -305,9 +306,34 @@ def main():
             res["host_path"] = {"value": nb * n / dtp, "unit": "reads/s", "gbytes_per_s_h2d": nb * n * (L + 4) / dtp / 1e9, "reads": nb * n,
                                 "pageable_value": nb * n / dt, "pageable_gbytes_per_s": nb * n * (L + 4) / dt / 1e9,
                                 "note": "rk_classify_batch, PCIe inclusive (H2D + kernel + D2H overlapped chunk by chunk): value = from page-locked "
-                                        "host buffers (rk_host_alloc), read by DMA in place; pageable_value = from ordinary memory through the "
-                                        "library's pinned staging buffers"}
+                                        "host buffers (rk_host_alloc), read by DMA in place; pageable_value = from ordinary memory, which the "
+                                        "library page-locks for the call (hipHostRegister) or, failing that, copies through its staging buffers"}
             del pb, po
+        if world == 1 and not a.no_depth_filter:
+            # -M (rkmh.cpp:904-917) on the first batch, the reference's 200 M-slot table: pass 1 (count every window's hash) and the
+            # masked classification that reads it back.  Informational: never the reported value.
+            slots = 200000000
+            cnt = api.Counter(ctx, slots)
+
+            def timed(f, reps=10, warm=3):
+                for _ in range(warm):
+                    f()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    f()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / reps
+            count_ms = timed(lambda: ctx.count_device(d_bs[0].data_ptr(), d_os[0].data_ptr(), n, cnt, stream=stream))
+            ctx.set_depth_filter(cnt, 2)
+            masked_ms = timed(lambda: ctx.classify_device(d_bs[0].data_ptr(), d_os[0].data_ptr(), n, d_outs[0].data_ptr(), max_read_len=L, stream=stream))
+            ctx.set_depth_filter(None, 0)
+            cnt.destroy()
+            res["depth_filter"] = {"slots": slots, "count_pass_ms": count_ms, "masked_classify_ms": masked_ms, "reads": n,
+                                   "note": "-M on one resident 1 M-read batch: pass 1 without global atomics (slots binned by table range and counted "
+                                           "in LDS, rk_count.hip) and the masked hash-space classification (one keep bit per window from a 25 MB bitmap)"}
         if world == 1 and a.e2e_reads > 0:
             res["e2e"] = e2e_stream(a.e2e_reads, L, rb, ro, synth)
         print(json.dumps(res))

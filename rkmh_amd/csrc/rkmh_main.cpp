@@ -641,12 +641,10 @@ static int main_filter(int argc, char** argv) {
         }
         rk_reader_close(rd);
     }
-    fflush(stdout);
-    for (size_t d = 0; d < group.size(); ++d) CK(rk_set_depth_filter(group.ctx[d], nullptr, 0));
-    for (rk_counter* k : cnts) rk_counter_destroy(k);
-    rk_seqset_free(&refs);
-    group.destroy();
-    return 0;
+    fflush(stdout); fflush(stderr);
+    // everything is written: the process ends here, as in main_stream -- freeing a genome-sized reference set, the contexts and the
+    // HIP runtime's exit handlers took 0.7 s of a 2.5 s C4 run and produce nothing
+    _exit(0);
 }
 
 // call: main_call, src/rkmh.cpp:1455-1904.  The GPU returns one record per candidate k-mer that passed the depth

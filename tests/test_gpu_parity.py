@@ -429,6 +429,8 @@ def test_bench_json_contract(root):
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "bit-exact" in cb["oracle_check"]
+    assert d["host_path"]["value"] > 0 and d["host_path"]["pageable_value"] > 0 and d["e2e"]["output_lines"] == d["e2e"]["reads"]
+    assert d["depth_filter"]["count_pass_ms"] > 0 and d["depth_filter"]["masked_classify_ms"] > 0 and d["depth_filter"]["slots"] == 200000000
 
 
 def test_bench_two_ranks_launched_like_the_driver(root):
