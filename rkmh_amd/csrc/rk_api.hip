@@ -1089,11 +1089,25 @@ static int build_index(rk_ctx* c) {
         }
         if (ok) {
             // group filter of k_classify_kmer (kf4_sector in rk_device.hpp): every found k-mer in both orientations under its four
-            // alignments, two bits each in dword j of the 16-byte sector its alignment-j core selects; sized for ~10 entries per
-            // sector (about 5 of a dword's 32 bits set: one window in ~45 of those that hit nothing passes by chance)
+            // alignments, two bits each in dword j of the 16-byte sector its alignment-j core selects (at ~10 entries per sector about 5 of
+            // a dword's 32 bits are set: one window in ~45 of those that hit nothing passes by chance)
+            // Size: a sparser filter sends fewer windows to the exact map, a smaller one (together with the map) stays in the 4 MB
+            // of an XCD's L2 -- and the second matters more until the panel is far beyond any cache.  Measured (1 M reads, ms; entries
+            // per sector 5-10 / 10-20): 161 k keys (C2) 0.337 / 0.357 (both fit); 239 k keys (266 references, C3) 0.425 / 0.345 (6 MB
+            // / 4 MB with the map); 360 k 0.584 / 0.457; 540 k 0.655 / 0.594; 900 k 0.787 / 0.745; 1.8 M 0.896 / 0.906; 3.6 M 0.947 /
+            // 0.995.  So: 5-10 entries per sector when filter + map then fit the L2 or the panel has more than 1.5 M keys, else 10-20.
             uint32_t lg = 8;
-            static const long kf4_entries = getenv("RKMH_KF4_ENTRIES") ? atol(getenv("RKMH_KF4_ENTRIES")) : 10;
-            while (((size_t)1 << lg) * (size_t)(kf4_entries > 0 ? kf4_entries : 10) < (size_t)found * 8 && lg < 24) ++lg;
+            static const long kf4_entries = getenv("RKMH_KF4_ENTRIES") ? atol(getenv("RKMH_KF4_ENTRIES")) : 0;
+            if (kf4_entries > 0) { // forced density (A/B runs)
+                while (((size_t)1 << lg) * (size_t)kf4_entries < (size_t)found * 8 && lg < 24) ++lg;
+            } else {
+                while (((size_t)1 << lg) * 20 < (size_t)found * 8 && lg < 24) ++lg;    // 10-20 entries per sector
+                static const double km1_load_est = getenv("RKMH_KM1_LOAD") ? atof(getenv("RKMH_KM1_LOAD")) : 0.65;
+                uint32_t be = 2u * (uint32_t)k < 12u ? 2u * (uint32_t)k : 12u;           // the map's size, as its builder below will choose it
+                while (be < 2u * (uint32_t)k && be < 28 && (double)found > km1_load_est * 4.0 * (double)((size_t)1 << be)) ++be;
+                const size_t map_bytes = (size_t)16 << be, sparse_bytes = (size_t)16 << (lg + 1);
+                if (lg < 24 && (sparse_bytes + map_bytes <= ((size_t)4 << 20) || found > 1500000u)) ++lg; // 5-10 entries per sector
+            }
             std::vector<uint32_t> f4((size_t)4 << lg, 0u);
             const uint32_t cm = kf4_core_mask(k);
             for (uint32_t i = 0; i < found; ++i) {
