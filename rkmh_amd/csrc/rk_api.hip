@@ -1046,7 +1046,7 @@ static int build_index(rk_ctx* c) {
     // (or 0), found by exhaustive enumeration on the device -- see k_enum_kmers -- goes into the group filter and the exact map of
     // k_classify_kmer (rk_kmer.hip), one pair per size.  RKMH_KMER_PREFILTER=0 turns them off (A/B runs, tests).
     c->ix.kpk = 0; c->kpre_inserted = 0;
-    c->ix.kf4 = nullptr; c->ix.kf4_lg = 0; c->ix.km1 = nullptr; c->ix.km1_b = 0; c->ix.km1_vals = nullptr;
+    c->ix.kf4 = nullptr; c->ix.kf4_n = 0; c->ix.km1 = nullptr; c->ix.km1_b = 0; c->ix.km1_vals = nullptr;
     memset(&c->ksets, 0, sizeof c->ksets);
     static const int kmer_env = getenv("RKMH_KMER_PREFILTER") ? atoi(getenv("RKMH_KMER_PREFILTER")) : -1;
     const int kmer_mode = kmer_env >= 0 ? kmer_env : (pre_mode > 0 ? 1 : 0);
@@ -1091,31 +1091,36 @@ static int build_index(rk_ctx* c) {
             // group filter of k_classify_kmer (kf4_sector in rk_device.hpp): every found k-mer in both orientations under its four
             // alignments, two bits each in dword j of the 16-byte sector its alignment-j core selects (at ~10 entries per sector about 5 of
             // a dword's 32 bits are set: one window in ~45 of those that hit nothing passes by chance)
-            // Size: a sparser filter sends fewer windows to the exact map, a smaller one (together with the map) stays in the 4 MB
-            // of an XCD's L2 -- and the second matters more until the panel is far beyond any cache.  Measured (1 M reads, ms; entries
-            // per sector 5-10 / 10-20): 161 k keys (C2) 0.337 / 0.357 (both fit); 239 k keys (266 references, C3) 0.425 / 0.345 (6 MB
-            // / 4 MB with the map); 360 k 0.584 / 0.457; 540 k 0.655 / 0.594; 900 k 0.787 / 0.745; 1.8 M 0.896 / 0.906; 3.6 M 0.947 /
-            // 0.995.  So: 5-10 entries per sector when filter + map then fit the L2 or the panel has more than 1.5 M keys, else 10-20.
-            uint32_t lg = 8;
-            static const long kf4_entries = getenv("RKMH_KF4_ENTRIES") ? atol(getenv("RKMH_KF4_ENTRIES")) : 0;
-            if (kf4_entries > 0) { // forced density (A/B runs)
-                while (((size_t)1 << lg) * (size_t)kf4_entries < (size_t)found * 8 && lg < 24) ++lg;
-            } else {
-                while (((size_t)1 << lg) * 20 < (size_t)found * 8 && lg < 24) ++lg;    // 10-20 entries per sector
+            // Size (any sector count, kf4_sector scales the hashed core): a sparser filter sends fewer windows to the exact map, a
+            // smaller one leaves more of an XCD's 4 MB of L2 to the map and the streaming bases -- and the second matters more until
+            // the panel is far beyond any cache.  Measured optimum, entries per sector (tools/kf4_density.sh, 1 M reads; ms at the
+            // optimum / at the 5-10 a power-of-two size would give): 161 k keys (C2, 1 MB map) 12-13.5 (0.321 / 0.335); 239 k keys
+            // (266 references, C3; 2 MB map) 12.5-16 (0.343 / 0.425); 270 k 14 (0.353 / 0.433); 360 k (4 MB map) 20 (0.397 / 0.584);
+            // 540 k 20-24 (0.592 / 0.655); 900 k (8 MB map) 14 (0.747 / 0.787); 1.8 M <= 10 (0.894); 3.6 M <= 10 (0.947).
+            uint32_t nsect = 0;
+            {
+                static const double kf4_entries = getenv("RKMH_KF4_ENTRIES") ? atof(getenv("RKMH_KF4_ENTRIES")) : 0.0; // forced density (A/B runs)
                 static const double km1_load_est = getenv("RKMH_KM1_LOAD") ? atof(getenv("RKMH_KM1_LOAD")) : 0.65;
                 uint32_t be = 2u * (uint32_t)k < 12u ? 2u * (uint32_t)k : 12u;           // the map's size, as its builder below will choose it
                 while (be < 2u * (uint32_t)k && be < 28 && (double)found > km1_load_est * 4.0 * (double)((size_t)1 << be)) ++be;
-                const size_t map_bytes = (size_t)16 << be, sparse_bytes = (size_t)16 << (lg + 1);
-                if (lg < 24 && (sparse_bytes + map_bytes <= ((size_t)4 << 20) || found > 1500000u)) ++lg; // 5-10 entries per sector
+                const size_t map_bytes = (size_t)16 << be;
+                // (k = 16 with s = 2000, 322 k keys: 20 entries 0.646, 13 entries 0.665; k = 12, whose 9-base cores crowd the sectors
+                // unevenly: 6-8 entries 0.477, 10 entries 0.504, 13 entries 0.555; k = 13: 9-13 entries 0.40, 6 entries 0.435)
+                double e = k <= 12 ? 7.0 : (k == 13 ? 10.0 : 13.0);
+                if (found > 1500000u) e = 8.0;                                             // far beyond any cache: fewer false candidates win
+                else if (found > 300000u && map_bytes <= ((size_t)4 << 20)) e = 20.0;      // map and filter fight for the L2: smallest useful filter
+                if (kf4_entries > 0.0) e = kf4_entries;
+                const double want = (double)found * 8.0 / e;
+                nsect = want < 256.0 ? 256u : (want > 16777216.0 ? 16777216u : ((uint32_t)want + 7u) & ~7u);
             }
-            std::vector<uint32_t> f4((size_t)4 << lg, 0u);
+            std::vector<uint32_t> f4((size_t)4 * nsect, 0u);
             const uint32_t cm = kf4_core_mask(k);
             for (uint32_t i = 0; i < found; ++i) {
                 const uint32_t v = list[2 * (size_t)i], rv = packed_revcomp(v, k);
                 for (int o = 0; o < (rv == v ? 1 : 2); ++o) {
                     const uint32_t X = o ? rv : v, bits = kf4_bits(X);
                     for (uint32_t j = 0; j < 4; ++j)
-                        f4[(size_t)kf4_sector((X >> (2 * (3 - j))) & cm, lg) * 4 + j] |= bits;
+                        f4[(size_t)kf4_sector((X >> (2 * (3 - j))) & cm, nsect) * 4 + j] |= bits;
                 }
             }
             // exact map (KM1_C in rk_device.hpp).  A key whose bucket is full moves on by up to 2^KM1_HB - 1 buckets; if that is not
@@ -1177,14 +1182,14 @@ static int build_index(rk_ctx* c) {
             DevBuf& d_kf4 = c->d_kf4[(size_t)kidx];
             RKCHK(d_kf4.reserve(f4.size() * 4));
             HIPCHK(hipMemcpy(d_kf4.p, f4.data(), f4.size() * 4, hipMemcpyHostToDevice));
-            if (c->ksets.km1[kidx]) { c->ksets.kf4[kidx] = d_kf4.as<uint4>(); c->ksets.kf4_lg[kidx] = lg; c->ksets.k[kidx] = k; ++built; }
+            if (c->ksets.km1[kidx]) { c->ksets.kf4[kidx] = d_kf4.as<uint4>(); c->ksets.kf4_n[kidx] = nsect; c->ksets.k[kidx] = k; ++built; }
             else ok = false;
         }
         if (!ok) break; // one size without its structures: the hash-space kernels serve the run
     }
     if (built == c->ks.n && built > 0) { // every size has its filter and map
         c->ksets.n = built;
-        c->ix.kf4 = c->ksets.kf4[0]; c->ix.kf4_lg = c->ksets.kf4_lg[0]; c->ix.km1 = c->ksets.km1[0]; c->ix.km1_b = c->ksets.km1_b[0];
+        c->ix.kf4 = c->ksets.kf4[0]; c->ix.kf4_n = c->ksets.kf4_n[0]; c->ix.km1 = c->ksets.km1[0]; c->ix.km1_b = c->ksets.km1_b[0];
         c->ix.km1_vals = c->ksets.km1_vals[0]; c->ix.kpk = (uint32_t)c->ksets.k[0];
     } else memset(&c->ksets, 0, sizeof c->ksets);
     // a full bottom-S sketch of uniform hashes keeps the fraction (largest kept hash / 2^64) of the k-mers

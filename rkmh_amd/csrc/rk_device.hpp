@@ -103,7 +103,15 @@ __device__ __forceinline__ uint64_t min_swapped(uint64_t f, uint64_t r) {
 // pairs of every found k-mer X whose alignment-j core (X >> 2 * (3 - j)) maps to the sector.  Keys are entered in BOTH orientations
 // (X and its reverse complement), so the window loop never forms a reverse complement; the drain canonicalises the few candidates.
 __host__ __device__ __forceinline__ uint32_t kf4_core_mask(int k) { return k > 3 ? (1u << (2 * (k - 3))) - 1u : 0u; }
-__host__ __device__ __forceinline__ uint32_t kf4_sector(uint32_t core, uint32_t lg) { return (core * 0x85EBCA6Bu) >> (32u - lg); } // 1 <= lg <= 31
+// sector of a core among n sectors (any n, not only powers of two: the filter is sized against the L2 in steps finer than x 2):
+// the hashed core scaled to [0, n) by the high half of a 32 x 32 product (for n = 2^lg this is the old `>> (32 - lg)`)
+__host__ __device__ __forceinline__ uint32_t kf4_sector(uint32_t core, uint32_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(core * 0x85EBCA6Bu, n);
+#else
+    return (uint32_t)(((uint64_t)(core * 0x85EBCA6Bu) * (uint64_t)n) >> 32);
+#endif
+}
 // the two bits of a k-mer inside its dword: the TOP ten bits of x * odd constant (mod 2^32), which every bit of x reaches -- a
 // window that differs from a found k-mer only in a base outside the core (a sequencing error in the flank) lands in the same
 // sector and must not land on the same bits (the middle bits of the 64-bit product, one instruction cheaper, fail that for the
@@ -442,9 +450,9 @@ struct RefIndex {
     // sketch, and k_classify_kmer does not hash it at all.  They are only built when every index key has exactly one preimage
     // (the enumeration checks); otherwise the hash-space kernels serve the panel.
     uint32_t kpk;     // the k they were enumerated for
-    // forward-strand group filter of k_classify_kmer (rk_kmer.hip; see kf4_sector above): 2^kf4_lg sectors of 16 bytes
+    // forward-strand group filter of k_classify_kmer (rk_kmer.hip; see kf4_sector above): kf4_n sectors of 16 bytes
     const uint4* kf4;
-    uint32_t kf4_lg;
+    uint32_t kf4_n;
     const uint4* km1;      // single-probe exact map (see KM1_C above), 2^km1_b buckets
     uint32_t km1_b;
     const uint32_t* km1_vals;
@@ -471,7 +479,7 @@ struct KmerSets {
     const uint4* kf4[KM_MAX_KS];
     const uint4* km1[KM_MAX_KS];
     const uint32_t* km1_vals[KM_MAX_KS];
-    uint32_t kf4_lg[KM_MAX_KS], km1_b[KM_MAX_KS];
+    uint32_t kf4_n[KM_MAX_KS], km1_b[KM_MAX_KS];
 };
 // filter word and bit pair of a hash: the word from the low bits of the high hash word (like the bucket), the two bits
 // from bits 14..23 of the low word (bits 0..13 are the fingerprint)

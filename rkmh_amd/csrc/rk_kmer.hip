@@ -286,7 +286,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         const uint4* const kf4p = KT ? ix.kf4 : ksets.kf4[kk];
         const uint4* const km1p = KT ? ix.km1 : ksets.km1[kk];
         const uint32_t* const km1v = KT ? ix.km1_vals : ksets.km1_vals[kk];
-        const uint32_t kf4_lg = KT ? ix.kf4_lg : ksets.kf4_lg[kk], km1_b = KT ? ix.km1_b : ksets.km1_b[kk];
+        const uint32_t kf4_n = KT ? ix.kf4_n : ksets.kf4_n[kk], km1_b = KT ? ix.km1_b : ksets.km1_b[kk];
         wave_sync(); // the previous size's pass is over (first pass: the image is staged)
         uint32_t nw = 0, ng = 0;
         if (lane < Tn) { nw = (uint32_t)num_windows((int)len, k, pol.drop_last_window); ng = (nw + 3u) >> 2; }
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                 wl[s] = __builtin_amdgcn_alignbit(w.y, w.x, sh);
                 wh[s] = w.y >> sh;
                 const uint32_t core = k == 16 ? wl[s] >> 6 : (wl[s] >> 6) & CMASK; // k = 16: the 13-mer is all of bits 6..31
-                fw[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(kf4p) + ((uint64_t)kf4_sector(core, kf4_lg) << 4));
+                fw[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(kf4p) + ((uint64_t)kf4_sector(core, kf4_n) << 4));
             }
             // test + push.  has_invalid (a tile with a non-ACGT base, rare) runs its own copy of the code.
             bool stop = false;
