@@ -285,8 +285,25 @@ static bool is_pinned_host(const void* p, size_t bytes) {
 // 2-3 ms per 256 MB on the MI355X host, measured: tools/ubench/host_register.hip -- a tenth of the staging copy it replaces), so the
 // DMA engines read / write it in place.  Fails quietly (read-only mappings, a page shared with another registration, a platform
 // limit): the caller then takes the staging path.  RKMH_HOST_REGISTER=0 disables.
+// Several host threads may work on neighbouring pieces of ONE caller buffer (bin/rkmh --devices: a context per device, each with its
+// range of the reads): their page-rounded registrations would overlap, and a piece whose first and last byte lie in a neighbour's
+// registered pages would LOOK page-locked (is_pinned_host samples both ends) while its middle is not.  So temporary registrations
+// are kept in a process-wide list: a range that touches another thread's registration is neither registered nor trusted.
+static std::mutex g_temp_reg_mu;
+static std::vector<std::pair<uintptr_t, uintptr_t>> g_temp_reg; // [lo, hi) page ranges registered by a ScopedHostRegister that is alive
+static bool touches_temp_registration(const void* p, size_t bytes) { // caller holds g_temp_reg_mu
+    const uintptr_t lo = (uintptr_t)p & ~(uintptr_t)4095, hi = ((uintptr_t)p + bytes + 4095) & ~(uintptr_t)4095;
+    for (const auto& r : g_temp_reg) if (lo < r.second && r.first < hi) return true;
+    return false;
+}
+// is_pinned_host for a caller's buffer: page-locked by the caller, not merely overlapping a temporary registration of ours
+static bool caller_pinned_host(const void* p, size_t bytes) {
+    if (!p || bytes == 0) return false;
+    std::lock_guard<std::mutex> l(g_temp_reg_mu);
+    return !touches_temp_registration(p, bytes) && is_pinned_host(p, bytes);
+}
 struct ScopedHostRegister {
-    void* base = nullptr;
+    uintptr_t lo = 0, hi = 0;
     bool ok = false;
     static bool enabled() {
         static const bool on = [] { const char* e = getenv("RKMH_HOST_REGISTER"); return !(e && *e == '0'); }();
@@ -294,11 +311,18 @@ struct ScopedHostRegister {
     }
     ScopedHostRegister(const void* p, size_t bytes, size_t min_bytes) {
         if (!p || bytes < min_bytes || !enabled()) return;
-        const uintptr_t lo = (uintptr_t)p & ~(uintptr_t)4095, hi = ((uintptr_t)p + bytes + 4095) & ~(uintptr_t)4095;
-        if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterPortable) == hipSuccess) { base = (void*)lo; ok = true; }
+        std::lock_guard<std::mutex> l(g_temp_reg_mu);
+        if (touches_temp_registration(p, bytes)) return; // a neighbouring piece of the same buffer is registered: staging path
+        lo = (uintptr_t)p & ~(uintptr_t)4095; hi = ((uintptr_t)p + bytes + 4095) & ~(uintptr_t)4095;
+        if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterPortable) == hipSuccess) { ok = true; g_temp_reg.emplace_back(lo, hi); }
         else (void)hipGetLastError();
     }
-    ~ScopedHostRegister() { if (ok) { hipError_t e = hipHostUnregister(base); (void)e; } }
+    ~ScopedHostRegister() {
+        if (!ok) return;
+        std::lock_guard<std::mutex> l(g_temp_reg_mu);
+        hipError_t e = hipHostUnregister((void*)lo); (void)e;
+        for (size_t i = 0; i < g_temp_reg.size(); ++i) if (g_temp_reg[i].first == lo && g_temp_reg[i].second == hi) { g_temp_reg.erase(g_temp_reg.begin() + (long)i); break; }
+    }
     ScopedHostRegister(const ScopedHostRegister&) = delete;
     ScopedHostRegister& operator=(const ScopedHostRegister&) = delete;
 };
@@ -1089,8 +1113,8 @@ static int build_index(rk_ctx* c) {
         }
         if (ok) {
             // group filter of k_classify_kmer (kf4_sector in rk_device.hpp): every found k-mer in both orientations under its four
-            // alignments, two bits each in dword j of the 16-byte sector its alignment-j core selects (at ~10 entries per sector about 5 of
-            // a dword's 32 bits are set: one window in ~45 of those that hit nothing passes by chance)
+            // alignments, RK_KF4_NBITS (three) bits each in dword j of the 16-byte sector its alignment-j core selects (at 14 entries per
+            // sector about 9 of a dword's 32 bits are set: one window in ~45 of those that hit nothing passes by chance)
             // Size (any sector count, kf4_sector scales the hashed core): a sparser filter sends fewer windows to the exact map, a
             // smaller one leaves more of an XCD's 4 MB of L2 to the map and the streaming bases -- and the second matters more until
             // the panel is far beyond any cache.  Measured optimum, entries per sector (tools/kf4_density.sh, 1 M reads; ms at the
@@ -1106,9 +1130,11 @@ static int build_index(rk_ctx* c) {
                 const size_t map_bytes = (size_t)16 << be;
                 // (k = 16 with s = 2000, 322 k keys: 20 entries 0.646, 13 entries 0.665; k = 12, whose 9-base cores crowd the sectors
                 // unevenly: 6-8 entries 0.477, 10 entries 0.504, 13 entries 0.555; k = 13: 9-13 entries 0.40, 6 entries 0.435)
-                double e = k <= 12 ? 7.0 : (k == 13 ? 10.0 : 13.0);
+                // (all of the above with two bits per entry; with the three shipped -- kf4_bits -- the optima move little: C2 14 entries
+                // 0.314, 12 0.317, 17 0.326; 266 references 13-14 0.332; s = 2000 16 0.626, 20 0.635; 400 references 20 0.407)
+                double e = k <= 12 ? 7.0 : (k == 13 ? 10.0 : 14.0);
                 if (found > 1500000u) e = 8.0;                                             // far beyond any cache: fewer false candidates win
-                else if (found > 300000u && map_bytes <= ((size_t)4 << 20)) e = 20.0;      // map and filter fight for the L2: smallest useful filter
+                else if (found > 300000u && map_bytes <= ((size_t)4 << 20)) e = 18.0;      // map and filter fight for the L2: smallest useful filter
                 if (kf4_entries > 0.0) e = kf4_entries;
                 const double want = (double)found * 8.0 / e;
                 nsect = want < 256.0 ? 256u : (want > 16777216.0 ? 16777216u : ((uint32_t)want + 7u) & ~7u);
@@ -1480,8 +1506,8 @@ static int host_pipeline(rk_ctx* c, const uint8_t* bases, const uint64_t* offset
     // chunks of 2 M / 512 k / 128 k reads): 4 M reads 278 / 292 / 252 M reads/s, 16 M reads 300 / 313 M reads/s.  RKMH_CHUNK_READS overrides.
     static const int64_t MAX_READS = [] { const char* e = getenv("RKMH_CHUNK_READS"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 4096 ? v : (1 << 19)); }();
     const uint64_t MAX_BASES = 1ull << 29;
-    bool src_pinned = nreads > 0 && is_pinned_host(bases + offsets[0], (size_t)(offsets[nreads] - offsets[0]) + 4);
-    bool out_pinned = mode == 0 && nreads > 0 && is_pinned_host(out4, (size_t)nreads * 16);
+    bool src_pinned = nreads > 0 && caller_pinned_host(bases + offsets[0], (size_t)(offsets[nreads] - offsets[0]) + 4);
+    bool out_pinned = mode == 0 && nreads > 0 && caller_pinned_host(out4, (size_t)nreads * 16);
     // pageable buffers of some size are page-locked for this call instead of being copied through the staging buffers
     ScopedHostRegister reg_src(nreads > 0 && !src_pinned ? bases + offsets[0] : nullptr, nreads > 0 ? (size_t)(offsets[nreads] - offsets[0]) + 4 : 0, (size_t)8 << 20);
     ScopedHostRegister reg_out(mode == 0 && nreads > 0 && !out_pinned ? out4 : nullptr, (size_t)nreads * 16, (size_t)4 << 20);

@@ -112,12 +112,21 @@ __host__ __device__ __forceinline__ uint32_t kf4_sector(uint32_t core, uint32_t 
     return (uint32_t)(((uint64_t)(core * 0x85EBCA6Bu) * (uint64_t)n) >> 32);
 #endif
 }
-// the two bits of a k-mer inside its dword: the TOP ten bits of x * odd constant (mod 2^32), which every bit of x reaches -- a
+// the bits of a k-mer inside its dword: the TOP fifteen (ten with two bits per entry) bits of x * odd constant (mod 2^32), which every bit of x reaches -- a
 // window that differs from a found k-mer only in a base outside the core (a sequencing error in the flank) lands in the same
 // sector and must not land on the same bits (the middle bits of the 64-bit product, one instruction cheaper, fail that for the
 // low bases of x: they only reach bit 32 and up through a carry)
 __host__ __device__ __forceinline__ uint32_t kf4_h(uint32_t x) { return x * 0x9E3779B1u; }
-__host__ __device__ __forceinline__ uint32_t kf4_bits(uint32_t x) { const uint32_t h = kf4_h(x); return (1u << (h >> 27)) | (1u << ((h >> 22) & 31u)); }
+#ifndef RK_KF4_NBITS
+#define RK_KF4_NBITS 3 // bits per entry.  3 against 2 (measured, each at its best density): C2 0.314 / 0.321 ms, 266 references 0.332 / 0.343,
+                       // s = 2000 0.626 / 0.646, 400 references 0.407 / 0.397: fewer false candidates per byte of filter for one more bit test per window
+#endif
+__host__ __device__ __forceinline__ uint32_t kf4_bits(uint32_t x) {
+    const uint32_t h = kf4_h(x);
+    uint32_t b = (1u << (h >> 27)) | (1u << ((h >> 22) & 31u));
+    if (RK_KF4_NBITS >= 3) b |= 1u << ((h >> 17) & 31u);
+    return b;
+}
 
 // reverse complement of a packed k-mer (k <= 16)
 __host__ __device__ __forceinline__ uint32_t packed_revcomp(uint32_t v, int k) {

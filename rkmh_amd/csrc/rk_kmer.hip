@@ -507,7 +507,9 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                     if (k < 16) x &= KMASK;
                     const uint32_t h = kf4_h(x);
                     const uint32_t f = j == 0 ? fw[s].x : (j == 1 ? fw[s].y : (j == 2 ? fw[s].z : fw[s].w));
-                    bool cand = (__builtin_amdgcn_ubfe(f, h >> 27, 1u) & __builtin_amdgcn_ubfe(f, h >> 22, 1u)) != 0u;
+                    bool cand;
+                    if (RK_KF4_NBITS >= 3) cand = (__builtin_amdgcn_ubfe(f, h >> 27, 1u) & __builtin_amdgcn_ubfe(f, h >> 22, 1u) & __builtin_amdgcn_ubfe(f, h >> 17, 1u)) != 0u;
+                    else cand = (__builtin_amdgcn_ubfe(f, h >> 27, 1u) & __builtin_amdgcn_ubfe(f, h >> 22, 1u)) != 0u;
                     if constexpr (INV) {
                         if (act && ((ib >> j) & KBITS) != 0u) { // a window holding a non-ACGT base hashes to 0 (if it is a window of the read)
                             cand = false;
