@@ -1132,7 +1132,8 @@ static int build_index(rk_ctx* c) {
                 // unevenly: 6-8 entries 0.477, 10 entries 0.504, 13 entries 0.555; k = 13: 9-13 entries 0.40, 6 entries 0.435)
                 // (all of the above with two bits per entry; with the three shipped -- kf4_bits -- the optima move little: C2 14 entries
                 // 0.314, 12 0.317, 17 0.326; 266 references 13-14 0.332; s = 2000 16 0.626, 20 0.635; 400 references 20 0.407)
-                double e = k <= 12 ? 7.0 : (k == 13 ? 10.0 : 14.0);
+                // (k = 15 / 14 with three bits: 12.5 entries 0.348 / 0.366, 14 entries 0.360 / 0.369, 11 entries 0.353 / 0.375)
+                double e = k <= 12 ? 7.0 : (k == 13 ? 10.0 : 13.0);
                 if (found > 1500000u) e = 8.0;                                             // far beyond any cache: fewer false candidates win
                 else if (found > 300000u && map_bytes <= ((size_t)4 << 20)) e = 18.0;      // map and filter fight for the L2: smallest useful filter
                 if (kf4_entries > 0.0) e = kf4_entries;
