@@ -1105,6 +1105,39 @@ def test_count_pass_slot_partitioned_equals_atomic(data_dir, slots, ks, ragged, 
         c.close()
 
 
+@pytest.mark.parametrize("entries,k", [("5.3", 16), ("41", 16), ("17.7", 12), ("9.9", 14)])
+def test_kmer_space_filter_of_any_sector_count(root, entries, k):
+    """The group filter of the k-mer-space kernel has ANY number of sectors (the hashed core is scaled by a 32 x 32 high product),
+    chosen by entries per sector.  The knob is read once per process, so each forced density runs in its own interpreter: 30 000
+    C2 reads (1 in 1000 with an N) and 5 000 reads of unequal length against the oracle, sector counts that are no power of two,
+    from far sparser to far denser than the shipped rule."""
+    code = r"""
+import os, sys
+import numpy as np
+root = sys.argv[1]; k = int(sys.argv[2])
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle"))
+import oracle, rkmh_amd
+from rkmh_amd import api, synth
+refs = api.parse_files([os.path.join(root, "tests", "golden", "data", "all_pave_ref.fa.gz")])
+rb, ro = refs["bases"], refs["offsets"]
+ctx = rkmh_amd.Context(0)
+ctx.set_references(rb, ro, [k], 1000)
+assert ctx.kmer_form()[0]
+sk, ln = ctx.get_reference_sketches()
+qb, qo = synth.generate_reads_fast(rb, ro, 0, 30000)
+assert (ctx.classify(qb, qo) == oracle.classify_stream(qb, qo, [k], 1000, sk, ln, threads=8)).all()
+rng = np.random.default_rng(5)
+qb2, _ = synth.generate_reads_fast(rb, ro, 40000, 45000)
+lens = rng.integers(0, 151, size=5000)
+offs = np.zeros(5001, np.uint64); offs[1:] = np.cumsum(lens)
+b2 = np.concatenate([qb2[i * 150:i * 150 + int(lens[i])] for i in range(5000)] + [np.zeros(64, np.uint8)])
+assert (ctx.classify(b2, offs) == oracle.classify_stream(b2, offs, [k], 1000, sk, ln, threads=8)).all()
+print("ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code, root, str(k)], capture_output=True, env=dict(os.environ, RKMH_KF4_ENTRIES=entries))
+    assert r.returncode == 0 and r.stdout.strip().endswith(b"ok"), r.stderr.decode()[-2000:]
+
+
 def test_count_pass_slot_partitioned_degenerate_batches(ctx, pave):
     """The slot-partitioned count pass on batches that stress its binning: no window at all (every read shorter than k), every
     window the same k-mer (poly-A reads: one slot receives 1.7 M increments, one bin receives every entry, the LDS rank counters of
