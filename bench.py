@@ -117,6 +117,145 @@ def e2e_stream(n, L, rb, ro, synth):
             pass
 
 
+def config_legs(rkmh_amd, api, synth, dev, n, L, check):
+    """Informational legs for the other BASELINE configs (never `value`): c3_panel = config 3's ~270-reference panel (every bundled
+    FASTA) on one GPU's resident batch; c4_filter = filter's k = 20, s = 2000 shape, plain and with -M 2; c5_call = rkmh call at
+    1000x coverage of HPV16.  Each leg samples rows against the CPU oracle when `check`."""
+    import subprocess
+    import tempfile
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    legs = {}
+    if check:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle  # checker only
+
+    def kernel_ms(ctx, d_b, d_o, d_out, stream, reps=20, warm=5):
+        f = lambda: ctx.classify_device(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=L, stream=stream)  # noqa: E731
+        for _ in range(warm):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def sample_check(out, qb, qo, ks, S, sk, ln):
+        if not check:
+            return 0
+        w = min(n, 4096)
+        tot = 0
+        for lo_ in (0, n // 2, max(0, n - w)):
+            want = oracle.classify_stream(qb, qo[lo_: lo_ + w + 1], ks, S, sk, ln, threads=oracle.max_threads())
+            if not (want == out[lo_: lo_ + w]).all():
+                raise SystemExit("ORACLE CHECK FAILED in a config leg (k=%s S=%d, reads %d..)" % (ks, S, lo_))
+            tot += w
+        return tot
+
+    stream = torch.cuda.current_stream().cuda_stream
+    # ---- config 3's panel: every bundled reference
+    files = ["all_pave_ref.fa.gz", "zika.refs.fa.gz", "dengue.fa.gz", "new_refs.fa.gz", "hpv_16.fa.gz", "zika.fa.gz", "yellow_fever.fa.gz",
+             "hpv_16_allFasta.fa.gz"]
+    panel = api.parse_files([os.path.join(data, f) for f in files])
+    pb, po, PR = panel["bases"], panel["offsets"], panel["nseq"]
+    ctx = rkmh_amd.Context(dev.index)
+    try:
+        ctx.set_references(pb, po, [16], 1000)
+        sk, ln = ctx.get_reference_sketches()
+        qb, qo = synth.generate_reads_fast(pb, po, 0, n, read_len=L, threads=min(32, os.cpu_count() or 1))
+        d_b = torch.from_numpy(qb).to(dev)
+        d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev)
+        d_out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        ms = kernel_ms(ctx, d_b, d_o, d_out, stream)
+        out = d_out.cpu().numpy()
+        legs["c3_panel"] = {"references": PR, "k": 16, "sketch_size": 1000, "reads": n, "kernel_ms": ms, "reads_per_s": n / ms * 1e3,
+                            "rerouted_rows": int((out[:, 0] < 0).sum()), "oracle_checked_reads": sample_check(out, qb, qo, [16], 1000, sk, ln),
+                            "note": "BASELINE config 3's panel (every bundled FASTA), one GPU's resident batch of synthetic reads drawn from it"}
+    finally:
+        ctx.close()
+    # ---- config 4's shape: k = 20, s = 2000 against the PaVE panel, plain and with -M 2 (filter's 10 M-slot table)
+    pave = api.parse_files([os.path.join(data, "all_pave_ref.fa.gz")])
+    rb, ro = pave["bases"], pave["offsets"]
+    ctx = rkmh_amd.Context(dev.index)
+    try:
+        ctx.set_references(rb, ro, [20], 2000)
+        sk, ln = ctx.get_reference_sketches()
+        qb, qo = synth.generate_reads_fast(rb, ro, 0, n, read_len=L, threads=min(32, os.cpu_count() or 1))
+        d_b = torch.from_numpy(qb).to(dev)
+        d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev)
+        d_out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        ms = kernel_ms(ctx, d_b, d_o, d_out, stream)
+        out = d_out.cpu().numpy()
+        nchk = sample_check(out[:], qb, qo, [20], 2000, sk, ln) if not (out[:, 0] < 0).any() else 0
+        slots = 10000000
+        cnt = api.Counter(ctx, slots)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ctx.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt, stream=stream)
+        torch.cuda.synchronize()
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            ctx.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt, stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        count_ms = e0.elapsed_time(e1) / reps
+        ctx.set_depth_filter(cnt, 2)
+        masked_ms = kernel_ms(ctx, d_b, d_o, d_out, stream, reps=10, warm=3)
+        ctx.set_depth_filter(None, 0)
+        cnt.destroy()
+        legs["c4_filter"] = {"references": pave["nseq"], "k": 20, "sketch_size": 2000, "reads": n, "kernel_ms": ms, "reads_per_s": n / ms * 1e3,
+                             "M2_slots": slots, "M2_count_pass_ms": count_ms, "M2_masked_classify_ms": masked_ms,
+                             "rerouted_rows": int((out[:, 0] < 0).sum()), "oracle_checked_reads": nchk,
+                             "note": "BASELINE config 4's kernel shape (filter: k = 20, s = 2000; hash-space kernel) on one resident batch against the "
+                                     "PaVE panel; hg38-sized references are a GPU test in miniature (tests/test_gpu_parity.py), not a bench leg"}
+    finally:
+        ctx.close()
+    # ---- config 5: rkmh call, whole process, 1000x coverage of HPV16 with planted variants
+    exe = os.path.join(ROOT, "bin", "rkmh")
+    tmp = tempfile.mkdtemp(prefix="rkmh_c5_")
+    try:
+        h16 = api.parse_files([os.path.join(data, "hpv_16.fa.gz")])
+        ref = bytes(h16["bases"][: int(h16["offsets"][1])]).upper()
+        mut = bytearray(ref)
+        for pos, alt in ((500, b"A"), (1200, b"C"), (2503, b"G"), (4000, b"T"), (6100, b"A")):
+            mut[pos] = alt[0] if mut[pos] != alt[0] else b"ACGT"[(b"ACGT".index(alt) + 1) % 4]
+        for pos in (7000, 3100):
+            del mut[pos]
+        rng = np.random.default_rng(5)
+        nr = 1000 * len(ref) // 150
+        st = rng.integers(0, len(mut) - 150, size=nr)
+        arr = np.frombuffer(bytes(mut), dtype=np.uint8)
+        reads = arr[st[:, None] + np.arange(150)[None, :]].copy()
+        noise = rng.random(reads.shape) < 0.005
+        reads[noise] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(noise.sum()))]
+        fa, fq = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fq")
+        with open(fa, "wb") as f:
+            f.write(b">HPV16\n" + ref + b"\n")
+        with open(fq, "wb") as f:
+            f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (i, reads[i].tobytes(), b"I" * 150) for i in range(nr)))
+        best, rows = None, 0
+        for _ in range(2):
+            t = time.perf_counter()
+            r = subprocess.run([exe, "call", "-r", fa, "-f", fq, "-k", "12"], capture_output=True)
+            dt = time.perf_counter() - t
+            if r.returncode != 0:
+                legs["c5_call"] = {"error": r.stderr.decode()[-300:]}
+                break
+            rows = sum(1 for l in r.stdout.decode().splitlines() if l and not l.startswith("#"))
+            best = dt if best is None or dt < best else best
+        else:
+            legs["c5_call"] = {"reads": nr, "k": 12, "wall_s": best, "reads_per_s": nr / best, "vcf_rows": rows,
+                               "note": "bin/rkmh call -k 12, whole process, 1000x coverage of HPV16 (5 planted SNPs, 2 planted deletions, 0.5 % noise); "
+                                       "rows vs the oracle are a GPU test (test_call_matches_oracle / test_call_at_c5_scale)"}
+    finally:
+        for x in os.listdir(tmp):
+            os.remove(os.path.join(tmp, x))
+        os.rmdir(tmp)
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,7 +271,22 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive rk_classify_batch figure (N=1 only)")
     ap.add_argument("--no-depth-filter", action="store_true", help="skip the -M figures (count pass + masked classify at 200 M slots; N=1 only)")
     ap.add_argument("--e2e-reads", type=int, default=16000000, help="reads of the generated FASTQ for the bin/rkmh stream end-to-end figure (0 disables; N=1 only)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the informational legs for BASELINE configs 3, 4 and 5 (N=1 only)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not started by a launcher: start the N ranks ourselves, as CHILD processes of torch.distributed.run, before anything in this
+        # process has touched the GPU (a process that has initialised HIP must never exec or fork workers)
+        import socket
+        import subprocess
+        with socket.socket() as sk_:
+            sk_.bind(("127.0.0.1", 0))
+            port = sk_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
 
     import rkmh_amd
     from rkmh_amd import api, dist as rdist, synth
@@ -274,6 +428,17 @@ def main():
             dt = time.perf_counter() - t
             if not (want == out[:m]).all():
                 raise SystemExit("ORACLE CHECK FAILED: GPU rows differ from the CPU oracle")
+            # every OTHER timed batch too: windows of consecutive reads spread over the batch (its first and its last reads included,
+            # where tiles are cut differently), so a row that is only wrong in batches 1.. cannot pass
+            checked_other = 0
+            for b in range(1, nb):
+                w = min(n, 8192)
+                starts = sorted(set([0, max(0, n - w)] + [int(x) for x in np.random.default_rng(1000 + b).integers(0, max(1, n - w), size=6)]))
+                for lo_ in starts:
+                    wb = oracle.classify_stream(qbs[b], qos[b][lo_: lo_ + w + 1], ks, S, sk, ln, threads=thr)
+                    if not (wb == outs[b][lo_: lo_ + w]).all():
+                        raise SystemExit("ORACLE CHECK FAILED: GPU rows of batch %d differ from the CPU oracle (reads %d..%d)" % (b, lo_, lo_ + w))
+                    checked_other += w
             t = time.perf_counter()
             m1 = max(min(m, int(m / thr * 4)), 1)
             oracle.classify_stream(qb, qo[: m1 + 1], ks, S, sk, ln, threads=1)
@@ -281,8 +446,10 @@ def main():
             res["cpu_baseline"] = {"value": m / dt, "unit": "reads/s", "cores": thr, "kind": "port", "cpu_model": cpu_model(),
                                    "sample": "first %d reads of the same batch, OpenMP x%d, refs pre-sketched; %.1f s" % (m, thr, dt),
                                    "single_thread_value": m1 / dt1,
-                                   "oracle_check": "GPU rows bit-exact vs the CPU oracle on the %d sampled reads (oracle-consistent; the mkmh policies "
-                                                   "are unpinned by any reference artefact, DESIGN.md section 0)" % m}
+                                   "oracle_check": "GPU rows bit-exact vs the CPU oracle on the first %d reads of batch 0 and on %d reads sampled from the "
+                                                   "other %d timed batches (oracle-consistent; the mkmh policies are unpinned by any reference "
+                                                   "artefact, DESIGN.md section 0)" % (m, checked_other, nb - 1),
+                                   "oracle_checked_reads": m + checked_other}
         if world == 1 and not a.no_host_path:
             # PCIe-inclusive: the same batches from PAGEABLE host memory through rk_classify_batch (pinned staging, H2D, kernel,
             # D2H overlapped chunk by chunk).  Never the reported value.
@@ -334,6 +501,8 @@ def main():
             res["depth_filter"] = {"slots": slots, "count_pass_ms": count_ms, "masked_classify_ms": masked_ms, "reads": n,
                                    "note": "-M on one resident 1 M-read batch: pass 1 without global atomics (slots binned by table range and counted "
                                            "in LDS, rk_count.hip) and the masked hash-space classification (one keep bit per window from a 25 MB bitmap)"}
+        if world == 1 and not a.no_configs:
+            res.update(config_legs(rkmh_amd, api, synth, dev, n, L, a.cpu_seconds > 0))
         if world == 1 and a.e2e_reads > 0:
             res["e2e"] = e2e_stream(a.e2e_reads, L, rb, ro, synth)
         print(json.dumps(res))

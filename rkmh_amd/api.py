@@ -295,6 +295,14 @@ class Counter:
     def clear(self):
         _chk(self._lib.rk_counter_clear(self._h))
 
+    def add(self, other):
+        """self += other (tables of equal size, possibly on two devices of this process): the reduce step of a multi-device -M run."""
+        _chk(self._lib.rk_counter_add(self._h, other._h))
+
+    def copy_from(self, other):
+        """self = other (the broadcast step)."""
+        _chk(self._lib.rk_counter_copy(self._h, other._h))
+
     def save(self, path, tag=None):
         """tag: bytes from Context.depth_map_tag (provenance of a read-depth map) or None for an untagged file."""
         if tag is None:

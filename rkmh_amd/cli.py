@@ -129,6 +129,12 @@ def main_stream(argv, filter_mode=False):
         ctx.set_depth_filter(None, 0)
         counter.destroy()
     ctx.close()
+    try:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except ImportError:
+        pass
     return 0
 
 

@@ -623,12 +623,51 @@ static int minhashes_impl(rk_ctx* c, uint64_t* h, int n, int S, uint64_t** mins,
                           int filter_mode, int fmin, int fmax, bool sort_input) {
     if (!c || (!h && n > 0) || n < 0 || !mins || !m) return fail(RK_ERR_ARG, "bad arguments");
     if (S < 1 || S > RK_MAX_SKETCH) return fail(RK_ERR_LIMIT, "sketch size %d outside [1,%d]", S, RK_MAX_SKETCH);
-    if (n > SORT_MAX_P) return fail(RK_ERR_LIMIT, "%d hashes; the in-LDS sketcher handles <= %d", n, SORT_MAX_P);
     RKCHK(set_dev(c));
     uint64_t* r = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)S);
     if (!r) return fail(RK_ERR_NOMEM, "malloc");
     int rc = RK_OK;
-    do {
+    if (n > SORT_MAX_P) do {
+        // Longer than the in-LDS sorter holds (the reference calls minhashes on every whole reference, rkmh.cpp:822, :835-836):
+        // the sketch is the exact bottom S of the kept hashes by radix select (the route rk_set_references takes for long
+        // sequences) + a sort of those <= S values; the side effect of mkmh::minhashes -- the caller's array comes back sorted
+        // ascending -- is a whole-array device sort (rk_sort.hip).
+        size_t tmp_bytes = 0;
+        hipError_t e = sort_input ? sort_u64_temp_bytes((uint64_t)n, &tmp_bytes) : hipSuccess;
+        if (e != hipSuccess) { rc = fail(RK_ERR_HIP, "minhashes (long input): %s", hipGetErrorString(e)); break; }
+        if ((rc = c->w_hashes.reserve((size_t)(n + 1) * 8)) != RK_OK) break;
+        if ((rc = c->w_segoff.reserve(16)) != RK_OK) break;
+        if ((rc = c->w_ids.reserve(4)) != RK_OK) break;
+        if ((rc = c->w_sk.reserve((size_t)S * 8)) != RK_OK) break;
+        if ((rc = c->w_lens.reserve(4)) != RK_OK) break;
+        if ((rc = c->w_sel.reserve((size_t)S * 8 + 64)) != RK_OK) break;
+        if ((rc = c->w_selstate.reserve(16 * 4 + 8192 * 4)) != RK_OK) break;
+        if (sort_input && (rc = c->w_misc.reserve(tmp_bytes)) != RK_OK) break;
+        uint64_t seg[2] = {0, (uint64_t)n};
+        uint32_t id0 = 0;
+        int32_t len = 0;
+        uint32_t* st_ = c->w_selstate.as<uint32_t>();
+        e = hipMemcpyAsync(c->w_hashes.p, h, (size_t)n * 8, hipMemcpyHostToDevice, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->w_segoff.p, seg, 16, hipMemcpyHostToDevice, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->w_ids.p, &id0, 4, hipMemcpyHostToDevice, c->st);
+        if (e == hipSuccess) e = launch_select_bottom(c->w_hashes.as<uint64_t>(), (uint64_t)n, S, counter ? counter->d : nullptr, counter ? counter->slots : 1,
+                                                      filter_mode, fmin, fmax, c->pol, st_, st_ + 16, c->w_sel.as<uint64_t>(), c->st);
+        SortArgs a{};
+        a.hashes = c->w_hashes.as<uint64_t>(); a.seg_off = c->w_segoff.as<uint64_t>(); a.seq_ids = c->w_ids.as<uint32_t>();
+        a.nlist = 1; a.P = std::max<uint32_t>(64u, next_pow2((uint32_t)S)); a.S = S; a.write_back = 0;
+        a.sketches = c->w_sk.as<uint64_t>(); a.lens = c->w_lens.as<int32_t>(); a.out4 = nullptr;
+        a.filter_mode = FILTER_NONE; // the selection already applied the filter
+        a.sel_hashes = c->w_sel.as<uint64_t>(); a.sel_len = st_ + 8;
+        if (e == hipSuccess) e = launch_sort_intersect(a, nullptr, c->pol, c->st);
+        if (e == hipSuccess && sort_input) e = launch_sort_u64(c->w_hashes.as<uint64_t>(), (uint64_t)n, c->w_misc.p, tmp_bytes, c->st);
+        if (e == hipSuccess && sort_input) e = hipMemcpyAsync(h, c->w_hashes.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(r, c->w_sk.p, (size_t)S * 8, hipMemcpyDeviceToHost, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&len, c->w_lens.p, 4, hipMemcpyDeviceToHost, c->st);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->st);
+        if (e != hipSuccess) { rc = fail(RK_ERR_HIP, "minhashes pipeline (long input): %s", hipGetErrorString(e)); break; }
+        *m = len;
+    } while (0);
+    else do {
         if ((rc = c->w_hashes.reserve((size_t)(n + 1) * 8)) != RK_OK) break;
         if ((rc = c->w_segoff.reserve(16)) != RK_OK) break;
         if ((rc = c->w_ids.reserve(4)) != RK_OK) break;
@@ -775,22 +814,51 @@ static int counter_combine(rk_counter* dst, const rk_counter* src, bool add) {
     RKCHK(counter_settle(dst));
     hipStream_t st = dst->ctx->st;
     if (!add) { HIPCHK(hipMemcpyAsync(dst->d, src->d, src->slots * 4, hipMemcpyDefault, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
-    if (dst->device == src->device) { HIPCHK(launch_counter_add(dst->d, src->d, dst->slots, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
-    const uint64_t CH = (uint64_t)16 << 20; // slots per piece (64 MB)
+    // RKMH_COUNTER_STAGED=1 takes the staged branch below even for two tables of ONE device (a one-GPU box can test it)
+    static const bool force_staged = getenv("RKMH_COUNTER_STAGED") && atoi(getenv("RKMH_COUNTER_STAGED")) != 0;
+    if (dst->device == src->device && !force_staged) { HIPCHK(launch_counter_add(dst->d, src->d, dst->slots, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
+    if (dst->device != src->device && !force_staged) {
+        // two devices of one node: with peer access the add kernel reads the other device's table in place over xGMI
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dst->device, src->device) == hipSuccess && can) {
+            hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);
+            if (pe == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); pe = hipSuccess; }
+            if (pe == hipSuccess) { HIPCHK(launch_counter_add(dst->d, src->d, dst->slots, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
+            (void)hipGetLastError();
+        }
+    }
+    // staged: the other table comes over in 64 MB pieces (hipMemcpyDefault device -> device) on a copy stream, two buffers, so that
+    // piece i + 1 is in flight while piece i is being added
+    const uint64_t CH = (uint64_t)16 << 20; // slots per piece
     DevBuf tmp[2];
     int rc = RK_OK;
     for (int i = 0; i < 2 && rc == RK_OK; ++i) rc = tmp[i].reserve(std::min<uint64_t>(CH, dst->slots) * 4);
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    for (int i = 0; i < 2 && rc == RK_OK; ++i) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(RK_ERR_HIP, "hipEventCreate failed");
+    hipEvent_t copied[2] = {nullptr, nullptr}, added[2] = {nullptr, nullptr};
+    hipStream_t cst = nullptr;
+    if (rc == RK_OK && hipStreamCreateWithFlags(&cst, hipStreamNonBlocking) != hipSuccess) rc = fail(RK_ERR_HIP, "hipStreamCreate failed");
+    for (int i = 0; i < 2 && rc == RK_OK; ++i)
+        if (hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&added[i], hipEventDisableTiming) != hipSuccess)
+            rc = fail(RK_ERR_HIP, "hipEventCreate failed");
     int which = 0;
-    for (uint64_t off = 0; off < dst->slots && rc == RK_OK; off += CH, which ^= 1) {
+    uint64_t piece = 0;
+    for (uint64_t off = 0; off < dst->slots && rc == RK_OK; off += CH, which ^= 1, ++piece) {
         const uint64_t n = std::min<uint64_t>(CH, dst->slots - off);
-        hipError_t e = hipMemcpyAsync(tmp[which].p, src->d + off, n * 4, hipMemcpyDefault, st);
+        hipError_t e = hipSuccess;
+        if (piece >= 2) e = hipStreamWaitEvent(cst, added[which], 0);           // the buffer's previous piece has been added
+        if (e == hipSuccess) e = hipMemcpyAsync(tmp[which].p, src->d + off, n * 4, hipMemcpyDefault, cst);
+        if (e == hipSuccess) e = hipEventRecord(copied[which], cst);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, copied[which], 0);
         if (e == hipSuccess) e = launch_counter_add(dst->d + off, tmp[which].as<int32_t>(), n, st);
+        if (e == hipSuccess) e = hipEventRecord(added[which], st);
         if (e != hipSuccess) rc = fail(RK_ERR_HIP, "rk_counter_add: %s", hipGetErrorString(e));
     }
     if (hipStreamSynchronize(st) != hipSuccess && rc == RK_OK) rc = fail(RK_ERR_HIP, "rk_counter_add: synchronize failed");
-    for (int i = 0; i < 2; ++i) { if (ev[i]) { hipError_t e = hipEventDestroy(ev[i]); (void)e; } tmp[i].release(); }
+    if (cst) { hipError_t e = hipStreamSynchronize(cst); (void)e; e = hipStreamDestroy(cst); (void)e; }
+    for (int i = 0; i < 2; ++i) {
+        if (copied[i]) { hipError_t e = hipEventDestroy(copied[i]); (void)e; }
+        if (added[i]) { hipError_t e = hipEventDestroy(added[i]); (void)e; }
+        tmp[i].release();
+    }
     return rc;
 }
 extern "C" int rk_counter_add(rk_counter* dst, const rk_counter* src) { return counter_combine(dst, src, true); }
@@ -1367,10 +1435,14 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
         // atomic form: other passes into this table may still be adding with plain stores
         std::lock_guard<std::mutex> lock(count_into->mu);
         if (count_into->last_set) HIPCHK(hipStreamWaitEvent(st, count_into->last, 0));
+        // atomic passes are CHAINED too (each waits for the one before): last_atomic is a single event re-recorded by every pass, so
+        // it only covers all of them if every pass already contains its predecessors -- otherwise a slot-partitioned pass that follows
+        // two atomic passes on different streams would wait for the second one only and its plain adds could lose the first one's counts
+        if (count_into->last_atomic_set) HIPCHK(hipStreamWaitEvent(st, count_into->last_atomic, 0));
         if (!classify_tile_supported(0, (int)ml)) return fail(RK_ERR_LIMIT, "count pass: batch not supported by the fused kernel");
         HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
                                     counter, slots, min_occ, 1, nullptr, c->pol, (int)ml, expect, st)); // (given an array there, it would write slots to it)
-        // atomic passes may overlap each other; a later slot-partitioned pass must not overlap this one
+        // a later pass of either form must not overlap this one
         if (!count_into->last_atomic) HIPCHK(hipEventCreateWithFlags(&count_into->last_atomic, hipEventDisableTiming));
         HIPCHK(hipEventRecord(count_into->last_atomic, st));
         count_into->last_atomic_set = true;

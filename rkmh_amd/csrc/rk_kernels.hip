@@ -666,7 +666,14 @@ hipError_t launch_count_distinct(const uint64_t* hashes, uint64_t n, uint64_t* t
 
 __global__ void k_counter_inc(int32_t* counter, uint64_t slots, uint64_t key) { atomicAdd(&counter[key % slots], 1); }
 // dst[i] += src[i]: the sum of two devices' (or two passes') depth tables -- the all-reduce step of a multi-device -M run
+// ALIGNED: both tables start on a 16-byte boundary (every table the library allocates does; a table adopted with rk_counter_wrap --
+// a slice of a torch tensor, say -- may be only 4-byte aligned and takes the dword form)
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_counter_add(int32_t* __restrict__ dst, const int32_t* __restrict__ src, uint64_t n) {
+    if (!ALIGNED) {
+        for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] += src[i];
+        return;
+    }
     const uint64_t n4 = n >> 2;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) {
         int4 a = reinterpret_cast<int4*>(dst)[i];
@@ -678,10 +685,16 @@ __global__ __launch_bounds__(256) void k_counter_add(int32_t* __restrict__ dst, 
 }
 hipError_t launch_counter_add(int32_t* dst, const int32_t* src, uint64_t n, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) != 0) {
+        uint64_t b = (n + 255) / 256;
+        if (b > 256 * 32) b = 256 * 32;
+        hipLaunchKernelGGL(k_counter_add<false>, dim3((uint32_t)b), dim3(256), 0, st, dst, src, n);
+        return hipGetLastError();
+    }
     uint64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_counter_add, dim3((uint32_t)blocks), dim3(256), 0, st, dst, src, n);
+    hipLaunchKernelGGL(k_counter_add<true>, dim3((uint32_t)blocks), dim3(256), 0, st, dst, src, n);
     return hipGetLastError();
 }
 hipError_t launch_counter_inc(int32_t* counter, uint64_t slots, uint64_t key, hipStream_t st) {

@@ -93,6 +93,9 @@ hipError_t launch_sort_intersect(const SortArgs& a, const RefIndex* ix, const De
 hipError_t launch_select_bottom(const uint64_t* hashes, uint64_t n, int S, const int32_t* counter, uint64_t slots,
                                 int filter_mode, int fmin, int fmax, const DevPolicy& pol, uint32_t* sel_state,
                                 uint32_t* hist, uint64_t* sel_out, hipStream_t st);
+// whole-array ascending sort of u64 keys in place (rk_sort.hip: rocPRIM radix sort); tmp holds sort_u64_temp_bytes(n) bytes
+hipError_t sort_u64_temp_bytes(uint64_t n, size_t* bytes);
+hipError_t launch_sort_u64(uint64_t* keys, uint64_t n, void* tmp, size_t tmp_bytes, hipStream_t st);
 // bits[s / 32] bit (s % 32) = the count of slot s passes mask_by_frequency's threshold (one streaming pass over the table)
 hipError_t launch_keep_bits(const int32_t* counter, uint64_t slots, int min_occ, const DevPolicy& pol, uint32_t* bits, hipStream_t st);
 // hashes all 4^k k-mers; stats[0] = k-mers found (one per strand pair), the first list_cap of them in list[] as (packed canonical

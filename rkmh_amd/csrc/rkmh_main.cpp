@@ -274,9 +274,15 @@ static void two_pass_on_group(DeviceGroup& g, const rk_seqset& reads, uint64_t s
             const int64_t lo = share_lo(reads.nseq, d, D), hi = share_lo(reads.nseq, d + 1, D);
             return rk_count_batch(g.ctx[d], reads.bases, reads.offsets + lo, hi - lo, cnt[d]);
         });
-        for (size_t d = 1; d < D; ++d) CK(rk_counter_add(cnt[0], cnt[d]));
+        // all-reduce inside one process: a binary tree onto device 0 (log2 D rounds, the adds of one round on different devices run
+        // concurrently), then the full table is handed back down the same tree
+        for (size_t step = 1; step < D; step <<= 1)
+            run([&](size_t d) { return (d % (2 * step) == 0 && d + step < D) ? rk_counter_add(cnt[d], cnt[d + step]) : RK_OK; });
     }
-    for (size_t d = 1; d < D; ++d) CK(rk_counter_copy(cnt[d], cnt[0]));
+    size_t top = 1;
+    while (top < D) top <<= 1;
+    for (size_t step = top >> 1; step >= 1; step >>= 1)
+        run([&](size_t d) { return (d % (2 * step) == 0 && d + step < D) ? rk_counter_copy(cnt[d + step], cnt[d]) : RK_OK; });
     run([&](size_t d) {
         const int64_t lo = share_lo(reads.nseq, d, D), hi = share_lo(reads.nseq, d + 1, D);
         int r = rk_set_depth_filter(g.ctx[d], cnt[d], min_occ);

@@ -17,11 +17,18 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), local, int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def _collectives_on():
+    """The collectives run when there is more than one rank -- or with a single rank when RKMH_DIST_FORCE=1, which exists so that the
+    RCCL code path (device tensors, nccl backend) can be executed on a one-GPU box (tests/test_gpu_parity.py)."""
+    import torch.distributed as dist
+    return dist.is_initialized() and (dist.get_world_size() > 1 or bool(os.environ.get("RKMH_DIST_FORCE")))
+
+
 def init(backend=None):
     import torch
     import torch.distributed as dist
     rank, local, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("RKMH_DIST_FORCE")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -41,7 +48,7 @@ def broadcast_sketches(sketches, lens, nref, sketch_size, src=0, device=None):
     """Rank `src` passes (sketches [R,S] uint64, lens [R] int32); the others pass None. Returns numpy arrays."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collectives_on():
         return sketches, lens
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
     if dist.get_rank() == src:
@@ -58,7 +65,7 @@ def broadcast_sketches(sketches, lens, nref, sketch_size, src=0, device=None):
 def allreduce_counter(t_counts):
     """Sum the per-rank HASHTCounter tables in place (torch int32 tensor that the rk_counter wraps)."""
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         dist.all_reduce(t_counts, op=dist.ReduceOp.SUM)
     return t_counts
 
@@ -69,7 +76,7 @@ def gather_rows(rows, dst=0):
     gigabyte-sized results, and the same code under RCCL (device tensors) and gloo (host tensors)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collectives_on():
         return rows
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"

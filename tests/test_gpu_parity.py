@@ -90,6 +90,38 @@ def test_minhashes_and_intersection_mirrors(ctx, orc):
         mins, srt = ctx.minhashes(h, S)
         assert (mins == orc.minhashes(h, S)).all()
         assert (srt == np.sort(h)).all()
+    # inputs longer than the in-LDS sorter (the reference calls minhashes on whole references, rkmh.cpp:822): exact bottom S by
+    # radix select, the caller's array back sorted ascending by a whole-array device sort
+    for n, S, zero_frac, few in ((16385, 1000, 0.1, 0), (100000, 1000, 0.1, 0), (3000000, 2000, 0.3, 0), (50000, 1000, 1.0, 0),
+                                 (70000, 1000, 0.0, 300), (200000, 16384, 0.05, 0)):
+        h = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+        h[rng.random(n) < zero_frac] = 0
+        if few:                      # fewer kept hashes than S: all of them
+            h[few:] = 0
+            rng.shuffle(h)
+        h[1000:1040] = h[999]        # a run of duplicates (no dedup), possibly of the threshold value
+        h[-1] = np.uint64((1 << 64) - 1)
+        mins, srt = ctx.minhashes(h, S)
+        want = orc.minhashes(h, S)
+        assert len(mins) == len(want) and (mins == want).all(), (n, S)
+        assert (srt == np.sort(h)).all(), (n, S)
+    # minhashes_frequency_filter (rkmh.cpp:835-836) on a long input: the table is a torch tensor the counter wraps
+    import torch
+    import rkmh_amd
+    slots = 100003
+    hL = rng.integers(1, 1 << 40, size=60000, dtype=np.uint64)
+    hL[rng.random(60000) < 0.05] = 0
+    counts = np.bincount((hL % np.uint64(slots)).astype(np.int64), minlength=slots).astype(np.int32)
+    counts[0] = 1 << 20
+    t = torch.from_numpy(counts).cuda()
+    cntL = rkmh_amd.Counter(ctx, slots=slots, device_ptr=t.data_ptr())
+    for S, mx in ((1000, 1), (1000, 0), (5000, 2)):
+        mins, srt = ctx.minhashes(hL, S, counter=cntL, min_count=0, max_count=mx)
+        hs = np.sort(hL)
+        want = hs[(hs != 0) & (counts[(hs % np.uint64(slots)).astype(np.int64)] <= mx)][:S]
+        assert len(mins) == len(want) and (mins == want).all(), (S, mx)
+        assert (srt == hs).all()
+    cntL.destroy()
     a = np.sort(rng.integers(1, 500, size=300, dtype=np.uint64))
     b = np.sort(rng.integers(1, 500, size=1000, dtype=np.uint64))
     assert ctx.hash_intersection_size(a, b) == orc.hash_intersection_size(a, b)
@@ -431,6 +463,28 @@ def test_bench_json_contract(root):
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "bit-exact" in cb["oracle_check"]
     assert d["host_path"]["value"] > 0 and d["host_path"]["pageable_value"] > 0 and d["e2e"]["output_lines"] == d["e2e"]["reads"]
     assert d["depth_filter"]["count_pass_ms"] > 0 and d["depth_filter"]["masked_classify_ms"] > 0 and d["depth_filter"]["slots"] == 200000000
+    # every timed batch is sampled against the oracle, not only the first
+    assert cb["oracle_checked_reads"] > 30000 and "other 3 timed batches" in cb["oracle_check"]
+    # informational legs for BASELINE configs 3, 4 and 5 (never `value`)
+    c3, c4, c5 = d["c3_panel"], d["c4_filter"], d["c5_call"]
+    assert c3["references"] >= 260 and c3["kernel_ms"] > 0 and c3["rerouted_rows"] == 0 and c3["oracle_checked_reads"] > 0
+    assert c4["k"] == 20 and c4["sketch_size"] == 2000 and c4["kernel_ms"] > 0 and c4["M2_count_pass_ms"] > 0 and c4["M2_masked_classify_ms"] > 0
+    assert c4["oracle_checked_reads"] > 0
+    assert c5["k"] == 12 and c5["wall_s"] > 0 and c5["vcf_rows"] >= 5 and c5["reads"] > 50000
+
+
+def test_bench_spawns_its_own_ranks(root):
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset): bench.py starts torch.distributed.run as a child
+    process before it has touched the GPU, the two ranks run (here on GPU 0 over gloo), and the one JSON line comes through."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RKMH_BENCH_ONE_DEVICE="1", RKMH_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--reads", "40000", "--steps", "4", "--warmup", "1",
+                        "--spinup-seconds", "0"], capture_output=True, cwd=root, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and "cpu_baseline" not in d and "c3_panel" not in d
 
 
 def test_bench_two_ranks_launched_like_the_driver(root):
@@ -563,6 +617,100 @@ def test_python_cli_single_rank(orc, root, data_dir, golden_dir):
     want = "".join(orc.stream_line(refs[o4[i, 0]][0].decode(), reads[i][0].decode(), o4[i, 1], o4[i, 2], o4[i, 3], 1000)
                    for i in range(len(reads)))
     assert r.stdout.decode() == want
+
+
+def test_counter_add_staged_and_unaligned(root):
+    """rk_counter_add / rk_counter_copy, the in-process reduce and broadcast of a multi-device -M run: the STAGED branch (the other
+    device's table brought over piece by piece through two buffers; forced here for two tables of one device with
+    RKMH_COUNTER_STAGED=1, several 64 MB pieces + a ragged tail) and tables that are only 4-byte aligned (a slice of a tensor the
+    counter wraps: the add falls back to dword accesses)."""
+    import sys
+    code = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+import rkmh_amd
+from rkmh_amd import api
+ctx = rkmh_amd.Context(0)
+slots = 40000003
+g = torch.Generator(device="cuda").manual_seed(7)
+for off in (0, 1):          # 16-byte aligned / only 4-byte aligned tables
+    a = torch.randint(0, 1000, (slots + 4,), dtype=torch.int32, device="cuda", generator=g)
+    b = torch.randint(0, 1000, (slots + 4,), dtype=torch.int32, device="cuda", generator=g)
+    want = (a + b)[off:off + slots].clone()
+    a0, b0 = a.clone(), b.clone()
+    ca = api.Counter(ctx, slots=slots, device_ptr=a[off:].data_ptr())
+    cb = api.Counter(ctx, slots=slots, device_ptr=b[off:].data_ptr())
+    ca.add(cb)
+    torch.cuda.synchronize()
+    assert bool((a[off:off + slots] == want).all()) and bool((b == b0).all())
+    assert bool((a[:off] == a0[:off]).all()) and bool((a[off + slots:] == a0[off + slots:]).all())      # nothing outside the table
+    cb.copy_from(ca)
+    torch.cuda.synchronize()
+    assert bool((b[off:off + slots] == want).all()) and bool((b[off + slots:] == b0[off + slots:]).all())
+    ca.destroy(); cb.destroy()
+ctx.close()
+print("COUNTER_ADD_OK")
+""" % root
+    for staged in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, cwd=root, env=dict(os.environ, RKMH_COUNTER_STAGED=staged), timeout=600)
+        assert r.returncode == 0 and b"COUNTER_ADD_OK" in r.stdout, (staged, r.stderr.decode()[-3000:])
+
+
+def test_rccl_path_at_world_size_one(orc, root, data_dir, golden_dir):
+    """The RCCL code path of rkmh_amd/dist.py executed for real on a one-GPU box: a process group of ONE rank on the nccl backend
+    (RKMH_DIST_FORCE=1 keeps the collectives from short-cutting at world size 1) through broadcast_sketches, allreduce_counter
+    (the table an rk_counter wraps) and gather_rows on device tensors -- and the whole python CLI with -M 2 the same way,
+    whose lines must equal the oracle's."""
+    import sys
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RKMH_DIST_FORCE="1", RKMH_DIST_BACKEND="nccl", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    code = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+import rkmh_amd
+from rkmh_amd import api, dist as rdist
+rank, local, world = rdist.init()
+assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" and world == 1
+rng = np.random.default_rng(3)
+sk0 = rng.integers(0, np.iinfo(np.uint64).max, size=(9, 64), dtype=np.uint64)
+ln0 = rng.integers(0, 65, size=9).astype(np.int32)
+sk, ln = rdist.broadcast_sketches(sk0, ln0, 9, 64, src=0, device=torch.device("cuda", 0))
+assert (sk == sk0).all() and (ln == ln0).all() and sk.dtype == np.uint64
+ctx = rkmh_amd.Context(0)
+t = torch.zeros(100003, dtype=torch.int32, device="cuda:0")
+cnt = api.Counter(ctx, slots=100003, device_ptr=t.data_ptr())
+for key in (5, 5, 100003 + 5, 77):
+    cnt.increment(key)
+ctx.synchronize()
+rdist.allreduce_counter(t)
+torch.cuda.synchronize()
+assert cnt.get(5) == 3 and cnt.get(77) == 1 and int(t.sum().item()) == 4
+rows = np.arange(4000, dtype=np.int32).reshape(1000, 4)
+got = rdist.gather_rows(rows, dst=0)
+assert got.shape == (1000, 4) and (got == rows).all()
+cnt.destroy(); ctx.close()
+torch.distributed.destroy_process_group()
+print("RCCL_WS1_OK")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, cwd=root, env=env, timeout=600)
+    assert r.returncode == 0 and b"RCCL_WS1_OK" in r.stdout, r.stderr.decode()[-3000:]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); env["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
+    r = subprocess.run([sys.executable, "-m", "rkmh_amd.cli", "stream", "-r", os.path.join(data_dir, "zika.refs.fa.gz"), "-f",
+                        os.path.join(data_dir, "z1.fq.gz"), "-k", "16", "-M", "2"], capture_output=True, cwd=root, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    refs = orc.kseq_parse_file(os.path.join(data_dir, "zika.refs.fa.gz"))
+    reads = orc.kseq_parse_file(os.path.join(data_dir, "z1.fq.gz"))
+    rb, ro = orc.pack([x[1] for x in refs])
+    qb, qo = orc.pack([x[1] for x in reads])
+    sk, ln = orc.sketch_refs(rb, ro, [16], 1000, threads=4)
+    o4 = orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=4, min_kmer_occ=2)
+    want = "".join(orc.stream_line(refs[o4[i, 0]][0].decode(), reads[i][0].decode(), o4[i, 1], o4[i, 2], o4[i, 3], 1000)
+                   for i in range(len(reads)))
+    # (librccl prints a version banner to stdout on some boxes: result lines are the ones with tabs)
+    got = "".join(l + "\n" for l in r.stdout.decode().splitlines() if "\t" in l)
+    assert got == want
 
 
 def test_many_references_sparse_counters(ctx, orc):
@@ -1057,9 +1205,11 @@ def test_count_pass_slot_partitioned_equals_atomic(data_dir, slots, ks, ragged, 
                 qb, qo = _ragged(qb, n, L, seed=3 + seed)
             batches.append((qb, qo))
         want = torch.zeros(slots, dtype=torch.int64, device=dev)
+        want_b = []
         for qb, qo in batches:
             h, ho = c.hash_batch(_pad(qb), qo, ks)
-            want += torch.bincount(torch.from_numpy((h % np.uint64(slots)).astype(np.int64)).to(dev), minlength=slots)
+            want_b.append(torch.bincount(torch.from_numpy((h % np.uint64(slots)).astype(np.int64)).to(dev), minlength=slots))
+            want += want_b[-1]
         want = want.to(torch.int32)
         store = torch.zeros(slots + 4, dtype=torch.int32, device=dev)
         table = store[1:slots + 1] if unaligned else store[:slots]
@@ -1098,6 +1248,18 @@ def test_count_pass_slot_partitioned_equals_atomic(data_dir, slots, ks, ragged, 
             c.count_device(dbs[1][0].data_ptr(), dbs[1][1].data_ptr(), n, cnt, stream=streams[1].cuda_stream)
             torch.cuda.synchronize()
             assert int((table != want).sum().item()) == 0
+            # three streams in the order atomic, atomic, partitioned: the partitioned pass must wait for BOTH atomic passes (they
+            # share one event, so the atomic passes are chained and the event of the second covers the first)
+            store.zero_()
+            torch.cuda.synchronize()
+            s3 = streams + [torch.cuda.Stream()]
+            os.environ["RKMH_COUNT_BINS"] = "0"
+            c.count_device(dbs[0][0].data_ptr(), dbs[0][1].data_ptr(), n, cnt, stream=s3[0].cuda_stream)
+            c.count_device(dbs[1][0].data_ptr(), dbs[1][1].data_ptr(), n, cnt, stream=s3[1].cuda_stream)
+            os.environ["RKMH_COUNT_BINS"] = "1"
+            c.count_device(dbs[0][0].data_ptr(), dbs[0][1].data_ptr(), n, cnt, stream=s3[2].cuda_stream)
+            torch.cuda.synchronize()
+            assert int((table != (2 * want_b[0] + want_b[1]).to(torch.int32)).sum().item()) == 0
         finally:
             os.environ.pop("RKMH_COUNT_BINS", None)
         cnt.destroy()

@@ -216,3 +216,32 @@ def test_hpv16_golden_matches_oracle(orc, golden_dir, data_dir):
     assert hashlib.sha256(tst.encode()).hexdigest() == g["tst_sha256"] and tst[:80] == g["tst_first_80"]
     # every one of the reference's own HPV16 nanopore reads names the HPV16 type reference
     assert all("HPV16" in l.split("\t")[1] for l in lines)
+
+
+def test_pin_tooling_reports_exactly_the_policy_of_the_probed_library(tmp_path):
+    """tools/pin_compare.py, which decides U1-U12 the day mkmh's sources exist (tools/pin_from_mkmh.sh), exercised on stand-in
+    probe files written from the oracle under KNOWN policies: exit 0 and no flips for the shipped defaults, exit 1 and exactly the
+    differing constants otherwise -- so that the first real run is not the script's debut."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen, cmp_ = os.path.join(root, "tools", "pin_probes_from_oracle.py"), os.path.join(root, "tools", "pin_compare.py")
+
+    def run(policy):
+        f = str(tmp_path / "probes.json")
+        subprocess.check_call([sys.executable, gen, f] + ["%s=%d" % kv for kv in policy.items()])
+        r = subprocess.run([sys.executable, cmp_, f], capture_output=True)
+        flips = {}
+        for line in r.stdout.decode().splitlines():
+            if line.startswith("  ") and " -> " in line:
+                k, v = line.strip().split(" -> ")
+                flips[k] = int(v)
+        return r.returncode, flips, r.stdout.decode()
+
+    rc, flips, out = run({})
+    assert rc == 0 and flips == {} and "reproduce every probe" in out
+    for policy in ({"fold": 1, "drop_last_window": 0, "counter_counts_zero": 0, "mask_strict_less": 0}, {"fold": 2}, {"drop_last_window": 0},
+                   {"counter_counts_zero": 0}, {"mask_strict_less": 0}, {"fold": 1, "mask_strict_less": 0}):
+        rc, flips, out = run(policy)
+        assert rc == 1 and flips == policy, (policy, out)
+        assert "AMBIGUOUS" not in out and "NO candidate" not in out
