@@ -112,20 +112,47 @@ __host__ __device__ __forceinline__ uint32_t kf4_sector(uint32_t core, uint32_t 
     return (uint32_t)(((uint64_t)(core * 0x85EBCA6Bu) * (uint64_t)n) >> 32);
 #endif
 }
-// the bits of a k-mer inside its dword: the TOP fifteen (ten with two bits per entry) bits of x * odd constant (mod 2^32), which every bit of x reaches -- a
-// window that differs from a found k-mer only in a base outside the core (a sequencing error in the flank) lands in the same
-// sector and must not land on the same bits (the middle bits of the 64-bit product, one instruction cheaper, fail that for the
-// low bases of x: they only reach bit 32 and up through a carry)
-__host__ __device__ __forceinline__ uint32_t kf4_h(uint32_t x) { return x * 0x9E3779B1u; }
+// The bits of a k-mer inside its dword.  RK_KF4_MID = 1 (round 4): three five-bit numbers out of the MIDDLE of the 64-bit product
+// p = x * odd constant -- bits 24..28 (byte 3 of the low half), 32..36 and 48..52 (bytes 0 and 2 of the high half).  Byte-aligned
+// fields cost one instruction each on the device (v_lshlrev_b32 takes the low five bits of its shift operand, SDWA selects the
+// byte: 1 << field without a shift or a mask in front), the whole test is v_mad_u64_u32 + 3 shifts + v_or3 + v_and + v_cmp = 7
+// instructions against 9 for three v_bfe of the top fifteen bits of the low half (RK_KF4_MID = 0, rounds 2-3) -- and the middle
+// bits mix better: 3.9 false candidates per C2 read against 4.1 (tools/kf4_fp_model.py, which also shows what does NOT work:
+// bytes 3,2,1 of the high half alone -- nearly linear in the top bases of x -- pass 6.1).
+#ifndef RK_KF4_MID
+#define RK_KF4_MID 1
+#endif
 #ifndef RK_KF4_NBITS
 #define RK_KF4_NBITS 3 // bits per entry.  3 against 2 (measured, each at its best density): C2 0.314 / 0.321 ms, 266 references 0.332 / 0.343,
                        // s = 2000 0.626 / 0.646, 400 references 0.407 / 0.397: fewer false candidates per byte of filter for one more bit test per window
 #endif
+__host__ __device__ __forceinline__ uint32_t kf4_h(uint32_t x) { return x * 0x9E3779B1u; }
 __host__ __device__ __forceinline__ uint32_t kf4_bits(uint32_t x) {
+#if RK_KF4_MID
+    const uint64_t p = (uint64_t)x * 0x9E3779B1ull;
+    const uint32_t lo = (uint32_t)p, hi = (uint32_t)(p >> 32);
+    uint32_t b = (1u << ((lo >> 24) & 31u)) | (1u << (hi & 31u));
+    if (RK_KF4_NBITS >= 3) b |= 1u << ((hi >> 16) & 31u);
+    return b;
+#else
     const uint32_t h = kf4_h(x);
     uint32_t b = (1u << (h >> 27)) | (1u << ((h >> 22) & 31u));
     if (RK_KF4_NBITS >= 3) b |= 1u << ((h >> 17) & 31u);
     return b;
+#endif
+}
+// kf4_bits on the device (same value; host compilation pass: the portable form)
+__device__ __forceinline__ uint32_t kf4_bits_dev(uint32_t x) {
+#if RK_KF4_MID && defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t p = (uint64_t)x * 0x9E3779B1ull;
+    const uint32_t lo = (uint32_t)p, hi = (uint32_t)(p >> 32), one = 1u;
+    uint32_t b3, b2 = 0u;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(b3) : "v"(lo), "v"(one));
+    if (RK_KF4_NBITS >= 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(b2) : "v"(hi), "v"(one));
+    return b3 | (1u << (hi & 31u)) | b2;
+#else
+    return kf4_bits(x);
+#endif
 }
 
 // reverse complement of a packed k-mer (k <= 16)

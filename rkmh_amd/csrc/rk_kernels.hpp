@@ -93,6 +93,22 @@ hipError_t launch_sort_intersect(const SortArgs& a, const RefIndex* ix, const De
 hipError_t launch_select_bottom(const uint64_t* hashes, uint64_t n, int S, const int32_t* counter, uint64_t slots,
                                 int filter_mode, int fmin, int fmax, const DevPolicy& pol, uint32_t* sel_state,
                                 uint32_t* hist, uint64_t* sel_out, hipStream_t st);
+// ---- FASTQ text indexed on the device (rk_fastq.hip) ----
+enum { FQ_BAD_CR = 1, FQ_BAD_LINES = 2, FQ_BAD_RECORD = 4, FQ_BAD_CHAR = 8, FQ_BAD_CAP = 16 }; // status bits: any of them = parse this block on the host
+struct FqDev {
+    uint32_t* chunk_cnt;   // [chunks + 1] newlines per 4 KB chunk
+    uint32_t* chunk_base;  // [chunks + 1] their exclusive scan; [chunks] = lines of the block
+    uint32_t* nl;          // [line_cap] newline positions
+    uint32_t line_cap, rec_cap;
+    uint32_t *seq_off, *seq_len, *qual_off, *name_off, *name_len; // [rec_cap + 1]
+    uint32_t* out_off;     // [rec_cap + 1] offsets of the packed batch
+    uint8_t* bases;        // packed batch (block bytes + slack)
+    uint32_t* info;        // [4] status bits, records, longest sequence, -
+    void* scan_tmp;
+    size_t scan_tmp_bytes;
+};
+size_t fq_scan_temp_bytes(uint32_t n);
+hipError_t launch_fastq_index(const FqDev& d, const uint8_t* raw, uint64_t nbytes, hipStream_t st);
 // whole-array ascending sort of u64 keys in place (rk_sort.hip: rocPRIM radix sort); tmp holds sort_u64_temp_bytes(n) bytes
 hipError_t sort_u64_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t launch_sort_u64(uint64_t* keys, uint64_t n, void* tmp, size_t tmp_bytes, hipStream_t st);

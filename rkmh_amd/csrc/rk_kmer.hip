@@ -46,6 +46,9 @@ constexpr int KM_MQ = 32;            // deferred multi-posting hits per drain (m
 #endif
 constexpr int KM_CH = RK_KMER_CH;     // steps (64 groups = 256 windows each) whose filter sectors are requested together
 constexpr int KM_QCAP = 64 + 4 * KW; // candidate queue entries (4 bytes each): a step adds at most 256 to a remainder of < 64
+#ifndef RK_KMER_QSTEP
+#define RK_KMER_QSTEP 1 // a last step of at most 16 groups runs a quarter wide (four lanes per group, one window each)
+#endif
 constexpr int KM_LDS_SMALL = 5120;   // static LDS of the common instantiation: 32 single-wave workgroups per CU (8 per SIMD)
 constexpr int KM_LDS_BIG = 20480;    // ... of the one for large hit multisets / counter rows (8 per CU)
 #ifndef RK_KMER_WAVES
@@ -73,7 +76,7 @@ template <int NQ>
 struct KmLds {
     static constexpr int PK = 0;                              // packed 2-bit image of the staged quads + two zero dwords (position P = byte P of the quads)
     static constexpr int INV = PK + NQ * 64 + 2;              // bit P set <=> base P is not ACGT (built only for tiles that hold one)
-    static constexpr int Q = INV + NQ * 32 + 2;               // candidate queue: P | read << 12 | (window within the read) << 15
+    static constexpr int Q = INV + NQ * 32 + 2;               // candidate queue: P | read << 12 (read 8: a lane without a group; rinfo[8] has no windows)
     static constexpr int MQ = Q + KM_QCAP;                    // [KM_MQ][2] deferred hits with a posting list: read | rank << 8, list offset
     static constexpr int RI = MQ + 2 * KM_MQ;                 // [9] uint4 {start position, windows, first group, -} of read t
     static constexpr int NZ = RI + 4 * (KM_MAX_T + 1);        // [8] zero hashes of read t
@@ -197,7 +200,10 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             u32x4 v = {0u, 0u, 0u, 0u};
             if (qi < nq) {
                 const uintptr_t qa = base16 + 16u * (uintptr_t)qi;
-                if (safe) v = RK_KMER_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(qa)) : *reinterpret_cast<const u32x4*>(qa);
+                if (safe) { // through a global-address-space pointer: the integer round trip would otherwise make it a flat load
+                    typedef const u32x4 __attribute__((address_space(1))) * gq_t;
+                    v = RK_KMER_NT ? __builtin_nontemporal_load((gq_t)qa) : *(gq_t)qa;
+                }
                 else {
                     uint32_t d[4];
 #pragma unroll
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         gs += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gs, 0x112, 0xf, 0xf, true); // row_shr:2
         gs += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gs, 0x114, 0xf, 0xf, true); // row_shr:4
         const uint32_t NG = (uint32_t)__builtin_amdgcn_readlane((int)gs, KM_MAX_T - 1); // groups of the tile
-        if (lane <= KM_MAX_T) rinfo[lane] = make_uint4(cur_o - ta + mis, nw, gs - ng, 0u); // entries past the tile's last read: no windows, first group = NG
+        if (lane <= KM_MAX_T) rinfo[lane] = make_uint4(cur_o - ta + mis, nw, gs - ng, 0u); // entries past the tile's last read (and entry 8, always): no windows, first group = NG
         { // clear the hit multisets (repeats only exist within one k-mer size: different sizes never share a hash): 16 bytes per lane and store
             uint4* d4 = reinterpret_cast<uint4*>(dset);
             for (uint32_t i = lane; i < ((uint32_t)Tn * DS) >> 2; i += KW) d4[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -308,6 +314,11 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         const bool uniform = same_len && gpr_u >= 2u; // >= 2: the magic division needs a divisor > 1
         uint32_t magic = 0;
         if (uniform) magic = ulen == (uint32_t)geo.L ? geo.magic[kk] : (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu / gpr_u + 1u));
+        // P0 of group G of a tile of equally long reads: read t = G / gpr starts at mis + t ulen, group g = G - t gpr at + 4 g, so
+        // P0 = (mis + 4 G) + t (ulen - 4 gpr): one multiply-add.  The two constants live in VGPRs (broadcast): as scalars they were
+        // spilled to VGPR lanes and read back with a v_readlane each in every step (the kernel has registers to spare, not SGPRs).
+        uint32_t magic_v = magic, dlen_v = ulen - 4u * gpr_u;
+        asm volatile("" : "+v"(magic_v), "+v"(dlen_v));
 
         // +1 for reference `ref` of read t, whose counter row starts crow_b bytes into cnt; the monotone counters make
         // (max_shared, first max_id) a running atomicMax
@@ -355,14 +366,15 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         const uint32_t km_vmask = (1u << (km_vb1 - 1u)) - 1u, km_rmask = (1u << km_r) - 1u, nref = (uint32_t)ix.nref;
         auto lookup = [&](uint32_t e, uint32_t qn) -> Cand {
             Cand c;
-            uint32_t ent = PAD_P | (0x1FFFFu << 15); // past the queue's end: the all-A k-mer of the padding, never a window of its read
+            uint32_t ent = PAD_P | (8u << 12); // past the queue's end: the all-A k-mer of the padding, of read 8 which has no windows
             if (e < qn) ent = q[e];
-            const uint32_t P = ent & 4095u, t = (ent >> 12) & 7u, o = ent >> 15;
+            const uint32_t P = ent & 4095u, t = ent >> 12;
             const km_pair1 w = *reinterpret_cast<const km_pair1*>(reinterpret_cast<const uint8_t*>(pk) + (P >> 2));
             const uint32_t x = __builtin_amdgcn_alignbit(w.y, w.x, (P & 3u) << 1) & KMASK;
             const uint32_t r = packed_revcomp(x, k);
             c.key = x < r ? x : r;
-            c.t = o < rinfo[t].y ? t : 0xFFFFFFFFu; // the last group of a read may reach past its last window
+            const uint2 ri = *reinterpret_cast<const uint2*>(&rinfo[t]);
+            c.t = P - ri.x < ri.y ? t : 0xFFFFFFFFu; // window number = position - read start; the last group of a read may reach past its last window
             c.y = km1_y(c.key, k);
             c.c = km1p[c.y >> km_r];
             return c;
@@ -455,70 +467,90 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
 
         // ---- window phase: 64 groups (256 windows) per step, KM_CH steps' filter sectors requested together ---------------------
         const uint32_t nsteps = (NG + KW - 1) / KW;
+        // a last step of 1 .. 16 groups runs a QUARTER wide: four lanes per group, one window (and one dword of the sector) each --
+        // a fourth of the window tests for the step that would otherwise run 64 lanes for a dozen groups (six 150-base reads: 204 groups)
+        const bool qlast = RK_KMER_QSTEP && NG != 0u && ((NG - 1u) & (uint32_t)(KW - 1)) < 16u;
+        const uint32_t kf4_n16 = kf4_n << 4; // (sector count < 2^28: checked where the filter is built)
         uint32_t qcount = 0;
         uint32_t step = 0;
         for (;;) {
             // issue: every lane computes; a lane without a group looks at the image's zero padding (the all-A k-mer) and tags its
-            // candidates, should the filter pass that k-mer, with a window number no read has -- the drain drops them
-            uint32_t wl[KM_CH], wh[KM_CH], e0v[KM_CH];
+            // candidates, should the filter pass that k-mer, with read 8, which has no windows -- the drain drops them
+            uint32_t wl[KM_CH], wh[KM_CH], e0v[KM_CH], fq[KM_CH];
             u32x4 fw[KM_CH];
+            bool isqv[KM_CH];
 #pragma unroll
             for (int s = 0; s < KM_CH; ++s) {
-                const uint32_t G = (step + (uint32_t)s) * KW + (uint32_t)lane;
-                uint32_t t, g, rs;
+                const bool isq = qlast && step + (uint32_t)s + 1u == nsteps; // wave-uniform
+                isqv[s] = isq;
+                const uint32_t jq = isq ? (uint32_t)lane & 3u : 0u;
+                const uint32_t G = (step + (uint32_t)s) * KW + (isq ? (uint32_t)lane >> 2 : (uint32_t)lane);
+                uint32_t t, P0;
                 if (uniform) { // wave-uniform
-                    t = __umulhi(G, magic);
-                    g = G - __umul24(t, gpr_u);
-                    rs = mis + __umul24(t, ulen);
+                    t = __umulhi(G, magic_v);
+                    P0 = __umul24(t, dlen_v) + ((G << 2) + mis);
                 } else {
                     t = 0; // the last read whose first group is <= G (rinfo[i].z of reads past the tile's last is NG)
 #pragma unroll
                     for (int i = 1; i < KM_MAX_T; ++i) t += G >= rinfo[i].z ? 1u : 0u;
                     const uint4 ri = rinfo[t];
-                    g = G - ri.z;
-                    rs = ri.x;
+                    P0 = ri.x + 4u * (G - ri.z);
                 }
                 const bool act = G < NG;
-                const uint32_t P0 = act ? rs + 4u * g : PAD_P;
-                e0v[s] = act ? (P0 | (t << 12) | (g << 17)) : (PAD_P | (0x1FFFCu << 15));
+                if (!act) { P0 = PAD_P; t = 8u; }
                 const km_pair1 w = *reinterpret_cast<const km_pair1*>(reinterpret_cast<const uint8_t*>(pk) + (P0 >> 2));
                 const uint32_t sh = (P0 & 3u) << 1;
                 wl[s] = __builtin_amdgcn_alignbit(w.y, w.x, sh);
                 wh[s] = w.y >> sh;
                 const uint32_t core = k == 16 ? wl[s] >> 6 : (wl[s] >> 6) & CMASK; // k = 16: the 13-mer is all of bits 6..31
-                fw[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(kf4p) + ((uint64_t)kf4_sector(core, kf4_n) << 4));
+                // byte offset of the sector: 16 * (hashed core scaled to [0, kf4_n)) = the high product with 16 kf4_n, less its low four bits
+                const uint32_t sect_b = __umulhi(core * 0x85EBCA6Bu, kf4_n16) & ~15u;
+                e0v[s] = P0 | (t << 12);
+                fq[s] = 0u;
+                fw[s] = u32x4{0u, 0u, 0u, 0u}; // (defined on both paths: left undefined, the compiler reuses a register still in flight and waits)
+                if (isq) { // this lane's window of the group: its k-mer moves to the front, its entry names position + jq
+                    wl[s] = __builtin_amdgcn_alignbit(wh[s], wl[s], 2u * jq);
+                    if (act) e0v[s] += jq;
+                    fq[s] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(kf4p) + (sect_b + 4u * jq));
+                } else fw[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(kf4p) + sect_b);
             }
             // test + push.  has_invalid (a tile with a non-ACGT base, rare) runs its own copy of the code.
             bool stop = false;
             uint32_t done = 0;
-            auto test_step = [&](int s, auto inv_tag) {
+            auto test_step = [&](int s, auto inv_tag, auto nw_tag) {
                 constexpr bool INV = decltype(inv_tag)::value;
-                uint32_t ib = 0, nz = 0, nwt = 0, t_ = 0;
+                constexpr int NW = decltype(nw_tag)::value; // windows this lane tests: 4, or 1 in a quarter-wide step (wl / fq / e0v are then that window's)
+                uint32_t ib = 0, nz = 0, nwt = 0, t_ = 0, o0 = 0;
                 bool act = true;
                 if constexpr (INV) {
                     const uint32_t P0 = e0v[s] & 4095u;
-                    act = P0 != PAD_P;
-                    t_ = (e0v[s] >> 12) & 7u;
-                    if (act) { ib = __builtin_amdgcn_alignbit(inv[(P0 >> 5) + 1], inv[P0 >> 5], P0 & 31u); nwt = rinfo[t_].y; }
+                    t_ = e0v[s] >> 12;
+                    act = t_ != 8u;
+                    if (act) {
+                        ib = __builtin_amdgcn_alignbit(inv[(P0 >> 5) + 1], inv[P0 >> 5], P0 & 31u);
+                        const uint2 ri = *reinterpret_cast<const uint2*>(&rinfo[t_]);
+                        nwt = ri.y; o0 = P0 - ri.x; // windows of the read, window number of this lane's first window
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NW; ++j) {
                     uint32_t x = j == 0 ? wl[s] : __builtin_amdgcn_alignbit(wh[s], wl[s], 2 * j);
                     if (k < 16) x &= KMASK;
-                    const uint32_t h = kf4_h(x);
-                    const uint32_t f = j == 0 ? fw[s].x : (j == 1 ? fw[s].y : (j == 2 ? fw[s].z : fw[s].w));
-                    bool cand;
-                    if (RK_KF4_NBITS >= 3) cand = (__builtin_amdgcn_ubfe(f, h >> 27, 1u) & __builtin_amdgcn_ubfe(f, h >> 22, 1u) & __builtin_amdgcn_ubfe(f, h >> 17, 1u)) != 0u;
-                    else cand = (__builtin_amdgcn_ubfe(f, h >> 27, 1u) & __builtin_amdgcn_ubfe(f, h >> 22, 1u)) != 0u;
+                    const uint32_t f = NW == 1 ? fq[s] : (j == 0 ? fw[s].x : (j == 1 ? fw[s].y : (j == 2 ? fw[s].z : fw[s].w)));
+                    const uint32_t fb = kf4_bits_dev(x);
+                    bool cand = (fb & f) == fb; // (not (fb & ~f) == 0: the compiler moves a NOT of the loaded dword up to the load and waits there)
                     if constexpr (INV) {
                         if (act && ((ib >> j) & KBITS) != 0u) { // a window holding a non-ACGT base hashes to 0 (if it is a window of the read)
                             cand = false;
-                            if ((e0v[s] >> 15) + (uint32_t)j < nwt) ++nz;
+                            if (o0 + (uint32_t)j < nwt) ++nz;
                         }
                     }
                     const uint64_t m = __builtin_amdgcn_ballot_w64(cand);
                     // inverse_ballot turns the mask back into the branch predicate (no second compare for the exec mask)
-                    if (__builtin_amdgcn_inverse_ballot_w64(m)) q[qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = e0v[s] + (uint32_t)j * 0x8001u;
+                    if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                        const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(q) + ((mb << 2) + (qcount << 2))) = e0v[s] + (uint32_t)j;
+                    }
                     qcount += (uint32_t)__builtin_popcountll(m);
                 }
                 if constexpr (INV) { if (nz) atomicAdd(&nzero[t_], nz); }
@@ -530,8 +562,11 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                     else {
                         ++done;
                         if (RK_KMER_ABL & 1) { if (wl[s] == 0x12345u && fw[s].x == 77u) q[qcount++] = e0v[s]; }
-                        else if (has_invalid) test_step(s, std::true_type{});
-                        else test_step(s, std::false_type{});
+                        else if (isqv[s]) { // wave-uniform
+                            if (has_invalid) test_step(s, std::true_type{}, std::integral_constant<int, 1>{});
+                            else test_step(s, std::false_type{}, std::integral_constant<int, 1>{});
+                        } else if (has_invalid) test_step(s, std::true_type{}, std::integral_constant<int, 4>{});
+                        else test_step(s, std::false_type{}, std::integral_constant<int, 4>{});
                     }
                 }
             }

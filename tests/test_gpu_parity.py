@@ -640,6 +640,7 @@ for off in (0, 1):          # 16-byte aligned / only 4-byte aligned tables
     a0, b0 = a.clone(), b.clone()
     ca = api.Counter(ctx, slots=slots, device_ptr=a[off:].data_ptr())
     cb = api.Counter(ctx, slots=slots, device_ptr=b[off:].data_ptr())
+    torch.cuda.synchronize()      # the tables were filled on torch's stream; the library works on its context's own
     ca.add(cb)
     torch.cuda.synchronize()
     assert bool((a[off:off + slots] == want).all()) and bool((b == b0).all())

@@ -70,7 +70,7 @@ def bits_scheme(name, x):
         return f(g, 24) | f(g, 16) | f(g, 8)
     if name == "lo byte 3 + hi bytes 0,1":
         return f(lo, 24) | f(hi, 0) | f(hi, 8)
-    if name == "lo byte 3 + hi bytes 0,2":
+    if name == "lo byte 3 + hi bytes 0,2":  # = RK_KF4_MID (shipped from round 4)
         return f(lo, 24) | f(hi, 0) | f(hi, 16)
     if name == "lo bytes 2,3 + hi byte 0":
         return f(lo, 24) | f(lo, 16) | f(hi, 0)
