@@ -275,6 +275,13 @@ void rk_seqset_free(rk_seqset* s);
  * line-structured falls back to the sequential kseq-grammar scanner with identical results. */
 typedef struct rk_reader rk_reader;
 int rk_reader_open(const char* path, rk_reader** out);
+/* the same reader, starting `offset` bytes into the file at a record start (how a file is handed from the device-side FASTQ front
+ * end, rk_fastq_slot_*, to this scanner at the first block the device refuses) */
+int rk_reader_open_at(const char* path, uint64_t offset, rk_reader** out);
+/* the records that START in bytes [lo, hi) of a regular uncompressed FASTQ file (how the ranks of a multi-process run each read
+ * their own part of the reads); valid only while rk_reader_strict() stays 1 -- see rk_parse.cpp */
+int rk_reader_open_range(const char* path, uint64_t lo, uint64_t hi, rk_reader** out);
+int rk_reader_strict(const rk_reader* r);
 #define RK_READER_NO_QUALS 1 /* do not keep quality strings (stream/classify never read them) */
 void rk_reader_set_options(rk_reader* r, int flags);
 int rk_reader_next(rk_reader* r, int64_t max_records, uint64_t max_bases, rk_seqset* out);
@@ -285,6 +292,38 @@ void rk_reader_close(rk_reader* r);
  * Host-side utility for bench.py and the tests; out holds (hi-lo)*read_len bytes. */
 int rk_synth_reads(const uint8_t* ref_bases, const uint64_t* ref_offsets, int nref, uint64_t lo, uint64_t hi,
                    int read_len, uint64_t seed, uint8_t* out, int threads);
+
+/* ------------------------------------------------------------------------------------------------
+ * FASTQ text parsed ON THE DEVICE: a block of raw FASTQ text (as it lies in the file, starting at a record start and ending after
+ * a record's last newline) is uploaded, split into records, checked, packed and classified by the GPU (rk_fastq.hip) -- the
+ * device-side replacement of the host loop  parse_fastas -> kseq_read  (src/rkmh.cpp:238-263; grammar src/kseq.hpp:170-208)
+ * followed by the per-read loop (src/rkmh.cpp:845-898), for text that is strictly four lines per record.  For any other text
+ * (multi-line sequences, blank lines, carriage returns, '>' / '+' / '@' inside a sequence, a quality string of another length,
+ * ...) the call reports status != 0 and leaves the block to the kseq-grammar scanner (rk_reader_* / rk_parse_*): it never guesses.
+ * One slot = one block in flight (own stream, page-locked text buffer); several slots of a context may be used from several threads.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rk_fastq_slot rk_fastq_slot;
+typedef struct rk_fastq_result {
+    int32_t status;            /* 0: the fields below are valid; != 0 (RK_FASTQ_* bits): parse this block on the host instead */
+    int64_t nrec;              /* records of the block */
+    const int32_t* out4;       /* [nrec][4] rows (max_id, max_shared, diff, min_num) as rk_classify_batch writes them */
+    const uint32_t* name_off;  /* name of record i = text[name_off[i] .. name_off[i] + name_len[i])  (header up to the first whitespace) */
+    const uint32_t* name_len;
+    const uint32_t* seq_off;   /* its sequence = text[seq_off[i] .. + seq_len[i]) */
+    const uint32_t* seq_len;
+} rk_fastq_result;             /* the arrays live in the slot and are overwritten by its next call */
+#define RK_FASTQ_CR 1          /* a carriage return somewhere in the block */
+#define RK_FASTQ_LINES 2       /* lines do not come in fours / no final newline */
+#define RK_FASTQ_RECORD 4      /* a record without '@' / '+' line starts, with an empty sequence or a quality string of another length */
+#define RK_FASTQ_CHAR 8        /* a sequence byte kseq would not keep, or a quality byte outside 33..127 */
+#define RK_FASTQ_CAP 16        /* more records than a block of this size is sized for (records of under 64 bytes on average) */
+int rk_fastq_slot_create(rk_ctx* ctx, uint64_t max_bytes, rk_fastq_slot** out);
+uint8_t* rk_fastq_slot_text(rk_fastq_slot* slot);  /* page-locked buffer of max_bytes: the caller fills it with the block's text */
+int rk_fastq_slot_classify(rk_fastq_slot* slot, uint64_t nbytes, rk_fastq_result* res);
+void rk_fastq_slot_destroy(rk_fastq_slot* slot);
+/* Where to cut: the offset of the LAST record start in text[1 .. n) under the four-line rule (a line that begins with '@' whose
+ * second line below begins with '+'), or -1 when there is none: text[0 .. offset) then holds whole records only. */
+int64_t rk_fastq_cut(const uint8_t* text, uint64_t n);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,14 @@ _SIGS = {
     "rk_reader_next": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(SeqSet)]),
     "rk_reader_set_options": (None, [C.c_void_p, C.c_int]),
     "rk_reader_close": (None, [C.c_void_p]),
+    "rk_reader_open_at": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "rk_reader_open_range": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "rk_reader_strict": (C.c_int, [C.c_void_p]),
+    "rk_fastq_slot_create": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "rk_fastq_slot_text": (C.c_void_p, [C.c_void_p]),
+    "rk_fastq_slot_classify": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "rk_fastq_slot_destroy": (None, [C.c_void_p]),
+    "rk_fastq_cut": (C.c_int64, [C.c_void_p, C.c_uint64]),
     "rk_synth_reads": (C.c_int, [_u8p, _u64p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, _u8p, C.c_int]),
 }
 
@@ -185,26 +193,28 @@ def _seqset_to_py(ss):
     return {"bases": bases, "offsets": offs, "names": names, "quals": quals, "nseq": n}
 
 
+def _pinned_block(nbytes):
+    """A ctypes byte array over rk_host_alloc memory that frees it when the LAST reference to the array goes away: numpy views made
+    with np.frombuffer keep the ctypes object alive through their .base chain, so the page-locked memory lives exactly as long as
+    any view of it (the DMA engine may still be reading or writing it until then)."""
+    import weakref
+    lib = load_library()
+    ptr = C.c_void_p()
+    _chk(lib.rk_host_alloc(max(nbytes, 1), C.byref(ptr)))
+    buf = (C.c_uint8 * max(nbytes, 1)).from_address(ptr.value)
+    weakref.finalize(buf, lib.rk_host_free, C.c_void_p(ptr.value))
+    return buf
+
+
 class PinnedArray:
-    """A numpy view of page-locked host memory from rk_host_alloc (freed when the object dies): the host entry points read and
-    write such buffers by DMA where they lie."""
+    """A numpy array in page-locked host memory from rk_host_alloc: the host entry points read and write such buffers by DMA where
+    they lie.  The memory belongs to `.array` (and to every view of it): it is freed when the last of them is collected, not when
+    this wrapper is."""
 
     def __init__(self, shape, dtype):
-        lib = load_library()
-        self._lib = lib
-        self._ptr = C.c_void_p()
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-        _chk(lib.rk_host_alloc(max(nbytes, 1), C.byref(self._ptr)))
-        buf = (C.c_uint8 * max(nbytes, 1)).from_address(self._ptr.value)
+        buf = _pinned_block(nbytes)
         self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-
-    def __del__(self):
-        try:
-            if self._ptr:
-                self._lib.rk_host_free(self._ptr)
-                self._ptr = None
-        except Exception:
-            pass
 
 
 def pinned_array(shape, dtype):
@@ -253,6 +263,42 @@ class Reader:
             pass
 
 
+def parse_file_range(path, lo, hi):
+    """The records that START in bytes [lo, hi) of a regular uncompressed FASTQ file (rk_reader_open_range): how each rank of a
+    multi-process run reads only its own part of the reads.  Returns the same dict as parse_files plus "strict": False means the
+    text is not four lines per record, the range boundaries cannot be trusted and the caller must parse the whole file instead.
+    Raises RkmhError for input that cannot be split at all (gzip, FASTA, STDIN)."""
+    lib = load_library()
+    h = C.c_void_p()
+    _chk(lib.rk_reader_open_range(os.fsencode(path), int(lo), int(hi), C.byref(h)))
+    parts = []
+    try:
+        while True:
+            ss = SeqSet()
+            _chk(lib.rk_reader_next(h, 1 << 22, 1 << 30, C.byref(ss)))
+            n = ss.nseq
+            if n:
+                parts.append(_seqset_to_py(ss))
+            lib.rk_seqset_free(C.byref(ss))
+            if n == 0:
+                break
+        strict = bool(lib.rk_reader_strict(h))
+    finally:
+        lib.rk_reader_close(h)
+    if not parts:
+        return {"bases": np.zeros(16, np.uint8), "offsets": np.zeros(1, np.uint64), "names": [], "quals": [], "nseq": 0, "strict": strict}
+    out = parts[0]
+    for p in parts[1:]:
+        nb = int(out["offsets"][-1])
+        out["bases"] = np.concatenate([out["bases"][:nb], p["bases"]])
+        out["offsets"] = np.concatenate([out["offsets"], p["offsets"][1:] + np.uint64(nb)])
+        out["names"] += p["names"]
+        out["quals"] = None if out["quals"] is None or p["quals"] is None else out["quals"] + p["quals"]
+        out["nseq"] += p["nseq"]
+    out["strict"] = strict
+    return out
+
+
 def format_stream_line(ref_name, read_name, max_shared, diff, min_num, sketch_size, min_matches=-1, min_diff=0):
     lib = load_library()
     cap = len(ref_name) + len(read_name) + 128
@@ -270,6 +316,56 @@ def device_props(device=0) -> dict:
     cu, khz, l2, hbm = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
     _chk(lib.rk_device_props(device, C.byref(cu), C.byref(khz), C.byref(l2), C.byref(hbm)))
     return {"compute_units": cu.value, "clock_khz": khz.value, "l2_bytes": l2.value, "hbm_bytes": hbm.value}
+
+
+class FastqResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("nrec", C.c_int64), ("out4", C.POINTER(C.c_int32)), ("name_off", C.POINTER(C.c_uint32)),
+                ("name_len", C.POINTER(C.c_uint32)), ("seq_off", C.POINTER(C.c_uint32)), ("seq_len", C.POINTER(C.c_uint32))]
+
+
+def fastq_cut(text: bytes) -> int:
+    """Offset of the last record start in text[1:] under the four-line rule, or -1 (rk_fastq_cut)."""
+    b = (C.c_char * len(text)).from_buffer_copy(text)
+    return int(load_library().rk_fastq_cut(C.cast(b, C.c_void_p), len(text)))
+
+
+class FastqSlot:
+    """One block of raw FASTQ text in flight (rk_fastq_slot_*): the text is split into records, checked, packed and classified on the device."""
+
+    def __init__(self, ctx, max_bytes=1 << 26):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.max_bytes = max_bytes
+        _chk(self._lib.rk_fastq_slot_create(ctx._h, max_bytes, C.byref(self._h)))
+
+    def classify(self, text: bytes):
+        """Returns (status, rows [n,4] int32, names [n] bytes, seqs [n] bytes); status != 0: the block must be parsed on the host."""
+        n = len(text)
+        if n > self.max_bytes:
+            raise ValueError("block larger than the slot")
+        C.memmove(self._lib.rk_fastq_slot_text(self._h), text, n)
+        res = FastqResult()
+        _chk(self._lib.rk_fastq_slot_classify(self._h, n, C.byref(res)))
+        if res.status != 0 or res.nrec == 0:
+            return int(res.status), np.zeros((0, 4), np.int32), [], []
+        m = int(res.nrec)
+        rows = np.ctypeslib.as_array(res.out4, shape=(m, 4)).copy()
+        no = np.ctypeslib.as_array(res.name_off, shape=(m,)); nl = np.ctypeslib.as_array(res.name_len, shape=(m,))
+        so = np.ctypeslib.as_array(res.seq_off, shape=(m,)); sl = np.ctypeslib.as_array(res.seq_len, shape=(m,))
+        names = [text[int(no[i]): int(no[i]) + int(nl[i])] for i in range(m)]
+        seqs = [text[int(so[i]): int(so[i]) + int(sl[i])] for i in range(m)]
+        return 0, rows, names, seqs
+
+    def destroy(self):
+        if self._h:
+            self._lib.rk_fastq_slot_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 class Counter:

@@ -10,6 +10,7 @@ on the gathered rows, passing reads printed by rank 0 in input order.  (The sing
 `call` and `hash` exist only there: a 52 k-read `call` takes 0.2 s on one GPU.)
 """
 import getopt
+import os
 import sys
 
 import numpy as np
@@ -63,6 +64,12 @@ def main_stream(argv, filter_mode=False):
     if filter_mode and (in_stream or not reads):
         sys.stderr.write("rkmh_amd.cli filter: file mode only (-f); for -i use bin/rkmh filter\n")
         return 1
+    # The result lines own standard output: descriptor 1 is kept aside for them and re-pointed at standard error for everything else
+    # in the process (RCCL prints a version banner, gloo its connection messages -- to stdout, which a drop-in tool must not do).
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    out = os.fdopen(result_fd, "wb")
     rank, local, world = rdist.init()
     ctx = api.Context(local)
     R = api.parse_files(refs)
@@ -81,12 +88,41 @@ def main_stream(argv, filter_mode=False):
     sk, ln = rdist.broadcast_sketches(sk, ln, R["nseq"], sketch, src=0)
     if rank != 0:
         ctx.set_reference_sketches(sk, ln, ks, sketch)
-    Q = api.parse_files(reads)  # every rank parses; it classifies only its block
-    lo, hi = rdist.shard_bounds(Q["nseq"], rank, world)
-    offs = Q["offsets"][lo: hi + 1]
-    b0, b1 = int(offs[0]), int(offs[-1])
-    bases = np.concatenate([Q["bases"][b0:b1], np.zeros(16, np.uint8)])
-    offs = offs - np.uint64(b0)
+    # Every rank reads ITS part of the reads only: byte range rank/world of every uncompressed FASTQ file, cut at record starts
+    # (rk_reader_open_range); the ranks' record counts put the blocks back in input order.  Text that is not four lines per record
+    # (or gzip / FASTA input) cannot be split by bytes: if ANY rank finds that, all of them parse everything and shard by record index.
+    parts, ok = [], world > 1 and not os.environ.get("RKMH_CLI_WHOLE_PARSE")
+    for path in (reads if ok else []):
+        try:
+            size = os.path.getsize(path)
+            part = api.parse_file_range(path, size * rank // world, size * (rank + 1) // world)
+        except (OSError, api.RkmhError):
+            ok = False
+            break
+        if not part["strict"]:
+            ok = False
+            break
+        parts.append(part)
+    sharded_ingest = world > 1 and rdist.all_true(ok and len(parts) == len(reads))
+    if sharded_ingest:
+        Q = parts[0]
+        for p in parts[1:]:   # this rank's share of every file, file after file
+            nb = int(Q["offsets"][-1])
+            Q = {"bases": np.concatenate([Q["bases"][:nb], p["bases"]]), "offsets": np.concatenate([Q["offsets"], p["offsets"][1:] + np.uint64(nb)]),
+                 "names": Q["names"] + p["names"], "nseq": Q["nseq"] + p["nseq"],
+                 "quals": None if Q["quals"] is None or p["quals"] is None else Q["quals"] + p["quals"]}
+        file_counts = [p["nseq"] for p in parts]
+        bases, offs = Q["bases"], Q["offsets"]
+        lo = 0
+    else:
+        Q = api.parse_files(reads)  # every rank parses; it classifies only its block of records
+        lo, hi = rdist.shard_bounds(Q["nseq"], rank, world)
+        offs = Q["offsets"][lo: hi + 1]
+        b0, b1 = int(offs[0]), int(offs[-1])
+        bases = np.concatenate([Q["bases"][b0:b1], np.zeros(16, np.uint8)])
+        offs = offs - np.uint64(b0)
+        file_counts = None
+    nmine = len(offs) - 1
     counter = None
     if min_occ is not None:
         import torch
@@ -101,29 +137,36 @@ def main_stream(argv, filter_mode=False):
             torch.cuda.synchronize()
         ctx.set_depth_filter(counter, min_occ)
     rows = ctx.classify(bases, offs)
-    allrows = rdist.gather_rows(rows, dst=0)
-    if rank == 0 and filter_mode:
-        out = sys.stdout.buffer
-        qoff, qbases, quals = Q["offsets"], Q["bases"], Q.get("quals")
-        for i in range(Q["nseq"]):
-            r = allrows[i]
-            # classify_and_count_diff_filter scans from max_shared = prev_best = 0 (the stream scan starts at -1)
-            if int(r[1]) <= 0:
-                shared, diff_ok = 0, 0 > min_diff
-            else:
-                shared, diff_ok = int(r[1]), (int(r[2]) - (1 if int(r[0]) == 0 else 0)) > min_diff
-            if int(r[3]) <= 0 or shared < min_matches or not diff_ok:      # rkmh.cpp:1292-1298
-                continue
-            a, b = int(qoff[i]), int(qoff[i + 1])
-            out.write(b">" + Q["names"][i] + b"\n" + _upper(qbases[a:b]) + b"\n+\n" +
-                      (quals[i] if quals is not None else b"") + b"\n")   # rkmh.cpp:1299-1302
-        out.flush()
-    elif rank == 0:
-        out = sys.stdout.buffer
-        for i in range(Q["nseq"]):
-            r = allrows[i]
-            out.write(api.format_stream_line(R["names"][int(r[0])], Q["names"][i], int(r[1]), int(r[2]), int(r[3]), sketch,
-                                             min_matches, min_diff))
+    # every rank formats the lines of ITS reads; rank 0 gathers the text in rank order (file by file when the ingest was sharded by bytes)
+    qoff, qbases, quals, qnames = Q["offsets"], Q["bases"], Q.get("quals"), Q["names"]
+
+    def fmt(i_local):
+        i = lo + i_local
+        r = rows[i_local]
+        if not filter_mode:
+            return api.format_stream_line(R["names"][int(r[0])], qnames[i], int(r[1]), int(r[2]), int(r[3]), sketch, min_matches, min_diff)
+        # classify_and_count_diff_filter scans from max_shared = prev_best = 0 (the stream scan starts at -1)
+        if int(r[1]) <= 0:
+            shared, diff_ok = 0, 0 > min_diff
+        else:
+            shared, diff_ok = int(r[1]), (int(r[2]) - (1 if int(r[0]) == 0 else 0)) > min_diff
+        if int(r[3]) <= 0 or shared < min_matches or not diff_ok:      # rkmh.cpp:1292-1298
+            return b""
+        a, b = int(qoff[i]), int(qoff[i + 1])
+        return b">" + qnames[i] + b"\n" + _upper(qbases[a:b]) + b"\n+\n" + (quals[i] if quals is not None else b"") + b"\n"   # rkmh.cpp:1299-1302
+
+    if file_counts is None:
+        text = rdist.gather_bytes(b"".join(fmt(i) for i in range(nmine)), dst=0)
+        if rank == 0:
+            out.write(text)
+    else:
+        first = 0
+        for cnt_f in file_counts:
+            text = rdist.gather_bytes(b"".join(fmt(i) for i in range(first, first + cnt_f)), dst=0)
+            if rank == 0:
+                out.write(text)
+            first += cnt_f
+    if rank == 0:
         out.flush()
     if counter is not None:
         ctx.set_depth_filter(None, 0)

@@ -130,6 +130,7 @@ struct rk_ctx {
     RefIndex ix{};
     bool have_refs = false;
     double density = 1.0; // fraction of a reference's k-mers that its sketch keeps (largest over references)
+    std::mutex general_mu; // the general path (rerouted rows) works in the context's own buffers: FASTQ slots take turns
     // -M
     rk_counter* depth = nullptr;
     int min_occ = 0;
@@ -1843,5 +1844,130 @@ extern "C" int rk_call(rk_ctx* c, const uint8_t* ref_bases, const uint64_t* ref_
     if (!r) return fail(RK_ERR_NOMEM, "malloc");
     if (!recs.empty()) memcpy(r, recs.data(), recs.size() * sizeof(rk_call_record));
     *out = r; *nout = (int64_t)recs.size();
+    return RK_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// FASTQ text parsed on the device (rk_fastq.hip): one slot = one block in flight (its own stream, page-locked text buffer, device
+// arrays).  Several slots of one context may be driven from several host threads at once.
+struct rk_fastq_slot {
+    rk_ctx* c = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr; // blocking-sync event: a dozen host threads wait for their blocks at once and must SLEEP while they
+                             // do (hipStreamSynchronize spins: the waiting threads would take the cores the reading and formatting ones need)
+    uint64_t max_bytes = 0;
+    PinBuf h_text, h_out4, h_spans, h_info;
+    DevBuf d_text, d_u32, d_bases, d_out4, d_scan;
+    FqDev d{};
+};
+
+extern "C" void rk_fastq_slot_destroy(rk_fastq_slot* s) {
+    if (!s) return;
+    if (s->c) { hipError_t e = hipSetDevice(s->c->device); (void)e; }
+    if (s->st) { hipError_t e = hipStreamSynchronize(s->st); (void)e; e = hipStreamDestroy(s->st); (void)e; }
+    if (s->ev) { hipError_t e = hipEventDestroy(s->ev); (void)e; }
+    for (PinBuf* b : {&s->h_text, &s->h_out4, &s->h_spans, &s->h_info}) b->release();
+    for (DevBuf* b : {&s->d_text, &s->d_u32, &s->d_bases, &s->d_out4, &s->d_scan}) b->release();
+    delete s;
+}
+
+extern "C" int rk_fastq_slot_create(rk_ctx* c, uint64_t max_bytes, rk_fastq_slot** out) {
+    if (!c || !out || max_bytes < 4096 || max_bytes > ((uint64_t)1 << 31)) return fail(RK_ERR_ARG, "bad arguments (block size 4 KB .. 2 GB)");
+    RKCHK(set_dev(c));
+    rk_fastq_slot* s = new rk_fastq_slot();
+    s->c = c; s->max_bytes = max_bytes;
+    struct Guard { rk_fastq_slot* s; ~Guard() { if (s) rk_fastq_slot_destroy(s); } } guard{s};
+    HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&s->ev, hipEventBlockingSync | hipEventDisableTiming));
+    // capacities: records of fewer than 64 bytes on average (reads of about 25 bases) make the block "irregular" (FQ_BAD_CAP) --
+    // the host scanner takes it -- instead of sizing every array, page-locked ones included, for the worst case
+    const uint32_t chunks = (uint32_t)((max_bytes + 4095) / 4096);
+    const uint32_t rec_cap = (uint32_t)(max_bytes / 64 + 64), line_cap = 4 * rec_cap + 16;
+    RKCHK(s->h_text.reserve(max_bytes + 64));
+    RKCHK(s->h_out4.reserve((size_t)rec_cap * 16));
+    RKCHK(s->h_spans.reserve((size_t)rec_cap * 16));
+    RKCHK(s->h_info.reserve(16));
+    RKCHK(s->d_text.reserve(max_bytes + 64));
+    RKCHK(s->d_bases.reserve(max_bytes + 64));
+    RKCHK(s->d_out4.reserve((size_t)rec_cap * 16));
+    const size_t n32 = (size_t)2 * (chunks + 1) + line_cap + (size_t)6 * (rec_cap + 1) + 4;
+    RKCHK(s->d_u32.reserve(n32 * 4));
+    const size_t tb = fq_scan_temp_bytes(std::max(chunks + 1, rec_cap + 1));
+    RKCHK(s->d_scan.reserve(tb));
+    uint32_t* u = s->d_u32.as<uint32_t>();
+    FqDev& d = s->d;
+    d.chunk_cnt = u; u += chunks + 1;
+    d.chunk_base = u; u += chunks + 1;
+    d.nl = u; u += line_cap;
+    d.seq_off = u; u += rec_cap + 1;
+    d.seq_len = u; u += rec_cap + 1;
+    d.qual_off = u; u += rec_cap + 1;
+    d.name_off = u; u += rec_cap + 1;
+    d.name_len = u; u += rec_cap + 1;
+    d.out_off = u; u += rec_cap + 1;
+    d.info = u;
+    d.line_cap = line_cap; d.rec_cap = rec_cap;
+    d.bases = s->d_bases.as<uint8_t>();
+    d.scan_tmp = s->d_scan.p; d.scan_tmp_bytes = tb;
+    HIPCHK(hipMemsetAsync(s->d_u32.p, 0, n32 * 4, s->st)); // stale lengths past a block's last record must at least be defined
+    HIPCHK(hipStreamSynchronize(s->st));
+    guard.s = nullptr;
+    *out = s;
+    return RK_OK;
+}
+
+extern "C" uint8_t* rk_fastq_slot_text(rk_fastq_slot* s) { return s ? s->h_text.as<uint8_t>() : nullptr; }
+
+extern "C" int rk_fastq_slot_classify(rk_fastq_slot* s, uint64_t nbytes, rk_fastq_result* res) {
+    if (!s || !res || nbytes > s->max_bytes) return fail(RK_ERR_ARG, "bad arguments");
+    rk_ctx* c = s->c;
+    if (!c->have_refs) return fail(RK_ERR_STATE, "classify before rk_set_references");
+    memset(res, 0, sizeof *res);
+    if (nbytes == 0) return RK_OK;
+    RKCHK(set_dev(c));
+    hipStream_t st = s->st;
+    uint8_t* text = s->h_text.as<uint8_t>();
+    memset(text + nbytes, 'A', 16); // the device reads whole 16-byte pieces
+    HIPCHK(hipMemcpyAsync(s->d_text.p, text, (nbytes + 15) & ~(uint64_t)15, hipMemcpyHostToDevice, st));
+    HIPCHK(launch_fastq_index(s->d, s->d_text.as<uint8_t>(), nbytes, st));
+    uint32_t* info = s->h_info.as<uint32_t>();
+    HIPCHK(hipMemcpyAsync(info, s->d.info, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(s->ev, st));
+    HIPCHK(hipEventSynchronize(s->ev));
+    if (info[0] != 0) { res->status = (int32_t)info[0]; return RK_OK; } // not strictly four lines per record: the caller's scanner takes the block
+    const int64_t nrec = (int64_t)info[1];
+    res->nrec = nrec;
+    if (nrec == 0) return RK_OK;
+    int32_t* out4 = s->h_out4.as<int32_t>();
+    uint32_t* spans = s->h_spans.as<uint32_t>();
+    RKCHK(fused_device(c, s->d.bases, s->d.out_off, nrec, s->d_out4.p, info[2], 0, nullptr, st));
+    HIPCHK(hipMemcpyAsync(out4, s->d_out4.p, (size_t)nrec * 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(spans, s->d.name_off, (size_t)nrec * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(spans + nrec, s->d.name_len, (size_t)nrec * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(spans + 2 * nrec, s->d.seq_off, (size_t)nrec * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(spans + 3 * nrec, s->d.seq_len, (size_t)nrec * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(s->ev, st));
+    HIPCHK(hipEventSynchronize(s->ev));
+    res->out4 = out4;
+    res->name_off = spans; res->name_len = spans + nrec; res->seq_off = spans + 2 * nrec; res->seq_len = spans + 3 * nrec;
+    // rows the fused kernel handed back (long reads, more windows than the sketch keeps, ...): the general path, from the text
+    std::vector<int64_t> idx;
+    for (int64_t i = 0; i < nrec; ++i) if (out4[i * 4] == -2) idx.push_back(i);
+    if (!idx.empty()) {
+        std::vector<uint64_t> offs(idx.size() + 1, 0);
+        for (size_t j = 0; j < idx.size(); ++j) offs[j + 1] = offs[j] + res->seq_len[idx[j]];
+        std::vector<uint8_t> sub((size_t)offs.back() + 16);
+        for (size_t j = 0; j < idx.size(); ++j) memcpy(sub.data() + offs[j], text + res->seq_off[idx[j]], res->seq_len[idx[j]]);
+        std::vector<int32_t> rows(idx.size() * 4);
+        GeneralCfg cfg; cfg.ks = c->ks; cfg.S = c->S; cfg.classify = true;
+        if (c->depth) { cfg.filt_counter = c->depth; cfg.filter_mode = FILTER_MASK_MIN; cfg.fmin = c->min_occ; }
+        GeneralOut go; go.out4 = rows.data();
+        {
+            std::lock_guard<std::mutex> lock(c->general_mu);
+            RKCHK(general_run(c, sub.data(), nullptr, offs.data(), (int64_t)idx.size(), cfg, go));
+        }
+        for (size_t j = 0; j < idx.size(); ++j) memcpy(out4 + idx[j] * 4, rows.data() + j * 4, 16);
+    }
     return RK_OK;
 }

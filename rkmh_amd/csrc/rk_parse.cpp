@@ -172,7 +172,9 @@ struct rk_reader {
     bool skip_quals = false;   // RK_READER_NO_QUALS
     int nthreads = 1;
     const unsigned char* map = nullptr; // regular uncompressed file: the whole file, mmap'd
-    size_t map_size = 0, map_pos = 0;
+    size_t map_size = 0, map_pos = 0, map_start = 0; // map_start: where this reader began (rk_reader_open_at); map_size: where it ends
+    size_t map_total = 0;                            // bytes really mapped (rk_reader_open_range reads a part of the file)
+    bool was_irregular = false;                      // the block-parallel front end handed the input to the sequential scanner
     std::vector<unsigned char> blk;     // pipes: current block; starts with the tail of the previous one
     bool blk_eof = false;
     const unsigned char* pend_ptr = nullptr; // after a fallback the sequential scanner is fed from here first
@@ -184,6 +186,7 @@ struct rk_reader {
     std::vector<Piece> pieces;     // per-worker scratch, reused across blocks
 
     void to_sequential() {
+        if (par_ok) was_irregular = true;
         par_ok = false;
         pending = true;
         pend_pos = 0;
@@ -494,7 +497,7 @@ int rk_reader::next_block(Batch& b, int64_t max_records, bool open_cuts) {
         if (open_cuts) { // ... from the first byte of the file, dropping what this file contributed so far
             b.nseq = (int64_t)f_nseq; b.bases.n = f_bases; b.names.n = f_names; b.quals.n = f_quals; b.quals_ok = f_quals_ok;
             b.offsets.n = f_nseq + 1; b.name_offsets.n = f_nseq + 1;
-            map_pos = 0; rec_open = false;
+            map_pos = map_start; rec_open = false;
         }
         to_sequential();
         return -1;
@@ -709,7 +712,50 @@ static int granted_cpus() {
     return n;
 }
 
-int rk_reader_open(const char* path, rk_reader** out) {
+int64_t rk_fastq_cut(const uint8_t* text, uint64_t n) {
+    if (!text || n < 2) return -1;
+    const unsigned char* p = find_last_record_start(text, text + n, true);
+    return p ? (int64_t)(p - text) : -1;
+}
+
+static int reader_open_at(const char* path, uint64_t offset, rk_reader** out);
+int rk_reader_open(const char* path, rk_reader** out) { return reader_open_at(path, 0, out); }
+// A reader that starts `offset` bytes into a regular uncompressed file, at a record start (the device-side FASTQ front end hands
+// a file over to this scanner at the first block it refuses).
+int rk_reader_open_at(const char* path, uint64_t offset, rk_reader** out) {
+    if (path && strcmp(path, "-") == 0 && offset) return perr(RK_ERR_ARG, "rk_reader_open_at: STDIN has no offsets");
+    return reader_open_at(path, offset, out);
+}
+// The records that START in bytes [lo, hi) of a regular uncompressed FASTQ file: from the first record start at or after lo (the
+// four-line rule of find_record_start; lo = 0: the file's first byte) up to the first record start at or after hi.  Ranks of a
+// multi-process run each read their own range this way.  The rule is only right for text that IS four lines per record, so the
+// caller must check rk_reader_strict() after the last batch: 0 there (or here: RK_ERR_ARG for input that cannot be split at all)
+// means "parse the whole file instead".
+int rk_reader_open_range(const char* path, uint64_t lo, uint64_t hi, rk_reader** out) {
+    if (!path || !out || hi < lo || strcmp(path, "-") == 0) return perr(RK_ERR_ARG, "bad arguments");
+    rk_reader* r = nullptr;
+    int rc = reader_open_at(path, 0, &r);
+    if (rc != RK_OK) return rc;
+    if (!r->map || !r->par_ok || r->map_size == 0 || r->map[0] != '@') { rk_reader_close(r); return perr(RK_ERR_ARG, "byte ranges need an uncompressed regular FASTQ file"); }
+    const unsigned char* base = r->map;
+    const unsigned char* end = base + r->map_size;
+    auto start_at = [&](uint64_t off) -> size_t {
+        if (off == 0) return 0;
+        if (off >= r->map_size) return r->map_size;
+        const unsigned char* p = find_record_start(base, base + off, end, true);
+        return p ? (size_t)(p - base) : r->map_size;
+    };
+    const size_t s = start_at(lo), e = start_at(hi);
+    r->map_start = r->map_pos = s;
+    r->map_size = e < s ? s : e;
+    *out = r;
+    return RK_OK;
+}
+// 1 while everything this reader has returned was read by the strict block-parallel front end (text that is four lines per
+// record, on which its cuts and rk_reader_open_range's boundaries are exact); 0 once the sequential kseq scanner took over
+int rk_reader_strict(const rk_reader* r) { return r && r->par_ok && !r->was_irregular ? 1 : 0; }
+
+static int reader_open_at(const char* path, uint64_t offset, rk_reader** out) {
     if (!path || !out) return perr(RK_ERR_ARG, "bad arguments");
     rk_reader* r = new rk_reader();
     r->buf.resize(4u << 20);
@@ -737,7 +783,8 @@ int rk_reader_open(const char* path, rk_reader** out) {
             if (m != MAP_FAILED) {
                 madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
                 r->map = (const unsigned char*)m;
-                r->map_size = (size_t)st.st_size;
+                r->map_size = r->map_total = (size_t)st.st_size;
+                r->map_start = r->map_pos = (size_t)std::min<uint64_t>(offset, (uint64_t)st.st_size);
                 plain = true;
             }
         }
@@ -749,6 +796,7 @@ int rk_reader_open(const char* path, rk_reader** out) {
         gzbuffer(fp, 1 << 20);
         r->fp = fp;
         plain = gzdirect(fp) != 0;
+        if (offset && gzseek(fp, (z_off_t)offset, SEEK_SET) < 0) { gzclose(fp); delete r; return perr(RK_ERR_IO, std::string("cannot seek in ") + path); }
     }
     r->par_ok = plain && r->nthreads > 1;
     if (!r->par_ok && r->map) r->to_sequential();
@@ -763,7 +811,7 @@ void rk_reader_set_options(rk_reader* r, int flags) {
 void rk_reader_close(rk_reader* r) {
     if (!r) return;
     if (r->fp) gzclose(r->fp);
-    if (r->map) munmap((void*)r->map, r->map_size);
+    if (r->map) munmap((void*)r->map, r->map_total);
     delete r;
 }
 

@@ -12,6 +12,7 @@
 #include <getopt.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +26,11 @@
 #include <vector>
 
 #include "../../include/rkmh_amd.h"
+
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <chrono>
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -291,6 +297,395 @@ static void two_pass_on_group(DeviceGroup& g, const rk_seqset& reads, uint64_t s
     });
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// stream / classify with the FASTQ front end ON THE DEVICE (rk_fastq_slot_*, rkmh_amd/csrc/rk_fastq.hip).  The host no longer
+// parses the reads (parse_fastas -> kseq_read, rkmh.cpp:238-263): a coordinator cuts the file into byte ranges of whole records,
+// N identical workers each read their range straight into a page-locked buffer, have the GPU split it into records, check it,
+// pack it and classify it, and format the lines from the record names where they lie in the raw text; one writer puts the
+// blocks back in input order.  Text the device refuses (anything but strictly four lines per record) hands the file over to the
+// kseq-grammar scanner from that block on, so the output never depends on which front end ran.
+static int granted_cpus_main() {
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (n < 1) n = (int)std::thread::hardware_concurrency();
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long long per = 0;
+        if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+            const long long quota = atoll(q);
+            const int c = (int)((quota + per - 1) / per);
+            if (c >= 1 && c < n) n = c;
+        }
+        fclose(f);
+    }
+    return n < 1 ? 1 : n;
+}
+
+// a regular, uncompressed file that begins with '@'
+static bool raw_eligible(const char* path, int64_t* size) {
+    if (!path || strcmp(path, "-") == 0) return false;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    unsigned char magic[2] = {0, 0};
+    const bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) >= 1 && magic[0] == '@';
+    close(fd);
+    if (ok) *size = (int64_t)st.st_size;
+    return ok;
+}
+
+// formatted blocks leave in the order of their numbers
+struct OrderedOut {
+    std::mutex m;
+    std::condition_variable cv;
+    std::map<int64_t, std::string> waiting;
+    int64_t next = 0;
+    bool done = false, failed = false;
+    std::atomic<int64_t> limit{INT64_MAX}; // blocks from this number on are dropped, not written (another front end redoes them)
+    std::thread th;
+    // direct mode (standard output is a regular file not opened for appending): no writer thread -- a block's place in the file is
+    // known as soon as every earlier block has reported its size, and the workers pwrite their own blocks side by side
+    bool direct = false;
+    off_t base = 0, total = 0;
+    void lower_limit(int64_t seq) { int64_t cur = limit.load(); while (seq < cur && !limit.compare_exchange_weak(cur, seq)) {} }
+    void start() {
+        fflush(stdout);
+        struct stat st;
+        const int fl = fcntl(1, F_GETFL);
+        const bool off_env = getenv("RKMH_OUT_DIRECT") && atoi(getenv("RKMH_OUT_DIRECT")) == 0;
+        if (!off_env && fstat(1, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 && !(fl & O_APPEND)) {
+            const off_t cur = lseek(1, 0, SEEK_CUR);
+            if (cur >= 0) { direct = true; base = cur; return; }
+        }
+        start_thread();
+    }
+    // direct mode: blocks until every earlier block has claimed, returns where this block goes (-1: dropped)
+    off_t claim(int64_t seq, size_t size) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return next == seq; });
+        off_t at = -1;
+        if (seq < limit.load()) { at = base + total; total += (off_t)size; }
+        ++next;
+        cv.notify_all();
+        return at;
+    }
+    void put(int64_t seq, const char* p, size_t len, int64_t window) { // p stays the caller's: written (direct) or copied (queued) before the return
+        if (!direct) { push(seq, std::string(p, len), window); return; }
+        const off_t at = claim(seq, len);
+        size_t done_ = 0;
+        while (at >= 0 && done_ < len) {
+            const ssize_t n = pwrite(1, p + done_, len - done_, at + (off_t)done_);
+            if (n <= 0) { failed = true; break; }
+            done_ += (size_t)n;
+        }
+    }
+    void start_thread() {
+        th = std::thread([this] {
+            std::unique_lock<std::mutex> l(m);
+            for (;;) {
+                cv.wait(l, [&] { return done || waiting.count(next); });
+                auto it = waiting.find(next);
+                if (it == waiting.end()) { if (done) return; continue; }
+                std::string buf = std::move(it->second);
+                waiting.erase(it);
+                ++next;
+                l.unlock();
+                if (!buf.empty() && next - 1 < limit.load() && fwrite(buf.data(), 1, buf.size(), stdout) != buf.size()) failed = true;
+                l.lock();
+                cv.notify_all();
+            }
+        });
+    }
+    void push(int64_t seq, std::string&& buf, int64_t window) { // a worker far ahead of the writer waits (bounds the memory)
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return seq < next + window; });
+        waiting.emplace(seq, std::move(buf));
+        cv.notify_all();
+    }
+    void finish() {
+        if (direct) { if (lseek(1, base + total, SEEK_SET) < 0) failed = true; return; } // later output continues behind the blocks
+        { std::lock_guard<std::mutex> l(m); done = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
+struct RawEngine {
+    struct Worker { rk_fastq_slot* slot = nullptr; size_t dev = 0; };
+    std::vector<Worker> w;
+    uint64_t block = 0;
+    double t_read = 0, t_dev = 0, t_fmt = 0;
+    int64_t blocks = 0, records = 0;
+    bool create(DeviceGroup& g) {
+        if (!w.empty()) return true;
+        long mb = 32;
+        if (const char* e = getenv("RKMH_RAW_BLOCK_KB")) { long v = atol(e); if (v >= 4) { block = (uint64_t)v << 10; mb = 0; } }
+        if (mb) block = (uint64_t)mb << 20;
+        long nw = std::max(2, granted_cpus_main() - 2);
+        if (nw > 16) nw = 16;
+        if (const char* e = getenv("RKMH_RAW_WORKERS")) { long v = atol(e); if (v >= 1 && v <= 64) nw = v; }
+        if ((size_t)nw < g.size()) nw = (long)g.size();
+        w.resize((size_t)nw);
+        for (size_t i = 0; i < w.size(); ++i) w[i].dev = i % g.size();
+        // each worker creates its own slot when it starts (page-locking ~50 MB takes ~10 ms): the first blocks are on their way
+        // while the later workers are still setting up.  Only the first slot is made here, to find out whether the front end works at all.
+        if (rk_fastq_slot_create(g.ctx[0], block, &w[0].slot) != RK_OK) {
+            fprintf(stderr, "rkmh: device FASTQ front end unavailable (%s): using the host scanner\n", rk_last_error());
+            w.clear();
+            return false;
+        }
+        return true;
+    }
+    void destroy() { for (auto& x : w) if (x.slot) rk_fastq_slot_destroy(x.slot); w.clear(); }
+};
+
+// Everything of a line that does not depend on the read, prepared once per run: "ref name \t" per reference and the eight
+// possible tails "<sketch>[FAIL:DEPTH] \t [FAIL:MATCHES] \t [FAIL:DIFF] \n" (format of rkmh.cpp:887-892).
+struct LineParts {
+    std::vector<char> ref_text;          // padded: copies run in 16-byte steps
+    std::vector<uint32_t> ref_off, ref_len;
+    char tail[8][48];
+    uint32_t tail_len[8];
+    size_t maxref = 0;
+    void build(const rk_seqset& refs, const Opts& o) {
+        ref_off.resize((size_t)refs.nseq); ref_len.resize((size_t)refs.nseq);
+        for (int64_t r = 0; r < refs.nseq; ++r) {
+            const size_t ln = (size_t)(refs.name_offsets[r + 1] - refs.name_offsets[r]) - 1; // offsets include the NUL
+            ref_off[(size_t)r] = (uint32_t)ref_text.size(); ref_len[(size_t)r] = (uint32_t)ln + 1;
+            ref_text.insert(ref_text.end(), refs.names + refs.name_offsets[r], refs.names + refs.name_offsets[r] + ln);
+            ref_text.push_back('\t');
+            maxref = std::max(maxref, ln + 1);
+        }
+        ref_text.resize(ref_text.size() + 32, 0);
+        for (int f = 0; f < 8; ++f) {
+            char* w = put_int(tail[f], o.sketch);
+            if (f & 1) { memcpy(w, "FAIL:DEPTH", 10); w += 10; }
+            *w++ = '\t';
+            if (f & 2) { memcpy(w, "FAIL:MATCHES", 12); w += 12; }
+            *w++ = '\t';
+            if (f & 4) { memcpy(w, "FAIL:DIFF", 9); w += 9; }
+            *w++ = '\n';
+            tail_len[f] = (uint32_t)(w - tail[f]);
+        }
+    }
+};
+// copies n bytes in 16-byte steps (both buffers have the slack): no call into memcpy for a ten-byte name
+static inline char* copy16(char* w, const char* src, size_t n) {
+    for (size_t i = 0; i < n; i += 16) memcpy(w + i, src + i, 16);
+    return w + n;
+}
+
+// the lines of one block, names taken from the raw text
+static size_t format_raw(const LineParts& lp, const rk_fastq_result& r, const uint8_t* text, const Opts& o, std::vector<char>& buf) {
+    size_t names = 0;
+    for (int64_t i = 0; i < r.nrec; ++i) names += r.name_len[i];
+    const size_t need = names + (size_t)r.nrec * (lp.maxref + 64) + 64;
+    if (buf.size() < need) buf.resize(need + need / 8); // (grows a few times, then stays: no per-block allocation or zero-fill)
+    char* const w0 = buf.data();
+    char* w = w0;
+    for (int64_t i = 0; i < r.nrec; ++i) {
+        const int32_t* q = r.out4 + i * 4;
+        w = copy16(w, lp.ref_text.data() + lp.ref_off[(size_t)q[0]], lp.ref_len[(size_t)q[0]]);
+        w = copy16(w, (const char*)text + r.name_off[i], r.name_len[i]); *w++ = '\t';
+        w = put_int(w, q[1]); *w++ = '\t';
+        const int f = (q[3] <= o.min_matches ? 1 : 0) | (q[1] < o.min_matches ? 2 : 0) | (!(q[2] > o.min_diff) ? 4 : 0);
+        memcpy(w, lp.tail[f], 48);
+        w += lp.tail_len[f];
+    }
+    return (size_t)(w - w0);
+}
+
+// One file through the device front end.  Returns -1 when the whole file was taken, else the byte offset (a record start) from
+// which the kseq-grammar scanner must continue.
+static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& refs, const Opts& o, const char* path, int64_t fsize) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { fprintf(stderr, "rkmh: cannot open %s\n", path); exit(1); }
+    LineParts lp;
+    lp.build(refs, o);
+    struct Job { int64_t seq = 0, lo = 0, hi = 0; };
+    QueueT<Job> jobs;
+    jobs.cap = eng.w.size();
+    OrderedOut out;
+    out.start();
+    std::atomic<int64_t> fail_seq{INT64_MAX};
+    std::mutex fm;
+    std::map<int64_t, int64_t> fail_at; // block number -> its first byte
+    std::vector<std::string> werr(eng.w.size());
+    std::mutex tm;
+    auto work = [&](size_t wi) {
+        if (!eng.w[wi].slot && rk_fastq_slot_create(g.ctx[eng.w[wi].dev], eng.block, &eng.w[wi].slot) != RK_OK) {
+            // (memory for another slot ran out: the other workers carry on)
+            fprintf(stderr, "rkmh: worker %zu: %s\n", wi, rk_last_error());
+            return;
+        }
+        rk_fastq_slot* slot = eng.w[wi].slot;
+        uint8_t* text = rk_fastq_slot_text(slot);
+        std::vector<char> buf;
+        Job j;
+        while (jobs.pop(&j)) {
+            if (j.seq > fail_seq.load()) { out.put(j.seq, nullptr, 0, (int64_t)eng.w.size() * 2 + 2); continue; } // the scanner will redo this range
+            const double a = now_s();
+            int64_t got = 0;
+            while (got < j.hi - j.lo) {
+                const ssize_t n = pread(fd, text + got, (size_t)(j.hi - j.lo - got), (off_t)(j.lo + got));
+                if (n <= 0) { werr[wi] = std::string("read error on ") + path; break; }
+                got += n;
+            }
+            if (!werr[wi].empty()) break;
+            uint64_t nbytes = (uint64_t)(j.hi - j.lo);
+            if (j.hi == fsize && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n'; // a last line without its newline (the slot holds 64 spare bytes)
+            const double b = now_s();
+            rk_fastq_result res;
+            if (rk_fastq_slot_classify(slot, nbytes, &res) != RK_OK) { werr[wi] = rk_last_error(); break; }
+            const double c = now_s();
+            size_t outlen = 0;
+            if (res.status != 0) {
+                { std::lock_guard<std::mutex> l(fm); fail_at[j.seq] = j.lo; }
+                out.lower_limit(j.seq); // (before this block is pushed: the writer cannot pass it)
+                int64_t cur = fail_seq.load();
+                while (j.seq < cur && !fail_seq.compare_exchange_weak(cur, j.seq)) {}
+            } else outlen = format_raw(lp, res, text, o, buf);
+            const double d = now_s();
+            {
+                std::lock_guard<std::mutex> l(tm);
+                eng.t_read += b - a; eng.t_dev += c - b; eng.t_fmt += d - c; eng.blocks += 1; eng.records += res.status == 0 ? res.nrec : 0;
+            }
+            out.put(j.seq, buf.data(), outlen, (int64_t)eng.w.size() * 2 + 2);
+        }
+    };
+    std::vector<std::thread> workers;
+    for (size_t i = 0; i < eng.w.size(); ++i) workers.emplace_back(work, i);
+    // coordinator: ranges of whole records.  The end of a range is the last record start (four-line rule, rk_fastq_cut) inside a
+    // window in front of its nominal end; a range that is cut wrongly (possible only in text that is not four lines per record) is
+    // refused by the device and the scanner takes over from its first byte.
+    {
+        std::vector<uint8_t> win;
+        int64_t pos = 0, seq = 0;
+        const int64_t B = (int64_t)eng.block;
+        while (pos < fsize && fail_seq.load() == INT64_MAX) {
+            int64_t hi = fsize;
+            if (fsize - pos > B) {
+                int64_t wlen = 1 << 16;
+                hi = -1;
+                while (hi < 0) {
+                    if (wlen > B - 1) wlen = B - 1;
+                    const int64_t wlo = pos + B - wlen; // the window ends at the nominal end of the range
+                    win.resize((size_t)wlen);
+                    int64_t got = 0;
+                    while (got < wlen) {
+                        const ssize_t n = pread(fd, win.data() + got, (size_t)(wlen - got), (off_t)(wlo + got));
+                        if (n <= 0) break;
+                        got += n;
+                    }
+                    const int64_t cut = got == wlen ? rk_fastq_cut(win.data(), (uint64_t)wlen) : -1;
+                    if (cut > 0) hi = wlo + cut;
+                    else if (wlen >= B - 1) break; // no record start anywhere in the range: not for the device
+                    else wlen *= 8;
+                }
+                if (hi < 0) { // hand the file over from here
+                    std::lock_guard<std::mutex> l(fm);
+                    fail_at[seq] = pos;
+                    out.lower_limit(seq);
+                    int64_t cur = fail_seq.load();
+                    while (seq < cur && !fail_seq.compare_exchange_weak(cur, seq)) {}
+                    break;
+                }
+            }
+            Job j; j.seq = seq++; j.lo = pos; j.hi = hi;
+            jobs.push(j);
+            pos = hi;
+        }
+        jobs.finish();
+    }
+    for (auto& t : workers) t.join();
+    out.finish();
+    close(fd);
+    for (auto& e : werr) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
+    if (out.failed) { fprintf(stderr, "rkmh: write error on standard output\n"); exit(1); }
+    const int64_t fs = fail_seq.load();
+    if (fs == INT64_MAX) return -1;
+    return fail_at[fs];
+}
+
+
+// the kseq-grammar scanner as a producer thread: batches of the given files (each from a byte offset, 0 = its start), numbered
+static std::thread start_scanner(QueueT<Numbered>& q, std::vector<std::pair<const char*, uint64_t>> files) {
+    return std::thread([&q, files] {
+        int64_t seq = 0;
+        for (auto& f : files) {
+            rk_reader* rd = nullptr;
+            if ((f.second ? rk_reader_open_at(f.first, f.second, &rd) : rk_reader_open(f.first, &rd)) != RK_OK) { q.err = rk_last_error(); break; }
+            rk_reader_set_options(rd, RK_READER_NO_QUALS); // stream never looks at qualities
+            for (;;) {
+                Numbered nb;
+                if (rk_reader_next(rd, 1 << 20, 1ull << 28, &nb.reads) != RK_OK) { q.err = rk_last_error(); break; }
+                if (nb.reads.nseq == 0) { rk_seqset_free(&nb.reads); break; }
+                nb.seq = seq++;
+                q.push(nb);
+            }
+            rk_reader_close(rd);
+            if (!q.err.empty()) break;
+        }
+        q.finish();
+    });
+}
+
+static void run_scanner_pipeline(DeviceGroup& group, const rk_seqset& refs, const Opts& o, QueueT<Numbered>& q, std::thread& producer) {
+    double t_cls = 0, t_emit = 0, t_wait = 0;
+    // parser -> (one classify thread per device) -> writer.  Batches are numbered by the parser; the writer puts them back in
+    // input order, so the output does not depend on how many devices took part or on which one was faster.
+    if (q.cap < 2 * group.size()) { std::lock_guard<std::mutex> l(q.m); q.cap = 2 * group.size(); q.cv.notify_all(); }
+    QueueT<Classified> done_q;
+    done_q.cap = 2 * group.size() + 2;
+    OutPool out_pool;
+    std::thread writer([&] { // lines leave in read order: one writer, batches by number
+        Classified c;
+        std::string wbuf;
+        std::map<int64_t, Classified> waiting;
+        int64_t next = 0;
+        while (done_q.pop(&c)) {
+            waiting.emplace(c.seq, std::move(c));
+            for (auto it = waiting.find(next); it != waiting.end(); it = waiting.find(next)) {
+                double a = now_s();
+                emit_lines(refs, it->second.reads, it->second.out4, o, wbuf);
+                out_pool.put(it->second.out4, it->second.out_cap);
+                rk_seqset_free(&it->second.reads);
+                t_emit += now_s() - a;
+                waiting.erase(it);
+                ++next;
+            }
+        }
+    });
+    std::mutex tm;
+    std::vector<std::string> werr(group.size());
+    auto work = [&](size_t d) {
+        for (;;) {
+            double a = now_s();
+            Numbered nb;
+            if (!q.pop(&nb)) break;
+            double b = now_s();
+            Classified c;
+            c.reads = nb.reads; c.seq = nb.seq;
+            c.out4 = out_pool.get((size_t)c.reads.nseq, &c.out_cap);
+            if (rk_classify_batch(group.ctx[d], c.reads.bases, c.reads.offsets, c.reads.nseq, c.out4) != RK_OK) { werr[d] = rk_last_error(); break; }
+            double c2 = now_s();
+            done_q.push(std::move(c));
+            std::lock_guard<std::mutex> l(tm);
+            t_wait += b - a; t_cls += c2 - b;
+        }
+    };
+    std::vector<std::thread> workers;
+    for (size_t d = 1; d < group.size(); ++d) workers.emplace_back(work, d);
+    work(0);
+    for (auto& t : workers) t.join();
+    for (auto& e : werr) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
+    done_q.finish();
+    writer.join();
+    if (g_timing) fprintf(stderr, "[rkmh timing] wait-for-parser %.3f s, classify %.3f s, format+write %.3f s (overlapped; summed over %zu device(s))\n", t_wait, t_cls, t_emit, group.size());
+    producer.join();
+    if (!q.err.empty()) { fprintf(stderr, "rkmh: %s\n", q.err.c_str()); exit(1); }
+}
+
 static int main_stream(int argc, char** argv) {
     Opts o;
     const char* pre_refs = nullptr;
@@ -343,30 +738,22 @@ static int main_stream(int argc, char** argv) {
     }
     if (o.refs.empty() && !pre_refs) { fprintf(stderr, "rkmh: at least one -r reference file (or -R sketches) is required\n"); exit(1); }
 
-    // The FASTQ front end starts NOW (streaming path): while the GPU contexts come up and the references are sketched -- a few
-    // tenths of a second -- the parser is already filling its first batches.
+    // Which front end reads the reads: regular uncompressed FASTQ files go through the device (stream_file_raw); everything else --
+    // gzip, STDIN, FASTA, -M (which needs all reads twice) -- through the kseq-grammar scanner.  RKMH_RAW=0 forces the scanner.
+    std::vector<int64_t> raw_size(o.reads.size(), -1);
+    bool any_raw = false;
+    if (!o.read_depth && !(getenv("RKMH_RAW") && atoi(getenv("RKMH_RAW")) == 0))
+        for (size_t i = 0; i < o.reads.size(); ++i) { if (raw_eligible(o.reads[i], &raw_size[i])) any_raw = true; else raw_size[i] = -1; }
+    // The scanner starts NOW when it has all the files (streaming path): while the GPU contexts come up and the references are
+    // sketched -- a few tenths of a second -- it is already filling its first batches.
     QueueT<Numbered> q;
     q.cap = 4;
     std::thread producer;
-    if (!o.read_depth)
-        producer = std::thread([&] {
-            int64_t seq = 0;
-            for (const char* path : o.reads) {
-                rk_reader* rd = nullptr;
-                if (rk_reader_open(path, &rd) != RK_OK) { q.err = rk_last_error(); break; }
-                rk_reader_set_options(rd, RK_READER_NO_QUALS); // stream never looks at qualities
-                for (;;) {
-                    Numbered nb;
-                    if (rk_reader_next(rd, 1 << 20, 1ull << 28, &nb.reads) != RK_OK) { q.err = rk_last_error(); break; }
-                    if (nb.reads.nseq == 0) { rk_seqset_free(&nb.reads); break; }
-                    nb.seq = seq++;
-                    q.push(nb);
-                }
-                rk_reader_close(rd);
-                if (!q.err.empty()) break;
-            }
-            q.finish();
-        });
+    if (!o.read_depth && !any_raw) {
+        std::vector<std::pair<const char*, uint64_t>> files;
+        for (const char* path : o.reads) files.emplace_back(path, 0);
+        producer = start_scanner(q, files);
+    }
 
     double t0 = now_s();
     DeviceGroup group;
@@ -394,7 +781,6 @@ static int main_stream(int argc, char** argv) {
     tick("references", t0);
     std::string buf;
     std::vector<int32_t> out4;
-    double t_cls = 0, t_emit = 0, t_wait = 0;
     if (o.read_depth) {
         // two passes over ALL reads (rkmh.cpp:904-948): the reference holds them in RAM, so do we
         rk_seqset reads;
@@ -432,58 +818,28 @@ static int main_stream(int argc, char** argv) {
         for (rk_counter* k : cnts) rk_counter_destroy(k);
         rk_seqset_free(&reads);
     } else {
-        // parser -> (one classify thread per device) -> writer.  Batches are numbered by the parser; the writer puts them back in
-        // input order, so the output does not depend on how many devices took part or on which one was faster.
-        if (q.cap < 2 * group.size()) { std::lock_guard<std::mutex> l(q.m); q.cap = 2 * group.size(); q.cv.notify_all(); }
-        QueueT<Classified> done_q;
-        done_q.cap = 2 * group.size() + 2;
-        OutPool out_pool;
-        std::thread writer([&] { // lines leave in read order: one writer, batches by number
-            Classified c;
-            std::string wbuf;
-            std::map<int64_t, Classified> waiting;
-            int64_t next = 0;
-            while (done_q.pop(&c)) {
-                waiting.emplace(c.seq, std::move(c));
-                for (auto it = waiting.find(next); it != waiting.end(); it = waiting.find(next)) {
-                    double a = now_s();
-                    emit_lines(refs, it->second.reads, it->second.out4, o, wbuf);
-                    out_pool.put(it->second.out4, it->second.out_cap);
-                    rk_seqset_free(&it->second.reads);
-                    t_emit += now_s() - a;
-                    waiting.erase(it);
-                    ++next;
+        if (!any_raw) run_scanner_pipeline(group, refs, o, q, producer);
+        else {
+            RawEngine eng;
+            const bool eng_ok = eng.create(group);
+            tick("device front end", t0);
+            for (size_t i = 0; i < o.reads.size(); ++i) {
+                int64_t resume = 0;
+                if (eng_ok && raw_size[i] >= 0) {
+                    resume = stream_file_raw(eng, group, refs, o, o.reads[i], raw_size[i]);
+                    if (resume < 0) continue;
+                    fflush(stdout);
+                    if (g_timing) fprintf(stderr, "[rkmh timing] %s: not four lines per record at byte %lld: the scanner reads on from there\n", o.reads[i], (long long)resume);
                 }
+                QueueT<Numbered> q1;
+                q1.cap = 4;
+                std::thread p1 = start_scanner(q1, {{o.reads[i], (uint64_t)resume}});
+                run_scanner_pipeline(group, refs, o, q1, p1);
             }
-        });
-        std::mutex tm;
-        std::vector<std::string> werr(group.size());
-        auto work = [&](size_t d) {
-            for (;;) {
-                double a = now_s();
-                Numbered nb;
-                if (!q.pop(&nb)) break;
-                double b = now_s();
-                Classified c;
-                c.reads = nb.reads; c.seq = nb.seq;
-                c.out4 = out_pool.get((size_t)c.reads.nseq, &c.out_cap);
-                if (rk_classify_batch(group.ctx[d], c.reads.bases, c.reads.offsets, c.reads.nseq, c.out4) != RK_OK) { werr[d] = rk_last_error(); break; }
-                double c2 = now_s();
-                done_q.push(std::move(c));
-                std::lock_guard<std::mutex> l(tm);
-                t_wait += b - a; t_cls += c2 - b;
-            }
-        };
-        std::vector<std::thread> workers;
-        for (size_t d = 1; d < group.size(); ++d) workers.emplace_back(work, d);
-        work(0);
-        for (auto& t : workers) t.join();
-        for (auto& e : werr) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
-        done_q.finish();
-        writer.join();
-        if (g_timing) fprintf(stderr, "[rkmh timing] wait-for-parser %.3f s, classify %.3f s, format+write %.3f s (overlapped; summed over %zu device(s))\n", t_wait, t_cls, t_emit, group.size());
-        producer.join();
-        if (!q.err.empty()) { fprintf(stderr, "rkmh: %s\n", q.err.c_str()); exit(1); }
+            if (g_timing) fprintf(stderr, "[rkmh timing] device front end: %lld blocks, %lld records; read %.3f s, upload + index + classify %.3f s, format %.3f s (summed over %zu workers)\n",
+                                  (long long)eng.blocks, (long long)eng.records, eng.t_read, eng.t_dev, eng.t_fmt, eng.w.size());
+            eng.destroy();
+        }
     }
     fflush(stdout);
     tick("main loop + flush", t0);

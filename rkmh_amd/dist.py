@@ -95,3 +95,39 @@ def gather_rows(rows, dst=0):
         return np.concatenate([outs[r][: sizes[r]].cpu().numpy() for r in range(world)], axis=0)
     dist.gather(buf, None, dst=dst)
     return None
+
+
+def all_true(flag):
+    """Logical AND of a per-rank boolean (MIN all-reduce): does every rank agree that a shortcut is safe?"""
+    import torch
+    import torch.distributed as dist
+    if not _collectives_on():
+        return bool(flag)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def gather_bytes(data, dst=0):
+    """Per-rank byte strings concatenated on `dst` in rank order (formatted output lines of the ranks' read shards); None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if not _collectives_on():
+        return bytes(data)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t_n = torch.tensor([len(data)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, t_n)
+    sizes = [int(x.item()) for x in sizes]
+    cap = max(max(sizes), 1)
+    buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if len(data):
+        buf[: len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+    if rank == dst:
+        outs = [torch.empty_like(buf) for _ in range(world)]
+        dist.gather(buf, outs, dst=dst)
+        return b"".join(outs[r][: sizes[r]].cpu().numpy().tobytes() for r in range(world))
+    dist.gather(buf, None, dst=dst)
+    return None

@@ -50,6 +50,11 @@ def _worker(rank, world, port, q):
         ok_g = allrows.shape == (N, 4) and bool((allrows[:, 1] == np.arange(N)).all())
     else:
         ok_g = allrows is None
+    # 5. formatted text of the ranks' shards comes back in rank order; a shortcut is taken only if every rank agrees
+    text = rdist.gather_bytes((b"rank%d\n" % rank) * (rank + 2), dst=0)
+    ok_g = ok_g and (text == b"".join((b"rank%d\n" % r) * (r + 2) for r in range(world)) if rank == 0 else text is None)
+    ok_g = ok_g and rdist.gather_bytes(b"" if rank else b"only rank 0", dst=0) == (b"only rank 0" if rank == 0 else None)
+    ok_g = ok_g and rdist.all_true(True) is True and rdist.all_true(rank != 1) is False
     q.put((rank, lo, hi, ok_b, ok_c, ok_g))
     torch.distributed.destroy_process_group()
 

@@ -1,0 +1,283 @@
+"""The FASTQ front end on the device (rkmh_amd/csrc/rk_fastq.hip, rk_fastq_slot_* in include/rkmh_amd.h) against the literal kseq
+grammar of the oracle (oracle.kseq_parse_bytes <- /root/reference/src/kseq.hpp:170-208): text that is strictly four lines per record
+must come out record for record as kseq reads it (names, sequences) and classify to the oracle's rows; ANY other text must either
+be reported irregular (status != 0: the caller's kseq-grammar scanner takes the block) or still come out exactly as kseq reads
+it -- the device never guesses."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(ctx, orc, data_dir):
+    import rkmh_amd
+    from rkmh_amd import api, synth
+    refs = api.parse_files([os.path.join(data_dir, "all_pave_ref.fa.gz")])
+    rb, ro = refs["bases"], refs["offsets"]
+    ctx.set_references(rb, ro, [16], 1000)
+    sk, ln = ctx.get_reference_sketches()
+    slot = api.FastqSlot(ctx, max_bytes=1 << 24)
+    yield ctx, slot, rb, ro, sk, ln
+    slot.destroy()
+
+
+def _fastq(reads, names=None, plus=None, quals=None):
+    out = []
+    for i, r in enumerate(reads):
+        nm = names[i] if names else b"r%d" % i
+        q = quals[i] if quals else b"I" * len(r)
+        out.append(b"@" + nm + b"\n" + r + b"\n+" + (plus[i] if plus else b"") + b"\n" + q + b"\n")
+    return b"".join(out)
+
+
+def _check_against_kseq(orc, slot, text, sk, ln, must_be_regular=None):
+    st, rows, names, seqs = slot.classify(text)
+    want = orc.kseq_parse_bytes(text)
+    if must_be_regular is True:
+        assert st == 0, st
+    if must_be_regular is False:
+        assert st != 0
+    if st != 0:
+        return st
+    assert len(names) == len(want), (len(names), len(want))
+    for i, (nm, sq, _q) in enumerate(want):
+        assert names[i] == nm and seqs[i] == sq, i
+    if want:
+        qb, qo = orc.pack([orc.to_upper(w[1]) for w in want])
+        exp = orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=4)
+        assert (rows == exp).all()
+    return 0
+
+
+def test_regular_text_equals_kseq_and_the_oracle_rows(setup, orc):
+    from rkmh_amd import synth
+    ctx, slot, rb, ro, sk, ln = setup
+    qb, qo = synth.generate_reads_fast(rb, ro, 0, 20000, read_len=150, threads=4)
+    reads = [bytes(qb[int(qo[i]):int(qo[i + 1])]) for i in range(20000)]
+    rng = np.random.default_rng(1)
+    # names with descriptions, '+' lines that repeat the name, quality strings that begin with '@' and '+', lower case, reads of unequal length
+    names, plus, quals = [], [], []
+    for i, r in enumerate(reads):
+        if i % 7 == 0:
+            reads[i] = r = r.lower()
+        if i % 11 == 0:
+            reads[i] = r = r[: int(rng.integers(17, 150))]
+        if i % 13 == 0:
+            reads[i] = r = r[:5]                       # shorter than k: no windows
+        names.append(b"read_%d/1" % i + (b" desc tab\there" if i % 3 == 0 else b"") + (b"\tx" if i % 5 == 0 else b""))
+        plus.append(names[-1] if i % 4 == 0 else b"")
+        q = bytearray(b"I" * len(r))
+        if i % 6 == 0:
+            q[0] = ord("@")
+        if i % 9 == 0:
+            q[0] = ord("+")
+        if len(q) > 3 and i % 10 == 0:
+            q[3] = 127
+        quals.append(bytes(q))
+    text = _fastq(reads, names, plus, quals)
+    assert _check_against_kseq(orc, slot, text, sk, ln, must_be_regular=True) == 0
+    # a block cut by rk_fastq_cut holds whole records only and the remainder starts at a record
+    from rkmh_amd import api
+    cut = api.fastq_cut(text[: len(text) // 2])
+    assert cut > 0 and text[cut:cut + 1] == b"@" and text[cut - 1:cut] == b"\n"
+    assert _check_against_kseq(orc, slot, text[:cut], sk, ln, must_be_regular=True) == 0
+    assert _check_against_kseq(orc, slot, text[cut:], sk, ln, must_be_regular=True) == 0
+    # long reads (several thousand bases: rows come back through the general path) keep their place
+    long_reads = [bytes(rb[int(ro[j]):int(ro[j]) + 3000 + 500 * j]) for j in range(4)]
+    mixed = reads[:50] + long_reads + reads[50:100]
+    assert _check_against_kseq(orc, slot, _fastq(mixed), sk, ln, must_be_regular=True) == 0
+    assert slot.classify(b"")[0] == 0
+
+
+def test_irregular_text_is_refused_or_exact(setup, orc):
+    ctx, slot, rb, ro, sk, ln = setup
+    a, b = bytes(rb[100:250]), bytes(rb[1000:1150])
+    ok = _fastq([a, b])
+    cases = {
+        "crlf": ok.replace(b"\n", b"\r\n"),
+        "multi-line sequence": b"@r0\n" + a[:75] + b"\n" + a[75:] + b"\n+\n" + b"I" * 150 + b"\n",
+        "blank line between records": _fastq([a]) + b"\n" + _fastq([b]),
+        "leading blank line": b"\n" + ok,
+        "no final newline": ok[:-1],
+        "at-sign inside a sequence": _fastq([a[:70] + b"@" + a[71:], b]),
+        "plus inside a sequence": _fastq([a[:70] + b"+" + a[71:], b]),
+        "gt inside a sequence": _fastq([a[:70] + b">" + a[71:], b]),
+        "space inside a sequence": _fastq([a[:70] + b" " + a[71:], b]),
+        "short quality": b"@r0\n" + a + b"\n+\n" + b"I" * 149 + b"\n" + _fastq([b]),
+        "long quality": b"@r0\n" + a + b"\n+\n" + b"I" * 151 + b"\n" + _fastq([b]),
+        "quality byte 128": b"@r0\n" + a + b"\n+\n" + b"I" * 149 + b"\x80\n",
+        "quality with a space": b"@r0\n" + a + b"\n+\n" + b"I" * 149 + b" \n",
+        "empty sequence": b"@r0\n\n+\n\n" + _fastq([b]),
+        "fasta": b">r0\n" + a + b"\n>r1\n" + b + b"\n",
+        "missing plus line": b"@r0\n" + a + b"\n" + b"I" * 150 + b"\n" + _fastq([b]),
+        "three lines": b"@r0\n" + a + b"\n+\n",
+        "header only": b"@r0\n",
+        "garbage": bytes(range(1, 255)) * 40,
+        "only newlines": b"\n" * 1000,
+        "very short records": b"@a\nA\n+\nI\n" * 3000,     # more lines than a block of that size is sized for -> refused, or exact
+    }
+    refused = 0
+    for name, text in cases.items():
+        st = _check_against_kseq(orc, slot, text, sk, ln)
+        refused += st != 0
+        if name in ("crlf", "multi-line sequence", "blank line between records", "no final newline", "at-sign inside a sequence",
+                    "short quality", "long quality", "missing plus line", "three lines", "fasta", "empty sequence"):
+            assert st != 0, name
+    assert refused >= 11
+    # and the slot still works
+    assert _check_against_kseq(orc, slot, ok, sk, ln, must_be_regular=True) == 0
+
+
+def test_mutated_text_never_parses_differently_from_kseq(setup, orc):
+    """Fuzz: random byte edits of regular FASTQ text (RKMH_TEST_FUZZ raises the count).  Whatever the edit, the device either
+    refuses the block or returns exactly the records kseq reads."""
+    ctx, slot, rb, ro, sk, ln = setup
+    rng = np.random.default_rng(int(os.environ.get("RKMH_TEST_SEED_BASE", "7")))
+    reads = [bytes(rb[s:s + int(rng.integers(20, 160))]) for s in rng.integers(0, 100000, size=40)]
+    base = _fastq(reads, names=[b"n%d d" % i for i in range(40)])
+    pool = b"\n\n\n\r@+> \tACGTNacgtI!~\x7f\x80\x00"
+    n = int(os.environ.get("RKMH_TEST_FUZZ", "400"))
+    accepted = 0
+    for it in range(n):
+        t = bytearray(base)
+        for _ in range(int(rng.integers(1, 4))):
+            op = int(rng.integers(0, 3))
+            pos = int(rng.integers(0, len(t)))
+            if op == 0:
+                t[pos] = pool[int(rng.integers(0, len(pool)))]
+            elif op == 1:
+                del t[pos]
+            else:
+                t.insert(pos, pool[int(rng.integers(0, len(pool)))])
+        accepted += _check_against_kseq(orc, slot, bytes(t), sk, ln) == 0
+    assert 0 < accepted < n      # both outcomes occur: harmless edits are accepted, structural ones refused
+
+
+def _cli(root, args, env=None, stdin=None):
+    r = subprocess.run([os.path.join(root, "bin", "rkmh")] + args, capture_output=True, env=dict(os.environ, **(env or {})), timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return r.stdout
+
+
+def test_cli_device_front_end_equals_the_scanner(root, data_dir, tmp_path, orc):
+    """bin/rkmh stream on uncompressed FASTQ files: the device front end (default) and the kseq-grammar scanner (RKMH_RAW=0) print
+    the same bytes -- one block, many small blocks (cuts at record starts, a worker pool far larger than the block count and far
+    smaller), a last line without newline, several -f files, two contexts on one GPU; and a file that stops being four lines per
+    record half way through (multi-line sequences, then CRLF) is handed to the scanner at that block, the output still the same."""
+    from rkmh_amd import api, synth
+    refs = api.parse_files([os.path.join(data_dir, "all_pave_ref.fa.gz")])
+    rb, ro = refs["bases"], refs["offsets"]
+    n = 30000
+    qb, qo = synth.generate_reads_fast(rb, ro, 0, n, read_len=150, threads=4)
+    reads = [bytes(qb[int(qo[i]):int(qo[i + 1])]) for i in range(n)]
+    rng = np.random.default_rng(3)
+    for i in range(0, n, 17):
+        reads[i] = reads[i][: int(rng.integers(16, 150))]
+    text = _fastq(reads, names=[b"read%07d some description" % i for i in range(n)])
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(text)
+    ref = os.path.join(data_dir, "all_pave_ref.fa.gz")
+    base = ["stream", "-r", ref, "-k", "16", "-s", "1000"]
+    want = _cli(root, base + ["-f", str(fq)], env={"RKMH_RAW": "0"})
+    assert want.count(b"\n") == n
+    for env in ({}, {"RKMH_RAW_BLOCK_KB": "64"}, {"RKMH_RAW_BLOCK_KB": "256", "RKMH_RAW_WORKERS": "2"}, {"RKMH_RAW_BLOCK_KB": "40", "RKMH_RAW_WORKERS": "24"}):
+        err = subprocess.run([os.path.join(root, "bin", "rkmh")] + base + ["-f", str(fq)], capture_output=True, env=dict(os.environ, RKMH_TIMING="1", **env))
+        assert err.stdout == want, env
+        assert b"device front end: " in err.stderr and b" %d records" % n in err.stderr, err.stderr[-600:]   # the device really parsed all of it
+    # no newline after the last quality string
+    fq2 = tmp_path / "nonl.fq"
+    fq2.write_bytes(text[:-1])
+    assert _cli(root, base + ["-f", str(fq2)], env={"RKMH_RAW_BLOCK_KB": "512"}) == want
+    # several files, several contexts
+    got = _cli(root, base + ["-f", str(fq), "-f", str(fq2), "--devices", "0,0"], env={"RKMH_RAW_BLOCK_KB": "300"})
+    assert got == want + want
+    # a gzip file beside a plain one: the scanner takes the first, the device the second
+    import gzip
+    gz = tmp_path / "reads.fq.gz"
+    gz.write_bytes(gzip.compress(text, 1))
+    assert _cli(root, base + ["-f", str(gz), "-f", str(fq)]) == want + want
+    # irregular from the middle on: records with their sequence on two lines, then CRLF line ends
+    half = _fastq(reads[: n // 2], names=[b"read%07d some description" % i for i in range(n // 2)])
+    odd = b"".join(b"@m%d\n" % i + r[:70] + b"\n" + r[70:] + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(reads[n // 2: n // 2 + 500]))
+    crlf = _fastq(reads[n // 2 + 500: n // 2 + 900]).replace(b"\n", b"\r\n")
+    tail = _fastq(reads[n // 2 + 900: n // 2 + 2000], names=[b"t%d" % i for i in range(1100)])
+    mixed = tmp_path / "mixed.fq"
+    mixed.write_bytes(half + odd + crlf + tail)
+    want_m = _cli(root, base + ["-f", str(mixed)], env={"RKMH_RAW": "0"})
+    assert want_m.count(b"\n") == n // 2 + 500 + 400 + 1100
+    for env in ({}, {"RKMH_RAW_BLOCK_KB": "128"}, {"RKMH_RAW_BLOCK_KB": "64", "RKMH_RAW_WORKERS": "3"}):
+        r = subprocess.run([os.path.join(root, "bin", "rkmh")] + base + ["-f", str(mixed)], capture_output=True, env=dict(os.environ, RKMH_TIMING="1", **env))
+        assert r.returncode == 0 and r.stdout == want_m, env
+        assert b"the scanner reads on from there" in r.stderr
+    # standard output a regular FILE: the workers write their blocks side by side at their final offsets (no writer thread);
+    # what the scanner writes after a hand-over continues behind them
+    for src, want_x, env in ((fq, want, {"RKMH_RAW_BLOCK_KB": "96"}), (mixed, want_m, {"RKMH_RAW_BLOCK_KB": "128"}), (fq, want, {})):
+        outp = tmp_path / "out.tsv"
+        with open(outp, "wb") as f:
+            f.write(b"# header written before the run\n")
+            f.flush()
+            r = subprocess.run([os.path.join(root, "bin", "rkmh")] + base + ["-f", str(src), "-f", str(fq2)], stdout=f, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()[-1000:]
+        assert outp.read_bytes() == b"# header written before the run\n" + want_x + want
+    # the oracle's kseq grammar agrees with both on the mixed file (names in order)
+    names = [x[0] for x in orc.kseq_parse_bytes(half + odd + crlf + tail)]
+    assert [l.split(b"\t")[1] for l in want_m.splitlines()] == names
+
+
+def test_ranks_read_their_own_byte_range(root, data_dir, tmp_path):
+    """python -m rkmh_amd.cli under torch.distributed.run (two and three ranks on GPU 0, gloo): every rank parses only ITS byte
+    range of an uncompressed FASTQ file (rk_reader_open_range) and formats its own lines; rank 0 prints the gathered text, which
+    equals the single-process binary's -- for stream, stream -M 2, filter, two -f files, and for input that cannot be split by
+    bytes (gzip; text that is not four lines per record), where every rank falls back to parsing everything."""
+    from rkmh_amd import api, synth
+    refs = api.parse_files([os.path.join(data_dir, "all_pave_ref.fa.gz")])
+    rb, ro = refs["bases"], refs["offsets"]
+    n = 6000
+    qb, qo = synth.generate_reads_fast(rb, ro, 0, n, read_len=150, threads=4)
+    reads = [bytes(qb[int(qo[i]):int(qo[i + 1])]) for i in range(n)]
+    rng = np.random.default_rng(5)
+    for i in range(0, n, 9):
+        reads[i] = reads[i][: int(rng.integers(16, 150))]
+    text = _fastq(reads, names=[b"q%d x" % i for i in range(n)], quals=[bytes(rng.integers(33, 74, size=len(r), dtype=np.uint8)) for r in reads])
+    fq = tmp_path / "r.fq"
+    fq.write_bytes(text)
+    import gzip
+    gz = tmp_path / "r.fq.gz"
+    gz.write_bytes(gzip.compress(text, 1))
+    odd = tmp_path / "odd.fq"      # the second half has its sequences on two lines
+    odd.write_bytes(_fastq(reads[:3000]) + b"".join(b"@m%d\n" % i + r[:40] + b"\n" + r[40:] + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(reads[3000:])))
+    ref = os.path.join(data_dir, "all_pave_ref.fa.gz")
+    exe = os.path.join(root, "bin", "rkmh")
+    port = [29600]
+
+    def ranks(world, args, extra_env=None):
+        port[0] += 1
+        env = dict(os.environ, RKMH_ONE_DEVICE="1", RKMH_DIST_BACKEND="gloo", **(extra_env or {}))
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                            "--master-port", str(port[0]), "-m", "rkmh_amd.cli"] + args, capture_output=True, cwd=root, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        return r.stdout
+
+    def one(args):
+        r = subprocess.run([exe] + args, capture_output=True, timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        return r.stdout
+
+    st = ["stream", "-r", ref, "-k", "16", "-s", "1000"]
+    want = one(st + ["-f", str(fq)])
+    assert want.count(b"\n") == n
+    assert ranks(2, st + ["-f", str(fq)]) == want
+    assert ranks(3, st + ["-f", str(fq), "-f", str(fq)]) == want + want
+    assert ranks(2, st + ["-f", str(gz)]) == want                                   # cannot be split by bytes: whole parse on every rank
+    assert ranks(2, st + ["-f", str(fq)], {"RKMH_CLI_WHOLE_PARSE": "1"}) == want
+    assert ranks(3, st + ["-f", str(odd)]) == one(st + ["-f", str(odd)])            # not four lines per record: every rank notices and falls back
+    assert ranks(2, st + ["-f", str(fq), "-M", "2"]) == one(st + ["-f", str(fq), "-M", "2"])
+    fl = ["filter", "-r", ref, "-k", "16", "-s", "1000", "-N", "3"]
+    wf = one(fl + ["-f", str(fq)])
+    assert wf.startswith(b">q") and 0 < len(wf) < len(text) + n      # some reads pass, some do not
+    assert ranks(2, fl + ["-f", str(fq)]) == wf
