@@ -104,6 +104,16 @@ def e2e_stream(n, L, rb, ro, synth):
         dt4 = time.perf_counter() - t
         if r.returncode == 0 and dt4 > best:
             res["x4"] = {"reads": 4 * n, "wall_s": dt4, "value": 4 * n / dt4, "marginal_reads_per_s": 3 * n / (dt4 - best)}
+        # the same two runs with the lines going to /dev/null: what the pipeline itself sustains (parsing on the device, PCIe, kernel,
+        # formatting) when the file system the TSV is written to -- one file, ~2-2.6 GB/s of buffered writes -- is out of the way
+        t1 = []
+        for nf in (1, 4):
+            t = time.perf_counter()
+            r = subprocess.run([exe, "stream", "-r", ref] + ["-f", fq] * nf + ["-k", "16", "-s", "1000"], stdout=open(os.devnull, "wb"), stderr=subprocess.PIPE)
+            t1.append(time.perf_counter() - t if r.returncode == 0 else None)
+        if None not in t1 and t1[1] > t1[0]:
+            res["x4_devnull"] = {"wall_s_1": t1[0], "wall_s_4": t1[1], "marginal_reads_per_s": 3 * n / (t1[1] - t1[0]),
+                                 "note": "stdout = /dev/null: the pipeline without the output file's write bandwidth"}
         return res
     finally:
         for x in (fq, tsv):

@@ -267,6 +267,9 @@ typedef struct rk_seqset {
 } rk_seqset;
 int rk_parse_files(const char* const* paths, int npaths, rk_seqset* out);
 void rk_seqset_free(rk_seqset* s);
+/* rk_seqset_free parks large batch buffers (up to 1.5 GB in all) for the next batch instead of returning them to the system;
+ * this releases whatever is parked (a long-lived process that has finished parsing) */
+void rk_pool_trim(void);
 /* Streaming form (the build's replacement of KSEQ_Reader::get_next_buffer, src/rkmh.cpp:951-959, 2085-2094):
  * up to max_records records / max_bases bases per call (0 = unlimited); out->nseq == 0 at end of input.
  * path "-" reads STDIN.  Uncompressed input read with max_records == 0 or >= 65536 goes through the

@@ -59,9 +59,13 @@ struct State {
 };
 static State& st() { static State* s = new State(); return *s; } // leaked on purpose: buffers may be returned during exit
 static void remember(void* p, size_t bytes) {
-    if (!p || bytes < MIN_BYTES) return;
+    if (!p) return;
     std::lock_guard<std::mutex> g(st().mu);
-    st().cap[p] = bytes;
+    // an address this map still knows from an EARLIER buffer (one the caller released with plain free(), which the header allows
+    // for malloc'd arrays) must not keep that buffer's capacity: a small buffer at the same address would later be parked and
+    // reused with it.  The entry is overwritten, or dropped when the new buffer is too small to be worth parking.
+    if (bytes < MIN_BYTES) st().cap.erase(p);
+    else st().cap[p] = bytes;
 }
 static void forget(void* p) {
     if (!p) return;
@@ -100,8 +104,19 @@ static void give_back(void* p) {
     }
     free(p);
 }
+// frees every parked buffer (a long-lived caller that is done parsing gets its ~1.5 GB back)
+static void trim() {
+    std::vector<std::pair<size_t, void*>> old;
+    {
+        std::lock_guard<std::mutex> g(st().mu);
+        old.swap(st().parked);
+        st().parked_bytes = 0;
+    }
+    for (auto& e : old) free(e.second);
+}
 } // namespace pool
 extern "C" void rk__pool_forget(void* p) { pool::forget(p); } // rk_free (rk_api.hip) calls this before free()
+extern "C" void rk_pool_trim(void) { pool::trim(); }
 
 template <typename V> struct Grow { // malloc-backed growable array handed over to C callers
     V* p = nullptr;

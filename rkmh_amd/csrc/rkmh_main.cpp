@@ -29,6 +29,7 @@
 
 #include <fcntl.h>
 #include <sched.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -42,9 +43,22 @@ static void tick(const char* what, double& t0) {
     t0 = t;
 }
 
+// Leaving after an error: flush what there is and go, WITHOUT running static destructors -- a parser or worker thread may still be
+// running, and the HIP runtime's exit handlers are not something to run under it.
+[[noreturn]] static void fail_exit() {
+    fflush(stdout); fflush(stderr);
+    _exit(1);
+}
 static void die(const char* what) {
     fprintf(stderr, "rkmh: %s: %s\n", what, rk_last_error());
-    exit(1);
+    fail_exit();
+}
+// Leaving after success: only if every byte really reached standard output (a full disk or a closed pipe must not exit 0)
+[[noreturn]] static void done_exit() {
+    const bool bad = fflush(stdout) != 0 || ferror(stdout);
+    fflush(stderr);
+    if (bad) fprintf(stderr, "rkmh: write error on standard output\n");
+    _exit(bad ? 1 : 0); // skips the HIP runtime's and the loader's exit handlers (~0.1-0.2 s of a 1 s run)
 }
 #define CK(call) do { if ((call) != RK_OK) die(#call); } while (0)
 
@@ -66,7 +80,7 @@ static void help_stream() {
             "  -r/--reference <file>   reference FASTA/FASTQ(.gz); repeatable\n"
             "  -f/--fasta <file>       read FASTA/FASTQ(.gz); repeatable\n"
             "  -k/--kmer <k>           k-mer size; repeatable (default 16)\n"
-            "  -s/--sketch-size <s>    sketch size (default 1000)\n"
+            "  -s/--sketch-size <s>    sketch size (default 1000; at most 16384 in this build)\n"
             "  -t/--threads <n>        accepted for compatibility (the per-read loop runs on the GPU)\n"
             "  -M/--min-kmer-occurence <n>  drop read k-mers seen fewer than n times across all reads\n"
             "  -I/--max-samples <n>    drop reference k-mers counted more than n times across references\n"
@@ -334,17 +348,21 @@ static bool raw_eligible(const char* path, int64_t* size) {
     return ok;
 }
 
-// formatted blocks leave in the order of their numbers
+// Formatted blocks leave in the order of their numbers.  No writer thread: a worker parks its finished block and, if the next block
+// due is there, WRITES the run of consecutive blocks that are ready (its own included) -- otherwise it goes straight on to its next
+// block.  A worker therefore never waits for a slower neighbour (only for memory: at most `window` blocks may be parked ahead of the
+// one due), which in-order hand-over by the workers themselves did: one straggler stalled all eight.
 struct OrderedOut {
+    struct Parked { std::vector<char> buf; size_t len = 0; };
     std::mutex m;
     std::condition_variable cv;
-    std::map<int64_t, std::string> waiting;
+    std::map<int64_t, Parked> parked;
+    std::vector<std::vector<char>> spare; // buffers to format the next blocks into
     int64_t next = 0;
-    bool done = false, failed = false;
+    bool draining = false, failed = false;
     std::atomic<int64_t> limit{INT64_MAX}; // blocks from this number on are dropped, not written (another front end redoes them)
-    std::thread th;
-    // direct mode (standard output is a regular file not opened for appending): no writer thread -- a block's place in the file is
-    // known as soon as every earlier block has reported its size, and the workers pwrite their own blocks side by side
+    // standard output a regular file not opened for appending: blocks are written with pwrite at their final offsets (the file
+    // position is moved behind them at the end); otherwise with fwrite
     bool direct = false;
     off_t base = 0, total = 0;
     void lower_limit(int64_t seq) { int64_t cur = limit.load(); while (seq < cur && !limit.compare_exchange_weak(cur, seq)) {} }
@@ -355,58 +373,50 @@ struct OrderedOut {
         const bool off_env = getenv("RKMH_OUT_DIRECT") && atoi(getenv("RKMH_OUT_DIRECT")) == 0;
         if (!off_env && fstat(1, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 && !(fl & O_APPEND)) {
             const off_t cur = lseek(1, 0, SEEK_CUR);
-            if (cur >= 0) { direct = true; base = cur; return; }
-        }
-        start_thread();
-    }
-    // direct mode: blocks until every earlier block has claimed, returns where this block goes (-1: dropped)
-    off_t claim(int64_t seq, size_t size) {
-        std::unique_lock<std::mutex> l(m);
-        cv.wait(l, [&] { return next == seq; });
-        off_t at = -1;
-        if (seq < limit.load()) { at = base + total; total += (off_t)size; }
-        ++next;
-        cv.notify_all();
-        return at;
-    }
-    void put(int64_t seq, const char* p, size_t len, int64_t window) { // p stays the caller's: written (direct) or copied (queued) before the return
-        if (!direct) { push(seq, std::string(p, len), window); return; }
-        const off_t at = claim(seq, len);
-        size_t done_ = 0;
-        while (at >= 0 && done_ < len) {
-            const ssize_t n = pwrite(1, p + done_, len - done_, at + (off_t)done_);
-            if (n <= 0) { failed = true; break; }
-            done_ += (size_t)n;
+            if (cur >= 0) { direct = true; base = cur; }
         }
     }
-    void start_thread() {
-        th = std::thread([this] {
-            std::unique_lock<std::mutex> l(m);
-            for (;;) {
-                cv.wait(l, [&] { return done || waiting.count(next); });
-                auto it = waiting.find(next);
-                if (it == waiting.end()) { if (done) return; continue; }
-                std::string buf = std::move(it->second);
-                waiting.erase(it);
-                ++next;
-                l.unlock();
-                if (!buf.empty() && next - 1 < limit.load() && fwrite(buf.data(), 1, buf.size(), stdout) != buf.size()) failed = true;
-                l.lock();
-                cv.notify_all();
-            }
-        });
+    std::vector<char> take_buffer() {
+        std::lock_guard<std::mutex> l(m);
+        if (spare.empty()) return std::vector<char>();
+        std::vector<char> b = std::move(spare.back());
+        spare.pop_back();
+        return b;
     }
-    void push(int64_t seq, std::string&& buf, int64_t window) { // a worker far ahead of the writer waits (bounds the memory)
+    // buf[0 .. len) are the lines of block seq; the buffer becomes the sink's (a spare one comes back from take_buffer)
+    void put(int64_t seq, std::vector<char>&& buf, size_t len, int64_t window) {
         std::unique_lock<std::mutex> l(m);
         cv.wait(l, [&] { return seq < next + window; });
-        waiting.emplace(seq, std::move(buf));
-        cv.notify_all();
+        Parked& pk = parked[seq];
+        pk.buf = std::move(buf); pk.len = len;
+        if (draining) return; // the thread that is writing will find this block when its turn comes
+        draining = true;
+        for (auto it = parked.find(next); it != parked.end(); it = parked.find(next)) {
+            Parked e = std::move(it->second);
+            parked.erase(it);
+            const bool keep = next < limit.load();
+            const off_t at = base + total;
+            if (keep) total += (off_t)e.len;
+            ++next;
+            cv.notify_all();
+            l.unlock();
+            if (keep && e.len) {
+                if (direct) {
+                    size_t done_ = 0;
+                    while (done_ < e.len) {
+                        const ssize_t n = pwrite(1, e.buf.data() + done_, e.len - done_, at + (off_t)done_);
+                        if (n <= 0) { failed = true; break; }
+                        done_ += (size_t)n;
+                    }
+                } else if (fwrite(e.buf.data(), 1, e.len, stdout) != e.len) failed = true;
+            }
+            l.lock();
+            if (spare.size() < 32) spare.push_back(std::move(e.buf));
+        }
+        draining = false;
     }
     void finish() {
-        if (direct) { if (lseek(1, base + total, SEEK_SET) < 0) failed = true; return; } // later output continues behind the blocks
-        { std::lock_guard<std::mutex> l(m); done = true; }
-        cv.notify_all();
-        if (th.joinable()) th.join();
+        if (direct && lseek(1, base + total, SEEK_SET) < 0) failed = true; // later output continues behind the blocks
     }
 };
 
@@ -418,11 +428,11 @@ struct RawEngine {
     int64_t blocks = 0, records = 0;
     bool create(DeviceGroup& g) {
         if (!w.empty()) return true;
-        long mb = 32;
+        long mb = 16; // measured (tools/e2e_sweep.py, 16 CPUs): 8-16 MB blocks and 8 workers 82 M reads/s, 32 MB and 14 workers 56-73
         if (const char* e = getenv("RKMH_RAW_BLOCK_KB")) { long v = atol(e); if (v >= 4) { block = (uint64_t)v << 10; mb = 0; } }
         if (mb) block = (uint64_t)mb << 20;
-        long nw = std::max(2, granted_cpus_main() - 2);
-        if (nw > 16) nw = 16;
+        long nw = std::max(2, granted_cpus_main() * 5 / 8); // 10 of 16 CPUs: 6 / 8 / 10 / 12 workers measured 57-78 / 56-83 / 64-89 / 64-87 M reads/s
+        if (nw > 12) nw = 12;
         if (const char* e = getenv("RKMH_RAW_WORKERS")) { long v = atol(e); if (v >= 1 && v <= 64) nw = v; }
         if ((size_t)nw < g.size()) nw = (long)g.size();
         w.resize((size_t)nw);
@@ -499,7 +509,7 @@ static size_t format_raw(const LineParts& lp, const rk_fastq_result& r, const ui
 // which the kseq-grammar scanner must continue.
 static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& refs, const Opts& o, const char* path, int64_t fsize) {
     const int fd = open(path, O_RDONLY);
-    if (fd < 0) { fprintf(stderr, "rkmh: cannot open %s\n", path); exit(1); }
+    if (fd < 0) { fprintf(stderr, "rkmh: cannot open %s\n", path); fail_exit(); }
     LineParts lp;
     lp.build(refs, o);
     struct Job { int64_t seq = 0, lo = 0, hi = 0; };
@@ -510,7 +520,6 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     std::atomic<int64_t> fail_seq{INT64_MAX};
     std::mutex fm;
     std::map<int64_t, int64_t> fail_at; // block number -> its first byte
-    std::vector<std::string> werr(eng.w.size());
     std::mutex tm;
     auto work = [&](size_t wi) {
         if (!eng.w[wi].slot && rk_fastq_slot_create(g.ctx[eng.w[wi].dev], eng.block, &eng.w[wi].slot) != RK_OK) {
@@ -520,23 +529,22 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
         }
         rk_fastq_slot* slot = eng.w[wi].slot;
         uint8_t* text = rk_fastq_slot_text(slot);
-        std::vector<char> buf;
         Job j;
         while (jobs.pop(&j)) {
-            if (j.seq > fail_seq.load()) { out.put(j.seq, nullptr, 0, (int64_t)eng.w.size() * 2 + 2); continue; } // the scanner will redo this range
+            std::vector<char> buf = out.take_buffer();
+            if (j.seq > fail_seq.load()) { out.put(j.seq, std::move(buf), 0, (int64_t)eng.w.size() * 3 + 2); continue; } // the scanner will redo this range
             const double a = now_s();
             int64_t got = 0;
             while (got < j.hi - j.lo) {
                 const ssize_t n = pread(fd, text + got, (size_t)(j.hi - j.lo - got), (off_t)(j.lo + got));
-                if (n <= 0) { werr[wi] = std::string("read error on ") + path; break; }
+                if (n <= 0) { fprintf(stderr, "rkmh: read error on %s\n", path); fail_exit(); } // (the other workers may be waiting for this block)
                 got += n;
             }
-            if (!werr[wi].empty()) break;
             uint64_t nbytes = (uint64_t)(j.hi - j.lo);
             if (j.hi == fsize && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n'; // a last line without its newline (the slot holds 64 spare bytes)
             const double b = now_s();
             rk_fastq_result res;
-            if (rk_fastq_slot_classify(slot, nbytes, &res) != RK_OK) { werr[wi] = rk_last_error(); break; }
+            if (rk_fastq_slot_classify(slot, nbytes, &res) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
             const double c = now_s();
             size_t outlen = 0;
             if (res.status != 0) {
@@ -550,7 +558,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                 std::lock_guard<std::mutex> l(tm);
                 eng.t_read += b - a; eng.t_dev += c - b; eng.t_fmt += d - c; eng.blocks += 1; eng.records += res.status == 0 ? res.nrec : 0;
             }
-            out.put(j.seq, buf.data(), outlen, (int64_t)eng.w.size() * 2 + 2);
+            out.put(j.seq, std::move(buf), outlen, (int64_t)eng.w.size() * 3 + 2);
         }
     };
     std::vector<std::thread> workers;
@@ -600,8 +608,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     for (auto& t : workers) t.join();
     out.finish();
     close(fd);
-    for (auto& e : werr) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
-    if (out.failed) { fprintf(stderr, "rkmh: write error on standard output\n"); exit(1); }
+    if (out.failed) { fprintf(stderr, "rkmh: write error on standard output\n"); fail_exit(); }
     const int64_t fs = fail_seq.load();
     if (fs == INT64_MAX) return -1;
     return fail_at[fs];
@@ -678,12 +685,12 @@ static void run_scanner_pipeline(DeviceGroup& group, const rk_seqset& refs, cons
     for (size_t d = 1; d < group.size(); ++d) workers.emplace_back(work, d);
     work(0);
     for (auto& t : workers) t.join();
-    for (auto& e : werr) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
+    for (auto& e : werr) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); fail_exit(); }
     done_q.finish();
     writer.join();
     if (g_timing) fprintf(stderr, "[rkmh timing] wait-for-parser %.3f s, classify %.3f s, format+write %.3f s (overlapped; summed over %zu device(s))\n", t_wait, t_cls, t_emit, group.size());
     producer.join();
-    if (!q.err.empty()) { fprintf(stderr, "rkmh: %s\n", q.err.c_str()); exit(1); }
+    if (!q.err.empty()) { fprintf(stderr, "rkmh: %s\n", q.err.c_str()); fail_exit(); }
 }
 
 static int main_stream(int argc, char** argv) {
@@ -846,8 +853,7 @@ static int main_stream(int argc, char** argv) {
     if (!pre_refs) rk_seqset_free(&refs);
     group.destroy();
     tick("teardown", t0);
-    fflush(stdout); fflush(stderr);
-    _exit(0); // everything is written: skip the HIP runtime's and the loader's exit handlers (~0.1-0.2 s of a 1 s run)
+    done_exit();
 }
 
 // filter: main_filter, src/rkmh.cpp:996-1424.  Same sketches as stream; the decision is
@@ -1003,10 +1009,9 @@ static int main_filter(int argc, char** argv) {
         }
         rk_reader_close(rd);
     }
-    fflush(stdout); fflush(stderr);
     // everything is written: the process ends here, as in main_stream -- freeing a genome-sized reference set, the contexts and the
     // HIP runtime's exit handlers took 0.7 s of a 2.5 s C4 run and produce nothing
-    _exit(0);
+    done_exit();
 }
 
 // call: main_call, src/rkmh.cpp:1455-1904.  The GPU returns one record per candidate k-mer that passed the depth

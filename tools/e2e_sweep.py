@@ -38,7 +38,11 @@ def run(env, nfiles):
     return dt, r.stderr.decode()
 
 
-settings = [{}] + [{"RKMH_RAW_BLOCK_KB": str(b), "RKMH_RAW_WORKERS": str(w)} for b in (8192, 16384, 32768, 65536) for w in (8, 12, 14, 16, 20)] + \
+if os.environ.get("SWEEP_SMALL"):
+    settings = [{}, {}, {"RKMH_OUT_DIRECT": "1"}, {"RKMH_OUT_DIRECT": "0"}, {"RKMH_RAW_WORKERS": "6"}, {"RKMH_RAW_WORKERS": "10"}, {"RKMH_RAW_WORKERS": "12"},
+                {"RKMH_RAW_BLOCK_KB": "8192"}, {"RKMH_RAW_BLOCK_KB": "8192", "RKMH_RAW_WORKERS": "12"}, {"RKMH_RAW_BLOCK_KB": "4096", "RKMH_RAW_WORKERS": "12"}, {"RKMH_RAW": "0"}]
+else:
+  settings = [{}] + [{"RKMH_RAW_BLOCK_KB": str(b), "RKMH_RAW_WORKERS": str(w)} for b in (8192, 16384, 32768, 65536) for w in (8, 12, 14, 16, 20)] + \
            [{"RKMH_OUT_DIRECT": "0"}, {"RKMH_RAW": "0"}]
 for env in settings:
     best1 = min(run(env, 1)[0] for _ in range(2))
