@@ -99,6 +99,7 @@ _SIGS = {
     "rk_format_stream_line": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rk_parse_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.POINTER(SeqSet)]),
     "rk_seqset_free": (None, [C.POINTER(SeqSet)]),
+    "rk_pool_trim": (None, []),
     "rk_reader_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "rk_reader_next": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(SeqSet)]),
     "rk_reader_set_options": (None, [C.c_void_p, C.c_int]),
@@ -261,6 +262,11 @@ class Reader:
             self.close()
         except Exception:
             pass
+
+
+def pool_trim():
+    """Returns the parser's parked batch buffers (up to 1.5 GB) to the system (rk_pool_trim)."""
+    load_library().rk_pool_trim()
 
 
 def parse_file_range(path, lo, hi):
