@@ -33,7 +33,7 @@ constexpr int KW = 64;
 constexpr int KM_MAX_T = 8;          // reads per tile (phase 2 takes eight reads in one pass; the group -> read search is unrolled for it)
 constexpr int KM_MQ = 32;            // deferred multi-posting hits per drain (more are walked by their own lane)
 #ifndef RK_KMER_ABL
-#define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length
+#define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length, 128 filter sectors of lane pairs in one line
 #endif
 #ifndef RK_KMER_NT
 #define RK_KMER_NT 1 // the bases are read once: streaming loads keep them from evicting the filter and the map from L2
@@ -504,7 +504,12 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                 wh[s] = w.y >> sh;
                 const uint32_t core = k == 16 ? wl[s] >> 6 : (wl[s] >> 6) & CMASK; // k = 16: the 13-mer is all of bits 6..31
                 // byte offset of the sector: 16 * (hashed core scaled to [0, kf4_n)) = the high product with 16 kf4_n, less its low four bits
-                const uint32_t sect_b = __umulhi(core * 0x85EBCA6Bu, kf4_n16) & ~15u;
+                uint32_t sect_b = __umulhi(core * 0x85EBCA6Bu, kf4_n16) & ~15u;
+                if (RK_KMER_ABL & 128) { // timing experiment (WRONG results): an odd lane reads the other half of its even neighbour's 32 bytes --
+                    // what halving the filter's L2 requests would buy before anything is built for it
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sect_b, 0x111, 0xf, 0xf, true); // row_shr:1
+                    if (lane & 1) sect_b = (nb & ~31u) | 16u; else sect_b &= ~31u;
+                }
                 e0v[s] = P0 | (t << 12);
                 fq[s] = 0u;
                 fw[s] = u32x4{0u, 0u, 0u, 0u}; // (defined on both paths: left undefined, the compiler reuses a register still in flight and waits)

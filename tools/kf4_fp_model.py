@@ -135,5 +135,82 @@ def main():
         print("%-28s candidates per read %.2f (false %.2f)" % (name, cand.sum() / nreads, (cand & ~true_hit).sum() / nreads))
 
 
+def paired():
+    """The paired layout: lanes 2i and 2i+1 (groups 2i, 2i+1 = eight consecutive windows) read the two halves of one 32-byte sector
+    chosen by the 9-mer the eight windows share; a key is entered under 8 (group parity x alignment) x 2 orientations.  Prints the
+    candidates per read by entries per sector and bits per entry."""
+    nreads = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    refs = orc.kseq_parse_file(os.path.join(data, "all_pave_ref.fa.gz"))
+    seqs = [orc.to_upper(r[1]) for r in refs]
+    rb, ro = orc.pack(seqs)
+    sk, ln = orc.sketch_refs(rb, ro, [K], 1000, threads=8)
+    keys = np.unique(np.concatenate([sk[i, :ln[i]] for i in range(len(refs))]))
+    found = []
+    for s_ in seqs:
+        h = orc.calc_hashes(s_, [K])
+        x, ok = pack_windows(s_)
+        x, ok = x[:len(h)], ok[:len(h)]
+        found.append(x[ok & np.isin(h, keys)])
+    found = np.unique(np.concatenate(found))
+    both = np.unique(np.concatenate([found, revcomp(found)]))
+    from rkmh_amd import synth
+    qb, qo = synth.generate_reads(rb, ro, 0, nreads, read_len=150)
+    L = 150
+    R = np.frombuffer(qb[: nreads * L].tobytes(), np.uint8).reshape(nreads, L)
+    nw = L - K
+    X = np.zeros((nreads, nw), np.uint64)
+    OK = np.ones((nreads, nw), bool)
+    Cd = CODE[R]
+    V = np.isin(R, np.frombuffer(b"ACGT", np.uint8))
+    for i in range(K):
+        X |= Cd[:, i:i + nw] << np.uint64(2 * i)
+        OK &= V[:, i:i + nw]
+    true_hit = np.isin(X, both) & OK
+    pos = np.arange(nw)
+    slot = pos % 8                      # 4 a + j
+    m18 = np.uint64((1 << 18) - 1)
+    C = np.uint64(0x9E3779B1)
+    one = np.uint64(1)
+
+    def bits(x, nb):
+        lo = (x * C) & M32
+        hi = (x * C) >> np.uint64(32)
+        f = lambda v, s_: one << ((v >> np.uint64(s_)) & np.uint64(31))  # noqa: E731
+        b = f(lo, 24) | f(hi, 0) | f(hi, 16)
+        if nb >= 4:
+            b |= f(hi, 8)
+        return b
+    # the 9-mer of window x under slot s = its bases (7 - s) .. (15 - s)
+    core_q = (X >> (np.uint64(2) * (np.uint64(7) - slot[None, :].astype(np.uint64)))) & m18
+    print("true hits per read %.2f; oriented keys %d" % (true_hit.sum() / nreads, len(both)))
+    m26 = np.uint64((1 << 26) - 1)
+    # the 13-mer core of the window's own group (parity a = slot // 4, alignment j = slot % 4): bases (3 - j) .. (15 - j)
+    jq = (slot % 4)[None, :].astype(np.uint64)
+    core13_q = (X >> (np.uint64(2) * (np.uint64(3) - jq))) & m26
+    for SUB in (1, 2, 4):          # 16-byte sub-sectors per lane inside the pair's line (line = 32 * SUB bytes)
+        for nb in (3, 4):
+            bq = bits(X, nb)
+            bk = bits(both, nb)
+            for mb in (2.0, 2.4, 3.0):
+                nline = int(mb * 1048576 / (32 * SUB))
+                f = np.zeros((nline, 2, SUB, 4), np.uint64)
+                for s_ in range(8):
+                    a_, j_ = s_ // 4, s_ % 4
+                    c9 = (both >> np.uint64(2 * (7 - s_))) & m18
+                    c13 = (both >> np.uint64(2 * (3 - j_))) & m26
+                    sub = ((c13 * np.uint64(0xC2B2AE35)) & M32) >> np.uint64(30) if SUB == 4 else (((c13 * np.uint64(0xC2B2AE35)) & M32) >> np.uint64(31) if SUB == 2 else np.zeros_like(c13))
+                    np.bitwise_or.at(f, (sector(c9, nline).astype(np.int64), a_, sub.astype(np.int64), j_), bk)
+                subq = ((core13_q * np.uint64(0xC2B2AE35)) & M32) >> np.uint64(30) if SUB == 4 else (((core13_q * np.uint64(0xC2B2AE35)) & M32) >> np.uint64(31) if SUB == 2 else np.zeros_like(core13_q))
+                fw = f[sector(core_q, nline).astype(np.int64), (slot // 4)[None, :].repeat(nreads, 0), subq.astype(np.int64), (slot % 4)[None, :].repeat(nreads, 0)]
+                cand = ((bq & fw) == bq) & OK
+                assert not (true_hit & ~cand).any()
+                print("paired, line %3d B, %d bits, %.1f MB: candidates per read %.2f (false %.2f)"
+                      % (32 * SUB, nb, mb, cand.sum() / nreads, (cand & ~true_hit).sum() / nreads))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "paired":
+        paired()
+    else:
+        main()
