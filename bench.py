@@ -181,6 +181,7 @@ def config_legs(rkmh_amd, api, synth, dev, n, L, check):
         ms = kernel_ms(ctx, d_b, d_o, d_out, stream)
         out = d_out.cpu().numpy()
         legs["c3_panel"] = {"references": PR, "k": 16, "sketch_size": 1000, "reads": n, "kernel_ms": ms, "reads_per_s": n / ms * 1e3,
+                            "kernel_form": "k-mer-space" if ctx.kmer_form()[0] else "hash-space",
                             "rerouted_rows": int((out[:, 0] < 0).sum()), "oracle_checked_reads": sample_check(out, qb, qo, [16], 1000, sk, ln),
                             "note": "BASELINE config 3's panel (every bundled FASTA), one GPU's resident batch of synthetic reads drawn from it"}
     finally:

@@ -323,6 +323,10 @@ typedef struct rk_fastq_result {
 int rk_fastq_slot_create(rk_ctx* ctx, uint64_t max_bytes, rk_fastq_slot** out);
 uint8_t* rk_fastq_slot_text(rk_fastq_slot* slot);  /* page-locked buffer of max_bytes: the caller fills it with the block's text */
 int rk_fastq_slot_classify(rk_fastq_slot* slot, uint64_t nbytes, rk_fastq_result* res);
+/* the same in two halves (classify = submit + finish): submit enqueues the upload and the splitting / checking / packing kernels and
+ * returns at once, finish waits, classifies and collects -- a host thread with two slots reads its next block in between */
+int rk_fastq_slot_submit(rk_fastq_slot* slot, uint64_t nbytes);
+int rk_fastq_slot_finish(rk_fastq_slot* slot, rk_fastq_result* res);
 void rk_fastq_slot_destroy(rk_fastq_slot* slot);
 /* Where to cut: the offset of the LAST record start in text[1 .. n) under the four-line rule (a line that begins with '@' whose
  * second line below begins with '+'), or -1 when there is none: text[0 .. offset) then holds whole records only. */

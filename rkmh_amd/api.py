@@ -111,6 +111,8 @@ _SIGS = {
     "rk_fastq_slot_text": (C.c_void_p, [C.c_void_p]),
     "rk_fastq_slot_classify": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "rk_fastq_slot_destroy": (None, [C.c_void_p]),
+    "rk_fastq_slot_submit": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "rk_fastq_slot_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rk_fastq_cut": (C.c_int64, [C.c_void_p, C.c_uint64]),
     "rk_synth_reads": (C.c_int, [_u8p, _u64p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, _u8p, C.c_int]),
 }
@@ -346,12 +348,23 @@ class FastqSlot:
 
     def classify(self, text: bytes):
         """Returns (status, rows [n,4] int32, names [n] bytes, seqs [n] bytes); status != 0: the block must be parsed on the host."""
+        self.submit(text)
+        return self.finish()
+
+    def submit(self, text: bytes):
+        """First half (rk_fastq_slot_submit): the upload and the splitting kernels are enqueued; returns at once."""
         n = len(text)
         if n > self.max_bytes:
             raise ValueError("block larger than the slot")
         C.memmove(self._lib.rk_fastq_slot_text(self._h), text, n)
+        self._text = text
+        _chk(self._lib.rk_fastq_slot_submit(self._h, n))
+
+    def finish(self):
+        """Second half (rk_fastq_slot_finish): waits, classifies, collects; same return value as classify()."""
+        text = self._text
         res = FastqResult()
-        _chk(self._lib.rk_fastq_slot_classify(self._h, n, C.byref(res)))
+        _chk(self._lib.rk_fastq_slot_finish(self._h, C.byref(res)))
         if res.status != 0 or res.nrec == 0:
             return int(res.status), np.zeros((0, 4), np.int32), [], []
         m = int(res.nrec)

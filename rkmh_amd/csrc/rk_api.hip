@@ -1860,6 +1860,8 @@ struct rk_fastq_slot {
     PinBuf h_text, h_out4, h_spans, h_info;
     DevBuf d_text, d_u32, d_bases, d_out4, d_scan;
     FqDev d{};
+    uint64_t pending = 0;   // bytes of the block between submit and finish
+    bool submitted = false;
 };
 
 extern "C" void rk_fastq_slot_destroy(rk_fastq_slot* s) {
@@ -1919,11 +1921,15 @@ extern "C" int rk_fastq_slot_create(rk_ctx* c, uint64_t max_bytes, rk_fastq_slot
 
 extern "C" uint8_t* rk_fastq_slot_text(rk_fastq_slot* s) { return s ? s->h_text.as<uint8_t>() : nullptr; }
 
-extern "C" int rk_fastq_slot_classify(rk_fastq_slot* s, uint64_t nbytes, rk_fastq_result* res) {
-    if (!s || !res || nbytes > s->max_bytes) return fail(RK_ERR_ARG, "bad arguments");
+// The two halves of rk_fastq_slot_classify, for callers that keep two slots per thread: submit() enqueues the upload and the
+// index / check / pack kernels and returns at once; finish() waits for them, launches the classification and collects the rows.
+// Between the two the caller can read its next block into its other slot -- the link and the GPU work while the host reads.
+extern "C" int rk_fastq_slot_submit(rk_fastq_slot* s, uint64_t nbytes) {
+    if (!s || nbytes > s->max_bytes) return fail(RK_ERR_ARG, "bad arguments");
     rk_ctx* c = s->c;
     if (!c->have_refs) return fail(RK_ERR_STATE, "classify before rk_set_references");
-    memset(res, 0, sizeof *res);
+    s->pending = nbytes;
+    s->submitted = true;
     if (nbytes == 0) return RK_OK;
     RKCHK(set_dev(c));
     hipStream_t st = s->st;
@@ -1931,9 +1937,22 @@ extern "C" int rk_fastq_slot_classify(rk_fastq_slot* s, uint64_t nbytes, rk_fast
     memset(text + nbytes, 'A', 16); // the device reads whole 16-byte pieces
     HIPCHK(hipMemcpyAsync(s->d_text.p, text, (nbytes + 15) & ~(uint64_t)15, hipMemcpyHostToDevice, st));
     HIPCHK(launch_fastq_index(s->d, s->d_text.as<uint8_t>(), nbytes, st));
-    uint32_t* info = s->h_info.as<uint32_t>();
-    HIPCHK(hipMemcpyAsync(info, s->d.info, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s->h_info.p, s->d.info, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(s->ev, st));
+    return RK_OK;
+}
+
+extern "C" int rk_fastq_slot_finish(rk_fastq_slot* s, rk_fastq_result* res) {
+    if (!s || !res) return fail(RK_ERR_ARG, "bad arguments");
+    if (!s->submitted) return fail(RK_ERR_STATE, "rk_fastq_slot_finish without rk_fastq_slot_submit");
+    s->submitted = false;
+    rk_ctx* c = s->c;
+    memset(res, 0, sizeof *res);
+    if (s->pending == 0) return RK_OK;
+    RKCHK(set_dev(c));
+    hipStream_t st = s->st;
+    uint8_t* text = s->h_text.as<uint8_t>();
+    uint32_t* info = s->h_info.as<uint32_t>();
     HIPCHK(hipEventSynchronize(s->ev));
     if (info[0] != 0) { res->status = (int32_t)info[0]; return RK_OK; } // not strictly four lines per record: the caller's scanner takes the block
     const int64_t nrec = (int64_t)info[1];
@@ -1970,4 +1989,10 @@ extern "C" int rk_fastq_slot_classify(rk_fastq_slot* s, uint64_t nbytes, rk_fast
         for (size_t j = 0; j < idx.size(); ++j) memcpy(out4 + idx[j] * 4, rows.data() + j * 4, 16);
     }
     return RK_OK;
+}
+
+extern "C" int rk_fastq_slot_classify(rk_fastq_slot* s, uint64_t nbytes, rk_fastq_result* res) {
+    if (!res) return fail(RK_ERR_ARG, "bad arguments");
+    RKCHK(rk_fastq_slot_submit(s, nbytes));
+    return rk_fastq_slot_finish(s, res);
 }

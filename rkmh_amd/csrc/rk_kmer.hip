@@ -31,7 +31,7 @@ namespace {
 
 constexpr int KW = 64;
 constexpr int KM_MAX_T = 8;          // reads per tile (phase 2 takes eight reads in one pass; the group -> read search is unrolled for it)
-constexpr int KM_MQ = 32;            // deferred multi-posting hits per drain (more are walked by their own lane)
+constexpr int KM_MQ = 32;            // deferred multi-posting hits (a full list is worked off at once: 16 lanes per hit)
 #ifndef RK_KMER_ABL
 #define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length, 128 filter sectors of lane pairs in one line
 #endif
@@ -322,7 +322,9 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
 
         // +1 for reference `ref` of read t, whose counter row starts crow_b bytes into cnt; the monotone counters make
         // (max_shared, first max_id) a running atomicMax
-        auto add_posting = [&](uint32_t t, uint32_t crow_b, uint32_t ref) {
+        // count_posting: +1 for reference `ref` of read t; returns the candidate for the read's running maximum, count << 16 | ~ref
+        // (0: the read left for the general path).  add_posting = count + atomicMax.
+        auto count_posting = [&](uint32_t t, uint32_t crow_b, uint32_t ref) -> uint32_t {
             uint32_t c;
             if constexpr (CMODE == CM_SPARSE) { // large panels keep (ref, count) pairs of the references a read really hits
                 uint32_t* crow = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(cnt) + crow_b);
@@ -335,18 +337,18 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                     if ((old >> 11) == key) { c = (atomicAdd(&crow[idx], 1u) & 0x7FFu) + 1u; break; }
                     idx = (idx + 1u) & M1;
                 }
-                if (probe > M1) { flags[t] = 1; return; } // the read hits more references than the map holds: general path
+                if (probe > M1) { flags[t] = 1; return 0u; } // the read hits more references than the map holds: general path
             } else {
                 const uint32_t sh = (ref << (5 - clg)) & (32u - cbits);           // bit position of the counter inside its word
                 const uint32_t woff = (ref >> clg) << 2;                          // byte offset of the word inside the row
                 const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(cnt) + crow_b + woff), 1u << sh);
                 c = __builtin_amdgcn_ubfe(old, sh, cbits) + 1u;
             }
-            atomicMax(&best[t], (c << 16) + (0xFFFFu - ref));
+            return (c << 16) + (0xFFFFu - ref);
         };
-        auto walk_list = [&](uint32_t t, uint32_t rank, uint32_t off) { // the postings of a list this occurrence counts for
-            const uint32_t n = ix.post[off];
-            for (uint32_t c = 0; c < n; ++c) if (rank < ix.post[off + 2 + 2 * c]) add_posting(t, __umul24(t, CW * 4u), ix.post[off + 1 + 2 * c]);
+        auto add_posting = [&](uint32_t t, uint32_t crow_b, uint32_t ref) {
+            const uint32_t v = count_posting(t, crow_b, ref);
+            if (v) atomicMax(&best[t], v);
         };
         uint32_t mqn = 0; // deferred list hits (wave-uniform)
         auto process_mq = [&]() { // 16 lanes walk one hit's posting list, 4 hits at a time
@@ -355,7 +357,18 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             for (uint32_t j = g; j < mqn; j += KW / 16) {
                 const uint32_t tr = mq[2 * j], off = mq[2 * j + 1];
                 const uint32_t n = ix.post[off], t = tr & 0xFFu;
-                for (uint32_t c = sl; c < n; c += 16) if ((tr >> 8) < ix.post[off + 2 + 2 * c]) add_posting(t, __umul24(t, CW * 4u), ix.post[off + 1 + 2 * c]);
+                // The 16 lanes of a hit all feed the SAME running maximum best[t]: left to themselves they issue 16 atomicMax on one LDS
+                // address per step (and the four hits of a step are often four hits of one read: 64 on one address, served one after the
+                // other).  Their candidates are reduced over the 16-lane row first (DPP) and one lane issues the atomic -- this and working a
+                // full list of deferred hits off at once took reads of a 60-member family of near-identical references (every hit: 60
+                // postings) from 2.3 to 1.1 ms per 1 M reads and BASELINE config 3's panel from 0.90 to 0.69 (profiles/r04_c3_probe.txt).
+                for (uint32_t c0 = 0; c0 < n; c0 += 16) { // (n is the same for the 16 lanes of the row: they run the same trips)
+                    const uint32_t c = c0 + sl;
+                    uint32_t v = 0;
+                    if (c < n && (tr >> 8) < ix.post[off + 2 + 2 * c]) v = count_posting(t, __umul24(t, CW * 4u), ix.post[off + 1 + 2 * c]);
+                    v = (uint32_t)row_max_i32((int)v); // (candidates are < 2^31: counts below 2^15)
+                    if (sl == 0 && v) atomicMax(&best[t], v);
+                }
             }
             wave_sync();
             mqn = 0;
@@ -434,15 +447,21 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                     } else multi = true;
                 }
             }
-            const uint64_t mm = __ballot(multi);
-            if (mm) { // hits with a posting list are deferred to the end of the drain; the few that find the list full walk their own
-                const uint32_t j = mqn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-                if (multi) {
-                    if (j < (uint32_t)KM_MQ) { mq[2 * j] = c.t | (rank << 8); mq[2 * j + 1] = val & 0x7fffffffu; }
-                    else walk_list(c.t, rank, val & 0x7fffffffu);
+            // hits with a posting list are deferred to the end of the drain (16 lanes then walk each list); when the list of deferred
+            // hits is full it is worked off at once and filled again (a read of a family of near-identical references has nothing but
+            // such hits: walking them one lane per list took most of its time)
+            uint64_t mm = __ballot(multi);
+            while (mm) { // wave-uniform
+                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                const uint32_t space = (uint32_t)KM_MQ - mqn;
+                if (multi && pos < space) {
+                    mq[2 * (mqn + pos)] = c.t | (rank << 8); mq[2 * (mqn + pos) + 1] = val & 0x7fffffffu;
+                    multi = false;
                 }
-                const uint32_t tot = mqn + (uint32_t)__popcll(mm);
-                mqn = tot < (uint32_t)KM_MQ ? tot : (uint32_t)KM_MQ;
+                const uint32_t tot = (uint32_t)__popcll(mm);
+                mqn += tot < space ? tot : space;
+                if (mqn == (uint32_t)KM_MQ) process_mq();
+                mm = __ballot(multi);
             }
         };
         auto drain = [&](uint32_t qn) {

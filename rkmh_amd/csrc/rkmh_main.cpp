@@ -58,6 +58,7 @@ static void die(const char* what) {
     const bool bad = fflush(stdout) != 0 || ferror(stdout);
     fflush(stderr);
     if (bad) fprintf(stderr, "rkmh: write error on standard output\n");
+    if (getenv("RKMH_SLOW_EXIT")) exit(bad ? 1 : 0); // profilers (rocprofv3) write their tables from an exit handler
     _exit(bad ? 1 : 0); // skips the HIP runtime's and the loader's exit handlers (~0.1-0.2 s of a 1 s run)
 }
 #define CK(call) do { if ((call) != RK_OK) die(#call); } while (0)
@@ -421,9 +422,10 @@ struct OrderedOut {
 };
 
 struct RawEngine {
-    struct Worker { rk_fastq_slot* slot = nullptr; size_t dev = 0; };
+    struct Worker { rk_fastq_slot* slot[2] = {nullptr, nullptr}; size_t dev = 0; }; // two slots: one block on the device while the next is read
     std::vector<Worker> w;
     uint64_t block = 0;
+    bool two_slots = true;
     double t_read = 0, t_dev = 0, t_fmt = 0;
     int64_t blocks = 0, records = 0;
     bool create(DeviceGroup& g) {
@@ -431,22 +433,23 @@ struct RawEngine {
         long mb = 16; // measured (tools/e2e_sweep.py, 16 CPUs): 8-16 MB blocks and 8 workers 82 M reads/s, 32 MB and 14 workers 56-73
         if (const char* e = getenv("RKMH_RAW_BLOCK_KB")) { long v = atol(e); if (v >= 4) { block = (uint64_t)v << 10; mb = 0; } }
         if (mb) block = (uint64_t)mb << 20;
-        long nw = std::max(2, granted_cpus_main() * 5 / 8); // 10 of 16 CPUs: 6 / 8 / 10 / 12 workers measured 57-78 / 56-83 / 64-89 / 64-87 M reads/s
+        long nw = std::max(2, granted_cpus_main() / 2); // (each worker keeps two blocks in flight)
         if (nw > 12) nw = 12;
         if (const char* e = getenv("RKMH_RAW_WORKERS")) { long v = atol(e); if (v >= 1 && v <= 64) nw = v; }
         if ((size_t)nw < g.size()) nw = (long)g.size();
+        if (const char* e = getenv("RKMH_RAW_SLOTS")) two_slots = atoi(e) != 1;
         w.resize((size_t)nw);
         for (size_t i = 0; i < w.size(); ++i) w[i].dev = i % g.size();
         // each worker creates its own slot when it starts (page-locking ~50 MB takes ~10 ms): the first blocks are on their way
         // while the later workers are still setting up.  Only the first slot is made here, to find out whether the front end works at all.
-        if (rk_fastq_slot_create(g.ctx[0], block, &w[0].slot) != RK_OK) {
+        if (rk_fastq_slot_create(g.ctx[0], block, &w[0].slot[0]) != RK_OK) {
             fprintf(stderr, "rkmh: device FASTQ front end unavailable (%s): using the host scanner\n", rk_last_error());
             w.clear();
             return false;
         }
         return true;
     }
-    void destroy() { for (auto& x : w) if (x.slot) rk_fastq_slot_destroy(x.slot); w.clear(); }
+    void destroy() { for (auto& x : w) for (auto* sl : x.slot) if (sl) rk_fastq_slot_destroy(sl); w.clear(); }
 };
 
 // Everything of a line that does not depend on the read, prepared once per run: "ref name \t" per reference and the eight
@@ -522,44 +525,59 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     std::map<int64_t, int64_t> fail_at; // block number -> its first byte
     std::mutex tm;
     auto work = [&](size_t wi) {
-        if (!eng.w[wi].slot && rk_fastq_slot_create(g.ctx[eng.w[wi].dev], eng.block, &eng.w[wi].slot) != RK_OK) {
-            // (memory for another slot ran out: the other workers carry on)
-            fprintf(stderr, "rkmh: worker %zu: %s\n", wi, rk_last_error());
-            return;
-        }
-        rk_fastq_slot* slot = eng.w[wi].slot;
-        uint8_t* text = rk_fastq_slot_text(slot);
-        Job j;
-        while (jobs.pop(&j)) {
-            std::vector<char> buf = out.take_buffer();
-            if (j.seq > fail_seq.load()) { out.put(j.seq, std::move(buf), 0, (int64_t)eng.w.size() * 3 + 2); continue; } // the scanner will redo this range
-            const double a = now_s();
-            int64_t got = 0;
-            while (got < j.hi - j.lo) {
-                const ssize_t n = pread(fd, text + got, (size_t)(j.hi - j.lo - got), (off_t)(j.lo + got));
-                if (n <= 0) { fprintf(stderr, "rkmh: read error on %s\n", path); fail_exit(); } // (the other workers may be waiting for this block)
-                got += n;
+        for (int k = 0; k < (eng.two_slots ? 2 : 1); ++k)
+            if (!eng.w[wi].slot[k] && rk_fastq_slot_create(g.ctx[eng.w[wi].dev], eng.block, &eng.w[wi].slot[k]) != RK_OK) {
+                // (memory for another slot ran out: the other workers carry on)
+                fprintf(stderr, "rkmh: worker %zu: %s\n", wi, rk_last_error());
+                return;
             }
-            uint64_t nbytes = (uint64_t)(j.hi - j.lo);
-            if (j.hi == fsize && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n'; // a last line without its newline (the slot holds 64 spare bytes)
+        const int64_t window = (int64_t)eng.w.size() * 4 + 2;
+        Job cur, prev;
+        bool have_prev = false;
+        int k = 0;
+        double t_rd = 0, t_dv = 0, t_fm = 0;
+        int64_t nblk = 0, nrec_ = 0;
+        auto finish_block = [&](const Job& jb, rk_fastq_slot* slot) {
             const double b = now_s();
             rk_fastq_result res;
-            if (rk_fastq_slot_classify(slot, nbytes, &res) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+            if (rk_fastq_slot_finish(slot, &res) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
             const double c = now_s();
+            std::vector<char> buf = out.take_buffer();
             size_t outlen = 0;
             if (res.status != 0) {
-                { std::lock_guard<std::mutex> l(fm); fail_at[j.seq] = j.lo; }
-                out.lower_limit(j.seq); // (before this block is pushed: the writer cannot pass it)
-                int64_t cur = fail_seq.load();
-                while (j.seq < cur && !fail_seq.compare_exchange_weak(cur, j.seq)) {}
-            } else outlen = format_raw(lp, res, text, o, buf);
-            const double d = now_s();
-            {
-                std::lock_guard<std::mutex> l(tm);
-                eng.t_read += b - a; eng.t_dev += c - b; eng.t_fmt += d - c; eng.blocks += 1; eng.records += res.status == 0 ? res.nrec : 0;
+                { std::lock_guard<std::mutex> l(fm); fail_at[jb.seq] = jb.lo; }
+                out.lower_limit(jb.seq); // (before this block is parked: the sink cannot pass it)
+                int64_t curf = fail_seq.load();
+                while (jb.seq < curf && !fail_seq.compare_exchange_weak(curf, jb.seq)) {}
+            } else outlen = format_raw(lp, res, rk_fastq_slot_text(slot), o, buf);
+            t_dv += c - b; t_fm += now_s() - c; ++nblk; nrec_ += res.status == 0 ? res.nrec : 0;
+            out.put(jb.seq, std::move(buf), outlen, window);
+        };
+        // block b is on its way to the device and through the index kernels (submit) while block b + 1 is read into the other slot
+        for (;;) {
+            const bool got = jobs.pop(&cur);
+            if (got && cur.seq > fail_seq.load()) { out.put(cur.seq, std::vector<char>(), 0, window); continue; } // the scanner will redo this range
+            if (got) {
+                const double a = now_s();
+                uint8_t* text = rk_fastq_slot_text(eng.w[wi].slot[k]);
+                int64_t have = 0;
+                while (have < cur.hi - cur.lo) {
+                    const ssize_t n = pread(fd, text + have, (size_t)(cur.hi - cur.lo - have), (off_t)(cur.lo + have));
+                    if (n <= 0) { fprintf(stderr, "rkmh: read error on %s\n", path); fail_exit(); } // (the other workers may be waiting for this block)
+                    have += n;
+                }
+                uint64_t nbytes = (uint64_t)(cur.hi - cur.lo);
+                if (cur.hi == fsize && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n'; // a last line without its newline (the slot holds 64 spare bytes)
+                if (rk_fastq_slot_submit(eng.w[wi].slot[k], nbytes) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+                t_rd += now_s() - a;
             }
-            out.put(j.seq, std::move(buf), outlen, (int64_t)eng.w.size() * 3 + 2);
+            if (got && !eng.two_slots) { finish_block(cur, eng.w[wi].slot[k]); continue; } // RKMH_RAW_SLOTS=1: one block per worker at a time
+            if (have_prev) { finish_block(prev, eng.w[wi].slot[k ^ 1]); have_prev = false; }
+            if (!got) break;
+            prev = cur; have_prev = true; k ^= 1;
         }
+        std::lock_guard<std::mutex> l(tm);
+        eng.t_read += t_rd; eng.t_dev += t_dv; eng.t_fmt += t_fm; eng.blocks += nblk; eng.records += nrec_;
     };
     std::vector<std::thread> workers;
     for (size_t i = 0; i < eng.w.size(); ++i) workers.emplace_back(work, i);

@@ -94,6 +94,38 @@ def test_regular_text_equals_kseq_and_the_oracle_rows(setup, orc):
     assert slot.classify(b"")[0] == 0
 
 
+def test_two_slots_in_flight(setup, orc):
+    """rk_fastq_slot_submit / _finish: two slots of one context with their blocks in flight together (what each worker of
+    bin/rkmh stream does), finished in either order; finish without submit is an error, not a crash."""
+    import rkmh_amd
+    from rkmh_amd import api, synth
+    ctx, slot, rb, ro, sk, ln = setup
+    other = api.FastqSlot(ctx, max_bytes=1 << 22)
+    try:
+        qb, qo = synth.generate_reads_fast(rb, ro, 100000, 104000, read_len=150, threads=4)
+        reads = [bytes(qb[int(qo[i]):int(qo[i + 1])]) for i in range(4000)]
+        t1, t2 = _fastq(reads[:2500], names=[b"a%d" % i for i in range(2500)]), _fastq(reads[2500:], names=[b"b%d" % i for i in range(1500)])
+        want = {}
+        for key, t in (("t1", t1), ("t2", t2)):
+            st, rows, names, seqs = slot.classify(t)
+            assert st == 0
+            want[key] = (rows, names)
+        for order in ((slot, other), (other, slot)):
+            order[0].submit(t1)
+            order[1].submit(t2)
+            st2, rows2, names2, _ = order[1].finish()
+            st1, rows1, names1, _ = order[0].finish()
+            assert st1 == 0 and st2 == 0
+            assert (rows1 == want["t1"][0]).all() and names1 == want["t1"][1]
+            assert (rows2 == want["t2"][0]).all() and names2 == want["t2"][1]
+        with pytest.raises(rkmh_amd.RkmhError):
+            other.finish()
+        other.submit(b"@x\nAC\nGT\n+\nIIII\n")   # irregular block through the split form
+        assert other.finish()[0] != 0
+    finally:
+        other.destroy()
+
+
 def test_irregular_text_is_refused_or_exact(setup, orc):
     ctx, slot, rb, ro, sk, ln = setup
     a, b = bytes(rb[100:250]), bytes(rb[1000:1150])
