@@ -425,7 +425,9 @@ struct RawEngine {
     struct Worker { rk_fastq_slot* slot[2] = {nullptr, nullptr}; size_t dev = 0; }; // two slots: one block on the device while the next is read
     std::vector<Worker> w;
     uint64_t block = 0;
-    bool two_slots = true;
+    bool two_slots = false; // RKMH_RAW_SLOTS=2: a worker reads its next block while the previous one is on the device.  Measured (profiles/r04_e2e_ab.txt,
+                            // medians of three): no faster on 64 M reads (1.54 against 1.53-1.58 s to a file, 1.25 against 1.16-1.29 to /dev/null) and
+                            // 0.2 s slower on 16 M (twice the page-locked buffers to create), so one slot per worker is the default
     double t_read = 0, t_dev = 0, t_fmt = 0;
     int64_t blocks = 0, records = 0;
     bool create(DeviceGroup& g) {
@@ -433,11 +435,11 @@ struct RawEngine {
         long mb = 16; // measured (tools/e2e_sweep.py, 16 CPUs): 8-16 MB blocks and 8 workers 82 M reads/s, 32 MB and 14 workers 56-73
         if (const char* e = getenv("RKMH_RAW_BLOCK_KB")) { long v = atol(e); if (v >= 4) { block = (uint64_t)v << 10; mb = 0; } }
         if (mb) block = (uint64_t)mb << 20;
-        long nw = std::max(2, granted_cpus_main() / 2); // (each worker keeps two blocks in flight)
+        long nw = std::max(2, granted_cpus_main() * 3 / 8); // 6 of 16 CPUs: 4 / 6 / 8 / 10 workers 77 / 97 / 83 / 95 M reads/s to /dev/null, 53-63 to a file
         if (nw > 12) nw = 12;
         if (const char* e = getenv("RKMH_RAW_WORKERS")) { long v = atol(e); if (v >= 1 && v <= 64) nw = v; }
         if ((size_t)nw < g.size()) nw = (long)g.size();
-        if (const char* e = getenv("RKMH_RAW_SLOTS")) two_slots = atoi(e) != 1;
+        if (const char* e = getenv("RKMH_RAW_SLOTS")) two_slots = atoi(e) == 2;
         w.resize((size_t)nw);
         for (size_t i = 0; i < w.size(); ++i) w[i].dev = i % g.size();
         // each worker creates its own slot when it starts (page-locking ~50 MB takes ~10 ms): the first blocks are on their way
