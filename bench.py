@@ -84,11 +84,17 @@ def e2e_stream(n, L, rb, ro, synth):
                 f.write(rec.tobytes())
         size = os.path.getsize(fq)
         best = None
-        for rep in range(2):                          # the second run finds the file in the page cache, as a pipeline's input would be
+        def fresh_out():                              # a NEW output file per run, opened before the clock starts: truncating the previous run's
+            if os.path.exists(tsv):                   # gigabyte of cached pages is the harness's cost, not the pipeline's
+                os.remove(tsv)
+            return open(tsv, "wb")
+        for rep in range(2):                          # the second run finds the FASTQ in the page cache, as a pipeline's input would be
+            fo = fresh_out()
             t = time.perf_counter()
-            r = subprocess.run([exe, "stream", "-r", ref, "-f", fq, "-k", "16", "-s", "1000"], stdout=open(tsv, "wb"), stderr=subprocess.PIPE,
+            r = subprocess.run([exe, "stream", "-r", ref, "-f", fq, "-k", "16", "-s", "1000"], stdout=fo, stderr=subprocess.PIPE,
                                env=dict(os.environ, RKMH_TIMING="1"))
             dt = time.perf_counter() - t
+            fo.close()
             if r.returncode != 0:
                 return {"error": r.stderr.decode()[-300:]}
             if best is None or dt < best:
@@ -99,13 +105,14 @@ def e2e_stream(n, L, rb, ro, synth):
                "note": "bin/rkmh stream -k 16 -s 1000 on a generated FASTQ, whole process: start-up + reference sketches + parser + PCIe + kernel + TSV"}
         # the same file four times over (-f x 4): what a longer input does to the fixed start-up / tear-down share, and the marginal
         # rate of the pipeline ((4 - 1) n reads in the extra time)
+        fo = fresh_out()
         t = time.perf_counter()
-        r = subprocess.run([exe, "stream", "-r", ref] + ["-f", fq] * 4 + ["-k", "16", "-s", "1000"], stdout=open(tsv, "wb"), stderr=subprocess.PIPE)
+        r = subprocess.run([exe, "stream", "-r", ref] + ["-f", fq] * 4 + ["-k", "16", "-s", "1000"], stdout=fo, stderr=subprocess.PIPE)
         dt4 = time.perf_counter() - t
+        fo.close()
         if r.returncode == 0 and dt4 > best:
             res["x4"] = {"reads": 4 * n, "wall_s": dt4, "value": 4 * n / dt4, "marginal_reads_per_s": 3 * n / (dt4 - best)}
-        # the same two runs with the lines going to /dev/null: what the pipeline itself sustains (parsing on the device, PCIe, kernel,
-        # formatting) when the file system the TSV is written to -- one file, ~2-2.6 GB/s of buffered writes -- is out of the way
+        # the same two runs with the lines going to /dev/null (one writer thread with fwrite, as for a pipe)
         t1 = []
         for nf in (1, 4):
             t = time.perf_counter()
@@ -113,7 +120,7 @@ def e2e_stream(n, L, rb, ro, synth):
             t1.append(time.perf_counter() - t if r.returncode == 0 else None)
         if None not in t1 and t1[1] > t1[0]:
             res["x4_devnull"] = {"wall_s_1": t1[0], "wall_s_4": t1[1], "marginal_reads_per_s": 3 * n / (t1[1] - t1[0]),
-                                 "note": "stdout = /dev/null: the pipeline without the output file's write bandwidth"}
+                                 "note": "stdout = /dev/null: the ordered single-writer path a pipe gets"}
         return res
     finally:
         for x in (fq, tsv):

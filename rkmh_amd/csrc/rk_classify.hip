@@ -389,8 +389,9 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         };
 
         // +1 for reference `ref` of read t; the monotone counters make (max_shared, first max_id) a running atomicMax
-        auto add_posting = [&](int t, uint32_t ref) {
-            if RK_DBG(128) return;
+        // count_posting: the +1 alone; returns the candidate for the running maximum (0: nothing to report)
+        auto count_posting = [&](int t, uint32_t ref) -> uint32_t {
+            if RK_DBG(128) return 0u;
             // packed counters: 16 bits each, or 8 bits when no read of the batch has more than 255 windows (a count never
             // exceeds the number of windows, so no field can carry into its neighbour)
             uint32_t cnt;
@@ -405,13 +406,17 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                     if ((old >> 11) == key) { cnt = (atomicAdd(&row[idx], 1u) & 0x7FFu) + 1u; break; }
                     idx = (idx + 1u) & M1;
                 }
-                if (probe > M1) { flags[t] = 1; return; } // the read hits more references than the map holds: general path
+                if (probe > M1) { flags[t] = 1; return 0u; } // the read hits more references than the map holds: general path
             } else {
                 const uint32_t sh = (ref & cper_m1) * cbits;
                 const uint32_t old = atomicAdd(&c16[t * geo.cwords + (int)(ref >> clg)], 1u << sh);
                 cnt = ((old >> sh) & cmask) + 1u;
             }
-            atomicMax(&best[t], (cnt << 16) | (0xFFFFu - ref));
+            return (cnt << 16) | (0xFFFFu - ref);
+        };
+        auto add_posting = [&](int t, uint32_t ref) {
+            const uint32_t v = count_posting(t, ref);
+            if (v) atomicMax(&best[t], v);
         };
         // one candidate window: verify the full key, find the occurrence rank of this sketch hash within the read
         // (exact LDS multiset: entry = (slot + 1) | (occurrences - 1) << 27) and add the postings the multiset merge of
@@ -474,9 +479,17 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                     for (uint32_t j = (uint32_t)g; j < nm; j += WAVE / 16) {
                         const uint32_t tr = mq[2 * j], off = mq[2 * j + 1];
                         const uint32_t cnt = ix.post[off];
-                        for (uint32_t c = (uint32_t)sl; c < cnt; c += 16) {
-                            const uint32_t ref = ix.post[off + 1 + 2 * c], mult = ix.post[off + 2 + 2 * c];
-                            if ((tr & 0xFFu) < mult) add_posting((int)(tr >> 8), ref);
+                        // as in k_classify_kmer: the 16 lanes' candidates for the read's running maximum are reduced over the row before
+                        // ONE lane issues the atomic (16 atomics on one LDS address per step otherwise)
+                        for (uint32_t c0 = 0; c0 < cnt; c0 += 16) {
+                            const uint32_t c = c0 + (uint32_t)sl;
+                            uint32_t v = 0;
+                            if (c < cnt) {
+                                const uint32_t ref = ix.post[off + 1 + 2 * c], mult = ix.post[off + 2 + 2 * c];
+                                if ((tr & 0xFFu) < mult) v = count_posting((int)(tr >> 8), ref);
+                            }
+                            v = (uint32_t)row_max_i32((int)v);
+                            if (sl == 0 && v) atomicMax(&best[tr >> 8], v);
                         }
                     }
                     wave_sync();

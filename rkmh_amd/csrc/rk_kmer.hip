@@ -70,6 +70,7 @@ struct KmerGeom {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(1))) km_pair1 { uint32_t x, y; };
+struct __attribute__((packed, aligned(4))) km_pair4 { uint32_t x, y; }; // two dwords at any dword-aligned address (posting entries)
 
 // static LDS layout (dwords)
 template <int NQ>
@@ -362,10 +363,17 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                 // other).  Their candidates are reduced over the 16-lane row first (DPP) and one lane issues the atomic -- this and working a
                 // full list of deferred hits off at once took reads of a 60-member family of near-identical references (every hit: 60
                 // postings) from 2.3 to 1.1 ms per 1 M reads and BASELINE config 3's panel from 0.90 to 0.69 (profiles/r04_c3_probe.txt).
+                // (Tried and rejected: lane sl taking postings 4 sl .. 4 sl + 3 so that neighbouring lanes do not meet in one counter word --
+                // four dependent atomics per lane cost more than the four-way conflicts: family reads 1.1 -> 2.0 ms.)
+                // (Also tried and rejected: the four rows of a step -- often four hits of one read with one list -- starting at different
+                // chunks of the list, so that they do not add to the same counter words in the same instruction: 1.08 -> 1.14 ms.)
                 for (uint32_t c0 = 0; c0 < n; c0 += 16) { // (n is the same for the 16 lanes of the row: they run the same trips)
                     const uint32_t c = c0 + sl;
                     uint32_t v = 0;
-                    if (c < n && (tr >> 8) < ix.post[off + 2 + 2 * c]) v = count_posting(t, __umul24(t, CW * 4u), ix.post[off + 1 + 2 * c]);
+                    if (c < n) {
+                        const km_pair4 pm = *reinterpret_cast<const km_pair4*>(ix.post + off + 1 + 2 * c); // (reference, multiplicity)
+                        if ((tr >> 8) < pm.y) v = count_posting(t, __umul24(t, CW * 4u), pm.x);
+                    }
                     v = (uint32_t)row_max_i32((int)v); // (candidates are < 2^31: counts below 2^15)
                     if (sl == 0 && v) atomicMax(&best[t], v);
                 }

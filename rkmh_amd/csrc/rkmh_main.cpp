@@ -349,22 +349,24 @@ static bool raw_eligible(const char* path, int64_t* size) {
     return ok;
 }
 
-// Formatted blocks leave in the order of their numbers.  No writer thread: a worker parks its finished block and, if the next block
-// due is there, WRITES the run of consecutive blocks that are ready (its own included) -- otherwise it goes straight on to its next
-// block.  A worker therefore never waits for a slower neighbour (only for memory: at most `window` blocks may be parked ahead of the
-// one due), which in-order hand-over by the workers themselves did: one straggler stalled all eight.
+// Formatted blocks leave in the order of their numbers.  A worker parks its finished block and goes straight on to its next one (it
+// only ever waits for memory: at most `window` blocks may be parked ahead of the one due); whoever parks the block that is DUE gives
+// the run of consecutive ready blocks their places in the output, in order, and hands them to the writer threads: several of them,
+// each with pwrite at the block's final offset, when standard output is a regular file (a file takes ~12 GB/s of buffered writes on the
+// test boxes, tools/ubench/file_write.cpp: the output is not what limits the pipeline), one with fwrite otherwise.
 struct OrderedOut {
-    struct Parked { std::vector<char> buf; size_t len = 0; };
+    struct Parked { std::vector<char> buf; size_t len = 0; off_t at = 0; bool keep = false; };
     std::mutex m;
-    std::condition_variable cv;
+    std::condition_variable cv, cv_task;
     std::map<int64_t, Parked> parked;
+    std::deque<Parked> tasks;             // blocks with their place assigned, waiting for a writer
     std::vector<std::vector<char>> spare; // buffers to format the next blocks into
+    std::vector<std::thread> writers;
     int64_t next = 0;
-    bool draining = false, failed = false;
+    size_t in_flight = 0;                 // tasks queued or being written
+    bool assigning = false, failed = false, closing = false;
     std::atomic<int64_t> limit{INT64_MAX}; // blocks from this number on are dropped, not written (another front end redoes them)
-    // standard output a regular file not opened for appending: blocks are written with pwrite at their final offsets (the file
-    // position is moved behind them at the end); otherwise with fwrite
-    bool direct = false;
+    bool direct = false;                   // standard output is a regular file not opened for appending
     off_t base = 0, total = 0;
     void lower_limit(int64_t seq) { int64_t cur = limit.load(); while (seq < cur && !limit.compare_exchange_weak(cur, seq)) {} }
     void start() {
@@ -376,6 +378,33 @@ struct OrderedOut {
             const off_t cur = lseek(1, 0, SEEK_CUR);
             if (cur >= 0) { direct = true; base = cur; }
         }
+        long nw = direct ? 3 : 1; // a pipe or a terminal takes the blocks from ONE thread, in order
+        if (const char* e = getenv("RKMH_OUT_WRITERS")) { long v = atol(e); if (direct && v >= 1 && v <= 16) nw = v; }
+        for (long i = 0; i < nw; ++i)
+            writers.emplace_back([this] {
+                std::unique_lock<std::mutex> l(m);
+                for (;;) {
+                    cv_task.wait(l, [&] { return !tasks.empty() || closing; });
+                    if (tasks.empty()) return;
+                    Parked e = std::move(tasks.front());
+                    tasks.pop_front();
+                    l.unlock();
+                    if (e.keep && e.len) {
+                        if (direct) {
+                            size_t done_ = 0;
+                            while (done_ < e.len) {
+                                const ssize_t n = pwrite(1, e.buf.data() + done_, e.len - done_, e.at + (off_t)done_);
+                                if (n <= 0) { failed = true; break; }
+                                done_ += (size_t)n;
+                            }
+                        } else if (fwrite(e.buf.data(), 1, e.len, stdout) != e.len) failed = true;
+                    }
+                    l.lock();
+                    if (spare.size() < 32) spare.push_back(std::move(e.buf));
+                    --in_flight;
+                    cv.notify_all();
+                }
+            });
     }
     std::vector<char> take_buffer() {
         std::lock_guard<std::mutex> l(m);
@@ -387,36 +416,33 @@ struct OrderedOut {
     // buf[0 .. len) are the lines of block seq; the buffer becomes the sink's (a spare one comes back from take_buffer)
     void put(int64_t seq, std::vector<char>&& buf, size_t len, int64_t window) {
         std::unique_lock<std::mutex> l(m);
-        cv.wait(l, [&] { return seq < next + window; });
+        cv.wait(l, [&] { return seq < next + window && in_flight < (size_t)window; });
         Parked& pk = parked[seq];
         pk.buf = std::move(buf); pk.len = len;
-        if (draining) return; // the thread that is writing will find this block when its turn comes
-        draining = true;
+        if (assigning) return; // the thread that is handing blocks out will find this one when its turn comes
+        assigning = true;
         for (auto it = parked.find(next); it != parked.end(); it = parked.find(next)) {
             Parked e = std::move(it->second);
             parked.erase(it);
-            const bool keep = next < limit.load();
-            const off_t at = base + total;
-            if (keep) total += (off_t)e.len;
+            e.keep = next < limit.load();
+            e.at = base + total;
+            if (e.keep) total += (off_t)e.len;
             ++next;
-            cv.notify_all();
-            l.unlock();
-            if (keep && e.len) {
-                if (direct) {
-                    size_t done_ = 0;
-                    while (done_ < e.len) {
-                        const ssize_t n = pwrite(1, e.buf.data() + done_, e.len - done_, at + (off_t)done_);
-                        if (n <= 0) { failed = true; break; }
-                        done_ += (size_t)n;
-                    }
-                } else if (fwrite(e.buf.data(), 1, e.len, stdout) != e.len) failed = true;
-            }
-            l.lock();
-            if (spare.size() < 32) spare.push_back(std::move(e.buf));
+            ++in_flight;
+            tasks.push_back(std::move(e));
         }
-        draining = false;
+        assigning = false;
+        cv_task.notify_all();
+        cv.notify_all();
     }
     void finish() {
+        {
+            std::unique_lock<std::mutex> l(m);
+            cv.wait(l, [&] { return in_flight == 0; });
+            closing = true;
+        }
+        cv_task.notify_all();
+        for (auto& t : writers) t.join();
         if (direct && lseek(1, base + total, SEEK_SET) < 0) failed = true; // later output continues behind the blocks
     }
 };

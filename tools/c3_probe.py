@@ -10,8 +10,9 @@ data = os.path.join(ROOT, "tests/golden/data")
 files = ["all_pave_ref.fa.gz", "zika.refs.fa.gz", "dengue.fa.gz", "new_refs.fa.gz", "hpv_16.fa.gz", "zika.fa.gz", "yellow_fever.fa.gz", "hpv_16_allFasta.fa.gz"]
 panel = api.parse_files([os.path.join(data, f) for f in files])
 pb, po = panel["bases"], panel["offsets"]
+K = int(os.environ.get("K", "16"))   # K=20: the same probe through the hash-space kernel (k_classify_tile)
 ctx = rkmh_amd.Context(0)
-ctx.set_references(pb, po, [16], 1000)
+ctx.set_references(pb, po, [K], 1000)
 print("references", panel["nseq"], "k-mer-space form:", ctx.kmer_form())
 n = 1000000
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)

@@ -43,20 +43,25 @@ if os.environ.get("SWEEP_AB"):
     import statistics
 
     def run_to(env, nfiles, sink):
+        if sink != os.devnull and os.path.exists(sink):
+            os.remove(sink)                        # a fresh output file, opened before the clock starts
+        fo = open(sink, "wb")
         t = time.perf_counter()
-        r = subprocess.run([exe, "stream", "-r", ref] + ["-f", fq] * nfiles + ["-k", "16", "-s", "1000"], stdout=open(sink, "wb"), stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        r = subprocess.run([exe, "stream", "-r", ref] + ["-f", fq] * nfiles + ["-k", "16", "-s", "1000"], stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        dt = time.perf_counter() - t
+        fo.close()
         assert r.returncode == 0, r.stderr.decode()[-500:]
-        return time.perf_counter() - t
-    for slots in ("1", "2"):
+        return dt
+    for slots, ow in (("1", "1"), ("1", "3"), ("2", "3")):
         for w in ("4", "6", "8", "10"):
-            env = {"RKMH_RAW_SLOTS": slots, "RKMH_RAW_WORKERS": w}
+            env = {"RKMH_RAW_SLOTS": slots, "RKMH_RAW_WORKERS": w, "RKMH_OUT_WRITERS": ow}
             row = []
             for sink in (tsv, os.devnull):
                 t1 = statistics.median(run_to(env, 1, sink) for _ in range(3))
                 t4 = statistics.median(run_to(env, 4, sink) for _ in range(3))
                 row.append((t1, t4, 3 * n / (t4 - t1) / 1e6))
-            print("slots %s workers %2s: file 1x %.3f s 4x %.3f s marginal %.1f M reads/s | /dev/null 1x %.3f s 4x %.3f s marginal %.1f M reads/s"
-                  % (slots, w, row[0][0], row[0][1], row[0][2], row[1][0], row[1][1], row[1][2]), flush=True)
+            print("slots %s writers %s workers %2s: file 1x %.3f s 4x %.3f s marginal %.1f M reads/s | /dev/null 1x %.3f s 4x %.3f s marginal %.1f M reads/s"
+                  % (slots, ow, w, row[0][0], row[0][1], row[0][2], row[1][0], row[1][1], row[1][2]), flush=True)
     settings = []
 elif os.environ.get("SWEEP_SMALL"):
     settings = [{}, {}, {"RKMH_OUT_DIRECT": "1"}, {"RKMH_OUT_DIRECT": "0"}, {"RKMH_RAW_WORKERS": "6"}, {"RKMH_RAW_WORKERS": "10"}, {"RKMH_RAW_WORKERS": "12"},
