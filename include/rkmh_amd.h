@@ -314,6 +314,7 @@ typedef struct rk_fastq_result {
     const uint32_t* name_len;
     const uint32_t* seq_off;   /* its sequence = text[seq_off[i] .. + seq_len[i]) */
     const uint32_t* seq_len;
+    const uint32_t* qual_off;  /* its quality string = text[qual_off[i] .. + seq_len[i]) */
 } rk_fastq_result;             /* the arrays live in the slot and are overwritten by its next call */
 #define RK_FASTQ_CR 1          /* a carriage return somewhere in the block */
 #define RK_FASTQ_LINES 2       /* lines do not come in fours / no final newline */
@@ -327,6 +328,9 @@ int rk_fastq_slot_classify(rk_fastq_slot* slot, uint64_t nbytes, rk_fastq_result
  * returns at once, finish waits, classifies and collects -- a host thread with two slots reads its next block in between */
 int rk_fastq_slot_submit(rk_fastq_slot* slot, uint64_t nbytes);
 int rk_fastq_slot_finish(rk_fastq_slot* slot, rk_fastq_result* res);
+/* pass 1 of -M (src/rkmh.cpp:904-910) on a block of raw text: every window's hash counted into `counter` (a table of the slot's
+ * context); *status != 0: the block is not four lines per record and nothing of it was counted */
+int rk_fastq_slot_count(rk_fastq_slot* slot, uint64_t nbytes, rk_counter* counter, int32_t* status, int64_t* nrec);
 void rk_fastq_slot_destroy(rk_fastq_slot* slot);
 /* Where to cut: the offset of the LAST record start in text[1 .. n) under the four-line rule (a line that begins with '@' whose
  * second line below begins with '+'), or -1 when there is none: text[0 .. offset) then holds whole records only. */

@@ -113,6 +113,7 @@ _SIGS = {
     "rk_fastq_slot_destroy": (None, [C.c_void_p]),
     "rk_fastq_slot_submit": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rk_fastq_slot_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rk_fastq_slot_count": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "rk_fastq_cut": (C.c_int64, [C.c_void_p, C.c_uint64]),
     "rk_synth_reads": (C.c_int, [_u8p, _u64p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, _u8p, C.c_int]),
 }
@@ -328,7 +329,8 @@ def device_props(device=0) -> dict:
 
 class FastqResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("nrec", C.c_int64), ("out4", C.POINTER(C.c_int32)), ("name_off", C.POINTER(C.c_uint32)),
-                ("name_len", C.POINTER(C.c_uint32)), ("seq_off", C.POINTER(C.c_uint32)), ("seq_len", C.POINTER(C.c_uint32))]
+                ("name_len", C.POINTER(C.c_uint32)), ("seq_off", C.POINTER(C.c_uint32)), ("seq_len", C.POINTER(C.c_uint32)),
+                ("qual_off", C.POINTER(C.c_uint32))]
 
 
 def fastq_cut(text: bytes) -> int:
@@ -350,6 +352,16 @@ class FastqSlot:
         """Returns (status, rows [n,4] int32, names [n] bytes, seqs [n] bytes); status != 0: the block must be parsed on the host."""
         self.submit(text)
         return self.finish()
+
+    def count(self, text: bytes, counter):
+        """Pass 1 of -M on a block (rk_fastq_slot_count): returns (status, records); status != 0: nothing was counted."""
+        n = len(text)
+        if n > self.max_bytes:
+            raise ValueError("block larger than the slot")
+        C.memmove(self._lib.rk_fastq_slot_text(self._h), text, n)
+        st, nrec = C.c_int32(), C.c_int64()
+        _chk(self._lib.rk_fastq_slot_count(self._h, n, counter._h, C.byref(st), C.byref(nrec)))
+        return st.value, nrec.value
 
     def submit(self, text: bytes):
         """First half (rk_fastq_slot_submit): the upload and the splitting kernels are enqueued; returns at once."""
@@ -373,6 +385,8 @@ class FastqSlot:
         so = np.ctypeslib.as_array(res.seq_off, shape=(m,)); sl = np.ctypeslib.as_array(res.seq_len, shape=(m,))
         names = [text[int(no[i]): int(no[i]) + int(nl[i])] for i in range(m)]
         seqs = [text[int(so[i]): int(so[i]) + int(sl[i])] for i in range(m)]
+        qo = np.ctypeslib.as_array(res.qual_off, shape=(m,))
+        self.last_quals = [text[int(qo[i]): int(qo[i]) + int(sl[i])] for i in range(m)]  # the quality strings of the block just finished
         return 0, rows, names, seqs
 
     def destroy(self):

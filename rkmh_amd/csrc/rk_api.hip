@@ -1888,7 +1888,7 @@ extern "C" int rk_fastq_slot_create(rk_ctx* c, uint64_t max_bytes, rk_fastq_slot
     const uint32_t rec_cap = (uint32_t)(max_bytes / 64 + 64), line_cap = 4 * rec_cap + 16;
     RKCHK(s->h_text.reserve(max_bytes + 64));
     RKCHK(s->h_out4.reserve((size_t)rec_cap * 16));
-    RKCHK(s->h_spans.reserve((size_t)rec_cap * 16));
+    RKCHK(s->h_spans.reserve((size_t)rec_cap * 20));
     RKCHK(s->h_info.reserve(16));
     RKCHK(s->d_text.reserve(max_bytes + 64));
     RKCHK(s->d_bases.reserve(max_bytes + 64));
@@ -1966,10 +1966,12 @@ extern "C" int rk_fastq_slot_finish(rk_fastq_slot* s, rk_fastq_result* res) {
     HIPCHK(hipMemcpyAsync(spans + nrec, s->d.name_len, (size_t)nrec * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(spans + 2 * nrec, s->d.seq_off, (size_t)nrec * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(spans + 3 * nrec, s->d.seq_len, (size_t)nrec * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(spans + 4 * nrec, s->d.qual_off, (size_t)nrec * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(s->ev, st));
     HIPCHK(hipEventSynchronize(s->ev));
     res->out4 = out4;
     res->name_off = spans; res->name_len = spans + nrec; res->seq_off = spans + 2 * nrec; res->seq_len = spans + 3 * nrec;
+    res->qual_off = spans + 4 * nrec;
     // rows the fused kernel handed back (long reads, more windows than the sketch keeps, ...): the general path, from the text
     std::vector<int64_t> idx;
     for (int64_t i = 0; i < nrec; ++i) if (out4[i * 4] == -2) idx.push_back(i);
@@ -1988,6 +1990,48 @@ extern "C" int rk_fastq_slot_finish(rk_fastq_slot* s, rk_fastq_result* res) {
         }
         for (size_t j = 0; j < idx.size(); ++j) memcpy(out4 + idx[j] * 4, rows.data() + j * 4, 16);
     }
+    return RK_OK;
+}
+
+// Pass 1 of -M on a block of raw FASTQ text (rkmh.cpp:904-910): split, check and pack on the device as rk_fastq_slot_classify does,
+// then count every window's hash into `counter`.  *status != 0: the block is not four lines per record and NOTHING was counted.
+extern "C" int rk_fastq_slot_count(rk_fastq_slot* s, uint64_t nbytes, rk_counter* counter, int32_t* status, int64_t* nrec_out) {
+    if (!s || !counter || !status) return fail(RK_ERR_ARG, "bad arguments");
+    if (counter->ctx != s->c) return fail(RK_ERR_ARG, "the counter belongs to another context");
+    *status = 0;
+    if (nrec_out) *nrec_out = 0;
+    RKCHK(rk_fastq_slot_submit(s, nbytes));
+    s->submitted = false;
+    if (nbytes == 0) return RK_OK;
+    rk_ctx* c = s->c;
+    RKCHK(set_dev(c));
+    uint32_t* info = s->h_info.as<uint32_t>();
+    HIPCHK(hipEventSynchronize(s->ev));
+    if (info[0] != 0) { *status = (int32_t)info[0]; return RK_OK; }
+    const int64_t nrec = (int64_t)info[1];
+    if (nrec_out) *nrec_out = nrec;
+    if (nrec == 0) return RK_OK;
+    if (info[2] > (uint32_t)FUSED_MAXLEN) {
+        // a read longer than the fused kernel's limit: the whole block through the tile hasher, from the text (as rk_count_batch does)
+        uint32_t* spans = s->h_spans.as<uint32_t>();
+        HIPCHK(hipMemcpyAsync(spans, s->d.seq_off, (size_t)nrec * 4, hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipMemcpyAsync(spans + nrec, s->d.seq_len, (size_t)nrec * 4, hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipEventRecord(s->ev, s->st));
+        HIPCHK(hipEventSynchronize(s->ev));
+        const uint8_t* text = s->h_text.as<uint8_t>();
+        std::vector<uint64_t> offs((size_t)nrec + 1, 0);
+        for (int64_t i = 0; i < nrec; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + spans[nrec + i];
+        std::vector<uint8_t> sub((size_t)offs.back() + 16);
+        for (int64_t i = 0; i < nrec; ++i) memcpy(sub.data() + offs[(size_t)i], text + spans[i], spans[nrec + i]);
+        std::lock_guard<std::mutex> lock(c->general_mu);
+        RKCHK(counter_settle(counter));
+        GeneralCfg cfg; cfg.ks = c->ks; cfg.inc_counter = counter;
+        GeneralOut none;
+        return general_run(c, sub.data(), nullptr, offs.data(), nrec, cfg, none);
+    }
+    RKCHK(fused_device(c, s->d.bases, s->d.out_off, nrec, nullptr, info[2], 1, counter, s->st));
+    HIPCHK(hipEventRecord(s->ev, s->st));
+    HIPCHK(hipEventSynchronize(s->ev));
     return RK_OK;
 }
 

@@ -276,35 +276,45 @@ static inline int64_t share_lo(int64_t n, size_t d, size_t nd) { return n * (int
 // Two passes over ALL reads on several devices (rkmh.cpp:904-948): device d counts and classifies reads [n d / D, n (d+1) / D);
 // the depth tables are summed onto device 0 and copied back between the passes, so every device masks with the counts of the WHOLE
 // read set, exactly as the reference's threads do with their shared counter.  cnt[0] holds the full table on return.
-static void two_pass_on_group(DeviceGroup& g, const rk_seqset& reads, uint64_t slots, int min_occ, std::vector<rk_counter*>& cnt,
-                              bool pass1, int32_t* out4) {
+static void group_run(DeviceGroup& g, const std::function<int(size_t)>& f) {
     const size_t D = g.size();
     std::vector<std::string> err(D);
-    auto run = [&](const std::function<int(size_t)>& f) {
-        std::vector<std::thread> th;
-        for (size_t d = 0; d < D; ++d) th.emplace_back([&, d] { if (f(d) != RK_OK) err[d] = rk_last_error(); });
-        for (auto& t : th) t.join();
-        for (auto& e : err) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
-    };
-    if (cnt.empty()) {
-        cnt.assign(D, nullptr);
-        run([&](size_t d) { return rk_counter_create(g.ctx[d], slots, &cnt[d]); });
-    }
-    if (pass1) {
-        run([&](size_t d) {
-            const int64_t lo = share_lo(reads.nseq, d, D), hi = share_lo(reads.nseq, d + 1, D);
-            return rk_count_batch(g.ctx[d], reads.bases, reads.offsets + lo, hi - lo, cnt[d]);
-        });
-        // all-reduce inside one process: a binary tree onto device 0 (log2 D rounds, the adds of one round on different devices run
-        // concurrently), then the full table is handed back down the same tree
-        for (size_t step = 1; step < D; step <<= 1)
-            run([&](size_t d) { return (d % (2 * step) == 0 && d + step < D) ? rk_counter_add(cnt[d], cnt[d + step]) : RK_OK; });
-    }
+    std::vector<std::thread> th;
+    for (size_t d = 0; d < D; ++d) th.emplace_back([&, d] { if (f(d) != RK_OK) err[d] = rk_last_error(); });
+    for (auto& t : th) t.join();
+    for (auto& e : err) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
+}
+// all-reduce of the per-device depth tables inside one process: a binary tree onto device 0 (log2 D rounds, the adds of one round
+// on different devices run concurrently) ...
+static void sum_counters_on_group(DeviceGroup& g, std::vector<rk_counter*>& cnt) {
+    const size_t D = g.size();
+    for (size_t step = 1; step < D; step <<= 1)
+        group_run(g, [&](size_t d) { return (d % (2 * step) == 0 && d + step < D) ? rk_counter_add(cnt[d], cnt[d + step]) : RK_OK; });
+}
+// ... and the full table handed back down the same tree
+static void share_counters_on_group(DeviceGroup& g, std::vector<rk_counter*>& cnt) {
+    const size_t D = g.size();
     size_t top = 1;
     while (top < D) top <<= 1;
     for (size_t step = top >> 1; step >= 1; step >>= 1)
-        run([&](size_t d) { return (d % (2 * step) == 0 && d + step < D) ? rk_counter_copy(cnt[d + step], cnt[d]) : RK_OK; });
-    run([&](size_t d) {
+        group_run(g, [&](size_t d) { return (d % (2 * step) == 0 && d + step < D) ? rk_counter_copy(cnt[d + step], cnt[d]) : RK_OK; });
+}
+static void two_pass_on_group(DeviceGroup& g, const rk_seqset& reads, uint64_t slots, int min_occ, std::vector<rk_counter*>& cnt,
+                              bool pass1, int32_t* out4) {
+    const size_t D = g.size();
+    if (cnt.empty()) {
+        cnt.assign(D, nullptr);
+        group_run(g, [&](size_t d) { return rk_counter_create(g.ctx[d], slots, &cnt[d]); });
+    }
+    if (pass1) {
+        group_run(g, [&](size_t d) {
+            const int64_t lo = share_lo(reads.nseq, d, D), hi = share_lo(reads.nseq, d + 1, D);
+            return rk_count_batch(g.ctx[d], reads.bases, reads.offsets + lo, hi - lo, cnt[d]);
+        });
+        sum_counters_on_group(g, cnt);
+    }
+    share_counters_on_group(g, cnt);
+    group_run(g, [&](size_t d) {
         const int64_t lo = share_lo(reads.nseq, d, D), hi = share_lo(reads.nseq, d + 1, D);
         int r = rk_set_depth_filter(g.ctx[d], cnt[d], min_occ);
         if (r == RK_OK) r = rk_classify_batch(g.ctx[d], reads.bases, reads.offsets + lo, hi - lo, out4 + lo * 4);
@@ -536,18 +546,62 @@ static size_t format_raw(const LineParts& lp, const rk_fastq_result& r, const ui
     return (size_t)(w - w0);
 }
 
+// filter's decision: classify_and_count_diff_filter (src/equiv.hpp:324-353): scan from max_shared = prev_best = 0, empty sample name
+struct FilterDecision { int ref; int shared; bool diff_ok; };
+static FilterDecision filter_decide(const int32_t* r, int min_diff) {
+    FilterDecision d;
+    if (r[1] <= 0) { d.ref = -1; d.shared = 0; d.diff_ok = 0 > min_diff; return d; }
+    d.ref = r[0]; d.shared = r[1];
+    const int diff = r[2] - (r[0] == 0 ? 1 : 0); // the stream scan starts at -1, this one at 0
+    d.diff_ok = diff > min_diff;
+    return d;
+}
+
+// filter's output for one block (rkmh.cpp:1292-1300): ">name \n SEQ \n + \n QUAL \n" of every read that passes, name, sequence
+// (upper-cased as parse_fastas does, rkmh.cpp:280) and quality string taken from the raw text
+static size_t format_filter_raw(const rk_fastq_result& r, const uint8_t* text, const Opts& o, std::vector<char>& buf) {
+    size_t need = 64;
+    for (int64_t i = 0; i < r.nrec; ++i) need += (size_t)r.name_len[i] + 2 * (size_t)r.seq_len[i] + 8;
+    if (buf.size() < need) buf.resize(need + need / 8);
+    char* const w0 = buf.data();
+    char* w = w0;
+    for (int64_t i = 0; i < r.nrec; ++i) {
+        const int32_t* q = r.out4 + i * 4;
+        const FilterDecision d = filter_decide(q, o.min_diff);
+        if (q[3] <= 0 || d.shared < o.min_matches || !d.diff_ok) continue;
+        *w++ = '>';
+        memcpy(w, text + r.name_off[i], r.name_len[i]); w += r.name_len[i];
+        *w++ = '\n';
+        const uint8_t* sq = text + r.seq_off[i];
+        const uint32_t n = r.seq_len[i];
+        for (uint32_t j = 0; j < n; ++j) { const signed char ch = (signed char)sq[j]; w[j] = (char)(((int)ch - 91) > 0 ? ch - 32 : ch); }
+        w += n;
+        *w++ = '\n'; *w++ = '+'; *w++ = '\n';
+        memcpy(w, text + r.qual_off[i], n); w += n;
+        *w++ = '\n';
+    }
+    return (size_t)(w - w0);
+}
+
+// what a pass over a file does with each block
+enum RawKind { RAW_STREAM, RAW_FILTER, RAW_COUNT };
+
 // One file through the device front end.  Returns -1 when the whole file was taken, else the byte offset (a record start) from
 // which the kseq-grammar scanner must continue.
-static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& refs, const Opts& o, const char* path, int64_t fsize) {
+// RAW_STREAM prints stream's lines, RAW_FILTER filter's records; RAW_COUNT prints nothing: it is pass 1 of -M (rkmh.cpp:904-910),
+// every worker counts its blocks into its device's table cnts[dev] (summed by the caller), and the first refused block ends the pass.
+static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& refs, const Opts& o, const char* path, int64_t fsize,
+                               RawKind kind = RAW_STREAM, std::vector<rk_counter*>* cnts = nullptr) {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) { fprintf(stderr, "rkmh: cannot open %s\n", path); fail_exit(); }
     LineParts lp;
-    lp.build(refs, o);
+    if (kind == RAW_STREAM) lp.build(refs, o);
+    const bool counting = kind == RAW_COUNT;
     struct Job { int64_t seq = 0, lo = 0, hi = 0; };
     QueueT<Job> jobs;
     jobs.cap = eng.w.size();
     OrderedOut out;
-    out.start();
+    if (!counting) out.start();
     std::atomic<int64_t> fail_seq{INT64_MAX};
     std::mutex fm;
     std::map<int64_t, int64_t> fail_at; // block number -> its first byte
@@ -577,14 +631,15 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                 out.lower_limit(jb.seq); // (before this block is parked: the sink cannot pass it)
                 int64_t curf = fail_seq.load();
                 while (jb.seq < curf && !fail_seq.compare_exchange_weak(curf, jb.seq)) {}
-            } else outlen = format_raw(lp, res, rk_fastq_slot_text(slot), o, buf);
+            } else if (kind == RAW_FILTER) outlen = format_filter_raw(res, rk_fastq_slot_text(slot), o, buf);
+            else outlen = format_raw(lp, res, rk_fastq_slot_text(slot), o, buf);
             t_dv += c - b; t_fm += now_s() - c; ++nblk; nrec_ += res.status == 0 ? res.nrec : 0;
             out.put(jb.seq, std::move(buf), outlen, window);
         };
         // block b is on its way to the device and through the index kernels (submit) while block b + 1 is read into the other slot
         for (;;) {
             const bool got = jobs.pop(&cur);
-            if (got && cur.seq > fail_seq.load()) { out.put(cur.seq, std::vector<char>(), 0, window); continue; } // the scanner will redo this range
+            if (got && cur.seq > fail_seq.load()) { if (!counting) out.put(cur.seq, std::vector<char>(), 0, window); continue; } // the scanner will redo this range
             if (got) {
                 const double a = now_s();
                 uint8_t* text = rk_fastq_slot_text(eng.w[wi].slot[k]);
@@ -596,6 +651,19 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                 }
                 uint64_t nbytes = (uint64_t)(cur.hi - cur.lo);
                 if (cur.hi == fsize && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n'; // a last line without its newline (the slot holds 64 spare bytes)
+                if (counting) {
+                    t_rd += now_s() - a;
+                    const double b = now_s();
+                    int32_t status = 0; int64_t nrec = 0;
+                    if (rk_fastq_slot_count(eng.w[wi].slot[k], nbytes, (*cnts)[eng.w[wi].dev], &status, &nrec) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+                    if (status != 0) {
+                        { std::lock_guard<std::mutex> l(fm); fail_at[cur.seq] = cur.lo; }
+                        int64_t curf = fail_seq.load();
+                        while (cur.seq < curf && !fail_seq.compare_exchange_weak(curf, cur.seq)) {}
+                    }
+                    t_dv += now_s() - b; ++nblk; nrec_ += nrec;
+                    continue;
+                }
                 if (rk_fastq_slot_submit(eng.w[wi].slot[k], nbytes) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
                 t_rd += now_s() - a;
             }
@@ -639,7 +707,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                 if (hi < 0) { // hand the file over from here
                     std::lock_guard<std::mutex> l(fm);
                     fail_at[seq] = pos;
-                    out.lower_limit(seq);
+                    if (!counting) out.lower_limit(seq);
                     int64_t cur = fail_seq.load();
                     while (seq < cur && !fail_seq.compare_exchange_weak(cur, seq)) {}
                     break;
@@ -652,7 +720,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
         jobs.finish();
     }
     for (auto& t : workers) t.join();
-    out.finish();
+    if (!counting) out.finish();
     close(fd);
     if (out.failed) { fprintf(stderr, "rkmh: write error on standard output\n"); fail_exit(); }
     const int64_t fs = fail_seq.load();
@@ -660,6 +728,32 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     return fail_at[fs];
 }
 
+
+// -M with the device front end (rkmh.cpp:904-948 without holding the reads in RAM): pass 1 counts every file's blocks, the depth
+// tables are summed over the devices and become every context's mask, pass 2 reads the files again and prints.  false: some block
+// is not four lines per record -- nothing was printed, the tables are clear again and the caller takes the parse-everything path.
+static bool two_pass_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& refs, const Opts& o, const std::vector<int64_t>& sizes,
+                         std::vector<rk_counter*>& cnts, RawKind kind, double& t0) {
+    for (size_t i = 0; i < o.reads.size(); ++i)
+        if (stream_file_raw(eng, g, refs, o, o.reads[i], sizes[i], RAW_COUNT, &cnts) >= 0) {
+            group_run(g, [&](size_t d) { return rk_counter_clear(cnts[d]); });
+            if (g_timing) fprintf(stderr, "[rkmh timing] %s: not four lines per record: the host scanner reads the run\n", o.reads[i]);
+            return false;
+        }
+    tick("pass 1 (device front end + count)", t0);
+    sum_counters_on_group(g, cnts);
+    share_counters_on_group(g, cnts);
+    group_run(g, [&](size_t d) { return rk_set_depth_filter(g.ctx[d], cnts[d], o.min_occ); });
+    tick("depth tables summed, mask built", t0);
+    for (size_t i = 0; i < o.reads.size(); ++i)
+        if (stream_file_raw(eng, g, refs, o, o.reads[i], sizes[i], kind) >= 0) {
+            fprintf(stderr, "rkmh: %s changed between the two passes\n", o.reads[i]);
+            fail_exit();
+        }
+    fflush(stdout);
+    tick("pass 2 (device front end + classify)", t0);
+    return true;
+}
 
 // the kseq-grammar scanner as a producer thread: batches of the given files (each from a byte offset, 0 = its start), numbered
 static std::thread start_scanner(QueueT<Numbered>& q, std::vector<std::pair<const char*, uint64_t>> files) {
@@ -794,9 +888,11 @@ static int main_stream(int argc, char** argv) {
     // Which front end reads the reads: regular uncompressed FASTQ files go through the device (stream_file_raw); everything else --
     // gzip, STDIN, FASTA, -M (which needs all reads twice) -- through the kseq-grammar scanner.  RKMH_RAW=0 forces the scanner.
     std::vector<int64_t> raw_size(o.reads.size(), -1);
-    bool any_raw = false;
-    if (!o.read_depth && !(getenv("RKMH_RAW") && atoi(getenv("RKMH_RAW")) == 0))
-        for (size_t i = 0; i < o.reads.size(); ++i) { if (raw_eligible(o.reads[i], &raw_size[i])) any_raw = true; else raw_size[i] = -1; }
+    bool any_raw = false, all_raw = !o.reads.empty();
+    if (!(getenv("RKMH_RAW") && atoi(getenv("RKMH_RAW")) == 0))
+        for (size_t i = 0; i < o.reads.size(); ++i) { if (raw_eligible(o.reads[i], &raw_size[i])) any_raw = true; else { raw_size[i] = -1; all_raw = false; } }
+    else all_raw = false;
+    if (o.read_depth) any_raw = false; // -M reads every file twice: device front end only when ALL files qualify (two_pass_raw)
     // The scanner starts NOW when it has all the files (streaming path): while the GPU contexts come up and the references are
     // sketched -- a few tenths of a second -- it is already filling its first batches.
     QueueT<Numbered> q;
@@ -834,13 +930,30 @@ static int main_stream(int argc, char** argv) {
     tick("references", t0);
     std::string buf;
     std::vector<int32_t> out4;
+    bool depth_done = false;
+    std::vector<rk_counter*> cnts;
     if (o.read_depth) {
+        cnts.assign(group.size(), nullptr);
+        CK(rk_counter_create(ctx, 200000000ull, &cnts[0])); // rkmh.cpp:739
+        for (size_t d = 1; d < group.size(); ++d) CK(rk_counter_create(group.ctx[d], 200000000ull, &cnts[d]));
+        tick("depth tables", t0);
+    }
+    if (o.read_depth && all_raw && !read_map) {
+        // regular FASTQ files: both passes through the device front end, the reads are never held in host memory
+        RawEngine eng;
+        if (eng.create(group)) {
+            depth_done = two_pass_raw(eng, group, refs, o, raw_size, cnts, RAW_STREAM, t0);
+            if (g_timing) fprintf(stderr, "[rkmh timing] device front end: %lld blocks, %lld records; read %.3f s, device %.3f s, format %.3f s (summed over %zu workers, both passes)\n",
+                                  (long long)eng.blocks, (long long)eng.records, eng.t_read, eng.t_dev, eng.t_fmt, eng.w.size());
+            eng.destroy();
+        }
+    }
+    if (o.read_depth && depth_done) {
+        for (rk_counter* k : cnts) rk_counter_destroy(k);
+    } else if (o.read_depth) {
         // two passes over ALL reads (rkmh.cpp:904-948): the reference holds them in RAM, so do we
         rk_seqset reads;
         CK(rk_parse_files(o.reads.data(), (int)o.reads.size(), &reads));
-        std::vector<rk_counter*> cnts(group.size(), nullptr);
-        CK(rk_counter_create(ctx, 200000000ull, &cnts[0])); // rkmh.cpp:739
-        for (size_t d = 1; d < group.size(); ++d) CK(rk_counter_create(group.ctx[d], 200000000ull, &cnts[d]));
         rk_counter* cnt = cnts[0];
         // --depth-map-cache FILE: reuse a saved depth map (pass 1 is skipped) or save this run's for the next one.  The file
         // records what it was counted from (k list, hashing policy, fingerprint of the read set); a file that does not match
@@ -902,17 +1015,7 @@ static int main_stream(int argc, char** argv) {
     done_exit();
 }
 
-// filter: main_filter, src/rkmh.cpp:996-1424.  Same sketches as stream; the decision is
-// classify_and_count_diff_filter (src/equiv.hpp:324-353): scan from max_shared = prev_best = 0, empty sample name.
-struct FilterDecision { int ref; int shared; bool diff_ok; };
-static FilterDecision filter_decide(const int32_t* r, int min_diff) {
-    FilterDecision d;
-    if (r[1] <= 0) { d.ref = -1; d.shared = 0; d.diff_ok = 0 > min_diff; return d; }
-    d.ref = r[0]; d.shared = r[1];
-    const int diff = r[2] - (r[0] == 0 ? 1 : 0); // the stream scan starts at -1, this one at 0
-    d.diff_ok = diff > min_diff;
-    return d;
-}
+// filter: main_filter, src/rkmh.cpp:996-1424.  Same sketches as stream; the decision is filter_decide (above).
 static void help_filter() {
     fprintf(stderr,
             "rkmh filter -r <refs.fa> -f <reads.fq> [-k <k>]... [-s <sketch>] [-M n] [-I n] [-N n] [-D n] [-i]\n"
@@ -986,29 +1089,10 @@ static int main_filter(int argc, char** argv) {
     rk_counter* cnt = cnts[0];
     std::string buf;
     std::vector<int32_t> out4;
-    if (!o.reads.empty()) {
-        rk_seqset reads;
-        CK(rk_parse_files(o.reads.data(), (int)o.reads.size(), &reads));
-        tick("parse reads", t0);
-        out4.resize((size_t)reads.nseq * 4);
-        if (o.read_depth) {
-            // count (rkmh.cpp:321-338), then keep get(h) >= min_kmer_occ (:1260); the reads are spread over the devices, the
-            // depth tables summed in between
-            two_pass_on_group(group, reads, 10000000ull, o.min_occ, cnts, true, out4.data());
-        } else {
-            std::vector<std::string> err(group.size());
-            std::vector<std::thread> th;
-            for (size_t d = 0; d < group.size(); ++d)
-                th.emplace_back([&, d] {
-                    const int64_t lo = share_lo(reads.nseq, d, group.size()), hi = share_lo(reads.nseq, d + 1, group.size());
-                    if (rk_classify_batch(group.ctx[d], reads.bases, reads.offsets + lo, hi - lo, out4.data() + lo * 4) != RK_OK) err[d] = rk_last_error();
-                });
-            for (auto& t : th) t.join();
-            for (auto& e : err) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
-        }
-        tick("count + classify", t0);
+    // filter's records of a parsed batch (rkmh.cpp:1292-1300)
+    auto emit_passing = [&](const rk_seqset& reads, const int32_t* rows) {
         for (int64_t i = 0; i < reads.nseq; ++i) {
-            const int32_t* r = &out4[(size_t)i * 4];
+            const int32_t* r = rows + (size_t)i * 4;
             const FilterDecision d = filter_decide(r, o.min_diff);
             const bool depth_filter = r[3] <= 0, match_filter = d.shared < o.min_matches; // rkmh.cpp:1292-1293
             if (depth_filter || match_filter || !d.diff_ok) continue;
@@ -1026,6 +1110,63 @@ static int main_filter(int argc, char** argv) {
         }
         fwrite(buf.data(), 1, buf.size(), stdout);
         buf.clear();
+    };
+    // Regular uncompressed FASTQ files go through the device front end (stream_file_raw / two_pass_raw): the host neither parses
+    // the reads nor holds them.  RKMH_RAW=0, gzip, FASTA and text that is not four lines per record take the parse-everything path.
+    std::vector<int64_t> raw_size(o.reads.size(), -1);
+    bool all_raw = !o.reads.empty() && !(getenv("RKMH_RAW") && atoi(getenv("RKMH_RAW")) == 0);
+    for (size_t i = 0; all_raw && i < o.reads.size(); ++i) all_raw = raw_eligible(o.reads[i], &raw_size[i]);
+    bool files_done = o.reads.empty();
+    if (all_raw) {
+        RawEngine eng;
+        if (eng.create(group)) {
+            if (o.read_depth) files_done = two_pass_raw(eng, group, refs, o, raw_size, cnts, RAW_FILTER, t0);
+            else {
+                for (size_t i = 0; i < o.reads.size(); ++i) {
+                    const int64_t resume = stream_file_raw(eng, group, refs, o, o.reads[i], raw_size[i], RAW_FILTER);
+                    if (resume < 0) continue;
+                    fflush(stdout);
+                    // the rest of this file through the kseq-grammar scanner, batch by batch
+                    if (g_timing) fprintf(stderr, "[rkmh timing] %s: not four lines per record at byte %lld: the scanner reads on from there\n", o.reads[i], (long long)resume);
+                    rk_reader* rd = nullptr;
+                    CK(rk_reader_open_at(o.reads[i], (uint64_t)resume, &rd));
+                    for (;;) {
+                        rk_seqset part;
+                        CK(rk_reader_next(rd, 1 << 20, 1ull << 28, &part));
+                        if (part.nseq == 0) { rk_seqset_free(&part); break; }
+                        out4.resize((size_t)part.nseq * 4);
+                        CK(rk_classify_batch(ctx, part.bases, part.offsets, part.nseq, out4.data()));
+                        emit_passing(part, out4.data());
+                        rk_seqset_free(&part);
+                    }
+                    rk_reader_close(rd);
+                }
+                fflush(stdout);
+                files_done = true;
+                tick("device front end + classify + emit", t0);
+            }
+            if (g_timing) fprintf(stderr, "[rkmh timing] device front end: %lld blocks, %lld records; read %.3f s, device %.3f s, format %.3f s (summed over %zu workers)\n",
+                                  (long long)eng.blocks, (long long)eng.records, eng.t_read, eng.t_dev, eng.t_fmt, eng.w.size());
+            eng.destroy();
+        }
+    }
+    if (!files_done) {
+        rk_seqset reads;
+        CK(rk_parse_files(o.reads.data(), (int)o.reads.size(), &reads));
+        tick("parse reads", t0);
+        out4.resize((size_t)reads.nseq * 4);
+        if (o.read_depth) {
+            // count (rkmh.cpp:321-338), then keep get(h) >= min_kmer_occ (:1260); the reads are spread over the devices, the
+            // depth tables summed in between
+            two_pass_on_group(group, reads, 10000000ull, o.min_occ, cnts, true, out4.data());
+        } else {
+            group_run(group, [&](size_t d) {
+                const int64_t lo = share_lo(reads.nseq, d, group.size()), hi = share_lo(reads.nseq, d + 1, group.size());
+                return rk_classify_batch(group.ctx[d], reads.bases, reads.offsets + lo, hi - lo, out4.data() + lo * 4);
+            });
+        }
+        tick("count + classify", t0);
+        emit_passing(reads, out4.data());
         tick("emit", t0);
         rk_seqset_free(&reads);
     }

@@ -45,8 +45,8 @@ def _check_against_kseq(orc, slot, text, sk, ln, must_be_regular=None):
     if st != 0:
         return st
     assert len(names) == len(want), (len(names), len(want))
-    for i, (nm, sq, _q) in enumerate(want):
-        assert names[i] == nm and seqs[i] == sq, i
+    for i, (nm, sq, q) in enumerate(want):
+        assert names[i] == nm and seqs[i] == sq and slot.last_quals[i] == q, i
     if want:
         qb, qo = orc.pack([orc.to_upper(w[1]) for w in want])
         exp = orc.classify_stream(qb, qo, [16], 1000, sk, ln, threads=4)
@@ -259,6 +259,97 @@ def test_cli_device_front_end_equals_the_scanner(root, data_dir, tmp_path, orc):
     # the oracle's kseq grammar agrees with both on the mixed file (names in order)
     names = [x[0] for x in orc.kseq_parse_bytes(half + odd + crlf + tail)]
     assert [l.split(b"\t")[1] for l in want_m.splitlines()] == names
+
+
+def test_slot_count_equals_count_batch(setup, orc):
+    """Pass 1 of -M on raw text (rk_fastq_slot_count) fills the depth table exactly as rk_count_batch does from the parsed reads
+    -- short reads, reads longer than the fused kernel's limit (the tile hasher takes the block), several blocks into one table --
+    and an irregular block leaves the table untouched."""
+    import torch
+    from rkmh_amd import api, synth
+    ctx, slot, rb, ro, sk, ln = setup
+    slots = 1 << 20
+    rng = np.random.default_rng(11)
+    qb, qo = synth.generate_reads_fast(rb, ro, 5, 6000, read_len=150, threads=4)
+    nr = len(qo) - 1
+    reads = [bytes(qb[int(qo[i]):int(qo[i + 1])]) for i in range(nr)]
+    for i in range(0, nr, 13):
+        reads[i] = reads[i][: int(rng.integers(1, 150))]
+    long_reads = [bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=int(n), p=[.24, .24, .24, .24, .04])) for n in (5000, 150, 70000, 16)]
+    for name, blocks in (("short", [reads[:3000], reads[3000:]]), ("with long reads", [reads[:500] + long_reads, reads[500:900]])):
+        ta_, tb_ = (torch.zeros(slots, dtype=torch.int32, device="cuda") for _ in range(2))
+        torch.cuda.synchronize()
+        a, b = api.Counter(ctx, slots, device_ptr=ta_.data_ptr()), api.Counter(ctx, slots, device_ptr=tb_.data_ptr())
+        snap = lambda k, t: (k.get(0), t.cpu().numpy())[1]     # (rk_counter_get settles the passes into the table first)
+        every = []
+        for blk in blocks:
+            st, nrec = slot.count(_fastq(blk), a)
+            assert (st, nrec) == (0, len(blk)), name
+            every += blk
+        pb, po = orc.pack([orc.to_upper(r) for r in every])
+        ctx.count_batch(pb, po, b)
+        ta, tb = snap(a, ta_), snap(b, tb_)
+        assert ta.sum() > 0 and (ta == tb).all(), name
+        # an irregular block: reported, nothing counted
+        st, nrec = slot.count(_fastq(reads[:50]).replace(b"\n", b"\r\n"), a)
+        assert st != 0 and (snap(a, ta_) == ta).all()
+
+
+def test_cli_minus_M_and_filter_through_the_device_front_end(root, data_dir, tmp_path):
+    """bin/rkmh stream -M and bin/rkmh filter (with and without -M) on uncompressed FASTQ files: both passes through the device front
+    end print the same bytes as the parse-everything path (RKMH_RAW=0) -- many small blocks, two files, two contexts; a file that is
+    not four lines per record makes -M fall back as a whole (pass 1 cleared) and plain filter hand over at the block."""
+    from rkmh_amd import api, synth
+    refs = api.parse_files([os.path.join(data_dir, "all_pave_ref.fa.gz")])
+    rb, ro = refs["bases"], refs["offsets"]
+    qb, qo = synth.generate_reads_fast(rb, ro, 1, 20000, read_len=150, threads=4)
+    n = len(qo) - 1
+    reads = [bytes(qb[int(qo[i]):int(qo[i + 1])]) for i in range(n)]
+    rng = np.random.default_rng(5)
+    for i in range(0, n, 19):
+        reads[i] = reads[i][: int(rng.integers(16, 150))]
+    for i in range(0, n, 23):
+        reads[i] = reads[i].lower()           # filter prints them upper-cased (rkmh.cpp:280)
+    quals = [bytes(rng.integers(33, 74, size=len(r)).astype(np.uint8)) for r in reads]
+    text = _fastq(reads, names=[b"read%07d extra words" % i for i in range(n)], quals=quals)
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(text)
+    fq2 = tmp_path / "second.fq"
+    fq2.write_bytes(_fastq(reads[:5000], names=[b"again%d" % i for i in range(5000)], quals=quals[:5000])[:-1])
+    ref = os.path.join(data_dir, "all_pave_ref.fa.gz")
+    opts = ["-r", ref, "-k", "16", "-s", "1000", "-f", str(fq), "-f", str(fq2)]
+    exe = os.path.join(root, "bin", "rkmh")
+    cases = (("stream", ["-M", "2"]), ("stream", ["-M", "3", "-N", "4"]), ("filter", ["-N", "6"]), ("filter", ["-M", "2", "-N", "6"]),
+             ("filter", ["-M", "2", "-N", "2", "-D", "1"]))
+    for cmd, extra in cases:
+        want = _cli(root, [cmd] + opts + extra, env={"RKMH_RAW": "0"})
+        assert len(want) > 1000, (cmd, extra)
+        for env, more in (({}, []), ({"RKMH_RAW_BLOCK_KB": "96", "RKMH_RAW_WORKERS": "5"}, []), ({"RKMH_RAW_BLOCK_KB": "200"}, ["--devices", "0,0"])):
+            r = subprocess.run([exe, cmd] + opts + extra + more, capture_output=True, env=dict(os.environ, RKMH_TIMING="1", **env))
+            assert r.returncode == 0, r.stderr.decode()[-1500:]
+            assert r.stdout == want, (cmd, extra, env)
+            assert b"device front end: " in r.stderr, r.stderr[-600:]
+            if "-M" in extra:
+                assert b" %d records" % (2 * (n + 5000)) in r.stderr, r.stderr[-600:]   # both passes on the device
+    # filter's records really are >name / SEQ / + / QUAL of reads in the file
+    got = _cli(root, ["filter"] + opts + ["-N", "6"]).split(b"\n")
+    assert got[0].startswith(b">read") and got[2] == b"+" and got[1] == got[1].upper() and len(got[3]) == len(got[1])
+    # irregular text half way through the first file
+    odd = b"".join(b"@m%d\n" % i + r[:70] + b"\n" + r[70:] + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(reads[:300]) if len(r) > 80)
+    mixed = tmp_path / "mixed.fq"
+    mixed.write_bytes(text[: text.index(b"@read0012000")] + odd + _fastq(reads[100:2000]))
+    optm = ["-r", ref, "-k", "16", "-s", "1000", "-f", str(mixed), "-f", str(fq2)]
+    for cmd, extra, note in (("stream", ["-M", "2"], b"the host scanner reads the run"), ("filter", ["-M", "2", "-N", "6"], b"the host scanner reads the run"),
+                             ("filter", ["-N", "6"], b"the scanner reads on from there")):
+        want = _cli(root, [cmd] + optm + extra, env={"RKMH_RAW": "0"})
+        r = subprocess.run([exe, cmd] + optm + extra, capture_output=True, env=dict(os.environ, RKMH_TIMING="1", RKMH_RAW_BLOCK_KB="128"))
+        assert r.returncode == 0 and r.stdout == want, (cmd, extra)
+        assert note in r.stderr, r.stderr[-800:]
+    # filter -i: the depth table of the file pass serves the STDIN pass, whichever front end filled it
+    stdin = _fastq(reads[:200])
+    a = subprocess.run([exe, "filter"] + opts + ["-M", "2", "-N", "6", "-i"], input=stdin, capture_output=True, env=dict(os.environ, RKMH_RAW="0"))
+    b = subprocess.run([exe, "filter"] + opts + ["-M", "2", "-N", "6", "-i"], input=stdin, capture_output=True)
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and b"Sample: " in b.stdout
 
 
 def test_ranks_read_their_own_byte_range(root, data_dir, tmp_path):

@@ -35,11 +35,24 @@ with open(fq, "wb") as f:
             if len(chunk) == 100000: f.write(b"".join(chunk)); chunk = []
         f.write(b"".join(chunk))
 print("inputs: genome %d Mb (%.0f MB fasta), %d reads (%.0f MB fastq) generated in %.0f s" % (gmb, os.path.getsize(fa) / 1e6, n, os.path.getsize(fq) / 1e6, time.time() - t), flush=True)
+import hashlib
 for args in (["-k", "20", "-s", "2000"], ["-k", "20", "-s", "2000", "-M", "2"]):
-    t = time.time()
-    r = subprocess.run([os.path.join(ROOT, "bin/rkmh"), "filter", "-r", fa, "-f", fq] + args, stdout=open("/tmp/filter.out", "wb"), stderr=subprocess.PIPE, env=dict(os.environ, RKMH_TIMING="1"))
-    print(r.stderr.decode()[-700:])
-    dt = time.time() - t
-    kept = sum(1 for l in open("/tmp/filter.out", "rb") if l.startswith(b">"))
-    print("rkmh filter %s: rc %d, %.2f s wall = %.2f M reads/s end to end; %d reads pass" % (" ".join(args), r.returncode, dt, n / dt / 1e6, kept), flush=True)
-    if r.returncode: print(r.stderr.decode()[-500:])
+    digests = []
+    for label, env in (("host parser (RKMH_RAW=0)", {"RKMH_RAW": "0"}), ("device front end", {})):
+        out = "/tmp/filter_%d.out" % len(digests)
+        if os.path.exists(out): os.remove(out)          # (deleting the previous output is not part of the run)
+        fo = open(out, "wb")
+        t = time.time()
+        r = subprocess.run([os.path.join(ROOT, "bin/rkmh"), "filter", "-r", fa, "-f", fq] + args, stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, RKMH_TIMING="1", **env))
+        dt = time.time() - t
+        fo.close()
+        print(r.stderr.decode()[-1100:])
+        h = hashlib.sha256()
+        kept = 0
+        with open(out, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk); kept += blk.count(b">")
+        digests.append(h.hexdigest())
+        print("rkmh filter %s [%s]: rc %d, %.2f s wall = %.2f M reads/s end to end; %d reads pass" % (" ".join(args), label, r.returncode, dt, n / dt / 1e6, kept), flush=True)
+        if r.returncode: print(r.stderr.decode()[-500:])
+    print("outputs identical: %s" % (digests[0] == digests[1]), flush=True)
