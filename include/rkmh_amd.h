@@ -331,6 +331,29 @@ int rk_fastq_slot_finish(rk_fastq_slot* slot, rk_fastq_result* res);
 /* pass 1 of -M (src/rkmh.cpp:904-910) on a block of raw text: every window's hash counted into `counter` (a table of the slot's
  * context); *status != 0: the block is not four lines per record and nothing of it was counted */
 int rk_fastq_slot_count(rk_fastq_slot* slot, uint64_t nbytes, rk_counter* counter, int32_t* status, int64_t* nrec);
+
+/* ---- references from raw FASTA text (replaces parse_fastas over the -r files, src/rkmh.cpp:238-263 + :816-826, for regular text).
+ * The text of the files, concatenated (a '\n' after each file), is uploaded block by block through a slot's page-locked buffer;
+ * rk_fasta_load_finish strips header lines and line ends ON THE DEVICE and returns the record table; rk_set_references_fasta
+ * sketches the packed bases where they lie.  status != 0 (RK_FASTA_* bits): the text is not plain line-structured FASTA (carriage
+ * returns, '>', '+' or '@' inside sequence lines, bases before the first header, bytes outside 33..126) -- parse it on the host. */
+typedef struct rk_fasta_load rk_fasta_load;
+typedef struct rk_fasta_index {
+    int32_t status;
+    int64_t nseq;
+    const uint64_t* offsets;       /* [nseq + 1] sequence i = packed bases [offsets[i], offsets[i+1]) (on the device) */
+    const char* names;             /* NUL-terminated names (header line up to the first whitespace), back to back */
+    const uint64_t* name_offsets;  /* [nseq + 1] */
+} rk_fasta_index;                  /* the arrays belong to the rk_fasta_load */
+#define RK_FASTA_BAD_CHAR 1
+#define RK_FASTA_BAD_NAME 2
+#define RK_FASTA_BAD_LEAD 4
+#define RK_FASTA_EMPTY 8
+int rk_fasta_load_create(rk_ctx* ctx, uint64_t text_bytes, rk_fasta_load** out);
+int rk_fasta_load_put(rk_fasta_load* load, rk_fastq_slot* via, uint64_t text_offset, uint64_t nbytes);
+int rk_fasta_load_finish(rk_fasta_load* load, uint64_t total_bytes, rk_fasta_index* out);
+int rk_set_references_fasta(rk_ctx* ctx, rk_fasta_load* load, const int* ks, int nks, int sketch_size, int max_samples, uint64_t counter_slots);
+void rk_fasta_load_destroy(rk_fasta_load* load);
 void rk_fastq_slot_destroy(rk_fastq_slot* slot);
 /* Where to cut: the offset of the LAST record start in text[1 .. n) under the four-line rule (a line that begins with '@' whose
  * second line below begins with '+'), or -1 when there is none: text[0 .. offset) then holds whole records only. */

@@ -113,6 +113,11 @@ _SIGS = {
     "rk_fastq_slot_destroy": (None, [C.c_void_p]),
     "rk_fastq_slot_submit": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rk_fastq_slot_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rk_fasta_load_create": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "rk_fasta_load_put": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "rk_fasta_load_finish": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "rk_set_references_fasta": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint64]),
+    "rk_fasta_load_destroy": (None, [C.c_void_p]),
     "rk_fastq_slot_count": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "rk_fastq_cut": (C.c_int64, [C.c_void_p, C.c_uint64]),
     "rk_synth_reads": (C.c_int, [_u8p, _u64p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, _u8p, C.c_int]),
@@ -331,6 +336,58 @@ class FastqResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("nrec", C.c_int64), ("out4", C.POINTER(C.c_int32)), ("name_off", C.POINTER(C.c_uint32)),
                 ("name_len", C.POINTER(C.c_uint32)), ("seq_off", C.POINTER(C.c_uint32)), ("seq_len", C.POINTER(C.c_uint32)),
                 ("qual_off", C.POINTER(C.c_uint32))]
+
+
+class FastaIndex(C.Structure):
+    _fields_ = [("status", C.c_int32), ("nseq", C.c_int64), ("offsets", C.POINTER(C.c_uint64)), ("names", C.c_void_p),
+                ("name_offsets", C.POINTER(C.c_uint64))]
+
+
+class FastaLoad:
+    """Reference FASTA text stripped on the device (rk_fasta_load_*): put() the raw text of the -r files block by block through a
+    FastqSlot's page-locked buffer, finish() returns (status, names, offsets) -- status != 0: parse on the host --, then
+    set_references() sketches the packed bases where they lie."""
+
+    def __init__(self, ctx, text_bytes):
+        self._lib = load_library()
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        self.text_bytes = text_bytes
+        _chk(self._lib.rk_fasta_load_create(ctx._h, text_bytes, C.byref(self._h)))
+
+    def put(self, slot, offset, text: bytes):
+        if len(text) > slot.max_bytes:
+            raise ValueError("block larger than the slot")
+        C.memmove(self._lib.rk_fastq_slot_text(slot._h), text, len(text))
+        _chk(self._lib.rk_fasta_load_put(self._h, slot._h, offset, len(text)))
+
+    def finish(self, total_bytes=None):
+        res = FastaIndex()
+        _chk(self._lib.rk_fasta_load_finish(self._h, self.text_bytes if total_bytes is None else total_bytes, C.byref(res)))
+        if res.status != 0:
+            return int(res.status), [], np.zeros(1, np.uint64)
+        n = int(res.nseq)
+        offs = np.ctypeslib.as_array(res.offsets, shape=(n + 1,)).copy()
+        noff = np.ctypeslib.as_array(res.name_offsets, shape=(n + 1,))
+        blob = C.string_at(res.names, int(noff[n]))
+        names = [blob[int(noff[i]): int(noff[i + 1]) - 1] for i in range(n)]
+        return 0, names, offs
+
+    def set_references(self, ks, sketch_size, max_samples=-1, counter_slots=0):
+        arr = (C.c_int * len(ks))(*ks)
+        _chk(self._lib.rk_set_references_fasta(self._ctx._h, self._h, arr, len(ks), sketch_size, max_samples, counter_slots))
+        self._ctx.sketch_size, self._ctx.ks = sketch_size, _ks(ks)
+
+    def destroy(self):
+        if self._h:
+            self._lib.rk_fasta_load_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 def fastq_cut(text: bytes) -> int:

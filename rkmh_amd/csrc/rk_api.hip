@@ -1314,8 +1314,9 @@ extern "C" int rk_set_reference_sketches(rk_ctx* c, const uint64_t* sketches, co
     return build_index(c);
 }
 
-extern "C" int rk_set_references(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int nref,
-                                 const int* ks, int nks, int S, int max_samples, uint64_t counter_slots) {
+// bases on the host, or (d_bases != nullptr) already on this context's device
+static int set_references_impl(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases, const uint64_t* offsets, int nref,
+                               const int* ks, int nks, int S, int max_samples, uint64_t counter_slots) {
     if (!c || !offsets || nref < 1) return fail(RK_ERR_ARG, "bad arguments (need >= 1 reference; rkmh.cpp:848 is undefined for 0)");
     if (S < 1 || S > RK_MAX_SKETCH) return fail(RK_ERR_LIMIT, "sketch size %d outside [1,%d]", S, RK_MAX_SKETCH);
     GeneralCfg cfg;
@@ -1331,14 +1332,18 @@ extern "C" int rk_set_references(rk_ctx* c, const uint8_t* bases, const uint64_t
         GeneralCfg c1 = cfg;
         if (c->ref_count_mode == 1) c1.distinct_counter = cnt; else c1.inc_counter = cnt;
         GeneralOut none;
-        int r = general_run(c, bases, nullptr, offsets, nref, c1, none);
+        int r = general_run(c, bases, d_bases, offsets, nref, c1, none);
         if (r != RK_OK) { rk_counter_destroy(cnt); return r; }
         cfg.filt_counter = cnt; cfg.filter_mode = FILTER_RANGE; cfg.fmin = 0; cfg.fmax = max_samples;
     }
-    int r = general_run(c, bases, nullptr, offsets, nref, cfg, go);
+    int r = general_run(c, bases, d_bases, offsets, nref, cfg, go);
     if (cnt) rk_counter_destroy(cnt);
     if (r != RK_OK) return r;
     return rk_set_reference_sketches(c, sk.data(), lens.data(), nref, ks, nks, S);
+}
+extern "C" int rk_set_references(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int nref,
+                                 const int* ks, int nks, int S, int max_samples, uint64_t counter_slots) {
+    return set_references_impl(c, bases, nullptr, offsets, nref, ks, nks, S, max_samples, counter_slots);
 }
 
 extern "C" int rk_get_reference_sketches(rk_ctx* c, uint64_t* sketches, int32_t* lens) {
@@ -2039,4 +2044,126 @@ extern "C" int rk_fastq_slot_classify(rk_fastq_slot* s, uint64_t nbytes, rk_fast
     if (!res) return fail(RK_ERR_ARG, "bad arguments");
     RKCHK(rk_fastq_slot_submit(s, nbytes));
     return rk_fastq_slot_finish(s, res);
+}
+
+// ---- reference FASTA text stripped on the device (rk_fasta.hip) -------------------------------------------------------------
+struct rk_fasta_load {
+    rk_ctx* c = nullptr;
+    uint64_t cap = 0;
+    DevBuf d_text, d_bases, d_u32, d_u64, d_rec, d_names, d_scan, d_info;
+    PinBuf h_small;
+    FaDev d{};
+    std::vector<uint64_t> offsets, name_offsets;
+    std::vector<char> names;
+    int64_t nseq = 0;
+    bool finished = false;
+};
+
+extern "C" void rk_fasta_load_destroy(rk_fasta_load* L) {
+    if (!L) return;
+    if (L->c) { hipError_t e = hipSetDevice(L->c->device); (void)e; e = hipStreamSynchronize(L->c->st); (void)e; }
+    for (DevBuf* b : {&L->d_text, &L->d_bases, &L->d_u32, &L->d_u64, &L->d_rec, &L->d_names, &L->d_scan, &L->d_info}) b->release();
+    L->h_small.release();
+    delete L;
+}
+
+extern "C" int rk_fasta_load_create(rk_ctx* c, uint64_t text_bytes, rk_fasta_load** out) {
+    if (!c || !out || text_bytes < 1 || text_bytes > ((uint64_t)1 << 37)) return fail(RK_ERR_ARG, "bad arguments (1 byte .. 128 GB of text)");
+    RKCHK(set_dev(c));
+    rk_fasta_load* L = new rk_fasta_load();
+    L->c = c; L->cap = text_bytes;
+    struct Guard { rk_fasta_load* L; ~Guard() { if (L) rk_fasta_load_destroy(L); } } guard{L};
+    const uint64_t chunks = fa_chunks(text_bytes);
+    RKCHK(L->d_text.reserve(chunks * 4096 + 64)); // the kernels read whole 4 KB chunks
+    RKCHK(L->d_u32.reserve(2 * chunks * 4 + 64));
+    RKCHK(L->d_u64.reserve(4 * (chunks + 1) * 8 + 64));
+    RKCHK(L->d_info.reserve(64));
+    RKCHK(L->h_small.reserve(64));
+    guard.L = nullptr;
+    *out = L;
+    return RK_OK;
+}
+
+// the first nbytes of the slot's page-locked text buffer become text[text_offset ..); returns when the buffer may be refilled
+extern "C" int rk_fasta_load_put(rk_fasta_load* L, rk_fastq_slot* via, uint64_t text_offset, uint64_t nbytes) {
+    if (!L || !via || L->finished) return fail(RK_ERR_ARG, "bad arguments");
+    if (via->c->device != L->c->device) return fail(RK_ERR_ARG, "the slot belongs to another device");
+    if (nbytes > via->max_bytes || text_offset > L->cap || nbytes > L->cap - text_offset) return fail(RK_ERR_ARG, "block outside the text");
+    if (nbytes == 0) return RK_OK;
+    RKCHK(set_dev(L->c));
+    HIPCHK(hipMemcpyAsync(L->d_text.as<uint8_t>() + text_offset, via->h_text.p, nbytes, hipMemcpyHostToDevice, via->st));
+    HIPCHK(hipEventRecord(via->ev, via->st));
+    HIPCHK(hipEventSynchronize(via->ev));
+    return RK_OK;
+}
+
+extern "C" int rk_fasta_load_finish(rk_fasta_load* L, uint64_t total_bytes, rk_fasta_index* out) {
+    if (!L || !out || total_bytes < 1 || total_bytes > L->cap || L->finished) return fail(RK_ERR_ARG, "bad arguments");
+    memset(out, 0, sizeof *out);
+    rk_ctx* c = L->c;
+    RKCHK(set_dev(c));
+    hipStream_t st = c->st;
+    const uint64_t chunks = fa_chunks(total_bytes);
+    FaDev& d = L->d;
+    d.chunk_map = L->d_u32.as<uint32_t>(); d.chunk_pre = d.chunk_map + chunks;
+    d.chunk_kept = L->d_u64.as<uint64_t>(); d.chunk_hdrs = d.chunk_kept + (chunks + 1);
+    d.kept_base = d.chunk_hdrs + (chunks + 1); d.hdr_base = d.kept_base + (chunks + 1);
+    d.info = L->d_info.as<uint32_t>();
+    RKCHK(L->d_scan.reserve(fa_scan_temp_bytes(chunks + 1)));
+    d.scan_tmp = L->d_scan.p; d.scan_tmp_bytes = L->d_scan.cap;
+    const uint8_t* raw = L->d_text.as<uint8_t>();
+    HIPCHK(launch_fasta_count(d, raw, total_bytes, st));
+    uint64_t* hs = L->h_small.as<uint64_t>(); // [0] bases, [1] records, [2] status word, [3] name bytes, [4] offset of the first record
+    HIPCHK(hipMemcpyAsync(hs, d.kept_base + chunks, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hs + 1, d.hdr_base + chunks, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hs + 2, d.info, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const uint64_t total = hs[0], nrec = hs[1];
+    uint32_t status = (uint32_t)hs[2];
+    if (nrec == 0) status |= FA_BAD_EMPTY;
+    if (nrec >= 0x7ffffff0ull) return fail(RK_ERR_LIMIT, "more than 2^31 reference sequences");
+    if (status) { out->status = (int32_t)status; return RK_OK; }
+    RKCHK(L->d_bases.reserve(total + 64));
+    RKCHK(L->d_rec.reserve((4 * (nrec + 1)) * 8 + 64));
+    RKCHK(L->d_scan.reserve(fa_scan_temp_bytes(nrec + 1)));
+    d.scan_tmp = L->d_scan.p; d.scan_tmp_bytes = L->d_scan.cap;
+    d.bases = L->d_bases.as<uint8_t>();
+    d.hdr_pos = L->d_rec.as<uint64_t>(); d.rec_off = d.hdr_pos + (nrec + 1);
+    d.name_len1 = d.rec_off + (nrec + 1); d.name_off = d.name_len1 + (nrec + 1);
+    HIPCHK(launch_fasta_compact(d, raw, total_bytes, nrec, st));
+    HIPCHK(hipMemcpyAsync(hs + 2, d.info, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hs + 3, d.name_off + nrec, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hs + 4, d.rec_off, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    status = (uint32_t)hs[2];
+    if (hs[4] != 0) status |= FA_BAD_LEAD; // bases before the first header line
+    if (status) { out->status = (int32_t)status; return RK_OK; }
+    const uint64_t name_bytes = hs[3];
+    RKCHK(L->d_names.reserve(name_bytes + 64));
+    d.names = L->d_names.as<uint8_t>();
+    HIPCHK(launch_fasta_names(d, raw, nrec, st));
+    L->offsets.assign((size_t)nrec + 1, 0);
+    L->name_offsets.assign((size_t)nrec + 1, 0);
+    L->names.assign((size_t)name_bytes + 1, 0);
+    HIPCHK(hipMemcpyAsync(L->offsets.data(), d.rec_off, nrec * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(L->name_offsets.data(), d.name_off, (nrec + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(L->names.data(), d.names, name_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    L->offsets[(size_t)nrec] = total;
+    L->nseq = (int64_t)nrec;
+    L->finished = true;
+    // the text has done its work; the packed bases stay for rk_set_references_fasta
+    L->d_text.release();
+    out->nseq = L->nseq;
+    out->offsets = L->offsets.data();
+    out->names = L->names.data();
+    out->name_offsets = L->name_offsets.data();
+    return RK_OK;
+}
+
+extern "C" int rk_set_references_fasta(rk_ctx* c, rk_fasta_load* L, const int* ks, int nks, int S, int max_samples, uint64_t counter_slots) {
+    if (!c || !L || !L->finished) return fail(RK_ERR_ARG, "rk_set_references_fasta needs a finished, regular rk_fasta_load");
+    if (L->c != c) return fail(RK_ERR_ARG, "the text was loaded through another context");
+    if (L->nseq > 0x7fffffffll) return fail(RK_ERR_LIMIT, "too many reference sequences");
+    return set_references_impl(c, nullptr, L->d_bases.as<uint8_t>(), L->offsets.data(), (int)L->nseq, ks, nks, S, max_samples, counter_slots);
 }

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void k_fq_gather(const uint8_t* __restrict__ r
 
 size_t fq_scan_temp_bytes(uint32_t n) {
     size_t tb = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, nullptr);
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, nullptr);
+    (void)e;
     return tb + 256;
 }
 

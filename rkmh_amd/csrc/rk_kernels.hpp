@@ -109,6 +109,25 @@ struct FqDev {
 };
 size_t fq_scan_temp_bytes(uint32_t n);
 hipError_t launch_fastq_index(const FqDev& d, const uint8_t* raw, uint64_t nbytes, hipStream_t st);
+// ---- reference FASTA text stripped on the device (rk_fasta.hip) ----
+enum { FA_BAD_CHAR = 1, FA_BAD_NAME = 2, FA_BAD_LEAD = 4, FA_BAD_EMPTY = 8 }; // status bits: any of them = parse the files on the host
+struct FaDev {
+    uint32_t *chunk_map, *chunk_pre;    // [chunks] state map of each 4 KB chunk; map of everything before it
+    uint64_t *chunk_kept, *chunk_hdrs;  // [chunks + 1] bases kept / headers begun per chunk
+    uint64_t *kept_base, *hdr_base;     // [chunks + 1] their exclusive sums; [chunks] = the totals
+    uint8_t* bases;                     // packed bases
+    uint64_t *hdr_pos, *rec_off;        // [records] text position of each '>' / offset of the record's first base
+    uint64_t *name_len1, *name_off;     // [records + 1] name length + 1 / its exclusive sum
+    uint8_t* names;                     // NUL-terminated names, back to back
+    uint32_t* info;                     // [4] status bits
+    void* scan_tmp;
+    size_t scan_tmp_bytes;
+};
+size_t fa_scan_temp_bytes(uint64_t n);
+uint64_t fa_chunks(uint64_t nbytes);
+hipError_t launch_fasta_count(const FaDev& d, const uint8_t* raw, uint64_t nbytes, hipStream_t st);
+hipError_t launch_fasta_compact(const FaDev& d, const uint8_t* raw, uint64_t nbytes, uint64_t nrec, hipStream_t st);
+hipError_t launch_fasta_names(const FaDev& d, const uint8_t* raw, uint64_t nrec, hipStream_t st);
 // whole-array ascending sort of u64 keys in place (rk_sort.hip: rocPRIM radix sort); tmp holds sort_u64_temp_bytes(n) bytes
 hipError_t sort_u64_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t launch_sort_u64(uint64_t* keys, uint64_t n, void* tmp, size_t tmp_bytes, hipStream_t st);

@@ -346,14 +346,14 @@ static int granted_cpus_main() {
     return n < 1 ? 1 : n;
 }
 
-// a regular, uncompressed file that begins with '@'
-static bool raw_eligible(const char* path, int64_t* size) {
+// a regular, uncompressed file that begins with '@' (FASTQ reads) / '>' (FASTA references)
+static bool raw_eligible(const char* path, int64_t* size, char first = '@') {
     if (!path || strcmp(path, "-") == 0) return false;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return false;
     struct stat st;
     unsigned char magic[2] = {0, 0};
-    const bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) >= 1 && magic[0] == '@';
+    const bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) >= 1 && magic[0] == (unsigned char)first;
     close(fd);
     if (ok) *size = (int64_t)st.st_size;
     return ok;
@@ -755,6 +755,98 @@ static bool two_pass_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& refs, 
     return true;
 }
 
+// The -r files through the device (rk_fasta_load_*, rkmh_amd/csrc/rk_fasta.hip) instead of parse_fastas (rkmh.cpp:238-263): the
+// workers of the read pipeline pread the raw text into their page-locked buffers and upload it, the GPU strips header lines and
+// line ends, and the references are sketched from the packed bases where they lie -- the host never sees a base.  Worth its set-up
+// for genome-sized references (BASELINE config 4: 3.1 GB of FASTA, where the host parser was the longest stage of the run);
+// RKMH_RAW_REFS=1 forces it for any size, =0 turns it off.  false: not taken (small, compressed, not regular FASTA, no memory):
+// the caller parses on the host.  On success refs carries the names only (all that stream / filter print).
+struct DeviceRefs { std::vector<char> names; std::vector<uint64_t> name_offsets; };
+static bool refs_through_device(RawEngine& eng, DeviceGroup& g, const Opts& o, int max_samples, uint64_t counter_slots, rk_seqset& refs,
+                                DeviceRefs& keep) {
+    const char* env = getenv("RKMH_RAW_REFS");
+    if (env && atoi(env) == 0) return false;
+    const bool forced = env && atoi(env) == 1;
+    std::vector<int64_t> size(o.refs.size(), 0);
+    uint64_t total = 0;
+    for (size_t i = 0; i < o.refs.size(); ++i) {
+        if (!raw_eligible(o.refs[i], &size[i], '>')) return false;
+        total += (uint64_t)size[i] + 1; // a '\n' after every file
+    }
+    if (o.refs.empty() || (!forced && total < ((uint64_t)64 << 20))) return false;
+    if (!eng.create(g)) return false;
+    rk_fasta_load* load = nullptr;
+    if (rk_fasta_load_create(g.ctx[0], total, &load) != RK_OK) {
+        fprintf(stderr, "rkmh: references through the device: %s; parsing on the host\n", rk_last_error());
+        return false;
+    }
+    struct Job { size_t file; int64_t lo, hi; uint64_t at; bool last; };
+    std::vector<Job> jobs;
+    std::vector<int> fds(o.refs.size(), -1);
+    {
+        uint64_t at = 0;
+        const int64_t B = (int64_t)eng.block;
+        for (size_t i = 0; i < o.refs.size(); ++i) {
+            fds[i] = open(o.refs[i], O_RDONLY);
+            if (fds[i] < 0) { fprintf(stderr, "rkmh: cannot open %s\n", o.refs[i]); fail_exit(); }
+            for (int64_t lo = 0; lo < size[i]; lo += B) {
+                const int64_t hi = std::min(size[i], lo + B);
+                jobs.push_back(Job{i, lo, hi, at + (uint64_t)lo, hi == size[i]});
+            }
+            at += (uint64_t)size[i] + 1;
+        }
+    }
+    std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
+    auto work = [&](size_t wi) {
+        if (eng.w[wi].dev != 0) return; // the text goes to the device that sketches
+        if (!eng.w[wi].slot[0] && rk_fastq_slot_create(g.ctx[0], eng.block, &eng.w[wi].slot[0]) != RK_OK) return;
+        rk_fastq_slot* slot = eng.w[wi].slot[0];
+        uint8_t* text = rk_fastq_slot_text(slot);
+        for (size_t j = next.fetch_add(1); j < jobs.size() && !failed.load(); j = next.fetch_add(1)) {
+            const Job& jb = jobs[j];
+            int64_t have = 0;
+            while (have < jb.hi - jb.lo) {
+                const ssize_t n = pread(fds[jb.file], text + have, (size_t)(jb.hi - jb.lo - have), (off_t)(jb.lo + have));
+                if (n <= 0) { fprintf(stderr, "rkmh: read error on %s\n", o.refs[jb.file]); fail_exit(); }
+                have += n;
+            }
+            uint64_t nbytes = (uint64_t)have;
+            if (jb.last) text[nbytes++] = '\n'; // (the slot holds 64 spare bytes)
+            if (rk_fasta_load_put(load, slot, jb.at, nbytes) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); failed = true; }
+        }
+    };
+    double tr = now_s();
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < eng.w.size(); ++i) th.emplace_back(work, i);
+    for (auto& t : th) t.join();
+    for (int fd : fds) close(fd);
+    tick("references: text read and uploaded", tr);
+    bool ok = !failed.load() && next.load() >= jobs.size();
+    rk_fasta_index ix;
+    memset(&ix, 0, sizeof ix);
+    if (ok && rk_fasta_load_finish(load, total, &ix) != RK_OK) { fprintf(stderr, "rkmh: references through the device: %s; parsing on the host\n", rk_last_error()); ok = false; }
+    if (ok && ix.status != 0) {
+        if (g_timing) fprintf(stderr, "[rkmh timing] references: not plain line-structured FASTA (status %d): the host parser reads them\n", ix.status);
+        ok = false;
+    }
+    tick("references: headers and line ends stripped on the device", tr);
+    if (ok) {
+        keep.name_offsets.assign(ix.name_offsets, ix.name_offsets + ix.nseq + 1);
+        keep.names.assign(ix.names, ix.names + keep.name_offsets.back());
+        keep.names.push_back('\0');
+        CK(rk_set_references_fasta(g.ctx[0], load, o.ks.data(), (int)o.ks.size(), o.sketch, max_samples, counter_slots));
+        memset(&refs, 0, sizeof refs);
+        refs.nseq = ix.nseq;
+        refs.names = keep.names.data();
+        refs.name_offsets = keep.name_offsets.data();
+        tick("references: sketched", tr);
+        if (g_timing) fprintf(stderr, "[rkmh timing] references through the device: %lld sequences, %.0f MB of text\n", (long long)ix.nseq, (double)total / 1e6);
+    }
+    rk_fasta_load_destroy(load);
+    return ok;
+}
+
 // the kseq-grammar scanner as a producer thread: batches of the given files (each from a byte offset, 0 = its start), numbered
 static std::thread start_scanner(QueueT<Numbered>& q, std::vector<std::pair<const char*, uint64_t>> files) {
     return std::thread([&q, files] {
@@ -911,6 +1003,9 @@ static int main_stream(int argc, char** argv) {
     tick("context", t0);
     rk_seqset refs;
     memset(&refs, 0, sizeof refs);
+    RawEngine eng;       // the workers and page-locked buffers of the device front ends (created by whoever needs them first)
+    DeviceRefs dev_refs;
+    bool refs_owned = !pre_refs;
     std::string pre_names;
     std::vector<uint64_t> pre_noff;
     if (pre_refs) { // names come from the JSON file; emit_lines only needs names + name_offsets
@@ -920,6 +1015,8 @@ static int main_stream(int argc, char** argv) {
         refs.names = &pre_names[0];
         refs.name_offsets = pre_noff.data();
         CK(rk_set_reference_sketches(ctx, pre.sk.data(), pre.lens.data(), (int)pre.lens.size(), o.ks.data(), (int)o.ks.size(), o.sketch));
+    } else if (refs_through_device(eng, group, o, o.ref_depth ? o.max_samples : -1, 0, refs, dev_refs)) {
+        refs_owned = false;
     } else {
         CK(rk_parse_files(o.refs.data(), (int)o.refs.size(), &refs));
         if (refs.nseq < 1) { fprintf(stderr, "rkmh: no reference sequences found\n"); exit(1); }
@@ -940,12 +1037,10 @@ static int main_stream(int argc, char** argv) {
     }
     if (o.read_depth && all_raw && !read_map) {
         // regular FASTQ files: both passes through the device front end, the reads are never held in host memory
-        RawEngine eng;
         if (eng.create(group)) {
             depth_done = two_pass_raw(eng, group, refs, o, raw_size, cnts, RAW_STREAM, t0);
             if (g_timing) fprintf(stderr, "[rkmh timing] device front end: %lld blocks, %lld records; read %.3f s, device %.3f s, format %.3f s (summed over %zu workers, both passes)\n",
                                   (long long)eng.blocks, (long long)eng.records, eng.t_read, eng.t_dev, eng.t_fmt, eng.w.size());
-            eng.destroy();
         }
     }
     if (o.read_depth && depth_done) {
@@ -986,7 +1081,6 @@ static int main_stream(int argc, char** argv) {
     } else {
         if (!any_raw) run_scanner_pipeline(group, refs, o, q, producer);
         else {
-            RawEngine eng;
             const bool eng_ok = eng.create(group);
             tick("device front end", t0);
             for (size_t i = 0; i < o.reads.size(); ++i) {
@@ -1004,12 +1098,12 @@ static int main_stream(int argc, char** argv) {
             }
             if (g_timing) fprintf(stderr, "[rkmh timing] device front end: %lld blocks, %lld records; read %.3f s, upload + index + classify %.3f s, format %.3f s (summed over %zu workers)\n",
                                   (long long)eng.blocks, (long long)eng.records, eng.t_read, eng.t_dev, eng.t_fmt, eng.w.size());
-            eng.destroy();
         }
     }
     fflush(stdout);
     tick("main loop + flush", t0);
-    if (!pre_refs) rk_seqset_free(&refs);
+    eng.destroy();
+    if (refs_owned) rk_seqset_free(&refs);
     group.destroy();
     tick("teardown", t0);
     done_exit();
@@ -1068,15 +1162,21 @@ static int main_filter(int argc, char** argv) {
     rk_ctx* ctx = group.ctx[0];
     tick("context", t0);
     rk_seqset refs;
-    CK(rk_parse_files(o.refs.data(), (int)o.refs.size(), &refs));
-    if (refs.nseq < 1) { fprintf(stderr, "rkmh: no reference sequences found\n"); exit(1); }
-    tick("parse references", t0);
+    memset(&refs, 0, sizeof refs);
+    RawEngine eng;       // the workers and page-locked buffers of the device front ends
+    DeviceRefs dev_refs;
     // reference sketches: the sample-count filter applies when max_samples < 100000 (rkmh.cpp:1211); its counter is
     // filled once per distinct hash per reference and only when -I was given (rkmh.cpp:1193, :348-355); 10 M slots (:1188)
     CK(rk_set_reference_count_mode(ctx, 1));
     const bool ref_filter = o.max_samples < 100000;
-    CK(rk_set_references(ctx, refs.bases, refs.offsets, (int)refs.nseq, o.ks.data(), (int)o.ks.size(), o.sketch,
-                         ref_filter ? o.max_samples : -1, 10000000ull));
+    if (refs_through_device(eng, group, o, ref_filter ? o.max_samples : -1, 10000000ull, refs, dev_refs)) tick("references: upload + strip + sketch on the device", t0);
+    else {
+        CK(rk_parse_files(o.refs.data(), (int)o.refs.size(), &refs));
+        if (refs.nseq < 1) { fprintf(stderr, "rkmh: no reference sequences found\n"); exit(1); }
+        tick("parse references", t0);
+        CK(rk_set_references(ctx, refs.bases, refs.offsets, (int)refs.nseq, o.ks.data(), (int)o.ks.size(), o.sketch,
+                             ref_filter ? o.max_samples : -1, 10000000ull));
+    }
     std::vector<int32_t> ref_lens((size_t)refs.nseq);
     {
         std::vector<uint64_t> sk((size_t)refs.nseq * (size_t)o.sketch);
@@ -1118,7 +1218,6 @@ static int main_filter(int argc, char** argv) {
     for (size_t i = 0; all_raw && i < o.reads.size(); ++i) all_raw = raw_eligible(o.reads[i], &raw_size[i]);
     bool files_done = o.reads.empty();
     if (all_raw) {
-        RawEngine eng;
         if (eng.create(group)) {
             if (o.read_depth) files_done = two_pass_raw(eng, group, refs, o, raw_size, cnts, RAW_FILTER, t0);
             else {
@@ -1147,7 +1246,6 @@ static int main_filter(int argc, char** argv) {
             }
             if (g_timing) fprintf(stderr, "[rkmh timing] device front end: %lld blocks, %lld records; read %.3f s, device %.3f s, format %.3f s (summed over %zu workers)\n",
                                   (long long)eng.blocks, (long long)eng.records, eng.t_read, eng.t_dev, eng.t_fmt, eng.w.size());
-            eng.destroy();
         }
     }
     if (!files_done) {
