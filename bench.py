@@ -134,6 +134,105 @@ def e2e_stream(n, L, rb, ro, synth):
             pass
 
 
+def c4_full_size(api, synth, genome_mb=3100, nreads=10000000, L=150):
+    """BASELINE config 4 at its own size, whole process: `bin/rkmh filter -k 20 -s 2000` (and with -M 2) of 10 M reads (90 % drawn from
+    the genome, 10 % from the PaVE panel) against a synthetic 24-sequence genome of 3.1 Gb written as FASTA in /tmp.  Each setting
+    runs twice (the second finds the files in the page cache); the run with the host parsers (RKMH_RAW=0 RKMH_RAW_REFS=0) is timed
+    once beside it and its output must be byte-identical."""
+    import hashlib
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "bin", "rkmh")
+    tmp = tempfile.mkdtemp(prefix="rkmh_c4_")
+    fa, fq = os.path.join(tmp, "genome.fa"), os.path.join(tmp, "reads.fq")
+    nthreads = min(32, os.cpu_count() or 1)
+    try:
+        t0 = time.perf_counter()
+        rng = np.random.default_rng(3)
+        chrom = genome_mb * 1000000 // 24
+        lut = np.frombuffer(b"ACGT" * 64, dtype=np.uint8)
+        parts, goffs = [], [0]
+        with open(fa, "wb") as f:
+            for c in range(24):
+                s_ = lut[np.frombuffer(rng.bytes(chrom), dtype=np.uint8)]
+                f.write(b">chr%d synthetic\n" % (c + 1))
+                for lo in range(0, chrom, 1 << 28):
+                    f.write(s_[lo: lo + (1 << 28)].tobytes())
+                f.write(b"\n")
+                parts.append(s_)
+                goffs.append(goffs[-1] + chrom)
+        gb = np.concatenate(parts + [np.zeros(16, np.uint8)])
+        del parts
+        go = np.array(goffs, dtype=np.uint64)
+        hpv = api.parse_files([os.path.join(ROOT, "tests", "golden", "data", "all_pave_ref.fa.gz")])
+        nh = nreads // 10
+        with open(fq, "wb") as f:
+            for src_b, src_o, m, tag in ((gb, go, nreads - nh, ord("g")), (hpv["bases"], hpv["offsets"], nh, ord("v"))):
+                for lo in range(0, m, 1000000):
+                    k = min(1000000, m - lo)
+                    qb, _ = synth.generate_reads_fast(src_b, src_o, lo, lo + k, read_len=L, threads=nthreads)
+                    rec = np.empty((k, 11 + L + 3 + L + 1), dtype=np.uint8)
+                    rec[:, 0] = ord("@"); rec[:, 1] = tag; rec[:, 10] = 10; rec[:, 11 + L] = 10
+                    idx = np.arange(lo, lo + k, dtype=np.int64)
+                    for d in range(8):
+                        rec[:, 9 - d] = 48 + (idx // 10 ** d) % 10
+                    rec[:, 11:11 + L] = qb[: k * L].reshape(k, L)
+                    rec[:, 12 + L] = ord("+"); rec[:, 13 + L] = 10
+                    rec[:, 14 + L:14 + 2 * L] = ord("I"); rec[:, 14 + 2 * L] = 10
+                    f.write(rec.tobytes())
+        del gb
+        gen_s = time.perf_counter() - t0
+        res = {"genome_bases": chrom * 24, "fasta_bytes": os.path.getsize(fa), "reads": nreads, "fastq_bytes": os.path.getsize(fq),
+               "k": 20, "sketch_size": 2000, "inputs_generated_s": gen_s,
+               "note": "bin/rkmh filter, whole process (start-up, 3.1 GB of reference FASTA, sketches, 10 M reads, output); wall_s = device front "
+                       "ends (default), host_parser_wall_s = RKMH_RAW=0 RKMH_RAW_REFS=0; outputs compared byte for byte"}
+
+        def run(extra, env, out):
+            if os.path.exists(out):
+                os.remove(out)
+            fo = open(out, "wb")
+            t = time.perf_counter()
+            r = subprocess.run([exe, "filter", "-r", fa, "-f", fq, "-k", "20", "-s", "2000"] + extra, stdout=fo, stderr=subprocess.PIPE,
+                               env=dict(os.environ, RKMH_TIMING="1", **env))
+            dt = time.perf_counter() - t
+            fo.close()
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr.decode()[-300:])
+            h = hashlib.sha256()
+            kept = 0
+            with open(out, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    h.update(blk)
+                    kept += blk.count(b">")
+            return dt, h.hexdigest(), kept, [l[len("[rkmh timing] "):].strip() for l in r.stderr.decode().splitlines() if l.startswith("[rkmh timing]")]
+
+        for key, extra in (("plain", []), ("M2", ["-M", "2"])):
+            out = os.path.join(tmp, "filter.out")
+            best = None
+            for _ in range(2):
+                dt, dig, kept, stages = run(extra, {}, out)
+                if best is None or dt < best[0]:
+                    best = (dt, dig, kept, stages)
+            hdt, hdig, _, _ = run(extra, {"RKMH_RAW": "0", "RKMH_RAW_REFS": "0"}, out)
+            res[key] = {"wall_s": best[0], "reads_per_s": nreads / best[0], "reads_passing": best[2], "host_parser_wall_s": hdt,
+                        "identical_to_host_parsed_run": best[1] == hdig, "stages": best[3]}
+            if best[1] != hdig:
+                raise SystemExit("c4_full_size: the device front ends and the host parsers printed different bytes (%s)" % key)
+        return res
+    except (OSError, MemoryError, RuntimeError) as e:
+        return {"error": str(e)[-300:]}
+    finally:
+        for x in os.listdir(tmp):
+            try:
+                os.remove(os.path.join(tmp, x))
+            except OSError:
+                pass
+        try:
+            os.rmdir(tmp)
+        except OSError:
+            pass
+
+
 def config_legs(rkmh_amd, api, synth, dev, n, L, check):
     """Informational legs for the other BASELINE configs (never `value`): c3_panel = config 3's ~270-reference panel (every bundled
     FASTA) on one GPU's resident batch; c4_filter = filter's k = 20, s = 2000 shape, plain and with -M 2; c5_call = rkmh call at
@@ -227,7 +326,7 @@ def config_legs(rkmh_amd, api, synth, dev, n, L, check):
                              "M2_slots": slots, "M2_count_pass_ms": count_ms, "M2_masked_classify_ms": masked_ms,
                              "rerouted_rows": int((out[:, 0] < 0).sum()), "oracle_checked_reads": nchk,
                              "note": "BASELINE config 4's kernel shape (filter: k = 20, s = 2000; hash-space kernel) on one resident batch against the "
-                                     "PaVE panel; hg38-sized references are a GPU test in miniature (tests/test_gpu_parity.py), not a bench leg"}
+                                     "PaVE panel; full_size = the whole command at the config's own size (3.1 Gb genome, 10 M reads)"}
     finally:
         ctx.close()
     # ---- config 5: rkmh call, whole process, 1000x coverage of HPV16 with planted variants
@@ -290,6 +389,9 @@ def main():
     ap.add_argument("--no-depth-filter", action="store_true", help="skip the -M figures (count pass + masked classify at 200 M slots; N=1 only)")
     ap.add_argument("--e2e-reads", type=int, default=16000000, help="reads of the generated FASTQ for the bin/rkmh stream end-to-end figure (0 disables; N=1 only)")
     ap.add_argument("--no-configs", action="store_true", help="skip the informational legs for BASELINE configs 3, 4 and 5 (N=1 only)")
+    ap.add_argument("--no-c4-full", action="store_true", help="skip config 4 at full size (3.1 Gb genome + 10 M reads generated in /tmp, ~40 s)")
+    ap.add_argument("--c4-genome-mb", type=int, default=3100, help="config 4 at full size: bases of the synthetic genome, in millions")
+    ap.add_argument("--c4-reads", type=int, default=10000000, help="config 4 at full size: reads")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -521,6 +623,8 @@ def main():
                                            "in LDS, rk_count.hip) and the masked hash-space classification (one keep bit per window from a 25 MB bitmap)"}
         if world == 1 and not a.no_configs:
             res.update(config_legs(rkmh_amd, api, synth, dev, n, L, a.cpu_seconds > 0))
+            if not a.no_c4_full and "c4_filter" in res:
+                res["c4_filter"]["full_size"] = c4_full_size(api, synth, a.c4_genome_mb, a.c4_reads)
         if world == 1 and a.e2e_reads > 0:
             res["e2e"] = e2e_stream(a.e2e_reads, L, rb, ro, synth)
         print(json.dumps(res))

@@ -446,7 +446,7 @@ def test_error_paths_of_the_c_abi(orc, pave):
 def test_bench_json_contract(root):
     """bench.py prints ONE JSON line with the driver's fields, the roofline object and (N=1) the CPU baseline."""
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "30000", "--steps", "3", "--warmup", "1",
-                        "--cpu-seconds", "0.5", "--spinup-seconds", "0"], capture_output=True, cwd=root)
+                        "--cpu-seconds", "0.5", "--spinup-seconds", "0", "--c4-genome-mb", "120", "--c4-reads", "200000"], capture_output=True, cwd=root)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1
@@ -470,6 +470,12 @@ def test_bench_json_contract(root):
     assert c3["references"] >= 260 and c3["kernel_ms"] > 0 and c3["rerouted_rows"] == 0 and c3["oracle_checked_reads"] > 0
     assert c4["k"] == 20 and c4["sketch_size"] == 2000 and c4["kernel_ms"] > 0 and c4["M2_count_pass_ms"] > 0 and c4["M2_masked_classify_ms"] > 0
     assert c4["oracle_checked_reads"] > 0
+    # config 4 as a whole command (here scaled down): device front ends against the host parsers, byte for byte
+    fs = c4["full_size"]
+    assert "error" not in fs, fs
+    for key in ("plain", "M2"):
+        assert fs[key]["identical_to_host_parsed_run"] is True and fs[key]["wall_s"] > 0 and fs[key]["reads_passing"] > 0
+        assert any("references through the device" in x for x in fs[key]["stages"]) and any("device front end" in x for x in fs[key]["stages"])
     assert c5["k"] == 12 and c5["wall_s"] > 0 and c5["vcf_rows"] >= 5 and c5["reads"] > 50000
 
 
