@@ -379,7 +379,7 @@ struct OrderedOut {
     bool direct = false;                   // standard output is a regular file not opened for appending
     off_t base = 0, total = 0;
     void lower_limit(int64_t seq) { int64_t cur = limit.load(); while (seq < cur && !limit.compare_exchange_weak(cur, seq)) {} }
-    void start() {
+    void start(size_t ndev = 1) {
         fflush(stdout);
         struct stat st;
         const int fl = fcntl(1, F_GETFL);
@@ -389,6 +389,7 @@ struct OrderedOut {
             if (cur >= 0) { direct = true; base = cur; }
         }
         long nw = direct ? 3 : 1; // a pipe or a terminal takes the blocks from ONE thread, in order
+        if (direct && ndev > 1) nw = std::min<long>(12, 2 + (long)ndev); // several devices produce lines several times as fast
         if (const char* e = getenv("RKMH_OUT_WRITERS")) { long v = atol(e); if (direct && v >= 1 && v <= 16) nw = v; }
         for (long i = 0; i < nw; ++i)
             writers.emplace_back([this] {
@@ -472,7 +473,10 @@ struct RawEngine {
         if (const char* e = getenv("RKMH_RAW_BLOCK_KB")) { long v = atol(e); if (v >= 4) { block = (uint64_t)v << 10; mb = 0; } }
         if (mb) block = (uint64_t)mb << 20;
         long nw = std::max(2, granted_cpus_main() * 3 / 8); // 6 of 16 CPUs: 4 / 6 / 8 / 10 workers 77 / 97 / 83 / 95 M reads/s to /dev/null, 53-63 to a file
-        if (nw > 12) nw = 12;
+        // one link is saturated by about six workers (the sweep above: one GPU); with several devices in the process every device
+        // gets that many as long as the CPUs last -- not measured (one-GPU boxes), the same reasoning per link
+        const long cap = g.size() > 1 ? std::min<long>(64, 6 * (long)g.size()) : 12;
+        if (nw > cap) nw = cap;
         if (const char* e = getenv("RKMH_RAW_WORKERS")) { long v = atol(e); if (v >= 1 && v <= 64) nw = v; }
         if ((size_t)nw < g.size()) nw = (long)g.size();
         if (const char* e = getenv("RKMH_RAW_SLOTS")) two_slots = atoi(e) == 2;
@@ -601,7 +605,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     QueueT<Job> jobs;
     jobs.cap = eng.w.size();
     OrderedOut out;
-    if (!counting) out.start();
+    if (!counting) out.start(g.size());
     std::atomic<int64_t> fail_seq{INT64_MAX};
     std::mutex fm;
     std::map<int64_t, int64_t> fail_at; // block number -> its first byte
