@@ -352,6 +352,7 @@ typedef struct rk_fasta_index {
 int rk_fasta_load_create(rk_ctx* ctx, uint64_t text_bytes, rk_fasta_load** out);
 int rk_fasta_load_put(rk_fasta_load* load, rk_fastq_slot* via, uint64_t text_offset, uint64_t nbytes);
 int rk_fasta_load_finish(rk_fasta_load* load, uint64_t total_bytes, rk_fasta_index* out);
+int rk_fasta_load_get_bases(rk_fasta_load* load, uint8_t* dst);   /* the packed bases, offsets[nseq] bytes, to the host */
 int rk_set_references_fasta(rk_ctx* ctx, rk_fasta_load* load, const int* ks, int nks, int sketch_size, int max_samples, uint64_t counter_slots);
 void rk_fasta_load_destroy(rk_fasta_load* load);
 void rk_fastq_slot_destroy(rk_fastq_slot* slot);

@@ -116,6 +116,7 @@ _SIGS = {
     "rk_fasta_load_create": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "rk_fasta_load_put": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "rk_fasta_load_finish": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "rk_fasta_load_get_bases": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rk_set_references_fasta": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint64]),
     "rk_fasta_load_destroy": (None, [C.c_void_p]),
     "rk_fastq_slot_count": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
@@ -371,7 +372,14 @@ class FastaLoad:
         noff = np.ctypeslib.as_array(res.name_offsets, shape=(n + 1,))
         blob = C.string_at(res.names, int(noff[n]))
         names = [blob[int(noff[i]): int(noff[i + 1]) - 1] for i in range(n)]
+        self._total = int(offs[n])
         return 0, names, offs
+
+    def bases(self):
+        """The packed bases on the host (rk_fasta_load_get_bases), as the text spells them."""
+        out = np.zeros(self._total + 16, dtype=np.uint8)
+        _chk(self._lib.rk_fasta_load_get_bases(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out[: self._total]
 
     def set_references(self, ks, sketch_size, max_samples=-1, counter_slots=0):
         arr = (C.c_int * len(ks))(*ks)

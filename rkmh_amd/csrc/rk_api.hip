@@ -2161,6 +2161,16 @@ extern "C" int rk_fasta_load_finish(rk_fasta_load* L, uint64_t total_bytes, rk_f
     return RK_OK;
 }
 
+// the packed bases (offsets[nseq] bytes, as the text spells them: not upper-cased) for callers that also want them on the host
+extern "C" int rk_fasta_load_get_bases(rk_fasta_load* L, uint8_t* dst) {
+    if (!L || !dst || !L->finished) return fail(RK_ERR_ARG, "rk_fasta_load_get_bases needs a finished, regular rk_fasta_load");
+    RKCHK(set_dev(L->c));
+    const uint64_t total = L->offsets.back();
+    if (total) HIPCHK(hipMemcpyAsync(dst, L->d_bases.p, total, hipMemcpyDeviceToHost, L->c->st));
+    HIPCHK(hipStreamSynchronize(L->c->st));
+    return RK_OK;
+}
+
 extern "C" int rk_set_references_fasta(rk_ctx* c, rk_fasta_load* L, const int* ks, int nks, int S, int max_samples, uint64_t counter_slots) {
     if (!c || !L || !L->finished) return fail(RK_ERR_ARG, "rk_set_references_fasta needs a finished, regular rk_fasta_load");
     if (L->c != c) return fail(RK_ERR_ARG, "the text was loaded through another context");

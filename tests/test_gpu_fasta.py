@@ -54,6 +54,7 @@ def test_regular_fasta_equals_the_host_parser(ctx, slot, data_dir, tmp_path):
         assert len(names) == want["nseq"], name
         assert names == [bytes(n) for n in want["names"]], name
         assert (offs == np.asarray(want["offsets"], dtype=np.uint64)).all(), name
+        assert bytes(ld.bases()).upper() == bytes(want["bases"][: int(offs[-1])]).upper(), name
         for ks, s, kw in (([16], 1000, {}), ([12, 20], 500, {}), ([16], 1000, {"max_samples": 3})):
             ld.set_references(ks, s, max_samples=kw.get("max_samples", -1), counter_slots=10000000 if kw else 0)
             got_sk, got_ln = ctx.get_reference_sketches()
@@ -81,6 +82,43 @@ def test_irregular_fasta_is_refused(ctx, slot):
         for step in (3, 1 << 20):
             st, names, offs = _load(api, ctx, slot, text, step).finish()
             assert st != 0, name
+
+
+def test_mutated_fasta_never_parses_differently_from_kseq(ctx, slot, orc):
+    """Fuzz: random byte edits of regular FASTA text (RKMH_TEST_FUZZ raises the count).  Whatever the edit, the device either refuses
+    the text or returns exactly the records the oracle's literal kseq grammar reads (names, sequences)."""
+    from rkmh_amd import api
+    rng = np.random.default_rng(int(os.environ.get("RKMH_TEST_SEED_BASE", "11")))
+    acgt = np.frombuffer(b"ACGTacgtN", np.uint8)
+    rnd = lambda n: bytes(acgt[rng.integers(0, len(acgt), size=n)])
+    base = b"".join(b">s%d some words\n" % i + _wrap(rnd(int(rng.integers(1, 400))), int(rng.integers(20, 90))) for i in range(12))
+    pool = b"\n\n\n\r@+>> \tACGTNacgt!~\x7f\x80\x00"
+    n = int(os.environ.get("RKMH_TEST_FUZZ", "300"))
+    accepted = 0
+    for it in range(n):
+        t = bytearray(base)
+        for _ in range(int(rng.integers(1, 4))):
+            op = int(rng.integers(0, 3))
+            pos = int(rng.integers(0, len(t)))
+            if op == 0:
+                t[pos] = pool[int(rng.integers(0, len(pool)))]
+            elif op == 1:
+                del t[pos]
+            else:
+                t.insert(pos, pool[int(rng.integers(0, len(pool)))])
+        text = bytes(t)
+        if not text.endswith(b"\n"):
+            text += b"\n"          # (the callers of rk_fasta_load_put end every file with a newline)
+        ld = _load(api, ctx, slot, text, int(rng.integers(1, 5000)))
+        st, names, offs = ld.finish()
+        if st == 0:
+            accepted += 1
+            want = orc.kseq_parse_bytes(text)
+            assert names == [w[0] for w in want], (it, text[:200])
+            got = bytes(ld.bases())
+            assert [got[int(offs[i]): int(offs[i + 1])] for i in range(len(names))] == [w[1] for w in want], it
+        ld.destroy()
+    assert 0 < accepted < n
 
 
 def _cli(root, args, env=None):
