@@ -6,7 +6,7 @@ CSRC := rkmh_amd/csrc
 # instantiations of the fused kernel the ISA lint must find (it fails closed below that): k = 12, 16 (x 3 folds), 20, 21, 31 and run-time k, x 5 modes x 3 prefetch depths
 MIN_TILE_KERNELS ?= 120
 LIB := rkmh_amd/lib/librkmh_amd.so
-OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_kmer.o $(CSRC)/rk_count.o $(CSRC)/rk_call.o $(CSRC)/rk_sort.o $(CSRC)/rk_fastq.o $(CSRC)/rk_fasta.o $(CSRC)/rk_api.o $(CSRC)/rk_parse.o $(CSRC)/rk_synth.o
+OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_kmer.o $(CSRC)/rk_count.o $(CSRC)/rk_call.o $(CSRC)/rk_sort.o $(CSRC)/rk_fastq.o $(CSRC)/rk_fasta.o $(CSRC)/rk_api.o $(CSRC)/rk_parse.o $(CSRC)/rk_format.o $(CSRC)/rk_synth.o
 
 all: $(LIB) bin/rkmh oracle
 
@@ -38,6 +38,8 @@ $(CSRC)/rk_call.o: $(CSRC)/rk_call.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.
 $(CSRC)/rk_api.o: $(CSRC)/rk_api.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp include/rkmh_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/rk_parse.o: $(CSRC)/rk_parse.cpp include/rkmh_amd.h
+	g++ -O3 -std=c++17 -fPIC -Wall -c $< -o $@
+$(CSRC)/rk_format.o: $(CSRC)/rk_format.cpp include/rkmh_amd.h
 	g++ -O3 -std=c++17 -fPIC -Wall -c $< -o $@
 
 $(CSRC)/rk_synth.o: $(CSRC)/rk_synth.cpp include/rkmh_amd.h

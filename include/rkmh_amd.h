@@ -332,6 +332,19 @@ int rk_fastq_slot_finish(rk_fastq_slot* slot, rk_fastq_result* res);
  * context); *status != 0: the block is not four lines per record and nothing of it was counted */
 int rk_fastq_slot_count(rk_fastq_slot* slot, uint64_t nbytes, rk_counter* counter, int32_t* status, int64_t* nrec);
 
+/* The output of stream / classify (line format src/rkmh.cpp:887-892) and of filter (records src/rkmh.cpp:1292-1300, decision
+ * src/equiv.hpp:324-353) for one classified block, written from the names, sequences and quality strings where they lie in the
+ * block's raw text (rk_fastq_slot_text).  rk_line_parts holds what does not depend on the read ("ref name \t" per reference, the
+ * eight possible line tails).  dst must hold *_bound() bytes; the functions return the bytes written or a negative RK_ERR_*. */
+typedef struct rk_line_parts rk_line_parts;
+int rk_line_parts_create(const char* ref_names, const uint64_t* ref_name_offsets, int64_t nref, int sketch_size, int min_matches,
+                         int min_diff, rk_line_parts** out);   /* names NUL-terminated, back to back, as in rk_seqset */
+void rk_line_parts_destroy(rk_line_parts* parts);
+uint64_t rk_fastq_stream_lines_bound(const rk_line_parts* parts, const rk_fastq_result* res);
+int64_t rk_fastq_stream_lines(const rk_line_parts* parts, const rk_fastq_result* res, const uint8_t* text, char* dst, uint64_t cap);
+uint64_t rk_fastq_filter_records_bound(const rk_fastq_result* res);
+int64_t rk_fastq_filter_records(const rk_fastq_result* res, const uint8_t* text, int min_matches, int min_diff, char* dst, uint64_t cap);
+
 /* ---- references from raw FASTA text (replaces parse_fastas over the -r files, src/rkmh.cpp:238-263 + :816-826, for regular text).
  * The text of the files, concatenated (a '\n' after each file), is uploaded block by block through a slot's page-locked buffer;
  * rk_fasta_load_finish strips header lines and line ends ON THE DEVICE and returns the record table; rk_set_references_fasta

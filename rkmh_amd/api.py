@@ -113,6 +113,12 @@ _SIGS = {
     "rk_fastq_slot_destroy": (None, [C.c_void_p]),
     "rk_fastq_slot_submit": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rk_fastq_slot_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rk_line_parts_create": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "rk_line_parts_destroy": (None, [C.c_void_p]),
+    "rk_fastq_stream_lines_bound": (C.c_uint64, [C.c_void_p, C.c_void_p]),
+    "rk_fastq_stream_lines": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "rk_fastq_filter_records_bound": (C.c_uint64, [C.c_void_p]),
+    "rk_fastq_filter_records": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64]),
     "rk_fasta_load_create": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "rk_fasta_load_put": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "rk_fasta_load_finish": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
@@ -404,6 +410,30 @@ def fastq_cut(text: bytes) -> int:
     return int(load_library().rk_fastq_cut(C.cast(b, C.c_void_p), len(text)))
 
 
+class LineParts:
+    """What does not depend on the read in a stream / classify line (rk_line_parts): reference names with their tab, the eight tails."""
+
+    def __init__(self, ref_names, sketch_size, min_matches, min_diff):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        blob = b"".join(bytes(n) + b"\0" for n in ref_names)
+        offs = np.zeros(len(ref_names) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(n) + 1 for n in ref_names])
+        _chk(self._lib.rk_line_parts_create(blob, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(ref_names), sketch_size, min_matches, min_diff,
+                                            C.byref(self._h)))
+
+    def destroy(self):
+        if self._h:
+            self._lib.rk_line_parts_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class FastqSlot:
     """One block of raw FASTQ text in flight (rk_fastq_slot_*): the text is split into records, checked, packed and classified on the device."""
 
@@ -427,6 +457,41 @@ class FastqSlot:
         st, nrec = C.c_int32(), C.c_int64()
         _chk(self._lib.rk_fastq_slot_count(self._h, n, counter._h, C.byref(st), C.byref(nrec)))
         return st.value, nrec.value
+
+    # -- the zero-copy forms the one-process-per-GPU front end uses (rkmh_amd/cli.py): the caller reads file bytes straight into the
+    # slot's page-locked buffer and the output text is formatted in C from the result where it lies
+    def text_buffer(self):
+        """The slot's page-locked text buffer as a writable ctypes array (max_bytes + 64 bytes): os.preadv() into it."""
+        return (C.c_char * (self.max_bytes + 64)).from_address(self._lib.rk_fastq_slot_text(self._h))
+
+    def classify_raw(self, nbytes):
+        """rk_fastq_slot_classify on the first nbytes of text_buffer(); returns the FastqResult structure (valid until the next call)."""
+        res = FastqResult()
+        _chk(self._lib.rk_fastq_slot_classify(self._h, nbytes, C.byref(res)))
+        return res
+
+    def count_raw(self, nbytes, counter):
+        st, nrec = C.c_int32(), C.c_int64()
+        _chk(self._lib.rk_fastq_slot_count(self._h, nbytes, counter._h, C.byref(st), C.byref(nrec)))
+        return st.value, nrec.value
+
+    def stream_lines(self, parts, res):
+        """The stream / classify lines of a classified block (rk_fastq_stream_lines), as bytes."""
+        cap = int(self._lib.rk_fastq_stream_lines_bound(parts._h, C.byref(res)))
+        buf = C.create_string_buffer(cap)
+        n = self._lib.rk_fastq_stream_lines(parts._h, C.byref(res), self._lib.rk_fastq_slot_text(self._h), buf, cap)
+        if n < 0:
+            _chk(int(n))
+        return buf.raw[:n]
+
+    def filter_records(self, res, min_matches, min_diff):
+        """filter's records of a classified block (rk_fastq_filter_records), as bytes."""
+        cap = int(self._lib.rk_fastq_filter_records_bound(C.byref(res)))
+        buf = C.create_string_buffer(cap)
+        n = self._lib.rk_fastq_filter_records(C.byref(res), self._lib.rk_fastq_slot_text(self._h), min_matches, min_diff, buf, cap)
+        if n < 0:
+            _chk(int(n))
+        return buf.raw[:n]
 
     def submit(self, text: bytes):
         """First half (rk_fastq_slot_submit): the upload and the splitting kernels are enqueued; returns at once."""

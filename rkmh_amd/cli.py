@@ -27,6 +27,143 @@ def _upper(a):
     return np.where(x > 91, x - 32, x).astype(np.int8).view(np.uint8).tobytes()
 
 
+def _cut_before(fd, size, p):
+    """The last record start (four-line rule, rk_fastq_cut) before byte p of the file: how byte ranges become ranges of whole records.
+    Every rank and every block computes its ends with this one function, so neighbours agree without talking."""
+    if p <= 0:
+        return 0
+    if p >= size:
+        return size
+    w = 1 << 16
+    while True:
+        lo = max(0, p - w)
+        cut = api.fastq_cut(os.pread(fd, p - lo, lo))
+        if cut > 0:
+            return lo + cut
+        if lo == 0:
+            return 0
+        w *= 8
+
+
+def _raw_eligible(path):
+    try:
+        if not os.path.isfile(path) or os.path.getsize(path) == 0:
+            return False
+        with open(path, "rb") as f:
+            return f.read(1) == b"@"
+    except OSError:
+        return False
+
+
+def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, min_matches, min_diff, filter_mode):
+    """This rank's byte range of every read file through the device FASTQ front end (rk_fastq_slot_*): worker threads read raw blocks
+    straight into page-locked buffers, the GPU splits / checks / packs / classifies them, the lines are written in C from the names
+    where they lie (rk_fastq_stream_lines / rk_fastq_filter_records) -- the host never parses a read, exactly as bin/rkmh does it
+    (rkmh_main.cpp, stream_file_raw).  -M: two such passes with the RCCL all-reduce of the table in between.  Returns this rank's
+    output text per file, or None when ANY rank met text that is not four lines per record (then every rank takes the parsing path)."""
+    import threading
+    ok = all(_raw_eligible(p) for p in reads) and bool(reads)
+    if not rdist.all_true(ok):
+        return None
+    block = max(4096, int(os.environ.get("RKMH_RAW_BLOCK_KB", "16384")) << 10)
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    nw = int(os.environ.get("RKMH_RAW_WORKERS", "0")) or max(2, min(6, ((os.cpu_count() or 8) * 3 // 8) // local_world))
+    fds = [os.open(p, os.O_RDONLY) for p in reads]
+    sizes = [os.fstat(fd).st_size for fd in fds]
+    slots, state = [], {"ok": True}
+    lock = threading.Lock()
+    try:
+        # this rank's blocks of every file: [cut(size r / world), cut(size (r + 1) / world)) in steps of `block`, ends cut the same way
+        plan = []
+        for fd, size in zip(fds, sizes):
+            a, b = _cut_before(fd, size, size * rank // world), _cut_before(fd, size, size * (rank + 1) // world)
+            ends = [_cut_before(fd, size, p) for p in range(a + block, b, block)] + [b]
+            blocks, s0 = [], a
+            for e in ends:
+                if e > s0:
+                    blocks.append((s0, e))
+                    s0 = e
+            plan.append(blocks)
+        longest = max([e - s0 for blocks in plan for s0, e in blocks] + [4096])
+        for _ in range(nw):
+            slots.append(api.FastqSlot(ctx, max_bytes=longest + 64))
+        parts = None if filter_mode else api.LineParts(ref_names, sketch, min_matches, min_diff)
+
+        def run_pass(counter):
+            texts = []
+            for fd, size, blocks in zip(fds, sizes, plan):
+                results, nxt = [b""] * len(blocks), [0]
+
+                def work(slot):
+                    buf = slot.text_buffer()
+                    mv = memoryview(buf).cast("B")
+                    while state["ok"]:
+                        with lock:
+                            i = nxt[0]
+                            nxt[0] += 1
+                        if i >= len(blocks):
+                            return
+                        s0, s1 = blocks[i]
+                        n, got = s1 - s0, 0
+                        while got < n:
+                            k = os.preadv(fd, [mv[got:n]], s0 + got)
+                            if k <= 0:
+                                state["ok"] = False
+                                return
+                            got += k
+                        if s1 == size and mv[n - 1] != 10:
+                            mv[n] = 10          # a last line without its newline (the slot holds spare bytes)
+                            n += 1
+                        if counter is not None:
+                            st, _ = slot.count_raw(n, counter)
+                            if st != 0:
+                                state["ok"] = False
+                        else:
+                            res = slot.classify_raw(n)
+                            if res.status != 0:
+                                state["ok"] = False
+                            elif res.nrec:
+                                results[i] = slot.filter_records(res, min_matches, min_diff) if filter_mode else slot.stream_lines(parts, res)
+
+                th = [threading.Thread(target=work, args=(sl,)) for sl in slots]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                texts.append(b"".join(results))
+            return texts
+
+        counter = t = None
+        if min_occ is not None:
+            import torch
+            nslots = 10000000 if filter_mode else 200000000  # rkmh.cpp:1187 / :739
+            t = torch.zeros(nslots, dtype=torch.int32, device="cuda:%d" % local)
+            torch.cuda.synchronize()
+            counter = api.Counter(ctx, slots=nslots, device_ptr=t.data_ptr())
+            run_pass(counter)                                   # pass 1 (rkmh.cpp:904-910) on this rank's blocks
+            ctx.synchronize()
+            if not rdist.all_true(state["ok"]):
+                counter.destroy()
+                return None
+            rdist.allreduce_counter(t)                          # RCCL sum over ranks
+            torch.cuda.synchronize()
+            ctx.set_depth_filter(counter, min_occ)
+        texts = run_pass(None)
+        good = rdist.all_true(state["ok"])
+        if os.environ.get("RKMH_TIMING"):
+            sys.stderr.write("[rkmh timing] rank %d: device front end: %d blocks of %d file(s), %d worker threads%s\n"
+                             % (rank, sum(len(b) for b in plan), len(plan), nw, "" if good else " -- refused, parsing on the host"))
+        if counter is not None:
+            ctx.set_depth_filter(None, 0)
+            counter.destroy()
+        return texts if good else None
+    finally:
+        for sl in slots:
+            sl.destroy()
+        for fd in fds:
+            os.close(fd)
+
+
 def main_stream(argv, filter_mode=False):
     if len(argv) <= 2:
         sys.stderr.write(HELP)
@@ -88,6 +225,24 @@ def main_stream(argv, filter_mode=False):
     sk, ln = rdist.broadcast_sketches(sk, ln, R["nseq"], sketch, src=0)
     if rank != 0:
         ctx.set_reference_sketches(sk, ln, ks, sketch)
+    # Uncompressed FASTQ files do not pass through a host parser at all (see _device_ingest); RKMH_RAW=0 turns that off.
+    if os.environ.get("RKMH_RAW", "1") != "0" and not os.environ.get("RKMH_CLI_WHOLE_PARSE"):
+        texts = _device_ingest(ctx, rank, local, world, reads, R["names"], sketch, min_occ, min_matches, min_diff, filter_mode)
+        if texts is not None:
+            for text in texts:          # file by file, every file's text in rank order
+                whole = rdist.gather_bytes(text, dst=0)
+                if rank == 0:
+                    out.write(whole)
+            if rank == 0:
+                out.flush()
+            ctx.close()
+            try:
+                import torch.distributed as dist
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except ImportError:
+                pass
+            return 0
     # Every rank reads ITS part of the reads only: byte range rank/world of every uncompressed FASTQ file, cut at record starts
     # (rk_reader_open_range); the ranks' record counts put the blocks back in input order.  Text that is not four lines per record
     # (or gzip / FASTA input) cannot be split by bytes: if ANY rank finds that, all of them parse everything and shard by record index.

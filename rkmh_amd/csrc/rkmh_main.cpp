@@ -494,60 +494,13 @@ struct RawEngine {
     void destroy() { for (auto& x : w) for (auto* sl : x.slot) if (sl) rk_fastq_slot_destroy(sl); w.clear(); }
 };
 
-// Everything of a line that does not depend on the read, prepared once per run: "ref name \t" per reference and the eight
-// possible tails "<sketch>[FAIL:DEPTH] \t [FAIL:MATCHES] \t [FAIL:DIFF] \n" (format of rkmh.cpp:887-892).
-struct LineParts {
-    std::vector<char> ref_text;          // padded: copies run in 16-byte steps
-    std::vector<uint32_t> ref_off, ref_len;
-    char tail[8][48];
-    uint32_t tail_len[8];
-    size_t maxref = 0;
-    void build(const rk_seqset& refs, const Opts& o) {
-        ref_off.resize((size_t)refs.nseq); ref_len.resize((size_t)refs.nseq);
-        for (int64_t r = 0; r < refs.nseq; ++r) {
-            const size_t ln = (size_t)(refs.name_offsets[r + 1] - refs.name_offsets[r]) - 1; // offsets include the NUL
-            ref_off[(size_t)r] = (uint32_t)ref_text.size(); ref_len[(size_t)r] = (uint32_t)ln + 1;
-            ref_text.insert(ref_text.end(), refs.names + refs.name_offsets[r], refs.names + refs.name_offsets[r] + ln);
-            ref_text.push_back('\t');
-            maxref = std::max(maxref, ln + 1);
-        }
-        ref_text.resize(ref_text.size() + 32, 0);
-        for (int f = 0; f < 8; ++f) {
-            char* w = put_int(tail[f], o.sketch);
-            if (f & 1) { memcpy(w, "FAIL:DEPTH", 10); w += 10; }
-            *w++ = '\t';
-            if (f & 2) { memcpy(w, "FAIL:MATCHES", 12); w += 12; }
-            *w++ = '\t';
-            if (f & 4) { memcpy(w, "FAIL:DIFF", 9); w += 9; }
-            *w++ = '\n';
-            tail_len[f] = (uint32_t)(w - tail[f]);
-        }
-    }
-};
-// copies n bytes in 16-byte steps (both buffers have the slack): no call into memcpy for a ten-byte name
-static inline char* copy16(char* w, const char* src, size_t n) {
-    for (size_t i = 0; i < n; i += 16) memcpy(w + i, src + i, 16);
-    return w + n;
-}
-
-// the lines of one block, names taken from the raw text
-static size_t format_raw(const LineParts& lp, const rk_fastq_result& r, const uint8_t* text, const Opts& o, std::vector<char>& buf) {
-    size_t names = 0;
-    for (int64_t i = 0; i < r.nrec; ++i) names += r.name_len[i];
-    const size_t need = names + (size_t)r.nrec * (lp.maxref + 64) + 64;
+// the lines of one block (rk_fastq_stream_lines: rk_format.cpp), names taken from the raw text
+static size_t format_raw(const rk_line_parts* lp, const rk_fastq_result& r, const uint8_t* text, std::vector<char>& buf) {
+    const size_t need = (size_t)rk_fastq_stream_lines_bound(lp, &r);
     if (buf.size() < need) buf.resize(need + need / 8); // (grows a few times, then stays: no per-block allocation or zero-fill)
-    char* const w0 = buf.data();
-    char* w = w0;
-    for (int64_t i = 0; i < r.nrec; ++i) {
-        const int32_t* q = r.out4 + i * 4;
-        w = copy16(w, lp.ref_text.data() + lp.ref_off[(size_t)q[0]], lp.ref_len[(size_t)q[0]]);
-        w = copy16(w, (const char*)text + r.name_off[i], r.name_len[i]); *w++ = '\t';
-        w = put_int(w, q[1]); *w++ = '\t';
-        const int f = (q[3] <= o.min_matches ? 1 : 0) | (q[1] < o.min_matches ? 2 : 0) | (!(q[2] > o.min_diff) ? 4 : 0);
-        memcpy(w, lp.tail[f], 48);
-        w += lp.tail_len[f];
-    }
-    return (size_t)(w - w0);
+    const int64_t n = rk_fastq_stream_lines(lp, &r, text, buf.data(), buf.size());
+    if (n < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+    return (size_t)n;
 }
 
 // filter's decision: classify_and_count_diff_filter (src/equiv.hpp:324-353): scan from max_shared = prev_best = 0, empty sample name
@@ -561,30 +514,13 @@ static FilterDecision filter_decide(const int32_t* r, int min_diff) {
     return d;
 }
 
-// filter's output for one block (rkmh.cpp:1292-1300): ">name \n SEQ \n + \n QUAL \n" of every read that passes, name, sequence
-// (upper-cased as parse_fastas does, rkmh.cpp:280) and quality string taken from the raw text
+// filter's output for one block (rk_fastq_filter_records: rk_format.cpp)
 static size_t format_filter_raw(const rk_fastq_result& r, const uint8_t* text, const Opts& o, std::vector<char>& buf) {
-    size_t need = 64;
-    for (int64_t i = 0; i < r.nrec; ++i) need += (size_t)r.name_len[i] + 2 * (size_t)r.seq_len[i] + 8;
+    const size_t need = (size_t)rk_fastq_filter_records_bound(&r);
     if (buf.size() < need) buf.resize(need + need / 8);
-    char* const w0 = buf.data();
-    char* w = w0;
-    for (int64_t i = 0; i < r.nrec; ++i) {
-        const int32_t* q = r.out4 + i * 4;
-        const FilterDecision d = filter_decide(q, o.min_diff);
-        if (q[3] <= 0 || d.shared < o.min_matches || !d.diff_ok) continue;
-        *w++ = '>';
-        memcpy(w, text + r.name_off[i], r.name_len[i]); w += r.name_len[i];
-        *w++ = '\n';
-        const uint8_t* sq = text + r.seq_off[i];
-        const uint32_t n = r.seq_len[i];
-        for (uint32_t j = 0; j < n; ++j) { const signed char ch = (signed char)sq[j]; w[j] = (char)(((int)ch - 91) > 0 ? ch - 32 : ch); }
-        w += n;
-        *w++ = '\n'; *w++ = '+'; *w++ = '\n';
-        memcpy(w, text + r.qual_off[i], n); w += n;
-        *w++ = '\n';
-    }
-    return (size_t)(w - w0);
+    const int64_t n = rk_fastq_filter_records(&r, text, o.min_matches, o.min_diff, buf.data(), buf.size());
+    if (n < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+    return (size_t)n;
 }
 
 // what a pass over a file does with each block
@@ -598,8 +534,8 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                                RawKind kind = RAW_STREAM, std::vector<rk_counter*>* cnts = nullptr) {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) { fprintf(stderr, "rkmh: cannot open %s\n", path); fail_exit(); }
-    LineParts lp;
-    if (kind == RAW_STREAM) lp.build(refs, o);
+    rk_line_parts* lp = nullptr;
+    if (kind == RAW_STREAM) CK(rk_line_parts_create(refs.names, refs.name_offsets, refs.nseq, o.sketch, o.min_matches, o.min_diff, &lp));
     const bool counting = kind == RAW_COUNT;
     struct Job { int64_t seq = 0, lo = 0, hi = 0; };
     QueueT<Job> jobs;
@@ -636,7 +572,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                 int64_t curf = fail_seq.load();
                 while (jb.seq < curf && !fail_seq.compare_exchange_weak(curf, jb.seq)) {}
             } else if (kind == RAW_FILTER) outlen = format_filter_raw(res, rk_fastq_slot_text(slot), o, buf);
-            else outlen = format_raw(lp, res, rk_fastq_slot_text(slot), o, buf);
+            else outlen = format_raw(lp, res, rk_fastq_slot_text(slot), buf);
             t_dv += c - b; t_fm += now_s() - c; ++nblk; nrec_ += res.status == 0 ? res.nrec : 0;
             out.put(jb.seq, std::move(buf), outlen, window);
         };
@@ -725,6 +661,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     }
     for (auto& t : workers) t.join();
     if (!counting) out.finish();
+    rk_line_parts_destroy(lp);
     close(fd);
     if (out.failed) { fprintf(stderr, "rkmh: write error on standard output\n"); fail_exit(); }
     const int64_t fs = fail_seq.load();

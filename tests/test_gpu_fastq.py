@@ -384,7 +384,10 @@ def test_ranks_read_their_own_byte_range(root, data_dir, tmp_path):
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                             "--master-port", str(port[0]), "-m", "rkmh_amd.cli"] + args, capture_output=True, cwd=root, env=env, timeout=900)
         assert r.returncode == 0, r.stderr.decode()[-3000:]
+        last_err[0] = r.stderr
         return r.stdout
+
+    last_err = [b""]
 
     def one(args):
         r = subprocess.run([exe] + args, capture_output=True, timeout=900)
@@ -404,3 +407,17 @@ def test_ranks_read_their_own_byte_range(root, data_dir, tmp_path):
     wf = one(fl + ["-f", str(fq)])
     assert wf.startswith(b">q") and 0 < len(wf) < len(text) + n      # some reads pass, some do not
     assert ranks(2, fl + ["-f", str(fq)]) == wf
+    # since round 4 the ranks do not parse at all: their byte ranges go through the device front end in raw blocks (cli._device_ingest);
+    # the parsing path per byte range (RKMH_RAW=0) and the whole-parse path stay covered above and here
+    assert ranks(2, st + ["-f", str(fq)], {"RKMH_TIMING": "1"}) == want
+    assert last_err[0].count(b"device front end: ") == 2 and b"refused" not in last_err[0]
+    assert ranks(2, st + ["-f", str(fq)], {"RKMH_RAW": "0", "RKMH_TIMING": "1"}) == want
+    assert b"device front end: " not in last_err[0]
+    assert ranks(3, st + ["-f", str(fq), "-f", str(fq)], {"RKMH_RAW_BLOCK_KB": "64", "RKMH_RAW_WORKERS": "3", "RKMH_TIMING": "1"}) == want + want
+    assert b"device front end: " in last_err[0]
+    assert ranks(2, fl + ["-f", str(fq), "-M", "2"], {"RKMH_RAW_BLOCK_KB": "100"}) == one(fl + ["-f", str(fq), "-M", "2"])
+    assert ranks(2, st + ["-f", str(fq), "-M", "3", "-N", "4"], {"RKMH_RAW_BLOCK_KB": "300"}) == one(st + ["-f", str(fq), "-M", "3", "-N", "4"])
+    assert ranks(3, st + ["-f", str(odd)], {"RKMH_TIMING": "1"}) == one(st + ["-f", str(odd)])
+    assert b"refused" in last_err[0]
+    r1 = subprocess.run([sys.executable, "-m", "rkmh_amd.cli"] + st + ["-f", str(fq)], capture_output=True, cwd=root, env=dict(os.environ, RKMH_TIMING="1"), timeout=900)
+    assert r1.returncode == 0 and r1.stdout == want and b"device front end: " in r1.stderr      # one process, no launcher

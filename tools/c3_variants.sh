@@ -6,7 +6,7 @@ cp rkmh_amd/lib/librkmh_amd.so /tmp/librkmh_amd.orig.so
 cp rkmh_amd/csrc/rk_kmer.o /tmp/rk_kmer.orig.o
 for v in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DRK_KMER_FAST_BUILD $v -c rkmh_amd/csrc/rk_kmer.hip -o rkmh_amd/csrc/rk_kmer.o 2>&1 | grep -i "error"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o rkmh_amd/lib/librkmh_amd.so rkmh_amd/csrc/rk_kernels.o rkmh_amd/csrc/rk_classify.o rkmh_amd/csrc/rk_kmer.o rkmh_amd/csrc/rk_count.o rkmh_amd/csrc/rk_call.o rkmh_amd/csrc/rk_sort.o rkmh_amd/csrc/rk_fastq.o rkmh_amd/csrc/rk_fasta.o rkmh_amd/csrc/rk_api.o rkmh_amd/csrc/rk_parse.o rkmh_amd/csrc/rk_synth.o -lz -lpthread
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o rkmh_amd/lib/librkmh_amd.so rkmh_amd/csrc/rk_kernels.o rkmh_amd/csrc/rk_classify.o rkmh_amd/csrc/rk_kmer.o rkmh_amd/csrc/rk_count.o rkmh_amd/csrc/rk_call.o rkmh_amd/csrc/rk_sort.o rkmh_amd/csrc/rk_fastq.o rkmh_amd/csrc/rk_fasta.o rkmh_amd/csrc/rk_api.o rkmh_amd/csrc/rk_parse.o rkmh_amd/csrc/rk_format.o rkmh_amd/csrc/rk_synth.o -lz -lpthread
   echo "variant [$v]"
   python3 tools/c3_probe.py 2>/dev/null | grep -v "^references"
 done
