@@ -200,11 +200,11 @@ def _seqset_to_py(ss):
     if nb:
         bases[:nb] = np.ctypeslib.as_array(ss.bases, shape=(nb,))
     noffs = np.ctypeslib.as_array(ss.name_offsets, shape=(n + 1,)).copy()
-    names_raw = C.string_at(ss.names, int(noffs[-1])) if n else b""
+    names_raw = (C.c_char * int(noffs[-1])).from_address(C.cast(ss.names, C.c_void_p).value).raw if n else b""
     names = [names_raw[int(noffs[i]): int(noffs[i + 1]) - 1] for i in range(n)]
     quals = None
     if ss.quals:
-        q = C.string_at(ss.quals, nb)
+        q = (C.c_char * nb).from_address(C.cast(ss.quals, C.c_void_p).value).raw if nb else b""   # (string_at takes a C int: 2 GB at most)
         quals = [q[int(offs[i]): int(offs[i + 1])] for i in range(n)]
     return {"bases": bases, "offsets": offs, "names": names, "quals": quals, "nseq": n}
 
@@ -475,23 +475,31 @@ class FastqSlot:
         _chk(self._lib.rk_fastq_slot_count(self._h, nbytes, counter._h, C.byref(st), C.byref(nrec)))
         return st.value, nrec.value
 
+    def _out_buffer(self, cap):
+        # one growing buffer per slot (a slot serves one thread): no allocation or zero-fill per block
+        if getattr(self, "_obuf", None) is None or len(self._obuf) < cap:
+            self._obuf = bytearray(cap + cap // 8)
+        return (C.c_char * len(self._obuf)).from_buffer(self._obuf)
+
     def stream_lines(self, parts, res):
         """The stream / classify lines of a classified block (rk_fastq_stream_lines), as bytes."""
         cap = int(self._lib.rk_fastq_stream_lines_bound(parts._h, C.byref(res)))
-        buf = C.create_string_buffer(cap)
-        n = self._lib.rk_fastq_stream_lines(parts._h, C.byref(res), self._lib.rk_fastq_slot_text(self._h), buf, cap)
+        buf = self._out_buffer(cap)
+        n = self._lib.rk_fastq_stream_lines(parts._h, C.byref(res), self._lib.rk_fastq_slot_text(self._h), buf, len(self._obuf))
+        del buf
         if n < 0:
             _chk(int(n))
-        return buf.raw[:n]
+        return bytes(memoryview(self._obuf)[:n])
 
     def filter_records(self, res, min_matches, min_diff):
         """filter's records of a classified block (rk_fastq_filter_records), as bytes."""
         cap = int(self._lib.rk_fastq_filter_records_bound(C.byref(res)))
-        buf = C.create_string_buffer(cap)
-        n = self._lib.rk_fastq_filter_records(C.byref(res), self._lib.rk_fastq_slot_text(self._h), min_matches, min_diff, buf, cap)
+        buf = self._out_buffer(cap)
+        n = self._lib.rk_fastq_filter_records(C.byref(res), self._lib.rk_fastq_slot_text(self._h), min_matches, min_diff, buf, len(self._obuf))
+        del buf
         if n < 0:
             _chk(int(n))
-        return buf.raw[:n]
+        return bytes(memoryview(self._obuf)[:n])
 
     def submit(self, text: bytes):
         """First half (rk_fastq_slot_submit): the upload and the splitting kernels are enqueued; returns at once."""

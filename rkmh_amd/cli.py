@@ -55,16 +55,63 @@ def _raw_eligible(path):
         return False
 
 
-def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, min_matches, min_diff, filter_mode):
+class _RankOutput:
+    """Standard output shared by the ranks (torch.distributed.run hands every worker the launcher's descriptor 1).  No text travels
+    between the processes: into a regular file every rank writes its blocks at their final offsets, all ranks at once (the byte
+    counts are all-gathered); into a pipe the ranks write one after the other.  A single rank streams its blocks out as they finish."""
+
+    def __init__(self, fd, rank, world):
+        import fcntl
+        import stat
+        self.fd, self.rank, self.world = fd, rank, world
+        st = os.fstat(fd)
+        self.regular = stat.S_ISREG(st.st_mode) and not (fcntl.fcntl(fd, fcntl.F_GETFL) & os.O_APPEND)
+        self.base = os.lseek(fd, 0, os.SEEK_CUR) if self.regular else 0
+
+    def _put(self, piece, at):
+        mv, done = memoryview(piece), 0
+        while done < len(mv):
+            done += os.pwrite(self.fd, mv[done:], at + done) if self.regular else os.write(self.fd, mv[done:])
+
+    def stream(self, piece):
+        """world == 1: the next block of the output, in order."""
+        self._put(piece, self.base)
+        self.base += len(piece)
+
+    def pieces_of_a_file(self, pieces):
+        """This rank's output for ONE input file (a list of blocks, in order); returns when every rank's part is written."""
+        n = sum(len(p) for p in pieces)
+        sizes = rdist.all_gather_int(n)
+        if self.regular:
+            at = self.base + sum(sizes[: self.rank])
+            for p in pieces:
+                self._put(p, at)
+                at += len(p)
+            self.base += sum(sizes)
+            rdist.barrier()
+        else:
+            for r in range(self.world):
+                if r == self.rank:
+                    for p in pieces:
+                        self._put(p, 0)
+                rdist.barrier()
+
+    def finish(self):
+        if self.regular and self.rank == 0:
+            os.lseek(self.fd, self.base, os.SEEK_SET)   # whatever is written next continues behind the blocks
+
+
+def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, min_matches, min_diff, filter_mode, out_fd):
     """This rank's byte range of every read file through the device FASTQ front end (rk_fastq_slot_*): worker threads read raw blocks
     straight into page-locked buffers, the GPU splits / checks / packs / classifies them, the lines are written in C from the names
     where they lie (rk_fastq_stream_lines / rk_fastq_filter_records) -- the host never parses a read, exactly as bin/rkmh does it
     (rkmh_main.cpp, stream_file_raw).  -M: two such passes with the RCCL all-reduce of the table in between.  Returns this rank's
-    output text per file, or None when ANY rank met text that is not four lines per record (then every rank takes the parsing path)."""
+    output is written to out_fd (see _RankOutput) and True returned -- or, when ANY rank met text that is not four lines per record,
+    nothing is written and False returned (then every rank takes the parsing path)."""
     import threading
     ok = all(_raw_eligible(p) for p in reads) and bool(reads)
     if not rdist.all_true(ok):
-        return None
+        return False
     block = max(4096, int(os.environ.get("RKMH_RAW_BLOCK_KB", "16384")) << 10)
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     nw = int(os.environ.get("RKMH_RAW_WORKERS", "0")) or max(2, min(6, ((os.cpu_count() or 8) * 3 // 8) // local_world))
@@ -89,10 +136,10 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
             slots.append(api.FastqSlot(ctx, max_bytes=longest + 64))
         parts = None if filter_mode else api.LineParts(ref_names, sketch, min_matches, min_diff)
 
-        def run_pass(counter):
+        def run_pass(counter, sink=None):
             texts = []
             for fd, size, blocks in zip(fds, sizes, plan):
-                results, nxt = [b""] * len(blocks), [0]
+                results, nxt, due = [None] * len(blocks), [0], [0]
 
                 def work(slot):
                     buf = slot.text_buffer()
@@ -122,15 +169,22 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
                             res = slot.classify_raw(n)
                             if res.status != 0:
                                 state["ok"] = False
-                            elif res.nrec:
-                                results[i] = slot.filter_records(res, min_matches, min_diff) if filter_mode else slot.stream_lines(parts, res)
+                                return
+                            text = b"" if not res.nrec else (slot.filter_records(res, min_matches, min_diff) if filter_mode else slot.stream_lines(parts, res))
+                            with lock:
+                                results[i] = text
+                                if sink is not None:      # one rank: blocks leave in order as soon as they are due
+                                    while due[0] < len(blocks) and results[due[0]] is not None:
+                                        sink.stream(results[due[0]])
+                                        results[due[0]] = b""
+                                        due[0] += 1
 
                 th = [threading.Thread(target=work, args=(sl,)) for sl in slots]
                 for t in th:
                     t.start()
                 for t in th:
                     t.join()
-                texts.append(b"".join(results))
+                texts.append([r for r in results if r])
             return texts
 
         counter = t = None
@@ -144,19 +198,33 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
             ctx.synchronize()
             if not rdist.all_true(state["ok"]):
                 counter.destroy()
-                return None
+                return False
             rdist.allreduce_counter(t)                          # RCCL sum over ranks
             torch.cuda.synchronize()
             ctx.set_depth_filter(counter, min_occ)
-        texts = run_pass(None)
+        # One rank streams its blocks out while later ones are still on the device.  That commits output before the whole input is
+        # known to be regular, so it is done only where that is harmless: after the counting pass of -M (which saw every block), or
+        # into a regular file (cut back to where it was if a block is refused after all).  Into a pipe a single rank collects like
+        # the others.  (bin/rkmh hands over to its scanner mid-file instead; this front end has no scanner thread.)
+        sink = _RankOutput(out_fd, rank, world)
+        base0 = sink.base
+        streaming = world == 1 and (counter is not None or sink.regular)
+        texts = run_pass(None, sink if streaming else None)
         good = rdist.all_true(state["ok"])
+        if streaming and not good and sink.regular:
+            os.ftruncate(out_fd, base0)
         if os.environ.get("RKMH_TIMING"):
             sys.stderr.write("[rkmh timing] rank %d: device front end: %d blocks of %d file(s), %d worker threads%s\n"
                              % (rank, sum(len(b) for b in plan), len(plan), nw, "" if good else " -- refused, parsing on the host"))
         if counter is not None:
             ctx.set_depth_filter(None, 0)
             counter.destroy()
-        return texts if good else None
+        if good and not streaming:
+            for pieces in texts:          # file by file, every file's text in rank order
+                sink.pieces_of_a_file(pieces)
+        if good:
+            sink.finish()
+        return good
     finally:
         for sl in slots:
             sl.destroy()
@@ -227,14 +295,8 @@ def main_stream(argv, filter_mode=False):
         ctx.set_reference_sketches(sk, ln, ks, sketch)
     # Uncompressed FASTQ files do not pass through a host parser at all (see _device_ingest); RKMH_RAW=0 turns that off.
     if os.environ.get("RKMH_RAW", "1") != "0" and not os.environ.get("RKMH_CLI_WHOLE_PARSE"):
-        texts = _device_ingest(ctx, rank, local, world, reads, R["names"], sketch, min_occ, min_matches, min_diff, filter_mode)
-        if texts is not None:
-            for text in texts:          # file by file, every file's text in rank order
-                whole = rdist.gather_bytes(text, dst=0)
-                if rank == 0:
-                    out.write(whole)
-            if rank == 0:
-                out.flush()
+        out.flush()
+        if _device_ingest(ctx, rank, local, world, reads, R["names"], sketch, min_occ, min_matches, min_diff, filter_mode, result_fd):
             ctx.close()
             try:
                 import torch.distributed as dist

@@ -131,3 +131,22 @@ def gather_bytes(data, dst=0):
         return b"".join(outs[r][: sizes[r]].cpu().numpy().tobytes() for r in range(world))
     dist.gather(buf, None, dst=dst)
     return None
+
+
+def all_gather_int(value):
+    """Every rank's integer, in rank order (the byte counts that place the ranks' output blocks in a shared file)."""
+    import torch
+    import torch.distributed as dist
+    if not _collectives_on():
+        return [int(value)]
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    outs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [int(x.item()) for x in outs]
+
+
+def barrier():
+    import torch.distributed as dist
+    if _collectives_on():
+        dist.barrier()

@@ -421,3 +421,24 @@ def test_ranks_read_their_own_byte_range(root, data_dir, tmp_path):
     assert b"refused" in last_err[0]
     r1 = subprocess.run([sys.executable, "-m", "rkmh_amd.cli"] + st + ["-f", str(fq)], capture_output=True, cwd=root, env=dict(os.environ, RKMH_TIMING="1"), timeout=900)
     assert r1.returncode == 0 and r1.stdout == want and b"device front end: " in r1.stderr      # one process, no launcher
+    # one process with -M (its blocks stream out in order while later ones are on the device), into a pipe and into a regular file
+    # that already holds a line; two ranks into a regular file (every rank writes its blocks at their final offsets)
+    wm = one(st + ["-f", str(fq), "-f", str(fq), "-M", "2"])
+    r2 = subprocess.run([sys.executable, "-m", "rkmh_amd.cli"] + st + ["-f", str(fq), "-f", str(fq), "-M", "2"], capture_output=True, cwd=root,
+                        env=dict(os.environ, RKMH_RAW_BLOCK_KB="128"), timeout=900)
+    assert r2.returncode == 0 and r2.stdout == wm
+    for world, args, expect in ((1, st + ["-f", str(fq), "-M", "2"], one(st + ["-f", str(fq), "-M", "2"])), (2, st + ["-f", str(fq), "-f", str(fq)], want + want),
+                                (3, fl + ["-f", str(fq)], wf),
+                                (1, st + ["-f", str(fq), "-f", str(odd)], want + one(st + ["-f", str(odd)]))):   # refused half way: cut back, parsed
+        outp = tmp_path / "cli_out.txt"
+        with open(outp, "wb") as f:
+            f.write(b"# header\n")
+            f.flush()
+            port[0] += 1
+            cmd = [sys.executable, "-m", "rkmh_amd.cli"] if world == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                                                                            "--master-addr", "127.0.0.1", "--master-port", str(port[0]), "-m", "rkmh_amd.cli"]
+            r3 = subprocess.run(cmd + args, stdout=f, stderr=subprocess.PIPE, cwd=root,
+                                env=dict(os.environ, RKMH_ONE_DEVICE="1", RKMH_DIST_BACKEND="gloo", RKMH_RAW_BLOCK_KB="200"), timeout=900)
+            assert r3.returncode == 0, r3.stderr.decode()[-2000:]
+            f.write(b"# trailer\n")
+        assert outp.read_bytes() == b"# header\n" + expect + b"# trailer\n", (world, args)
