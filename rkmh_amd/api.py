@@ -368,6 +368,10 @@ class FastaLoad:
         C.memmove(self._lib.rk_fastq_slot_text(slot._h), text, len(text))
         _chk(self._lib.rk_fasta_load_put(self._h, slot._h, offset, len(text)))
 
+    def put_raw(self, slot, offset, nbytes):
+        """The first nbytes of the slot's text_buffer() (filled by the caller) become text[offset ..)."""
+        _chk(self._lib.rk_fasta_load_put(self._h, slot._h, offset, nbytes))
+
     def finish(self, total_bytes=None):
         res = FastaIndex()
         _chk(self._lib.rk_fasta_load_finish(self._h, self.text_bytes if total_bytes is None else total_bytes, C.byref(res)))

@@ -101,6 +101,90 @@ class _RankOutput:
             os.lseek(self.fd, self.base, os.SEEK_SET)   # whatever is written next continues behind the blocks
 
 
+def _references_on_device(ctx, refs, ks, sketch, max_samples, counter_slots, count_distinct):
+    """The -r files as raw text through the device (rk_fasta_load_*): a few threads read blocks into page-locked buffers and upload
+    them, the GPU strips header lines and line ends, the sketches are made from the packed bases where they lie.  For plain FASTA
+    of 64 MB or more (RKMH_RAW_REFS=1: any size, =0: never); returns the reference names, or None: parse on the host."""
+    import threading
+    env = os.environ.get("RKMH_RAW_REFS")
+    if env == "0":
+        return None
+    try:
+        sizes = [os.path.getsize(p) for p in refs]
+        for p in refs:
+            with open(p, "rb") as f:
+                if not os.path.isfile(p) or f.read(1) != b">":
+                    return None
+    except OSError:
+        return None
+    total = sum(sz + 1 for sz in sizes)          # a newline after every file
+    if env != "1" and total < (64 << 20):
+        return None
+    block = max(4096, int(os.environ.get("RKMH_RAW_BLOCK_KB", "16384")) << 10)
+    jobs, at = [], 0
+    for i, sz in enumerate(sizes):
+        for lo in range(0, sz, block):
+            hi = min(sz, lo + block)
+            jobs.append((i, lo, hi, at + lo, hi == sz))
+        at += sz + 1
+    fds = [os.open(p, os.O_RDONLY) for p in refs]
+    nw = max(1, min(6, len(jobs)))
+    slots, load = [], None
+    state, lock, nxt = {"ok": True}, threading.Lock(), [0]
+    try:
+        load = api.FastaLoad(ctx, total)
+        for _ in range(nw):
+            slots.append(api.FastqSlot(ctx, max_bytes=block + 64))
+
+        def work(slot):
+            mv = memoryview(slot.text_buffer()).cast("B")
+            while state["ok"]:
+                with lock:
+                    j = nxt[0]
+                    nxt[0] += 1
+                if j >= len(jobs):
+                    return
+                i, lo, hi, at_, last = jobs[j]
+                n, got = hi - lo, 0
+                while got < n:
+                    k = os.preadv(fds[i], [mv[got:n]], lo + got)
+                    if k <= 0:
+                        state["ok"] = False
+                        return
+                    got += k
+                if last:
+                    mv[n] = 10
+                    n += 1
+                load.put_raw(slot, at_, n)
+
+        th = [threading.Thread(target=work, args=(sl,)) for sl in slots]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if not state["ok"]:
+            return None
+        st, names, _ = load.finish(total)
+        if st != 0:
+            return None
+        if count_distinct:
+            api._chk(load._lib.rk_set_reference_count_mode(ctx._h, 1))
+        load.set_references(ks, sketch, max_samples=-1 if max_samples is None else int(max_samples), counter_slots=counter_slots)
+        if os.environ.get("RKMH_TIMING"):
+            sys.stderr.write("[rkmh timing] references through the device: %d sequences, %.0f MB of text\n" % (len(names), total / 1e6))
+        return names
+    except api.RkmhError as e:
+        sys.stderr.write("rkmh: references through the device: %s; parsing on the host\n" % e)
+        return None
+    finally:
+        for sl in slots:
+            sl.destroy()
+        if load is not None:
+            load.destroy()
+        for fd in fds:
+            os.close(fd)
+
+
 def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, min_matches, min_diff, filter_mode, out_fd):
     """This rank's byte range of every read file through the device FASTQ front end (rk_fastq_slot_*): worker threads read raw blocks
     straight into page-locked buffers, the GPU splits / checks / packs / classifies them, the lines are written in C from the names
@@ -277,16 +361,31 @@ def main_stream(argv, filter_mode=False):
     out = os.fdopen(result_fd, "wb")
     rank, local, world = rdist.init()
     ctx = api.Context(local)
-    R = api.parse_files(refs)
+    # Rank 0 alone reads the reference files -- genome-sized plain FASTA as raw text stripped on the device (_references_on_device),
+    # anything else with the host parser --, sketches them and broadcasts sketches and names; the other ranks never open them.
+    ms_filter = max_samples if (max_samples is not None and max_samples < 100000) else None   # filter: rkmh.cpp:1211
+    names = None
+    if rank == 0:
+        names = _references_on_device(ctx, refs, ks, sketch, (ms_filter if filter_mode else max_samples), 10000000 if filter_mode else 0, filter_mode)
+        if names is None:
+            Rh = api.parse_files(refs)
+            if Rh["nseq"] >= 1:
+                if filter_mode:   # 10 M slots (:1188), filled once per distinct hash
+                    ctx.set_references(Rh["bases"], Rh["offsets"], ks, sketch, max_samples=ms_filter, counter_slots=10000000, count_distinct=True)
+                else:
+                    ctx.set_references(Rh["bases"], Rh["offsets"], ks, sketch, max_samples=max_samples)
+            names = Rh["names"]
+            del Rh
+        blob = b"\0".join(names) + b"\0" if names else b""
+    else:
+        blob = None
+    blob = rdist.broadcast_bytes(blob, src=0)
+    names = blob.split(b"\0")[:-1] if blob else []
+    R = {"names": names, "nseq": len(names)}
     if R["nseq"] < 1:
         sys.stderr.write("rkmh: no reference sequences found\n")
         return 1
     if rank == 0:
-        if filter_mode:   # the sample-count filter applies when max_samples < 100000 (rkmh.cpp:1211); 10 M slots (:1188),
-            ms = max_samples if (max_samples is not None and max_samples < 100000) else None   # filled once per distinct hash
-            ctx.set_references(R["bases"], R["offsets"], ks, sketch, max_samples=ms, counter_slots=10000000, count_distinct=True)
-        else:
-            ctx.set_references(R["bases"], R["offsets"], ks, sketch, max_samples=max_samples)
         sk, ln = ctx.get_reference_sketches()
     else:
         sk = ln = None

@@ -150,3 +150,21 @@ def barrier():
     import torch.distributed as dist
     if _collectives_on():
         dist.barrier()
+
+
+def broadcast_bytes(data, src=0):
+    """A byte string from rank `src` to every rank (the reference names, so that only one rank reads the reference files)."""
+    import torch
+    import torch.distributed as dist
+    if not _collectives_on():
+        return bytes(data)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t_n = torch.tensor([len(data) if dist.get_rank() == src else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(t_n, src=src)
+    n = int(t_n.item())
+    if dist.get_rank() == src:
+        buf = torch.frombuffer(bytearray(data) if n else bytearray(1), dtype=torch.uint8).to(dev)
+    else:
+        buf = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+    dist.broadcast(buf, src=src)
+    return buf[:n].cpu().numpy().tobytes()

@@ -55,6 +55,11 @@ def _worker(rank, world, port, q):
     ok_g = ok_g and (text == b"".join((b"rank%d\n" % r) * (r + 2) for r in range(world)) if rank == 0 else text is None)
     ok_g = ok_g and rdist.gather_bytes(b"" if rank else b"only rank 0", dst=0) == (b"only rank 0" if rank == 0 else None)
     ok_g = ok_g and rdist.all_true(True) is True and rdist.all_true(rank != 1) is False
+    # the reference names travel from rank 0; byte counts are all-gathered; a barrier is a barrier
+    ok_g = ok_g and rdist.broadcast_bytes(b"a\0bc\0" * 1000 if rank == 0 else None, src=0) == b"a\0bc\0" * 1000
+    ok_g = ok_g and rdist.broadcast_bytes(b"" if rank == 0 else None, src=0) == b""
+    ok_g = ok_g and rdist.all_gather_int(10 + rank) == [10 + r for r in range(world)]
+    rdist.barrier()
     q.put((rank, lo, hi, ok_b, ok_c, ok_g))
     torch.distributed.destroy_process_group()
 

@@ -419,6 +419,13 @@ def test_ranks_read_their_own_byte_range(root, data_dir, tmp_path):
     assert ranks(2, st + ["-f", str(fq), "-M", "3", "-N", "4"], {"RKMH_RAW_BLOCK_KB": "300"}) == one(st + ["-f", str(fq), "-M", "3", "-N", "4"])
     assert ranks(3, st + ["-f", str(odd)], {"RKMH_TIMING": "1"}) == one(st + ["-f", str(odd)])
     assert b"refused" in last_err[0]
+    # rank 0 alone reads the references (here forced through the device: rk_fasta_load_*), the others get names and sketches
+    plain_ref = tmp_path / "pave.fa"
+    plain_ref.write_bytes(gzip.open(ref).read())
+    st_plain = ["stream", "-r", str(plain_ref), "-k", "16", "-s", "1000"]
+    assert ranks(2, st_plain + ["-f", str(fq)], {"RKMH_RAW_REFS": "1", "RKMH_TIMING": "1", "RKMH_RAW_BLOCK_KB": "256"}) == want
+    assert last_err[0].count(b"references through the device: 182 sequences") == 1
+    assert ranks(2, ["filter", "-r", str(plain_ref), "-k", "16", "-s", "1000", "-N", "3", "-I", "2", "-f", str(fq)], {"RKMH_RAW_REFS": "1"}) == one(fl + ["-I", "2", "-f", str(fq)])
     r1 = subprocess.run([sys.executable, "-m", "rkmh_amd.cli"] + st + ["-f", str(fq)], capture_output=True, cwd=root, env=dict(os.environ, RKMH_TIMING="1"), timeout=900)
     assert r1.returncode == 0 and r1.stdout == want and b"device front end: " in r1.stderr      # one process, no launcher
     # one process with -M (its blocks stream out in order while later ones are on the device), into a pipe and into a regular file
