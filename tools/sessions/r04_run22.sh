@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "bench_json_contract" 2>&1 | tail -15
 ( time python3 bench.py > gpurun_out/r04_c_bench.json 2> gpurun_out/r04_c_bench.err ) 2>&1 | tail -4
