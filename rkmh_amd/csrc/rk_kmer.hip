@@ -397,7 +397,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             const uint2 ri = *reinterpret_cast<const uint2*>(&rinfo[t]);
             c.t = P - ri.x < ri.y ? t : 0xFFFFFFFFu; // window number = position - read start; the last group of a read may reach past its last window
             c.y = km1_y(c.key, k);
-            c.c = km1p[c.y >> km_r];
+            c.c = km1p[(RK_KMER_ABL & 256) ? ((c.y >> km_r) & 255u) : (c.y >> km_r)];
             return c;
         };
         // the cell of the bucket whose tag equals the one in wantsh (all ones: none)
