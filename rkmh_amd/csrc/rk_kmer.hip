@@ -33,7 +33,7 @@ constexpr int KW = 64;
 constexpr int KM_MAX_T = 8;          // reads per tile (phase 2 takes eight reads in one pass; the group -> read search is unrolled for it)
 constexpr int KM_MQ = 32;            // deferred multi-posting hits (a full list is worked off at once: 16 lanes per hit)
 #ifndef RK_KMER_ABL
-#define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length, 128 filter sectors of lane pairs in one line
+#define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length, 128 filter sectors of lane pairs in one line, 256 map look-ups from a 4 KB corner of the map (L1 hits)
 #endif
 #ifndef RK_KMER_NT
 #define RK_KMER_NT 1 // the bases are read once: streaming loads keep them from evicting the filter and the map from L2
