@@ -1108,7 +1108,7 @@ static int build_index(rk_ctx* c) {
     RKCHK(c->d_base.reserve(((size_t)nb + 1) * 4));
     HIPCHK(hipMemcpy(c->d_base.p, base.data(), ((size_t)nb + 1) * 4, hipMemcpyHostToDevice));
     RKCHK(c->d_kv.reserve((nkeys + 1) * 16));
-    RKCHK(c->d_post.reserve(post.size() * 4));
+    RKCHK(c->d_post.reserve(post.size() * 4 + 256)); // the k-mer-space kernel reads a hit's first sixteen postings before it knows the list's length
     HIPCHK(hipMemcpy(c->d_fpb.p, fpb.data(), (size_t)size * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_kv.p, dense.data(), (nkeys + 1) * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_post.p, post.data(), post.size() * 4, hipMemcpyHostToDevice));

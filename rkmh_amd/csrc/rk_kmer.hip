@@ -32,8 +32,11 @@ namespace {
 constexpr int KW = 64;
 constexpr int KM_MAX_T = 8;          // reads per tile (phase 2 takes eight reads in one pass; the group -> read search is unrolled for it)
 constexpr int KM_MQ = 32;            // deferred multi-posting hits (a full list is worked off at once: 16 lanes per hit)
+#ifndef RK_KMER_MQ_MODE
+#define RK_KMER_MQ_MODE 2 // posting lists of deferred hits: 0 length, then postings (two dependent loads); 1 both at once; 2 and the next hit's during this one's counting
+#endif
 #ifndef RK_KMER_ABL
-#define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length, 128 filter sectors of lane pairs in one line, 256 map look-ups from a 4 KB corner of the map (L1 hits)
+#define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length, 128 filter sectors of lane pairs in one line, 256 map look-ups from a 4 KB corner of the map (L1 hits), 512 no hit multiset (every occurrence has rank 0), 1024 hits with a posting list dropped
 #endif
 #ifndef RK_KMER_NT
 #define RK_KMER_NT 1 // the bases are read once: streaming loads keep them from evicting the filter and the map from L2
@@ -355,29 +358,61 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         auto process_mq = [&]() { // 16 lanes walk one hit's posting list, 4 hits at a time
             wave_sync();
             const uint32_t g = (uint32_t)lane >> 4, sl = (uint32_t)lane & 15u;
-            for (uint32_t j = g; j < mqn; j += KW / 16) {
-                const uint32_t tr = mq[2 * j], off = mq[2 * j + 1];
-                const uint32_t n = ix.post[off], t = tr & 0xFFu;
-                // The 16 lanes of a hit all feed the SAME running maximum best[t]: left to themselves they issue 16 atomicMax on one LDS
-                // address per step (and the four hits of a step are often four hits of one read: 64 on one address, served one after the
-                // other).  Their candidates are reduced over the 16-lane row first (DPP) and one lane issues the atomic -- this and working a
-                // full list of deferred hits off at once took reads of a 60-member family of near-identical references (every hit: 60
-                // postings) from 2.3 to 1.1 ms per 1 M reads and BASELINE config 3's panel from 0.90 to 0.69 (profiles/r04_c3_probe.txt).
-                // (Tried and rejected: lane sl taking postings 4 sl .. 4 sl + 3 so that neighbouring lanes do not meet in one counter word --
-                // four dependent atomics per lane cost more than the four-way conflicts: family reads 1.1 -> 2.0 ms.)
-                // (Also tried and rejected: the four rows of a step -- often four hits of one read with one list -- starting at different
-                // chunks of the list, so that they do not add to the same counter words in the same instruction: 1.08 -> 1.14 ms.)
+            // The 16 lanes of a hit all feed the SAME running maximum best[t]: left to themselves they issue 16 atomicMax on one LDS
+            // address per step (and the four hits of a step are often four hits of one read: 64 on one address, served one after the
+            // other).  Their candidates are reduced over the 16-lane row first (DPP) and one lane issues the atomic -- this and working a
+            // full list of deferred hits off at once took reads of a 60-member family of near-identical references (every hit: 60
+            // postings) from 2.3 to 1.1 ms per 1 M reads and BASELINE config 3's panel from 0.90 to 0.69 (profiles/r04_c3_probe.txt).
+            // (Tried and rejected: lane sl taking postings 4 sl .. 4 sl + 3 so that neighbouring lanes do not meet in one counter word --
+            // four dependent atomics per lane cost more than the four-way conflicts: family reads 1.1 -> 2.0 ms.)
+            // (Also tried and rejected: the four rows of a step -- often four hits of one read with one list -- starting at different
+            // chunks of the list, so that they do not add to the same counter words in the same instruction: 1.08 -> 1.14 ms.)
+            auto walk = [&](uint32_t tr, const uint32_t* lp, uint32_t n, const km_pair4& pm0) {
+                const uint32_t t = tr & 0xFFu;
                 for (uint32_t c0 = 0; c0 < n; c0 += 16) { // (n is the same for the 16 lanes of the row: they run the same trips)
                     const uint32_t c = c0 + sl;
                     uint32_t v = 0;
                     if (c < n) {
-                        const km_pair4 pm = *reinterpret_cast<const km_pair4*>(ix.post + off + 1 + 2 * c); // (reference, multiplicity)
+                        km_pair4 pm = pm0; // (reference, multiplicity)
+                        if (c0) pm = *reinterpret_cast<const km_pair4*>(lp + 1 + 2 * c);
                         if ((tr >> 8) < pm.y) v = count_posting(t, __umul24(t, CW * 4u), pm.x);
                     }
                     v = (uint32_t)row_max_i32((int)v); // (candidates are < 2^31: counts below 2^15)
                     if (sl == 0 && v) atomicMax(&best[t], v);
                 }
+            };
+#if RK_KMER_MQ_MODE == 2
+            // A list's length and its first sixteen postings are requested TOGETHER (the posting array ends in 256 bytes of padding,
+            // rk_api.hip), and the NEXT hit's while this one is counted: the posting lists live in global memory and a row used to pay
+            // two dependent round trips per hit, one hit after the other.
+            uint32_t j = g;
+            uint32_t tr = 0, n = 0;
+            const uint32_t* lp = ix.post;
+            km_pair4 pm0{0u, 0u};
+            if (j < mqn) { tr = mq[2 * j]; lp = ix.post + mq[2 * j + 1]; n = lp[0]; pm0 = *reinterpret_cast<const km_pair4*>(lp + 1 + 2 * sl); }
+            while (j < mqn) {
+                const uint32_t jn = j + KW / 16;
+                uint32_t trn = 0, nn = 0;
+                const uint32_t* lpn = ix.post;
+                km_pair4 pmn{0u, 0u};
+                if (jn < mqn) { trn = mq[2 * jn]; lpn = ix.post + mq[2 * jn + 1]; nn = lpn[0]; pmn = *reinterpret_cast<const km_pair4*>(lpn + 1 + 2 * sl); }
+                walk(tr, lp, n, pm0);
+                j = jn; tr = trn; lp = lpn; n = nn; pm0 = pmn;
             }
+#else
+            for (uint32_t j = g; j < mqn; j += KW / 16) {
+                const uint32_t tr = mq[2 * j];
+                const uint32_t* lp = ix.post + mq[2 * j + 1];
+                const uint32_t n = lp[0];
+#if RK_KMER_MQ_MODE == 1
+                const km_pair4 pm0 = *reinterpret_cast<const km_pair4*>(lp + 1 + 2 * sl);
+#else
+                km_pair4 pm0{0u, 0u};
+                if (sl < n) pm0 = *reinterpret_cast<const km_pair4*>(lp + 1 + 2 * sl);
+#endif
+                walk(tr, lp, n, pm0);
+            }
+#endif
             wave_sync();
             mqn = 0;
         };
@@ -436,7 +471,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                     uint32_t* ds = dset + c.t * DS;
                     const uint32_t id = c.key + 1u;
                     uint32_t idx = (c.key * 0x9E3779B1u) >> ds_shift;
-                    uint32_t old = atomicCAS(&ds[idx], 0u, id);
+                    uint32_t old = (RK_KMER_ABL & 512) ? 0u : atomicCAS(&ds[idx], 0u, id);
                     uint32_t probes = 1;
                     while (old != 0u && probes < DS) { // the wave leaves this loop when its last lane has found a free slot
                         rank += old == id ? 1u : 0u;
@@ -452,7 +487,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                             add_posting(c.t, crow_b, val & (two ? 0x7FFu : 0xFFFFFu));
                             if (two) add_posting(c.t, crow_b, (val >> 11) & 0x7FFu);
                         }
-                    } else multi = true;
+                    } else multi = !(RK_KMER_ABL & 1024);
                 }
             }
             // hits with a posting list are deferred to the end of the drain (16 lanes then walk each list); when the list of deferred
