@@ -1072,7 +1072,7 @@ static int build_index(rk_ctx* c) {
         else if (grp.size() == 2 && grp[0].second == 1 && grp[1].second == 1 && grp[0].first < 2048 && grp[1].first < 2048)
             v = (1u << 29) | grp[0].first | (grp[1].first << 11);
         else {
-            if (post.size() + 1 + 2 * grp.size() >= 0x7fffffffull) return fail(RK_ERR_LIMIT, "postings overflow");
+            if (post.size() + 1 + 2 * grp.size() >= 0x3fffffffull) return fail(RK_ERR_LIMIT, "postings overflow"); // (offsets stay below 2^30: the k-mer-space value table uses the two top bits)
             v = 0x80000000u | (uint32_t)post.size();
             post.push_back((uint32_t)grp.size());
             for (auto& g : grp) { post.push_back(g.first); post.push_back(g.second); }
@@ -1233,7 +1233,25 @@ static int build_index(rk_ctx* c) {
                     const uint32_t val = dense[(size_t)slot * 4 + 2];
                     if (!(val >> 31) && ((val >> 29) & 3u) == 0u && ((val >> 20) & 0x1FFu) == 1u) { vid[i] = val & 0xFFFFFu; continue; } // one posting, once: the reference
                     auto it = val_id.find(val);
-                    if (it == val_id.end()) { it = val_id.emplace(val, (uint32_t)(R + vals.size())).first; vals.push_back(val); }
+                    if (it == val_id.end()) {
+                        it = val_id.emplace(val, (uint32_t)(R + vals.size() / 2)).first;
+                        // two dwords per entry: the index value and, for a list of three to six references that each hold the hash
+                        // once (what related types of one panel share), the list itself, nine bits per reference -- the kernel then
+                        // counts it in the lane that found the hit instead of fetching the posting list from global memory (KM1V_INLINE)
+                        uint32_t x = val, y = 0;
+                        if (RK_KMER_INLINE_N && (val >> 31)) {
+                            const uint32_t off = val & 0x7fffffffu, n = post[off];
+                            bool ok = n >= 3 && n <= 6;
+                            for (uint32_t q = 0; ok && q < n; ++q) ok = post[off + 1 + 2 * q] < 512u && post[off + 2 + 2 * q] == 1u;
+                            if (ok) {
+                                uint32_t r[6] = {0, 0, 0, 0, 0, 0};
+                                for (uint32_t q = 0; q < n; ++q) r[q] = post[off + 1 + 2 * q];
+                                x = 0xC0000000u | ((n - 3u) << 27) | r[0] | (r[1] << 9) | (r[2] << 18);
+                                y = r[3] | (r[4] << 9) | (r[5] << 18);
+                            }
+                        }
+                        vals.push_back(x); vals.push_back(y);
+                    }
                     vid[i] = it->second;
                 }
                 const uint32_t kbits = 2u * (uint32_t)k;
@@ -1243,7 +1261,7 @@ static int build_index(rk_ctx* c) {
                 bool built = false;
                 for (; b <= kbits && b <= 28 && !built; ++b) {
                     const uint32_t r = kbits - b, vb = km1_vbits(k, b), vmask = (1u << vb) - 1u;
-                    if ((uint64_t)R + vals.size() + 2 > (uint64_t)vmask) continue; // ids need more bits: a longer bucket index frees them
+                    if ((uint64_t)R + vals.size() / 2 + 2 > (uint64_t)vmask) continue; // ids need more bits: a longer bucket index frees them
                     const uint32_t nbk = 1u << b, rmask = r ? (1u << r) - 1u : 0u;
                     c1.assign((size_t)nbk * 4, ~(1u << vb)); // empty: tag and id all ones, flag clear
                     bool placed_all = true;

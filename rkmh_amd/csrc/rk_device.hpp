@@ -466,6 +466,9 @@ __host__ __device__ __forceinline__ int num_windows(int len, int k, int drop_las
 // bucket instead of four wide ones halve the table for the same number of keys (1 MB at C2, 2 MB for ~300 references
 // against the 4 MB L2 of an XCD -- measured: a 4 MB table costs 20-25 % of the kernel, an 8 MB one doubles its time)
 // and make bucket overflow (> 8 keys where the mean is <= 2.5) a 0.1 % event.
+#ifndef RK_KMER_INLINE_N
+#define RK_KMER_INLINE_N 1 // k-mer-space value table: lists of 3..6 references that hold the hash once each are stored inline (see build_index)
+#endif
 struct RefIndex {
     const uint4* fpb;
     const uint32_t* base; // per bucket: number of keys stored in the buckets before it => key id = base[bucket] + slot in bucket

@@ -458,7 +458,11 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             uint32_t val = vid | (1u << 20); // a single posting of multiplicity 1, in the RefIndex::kv value format
             const bool hit = vid != km_vmask && c.t != 0xFFFFFFFFu; // else: a false positive of the bit filter, or a window past its read's last
             const bool zero = vid == km_vmask - 1u;
-            if (!(RK_KMER_ABL & 32) && hit && vid >= nref && !zero) val = km1v[vid - nref]; // compound value (a few KB: L1-resident)
+            uint32_t valy = 0;
+            if (!(RK_KMER_ABL & 32) && hit && vid >= nref && !zero) { // compound value, two dwords (a few KB: L1-resident)
+                const uint2 vv = *reinterpret_cast<const uint2*>(km1v + 2u * (vid - nref));
+                val = vv.x; valy = vv.y;
+            }
             uint32_t rank = 0;
             bool multi = false;
             if ((RK_KMER_ABL & 2) ? (val == 0x12345u) : hit) {
@@ -480,7 +484,17 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                         ++probes;
                     }
                     if (old != 0u) flags[c.t] = 1; // more hits than the set holds: general path
-                    else if (!(val >> 31)) { // one posting (with multiplicity) or two single postings, stored inline
+                    else if ((val >> 30) == 3u) { // three to six references that hold the hash once each, stored inline (build_index)
+                        if (rank == 0) {
+                            const uint32_t crow_b = __umul24(c.t, CW * 4u), n3 = (val >> 27) & 3u;
+                            add_posting(c.t, crow_b, val & 511u);
+                            add_posting(c.t, crow_b, (val >> 9) & 511u);
+                            add_posting(c.t, crow_b, (val >> 18) & 511u);
+                            if (n3 > 0u) add_posting(c.t, crow_b, valy & 511u);
+                            if (n3 > 1u) add_posting(c.t, crow_b, (valy >> 9) & 511u);
+                            if (n3 > 2u) add_posting(c.t, crow_b, (valy >> 18) & 511u);
+                        }
+                    } else if (!(val >> 31)) { // one posting (with multiplicity) or two single postings, stored inline
                         const bool two = ((val >> 29) & 3u) != 0u;
                         if (rank < (two ? 1u : ((val >> 20) & 0x1FFu))) {
                             const uint32_t crow_b = __umul24(c.t, CW * 4u);

@@ -12,7 +12,7 @@ for v in "$@"; do
   for w in $v; do case $w in ENV:*) envs="$envs ${w#ENV:}";; *) cf="$cf $w";; esac; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DRK_KMER_FAST_BUILD $cf -c rkmh_amd/csrc/rk_kmer.hip -o rkmh_amd/csrc/rk_kmer.o 2>&1 | grep -i "error" 
   # the filter's bit layout (RK_KF4_*) is shared with the host-side builder in rk_api.hip
-  case "$cf" in *RK_KF4*) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $cf -c rkmh_amd/csrc/rk_api.hip -o rkmh_amd/csrc/rk_api.o 2>&1 | grep -i "error";; *) cp /tmp/rk_api.orig.o rkmh_amd/csrc/rk_api.o;; esac
+  case "$cf" in *RK_KF4*|*RK_KMER_INLINE*) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $cf -c rkmh_amd/csrc/rk_api.hip -o rkmh_amd/csrc/rk_api.o 2>&1 | grep -i "error";; *) cp /tmp/rk_api.orig.o rkmh_amd/csrc/rk_api.o;; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o rkmh_amd/lib/librkmh_amd.so rkmh_amd/csrc/rk_kernels.o rkmh_amd/csrc/rk_classify.o rkmh_amd/csrc/rk_kmer.o rkmh_amd/csrc/rk_count.o rkmh_amd/csrc/rk_call.o rkmh_amd/csrc/rk_sort.o rkmh_amd/csrc/rk_fastq.o rkmh_amd/csrc/rk_fasta.o rkmh_amd/csrc/rk_api.o rkmh_amd/csrc/rk_parse.o rkmh_amd/csrc/rk_format.o rkmh_amd/csrc/rk_synth.o -lz -lpthread
   r=$(env $envs python3 bench.py --steps 100 --warmup 20 --cpu-seconds 0 --no-host-path --no-depth-filter --no-configs --e2e-reads 0 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('%.4f ms' % d['roofline']['kernel_ms'])")
   valu=""
