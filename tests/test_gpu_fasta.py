@@ -141,9 +141,10 @@ def test_cli_references_through_the_device(root, data_dir, tmp_path):
         args = [cmd] + refs + ["-f", str(fq), "-k", "16", "-s", "1000"] + extra
         want, _ = _cli(root, args, env={"RKMH_RAW_REFS": "0"})
         assert len(want) > 100, (cmd, extra)
-        for env in ({"RKMH_RAW_REFS": "1"}, {"RKMH_RAW_REFS": "1", "RKMH_RAW_BLOCK_KB": "64", "RKMH_RAW_WORKERS": "3"}):
-            got, err = _cli(root, args, env=env)
-            assert got == want, (cmd, extra, env)
+        for env, more in (({"RKMH_RAW_REFS": "1"}, []), ({"RKMH_RAW_REFS": "1", "RKMH_RAW_BLOCK_KB": "64", "RKMH_RAW_WORKERS": "3"}, []),
+                          ({"RKMH_RAW_REFS": "1", "RKMH_RAW_BLOCK_KB": "128"}, ["--devices", "0,0"])):      # two contexts: the text goes to the first
+            got, err = _cli(root, args + more, env=env)
+            assert got == want, (cmd, extra, env, more)
             assert b"references through the device: " in err, err[-800:]
     # CRLF references: refused by the device, parsed on the host, same output
     crlf = tmp_path / "crlf.fa"
