@@ -137,25 +137,28 @@ def _references_on_device(ctx, refs, ks, sketch, max_samples, counter_slots, cou
             slots.append(api.FastqSlot(ctx, max_bytes=block + 64))
 
         def work(slot):
-            mv = memoryview(slot.text_buffer()).cast("B")
-            while state["ok"]:
-                with lock:
-                    j = nxt[0]
-                    nxt[0] += 1
-                if j >= len(jobs):
-                    return
-                i, lo, hi, at_, last = jobs[j]
-                n, got = hi - lo, 0
-                while got < n:
-                    k = os.preadv(fds[i], [mv[got:n]], lo + got)
-                    if k <= 0:
-                        state["ok"] = False
+            try:
+                mv = memoryview(slot.text_buffer()).cast("B")
+                while state["ok"]:
+                    with lock:
+                        j = nxt[0]
+                        nxt[0] += 1
+                    if j >= len(jobs):
                         return
-                    got += k
-                if last:
-                    mv[n] = 10
-                    n += 1
-                load.put_raw(slot, at_, n)
+                    i, lo, hi, at_, last = jobs[j]
+                    n, got = hi - lo, 0
+                    while got < n:
+                        k = os.preadv(fds[i], [mv[got:n]], lo + got)
+                        if k <= 0:
+                            raise OSError("short read on %s" % refs[i])
+                        got += k
+                    if last:
+                        mv[n] = 10
+                        n += 1
+                    load.put_raw(slot, at_, n)
+            except Exception as e:      # (an exception would only end this thread: the text would be incomplete and nobody would know)
+                state["err"] = e
+                state["ok"] = False
 
         th = [threading.Thread(target=work, args=(sl,)) for sl in slots]
         for t in th:
@@ -163,6 +166,8 @@ def _references_on_device(ctx, refs, ks, sketch, max_samples, counter_slots, cou
         for t in th:
             t.join()
         if not state["ok"]:
+            if "err" in state:
+                sys.stderr.write("rkmh: references through the device: %s; parsing on the host\n" % state["err"])
             return None
         st, names, _ = load.finish(total)
         if st != 0:
@@ -226,48 +231,54 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
                 results, nxt, due = [None] * len(blocks), [0], [0]
 
                 def work(slot):
-                    buf = slot.text_buffer()
-                    mv = memoryview(buf).cast("B")
-                    while state["ok"]:
-                        with lock:
-                            i = nxt[0]
-                            nxt[0] += 1
-                        if i >= len(blocks):
-                            return
-                        s0, s1 = blocks[i]
-                        n, got = s1 - s0, 0
-                        while got < n:
-                            k = os.preadv(fd, [mv[got:n]], s0 + got)
-                            if k <= 0:
-                                state["ok"] = False
-                                return
-                            got += k
-                        if s1 == size and mv[n - 1] != 10:
-                            mv[n] = 10          # a last line without its newline (the slot holds spare bytes)
-                            n += 1
-                        if counter is not None:
-                            st, _ = slot.count_raw(n, counter)
-                            if st != 0:
-                                state["ok"] = False
-                        else:
-                            res = slot.classify_raw(n)
-                            if res.status != 0:
-                                state["ok"] = False
-                                return
-                            text = b"" if not res.nrec else (slot.filter_records(res, min_matches, min_diff) if filter_mode else slot.stream_lines(parts, res))
+                    try:
+                        buf = slot.text_buffer()
+                        mv = memoryview(buf).cast("B")
+                        while state["ok"]:
                             with lock:
-                                results[i] = text
-                                if sink is not None:      # one rank: blocks leave in order as soon as they are due
-                                    while due[0] < len(blocks) and results[due[0]] is not None:
-                                        sink.stream(results[due[0]])
-                                        results[due[0]] = b""
-                                        due[0] += 1
+                                i = nxt[0]
+                                nxt[0] += 1
+                            if i >= len(blocks):
+                                return
+                            s0, s1 = blocks[i]
+                            n, got = s1 - s0, 0
+                            while got < n:
+                                k = os.preadv(fd, [mv[got:n]], s0 + got)
+                                if k <= 0:
+                                    state["ok"] = False
+                                    return
+                                got += k
+                            if s1 == size and mv[n - 1] != 10:
+                                mv[n] = 10          # a last line without its newline (the slot holds spare bytes)
+                                n += 1
+                            if counter is not None:
+                                st, _ = slot.count_raw(n, counter)
+                                if st != 0:
+                                    state["ok"] = False
+                            else:
+                                res = slot.classify_raw(n)
+                                if res.status != 0:
+                                    state["ok"] = False
+                                    return
+                                text = b"" if not res.nrec else (slot.filter_records(res, min_matches, min_diff) if filter_mode else slot.stream_lines(parts, res))
+                                with lock:
+                                    results[i] = text
+                                    if sink is not None:      # one rank: blocks leave in order as soon as they are due
+                                        while due[0] < len(blocks) and results[due[0]] is not None:
+                                            sink.stream(results[due[0]])
+                                            results[due[0]] = b""
+                                            due[0] += 1
+                    except Exception as e:      # (an exception would only end this thread and its block would be missing from the output)
+                        state["err"] = e
+                        state["ok"] = False
 
                 th = [threading.Thread(target=work, args=(sl,)) for sl in slots]
                 for t in th:
                     t.start()
                 for t in th:
                     t.join()
+                if "err" in state:
+                    raise state["err"]
                 texts.append([r for r in results if r])
             return texts
 
