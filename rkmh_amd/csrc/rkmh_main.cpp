@@ -546,11 +546,13 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     std::mutex fm;
     std::map<int64_t, int64_t> fail_at; // block number -> its first byte
     std::mutex tm;
+    std::atomic<int> live{(int)eng.w.size()};
     auto work = [&](size_t wi) {
         for (int k = 0; k < (eng.two_slots ? 2 : 1); ++k)
             if (!eng.w[wi].slot[k] && rk_fastq_slot_create(g.ctx[eng.w[wi].dev], eng.block, &eng.w[wi].slot[k]) != RK_OK) {
-                // (memory for another slot ran out: the other workers carry on)
+                // (memory for another slot ran out: the other workers carry on -- unless this was the last one)
                 fprintf(stderr, "rkmh: worker %zu: %s\n", wi, rk_last_error());
+                if (live.fetch_sub(1) == 1) { fprintf(stderr, "rkmh: no worker of the device front end could start\n"); fail_exit(); }
                 return;
             }
         const int64_t window = (int64_t)eng.w.size() * 4 + 2;
