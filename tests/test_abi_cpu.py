@@ -111,3 +111,61 @@ def test_synth_generator_deterministic_and_sharded(data_dir):
     r = b[:450000].reshape(3000, 150)
     assert set(np.unique(r)) <= set(b"ACGTNWY")
     assert 0 < (r == ord("N")).any(axis=1).sum() < 30
+
+
+def test_block_formatters_match_the_line_formatter():
+    """rk_fastq_stream_lines / rk_fastq_filter_records (rk_format.cpp: the output of a whole classified block written from the raw
+    text) against rk_format_stream_line per read and a literal restatement of filter's rule (rkmh.cpp:1292-1300 with the decision of
+    equiv.hpp:324-353) -- host code only, on a hand-made result structure."""
+    import ctypes as C
+    lib = rkmh_amd.load_library()
+    rng = np.random.default_rng(9)
+    ref_names = [b"ref%d|with|bars" % i for i in range(7)] + [b"a-very-long-reference-name-" + b"x" * 70]
+    recs, text = [], bytearray()
+    n = 500
+    out4 = np.zeros((n, 4), np.int32)
+    name_off, name_len, seq_off, seq_len, qual_off = (np.zeros(n, np.uint32) for _ in range(5))
+    for i in range(n):
+        nm = b"read_%d/%d" % (i, i % 3) + (b"Z" * int(rng.integers(0, 40)))
+        ln = int(rng.integers(1, 200))
+        sq = bytes(rng.choice(np.frombuffer(b"ACGTacgtNn", np.uint8), size=ln))
+        ql = bytes(rng.integers(33, 127, size=ln, dtype=np.uint8))
+        text += b"@"
+        name_off[i], name_len[i] = len(text), len(nm)
+        text += nm + b" description\n"
+        seq_off[i], seq_len[i] = len(text), ln
+        text += sq + b"\n+\n"
+        qual_off[i] = len(text)
+        text += ql + b"\n"
+        out4[i] = (int(rng.integers(0, len(ref_names))), int(rng.integers(-1, 30)), int(rng.integers(-3, 12)), int(rng.integers(0, 140)))
+        recs.append((nm, sq, ql))
+    text += b"\0" * 64      # the slot's buffer has this slack: names are copied in 16-byte steps
+    res = api.FastqResult()
+    res.status, res.nrec = 0, n
+    res.out4 = out4.ctypes.data_as(C.POINTER(C.c_int32))
+    for fld, arr in (("name_off", name_off), ("name_len", name_len), ("seq_off", seq_off), ("seq_len", seq_len), ("qual_off", qual_off)):
+        setattr(res, fld, arr.ctypes.data_as(C.POINTER(C.c_uint32)))
+    tbuf = (C.c_char * len(text)).from_buffer(text)
+    for sketch, mm, md in ((1000, -1, 0), (2000, 5, 2), (37, 100, -5)):
+        parts = api.LineParts(ref_names, sketch, mm, md)
+        cap = int(lib.rk_fastq_stream_lines_bound(parts._h, C.byref(res)))
+        dst = C.create_string_buffer(cap)
+        got = lib.rk_fastq_stream_lines(parts._h, C.byref(res), tbuf, dst, cap)
+        want = b"".join(api.format_stream_line(ref_names[int(r[0])], recs[i][0], int(r[1]), int(r[2]), int(r[3]), sketch, mm, md) for i, r in enumerate(out4))
+        assert got == len(want) and dst.raw[:got] == want, (sketch, mm, md)
+        assert lib.rk_fastq_stream_lines(parts._h, C.byref(res), tbuf, dst, cap - 1) < 0            # a buffer below the bound is refused
+        parts.destroy()
+        want_f = bytearray()
+        for i, r in enumerate(out4):
+            shared, diff_ok = (0, 0 > md) if r[1] <= 0 else (int(r[1]), (int(r[2]) - (1 if r[0] == 0 else 0)) > md)
+            if r[3] <= 0 or shared < mm or not diff_ok:
+                continue
+            up = bytes((c - 32) if c > 91 else c for c in recs[i][1])
+            want_f += b">" + recs[i][0] + b"\n" + up + b"\n+\n" + recs[i][2] + b"\n"
+        cap = int(lib.rk_fastq_filter_records_bound(C.byref(res)))
+        dst = C.create_string_buffer(cap)
+        got = lib.rk_fastq_filter_records(C.byref(res), tbuf, mm, md, dst, cap)
+        assert got == len(want_f) and dst.raw[:got] == bytes(want_f), (mm, md)
+    bad = api.FastqResult()
+    bad.status = 4
+    assert lib.rk_fastq_filter_records(C.byref(bad), tbuf, 0, 0, dst, cap) < 0                       # a refused block has nothing to print
