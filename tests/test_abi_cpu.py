@@ -169,3 +169,36 @@ def test_block_formatters_match_the_line_formatter():
     bad = api.FastqResult()
     bad.status = 4
     assert lib.rk_fastq_filter_records(C.byref(bad), tbuf, 0, 0, dst, cap) < 0                       # a refused block has nothing to print
+
+
+def test_cut_before_finds_record_starts(tmp_path):
+    """cli._cut_before (how ranks and blocks turn byte ranges into ranges of whole records): every cut is a record start, cuts are
+    monotone, never past the position asked for and never far before it -- on records whose quality strings begin with '@' and '+'."""
+    from rkmh_amd import cli
+    rng = np.random.default_rng(4)
+    recs, starts, pos = [], [], 0
+    for i in range(3000):
+        ln = int(rng.integers(1, 300))
+        q = bytearray(rng.integers(33, 127, size=ln, dtype=np.uint8).tobytes())
+        if i % 3 == 0:
+            q[0] = ord("@")
+        if i % 5 == 0:
+            q[0] = ord("+")
+        r = b"@r%d extra\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=ln)) + b"\n+\n" + bytes(q) + b"\n"
+        starts.append(pos)
+        pos += len(r)
+        recs.append(r)
+    p = tmp_path / "r.fq"
+    p.write_bytes(b"".join(recs))
+    size, sset = pos, set(starts)
+    fd = os.open(str(p), os.O_RDONLY)
+    try:
+        assert cli._cut_before(fd, size, 0) == 0 and cli._cut_before(fd, size, size) == size and cli._cut_before(fd, size, size + 5) == size
+        last = 0
+        for q in sorted(int(x) for x in rng.integers(1, size, size=400)):
+            c = cli._cut_before(fd, size, q)
+            assert c in sset and c <= q and c >= last, (q, c)
+            assert q - c < 3 * 640, (q, c)      # (a record start counts once its '+' line is in sight: the cut may lie a record or two back)
+            last = c
+    finally:
+        os.close(fd)

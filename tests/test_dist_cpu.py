@@ -60,13 +60,38 @@ def _worker(rank, world, port, q):
     ok_g = ok_g and rdist.broadcast_bytes(b"" if rank == 0 else None, src=0) == b""
     ok_g = ok_g and rdist.all_gather_int(10 + rank) == [10 + r for r in range(world)]
     rdist.barrier()
+    # 6. the ranks' output blocks land in rank order without travelling: pwrite at final offsets into a regular file, in turn into a pipe
+    out_path = os.environ.get("RKMH_TEST_OUT")
+    if out_path:
+        from rkmh_amd import cli
+        fd = os.open(out_path, os.O_WRONLY)
+        sink = cli._RankOutput(fd, rank, world)
+        ok_g = ok_g and sink.regular
+        for f in range(2):      # two input files: every file's text in rank order, file after file
+            sink.pieces_of_a_file([b"file%d rank%d piece%d\n" % (f, rank, j) * (50 + 7 * rank) for j in range(3)])
+        sink.finish()
+        os.close(fd)
+        fifo = out_path + ".fifo"
+        fd = os.open(fifo, os.O_WRONLY)
+        sink = cli._RankOutput(fd, rank, world)
+        ok_g = ok_g and not sink.regular
+        sink.pieces_of_a_file([b"pipe rank%d\n" % rank * 1000])
+        os.close(fd)
     q.put((rank, lo, hi, ok_b, ok_c, ok_g))
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_plumbing_over_gloo():
+def test_two_rank_plumbing_over_gloo(tmp_path):
     world = 2
     port = _free_port()
+    out = tmp_path / "shared_out.txt"
+    out.write_bytes(b"")
+    os.mkfifo(str(out) + ".fifo")
+    os.environ["RKMH_TEST_OUT"] = str(out)
+    import threading
+    piped = []
+    reader = threading.Thread(target=lambda: piped.append(open(str(out) + ".fifo", "rb").read()))
+    reader.start()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -77,6 +102,11 @@ def test_two_rank_plumbing_over_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == 1000003
+    reader.join(timeout=60)
+    del os.environ["RKMH_TEST_OUT"]
+    want = b"".join(b"file%d rank%d piece%d\n" % (f, r, j) * (50 + 7 * r) for f in range(2) for r in range(world) for j in range(3))
+    assert out.read_bytes() == want
+    assert piped == [b"".join(b"pipe rank%d\n" % r * 1000 for r in range(world))]
     for r in res:
         assert r[3] and r[4] and r[5], r
 
