@@ -36,7 +36,7 @@ constexpr int KM_MQ = 32;            // deferred multi-posting hits (a full list
 #define RK_KMER_MQ_MODE 2 // posting lists of deferred hits: 0 length, then postings (two dependent loads); 1 both at once; 2 and the next hit's during this one's counting
 #endif
 #ifndef RK_KMER_ABL
-#define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length, 128 filter sectors of lane pairs in one line, 256 map look-ups from a 4 KB corner of the map (L1 hits), 512 no hit multiset (every occurrence has rank 0), 1024 hits with a posting list dropped
+#define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length, 128 filter sectors of lane pairs in one line, 256 map look-ups from a 4 KB corner of the map (L1 hits), 512 no hit multiset (every occurrence has rank 0), 1024 hits with a posting list dropped, 2048 two of three lanes' filter sectors in one 32-byte piece
 #endif
 #ifndef RK_KMER_NT
 #define RK_KMER_NT 1 // the bases are read once: streaming loads keep them from evicting the filter and the map from L2
@@ -585,6 +585,12 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                     // what halving the filter's L2 requests would buy before anything is built for it
                     const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sect_b, 0x111, 0xf, 0xf, true); // row_shr:1
                     if (lane & 1) sect_b = (nb & ~31u) | 16u; else sect_b &= ~31u;
+                }
+                if (RK_KMER_ABL & 2048) { // timing experiment (WRONG results): two of every three lanes share 32 bytes -- the filter requests of
+                    // six-window groups (22.5 per read instead of 34) at today's instruction count
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sect_b, 0x111, 0xf, 0xf, true); // row_shr:1
+                    const uint32_t l3 = (uint32_t)lane % 3u;
+                    if (l3 == 2u) sect_b = (nb & ~31u) | 16u; else if (l3 == 1u) sect_b &= ~31u;
                 }
                 e0v[s] = P0 | (t << 12);
                 fq[s] = 0u;
