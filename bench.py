@@ -136,7 +136,8 @@ def e2e_stream(n, L, rb, ro, synth):
 
 def c4_full_size(api, synth, genome_mb=3100, nreads=10000000, L=150):
     """BASELINE config 4 at its own size, whole process: `bin/rkmh filter -k 20 -s 2000` (and with -M 2) of 10 M reads (90 % drawn from
-    the genome, 10 % from the PaVE panel) against a synthetic 24-sequence genome of 3.1 Gb written as FASTA in /tmp.  Each setting
+    the genome, 10 % from data/hpv_16_allFasta.fa) against a synthetic genome of 24 sequences with hg38's chromosome lengths (3.1 Gb,
+    bases uniform at random) written as FASTA in /tmp.  Each setting
     runs twice (the second finds the files in the page cache); the run with the host parsers (RKMH_RAW=0 RKMH_RAW_REFS=0) is timed
     once beside it and its output must be byte-identical."""
     import hashlib
@@ -149,13 +150,17 @@ def c4_full_size(api, synth, genome_mb=3100, nreads=10000000, L=150):
     try:
         t0 = time.perf_counter()
         rng = np.random.default_rng(3)
-        chrom = genome_mb * 1000000 // 24
+        # 24 sequences with the lengths of hg38's primary chromosomes, scaled to genome_mb million bases in all
+        hg38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622, 133275309,
+                114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+        scale = genome_mb * 1e6 / sum(hg38)
         lut = np.frombuffer(b"ACGT" * 64, dtype=np.uint8)
         parts, goffs = [], [0]
         with open(fa, "wb") as f:
-            for c in range(24):
+            for c, full in enumerate(hg38):
+                chrom = max(1000, int(full * scale))
                 s_ = lut[np.frombuffer(rng.bytes(chrom), dtype=np.uint8)]
-                f.write(b">chr%d synthetic\n" % (c + 1))
+                f.write(b">chr%s synthetic\n" % (b"X" if c == 22 else b"Y" if c == 23 else b"%d" % (c + 1)))
                 for lo in range(0, chrom, 1 << 28):
                     f.write(s_[lo: lo + (1 << 28)].tobytes())
                 f.write(b"\n")
@@ -164,7 +169,7 @@ def c4_full_size(api, synth, genome_mb=3100, nreads=10000000, L=150):
         gb = np.concatenate(parts + [np.zeros(16, np.uint8)])
         del parts
         go = np.array(goffs, dtype=np.uint64)
-        hpv = api.parse_files([os.path.join(ROOT, "tests", "golden", "data", "all_pave_ref.fa.gz")])
+        hpv = api.parse_files([os.path.join(ROOT, "tests", "golden", "data", "hpv_16_allFasta.fa.gz")])
         nh = nreads // 10
         with open(fq, "wb") as f:
             for src_b, src_o, m, tag in ((gb, go, nreads - nh, ord("g")), (hpv["bases"], hpv["offsets"], nh, ord("v"))):
@@ -182,7 +187,7 @@ def c4_full_size(api, synth, genome_mb=3100, nreads=10000000, L=150):
                     f.write(rec.tobytes())
         del gb
         gen_s = time.perf_counter() - t0
-        res = {"genome_bases": chrom * 24, "fasta_bytes": os.path.getsize(fa), "reads": nreads, "fastq_bytes": os.path.getsize(fq),
+        res = {"genome_bases": int(goffs[-1]), "genome_scale_of_hg38": scale, "fasta_bytes": os.path.getsize(fa), "reads": nreads, "fastq_bytes": os.path.getsize(fq),
                "k": 20, "sketch_size": 2000, "inputs_generated_s": gen_s,
                "note": "bin/rkmh filter, whole process (start-up, 3.1 GB of reference FASTA, sketches, 10 M reads, output); wall_s = device front "
                        "ends (default), host_parser_wall_s = RKMH_RAW=0 RKMH_RAW_REFS=0; outputs compared byte for byte"}
