@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from rkmh_amd import api, synth
 out, n, L = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4000000, 150
-refs = api.parse_files([os.path.join(ROOT, "tests/golden/data/all_pave_ref.fa.gz")])
+files = ["all_pave_ref"] if not os.environ.get("C3_PANEL") else ["all_pave_ref", "zika.refs", "dengue", "new_refs", "hpv_16", "zika", "yellow_fever", "hpv_16_allFasta"]
+refs = api.parse_files([os.path.join(ROOT, "tests/golden/data/%s.fa.gz" % f) for f in files])
 rb, ro = refs["bases"], refs["offsets"]
 with open(out, "wb") as f:
     for lo in range(0, n, 1000000):
