@@ -1756,42 +1756,57 @@ static int main_hpv16(int argc, char** argv) {
     }
     tick("classify", t0);
     const bool den_read = getenv("RKMH_HPV16_SIM") && !strcmp(getenv("RKMH_HPV16_SIM"), "read");   // U14: similarity denominator
-    std::string buf;
-    char num[64];
-    std::vector<int> order;
-    std::vector<double> sims;
-    auto ranked = [&](const int32_t* cnts, int first, int n, int hashnum, const std::vector<std::string>& names, std::string& a, std::string& b) {
-        // sort_by_similarity (U14): intersection / list size, descending, ties in reference order
-        order.resize((size_t)n); sims.resize((size_t)n);
-        for (int i = 0; i < n; ++i) {
-            order[(size_t)i] = i;
-            const double den = den_read ? (double)hashnum : (double)full_len[(size_t)(first + i)];
-            sims[(size_t)i] = den > 0 ? (double)cnts[i] / den : 0.0;
-        }
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sims[(size_t)x] > sims[(size_t)y]; });
-        for (int i : order) {
-            a += names[(size_t)i]; a += ':';
-            snprintf(num, sizeof num, "%g", sims[(size_t)i]);        // ostream << double
-            a += num; a += ';';
-            b += std::to_string(cnts[i]); b += ';';
+    // The lines (one stable sort and a dozen "%g" per read) are written by all granted CPUs, 16 k reads per piece, and leave in input order.
+    auto emit_range = [&](int64_t lo, int64_t hi, std::string& buf) {
+        char num[64];
+        std::vector<int> order;
+        std::vector<double> sims;
+        auto ranked = [&](const int32_t* cnts, int first, int n, int hashnum, const std::vector<std::string>& names, std::string& a, std::string& b) {
+            // sort_by_similarity (U14): intersection / list size, descending, ties in reference order
+            order.resize((size_t)n); sims.resize((size_t)n);
+            for (int i = 0; i < n; ++i) {
+                order[(size_t)i] = i;
+                const double den = den_read ? (double)hashnum : (double)full_len[(size_t)(first + i)];
+                sims[(size_t)i] = den > 0 ? (double)cnts[i] / den : 0.0;
+            }
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sims[(size_t)x] > sims[(size_t)y]; });
+            for (int i : order) {
+                a += names[(size_t)i]; a += ':';
+                snprintf(num, sizeof num, "%g", sims[(size_t)i]);        // ostream << double
+                a += num; a += ';';
+                b += std::to_string(cnts[i]); b += ';';
+            }
+        };
+        std::string la, lb, sa, sb;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t len = (int64_t)(reads.offsets[i + 1] - reads.offsets[i]);
+            int64_t hashnum = 0;
+            for (int k : ks) { const int64_t nw = pol.drop_last_window ? len - k : len - k + 1; if (nw > 0) hashnum += nw; }
+            const int32_t* r = &out4[(size_t)i * 4];
+            const int32_t* t = &tail[(size_t)i * (size_t)(nlin + nsub)];
+            buf += reads.names + reads.name_offsets[i]; buf += '\t';
+            buf += types.names + types.name_offsets[r[0]]; buf += '\t';
+            buf += std::to_string(r[1]); buf += '/'; buf += std::to_string(hashnum); buf += '\t';
+            la.clear(); lb.clear(); sa.clear(); sb.clear();
+            ranked(t, ntype, nlin, (int)hashnum, lin_names, la, lb);
+            ranked(t + nlin, ntype + nlin, nsub, (int)hashnum, sublin_names, sa, sb);
+            buf += la; buf += '\t'; buf += sa; buf += '\t'; buf += lb; buf += '\t'; buf += sb; buf += '\n';
         }
     };
-    for (int64_t i = 0; i < reads.nseq; ++i) {
-        const int64_t len = (int64_t)(reads.offsets[i + 1] - reads.offsets[i]);
-        int64_t hashnum = 0;
-        for (int k : ks) { const int64_t nw = pol.drop_last_window ? len - k : len - k + 1; if (nw > 0) hashnum += nw; }
-        const int32_t* r = &out4[(size_t)i * 4];
-        const int32_t* t = &tail[(size_t)i * (size_t)(nlin + nsub)];
-        buf += reads.names + reads.name_offsets[i]; buf += '\t';
-        buf += types.names + types.name_offsets[r[0]]; buf += '\t';
-        buf += std::to_string(r[1]); buf += '/'; buf += std::to_string(hashnum); buf += '\t';
-        std::string la, lb, sa, sb;
-        ranked(t, ntype, nlin, (int)hashnum, lin_names, la, lb);
-        ranked(t + nlin, ntype + nlin, nsub, (int)hashnum, sublin_names, sa, sb);
-        buf += la; buf += '\t'; buf += sa; buf += '\t'; buf += lb; buf += '\t'; buf += sb; buf += '\n';
-        if (buf.size() > (1u << 22)) { fwrite(buf.data(), 1, buf.size(), stdout); buf.clear(); }
+    {
+        const int64_t PIECE = 1 << 14;
+        const int nth = std::max(1, std::min(granted_cpus_main(), 32));
+        const int64_t npieces = (reads.nseq + PIECE - 1) / PIECE;
+        for (int64_t p0 = 0; p0 < npieces; p0 += nth) { // a wave of pieces at a time: memory stays bounded, the order is the input's
+            const int64_t np = std::min<int64_t>(nth, npieces - p0);
+            std::vector<std::string> bufs((size_t)np);
+            std::vector<std::thread> th;
+            for (int64_t q = 0; q < np; ++q)
+                th.emplace_back([&, q] { emit_range((p0 + q) * PIECE, std::min(reads.nseq, (p0 + q + 1) * PIECE), bufs[(size_t)q]); });
+            for (auto& t : th) t.join();
+            for (auto& b : bufs) fwrite(b.data(), 1, b.size(), stdout);
+        }
     }
-    fwrite(buf.data(), 1, buf.size(), stdout);
     tick("emit", t0);
     if (cnt) rk_counter_destroy(cnt);
     rk_seqset_free(&types); rk_seqset_free(&subs);
