@@ -1280,6 +1280,8 @@ def test_kmer_space_filter_of_any_sector_count(root, entries, k):
     chosen by entries per sector.  The knob is read once per process, so each forced density runs in its own interpreter: 30 000
     C2 reads (1 in 1000 with an N) and 5 000 reads of unequal length against the oracle, sector counts that are no power of two,
     from far sparser to far denser than the shipped rule."""
+    if os.environ.get("RKMH_KMER_PREFILTER") == "0":
+        pytest.skip("the k-mer-space form is switched off for this run")
     code = r"""
 import os, sys
 import numpy as np
@@ -1415,6 +1417,8 @@ def test_every_kernel_form_at_scale(orc, data_dir, ks, depth, L):
                 c.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt)
                 c.set_depth_filter(cnt, 2)
             d_out.zero_()
+            torch.cuda.synchronize()   # (the fill runs on torch's stream, the classification on the context's: without this the fill can
+                                       # land on rows the kernel has already written -- seen once in ~40 runs, with another process on the GPU)
             c.classify_device_all(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=L)
             c.synchronize()
             got = d_out.cpu().numpy()
