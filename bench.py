@@ -449,6 +449,7 @@ def main():
         d_os.append(torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev))
         d_outs.append(torch.zeros((n, 4), dtype=torch.int32, device=dev))
     qb, qo = qbs[0], qos[0]
+    torch.cuda.synchronize()                         # (uploads and fills above ran on the default stream)
     tstream = torch.cuda.Stream(device=dev)          # the kernels AND the timing events go on this stream
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream

@@ -456,6 +456,8 @@ def main_stream(argv, filter_mode=False):
         slots = 10000000 if filter_mode else 200000000  # rkmh.cpp:1187 / :739
         dev = "cuda:%d" % local
         t = torch.zeros(slots, dtype=torch.int32, device=dev)
+        if t.is_cuda:
+            torch.cuda.synchronize()                 # (the fill runs on torch's stream, the count pass on the context's)
         counter = api.Counter(ctx, slots=slots, device_ptr=t.data_ptr())
         ctx.count_batch(bases, offs, counter)       # pass 1 on this rank's reads
         ctx.synchronize()

@@ -1330,6 +1330,7 @@ def test_count_pass_slot_partitioned_degenerate_batches(ctx, pave):
         for form in ("0", "1"):
             os.environ["RKMH_COUNT_BINS"] = form
             t = torch.zeros(slots, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()   # (the fill is torch's stream's, the count pass the context's)
             cnt = rkmh_amd.Counter(ctx, slots=slots, device_ptr=t.data_ptr())
             ctx.count_device(d_b.data_ptr(), d_o.data_ptr(), len(reads), cnt)
             torch.cuda.synchronize()
