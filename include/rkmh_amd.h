@@ -108,7 +108,10 @@ int rk_hash_intersection(rk_ctx* ctx, const uint64_t* a, int a_start, int a_len,
 
 /* HASHTCounter (ctor src/rkmh.cpp:739,742,1187; increment :335; get :1218,1260): int32 slots in HBM,
  * slot = key % slots.  rk_counter_wrap adopts caller-owned DEVICE memory (e.g. a torch tensor, so
- * that the table can be all-reduced over RCCL between pass 1 and pass 2 of the -M path). */
+ * that the table can be all-reduced over RCCL between pass 1 and pass 2 of the -M path).  The library orders ITS passes into a
+ * table among themselves; work the CALLER has in flight on the memory (a fill on torch's stream, a collective) must have
+ * finished -- or be on the stream given to the pass -- before a pass is started: the passes run on the context's or the given
+ * stream, not on the caller's. */
 int rk_counter_create(rk_ctx* ctx, uint64_t slots, rk_counter** out);
 int rk_counter_wrap(rk_ctx* ctx, void* d_counts_int32, uint64_t slots, rk_counter** out);
 void rk_counter_destroy(rk_counter* c);   /* allowed after rk_ctx_destroy of its context; every other call is not */
