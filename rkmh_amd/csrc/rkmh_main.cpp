@@ -1045,10 +1045,14 @@ static int main_stream(int argc, char** argv) {
     }
     fflush(stdout);
     tick("main loop + flush", t0);
-    eng.destroy();
-    if (refs_owned) rk_seqset_free(&refs);
-    group.destroy();
-    tick("teardown", t0);
+    // everything is written and the process ends here: releasing page-locked buffers, streams and contexts one by one took 0.08 s of
+    // a 0.55 s run and produces nothing (the operating system takes it all back at once); a profiler's run keeps the orderly way out
+    if (getenv("RKMH_SLOW_EXIT")) {
+        eng.destroy();
+        if (refs_owned) rk_seqset_free(&refs);
+        group.destroy();
+        tick("teardown", t0);
+    }
     done_exit();
 }
 
