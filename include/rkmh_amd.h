@@ -188,6 +188,15 @@ int rk_set_kmer_form(rk_ctx* ctx, int enable);
  * The table is read as it is AT THIS CALL (the fused kernel uses a one-bit-per-slot snapshot of the comparison): set the
  * filter after pass 1 (rk_count_batch*, and after any all-reduce of the table), and again if the table changes later. */
 int rk_set_depth_filter(rk_ctx* ctx, rk_counter* counter, int min_kmer_occ);
+/* How much of min_num (row field 3) the caller needs while a depth filter is set.  The reference uses num_mins in ONE predicate,
+ * `depth_filter = num_mins <= min_matches` (src/rkmh.cpp:938; filter: `read_min_lens[i] <= 0`, :1292), so a caller that compares
+ * with n needs min(num_mins, n + 1) and nothing more.  bound < 0 (default): row field 3 is num_mins exactly -- every window is
+ * looked up in the depth map.  bound >= 0: row field 3 = min(num_mins, bound); max_id / max_shared / diff are unchanged (the mask
+ * changes them only through windows whose hash is a sketch hash: one keep bit per index key, taken when the filter is set), and
+ * only the first windows of a read -- until `bound` of them survive -- are looked up by slot.  bound 0 looks up none.
+ * May be called before or after rk_set_depth_filter (the snapshot is rebuilt in the other form). */
+int rk_set_min_num_bound(rk_ctx* ctx, int bound);
+int rk_min_num_bound(const rk_ctx* ctx);
 
 /* Pass 1 of the -M path (src/rkmh.cpp:904-910): hash every read and increment the counter.
  * Passes into ONE counter are ordered by the library (each waits on its stream for the previous one: large batches add their

@@ -90,6 +90,8 @@ _SIGS = {
     "rk_get_reference_sketches": (C.c_int, [C.c_void_p, _u64p, _i32p]),
     "rk_num_references": (C.c_int, [C.c_void_p]),
     "rk_set_depth_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "rk_set_min_num_bound": (C.c_int, [C.c_void_p, C.c_int]),
+    "rk_min_num_bound": (C.c_int, [C.c_void_p]),
     "rk_count_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, C.c_void_p]),
     "rk_count_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "rk_classify_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, _i32p]),
@@ -751,6 +753,10 @@ class Context:
     def set_depth_filter(self, counter, min_kmer_occ):
         _chk(self._lib.rk_set_depth_filter(self._h, counter._h if counter is not None else None, min_kmer_occ))
         self._depth = counter
+
+    def set_min_num_bound(self, bound):
+        """Row field 3 under a depth filter: exact min_num (bound < 0, default) or min(min_num, bound) -- see rkmh_amd.h."""
+        _chk(self._lib.rk_set_min_num_bound(self._h, int(bound)))
 
     def count_batch(self, bases, offsets, counter):
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)

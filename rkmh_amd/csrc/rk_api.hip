@@ -134,6 +134,14 @@ struct rk_ctx {
     // -M
     rk_counter* depth = nullptr;
     int min_occ = 0;
+    // -M with a bounded min_num (rk_set_min_num_bound): < 0 exact (row field 3 = min_num); >= 0: row field 3 = min(min_num, bound),
+    // the mask is applied per index KEY (d_keepkey; the k-mer-space kernel reads the masked map copies d_km1m) and no window
+    // outside the index is looked up in the depth map except by the probe that counts the first `bound` survivors
+    int min_num_bound = -1;
+    uint32_t nkeys = 0;                      // distinct sketch hashes = key ids of the index
+    DevBuf d_keepkey, d_km1m[KM_MAX_KS], d_km1cells[KM_MAX_KS];
+    uint32_t km1_ncells[KM_MAX_KS] = {0}, km1_vmask[KM_MAX_KS] = {0};
+    KmerSets ksets_m{};                      // ksets with km1 = the masked copies (valid while a bounded depth filter is set)
     // workspaces for the general path
     DevBuf w_bases, w_tiles, w_hashes, w_segoff, w_ids, w_sk, w_lens, w_out, w_misc, w_sel, w_selstate, w_table, w_gcount, w_tail;
     int ref_count_mode = 0; // -I counter fill: 0 per k-mer occurrence (stream), 1 once per distinct hash per reference (filter)
@@ -183,7 +191,8 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     e = hipDeviceSynchronize(); (void)e;
     for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_keepbits, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount, &c->w_tail}) b->release();
-    for (int j = 0; j < KM_MAX_KS; ++j) { c->d_kf4[j].release(); c->d_km1[j].release(); c->d_km1v[j].release(); }
+    for (int j = 0; j < KM_MAX_KS; ++j) { c->d_kf4[j].release(); c->d_km1[j].release(); c->d_km1v[j].release(); c->d_km1m[j].release(); c->d_km1cells[j].release(); }
+    c->d_keepkey.release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
         s.d_bases.release(); s.d_offs.release(); s.d_out.release();
@@ -557,6 +566,9 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
             if (ntail) HIPCHK(hipMemcpyAsync(out.tail_counts + (size_t)i0 * ntail, c->w_tail.p, (size_t)cn * ntail * 4, hipMemcpyDeviceToHost, c->st));
         }
         HIPCHK(hipStreamSynchronize(c->st));
+        // -M with a bounded min_num: the general path computes min_num exactly; rows carry min(min_num, bound) on every path
+        if (out.out4 && cfg.classify && !cfg.keep_all && cfg.filter_mode == FILTER_MASK_MIN && c->min_num_bound >= 0)
+            for (int64_t q = i0; q < i1; ++q) if (out.out4[q * 4 + 3] > c->min_num_bound) out.out4[q * 4 + 3] = c->min_num_bound;
         hash_cursor += ch;
         i0 = i1;
     }
@@ -1033,6 +1045,7 @@ extern "C" int rk_sketch_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* 
 }
 
 // ---- references --------------------------------------------------------------------------------
+static int build_key_mask(rk_ctx* c);
 static int build_index(rk_ctx* c) {
     struct Pair { uint64_t h; uint32_t ref; };
     const int R = c->nref, S = c->S;
@@ -1101,6 +1114,8 @@ static int build_index(rk_ctx* c) {
         base[(size_t)b + 1] = base[b] + q;
     }
     const size_t nkeys = base[nb];
+    c->nkeys = (uint32_t)nkeys;
+    c->ix.keepkey = nullptr; memset(&c->ksets_m, 0, sizeof c->ksets_m); // a depth filter set earlier refers to the old key ids
     std::vector<uint32_t> dense((nkeys + 1) * 4, 0);
     for (uint32_t b = 0; b < nb; ++b)
         for (uint32_t q = 0; q < base[(size_t)b + 1] - base[b]; ++q)
@@ -1258,6 +1273,7 @@ static int build_index(rk_ctx* c) {
                 uint32_t b = kbits < 12u ? kbits : 12u;
                 while (b < kbits && b < 28 && (double)found > km1_load * 4.0 * (double)((size_t)1 << b)) ++b;
                 std::vector<uint32_t> c1;
+                std::vector<uint32_t> cell_of(found); // where each found k-mer was placed (rk_set_depth_filter masks cells by key)
                 bool built = false;
                 for (; b <= kbits && b <= 28 && !built; ++b) {
                     const uint32_t r = kbits - b, vb = km1_vbits(k, b), vmask = (1u << vb) - 1u;
@@ -1275,6 +1291,7 @@ static int build_index(rk_ctx* c) {
                             for (int q = 0; q < 4 && !placed; ++q)
                                 if ((e[q] & vmask) == vmask) { // empty (no key carries the all-ones id)
                                     e[q] = ((rem | (hop << r)) << (vb + 1)) | id;
+                                    cell_of[i] = bk * 4u + (uint32_t)q;
                                     placed = true;
                                 }
                             if (!placed) { e[3] |= 1u << vb; bk = (bk + 1) & (nbk - 1); } // full: later lookups that miss here try the next bucket
@@ -1291,6 +1308,11 @@ static int build_index(rk_ctx* c) {
                     RKCHK(d_km1v.reserve(vals.size() * 4 + 16));
                     if (!vals.empty()) HIPCHK(hipMemcpy(d_km1v.p, vals.data(), vals.size() * 4, hipMemcpyHostToDevice));
                     c->ksets.km1[kidx] = d_km1.as<uint4>(); c->ksets.km1_b[kidx] = b; c->ksets.km1_vals[kidx] = d_km1v.as<uint32_t>();
+                    std::vector<uint32_t> cells(2 * (size_t)found);
+                    for (uint32_t i = 0; i < found; ++i) { cells[2 * (size_t)i] = cell_of[i]; cells[2 * (size_t)i + 1] = list[2 * (size_t)i + 1]; }
+                    RKCHK(c->d_km1cells[(size_t)kidx].reserve(cells.size() * 4 + 16));
+                    if (found) HIPCHK(hipMemcpy(c->d_km1cells[(size_t)kidx].p, cells.data(), cells.size() * 4, hipMemcpyHostToDevice));
+                    c->km1_ncells[kidx] = found; c->km1_vmask[kidx] = (1u << km1_vbits(k, b)) - 1u;
                 }
             }
             DevBuf& d_kf4 = c->d_kf4[(size_t)kidx];
@@ -1315,7 +1337,7 @@ static int build_index(rk_ctx* c) {
         if (d > c->density) c->density = d;
     }
     c->have_refs = true;
-    return RK_OK;
+    return build_key_mask(c); // a bounded depth filter set earlier follows the new key ids
 }
 
 extern "C" int rk_set_reference_sketches(rk_ctx* c, const uint64_t* sketches, const int32_t* lens, int nref,
@@ -1391,9 +1413,34 @@ extern "C" int rk_kmer_form(const rk_ctx* c, uint32_t* kmers_found) {
     return c->ksets.n >= 1 ? 1 : 0;
 }
 
+// the per-key form of the depth filter (bounded min_num): keep bit per key id, masked copies of the exact k-mer maps
+static int build_key_mask(rk_ctx* c) {
+    c->ix.keepkey = nullptr;
+    memset(&c->ksets_m, 0, sizeof c->ksets_m);
+    if (!c->depth || c->min_num_bound < 0 || !c->have_refs) return RK_OK;
+    RKCHK(set_dev(c));
+    RKCHK(c->d_keepkey.reserve(((size_t)c->nkeys + 31) / 32 * 4 + 16));
+    HIPCHK(launch_keep_keys(c->ix, c->nkeys, c->depth->d, c->depth->slots, nullptr, c->min_occ, c->pol, c->d_keepkey.as<uint32_t>(), c->st));
+    if (c->ksets.n >= 1) {
+        c->ksets_m = c->ksets;
+        for (int j = 0; j < c->ksets.n; ++j) {
+            const size_t bytes = (size_t)16 << c->ksets.km1_b[j];
+            RKCHK(c->d_km1m[(size_t)j].reserve(bytes));
+            HIPCHK(hipMemcpyAsync(c->d_km1m[(size_t)j].p, c->ksets.km1[j], bytes, hipMemcpyDeviceToDevice, c->st));
+            HIPCHK(launch_km1_mask(c->d_km1cells[(size_t)j].as<uint2>(), c->km1_ncells[j], c->d_keepkey.as<uint32_t>(),
+                                   c->d_km1m[(size_t)j].as<uint32_t>(), c->km1_vmask[j], c->st));
+            c->ksets_m.km1[j] = c->d_km1m[(size_t)j].as<uint4>();
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->st));
+    c->ix.keepkey = c->d_keepkey.as<uint32_t>();
+    return RK_OK;
+}
+
 extern "C" int rk_set_depth_filter(rk_ctx* c, rk_counter* counter, int min_kmer_occ) {
     if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
     c->depth = counter; c->min_occ = min_kmer_occ;
+    c->ix.keepkey = nullptr;
     if (counter) {
         // the fused kernel's masked forms read one KEEP bit per slot instead of the 4-byte count (k_keep_bits): a snapshot of
         // the table as it is NOW -- the -M flow sets the filter after pass 1 (and after the all-reduce in multi-GPU runs)
@@ -1401,12 +1448,27 @@ extern "C" int rk_set_depth_filter(rk_ctx* c, rk_counter* counter, int min_kmer_
         // pass 1 (rk_count_batch_device) is asynchronous on the CALLER's stream, an all-reduce may run on yet another one: the
         // snapshot must see the finished table, so the whole device is drained first (once per -M run: not a hot path)
         HIPCHK(hipDeviceSynchronize());
-        RKCHK(c->d_keepbits.reserve(((counter->slots + 31) / 32) * 4 + 16));
-        HIPCHK(launch_keep_bits(counter->d, counter->slots, min_kmer_occ, c->pol, c->d_keepbits.as<uint32_t>(), c->st));
-        HIPCHK(hipStreamSynchronize(c->st));
+        if (c->min_num_bound != 0) { // bound 0: no window is ever looked up by slot (the mask acts through the keys alone)
+            RKCHK(c->d_keepbits.reserve(((counter->slots + 31) / 32) * 4 + 16));
+            HIPCHK(launch_keep_bits(counter->d, counter->slots, min_kmer_occ, c->pol, c->d_keepbits.as<uint32_t>(), c->st));
+            HIPCHK(hipStreamSynchronize(c->st));
+        }
+        RKCHK(build_key_mask(c));
     }
     return RK_OK;
 }
+
+// How much of min_num (row field 3) the caller needs under a depth filter.  num_mins only ever meets `num_mins <= min_matches`
+// (src/rkmh.cpp:938; filter: `read_min_lens <= 0`, :1292), so a caller that compares with n needs min(min_num, n + 1) and no more.
+extern "C" int rk_set_min_num_bound(rk_ctx* c, int bound) {
+    if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
+    const int nb = bound < 0 ? -1 : bound;
+    if (nb == c->min_num_bound) return RK_OK;
+    c->min_num_bound = nb;
+    if (c->depth) return rk_set_depth_filter(c, c->depth, c->min_occ); // rebuild the snapshot in the other form
+    return RK_OK;
+}
+extern "C" int rk_min_num_bound(const rk_ctx* c) { return c ? c->min_num_bound : -1; }
 
 // ---- the hot loop -------------------------------------------------------------------------------
 // The -M count pass in its slot-partitioned form (rk_count.hip): worth its fixed cost (six launches, two passes over a slot
@@ -1447,8 +1509,10 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     if (nreads > 0xfffffff0ll) return fail(RK_ERR_LIMIT, "more than 2^32-16 reads in one device batch");
     if (((uintptr_t)d_bases & 3) != 0) return fail(RK_ERR_ARG, "d_bases must be 4-byte aligned");
     int32_t* counter = nullptr; uint64_t slots = 1; int min_occ = 0;
+    const bool bounded = mode != 1 && c->depth && c->min_num_bound >= 0; // the mask acts per key: no slot bitmap in the kernels
+    if (bounded && !c->ix.keepkey) return fail(RK_ERR_STATE, "depth filter: the per-key mask was not built");
     if (mode == 1) { counter = count_into->d; slots = count_into->slots; }
-    else if (c->depth) { counter = c->d_keepbits.as<int32_t>(); slots = c->depth->slots; min_occ = c->min_occ; } // the keep bitmap, see rk_set_depth_filter
+    else if (c->depth && !bounded) { counter = c->d_keepbits.as<int32_t>(); slots = c->depth->slots; min_occ = c->min_occ; } // the keep bitmap, see rk_set_depth_filter
     uint32_t ml = max_read_len < 1 ? 1 : (max_read_len > (uint32_t)FUSED_MAXLEN ? (uint32_t)FUSED_MAXLEN : max_read_len);
     int expect = 0; // hits an error-free read is expected to score: sizes the kernel's per-read hit multiset
     for (int j = 0; j < c->ks.n; ++j) expect += (int)(c->density * (double)num_windows((int)ml, c->ks.k[j], c->pol.drop_last_window)) + 1;
@@ -1464,7 +1528,8 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
         // two atomic passes on different streams would wait for the second one only and its plain adds could lose the first one's counts
         if (count_into->last_atomic_set) HIPCHK(hipStreamWaitEvent(st, count_into->last_atomic, 0));
         if (!classify_tile_supported(0, (int)ml)) return fail(RK_ERR_LIMIT, "count pass: batch not supported by the fused kernel");
-        HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
+        RefIndex ix0 = c->ix; ix0.keepkey = nullptr;
+        HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, ix0,
                                     counter, slots, min_occ, 1, nullptr, c->pol, (int)ml, expect, st)); // (given an array there, it would write slots to it)
         // a later pass of either form must not overlap this one
         if (!count_into->last_atomic) HIPCHK(hipEventCreateWithFlags(&count_into->last_atomic, hipEventDisableTiming));
@@ -1472,15 +1537,25 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
         count_into->last_atomic_set = true;
         return RK_OK;
     }
-    // plain classification with the single k the exact k-mer map was enumerated for: the k-mer-space kernel (rk_kmer.hip)
-    if (!counter && c->ksets.n == c->ks.n && c->ksets.n >= 1 && classify_kmer_supported(c->ix.nref, (int)ml, c->ks.k[0]))
-        HIPCHK(launch_classify_kmer((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ksets, c->S, c->ix,
-                                    (int32_t*)d_out4, c->pol, (int)ml, expect, st));
+    RefIndex ix = c->ix;
+    if (!bounded) ix.keepkey = nullptr;
+    else if (c->ksets_m.n >= 1) ix.km1 = c->ksets_m.km1[0]; // (the compile-time-k kernels read the first size's structures from ix)
+    const int nmin_cap = bounded ? c->min_num_bound : 0x7fffffff;
+    // classification with k-mer sizes the exact k-mer maps were enumerated for: the k-mer-space kernel (rk_kmer.hip); under a
+    // bounded depth filter it reads the masked copies of the maps (a dropped key is a zero-hash k-mer there)
+    if (!counter && c->ksets.n == c->ks.n && c->ksets.n >= 1 && (!bounded || c->ksets_m.n == c->ksets.n) &&
+        classify_kmer_supported(c->ix.nref, (int)ml, c->ks.k[0]))
+        HIPCHK(launch_classify_kmer((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, bounded ? c->ksets_m : c->ksets, c->S, ix,
+                                    (int32_t*)d_out4, c->pol, (int)ml, expect, st, nmin_cap));
     else if (classify_tile_supported(c->ix.nref, (int)ml))
-        HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->ix,
-                                    counter, slots, min_occ, 0, (int32_t*)d_out4, c->pol, (int)ml, expect, st));
+        HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, ix,
+                                    counter, slots, min_occ, 0, (int32_t*)d_out4, c->pol, (int)ml, expect, st, 0, nmin_cap));
     else
         HIPCHK(launch_fill_reroute((int32_t*)d_out4, (uint32_t)nreads, st)); // e.g. more than 16384 references: general path
+    // bound > 0: the first `bound` surviving windows of every answered read are counted by hashing them (k_min_num_probe)
+    if (bounded && c->min_num_bound > 0)
+        HIPCHK(launch_min_num_probe((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, c->min_num_bound,
+                                    c->d_keepbits.as<uint32_t>(), c->depth->slots, c->pol, (int32_t*)d_out4, st));
     return RK_OK;
 }
 

@@ -119,39 +119,6 @@ hipError_t launch_exclusive_scan(const int32_t* in, uint64_t n, int64_t* out, in
     return hipGetLastError();
 }
 
-// ---- canonical murmur3 of a k-mer given by a byte functor (candidate k-mers are built on the fly) ----
-template <typename GetByte>
-__device__ __forceinline__ uint64_t murmur_bytes(GetByte gb, int k, uint32_t seed, int fold) {
-    uint64_t h1 = seed, h2 = seed;
-    const int nblocks = k >> 4;
-    int p = 0;
-    for (int b = 0; b < nblocks; ++b) {
-        uint64_t k1 = 0, k2 = 0;
-        for (int q = 0; q < 8; ++q) k1 |= (uint64_t)gb(p + q) << (8 * q);
-        for (int q = 0; q < 8; ++q) k2 |= (uint64_t)gb(p + 8 + q) << (8 * q);
-        mm_block(h1, h2, k1, k2);
-        p += 16;
-    }
-    const int rem = k & 15;
-    if (rem) {
-        uint64_t k1 = 0, k2 = 0;
-        for (int q = 0; q < rem && q < 8; ++q) k1 |= (uint64_t)gb(p + q) << (8 * q);
-        for (int q = 8; q < rem; ++q) k2 |= (uint64_t)gb(p + q) << (8 * (q - 8));
-        if (rem > 8) { k2 *= MM_C2; k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2; }
-        k1 *= MM_C1; k1 = rotl64(k1, 31); k1 *= MM_C2; h1 ^= k1;
-    }
-    return mm_finish<-1>(h1, h2, (uint32_t)k, fold);
-}
-__device__ __forceinline__ bool is_acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
-__device__ __forceinline__ uint8_t comp1(uint8_t c) { return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c; }
-template <typename GetByte>
-__device__ __forceinline__ uint64_t canonical_bytes(GetByte gb, int k, const DevPolicy& pol) {
-    for (int q = 0; q < k; ++q) if (!is_acgt(gb(q))) return 0;
-    const uint64_t f = murmur_bytes(gb, k, pol.seed, pol.fold);
-    const uint64_t r = murmur_bytes([&](int q) -> uint8_t { return comp1(gb(k - 1 - q)); }, k, pol.seed, pol.fold);
-    return f < r ? f : r;
-}
-
 // SNP alternatives in the order of rkmh.cpp:1634-1637: A->C,T,G  C->T,G,A  T->C,G,A  G->A,C,T (none for other bases)
 __device__ __forceinline__ uint8_t snp_alt(uint8_t orig, int j) {
     switch (orig) {

@@ -106,6 +106,7 @@ struct TileGeom {
     uint32_t slot_stride; // count pass that emits slots instead of counting (out4 = the flat array): entries per k-mer size
     int32_t magic_nw;   // windows (first k) of a read of the hinted length, and ...
     uint32_t magic;     // ... ceil(2^32 / magic_nw): the compact window -> read division of tiles made of such reads
+    int32_t nmin_cap;   // row field 3 = min(non-zero hashes, nmin_cap) (-M with a bounded min_num: rk_set_min_num_bound; else INT_MAX)
 };
 
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
@@ -166,16 +167,6 @@ __device__ __forceinline__ void word_load_async(const uint32_t* base, uint32_t b
     asm volatile("global_load_dword %0, %1, %2" : "=v"(f) : "v"(byte_off), "s"(base) : "memory");
 }
 __device__ __forceinline__ void word_wait(uint32_t& f) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : : "memory"); }
-
-// h % slots for the -M table (HASHTCounter slot, rkmh.cpp:739) without a 64-bit division: m = floor((2^64 - 1) / slots) comes
-// from the host; q = mulhi(h, m) is the quotient or one less (h * m / 2^64 lies in (h / slots - 1, h / slots]), so one conditional
-// subtraction finishes it.  Exact for every h and every slots >= 1 (2 * slots < 2^64).  ~20 VALU instead of ~55.
-__device__ __forceinline__ uint64_t mod_slots(uint64_t h, uint64_t slots, uint64_t m) {
-    const uint64_t q = __umul64hi(h, m);
-    uint64_t r = h - q * slots;
-    if (r >= slots) r -= slots;
-    return r;
-}
 
 // MODE 0: classify; MODE 1: count pass of -M (rkmh.cpp:904-910); MODE 2: classify with the -M mask (rkmh.cpp:916)
 // MODE_ 3 / 4: MODE 0 / 2 with the first-level filter of large panels (RefIndex::pre) in front of the bucket table
@@ -459,6 +450,8 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
             uint32_t slot = 0, v = 0;
             if RK_DBG(256) { slot = (uint32_t)h & 0xFFFFu; v = (uint32_t)(h >> 40) % 180u | (1u << 20); } else
             if (!index_lookup(ix, h, slot, v)) return false; // re-reads the bucket (L1/L2 hit), then key + value together
+            // -M with a bounded min_num: the mask is applied per KEY (one bit per key id) -- a masked hash is 0 (rkmh.cpp:916)
+            if (ix.keepkey && !((ix.keepkey[slot >> 5] >> (slot & 31u)) & 1u)) { atomicAdd(&nzero[t], 1u); return false; }
             return apply_hit(slot, v, t, m_tr, m_off);
         };
         auto drain_queue = [&](uint32_t qn) {
@@ -728,7 +721,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 prev = LPR == 16 ? row_max_i32(prev) : half_row_max_i32(prev);
                 wave_sync();
                 for (int w = sl; w < geo.cwords; w += LPR) ct[w] = 0;
-                if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(max_id, max_shared, max_shared - prev, nmins);
+                if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(max_id, max_shared, max_shared - prev, nmins < geo.nmin_cap ? nmins : geo.nmin_cap);
             }
         }
         // The prefetch registers cross the back edge of this loop.  hipcc does not know that an asm-issued load is still
@@ -832,7 +825,7 @@ bool classify_tile_supported(int nref, int maxlen) { return nref <= 16384 && max
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st,
-                                uint32_t slot_stride) {
+                                uint32_t slot_stride, int nmin_cap) {
     if (nreads == 0) return hipSuccess;
     const TileKnobs& kn = knobs();
     int win_total = 0; // most windows any read of the batch can have (all k): bounds every per-reference count
@@ -852,6 +845,7 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     geo.xcd = kn.xcd >= 0 ? (kn.xcd != 0) : 1;
     geo.slots_m = slots ? ~0ull / slots : 0;
     geo.slot_stride = slot_stride;
+    geo.nmin_cap = nmin_cap;
     geo.magic_nw = num_windows(maxlen, ks.k[0], pol.drop_last_window);
     geo.magic = geo.magic_nw >= 2 ? 0xFFFFFFFFu / (uint32_t)geo.magic_nw + 1u : 0u;
     const bool k16 = (ks.n == 1 && ks.k[0] == 16);

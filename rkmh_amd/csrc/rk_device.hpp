@@ -449,9 +449,54 @@ __device__ __forceinline__ uint64_t canonical_window(const Staged& s, uint32_t i
     return f < r ? f : r;
 }
 
+// ---- canonical murmur3 of a k-mer given by a byte functor (k-mers read from global memory or built on the fly) ----
+template <typename GetByte>
+__device__ __forceinline__ uint64_t murmur_bytes(GetByte gb, int k, uint32_t seed, int fold) {
+    uint64_t h1 = seed, h2 = seed;
+    const int nblocks = k >> 4;
+    int p = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        uint64_t k1 = 0, k2 = 0;
+        for (int q = 0; q < 8; ++q) k1 |= (uint64_t)gb(p + q) << (8 * q);
+        for (int q = 0; q < 8; ++q) k2 |= (uint64_t)gb(p + 8 + q) << (8 * q);
+        mm_block(h1, h2, k1, k2);
+        p += 16;
+    }
+    const int rem = k & 15;
+    if (rem) {
+        uint64_t k1 = 0, k2 = 0;
+        for (int q = 0; q < rem && q < 8; ++q) k1 |= (uint64_t)gb(p + q) << (8 * q);
+        for (int q = 8; q < rem; ++q) k2 |= (uint64_t)gb(p + q) << (8 * (q - 8));
+        if (rem > 8) { k2 *= MM_C2; k2 = rotl64(k2, 33); k2 *= MM_C1; h2 ^= k2; }
+        k1 *= MM_C1; k1 = rotl64(k1, 31); k1 *= MM_C2; h1 ^= k1;
+    }
+    return mm_finish<-1>(h1, h2, (uint32_t)k, fold);
+}
+__device__ __forceinline__ bool is_acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+__device__ __forceinline__ uint8_t comp1(uint8_t c) { return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c; }
+template <typename GetByte>
+__device__ __forceinline__ uint64_t canonical_bytes(GetByte gb, int k, const DevPolicy& pol) {
+    for (int q = 0; q < k; ++q) if (!is_acgt(gb(q))) return 0;
+    const uint64_t f = murmur_bytes(gb, k, pol.seed, pol.fold);
+    const uint64_t r = murmur_bytes([&](int q) -> uint8_t { return comp1(gb(k - 1 - q)); }, k, pol.seed, pol.fold);
+    return f < r ? f : r;
+}
+// mkmh::to_upper on one byte: every (signed) char > 91 gets -32 (see upper4)
+__device__ __forceinline__ uint8_t upper1(uint8_t c) { return (c > 91 && c < 128) ? (uint8_t)(c - 32) : c; }
+
 __host__ __device__ __forceinline__ int num_windows(int len, int k, int drop_last) {
     int n = drop_last ? len - k : len - k + 1;
     return n > 0 ? n : 0;
+}
+
+// h % slots for the -M table (HASHTCounter slot, rkmh.cpp:739) without a 64-bit division: m = floor((2^64 - 1) / slots) comes
+// from the host; q = mulhi(h, m) is the quotient or one less (h * m / 2^64 lies in (h / slots - 1, h / slots]), so one conditional
+// subtraction finishes it.  Exact for every h and every slots >= 1 (2 * slots < 2^64).  ~20 VALU instead of ~55.
+__device__ __forceinline__ uint64_t mod_slots(uint64_t h, uint64_t slots, uint64_t m) {
+    const uint64_t q = __umul64hi(h, m);
+    uint64_t r = h - q * slots;
+    if (r >= slots) r -= slots;
+    return r;
 }
 
 // ---- resident reference index ------------------------------------------------------------------
@@ -495,6 +540,10 @@ struct RefIndex {
     const uint4* km1;      // single-probe exact map (see KM1_C above), 2^km1_b buckets
     uint32_t km1_b;
     const uint32_t* km1_vals;
+    // -M with a bounded min_num (rk_set_min_num_bound): bit (key id) set <=> the key's slot of the depth map passes the threshold
+    // (nullptr = no per-key mask).  The hash-space kernels test it for the windows that HIT a key instead of one bit of the
+    // 25 MB slot bitmap for every window; the k-mer-space kernel reads a copy of km1 in which the dropped keys carry the zero id.
+    const uint32_t* keepkey;
 };
 // The exact map the k-mer-space kernel (rk_kmer.hip) resolves its candidates in: every k-mer the enumeration found, one 16-byte
 // bucket of four 4-byte cells per lookup.  y = (key * odd constant) mod 4^k is a bijection on the 2k-bit k-mers, so (bucket = top

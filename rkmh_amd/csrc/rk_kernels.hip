@@ -344,6 +344,129 @@ hipError_t launch_keep_bits(const int32_t* counter, uint64_t slots, int min_occ,
 }
 
 // ------------------------------------------------------------------------------------------------
+// -M with a bounded min_num (rk_set_min_num_bound; rkmh.cpp:916-917, :938).  mask_by_frequency changes what a read shares with
+// the references only through the windows whose hash is a KEY of the index, and whether a key survives is a property of the key:
+// one keep bit per key id, taken from the depth map once (full table: counter[key % slots]; compact table: counter[sid[key id]]).
+__global__ __launch_bounds__(256) void k_keep_keys(const uint4* __restrict__ kv, uint32_t nkeys, const int32_t* __restrict__ counter, uint64_t slots,
+                                                   const uint32_t* __restrict__ key_sid, int min_occ, int strict_less, uint32_t* __restrict__ bits) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w * 32u >= nkeys) return;
+    uint32_t v = 0;
+    for (uint32_t b = 0; b < 32; ++b) {
+        const uint32_t j = w * 32u + b;
+        if (j >= nkeys) break;
+        int c;
+        if (key_sid) c = counter[key_sid[j]];
+        else {
+            const uint2 k = *reinterpret_cast<const uint2*>(&kv[j]);
+            c = counter[(((uint64_t)k.y << 32) | k.x) % slots];
+        }
+        const bool masked = strict_less ? (c < min_occ) : (c <= min_occ);
+        v |= (masked ? 0u : 1u) << b;
+    }
+    bits[w] = v;
+}
+hipError_t launch_keep_keys(const RefIndex& ix, uint32_t nkeys, const int32_t* counter, uint64_t slots, const uint32_t* key_sid, int min_occ,
+                            const DevPolicy& pol, uint32_t* bits, hipStream_t st) {
+    const uint32_t nwords = (nkeys + 31u) / 32u;
+    if (!nwords) return hipSuccess;
+    hipLaunchKernelGGL(k_keep_keys, dim3((nwords + 255u) / 256u), dim3(256), 0, st, ix.kv, nkeys, counter, slots, key_sid, min_occ, pol.mask_strict_less, bits);
+    return hipGetLastError();
+}
+// the exact k-mer map with the dropped keys turned into zero-hash k-mers (a masked hash IS 0, rkmh.cpp:916): cells[i] = (cell of
+// found k-mer i, its key id or IDX_NOT_FOUND); km1m is a copy of the map
+__global__ __launch_bounds__(256) void k_km1_mask(const uint2* __restrict__ cells, uint32_t n, const uint32_t* __restrict__ keepkey, uint32_t* __restrict__ km1m,
+                                                  uint32_t vmask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 e = cells[i];
+    if (e.y == IDX_NOT_FOUND) return;
+    if (!((keepkey[e.y >> 5] >> (e.y & 31u)) & 1u)) km1m[e.x] = (km1m[e.x] & ~vmask) | (vmask - 1u);
+}
+hipError_t launch_km1_mask(const uint2* cells, uint32_t n, const uint32_t* keepkey, uint32_t* km1m, uint32_t vmask, hipStream_t st) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_km1_mask, dim3((n + 255u) / 256u), dim3(256), 0, st, cells, n, keepkey, km1m, vmask);
+    return hipGetLastError();
+}
+// min(min_num, bound) for the rows the fused kernels answered (not -2): num_mins only ever meets `num_mins <= min_matches`
+// (rkmh.cpp:938), so no caller needs more.  A row whose max_shared already reaches the bound needs nothing (max_shared <=
+// num_mins); for the others G lanes take one read and hash its windows G at a time (LDS image of the piece, both strands, as
+// k_hash_tiles does) until `bound` of them survive the mask -- a read whose first windows survive costs G hashes and G bits of
+// the slot bitmap instead of all of them.
+constexpr int PROBE_MAXB = 32 + MAX_K;
+template <int G>
+__global__ __launch_bounds__(256) void k_min_num_probe(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs, uint32_t nreads, KsArr ks,
+                                                       int S, int bound, const uint32_t* __restrict__ keepbits, uint64_t slots, uint64_t slots_m,
+                                                       DevPolicy pol, int32_t* __restrict__ out4) {
+    constexpr int GROUPS = 256 / G;
+    __shared__ uint32_t lds[GROUPS * stage_lds_dwords(PROBE_MAXB)];
+    const int tid = threadIdx.x % G, grp = threadIdx.x / G, lane = threadIdx.x & 63;
+    uint32_t* my = lds + grp * stage_lds_dwords(PROBE_MAXB);
+    const uint32_t i = blockIdx.x * GROUPS + grp;
+    const int want = bound < S ? bound : S;
+    bool done = i >= nreads;
+    uint32_t o = 0, len = 0;
+    int cnt = 0;
+    if (!done) {
+        const int2 r = *reinterpret_cast<const int2*>(out4 + 4 * (size_t)i);
+        if (r.x == -2) done = true; // the general path answers this read (exactly)
+        else if (r.y >= want) { cnt = want; done = true; out4[4 * (size_t)i + 3] = want; }
+        else { o = offs[i]; len = offs[i + 1] - o; }
+    }
+    const bool mine = !done;
+    int j = 0;
+    uint32_t w0 = 0;
+    auto sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    while (__ballot(!done)) { // (the lanes of a group always agree; a wave holds 64 / G groups)
+        bool go = !done;
+        int k = 1;
+        uint32_t nw = 0;
+        if (go) {
+            k = ks.k[j]; nw = (uint32_t)num_windows((int)len, k, pol.drop_last_window);
+            if (w0 >= nw) { // this size is exhausted: on to the next one (its windows start with the wave's next step)
+                ++j; w0 = 0; go = false;
+                if (j >= ks.n) done = true;
+            }
+        }
+        const uint32_t nwin = go ? ((nw - w0) < (uint32_t)G ? (nw - w0) : (uint32_t)G) : 0u;
+        const Staged st = stage_piece(bases, (uint64_t)o + w0, go ? nwin + (uint32_t)k - 1u : 0u, my, PROBE_MAXB, tid, G, sync);
+        bool surv = false;
+        if (go && (uint32_t)tid < nwin) {
+            const uint64_t h = canonical_window<0>(st, (uint32_t)tid, k, pol);
+            if (h != 0) {
+                const uint64_t sl = mod_slots(h, slots, slots_m);
+                surv = ((keepbits[sl >> 5] >> ((uint32_t)sl & 31u)) & 1u) != 0u;
+            }
+        }
+        const uint64_t m = __ballot(surv);
+        if (go) {
+            cnt += __popcll((m >> (lane & ~(G - 1))) & (G == 64 ? ~0ull : ((1ull << G) - 1ull)));
+            w0 += (uint32_t)G;
+            if (cnt >= want) done = true;
+        }
+        sync(); // the image is rebuilt by the next step
+    }
+    if (mine && tid == 0) out4[4 * (size_t)i + 3] = cnt < want ? cnt : want;
+}
+hipError_t launch_min_num_probe(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S, int bound,
+                                const uint32_t* keepbits, uint64_t slots, const DevPolicy& pol, int32_t* out4, hipStream_t st) {
+    if (!nreads) return hipSuccess;
+    const uint64_t slots_m = slots ? ~0ull / slots : 0;
+    const int want = bound < S ? bound : S;
+#define RK_PROBE(G) hipLaunchKernelGGL((k_min_num_probe<G>), dim3((nreads + (256 / G) - 1) / (256 / G)), dim3(256), 0, st, bases, offs, nreads, ks, S, bound, \
+                                       keepbits, slots, slots_m, pol, out4)
+    if (want <= 6) RK_PROBE(8);
+    else if (want <= 14) RK_PROBE(16);
+    else RK_PROBE(32);
+#undef RK_PROBE
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Exhaustive enumeration behind the k-mer-space kernel (rk_kmer.hip): EVERY k-mer of the 4^k universe (k <= 16) is hashed
 // exactly as calc_hashes would hash it as a window; those whose canonical hash is a key of the index -- the true preimages of
 // the sketch hashes and any other k-mer that happens to collide with one -- and those hashing to 0 are listed.  The host builds

@@ -133,6 +133,12 @@ hipError_t sort_u64_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t launch_sort_u64(uint64_t* keys, uint64_t n, void* tmp, size_t tmp_bytes, hipStream_t st);
 // bits[s / 32] bit (s % 32) = the count of slot s passes mask_by_frequency's threshold (one streaming pass over the table)
 hipError_t launch_keep_bits(const int32_t* counter, uint64_t slots, int min_occ, const DevPolicy& pol, uint32_t* bits, hipStream_t st);
+// -M with a bounded min_num: keep bit per index key, the masked copy of the exact k-mer map, min(min_num, bound) per read
+hipError_t launch_keep_keys(const RefIndex& ix, uint32_t nkeys, const int32_t* counter, uint64_t slots, const uint32_t* key_sid, int min_occ,
+                            const DevPolicy& pol, uint32_t* bits, hipStream_t st);
+hipError_t launch_km1_mask(const uint2* cells, uint32_t n, const uint32_t* keepkey, uint32_t* km1m, uint32_t vmask, hipStream_t st);
+hipError_t launch_min_num_probe(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S, int bound,
+                                const uint32_t* keepbits, uint64_t slots, const DevPolicy& pol, int32_t* out4, hipStream_t st);
 // hashes all 4^k k-mers; stats[0] = k-mers found (one per strand pair), the first list_cap of them in list[] as (packed canonical
 // k-mer, key id or IDX_NOT_FOUND for a zero hash)
 hipError_t launch_enum_kmers(const RefIndex& ix, const DevPolicy& pol, int k, uint32_t* stats, uint2* list, uint32_t list_cap,
@@ -148,12 +154,12 @@ constexpr int KPRE_MIN_K = 8; // the k-mer-space kernel (rk_kmer.hip) exists for
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st,
-                                uint32_t slot_stride = 0);
+                                uint32_t slot_stride = 0, int nmin_cap = 0x7fffffff);
 // the k-mer-space kernel (rk_kmer.hip): plain classification with k-mer sizes from KPRE_MIN_K to 16 whose exact k-mer maps and group
 // filters were built (KmerSets: one per size; a single size runs the compile-time-k kernels, several the run-time-k one)
 bool classify_kmer_supported(int nref, int maxlen, int k);
 hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KmerSets& ksets, int S, const RefIndex& ix,
-                                int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st);
+                                int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st, int nmin_cap = 0x7fffffff);
 hipError_t launch_max_len(const uint32_t* offs, uint32_t nreads, uint32_t* d_max, hipStream_t st);
 hipError_t launch_mask_by_frequency(uint64_t* h, uint64_t n, const int32_t* counter, uint64_t slots, int min_occ,
                                     const DevPolicy& pol, hipStream_t st);

@@ -66,6 +66,7 @@ struct KmerGeom {
     int32_t cwords;    // counter words per read
     int32_t dset;      // slots of the per-read hit multiset (power of two)
     int32_t xcd;
+    int32_t nmin_cap;  // row field 3 = min(non-zero hashes, nmin_cap) (-M with a bounded min_num: rk_set_min_num_bound; else INT_MAX)
     int32_t L;         // hinted read length ...
     int32_t gpr[KM_MAX_KS];    // ... its groups per read = ceil(windows / 4), per k-mer size ...
     uint32_t magic[KM_MAX_KS]; // ... and ceil(2^32 / gpr): the group -> read division of tiles made of such reads
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                     prev = (int)acc > prev ? (int)acc : prev;
                 }
                 prev = LPR == 16 ? row_max_i32(prev) : half_row_max_i32(prev);
-                if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(max_id, max_shared, max_shared - prev, nmins);
+                if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(max_id, max_shared, max_shared - prev, nmins < geo.nmin_cap ? nmins : geo.nmin_cap);
             }
         }
     }
@@ -793,7 +794,7 @@ bool classify_kmer_supported(int nref, int maxlen, int k) {
 
 // ksets: the structures of every k-mer size of the run (n = 1: the compile-time-k kernels, whose structures are ix.kf4 / km1 too)
 hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KmerSets& ksets, int S, const RefIndex& ix,
-                                int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st) {
+                                int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st, int nmin_cap) {
     if (nreads == 0) return hipSuccess;
     if (ksets.n < 1 || ksets.n > KM_MAX_KS) return hipErrorInvalidValue;
     const int nq = maxlen <= 1024 - 15 ? 1 : 2;
@@ -805,6 +806,7 @@ hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint
     if (!make_kmer_geom(geo, maxlen, ix.nref, expect_hits, win_total, nw_k, ksets.n, nq, cmode, big)) return hipErrorInvalidConfiguration;
     static const int xcd_env = getenv("RKMH_TILE_XCD") ? atoi(getenv("RKMH_TILE_XCD")) : -1;
     if (xcd_env >= 0) geo.xcd = xcd_env != 0;
+    geo.nmin_cap = nmin_cap;
     const uint32_t ntiles = (nreads + (uint32_t)geo.T - 1) / (uint32_t)geo.T;
     uint32_t grid = ntiles;
     grid = (grid + 7u) & ~7u; // whole rounds of the 8 XCDs: the virtual ids then cover [0, grid) exactly

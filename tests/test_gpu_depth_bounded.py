@@ -1,0 +1,197 @@
+"""-M with a bounded min_num (rk_set_min_num_bound; src/rkmh.cpp:916-917, :938): the mask is applied per index key, no window
+outside the index is looked up in the depth map, and row field 3 is min(num_mins, bound).  Every row must equal the oracle's
+two-pass result with its fourth column clamped -- on the k-mer-space kernel (k 8..16, one and several sizes), on the hash-space
+kernel (k = 20, 21), through reroutes (reads with more windows than the sketch keeps), for tables small enough that most keys
+are dropped, and for both comparison policies."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pad(b):
+    out = np.zeros(len(b) + 16, dtype=np.uint8)
+    out[: len(b)] = b
+    return out
+
+
+@pytest.fixture(scope="module")
+def pave(orc, data_dir):
+    recs = orc.kseq_parse_file(os.path.join(data_dir, "all_pave_ref.fa.gz"))
+    rb, ro = orc.pack([r[1] for r in recs])
+    return [r[0] for r in recs], _pad(rb), ro
+
+
+def _clamped(want, bound):
+    w = want.copy()
+    if bound >= 0:
+        w[:, 3] = np.minimum(w[:, 3], bound)
+    return w
+
+
+def _reads(rb, ro, lo, n, seed, with_n=True, ragged=True):
+    """synthetic reads; some with N, some shorter, a few shorter than k"""
+    from rkmh_amd import synth
+    qb, qo = synth.generate_reads_fast(rb, ro, lo, lo + n)
+    qb = qb.copy()
+    rng = np.random.default_rng(seed)
+    if with_n:
+        for i in rng.integers(0, n, size=n // 20):
+            qb[int(qo[i]) + int(rng.integers(0, 150))] = ord("N")
+        for i in rng.integers(0, n, size=n // 50):   # lower case: to_upper applies
+            s = int(qo[i])
+            qb[s: s + 40] = np.frombuffer(bytes(qb[s: s + 40]).lower(), dtype=np.uint8)
+    if ragged:
+        seqs = []
+        for i in range(n):
+            s = bytes(qb[int(qo[i]): int(qo[i + 1])])
+            r = rng.random()
+            if r < 0.05:
+                s = s[: int(rng.integers(0, 30))]
+            elif r < 0.25:
+                s = s[: int(rng.integers(30, 150))]
+            seqs.append(s)
+        import oracle
+        qb, qo = oracle.pack(seqs)
+    return _pad(qb), qo
+
+
+@pytest.mark.parametrize("ks,slots,min_occ", [([16], 200000000, 2), ([16], 1000003, 3), ([16], 4099, 60), ([12, 16], 1000003, 2),
+                                              ([15], 65537, 6), ([20], 1000003, 2), ([21], 4099, 40), ([10], 99991, 12)])
+def test_bounded_rows_equal_the_clamped_oracle(orc, pave, ks, slots, min_occ):
+    import rkmh_amd
+    _, rb, ro = pave
+    T = min(16, os.cpu_count() or 1)
+    n = 20000
+    qb, qo = _reads(rb, ro, 7000, n, seed=len(ks) * 1000 + ks[0] + slots % 97)
+    c = rkmh_amd.Context(0)
+    try:
+        c.set_references(rb, ro, ks, 1000)
+        sk, ln = c.get_reference_sketches()
+        want = orc.classify_stream(qb, qo, ks, 1000, sk, ln, threads=T, min_kmer_occ=min_occ, counter_slots=slots)
+        assert (want[:, 1] > 0).any()
+        cnt = rkmh_amd.Counter(c, slots=slots)
+        c.count_batch(qb, qo, cnt)
+        try:
+            # the bound is set before the filter, then changed while the filter is set, then back to exact
+            c.set_min_num_bound(0)
+            c.set_depth_filter(cnt, min_occ)
+            for bound in (0, 1, 4, 200, -1, 2):
+                c.set_min_num_bound(bound)
+                got = c.classify(qb, qo)
+                w = _clamped(want, bound)
+                bad = np.nonzero((got != w).any(axis=1))[0]
+                assert len(bad) == 0, (ks, slots, min_occ, bound, len(bad), got[bad[:4]], w[bad[:4]])
+        finally:
+            c.set_depth_filter(None, 0)
+            c.set_min_num_bound(-1)
+            cnt.destroy()
+        # without a filter the bound means nothing
+        c.set_min_num_bound(0)
+        plain = orc.classify_stream(qb, qo, ks, 1000, sk, ln, threads=T)
+        assert (c.classify(qb, qo) == plain).all()
+    finally:
+        c.close()
+
+
+def test_bounded_mode_uses_the_kmer_space_kernel_and_reroutes(orc, pave):
+    """k = 16 with a bounded filter must stay on the k-mer-space form (the point of the bound); reads longer than the sketch
+    (reroute through the general path, which masks by slot) still come back exact with the clamp applied."""
+    import rkmh_amd
+    from rkmh_amd import synth
+    _, rb, ro = pave
+    T = min(16, os.cpu_count() or 1)
+    S = 100
+    rng = np.random.default_rng(5)
+    short_b, short_o = synth.generate_reads_fast(rb, ro, 100, 100 + 3000)
+    seqs = [bytes(short_b[int(short_o[i]): int(short_o[i + 1])]) for i in range(3000)]
+    for j in range(0, 3000, 7):   # every seventh read: 400 bases = 384 windows > S -> bottom-S selection matters
+        r = int(rng.integers(0, len(ro) - 1))
+        st = int(ro[r]) + int(rng.integers(0, int(ro[r + 1] - ro[r]) - 400))
+        seqs[j] = bytes(rb[st: st + 400])
+    qb, qo = orc.pack(seqs)
+    qb = _pad(qb)
+    c = rkmh_amd.Context(0)
+    try:
+        c.set_references(rb, ro, [16], S)
+        assert c.kmer_form()[0] == 1
+        sk, ln = c.get_reference_sketches()
+        slots = 300007
+        want = orc.classify_stream(qb, qo, [16], S, sk, ln, threads=T, min_kmer_occ=2, counter_slots=slots)
+        cnt = rkmh_amd.Counter(c, slots=slots)
+        c.count_batch(qb, qo, cnt)
+        c.set_depth_filter(cnt, 2)
+        try:
+            for bound in (0, 3, 150):
+                c.set_min_num_bound(bound)
+                got = c.classify(qb, qo)
+                w = _clamped(want, bound)
+                bad = np.nonzero((got != w).any(axis=1))[0]
+                assert len(bad) == 0, (bound, len(bad), got[bad[:4]], w[bad[:4]])
+        finally:
+            c.set_depth_filter(None, 0)
+            cnt.destroy()
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("strict", [1, 0])
+def test_bounded_mode_honours_the_mask_comparison_policy(orc, pave, strict):
+    import rkmh_amd
+    _, rb, ro = pave
+    T = min(16, os.cpu_count() or 1)
+    qb, qo = _reads(rb, ro, 0, 8000, seed=99, ragged=False)
+    pol = orc.default_policy(mask_strict_less=strict)
+    c = rkmh_amd.Context(0, mask_strict_less=strict)
+    try:
+        c.set_references(rb, ro, [16], 1000)
+        sk, ln = c.get_reference_sketches()
+        want = orc.classify_stream(qb, qo, [16], 1000, sk, ln, pol, threads=T, min_kmer_occ=2, counter_slots=500009)
+        cnt = rkmh_amd.Counter(c, slots=500009)
+        c.count_batch(qb, qo, cnt)
+        c.set_min_num_bound(3)
+        c.set_depth_filter(cnt, 2)
+        try:
+            got = c.classify(qb, qo)
+        finally:
+            c.set_depth_filter(None, 0)
+            cnt.destroy()
+        assert (got == _clamped(want, 3)).all()
+    finally:
+        c.close()
+
+
+def test_new_references_under_a_bounded_filter(orc, pave):
+    """rk_set_references while a bounded filter is set: the per-key mask follows the new key ids."""
+    import rkmh_amd
+    _, rb, ro = pave
+    T = min(16, os.cpu_count() or 1)
+    qb, qo = _reads(rb, ro, 500, 5000, seed=3, ragged=False)
+    c = rkmh_amd.Context(0)
+    try:
+        c.set_references(rb, ro, [16], 1000)
+        cnt = rkmh_amd.Counter(c, slots=700001)
+        c.count_batch(qb, qo, cnt)
+        c.set_min_num_bound(1)
+        c.set_depth_filter(cnt, 2)
+        try:
+            for nref, k in ((60, 16), (182, 14)):
+                c.set_references(rb, ro[: nref + 1], [k], 1000)
+                sk, ln = c.get_reference_sketches()
+                # the table was counted with k = 16; any table is a table: the oracle counts with the classify k, so build the
+                # expectation from the library's own count with that k instead
+                cnt2 = rkmh_amd.Counter(c, slots=700001)
+                c.count_batch(qb, qo, cnt2)
+                c.set_depth_filter(cnt2, 2)
+                want = orc.classify_stream(qb, qo, [k], 1000, sk, ln, threads=T, min_kmer_occ=2, counter_slots=700001)
+                got = c.classify(qb, qo)
+                assert (got == _clamped(want, 1)).all(), (nref, k)
+                c.set_depth_filter(cnt, 2)
+                cnt2.destroy()
+        finally:
+            c.set_depth_filter(None, 0)
+            cnt.destroy()
+    finally:
+        c.close()

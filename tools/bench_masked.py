@@ -1,5 +1,6 @@
 """The masked classification of -M (pass 2, rkmh.cpp:911-948) on one resident 1 M-read batch: time per launch at several table sizes.
-Usage: [SLOTS=200000000,...] [REPS=10] [K=16] python tools/bench_masked.py"""
+Usage: [SLOTS=200000000,...] [REPS=10] [K=16] [BOUNDS=-1,0,1,6] python tools/bench_masked.py
+BOUNDS: rk_set_min_num_bound values (-1 = exact min_num: every window looked up by slot)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,12 +19,7 @@ d_out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
 st = torch.cuda.Stream()
 reps = int(os.environ.get("REPS", "10"))
 ctx.set_references(rb, ro, [k], S)
-for slots in [int(x) for x in os.environ.get("SLOTS", "200000000,10000000,1000000").split(",")]:
-    cnt = api.Counter(ctx, slots)
-    ctx.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt, stream=st.cuda_stream)
-    st.synchronize()
-    ctx.set_depth_filter(cnt, 2)
-    f = lambda: ctx.classify_device(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=150, stream=st.cuda_stream)  # noqa: E731
+def timed(f):
     for _ in range(3):
         f()
     st.synchronize()
@@ -34,6 +30,18 @@ for slots in [int(x) for x in os.environ.get("SLOTS", "200000000,10000000,100000
             f()
         e1.record(st)
     st.synchronize()
-    print("k=%d s=%d slots=%-10d masked classify %.3f ms per 1 M reads (keep bitmap %.1f MB)" % (k, S, slots, e0.elapsed_time(e1) / reps, slots / 8e6), flush=True)
+    return e0.elapsed_time(e1) / reps
+
+
+for slots in [int(x) for x in os.environ.get("SLOTS", "200000000,10000000,1000000").split(",")]:
+    cnt = api.Counter(ctx, slots)
+    ctx.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt, stream=st.cuda_stream)
+    st.synchronize()
+    ctx.set_depth_filter(cnt, 2)
+    for bound in [int(x) for x in os.environ.get("BOUNDS", "-1,0,1,6").split(",")]:
+        ctx.set_min_num_bound(bound)
+        ms = timed(lambda: ctx.classify_device(d_b.data_ptr(), d_o.data_ptr(), n, d_out.data_ptr(), max_read_len=150, stream=st.cuda_stream))
+        print("k=%d s=%d slots=%-10d bound=%-3d masked classify %.3f ms per 1 M reads (keep bitmap %.1f MB)" % (k, S, slots, bound, ms, slots / 8e6), flush=True)
+    ctx.set_min_num_bound(-1)
     ctx.set_depth_filter(None, 0)
     cnt.destroy()
