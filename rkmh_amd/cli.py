@@ -372,6 +372,11 @@ def main_stream(argv, filter_mode=False):
     out = os.fdopen(result_fd, "wb")
     rank, local, world = rdist.init()
     ctx = api.Context(local)
+    if min_occ is not None and not (os.environ.get("RKMH_EXACT_MIN_NUM", "0") not in ("", "0")):
+        # -M: the output compares num_mins with -N (stream, rkmh.cpp:938) or with 0 (filter, :1292) and nothing else, so
+        # min(num_mins, bound) is all it needs -- the masked pass then looks up index keys, not every window (rk_set_min_num_bound)
+        cmp_with = 0 if filter_mode else min_matches
+        ctx.set_min_num_bound(0 if cmp_with < 0 else cmp_with + 1)
     # Rank 0 alone reads the reference files -- genome-sized plain FASTA as raw text stripped on the device (_references_on_device),
     # anything else with the host parser --, sketches them and broadcasts sketches and names; the other ranks never open them.
     ms_filter = max_samples if (max_samples is not None and max_samples < 100000) else None   # filter: rkmh.cpp:1211

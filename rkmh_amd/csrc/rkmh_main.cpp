@@ -239,6 +239,14 @@ static bool load_sketch_json(const char* path, LoadedSketches& L);
 // The devices of one run (--devices): context 0 builds the reference sketches (rk_set_references on its GPU), the others import
 // them (rk_set_reference_sketches: a few MB through the host), all in parallel threads -- the in-process form of the one-rank-per-
 // GPU layout of rkmh_amd/cli.py, and the GPU analogue of the reference's -t OpenMP threads (rkmh.cpp:734, :813-898).
+// -M: how much of min_num the output needs (rk_set_min_num_bound).  stream / classify print FAIL:DEPTH iff num_mins <= -N
+// (rkmh.cpp:938), filter keeps a read iff read_min_lens > 0 (:1292): min(num_mins, bound) answers both, and with it the masked pass
+// looks up index keys (and at most `bound` surviving windows per read) in the depth map instead of every window.
+// RKMH_EXACT_MIN_NUM=1 keeps the exact form (A/B runs, tests).
+static int min_num_bound_for(int compare_with) {
+    if (getenv("RKMH_EXACT_MIN_NUM") && atoi(getenv("RKMH_EXACT_MIN_NUM")) != 0) return -1;
+    return compare_with < 0 ? 0 : (compare_with >= 0x3fffffff ? -1 : compare_with + 1);
+}
 struct DeviceGroup {
     std::vector<rk_ctx*> ctx;
     void create(const Opts& o) {
@@ -942,6 +950,7 @@ static int main_stream(int argc, char** argv) {
     double t0 = now_s();
     DeviceGroup group;
     group.create(o);
+    if (o.read_depth) for (rk_ctx* cx : group.ctx) CK(rk_set_min_num_bound(cx, min_num_bound_for(o.min_matches)));
     rk_ctx* ctx = group.ctx[0];
     tick("context", t0);
     rk_seqset refs;
@@ -1106,6 +1115,8 @@ static int main_filter(int argc, char** argv) {
     double t0 = now_s();
     DeviceGroup group;
     group.create(o);
+    // file mode compares read_min_lens with 0 (rkmh.cpp:1292); the STDIN lines print min(len) itself (:1397): exact there
+    if (o.read_depth && !in_stream) for (rk_ctx* cx : group.ctx) CK(rk_set_min_num_bound(cx, min_num_bound_for(0)));
     rk_ctx* ctx = group.ctx[0];
     tick("context", t0);
     rk_seqset refs;

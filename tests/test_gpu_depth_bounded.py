@@ -195,3 +195,69 @@ def test_new_references_under_a_bounded_filter(orc, pave):
             cnt.destroy()
     finally:
         c.close()
+
+
+def test_clis_print_the_same_bytes_in_bounded_and_exact_form(orc, root, data_dir, tmp_path):
+    """bin/rkmh and python -m rkmh_amd.cli set the bound from -N (stream: num_mins <= -N, rkmh.cpp:938; filter: read_min_lens <= 0,
+    :1292).  stdout must be byte-identical to the oracle's lines and to the exact form (RKMH_EXACT_MIN_NUM=1) for -M 2 with and
+    without -N / -D, including reads that match nothing, reads with few valid windows (N runs) and reads shorter than k -- the
+    cases in which FAIL:DEPTH can fire."""
+    import subprocess
+    import sys
+    from rkmh_amd import synth, api
+    exe = os.path.join(root, "bin", "rkmh")
+    refs = orc.kseq_parse_file(os.path.join(data_dir, "all_pave_ref.fa.gz"))[:80]
+    ref_fa = tmp_path / "refs.fa"
+    ref_fa.write_bytes(b"".join(b">" + r[0] + b"\n" + r[1] + b"\n" for r in refs))
+    R = api.parse_files([str(ref_fa)])
+    n = 3000
+    qb, qo = synth.generate_reads(R["bases"], R["offsets"], 0, n)
+    names = synth.read_names(0, n)
+    rng = np.random.default_rng(11)
+    seqs = [bytearray(qb[int(qo[i]): int(qo[i + 1])]) for i in range(n)]
+    for i in range(0, n, 5):        # random reads: every k-mer occurs once in the run -> masked by -M 2 -> num_mins small or 0
+        seqs[i] = bytearray(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=150).tobytes())
+    for i in range(1, n, 11):       # a run of N leaves only a few valid windows
+        keep = int(rng.integers(16, 24))
+        seqs[i][keep:] = b"N" * (150 - keep)
+    for i in range(2, n, 97):       # shorter than k
+        seqs[i] = seqs[i][: int(rng.integers(1, 16))]
+    seqs = [bytes(s) for s in seqs]
+    quals = [b"I" * len(s) for s in seqs]
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(b"".join(b"@" + names[i] + b"\n" + seqs[i] + b"\n+\n" + quals[i] + b"\n" for i in range(n)))
+    rb, ro = orc.pack([r[1] for r in refs])
+    pb, po = orc.pack(seqs)
+    sk, ln = orc.sketch_refs(rb, ro, [16], 1000, threads=4)
+
+    def run(cmd, flags, exact, python_cli=False):
+        env = dict(os.environ)
+        env["RKMH_EXACT_MIN_NUM"] = "1" if exact else "0"
+        argv = ([sys.executable, "-m", "rkmh_amd.cli"] if python_cli else [exe]) + [cmd, "-r", str(ref_fa), "-f", str(fq), "-k", "16"] + flags
+        r = subprocess.run(argv, capture_output=True, cwd=root, env=env)
+        assert r.returncode == 0, r.stderr
+        return r.stdout
+
+    # stream: 200 M slots (rkmh.cpp:739)
+    rows = orc.classify_stream(pb, po, [16], 1000, sk, ln, threads=8, min_kmer_occ=2, counter_slots=200000000)
+    assert (rows[:, 3] <= 5).any() and (rows[:, 3] > 5).any()
+    for flags, kw in ((["-M", "2"], {}), (["-M", "2", "-N", "5"], dict(min_matches=5)), (["-M", "2", "-N", "0", "-D", "3"], dict(min_matches=0, min_diff=3)),
+                      (["-M", "2", "-N", "40"], dict(min_matches=40))):
+        want = "".join(orc.stream_line(refs[rows[i, 0]][0].decode(), names[i].decode(), rows[i, 1], rows[i, 2], rows[i, 3], 1000, **kw)
+                       for i in range(n)).encode()
+        if "-N" in flags:
+            assert b"FAIL:DEPTH" in want
+        for exact in (False, True):
+            assert run("stream", flags, exact) == want, (flags, exact)
+        assert run("stream", flags, False, python_cli=True) == want, ("python cli", flags)
+    # filter: 10 M slots (:1187); -D -1 lets reads through that share nothing, so `read_min_lens <= 0` alone decides for them
+    frows = orc.classify_stream(pb, po, [16], 1000, sk, ln, threads=8, min_kmer_occ=2, counter_slots=10000000)
+    for flags, kw in ((["-M", "2"], {}), (["-M", "2", "-N", "3"], dict(min_matches=3)), (["-M", "2", "-D", "-1"], dict(min_diff=-1))):
+        want = b""
+        for i in range(n):
+            if orc.filter_decision(frows[i], kw.get("min_matches", -1), kw.get("min_diff", 0))[3]:
+                want += orc.filter_record(names[i], orc.to_upper(seqs[i]), quals[i])
+        assert want
+        for exact in (False, True):
+            assert run("filter", flags, exact) == want, (flags, exact)
+        assert run("filter", flags, False, python_cli=True) == want, ("python cli", flags)
