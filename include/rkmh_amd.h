@@ -37,6 +37,7 @@ extern "C" {
 #define RK_ERR_STATE (-4) /* e.g. classify before rk_set_references */
 #define RK_ERR_LIMIT (-5) /* exceeds a documented limit */
 #define RK_ERR_IO (-6)
+#define RK_ERR_NEED_FULL (-7) /* a compact depth map cannot answer this input: repeat the pass with a full rk_counter */
 
 #define RK_MAX_KS 8     /* number of -k values per run (src/rkmh.cpp:680-682 pushes onto a vector) */
 #define RK_MAX_K 64     /* largest k-mer size */
@@ -142,6 +143,21 @@ int rk_depth_map_tag(const rk_ctx* ctx, const int* ks, int nks, const uint8_t* b
                      int64_t nseq, uint8_t tag[RK_DEPTH_TAG_BYTES]);
 void* rk_counter_device_ptr(rk_counter* c);
 uint64_t rk_counter_slots(const rk_counter* c);
+/* Compact depth map for -M runs that need min_num only up to bound 0 (rk_set_min_num_bound(ctx, 0): `stream` without -N,
+ * `filter` with -D >= 0).  mask_by_frequency (src/rkmh.cpp:916) then changes a read's row only through windows whose hash is a
+ * sketch hash, and whether such a hash survives depends on ONE slot of the HASHTCounter, hash % slots -- so only the slots that
+ * some key of the reference index maps to are counted: rk_counter_entries() int32 instead of `slots` (a few hundred KB instead of
+ * the 800 MB of rkmh.cpp:739), counted EXACTLY (every window of every read is still hashed; collisions into a tracked slot count,
+ * as in the full table).  Laid out from the references of `ctx` at this call (create it after rk_set_references; it is refused
+ * once the references change).  d_counts_int32: NULL (the library allocates and zeroes) or caller-owned, ZEROED device memory of
+ * rk_counter_compact_entries() int32 (e.g. a torch tensor to all-reduce between the passes).
+ * Serves rk_count_batch / rk_count_batch_device / rk_fastq_slot_count, rk_counter_clear / _add / _copy / _get (of index keys) and
+ * rk_set_depth_filter.  Any batch holding a read with more hashes than the sketch keeps is refused with RK_ERR_NEED_FULL before
+ * anything is counted (bottom-s selection depends on the depth of every hash): the caller repeats the pass with a full table. */
+int rk_counter_create_compact(rk_ctx* ctx, uint64_t slots, void* d_counts_int32, rk_counter** out);
+int rk_counter_compact_entries(const rk_ctx* ctx, uint64_t slots, uint64_t* entries);
+uint64_t rk_counter_entries(const rk_counter* c); /* int32 entries behind rk_counter_device_ptr (= slots for a full table) */
+int rk_counter_is_compact(const rk_counter* c);
 
 /* ------------------------------------------------------------------------------------------------
  * OUTER boundary: batched replacements of main_stream's loops.

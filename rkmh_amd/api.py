@@ -17,7 +17,13 @@ FOLD_SWAP32, FOLD_H1, FOLD_W2W1 = 0, 1, 2
 
 
 class RkmhError(RuntimeError):
-    pass
+    code = 0
+
+
+class NeedFullDepthMap(RkmhError):
+    """RK_ERR_NEED_FULL: a compact depth map cannot answer this input (reads with more hashes than the sketch keeps); repeat the
+    pass with a full Counter."""
+    code = -7
 
 
 class Policy(C.Structure):
@@ -91,6 +97,10 @@ _SIGS = {
     "rk_num_references": (C.c_int, [C.c_void_p]),
     "rk_set_depth_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rk_set_min_num_bound": (C.c_int, [C.c_void_p, C.c_int]),
+    "rk_counter_create_compact": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rk_counter_compact_entries": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "rk_counter_entries": (C.c_uint64, [C.c_void_p]),
+    "rk_counter_is_compact": (C.c_int, [C.c_void_p]),
     "rk_min_num_bound": (C.c_int, [C.c_void_p]),
     "rk_count_batch": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_int64, C.c_void_p]),
     "rk_count_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -166,7 +176,10 @@ def load_library():
 
 def _chk(rc):
     if rc != 0:
-        raise RkmhError("rkmh_amd error %d: %s" % (rc, load_library().rk_last_error().decode()))
+        cls = NeedFullDepthMap if rc == -7 else RkmhError
+        e = cls("rkmh_amd error %d: %s" % (rc, load_library().rk_last_error().decode()))
+        e.code = rc
+        raise e
 
 
 def _p(a, t):
@@ -548,11 +561,15 @@ class FastqSlot:
 class Counter:
     """HASHTCounter (rkmh.cpp:739): int32 table in HBM, slot = key % slots."""
 
-    def __init__(self, ctx, slots=None, device_ptr=None):
+    def __init__(self, ctx, slots=None, device_ptr=None, compact=False):
+        """compact=True: the compact depth map of rk_counter_create_compact (only the slots of index keys; needs the references set
+        and min_num bound 0); device_ptr then names zeroed memory of Counter.compact_entries(ctx, slots) int32, or None."""
         self._lib = load_library()
         self._ctx = ctx
         self._h = C.c_void_p()
-        if device_ptr is not None:
+        if compact:
+            _chk(self._lib.rk_counter_create_compact(ctx._h, slots, C.c_void_p(device_ptr) if device_ptr is not None else None, C.byref(self._h)))
+        elif device_ptr is not None:
             _chk(self._lib.rk_counter_wrap(ctx._h, C.c_void_p(device_ptr), slots, C.byref(self._h)))
         else:
             _chk(self._lib.rk_counter_create(ctx._h, slots, C.byref(self._h)))
@@ -590,9 +607,23 @@ class Counter:
         else:
             _chk(self._lib.rk_counter_load_tagged(self._h, os.fsencode(path), C.c_char_p(bytes(tag)), len(tag)))
 
+    @staticmethod
+    def compact_entries(ctx, slots):
+        n = C.c_uint64()
+        _chk(load_library().rk_counter_compact_entries(ctx._h, slots, C.byref(n)))
+        return int(n.value)
+
     @property
     def slots(self):
         return int(self._lib.rk_counter_slots(self._h))
+
+    @property
+    def entries(self):
+        return int(self._lib.rk_counter_entries(self._h))
+
+    @property
+    def compact(self):
+        return bool(self._lib.rk_counter_is_compact(self._h))
 
     @property
     def device_ptr(self):

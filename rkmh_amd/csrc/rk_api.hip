@@ -86,6 +86,14 @@ struct rk_counter {
     rk_ctx* ctx;
     int32_t* d;
     uint64_t slots;
+    uint64_t entries = 0; // int32 entries behind d: `slots` for a full table, the tracked slots of a compact one
+    // compact depth map (rk_counter_create_compact): entry e counts the windows whose hash % slots is the e-th smallest of the
+    // slots that some key of the context's reference index maps to; key_sid[key id] = its entry
+    bool compact = false;
+    uint64_t index_gen = 0; // the reference index (rk_ctx::index_gen) the tracked slots were taken from
+    DevBuf c_pre, c_tab, c_keysid;
+    std::vector<uint32_t> h_tab; // host copy of the (slot, entry) table (rk_counter_get)
+    CompactSlots cs{};
     bool owned;
     int device; // copy of ctx->device: destroying a counter after its context must not touch the freed context
     // the slot-partitioned count pass (rk_count.hip) adds to the table with plain read-modify-writes: passes into one table are
@@ -139,6 +147,8 @@ struct rk_ctx {
     // outside the index is looked up in the depth map except by the probe that counts the first `bound` survivors
     int min_num_bound = -1;
     uint32_t nkeys = 0;                      // distinct sketch hashes = key ids of the index
+    std::vector<uint64_t> h_keyhash;         // [nkeys] the hash of each key id (compact depth maps are laid out from it)
+    uint64_t index_gen = 0;                  // bumped by every index build: compact depth maps belong to one index
     DevBuf d_keepkey, d_km1m[KM_MAX_KS], d_km1cells[KM_MAX_KS];
     uint32_t km1_ncells[KM_MAX_KS] = {0}, km1_vmask[KM_MAX_KS] = {0};
     KmerSets ksets_m{};                      // ksets with km1 = the masked copies (valid while a bounded depth filter is set)
@@ -250,6 +260,13 @@ struct GeneralCfg {
 };
 
 static uint32_t next_pow2(uint32_t x) { uint32_t p = 64; while (p < x) p <<= 1; return p; }
+
+// mask_by_frequency of the general path: by slot of the depth table, or -- compact depth map -- through the keep bits of the index keys
+static void apply_depth_cfg(const rk_ctx* c, GeneralCfg& cfg) {
+    if (!c->depth) return;
+    if (c->depth->compact) { cfg.filter_mode = FILTER_KEYMASK; return; }
+    cfg.filt_counter = c->depth; cfg.filter_mode = FILTER_MASK_MIN; cfg.fmin = c->min_occ;
+}
 
 // d_bases: device pointer to the batch's bases when already resident (else nullptr => upload from `bases`)
 // memcpy into a pinned staging buffer with a few threads: one core copies ~14 GB/s, the link takes several times that
@@ -367,6 +384,8 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
     RKCHK(set_dev(c));
     if (n <= 0) return RK_OK;
     const bool need_sort = out.sketches || out.lens || out.out4 || out.write_back_sorted;
+    if ((cfg.inc_counter && cfg.inc_counter->compact) || (cfg.distinct_counter && cfg.distinct_counter->compact) || (cfg.filt_counter && cfg.filt_counter->compact))
+        return fail(RK_ERR_STATE, "a compact depth map only serves rk_count_batch* of reads that fit the sketch and rk_set_depth_filter");
     if (cfg.classify && !c->have_refs) return fail(RK_ERR_STATE, "classify before rk_set_references");
     const uint64_t MAX_CHUNK_BASES = 1ull << 28, MAX_CHUNK_HASHES = 1ull << 26;
     std::vector<TileDesc> tiles;
@@ -390,6 +409,9 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
             if (cfg.single_kmer) nh = 1;
             else for (int j = 0; j < cfg.ks.n; ++j) nh += (uint64_t)num_windows((int)len, cfg.ks.k[j], c->pol.drop_last_window);
             if (len > 0x7fffffffull) return fail(RK_ERR_LIMIT, "sequence %lld longer than 2^31-1", (long long)i1);
+            if (cfg.filter_mode == FILTER_KEYMASK && (nh > (uint64_t)cfg.S || cfg.keep_all))
+                return fail(RK_ERR_NEED_FULL, "sequence %lld has %llu hashes for a sketch of %d: bottom-s selection needs the depth of every hash, "
+                            "which a compact depth map does not hold", (long long)i1, (unsigned long long)nh, cfg.S);
             if (cfg.keep_all && nh > (uint64_t)cfg.S)
                 return fail(RK_ERR_LIMIT, "sequence %lld has %llu hashes; without bottom-s selection at most %d take part", (long long)i1,
                             (unsigned long long)nh, cfg.S);
@@ -567,7 +589,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
         }
         HIPCHK(hipStreamSynchronize(c->st));
         // -M with a bounded min_num: the general path computes min_num exactly; rows carry min(min_num, bound) on every path
-        if (out.out4 && cfg.classify && !cfg.keep_all && cfg.filter_mode == FILTER_MASK_MIN && c->min_num_bound >= 0)
+        if (out.out4 && cfg.classify && !cfg.keep_all && (cfg.filter_mode == FILTER_MASK_MIN || cfg.filter_mode == FILTER_KEYMASK) && c->min_num_bound >= 0)
             for (int64_t q = i0; q < i1; ++q) if (out.out4[q * 4 + 3] > c->min_num_bound) out.out4[q * 4 + 3] = c->min_num_bound;
         hash_cursor += ch;
         i0 = i1;
@@ -783,14 +805,14 @@ extern "C" int rk_counter_create(rk_ctx* c, uint64_t slots, rk_counter** out) {
     HIPCHK(hipMemsetAsync(d, 0, slots * 4, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
     rk_counter* k = new rk_counter();
-    k->ctx = c; k->d = (int32_t*)d; k->slots = slots; k->owned = true; k->device = c->device;
+    k->ctx = c; k->d = (int32_t*)d; k->slots = slots; k->entries = slots; k->owned = true; k->device = c->device;
     *out = k;
     return RK_OK;
 }
 extern "C" int rk_counter_wrap(rk_ctx* c, void* d, uint64_t slots, rk_counter** out) {
     if (!c || !out || !d || slots == 0) return fail(RK_ERR_ARG, "bad arguments");
     rk_counter* k = new rk_counter();
-    k->ctx = c; k->d = (int32_t*)d; k->slots = slots; k->owned = false; k->device = c->device;
+    k->ctx = c; k->d = (int32_t*)d; k->slots = slots; k->entries = slots; k->owned = false; k->device = c->device;
     *out = k;
     return RK_OK;
 }
@@ -801,7 +823,7 @@ extern "C" void rk_counter_destroy(rk_counter* k) {
     if (k->last_atomic_set) { e = hipEventSynchronize(k->last_atomic); (void)e; }
     if (k->last) { e = hipEventDestroy(k->last); (void)e; }
     if (k->last_atomic) { e = hipEventDestroy(k->last_atomic); (void)e; }
-    k->ws.release();
+    k->ws.release(); k->c_pre.release(); k->c_tab.release(); k->c_keysid.release();
     if (k->owned) { e = hipFree(k->d); (void)e; }
     delete k;
 }
@@ -809,7 +831,7 @@ extern "C" int rk_counter_clear(rk_counter* k) {
     if (!k) return fail(RK_ERR_ARG, "counter is NULL");
     RKCHK(set_dev(k->ctx));
     RKCHK(counter_settle(k));
-    HIPCHK(hipMemsetAsync(k->d, 0, k->slots * 4, k->ctx->st));
+    HIPCHK(hipMemsetAsync(k->d, 0, k->entries * 4, k->ctx->st));
     HIPCHK(hipStreamSynchronize(k->ctx->st));
     return RK_OK;
 }
@@ -819,6 +841,8 @@ extern "C" int rk_counter_clear(rk_counter* k) {
 static int counter_combine(rk_counter* dst, const rk_counter* src, bool add) {
     if (!dst || !src) return fail(RK_ERR_ARG, "counter is NULL");
     if (dst->slots != src->slots) return fail(RK_ERR_ARG, "counters of %llu and %llu slots", (unsigned long long)dst->slots, (unsigned long long)src->slots);
+    if (dst->compact != src->compact || dst->entries != src->entries)
+        return fail(RK_ERR_ARG, "a compact and a full depth map, or compact maps of different reference sets, cannot be combined");
     if (dst == src || dst->d == src->d) return add ? fail(RK_ERR_ARG, "rk_counter_add of a table to itself") : RK_OK;
     RKCHK(set_dev(src->ctx));
     RKCHK(counter_settle(src));
@@ -826,17 +850,17 @@ static int counter_combine(rk_counter* dst, const rk_counter* src, bool add) {
     RKCHK(set_dev(dst->ctx));
     RKCHK(counter_settle(dst));
     hipStream_t st = dst->ctx->st;
-    if (!add) { HIPCHK(hipMemcpyAsync(dst->d, src->d, src->slots * 4, hipMemcpyDefault, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
+    if (!add) { HIPCHK(hipMemcpyAsync(dst->d, src->d, src->entries * 4, hipMemcpyDefault, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
     // RKMH_COUNTER_STAGED=1 takes the staged branch below even for two tables of ONE device (a one-GPU box can test it)
     static const bool force_staged = getenv("RKMH_COUNTER_STAGED") && atoi(getenv("RKMH_COUNTER_STAGED")) != 0;
-    if (dst->device == src->device && !force_staged) { HIPCHK(launch_counter_add(dst->d, src->d, dst->slots, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
+    if (dst->device == src->device && !force_staged) { HIPCHK(launch_counter_add(dst->d, src->d, dst->entries, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
     if (dst->device != src->device && !force_staged) {
         // two devices of one node: with peer access the add kernel reads the other device's table in place over xGMI
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, dst->device, src->device) == hipSuccess && can) {
             hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);
             if (pe == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); pe = hipSuccess; }
-            if (pe == hipSuccess) { HIPCHK(launch_counter_add(dst->d, src->d, dst->slots, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
+            if (pe == hipSuccess) { HIPCHK(launch_counter_add(dst->d, src->d, dst->entries, st)); HIPCHK(hipStreamSynchronize(st)); return RK_OK; }
             (void)hipGetLastError();
         }
     }
@@ -845,7 +869,7 @@ static int counter_combine(rk_counter* dst, const rk_counter* src, bool add) {
     const uint64_t CH = (uint64_t)16 << 20; // slots per piece
     DevBuf tmp[2];
     int rc = RK_OK;
-    for (int i = 0; i < 2 && rc == RK_OK; ++i) rc = tmp[i].reserve(std::min<uint64_t>(CH, dst->slots) * 4);
+    for (int i = 0; i < 2 && rc == RK_OK; ++i) rc = tmp[i].reserve(std::min<uint64_t>(CH, dst->entries) * 4);
     hipEvent_t copied[2] = {nullptr, nullptr}, added[2] = {nullptr, nullptr};
     hipStream_t cst = nullptr;
     if (rc == RK_OK && hipStreamCreateWithFlags(&cst, hipStreamNonBlocking) != hipSuccess) rc = fail(RK_ERR_HIP, "hipStreamCreate failed");
@@ -854,8 +878,8 @@ static int counter_combine(rk_counter* dst, const rk_counter* src, bool add) {
             rc = fail(RK_ERR_HIP, "hipEventCreate failed");
     int which = 0;
     uint64_t piece = 0;
-    for (uint64_t off = 0; off < dst->slots && rc == RK_OK; off += CH, which ^= 1, ++piece) {
-        const uint64_t n = std::min<uint64_t>(CH, dst->slots - off);
+    for (uint64_t off = 0; off < dst->entries && rc == RK_OK; off += CH, which ^= 1, ++piece) {
+        const uint64_t n = std::min<uint64_t>(CH, dst->entries - off);
         hipError_t e = hipSuccess;
         if (piece >= 2) e = hipStreamWaitEvent(cst, added[which], 0);           // the buffer's previous piece has been added
         if (e == hipSuccess) e = hipMemcpyAsync(tmp[which].p, src->d + off, n * 4, hipMemcpyDefault, cst);
@@ -876,8 +900,12 @@ static int counter_combine(rk_counter* dst, const rk_counter* src, bool add) {
 }
 extern "C" int rk_counter_add(rk_counter* dst, const rk_counter* src) { return counter_combine(dst, src, true); }
 extern "C" int rk_counter_copy(rk_counter* dst, const rk_counter* src) { return counter_combine(dst, src, false); }
+static int not_for_compact(const rk_counter* k, const char* what) {
+    return (k && k->compact) ? fail(RK_ERR_STATE, "%s: a compact depth map only counts whole batches (rk_count_batch*) and only the slots of index keys", what) : RK_OK;
+}
 extern "C" int rk_counter_increment(rk_counter* k, uint64_t key) {
     if (!k) return fail(RK_ERR_ARG, "counter is NULL");
+    RKCHK(not_for_compact(k, "rk_counter_increment"));
     RKCHK(set_dev(k->ctx));
     RKCHK(counter_settle(k));
     HIPCHK(launch_counter_inc(k->d, k->slots, key, k->ctx->st));
@@ -888,6 +916,13 @@ extern "C" int rk_counter_get(const rk_counter* k, uint64_t key, int32_t* out) {
     if (!k || !out) return fail(RK_ERR_ARG, "bad arguments");
     RKCHK(set_dev(k->ctx));
     RKCHK(counter_settle(k));
+    if (k->compact) { // the entry of the key's slot, if that slot is tracked (it is for every index key)
+        const uint32_t s32 = (uint32_t)(key % k->slots);
+        for (uint32_t idx = (s32 * 0x85EBCA6Bu) >> k->cs.tab_shift;; idx = (idx + 1u) & k->cs.tab_mask) {
+            if (k->h_tab[2 * (size_t)idx] == s32) { HIPCHK(hipMemcpy(out, k->d + k->h_tab[2 * (size_t)idx + 1], 4, hipMemcpyDeviceToHost)); return RK_OK; }
+            if (k->h_tab[2 * (size_t)idx] == CS_EMPTY) return fail(RK_ERR_STATE, "rk_counter_get: the key's slot is not tracked by this compact depth map");
+        }
+    }
     HIPCHK(hipMemcpy(out, k->d + (key % k->slots), 4, hipMemcpyDeviceToHost));
     return RK_OK;
 }
@@ -899,6 +934,7 @@ static int counter_save_impl(rk_counter* k, const char* path, const void* tag, u
     if (!k || !path || (tag_len && !tag)) return fail(RK_ERR_ARG, "bad arguments");
     if (tag_len > 4096) return fail(RK_ERR_ARG, "tag too long");
     if (k->slots > 0xffffffffull) return fail(RK_ERR_LIMIT, "counter too large to serialise (slot index is 32 bit)");
+    RKCHK(not_for_compact(k, "rk_counter_save"));
     RKCHK(set_dev(k->ctx));
     RKCHK(counter_settle(k));
     std::vector<int32_t> h((size_t)k->slots);
@@ -922,6 +958,7 @@ static int counter_save_impl(rk_counter* k, const char* path, const void* tag, u
 }
 static int counter_load_impl(rk_counter* k, const char* path, const void* tag, uint32_t tag_len) {
     if (!k || !path || (tag_len && !tag)) return fail(RK_ERR_ARG, "bad arguments");
+    RKCHK(not_for_compact(k, "rk_counter_load"));
     RKCHK(set_dev(k->ctx));
     RKCHK(counter_settle(k));
     FILE* f = fopen(path, "rb");
@@ -1015,6 +1052,84 @@ extern "C" int rk_depth_map_tag(const rk_ctx* c, const int* ks, int nks, const u
 }
 extern "C" void* rk_counter_device_ptr(rk_counter* k) { return k ? k->d : nullptr; }
 extern "C" uint64_t rk_counter_slots(const rk_counter* k) { return k ? k->slots : 0; }
+extern "C" uint64_t rk_counter_entries(const rk_counter* k) { return k ? k->entries : 0; }
+extern "C" int rk_counter_is_compact(const rk_counter* k) { return k && k->compact ? 1 : 0; }
+
+// The compact depth map of a -M run that only needs min_num up to bound 0 (rk_set_min_num_bound): mask_by_frequency then acts
+// through the index keys alone, and whether a key survives depends on ONE slot of the table -- key % slots.  So only those slots
+// are counted (pass 1 hashes every window as before, but a window whose slot is not one of them is dropped after one bit test):
+// the table shrinks from `slots` int32 (800 MB for the reference's 2 * 10^8, rkmh.cpp:739) to one int32 per distinct tracked slot,
+// there is no slot array to bin, and the sum over devices or ranks moves a few hundred KB.
+// the tracked slots of the compact map for the reference index of `c` and a table of `slots`, ascending; key_sid[key id] = the
+// entry that counts the key's slot.  Deterministic in (index, slots): every rank and device of a run lays its map out identically.
+static int compact_layout(const rk_ctx* c, uint64_t slots, std::vector<uint32_t>& islots, std::vector<uint32_t>* key_sid) {
+    if (!c->have_refs) return fail(RK_ERR_STATE, "a compact depth map is laid out from the reference index: call rk_set_references first");
+    if (slots == 0 || slots > 0xFFFFFFFFull) return fail(RK_ERR_LIMIT, "compact depth map: slots must be at most 2^32 - 1");
+    islots.resize(c->nkeys);
+    for (uint32_t j = 0; j < c->nkeys; ++j) islots[j] = (uint32_t)(c->h_keyhash[j] % slots);
+    std::vector<uint32_t> sorted(islots);
+    std::sort(sorted.begin(), sorted.end());
+    sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
+    if (key_sid) {
+        key_sid->resize(c->nkeys);
+        for (uint32_t j = 0; j < c->nkeys; ++j) (*key_sid)[j] = (uint32_t)(std::lower_bound(sorted.begin(), sorted.end(), islots[j]) - sorted.begin());
+    }
+    islots.swap(sorted);
+    return RK_OK;
+}
+extern "C" int rk_counter_compact_entries(const rk_ctx* c, uint64_t slots, uint64_t* entries) {
+    if (!c || !entries) return fail(RK_ERR_ARG, "bad arguments");
+    std::vector<uint32_t> islots;
+    RKCHK(compact_layout(c, slots, islots, nullptr));
+    *entries = islots.empty() ? 1 : islots.size();
+    return RK_OK;
+}
+extern "C" int rk_counter_create_compact(rk_ctx* c, uint64_t slots, void* d_counts_int32, rk_counter** out) {
+    if (!c || !out) return fail(RK_ERR_ARG, "bad arguments");
+    RKCHK(set_dev(c));
+    std::vector<uint32_t> islots, key_sid;
+    RKCHK(compact_layout(c, slots, islots, &key_sid));
+    const size_t m = islots.size(), entries = m ? m : 1;
+    // the slot filter: one bit per hashed slot, 32-64 bits per tracked slot, at most 2^23 bits = 1 MB (L2-resident beside the hashing)
+    uint32_t pre_lg = 12;
+    while (pre_lg < 23 && ((size_t)1 << pre_lg) < m * 64) ++pre_lg;
+    std::vector<uint32_t> pre(((size_t)1 << pre_lg) / 32, 0u);
+    uint32_t tab_lg = 4;
+    while (((size_t)1 << tab_lg) < 2 * m + 2) ++tab_lg;
+    std::vector<uint32_t> tab(((size_t)2 << tab_lg), CS_EMPTY);
+    const uint32_t pre_shift = 32u - pre_lg, tab_shift = 32u - tab_lg, tab_mask = (1u << tab_lg) - 1u;
+    for (size_t e = 0; e < m; ++e) {
+        const uint32_t s32 = islots[e], bit = (s32 * 0x9E3779B1u) >> pre_shift;
+        pre[bit >> 5] |= 1u << (bit & 31u);
+        uint32_t idx = (s32 * 0x85EBCA6Bu) >> tab_shift;
+        while (tab[2 * (size_t)idx] != CS_EMPTY) idx = (idx + 1u) & tab_mask;
+        tab[2 * (size_t)idx] = s32; tab[2 * (size_t)idx + 1] = (uint32_t)e;
+    }
+    rk_counter* k = new rk_counter();
+    k->ctx = c; k->slots = slots; k->entries = entries; k->compact = true; k->index_gen = c->index_gen; k->device = c->device;
+    k->owned = d_counts_int32 == nullptr; k->d = (int32_t*)d_counts_int32;
+    int rc = RK_OK;
+    if (k->owned) {
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, entries * 4);
+        if (e != hipSuccess) rc = fail(RK_ERR_NOMEM, "hipMalloc(%zu) for the compact depth map: %s", entries * 4, hipGetErrorString(e));
+        else { k->d = (int32_t*)d; if (hipMemsetAsync(d, 0, entries * 4, c->st) != hipSuccess) rc = fail(RK_ERR_HIP, "hipMemsetAsync failed"); }
+    }
+    if (rc == RK_OK) rc = k->c_pre.reserve(pre.size() * 4);
+    if (rc == RK_OK) rc = k->c_tab.reserve(tab.size() * 4);
+    if (rc == RK_OK) rc = k->c_keysid.reserve(key_sid.size() * 4 + 16);
+    if (rc == RK_OK && (hipMemcpyAsync(k->c_pre.p, pre.data(), pre.size() * 4, hipMemcpyHostToDevice, c->st) != hipSuccess ||
+                        hipMemcpyAsync(k->c_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->st) != hipSuccess ||
+                        (!key_sid.empty() && hipMemcpyAsync(k->c_keysid.p, key_sid.data(), key_sid.size() * 4, hipMemcpyHostToDevice, c->st) != hipSuccess) ||
+                        hipStreamSynchronize(c->st) != hipSuccess))
+        rc = fail(RK_ERR_HIP, "compact depth map: upload failed");
+    if (rc != RK_OK) { rk_counter_destroy(k); return rc; }
+    k->cs.pre = k->c_pre.as<uint32_t>(); k->cs.tab = k->c_tab.as<uint2>();
+    k->cs.pre_shift = pre_shift; k->cs.tab_shift = tab_shift; k->cs.tab_mask = tab_mask;
+    k->h_tab.swap(tab);
+    *out = k;
+    return RK_OK;
+}
 
 // ---- batched: hash / sketch --------------------------------------------------------------------
 extern "C" int rk_hash_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int64_t nseq,
@@ -1115,11 +1230,14 @@ static int build_index(rk_ctx* c) {
     }
     const size_t nkeys = base[nb];
     c->nkeys = (uint32_t)nkeys;
+    ++c->index_gen;
     c->ix.keepkey = nullptr; memset(&c->ksets_m, 0, sizeof c->ksets_m); // a depth filter set earlier refers to the old key ids
     std::vector<uint32_t> dense((nkeys + 1) * 4, 0);
     for (uint32_t b = 0; b < nb; ++b)
         for (uint32_t q = 0; q < base[(size_t)b + 1] - base[b]; ++q)
             memcpy(&dense[((size_t)base[b] + q) * 4], &kv[((size_t)IDX_SLOTS * b + q) * 4], 16);
+    c->h_keyhash.resize(nkeys);
+    for (size_t q = 0; q < nkeys; ++q) c->h_keyhash[q] = ((uint64_t)dense[q * 4 + 1] << 32) | dense[q * 4];
     RKCHK(c->d_base.reserve(((size_t)nb + 1) * 4));
     HIPCHK(hipMemcpy(c->d_base.p, base.data(), ((size_t)nb + 1) * 4, hipMemcpyHostToDevice));
     RKCHK(c->d_kv.reserve((nkeys + 1) * 16));
@@ -1420,7 +1538,10 @@ static int build_key_mask(rk_ctx* c) {
     if (!c->depth || c->min_num_bound < 0 || !c->have_refs) return RK_OK;
     RKCHK(set_dev(c));
     RKCHK(c->d_keepkey.reserve(((size_t)c->nkeys + 31) / 32 * 4 + 16));
-    HIPCHK(launch_keep_keys(c->ix, c->nkeys, c->depth->d, c->depth->slots, nullptr, c->min_occ, c->pol, c->d_keepkey.as<uint32_t>(), c->st));
+    if (c->depth->compact && c->depth->index_gen != c->index_gen)
+        return fail(RK_ERR_STATE, "the compact depth map was laid out for another reference set");
+    HIPCHK(launch_keep_keys(c->ix, c->nkeys, c->depth->d, c->depth->slots, c->depth->compact ? c->depth->c_keysid.as<uint32_t>() : nullptr,
+                            c->min_occ, c->pol, c->d_keepkey.as<uint32_t>(), c->st));
     if (c->ksets.n >= 1) {
         c->ksets_m = c->ksets;
         for (int j = 0; j < c->ksets.n; ++j) {
@@ -1439,21 +1560,30 @@ static int build_key_mask(rk_ctx* c) {
 
 extern "C" int rk_set_depth_filter(rk_ctx* c, rk_counter* counter, int min_kmer_occ) {
     if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
-    c->depth = counter; c->min_occ = min_kmer_occ;
+    if (counter && counter->compact && c->min_num_bound != 0)
+        return fail(RK_ERR_STATE, "a compact depth map only answers min_num bound 0 (rk_set_min_num_bound(ctx, 0) first)");
+    c->depth = nullptr; c->min_occ = min_kmer_occ;
     c->ix.keepkey = nullptr;
+    memset(&c->ksets_m, 0, sizeof c->ksets_m);
     if (counter) {
+        if (counter->compact && (counter->index_gen != c->index_gen || counter->ctx != c))
+            return fail(RK_ERR_STATE, "the compact depth map was laid out for another reference set or context");
+        c->depth = counter; // (every failure below leaves the context without a filter)
+        struct Undo { rk_ctx* c; bool armed = true; ~Undo() { if (armed) { c->depth = nullptr; c->ix.keepkey = nullptr; } } } undo{c};
         // the fused kernel's masked forms read one KEEP bit per slot instead of the 4-byte count (k_keep_bits): a snapshot of
         // the table as it is NOW -- the -M flow sets the filter after pass 1 (and after the all-reduce in multi-GPU runs)
         RKCHK(set_dev(c));
         // pass 1 (rk_count_batch_device) is asynchronous on the CALLER's stream, an all-reduce may run on yet another one: the
         // snapshot must see the finished table, so the whole device is drained first (once per -M run: not a hot path)
         HIPCHK(hipDeviceSynchronize());
+        RKCHK(counter_settle(counter));
         if (c->min_num_bound != 0) { // bound 0: no window is ever looked up by slot (the mask acts through the keys alone)
             RKCHK(c->d_keepbits.reserve(((counter->slots + 31) / 32) * 4 + 16));
             HIPCHK(launch_keep_bits(counter->d, counter->slots, min_kmer_occ, c->pol, c->d_keepbits.as<uint32_t>(), c->st));
             HIPCHK(hipStreamSynchronize(c->st));
         }
         RKCHK(build_key_mask(c));
+        undo.armed = false;
     }
     return RK_OK;
 }
@@ -1464,6 +1594,7 @@ extern "C" int rk_set_min_num_bound(rk_ctx* c, int bound) {
     if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
     const int nb = bound < 0 ? -1 : bound;
     if (nb == c->min_num_bound) return RK_OK;
+    if (c->depth && c->depth->compact && nb != 0) return fail(RK_ERR_STATE, "the depth filter in use is a compact map: it only answers min_num bound 0");
     c->min_num_bound = nb;
     if (c->depth) return rk_set_depth_filter(c, c->depth, c->min_occ); // rebuild the snapshot in the other form
     return RK_OK;
@@ -1516,6 +1647,24 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     uint32_t ml = max_read_len < 1 ? 1 : (max_read_len > (uint32_t)FUSED_MAXLEN ? (uint32_t)FUSED_MAXLEN : max_read_len);
     int expect = 0; // hits an error-free read is expected to score: sizes the kernel's per-read hit multiset
     for (int j = 0; j < c->ks.n; ++j) expect += (int)(c->density * (double)num_windows((int)ml, c->ks.k[j], c->pol.drop_last_window)) + 1;
+    if (mode == 1 && count_into->compact) {
+        // pass 1 into a compact depth map: hash every window, count the few whose slot is tracked (k_classify_tile, MODE 1, cs.tab)
+        if (count_into->index_gen != c->index_gen || count_into->ctx != c)
+            return fail(RK_ERR_STATE, "the compact depth map was laid out for another reference set or context");
+        uint64_t nh = 0;
+        for (int j = 0; j < c->ks.n; ++j) nh += (uint64_t)num_windows((int)max_read_len, c->ks.k[j], c->pol.drop_last_window);
+        if (nh > (uint64_t)c->S || max_read_len > (uint32_t)FUSED_MAXLEN || !classify_tile_supported(0, (int)ml))
+            return fail(RK_ERR_NEED_FULL, "reads of up to %u bases have more hashes (%llu) than the sketch keeps (%d): bottom-s selection needs the "
+                        "depth of every hash, which a compact depth map does not hold", max_read_len, (unsigned long long)nh, c->S);
+        RefIndex ix0 = c->ix; ix0.keepkey = nullptr;
+        HIPCHK(launch_classify_tile((const uint8_t*)d_bases, (const uint32_t*)d_offs, (uint32_t)nreads, c->ks, c->S, ix0,
+                                    counter, slots, 0, 1, nullptr, c->pol, (int)ml, expect, st, 0, 0x7fffffff, &count_into->cs));
+        std::lock_guard<std::mutex> lock(count_into->mu);
+        if (!count_into->last_atomic) HIPCHK(hipEventCreateWithFlags(&count_into->last_atomic, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(count_into->last_atomic, st)); // readers of the map wait for the latest pass (they all add with atomics: no order among them)
+        count_into->last_atomic_set = true;
+        return RK_OK;
+    }
     if (mode == 1) {
         bool done = false;
         RKCHK(count_partitioned(c, d_bases, d_offs, nreads, ml, expect, count_into, total_bases, st, &done));
@@ -1579,7 +1728,7 @@ static int reroute_flagged(rk_ctx* c, const uint8_t* bases, const uint64_t* offs
     for (size_t j = 0; j < idx.size(); ++j) memcpy(sub.data() + offs[j], bases + offsets[idx[j]], (size_t)(offs[j + 1] - offs[j]));
     std::vector<int32_t> res(idx.size() * 4);
     GeneralCfg cfg; cfg.ks = c->ks; cfg.S = c->S; cfg.classify = true;
-    if (c->depth) { cfg.filt_counter = c->depth; cfg.filter_mode = FILTER_MASK_MIN; cfg.fmin = c->min_occ; }
+    apply_depth_cfg(c, cfg);
     GeneralOut go; go.out4 = res.data();
     RKCHK(general_run(c, sub.data(), nullptr, offs.data(), (int64_t)idx.size(), cfg, go));
     for (size_t j = 0; j < idx.size(); ++j) memcpy(out4 + idx[j] * 4, res.data() + j * 4, 16);
@@ -1597,7 +1746,7 @@ extern "C" int rk_classify_groups_batch(rk_ctx* c, const uint8_t* bases, const u
     if (argmax_refs < c->ix.nref && !tail_counts && nreads > 0) return fail(RK_ERR_ARG, "tail_counts is NULL");
     GeneralCfg cfg; cfg.ks = c->ks; cfg.S = c->S; cfg.classify = true; cfg.keep_all = true;
     cfg.argmax_n = argmax_refs < c->ix.nref ? argmax_refs : 0;
-    if (c->depth) { cfg.filt_counter = c->depth; cfg.filter_mode = FILTER_MASK_MIN; cfg.fmin = c->min_occ; }
+    apply_depth_cfg(c, cfg);
     GeneralOut go; go.out4 = out4; go.tail_counts = cfg.argmax_n ? tail_counts : nullptr;
     return general_run(c, bases, nullptr, offsets, nreads, cfg, go);
 }
@@ -1640,7 +1789,7 @@ extern "C" int rk_classify_batch_device_all(rk_ctx* c, const void* d_bases, cons
     }
     std::vector<int32_t> res(m * 4);
     GeneralCfg cfg; cfg.ks = c->ks; cfg.S = c->S; cfg.classify = true; cfg.abs_starts = starts.data();
-    if (c->depth) { cfg.filt_counter = c->depth; cfg.filter_mode = FILTER_MASK_MIN; cfg.fmin = c->min_occ; }
+    apply_depth_cfg(c, cfg);
     GeneralOut go; go.out4 = res.data();
     RKCHK(general_run(c, nullptr, (const uint8_t*)d_bases, lens_ps.data(), (int64_t)m, cfg, go));
     // scatter the answers into the caller's result buffer
@@ -1789,7 +1938,7 @@ extern "C" int rk_classify_batch(rk_ctx* c, const uint8_t* bases, const uint64_t
     const int64_t ngen = ngen_a.load();
     if (ngen == nreads || !classify_tile_supported(c->ix.nref, 1)) { // e.g. a nanopore batch: one pass through the general path
         GeneralCfg cfg; cfg.ks = c->ks; cfg.S = c->S; cfg.classify = true;
-        if (c->depth) { cfg.filt_counter = c->depth; cfg.filter_mode = FILTER_MASK_MIN; cfg.fmin = c->min_occ; }
+        apply_depth_cfg(c, cfg);
         GeneralOut go; go.out4 = out4;
         return general_run(c, bases, nullptr, offsets, nreads, cfg, go);
     }
@@ -1822,6 +1971,7 @@ extern "C" int rk_count_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* o
     bool any_long = false;
     for (int64_t i = 0; i < nreads; ++i) if (offsets[i + 1] - offsets[i] > (uint64_t)FUSED_MAXLEN) { any_long = true; break; }
     if (!any_long) return host_pipeline(c, bases, offsets, nreads, nullptr, 1, counter);
+    if (counter->compact) return fail(RK_ERR_NEED_FULL, "reads longer than %d bases: a compact depth map only counts reads that fit the sketch", FUSED_MAXLEN);
     RKCHK(counter_settle(counter));
     GeneralCfg cfg; cfg.ks = c->ks; cfg.inc_counter = counter;
     GeneralOut none;
@@ -2080,7 +2230,7 @@ extern "C" int rk_fastq_slot_finish(rk_fastq_slot* s, rk_fastq_result* res) {
         for (size_t j = 0; j < idx.size(); ++j) memcpy(sub.data() + offs[j], text + res->seq_off[idx[j]], res->seq_len[idx[j]]);
         std::vector<int32_t> rows(idx.size() * 4);
         GeneralCfg cfg; cfg.ks = c->ks; cfg.S = c->S; cfg.classify = true;
-        if (c->depth) { cfg.filt_counter = c->depth; cfg.filter_mode = FILTER_MASK_MIN; cfg.fmin = c->min_occ; }
+        apply_depth_cfg(c, cfg);
         GeneralOut go; go.out4 = rows.data();
         {
             std::lock_guard<std::mutex> lock(c->general_mu);

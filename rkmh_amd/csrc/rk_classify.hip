@@ -41,6 +41,7 @@
 #include "rk_kernels.hpp"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace rk {
 
@@ -107,6 +108,7 @@ struct TileGeom {
     int32_t magic_nw;   // windows (first k) of a read of the hinted length, and ...
     uint32_t magic;     // ... ceil(2^32 / magic_nw): the compact window -> read division of tiles made of such reads
     int32_t nmin_cap;   // row field 3 = min(non-zero hashes, nmin_cap) (-M with a bounded min_num: rk_set_min_num_bound; else INT_MAX)
+    CompactSlots cs;    // count pass into a compact depth map (cs.tab != nullptr): `counter` then holds one entry per tracked slot
 };
 
 __host__ __device__ inline int tile_map_words(int cap_bytes) { return cap_bytes / 32 + 2; }
@@ -211,6 +213,28 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
 #pragma unroll
     for (int q = 0; q < PF; ++q) pf[q] = 0u;
     uint32_t cur_a = 0, cur_b = 0, cur_o = 0; // tile byte range [a,b) in the batch, this lane's read offset
+    // Count pass into a COMPACT depth map (MODE 1, geo.cs.tab): only slots that some index key maps to are tracked (a few hundred
+    // thousand out of 2 * 10^8).  One bit of an L2-resident filter -- its word requested one step ahead, like the classifier's
+    // first-level filter -- turns away the windows whose slot is not among them; the rest (true occurrences of sketch hashes and
+    // the few collisions: a dozen per read instead of 135) are queued in LDS and, 64 at a time with every lane busy, find their
+    // entry in a small table and count with an atomic.  The queue outlives the tiles: it holds slots, nothing of the tile.
+    uint32_t cslot = CS_EMPTY;   // this step's slot (CS_EMPTY: the lane hashed no countable window)
+    uint32_t cprev = CS_EMPTY;   // last step's slot, whose filter word is in flight ...
+    uint32_t cword = 0;          // ... here
+    uint32_t ccount = 0;         // queued slots (wave-uniform)
+    auto compact_drain = [&](uint32_t from, uint32_t n_) { // queue entries [from, from + n_), n_ <= 64
+        uint32_t* cq = reinterpret_cast<uint32_t*>(qe);
+        if ((uint32_t)lane < n_) {
+            const uint32_t s32 = cq[from + (uint32_t)lane];
+            uint32_t idx = (s32 * 0x85EBCA6Bu) >> geo.cs.tab_shift;
+            for (;;) {
+                const uint2 e = geo.cs.tab[idx];
+                if (e.x == s32) { atomicAdd(&counter[e.y], 1); break; }
+                if (e.x == CS_EMPTY) break; // a false positive of the filter
+                idx = (idx + 1u) & geo.cs.tab_mask;
+            }
+        }
+    };
     auto tile_reads = [&](uint32_t tl) -> int {
         const uint32_t r = tl * (uint32_t)T;
         return (int)((nreads - r) < (uint32_t)T ? (nreads - r) : (uint32_t)T);
@@ -547,7 +571,8 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                                     const uint64_t slot = mod_slots(hh, slots, geo.slots_m);
                                     // slot-partitioned count (rk_count.hip): the window's slot goes to the flat array, indexed by
                                     // the byte position of the window (tails keep the sentinel); no atomic here
-                                    if (out4) reinterpret_cast<uint32_t*>(out4)[(size_t)kk * geo.slot_stride + tstart + pp] = (uint32_t)slot;
+                                    if (geo.cs.tab) cslot = (uint32_t)slot; // compact depth map: looked up at the loop level (below), all lanes together
+                                    else if (out4) reinterpret_cast<uint32_t*>(out4)[(size_t)kk * geo.slot_stride + tstart + pp] = (uint32_t)slot;
                                     else atomicAdd(&counter[slot], 1);
                                 }
                             } else {
@@ -614,7 +639,28 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                         }
                         }
                     }
-                    if (MODE == 1) continue;
+                    if (MODE == 1) {
+                        if (geo.cs.tab) { // wave-uniform: the compact depth map
+                            uint32_t* cq = reinterpret_cast<uint32_t*>(qe);
+                            word_wait(cword);
+                            const uint32_t pbit = (cprev * 0x9E3779B1u) >> geo.cs.pre_shift;
+                            const bool pass = cprev != CS_EMPTY && ((cword >> (pbit & 31u)) & 1u) != 0u;
+                            const uint64_t m = __ballot(pass);
+                            if (pass) cq[ccount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = cprev;
+                            ccount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ccount + (uint32_t)__popcll(m)));
+                            const uint32_t nbit = (cslot * 0x9E3779B1u) >> geo.cs.pre_shift; // (CS_EMPTY looks some word up too: never tested)
+                            word_load_async(geo.cs.pre, (nbit >> 5) << 2, cword);
+                            cprev = cslot;
+                            cslot = CS_EMPTY;
+                            if (ccount >= 2u * WAVE) { // (the queue holds 3 * 64 entries)
+                                wave_sync();
+                                compact_drain(ccount - WAVE, WAVE);
+                                ccount -= WAVE;
+                                wave_sync();
+                            }
+                        }
+                        continue;
+                    }
                     // examine the lookup issued one step ago: fingerprint matches / full buckets are queued
                     if constexpr (PRE) { // large panel: the filter word decides what the drain will look up in the table
                         word_wait(fw);
@@ -731,6 +777,17 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         // the output of this statement, so any such copy follows it.  tools/lint_async_loads.py checks the ISA for this.
         wait_bases();
     }
+    if (MODE == 1 && geo.cs.tab) { // the compact count's last step and what is left in its queue
+        uint32_t* cq = reinterpret_cast<uint32_t*>(qe);
+        word_wait(cword);
+        const uint32_t pbit = (cprev * 0x9E3779B1u) >> geo.cs.pre_shift;
+        const bool pass = cprev != CS_EMPTY && ((cword >> (pbit & 31u)) & 1u) != 0u;
+        const uint64_t m = __ballot(pass);
+        if (pass) cq[ccount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = cprev;
+        ccount += (uint32_t)__popcll(m);
+        wave_sync();
+        for (uint32_t f = 0; f < ccount; f += WAVE) compact_drain(f, ccount - f < (uint32_t)WAVE ? ccount - f : (uint32_t)WAVE);
+    }
 }
 
 // LDS budget of one single-wave workgroup for 6 waves per SIMD (24 per CU, 512-byte allocation granules).  The kernel
@@ -825,14 +882,14 @@ bool classify_tile_supported(int nref, int maxlen) { return nref <= 16384 && max
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st,
-                                uint32_t slot_stride, int nmin_cap) {
+                                uint32_t slot_stride, int nmin_cap, const CompactSlots* compact) {
     if (nreads == 0) return hipSuccess;
     const TileKnobs& kn = knobs();
     int win_total = 0; // most windows any read of the batch can have (all k): bounds every per-reference count
     for (int j = 0; j < ks.n; ++j) win_total += num_windows(maxlen, ks.k[j], pol.drop_last_window);
     TileGeom geo = make_geom(maxlen, mode == 1 ? 0 : ix.nref, mode == 1 ? 0 : expect_hits,
                              num_windows(maxlen, ks.k[0], pol.drop_last_window), win_total);
-    if (mode == 1) { geo.qcap = 0; geo.dset = 0; }
+    if (mode == 1) { geo.qcap = compact ? 48 : 0; geo.dset = 0; } // (compact count: 3 * 64 queued slots of 4 bytes)
     while (tile_lds_bytes(geo) > 20 * 1024 && geo.T > 1) { geo.T -= 1; geo.cap_bytes = geo.T * maxlen; } // >= 8 waves per CU
     const size_t lds = tile_lds_bytes(geo);
     const uint32_t ntiles = (nreads + (uint32_t)geo.T - 1) / (uint32_t)geo.T;
@@ -846,6 +903,7 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
     geo.slots_m = slots ? ~0ull / slots : 0;
     geo.slot_stride = slot_stride;
     geo.nmin_cap = nmin_cap;
+    if (compact) geo.cs = *compact; else memset(&geo.cs, 0, sizeof geo.cs);
     geo.magic_nw = num_windows(maxlen, ks.k[0], pol.drop_last_window);
     geo.magic = geo.magic_nw >= 2 ? 0xFFFFFFFFu / (uint32_t)geo.magic_nw + 1u : 0u;
     const bool k16 = (ks.n == 1 && ks.k[0] == 16);

@@ -123,6 +123,9 @@ __global__ void k_sort_intersect(SortArgs a, RefIndex ix, int has_ix, DevPolicy 
             int c = a.counter[h % a.slots];
             bool keep = pol.freq_max_inclusive ? (c >= a.fmin && c <= a.fmax) : (c >= a.fmin && c < a.fmax);
             if (!keep) h = 0;
+        } else if (a.filter_mode == FILTER_KEYMASK && h != 0 && has_ix && ix.keepkey) { // the mask through the index keys (no selection follows)
+            const uint32_t slot = index_find(ix, h);
+            if (slot != IDX_NOT_FOUND && !((ix.keepkey[slot >> 5] >> (slot & 31u)) & 1u)) h = 0;
         }
         return h;
     };

@@ -25,7 +25,9 @@ struct TileDesc {
     uint32_t pad;
 };
 
-enum { FILTER_NONE = 0, FILTER_MASK_MIN = 1, FILTER_RANGE = 2 };
+// FILTER_KEYMASK: mask_by_frequency through the per-key keep bits of the index (RefIndex::keepkey) instead of the depth table --
+// for sequences whose hashes all fit the sketch (no bottom-S selection), where only hashes that ARE index keys matter
+enum { FILTER_NONE = 0, FILTER_MASK_MIN = 1, FILTER_RANGE = 2, FILTER_KEYMASK = 3 };
 
 struct SortArgs {
     uint64_t* hashes;          // all hashes (segments per sequence)
@@ -147,6 +149,17 @@ hipError_t launch_intersect_pair(const uint64_t* a, int na, const uint64_t* b, i
 hipError_t launch_intersect_pair_emit(const uint64_t* a, int na, const uint64_t* b, int nb, int cap, uint64_t* out, int* n_out, hipStream_t st);
 hipError_t launch_fill_reroute(int32_t* out4, uint32_t nreads, hipStream_t st);
 hipError_t launch_scatter_rows(const int32_t* rows, const uint32_t* ids, uint32_t m, int32_t* out4, hipStream_t st);
+// The compact depth map (rk_counter_create_compact): only the slots some index key maps to are counted, entry e of the map
+// counts the e-th smallest of them.  pre: one bit per hashed slot (an L2-resident filter: a window whose slot fails it is not
+// counted at all), tab: open-addressing (slot, entry) pairs, empty = slot CS_EMPTY.
+constexpr uint32_t CS_EMPTY = 0xFFFFFFFFu;
+struct CompactSlots {
+    const uint32_t* pre;
+    const uint2* tab;
+    uint32_t pre_shift;  // bit index = (slot * 0x9E3779B1) >> pre_shift
+    uint32_t tab_shift;  // first probe = (slot * 0x85EBCA6B) >> tab_shift
+    uint32_t tab_mask;
+};
 // mode 0: classify (out4 written); mode 1: count only (counter incremented)
 // wave-per-tile fused kernel (rk_classify.hip); expect_hits sizes the per-read hit multiset
 bool classify_tile_supported(int nref, int maxlen);
@@ -154,7 +167,7 @@ constexpr int KPRE_MIN_K = 8; // the k-mer-space kernel (rk_kmer.hip) exists for
 hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S,
                                 const RefIndex& ix, int32_t* counter, uint64_t slots, int min_occ, int mode,
                                 int32_t* out4, const DevPolicy& pol, int maxlen, int expect_hits, hipStream_t st,
-                                uint32_t slot_stride = 0, int nmin_cap = 0x7fffffff);
+                                uint32_t slot_stride = 0, int nmin_cap = 0x7fffffff, const CompactSlots* compact = nullptr);
 // the k-mer-space kernel (rk_kmer.hip): plain classification with k-mer sizes from KPRE_MIN_K to 16 whose exact k-mer maps and group
 // filters were built (KmerSets: one per size; a single size runs the compile-time-k kernels, several the run-time-k one)
 bool classify_kmer_supported(int nref, int maxlen, int k);

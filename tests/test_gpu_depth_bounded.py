@@ -261,3 +261,88 @@ def test_clis_print_the_same_bytes_in_bounded_and_exact_form(orc, root, data_dir
         for exact in (False, True):
             assert run("filter", flags, exact) == want, (flags, exact)
         assert run("filter", flags, False, python_cli=True) == want, ("python cli", flags)
+
+
+@pytest.mark.parametrize("ks,slots,min_occ", [([16], 200000000, 2), ([16], 4099, 60), ([12, 16], 1000003, 2), ([20], 10000000, 2), ([21], 65537, 9)])
+def test_compact_depth_map_equals_the_full_table(orc, pave, ks, slots, min_occ):
+    """rk_counter_create_compact counts only the slots index keys map to -- exactly: the entry of every sampled key equals the full
+    table's slot, two half-batches summed with rk_counter_add equal one pass, and the rows classified under it equal the oracle's
+    two-pass rows (min_num clamped to bound 0)."""
+    import rkmh_amd
+    _, rb, ro = pave
+    T = min(16, os.cpu_count() or 1)
+    n = 20000
+    qb, qo = _reads(rb, ro, 3000, n, seed=17 + slots % 13)
+    c = rkmh_amd.Context(0)
+    try:
+        c.set_references(rb, ro, ks, 1000)
+        sk, ln = c.get_reference_sketches()
+        want = _clamped(orc.classify_stream(qb, qo, ks, 1000, sk, ln, threads=T, min_kmer_occ=min_occ, counter_slots=slots), 0)
+        full = rkmh_amd.Counter(c, slots=slots)
+        c.count_batch(qb, qo, full)
+        comp = rkmh_amd.Counter(c, slots=slots, compact=True)
+        assert comp.compact and comp.entries == rkmh_amd.Counter.compact_entries(c, slots) <= len(np.unique(sk[sk != 0]))
+        c.count_batch(qb, qo, comp)
+        keys = np.unique(sk[sk != 0])
+        rng = np.random.default_rng(1)
+        for key in rng.choice(keys, size=40, replace=False):
+            assert comp.get(int(key)) == full.get(int(key)), int(key)
+        # two halves on two maps, summed
+        h1 = rkmh_amd.Counter(c, slots=slots, compact=True)
+        h2 = rkmh_amd.Counter(c, slots=slots, compact=True)
+        half = n // 2
+        c.count_batch(qb, qo[: half + 1], h1)
+        ob = qo[half:] - qo[half]
+        c.count_batch(_pad(qb[int(qo[half]): int(qo[-1])]), ob, h2)
+        h1.add(h2)
+        for key in rng.choice(keys, size=20, replace=False):
+            assert h1.get(int(key)) == full.get(int(key)), int(key)
+        with pytest.raises(rkmh_amd.api.RkmhError):
+            c.set_depth_filter(comp, min_occ)           # exact min_num needs the full table
+        c.set_min_num_bound(0)
+        try:
+            for cnt in (comp, h1, full):
+                c.set_depth_filter(cnt, min_occ)
+                got = c.classify(qb, qo)
+                bad = np.nonzero((got != want).any(axis=1))[0]
+                assert len(bad) == 0, (ks, slots, cnt.compact, len(bad), got[bad[:4]], want[bad[:4]])
+            c.set_depth_filter(comp, min_occ)
+            with pytest.raises(rkmh_amd.api.RkmhError):
+                c.set_min_num_bound(3)
+        finally:
+            c.set_depth_filter(None, 0)
+            c.set_min_num_bound(-1)
+        with pytest.raises(rkmh_amd.api.RkmhError):
+            comp.save("/tmp/never.bin")
+        for k in (full, comp, h1, h2):
+            k.destroy()
+    finally:
+        c.close()
+
+
+def test_compact_depth_map_refuses_what_it_cannot_answer(orc, pave):
+    import rkmh_amd
+    from rkmh_amd import api
+    _, rb, ro = pave
+    c = rkmh_amd.Context(0)
+    try:
+        with pytest.raises(api.RkmhError):
+            rkmh_amd.Counter(c, slots=1000003, compact=True)        # no references yet
+        c.set_references(rb, ro, [16], 100)
+        comp = rkmh_amd.Counter(c, slots=1000003, compact=True)
+        short = _pad(rb[:3000].copy())
+        c.count_batch(short, np.arange(0, 3001, 100, dtype=np.uint64), comp)   # 100-base reads: 84 windows <= 100
+        with pytest.raises(api.NeedFullDepthMap):                   # 150-base reads: 134 windows > s = 100
+            c.count_batch(short, np.arange(0, 3001, 150, dtype=np.uint64), comp)
+        with pytest.raises(api.NeedFullDepthMap):                   # long reads
+            c.count_batch(_pad(rb[:8000].copy()), np.array([0, 4000, 8000], dtype=np.uint64), comp)
+        c.set_references(rb, ro[:50], [16], 100)                    # another index: the map is stale
+        with pytest.raises(api.RkmhError):
+            c.count_batch(short, np.arange(0, 3001, 100, dtype=np.uint64), comp)
+        c.set_min_num_bound(0)
+        with pytest.raises(api.RkmhError):
+            c.set_depth_filter(comp, 2)
+        c.set_min_num_bound(-1)
+        comp.destroy()
+    finally:
+        c.close()
