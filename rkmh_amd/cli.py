@@ -190,7 +190,7 @@ def _references_on_device(ctx, refs, ks, sketch, max_samples, counter_slots, cou
             os.close(fd)
 
 
-def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, min_matches, min_diff, filter_mode, out_fd):
+def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, min_matches, min_diff, filter_mode, out_fd, compact_ok=False):
     """This rank's byte range of every read file through the device FASTQ front end (rk_fastq_slot_*): worker threads read raw blocks
     straight into page-locked buffers, the GPU splits / checks / packs / classifies them, the lines are written in C from the names
     where they lie (rk_fastq_stream_lines / rk_fastq_filter_records) -- the host never parses a read, exactly as bin/rkmh does it
@@ -286,11 +286,27 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
         if min_occ is not None:
             import torch
             nslots = 10000000 if filter_mode else 200000000  # rkmh.cpp:1187 / :739
-            t = torch.zeros(nslots, dtype=torch.int32, device="cuda:%d" % local)
-            torch.cuda.synchronize()
-            counter = api.Counter(ctx, slots=nslots, device_ptr=t.data_ptr())
-            run_pass(counter)                                   # pass 1 (rkmh.cpp:904-910) on this rank's blocks
+
+            def depth_map(compact):
+                # compact: only the slots of index keys (rk_counter_create_compact) -- the all-reduce then moves a few hundred KB
+                tt = torch.zeros(api.Counter.compact_entries(ctx, nslots) if compact else nslots, dtype=torch.int32, device="cuda:%d" % local)
+                torch.cuda.synchronize()
+                return tt, api.Counter(ctx, slots=nslots, device_ptr=tt.data_ptr(), compact=compact)
+
+            t, counter = depth_map(compact_ok)
+            need_full = False
+            try:
+                run_pass(counter)                               # pass 1 (rkmh.cpp:904-910) on this rank's blocks
+            except api.NeedFullDepthMap:                        # a read with more hashes than the sketch keeps
+                need_full = True
+                state.pop("err", None)
+                state["ok"] = True
             ctx.synchronize()
+            if compact_ok and not rdist.all_true(not need_full):   # on any rank: every rank repeats the pass into the full table
+                counter.destroy()
+                t, counter = depth_map(False)
+                run_pass(counter)
+                ctx.synchronize()
             if not rdist.all_true(state["ok"]):
                 counter.destroy()
                 return False
@@ -372,11 +388,15 @@ def main_stream(argv, filter_mode=False):
     out = os.fdopen(result_fd, "wb")
     rank, local, world = rdist.init()
     ctx = api.Context(local)
+    compact_ok = False
     if min_occ is not None and not (os.environ.get("RKMH_EXACT_MIN_NUM", "0") not in ("", "0")):
         # -M: the output compares num_mins with -N (stream, rkmh.cpp:938) or with 0 (filter, :1292) and nothing else, so
         # min(num_mins, bound) is all it needs -- the masked pass then looks up index keys, not every window (rk_set_min_num_bound)
-        cmp_with = 0 if filter_mode else min_matches
-        ctx.set_min_num_bound(0 if cmp_with < 0 else cmp_with + 1)
+        # (filter with -D >= 0: a read that shares nothing fails the diff test anyway, so not even min(read_min_lens, 1) is needed)
+        cmp_with = (-1 if min_diff >= 0 else 0) if filter_mode else min_matches
+        bound = 0 if cmp_with < 0 else cmp_with + 1
+        ctx.set_min_num_bound(bound)
+        compact_ok = bound == 0 and os.environ.get("RKMH_FULL_DEPTH_MAP", "0") in ("", "0")
     # Rank 0 alone reads the reference files -- genome-sized plain FASTA as raw text stripped on the device (_references_on_device),
     # anything else with the host parser --, sketches them and broadcasts sketches and names; the other ranks never open them.
     ms_filter = max_samples if (max_samples is not None and max_samples < 100000) else None   # filter: rkmh.cpp:1211
@@ -411,7 +431,7 @@ def main_stream(argv, filter_mode=False):
     # Uncompressed FASTQ files do not pass through a host parser at all (see _device_ingest); RKMH_RAW=0 turns that off.
     if os.environ.get("RKMH_RAW", "1") != "0" and not os.environ.get("RKMH_CLI_WHOLE_PARSE"):
         out.flush()
-        if _device_ingest(ctx, rank, local, world, reads, R["names"], sketch, min_occ, min_matches, min_diff, filter_mode, result_fd):
+        if _device_ingest(ctx, rank, local, world, reads, R["names"], sketch, min_occ, min_matches, min_diff, filter_mode, result_fd, compact_ok):
             ctx.close()
             try:
                 import torch.distributed as dist
@@ -460,10 +480,15 @@ def main_stream(argv, filter_mode=False):
         import torch
         slots = 10000000 if filter_mode else 200000000  # rkmh.cpp:1187 / :739
         dev = "cuda:%d" % local
-        t = torch.zeros(slots, dtype=torch.int32, device=dev)
+        # compact depth map (only the slots of index keys) when the output needs min_num up to bound 0 and no read of any rank has
+        # more hashes than the sketch keeps (bottom-s selection would need the depth of every hash)
+        lens = (offs[1:] - offs[:-1]).astype(np.int64) if len(offs) > 1 else np.zeros(0, dtype=np.int64)
+        fits = bool(len(lens) == 0 or (int(lens.max()) <= 1500 and int(sum(max(0, int(lens.max()) - k + 1) for k in ks)) <= sketch))
+        compact = rdist.all_true(compact_ok and fits)
+        t = torch.zeros(api.Counter.compact_entries(ctx, slots) if compact else slots, dtype=torch.int32, device=dev)
         if t.is_cuda:
             torch.cuda.synchronize()                 # (the fill runs on torch's stream, the count pass on the context's)
-        counter = api.Counter(ctx, slots=slots, device_ptr=t.data_ptr())
+        counter = api.Counter(ctx, slots=slots, device_ptr=t.data_ptr(), compact=compact)
         ctx.count_batch(bases, offs, counter)       # pass 1 on this rank's reads
         ctx.synchronize()
         rdist.allreduce_counter(t)                   # RCCL sum over ranks
@@ -484,7 +509,9 @@ def main_stream(argv, filter_mode=False):
             shared, diff_ok = 0, 0 > min_diff
         else:
             shared, diff_ok = int(r[1]), (int(r[2]) - (1 if int(r[0]) == 0 else 0)) > min_diff
-        if int(r[3]) <= 0 or shared < min_matches or not diff_ok:      # rkmh.cpp:1292-1298
+        # rkmh.cpp:1292-1298; read_min_lens <= 0 implies shared == 0, so the conjunction is the same predicate on exact rows and stays
+        # right on rows whose min_num was clamped to 0 (bound 0: only with -D >= 0)
+        if (int(r[3]) <= 0 and shared <= 0) or shared < min_matches or not diff_ok:
             return b""
         a, b = int(qoff[i]), int(qoff[i + 1])
         return b">" + qnames[i] + b"\n" + _upper(qbases[a:b]) + b"\n+\n" + (quals[i] if quals is not None else b"") + b"\n"   # rkmh.cpp:1299-1302

@@ -119,7 +119,9 @@ extern "C" int64_t rk_fastq_filter_records(const rk_fastq_result* r, const uint8
         int shared = 0;
         bool diff_ok = 0 > min_diff;
         if (q[1] > 0) { shared = q[1]; diff_ok = q[2] - (q[0] == 0 ? 1 : 0) > min_diff; }
-        if (q[3] <= 0 || shared < min_matches || !diff_ok) continue; // rkmh.cpp:1292-1293
+        // rkmh.cpp:1292-1293.  read_min_lens <= 0 implies shared == 0 (a shared hash is a min): the conjunction is the same predicate on
+        // exact rows and stays right on rows whose min_num was clamped to 0 (rk_set_min_num_bound(ctx, 0), which callers use with -D >= 0)
+        if ((q[3] <= 0 && shared <= 0) || shared < min_matches || !diff_ok) continue;
         *w++ = '>';
         memcpy(w, text + r->name_off[i], r->name_len[i]); w += r->name_len[i];
         *w++ = '\n';

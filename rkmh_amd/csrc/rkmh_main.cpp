@@ -307,6 +307,29 @@ static void share_counters_on_group(DeviceGroup& g, std::vector<rk_counter*>& cn
     for (size_t step = top >> 1; step >= 1; step >>= 1)
         group_run(g, [&](size_t d) { return (d % (2 * step) == 0 && d + step < D) ? rk_counter_copy(cnt[d + step], cnt[d]) : RK_OK; });
 }
+// The depth maps of a -M run, one per device: compact (rk_counter_create_compact: only the slots of index keys, a few hundred KB)
+// when the output needs min_num only up to bound 0 and every read's hashes fit the sketch, else the reference's full table.
+static void make_depth_maps(DeviceGroup& g, uint64_t slots, bool compact, std::vector<rk_counter*>& cnts) {
+    for (rk_counter* k : cnts) rk_counter_destroy(k);
+    cnts.assign(g.size(), nullptr);
+    group_run(g, [&](size_t d) { return compact ? rk_counter_create_compact(g.ctx[d], slots, nullptr, &cnts[d]) : rk_counter_create(g.ctx[d], slots, &cnts[d]); });
+}
+// RKMH_FULL_DEPTH_MAP=1 keeps the full table (A/B runs, tests)
+static bool compact_maps_wanted(int bound, const char* read_map) {
+    return bound == 0 && !read_map && !(getenv("RKMH_FULL_DEPTH_MAP") && atoi(getenv("RKMH_FULL_DEPTH_MAP")) != 0);
+}
+// every read short enough that bottom-s selection cannot matter (conservative: len - k + 1 windows per size) and for the fused kernel
+static bool reads_fit_sketch(const rk_seqset& reads, const Opts& o) {
+    for (int64_t i = 0; i < reads.nseq; ++i) {
+        const int64_t len = (int64_t)(reads.offsets[i + 1] - reads.offsets[i]);
+        int64_t nh = 0;
+        for (int k : o.ks) nh += len - k + 1 > 0 ? len - k + 1 : 0;
+        if (nh > o.sketch || len > 1500) return false;
+    }
+    return true;
+}
+static std::atomic<bool> g_need_full{false}; // a count pass met RK_ERR_NEED_FULL: repeat it with full tables
+
 static void two_pass_on_group(DeviceGroup& g, const rk_seqset& reads, uint64_t slots, int min_occ, std::vector<rk_counter*>& cnt,
                               bool pass1, int32_t* out4) {
     const size_t D = g.size();
@@ -605,7 +628,9 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                     t_rd += now_s() - a;
                     const double b = now_s();
                     int32_t status = 0; int64_t nrec = 0;
-                    if (rk_fastq_slot_count(eng.w[wi].slot[k], nbytes, (*cnts)[eng.w[wi].dev], &status, &nrec) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+                    const int crc = rk_fastq_slot_count(eng.w[wi].slot[k], nbytes, (*cnts)[eng.w[wi].dev], &status, &nrec);
+                    if (crc == RK_ERR_NEED_FULL) { g_need_full.store(true); status = 1; } // a read with more hashes than the sketch keeps: the pass ends, the caller repeats it with full tables
+                    else if (crc != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
                     if (status != 0) {
                         { std::lock_guard<std::mutex> l(fm); fail_at[cur.seq] = cur.lo; }
                         int64_t curf = fail_seq.load();
@@ -684,9 +709,16 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
 // tables are summed over the devices and become every context's mask, pass 2 reads the files again and prints.  false: some block
 // is not four lines per record -- nothing was printed, the tables are clear again and the caller takes the parse-everything path.
 static bool two_pass_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& refs, const Opts& o, const std::vector<int64_t>& sizes,
-                         std::vector<rk_counter*>& cnts, RawKind kind, double& t0) {
+                         std::vector<rk_counter*>& cnts, RawKind kind, double& t0, uint64_t slots) {
     for (size_t i = 0; i < o.reads.size(); ++i)
         if (stream_file_raw(eng, g, refs, o, o.reads[i], sizes[i], RAW_COUNT, &cnts) >= 0) {
+            if (g_need_full.exchange(false) && rk_counter_is_compact(cnts[0])) {
+                // a compact depth map cannot serve reads whose hashes exceed the sketch: the same pass again into full tables
+                if (g_timing) fprintf(stderr, "[rkmh timing] %s: reads with more hashes than the sketch keeps: pass 1 restarts with full depth tables\n", o.reads[i]);
+                make_depth_maps(g, slots, false, cnts);
+                i = (size_t)-1; // (the loop's ++i starts over at file 0)
+                continue;
+            }
             group_run(g, [&](size_t d) { return rk_counter_clear(cnts[d]); });
             if (g_timing) fprintf(stderr, "[rkmh timing] %s: not four lines per record: the host scanner reads the run\n", o.reads[i]);
             return false;
@@ -981,16 +1013,15 @@ static int main_stream(int argc, char** argv) {
     std::vector<int32_t> out4;
     bool depth_done = false;
     std::vector<rk_counter*> cnts;
+    const bool compact_ok = o.read_depth && compact_maps_wanted(min_num_bound_for(o.min_matches), read_map);
     if (o.read_depth) {
-        cnts.assign(group.size(), nullptr);
-        CK(rk_counter_create(ctx, 200000000ull, &cnts[0])); // rkmh.cpp:739
-        for (size_t d = 1; d < group.size(); ++d) CK(rk_counter_create(group.ctx[d], 200000000ull, &cnts[d]));
+        make_depth_maps(group, 200000000ull, compact_ok && all_raw, cnts); // HASHTCounter(200000000), rkmh.cpp:739
         tick("depth tables", t0);
     }
     if (o.read_depth && all_raw && !read_map) {
         // regular FASTQ files: both passes through the device front end, the reads are never held in host memory
         if (eng.create(group)) {
-            depth_done = two_pass_raw(eng, group, refs, o, raw_size, cnts, RAW_STREAM, t0);
+            depth_done = two_pass_raw(eng, group, refs, o, raw_size, cnts, RAW_STREAM, t0, 200000000ull);
             if (g_timing) fprintf(stderr, "[rkmh timing] device front end: %lld blocks, %lld records; read %.3f s, device %.3f s, format %.3f s (summed over %zu workers, both passes)\n",
                                   (long long)eng.blocks, (long long)eng.records, eng.t_read, eng.t_dev, eng.t_fmt, eng.w.size());
         }
@@ -1001,6 +1032,8 @@ static int main_stream(int argc, char** argv) {
         // two passes over ALL reads (rkmh.cpp:904-948): the reference holds them in RAM, so do we
         rk_seqset reads;
         CK(rk_parse_files(o.reads.data(), (int)o.reads.size(), &reads));
+        const bool cmp = compact_ok && reads_fit_sketch(reads, o);
+        if (cmp != (rk_counter_is_compact(cnts[0]) != 0)) make_depth_maps(group, 200000000ull, cmp, cnts);
         rk_counter* cnt = cnts[0];
         // --depth-map-cache FILE: reuse a saved depth map (pass 1 is skipped) or save this run's for the next one.  The file
         // records what it was counted from (k list, hashing policy, fingerprint of the read set); a file that does not match
@@ -1116,7 +1149,9 @@ static int main_filter(int argc, char** argv) {
     DeviceGroup group;
     group.create(o);
     // file mode compares read_min_lens with 0 (rkmh.cpp:1292); the STDIN lines print min(len) itself (:1397): exact there
-    if (o.read_depth && !in_stream) for (rk_ctx* cx : group.ctx) CK(rk_set_min_num_bound(cx, min_num_bound_for(0)));
+    // (with -D >= 0 a read that shares nothing fails the diff test anyway, so not even min(read_min_lens, 1) is needed: bound 0)
+    const int filter_bound = (o.read_depth && !in_stream) ? min_num_bound_for(o.min_diff >= 0 ? -1 : 0) : -1;
+    if (o.read_depth && !in_stream) for (rk_ctx* cx : group.ctx) CK(rk_set_min_num_bound(cx, filter_bound));
     rk_ctx* ctx = group.ctx[0];
     tick("context", t0);
     rk_seqset refs;
@@ -1142,9 +1177,8 @@ static int main_filter(int argc, char** argv) {
     }
     group.share_references(o);
     tick("sketch references", t0);
-    std::vector<rk_counter*> cnts(group.size(), nullptr);
-    for (size_t d = 0; d < group.size(); ++d) CK(rk_counter_create(group.ctx[d], 10000000ull, &cnts[d])); // read_hash_counter, rkmh.cpp:1187
-    rk_counter* cnt = cnts[0];
+    std::vector<rk_counter*> cnts;
+    const bool compact_ok = o.read_depth && !in_stream && compact_maps_wanted(filter_bound, nullptr);
     std::string buf;
     std::vector<int32_t> out4;
     // filter's records of a parsed batch (rkmh.cpp:1292-1300)
@@ -1152,7 +1186,9 @@ static int main_filter(int argc, char** argv) {
         for (int64_t i = 0; i < reads.nseq; ++i) {
             const int32_t* r = rows + (size_t)i * 4;
             const FilterDecision d = filter_decide(r, o.min_diff);
-            const bool depth_filter = r[3] <= 0, match_filter = d.shared < o.min_matches; // rkmh.cpp:1292-1293
+            // rkmh.cpp:1292-1293.  read_min_lens <= 0 implies shared == 0 (a shared hash is a min), so the conjunction is the same
+            // predicate on exact rows -- and it stays right on rows whose min_num was clamped to 0 (bound 0, only with -D >= 0)
+            const bool depth_filter = r[3] <= 0 && d.shared <= 0, match_filter = d.shared < o.min_matches;
             if (depth_filter || match_filter || !d.diff_ok) continue;
             buf += '>';
             buf += reads.names + reads.name_offsets[i];
@@ -1177,7 +1213,10 @@ static int main_filter(int argc, char** argv) {
     bool files_done = o.reads.empty();
     if (all_raw) {
         if (eng.create(group)) {
-            if (o.read_depth) files_done = two_pass_raw(eng, group, refs, o, raw_size, cnts, RAW_FILTER, t0);
+            if (o.read_depth) {
+                make_depth_maps(group, 10000000ull, compact_ok, cnts); // read_hash_counter, rkmh.cpp:1187
+                files_done = two_pass_raw(eng, group, refs, o, raw_size, cnts, RAW_FILTER, t0, 10000000ull);
+            }
             else {
                 for (size_t i = 0; i < o.reads.size(); ++i) {
                     const int64_t resume = stream_file_raw(eng, group, refs, o, o.reads[i], raw_size[i], RAW_FILTER);
@@ -1214,6 +1253,9 @@ static int main_filter(int argc, char** argv) {
         if (o.read_depth) {
             // count (rkmh.cpp:321-338), then keep get(h) >= min_kmer_occ (:1260); the reads are spread over the devices, the
             // depth tables summed in between
+            const bool cmp = compact_ok && reads_fit_sketch(reads, o);
+            if (cnts.empty() || cmp != (rk_counter_is_compact(cnts[0]) != 0)) make_depth_maps(group, 10000000ull, cmp, cnts);
+            else group_run(group, [&](size_t d) { return rk_counter_clear(cnts[d]); });
             two_pass_on_group(group, reads, 10000000ull, o.min_occ, cnts, true, out4.data());
         } else {
             group_run(group, [&](size_t d) {
@@ -1227,6 +1269,9 @@ static int main_filter(int argc, char** argv) {
         rk_seqset_free(&reads);
     }
     if (in_stream) { // rkmh.cpp:1329-1408: reads from STDIN are classified, one line each
+        // (-i keeps exact rows and full tables -- its lines print min(len) itself -- so the table, if any, is the one the files filled)
+        if (cnts.empty()) make_depth_maps(group, 10000000ull, false, cnts);
+        rk_counter* cnt = cnts[0];
         CK(rk_set_depth_filter(ctx, o.min_occ > 0 ? cnt : nullptr, o.min_occ)); // :1365
         rk_reader* rd = nullptr;
         CK(rk_reader_open("-", &rd));

@@ -230,9 +230,10 @@ def test_clis_print_the_same_bytes_in_bounded_and_exact_form(orc, root, data_dir
     pb, po = orc.pack(seqs)
     sk, ln = orc.sketch_refs(rb, ro, [16], 1000, threads=4)
 
-    def run(cmd, flags, exact, python_cli=False):
+    def run(cmd, flags, exact, python_cli=False, full_map=False):
         env = dict(os.environ)
         env["RKMH_EXACT_MIN_NUM"] = "1" if exact else "0"
+        env["RKMH_FULL_DEPTH_MAP"] = "1" if full_map else "0"
         argv = ([sys.executable, "-m", "rkmh_amd.cli"] if python_cli else [exe]) + [cmd, "-r", str(ref_fa), "-f", str(fq), "-k", "16"] + flags
         r = subprocess.run(argv, capture_output=True, cwd=root, env=env)
         assert r.returncode == 0, r.stderr
@@ -250,6 +251,7 @@ def test_clis_print_the_same_bytes_in_bounded_and_exact_form(orc, root, data_dir
         for exact in (False, True):
             assert run("stream", flags, exact) == want, (flags, exact)
         assert run("stream", flags, False, python_cli=True) == want, ("python cli", flags)
+        assert run("stream", flags, False, full_map=True) == want, ("full depth table", flags)
     # filter: 10 M slots (:1187); -D -1 lets reads through that share nothing, so `read_min_lens <= 0` alone decides for them
     frows = orc.classify_stream(pb, po, [16], 1000, sk, ln, threads=8, min_kmer_occ=2, counter_slots=10000000)
     for flags, kw in ((["-M", "2"], {}), (["-M", "2", "-N", "3"], dict(min_matches=3)), (["-M", "2", "-D", "-1"], dict(min_diff=-1))):
@@ -261,6 +263,7 @@ def test_clis_print_the_same_bytes_in_bounded_and_exact_form(orc, root, data_dir
         for exact in (False, True):
             assert run("filter", flags, exact) == want, (flags, exact)
         assert run("filter", flags, False, python_cli=True) == want, ("python cli", flags)
+        assert run("filter", flags, False, full_map=True) == want, ("full depth table", flags)
 
 
 @pytest.mark.parametrize("ks,slots,min_occ", [([16], 200000000, 2), ([16], 4099, 60), ([12, 16], 1000003, 2), ([20], 10000000, 2), ([21], 65537, 9)])
@@ -346,3 +349,45 @@ def test_compact_depth_map_refuses_what_it_cannot_answer(orc, pave):
         comp.destroy()
     finally:
         c.close()
+
+
+def test_clis_fall_back_to_full_depth_tables_for_reads_beyond_the_sketch(orc, root, data_dir, tmp_path):
+    """stream -M 2 / filter -M 2 start with compact depth maps; a read with more hashes than the sketch keeps (here 1200 bases
+    against s = 1000, in the LAST block of the file so that pass 1 is well under way) makes the count pass answer
+    RK_ERR_NEED_FULL and the CLIs repeat it with the reference's full tables.  stdout equals the oracle's, through the device
+    front end and through the parse-everything path (RKMH_RAW=0), for both CLIs."""
+    import subprocess
+    import sys
+    from rkmh_amd import synth, api
+    exe = os.path.join(root, "bin", "rkmh")
+    refs = orc.kseq_parse_file(os.path.join(data_dir, "all_pave_ref.fa.gz"))[:40]
+    ref_fa = tmp_path / "refs.fa"
+    ref_fa.write_bytes(b"".join(b">" + r[0] + b"\n" + r[1] + b"\n" for r in refs))
+    R = api.parse_files([str(ref_fa)])
+    n = 2000
+    qb, qo = synth.generate_reads(R["bases"], R["offsets"], 0, n)
+    names = [b"r%d" % i for i in range(n)]
+    seqs = [bytes(qb[int(qo[i]): int(qo[i + 1])]) for i in range(n)]
+    for i in (n - 3, n - 40):
+        seqs[i] = refs[i % 40][1][100:1300]
+    quals = [b"F" * len(s) for s in seqs]
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(b"".join(b"@" + names[i] + b"\n" + seqs[i] + b"\n+\n" + quals[i] + b"\n" for i in range(n)))
+    rb, ro = orc.pack([r[1] for r in refs])
+    pb, po = orc.pack(seqs)
+    sk, ln = orc.sketch_refs(rb, ro, [16], 1000, threads=4)
+    rows = orc.classify_stream(pb, po, [16], 1000, sk, ln, threads=8, min_kmer_occ=2, counter_slots=200000000)
+    want_stream = "".join(orc.stream_line(refs[rows[i, 0]][0].decode(), names[i].decode(), rows[i, 1], rows[i, 2], rows[i, 3], 1000)
+                          for i in range(n)).encode()
+    frows = orc.classify_stream(pb, po, [16], 1000, sk, ln, threads=8, min_kmer_occ=2, counter_slots=10000000)
+    want_filter = b"".join(orc.filter_record(names[i], orc.to_upper(seqs[i]), quals[i]) for i in range(n) if orc.filter_decision(frows[i])[3])
+    for cmd, want in (("stream", want_stream), ("filter", want_filter)):
+        for raw in ("1", "0"):
+            for python_cli in (False, True):
+                env = dict(os.environ, RKMH_RAW=raw, RKMH_RAW_BLOCK_KB="64", RKMH_TIMING="1")
+                argv = ([sys.executable, "-m", "rkmh_amd.cli"] if python_cli else [exe]) + [cmd, "-r", str(ref_fa), "-f", str(fq), "-k", "16", "-M", "2"]
+                r = subprocess.run(argv, capture_output=True, cwd=root, env=env)
+                assert r.returncode == 0, r.stderr
+                assert r.stdout == want, (cmd, raw, python_cli)
+                if raw == "1" and not python_cli:
+                    assert b"pass 1 restarts with full depth tables" in r.stderr, r.stderr
