@@ -275,6 +275,16 @@ def config_legs(rkmh_amd, api, synth, dev, n, L, check):
             tot += w
         return tot
 
+    def oracle_sketches(ctx, bases, offs, ks, S):
+        """the device's reference sketches, which must equal the oracle's own when the leg is checked"""
+        sk, ln = ctx.get_reference_sketches()
+        if check:
+            osk, oln = oracle.sketch_refs(bases, offs, ks, S, threads=oracle.max_threads())
+            if not ((osk == sk).all() and (oln == ln).all()):
+                raise SystemExit("ORACLE CHECK FAILED in a config leg: reference sketches (k=%s S=%d)" % (ks, S))
+            return osk, oln
+        return sk, ln
+
     stream = torch.cuda.current_stream().cuda_stream
     # ---- config 3's panel: every bundled reference
     files = ["all_pave_ref.fa.gz", "zika.refs.fa.gz", "dengue.fa.gz", "new_refs.fa.gz", "hpv_16.fa.gz", "zika.fa.gz", "yellow_fever.fa.gz",
@@ -284,7 +294,7 @@ def config_legs(rkmh_amd, api, synth, dev, n, L, check):
     ctx = rkmh_amd.Context(dev.index)
     try:
         ctx.set_references(pb, po, [16], 1000)
-        sk, ln = ctx.get_reference_sketches()
+        sk, ln = oracle_sketches(ctx, pb, po, [16], 1000)
         qb, qo = synth.generate_reads_fast(pb, po, 0, n, read_len=L, threads=min(32, os.cpu_count() or 1))
         d_b = torch.from_numpy(qb).to(dev)
         d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev)
@@ -294,6 +304,7 @@ def config_legs(rkmh_amd, api, synth, dev, n, L, check):
         legs["c3_panel"] = {"references": PR, "k": 16, "sketch_size": 1000, "reads": n, "kernel_ms": ms, "reads_per_s": n / ms * 1e3,
                             "kernel_form": "k-mer-space" if ctx.kmer_form()[0] else "hash-space",
                             "rerouted_rows": int((out[:, 0] < 0).sum()), "oracle_checked_reads": sample_check(out, qb, qo, [16], 1000, sk, ln),
+                            "oracle_checked_ref_sketches": int(PR) if check else 0,
                             "note": "BASELINE config 3's panel (every bundled FASTA), one GPU's resident batch of synthetic reads drawn from it"}
     finally:
         ctx.close()
@@ -303,7 +314,7 @@ def config_legs(rkmh_amd, api, synth, dev, n, L, check):
     ctx = rkmh_amd.Context(dev.index)
     try:
         ctx.set_references(rb, ro, [20], 2000)
-        sk, ln = ctx.get_reference_sketches()
+        sk, ln = oracle_sketches(ctx, rb, ro, [20], 2000)
         qb, qo = synth.generate_reads_fast(rb, ro, 0, n, read_len=L, threads=min(32, os.cpu_count() or 1))
         d_b = torch.from_numpy(qb).to(dev)
         d_o = torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev)
@@ -312,23 +323,36 @@ def config_legs(rkmh_amd, api, synth, dev, n, L, check):
         out = d_out.cpu().numpy()
         nchk = sample_check(out[:], qb, qo, [20], 2000, sk, ln) if not (out[:, 0] < 0).any() else 0
         slots = 10000000
-        cnt = api.Counter(ctx, slots)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ctx.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt, stream=stream)
-        torch.cuda.synchronize()
-        reps = 5
-        e0.record()
-        for _ in range(reps):
+
+        def count_ms_of(cnt, reps=5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ctx.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt, stream=stream)
-        e1.record()
-        torch.cuda.synchronize()
-        count_ms = e0.elapsed_time(e1) / reps
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                ctx.count_device(d_b.data_ptr(), d_o.data_ptr(), n, cnt, stream=stream)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        cnt = api.Counter(ctx, slots)
+        count_full_ms = count_ms_of(cnt)
+        ctx.set_depth_filter(cnt, 2)
+        masked_exact_ms = kernel_ms(ctx, d_b, d_o, d_out, stream, reps=10, warm=3)
+        ctx.set_depth_filter(None, 0)
+        cnt.destroy()
+        # as `filter -M 2` runs it (-D >= 0): min_num bound 0, compact depth map, the mask per index key
+        ctx.set_min_num_bound(0)
+        cnt = api.Counter(ctx, slots, compact=True)
+        count_ms = count_ms_of(cnt)
         ctx.set_depth_filter(cnt, 2)
         masked_ms = kernel_ms(ctx, d_b, d_o, d_out, stream, reps=10, warm=3)
         ctx.set_depth_filter(None, 0)
         cnt.destroy()
+        ctx.set_min_num_bound(-1)
         legs["c4_filter"] = {"references": pave["nseq"], "k": 20, "sketch_size": 2000, "reads": n, "kernel_ms": ms, "reads_per_s": n / ms * 1e3,
-                             "M2_slots": slots, "M2_count_pass_ms": count_ms, "M2_masked_classify_ms": masked_ms,
+                             "M2_slots": slots, "M2_count_pass_ms": count_ms, "M2_masked_classify_ms": masked_ms, "M2_min_num_bound": 0,
+                             "M2_count_pass_full_table_ms": count_full_ms, "M2_masked_classify_exact_min_num_ms": masked_exact_ms,
+                             "oracle_checked_ref_sketches": int(pave["nseq"]) if check else 0,
                              "rerouted_rows": int((out[:, 0] < 0).sum()), "oracle_checked_reads": nchk,
                              "note": "BASELINE config 4's kernel shape (filter: k = 20, s = 2000; hash-space kernel) on one resident batch against the "
                                      "PaVE panel; full_size = the whole command at the config's own size (3.1 Gb genome, 10 M reads)"}
@@ -544,6 +568,13 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle  # CPU baseline + checker only
             thr = a.cpu_threads or min(oracle.max_threads(), usable_cpus())
+            # the reference sketches the rows are checked against are the ORACLE's own (sketched here from the reference bases), and the
+            # device's must equal them -- the check below must not be able to pass on a wrong sketch
+            osk, oln = oracle.sketch_refs(rb, ro, ks, S, threads=thr)
+            if not ((osk == sk).all() and (oln == ln).all()):
+                raise SystemExit("ORACLE CHECK FAILED: the device's reference sketches differ from the CPU oracle's")
+            sk, ln = osk, oln
+            res["oracle_checked_ref_sketches"] = int(R)
             probe = min(n, 4 * thr)
             t = time.perf_counter()
             oracle.classify_stream(qb, qo[: probe + 1], ks, S, sk, ln, threads=thr)
@@ -619,14 +650,53 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 return e0.elapsed_time(e1) / reps
-            count_ms = timed(lambda: ctx.count_device(d_bs[0].data_ptr(), d_os[0].data_ptr(), n, cnt, stream=stream))
+            count_full_ms = timed(lambda: ctx.count_device(d_bs[0].data_ptr(), d_os[0].data_ptr(), n, cnt, stream=stream))
             ctx.set_depth_filter(cnt, 2)
-            masked_ms = timed(lambda: ctx.classify_device(d_bs[0].data_ptr(), d_os[0].data_ptr(), n, d_outs[0].data_ptr(), max_read_len=L, stream=stream))
+            masked_exact_ms = timed(lambda: ctx.classify_device(d_bs[0].data_ptr(), d_os[0].data_ptr(), n, d_outs[0].data_ptr(), max_read_len=L, stream=stream))
             ctx.set_depth_filter(None, 0)
             cnt.destroy()
+            # what `stream -M 2` runs by default (no -N: num_mins only meets `num_mins <= -1`, rkmh.cpp:938): min_num bound 0, the
+            # compact depth map (only the slots of index keys), the mask applied per key on the k-mer-space kernel
+            ctx.set_min_num_bound(0)
+            ccnt = api.Counter(ctx, slots, compact=True)
+            count_ms = timed(lambda: ctx.count_device(d_bs[0].data_ptr(), d_os[0].data_ptr(), n, ccnt, stream=stream))
+            ctx.set_depth_filter(ccnt, 2)
+            masked_ms = timed(lambda: ctx.classify_device(d_bs[0].data_ptr(), d_os[0].data_ptr(), n, d_outs[0].data_ptr(), max_read_len=L, stream=stream))
+            ctx.set_depth_filter(None, 0)
+            entries = ccnt.entries
+            ccnt.destroy()
+            checked = 0
+            if a.cpu_seconds > 0:
+                # both passes on a sub-batch against the oracle's two-pass loop (min_num clamped to the bound), compact and full maps
+                import oracle
+                cores = a.cpu_threads or min(oracle.max_threads(), usable_cpus())
+                m = min(n, 65536)
+                sub_o = np.ascontiguousarray(qos[0][: m + 1])
+                sub_b = np.ascontiguousarray(qbs[0][: int(sub_o[-1]) + 16])
+                want = oracle.classify_stream(sub_b, sub_o, ks, S, sk, ln, threads=cores, min_kmer_occ=2, counter_slots=slots)
+                for compact, bound in ((True, 0), (False, 0), (False, 3), (False, -1)):
+                    ctx.set_min_num_bound(bound)
+                    c2 = api.Counter(ctx, slots, compact=compact)
+                    ctx.count_batch(sub_b, sub_o, c2)
+                    ctx.set_depth_filter(c2, 2)
+                    got = ctx.classify(sub_b, sub_o)
+                    ctx.set_depth_filter(None, 0)
+                    c2.destroy()
+                    w = want.copy()
+                    if bound >= 0:
+                        w[:, 3] = np.minimum(w[:, 3], bound)
+                    if not (got == w).all():
+                        raise SystemExit("-M rows differ from the oracle (compact=%s bound=%d)" % (compact, bound))
+                    checked += m
+            ctx.set_min_num_bound(-1)
             res["depth_filter"] = {"slots": slots, "count_pass_ms": count_ms, "masked_classify_ms": masked_ms, "reads": n,
-                                   "note": "-M on one resident 1 M-read batch: pass 1 without global atomics (slots binned by table range and counted "
-                                           "in LDS, rk_count.hip) and the masked hash-space classification (one keep bit per window from a 25 MB bitmap)"}
+                                   "min_num_bound": 0, "compact_map_entries": entries,
+                                   "count_pass_full_table_ms": count_full_ms, "masked_classify_exact_min_num_ms": masked_exact_ms,
+                                   "oracle_checked_reads": checked,
+                                   "note": "-M on one resident 1 M-read batch as `stream -M 2` runs it: min_num bound 0 (rk_set_min_num_bound), pass 1 into "
+                                           "the compact depth map (only the slots of index keys), the mask per index key on the k-mer-space kernel; "
+                                           "*_full_table / *_exact_min_num = the 200 M-slot table and the per-window slot lookup (what -N >= 0 with a "
+                                           "large bound, or RKMH_EXACT_MIN_NUM=1, still runs)"}
         if world == 1 and not a.no_configs:
             res.update(config_legs(rkmh_amd, api, synth, dev, n, L, a.cpu_seconds > 0))
             if not a.no_c4_full and "c4_filter" in res:

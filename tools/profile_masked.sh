@@ -1,5 +1,6 @@
 #!/bin/bash
-# Usage (on the GPU box): bash tools/profile_masked.sh <tag>   -> gpurun_out/<tag>_M2_*.{txt,csv}
+# Usage (on the GPU box): [BOUNDS=0] bash tools/profile_masked.sh <tag>   -> gpurun_out/<tag>_M2_*.{txt,csv}
+# BOUNDS: the rk_set_min_num_bound values the masked pass is run under (default -1,0,1,6; one value for a PMC profile of that form)
 # The masked classification of -M (pass 2: every window's keep bit from the bitmap of the depth table, rkmh.cpp:911-948) on 1 M reads of
 # 150 bp, k = 16: time at three table sizes (the bitmap goes from 25 MB to 125 KB: what the random bit lookups cost), rocprof
 # kernel stats, and the counters that say where the requests go -- each group in its own --pmc pass (kernel-trace only beside it).
@@ -22,7 +23,7 @@ acc = defaultdict(list)
 for f in glob.glob("/tmp/pm/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         n = row["Kernel_Name"]
-        if "k_classify_tile" in n:
+        if "k_classify_tile" in n or "k_classify_kmer" in n or "k_min_num_probe" in n:
             acc[(n.split("(")[0][-70:], row["Counter_Name"])].append(float(row["Counter_Value"]))
 for (n, c), v in sorted(acc.items()):
     # the masked launches are the last ones of the run (the count pass and warm-ups come first); all launches of this kernel name are pass 2
