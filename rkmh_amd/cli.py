@@ -62,11 +62,23 @@ class _RankOutput:
 
     def __init__(self, fd, rank, world):
         import fcntl
+        import socket
         import stat
+        import zlib
         self.fd, self.rank, self.world = fd, rank, world
         st = os.fstat(fd)
         self.regular = stat.S_ISREG(st.st_mode) and not (fcntl.fcntl(fd, fcntl.F_GETFL) & os.O_APPEND)
         self.base = os.lseek(fd, 0, os.SEEK_CUR) if self.regular else 0
+        # Writing at final offsets (or in turn into a pipe) is only right when every rank's descriptor is the SAME open file: one
+        # host, one device and inode, the same kind and the same offset.  A launcher that gives each rank its own stdout
+        # (torchrun --redirects / --log-dir) or ranks on several hosts break that -- every rank would write its fragment at a global
+        # offset of ITS file.  Then rank 0 gathers the text and writes it alone (`shared` False).
+        ident = (zlib.crc32(socket.gethostname().encode()), int(st.st_dev), int(st.st_ino), 1 if self.regular else 0, int(self.base))
+        self.shared = True
+        if world > 1:
+            for v in ident:
+                got = rdist.all_gather_int(v)
+                self.shared = self.shared and all(x == got[0] for x in got)
 
     def _put(self, piece, at):
         mv, done = memoryview(piece), 0
@@ -80,6 +92,12 @@ class _RankOutput:
 
     def pieces_of_a_file(self, pieces):
         """This rank's output for ONE input file (a list of blocks, in order); returns when every rank's part is written."""
+        if not self.shared: # the ranks' descriptors are different files: all text to rank 0, which writes it in rank order
+            text = rdist.gather_bytes(b"".join(bytes(p) for p in pieces), dst=0)
+            if self.rank == 0:
+                self._put(text, self.base)
+                self.base += len(text)
+            return
         n = sum(len(p) for p in pieces)
         sizes = rdist.all_gather_int(n)
         if self.regular:
@@ -324,6 +342,9 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
         good = rdist.all_true(state["ok"])
         if streaming and not good and sink.regular:
             os.ftruncate(out_fd, base0)
+        elif streaming and not good:
+            # blocks already left through a pipe and cannot be taken back: falling back to the parsing path would print them twice
+            raise SystemExit("rkmh: %s changed between the two passes (or could not be read)" % ", ".join(reads))
         if os.environ.get("RKMH_TIMING"):
             sys.stderr.write("[rkmh timing] rank %d: device front end: %d blocks of %d file(s), %d worker threads%s\n"
                              % (rank, sum(len(b) for b in plan), len(plan), nw, "" if good else " -- refused, parsing on the host"))

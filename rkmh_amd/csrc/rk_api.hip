@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -130,7 +131,7 @@ struct rk_ctx {
     KsArr ks{};
     std::vector<uint64_t> h_sk;
     std::vector<int32_t> h_lens;
-    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_keepbits;
+    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_keepbits, d_kpost, d_kbase;
     DevBuf d_kf4[KM_MAX_KS], d_km1[KM_MAX_KS], d_km1v[KM_MAX_KS]; // k-mer-space structures, one set per k-mer size
     KmerSets ksets{};
     uint32_t kpre_inserted = 0; // k-mers the enumeration found for the k-mer-space structures (diagnostic)
@@ -199,7 +200,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
-    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_keepbits, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_keepbits, &c->d_kpost, &c->d_kbase, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount, &c->w_tail}) b->release();
     for (int j = 0; j < KM_MAX_KS; ++j) { c->d_kf4[j].release(); c->d_km1[j].release(); c->d_km1v[j].release(); c->d_km1m[j].release(); c->d_km1cells[j].release(); }
     c->d_keepkey.release();
@@ -1160,6 +1161,109 @@ extern "C" int rk_sketch_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* 
 }
 
 // ---- references --------------------------------------------------------------------------------
+// The posting lists of the k-mer-space kernel (RefIndex::kpost).  `post` holds one list per key; the genomes of one family share
+// most of their sketch hashes, so many keys carry the same list and most of the others carry a list that differs from it in a
+// few places (BASELINE config 3's panel: 61 near-identical Zika genomes, 21 HPV16 variants -- a read of theirs walked ~640
+// postings).  Identical lists are stored once, and up to KBASE_MAX frequent long lists become BASES: a list close to a base is
+// stored as (base, exceptions) -- the kernel adds one to the read's counter of that base, applies the few exceptions (+1 for a
+// reference the base lacks, -1 for one it has in excess) and expands each touched base once per read before the arg-max
+// (k_classify_kmer, phase 2).  Every such list is ALSO kept in plain form (the sparse-counter kernels cannot subtract).
+// remap[offset in post] = (offset of the form the dense-counter kernels walk, offset of the plain form), both into kpost.
+// kpost list = header (entries | (base + 1) << 24; base field 0: plain) then entries x (reference, multiplicity; bit 31: -1).
+// A list within eight exceptions of its base (most of them) needs no list at all: base and exceptions go INTO the compound value
+// (ix, iy, iw: tag 111, base, count, eight 10-bit fields of reference and sign) and the lane that finds the hit applies them.
+constexpr int KBASE_MAX = 8;
+struct KList { uint32_t enc = 0, plain = 0, ix = 0, iy = 0, iw = 0; };
+static void build_kpost(const std::vector<uint32_t>& post, int R, std::vector<uint32_t>& kpost, std::vector<uint32_t>& kbase,
+                        std::unordered_map<uint32_t, KList>& remap) {
+    struct Dist { std::vector<std::pair<uint32_t, uint32_t>> e; uint32_t weight = 0, plain = 0, enc = 0, ix = 0, iy = 0, iw = 0; bool simple = true; };
+    std::map<std::vector<std::pair<uint32_t, uint32_t>>, uint32_t> ids; // list content (sorted by reference) -> distinct id
+    std::vector<Dist> dl;
+    std::vector<std::pair<uint32_t, uint32_t>> owner; // (offset in post, distinct id)
+    for (size_t off = 1; off < post.size();) {
+        const uint32_t n = post[off];
+        std::vector<std::pair<uint32_t, uint32_t>> e(n);
+        for (uint32_t q = 0; q < n; ++q) e[q] = {post[off + 1 + 2 * q], post[off + 2 + 2 * q]};
+        std::sort(e.begin(), e.end());
+        auto it = ids.find(e);
+        if (it == ids.end()) {
+            it = ids.emplace(e, (uint32_t)dl.size()).first;
+            Dist d; d.e = e;
+            for (auto& x : e) d.simple = d.simple && x.second == 1u;
+            dl.push_back(std::move(d));
+        }
+        dl[it->second].weight += 1;
+        owner.emplace_back((uint32_t)off, it->second);
+        off += 1 + 2 * (size_t)n;
+    }
+    static const int nbase_env = getenv("RKMH_KBASES") ? atoi(getenv("RKMH_KBASES")) : KBASE_MAX;
+    const int nbase_max = R <= 0xFFFF ? std::min(std::max(nbase_env, 0), KBASE_MAX) : 0;
+    // bases: the heaviest long lists (keys x references) that are not close to a base already chosen
+    std::vector<uint32_t> order;
+    for (uint32_t i = 0; i < dl.size(); ++i) if (dl[i].simple && dl[i].e.size() >= 8) order.push_back(i);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        const uint64_t wa = (uint64_t)dl[a].weight * dl[a].e.size(), wb = (uint64_t)dl[b].weight * dl[b].e.size();
+        return wa != wb ? wa > wb : a < b;
+    });
+    auto sym_diff = [](const std::vector<std::pair<uint32_t, uint32_t>>& a, const std::vector<uint32_t>& b) {
+        size_t i = 0, j = 0, d = 0;
+        while (i < a.size() && j < b.size()) { if (a[i].first == b[j]) { ++i; ++j; } else if (a[i].first < b[j]) { ++i; ++d; } else { ++j; ++d; } }
+        return d + (a.size() - i) + (b.size() - j);
+    };
+    std::vector<std::vector<uint32_t>> bases;
+    for (uint32_t i : order) {
+        if ((int)bases.size() >= nbase_max) break;
+        bool far = true;
+        for (auto& b : bases) far = far && sym_diff(dl[i].e, b) > std::max<size_t>(4, dl[i].e.size() / 4);
+        if (!far) continue;
+        std::vector<uint32_t> b;
+        for (auto& x : dl[i].e) b.push_back(x.first);
+        bases.push_back(std::move(b));
+    }
+    kbase.assign(2 * KBASE_MAX, 0u);
+    for (size_t b = 0; b < bases.size(); ++b) {
+        kbase[2 * b] = (uint32_t)kbase.size(); kbase[2 * b + 1] = (uint32_t)bases[b].size();
+        kbase.insert(kbase.end(), bases[b].begin(), bases[b].end());
+    }
+    kbase.resize(kbase.size() + 64, 0u); // (the expansion reads 16 members at a time)
+    kpost.assign(1, 0u);
+    for (auto& d : dl) {
+        d.plain = (uint32_t)kpost.size();
+        kpost.push_back((uint32_t)d.e.size());
+        for (auto& x : d.e) { kpost.push_back(x.first); kpost.push_back(x.second); }
+        d.enc = d.plain;
+        if (!d.simple || d.e.size() < 8 || bases.empty()) continue;
+        size_t best = 0, bd = ~(size_t)0;
+        for (size_t b = 0; b < bases.size(); ++b) { const size_t dd = sym_diff(d.e, bases[b]); if (dd < bd) { bd = dd; best = b; } }
+        if (2 * (1 + bd) > d.e.size()) continue; // not worth it: at least half of the walk must go
+        d.enc = (uint32_t)kpost.size();
+        kpost.push_back((uint32_t)bd | ((uint32_t)(best + 1) << 24));
+        const std::vector<uint32_t>& B = bases[best];
+        size_t i = 0, j = 0;
+        uint32_t ex[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nex = 0;
+        bool small_refs = true;
+        auto exception = [&](uint32_t ref, bool neg) {
+            kpost.push_back(ref); kpost.push_back(neg ? 0x80000001u : 1u);
+            small_refs = small_refs && ref < 512u;
+            if (nex < 8) ex[nex] = ref | (neg ? 512u : 0u);
+            ++nex;
+        };
+        while (i < d.e.size() || j < B.size()) {
+            if (j == B.size() || (i < d.e.size() && d.e[i].first < B[j])) { exception(d.e[i].first, false); ++i; }
+            else if (i == d.e.size() || B[j] < d.e[i].first) { exception(B[j], true); ++j; }
+            else { ++i; ++j; }
+        }
+        static const bool inline_ok = !(getenv("RKMH_KBASE_INLINE") && atoi(getenv("RKMH_KBASE_INLINE")) == 0);
+        if (inline_ok && nex <= 8 && small_refs) {
+            d.ix = 0xE0000000u | ((uint32_t)best << 26) | (nex << 22) | ex[0] | (ex[1] << 10);
+            d.iy = ex[2] | (ex[3] << 10) | (ex[4] << 20);
+            d.iw = ex[5] | (ex[6] << 10) | (ex[7] << 20);
+        }
+    }
+    kpost.resize(kpost.size() + 64, 0u); // a hit's first sixteen postings are requested with the header
+    for (auto& o : owner) { KList kl; kl.enc = dl[o.second].enc; kl.plain = dl[o.second].plain; kl.ix = dl[o.second].ix; kl.iy = dl[o.second].iy; kl.iw = dl[o.second].iw; remap[o.first] = kl; }
+}
+
 static int build_key_mask(rk_ctx* c);
 static int build_index(rk_ctx* c) {
     struct Pair { uint64_t h; uint32_t ref; };
@@ -1203,6 +1307,12 @@ static int build_index(rk_ctx* c) {
             if (post.size() + 1 + 2 * grp.size() >= 0x3fffffffull) return fail(RK_ERR_LIMIT, "postings overflow"); // (offsets stay below 2^30: the k-mer-space value table uses the two top bits)
             v = 0x80000000u | (uint32_t)post.size();
             post.push_back((uint32_t)grp.size());
+            // Order inside a list is free.  The fused kernels walk a list 16 postings per step and add to packed per-reference
+            // counters, four (or two) references per LDS word: in ascending order the 16 lanes of a step meet four by four in one word
+            // (the genomes of one family have consecutive ids) and the LDS serves them one after the other.  Ordered by
+            // (ref mod 4, ref) a step's postings fall into 16 different words instead.
+            static const bool spread = !(getenv("RKMH_POST_ORDER") && atoi(getenv("RKMH_POST_ORDER")) == 0);
+            if (spread) std::stable_sort(grp.begin(), grp.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return (a.first & 3u) < (b.first & 3u); });
             for (auto& g : grp) { post.push_back(g.first); post.push_back(g.second); }
         }
         uint32_t b = index_bucket(pairs[i].h, bmask);
@@ -1281,6 +1391,20 @@ static int build_index(rk_ctx* c) {
     bool all_k_ok = kmer_mode > 0 && c->kmer_form_allowed && c->ks.n >= 1 && c->ks.n <= KM_MAX_KS && distinct <= kmer_max_keys;
     for (int j = 0; j < c->ks.n; ++j) all_k_ok = all_k_ok && c->ks.k[j] >= KPRE_MIN_K && c->ks.k[j] <= 16;
     for (int j = 0; j + 1 < c->ks.n; ++j) for (int i = j + 1; i < c->ks.n; ++i) all_k_ok = all_k_ok && c->ks.k[j] != c->ks.k[i]; // a size given twice hashes twice: hash-space path
+    std::vector<uint32_t> kpost, kbase;
+    std::unordered_map<uint32_t, KList> kremap;
+    c->ix.kpost = nullptr; c->ix.kbase = nullptr;
+    if (all_k_ok) {
+        build_kpost(post, R, kpost, kbase, kremap);
+        if (kpost.size() >= 0x3fffffffull) all_k_ok = false;
+        else {
+            RKCHK(c->d_kpost.reserve(kpost.size() * 4));
+            RKCHK(c->d_kbase.reserve(kbase.size() * 4));
+            HIPCHK(hipMemcpy(c->d_kpost.p, kpost.data(), kpost.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(c->d_kbase.p, kbase.data(), kbase.size() * 4, hipMemcpyHostToDevice));
+            c->ix.kpost = c->d_kpost.as<uint32_t>(); c->ix.kbase = c->d_kbase.as<uint32_t>();
+        }
+    }
     std::vector<uint8_t> seen(all_k_ok ? nkeys + 1 : 0, 0); // across the sizes: a key found by two k-mers of ANY sizes disables the form
     int built = 0;
     for (int kidx = 0; all_k_ok && kidx < c->ks.n; ++kidx) {
@@ -1365,9 +1489,13 @@ static int build_index(rk_ctx* c) {
                     if (slot == IDX_NOT_FOUND) { vid[i] = VID_ZERO; continue; }
                     const uint32_t val = dense[(size_t)slot * 4 + 2];
                     if (!(val >> 31) && ((val >> 29) & 3u) == 0u && ((val >> 20) & 0x1FFu) == 1u) { vid[i] = val & 0xFFFFFu; continue; } // one posting, once: the reference
-                    auto it = val_id.find(val);
+                    // lists: identical ones share one compound value (and one copy in kpost, see build_kpost)
+                    uint32_t vkey = val;
+                    KList kl;
+                    if (val >> 31) { kl = kremap.at(val & 0x7fffffffu); vkey = 0x80000000u | kl.plain; }
+                    auto it = val_id.find(vkey);
                     if (it == val_id.end()) {
-                        it = val_id.emplace(val, (uint32_t)(R + vals.size() / 2)).first;
+                        it = val_id.emplace(vkey, (uint32_t)(R + vals.size() / 4)).first;
                         // two dwords per entry: the index value and, for a list of three to six references that each hold the hash
                         // once (what related types of one panel share), the list itself, nine bits per reference -- the kernel then
                         // counts it in the lane that found the hit instead of fetching the posting list from global memory (KM1V_INLINE)
@@ -1383,7 +1511,14 @@ static int build_index(rk_ctx* c) {
                                 y = r[3] | (r[4] << 9) | (r[5] << 18);
                             }
                         }
-                        vals.push_back(x); vals.push_back(y);
+                        // a list that stays a list: x = the form the dense-counter kernels walk (plain, or base + exceptions) -- or, within five
+                        // exceptions of its base, x and y hold base and exceptions themselves -- and z = the plain form (sparse counters)
+                        uint32_t z = 0, w = 0;
+                        if ((x >> 30) == 2u) {
+                            z = kl.plain;
+                            if (kl.ix) { x = kl.ix; y = kl.iy; w = kl.iw; } else x = 0x80000000u | kl.enc;
+                        }
+                        vals.push_back(x); vals.push_back(y); vals.push_back(z); vals.push_back(w);
                     }
                     vid[i] = it->second;
                 }
@@ -1395,7 +1530,7 @@ static int build_index(rk_ctx* c) {
                 bool built = false;
                 for (; b <= kbits && b <= 28 && !built; ++b) {
                     const uint32_t r = kbits - b, vb = km1_vbits(k, b), vmask = (1u << vb) - 1u;
-                    if ((uint64_t)R + vals.size() / 2 + 2 > (uint64_t)vmask) continue; // ids need more bits: a longer bucket index frees them
+                    if ((uint64_t)R + vals.size() / 4 + 2 > (uint64_t)vmask) continue; // ids need more bits: a longer bucket index frees them
                     const uint32_t nbk = 1u << b, rmask = r ? (1u << r) - 1u : 0u;
                     c1.assign((size_t)nbk * 4, ~(1u << vb)); // empty: tag and id all ones, flag clear
                     bool placed_all = true;
@@ -2259,6 +2394,8 @@ extern "C" int rk_fastq_slot_count(rk_fastq_slot* s, uint64_t nbytes, rk_counter
     const int64_t nrec = (int64_t)info[1];
     if (nrec_out) *nrec_out = nrec;
     if (nrec == 0) return RK_OK;
+    if (info[2] > (uint32_t)FUSED_MAXLEN && counter->compact)
+        return fail(RK_ERR_NEED_FULL, "reads longer than %d bases: a compact depth map only counts reads that fit the sketch", FUSED_MAXLEN);
     if (info[2] > (uint32_t)FUSED_MAXLEN) {
         // a read longer than the fused kernel's limit: the whole block through the tile hasher, from the text (as rk_count_batch does)
         uint32_t* spans = s->h_spans.as<uint32_t>();

@@ -540,6 +540,10 @@ struct RefIndex {
     const uint4* km1;      // single-probe exact map (see KM1_C above), 2^km1_b buckets
     uint32_t km1_b;
     const uint32_t* km1_vals;
+    // posting lists of the k-mer-space kernel (rk_api.hip, build_kpost): identical lists stored once, lists close to one of up to
+    // eight BASE lists stored as (base, exceptions); kbase = [8 x (start, members)] then the members
+    const uint32_t* kpost;
+    const uint32_t* kbase;
     // -M with a bounded min_num (rk_set_min_num_bound): bit (key id) set <=> the key's slot of the depth map passes the threshold
     // (nullptr = no per-key mask).  The hash-space kernels test it for the windows that HIT a key instead of one bit of the
     // 25 MB slot bitmap for every window; the k-mer-space kernel reads a copy of km1 in which the dropped keys carry the zero id.

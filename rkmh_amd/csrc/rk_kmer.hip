@@ -32,9 +32,6 @@ namespace {
 constexpr int KW = 64;
 constexpr int KM_MAX_T = 8;          // reads per tile (phase 2 takes eight reads in one pass; the group -> read search is unrolled for it)
 constexpr int KM_MQ = 32;            // deferred multi-posting hits (a full list is worked off at once: 16 lanes per hit)
-#ifndef RK_KMER_MQ_MODE
-#define RK_KMER_MQ_MODE 2 // posting lists of deferred hits: 0 length, then postings (two dependent loads); 1 both at once; 2 and the next hit's during this one's counting
-#endif
 #ifndef RK_KMER_ABL
 #define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length, 128 filter sectors of lane pairs in one line, 256 map look-ups from a 4 KB corner of the map (L1 hits), 512 no hit multiset (every occurrence has rank 0), 1024 hits with a posting list dropped, 2048 two of three lanes' filter sectors in one 32-byte piece
 #endif
@@ -88,7 +85,9 @@ struct KmLds {
     static constexpr int BEST = NZ + KM_MAX_T;                // [8] max over increments of (count << 16 | 0xFFFF - ref)
     static constexpr int FLAGS = BEST + KM_MAX_T;             // [8] read must take the general path
     static constexpr int NWT = FLAGS + KM_MAX_T;              // [8] windows of read t, all k-mer sizes together
-    static constexpr int CNT = NWT + KM_MAX_T;                // [T][cwords] per-reference counters, then [T][dset] hit multisets
+    static constexpr int FAM = NWT + KM_MAX_T;                // [8][4] hits of read t on lists stored as (base, exceptions): eight 16-bit counters, one per base
+    static constexpr int FAMF = FAM + 4 * KM_MAX_T;           // [8] read t has such hits: its arg-max comes from a scan of the counters, not from the running best
+    static constexpr int CNT = FAMF + KM_MAX_T;               // [T][cwords] per-reference counters, then [T][dset] hit multisets
     static_assert(RI % 4 == 0, "rinfo is read with 16-byte LDS loads");
     static_assert(CNT % 4 == 0, "the multisets are cleared with 16-byte LDS stores");
 };
@@ -160,6 +159,8 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
     uint32_t* const best = smem + L::BEST;
     uint32_t* const flags = smem + L::FLAGS;
     uint32_t* const nwtot = smem + L::NWT;
+    uint32_t* const fam = smem + L::FAM;
+    uint32_t* const famf = smem + L::FAMF;
     uint32_t* const cnt = smem + L::CNT;
     const int T = geo.T;
     const uint32_t CW = (uint32_t)geo.cwords, DS = (uint32_t)geo.dset;
@@ -260,8 +261,9 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
 #pragma unroll
             for (int j = 0; j < NKC; ++j) if (j < NK) nw_all += (uint32_t)num_windows((int)len, KT ? KT : ksets.k[j], pol.drop_last_window);
         }
+        if (lane < 4 * KM_MAX_T) fam[lane] = 0;
         if (lane < KM_MAX_T) {
-            nzero[lane] = 0; best[lane] = 0; nwtot[lane] = nw_all;
+            nzero[lane] = 0; best[lane] = 0; nwtot[lane] = nw_all; famf[lane] = 0;
             // more windows than a packed counter can count (only possible when the caller's length hint was too small)
             flags[lane] = nw_all > (CMODE == CM_SPARSE ? 0x7FFu : cmask) ? 1u : 0u;
         }
@@ -368,8 +370,26 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             // four dependent atomics per lane cost more than the four-way conflicts: family reads 1.1 -> 2.0 ms.)
             // (Also tried and rejected: the four rows of a step -- often four hits of one read with one list -- starting at different
             // chunks of the list, so that they do not add to the same counter words in the same instruction: 1.08 -> 1.14 ms.)
-            auto walk = [&](uint32_t tr, const uint32_t* lp, uint32_t n, const km_pair4& pm0) {
-                const uint32_t t = tr & 0xFFu;
+            auto walk = [&](uint32_t tr, const uint32_t* lp, uint32_t hdr, const km_pair4& pm0) {
+                const uint32_t t = tr & 0xFFu, n = hdr & 0xFFFFFFu, base = hdr >> 24;
+                if (base) {
+                    // a list stored as (base, exceptions) (build_kpost; every member holds the hash once, so only a k-mer's first
+                    // occurrence counts): one more hit on the base -- expanded once per read in phase 2 -- and +1 / -1 for the few
+                    // references in which this list differs from it.  A packed counter may pass below zero on the way; the row is
+                    // only read after the expansion, when every field is its final value again (the adds commute mod 2^32).
+                    if ((tr >> 8) != 0u) return;
+                    if (sl == 0) { atomicAdd(&fam[4u * t + ((base - 1u) >> 1)], 1u << (16u * ((base - 1u) & 1u))); famf[t] = 1u; }
+                    for (uint32_t c0 = 0; c0 < n; c0 += 16) {
+                        const uint32_t c = c0 + sl;
+                        if (c < n) {
+                            km_pair4 pm = pm0;
+                            if (c0) pm = *reinterpret_cast<const km_pair4*>(lp + 1 + 2 * c);
+                            const uint32_t sh = (pm.x << (5 - clg)) & (32u - cbits), woff = (pm.x >> clg) << 2;
+                            atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(cnt) + __umul24(t, CW * 4u) + woff), (pm.y >> 31) ? 0u - (1u << sh) : 1u << sh);
+                        }
+                    }
+                    return;
+                }
                 for (uint32_t c0 = 0; c0 < n; c0 += 16) { // (n is the same for the 16 lanes of the row: they run the same trips)
                     const uint32_t c = c0 + sl;
                     uint32_t v = 0;
@@ -382,38 +402,23 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                     if (sl == 0 && v) atomicMax(&best[t], v);
                 }
             };
-#if RK_KMER_MQ_MODE == 2
-            // A list's length and its first sixteen postings are requested TOGETHER (the posting array ends in 256 bytes of padding,
+            // A list's header and its first sixteen postings are requested TOGETHER (the posting array ends in 256 bytes of padding,
             // rk_api.hip), and the NEXT hit's while this one is counted: the posting lists live in global memory and a row used to pay
             // two dependent round trips per hit, one hit after the other.
             uint32_t j = g;
             uint32_t tr = 0, n = 0;
-            const uint32_t* lp = ix.post;
+            const uint32_t* lp = ix.kpost;
             km_pair4 pm0{0u, 0u};
-            if (j < mqn) { tr = mq[2 * j]; lp = ix.post + mq[2 * j + 1]; n = lp[0]; pm0 = *reinterpret_cast<const km_pair4*>(lp + 1 + 2 * sl); }
+            if (j < mqn) { tr = mq[2 * j]; lp = ix.kpost + mq[2 * j + 1]; n = lp[0]; pm0 = *reinterpret_cast<const km_pair4*>(lp + 1 + 2 * sl); }
             while (j < mqn) {
                 const uint32_t jn = j + KW / 16;
                 uint32_t trn = 0, nn = 0;
-                const uint32_t* lpn = ix.post;
+                const uint32_t* lpn = ix.kpost;
                 km_pair4 pmn{0u, 0u};
-                if (jn < mqn) { trn = mq[2 * jn]; lpn = ix.post + mq[2 * jn + 1]; nn = lpn[0]; pmn = *reinterpret_cast<const km_pair4*>(lpn + 1 + 2 * sl); }
+                if (jn < mqn) { trn = mq[2 * jn]; lpn = ix.kpost + mq[2 * jn + 1]; nn = lpn[0]; pmn = *reinterpret_cast<const km_pair4*>(lpn + 1 + 2 * sl); }
                 walk(tr, lp, n, pm0);
                 j = jn; tr = trn; lp = lpn; n = nn; pm0 = pmn;
             }
-#else
-            for (uint32_t j = g; j < mqn; j += KW / 16) {
-                const uint32_t tr = mq[2 * j];
-                const uint32_t* lp = ix.post + mq[2 * j + 1];
-                const uint32_t n = lp[0];
-#if RK_KMER_MQ_MODE == 1
-                const km_pair4 pm0 = *reinterpret_cast<const km_pair4*>(lp + 1 + 2 * sl);
-#else
-                km_pair4 pm0{0u, 0u};
-                if (sl < n) pm0 = *reinterpret_cast<const km_pair4*>(lp + 1 + 2 * sl);
-#endif
-                walk(tr, lp, n, pm0);
-            }
-#endif
             wave_sync();
             mqn = 0;
         };
@@ -459,10 +464,11 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             uint32_t val = vid | (1u << 20); // a single posting of multiplicity 1, in the RefIndex::kv value format
             const bool hit = vid != km_vmask && c.t != 0xFFFFFFFFu; // else: a false positive of the bit filter, or a window past its read's last
             const bool zero = vid == km_vmask - 1u;
-            uint32_t valy = 0;
-            if (!(RK_KMER_ABL & 32) && hit && vid >= nref && !zero) { // compound value, two dwords (a few KB: L1-resident)
-                const uint2 vv = *reinterpret_cast<const uint2*>(km1v + 2u * (vid - nref));
-                val = vv.x; valy = vv.y;
+            uint32_t valy = 0, valz = 0, valw = 0;
+            if (!(RK_KMER_ABL & 32) && hit && vid >= nref && !zero) { // compound value, four dwords (a few KB: L1-resident)
+                const uint4 vv = *reinterpret_cast<const uint4*>(km1v + 4u * (vid - nref));
+                val = vv.x; valy = vv.y; valz = vv.z; valw = vv.w;
+                if constexpr (CMODE == CM_SPARSE) { if ((val >> 29) == 7u) val = 0x80000000u | valz; } // (base, exceptions): the sparse counters cannot subtract
             }
             uint32_t rank = 0;
             bool multi = false;
@@ -485,6 +491,25 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                         ++probes;
                     }
                     if (old != 0u) flags[c.t] = 1; // more hits than the set holds: general path
+                    else if ((val >> 29) == 7u) { // a list within eight exceptions of a base list (build_kpost): one more hit on the base, +-1 for the exceptions
+                        if (rank == 0) {
+                            const uint32_t base = (val >> 26) & 7u, nex = (val >> 22) & 15u, crow_b = __umul24(c.t, CW * 4u);
+                            atomicAdd(&fam[4u * c.t + (base >> 1)], 1u << (16u * (base & 1u)));
+                            famf[c.t] = 1u;
+                            auto signed_add = [&](uint32_t f) { // f = reference | 512 for -1
+                                const uint32_t ref = f & 511u, sh = (ref << (5 - clg)) & (32u - cbits);
+                                atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(cnt) + crow_b + ((ref >> clg) << 2)), (f & 512u) ? 0u - (1u << sh) : 1u << sh);
+                            };
+                            if (nex > 0u) signed_add(val & 1023u);
+                            if (nex > 1u) signed_add((val >> 10) & 1023u);
+                            if (nex > 2u) signed_add(valy & 1023u);
+                            if (nex > 3u) signed_add((valy >> 10) & 1023u);
+                            if (nex > 4u) signed_add((valy >> 20) & 1023u);
+                            if (nex > 5u) signed_add(valw & 1023u);
+                            if (nex > 6u) signed_add((valw >> 10) & 1023u);
+                            if (nex > 7u) signed_add((valw >> 20) & 1023u);
+                        }
+                    }
                     else if ((val >> 30) == 3u) { // three to six references that hold the hash once each, stored inline (build_index)
                         if (rank == 0) {
                             const uint32_t crow_b = __umul24(c.t, CW * 4u), n3 = (val >> 27) & 3u;
@@ -508,12 +533,14 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             // hits with a posting list are deferred to the end of the drain (16 lanes then walk each list); when the list of deferred
             // hits is full it is worked off at once and filled again (a read of a family of near-identical references has nothing but
             // such hits: walking them one lane per list took most of its time)
+            // the form of the list this kernel walks: (base, exceptions) where there is one -- the sparse counters cannot subtract
+            const uint32_t listoff = (CMODE == CM_SPARSE ? valz : val) & 0x3fffffffu;
             uint64_t mm = __ballot(multi);
             while (mm) { // wave-uniform
                 const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
                 const uint32_t space = (uint32_t)KM_MQ - mqn;
                 if (multi && pos < space) {
-                    mq[2 * (mqn + pos)] = c.t | (rank << 8); mq[2 * (mqn + pos) + 1] = val & 0x7fffffffu;
+                    mq[2 * (mqn + pos)] = c.t | (rank << 8); mq[2 * (mqn + pos) + 1] = listoff;
                     multi = false;
                 }
                 const uint32_t tot = (uint32_t)__popcll(mm);
@@ -686,10 +713,41 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                 const int nmins = (int)nwtot[t] - (int)nzero[t];
                 // bottom-S selection matters, or the hit multiset overflowed: exact answer comes from the general path
                 const bool reroute = nmins > S || flags[t] != 0;
-                const uint32_t bk = best[t];
+                uint32_t bk = best[t];
                 if (reroute) {
                     if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(-2, 0, 0, 0);
                     continue;
+                }
+                if constexpr (CMODE != CM_SPARSE) {
+                    if (famf[t]) { // hits on (base, exceptions) lists: each touched base is expanded into the counters ONCE, then the
+                        // maximum and its first reference come from a scan of the row (the running best saw partial counts)
+                        for (uint32_t b = 0; b < 8u; ++b) {
+                            const uint32_t h = (fam[4u * (uint32_t)t + (b >> 1)] >> (16u * (b & 1u))) & 0xFFFFu;
+                            if (h == 0u) continue;
+                            const uint32_t start = ix.kbase[2u * b], nm = ix.kbase[2u * b + 1u];
+                            for (uint32_t m0 = 0; m0 < nm; m0 += (uint32_t)LPR) {
+                                const uint32_t m = m0 + (uint32_t)sl;
+                                if (m < nm) {
+                                    const uint32_t ref = ix.kbase[start + m];
+                                    atomicAdd(&ct[ref >> clg], h << ((ref << (5 - clg)) & (32u - cbits)));
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        uint32_t km = 0;
+                        for (uint32_t w = (uint32_t)sl; w < CW; w += (uint32_t)LPR) {
+                            uint32_t x = ct[w];
+#pragma unroll
+                            for (uint32_t q = 0; q < (1u << clg); ++q) {
+                                const uint32_t cq = x & cmask, ref = (w << clg) + q;
+                                x >>= cbits;
+                                const uint32_t key = (cq << 16) + (0xFFFFu - ref);
+                                km = (cq != 0u && key > km) ? key : km;
+                            }
+                        }
+                        bk = (uint32_t)(LPR == 16 ? row_max_i32((int)km) : half_row_max_i32((int)km));
+                    }
                 }
                 // first max wins (rkmh.cpp:878); diff = max - best EARLIER score (untouched refs score 0; none => -1)
                 const int max_id = bk ? (int)(0xFFFFu - (bk & 0xFFFFu)) : 0;

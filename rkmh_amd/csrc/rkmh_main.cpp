@@ -405,7 +405,8 @@ struct OrderedOut {
     std::vector<std::thread> writers;
     int64_t next = 0;
     size_t in_flight = 0;                 // tasks queued or being written
-    bool assigning = false, failed = false, closing = false;
+    bool assigning = false, closing = false;
+    std::atomic<bool> failed{false};      // set by any writer thread
     std::atomic<int64_t> limit{INT64_MAX}; // blocks from this number on are dropped, not written (another front end redoes them)
     bool direct = false;                   // standard output is a regular file not opened for appending
     off_t base = 0, total = 0;
@@ -416,8 +417,12 @@ struct OrderedOut {
         const int fl = fcntl(1, F_GETFL);
         const bool off_env = getenv("RKMH_OUT_DIRECT") && atoi(getenv("RKMH_OUT_DIRECT")) == 0;
         if (!off_env && fstat(1, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 && !(fl & O_APPEND)) {
+            // ("> out 2>&1": both descriptors are ONE open file; a diagnostic written to stderr during the pass would land at the
+            // shared offset, inside the region the blocks are pwritten to -- such a run takes the ordered single-writer path)
+            struct stat se;
+            const bool same_as_stderr = fstat(2, &se) == 0 && se.st_dev == st.st_dev && se.st_ino == st.st_ino;
             const off_t cur = lseek(1, 0, SEEK_CUR);
-            if (cur >= 0) { direct = true; base = cur; }
+            if (cur >= 0 && !same_as_stderr) { direct = true; base = cur; }
         }
         long nw = direct ? 3 : 1; // a pipe or a terminal takes the blocks from ONE thread, in order
         if (direct && ndev > 1) nw = std::min<long>(12, 2 + (long)ndev); // several devices produce lines several times as fast
@@ -515,7 +520,7 @@ struct RawEngine {
         for (size_t i = 0; i < w.size(); ++i) w[i].dev = i % g.size();
         // each worker creates its own slot when it starts (page-locking ~50 MB takes ~10 ms): the first blocks are on their way
         // while the later workers are still setting up.  Only the first slot is made here, to find out whether the front end works at all.
-        if (rk_fastq_slot_create(g.ctx[0], block, &w[0].slot[0]) != RK_OK) {
+        if (rk_fastq_slot_create(g.ctx[0], block + 64, &w[0].slot[0]) != RK_OK) { // (+ 64: a last block of exactly `block` bytes may get its missing newline)
             fprintf(stderr, "rkmh: device FASTQ front end unavailable (%s): using the host scanner\n", rk_last_error());
             w.clear();
             return false;
@@ -580,7 +585,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     std::atomic<int> live{(int)eng.w.size()};
     auto work = [&](size_t wi) {
         for (int k = 0; k < (eng.two_slots ? 2 : 1); ++k)
-            if (!eng.w[wi].slot[k] && rk_fastq_slot_create(g.ctx[eng.w[wi].dev], eng.block, &eng.w[wi].slot[k]) != RK_OK) {
+            if (!eng.w[wi].slot[k] && rk_fastq_slot_create(g.ctx[eng.w[wi].dev], eng.block + 64, &eng.w[wi].slot[k]) != RK_OK) {
                 // (memory for another slot ran out: the other workers carry on -- unless this was the last one)
                 fprintf(stderr, "rkmh: worker %zu: %s\n", wi, rk_last_error());
                 if (live.fetch_sub(1) == 1) { fprintf(stderr, "rkmh: no worker of the device front end could start\n"); fail_exit(); }
@@ -783,7 +788,7 @@ static bool refs_through_device(RawEngine& eng, DeviceGroup& g, const Opts& o, i
     std::atomic<bool> failed{false};
     auto work = [&](size_t wi) {
         if (eng.w[wi].dev != 0) return; // the text goes to the device that sketches
-        if (!eng.w[wi].slot[0] && rk_fastq_slot_create(g.ctx[0], eng.block, &eng.w[wi].slot[0]) != RK_OK) return;
+        if (!eng.w[wi].slot[0] && rk_fastq_slot_create(g.ctx[0], eng.block + 64, &eng.w[wi].slot[0]) != RK_OK) return;
         rk_fastq_slot* slot = eng.w[wi].slot[0];
         uint8_t* text = rk_fastq_slot_text(slot);
         for (size_t j = next.fetch_add(1); j < jobs.size() && !failed.load(); j = next.fetch_add(1)) {

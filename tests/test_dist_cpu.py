@@ -77,6 +77,15 @@ def _worker(rank, world, port, q):
         ok_g = ok_g and not sink.regular
         sink.pieces_of_a_file([b"pipe rank%d\n" % rank * 1000])
         os.close(fd)
+        # every rank its OWN stdout (torchrun --redirects): nothing may be written at offsets of a file the others do not share --
+        # rank 0 gathers the text and writes it alone
+        fd = os.open(out_path + ".rank%d" % rank, os.O_WRONLY | os.O_CREAT, 0o644)
+        sink = cli._RankOutput(fd, rank, world)
+        ok_g = ok_g and sink.regular and not sink.shared
+        for f in range(2):
+            sink.pieces_of_a_file([b"own file%d rank%d piece%d\n" % (f, rank, j) * (20 + 3 * rank) for j in range(2)])
+        sink.finish()
+        os.close(fd)
     q.put((rank, lo, hi, ok_b, ok_c, ok_g))
     torch.distributed.destroy_process_group()
 
@@ -107,6 +116,8 @@ def test_two_rank_plumbing_over_gloo(tmp_path):
     want = b"".join(b"file%d rank%d piece%d\n" % (f, r, j) * (50 + 7 * r) for f in range(2) for r in range(world) for j in range(3))
     assert out.read_bytes() == want
     assert piped == [b"".join(b"pipe rank%d\n" % r * 1000 for r in range(world))]
+    own = b"".join(b"own file%d rank%d piece%d\n" % (f, r, j) * (20 + 3 * r) for f in range(2) for r in range(world) for j in range(2))
+    assert open(str(out) + ".rank0", "rb").read() == own and open(str(out) + ".rank1", "rb").read() == b""
     for r in res:
         assert r[3] and r[4] and r[5], r
 
