@@ -134,7 +134,25 @@ def e2e_stream(n, L, rb, ro, synth):
             pass
 
 
-def c4_full_size(api, synth, genome_mb=3100, nreads=10000000, L=150):
+def oracle_sketch_long(oracle, arr, k, S, threads):
+    """Bottom-S sketch (non-zero hashes, no dedup: rkmh.cpp:822) of ONE long upper-case sequence by the CPU oracle: calc_hashes on
+    4 M-window pieces in `threads` threads (ctypes releases the GIL), the S smallest of each piece, then of all.  Checker only."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(arr)
+    step = 4 << 20
+
+    def piece(lo):
+        hi = min(n, lo + step + k)          # len - k windows per piece (the default window rule): windows starting in [lo, lo + step)
+        h = oracle.calc_hashes(arr[lo:hi].tobytes(), [k])
+        h = h[h != 0]
+        return np.partition(h, S - 1)[:S] if len(h) > S else h
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(piece, range(0, max(n - k, 1), step)))
+    h = np.sort(np.concatenate(parts))
+    return h[:S]
+
+
+def c4_full_size(api, synth, genome_mb=3100, nreads=10000000, L=150, check=True):
     """BASELINE config 4 at its own size, whole process: `bin/rkmh filter -k 20 -s 2000` (and with -M 2) of 10 M reads (90 % drawn from
     the genome, 10 % from data/hpv_16_allFasta.fa) against a synthetic genome of 24 sequences with hg38's chromosome lengths (3.1 Gb,
     bases uniform at random) written as FASTA in /tmp.  Each setting
@@ -185,8 +203,49 @@ def c4_full_size(api, synth, genome_mb=3100, nreads=10000000, L=150):
                     rec[:, 12 + L] = ord("+"); rec[:, 13 + L] = 10
                     rec[:, 14 + L:14 + 2 * L] = ord("I"); rec[:, 14 + 2 * L] = 10
                     f.write(rec.tobytes())
-        del gb
         gen_s = time.perf_counter() - t0
+        checked = None
+        if check:
+            # the oracle at C4's OWN size: the device's sketches of the largest and the smallest chromosome (248 M and 47 M hashes
+            # through the multi-block radix select) against the CPU oracle's, and 55 000 sampled reads -- rows bit-exact, and the
+            # filter decisions against what bin/rkmh prints for them (below)
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle  # checker only
+            import rkmh_amd
+            from rkmh_amd import cli
+            thr = min(oracle.max_threads(), usable_cpus())
+            tc = time.perf_counter()
+            cx = rkmh_amd.Context(0)
+            try:
+                names = cli._references_on_device(cx, [fa], [20], 2000, None, 10000000, True)   # as bin/rkmh filter sets them
+                if names is None:
+                    raise RuntimeError("the references did not go through the device front end")
+                dsk, dln = cx.get_reference_sketches()
+                lens = [int(go[i + 1] - go[i]) for i in range(24)]
+                which = sorted({int(np.argmax(lens)), int(np.argmin(lens))})
+                for c in which:
+                    osk = oracle_sketch_long(oracle, gb[int(go[c]): int(go[c + 1])], 20, 2000, thr)
+                    if not (int(dln[c]) == len(osk) and (dsk[c, : len(osk)] == osk).all()):
+                        raise SystemExit("c4_full_size: ORACLE CHECK FAILED: the device's sketch of sequence %d (%d bases) differs" % (c, lens[c]))
+                ng, nv = min(50000, nreads - nh), min(5000, nh)
+                sb, so = synth.generate_reads_fast(gb, go, 0, ng, read_len=L, threads=nthreads)
+                vb, vo = synth.generate_reads_fast(hpv["bases"], hpv["offsets"], 0, nv, read_len=L, threads=nthreads)
+                qb = np.concatenate([sb[: ng * L], vb[: nv * L], np.zeros(16, np.uint8)])
+                qo = np.arange(0, (ng + nv) * L + 1, L, dtype=np.uint64)
+                want = oracle.classify_stream(qb, qo, [20], 2000, dsk, dln, threads=thr)
+                got = cx.classify(qb, qo)
+                if not (got == want).all():
+                    raise SystemExit("c4_full_size: ORACLE CHECK FAILED: rows of the sampled reads differ")
+                expect = set()
+                for i in range(ng + nv):
+                    if oracle.filter_decision(want[i])[3]:
+                        expect.add(b"%c%08d" % (ord("g") if i < ng else ord("v"), i if i < ng else i - ng))
+                checked = {"ref_sketches": len(which), "ref_sketch_hashes": [lens[c] - 20 for c in which], "reads": ng + nv, "passing": len(expect),
+                           "ranges": (ng, nv), "expect": expect, "seconds": 0.0}
+            finally:
+                cx.close()
+            checked["seconds"] = time.perf_counter() - tc
+        del gb
         res = {"genome_bases": int(goffs[-1]), "genome_scale_of_hg38": scale, "fasta_bytes": os.path.getsize(fa), "reads": nreads, "fastq_bytes": os.path.getsize(fq),
                "k": 20, "sketch_size": 2000, "inputs_generated_s": gen_s,
                "note": "bin/rkmh filter, whole process (start-up, 3.1 GB of reference FASTA, sketches, 10 M reads, output); wall_s = device front "
@@ -211,6 +270,17 @@ def c4_full_size(api, synth, genome_mb=3100, nreads=10000000, L=150):
                     kept += blk.count(b">")
             return dt, h.hexdigest(), kept, [l[len("[rkmh timing] "):].strip() for l in r.stderr.decode().splitlines() if l.startswith("[rkmh timing]")]
 
+        def printed_names(out, ng, nv):
+            """names of the sampled id ranges among the records bin/rkmh printed"""
+            got = set()
+            with open(out, "rb") as f:
+                for line in f:
+                    if line[:1] == b">" and len(line) == 11:
+                        nm = line[1:10]
+                        if int(nm[1:]) < (ng if nm[:1] == b"g" else nv):
+                            got.add(nm)
+            return got
+
         for key, extra in (("plain", []), ("M2", ["-M", "2"])):
             out = os.path.join(tmp, "filter.out")
             best = None
@@ -218,11 +288,22 @@ def c4_full_size(api, synth, genome_mb=3100, nreads=10000000, L=150):
                 dt, dig, kept, stages = run(extra, {}, out)
                 if best is None or dt < best[0]:
                     best = (dt, dig, kept, stages)
+            if checked is not None: # the decisions bin/rkmh printed for the sampled reads (the last run's file) against the oracle's
+                if key == "M2":
+                    pass   # (-M at this size has no oracle run: 10 M reads through the two-pass CPU loop; tests cover it in miniature)
+                elif printed_names(out, *checked["ranges"]) != checked["expect"]:
+                    raise SystemExit("c4_full_size: ORACLE CHECK FAILED: bin/rkmh filter printed other reads of the sample than the oracle passes")
             hdt, hdig, _, _ = run(extra, {"RKMH_RAW": "0", "RKMH_RAW_REFS": "0"}, out)
             res[key] = {"wall_s": best[0], "reads_per_s": nreads / best[0], "reads_passing": best[2], "host_parser_wall_s": hdt,
                         "identical_to_host_parsed_run": best[1] == hdig, "stages": best[3]}
             if best[1] != hdig:
                 raise SystemExit("c4_full_size: the device front ends and the host parsers printed different bytes (%s)" % key)
+        if checked is not None:
+            res["oracle_checked_ref_sketches"] = checked["ref_sketches"]
+            res["oracle_checked_ref_sketch_hashes"] = checked["ref_sketch_hashes"]
+            res["oracle_checked_reads"] = checked["reads"]
+            res["oracle_checked_reads_passing"] = checked["passing"]
+            res["oracle_check_s"] = checked["seconds"]
         return res
     except (OSError, MemoryError, RuntimeError) as e:
         return {"error": str(e)[-300:]}
@@ -421,6 +502,9 @@ def main():
     ap.add_argument("--no-c4-full", action="store_true", help="skip config 4 at full size (3.1 Gb genome + 10 M reads generated in /tmp, ~40 s)")
     ap.add_argument("--c4-genome-mb", type=int, default=3100, help="config 4 at full size: bases of the synthetic genome, in millions")
     ap.add_argument("--c4-reads", type=int, default=10000000, help="config 4 at full size: reads")
+    ap.add_argument("--c3-total-reads", type=int, default=100000000,
+                    help="N > 1 runs BASELINE config 3: this many reads IN ALL (strong scaling: each rank classifies total / N) against every bundled reference")
+    ap.add_argument("--c3-launch-reads", type=int, default=12500000, help="N > 1: reads per kernel launch (a rank's shard is resident as batches of at most this many)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -450,28 +534,51 @@ def main():
     ctx = rkmh_amd.Context(local)
 
     ks, S, L = [16], 1000, 150
-    refs = api.parse_files([os.path.join(ROOT, "tests", "golden", "data", "all_pave_ref.fa.gz")])
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    # N = 1: BASELINE config 2 (stream: 1 M-read batches against the PaVE panel), weak scaling never applies.  N > 1: config 3 --
+    # --c3-total-reads reads IN ALL against every bundled reference (266 sequences), sharded over the ranks: STRONG scaling.
+    c3_mode = world > 1
+    ref_files = (["all_pave_ref.fa.gz", "zika.refs.fa.gz", "dengue.fa.gz", "new_refs.fa.gz", "hpv_16.fa.gz", "zika.fa.gz", "yellow_fever.fa.gz",
+                  "hpv_16_allFasta.fa.gz"] if c3_mode else ["all_pave_ref.fa.gz"])
+    refs = api.parse_files([os.path.join(data, f) for f in ref_files])
     rb, ro, R = refs["bases"], refs["offsets"], refs["nseq"]
     if rank == 0:
         ctx.set_references(rb, ro, ks, S)                 # sketched on this GPU
         sk, ln = ctx.get_reference_sketches()
     else:
         sk = ln = None
+    if world > 1:
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+    t_bc = time.perf_counter()
     sk, ln = rdist.broadcast_sketches(sk, ln, R, S, src=0,                 # RCCL over xGMI, once
                                       device=dev if os.environ.get("RKMH_DIST_BACKEND", "nccl") == "nccl" else "cpu")
+    broadcast_ms = (time.perf_counter() - t_bc) * 1e3
     if rank != 0:
         ctx.set_reference_sketches(sk, ln, ks, S)
 
-    n = a.reads
-    nb = max(1, a.batches)
-    lo = rank * n * nb          # every rank owns nb consecutive batches of n reads of the global read set
+    if c3_mode:
+        total = a.c3_total_reads
+        my_lo, my_hi = rdist.shard_bounds(total, rank, world)
+        per = max(1, min(a.c3_launch_reads, 28000000 * 150 // L))   # (32-bit base offsets inside one launch)
+        bounds = [(x, min(my_hi, x + per)) for x in range(my_lo, my_hi, per)]
+        nb = len(bounds)
+        n = my_hi - my_lo                                  # reads of this rank per step (one step = its whole shard)
+    else:
+        n = a.reads
+        nb = max(1, a.batches)
+        lo = rank * n * nb          # (N = 1: nb consecutive batches of n reads)
+        bounds = [(lo + b * n, lo + (b + 1) * n) for b in range(nb)]
+    ns = [hi_ - lo_ for lo_, hi_ in bounds]
     d_bs, d_os, d_outs, qbs, qos = [], [], [], [], []
-    for b in range(nb):
-        qb, qo = synth.generate_reads_fast(rb, ro, lo + b * n, lo + (b + 1) * n, read_len=L, threads=min(32, os.cpu_count() or 1))
-        qbs.append(qb); qos.append(qo)
+    for b, (lo_, hi_) in enumerate(bounds):
+        qb, qo = synth.generate_reads_fast(rb, ro, lo_, hi_, read_len=L, threads=min(32, os.cpu_count() or 1))
+        if not c3_mode or b == 0:
+            qbs.append(qb); qos.append(qo)                 # (config 3: only the first batch stays on the host, for the oracle samples)
         d_bs.append(torch.from_numpy(qb).to(dev))
         d_os.append(torch.from_numpy(qo.astype(np.int64)).to(torch.int32).to(dev))
-        d_outs.append(torch.zeros((n, 4), dtype=torch.int32, device=dev))
+        d_outs.append(torch.zeros((hi_ - lo_, 4), dtype=torch.int32, device=dev))
+        del qb, qo
     qb, qo = qbs[0], qos[0]
     torch.cuda.synchronize()                         # (uploads and fills above ran on the default stream)
     tstream = torch.cuda.Stream(device=dev)          # the kernels AND the timing events go on this stream
@@ -480,6 +587,10 @@ def main():
     step_no = [0]
 
     def step():
+        if c3_mode:     # one step = this rank's whole shard of the 100 M reads
+            for b in range(nb):
+                ctx.classify_device(d_bs[b].data_ptr(), d_os[b].data_ptr(), ns[b], d_outs[b].data_ptr(), max_read_len=L, stream=stream)
+            return
         b = step_no[0] % nb
         step_no[0] += 1
         ctx.classify_device(d_bs[b].data_ptr(), d_os[b].data_ptr(), n, d_outs[b].data_ptr(), max_read_len=L, stream=stream)
@@ -515,14 +626,30 @@ def main():
     elapsed = float(el.item())
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))   # HIP events on the launch stream
 
-    outs = [d.cpu().numpy() for d in d_outs]
-    out = outs[0]
-    if any((o[:, 0] < 0).any() for o in outs):
+    if any(bool((d[:, 0] < 0).any().item()) for d in d_outs):
         raise SystemExit("fused path flagged reads for rerouting: the benchmark batch must be fused-eligible")
+    outs = [d.cpu().numpy() for d in (d_outs[:1] if c3_mode else d_outs)]
+    out = outs[0]
+    c3_checked = 0
+    if c3_mode and a.cpu_seconds > 0:
+        # every rank samples rows of its first launch against the CPU oracle (sketches from the oracle too); the counts are summed
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle  # checker only
+        thr = a.cpu_threads or max(1, min(oracle.max_threads(), usable_cpus()) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
+        osk, oln = oracle.sketch_refs(rb, ro, ks, S, threads=thr)
+        ok = bool((osk == sk).all() and (oln == ln).all())
+        w = min(ns[0], 4096)
+        for lo_ in sorted({0, max(0, ns[0] // 2 - w), max(0, ns[0] - w)}):
+            want = oracle.classify_stream(qb, qo[lo_: lo_ + w + 1], ks, S, osk, oln, threads=thr)
+            ok = ok and bool((want == out[lo_: lo_ + w]).all())
+            c3_checked += w
+        if not rdist.all_true(ok):
+            raise SystemExit("ORACLE CHECK FAILED on some rank: GPU rows or reference sketches differ from the CPU oracle")
+        c3_checked = sum(rdist.all_gather_int(c3_checked))
 
     if rank == 0:
-        value = world * n * a.steps / elapsed
-        achieved = B_READ * n / (kern_ms * 1e-3) / 1e9
+        value = (a.c3_total_reads if c3_mode else n) * a.steps / elapsed
+        achieved = B_READ * n / (kern_ms * 1e-3) / 1e9     # (config 3: kern_ms spans the launches of one step = this rank's n reads)
         # Offline PMC figures (rocprofv3 --pmc passes of this same command, tools/profile.sh -> tools/make_pmc_json.py) are only
         # quoted while they describe THIS build: same kernel sources (stamp), same reads per launch.  Otherwise null.
         traffic = None
@@ -549,10 +676,12 @@ def main():
                 valu = None
         res = {
             "metric": "reads classified/sec", "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if c3_mode else "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "stream (C2): %d synthetic %d bp reads per GPU vs data/all_pave_ref.fa (%d refs), k=16 s=1000"
-                                   % (n, L, R), "reads_per_gpu": n, "read_len": L, "k": 16, "sketch_size": S,
+            "config": {"workload": ("classify (C3): %d synthetic %d bp reads IN ALL vs every bundled viral reference (%d sequences), k=16 s=1000, "
+                                    "reads sharded over %d GPUs; one step = one pass over all of them" % (a.c3_total_reads, L, R, world)) if c3_mode else
+                                   ("stream (C2): %d synthetic %d bp reads per GPU vs data/all_pave_ref.fa (%d refs), k=16 s=1000" % (n, L, R)),
+                       "reads_per_gpu": n, "read_len": L, "k": 16, "sketch_size": S,
                        "references": R, "parallelism": "reads sharded over %d rank(s); ref sketches RCCL-broadcast once" % world,
                        "spinup_seconds": a.spinup_seconds},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -564,6 +693,11 @@ def main():
                          # window is hashed in the kernel
                          "kernel_form": "k-mer-space" if ctx.kmer_form()[0] else "hash-space"},
         }
+        if c3_mode:
+            res["config"].update({"reads_total": a.c3_total_reads, "launches_per_step": nb, "sketch_broadcast_ms": broadcast_ms})
+            if c3_checked:
+                res["oracle_checked_reads"] = c3_checked
+                res["oracle_checked_ref_sketches"] = int(R)
         if world == 1 and a.cpu_seconds > 0:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle  # CPU baseline + checker only
@@ -700,7 +834,7 @@ def main():
         if world == 1 and not a.no_configs:
             res.update(config_legs(rkmh_amd, api, synth, dev, n, L, a.cpu_seconds > 0))
             if not a.no_c4_full and "c4_filter" in res:
-                res["c4_filter"]["full_size"] = c4_full_size(api, synth, a.c4_genome_mb, a.c4_reads)
+                res["c4_filter"]["full_size"] = c4_full_size(api, synth, a.c4_genome_mb, a.c4_reads, check=a.cpu_seconds > 0)
         if world == 1 and a.e2e_reads > 0:
             res["e2e"] = e2e_stream(a.e2e_reads, L, rb, ro, synth)
         print(json.dumps(res))

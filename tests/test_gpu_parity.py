@@ -462,7 +462,10 @@ def test_bench_json_contract(root):
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "bit-exact" in cb["oracle_check"]
     assert d["host_path"]["value"] > 0 and d["host_path"]["pageable_value"] > 0 and d["e2e"]["output_lines"] == d["e2e"]["reads"]
-    assert d["depth_filter"]["count_pass_ms"] > 0 and d["depth_filter"]["masked_classify_ms"] > 0 and d["depth_filter"]["slots"] == 200000000
+    df = d["depth_filter"]
+    assert df["count_pass_ms"] > 0 and df["masked_classify_ms"] > 0 and df["slots"] == 200000000 and df["min_num_bound"] == 0
+    assert df["count_pass_full_table_ms"] > 0 and df["masked_classify_exact_min_num_ms"] > 0 and df["oracle_checked_reads"] >= 4 * 30000
+    assert d["oracle_checked_ref_sketches"] == 182 and d["c3_panel"]["oracle_checked_ref_sketches"] >= 260
     # every timed batch is sampled against the oracle, not only the first
     assert cb["oracle_checked_reads"] > 30000 and "other 3 timed batches" in cb["oracle_check"]
     # informational legs for BASELINE configs 3, 4 and 5 (never `value`)
@@ -473,6 +476,7 @@ def test_bench_json_contract(root):
     # config 4 as a whole command (here scaled down): device front ends against the host parsers, byte for byte
     fs = c4["full_size"]
     assert "error" not in fs, fs
+    assert fs["oracle_checked_ref_sketches"] == 2 and fs["oracle_checked_reads"] >= 20000 and fs["oracle_checked_reads_passing"] > 0
     for key in ("plain", "M2"):
         assert fs[key]["identical_to_host_parsed_run"] is True and fs[key]["wall_s"] > 0 and fs[key]["reads_passing"] > 0
         assert any("references through the device" in x for x in fs[key]["stages"]) and any("device front end" in x for x in fs[key]["stages"])
@@ -484,29 +488,35 @@ def test_bench_spawns_its_own_ranks(root):
     process before it has touched the GPU, the two ranks run (here on GPU 0 over gloo), and the one JSON line comes through."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(RKMH_BENCH_ONE_DEVICE="1", RKMH_DIST_BACKEND="gloo")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--reads", "40000", "--steps", "4", "--warmup", "1",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--c3-total-reads", "80000", "--steps", "4", "--warmup", "1",
                         "--spinup-seconds", "0"], capture_output=True, cwd=root, env=env, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout.decode()[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and "cpu_baseline" not in d and "c3_panel" not in d
+    assert d["scaling"] == "strong" and d["config"]["reads_per_gpu"] == 40000
 
 
 def test_bench_two_ranks_launched_like_the_driver(root):
     """The driver's N>1 launch line (torch.distributed.run, one rank per GPU) with both ranks on GPU 0 and gloo instead of RCCL
-    (a one-GPU box): rank 0 prints ONE line, n_gpus = 2, value = reads of BOTH ranks over the slowest rank's time, no CPU baseline."""
+    (a one-GPU box).  N > 1 measures BASELINE config 3: a FIXED total of reads against every bundled reference (266 sequences),
+    sharded over the ranks -- strong scaling; rank 0 prints ONE line, value = all reads over the slowest rank's time, every rank
+    sampled its rows against the oracle, no CPU baseline."""
     env = dict(os.environ, RKMH_BENCH_ONE_DEVICE="1", RKMH_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--reads", "40000", "--steps", "4",
-                        "--warmup", "1", "--spinup-seconds", "0"], capture_output=True, cwd=root, env=env, timeout=600)
+                        "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--c3-total-reads", "100001", "--c3-launch-reads", "30000",
+                        "--steps", "4", "--warmup", "1", "--spinup-seconds", "0"], capture_output=True, cwd=root, env=env, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout.decode()[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and "cpu_baseline" not in d
-    assert abs(d["value"] - 2 * 40000 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6
-    assert d["config"]["reads_per_gpu"] == 40000 and "2 rank" in d["config"]["parallelism"]
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "strong" and "cpu_baseline" not in d
+    assert abs(d["value"] - 100001 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6
+    cfg = d["config"]
+    assert "(C3)" in cfg["workload"] and cfg["references"] >= 260 and cfg["reads_total"] == 100001 and cfg["reads_per_gpu"] == 100001 // 2
+    assert cfg["launches_per_step"] == 2 and cfg["sketch_broadcast_ms"] >= 0 and "2 rank" in cfg["parallelism"]
+    assert d["oracle_checked_reads"] >= 2 * 4096 and d["oracle_checked_ref_sketches"] == cfg["references"]
 
 
 def test_resident_input_entry_point(ctx, orc, pave):
