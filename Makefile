@@ -47,7 +47,7 @@ $(CSRC)/rk_synth.o: $(CSRC)/rk_synth.cpp include/rkmh_amd.h
 
 $(LIB): $(OBJS)
 	@mkdir -p rkmh_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz -lpthread -ldl
 
 bin/rkmh: $(CSRC)/rkmh_main.cpp $(LIB) include/rkmh_amd.h
 	@mkdir -p bin

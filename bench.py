@@ -68,6 +68,7 @@ def e2e_stream(n, L, rb, ro, synth):
     ref = os.path.join(ROOT, "tests", "golden", "data", "all_pave_ref.fa.gz")
     tmp = tempfile.mkdtemp(prefix="rkmh_e2e_")
     fq, tsv = os.path.join(tmp, "reads.fq"), os.path.join(tmp, "out.tsv")
+    extra = []
     try:
         with open(fq, "wb") as f:
             for lo in range(0, n, 1000000):          # fixed-width records, built 1 M at a time: "@r%09d\n" seq "\n+\n" qual "\n"
@@ -121,9 +122,65 @@ def e2e_stream(n, L, rb, ro, synth):
         if None not in t1 and t1[1] > t1[0]:
             res["x4_devnull"] = {"wall_s_1": t1[0], "wall_s_4": t1[1], "marginal_reads_per_s": 3 * n / (t1[1] - t1[0]),
                                  "note": "stdout = /dev/null: the ordered single-writer path a pipe gets"}
+        # compressed reads (the reference opens every input with gzopen, rkmh.cpp:238-263): the first reads of the file again with
+        # qualities that do not compress to nothing, as plain text, as BGZF (bgzip: independent members, inflated by the front end's
+        # workers) and as ordinary single-member gzip (one deflate stream: zlib on one thread, the block scanner behind it)
+        ng = min(n, 4000000)
+        if ng >= 1000:
+            import gzip
+            import hashlib
+            gq, bg, sg = os.path.join(tmp, "gz.fq"), os.path.join(tmp, "gz.bgzf.fq.gz"), os.path.join(tmp, "gz.single.fq.gz")
+            extra += [gq, bg, sg]
+            rl = 14 + 2 * L + 1
+            n1 = min(ng, 1000000)
+            with open(fq, "rb") as f, open(gq, "wb") as fo, open(bg, "wb") as fb:
+                for lo in range(0, ng, 1000000):
+                    m = min(1000000, ng - lo)
+                    rec = np.frombuffer(f.read(m * rl), dtype=np.uint8).reshape(m, rl).copy()
+                    rec[:, 14 + L:14 + 2 * L] = np.random.default_rng(lo).integers(35, 75, size=(m, L), dtype=np.uint8)
+                    raw = rec.tobytes()
+                    fo.write(raw)
+                    img = synth.bgzf_compress(raw, level=1, threads=min(32, os.cpu_count() or 1))
+                    fb.write(img[:-28] if lo + m < ng else img)      # (one end-of-file member, at the end)
+                    if lo == 0:
+                        with open(sg, "wb") as fs:
+                            fs.write(gzip.compress(raw[: n1 * rl], 1))
+
+            def timed(files):
+                fo_ = fresh_out()
+                t_ = time.perf_counter()
+                r_ = subprocess.run([exe, "stream", "-r", ref, "-k", "16", "-s", "1000"] + sum((["-f", x] for x in files), []), stdout=fo_, stderr=subprocess.PIPE)
+                d_ = time.perf_counter() - t_
+                fo_.close()
+                if r_.returncode != 0:
+                    raise RuntimeError(r_.stderr.decode()[-300:])
+                h = hashlib.sha256()
+                with open(tsv, "rb") as f_:
+                    for blk in iter(lambda: f_.read(1 << 24), b""):
+                        h.update(blk)
+                return d_, h.hexdigest()
+            try:
+                p1, hp = timed([gq])
+                b1, hb = timed([bg])
+                b4, _ = timed([bg] * 4)
+                s1, _ = timed([sg])
+                s4, _ = timed([sg] * 4)
+                res["gz"] = {"reads": ng, "fastq_bytes": os.path.getsize(gq), "bgzf_bytes": os.path.getsize(bg),
+                             "plain_wall_s": p1, "bgzf_wall_s": b1, "bgzf_x4_wall_s": b4,
+                             "bgzf_marginal_reads_per_s": 3 * ng / (b4 - b1) if b4 > b1 else None,
+                             "bgzf_output_identical_to_plain": hb == hp,
+                             "single_member_reads": n1, "single_member_wall_s": s1,
+                             "single_member_marginal_reads_per_s": 3 * n1 / (s4 - s1) if s4 > s1 else None,
+                             "note": "bin/rkmh stream on the same reads as plain FASTQ, as BGZF (level 1, 64 KB members; the workers of the device "
+                                     "front end inflate their jobs' members: libdeflate, all but two CPUs) and as single-member gzip (zlib on its "
+                                     "own thread + the block-parallel scanner); marginal = the extra reads of four -f files over one, per extra second"}
+                if hb != hp:
+                    raise SystemExit("e2e: the BGZF run printed other bytes than the plain-text run")
+            except RuntimeError as e:
+                res["gz"] = {"error": str(e)}
         return res
     finally:
-        for x in (fq, tsv):
+        for x in [fq, tsv] + extra:
             try:
                 os.remove(x)
             except OSError:

@@ -401,6 +401,23 @@ void rk_fastq_slot_destroy(rk_fastq_slot* slot);
  * second line below begins with '+'), or -1 when there is none: text[0 .. offset) then holds whole records only. */
 int64_t rk_fastq_cut(const uint8_t* text, uint64_t n);
 
+/* BGZF (bgzip) FASTQ files for the device front end.  The reference opens every input through gzFile (src/rkmh.cpp:238-263): one
+ * sequential inflater.  A BGZF file is a chain of independent gzip members (<= 64 KB of text each) whose headers give their
+ * lengths, so any number of threads can each inflate the members of their own block of the file.  rk_bgzf_open: RK_ERR_ARG = not a
+ * BGZF file (plain gzip, plain text: take another path).  rk_bgzf_plan groups consecutive members into jobs of about target_bytes
+ * of text (first[j] .. first[j + 1]); rk_bgzf_fastq_records inflates one job and copies the whole FASTQ records that START in it
+ * (four-line rule at both ends, as rk_fastq_cut) to dst, ready for rk_fastq_slot_submit; it returns 1 when the text does not
+ * begin with '@'.  Thread-safe on one rk_bgzf. */
+typedef struct rk_bgzf rk_bgzf;
+int rk_bgzf_open(const char* path, rk_bgzf** out);
+void rk_bgzf_close(rk_bgzf* z);
+int64_t rk_bgzf_members(const rk_bgzf* z);
+uint64_t rk_bgzf_text_bytes(const rk_bgzf* z);
+uint64_t rk_bgzf_text_offset(const rk_bgzf* z, int64_t member);
+int rk_bgzf_first_byte(const rk_bgzf* z);
+int64_t rk_bgzf_plan(const rk_bgzf* z, uint64_t target_bytes, int64_t* first, int64_t cap);
+int rk_bgzf_fastq_records(const rk_bgzf* z, int64_t b0, int64_t b1, uint8_t* dst, uint64_t cap, uint64_t* nbytes, uint64_t* text_off);
+
 #ifdef __cplusplus
 }
 #endif

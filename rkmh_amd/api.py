@@ -97,6 +97,14 @@ _SIGS = {
     "rk_num_references": (C.c_int, [C.c_void_p]),
     "rk_set_depth_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rk_set_min_num_bound": (C.c_int, [C.c_void_p, C.c_int]),
+    "rk_bgzf_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "rk_bgzf_close": (None, [C.c_void_p]),
+    "rk_bgzf_members": (C.c_int64, [C.c_void_p]),
+    "rk_bgzf_text_bytes": (C.c_uint64, [C.c_void_p]),
+    "rk_bgzf_text_offset": (C.c_uint64, [C.c_void_p, C.c_int64]),
+    "rk_bgzf_first_byte": (C.c_int, [C.c_void_p]),
+    "rk_bgzf_plan": (C.c_int64, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), C.c_int64]),
+    "rk_bgzf_fastq_records": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_counter_create_compact": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rk_counter_compact_entries": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rk_counter_entries": (C.c_uint64, [C.c_void_p]),
@@ -554,6 +562,68 @@ class FastqSlot:
     def __del__(self):
         try:
             self.destroy()
+        except Exception:
+            pass
+
+
+class Bgzf:
+    """A BGZF (bgzip) file whose members any number of threads may inflate (rk_bgzf_*): the compressed form of the device FASTQ
+    front end's input.  Bgzf.open returns None for anything that is not BGZF."""
+
+    def __init__(self, handle):
+        self._lib = load_library()
+        self._h = handle
+
+    @staticmethod
+    def open(path):
+        lib = load_library()
+        h = C.c_void_p()
+        rc = lib.rk_bgzf_open(os.fsencode(path), C.byref(h))
+        if rc == -1:         # RK_ERR_ARG: not BGZF
+            return None
+        _chk(rc)
+        return Bgzf(h)
+
+    @property
+    def members(self):
+        return int(self._lib.rk_bgzf_members(self._h))
+
+    @property
+    def text_bytes(self):
+        return int(self._lib.rk_bgzf_text_bytes(self._h))
+
+    def text_offset(self, member):
+        return int(self._lib.rk_bgzf_text_offset(self._h, member))
+
+    def first_byte(self):
+        return int(self._lib.rk_bgzf_first_byte(self._h))
+
+    def plan(self, target_bytes):
+        """first members of the jobs of about target_bytes of text each, and the member count last"""
+        cap = self.members + 2
+        first = (C.c_int64 * cap)()
+        n = int(self._lib.rk_bgzf_plan(self._h, target_bytes, first, cap))
+        if n < 0:
+            _chk(n)
+        return [int(first[i]) for i in range(n + 1)]
+
+    def fastq_records(self, b0, b1, dst, cap):
+        """the whole FASTQ records that start in members [b0, b1) -> (status, bytes written to dst, their offset in the text);
+        status 1: the text does not begin with '@'.  dst: address or ctypes buffer of cap bytes."""
+        n, off = C.c_uint64(), C.c_uint64()
+        rc = self._lib.rk_bgzf_fastq_records(self._h, b0, b1, dst, cap, C.byref(n), C.byref(off))
+        if rc < 0:
+            _chk(rc)
+        return rc, int(n.value), int(off.value)
+
+    def close(self):
+        if self._h:
+            self._lib.rk_bgzf_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -10,6 +10,7 @@ on the gathered rows, passing reads printed by rank 0 in input order.  (The sing
 `call` and `hash` exist only there: a 52 k-read `call` takes 0.2 s on one GPU.)
 """
 import getopt
+import ctypes as C
 import os
 import sys
 
@@ -216,20 +217,33 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
     output is written to out_fd (see _RankOutput) and True returned -- or, when ANY rank met text that is not four lines per record,
     nothing is written and False returned (then every rank takes the parsing path)."""
     import threading
-    ok = all(_raw_eligible(p) for p in reads) and bool(reads)
+    # BGZF (bgzip) files: chains of independent gzip members -- every rank takes its share of the members and its worker threads
+    # inflate them (rk_bgzf_*), so compressed reads are neither inflated by one thread nor parsed by every rank
+    bzs = [api.Bgzf.open(p) if (os.path.isfile(p) and os.environ.get("RKMH_BGZF", "1") != "0") else None for p in reads]
+    ok = bool(reads) and all((bz.first_byte() == 0x40) if bz is not None else _raw_eligible(p) for p, bz in zip(reads, bzs))
     if not rdist.all_true(ok):
+        for bz in bzs:
+            if bz is not None:
+                bz.close()
         return False
     block = max(4096, int(os.environ.get("RKMH_RAW_BLOCK_KB", "16384")) << 10)
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     nw = int(os.environ.get("RKMH_RAW_WORKERS", "0")) or max(2, min(6, ((os.cpu_count() or 8) * 3 // 8) // local_world))
+    if any(bz is not None for bz in bzs) and not os.environ.get("RKMH_RAW_WORKERS"):
+        nw = max(nw, min(32, ((os.cpu_count() or 8) - 2) // local_world))      # inflating is CPU work: all but two of the CPUs
     fds = [os.open(p, os.O_RDONLY) for p in reads]
-    sizes = [os.fstat(fd).st_size for fd in fds]
+    sizes = [bz.members if bz is not None else os.fstat(fd).st_size for fd, bz in zip(fds, bzs)]
     slots, state = [], {"ok": True}
     lock = threading.Lock()
     try:
         # this rank's blocks of every file: [cut(size r / world), cut(size (r + 1) / world)) in steps of `block`, ends cut the same way
         plan = []
-        for fd, size in zip(fds, sizes):
+        for fd, size, bz in zip(fds, sizes, bzs):
+            if bz is not None:      # jobs = runs of members holding about a block of text; this rank's share of them
+                first = bz.plan(block - (256 << 10) if block > (1 << 20) else block * 3 // 4)
+                nj = len(first) - 1
+                plan.append([(first[j], first[j + 1]) for j in range(nj * rank // world, nj * (rank + 1) // world)])
+                continue
             a, b = _cut_before(fd, size, size * rank // world), _cut_before(fd, size, size * (rank + 1) // world)
             ends = [_cut_before(fd, size, p) for p in range(a + block, b, block)] + [b]
             blocks, s0 = [], a
@@ -238,17 +252,17 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
                     blocks.append((s0, e))
                     s0 = e
             plan.append(blocks)
-        longest = max([e - s0 for blocks in plan for s0, e in blocks] + [4096])
+        longest = max([e - s0 for blocks, bz in zip(plan, bzs) if bz is None for s0, e in blocks] + [4096] + ([block] if any(bz is not None for bz in bzs) else []))
         for _ in range(nw):
             slots.append(api.FastqSlot(ctx, max_bytes=longest + 64))
         parts = None if filter_mode else api.LineParts(ref_names, sketch, min_matches, min_diff)
 
         def run_pass(counter, sink=None):
             texts = []
-            for fd, size, blocks in zip(fds, sizes, plan):
+            for fd, size, blocks, bz in zip(fds, sizes, plan, bzs):
                 results, nxt, due = [None] * len(blocks), [0], [0]
 
-                def work(slot):
+                def work(slot, fd=fd, size=size, blocks=blocks, bz=bz, results=results, nxt=nxt, due=due):
                     try:
                         buf = slot.text_buffer()
                         mv = memoryview(buf).cast("B")
@@ -259,14 +273,20 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
                             if i >= len(blocks):
                                 return
                             s0, s1 = blocks[i]
-                            n, got = s1 - s0, 0
-                            while got < n:
-                                k = os.preadv(fd, [mv[got:n]], s0 + got)
-                                if k <= 0:
+                            if bz is not None:      # members [s0, s1): inflated here, cut to the whole records that start in them
+                                st, n, _ = bz.fastq_records(s0, s1, C.addressof(buf), slot.max_bytes + 63)
+                                if st != 0:
                                     state["ok"] = False
                                     return
-                                got += k
-                            if s1 == size and mv[n - 1] != 10:
+                            else:
+                                n, got = s1 - s0, 0
+                                while got < n:
+                                    k = os.preadv(fd, [mv[got:n]], s0 + got)
+                                    if k <= 0:
+                                        state["ok"] = False
+                                        return
+                                    got += k
+                            if s1 == size and n and mv[n - 1] != 10:
                                 mv[n] = 10          # a last line without its newline (the slot holds spare bytes)
                                 n += 1
                             if counter is not None:

@@ -10,6 +10,7 @@
 // Bases are NOT upper-cased here: the device does that while staging (rkmh.cpp:252 / :856).
 #include "../../include/rkmh_amd.h"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -19,6 +20,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -174,8 +177,60 @@ struct Piece {
 
 } // namespace
 
+// Compressed input (one deflate stream: only a sequential reader can follow it, src/rkmh.cpp:238-263): zlib inflates on its OWN
+// thread, a few 8 MB pieces ahead, while the block scanner's threads parse what has arrived.
+struct AsyncGz {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::vector<unsigned char>> q;
+    bool done = false, stop = false;
+    std::vector<unsigned char> cur;
+    size_t cur_pos = 0;
+};
+
 struct rk_reader {
     gzFile fp = nullptr;
+    AsyncGz* az = nullptr;       // compressed input only
+    bool compressed = false;
+    // `want` bytes of the (inflated) input, fewer only at its end
+    size_t pull(unsigned char* dst, size_t want) {
+        if (!compressed) { const int r = gzread(fp, dst, (unsigned)want); return r > 0 ? (size_t)r : 0; }
+        if (!az) {
+            az = new AsyncGz();
+            az->th = std::thread([this] {
+                for (;;) {
+                    std::vector<unsigned char> piece((size_t)8 << 20);
+                    const int r = gzread(fp, piece.data(), (unsigned)piece.size());
+                    piece.resize(r > 0 ? (size_t)r : 0);
+                    std::unique_lock<std::mutex> l(az->m);
+                    az->cv.wait(l, [&] { return az->q.size() < 6 || az->stop; });
+                    if (az->stop) return;
+                    const bool last = piece.size() < ((size_t)8 << 20);
+                    if (!piece.empty()) az->q.push_back(std::move(piece));
+                    if (last) az->done = true;
+                    az->cv.notify_all();
+                    if (last) return;
+                }
+            });
+        }
+        size_t got = 0;
+        while (got < want) {
+            if (az->cur_pos == az->cur.size()) {
+                std::unique_lock<std::mutex> l(az->m);
+                az->cv.wait(l, [&] { return !az->q.empty() || az->done; });
+                if (az->q.empty()) break; // end of input
+                az->cur = std::move(az->q.front());
+                az->q.pop_front();
+                az->cur_pos = 0;
+                az->cv.notify_all();
+            }
+            const size_t n = std::min(want - got, az->cur.size() - az->cur_pos);
+            memcpy(dst + got, az->cur.data() + az->cur_pos, n);
+            az->cur_pos += n; got += n;
+        }
+        return got;
+    }
     std::vector<unsigned char> buf;
     size_t beg = 0, end = 0;
     bool eof = false;
@@ -224,9 +279,8 @@ struct rk_reader {
             if (pend_then_eof) eof = true;
         }
         if (eof || !fp) return false;
-        int r = gzread(fp, buf.data(), (unsigned)buf.size());
         beg = 0;
-        end = r > 0 ? (size_t)r : 0;
+        end = pull(buf.data(), buf.size());
         if (end < buf.size()) eof = true;
         return end > 0;
     }
@@ -539,8 +593,7 @@ int rk_reader::next_block(Batch& b, int64_t max_records, bool open_cuts) {
                 size_t want = target - have;
                 if (want > (1u << 30)) want = 1u << 30;
                 blk.resize(have + want);
-                int r = gzread(fp, blk.data() + have, (unsigned)want);
-                size_t got = r > 0 ? (size_t)r : 0;
+                size_t got = pull(blk.data() + have, want);
                 blk.resize(have + got);
                 if (got < want) blk_eof = true;
             }
@@ -811,6 +864,10 @@ static int reader_open_at(const char* path, uint64_t offset, rk_reader** out) {
         gzbuffer(fp, 1 << 20);
         r->fp = fp;
         plain = gzdirect(fp) != 0;
+        // compressed: the inflater gets its own thread, and the block-parallel scanner parses what it delivers (RKMH_GZ_BLOCKS=0: the
+        // sequential scanner on the calling thread, as before round 5)
+        r->compressed = !plain && !(getenv("RKMH_GZ_BLOCKS") && atoi(getenv("RKMH_GZ_BLOCKS")) == 0);
+        if (r->compressed) plain = true;
         if (offset && gzseek(fp, (z_off_t)offset, SEEK_SET) < 0) { gzclose(fp); delete r; return perr(RK_ERR_IO, std::string("cannot seek in ") + path); }
     }
     r->par_ok = plain && r->nthreads > 1;
@@ -825,6 +882,12 @@ void rk_reader_set_options(rk_reader* r, int flags) {
 
 void rk_reader_close(rk_reader* r) {
     if (!r) return;
+    if (r->az) {
+        { std::lock_guard<std::mutex> l(r->az->m); r->az->stop = true; }
+        r->az->cv.notify_all();
+        if (r->az->th.joinable()) r->az->th.join();
+        delete r->az;
+    }
     if (r->fp) gzclose(r->fp);
     if (r->map) munmap((void*)r->map, r->map_total);
     delete r;
@@ -879,6 +942,199 @@ void rk_seqset_free(rk_seqset* s) {
     if (!s) return;
     pool::give_back(s->bases); pool::give_back(s->offsets); pool::give_back(s->names); pool::give_back(s->name_offsets); pool::give_back(s->quals);
     memset(s, 0, sizeof *s);
+}
+
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------------
+// BGZF (bgzip) input: the file is a chain of INDEPENDENT gzip members of at most 64 KB of text each, and every member's header
+// says how long the member is ('BC' extra field) -- so, unlike plain gzip (one deflate stream that only a sequential reader can
+// follow, src/rkmh.cpp:238-263 through gzFile), the members can be found without inflating anything and inflated by as many
+// threads as there are.  The device FASTQ front end's workers each inflate the members of their job straight in front of the
+// upload (rkmh_main.cpp, stream_file_raw); nothing in the process ever reads the file sequentially.
+// Inflate = libdeflate when the system has it (dlopen: ~3 x zlib's rate per core), zlib otherwise; CRC-32 and ISIZE are checked.
+struct rk_bgzf {
+    int fd = -1;
+    const unsigned char* map = nullptr;
+    size_t size = 0;
+    std::vector<uint64_t> coff, uoff; // [members + 1] offset in the file / in the text
+    std::vector<uint16_t> hlen;       // [members] header bytes (12 + XLEN)
+};
+
+namespace {
+struct Deflate {
+    void* h = nullptr;
+    void* (*alloc)() = nullptr;
+    int (*run)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
+    Deflate() {
+        if (getenv("RKMH_NO_LIBDEFLATE")) return;
+        h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
+        run = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_deflate_decompress");
+        crc = (uint32_t (*)(uint32_t, const void*, size_t))dlsym(h, "libdeflate_crc32");
+        if (!alloc || !run || !crc) { alloc = nullptr; run = nullptr; crc = nullptr; }
+    }
+};
+const Deflate& deflate_lib() { static const Deflate d; return d; }
+
+// one member's text into dst[0 .. usize); false: corrupt
+bool inflate_member(const rk_bgzf* z, size_t b, unsigned char* dst) {
+    const unsigned char* m = z->map + z->coff[b];
+    const size_t total = (size_t)(z->coff[b + 1] - z->coff[b]), h = z->hlen[b], usize = (size_t)(z->uoff[b + 1] - z->uoff[b]);
+    const unsigned char* payload = m + h;
+    const size_t clen = total - h - 8;
+    uint32_t want_crc;
+    memcpy(&want_crc, m + total - 8, 4);
+    const Deflate& L = deflate_lib();
+    if (L.run) {
+        static thread_local void* dec = L.alloc();
+        size_t got = 0;
+        if (!dec || L.run(dec, payload, clen, dst, usize, &got) != 0 || got != usize) return false;
+        return L.crc(0, dst, usize) == want_crc;
+    }
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<unsigned char*>(payload); zs.avail_in = (uInt)clen;
+    zs.next_out = dst; zs.avail_out = (uInt)usize;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.total_out == usize;
+    inflateEnd(&zs);
+    return ok && (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, (uInt)usize) == want_crc;
+}
+} // namespace
+
+extern "C" {
+
+// RK_OK and *out = the opened file; RK_ERR_ARG: not a BGZF file (not an error to report: the caller takes another path)
+int rk_bgzf_open(const char* path, rk_bgzf** out) {
+    if (!path || !out) return perr(RK_ERR_ARG, "bad arguments");
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return perr(RK_ERR_IO, std::string("cannot open ") + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 28) { close(fd); return perr(RK_ERR_ARG, "not a BGZF file"); }
+    void* mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+    if (mp == MAP_FAILED) { close(fd); return perr(RK_ERR_IO, std::string("cannot map ") + path); }
+    rk_bgzf* z = new rk_bgzf();
+    z->fd = fd; z->map = (const unsigned char*)mp; z->size = (size_t)st.st_size;
+    size_t p = 0;
+    uint64_t u = 0;
+    bool ok = true;
+    while (ok && p < z->size) {
+        const unsigned char* m = z->map + p;
+        if (z->size - p < 26 || m[0] != 0x1f || m[1] != 0x8b || m[2] != 8 || m[3] != 4) { ok = false; break; } // FLG = FEXTRA alone, as bgzip writes it
+        const size_t xlen = (size_t)m[10] | ((size_t)m[11] << 8);
+        if (12 + xlen + 8 > z->size - p) { ok = false; break; }
+        size_t bsize = 0;
+        for (size_t q = 12; q + 4 <= 12 + xlen;) {
+            const size_t slen = (size_t)m[q + 2] | ((size_t)m[q + 3] << 8);
+            if (m[q] == 'B' && m[q + 1] == 'C' && slen == 2 && q + 6 <= 12 + xlen) bsize = ((size_t)m[q + 4] | ((size_t)m[q + 5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || bsize > z->size - p) { ok = false; break; }
+        uint32_t isize;
+        memcpy(&isize, m + bsize - 4, 4);
+        if (isize > 65536) { ok = false; break; }
+        z->coff.push_back(p); z->uoff.push_back(u); z->hlen.push_back((uint16_t)(12 + xlen));
+        p += bsize; u += isize;
+    }
+    if (!ok || z->coff.empty()) { rk_bgzf_close(z); return perr(RK_ERR_ARG, "not a BGZF file"); }
+    z->coff.push_back(p); z->uoff.push_back(u);
+    madvise(mp, z->size, MADV_WILLNEED);
+    *out = z;
+    return RK_OK;
+}
+void rk_bgzf_close(rk_bgzf* z) {
+    if (!z) return;
+    if (z->map) munmap((void*)z->map, z->size);
+    if (z->fd >= 0) close(z->fd);
+    delete z;
+}
+int64_t rk_bgzf_members(const rk_bgzf* z) { return z ? (int64_t)z->hlen.size() : 0; }
+uint64_t rk_bgzf_text_bytes(const rk_bgzf* z) { return z ? z->uoff.back() : 0; }
+uint64_t rk_bgzf_text_offset(const rk_bgzf* z, int64_t member) {
+    if (!z || member < 0) return 0;
+    return z->uoff[(size_t)std::min<int64_t>(member, (int64_t)z->hlen.size())];
+}
+// the text's first byte (0: empty or corrupt): '@' = FASTQ
+int rk_bgzf_first_byte(const rk_bgzf* z) {
+    if (!z) return 0;
+    std::vector<unsigned char> t(65536);
+    for (size_t b = 0; b < z->hlen.size(); ++b) {
+        if (z->uoff[b + 1] == z->uoff[b]) continue;
+        return inflate_member(z, b, t.data()) ? (int)t[0] : 0;
+    }
+    return 0;
+}
+// consecutive members grouped into jobs of about target_bytes of text: first[j] = first member of job j, first[jobs] = members
+int64_t rk_bgzf_plan(const rk_bgzf* z, uint64_t target_bytes, int64_t* first, int64_t cap) {
+    if (!z || !first || cap < 2) return perr(RK_ERR_ARG, "bad arguments");
+    const size_t nb = z->hlen.size();
+    int64_t nj = 0;
+    size_t b = 0;
+    while (b < nb) {
+        if (nj + 1 >= cap) return perr(RK_ERR_LIMIT, "rk_bgzf_plan: more jobs than the caller's array holds");
+        first[nj++] = (int64_t)b;
+        const uint64_t start = z->uoff[b];
+        while (b < nb && z->uoff[b + 1] - start <= target_bytes) ++b;
+        if (z->uoff[b] == start && b < nb) ++b; // (a member larger than the target: alone)
+    }
+    first[nj] = (int64_t)nb;
+    return nj;
+}
+// The whole FASTQ records that START in the text of members [b0, b1): the members are inflated (with the one in front, for its
+// last byte, and as many behind as the last record reaches into), the first record start at or after the text of b0 and of b1
+// is found by the four-line rule of find_record_start -- the same function at both ends, so neighbouring jobs agree -- and the
+// bytes between them are copied to dst.  *text_off = where they begin in the uncompressed text.  Returns RK_OK, RK_ERR_IO
+// (corrupt member), RK_ERR_LIMIT (more than cap bytes), or 1: the text does not begin with '@' (member 0 only).
+int rk_bgzf_fastq_records(const rk_bgzf* z, int64_t b0, int64_t b1, uint8_t* dst, uint64_t cap, uint64_t* nbytes, uint64_t* text_off) {
+    if (!z || !dst || !nbytes || b0 < 0 || b1 < b0 || (size_t)b1 > z->hlen.size()) return perr(RK_ERR_ARG, "bad arguments");
+    *nbytes = 0;
+    const size_t nb = z->hlen.size();
+    const size_t lo = b0 > 0 ? (size_t)b0 - 1 : 0;
+    static thread_local std::vector<unsigned char> buf;
+    size_t have_b = lo; // members [lo, have_b) are in buf
+    auto extend_to = [&](size_t upto) -> bool {
+        if (upto > nb) upto = nb;
+        const size_t need = (size_t)(z->uoff[upto] - z->uoff[lo]);
+        if (buf.size() < need + 64) buf.resize(need + (need >> 2) + 65536);
+        for (; have_b < upto; ++have_b)
+            if (!inflate_member(z, have_b, buf.data() + (z->uoff[have_b] - z->uoff[lo]))) return false;
+        return true;
+    };
+    if (!extend_to((size_t)b1)) return perr(RK_ERR_IO, "corrupt BGZF member");
+    const uint64_t u_lo = z->uoff[lo];
+    auto first_start = [&](size_t member, bool* need_more) -> size_t { // offset in buf; == text in buf when there is none
+        *need_more = false;
+        const unsigned char* base = buf.data();
+        const unsigned char* e = base + (z->uoff[have_b] - u_lo);
+        const unsigned char* from = base + (z->uoff[member] - u_lo);
+        if (member == 0) return 0;
+        if (from >= e) { *need_more = have_b < nb; return (size_t)(e - base); }
+        const unsigned char* q = find_record_start(base, from, e, true);
+        if (q) return (size_t)(q - base);
+        *need_more = have_b < nb;
+        return (size_t)(e - base);
+    };
+    bool more = false;
+    size_t tail = first_start((size_t)b1, &more);
+    for (size_t step = 2; more; step *= 2) { // the last record reaches into the members behind
+        if (!extend_to(have_b + step)) return perr(RK_ERR_IO, "corrupt BGZF member");
+        tail = first_start((size_t)b1, &more);
+    }
+    size_t head = first_start((size_t)b0, &more);
+    if (head > tail) head = tail;
+    if (b0 == 0 && tail > 0 && buf[0] != '@') return 1;
+    const size_t n = tail - head;
+    if (text_off) *text_off = u_lo + head;
+    if (n > cap) return perr(RK_ERR_LIMIT, "rk_bgzf_fastq_records: the records of the job need more bytes than the buffer holds");
+    memcpy(dst, buf.data() + head, n);
+    *nbytes = n;
+    return RK_OK;
 }
 
 } // extern "C"

@@ -377,9 +377,23 @@ static int granted_cpus_main() {
     return n < 1 ? 1 : n;
 }
 
-// a regular, uncompressed file that begins with '@' (FASTQ reads) / '>' (FASTA references)
+// BGZF (bgzip) read files found by raw_eligible: the device front end's workers inflate their members themselves (rk_bgzf_*)
+static std::map<std::string, rk_bgzf*> g_bgzf;
+static rk_bgzf* bgzf_of(const char* path) { auto it = g_bgzf.find(path); return it == g_bgzf.end() ? nullptr : it->second; }
+
+// a regular, uncompressed file that begins with '@' (FASTQ reads) / '>' (FASTA references) -- or, for reads, a BGZF file whose text
+// does (*size is then the length of the text); RKMH_BGZF=0 leaves compressed files to the sequential zlib scanner
 static bool raw_eligible(const char* path, int64_t* size, char first = '@') {
     if (!path || strcmp(path, "-") == 0) return false;
+    if (first == '@' && !(getenv("RKMH_BGZF") && atoi(getenv("RKMH_BGZF")) == 0)) {
+        if (rk_bgzf* z = bgzf_of(path)) { *size = (int64_t)rk_bgzf_text_bytes(z); return true; }
+        rk_bgzf* z = nullptr;
+        if (rk_bgzf_open(path, &z) == RK_OK) {
+            if (rk_bgzf_first_byte(z) == '@') { g_bgzf[path] = z; *size = (int64_t)rk_bgzf_text_bytes(z); return true; }
+            rk_bgzf_close(z);
+            return false;
+        }
+    }
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return false;
     struct stat st;
@@ -513,6 +527,9 @@ struct RawEngine {
         // gets that many as long as the CPUs last -- not measured (one-GPU boxes), the same reasoning per link
         const long cap = g.size() > 1 ? std::min<long>(64, 6 * (long)g.size()) : 12;
         if (nw > cap) nw = cap;
+        // BGZF input: a worker inflates its job's members before the upload (~1 GB/s of text per core with libdeflate, a third of
+        // that with zlib) -- the CPUs, not the link, set the rate, so all but two of them work
+        if (!g_bgzf.empty()) nw = std::max<long>(nw, std::min<long>(32, granted_cpus_main() - 2));
         if (const char* e = getenv("RKMH_RAW_WORKERS")) { long v = atol(e); if (v >= 1 && v <= 64) nw = v; }
         if ((size_t)nw < g.size()) nw = (long)g.size();
         if (const char* e = getenv("RKMH_RAW_SLOTS")) two_slots = atoi(e) == 2;
@@ -573,7 +590,8 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     rk_line_parts* lp = nullptr;
     if (kind == RAW_STREAM) CK(rk_line_parts_create(refs.names, refs.name_offsets, refs.nseq, o.sketch, o.min_matches, o.min_diff, &lp));
     const bool counting = kind == RAW_COUNT;
-    struct Job { int64_t seq = 0, lo = 0, hi = 0; };
+    rk_bgzf* const bz = bgzf_of(path); // compressed (BGZF): a job is a run of members [lo, hi), inflated by the worker that takes it
+    struct Job { int64_t seq = 0, lo = 0, hi = 0, at = 0; }; // at: where the job's first record starts in the (uncompressed) text
     QueueT<Job> jobs;
     jobs.cap = eng.w.size();
     OrderedOut out;
@@ -605,7 +623,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
             std::vector<char> buf = out.take_buffer();
             size_t outlen = 0;
             if (res.status != 0) {
-                { std::lock_guard<std::mutex> l(fm); fail_at[jb.seq] = jb.lo; }
+                { std::lock_guard<std::mutex> l(fm); fail_at[jb.seq] = jb.at; }
                 out.lower_limit(jb.seq); // (before this block is parked: the sink cannot pass it)
                 int64_t curf = fail_seq.load();
                 while (jb.seq < curf && !fail_seq.compare_exchange_weak(curf, jb.seq)) {}
@@ -621,14 +639,35 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
             if (got) {
                 const double a = now_s();
                 uint8_t* text = rk_fastq_slot_text(eng.w[wi].slot[k]);
-                int64_t have = 0;
-                while (have < cur.hi - cur.lo) {
-                    const ssize_t n = pread(fd, text + have, (size_t)(cur.hi - cur.lo - have), (off_t)(cur.lo + have));
-                    if (n <= 0) { fprintf(stderr, "rkmh: read error on %s\n", path); fail_exit(); } // (the other workers may be waiting for this block)
-                    have += n;
+                uint64_t nbytes = 0;
+                bool refused = false; // (BGZF: text that does not begin with '@', or a job whose records outgrow the slot)
+                if (bz) {
+                    uint64_t off = 0;
+                    const int rc = rk_bgzf_fastq_records(bz, cur.lo, cur.hi, text, eng.block + 63, &nbytes, &off);
+                    cur.at = (int64_t)off;
+                    if (rc == 1 || rc == RK_ERR_LIMIT) { refused = true; nbytes = 0; }
+                    else if (rc != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
+                    if (cur.hi == rk_bgzf_members(bz) && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n';
+                } else {
+                    cur.at = cur.lo;
+                    int64_t have = 0;
+                    while (have < cur.hi - cur.lo) {
+                        const ssize_t n = pread(fd, text + have, (size_t)(cur.hi - cur.lo - have), (off_t)(cur.lo + have));
+                        if (n <= 0) { fprintf(stderr, "rkmh: read error on %s\n", path); fail_exit(); } // (the other workers may be waiting for this block)
+                        have += n;
+                    }
+                    nbytes = (uint64_t)(cur.hi - cur.lo);
+                    if (cur.hi == fsize && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n'; // a last line without its newline (the slot holds 64 spare bytes)
                 }
-                uint64_t nbytes = (uint64_t)(cur.hi - cur.lo);
-                if (cur.hi == fsize && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n'; // a last line without its newline (the slot holds 64 spare bytes)
+                if (refused) { // the scanner takes the file over from this job's first record
+                    { std::lock_guard<std::mutex> l(fm); fail_at[cur.seq] = cur.at; }
+                    if (!counting) out.lower_limit(cur.seq);
+                    int64_t curf = fail_seq.load();
+                    while (cur.seq < curf && !fail_seq.compare_exchange_weak(curf, cur.seq)) {}
+                    if (!counting) out.put(cur.seq, std::vector<char>(), 0, window);
+                    t_rd += now_s() - a;
+                    continue;
+                }
                 if (counting) {
                     t_rd += now_s() - a;
                     const double b = now_s();
@@ -637,7 +676,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                     if (crc == RK_ERR_NEED_FULL) { g_need_full.store(true); status = 1; } // a read with more hashes than the sketch keeps: the pass ends, the caller repeats it with full tables
                     else if (crc != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
                     if (status != 0) {
-                        { std::lock_guard<std::mutex> l(fm); fail_at[cur.seq] = cur.lo; }
+                        { std::lock_guard<std::mutex> l(fm); fail_at[cur.seq] = cur.at; }
                         int64_t curf = fail_seq.load();
                         while (cur.seq < curf && !fail_seq.compare_exchange_weak(curf, cur.seq)) {}
                     }
@@ -660,7 +699,14 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     // coordinator: ranges of whole records.  The end of a range is the last record start (four-line rule, rk_fastq_cut) inside a
     // window in front of its nominal end; a range that is cut wrongly (possible only in text that is not four lines per record) is
     // refused by the device and the scanner takes over from its first byte.
-    {
+    if (bz) { // jobs = runs of members holding about a block of text (the records are cut by the worker, after inflating)
+        std::vector<int64_t> first((size_t)rk_bgzf_members(bz) + 2);
+        const uint64_t target = eng.block > ((uint64_t)1 << 20) ? eng.block - ((uint64_t)1 << 18) : eng.block * 3 / 4;
+        const int64_t nj = rk_bgzf_plan(bz, target, first.data(), (int64_t)first.size());
+        if (nj < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+        for (int64_t j = 0; j < nj && fail_seq.load() == INT64_MAX; ++j) { Job jb; jb.seq = j; jb.lo = first[(size_t)j]; jb.hi = first[(size_t)j + 1]; jobs.push(jb); }
+        jobs.finish();
+    } else {
         std::vector<uint8_t> win;
         int64_t pos = 0, seq = 0;
         const int64_t B = (int64_t)eng.block;

@@ -116,3 +116,27 @@ def synthetic_panel(nref=182, min_len=7100, max_len=8104, seed=SEED ^ 0xFFFF):
     bases = np.zeros(tot + 16, dtype=np.uint8)
     bases[:tot] = _ACGT[(z >> np.uint64(33)) % np.uint64(4)]
     return bases, offs
+
+
+def bgzf_compress(data, level=1, block=0xff00, threads=8):
+    """`data` (bytes-like) as a BGZF file image: independent gzip members of at most `block` bytes of text each, the 'BC' extra
+    field carrying each member's length, the empty end-of-file member last -- what `bgzip` writes (SAM specification, section 4.1).
+    Members are deflated in `threads` threads (zlib releases the GIL)."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    mv = memoryview(data)
+
+    def member(lo):
+        chunk = mv[lo: lo + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        if len(body) + 26 > 65536:                       # incompressible: store it
+            co = zlib.compressobj(0, zlib.DEFLATED, -15)
+            body = co.compress(chunk) + co.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(body) + 25) + body +
+                struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        parts = list(ex.map(member, range(0, len(mv), block)))
+    parts.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00")
+    return b"".join(parts)

@@ -419,6 +419,14 @@ def test_ranks_read_their_own_byte_range(root, data_dir, tmp_path):
     assert ranks(2, st + ["-f", str(fq), "-M", "3", "-N", "4"], {"RKMH_RAW_BLOCK_KB": "300"}) == one(st + ["-f", str(fq), "-M", "3", "-N", "4"])
     assert ranks(3, st + ["-f", str(odd)], {"RKMH_TIMING": "1"}) == one(st + ["-f", str(odd)])
     assert b"refused" in last_err[0]
+    # BGZF: every rank inflates ITS share of the members through the device front end (no rank parses, none inflates the whole file)
+    bg = tmp_path / "r.bgzf.fq.gz"
+    bg.write_bytes(synth.bgzf_compress(text, level=1, block=30000))
+    assert ranks(2, st + ["-f", str(bg)], {"RKMH_TIMING": "1", "RKMH_RAW_BLOCK_KB": "256"}) == want
+    assert last_err[0].count(b"device front end: ") == 2 and b"refused" not in last_err[0]
+    assert ranks(3, st + ["-f", str(bg), "-f", str(fq), "-M", "2"], {"RKMH_RAW_BLOCK_KB": "128"}) == one(st + ["-f", str(fq), "-f", str(fq), "-M", "2"])
+    assert ranks(2, fl + ["-f", str(bg)], {"RKMH_RAW_BLOCK_KB": "512"}) == wf
+    assert ranks(2, st + ["-f", str(bg)], {"RKMH_BGZF": "0"}) == want                # left to zlib: whole parse on every rank
     # rank 0 alone reads the references (here forced through the device: rk_fasta_load_*), the others get names and sketches
     plain_ref = tmp_path / "pave.fa"
     plain_ref.write_bytes(gzip.open(ref).read())
@@ -449,3 +457,59 @@ def test_ranks_read_their_own_byte_range(root, data_dir, tmp_path):
             assert r3.returncode == 0, r3.stderr.decode()[-2000:]
             f.write(b"# trailer\n")
         assert outp.read_bytes() == b"# header\n" + expect + b"# trailer\n", (world, args)
+
+
+def test_cli_bgzf_input_goes_through_the_device_front_end(root, data_dir, tmp_path, orc):
+    """BGZF (bgzip) FASTQ: the front end's workers inflate the members of their jobs themselves (rk_bgzf_*) -- stdout is byte-identical
+    to the plain-text run for stream, stream -M 2 (both passes), filter and filter -M 2, for member sizes from 300 bytes (records span
+    many members) to the full 64 KB, jobs of 40 KB to 16 MB, a last line without newline, and a file that turns irregular half way
+    (handed to the zlib scanner at that job, by its offset in the TEXT).  RKMH_BGZF=0 leaves the file to the scanner: same bytes."""
+    import gzip
+    from rkmh_amd import api, synth
+    refs = api.parse_files([os.path.join(data_dir, "all_pave_ref.fa.gz")])
+    rb, ro = refs["bases"], refs["offsets"]
+    n = 40000
+    qb, qo = synth.generate_reads_fast(rb, ro, 0, n, read_len=150, threads=4)
+    reads = [bytes(qb[int(qo[i]):int(qo[i + 1])]) for i in range(n)]
+    rng = np.random.default_rng(8)
+    for i in range(0, n, 13):
+        reads[i] = reads[i][: int(rng.integers(16, 150))]
+    text = _fastq(reads, names=[b"read%07d comment" % i for i in range(n)])
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(text)
+    ref = os.path.join(data_dir, "all_pave_ref.fa.gz")
+    exe = os.path.join(root, "bin", "rkmh")
+    for cmd, flags in (("stream", []), ("stream", ["-M", "2"]), ("filter", []), ("filter", ["-M", "2", "-N", "3"])):
+        base = [cmd, "-r", ref, "-k", "16", "-s", "1000"] + flags
+        want = _cli(root, base + ["-f", str(fq)])
+        assert len(want) > 1000
+        for member, level, env in ((0xff00, 1, {}), (300, 6, {"RKMH_RAW_BLOCK_KB": "40"}), (20000, 6, {"RKMH_RAW_BLOCK_KB": "128", "RKMH_RAW_WORKERS": "3"})):
+            if cmd == "filter" and member == 300:
+                continue
+            gz = tmp_path / ("reads_%d.fq.gz" % member)
+            if not gz.exists():
+                gz.write_bytes(synth.bgzf_compress(text, level=level, block=member))
+            r = subprocess.run([exe] + base + ["-f", str(gz)], capture_output=True, env=dict(os.environ, RKMH_TIMING="1", **env))
+            assert r.returncode == 0, r.stderr.decode()[-1500:]
+            assert r.stdout == want, (cmd, flags, member)
+            assert b"device front end: " in r.stderr and (b" %d records" % (n * (2 if "-M" in flags else 1))) in r.stderr, r.stderr[-800:]
+        assert _cli(root, base + ["-f", str(tmp_path / "reads_65280.fq.gz")], env={"RKMH_BGZF": "0"}) == want
+    base = ["stream", "-r", ref, "-k", "16", "-s", "1000"]
+    want = _cli(root, base + ["-f", str(fq)])
+    # no final newline; a BGZF file beside a plain one and a plain gzip one
+    nonl = tmp_path / "nonl.fq.gz"
+    nonl.write_bytes(synth.bgzf_compress(text[:-1], level=1))
+    plain_gz = tmp_path / "plain.fq.gz"
+    plain_gz.write_bytes(gzip.compress(text, 1))
+    assert _cli(root, base + ["-f", str(nonl), "-f", str(fq), "-f", str(plain_gz)], env={"RKMH_RAW_BLOCK_KB": "700"}) == want * 3
+    # irregular from the middle on (sequences on two lines): the scanner takes over at that job's first record
+    half = _fastq(reads[: n // 2], names=[b"read%07d comment" % i for i in range(n // 2)])
+    odd = b"".join(b"@m%d\n" % i + r[:70] + b"\n" + r[70:] + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(reads[n // 2: n // 2 + 800]) if len(r) > 80)
+    mixed = tmp_path / "mixed.fq"
+    mixed.write_bytes(half + odd + half)
+    mixed_gz = tmp_path / "mixed.fq.gz"
+    mixed_gz.write_bytes(synth.bgzf_compress(half + odd + half, level=1))
+    want_mixed = _cli(root, base + ["-f", str(mixed)], env={"RKMH_RAW": "0"})
+    r = subprocess.run([exe] + base + ["-f", str(mixed_gz)], capture_output=True, env=dict(os.environ, RKMH_TIMING="1", RKMH_RAW_BLOCK_KB="256"))
+    assert r.returncode == 0 and r.stdout == want_mixed
+    assert b"not four lines per record" in r.stderr
