@@ -122,6 +122,16 @@ def e2e_stream(n, L, rb, ro, synth):
         if None not in t1 and t1[1] > t1[0]:
             res["x4_devnull"] = {"wall_s_1": t1[0], "wall_s_4": t1[1], "marginal_reads_per_s": 3 * n / (t1[1] - t1[0]),
                                  "note": "stdout = /dev/null: the ordered single-writer path a pipe gets"}
+        # --kmer-cache: the enumeration of the 4^k k-mer universe kept between runs (rk_set_kmer_cache): the "references" stage cold and warm
+        kc = os.path.join(tmp, "refs.kmers")
+        extra.append(kc)
+        ref_s = []
+        for _ in range(2):
+            r = subprocess.run([exe, "stream", "-r", ref, "-f", fq, "-k", "16", "-s", "1000", "--kmer-cache", kc], stdout=open(os.devnull, "wb"), stderr=subprocess.PIPE,
+                               env=dict(os.environ, RKMH_TIMING="1"))
+            st_ = [l for l in r.stderr.decode().splitlines() if l.startswith("[rkmh timing] references")]
+            ref_s.append(float(st_[0].split()[-2]) if r.returncode == 0 and st_ else None)
+        res["kmer_cache"] = {"references_s_enumerated": ref_s[0], "references_s_from_cache": ref_s[1], "file_bytes": os.path.getsize(kc) if os.path.exists(kc) else 0}
         # compressed reads (the reference opens every input with gzopen, rkmh.cpp:238-263): the first reads of the file again with
         # qualities that do not compress to nothing, as plain text, as BGZF (bgzip: independent members, inflated by the front end's
         # workers) and as ordinary single-member gzip (one deflate stream: zlib on one thread, the block scanner behind it)

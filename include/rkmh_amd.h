@@ -198,6 +198,14 @@ int rk_kmer_form(const rk_ctx* ctx, uint32_t* kmers_found);
 /* Whether the NEXT rk_set_references / rk_set_reference_sketches may build the k-mer-space form (default 1).  A caller that only
  * uses the general kernels on these references (hpv16's rk_classify_groups_batch) saves the enumeration by passing 0. */
 int rk_set_kmer_form(rk_ctx* ctx, int enable);
+/* The k-mer-space form rests on an enumeration of the whole 4^k k-mer universe (every k-mer whose canonical hash is an index key:
+ * 26 ms at k = 16 on MI355X, 4 x per further base) -- a function of the index keys, k, fold and seed alone.  With a cache file set,
+ * the NEXT rk_set_references / rk_set_reference_sketches loads the lists from it when its tag (a hash of exactly those inputs)
+ * matches and skips the enumeration; otherwise it enumerates and (re)writes the file.  A stale or foreign file is never used.
+ * path NULL or "": no cache.  rk_kmer_cache_state: of the last index build -- 0 none, 1 loaded, 2 enumerated and written, 3
+ * enumerated (the file could not be written). */
+int rk_set_kmer_cache(rk_ctx* ctx, const char* path);
+int rk_kmer_cache_state(const rk_ctx* ctx);
 
 /* Read-depth filter (-M, src/rkmh.cpp:701-704): when set, classify masks hashes whose counter
  * value is below min_kmer_occ (mask_by_frequency, :916) before sketching.  NULL disables.

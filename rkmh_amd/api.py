@@ -97,6 +97,8 @@ _SIGS = {
     "rk_num_references": (C.c_int, [C.c_void_p]),
     "rk_set_depth_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rk_set_min_num_bound": (C.c_int, [C.c_void_p, C.c_int]),
+    "rk_set_kmer_cache": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rk_kmer_cache_state": (C.c_int, [C.c_void_p]),
     "rk_bgzf_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "rk_bgzf_close": (None, [C.c_void_p]),
     "rk_bgzf_members": (C.c_int64, [C.c_void_p]),
@@ -884,6 +886,14 @@ class Context:
     def set_kmer_form(self, enable):
         """Allow (default) or forbid the k-mer-space form for the references set next."""
         _chk(self._lib.rk_set_kmer_form(self._h, 1 if enable else 0))
+
+    def set_kmer_cache(self, path):
+        """File that keeps the k-mer enumeration of the next set_references between runs (rk_set_kmer_cache); None: no cache."""
+        _chk(self._lib.rk_set_kmer_cache(self._h, os.fsencode(path) if path else None))
+
+    def kmer_cache_state(self):
+        """0 none, 1 loaded, 2 enumerated and written, 3 enumerated (file not writable) -- of the last set_references"""
+        return int(self._lib.rk_kmer_cache_state(self._h))
 
     def kmer_form(self):
         """(active, k-mers found by the enumeration): is the k-mer-space form of the fused kernel in use for these references?"""

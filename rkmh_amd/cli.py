@@ -429,6 +429,8 @@ def main_stream(argv, filter_mode=False):
     out = os.fdopen(result_fd, "wb")
     rank, local, world = rdist.init()
     ctx = api.Context(local)
+    if os.environ.get("RKMH_KMER_CACHE"):
+        ctx.set_kmer_cache(os.environ["RKMH_KMER_CACHE"])    # the k-mer enumeration of these references, kept between runs
     compact_ok = False
     if min_occ is not None and not (os.environ.get("RKMH_EXACT_MIN_NUM", "0") not in ("", "0")):
         # -M: the output compares num_mins with -N (stream, rkmh.cpp:938) or with 0 (filter, :1292) and nothing else, so

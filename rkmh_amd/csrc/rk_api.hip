@@ -15,6 +15,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <unordered_map>
 #include <vector>
 
@@ -136,6 +137,10 @@ struct rk_ctx {
     KmerSets ksets{};
     uint32_t kpre_inserted = 0; // k-mers the enumeration found for the k-mer-space structures (diagnostic)
     bool kmer_form_allowed = true; // rk_set_kmer_form
+    // rk_set_kmer_cache: the enumeration of the 4^k k-mer universe behind the k-mer-space structures (k_enum_kmers: 26 ms at k = 16,
+    // 0.4 s at k = 18) is a function of (the index keys, k, fold, seed) alone -- kept in this file between runs
+    std::string kmer_cache_path;
+    int kmer_cache_state = 0; // of the last index build: 0 no file given, 1 loaded, 2 enumerated and written, 3 enumerated (the file could not be written)
     RefIndex ix{};
     bool have_refs = false;
     double density = 1.0; // fraction of a reference's k-mers that its sketch keeps (largest over references)
@@ -1264,6 +1269,52 @@ static void build_kpost(const std::vector<uint32_t>& post, int R, std::vector<ui
     for (auto& o : owner) { KList kl; kl.enc = dl[o.second].enc; kl.plain = dl[o.second].plain; kl.ix = dl[o.second].ix; kl.iy = dl[o.second].iy; kl.iw = dl[o.second].iw; remap[o.first] = kl; }
 }
 
+// ---- the k-mer enumeration cache (rk_set_kmer_cache) ----
+// File: "RKKM1\n", u64 tag, u32 entries, then per entry {u32 k, u32 found, found x (u32 k-mer, u32 key id)}.  The tag is a hash of
+// everything the lists depend on: every index key in key-id order, the number of keys, fold and seed.  Any other file is ignored
+// (and overwritten after the enumeration has run): a cache never changes results, it only skips the work that would reproduce it.
+static uint64_t kmer_cache_tag(const rk_ctx* c, const std::vector<uint32_t>& dense, size_t nkeys) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&](uint64_t v) { h ^= v; h *= 0x100000001b3ull; h ^= h >> 29; };
+    mix(0x726b6b6d31ull); mix((uint64_t)nkeys); mix((uint64_t)(uint32_t)c->pol.fold); mix((uint64_t)c->pol.seed);
+    for (size_t q = 0; q < nkeys; ++q) mix(((uint64_t)dense[q * 4 + 1] << 32) | dense[q * 4]);
+    return h;
+}
+static bool kmer_cache_read(const std::string& path, uint64_t tag, std::map<int, std::vector<uint32_t>>& lists) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[6];
+    uint64_t ftag = 0;
+    uint32_t n = 0;
+    bool ok = fread(magic, 1, 6, f) == 6 && memcmp(magic, "RKKM1\n", 6) == 0 && fread(&ftag, 8, 1, f) == 1 && fread(&n, 4, 1, f) == 1 && ftag == tag && n <= 64;
+    for (uint32_t i = 0; ok && i < n; ++i) {
+        uint32_t k = 0, found = 0;
+        ok = fread(&k, 4, 1, f) == 1 && fread(&found, 4, 1, f) == 1 && k >= 1 && k <= 16 && found <= 0x3fffffffu;
+        if (!ok) break;
+        std::vector<uint32_t> l((size_t)found * 2);
+        ok = l.empty() || fread(l.data(), 4, l.size(), f) == l.size();
+        if (ok) lists[(int)k] = std::move(l);
+    }
+    fclose(f);
+    if (!ok) lists.clear();
+    return ok;
+}
+static bool kmer_cache_write(const std::string& path, uint64_t tag, const std::map<int, std::vector<uint32_t>>& lists) {
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const uint32_t n = (uint32_t)lists.size();
+    bool ok = fwrite("RKKM1\n", 1, 6, f) == 6 && fwrite(&tag, 8, 1, f) == 1 && fwrite(&n, 4, 1, f) == 1;
+    for (auto& kv : lists) {
+        const uint32_t k = (uint32_t)kv.first, found = (uint32_t)(kv.second.size() / 2);
+        ok = ok && fwrite(&k, 4, 1, f) == 1 && fwrite(&found, 4, 1, f) == 1 && (kv.second.empty() || fwrite(kv.second.data(), 4, kv.second.size(), f) == kv.second.size());
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0; // (atomic: a concurrent reader sees the old file or the new one)
+    if (!ok) remove(tmp.c_str());
+    return ok;
+}
+
 static int build_key_mask(rk_ctx* c);
 static int build_index(rk_ctx* c) {
     struct Pair { uint64_t h; uint32_t ref; };
@@ -1405,6 +1456,14 @@ static int build_index(rk_ctx* c) {
             c->ix.kpost = c->d_kpost.as<uint32_t>(); c->ix.kbase = c->d_kbase.as<uint32_t>();
         }
     }
+    std::map<int, std::vector<uint32_t>> kcache;
+    bool kcache_dirty = false;
+    uint64_t kcache_tag = 0;
+    c->kmer_cache_state = 0;
+    if (all_k_ok && !c->kmer_cache_path.empty()) {
+        kcache_tag = kmer_cache_tag(c, dense, nkeys);
+        if (kmer_cache_read(c->kmer_cache_path, kcache_tag, kcache)) c->kmer_cache_state = 1;
+    }
     std::vector<uint8_t> seen(all_k_ok ? nkeys + 1 : 0, 0); // across the sizes: a key found by two k-mers of ANY sizes disables the form
     int built = 0;
     for (int kidx = 0; all_k_ok && kidx < c->ks.n; ++kidx) {
@@ -1414,16 +1473,32 @@ static int build_index(rk_ctx* c) {
         const uint32_t list_cap = (uint32_t)std::min<size_t>(2 * distinct + 4096, 0x3fffffffu);
         DevBuf d_list, d_stats;
         struct Release { DevBuf& a; DevBuf& b; ~Release() { a.release(); b.release(); } } release_list{d_list, d_stats}; // freed on every path out
-        RKCHK(d_list.reserve((size_t)list_cap * 8));
-        RKCHK(d_stats.reserve(16));
-        HIPCHK(hipMemsetAsync(d_stats.p, 0, 16, c->st));
-        hipError_t le = launch_enum_kmers(c->ix, c->pol, k, d_stats.as<uint32_t>(), d_list.as<uint2>(), list_cap, c->st);
         uint32_t found = 0;
-        if (le == hipSuccess) le = hipMemcpyAsync(&found, d_stats.p, 4, hipMemcpyDeviceToHost, c->st);
-        if (le == hipSuccess) le = hipStreamSynchronize(c->st);
-        std::vector<uint32_t> list((size_t)std::min<uint32_t>(found, list_cap) * 2);
-        if (le == hipSuccess && !list.empty()) le = hipMemcpy(list.data(), d_list.p, list.size() * 4, hipMemcpyDeviceToHost);
-        if (le != hipSuccess) return fail(RK_ERR_HIP, "k-mer enumeration: %s", hipGetErrorString(le));
+        std::vector<uint32_t> list;
+        auto cached = kcache.find(k);
+        if (cached != kcache.end()) { // the enumeration of an earlier run with these keys, this k and this hashing policy
+            list = cached->second;
+            found = (uint32_t)(list.size() / 2);
+        } else {
+            RKCHK(d_list.reserve((size_t)list_cap * 8));
+            RKCHK(d_stats.reserve(16));
+            HIPCHK(hipMemsetAsync(d_stats.p, 0, 16, c->st));
+            hipError_t le = launch_enum_kmers(c->ix, c->pol, k, d_stats.as<uint32_t>(), d_list.as<uint2>(), list_cap, c->st);
+            if (le == hipSuccess) le = hipMemcpyAsync(&found, d_stats.p, 4, hipMemcpyDeviceToHost, c->st);
+            if (le == hipSuccess) le = hipStreamSynchronize(c->st);
+            list.resize((size_t)std::min<uint32_t>(found, list_cap) * 2);
+            if (le == hipSuccess && !list.empty()) le = hipMemcpy(list.data(), d_list.p, list.size() * 4, hipMemcpyDeviceToHost);
+            if (le != hipSuccess) return fail(RK_ERR_HIP, "k-mer enumeration: %s", hipGetErrorString(le));
+            if (found <= list_cap && !c->kmer_cache_path.empty()) {
+                // (key id order inside the list does not matter, but the device appends in a racy order: sorted, the file is reproducible)
+                std::vector<uint64_t> pairs((size_t)found);
+                for (uint32_t i = 0; i < found; ++i) pairs[i] = ((uint64_t)list[2 * (size_t)i] << 32) | list[2 * (size_t)i + 1];
+                std::sort(pairs.begin(), pairs.end());
+                for (uint32_t i = 0; i < found; ++i) { list[2 * (size_t)i] = (uint32_t)(pairs[i] >> 32); list[2 * (size_t)i + 1] = (uint32_t)pairs[i]; }
+                kcache[k] = list;
+                kcache_dirty = true;
+            }
+        }
         c->kpre_inserted += found;
         // Built only when every key has exactly one preimage (found == keys + zero-hash k-mers with no two entries sharing a key id):
         // the k-mer then identifies the key in the per-read hit multiset.  Anything else leaves the hash-space kernels in charge.
@@ -1576,6 +1651,7 @@ static int build_index(rk_ctx* c) {
         }
         if (!ok) break; // one size without its structures: the hash-space kernels serve the run
     }
+    if (kcache_dirty) c->kmer_cache_state = kmer_cache_write(c->kmer_cache_path, kcache_tag, kcache) ? 2 : 3;
     if (built == c->ks.n && built > 0) { // every size has its filter and map
         c->ksets.n = built;
         c->ix.kf4 = c->ksets.kf4[0]; c->ix.kf4_n = c->ksets.kf4_n[0]; c->ix.km1 = c->ksets.km1[0]; c->ix.km1_b = c->ksets.km1_b[0];
@@ -1659,6 +1735,12 @@ extern "C" int rk_set_kmer_form(rk_ctx* c, int enable) {
     c->kmer_form_allowed = enable != 0;
     return RK_OK;
 }
+extern "C" int rk_set_kmer_cache(rk_ctx* c, const char* path) {
+    if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
+    c->kmer_cache_path = path ? path : "";
+    return RK_OK;
+}
+extern "C" int rk_kmer_cache_state(const rk_ctx* c) { return c ? c->kmer_cache_state : 0; }
 extern "C" int rk_kmer_form(const rk_ctx* c, uint32_t* kmers_found) {
     if (!c) return fail(RK_ERR_ARG, "ctx is NULL");
     if (!c->have_refs) return fail(RK_ERR_STATE, "no references set");

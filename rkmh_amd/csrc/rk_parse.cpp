@@ -27,6 +27,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -180,12 +181,13 @@ struct Piece {
 // Compressed input (one deflate stream: only a sequential reader can follow it, src/rkmh.cpp:238-263): zlib inflates on its OWN
 // thread, a few 8 MB pieces ahead, while the block scanner's threads parse what has arrived.
 struct AsyncGz {
+    struct Piece { std::unique_ptr<unsigned char[]> p; size_t n = 0; }; // (not a vector: no zero fill of megabytes that gzread overwrites)
     std::thread th;
     std::mutex m;
     std::condition_variable cv;
-    std::deque<std::vector<unsigned char>> q;
+    std::deque<Piece> q;
     bool done = false, stop = false;
-    std::vector<unsigned char> cur;
+    Piece cur;
     size_t cur_pos = 0;
 };
 
@@ -199,15 +201,18 @@ struct rk_reader {
         if (!az) {
             az = new AsyncGz();
             az->th = std::thread([this] {
+                size_t want_n = (size_t)256 << 10; // the first pieces are small (a reference panel of a megabyte is one of them), later ones 8 MB
                 for (;;) {
-                    std::vector<unsigned char> piece((size_t)8 << 20);
-                    const int r = gzread(fp, piece.data(), (unsigned)piece.size());
-                    piece.resize(r > 0 ? (size_t)r : 0);
+                    AsyncGz::Piece piece;
+                    piece.p.reset(new unsigned char[want_n]);
+                    const int r = gzread(fp, piece.p.get(), (unsigned)want_n);
+                    piece.n = r > 0 ? (size_t)r : 0;
+                    const bool last = piece.n < want_n;
+                    if (want_n < ((size_t)8 << 20)) want_n *= 4;
                     std::unique_lock<std::mutex> l(az->m);
                     az->cv.wait(l, [&] { return az->q.size() < 6 || az->stop; });
                     if (az->stop) return;
-                    const bool last = piece.size() < ((size_t)8 << 20);
-                    if (!piece.empty()) az->q.push_back(std::move(piece));
+                    if (piece.n) az->q.push_back(std::move(piece));
                     if (last) az->done = true;
                     az->cv.notify_all();
                     if (last) return;
@@ -216,7 +221,7 @@ struct rk_reader {
         }
         size_t got = 0;
         while (got < want) {
-            if (az->cur_pos == az->cur.size()) {
+            if (az->cur_pos == az->cur.n) {
                 std::unique_lock<std::mutex> l(az->m);
                 az->cv.wait(l, [&] { return !az->q.empty() || az->done; });
                 if (az->q.empty()) break; // end of input
@@ -225,8 +230,8 @@ struct rk_reader {
                 az->cur_pos = 0;
                 az->cv.notify_all();
             }
-            const size_t n = std::min(want - got, az->cur.size() - az->cur_pos);
-            memcpy(dst + got, az->cur.data() + az->cur_pos, n);
+            const size_t n = std::min(want - got, az->cur.n - az->cur_pos);
+            memcpy(dst + got, az->cur.p.get() + az->cur_pos, n);
             az->cur_pos += n; got += n;
         }
         return got;
@@ -867,6 +872,10 @@ static int reader_open_at(const char* path, uint64_t offset, rk_reader** out) {
         // compressed: the inflater gets its own thread, and the block-parallel scanner parses what it delivers (RKMH_GZ_BLOCKS=0: the
         // sequential scanner on the calling thread, as before round 5)
         r->compressed = !plain && !(getenv("RKMH_GZ_BLOCKS") && atoi(getenv("RKMH_GZ_BLOCKS")) == 0);
+        if (r->compressed && strcmp(path, "-") != 0) { // a small file (a reference panel) is done before a thread and a block would be set up
+            struct stat zst;
+            if (stat(path, &zst) == 0 && zst.st_size < ((off_t)8 << 20) && !(getenv("RKMH_GZ_BLOCKS") && atoi(getenv("RKMH_GZ_BLOCKS")) == 2)) r->compressed = false;
+        }
         if (r->compressed) plain = true;
         if (offset && gzseek(fp, (z_off_t)offset, SEEK_SET) < 0) { gzclose(fp); delete r; return perr(RK_ERR_IO, std::string("cannot seek in ") + path); }
     }

@@ -90,6 +90,7 @@ static void help_stream() {
             "  -p/-q/-F <file>, -S <n>, -i, -z, -m   parsed and ignored, as in the reference\n"
             "  -R <sketches.json>      reference sketches written by `rkmh sketch` instead of -r\n"
             "  --depth-map-cache <file>  (with -M) save the read-depth map of this run, or reuse the file if it was saved\n"
+            "  --kmer-cache <file>       keep the k-mer enumeration of these references (k <= 16) in <file>; reused while references, k and hashing match\n"
             "                          from the same reads, k-mer sizes and hashing policy (anything else is refused)\n"
             "  --device <id>           GPU to use (default 0)\n"
             "  --devices <a,b,..|all>  spread the reads over several GPUs of this node (stream, filter): one host thread and one\n"
@@ -106,6 +107,7 @@ struct Opts {
     std::vector<const char*> refs, reads;
     std::vector<int> ks;
     int sketch = 1000, threads = 1, min_occ = -1, min_matches = -1, min_diff = 0, max_samples = 100000;
+    const char* kmer_cache = getenv("RKMH_KMER_CACHE"); // --kmer-cache FILE: the k-mer enumeration of these references, kept between runs (rk_set_kmer_cache)
     bool read_depth = false, ref_depth = false;
     int device = 0;
     std::vector<int> devices; // --devices a,b,...: reads are spread over these GPUs (one host thread + rk_ctx each); empty = --device
@@ -258,6 +260,7 @@ struct DeviceGroup {
             th.emplace_back([&, i] { if (rk_ctx_create(ids[i], nullptr, &ctx[i]) != RK_OK) err[i] = rk_last_error(); });
         for (auto& t : th) t.join();
         for (auto& e : err) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
+        if (o.kmer_cache && *o.kmer_cache) for (rk_ctx* cx : ctx) CK(rk_set_kmer_cache(cx, o.kmer_cache));
     }
     // after the references were set on ctx[0]: the same sketches on every other context
     void share_references(const Opts& o) {
@@ -974,7 +977,7 @@ static int main_stream(int argc, char** argv) {
         {"pre-references", required_argument, 0, 'R'}, {"read-kmer-map-file", required_argument, 0, 'p'},
         {"ref-kmer-map-file", required_argument, 0, 'q'}, {"in-stream", no_argument, 0, 'i'},
         {"output-reads", no_argument, 0, 'z'},   {"merge-sketch", no_argument, 0, 'm'},
-        {"device", required_argument, 0, 1000},  {"depth-map-cache", required_argument, 0, 1001},
+        {"device", required_argument, 0, 1000},  {"depth-map-cache", required_argument, 0, 1001}, {"kmer-cache", required_argument, 0, 1003},
         {"devices", required_argument, 0, 1002}, {0, 0, 0, 0}};
     optind = 2;
     int c;
@@ -986,6 +989,7 @@ static int main_stream(int argc, char** argv) {
             // so do we -- no file is read or written.  The reusable depth map is this build's own, explicit option below.
             case 'F': case 'p': case 'q': case 'S': break; // parsed, bodies empty in the reference (:659-670,:697-700)
             case 1001: read_map = optarg; break;              // --depth-map-cache FILE (not a reference flag): see the -M block
+            case 1003: o.kmer_cache = optarg; break;          // --kmer-cache FILE (not a reference flag): rk_set_kmer_cache
             case 't': o.threads = atoi(optarg); break;
             case 'r': o.refs.push_back(optarg); break;
             case 'f': o.reads.push_back(optarg); break;
@@ -1170,11 +1174,12 @@ static int main_filter(int argc, char** argv) {
         {"max-samples", required_argument, 0, 'I'}, {"pre-reads", required_argument, 0, 'F'},
         {"pre-references", required_argument, 0, 'R'}, {"read-kmer-map-file", required_argument, 0, 'p'},
         {"ref-kmer-map-file", required_argument, 0, 'q'}, {"in-stream", no_argument, 0, 'i'},
-        {"device", required_argument, 0, 1000}, {"devices", required_argument, 0, 1002}, {0, 0, 0, 0}};
+        {"device", required_argument, 0, 1000}, {"devices", required_argument, 0, 1002}, {"kmer-cache", required_argument, 0, 1003}, {0, 0, 0, 0}};
     optind = 2;
     int c;
     while ((c = getopt_long(argc, argv, "hdk:f:r:s:S:t:M:N:I:R:F:p:q:iD:", long_options, nullptr)) != -1) {
         switch (c) {
+            case 1003: o.kmer_cache = optarg; break;
             case 'F': case 'R': case 'p': case 'q': case 'S': break; // parsed, bodies empty (rkmh.cpp:1139-1151)
             case 't': o.threads = atoi(optarg); break;
             case 'r': o.refs.push_back(optarg); break;
