@@ -497,7 +497,25 @@ def config_legs(rkmh_amd, api, synth, dev, n, L, check):
         ctx.set_depth_filter(None, 0)
         cnt.destroy()
         ctx.set_min_num_bound(-1)
-        legs["c4_filter"] = {"references": pave["nseq"], "k": 20, "sketch_size": 2000, "reads": n, "kernel_ms": ms, "reads_per_s": n / ms * 1e3,
+        # the same batch on the k-mer-space kernel (wide k-mers, k = 17 .. 20): needs the 4^20 k-mer universe enumerated once per reference
+        # set (seconds: done unasked only up to k = 18, RKMH_KMER_ENUM_MAXK; a --kmer-cache file keeps it between runs)
+        wide = {}
+        try:
+            os.environ["RKMH_KMER_ENUM_MAXK"] = "20"
+            cw = rkmh_amd.Context(dev.index)
+            t_en = time.perf_counter()
+            cw.set_references(rb, ro, [20], 2000)
+            t_en = time.perf_counter() - t_en
+            if cw.kmer_form()[0]:
+                d_out2 = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+                wms = kernel_ms(cw, d_b, d_o, d_out2, stream)
+                if not bool((d_out2 == d_out).all().item()):
+                    raise SystemExit("c4_filter: the k-mer-space kernel (wide k-mers) and the hash-space kernel disagree")
+                wide = {"kmer_space_kernel_ms": wms, "kmer_space_reads_per_s": n / wms * 1e3, "kmer_space_set_references_s": t_en}
+            cw.close()
+        finally:
+            os.environ.pop("RKMH_KMER_ENUM_MAXK", None)
+        legs["c4_filter"] = {"references": pave["nseq"], "k": 20, "sketch_size": 2000, "reads": n, "kernel_ms": ms, "reads_per_s": n / ms * 1e3, **wide,
                              "M2_slots": slots, "M2_count_pass_ms": count_ms, "M2_masked_classify_ms": masked_ms, "M2_min_num_bound": 0,
                              "M2_count_pass_full_table_ms": count_full_ms, "M2_masked_classify_exact_min_num_ms": masked_exact_ms,
                              "oracle_checked_ref_sketches": int(pave["nseq"]) if check else 0,

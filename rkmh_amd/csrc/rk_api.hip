@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -132,7 +133,7 @@ struct rk_ctx {
     KsArr ks{};
     std::vector<uint64_t> h_sk;
     std::vector<int32_t> h_lens;
-    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_keepbits, d_kpost, d_kbase;
+    DevBuf d_fpb, d_base, d_kv, d_post, d_pre, d_keepbits, d_kpost, d_kbase, d_kkeys, d_kslots;
     DevBuf d_kf4[KM_MAX_KS], d_km1[KM_MAX_KS], d_km1v[KM_MAX_KS]; // k-mer-space structures, one set per k-mer size
     KmerSets ksets{};
     uint32_t kpre_inserted = 0; // k-mers the enumeration found for the k-mer-space structures (diagnostic)
@@ -205,7 +206,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipDeviceSynchronize(); (void)e;
-    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_keepbits, &c->d_kpost, &c->d_kbase, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
+    for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_keepbits, &c->d_kpost, &c->d_kbase, &c->d_kkeys, &c->d_kslots, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount, &c->w_tail}) b->release();
     for (int j = 0; j < KM_MAX_KS; ++j) { c->d_kf4[j].release(); c->d_km1[j].release(); c->d_km1v[j].release(); c->d_km1m[j].release(); c->d_km1cells[j].release(); }
     c->d_keepkey.release();
@@ -1289,9 +1290,9 @@ static bool kmer_cache_read(const std::string& path, uint64_t tag, std::map<int,
     bool ok = fread(magic, 1, 6, f) == 6 && memcmp(magic, "RKKM1\n", 6) == 0 && fread(&ftag, 8, 1, f) == 1 && fread(&n, 4, 1, f) == 1 && ftag == tag && n <= 64;
     for (uint32_t i = 0; ok && i < n; ++i) {
         uint32_t k = 0, found = 0;
-        ok = fread(&k, 4, 1, f) == 1 && fread(&found, 4, 1, f) == 1 && k >= 1 && k <= 16 && found <= 0x3fffffffu;
+        ok = fread(&k, 4, 1, f) == 1 && fread(&found, 4, 1, f) == 1 && k >= 1 && k <= (uint32_t)KW_MAX_K && found <= 0x3fffffffu;
         if (!ok) break;
-        std::vector<uint32_t> l((size_t)found * 2);
+        std::vector<uint32_t> l((size_t)found * (k > 16 ? 3 : 2)); // (k-mer, key id) -- a wide k-mer takes two words
         ok = l.empty() || fread(l.data(), 4, l.size(), f) == l.size();
         if (ok) lists[(int)k] = std::move(l);
     }
@@ -1306,7 +1307,8 @@ static bool kmer_cache_write(const std::string& path, uint64_t tag, const std::m
     const uint32_t n = (uint32_t)lists.size();
     bool ok = fwrite("RKKM1\n", 1, 6, f) == 6 && fwrite(&tag, 8, 1, f) == 1 && fwrite(&n, 4, 1, f) == 1;
     for (auto& kv : lists) {
-        const uint32_t k = (uint32_t)kv.first, found = (uint32_t)(kv.second.size() / 2);
+        const uint32_t k = (uint32_t)kv.first;
+        const uint32_t found = (uint32_t)(kv.second.size() / (k > 16 ? 3 : 2));
         ok = ok && fwrite(&k, 4, 1, f) == 1 && fwrite(&found, 4, 1, f) == 1 && (kv.second.empty() || fwrite(kv.second.data(), 4, kv.second.size(), f) == kv.second.size());
     }
     ok = (fclose(f) == 0) && ok;
@@ -1316,7 +1318,19 @@ static bool kmer_cache_write(const std::string& path, uint64_t tag, const std::m
 }
 
 static int build_key_mask(rk_ctx* c);
+// RKMH_INDEX_TIMING=1: where the time of an index build goes (stderr)
+struct IndexClock {
+    bool on = getenv("RKMH_INDEX_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void tick(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rkmh index] %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 static int build_index(rk_ctx* c) {
+    IndexClock clk;
     struct Pair { uint64_t h; uint32_t ref; };
     const int R = c->nref, S = c->S;
     if (R > 0xFFFFF) return fail(RK_ERR_LIMIT, "more than 2^20-1 references");
@@ -1327,6 +1341,7 @@ static int build_index(rk_ctx* c) {
             if (h != 0) pairs.push_back(Pair{h, (uint32_t)r});
         }
     std::sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) { return a.h != b.h ? a.h < b.h : a.ref < b.ref; });
+    clk.tick("pairs sorted");
     size_t distinct = 0;
     for (size_t i = 0; i < pairs.size(); ++i) if (i == 0 || pairs[i].h != pairs[i - 1].h) ++distinct;
     // bucketed table: 8 slots per bucket, at most 2.5 keys per bucket on average (P(more than 8) ~ 0.1 %)
@@ -1381,6 +1396,7 @@ static int build_index(rk_ctx* c) {
         }
         i = j;
     }
+    clk.tick("bucket table");
     RKCHK(c->d_fpb.reserve((size_t)size * 2));
     // compact the key/value entries: key id = (keys stored in earlier buckets) + position in the bucket
     std::vector<uint32_t> base((size_t)nb + 1, 0);
@@ -1440,11 +1456,17 @@ static int build_index(rk_ctx* c) {
     static const long kmer_max_keys_env = getenv("RKMH_KPRE_MAXKEYS") ? atol(getenv("RKMH_KPRE_MAXKEYS")) : -1;
     const size_t kmer_max_keys = kmer_max_keys_env >= 0 ? (size_t)kmer_max_keys_env : 6000000;
     bool all_k_ok = kmer_mode > 0 && c->kmer_form_allowed && c->ks.n >= 1 && c->ks.n <= KM_MAX_KS && distinct <= kmer_max_keys;
-    for (int j = 0; j < c->ks.n; ++j) all_k_ok = all_k_ok && c->ks.k[j] >= KPRE_MIN_K && c->ks.k[j] <= 16;
+    // one k of 17 .. 20 (wide k-mers, 64-bit): the 4^k enumeration takes 0.1 s (k = 17), 0.4 s (18), 1.7 s (19), 6.7 s (20) -- done unasked
+    // up to RKMH_KMER_ENUM_MAXK (default 18); beyond that only when the cache file (rk_set_kmer_cache) already holds the list
+    const int enum_maxk = getenv("RKMH_KMER_ENUM_MAXK") ? atoi(getenv("RKMH_KMER_ENUM_MAXK")) : 18; // (read per build: a few per process)
+    const bool wide_k = c->ks.n == 1 && c->ks.k[0] > 16 && c->ks.k[0] <= KW_MAX_K;
+    for (int j = 0; j < c->ks.n; ++j) all_k_ok = all_k_ok && c->ks.k[j] >= KPRE_MIN_K && (c->ks.k[j] <= 16 || wide_k);
+    if (wide_k && distinct >= (size_t)KW_EMPTY - 16) all_k_ok = false; // (key numbers of the wide map are 20 bits)
     for (int j = 0; j + 1 < c->ks.n; ++j) for (int i = j + 1; i < c->ks.n; ++i) all_k_ok = all_k_ok && c->ks.k[j] != c->ks.k[i]; // a size given twice hashes twice: hash-space path
+    clk.tick("index + prefilter uploaded");
     std::vector<uint32_t> kpost, kbase;
     std::unordered_map<uint32_t, KList> kremap;
-    c->ix.kpost = nullptr; c->ix.kbase = nullptr;
+    c->ix.kpost = nullptr; c->ix.kbase = nullptr; c->ix.kkeys = nullptr; c->ix.kslots = nullptr;
     if (all_k_ok) {
         build_kpost(post, R, kpost, kbase, kremap);
         if (kpost.size() >= 0x3fffffffull) all_k_ok = false;
@@ -1456,6 +1478,7 @@ static int build_index(rk_ctx* c) {
             c->ix.kpost = c->d_kpost.as<uint32_t>(); c->ix.kbase = c->d_kbase.as<uint32_t>();
         }
     }
+    clk.tick("posting lists (kpost)");
     std::map<int, std::vector<uint32_t>> kcache;
     bool kcache_dirty = false;
     uint64_t kcache_tag = 0;
@@ -1464,6 +1487,7 @@ static int build_index(rk_ctx* c) {
         kcache_tag = kmer_cache_tag(c, dense, nkeys);
         if (kmer_cache_read(c->kmer_cache_path, kcache_tag, kcache)) c->kmer_cache_state = 1;
     }
+    if (all_k_ok && wide_k && c->ks.k[0] > enum_maxk && kcache.find(c->ks.k[0]) == kcache.end()) all_k_ok = false; // too long to do unasked
     std::vector<uint8_t> seen(all_k_ok ? nkeys + 1 : 0, 0); // across the sizes: a key found by two k-mers of ANY sizes disables the form
     int built = 0;
     for (int kidx = 0; all_k_ok && kidx < c->ks.n; ++kidx) {
@@ -1476,41 +1500,161 @@ static int build_index(rk_ctx* c) {
         uint32_t found = 0;
         std::vector<uint32_t> list;
         auto cached = kcache.find(k);
+        const size_t lw = k > 16 ? 3 : 2; // words per list item on the host: (k-mer [low, high], key id)
         if (cached != kcache.end()) { // the enumeration of an earlier run with these keys, this k and this hashing policy
             list = cached->second;
-            found = (uint32_t)(list.size() / 2);
+            found = (uint32_t)(list.size() / lw);
         } else {
-            RKCHK(d_list.reserve((size_t)list_cap * 8));
+            RKCHK(d_list.reserve((size_t)list_cap * (k > 16 ? 16 : 8)));
             RKCHK(d_stats.reserve(16));
             HIPCHK(hipMemsetAsync(d_stats.p, 0, 16, c->st));
             hipError_t le = launch_enum_kmers(c->ix, c->pol, k, d_stats.as<uint32_t>(), d_list.as<uint2>(), list_cap, c->st);
             if (le == hipSuccess) le = hipMemcpyAsync(&found, d_stats.p, 4, hipMemcpyDeviceToHost, c->st);
             if (le == hipSuccess) le = hipStreamSynchronize(c->st);
-            list.resize((size_t)std::min<uint32_t>(found, list_cap) * 2);
-            if (le == hipSuccess && !list.empty()) le = hipMemcpy(list.data(), d_list.p, list.size() * 4, hipMemcpyDeviceToHost);
+            const size_t got = std::min<uint32_t>(found, list_cap);
+            std::vector<uint32_t> raw(got * (k > 16 ? 4 : 2));
+            if (le == hipSuccess && !raw.empty()) le = hipMemcpy(raw.data(), d_list.p, raw.size() * 4, hipMemcpyDeviceToHost);
             if (le != hipSuccess) return fail(RK_ERR_HIP, "k-mer enumeration: %s", hipGetErrorString(le));
-            if (found <= list_cap && !c->kmer_cache_path.empty()) {
-                // (key id order inside the list does not matter, but the device appends in a racy order: sorted, the file is reproducible)
-                std::vector<uint64_t> pairs((size_t)found);
-                for (uint32_t i = 0; i < found; ++i) pairs[i] = ((uint64_t)list[2 * (size_t)i] << 32) | list[2 * (size_t)i + 1];
-                std::sort(pairs.begin(), pairs.end());
-                for (uint32_t i = 0; i < found; ++i) { list[2 * (size_t)i] = (uint32_t)(pairs[i] >> 32); list[2 * (size_t)i + 1] = (uint32_t)pairs[i]; }
-                kcache[k] = list;
-                kcache_dirty = true;
+            // (the device appends in a racy order: sorted by k-mer, the list -- and the cache file -- is reproducible)
+            std::vector<std::pair<uint64_t, uint32_t>> items(got);
+            for (size_t i = 0; i < got; ++i)
+                items[i] = k > 16 ? std::make_pair(((uint64_t)raw[4 * i + 1] << 32) | raw[4 * i], raw[4 * i + 2]) : std::make_pair((uint64_t)raw[2 * i], raw[2 * i + 1]);
+            std::sort(items.begin(), items.end());
+            list.resize(got * lw);
+            for (size_t i = 0; i < got; ++i) {
+                list[lw * i] = (uint32_t)items[i].first;
+                if (k > 16) list[lw * i + 1] = (uint32_t)(items[i].first >> 32);
+                list[lw * i + lw - 1] = items[i].second;
             }
+            if (found <= list_cap && !c->kmer_cache_path.empty()) { kcache[k] = list; kcache_dirty = true; }
         }
         c->kpre_inserted += found;
         // Built only when every key has exactly one preimage (found == keys + zero-hash k-mers with no two entries sharing a key id):
         // the k-mer then identifies the key in the per-read hit multiset.  Anything else leaves the hash-space kernels in charge.
         bool ok = found <= list_cap;
         if (getenv("RKMH_KMAP_FORCE_DUP")) ok = false; // tests: behave as if two k-mers shared a key (nothing is built)
+        clk.tick(cached != kcache.end() ? "k-mer lists from the cache" : "k-mer enumeration");
         if (ok) {
             for (uint32_t i = 0; ok && i < found; ++i) {
-                const uint32_t slot = list[2 * (size_t)i + 1];
+                const uint32_t slot = list[lw * (size_t)i + lw - 1];
                 if (slot == IDX_NOT_FOUND) continue;
                 if (slot >= nkeys || seen[slot]) ok = false; // two different k-mers with the same 64-bit canonical hash
                 else seen[slot] = 1;
             }
+        }
+        // value id of an index key for the k-mer-space kernels: the reference itself (one posting, once) or nref + the number of a
+        // compound value of four dwords in `vals` (km1_vals) -- shared by the narrow and the wide form
+        std::vector<uint32_t> vals;
+        std::unordered_map<uint32_t, uint32_t> val_id;
+        auto value_id_of = [&](uint32_t slot) -> uint32_t {
+            const uint32_t val = dense[(size_t)slot * 4 + 2];
+            if (!(val >> 31) && ((val >> 29) & 3u) == 0u && ((val >> 20) & 0x1FFu) == 1u) return val & 0xFFFFFu; // one posting, once: the reference
+            // lists: identical ones share one compound value (and one copy in kpost, see build_kpost)
+            uint32_t vkey = val;
+            KList kl;
+            if (val >> 31) { kl = kremap.at(val & 0x7fffffffu); vkey = 0x80000000u | kl.plain; }
+            auto it = val_id.find(vkey);
+            if (it == val_id.end()) {
+                it = val_id.emplace(vkey, (uint32_t)(R + vals.size() / 4)).first;
+                // four dwords per entry: the index value and, for a list of three to six references that each hold the hash
+                // once (what related types of one panel share), the list itself, nine bits per reference -- the kernel then
+                // counts it in the lane that found the hit instead of fetching the posting list from global memory (KM1V_INLINE)
+                uint32_t x = val, y = 0;
+                if (RK_KMER_INLINE_N && (val >> 31)) {
+                    const uint32_t off = val & 0x7fffffffu, n = post[off];
+                    bool ok3 = n >= 3 && n <= 6;
+                    for (uint32_t q = 0; ok3 && q < n; ++q) ok3 = post[off + 1 + 2 * q] < 512u && post[off + 2 + 2 * q] == 1u;
+                    if (ok3) {
+                        uint32_t r[6] = {0, 0, 0, 0, 0, 0};
+                        for (uint32_t q = 0; q < n; ++q) r[q] = post[off + 1 + 2 * q];
+                        x = 0xC0000000u | ((n - 3u) << 27) | r[0] | (r[1] << 9) | (r[2] << 18);
+                        y = r[3] | (r[4] << 9) | (r[5] << 18);
+                    }
+                }
+                // a list that stays a list: x = the form the dense-counter kernels walk (plain, or base + exceptions) -- or, within eight
+                // exceptions of its base, x, y and w hold base and exceptions themselves -- and z = the plain form (sparse counters)
+                uint32_t z = 0, w = 0;
+                if ((x >> 30) == 2u) {
+                    z = kl.plain;
+                    if (kl.ix) { x = kl.ix; y = kl.iy; w = kl.iw; } else x = 0x80000000u | kl.enc;
+                }
+                vals.push_back(x); vals.push_back(y); vals.push_back(z); vals.push_back(w);
+            }
+            return it->second;
+        };
+        if (ok && k > 16) {
+            // ---- wide k-mers: the same group filter (sector and bits from kw_fold of core and k-mer), the km2 map and kkeys ----
+            std::vector<uint64_t> km(found);
+            for (uint32_t i = 0; i < found; ++i) km[i] = ((uint64_t)list[3 * (size_t)i + 1] << 32) | list[3 * (size_t)i];
+            const double want = (double)found * 8.0 / (found > 300000u ? 18.0 : 13.0);
+            const uint32_t nsect = want < 256.0 ? 256u : (want > 16777216.0 ? 16777216u : ((uint32_t)want + 7u) & ~7u);
+            std::vector<uint32_t> f4((size_t)4 * nsect, 0u);
+            const uint64_t cm = (1ull << (2 * (k - 3))) - 1ull;
+            for (uint32_t i = 0; i < found; ++i) {
+                const uint64_t v = km[i], rv = packed_revcomp64(v, k);
+                for (int o = 0; o < (rv == v ? 1 : 2); ++o) {
+                    const uint64_t X = o ? rv : v;
+                    const uint32_t bits = kf4_bits(kw_fold(X));
+                    for (uint32_t j = 0; j < 4; ++j) f4[(size_t)kf4_sector(kw_fold((X >> (2 * (3 - j))) & cm), nsect) * 4 + j] |= bits;
+                }
+            }
+            std::vector<uint32_t> kk((size_t)found * 2 + 4, 0u), kslot((size_t)found + 4, 0u);
+            for (uint32_t i = 0; ok && i < found; ++i) {
+                const uint32_t slot = list[3 * (size_t)i + 2];
+                const uint32_t vid_ = slot == IDX_NOT_FOUND ? KW_VID_ZERO : value_id_of(slot);
+                if (vid_ >= KW_VID_ZERO && slot != IDX_NOT_FOUND) ok = false; // (value ids are 24 bits here)
+                kk[2 * (size_t)i] = (uint32_t)km[i]; kk[2 * (size_t)i + 1] = (uint32_t)(km[i] >> 32) | (vid_ << 8);
+                kslot[i] = slot == IDX_NOT_FOUND ? 0u : slot;
+            }
+            const uint32_t kbits = 2u * (uint32_t)k;
+            uint32_t b = 12;
+            static const double km2_load = getenv("RKMH_KM2_LOAD") ? atof(getenv("RKMH_KM2_LOAD")) : 0.65;
+            while (b < 26 && (double)found > km2_load * 4.0 * (double)((size_t)1 << b)) ++b;
+            std::vector<uint32_t> c1;
+            bool placed_all = false;
+            for (; b <= 26 && !placed_all; ++b) {
+                const uint32_t nbk = 1u << b;
+                c1.assign((size_t)nbk * 4, KW_EMPTY); // empty: key number all ones, hop / tag / flag clear
+                placed_all = true;
+                for (uint32_t i = 0; i < found && placed_all; ++i) {
+                    const uint64_t y = kw_y(km[i], k);
+                    uint32_t bk = (uint32_t)(y >> (kbits - b));
+                    const uint32_t tag = (uint32_t)(y >> (kbits - b - KW_TAG)) & ((1u << KW_TAG) - 1u);
+                    bool placed = false;
+                    for (uint32_t hop = 0; hop < (1u << KM1_HB) && !placed; ++hop) {
+                        uint32_t* e = &c1[(size_t)bk * 4];
+                        for (int q = 0; q < 4 && !placed; ++q)
+                            if ((e[q] & KW_EMPTY) == KW_EMPTY) {
+                                e[q] = (e[q] & (1u << KW_IDBITS)) | (((hop << KW_TAG) | tag) << (KW_IDBITS + 1)) | i; // (the flag of a last cell stays)
+                                placed = true;
+                            }
+                        if (!placed) { e[3] |= 1u << KW_IDBITS; bk = (bk + 1) & (nbk - 1); }
+                    }
+                    placed_all = placed;
+                }
+                if (placed_all) break;
+            }
+            if (!placed_all) ok = false;
+            else {
+                RKCHK(c->d_km1[(size_t)kidx].reserve(c1.size() * 4));
+                HIPCHK(hipMemcpy(c->d_km1[(size_t)kidx].p, c1.data(), c1.size() * 4, hipMemcpyHostToDevice));
+                RKCHK(c->d_km1v[(size_t)kidx].reserve(vals.size() * 4 + 16));
+                if (!vals.empty()) HIPCHK(hipMemcpy(c->d_km1v[(size_t)kidx].p, vals.data(), vals.size() * 4, hipMemcpyHostToDevice));
+                RKCHK(c->d_kkeys.reserve(kk.size() * 4));
+                HIPCHK(hipMemcpy(c->d_kkeys.p, kk.data(), kk.size() * 4, hipMemcpyHostToDevice));
+                RKCHK(c->d_kslots.reserve(kslot.size() * 4));
+                HIPCHK(hipMemcpy(c->d_kslots.p, kslot.data(), kslot.size() * 4, hipMemcpyHostToDevice));
+                RKCHK(c->d_kf4[(size_t)kidx].reserve(f4.size() * 4));
+                HIPCHK(hipMemcpy(c->d_kf4[(size_t)kidx].p, f4.data(), f4.size() * 4, hipMemcpyHostToDevice));
+                c->ksets.km1[kidx] = c->d_km1[(size_t)kidx].as<uint4>(); c->ksets.km1_b[kidx] = b; c->ksets.km1_vals[kidx] = c->d_km1v[(size_t)kidx].as<uint32_t>();
+                c->ksets.kf4[kidx] = c->d_kf4[(size_t)kidx].as<uint4>(); c->ksets.kf4_n[kidx] = nsect; c->ksets.k[kidx] = k;
+                c->ix.kkeys = c->d_kkeys.as<uint2>(); c->ix.kslots = c->d_kslots.as<uint32_t>();
+                c->km1_ncells[kidx] = 0;
+                ++built;
+            }
+            clk.tick("wide filter + map");
+            if (!ok) break;
+            continue;
         }
         if (ok) {
             // group filter of k_classify_kmer (kf4_sector in rk_device.hpp): every found k-mer in both orientations under its four
@@ -1555,47 +1699,11 @@ static int build_index(rk_ctx* c) {
             // enough, or the value ids do not fit the cell, the table doubles (shorter remainders leave more bits for the id).
             {
                 static const double km1_load = getenv("RKMH_KM1_LOAD") ? atof(getenv("RKMH_KM1_LOAD")) : 0.65;
-                std::vector<uint32_t> vals;
-                std::unordered_map<uint32_t, uint32_t> val_id;
                 std::vector<uint32_t> vid(found);
                 const uint32_t VID_ZERO = 0xFFFFFFFEu; // placeholder, mapped to the layout's id below
                 for (uint32_t i = 0; i < found; ++i) {
                     const uint32_t slot = list[2 * (size_t)i + 1];
-                    if (slot == IDX_NOT_FOUND) { vid[i] = VID_ZERO; continue; }
-                    const uint32_t val = dense[(size_t)slot * 4 + 2];
-                    if (!(val >> 31) && ((val >> 29) & 3u) == 0u && ((val >> 20) & 0x1FFu) == 1u) { vid[i] = val & 0xFFFFFu; continue; } // one posting, once: the reference
-                    // lists: identical ones share one compound value (and one copy in kpost, see build_kpost)
-                    uint32_t vkey = val;
-                    KList kl;
-                    if (val >> 31) { kl = kremap.at(val & 0x7fffffffu); vkey = 0x80000000u | kl.plain; }
-                    auto it = val_id.find(vkey);
-                    if (it == val_id.end()) {
-                        it = val_id.emplace(vkey, (uint32_t)(R + vals.size() / 4)).first;
-                        // two dwords per entry: the index value and, for a list of three to six references that each hold the hash
-                        // once (what related types of one panel share), the list itself, nine bits per reference -- the kernel then
-                        // counts it in the lane that found the hit instead of fetching the posting list from global memory (KM1V_INLINE)
-                        uint32_t x = val, y = 0;
-                        if (RK_KMER_INLINE_N && (val >> 31)) {
-                            const uint32_t off = val & 0x7fffffffu, n = post[off];
-                            bool ok = n >= 3 && n <= 6;
-                            for (uint32_t q = 0; ok && q < n; ++q) ok = post[off + 1 + 2 * q] < 512u && post[off + 2 + 2 * q] == 1u;
-                            if (ok) {
-                                uint32_t r[6] = {0, 0, 0, 0, 0, 0};
-                                for (uint32_t q = 0; q < n; ++q) r[q] = post[off + 1 + 2 * q];
-                                x = 0xC0000000u | ((n - 3u) << 27) | r[0] | (r[1] << 9) | (r[2] << 18);
-                                y = r[3] | (r[4] << 9) | (r[5] << 18);
-                            }
-                        }
-                        // a list that stays a list: x = the form the dense-counter kernels walk (plain, or base + exceptions) -- or, within five
-                        // exceptions of its base, x and y hold base and exceptions themselves -- and z = the plain form (sparse counters)
-                        uint32_t z = 0, w = 0;
-                        if ((x >> 30) == 2u) {
-                            z = kl.plain;
-                            if (kl.ix) { x = kl.ix; y = kl.iy; w = kl.iw; } else x = 0x80000000u | kl.enc;
-                        }
-                        vals.push_back(x); vals.push_back(y); vals.push_back(z); vals.push_back(w);
-                    }
-                    vid[i] = it->second;
+                    vid[i] = slot == IDX_NOT_FOUND ? VID_ZERO : value_id_of(slot);
                 }
                 const uint32_t kbits = 2u * (uint32_t)k;
                 uint32_t b = kbits < 12u ? kbits : 12u;
@@ -1651,6 +1759,7 @@ static int build_index(rk_ctx* c) {
         }
         if (!ok) break; // one size without its structures: the hash-space kernels serve the run
     }
+    clk.tick("filter + exact map");
     if (kcache_dirty) c->kmer_cache_state = kmer_cache_write(c->kmer_cache_path, kcache_tag, kcache) ? 2 : 3;
     if (built == c->ks.n && built > 0) { // every size has its filter and map
         c->ksets.n = built;
@@ -1705,7 +1814,9 @@ static int set_references_impl(rk_ctx* c, const uint8_t* bases, const uint8_t* d
         if (r != RK_OK) { rk_counter_destroy(cnt); return r; }
         cfg.filt_counter = cnt; cfg.filter_mode = FILTER_RANGE; cfg.fmin = 0; cfg.fmax = max_samples;
     }
+    IndexClock clk;
     int r = general_run(c, bases, d_bases, offsets, nref, cfg, go);
+    clk.tick("reference sketches (device)");
     if (cnt) rk_counter_destroy(cnt);
     if (r != RK_OK) return r;
     return rk_set_reference_sketches(c, sk.data(), lens.data(), nref, ks, nks, S);
@@ -1762,6 +1873,7 @@ static int build_key_mask(rk_ctx* c) {
     if (c->ksets.n >= 1) {
         c->ksets_m = c->ksets;
         for (int j = 0; j < c->ksets.n; ++j) {
+            if (c->ksets.k[j] > 16) continue; // wide k-mers: the kernel tests the key's keep bit itself (kkeys carries the key id)
             const size_t bytes = (size_t)16 << c->ksets.km1_b[j];
             RKCHK(c->d_km1m[(size_t)j].reserve(bytes));
             HIPCHK(hipMemcpyAsync(c->d_km1m[(size_t)j].p, c->ksets.km1[j], bytes, hipMemcpyDeviceToDevice, c->st));

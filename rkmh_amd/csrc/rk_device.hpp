@@ -169,6 +169,32 @@ __host__ __device__ __forceinline__ uint32_t packed_revcomp(uint32_t v, int k) {
     return (r ^ 0xAAAAAAAAu) & m;
 }
 
+// ---- wide k-mers of the k-mer-space kernel: k = 17 .. KW_MAX_K (34 .. 40 bits, held in 64) ------------------------------------
+constexpr int KW_MAX_K = 20;
+__host__ __device__ __forceinline__ uint64_t packed_revcomp64(uint64_t v, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t r = __builtin_bitreverse64(v);
+#else
+    uint64_t r = 0;
+    for (int i = 0; i < 64; ++i) r |= ((v >> i) & 1ull) << (63 - i);
+#endif
+    r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1); // 2-bit groups in reverse order, bits of a group in order
+    if (k < 32) r >>= 2 * (32 - k);
+    const uint64_t m = k < 32 ? ((1ull << (2 * k)) - 1ull) : ~0ull;
+    return (r ^ 0xAAAAAAAAAAAAAAAAull) & m;
+}
+// 32 bits out of a wide k-mer (or core) for the filter's sector and bit choices: the same function on host and device
+__host__ __device__ __forceinline__ uint32_t kw_fold(uint64_t x) { return (uint32_t)x ^ ((uint32_t)(x >> 32) * 0x85EBCA6Bu + 0x7F4A7C15u); }
+// The exact map of wide k-mers (km2): y = (key * odd constant) mod 4^k is a bijection on the 2k-bit k-mers; bucket = its top km1_b bits,
+// tag = the next KW_TAG bits.  A bucket is four 4-byte cells hop:3 | tag:8 | flag:1 | key number:20 (flag in the last cell as in
+// km1; key number all ones = empty); the key number leads to kkeys[number] = {k-mer bits 0..31, k-mer bits 32..39 | value id << 8}
+// (8 bytes: the table shares the L2 with the map and the filter): the full k-mer settles what the 8-bit tag could not, the value
+// id is km1's (below the reference count: that reference once; KW_VID_ZERO: canonical hash 0; else nref + compound index);
+// kslots[number] = the index key id, read only under the per-key mask of -M.
+constexpr uint64_t KW_C = 0x9E3779B97F4A7C15ull;
+constexpr uint32_t KW_TAG = 8, KW_IDBITS = 20, KW_EMPTY = (1u << KW_IDBITS) - 1u, KW_VID_ZERO = 0xFFFFFEu, KW_VID_NONE = 0xFFFFFFu; // (value ids are 24 bits)
+__host__ __device__ __forceinline__ uint64_t kw_y(uint64_t key, int k) { return (key * KW_C) & ((1ull << (2 * k)) - 1ull); }
+
 // MurmurHash3_x64_128 of a k-mer of k <= 16 bytes held in four dwords (little-endian byte order, bytes beyond k zero)
 template <int FOLD = -1>
 __device__ __forceinline__ uint64_t murmur_regs16(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int k, uint32_t seed, int fold) {
@@ -200,6 +226,34 @@ __device__ __forceinline__ uint64_t canonical_packed(uint32_t v, int k, uint32_t
     }
     const uint64_t hf = murmur_regs16<-1>(f[0], f[1], f[2], f[3], k, seed, fold);
     const uint64_t hr = murmur_regs16<-1>(r[0], r[1], r[2], r[3], k, seed, fold);
+    return hf < hr ? hf : hr;
+}
+
+// canonical hash of a wide packed k-mer (16 < k <= 20): one 16-byte block and a tail of k - 16 bytes per strand
+__device__ __forceinline__ uint64_t murmur_regs20(const uint32_t* w, int k, uint32_t seed, int fold) {
+    uint64_t h1 = seed, h2 = seed;
+    mm_block_first(h1, h2, seed, join64(w[0], w[1]), join64(w[2], w[3]));
+    uint64_t k1 = (uint64_t)w[4]; // (k - 16 <= 4 tail bytes: k2 stays 0)
+    k1 *= MM_C1; k1 = rotl64(k1, 31); k1 *= MM_C2; h1 ^= k1;
+    return mm_finish<-1>(h1, h2, (uint32_t)k, fold);
+}
+__device__ __forceinline__ uint32_t packed_to_ascii4_64(uint64_t v, int d) {
+    const uint32_t b = (uint32_t)(v >> (8 * d)) & 0xffu;
+    const uint32_t sel = (b & 3u) | ((b & 0xCu) << 6) | ((b & 0x30u) << 12) | ((b & 0xC0u) << 18);
+    return __builtin_amdgcn_perm(0x47544341u, 0x47544341u, sel);
+}
+__device__ __forceinline__ uint64_t canonical_packed64(uint64_t v, int k, uint32_t seed, int fold) {
+    const uint64_t rv = packed_revcomp64(v, k);
+    uint32_t f[5], r[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        const int nv = k - 4 * d;
+        const uint32_t m = nv >= 4 ? 0xffffffffu : (nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u));
+        f[d] = packed_to_ascii4_64(v, d) & m;
+        r[d] = packed_to_ascii4_64(rv, d) & m;
+    }
+    const uint64_t hf = murmur_regs20(f, k, seed, fold);
+    const uint64_t hr = murmur_regs20(r, k, seed, fold);
     return hf < hr ? hf : hr;
 }
 
@@ -544,6 +598,8 @@ struct RefIndex {
     // eight BASE lists stored as (base, exceptions); kbase = [8 x (start, members)] then the members
     const uint32_t* kpost;
     const uint32_t* kbase;
+    const uint2* kkeys;   // wide k-mers (k = 17 .. 20, kpk says which): km1 then holds km2 buckets, see KW_C above
+    const uint32_t* kslots;
     // -M with a bounded min_num (rk_set_min_num_bound): bit (key id) set <=> the key's slot of the depth map passes the threshold
     // (nullptr = no per-key mask).  The hash-space kernels test it for the windows that HIT a key instead of one bit of the
     // 25 MB slot bitmap for every window; the k-mer-space kernel reads a copy of km1 in which the dropped keys carry the zero id.

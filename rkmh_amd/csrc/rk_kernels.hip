@@ -496,12 +496,33 @@ __global__ __launch_bounds__(256) void k_enum_kmers(RefIndex ix, DevPolicy pol, 
         if (pos < list_cap) list[pos] = make_uint2(v, slot); // slot = IDX_NOT_FOUND: the k-mer hashes to 0
     }
 }
+// the same for wide k-mers (16 < k <= KW_MAX_K): 4^k is 1.7 * 10^10 at k = 17 and 1.1 * 10^12 at k = 20 -- 0.1 s to several seconds, once per
+// reference set (rk_set_kmer_cache keeps the list); list entries (k-mer low, k-mer high, key id or IDX_NOT_FOUND, 0)
+__global__ __launch_bounds__(256) void k_enum_kmers64(RefIndex ix, DevPolicy pol, int k, uint64_t total, uint32_t* stats, uint4* list, uint32_t list_cap) {
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t rv = packed_revcomp64(v, k);
+        if (rv < v) continue;
+        const uint64_t h = canonical_packed64(v, k, pol.seed, pol.fold);
+        uint32_t slot = IDX_NOT_FOUND;
+        if (h != 0) {
+            if (ix.pre) {
+                const uint32_t bm = index_pre_bits(h);
+                if ((ix.pre[index_pre_word(h, ix.pmask)] & bm) != bm) continue;
+            }
+            slot = index_find(ix, h);
+            if (slot == IDX_NOT_FOUND) continue;
+        }
+        const uint32_t pos = atomicAdd(stats, 1u);
+        if (pos < list_cap) list[pos] = make_uint4((uint32_t)v, (uint32_t)(v >> 32), slot, 0u);
+    }
+}
 hipError_t launch_enum_kmers(const RefIndex& ix, const DevPolicy& pol, int k, uint32_t* stats, uint2* list, uint32_t list_cap,
                              hipStream_t st) {
     const uint64_t total = 1ull << (2 * k);
     uint64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_enum_kmers, dim3((uint32_t)blocks), dim3(256), 0, st, ix, pol, k, total, stats, list, list_cap);
+    if (k > 16) hipLaunchKernelGGL(k_enum_kmers64, dim3((uint32_t)blocks), dim3(256), 0, st, ix, pol, k, total, stats, reinterpret_cast<uint4*>(list), list_cap);
+    else hipLaunchKernelGGL(k_enum_kmers, dim3((uint32_t)blocks), dim3(256), 0, st, ix, pol, k, total, stats, list, list_cap);
     return hipGetLastError();
 }
 

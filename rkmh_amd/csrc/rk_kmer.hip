@@ -145,7 +145,9 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                                                                               uint32_t nreads, int S, RefIndex ix, KmerSets ksets,
                                                                               int32_t* __restrict__ out4, DevPolicy pol, KmerGeom geo) {
     // KT = 0: several k-mer sizes (ksets.k[], each from 8 to 16), one pass over the tile's windows per size
-    static_assert(KT == 0 || (KT >= 4 && KT <= 16), "a k-mer packs into 32 bits; the core is the (k-3)-mer");
+    // KT = 32: ONE k-mer size from 17 to KW_MAX_K, known at run time (ix.kpk): wide k-mers, 64-bit arithmetic, the km2 map (rk_device.hpp)
+    static_assert(KT == 0 || KT == 32 || (KT >= 4 && KT <= 16), "a k-mer packs into 32 bits; the core is the (k-3)-mer");
+    constexpr bool WIDE = KT == 32;
     using L = KmLds<NQ>;
     __shared__ __attribute__((aligned(16))) uint32_t smem[(BIG ? KM_LDS_BIG : KM_LDS_SMALL) / 4];
     constexpr uint32_t PAD_P = NQ * 1024;       // position of the image's zero padding: where lanes without a group look
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         uint32_t nw_all = 0;             // windows of this lane's read, all sizes together
         if (lane < Tn) {
 #pragma unroll
-            for (int j = 0; j < NKC; ++j) if (j < NK) nw_all += (uint32_t)num_windows((int)len, KT ? KT : ksets.k[j], pol.drop_last_window);
+            for (int j = 0; j < NKC; ++j) if (j < NK) nw_all += (uint32_t)num_windows((int)len, WIDE ? (int)ix.kpk : (KT ? KT : ksets.k[j]), pol.drop_last_window);
         }
         if (lane < 4 * KM_MAX_T) fam[lane] = 0;
         if (lane < KM_MAX_T) {
@@ -292,9 +294,10 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         }
         for (int kk = 0; kk < NK; ++kk) {
         // ---- one k-mer size: its windows, its filter and map; the per-read counters, zero counts and running best carry over ----
-        const int k = KT ? KT : ksets.k[kk];
-        const uint32_t KMASK = k == 16 ? 0xffffffffu : ((1u << (2 * k)) - 1u);
-        const uint32_t CMASK = (1u << (2 * (k - 3))) - 1u;
+        const int k = WIDE ? (int)ix.kpk : (KT ? KT : ksets.k[kk]);
+        const uint32_t KMASK = (WIDE || k == 16) ? 0xffffffffu : ((1u << (2 * k)) - 1u);
+        const uint32_t CMASK = WIDE ? 0xffffffffu : (1u << (2 * (k - 3))) - 1u;
+        const uint64_t KMASK64 = WIDE ? (1ull << (2 * k)) - 1ull : 0ull, CMASK64 = WIDE ? (1ull << (2 * (k - 3))) - 1ull : 0ull; // wide k-mers
         const uint32_t KBITS = (1u << k) - 1u; // k validity bits
         const uint4* const kf4p = KT ? ix.kf4 : ksets.kf4[kk];
         const uint4* const km1p = KT ? ix.km1 : ksets.km1[kk];
@@ -423,20 +426,46 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
             mqn = 0;
         };
         // one candidate of the queue: canonical k-mer, its read, its bucket of the exact map (load in flight on return)
-        struct Cand { uint32_t key, t, y; uint4 c; };
-        const uint32_t km_r = 2u * (uint32_t)k - km1_b, km_vb1 = 32u - KM1_HB - km_r;      // remainder bits; value id bits + the flag bit
+        struct Cand { uint32_t key, t, y, key_hi; uint4 c; }; // (wide: key / key_hi = the k-mer, y = bucket << KW_TAG | tag)
+        const uint32_t km_r = WIDE ? 8u : 2u * (uint32_t)k - km1_b, km_vb1 = 32u - KM1_HB - km_r;      // remainder bits; value id bits + the flag bit (wide: unused)
         const uint32_t km_vmask = (1u << (km_vb1 - 1u)) - 1u, km_rmask = (1u << km_r) - 1u, nref = (uint32_t)ix.nref;
+        // wide k-mers: the bucket's cells whose (hop, tag) match are settled by the full k-mer in kkeys; res = {value id, -, key number}
+        // (value id KW_VID_NONE: no such k-mer); again: the search goes on in the next bucket
+        auto wide_probe = [&](const Cand& c, const uint4& b, uint32_t hop, uint3& res, bool& again) {
+            const uint32_t want = (hop << KW_TAG) | (c.y & ((1u << KW_TAG) - 1u));
+            const uint32_t cells[4] = {b.x, b.y, b.z, b.w};
+            res = make_uint3(KW_VID_NONE, 0u, 0u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t num = cells[q] & KW_EMPTY;
+                if ((cells[q] >> (KW_IDBITS + 1)) == want && num != KW_EMPTY && res.x == KW_VID_NONE) {
+                    const uint2 kk = ix.kkeys[num];
+                    if (kk.x == c.key && (kk.y & 0xFFu) == c.key_hi) res = make_uint3(kk.y >> 8, 0u, num);
+                }
+            }
+            again = res.x == KW_VID_NONE && ((b.w >> KW_IDBITS) & 1u) != 0u && c.t != 0xFFFFFFFFu;
+        };
         auto lookup = [&](uint32_t e, uint32_t qn) -> Cand {
             Cand c;
             uint32_t ent = PAD_P | (8u << 12); // past the queue's end: the all-A k-mer of the padding, of read 8 which has no windows
             if (e < qn) ent = q[e];
             const uint32_t P = ent & 4095u, t = ent >> 12;
             const km_pair1 w = *reinterpret_cast<const km_pair1*>(reinterpret_cast<const uint8_t*>(pk) + (P >> 2));
+            const uint2 ri = *reinterpret_cast<const uint2*>(&rinfo[t]);
+            c.t = P - ri.x < ri.y ? t : 0xFFFFFFFFu; // window number = position - read start; the last group of a read may reach past its last window
+            if constexpr (WIDE) {
+                const uint64_t x = (join64(w.x, w.y) >> ((P & 3u) << 1)) & KMASK64; // (58 bits follow the byte the window starts in: k <= 20 needs 40)
+                const uint64_t r = packed_revcomp64(x, k);
+                const uint64_t key = x < r ? x : r;
+                c.key = (uint32_t)key; c.key_hi = (uint32_t)(key >> 32);
+                c.y = (uint32_t)(kw_y(key, k) >> (2u * (uint32_t)k - km1_b - KW_TAG));
+                c.c = km1p[c.y >> KW_TAG];
+                return c;
+            }
             const uint32_t x = __builtin_amdgcn_alignbit(w.y, w.x, (P & 3u) << 1) & KMASK;
             const uint32_t r = packed_revcomp(x, k);
             c.key = x < r ? x : r;
-            const uint2 ri = *reinterpret_cast<const uint2*>(&rinfo[t]);
-            c.t = P - ri.x < ri.y ? t : 0xFFFFFFFFu; // window number = position - read start; the last group of a read may reach past its last window
+            c.key_hi = 0;
             c.y = km1_y(c.key, k);
             c.c = km1p[(RK_KMER_ABL & 256) ? ((c.y >> km_r) & 255u) : (c.y >> km_r)];
             return c;
@@ -459,11 +488,19 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                 again = (cell & km_vmask) == km_vmask && ((nb.w >> (km_vb1 - 1u)) & 1u) != 0u;
             }
         };
-        auto apply = [&](const Cand& c, uint32_t cell) {
-            const uint32_t vid = cell & km_vmask;
+        auto apply = [&](const Cand& c, uint32_t cell, uint3 wres = make_uint3(0u, 0u, 0u)) {
+            // narrow: the cell's value id (all ones: no such k-mer; all ones - 1: canonical hash 0).  wide: wres from wide_probe.
+            uint32_t vid = cell & km_vmask;
+            bool hit = vid != km_vmask && c.t != 0xFFFFFFFFu; // else: a false positive of the bit filter, or a window past its read's last
+            bool zero = vid == km_vmask - 1u;
+            if constexpr (WIDE) {
+                vid = wres.x;
+                hit = vid != KW_VID_NONE && c.t != 0xFFFFFFFFu;
+                zero = vid == KW_VID_ZERO;
+                // -M with a bounded min_num: a key the mask drops is a zero-hash k-mer (the narrow form reads a masked copy of its map)
+                if (hit && !zero && ix.keepkey) { const uint32_t kid = ix.kslots[wres.z]; if (!((ix.keepkey[kid >> 5] >> (kid & 31u)) & 1u)) zero = true; }
+            }
             uint32_t val = vid | (1u << 20); // a single posting of multiplicity 1, in the RefIndex::kv value format
-            const bool hit = vid != km_vmask && c.t != 0xFFFFFFFFu; // else: a false positive of the bit filter, or a window past its read's last
-            const bool zero = vid == km_vmask - 1u;
             uint32_t valy = 0, valz = 0, valw = 0;
             if (!(RK_KMER_ABL & 32) && hit && vid >= nref && !zero) { // compound value, four dwords (a few KB: L1-resident)
                 const uint4 vv = *reinterpret_cast<const uint4*>(km1v + 4u * (vid - nref));
@@ -480,8 +517,8 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                     // of rkmh.cpp:869 counts min(occurrences in the read, multiplicity in the sketch): occurrence `rank` of a k-mer
                     // counts for a posting iff rank < its multiplicity.
                     uint32_t* ds = dset + c.t * DS;
-                    const uint32_t id = c.key + 1u;
-                    uint32_t idx = (c.key * 0x9E3779B1u) >> ds_shift;
+                    const uint32_t id = (WIDE ? wres.z : c.key) + 1u; // (wide: the key's number in kkeys)
+                    uint32_t idx = ((id - 1u) * 0x9E3779B1u) >> ds_shift;
                     uint32_t old = (RK_KMER_ABL & 512) ? 0u : atomicCAS(&ds[idx], 0u, id);
                     uint32_t probes = 1;
                     while (old != 0u && probes < DS) { // the wave leaves this loop when its last lane has found a free slot
@@ -555,6 +592,20 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                 const Cand a = lookup(e0 + (uint32_t)lane, qn);
                 Cand b = a;
                 if (two) b = lookup(e0 + KW + (uint32_t)lane, qn);
+                if constexpr (WIDE) {
+                    uint3 ra, rb = make_uint3(KW_VID_NONE, 0u, 0u);
+                    bool ga, gb = false;
+                    wide_probe(a, a.c, 0u, ra, ga);
+                    if (two) wide_probe(b, b.c, 0u, rb, gb);
+                    for (uint32_t hop = 1; hop < (1u << KM1_HB) && __ballot(ga || gb); ++hop) {
+                        const uint32_t bm = (1u << km1_b) - 1u;
+                        if (ga) { const uint4 nb = km1p[((a.y >> KW_TAG) + hop) & bm]; wide_probe(a, nb, hop, ra, ga); }
+                        if (gb) { const uint4 nb = km1p[((b.y >> KW_TAG) + hop) & bm]; wide_probe(b, nb, hop, rb, gb); }
+                    }
+                    apply(a, 0u, ra);
+                    if (two) apply(b, 0u, rb);
+                    continue;
+                }
                 uint32_t ca, cb = 0xFFFFFFFFu;
                 bool ga, gb = false;
                 first_match(a, ca, ga);
@@ -573,7 +624,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
         const uint32_t nsteps = (NG + KW - 1) / KW;
         // a last step of 1 .. 16 groups runs a QUARTER wide: four lanes per group, one window (and one dword of the sector) each --
         // a fourth of the window tests for the step that would otherwise run 64 lanes for a dozen groups (six 150-base reads: 204 groups)
-        const bool qlast = RK_KMER_QSTEP && NG != 0u && ((NG - 1u) & (uint32_t)(KW - 1)) < 16u;
+        const bool qlast = RK_KMER_QSTEP && !WIDE && NG != 0u && ((NG - 1u) & (uint32_t)(KW - 1)) < 16u;
         const uint32_t kf4_n16 = kf4_n << 4; // (sector count < 2^28: checked where the filter is built)
         uint32_t qcount = 0;
         uint32_t step = 0;
@@ -606,7 +657,8 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                 const uint32_t sh = (P0 & 3u) << 1;
                 wl[s] = __builtin_amdgcn_alignbit(w.y, w.x, sh);
                 wh[s] = w.y >> sh;
-                const uint32_t core = k == 16 ? wl[s] >> 6 : (wl[s] >> 6) & CMASK; // k = 16: the 13-mer is all of bits 6..31
+                uint32_t core = k == 16 ? wl[s] >> 6 : (wl[s] >> 6) & CMASK; // k = 16: the 13-mer is all of bits 6..31
+                if constexpr (WIDE) core = kw_fold((join64(wl[s], wh[s]) >> 6) & CMASK64); // the (k - 3)-mer, up to 34 bits, folded to 32
                 // byte offset of the sector: 16 * (hashed core scaled to [0, kf4_n)) = the high product with 16 kf4_n, less its low four bits
                 uint32_t sect_b = __umulhi(core * 0x85EBCA6Bu, kf4_n16) & ~15u;
                 if (RK_KMER_ABL & 128) { // timing experiment (WRONG results): an odd lane reads the other half of its even neighbour's 32 bytes --
@@ -651,6 +703,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(c
                 for (int j = 0; j < NW; ++j) {
                     uint32_t x = j == 0 ? wl[s] : __builtin_amdgcn_alignbit(wh[s], wl[s], 2 * j);
                     if (k < 16) x &= KMASK;
+                    if constexpr (WIDE) x = kw_fold((join64(wl[s], wh[s]) >> (2 * j)) & KMASK64);
                     const uint32_t f = NW == 1 ? fq[s] : (j == 0 ? fw[s].x : (j == 1 ? fw[s].y : (j == 2 ? fw[s].z : fw[s].w)));
                     const uint32_t fb = kf4_bits_dev(x);
                     bool cand = (fb & f) == fb; // (not (fb & ~f) == 0: the compiler moves a NOT of the loaded dword up to the load and waits there)
@@ -847,7 +900,7 @@ hipError_t launch_k(int nq, int cmode, bool big, dim3 grid, hipStream_t st, cons
 
 // reads of up to 2 * 1024 - 15 bytes (two quads per lane), panels the 16-bit reference field of the running maximum can name
 bool classify_kmer_supported(int nref, int maxlen, int k) {
-    return nref <= 16384 && maxlen <= 2 * 1024 - 15 && k >= KPRE_MIN_K && k <= 16;
+    return nref <= 16384 && maxlen <= 2 * 1024 - 15 && k >= KPRE_MIN_K && k <= KW_MAX_K; // (17 .. 20: the wide form, when its structures were built)
 }
 
 // ksets: the structures of every k-mer size of the run (n = 1: the compile-time-k kernels, whose structures are ix.kf4 / km1 too)
@@ -875,6 +928,8 @@ hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint
         RK_KM_K(8); RK_KM_K(9); RK_KM_K(10); RK_KM_K(11); RK_KM_K(12); RK_KM_K(13); RK_KM_K(14); RK_KM_K(15);
 #endif
         RK_KM_K(16);
+        case 17: case 18: case 19: case 20: // wide k-mers: one run-time-k instantiation (KT = 32)
+            return ix.kkeys ? launch_k<32>(nq, cmode, big, dim3(grid), st, bases, offs, nreads, S, ix, ksets, out4, pol, geo) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 #undef RK_KM_K
