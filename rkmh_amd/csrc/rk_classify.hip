@@ -154,21 +154,20 @@ __device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uin
     }
 }
 
-// The bucket load of the software-pipelined lookup is issued through inline asm so that hipcc does not count
-// it: left to itself the compiler drains vmcnt at the loop header and exposes the full L2 latency every
-// iteration.  Form (ii) of the guide: "=v" load, then a wait statement naming the destination "+v" right
-// before the first consumer.  Over-waiting by compiler-inserted waits is harmless (loads return in order).
+// The lookup of a window is issued one step ahead: the bucket (or filter word) of window i is requested at the end of step i and
+// examined after window i + 1 has been hashed.  Plain loads: hipcc places the wait in front of the first use, i.e. behind the next
+// window's hashing (rounds 1-4 issued these loads through inline asm with hand-placed s_waitcnt and policed the ISA with a lint;
+// k_classify_kmer showed that the compiler keeps the same overlap on its own).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void bucket_load_async(const uint4* base, uint32_t byte_off, u32x4& f) {
-    // saddr form: wave-uniform table base in SGPRs + 32-bit byte offset per lane (no 64-bit address arithmetic)
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f) : "v"(byte_off), "s"(base) : "memory");
+    f = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(base) + byte_off);
 }
-__device__ __forceinline__ void bucket_wait(u32x4& f) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : : "memory"); }
+__device__ __forceinline__ void bucket_wait(u32x4&) {}
 // the same for one word of the first-level filter (RefIndex::pre)
 __device__ __forceinline__ void word_load_async(const uint32_t* base, uint32_t byte_off, uint32_t& f) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(f) : "v"(byte_off), "s"(base) : "memory");
+    f = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(base) + byte_off);
 }
-__device__ __forceinline__ void word_wait(uint32_t& f) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : : "memory"); }
+__device__ __forceinline__ void word_wait(uint32_t&) {}
 
 // MODE 0: classify; MODE 1: count pass of -M (rkmh.cpp:904-910); MODE 2: classify with the -M mask (rkmh.cpp:916)
 // MODE_ 3 / 4: MODE 0 / 2 with the first-level filter of large panels (RefIndex::pre) in front of the bucket table
@@ -246,9 +245,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         b_ = offs[r + (uint32_t)n];
         o_ = offs[r + (uint32_t)(lane <= n ? lane : n)];
     };
-    // The base prefetch is issued through inline asm (loads hipcc does not count): otherwise the compiler, seeing
-    // loads pending at the hashing loop's header, drains vmcnt inside every iteration and with it the pipelined
-    // bucket lookup.  Addresses are clamped into the tile (out-of-range lanes are zeroed when the image is built).
+    // Addresses are clamped into the tile (out-of-range lanes are zeroed when the image is built).
     auto load_bases = [&](uint32_t a_, uint32_t b_) {
         const uint32_t* g32 = reinterpret_cast<const uint32_t*>(bases) + (a_ >> 2);
         uint32_t ndw = ((a_ & 3u) + (b_ - a_) + 3u) >> 2;
@@ -258,15 +255,11 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
             if ((uint32_t)q * WAVE <= ndw) { // wave-uniform
                 const uint32_t jf = (uint32_t)q * WAVE + (uint32_t)lane;
                 const uint32_t j = jf >= 1 ? (jf <= ndw ? jf - 1 : (ndw ? ndw - 1 : 0u)) : 0u;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(pf[q]) : "v"(g32 + j) : "memory");
+                pf[q] = g32[j];
             }
         }
     };
-    auto wait_bases = [&]() {
-        if constexpr (PF == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]) : : "memory");
-        else if constexpr (PF == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]) : : "memory");
-    };
+    auto wait_bases = [&]() {}; // (plain loads: the compiler waits where the registers are first read)
     // XCD-aware tile ownership: the dispatcher deals workgroups round-robin over the 8 XCDs, each with its own L2.
     // Workgroup b is given the tiles of "virtual" workgroup (b % 8) * ceil(grid / 8) + b / 8, so the workgroups of one
     // XCD walk one contiguous eighth of the batch and the cache lines that straddle two tiles are fetched into one L2.
@@ -287,8 +280,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         if (ntile < ntiles) load_offsets(ntile, nxt_a, nxt_b, nxt_o); // lands during phase 0
         wave_sync(); // previous tile fully consumed
         // A tile holding a read longer than the caller's hint is rerouted by the host (rows of -2; the count pass skips it).
-        // Here it becomes an EMPTY tile (no reads, no bytes) that runs through the body like any other: a branch around the
-        // body would fork the path between the asm-issued prefetch and its wait (see the end of the loop body).
+        // Here it becomes an EMPTY tile (no reads, no bytes) that runs through the body like any other.
         const bool oversized = B_all > (uint32_t)geo.cap_bytes;
         if (MODE != 1 && oversized && lane < tile_reads(tile)) reinterpret_cast<int4*>(out4)[r0 + lane] = make_int4(-2, 0, 0, 0);
         const int Tn = oversized ? 0 : tile_reads(tile);
@@ -710,13 +702,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 const bool last = it > nIt;
                 const uint32_t qn = last ? qcount : (qcount & ~(uint32_t)(WAVE - 1)); // mid-tile: whole waves of candidates only
                 if (!RK_DBG(32)) drain_queue(qn);
-                // tell hipcc that no load of the drain is pending any more: otherwise it drains vmcnt inside every
-                // hashing step (a vals/keys destination register is reused there) and with it the pipelined lookup
-                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
                 wave_sync();
-                // the last step's filter word is never examined: retire that asm-issued load HERE, tied to its register, so that no
-                // later code (the next tile may run the other loop form) can be given the register while the load is in flight
-                if constexpr (PRE) { if (last) word_wait(fw); }
                 if (last) { qcount = 0; break; }
                 const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
                 uint4 ce = make_uint4(0u, 0u, 0u, 0u);
@@ -770,11 +756,6 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(max_id, max_shared, max_shared - prev, nmins < geo.nmin_cap ? nmins : geo.nmin_cap);
             }
         }
-        // The prefetch registers cross the back edge of this loop.  hipcc does not know that an asm-issued load is still
-        // writing them, and may resolve the loop-carried value with a register copy at the end of the body: a copy taken
-        // before the data has landed reads the previous tile's bases (seen in the count pass of -M, whose hashing loop
-        // holds no other wait, as a one-in-thousands wrong count).  Retiring the loads HERE makes the loop-carried value
-        // the output of this statement, so any such copy follows it.  tools/lint_async_loads.py checks the ISA for this.
         wait_bases();
     }
     if (MODE == 1 && geo.cs.tab) { // the compact count's last step and what is left in its queue

@@ -33,7 +33,7 @@ def timed(ctx, d_out, reps=20):
 
 for k in [int(x) for x in os.environ.get("KS", "17,18,19,20").split(",")]:
     outs = []
-    for form in ("hash-space", "k-mer-space"):
+    for form in os.environ.get("FORMS", "hash-space,k-mer-space").split(","):
         ctx = rkmh_amd.Context(0)
         ctx._lib.rk_set_kmer_form(ctx._h, 1 if form == "k-mer-space" else 0)
         t = time.perf_counter()
@@ -45,4 +45,4 @@ for k in [int(x) for x in os.environ.get("KS", "17,18,19,20").split(",")]:
         outs.append(d_out.cpu().numpy())
         print("k=%d s=%d %-12s %.3f ms per 1 M reads (%.2f G reads/s); set_references %.2f s" % (k, S, form, ms, n / ms / 1e6, setup), flush=True)
         ctx.close()
-    assert (outs[0] == outs[1]).all(), "the two forms disagree at k = %d" % k
+    assert len(outs) < 2 or (outs[0] == outs[1]).all(), "the two forms disagree at k = %d" % k
