@@ -509,7 +509,7 @@ def config_legs(rkmh_amd, api, synth, dev, n, L, check):
             if cw.kmer_form()[0]:
                 d_out2 = torch.zeros((n, 4), dtype=torch.int32, device=dev)
                 wms = kernel_ms(cw, d_b, d_o, d_out2, stream)
-                if not bool((d_out2 == d_out).all().item()):
+                if not (d_out2.cpu().numpy() == out).all():      # (`out`: the hash-space kernel's rows of the plain run above)
                     raise SystemExit("c4_filter: the k-mer-space kernel (wide k-mers) and the hash-space kernel disagree")
                 wide = {"kmer_space_kernel_ms": wms, "kmer_space_reads_per_s": n / wms * 1e3, "kmer_space_set_references_s": t_en}
             cw.close()

@@ -923,7 +923,7 @@ hipError_t launch_classify_tile(const uint8_t* bases, const uint32_t* offs, uint
         else if (!ix.pre || !pre_masked) RK_LAUNCH(KT, 2, FOLD);                                                     \
         else RK_LAUNCH(KT, 4, FOLD);                                                                                 \
     } while (0)
-#ifdef RK_TILE_ONLY_K // experiment builds (tools/classify_variants.sh): one compile-time k, seconds to compile
+#ifdef RK_TILE_ONLY_K // experiment builds : one compile-time k, seconds to compile
     if (ks.n != 1 || ks.k[0] != RK_TILE_ONLY_K) return hipErrorInvalidValue;
     RK_LAUNCH_M(RK_TILE_ONLY_K, -1);
     return hipGetLastError();

@@ -260,7 +260,7 @@ __device__ __forceinline__ uint64_t canonical_packed64(uint64_t v, int k, uint32
 // MurmurHash3_x64_128 of the k bytes starting at byte offset `a` of the LDS dword array w32.
 // The array must be readable for 16 bytes past the window (buffers are padded).
 // Windows are fetched with UNALIGNED 16-byte LDS reads: gfx950 runs with unaligned DS access enabled (hipcc itself
-// emits one ds_read_b128 for an align-1 vector load; verified on MI355X by tools/ubench_unaligned_lds.hip), so no
+// emits one ds_read_b128 for an align-1 vector load; verified on MI355X by tools/ubench/ubench_unaligned_lds.hip), so no
 // dword-aligned reads + v_alignbyte funnel is needed.
 typedef uint32_t rk_u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed)) rk_unaligned16 { rk_u32x4 v; };

@@ -33,7 +33,7 @@ constexpr int KW = 64;
 constexpr int KM_MAX_T = 8;          // reads per tile (phase 2 takes eight reads in one pass; the group -> read search is unrolled for it)
 constexpr int KM_MQ = 32;            // deferred multi-posting hits (a full list is worked off at once: 16 lanes per hit)
 #ifndef RK_KMER_ABL
-#define RK_KMER_ABL 0 // timing experiments with WRONG results (tools/kmer_variants.sh): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length, 128 filter sectors of lane pairs in one line, 256 map look-ups from a 4 KB corner of the map (L1 hits), 512 no hit multiset (every occurrence has rank 0), 1024 hits with a posting list dropped, 2048 two of three lanes' filter sectors in one 32-byte piece
+#define RK_KMER_ABL 0 // timing experiments with WRONG results (-DRK_KMER_ABL=<bits> -DRK_KMER_FAST_BUILD builds): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length, 128 filter sectors of lane pairs in one line, 256 map look-ups from a 4 KB corner of the map (L1 hits), 512 no hit multiset (every occurrence has rank 0), 1024 hits with a posting list dropped, 2048 two of three lanes' filter sectors in one 32-byte piece
 #endif
 #ifndef RK_KMER_NT
 #define RK_KMER_NT 1 // the bases are read once: streaming loads keep them from evicting the filter and the map from L2
@@ -924,7 +924,7 @@ hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint
     if (ksets.n > 1) return launch_k<0>(nq, cmode, big, dim3(grid), st, bases, offs, nreads, S, ix, ksets, out4, pol, geo);
 #define RK_KM_K(KT) case KT: return launch_k<KT>(nq, cmode, big, dim3(grid), st, bases, offs, nreads, S, ix, ksets, out4, pol, geo)
     switch (ksets.k[0]) {
-#ifndef RK_KMER_FAST_BUILD // tools/kmer_variants.sh: timing experiments compile the k = 16 kernels only
+#ifndef RK_KMER_FAST_BUILD // timing experiments compile the k = 16 kernels only
         RK_KM_K(8); RK_KM_K(9); RK_KM_K(10); RK_KM_K(11); RK_KM_K(12); RK_KM_K(13); RK_KM_K(14); RK_KM_K(15);
 #endif
         RK_KM_K(16);

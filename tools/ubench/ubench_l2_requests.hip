@@ -1,7 +1,7 @@
 // ubench_l2_requests.hip -- how many DISTINCT-LINE 16-byte requests per second this chip serves out of tables that live in the L2s
 // (the access pattern of k_classify_kmer's filter sectors and map buckets: every lane of a wave its own cache line), by table size
 // and by loads in flight per lane.  Build + run on the GPU box:
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_l2_requests.hip -o /tmp/ubench_l2 && /tmp/ubench_l2
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/ubench_l2_requests.hip -o /tmp/ubench_l2 && /tmp/ubench_l2
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

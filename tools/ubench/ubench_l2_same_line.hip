@@ -2,7 +2,7 @@
 // (What a filter sector of 24 or 32 bytes for six or eight windows would do: global_load_dwordx4 + global_load_dwordx2/x4 at +16.)
 // Lanes touch distinct random lines of an L2-resident 2 MB table; variants: one 16-byte load per line; two 16-byte loads from the
 // same 32-byte half of the line, issued back to back; two loads from two DIFFERENT lines (the price of two requests).
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_l2_same_line.hip -o /tmp/ubench_sl && /tmp/ubench_sl
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/ubench_l2_same_line.hip -o /tmp/ubench_sl && /tmp/ubench_sl
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

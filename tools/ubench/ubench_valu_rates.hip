@@ -1,6 +1,6 @@
 // ubench_valu_rates.hip -- issue cost (cycles per wave64 instruction on one SIMD) of the VALU / SALU / LDS instructions k_classify_kmer is
 // made of, measured with every SIMD of the chip full (8 waves per SIMD, independent chains).  Build + run on the GPU box:
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_valu_rates.hip -o /tmp/ubench_valu && /tmp/ubench_valu
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/ubench_valu_rates.hip -o /tmp/ubench_valu && /tmp/ubench_valu
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
