@@ -359,6 +359,12 @@ typedef struct rk_fastq_result {
 #define RK_FASTQ_CAP 16        /* more records than a block of this size is sized for (records of under 64 bytes on average) */
 int rk_fastq_slot_create(rk_ctx* ctx, uint64_t max_bytes, rk_fastq_slot** out);
 uint8_t* rk_fastq_slot_text(rk_fastq_slot* slot);  /* page-locked buffer of max_bytes: the caller fills it with the block's text */
+/* ... or names the text where it lies: the slot's NEXT block (submit / classify / count) is uploaded from `text` -- caller memory,
+ * ideally page-locked (a mapping of the input file registered with hipHostRegister: the link reads the page cache, no copy), valid
+ * and unchanged until that block's finish / count has returned.  The formatters are given the same pointer. */
+int rk_fastq_slot_set_source(rk_fastq_slot* slot, const uint8_t* text);
+int rk_host_register_readonly(const void* p, size_t bytes);   /* hipHostRegister of memory that is only read (a file mapping) */
+void rk_host_unregister(const void* p);
 int rk_fastq_slot_classify(rk_fastq_slot* slot, uint64_t nbytes, rk_fastq_result* res);
 /* the same in two halves (classify = submit + finish): submit enqueues the upload and the splitting / checking / packing kernels and
  * returns at once, finish waits, classifies and collects -- a host thread with two slots reads its next block in between */
@@ -425,6 +431,14 @@ uint64_t rk_bgzf_text_offset(const rk_bgzf* z, int64_t member);
 int rk_bgzf_first_byte(const rk_bgzf* z);
 int64_t rk_bgzf_plan(const rk_bgzf* z, uint64_t target_bytes, int64_t* first, int64_t cap);
 int rk_bgzf_fastq_records(const rk_bgzf* z, int64_t b0, int64_t b1, uint8_t* dst, uint64_t cap, uint64_t* nbytes, uint64_t* text_off);
+const uint8_t* rk_bgzf_image(const rk_bgzf* z);   /* the mapped file */
+int rk_bgzf_member(const rk_bgzf* z, int64_t member, uint64_t* file_off, uint32_t* total_bytes, uint32_t* header_bytes, uint32_t* text_bytes);
+/* The same job inflated ON THE DEVICE (rk_inflate.hip: one wave per member, the text built in LDS): the compressed bytes cross the
+ * link instead of the text, the records that start in members [b0, b1) land in the slot's device text buffer and a copy of them in
+ * rk_fastq_slot_text() (for the output formatters); the NEXT rk_fastq_slot_submit / _classify / _count of the slot is given
+ * *nbytes and skips its upload.  Returns RK_OK, or 1: take the host route (rk_bgzf_fastq_records) for this job.  CRC-32 is not
+ * checked on this route (ISIZE and the four-line grammar are). */
+int rk_fastq_slot_load_bgzf(rk_fastq_slot* slot, const rk_bgzf* z, int64_t b0, int64_t b1, uint64_t* nbytes, uint64_t* text_off);
 
 #ifdef __cplusplus
 }

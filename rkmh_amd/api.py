@@ -107,6 +107,7 @@ _SIGS = {
     "rk_bgzf_first_byte": (C.c_int, [C.c_void_p]),
     "rk_bgzf_plan": (C.c_int64, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), C.c_int64]),
     "rk_bgzf_fastq_records": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rk_fastq_slot_load_bgzf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_counter_create_compact": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rk_counter_compact_entries": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rk_counter_entries": (C.c_uint64, [C.c_void_p]),
@@ -492,6 +493,15 @@ class FastqSlot:
     def text_buffer(self):
         """The slot's page-locked text buffer as a writable ctypes array (max_bytes + 64 bytes): os.preadv() into it."""
         return (C.c_char * (self.max_bytes + 64)).from_address(self._lib.rk_fastq_slot_text(self._h))
+
+    def load_bgzf(self, bz, b0, b1):
+        """Members [b0, b1) of a Bgzf file inflated on the device into this slot (rk_fastq_slot_load_bgzf) -> (status, nbytes, text
+        offset); status 1: take the host route.  Follow with classify_raw(nbytes) / count_raw(nbytes, counter)."""
+        n, off = C.c_uint64(), C.c_uint64()
+        rc = self._lib.rk_fastq_slot_load_bgzf(self._h, bz._h, b0, b1, C.byref(n), C.byref(off))
+        if rc < 0:
+            _chk(rc)
+        return rc, int(n.value), int(off.value)
 
     def classify_raw(self, nbytes):
         """rk_fastq_slot_classify on the first nbytes of text_buffer(); returns the FastqResult structure (valid until the next call)."""

@@ -229,8 +229,8 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
     block = max(4096, int(os.environ.get("RKMH_RAW_BLOCK_KB", "16384")) << 10)
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     nw = int(os.environ.get("RKMH_RAW_WORKERS", "0")) or max(2, min(6, ((os.cpu_count() or 8) * 3 // 8) // local_world))
-    if any(bz is not None for bz in bzs) and not os.environ.get("RKMH_RAW_WORKERS"):
-        nw = max(nw, min(32, ((os.cpu_count() or 8) - 2) // local_world))      # inflating is CPU work: all but two of the CPUs
+    if any(bz is not None for bz in bzs) and not os.environ.get("RKMH_RAW_WORKERS") and os.environ.get("RKMH_BGZF_DEVICE", "0") in ("", "0"):
+        nw = max(nw, min(32, ((os.cpu_count() or 8) - 2) // local_world))      # inflating on the host is CPU work: all but two of the CPUs
     fds = [os.open(p, os.O_RDONLY) for p in reads]
     sizes = [bz.members if bz is not None else os.fstat(fd).st_size for fd, bz in zip(fds, bzs)]
     slots, state = [], {"ok": True}
@@ -273,8 +273,14 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
                             if i >= len(blocks):
                                 return
                             s0, s1 = blocks[i]
-                            if bz is not None:      # members [s0, s1): inflated here, cut to the whole records that start in them
-                                st, n, _ = bz.fastq_records(s0, s1, C.addressof(buf), slot.max_bytes + 63)
+                            on_device = False
+                            if bz is not None:      # members [s0, s1): inflated on the device (rk_inflate.hip), else here; cut to the whole records that start in them
+                                st = 1
+                                if os.environ.get("RKMH_BGZF_DEVICE", "0") not in ("", "0"):      # opt-in: the host inflater is faster (profiles/r05_gz.txt)
+                                    st, n, _ = slot.load_bgzf(bz, s0, s1)
+                                    on_device = st == 0
+                                if st != 0:
+                                    st, n, _ = bz.fastq_records(s0, s1, C.addressof(buf), slot.max_bytes + 63)
                                 if st != 0:
                                     state["ok"] = False
                                     return
@@ -286,7 +292,7 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
                                         state["ok"] = False
                                         return
                                     got += k
-                            if s1 == size and n and mv[n - 1] != 10:
+                            if not on_device and s1 == size and n and mv[n - 1] != 10:
                                 mv[n] = 10          # a last line without its newline (the slot holds spare bytes)
                                 n += 1
                             if counter is not None:

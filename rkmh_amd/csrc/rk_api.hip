@@ -2242,6 +2242,15 @@ extern "C" int rk_host_alloc(size_t bytes, void** out) {
     if (e != hipSuccess) { *out = nullptr; return fail(RK_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
     return RK_OK;
 }
+// page-lock caller memory that is only read (a mapping of an input file): the DMA engines then read it in place
+extern "C" int rk_host_register_readonly(const void* p, size_t bytes) {
+    if (!p || !bytes) return fail(RK_ERR_ARG, "bad arguments");
+    hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterReadOnly);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault); }
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(RK_ERR_HIP, "hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+    return RK_OK;
+}
+extern "C" void rk_host_unregister(const void* p) { if (p) { hipError_t e = hipHostUnregister(const_cast<void*>(p)); (void)e; } }
 extern "C" void rk_host_free(void* p) { if (p) { hipError_t e = hipHostFree(p); (void)e; } }
 
 extern "C" int rk_classify_batch(rk_ctx* c, const uint8_t* bases, const uint64_t* offsets, int64_t nreads, int32_t* out4) {
@@ -2439,6 +2448,15 @@ struct rk_fastq_slot {
     FqDev d{};
     uint64_t pending = 0;   // bytes of the block between submit and finish
     bool submitted = false;
+    // BGZF members inflated on the device (rk_fastq_slot_load_bgzf): compressed bytes + member table up, text built in d_inf, the
+    // job's records moved to d_text -- the next submit / count then skips its upload (text_on_device)
+    PinBuf h_comp, h_mem;
+    DevBuf d_comp, d_mem, d_inf;
+    bool text_on_device = false;
+    // rk_fastq_slot_set_source: the block's text lies in caller memory (a page-locked mapping of the file): the next submit uploads it
+    // from there, and the slot reads the text there where it needs it on the host (rerouted reads)
+    const uint8_t* src = nullptr;      // of the block in flight (nullptr: h_text)
+    const uint8_t* next_src = nullptr; // armed for the next submit
 };
 
 extern "C" void rk_fastq_slot_destroy(rk_fastq_slot* s) {
@@ -2446,8 +2464,8 @@ extern "C" void rk_fastq_slot_destroy(rk_fastq_slot* s) {
     if (s->c) { hipError_t e = hipSetDevice(s->c->device); (void)e; }
     if (s->st) { hipError_t e = hipStreamSynchronize(s->st); (void)e; e = hipStreamDestroy(s->st); (void)e; }
     if (s->ev) { hipError_t e = hipEventDestroy(s->ev); (void)e; }
-    for (PinBuf* b : {&s->h_text, &s->h_out4, &s->h_spans, &s->h_info}) b->release();
-    for (DevBuf* b : {&s->d_text, &s->d_u32, &s->d_bases, &s->d_out4, &s->d_scan}) b->release();
+    for (PinBuf* b : {&s->h_text, &s->h_out4, &s->h_spans, &s->h_info, &s->h_comp, &s->h_mem}) b->release();
+    for (DevBuf* b : {&s->d_text, &s->d_u32, &s->d_bases, &s->d_out4, &s->d_scan, &s->d_comp, &s->d_mem, &s->d_inf}) b->release();
     delete s;
 }
 
@@ -2497,6 +2515,92 @@ extern "C" int rk_fastq_slot_create(rk_ctx* c, uint64_t max_bytes, rk_fastq_slot
 }
 
 extern "C" uint8_t* rk_fastq_slot_text(rk_fastq_slot* s) { return s ? s->h_text.as<uint8_t>() : nullptr; }
+// The NEXT block of this slot is read from `text` (caller memory that stays valid and unchanged until the block's finish / count
+// has returned) instead of the slot's own buffer: a page-locked mapping of the input file (mmap + hipHostRegister) lets the DMA
+// engine read the page cache itself -- no pread copy (tools/ubench/mmap_register.hip: 55 GB/s against 18-20 for one thread's pread + upload).
+extern "C" int rk_fastq_slot_set_source(rk_fastq_slot* s, const uint8_t* text) {
+    if (!s) return fail(RK_ERR_ARG, "slot is NULL");
+    s->next_src = text;
+    return RK_OK;
+}
+
+// A BGZF job inflated ON THE DEVICE (rk_inflate.hip): the compressed bytes of members [b0 - 1, b1 + 2) go up -- 0.58 x the text for
+// level-1 FASTQ --, one wave per member inflates them, the first record starts at or after the text of b0 and of b1 are found by
+// the four-line rule (k_fastq_first_start: the rule of rk_bgzf_fastq_records, so host-inflated and device-inflated jobs agree),
+// and the records between them are moved to the slot's text buffer; a copy travels back to rk_fastq_slot_text() for the output
+// formatters.  The NEXT rk_fastq_slot_submit / _classify / _count of this slot takes *nbytes and skips its upload.
+// Returns RK_OK, or 1: this job is for the host route (rk_bgzf_fastq_records) -- a member the device could not inflate, text that
+// does not begin with '@', a record that outgrows the lookahead or the slot.
+extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64_t b0, int64_t b1, uint64_t* nbytes, uint64_t* text_off) {
+    if (!s || !z || !nbytes || b0 < 0 || b1 <= b0 || b1 > rk_bgzf_members(z)) return fail(RK_ERR_ARG, "bad arguments");
+    *nbytes = 0;
+    s->text_on_device = false;
+    rk_ctx* c = s->c;
+    RKCHK(set_dev(c));
+    hipStream_t st = s->st;
+    const int64_t nb = rk_bgzf_members(z);
+    const int64_t lo = b0 > 0 ? b0 - 1 : 0, ext = std::min<int64_t>(nb, b1 + 2);
+    const uint32_t nm = (uint32_t)(ext - lo);
+    uint64_t f_lo = 0, f_hi = 0;
+    uint32_t tot = 0, hd = 0, us = 0;
+    RKCHK(rk_bgzf_member(z, lo, &f_lo, &tot, &hd, &us));
+    RKCHK(rk_bgzf_member(z, ext - 1, &f_hi, &tot, &hd, &us));
+    const uint64_t cbytes = f_hi + tot - f_lo;
+    const uint64_t u_lo = rk_bgzf_text_offset(z, lo), u_b0 = rk_bgzf_text_offset(z, b0), u_b1 = rk_bgzf_text_offset(z, b1), u_ext = rk_bgzf_text_offset(z, ext);
+    const uint64_t ntext = u_ext - u_lo;
+    if (text_off) *text_off = u_b0;
+    if (ntext > s->max_bytes + 4 * 65536ull || cbytes >= ((uint64_t)1 << 31)) return 1;
+    RKCHK(s->h_comp.reserve(cbytes + 64));
+    RKCHK(s->h_mem.reserve((size_t)nm * sizeof(InflateMember) + (size_t)nm * 4 + 64));
+    RKCHK(s->d_comp.reserve(cbytes + 64));
+    RKCHK(s->d_mem.reserve((size_t)nm * sizeof(InflateMember) + (size_t)nm * 4 + 64));
+    RKCHK(s->d_inf.reserve(s->max_bytes + 5 * 65536ull + 64));
+    memcpy(s->h_comp.p, rk_bgzf_image(z) + f_lo, cbytes);
+    memset(s->h_comp.as<uint8_t>() + cbytes, 0, 16);
+    InflateMember* mt = s->h_mem.as<InflateMember>();
+    for (uint32_t i = 0; i < nm; ++i) {
+        uint64_t fo = 0;
+        RKCHK(rk_bgzf_member(z, lo + i, &fo, &tot, &hd, &us));
+        mt[i].in_off = (uint32_t)(fo - f_lo) + hd; mt[i].in_len = tot - hd - 8;
+        mt[i].out_off = (uint32_t)(rk_bgzf_text_offset(z, lo + i) - u_lo); mt[i].out_len = us;
+    }
+    const size_t cpad = (cbytes + 15) & ~(size_t)15;
+    HIPCHK(hipMemcpyAsync(s->d_comp.p, s->h_comp.p, cpad, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->d_mem.p, mt, (size_t)nm * sizeof(InflateMember), hipMemcpyHostToDevice, st));
+    uint32_t* d_status = reinterpret_cast<uint32_t*>(s->d_mem.as<uint8_t>() + (((size_t)nm * sizeof(InflateMember) + 15) & ~(size_t)15));
+    uint32_t* h_status = reinterpret_cast<uint32_t*>(s->h_mem.as<uint8_t>() + (((size_t)nm * sizeof(InflateMember) + 15) & ~(size_t)15));
+    HIPCHK(launch_inflate_members(s->d_comp.as<uint8_t>(), (uint32_t)cpad, s->d_mem.as<InflateMember>(), nm, s->d_inf.as<uint8_t>(), d_status, st));
+    // the cuts: cuts[0] = head, cuts[1] = tail (in the inflated text of members lo .. ext)
+    uint32_t* d_cuts = s->d.info; // (the index kernels write it afterwards)
+    const bool at_eof = ext == nb;
+    if (b0 > 0) HIPCHK(launch_fastq_first_start(s->d_inf.as<uint8_t>(), (uint32_t)ntext, (uint32_t)(u_b0 - u_lo), 1u << 18, at_eof, d_cuts, 0, st));
+    if (b1 < nb) HIPCHK(launch_fastq_first_start(s->d_inf.as<uint8_t>(), (uint32_t)ntext, (uint32_t)(u_b1 - u_lo), 1u << 18, at_eof, d_cuts, 1, st));
+    uint32_t* h_info = s->h_info.as<uint32_t>();
+    HIPCHK(hipMemcpyAsync(h_info, d_cuts, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_status, d_status, (size_t)nm * 4, hipMemcpyDeviceToHost, st));
+    // (the first and the last byte of the text decide two small things on the host)
+    HIPCHK(hipMemcpyAsync(h_info + 2, s->d_inf.as<uint8_t>(), 1, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(h_info + 2) + 1, s->d_inf.as<uint8_t>() + (ntext ? ntext - 1 : 0), 1, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(s->ev, st));
+    HIPCHK(hipEventSynchronize(s->ev));
+    for (uint32_t i = 0; i < nm; ++i) if (h_status[i] != 0) return 1;
+    const uint8_t first_byte = reinterpret_cast<uint8_t*>(h_info + 2)[0], last_byte = reinterpret_cast<uint8_t*>(h_info + 2)[1];
+    uint64_t head = b0 > 0 ? h_info[0] : 0, tail = b1 < nb ? h_info[1] : ntext;
+    if (head == 0xFFFFFFFFull || tail == 0xFFFFFFFFull) return 1;
+    if (head > tail) head = tail;
+    if (b0 == 0 && tail > 0 && first_byte != '@') return 1;
+    uint64_t n = tail - head;
+    if (n + 1 > s->max_bytes) return 1;
+    if (text_off) *text_off = u_lo + head;
+    if (n == 0) return RK_OK;
+    HIPCHK(hipMemcpyAsync(s->d_text.p, s->d_inf.as<uint8_t>() + head, n, hipMemcpyDeviceToDevice, st));
+    if (b1 == nb && tail == ntext && last_byte != '\n') { HIPCHK(hipMemsetAsync(s->d_text.as<uint8_t>() + n, '\n', 1, st)); ++n; } // a last line without its newline
+    HIPCHK(hipMemsetAsync(s->d_text.as<uint8_t>() + n, 'A', 16, st)); // the index kernels read whole 16-byte pieces
+    HIPCHK(hipMemcpyAsync(s->h_text.p, s->d_text.p, n, hipMemcpyDeviceToHost, st)); // names, sequences and qualities for the formatters
+    s->text_on_device = true;
+    *nbytes = n;
+    return RK_OK;
+}
 
 // The two halves of rk_fastq_slot_classify, for callers that keep two slots per thread: submit() enqueues the upload and the
 // index / check / pack kernels and returns at once; finish() waits for them, launches the classification and collects the rows.
@@ -2510,9 +2614,17 @@ extern "C" int rk_fastq_slot_submit(rk_fastq_slot* s, uint64_t nbytes) {
     if (nbytes == 0) return RK_OK;
     RKCHK(set_dev(c));
     hipStream_t st = s->st;
-    uint8_t* text = s->h_text.as<uint8_t>();
-    memset(text + nbytes, 'A', 16); // the device reads whole 16-byte pieces
-    HIPCHK(hipMemcpyAsync(s->d_text.p, text, (nbytes + 15) & ~(uint64_t)15, hipMemcpyHostToDevice, st));
+    s->src = nullptr;
+    if (s->text_on_device) { s->text_on_device = false; s->next_src = nullptr; } // rk_fastq_slot_load_bgzf left this block's text in d_text (and on its way to h_text)
+    else if (s->next_src) { // straight from the caller's (page-locked) memory: no copy into the slot's buffer
+        s->src = s->next_src; s->next_src = nullptr;
+        HIPCHK(hipMemcpyAsync(s->d_text.p, s->src, nbytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(s->d_text.as<uint8_t>() + nbytes, 'A', 16, st)); // the device reads whole 16-byte pieces
+    } else {
+        uint8_t* text = s->h_text.as<uint8_t>();
+        memset(text + nbytes, 'A', 16); // the device reads whole 16-byte pieces
+        HIPCHK(hipMemcpyAsync(s->d_text.p, text, (nbytes + 15) & ~(uint64_t)15, hipMemcpyHostToDevice, st));
+    }
     HIPCHK(launch_fastq_index(s->d, s->d_text.as<uint8_t>(), nbytes, st));
     HIPCHK(hipMemcpyAsync(s->h_info.p, s->d.info, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(s->ev, st));
@@ -2528,7 +2640,7 @@ extern "C" int rk_fastq_slot_finish(rk_fastq_slot* s, rk_fastq_result* res) {
     if (s->pending == 0) return RK_OK;
     RKCHK(set_dev(c));
     hipStream_t st = s->st;
-    uint8_t* text = s->h_text.as<uint8_t>();
+    const uint8_t* text = s->src ? s->src : s->h_text.as<uint8_t>();
     uint32_t* info = s->h_info.as<uint32_t>();
     HIPCHK(hipEventSynchronize(s->ev));
     if (info[0] != 0) { res->status = (int32_t)info[0]; return RK_OK; } // not strictly four lines per record: the caller's scanner takes the block
@@ -2597,7 +2709,7 @@ extern "C" int rk_fastq_slot_count(rk_fastq_slot* s, uint64_t nbytes, rk_counter
         HIPCHK(hipMemcpyAsync(spans + nrec, s->d.seq_len, (size_t)nrec * 4, hipMemcpyDeviceToHost, s->st));
         HIPCHK(hipEventRecord(s->ev, s->st));
         HIPCHK(hipEventSynchronize(s->ev));
-        const uint8_t* text = s->h_text.as<uint8_t>();
+        const uint8_t* text = s->src ? s->src : s->h_text.as<uint8_t>();
         std::vector<uint64_t> offs((size_t)nrec + 1, 0);
         for (int64_t i = 0; i < nrec; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + spans[nrec + i];
         std::vector<uint8_t> sub((size_t)offs.back() + 16);

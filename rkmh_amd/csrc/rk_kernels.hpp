@@ -130,6 +130,11 @@ uint64_t fa_chunks(uint64_t nbytes);
 hipError_t launch_fasta_count(const FaDev& d, const uint8_t* raw, uint64_t nbytes, hipStream_t st);
 hipError_t launch_fasta_compact(const FaDev& d, const uint8_t* raw, uint64_t nbytes, uint64_t nrec, hipStream_t st);
 hipError_t launch_fasta_names(const FaDev& d, const uint8_t* raw, uint64_t nrec, hipStream_t st);
+// ---- DEFLATE on the device for BGZF members (rk_inflate.hip): one wave per member ----
+struct InflateMember { uint32_t in_off, in_len, out_off, out_len; }; // deflate payload in the compressed buffer; text in the output buffer
+hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint32_t* status, hipStream_t st);
+// cuts[which] = first FASTQ record start (four-line rule) at or after `from`; n: none and the text ends here; 0xFFFFFFFF: not decidable from this text
+hipError_t launch_fastq_first_start(const uint8_t* text, uint32_t n, uint32_t from, uint32_t window, bool at_eof, uint32_t* cuts, int which, hipStream_t st);
 // whole-array ascending sort of u64 keys in place (rk_sort.hip: rocPRIM radix sort); tmp holds sort_u64_temp_bytes(n) bytes
 hipError_t sort_u64_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t launch_sort_u64(uint64_t* keys, uint64_t n, void* tmp, size_t tmp_bytes, hipStream_t st);

@@ -1064,6 +1064,16 @@ void rk_bgzf_close(rk_bgzf* z) {
     delete z;
 }
 int64_t rk_bgzf_members(const rk_bgzf* z) { return z ? (int64_t)z->hlen.size() : 0; }
+// the file image and one member's place in it: bytes [*file_off, *file_off + *total) = header (*header bytes) + deflate stream + CRC-32 + ISIZE
+const uint8_t* rk_bgzf_image(const rk_bgzf* z) { return z ? z->map : nullptr; }
+int rk_bgzf_member(const rk_bgzf* z, int64_t m, uint64_t* file_off, uint32_t* total, uint32_t* header, uint32_t* text_bytes) {
+    if (!z || m < 0 || (size_t)m >= z->hlen.size()) return perr(RK_ERR_ARG, "bad arguments");
+    if (file_off) *file_off = z->coff[(size_t)m];
+    if (total) *total = (uint32_t)(z->coff[(size_t)m + 1] - z->coff[(size_t)m]);
+    if (header) *header = z->hlen[(size_t)m];
+    if (text_bytes) *text_bytes = (uint32_t)(z->uoff[(size_t)m + 1] - z->uoff[(size_t)m]);
+    return RK_OK;
+}
 uint64_t rk_bgzf_text_bytes(const rk_bgzf* z) { return z ? z->uoff.back() : 0; }
 uint64_t rk_bgzf_text_offset(const rk_bgzf* z, int64_t member) {
     if (!z || member < 0) return 0;

@@ -382,6 +382,10 @@ static int granted_cpus_main() {
 
 // BGZF (bgzip) read files found by raw_eligible: the device front end's workers inflate their members themselves (rk_bgzf_*)
 static std::map<std::string, rk_bgzf*> g_bgzf;
+// RKMH_BGZF_DEVICE=1: the members are inflated on the device (rk_inflate.hip).  Not the default: one wave per member decodes its
+// Huffman symbols serially with a 64 KB LDS window (two waves per CU): 2.6 GB/s of text on MI355X against 6.8 GB/s for fourteen
+// host threads with libdeflate (profiles/r05_gz.txt) -- the device needs ~10^4 members in flight, not the few hundred of a block.
+static bool bgzf_on_device() { static const bool on = getenv("RKMH_BGZF_DEVICE") && atoi(getenv("RKMH_BGZF_DEVICE")) != 0; return on; }
 static rk_bgzf* bgzf_of(const char* path) { auto it = g_bgzf.find(path); return it == g_bgzf.end() ? nullptr : it->second; }
 
 // a regular, uncompressed file that begins with '@' (FASTQ reads) / '>' (FASTA references) -- or, for reads, a BGZF file whose text
@@ -532,7 +536,8 @@ struct RawEngine {
         if (nw > cap) nw = cap;
         // BGZF input: a worker inflates its job's members before the upload (~1 GB/s of text per core with libdeflate, a third of
         // that with zlib) -- the CPUs, not the link, set the rate, so all but two of them work
-        if (!g_bgzf.empty()) nw = std::max<long>(nw, std::min<long>(32, granted_cpus_main() - 2));
+        // (inflated on the device -- the default -- the workers only copy the compressed bytes: two more than for plain text)
+        if (!g_bgzf.empty()) nw = bgzf_on_device() ? std::min<long>(cap, nw + 2) : std::max<long>(nw, std::min<long>(32, granted_cpus_main() - 2));
         if (const char* e = getenv("RKMH_RAW_WORKERS")) { long v = atol(e); if (v >= 1 && v <= 64) nw = v; }
         if ((size_t)nw < g.size()) nw = (long)g.size();
         if (const char* e = getenv("RKMH_RAW_SLOTS")) two_slots = atoi(e) == 2;
@@ -594,7 +599,17 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     if (kind == RAW_STREAM) CK(rk_line_parts_create(refs.names, refs.name_offsets, refs.nseq, o.sketch, o.min_matches, o.min_diff, &lp));
     const bool counting = kind == RAW_COUNT;
     rk_bgzf* const bz = bgzf_of(path); // compressed (BGZF): a job is a run of members [lo, hi), inflated by the worker that takes it
-    struct Job { int64_t seq = 0, lo = 0, hi = 0, at = 0; }; // at: where the job's first record starts in the (uncompressed) text
+    struct Job { int64_t seq = 0, lo = 0, hi = 0, at = 0; const uint8_t* ext = nullptr; }; // at: where the job's first record starts in the (uncompressed) text; ext: its text in the mapped file
+    // RKMH_RAW_MMAP=1: the file is mapped and the mapping page-locked (hipHostRegister): the link reads the page cache itself, the
+    // workers copy nothing (tools/ubench/mmap_register.hip)
+    const uint8_t* fmap = nullptr;
+    if (!bz && fsize > 0 && getenv("RKMH_RAW_MMAP") && atoi(getenv("RKMH_RAW_MMAP")) != 0) {
+        void* mp = mmap(nullptr, (size_t)fsize, PROT_READ, MAP_SHARED, fd, 0);
+        if (mp != MAP_FAILED) {
+            if (rk_host_register_readonly(mp, (size_t)fsize) == RK_OK) fmap = (const uint8_t*)mp;
+            else munmap(mp, (size_t)fsize);
+        }
+    }
     QueueT<Job> jobs;
     jobs.cap = eng.w.size();
     OrderedOut out;
@@ -630,8 +645,8 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                 out.lower_limit(jb.seq); // (before this block is parked: the sink cannot pass it)
                 int64_t curf = fail_seq.load();
                 while (jb.seq < curf && !fail_seq.compare_exchange_weak(curf, jb.seq)) {}
-            } else if (kind == RAW_FILTER) outlen = format_filter_raw(res, rk_fastq_slot_text(slot), o, buf);
-            else outlen = format_raw(lp, res, rk_fastq_slot_text(slot), buf);
+            } else if (kind == RAW_FILTER) outlen = format_filter_raw(res, jb.ext ? jb.ext : rk_fastq_slot_text(slot), o, buf);
+            else outlen = format_raw(lp, res, jb.ext ? jb.ext : rk_fastq_slot_text(slot), buf);
             t_dv += c - b; t_fm += now_s() - c; ++nblk; nrec_ += res.status == 0 ? res.nrec : 0;
             out.put(jb.seq, std::move(buf), outlen, window);
         };
@@ -646,11 +661,20 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                 bool refused = false; // (BGZF: text that does not begin with '@', or a job whose records outgrow the slot)
                 if (bz) {
                     uint64_t off = 0;
-                    const int rc = rk_bgzf_fastq_records(bz, cur.lo, cur.hi, text, eng.block + 63, &nbytes, &off);
+                    // the members inflated by this thread, or (RKMH_BGZF_DEVICE=1) on the device, which may hand a job back
+                    int rc = bgzf_on_device() ? rk_fastq_slot_load_bgzf(eng.w[wi].slot[k], bz, cur.lo, cur.hi, &nbytes, &off) : 1;
+                    if (rc < 0) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
+                    const bool on_device = rc == RK_OK;
+                    if (!on_device) rc = rk_bgzf_fastq_records(bz, cur.lo, cur.hi, text, eng.block + 63, &nbytes, &off);
                     cur.at = (int64_t)off;
                     if (rc == 1 || rc == RK_ERR_LIMIT) { refused = true; nbytes = 0; }
                     else if (rc != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
-                    if (cur.hi == rk_bgzf_members(bz) && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n';
+                    if (!on_device && cur.hi == rk_bgzf_members(bz) && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n';
+                } else if (fmap && !(cur.hi == fsize && fmap[fsize - 1] != '\n')) { // (a last block without its newline is copied, to get one)
+                    cur.at = cur.lo;
+                    cur.ext = fmap + cur.lo;
+                    nbytes = (uint64_t)(cur.hi - cur.lo);
+                    if (rk_fastq_slot_set_source(eng.w[wi].slot[k], cur.ext) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
                 } else {
                     cur.at = cur.lo;
                     int64_t have = 0;
@@ -751,6 +775,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     for (auto& t : workers) t.join();
     if (!counting) out.finish();
     rk_line_parts_destroy(lp);
+    if (fmap) { rk_host_unregister(fmap); munmap((void*)fmap, (size_t)fsize); }
     close(fd);
     if (out.failed) { fprintf(stderr, "rkmh: write error on standard output\n"); fail_exit(); }
     const int64_t fs = fail_seq.load();

@@ -427,6 +427,7 @@ def test_ranks_read_their_own_byte_range(root, data_dir, tmp_path):
     assert ranks(3, st + ["-f", str(bg), "-f", str(fq), "-M", "2"], {"RKMH_RAW_BLOCK_KB": "128"}) == one(st + ["-f", str(fq), "-f", str(fq), "-M", "2"])
     assert ranks(2, fl + ["-f", str(bg)], {"RKMH_RAW_BLOCK_KB": "512"}) == wf
     assert ranks(2, st + ["-f", str(bg)], {"RKMH_BGZF": "0"}) == want                # left to zlib: whole parse on every rank
+    assert ranks(2, st + ["-f", str(bg), "-M", "2"], {"RKMH_BGZF_DEVICE": "1", "RKMH_RAW_BLOCK_KB": "200"}) == one(st + ["-f", str(fq), "-M", "2"])   # inflated on the device
     # rank 0 alone reads the references (here forced through the device: rk_fasta_load_*), the others get names and sketches
     plain_ref = tmp_path / "pave.fa"
     plain_ref.write_bytes(gzip.open(ref).read())
@@ -483,7 +484,9 @@ def test_cli_bgzf_input_goes_through_the_device_front_end(root, data_dir, tmp_pa
         base = [cmd, "-r", ref, "-k", "16", "-s", "1000"] + flags
         want = _cli(root, base + ["-f", str(fq)])
         assert len(want) > 1000
-        for member, level, env in ((0xff00, 1, {}), (300, 6, {"RKMH_RAW_BLOCK_KB": "40"}), (20000, 6, {"RKMH_RAW_BLOCK_KB": "128", "RKMH_RAW_WORKERS": "3"})):
+        # (RKMH_BGZF_DEVICE=1: the members inflated on the device, rk_inflate.hip -- same bytes)
+        for member, level, env in ((0xff00, 1, {}), (300, 6, {"RKMH_RAW_BLOCK_KB": "40"}), (20000, 6, {"RKMH_RAW_BLOCK_KB": "128", "RKMH_RAW_WORKERS": "3"}),
+                                   (0xff00, 1, {"RKMH_BGZF_DEVICE": "1", "RKMH_RAW_BLOCK_KB": "2048"}), (20000, 6, {"RKMH_BGZF_DEVICE": "1", "RKMH_RAW_BLOCK_KB": "300"})):
             if cmd == "filter" and member == 300:
                 continue
             gz = tmp_path / ("reads_%d.fq.gz" % member)
@@ -513,3 +516,28 @@ def test_cli_bgzf_input_goes_through_the_device_front_end(root, data_dir, tmp_pa
     r = subprocess.run([exe] + base + ["-f", str(mixed_gz)], capture_output=True, env=dict(os.environ, RKMH_TIMING="1", RKMH_RAW_BLOCK_KB="256"))
     assert r.returncode == 0 and r.stdout == want_mixed
     assert b"not four lines per record" in r.stderr
+
+
+def test_cli_reads_from_a_registered_file_mapping(root, data_dir, tmp_path):
+    """RKMH_RAW_MMAP=1: the FASTQ file is mapped, the mapping page-locked and every block uploaded from the page cache where it lies
+    (rk_fastq_slot_set_source) -- same bytes out as with the workers' pread copies, for stream, stream -M 2, filter, several files,
+    small blocks and a file without its final newline (whose last block is copied)."""
+    from rkmh_amd import api, synth
+    refs = api.parse_files([os.path.join(data_dir, "all_pave_ref.fa.gz")])
+    n = 30000
+    qb, qo = synth.generate_reads_fast(refs["bases"], refs["offsets"], 0, n, read_len=150, threads=4)
+    reads = [bytes(qb[int(qo[i]):int(qo[i + 1])]) for i in range(n)]
+    text = _fastq(reads, names=[b"mm%07d x" % i for i in range(n)])
+    fq = tmp_path / "r.fq"
+    fq.write_bytes(text)
+    nonl = tmp_path / "nonl.fq"
+    nonl.write_bytes(text[:-1])
+    ref = os.path.join(data_dir, "all_pave_ref.fa.gz")
+    for cmd, flags in (("stream", []), ("stream", ["-M", "2"]), ("filter", ["-N", "3"])):
+        base = [cmd, "-r", ref, "-k", "16", "-s", "1000"] + flags
+        want = _cli(root, base + ["-f", str(fq)])
+        assert len(want) > 1000
+        for env in ({"RKMH_RAW_MMAP": "1"}, {"RKMH_RAW_MMAP": "1", "RKMH_RAW_BLOCK_KB": "96", "RKMH_RAW_WORKERS": "5"}):
+            assert _cli(root, base + ["-f", str(fq)], env=env) == want, (cmd, flags, env)
+        two = base + ["-f", str(nonl), "-f", str(fq)]      # (-M counts over both files: compare the same command with and without the mapping)
+        assert _cli(root, two, env={"RKMH_RAW_MMAP": "1", "RKMH_RAW_BLOCK_KB": "512"}) == _cli(root, two, env={"RKMH_RAW_BLOCK_KB": "512"})

@@ -66,10 +66,13 @@ def run(files, env=None):
     return best, lines, h.hexdigest(), stages
 
 
-for tag, files, reads in (("plain FASTQ", [fq], n), ("plain FASTQ x4", [fq] * 4, 4 * n), ("BGZF", [bg], n), ("BGZF x4", [bg] * 4, 4 * n),
-                          ("single-member gzip", [gz], min(gz_n, 1000000)), ("single-member gzip x4", [gz] * 4, 4 * min(gz_n, 1000000))):
-    dt, lines, dig, stages = run(files)
+for tag, files, reads, env in (("plain FASTQ", [fq], n, {}), ("plain FASTQ x4", [fq] * 4, 4 * n, {}),
+                               ("plain FASTQ, RKMH_RAW_MMAP=1", [fq], n, {"RKMH_RAW_MMAP": "1"}), ("plain FASTQ x4, RKMH_RAW_MMAP=1", [fq] * 4, 4 * n, {"RKMH_RAW_MMAP": "1"}),
+                               ("BGZF (device inflate)", [bg], n, {"RKMH_BGZF_DEVICE": "1"}), ("BGZF x4 (device inflate)", [bg] * 4, 4 * n, {"RKMH_BGZF_DEVICE": "1"}),
+                               ("BGZF (host inflate)", [bg], n, {}), ("BGZF x4 (host inflate)", [bg] * 4, 4 * n, {}),
+                               ("single-member gzip", [gz], min(gz_n, 1000000), {}), ("single-member gzip x4", [gz] * 4, 4 * min(gz_n, 1000000), {})):
+    dt, lines, dig, stages = run(files, env)
     assert lines == reads, (tag, lines, reads)
-    print("%-24s %9d reads  wall %.3f s  %.1f M reads/s whole process  sha %s" % (tag, reads, dt, reads / dt / 1e6, dig[:12]), flush=True)
+    print("%-34s %9d reads  wall %.3f s  %.1f M reads/s whole process  sha %s" % (tag, reads, dt, reads / dt / 1e6, dig[:12]), flush=True)
     for s in stages:
         print("    " + s.strip())
