@@ -2451,7 +2451,7 @@ struct rk_fastq_slot {
     // BGZF members inflated on the device (rk_fastq_slot_load_bgzf): compressed bytes + member table up, text built in d_inf, the
     // job's records moved to d_text -- the next submit / count then skips its upload (text_on_device)
     PinBuf h_comp, h_mem;
-    DevBuf d_comp, d_mem, d_inf;
+    DevBuf d_comp, d_mem, d_inf, d_match;
     bool text_on_device = false;
     // rk_fastq_slot_set_source: the block's text lies in caller memory (a page-locked mapping of the file): the next submit uploads it
     // from there, and the slot reads the text there where it needs it on the host (rerouted reads)
@@ -2465,7 +2465,7 @@ extern "C" void rk_fastq_slot_destroy(rk_fastq_slot* s) {
     if (s->st) { hipError_t e = hipStreamSynchronize(s->st); (void)e; e = hipStreamDestroy(s->st); (void)e; }
     if (s->ev) { hipError_t e = hipEventDestroy(s->ev); (void)e; }
     for (PinBuf* b : {&s->h_text, &s->h_out4, &s->h_spans, &s->h_info, &s->h_comp, &s->h_mem}) b->release();
-    for (DevBuf* b : {&s->d_text, &s->d_u32, &s->d_bases, &s->d_out4, &s->d_scan, &s->d_comp, &s->d_mem, &s->d_inf}) b->release();
+    for (DevBuf* b : {&s->d_text, &s->d_u32, &s->d_bases, &s->d_out4, &s->d_scan, &s->d_comp, &s->d_mem, &s->d_inf, &s->d_match}) b->release();
     delete s;
 }
 
@@ -2551,9 +2551,10 @@ extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64
     if (text_off) *text_off = u_b0;
     if (ntext > s->max_bytes + 4 * 65536ull || cbytes >= ((uint64_t)1 << 31)) return 1;
     RKCHK(s->h_comp.reserve(cbytes + 64));
-    RKCHK(s->h_mem.reserve((size_t)nm * sizeof(InflateMember) + (size_t)nm * 4 + 64));
+    RKCHK(s->h_mem.reserve((size_t)nm * sizeof(InflateMember) + (size_t)nm * 8 + 64));
     RKCHK(s->d_comp.reserve(cbytes + 64));
-    RKCHK(s->d_mem.reserve((size_t)nm * sizeof(InflateMember) + (size_t)nm * 4 + 64));
+    RKCHK(s->d_mem.reserve((size_t)nm * sizeof(InflateMember) + (size_t)nm * 8 + 64));
+    RKCHK(s->d_match.reserve((ntext / 3 + nm + 16) * sizeof(uint2)));
     RKCHK(s->d_inf.reserve(s->max_bytes + 5 * 65536ull + 64));
     memcpy(s->h_comp.p, rk_bgzf_image(z) + f_lo, cbytes);
     memset(s->h_comp.as<uint8_t>() + cbytes, 0, 16);
@@ -2563,13 +2564,14 @@ extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64
         RKCHK(rk_bgzf_member(z, lo + i, &fo, &tot, &hd, &us));
         mt[i].in_off = (uint32_t)(fo - f_lo) + hd; mt[i].in_len = tot - hd - 8;
         mt[i].out_off = (uint32_t)(rk_bgzf_text_offset(z, lo + i) - u_lo); mt[i].out_len = us;
+        mt[i].match_off = mt[i].out_off / 3u + i; mt[i].pad = 0; // (out_len / 3 + 1 entries each: the offsets of the members before it, summed)
     }
     const size_t cpad = (cbytes + 15) & ~(size_t)15;
     HIPCHK(hipMemcpyAsync(s->d_comp.p, s->h_comp.p, cpad, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(s->d_mem.p, mt, (size_t)nm * sizeof(InflateMember), hipMemcpyHostToDevice, st));
     uint32_t* d_status = reinterpret_cast<uint32_t*>(s->d_mem.as<uint8_t>() + (((size_t)nm * sizeof(InflateMember) + 15) & ~(size_t)15));
     uint32_t* h_status = reinterpret_cast<uint32_t*>(s->h_mem.as<uint8_t>() + (((size_t)nm * sizeof(InflateMember) + 15) & ~(size_t)15));
-    HIPCHK(launch_inflate_members(s->d_comp.as<uint8_t>(), (uint32_t)cpad, s->d_mem.as<InflateMember>(), nm, s->d_inf.as<uint8_t>(), d_status, st));
+    HIPCHK(launch_inflate_members(s->d_comp.as<uint8_t>(), (uint32_t)cpad, s->d_mem.as<InflateMember>(), nm, s->d_inf.as<uint8_t>(), s->d_match.as<uint2>(), d_status, st));
     // the cuts: cuts[0] = head, cuts[1] = tail (in the inflated text of members lo .. ext)
     uint32_t* d_cuts = s->d.info; // (the index kernels write it afterwards)
     const bool at_eof = ext == nb;

@@ -3,8 +3,11 @@
 // The reference opens every input with gzopen (/root/reference/src/rkmh.cpp:238-263): one sequential inflater.  A BGZF file is a chain
 // of INDEPENDENT gzip members of at most 64 KB of text each (SAM specification 4.1), thousands per block of the device FASTQ front
 // end -- so the block's compressed bytes cross the link (0.58 x the text for level-1 FASTQ) and ONE WAVE PER MEMBER inflates them:
-//   * the member's text is built in a 64 KB LDS window (a match copies from the window: 64 lanes, one ds_read / ds_write pair for
-//     up to 64 bytes) and written to HBM once, coalesced, when the member is done;
+//   * TWO PASSES.  Decoding the Huffman symbols needs the bit stream and the code tables, not the text: pass 1 (k_inflate_members) decodes
+//     with 8 KB of LDS per wave -- five waves per SIMD hide each other's table and refill latencies --, stores every literal at its final
+//     place in HBM and appends every match (position, length, distance) to the member's list; pass 2 (k_inflate_resolve) loads the
+//     member's text into a 64 KB LDS window, applies the matches in order (64 lanes per copy) and writes the member back.  A first
+//     version did both in one pass with the window in LDS: two waves per CU, 2.6 GB/s of text (profiles/r05_gz.txt);
 //   * the Huffman decode is the wave's serial part, executed uniformly by all lanes (no divergence, LDS table reads are
 //     broadcasts): one 10-bit lookup per symbol for codes of up to 10 bits, the canonical count / offset walk for the rare longer ones;
 //   * the compressed stream lives in registers, 8 bytes per lane (512 bytes per wave, the next 512 already requested): the bit
@@ -25,7 +28,6 @@ constexpr uint32_t WIN_BYTES = 65536;
 //   lit/len kind 0 literal (payload = byte), 1 length (payload = base | extra << 9), 2 end of block, 3 invalid
 //   dist    payload = base | extra << 16
 struct InfLds {
-    uint8_t win[WIN_BYTES];
     uint32_t lit[1 << LIT_BITS];
     uint32_t dist[1 << DIST_BITS];
     uint16_t lsym[288], dsym[32];   // symbols sorted by (code length, symbol): the canonical walk for long codes
@@ -155,14 +157,17 @@ __device__ __forceinline__ int walk_long(InStream& in, const uint16_t* count, co
 
 // status[m]: 0 ok, else the member could not be inflated (nothing of the job is used)
 __global__ __launch_bounds__(IW) void k_inflate_members(const uint8_t* __restrict__ comp, uint32_t comp_bytes, const InflateMember* __restrict__ mem, uint32_t nmem,
-                                                        uint8_t* __restrict__ text, uint32_t* __restrict__ status) {
+                                                        uint8_t* __restrict__ text, uint2* __restrict__ matches, uint32_t* __restrict__ status) {
     __shared__ InfLds L;
     const int lane = threadIdx.x;
     const uint32_t m = blockIdx.x;
     if (m >= nmem) return;
     const InflateMember me = mem[m];
     uint32_t bad = 0;
-    uint32_t op = 0;
+    uint32_t op = 0, nmatch = 0;
+    uint8_t* const dst = text + me.out_off;
+    uint2* const ml = matches + me.match_off;
+    const uint32_t match_cap = me.out_len / 3u + 1u; // (a match is at least three bytes)
     if (me.out_len > WIN_BYTES) bad = 1;
     InStream in;
     in.start(comp, comp_bytes & ~7u, me.in_off, lane);
@@ -178,9 +183,8 @@ __global__ __launch_bounds__(IW) void k_inflate_members(const uint8_t* __restric
             const uint32_t len = (uint32_t)comp[p] | ((uint32_t)comp[p + 1] << 8), nlen = (uint32_t)comp[p + 2] | ((uint32_t)comp[p + 3] << 8);
             p += 4u;
             if ((len ^ 0xFFFFu) != nlen || p + len > in_end || op + len > me.out_len) { bad = 3; break; }
-            for (uint32_t i = (uint32_t)lane; i < len; i += IW) L.win[op + i] = comp[p + i];
+            for (uint32_t i = (uint32_t)lane; i < len; i += IW) dst[op + i] = comp[p + i];
             op += len;
-            isync();
             in.seek(p + len);
             continue;
         }
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(IW) void k_inflate_members(const uint8_t* __restric
             }
             if (kind == 0u) {
                 if (op >= me.out_len) { bad = 16; break; }
-                if (lane == 0) L.win[op] = (uint8_t)payload;
+                if (lane == 0) dst[op] = (uint8_t)payload;
                 ++op;
                 continue;
             }
@@ -273,41 +277,65 @@ __global__ __launch_bounds__(IW) void k_inflate_members(const uint8_t* __restric
             }
             in.refill();
             const uint32_t dist = dbase + in.take(dext);
-            if (dist > op || op + len > me.out_len) { bad = 20; break; }
-            // the copy: 64 bytes per step; a source that overlaps the destination (dist < len) repeats with period dist
-            if (dist >= len || dist >= (uint32_t)IW) {
-                for (uint32_t i0 = 0; i0 < len; i0 += IW) { // (dist >= 64: a step's 64 source bytes were all written before it)
-                    const uint32_t i = i0 + (uint32_t)lane;
-                    uint8_t v = 0;
-                    if (i < len) v = L.win[op - dist + i];
-                    isync();
-                    if (i < len) L.win[op + i] = v;
-                    isync();
-                }
-            } else {
-                for (uint32_t i = (uint32_t)lane; i < len; i += IW) L.win[op + i] = L.win[op - dist + i % dist];
-                isync();
-            }
+            if (dist > op || op + len > me.out_len || nmatch >= match_cap) { bad = 20; break; }
+            if (lane == 0) ml[nmatch] = make_uint2(op, len | (dist << 16)); // resolved by pass 2, in order
+            ++nmatch;
             op += len;
         }
     }
     if (!bad && op != me.out_len) bad = 21;
-    isync();
-    if (!bad) {
-        // the window to HBM: 4 bytes per lane and step where the destination is aligned, bytes at the ends
-        uint8_t* dst = text + me.out_off;
-        const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u) < op ? (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u) : op;
-        if ((uint32_t)lane < head) dst[lane] = L.win[lane];
-        const uint32_t nd = (op - head) >> 2;
-        for (uint32_t i = (uint32_t)lane; i < nd; i += IW) {
-            const uint32_t o = head + 4u * i;
-            const uint32_t v = (uint32_t)L.win[o] | ((uint32_t)L.win[o + 1] << 8) | ((uint32_t)L.win[o + 2] << 16) | ((uint32_t)L.win[o + 3] << 24);
-            *reinterpret_cast<uint32_t*>(dst + o) = v;
-        }
-        const uint32_t done = head + 4u * nd;
-        if ((uint32_t)lane < op - done) dst[done + lane] = L.win[done + lane];
+    if (lane == 0) { status[m] = bad; status[nmem + m] = bad ? 0u : nmatch; }
+}
+
+// pass 2: the member's matches applied in order inside a 64 KB LDS window (a match may copy what an earlier match wrote)
+__global__ __launch_bounds__(IW) void k_inflate_resolve(const InflateMember* __restrict__ mem, uint32_t nmem, uint8_t* __restrict__ text, const uint2* __restrict__ matches,
+                                                        const uint32_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t win[WIN_BYTES];
+    const int lane = threadIdx.x;
+    const uint32_t m = blockIdx.x;
+    if (m >= nmem) return;
+    const uint32_t nmatch = status[nmem + m];
+    if (status[m] != 0u || nmatch == 0u) return; // (no matches: the literals are the text)
+    const InflateMember me = mem[m];
+    uint8_t* const dst = text + me.out_off;
+    const uint32_t n = me.out_len;
+    // the text so far (literals in place, holes where matches go): 4 bytes per lane where the address allows
+    const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u) < n ? (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u) : n;
+    const uint32_t nd = (n - head) >> 2, done = head + 4u * nd;
+    if ((uint32_t)lane < head) win[lane] = dst[lane];
+    for (uint32_t i = (uint32_t)lane; i < nd; i += IW) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(dst + head + 4u * i);
+        const uint32_t o = head + 4u * i;
+        win[o] = (uint8_t)v; win[o + 1] = (uint8_t)(v >> 8); win[o + 2] = (uint8_t)(v >> 16); win[o + 3] = (uint8_t)(v >> 24);
     }
-    if (lane == 0) status[m] = bad;
+    if ((uint32_t)lane < n - done) win[done + lane] = dst[done + lane];
+    isync();
+    const uint2* ml = matches + me.match_off;
+    uint2 nx = ml[0];
+    for (uint32_t q = 0; q < nmatch; ++q) {
+        const uint2 e = nx;
+        if (q + 1u < nmatch) nx = ml[q + 1u]; // (the next entry travels while this one is copied)
+        const uint32_t op = e.x, len = e.y & 0xFFFFu, dist = e.y >> 16;
+        if (dist >= len || dist >= (uint32_t)IW) {
+            for (uint32_t i0 = 0; i0 < len; i0 += IW) { // (dist >= 64: a step's 64 source bytes were all written before it)
+                const uint32_t i = i0 + (uint32_t)lane;
+                uint8_t v = 0;
+                if (i < len) v = win[op - dist + i];
+                isync();
+                if (i < len) win[op + i] = v;
+                isync();
+            }
+        } else { // the source overlaps the destination: it repeats with period dist
+            for (uint32_t i = (uint32_t)lane; i < len; i += IW) win[op + i] = win[op - dist + i % dist];
+            isync();
+        }
+    }
+    if ((uint32_t)lane < head) dst[lane] = win[lane];
+    for (uint32_t i = (uint32_t)lane; i < nd; i += IW) {
+        const uint32_t o = head + 4u * i;
+        *reinterpret_cast<uint32_t*>(dst + o) = (uint32_t)win[o] | ((uint32_t)win[o + 1] << 8) | ((uint32_t)win[o + 2] << 16) | ((uint32_t)win[o + 3] << 24);
+    }
+    if ((uint32_t)lane < n - done) dst[done + lane] = win[done + lane];
 }
 
 // first record start (four-line rule, as find_record_start in rk_parse.cpp) at or after `from` in text[0 .. n): a line start p with
@@ -335,9 +363,11 @@ __global__ __launch_bounds__(256) void k_fastq_first_start(const uint8_t* __rest
     }
 }
 
-hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint32_t* status, hipStream_t st) {
+hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint2* matches, uint32_t* status,
+                                  hipStream_t st) {
     if (!nmem) return hipSuccess;
-    hipLaunchKernelGGL(k_inflate_members, dim3(nmem), dim3(IW), 0, st, comp, comp_bytes, mem, nmem, text, status);
+    hipLaunchKernelGGL(k_inflate_members, dim3(nmem), dim3(IW), 0, st, comp, comp_bytes, mem, nmem, text, matches, status);
+    hipLaunchKernelGGL(k_inflate_resolve, dim3(nmem), dim3(IW), 0, st, mem, nmem, text, matches, status);
     return hipGetLastError();
 }
 hipError_t launch_fastq_first_start(const uint8_t* text, uint32_t n, uint32_t from, uint32_t window, bool at_eof, uint32_t* cuts, int which, hipStream_t st) {
