@@ -156,7 +156,7 @@ struct rk_ctx {
     uint32_t nkeys = 0;                      // distinct sketch hashes = key ids of the index
     std::vector<uint64_t> h_keyhash;         // [nkeys] the hash of each key id (compact depth maps are laid out from it)
     uint64_t index_gen = 0;                  // bumped by every index build: compact depth maps belong to one index
-    DevBuf d_keepkey, d_km1m[KM_MAX_KS], d_km1cells[KM_MAX_KS];
+    DevBuf d_keepkey, d_kvm, d_km1m[KM_MAX_KS], d_km1cells[KM_MAX_KS];
     uint32_t km1_ncells[KM_MAX_KS] = {0}, km1_vmask[KM_MAX_KS] = {0};
     KmerSets ksets_m{};                      // ksets with km1 = the masked copies (valid while a bounded depth filter is set)
     // workspaces for the general path
@@ -209,7 +209,7 @@ extern "C" void rk_ctx_destroy(rk_ctx* c) {
     for (DevBuf* b : {&c->d_fpb, &c->d_base, &c->d_kv, &c->d_post, &c->d_pre, &c->d_keepbits, &c->d_kpost, &c->d_kbase, &c->d_kkeys, &c->d_kslots, &c->w_bases, &c->w_tiles, &c->w_hashes, &c->w_segoff,
                       &c->w_ids, &c->w_sk, &c->w_lens, &c->w_out, &c->w_misc, &c->w_sel, &c->w_selstate, &c->w_table, &c->w_gcount, &c->w_tail}) b->release();
     for (int j = 0; j < KM_MAX_KS; ++j) { c->d_kf4[j].release(); c->d_km1[j].release(); c->d_km1v[j].release(); c->d_km1m[j].release(); c->d_km1cells[j].release(); }
-    c->d_keepkey.release();
+    c->d_keepkey.release(); c->d_kvm.release();
     for (auto& s : c->slot) {
         s.h_bases.release(); s.h_offs.release(); s.h_out.release();
         s.d_bases.release(); s.d_offs.release(); s.d_out.release();
@@ -1882,6 +1882,9 @@ static int build_key_mask(rk_ctx* c) {
             c->ksets_m.km1[j] = c->d_km1m[(size_t)j].as<uint4>();
         }
     }
+    // the hash-space kernels: a copy of the key array with the verdict in each entry's fourth dword
+    RKCHK(c->d_kvm.reserve(((size_t)c->nkeys + 1) * 16));
+    HIPCHK(launch_kv_mask(c->ix.kv, c->nkeys, c->d_keepkey.as<uint32_t>(), c->d_kvm.as<uint4>(), c->st));
     HIPCHK(hipStreamSynchronize(c->st));
     c->ix.keepkey = c->d_keepkey.as<uint32_t>();
     return RK_OK;
@@ -2017,7 +2020,10 @@ static int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int6
     }
     RefIndex ix = c->ix;
     if (!bounded) ix.keepkey = nullptr;
-    else if (c->ksets_m.n >= 1) ix.km1 = c->ksets_m.km1[0]; // (the compile-time-k kernels read the first size's structures from ix)
+    else {
+        if (c->ksets_m.n >= 1) ix.km1 = c->ksets_m.km1[0]; // (the compile-time-k kernels read the first size's structures from ix)
+        ix.kv = c->d_kvm.as<uint4>();                       // (hash-space kernels: the key array with the mask's verdict in it)
+    }
     const int nmin_cap = bounded ? c->min_num_bound : 0x7fffffff;
     // classification with k-mer sizes the exact k-mer maps were enumerated for: the k-mer-space kernel (rk_kmer.hip); under a
     // bounded depth filter it reads the masked copies of the maps (a dropped key is a zero-hash k-mer there)

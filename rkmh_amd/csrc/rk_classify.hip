@@ -135,7 +135,8 @@ __device__ __forceinline__ void for_postings(const RefIndex& ix, uint32_t v, F f
 
 // full lookup: fingerprint scan (+ the bucket's first key id), then key and value of a matching key are fetched together;
 // `slot` returns the key id (a dense number unique to the sketch hash)
-__device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uint32_t& slot, uint32_t& val) {
+// dropped: the key's entry carries the -M mask's verdict (RefIndex::kv is then the masked copy, rk_set_depth_filter with a bounded min_num)
+__device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uint32_t& slot, uint32_t& val, bool& dropped) {
     const uint32_t fp = index_fp(h);
     uint32_t b = index_bucket(h, ix.bmask);
     for (;;) {
@@ -147,7 +148,7 @@ __device__ __forceinline__ bool index_lookup(const RefIndex& ix, uint64_t h, uin
             m &= m - 1u;
             const uint32_t s = id0 + q;
             const uint4 e = ix.kv[s]; // key and value in one 16-byte fetch from the dense (L2-resident) key array
-            if (e.x == (uint32_t)h && e.y == (uint32_t)(h >> 32)) { slot = s; val = e.z; return true; }
+            if (e.x == (uint32_t)h && e.y == (uint32_t)(h >> 32)) { slot = s; val = e.z; dropped = e.w != 0u; return true; }
         }
         if (!(f.x & IDX_OVF)) return false;
         b = (b + 1) & ix.bmask;
@@ -464,10 +465,11 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         };
         auto take_candidate = [&](uint64_t h, int t, uint32_t& m_tr, uint32_t& m_off) -> bool {
             uint32_t slot = 0, v = 0;
+            bool dropped = false;
             if RK_DBG(256) { slot = (uint32_t)h & 0xFFFFu; v = (uint32_t)(h >> 40) % 180u | (1u << 20); } else
-            if (!index_lookup(ix, h, slot, v)) return false; // re-reads the bucket (L1/L2 hit), then key + value together
-            // -M with a bounded min_num: the mask is applied per KEY (one bit per key id) -- a masked hash is 0 (rkmh.cpp:916)
-            if (ix.keepkey && !((ix.keepkey[slot >> 5] >> (slot & 31u)) & 1u)) { atomicAdd(&nzero[t], 1u); return false; }
+            if (!index_lookup(ix, h, slot, v, dropped)) return false; // re-reads the bucket (L1/L2 hit), then key + value together
+            // -M with a bounded min_num: the mask is applied per KEY (the verdict rides in the key's entry) -- a masked hash is 0 (rkmh.cpp:916)
+            if (dropped) { atomicAdd(&nzero[t], 1u); return false; }
             return apply_hit(slot, v, t, m_tr, m_off);
         };
         auto drain_queue = [&](uint32_t qn) {

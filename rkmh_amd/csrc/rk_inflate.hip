@@ -59,10 +59,13 @@ struct InStream {
     uint64_t bb;          // bit buffer
     uint32_t nb;          // valid bits in bb
     int lane;
+    // (the load is waited for HERE: with a load in flight the compiler's waits inside the symbol loop would also wait for every
+    // literal store before them -- a microsecond per symbol; a chunk is 512 bytes of input, about a kilobyte of text)
     __device__ __forceinline__ uint2 load_chunk(uint32_t off) const {
         const uint32_t o = off + 8u * (uint32_t)lane;
         uint2 v = make_uint2(0u, 0u);
         if (o + 8u <= limit) v = *reinterpret_cast<const uint2*>(src + o);
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
         return v;
     }
     __device__ __forceinline__ void start(const uint8_t* s, uint32_t lim, uint32_t first, int ln) {
@@ -311,23 +314,27 @@ __global__ __launch_bounds__(IW) void k_inflate_resolve(const InflateMember* __r
     if ((uint32_t)lane < n - done) win[done + lane] = dst[done + lane];
     isync();
     const uint2* ml = matches + me.match_off;
-    uint2 nx = ml[0];
-    for (uint32_t q = 0; q < nmatch; ++q) {
-        const uint2 e = nx;
-        if (q + 1u < nmatch) nx = ml[q + 1u]; // (the next entry travels while this one is copied)
-        const uint32_t op = e.x, len = e.y & 0xFFFFu, dist = e.y >> 16;
-        if (dist >= len || dist >= (uint32_t)IW) {
-            for (uint32_t i0 = 0; i0 < len; i0 += IW) { // (dist >= 64: a step's 64 source bytes were all written before it)
-                const uint32_t i = i0 + (uint32_t)lane;
-                uint8_t v = 0;
-                if (i < len) v = win[op - dist + i];
-                isync();
-                if (i < len) win[op + i] = v;
+    for (uint32_t q0 = 0; q0 < nmatch; q0 += IW) { // 64 entries per load (one per lane), handed round by v_readlane
+        uint2 mine = make_uint2(0u, 0u);
+        if (q0 + (uint32_t)lane < nmatch) mine = ml[q0 + (uint32_t)lane];
+        const uint32_t cnt = nmatch - q0 < (uint32_t)IW ? nmatch - q0 : (uint32_t)IW;
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t op = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, (int)__builtin_amdgcn_readfirstlane((int)j));
+            const uint32_t ld = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, (int)__builtin_amdgcn_readfirstlane((int)j));
+            const uint32_t len = ld & 0xFFFFu, dist = ld >> 16;
+            if (dist >= len || dist >= (uint32_t)IW) {
+                for (uint32_t i0 = 0; i0 < len; i0 += IW) { // (dist >= 64: a step's 64 source bytes were all written before it)
+                    const uint32_t i = i0 + (uint32_t)lane;
+                    uint8_t v = 0;
+                    if (i < len) v = win[op - dist + i];
+                    isync();
+                    if (i < len) win[op + i] = v;
+                    isync();
+                }
+            } else { // the source overlaps the destination: it repeats with period dist
+                for (uint32_t i = (uint32_t)lane; i < len; i += IW) win[op + i] = win[op - dist + i % dist];
                 isync();
             }
-        } else { // the source overlaps the destination: it repeats with period dist
-            for (uint32_t i = (uint32_t)lane; i < len; i += IW) win[op + i] = win[op - dist + i % dist];
-            isync();
         }
     }
     if ((uint32_t)lane < head) dst[lane] = win[lane];

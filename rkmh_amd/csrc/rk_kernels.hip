@@ -386,6 +386,19 @@ __global__ __launch_bounds__(256) void k_km1_mask(const uint2* __restrict__ cell
     if (e.y == IDX_NOT_FOUND) return;
     if (!((keepkey[e.y >> 5] >> (e.y & 31u)) & 1u)) km1m[e.x] = (km1m[e.x] & ~vmask) | (vmask - 1u);
 }
+// the key array of the hash-space kernels with the mask folded in: kvm[j].w = 1 for a key the mask drops (the drain loads kv[j]
+// anyway to verify a hit: no further load for the keep bit)
+__global__ __launch_bounds__(256) void k_kv_mask(const uint4* __restrict__ kv, uint32_t nkeys, const uint32_t* __restrict__ keepkey, uint4* __restrict__ kvm) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nkeys) return; // (the array holds nkeys + 1 entries)
+    uint4 e = kv[j];
+    e.w = (j < nkeys && !((keepkey[j >> 5] >> (j & 31u)) & 1u)) ? 1u : 0u;
+    kvm[j] = e;
+}
+hipError_t launch_kv_mask(const uint4* kv, uint32_t nkeys, const uint32_t* keepkey, uint4* kvm, hipStream_t st) {
+    hipLaunchKernelGGL(k_kv_mask, dim3((nkeys + 256u) / 256u), dim3(256), 0, st, kv, nkeys, keepkey, kvm);
+    return hipGetLastError();
+}
 hipError_t launch_km1_mask(const uint2* cells, uint32_t n, const uint32_t* keepkey, uint32_t* km1m, uint32_t vmask, hipStream_t st) {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(k_km1_mask, dim3((n + 255u) / 256u), dim3(256), 0, st, cells, n, keepkey, km1m, vmask);

@@ -145,6 +145,7 @@ hipError_t launch_keep_bits(const int32_t* counter, uint64_t slots, int min_occ,
 // -M with a bounded min_num: keep bit per index key, the masked copy of the exact k-mer map, min(min_num, bound) per read
 hipError_t launch_keep_keys(const RefIndex& ix, uint32_t nkeys, const int32_t* counter, uint64_t slots, const uint32_t* key_sid, int min_occ,
                             const DevPolicy& pol, uint32_t* bits, hipStream_t st);
+hipError_t launch_kv_mask(const uint4* kv, uint32_t nkeys, const uint32_t* keepkey, uint4* kvm, hipStream_t st);
 hipError_t launch_km1_mask(const uint2* cells, uint32_t n, const uint32_t* keepkey, uint32_t* km1m, uint32_t vmask, hipStream_t st);
 hipError_t launch_min_num_probe(const uint8_t* bases, const uint32_t* offs, uint32_t nreads, const KsArr& ks, int S, int bound,
                                 const uint32_t* keepbits, uint64_t slots, const DevPolicy& pol, int32_t* out4, hipStream_t st);
