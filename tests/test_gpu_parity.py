@@ -1134,6 +1134,36 @@ def test_randomized_differential(orc, seed):
             want = orc.classify_stream(qb, qo, ks, S, sk, ln, pol, threads=4, min_kmer_occ=2, counter_slots=slots)
             bad = np.nonzero((got != want).any(axis=1))[0]
             assert len(bad) == 0, ("-M", seed, ks, S, bad[:5], got[bad[:5]], want[bad[:5]])
+            # the bounded forms (rk_set_min_num_bound): the mask per index key, min_num clamped -- and, at bound 0, the compact depth
+            # map, which must either equal the full table's verdicts or refuse the batch because a read outgrows the sketch
+            for bound in (0, int(rng.integers(1, 7))):
+                c.set_min_num_bound(bound)
+                c.set_depth_filter(cnt, 2)
+                got = c.classify(_pad(qb), qo)
+                c.set_depth_filter(None, 0)
+                w = want.copy()
+                w[:, 3] = np.minimum(w[:, 3], bound)
+                bad = np.nonzero((got != w).any(axis=1))[0]
+                assert len(bad) == 0, ("-M bounded", seed, ks, S, bound, bad[:5], got[bad[:5]], w[bad[:5]])
+            c.set_min_num_bound(0)
+            comp = rkmh_amd.Counter(c, slots=slots, compact=True)
+            nwin = max([sum(max(0, len(r) - k + 1 - drop) for k in ks) for r in reads] + [0])
+            try:
+                c.count_batch(_pad(qb), qo, comp)
+                refused = False
+            except rkmh_amd.api.NeedFullDepthMap:
+                refused = True
+            assert refused == (nwin > S or max(len(r) for r in reads) > 1528), (seed, nwin, S)
+            if not refused:
+                c.set_depth_filter(comp, 2)
+                got = c.classify(_pad(qb), qo)
+                c.set_depth_filter(None, 0)
+                w = want.copy()
+                w[:, 3] = 0
+                bad = np.nonzero((got != w).any(axis=1))[0]
+                assert len(bad) == 0, ("-M compact", seed, ks, S, bad[:5], got[bad[:5]], w[bad[:5]])
+            comp.destroy()
+            c.set_min_num_bound(-1)
             cnt.destroy()
         if seed % 4 == 0:                                     # pass 1 in both device forms (rk_count.hip): identical tables
             import torch
