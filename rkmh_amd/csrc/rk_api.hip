@@ -2538,6 +2538,10 @@ extern "C" int rk_fastq_slot_set_source(rk_fastq_slot* s, const uint8_t* text) {
 // Returns RK_OK, or 1: this job is for the host route (rk_bgzf_fastq_records) -- a member the device could not inflate, text that
 // does not begin with '@', a record that outgrows the lookahead or the slot.
 extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64_t b0, int64_t b1, uint64_t* nbytes, uint64_t* text_off) {
+    static const bool timing = getenv("RKMH_BGZF_TIMING") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+
     if (!s || !z || !nbytes || b0 < 0 || b1 <= b0 || b1 > rk_bgzf_members(z)) return fail(RK_ERR_ARG, "bad arguments");
     *nbytes = 0;
     s->text_on_device = false;
@@ -2556,28 +2560,35 @@ extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64
     const uint64_t ntext = u_ext - u_lo;
     if (text_off) *text_off = u_b0;
     if (ntext > s->max_bytes + 4 * 65536ull || cbytes >= ((uint64_t)1 << 31)) return 1;
-    RKCHK(s->h_comp.reserve(cbytes + 64));
-    RKCHK(s->h_mem.reserve((size_t)nm * sizeof(InflateMember) + (size_t)nm * 8 + 64));
-    RKCHK(s->d_comp.reserve(cbytes + 64));
-    RKCHK(s->d_mem.reserve((size_t)nm * sizeof(InflateMember) + (size_t)nm * 8 + 64));
-    RKCHK(s->d_match.reserve((ntext / 3 + nm + 16) * sizeof(uint2)));
-    RKCHK(s->d_inf.reserve(s->max_bytes + 5 * 65536ull + 64));
+    // (sized for the slot, not for this job: growing a page-locked buffer by a few kilobytes per job costs ~100 ms each time, and
+    // every job of a file is a little different -- 5/8 of the text covers level-1 FASTQ, a member is at most 64 KB of text)
+    const uint64_t cap_text = s->max_bytes + 5 * 65536ull + 64, cap_mem = std::max<uint64_t>(nm, cap_text / 32768 + 16);
+    RKCHK(s->h_comp.reserve(std::max<uint64_t>(cbytes + 160, cap_text * 5 / 8)));
+    RKCHK(s->h_mem.reserve((size_t)cap_mem * sizeof(InflateMember) + (size_t)cap_mem * 8 + 64));
+    RKCHK(s->d_comp.reserve(std::max<uint64_t>(cbytes + 160, cap_text * 5 / 8)));
+    RKCHK(s->d_mem.reserve((size_t)cap_mem * sizeof(InflateMember) + (size_t)cap_mem * 8 + 64));
+    RKCHK(s->d_inf.reserve(cap_text));
+    const double t_reserve = ms_since(t_0);
     memcpy(s->h_comp.p, rk_bgzf_image(z) + f_lo, cbytes);
-    memset(s->h_comp.as<uint8_t>() + cbytes, 0, 16);
+    const double t_copy = ms_since(t_0);
+    memset(s->h_comp.as<uint8_t>() + cbytes, 0, 80);
     InflateMember* mt = s->h_mem.as<InflateMember>();
+    uint64_t scratch_dw = 0;
     for (uint32_t i = 0; i < nm; ++i) {
         uint64_t fo = 0;
         RKCHK(rk_bgzf_member(z, lo + i, &fo, &tot, &hd, &us));
         mt[i].in_off = (uint32_t)(fo - f_lo) + hd; mt[i].in_len = tot - hd - 8;
         mt[i].out_off = (uint32_t)(rk_bgzf_text_offset(z, lo + i) - u_lo); mt[i].out_len = us;
-        mt[i].match_off = mt[i].out_off / 3u + i; mt[i].pad = 0; // (out_len / 3 + 1 entries each: the offsets of the members before it, summed)
+        mt[i].match_off = (uint32_t)scratch_dw; mt[i].pad = 0;
+        scratch_dw += inflate_scratch_dwords(us);
     }
-    const size_t cpad = (cbytes + 15) & ~(size_t)15;
+    RKCHK(s->d_match.reserve(std::max<uint64_t>(scratch_dw * 4 + 64, cap_text * 5 / 2 + cap_mem * 32)));
+    const size_t cpad = ((cbytes + 15) & ~(size_t)15) + 64; // (the lanes of pass 1 request whole 16-byte pieces a little past their member)
     HIPCHK(hipMemcpyAsync(s->d_comp.p, s->h_comp.p, cpad, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(s->d_mem.p, mt, (size_t)nm * sizeof(InflateMember), hipMemcpyHostToDevice, st));
     uint32_t* d_status = reinterpret_cast<uint32_t*>(s->d_mem.as<uint8_t>() + (((size_t)nm * sizeof(InflateMember) + 15) & ~(size_t)15));
     uint32_t* h_status = reinterpret_cast<uint32_t*>(s->h_mem.as<uint8_t>() + (((size_t)nm * sizeof(InflateMember) + 15) & ~(size_t)15));
-    HIPCHK(launch_inflate_members(s->d_comp.as<uint8_t>(), (uint32_t)cpad, s->d_mem.as<InflateMember>(), nm, s->d_inf.as<uint8_t>(), s->d_match.as<uint2>(), d_status, st));
+    HIPCHK(launch_inflate_members(s->d_comp.as<uint8_t>(), (uint32_t)cpad, s->d_mem.as<InflateMember>(), nm, s->d_inf.as<uint8_t>(), s->d_match.as<uint32_t>(), d_status, st));
     // the cuts: cuts[0] = head, cuts[1] = tail (in the inflated text of members lo .. ext)
     uint32_t* d_cuts = s->d.info; // (the index kernels write it afterwards)
     const bool at_eof = ext == nb;
@@ -2590,7 +2601,10 @@ extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64
     HIPCHK(hipMemcpyAsync(h_info + 2, s->d_inf.as<uint8_t>(), 1, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(h_info + 2) + 1, s->d_inf.as<uint8_t>() + (ntext ? ntext - 1 : 0), 1, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(s->ev, st));
+    const double t_enq = ms_since(t_0);
     HIPCHK(hipEventSynchronize(s->ev));
+    if (timing) fprintf(stderr, "[bgzf device] %u members, %.1f MB in, %.1f MB text: reserve %.1f ms, copy %.1f, enqueue %.1f, wait %.1f\n", nm, cbytes / 1e6, ntext / 1e6,
+                        t_reserve, t_copy - t_reserve, t_enq - t_copy, ms_since(t_0) - t_enq);
     for (uint32_t i = 0; i < nm; ++i) if (h_status[i] != 0) return 1;
     const uint8_t first_byte = reinterpret_cast<uint8_t*>(h_info + 2)[0], last_byte = reinterpret_cast<uint8_t*>(h_info + 2)[1];
     uint64_t head = b0 > 0 ? h_info[0] : 0, tail = b1 < nb ? h_info[1] : ntext;

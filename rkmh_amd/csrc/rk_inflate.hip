@@ -1,17 +1,24 @@
 // rk_inflate.hip -- DEFLATE (RFC 1951) on the device, for BGZF members (gfx950, wave64).
 //
 // The reference opens every input with gzopen (/root/reference/src/rkmh.cpp:238-263): one sequential inflater.  A BGZF file is a chain
-// of INDEPENDENT gzip members of at most 64 KB of text each (SAM specification 4.1), thousands per block of the device FASTQ front
-// end -- so the block's compressed bytes cross the link (0.58 x the text for level-1 FASTQ) and ONE WAVE PER MEMBER inflates them:
-//   * TWO PASSES.  Decoding the Huffman symbols needs the bit stream and the code tables, not the text: pass 1 (k_inflate_members) decodes
-//     with 8 KB of LDS per wave -- five waves per SIMD hide each other's table and refill latencies --, stores every literal at its final
-//     place in HBM and appends every match (position, length, distance) to the member's list; pass 2 (k_inflate_resolve) loads the
-//     member's text into a 64 KB LDS window, applies the matches in order (64 lanes per copy) and writes the member back.  A first
-//     version did both in one pass with the window in LDS: two waves per CU, 2.6 GB/s of text (profiles/r05_gz.txt);
-//   * the Huffman decode is the wave's serial part, executed uniformly by all lanes (no divergence, LDS table reads are
-//     broadcasts): one 10-bit lookup per symbol for codes of up to 10 bits, the canonical count / offset walk for the rare longer ones;
-//   * the compressed stream lives in registers, 8 bytes per lane (512 bytes per wave, the next 512 already requested): the bit
-//     reader refills with two v_readlane, never from memory.
+// of INDEPENDENT gzip members of at most 64 KB of text each (SAM specification 4.1), about a thousand per block of the device FASTQ
+// front end -- so the block's compressed bytes cross the link (0.58 x the text for level-1 FASTQ) and the device inflates them:
+//   * pass 1, k_inflate_lanes: ONE LANE PER MEMBER.  Huffman decoding is a serial chain per stream; a wave that decodes one stream
+//     uniformly spends 64 lanes on it (the first version here: ~800 cycles per symbol, the chip's issue slots full at 3 GB/s of
+//     text, profiles/r05_gz.txt).  Here every lane runs its own stream: bit buffer, position and block state in registers, its code
+//     tables (9-bit literal/length root, 7-bit distance root, 16-bit entries), its input ring and its output rings in LDS, all
+//     arrays interleaved by lane.  What a lane produces is NOT text but (a) the member's literals as one packed byte stream and (b) a
+//     32-bit entry per match: run of literals before it (8 bits) | length (9) | distance - 1 (15); an entry of length 0 carries 255
+//     literals of a longer run, or the tail.
+//   * the wave's memory traffic is wave-uniform: a wait for a load is a wait for the whole wave, so no lane ever loads or stores
+//     inside the symbol loop.  Once per PERIOD (K_SYM symbol steps) every lane takes the 16 input bytes it requested one period
+//     earlier into its ring, flushes whole literal dwords and entries, and requests its next 16 bytes; a lane whose ring runs low or
+//     whose output rings fill idles until the next period.  Block headers are decoded a few steps per period by the lanes that are
+//     at one; a lane that needs code tables asks for them and the WAVE builds them (64 symbols at a time: codes by ballot ranks);
+//   * pass 2, k_inflate_place: one wave per member and a 64 KB LDS window.  Entries are taken 64 at a time: prefix sums give every
+//     literal run and match its place; the runs are copied from the literal stream (64 bytes per step), then the matches whose
+//     source lies before the batch -- most of them: a batch covers about a kilobyte -- are copied by one lane each, and the rest in
+//     order, 64 lanes per copy.
 // CRC-32 is NOT checked here (ISIZE and the stream's own end-of-block structure are); a damaged member almost surely breaks the
 // four-line grammar that the front end verifies next, and RKMH_BGZF_DEVICE=0 keeps the host inflater with its CRC check.
 #include "rk_kernels.hpp"
@@ -21,322 +28,475 @@ namespace rk {
 namespace {
 
 constexpr int IW = 64;
-constexpr int LIT_BITS = 10, DIST_BITS = 9;
+constexpr int LT = 9, DT = 7, CT = 7;         // root table bits: literal/length, distance, code-length code
+constexpr int LONG_CAP = 96, DLONG_CAP = 32;  // symbols with codes longer than the root (more: the member is the host's)
+constexpr int CL_AT = 320, LENS_N = 352;      // lens[0 .. 316): literal/length + distance code lengths; lens[320 .. 339): code-length code
+constexpr int IN_RING = 16, ENT_RING = 16, OUT_RING = 4; // dwords per lane
+constexpr int K_SYM = 8, K_HDR = 8;           // symbol steps / header steps (inside a header window) per period
+constexpr uint32_t HDR_EVERY = 64;            // periods between header windows (a power of two)
+constexpr int HDR_LANES = 12;                 // ... unless this many lanes wait
+constexpr uint32_t E_INVALID = 0x0FFFu;       // table entry: code length << 12 | symbol; length 0: E_INVALID, or a long code's prefix
 constexpr uint32_t WIN_BYTES = 65536;
 
-// table entry: bits 0..3 code length (0: longer than the table's bits -> canonical walk), 4..5 kind, 8.. payload
-//   lit/len kind 0 literal (payload = byte), 1 length (payload = base | extra << 9), 2 end of block, 3 invalid
-//   dist    payload = base | extra << 16
-struct InfLds {
-    uint32_t lit[1 << LIT_BITS];
-    uint32_t dist[1 << DIST_BITS];
-    uint16_t lsym[288], dsym[32];   // symbols sorted by (code length, symbol): the canonical walk for long codes
-    uint16_t lcount[16], dcount[16];
-    uint8_t lens[320];
-    uint32_t clt[128];              // code-length code table (<= 7 bits)
+__device__ const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// everything a wave of 64 streams keeps in LDS; arrays are [index][lane]
+struct LaneLds {
+    uint16_t lit[(1 << LT) * IW];
+    uint16_t dist[(1 << DT) * IW];
+    uint16_t lsort[LONG_CAP * IW], dsort[DLONG_CAP * IW]; // long-coded symbols in (length, symbol) order: the canonical walk
+    // per code length above the root's bits: left-justified 15-bit upper limit of its codes | (index in the sorted list - first code) << 16
+    uint32_t lwalk[8 * IW], dwalk[8 * IW];
+    uint32_t inr[IN_RING * IW];
+    uint32_t entr[(ENT_RING + 1) * IW]; // (one more row each: where a step's store goes that is not due)
+    uint32_t outr[(OUT_RING + 1) * IW];
+    uint8_t lens[LENS_N * IW];
+    uint8_t clorder[32];
 };
 
-__device__ const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__device__ const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-__device__ const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+enum : uint32_t { ST_BLOCK = 0, ST_STORED_HDR, ST_DYN_HDR, ST_CL_READ, ST_LENS, ST_WAIT, ST_SYM, ST_STORED, ST_DONE, ST_FIN };
 
 __device__ __forceinline__ void isync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ uint32_t bitrev(uint32_t v, int n) { return __builtin_bitreverse32(v) >> (32 - n); }
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t n) { return __builtin_bitreverse32(v) >> (32u - n); }
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m, int lane) { return (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); }
+__device__ __host__ __forceinline__ uint32_t entry_cap(uint32_t out_len) { return out_len / 3u + out_len / 255u + 4u; }
 
-// the compressed stream of one member in registers: A = bytes [base, base + 512), B = the next 512, 8 bytes per lane
-struct InStream {
-    const uint8_t* src;   // 8-byte aligned start (at or below the member's first payload byte)
-    uint32_t limit;       // bytes readable from src (whole 8-byte words inside the block's compressed buffer)
-    uint32_t base;        // offset of A in src
-    uint2 a, b;
-    uint32_t pos;         // next unread byte, relative to src
-    uint64_t bb;          // bit buffer
-    uint32_t nb;          // valid bits in bb
-    int lane;
-    // (the load is waited for HERE: with a load in flight the compiler's waits inside the symbol loop would also wait for every
-    // literal store before them -- a microsecond per symbol; a chunk is 512 bytes of input, about a kilobyte of text)
-    __device__ __forceinline__ uint2 load_chunk(uint32_t off) const {
-        const uint32_t o = off + 8u * (uint32_t)lane;
-        uint2 v = make_uint2(0u, 0u);
-        if (o + 8u <= limit) v = *reinterpret_cast<const uint2*>(src + o);
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-        return v;
+// The wave builds stream t's canonical Huffman table from lens[(at + s) * 64 + t], s < n: root table of 2^TB entries, counts per
+// length above the root (limit | offset, see LaneLds), the long-coded symbols in canonical order.  NCH = chunks of 64 symbols.  False: over-subscribed, or more long codes than cap.
+template <int TB, int NCH>
+__device__ bool coop_build(LaneLds& L, int t, int at, int n, uint16_t* tab, uint16_t* sorted, int cap, uint32_t* walk, int lane) {
+    uint32_t l[NCH], code_of[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int s = lane + IW * c;
+        l[c] = s < n ? L.lens[(at + s) * IW + t] : 0u;
+        code_of[c] = 0;
     }
-    __device__ __forceinline__ void start(const uint8_t* s, uint32_t lim, uint32_t first, int ln) {
-        src = s; limit = lim; lane = ln; base = first & ~511u;
-        a = load_chunk(base); b = load_chunk(base + 512u);
-        pos = first; bb = 0; nb = 0;
-    }
-    __device__ __forceinline__ uint32_t dword(uint32_t w) const { // dword w of A|B (0 .. 255), w wave-uniform
-        const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)((w >> 1) & 63u));
-        const bool hi = (w & 1u) != 0u, second = w >= 128u;
-        const uint32_t va = hi ? a.y : a.x, vb = hi ? b.y : b.x;
-        return (uint32_t)__builtin_amdgcn_readlane((int)(second ? vb : va), (int)l);
-    }
-    __device__ __forceinline__ void refill() { // afterwards nb >= 33 (while input lasts)
-        if (nb <= 32u) {
-            if (pos - base >= 512u) { a = b; base += 512u; b = load_chunk(base + 512u); }
-            const uint32_t r = pos - base, w = r >> 2, sh = (r & 3u) * 8u;
-            const uint32_t d0 = dword(w), d1 = dword(w + 1u);
-            const uint32_t v = sh ? (d0 >> sh) | (d1 << (32u - sh)) : d0;
-            bb |= (uint64_t)v << nb;
-            pos += 4u; nb += 32u;
-        }
-    }
-    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)bb & ((1u << n) - 1u); }
-    __device__ __forceinline__ void drop(uint32_t n) { bb >>= n; nb -= n; }
-    __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
-    // byte position of the next unread BIT's byte after aligning to a byte boundary
-    __device__ __forceinline__ uint32_t align_to_byte() { drop(nb & 7u); const uint32_t p = pos - (nb >> 3); bb = 0; nb = 0; return p; }
-    __device__ __forceinline__ void seek(uint32_t p) { pos = p; bb = 0; nb = 0; if (p - base >= 1024u || p < base) { base = p & ~511u; a = load_chunk(base); b = load_chunk(base + 512u); } }
-};
-
-// canonical Huffman tables from code lengths lens[0 .. n): table of 2^TB entries for codes of <= TB bits, count / sorted symbols for longer ones
-template <int TB, bool DIST>
-__device__ bool build_table(const uint8_t* lens, int n, uint32_t* tab, uint16_t* count, uint16_t* sorted, int lane) {
-    if (lane < 16) count[lane] = 0;
-    isync();
-    if (lane == 0) for (int s = 0; s < n; ++s) count[lens[s]]++;
-    isync();
-    // over-subscribed code -> invalid; (incomplete codes are legal for a single distance code)
+    for (int i = lane; i < (1 << TB); i += IW) tab[i * IW + t] = (uint16_t)E_INVALID;
+    if (walk && lane < 8) walk[lane * IW + t] = 0; // (limit 0: no code of that length)
+    uint32_t code = 0, longbase = 0;
     int left = 1;
-    uint32_t first[16], offs[16];
-    uint32_t code = 0, o = 0;
-    for (int l = 1; l <= 15; ++l) {
-        left = (left << 1) - (int)count[l];
-        if (left < 0) return false;
-        first[l] = code; offs[l] = o;
-        code = (code + count[l]) << 1; o += count[l];
-    }
-    for (int i = lane; i < (1 << TB); i += IW) tab[i] = 0x3u << 4; // invalid
-    isync();
-    // symbols in order: code(sym) = first[len]++ ; entry replicated over the unused high index bits
-    uint32_t next[16], noff[16];
+    bool ok = true;
+    for (uint32_t len = 1; len <= 15; ++len) {
+        uint32_t n_len = 0;
 #pragma unroll
-    for (int l = 0; l < 16; ++l) { next[l] = l ? first[l] : 0u; noff[l] = l ? offs[l] : 0u; }
-    for (int s = 0; s < n; ++s) {
-        const int l = lens[s];
-        if (l == 0) continue;
-        uint32_t c = 0, so = 0;
-#pragma unroll
-        for (int q = 1; q < 16; ++q) if (q == l) { c = next[q]++; so = noff[q]++; }
-        if (lane == 0) sorted[so] = (uint16_t)s;
-        if (l > TB) {
-            if (lane == 0) tab[bitrev(c >> (l - TB), TB)] = 0u; // (prefix of a long code: length 0 = walk)
-            continue;
+        for (int c = 0; c < NCH; ++c) {
+            const uint64_t m = __ballot(l[c] == len);
+            if (l[c] == len) code_of[c] = code + n_len + lanes_below(m, lane);
+            n_len += (uint32_t)__popcll(m);
         }
-        uint32_t e;
-        if (DIST) e = (uint32_t)l | ((uint32_t)DIST_BASE[s < 30 ? s : 0] << 8) | ((uint32_t)DIST_EXTRA[s < 30 ? s : 0] << 24) | (s >= 30 ? 0x30u : 0u);
-        else if (s < 256) e = (uint32_t)l | ((uint32_t)s << 8);
-        else if (s == 256) e = (uint32_t)l | (2u << 4);
-        else if (s < 286) e = (uint32_t)l | (1u << 4) | ((uint32_t)LEN_BASE[s - 257] << 8) | ((uint32_t)LEN_EXTRA[s - 257] << 17);
-        else e = (uint32_t)l | (3u << 4);
-        const uint32_t r = bitrev(c, l);
-        for (uint32_t j = (uint32_t)lane; j < (1u << (TB - l)); j += IW) tab[r | (j << l)] = e;
+        left = (left << 1) - (int)n_len;
+        if (left < 0) ok = false;
+        if (len > (uint32_t)TB) {
+            if (longbase + n_len > (uint32_t)cap) ok = false;
+            else {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if (l[c] == len) sorted[(longbase + code_of[c] - code) * IW + t] = (uint16_t)(lane + IW * c);
+            }
+            if (lane == 0 && walk) walk[(len - TB - 1) * IW + t] = ((code + n_len) << (15u - len)) | (((longbase - code) & 0xFFFFu) << 16);
+            longbase += n_len;
+        }
+        code = (code + n_len) << 1;
+    }
+    isync(); // (the invalid fill is in the table before the entries)
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint32_t len = l[c];
+            if (len == 0u) continue;
+            if (len <= (uint32_t)TB) {
+                const uint32_t e = (len << 12) | (uint32_t)(lane + IW * c);
+                for (uint32_t j = bitrev(code_of[c], len); j < (1u << TB); j += 1u << len) tab[j * IW + t] = (uint16_t)e;
+            } else {
+                tab[bitrev(code_of[c] >> (len - TB), TB) * IW + t] = 0; // a long code's prefix: length 0, not E_INVALID
+            }
+        }
     }
     isync();
-    return true;
+    return ok;
 }
 
-// a symbol whose code is longer than the table's bits: the canonical walk (puff.c), bit by bit from the stream
-__device__ __forceinline__ int walk_long(InStream& in, const uint16_t* count, const uint16_t* sorted) {
-    int code = 0, first = 0, index = 0;
-    for (int l = 1; l <= 15; ++l) {
-        code |= (int)in.take(1);
-        const int c = count[l];
-        if (code - c < first) return sorted[index + (code - first)];
-        index += c; first += c; first <<= 1; code <<= 1;
-    }
-    return -1;
-}
+struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };
 
 } // namespace
 
-// status[m]: 0 ok, else the member could not be inflated (nothing of the job is used)
-__global__ __launch_bounds__(IW) void k_inflate_members(const uint8_t* __restrict__ comp, uint32_t comp_bytes, const InflateMember* __restrict__ mem, uint32_t nmem,
-                                                        uint8_t* __restrict__ text, uint2* __restrict__ matches, uint32_t* __restrict__ status) {
-    __shared__ InfLds L;
+// Pass 1.  scratch: per member at dword me.match_off: entry_cap(out_len) entries, then the literal stream.
+// status[m]: 0 ok, else why the member is the host's; status[nmem + m] = its entries | its literals << 15.
+__global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict__ comp, uint32_t comp_bytes, const InflateMember* __restrict__ mem, uint32_t nmem,
+                                                      uint32_t* __restrict__ scratch, uint32_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t inflate_lds[];
+    LaneLds& L = *reinterpret_cast<LaneLds*>(inflate_lds);
     const int lane = threadIdx.x;
-    const uint32_t m = blockIdx.x;
-    if (m >= nmem) return;
-    const InflateMember me = mem[m];
-    uint32_t bad = 0;
-    uint32_t op = 0, nmatch = 0;
-    uint8_t* const dst = text + me.out_off;
-    uint2* const ml = matches + me.match_off;
-    const uint32_t match_cap = me.out_len / 3u + 1u; // (a match is at least three bytes)
-    if (me.out_len > WIN_BYTES) bad = 1;
-    InStream in;
-    in.start(comp, comp_bytes & ~7u, me.in_off, lane);
-    const uint32_t in_end = me.in_off + me.in_len;
-    bool final_block = false;
-    while (!bad && !final_block) {
-        in.refill();
-        final_block = in.take(1) != 0u;
-        const uint32_t type = in.take(2);
-        if (type == 0u) { // stored
-            uint32_t p = in.align_to_byte();
-            if (p + 4u > in_end) { bad = 2; break; }
-            const uint32_t len = (uint32_t)comp[p] | ((uint32_t)comp[p + 1] << 8), nlen = (uint32_t)comp[p + 2] | ((uint32_t)comp[p + 3] << 8);
-            p += 4u;
-            if ((len ^ 0xFFFFu) != nlen || p + len > in_end || op + len > me.out_len) { bad = 3; break; }
-            for (uint32_t i = (uint32_t)lane; i < len; i += IW) dst[op + i] = comp[p + i];
-            op += len;
-            in.seek(p + len);
-            continue;
+    const uint32_t m = blockIdx.x * IW + (uint32_t)lane;
+    const bool live = m < nmem;
+    if (lane < 19) L.clorder[lane] = CL_ORDER[lane];
+    InflateMember me = {0, 0, 0, 0, 0, 0};
+    if (live) me = mem[m];
+    const uint32_t w0 = me.in_off >> 2;
+    const uint32_t* const src = reinterpret_cast<const uint32_t*>(comp) + w0;
+    uint32_t in_lim = live ? ((me.in_off & 3u) + me.in_len + 32u + 3u) >> 2 : 0u; // dwords of this stream worth loading (footer and a little more: the caller's buffer has 64 bytes of slack)
+    { const uint32_t have = (comp_bytes >> 2) > w0 ? (comp_bytes >> 2) - w0 : 0u; if (in_lim > have) in_lim = have; }
+    in_lim &= ~3u; // (whole 16-byte requests; the 32 bytes above leave the deflate data and two more dwords inside them)
+    uint32_t* const ents = scratch + me.match_off;
+    uint32_t* const lits = ents + entry_cap(me.out_len);
+    uint64_t bb = 0;
+    uint32_t nb = 0, in_r = 0, in_w = 0;
+    uint32_t state = live ? ST_BLOCK : ST_FIN, bad = 0, need_build = 0;
+    if (live && me.out_len > WIN_BYTES) { bad = 1; state = ST_FIN; }
+    uint32_t op = 0, run = 0, lit_n = 0, lit_acc = 0, out_f = 0, out_target = 0, ent_w = 0, ent_f = 0;
+    uint32_t final_block = 0, nlit = 0, ndist = 0, ncl = 0, hi = 0, prev = 0, stored_left = 0;
+    Quad pend = {{0, 0, 0, 0}};
+    bool pending = live && in_lim >= 4u;
+    if (pending) pend = *reinterpret_cast<const Quad*>(src);
+    isync();
+
+    // the bit buffer is refilled from two dwords held in registers (taken from the ring one step ahead: no LDS latency in the chain)
+    uint32_t nx0 = 0, nx1 = 0, nav = 0;
+    auto refill = [&]() {
+        if (nb <= 32u && nav) { bb |= (uint64_t)nx0 << nb; nb += 32u; nx0 = nx1; --nav; }
+    };
+    auto topup = [&]() {
+        if (nav < 2u && in_r < in_w) {
+            const uint32_t at = (in_r & (IN_RING - 1)) * IW + lane;
+            if (nav == 0u) nx0 = L.inr[at]; else nx1 = L.inr[at];
+            ++nav; ++in_r;
         }
-        if (type == 3u) { bad = 4; break; }
-        int nlit = 288, ndist = 30;
-        if (type == 1u) { // fixed codes
-            for (int i = lane; i < 288; i += IW) L.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
-            if (lane < 30) L.lens[288 + lane] = 5;
-            isync();
-        } else { // dynamic: code length code, then the literal/length and distance code lengths
-            in.refill();
-            nlit = (int)in.take(5) + 257; ndist = (int)in.take(5) + 1;
-            const int ncl = (int)in.take(4) + 4;
-            if (nlit > 286 || ndist > 30) { bad = 5; break; }
-            if (lane < 19) L.lens[lane] = 0;
-            isync();
-            for (int i = 0; i < ncl; ++i) { in.refill(); const uint32_t v = in.take(3); if (lane == 0) L.lens[CL_ORDER[i]] = (uint8_t)v; }
-            isync();
-            // (the code-length table reuses the literal builder: symbols 0..18 as "literals")
-            if (!build_table<7, false>(L.lens, 19, L.clt, L.lcount, L.lsym, lane)) { bad = 6; break; }
-            int i = 0;
-            uint32_t prev = 0;
-            // the lengths go to lens[32 ..) while lens[0..19) still holds the code-length code
-            uint8_t* out = L.lens;
-            uint8_t tmp_prev = 0;
-            (void)tmp_prev;
-            // decode into registers-free LDS area: first pass writes to a second array -- the builder's input is read before it is
-            // overwritten because the table above is complete
-            while (i < nlit + ndist && !bad) {
-                in.refill();
-                const uint32_t e = L.clt[in.peek(7)];
-                const uint32_t l = e & 15u;
-                if (l == 0u || ((e >> 4) & 3u) == 3u) { bad = 7; break; }
-                in.drop(l);
-                const uint32_t sym = e >> 8;
-                if (sym < 16u) { if (lane == 0) out[i] = (uint8_t)sym; prev = sym; ++i; }
-                else {
-                    uint32_t rep, val = 0;
-                    if (sym == 16u) { if (i == 0) { bad = 8; break; } rep = 3u + in.take(2); val = prev; }
-                    else if (sym == 17u) { rep = 3u + in.take(3); prev = 0; }
-                    else { rep = 11u + in.take(7); prev = 0; }
-                    if (i + (int)rep > nlit + ndist) { bad = 9; break; }
-                    for (uint32_t j = (uint32_t)lane; j < rep; j += IW) out[i + (int)j] = (uint8_t)val;
-                    i += (int)rep;
+    };
+    auto take = [&](uint32_t n) { const uint32_t v = (uint32_t)bb & ((1u << n) - 1u); bb >>= n; nb -= n; return v; };
+    auto push_entry = [&](uint32_t e) { L.entr[(ent_w & (ENT_RING - 1)) * IW + lane] = e; ++ent_w; };
+    auto fail = [&](uint32_t why) { bad = why; state = ST_FIN; };
+    auto literal = [&](uint32_t byte) {
+        lit_acc |= byte << (8u * (lit_n & 3u));
+        ++lit_n;
+        if ((lit_n & 3u) == 0u) { L.outr[(((lit_n >> 2) - 1u) & (OUT_RING - 1)) * IW + lane] = lit_acc; lit_acc = 0; }
+        ++op;
+        if (++run == 255u) { push_entry(255u); run = 0; }
+    };
+    // What the symbol step leaves aside (it sets want / slow and the lane waits): twice per period, for all waiting lanes together.
+    //   want 1 / 2: a literal/length / distance code longer than its root table's bits -- one pass of loads for the limits per length,
+    //     one for the symbol; the lane goes on with (wsym, wlen).  Any lane's long code would otherwise cost every lane of the wave
+    //     the slow path, in most steps;
+    //   slow 1: a symbol that is no literal, length or distance: the end of the block, or outside the alphabet; 2: text beyond ISIZE;
+    //   3: the 255th literal of a run (an entry of length 0 carries them); 4: a match that reaches outside the text;
+    //   and the bytes of a stored block, four at a time.
+    uint32_t want = 0, slow = 0, have_w = 0, wsym = 0, wlen = 0, phase = 0, pend_len = 0;
+    auto rare_cases = [&]() {
+        if (__ballot((want | slow) != 0u || state == ST_STORED) == 0ull) return;
+        if (want != 0u) {
+            const bool is_lit = want == 1u;
+            const uint32_t* const wk = is_lit ? L.lwalk : L.dwalk;
+            const uint32_t tb = is_lit ? (uint32_t)LT : (uint32_t)DT;
+            const uint32_t v = bitrev((uint32_t)bb & 0x7FFFu, 15);
+            uint32_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = wk[i * IW + lane];
+            uint32_t len = 0, idx = 0;
+#pragma unroll
+            for (int i = 7; i >= 0; --i)
+                if (v < (w[i] & 0xFFFFu)) { len = tb + 1u + (uint32_t)i; idx = ((w[i] >> 16) + (v >> (14u - tb - (uint32_t)i))) & 0xFFFFu; }
+            if (len == 0u || idx >= (is_lit ? (uint32_t)LONG_CAP : (uint32_t)DLONG_CAP)) fail(13);
+            else { wsym = (is_lit ? L.lsort : L.dsort)[idx * IW + lane]; wlen = len; have_w = 1; }
+            want = 0;
+        }
+        if (slow != 0u) {
+            if (slow == 1u) {
+                if (phase == 0u && wsym == 256u) { take(wlen); state = final_block ? ST_DONE : ST_BLOCK; }
+                else fail(14);
+                have_w = 0;
+            } else if (slow == 2u) fail(16);
+            else if (slow == 3u) { push_entry(255u); run = 0; }
+            else fail(20);
+            slow = 0;
+        }
+        if (__ballot(state == ST_STORED) != 0ull) {
+            for (int j = 0; j < 4; ++j) {
+                topup(); refill();
+                if (state == ST_STORED && nb >= 8u && ent_w - ent_f <= (uint32_t)(ENT_RING - 2) && (lit_n >> 2) - out_f < (uint32_t)(OUT_RING - 1)) {
+                    literal(take(8));
+                    if (--stored_left == 0u) state = final_block ? ST_DONE : ST_BLOCK;
                 }
             }
-            if (bad) break;
-            isync();
-            if (L.lens[256] == 0) { bad = 10; break; }
         }
-        if (!build_table<LIT_BITS, false>(L.lens, nlit, L.lit, L.lcount, L.lsym, lane)) { bad = 11; break; }
-        if (!build_table<DIST_BITS, true>(L.lens + nlit, ndist, L.dist, L.dcount, L.dsym, lane)) { bad = 12; break; }
-        // ---- symbols ----
-        for (;;) {
-            in.refill();
-            uint32_t e = L.lit[in.peek(LIT_BITS)];
-            uint32_t l = e & 15u, kind = (e >> 4) & 3u, payload = e >> 8;
-            if (l == 0u) { // a code longer than the table's bits (or an unused prefix)
-                if (kind == 3u) { bad = 13; break; }
-                const int s = walk_long(in, L.lcount, L.lsym);
-                if (s < 0 || s >= 286) { bad = 14; break; }
-                if (s < 256) { kind = 0; payload = (uint32_t)s; }
-                else if (s == 256) kind = 2;
-                else { kind = 1; payload = (uint32_t)LEN_BASE[s - 257] | ((uint32_t)LEN_EXTRA[s - 257] << 9); }
+    };
+
+    bool first_period = true;
+    uint32_t periods = 0;
+    bool hdr_on = true; // (every stream begins with a header)
+#ifdef RK_INFLATE_DEBUG
+    uint32_t dbg_steps = 0, dbg_sym = 0, dbg_hdr = 0, dbg_long = 0, dbg_build = 0, dbg_symlanes = 0;
+#endif
+    for (;;) {
+        // (a stream that cannot go on -- its input used up, or nothing decoded for far longer than a member takes -- is the host's)
+        if (state != ST_FIN && state != ST_DONE && ((!pending && in_w + 4u > in_lim && in_r == in_w && nav == 0u && nb <= 32u) || periods > 400000u)) fail(2);
+        ++periods;
+        // ---- the wave's memory traffic: once per period, for all lanes
+        if (pending) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) L.inr[((in_w + i) & (IN_RING - 1)) * IW + lane] = pend.v[i];
+            in_w += 4u;
+        }
+        if (first_period) { // the stream begins inside its first dword
+            first_period = false;
+            topup(); topup(); refill(); topup();
+            if (live && nb) { const uint32_t skip = (me.in_off & 3u) * 8u; bb >>= skip; nb -= skip; }
+        }
+        if (state == ST_DONE && ent_w - ent_f < (uint32_t)ENT_RING) { // the tail: literals after the last match, the last partial dword
+            if (op != me.out_len) fail(21);
+            else {
+                push_entry(run);
+                if (lit_n & 3u) L.outr[((lit_n >> 2) & (OUT_RING - 1)) * IW + lane] = lit_acc;
+                state = ST_FIN;
+            }
+        }
+        out_target = bad ? out_f : (state == ST_FIN ? (lit_n + 3u) >> 2 : lit_n >> 2);
+        if (bad) ent_f = ent_w;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+            if (out_f < out_target) { lits[out_f] = L.outr[(out_f & (OUT_RING - 1)) * IW + lane]; ++out_f; }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            if (__ballot(ent_f < ent_w) == 0ull) break;
+            if (ent_f < ent_w) { ents[ent_f] = L.entr[(ent_f & (ENT_RING - 1)) * IW + lane]; ++ent_f; }
+        }
+        pending = state != ST_FIN && in_w - in_r <= (uint32_t)(IN_RING - 4) && in_w + 4u <= in_lim;
+        if (pending) pend = *reinterpret_cast<const Quad*>(src + in_w);
+        if (__ballot(state != ST_FIN || out_f < out_target || ent_f < ent_w) == 0ull) break;
+
+        // ---- block headers: the lanes that are at one.  Header steps cost the wave the same whether one lane or forty take them, and
+        // the lanes reach their blocks' ends at different times: a lane at a header waits for the next window (every HDR_EVERY
+        // periods, or HDR_LANES lanes waiting, or nothing else left to do), and a window lasts until no lane is at a header
+        {
+            const uint64_t at_hdr = __ballot(state < ST_WAIT);
+            if (!hdr_on && at_hdr && ((periods & (HDR_EVERY - 1)) == 0u || __popcll(at_hdr) >= HDR_LANES || __ballot(state >= ST_SYM && state < ST_DONE) == 0ull)) hdr_on = true;
+            if (!at_hdr) hdr_on = false;
+        }
+        for (int h = 0; hdr_on && h < K_HDR; ++h) {
+            if (__ballot(state < ST_WAIT) == 0ull) break;
+#ifdef RK_INFLATE_DEBUG
+            ++dbg_hdr;
+#endif
+            topup(); refill(); topup();
+            if (state == ST_BLOCK) {
+                if (nb >= 3u) {
+                    final_block = take(1);
+                    const uint32_t type = take(2);
+                    if (type == 0u) { take(nb & 7u); state = ST_STORED_HDR; }
+                    else if (type == 1u) { nlit = 288; ndist = 30; need_build = 3; state = ST_WAIT; }
+                    else if (type == 2u) state = ST_DYN_HDR;
+                    else fail(4);
+                }
+            } else if (state == ST_STORED_HDR) {
+                if (nb >= 32u) {
+                    const uint32_t len = take(16), nlen = take(16);
+                    if ((len ^ 0xFFFFu) != nlen || op + len > me.out_len) fail(3);
+                    else { stored_left = len; state = len ? ST_STORED : (final_block ? ST_DONE : ST_BLOCK); }
+                }
+            } else if (state == ST_DYN_HDR) {
+                if (nb >= 14u) {
+                    nlit = take(5) + 257u; ndist = take(5) + 1u; ncl = take(4) + 4u;
+                    if (nlit > 286u || ndist > 30u) fail(5);
+                    else {
+                        for (int i = 0; i < 19; ++i) L.lens[(CL_AT + i) * IW + lane] = 0;
+                        hi = 0; state = ST_CL_READ;
+                    }
+                }
+            } else if (state == ST_CL_READ) {
+                for (int j = 0; j < 8 && hi < ncl && nb >= 3u; ++j) { L.lens[(CL_AT + L.clorder[hi]) * IW + lane] = (uint8_t)take(3); ++hi; }
+                if (hi == ncl) { need_build = 1; state = ST_WAIT; }
+            } else if (state == ST_LENS) {
+                if (nb >= 14u) {
+                    const uint32_t e = L.lit[((uint32_t)bb & ((1u << CT) - 1u)) * IW + lane];
+                    const uint32_t l = e >> 12, sym = e & 0xFFFu;
+                    if (l == 0u) fail(7);
+                    else {
+                        take(l);
+                        if (sym < 16u) { L.lens[hi * IW + lane] = (uint8_t)sym; prev = sym; ++hi; }
+                        else {
+                            uint32_t rep, val = 0;
+                            if (sym == 16u) { rep = 3u + take(2); val = prev; if (hi == 0u) rep = 1000u; }
+                            else if (sym == 17u) { rep = 3u + take(3); prev = 0; }
+                            else { rep = 11u + take(7); prev = 0; }
+                            if (hi + rep > nlit + ndist) fail(9);
+                            else { for (uint32_t j = 0; j < rep; ++j) L.lens[(hi + j) * IW + lane] = (uint8_t)val; hi += rep; }
+                        }
+                        if (state == ST_LENS && hi == nlit + ndist) {
+                            if (L.lens[256 * IW + lane] == 0) fail(10);
+                            else { need_build = 2; state = ST_WAIT; }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- code tables: the wave builds them, one asking lane at a time
+        for (uint64_t req = __ballot(need_build != 0u && state == ST_WAIT); req; req &= req - 1ull) {
+            const int t = __builtin_ctzll(req);
+#ifdef RK_INFLATE_DEBUG
+            ++dbg_build;
+#endif
+            const uint32_t kind = (uint32_t)__builtin_amdgcn_readlane((int)need_build, t);
+            bool ok;
+            if (kind == 1u) {
+                isync();
+                ok = coop_build<CT, 1>(L, t, CL_AT, 19, L.lit, L.lsort, 0, nullptr, lane);
             } else {
-                if (kind == 3u) { bad = 15; break; }
-                in.drop(l);
+                const int nl = __builtin_amdgcn_readlane((int)nlit, t), nd = __builtin_amdgcn_readlane((int)ndist, t);
+                if (kind == 3u) {
+                    for (int i = lane; i < 288; i += IW) L.lens[i * IW + t] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+                    if (lane < 30) L.lens[(288 + lane) * IW + t] = 5;
+                }
+                isync();
+                ok = coop_build<LT, 5>(L, t, 0, nl, L.lit, L.lsort, LONG_CAP, L.lwalk, lane);
+                ok = coop_build<DT, 1>(L, t, nl, nd, L.dist, L.dsort, DLONG_CAP, L.dwalk, lane) && ok;
             }
-            if (kind == 0u) {
-                if (op >= me.out_len) { bad = 16; break; }
-                if (lane == 0) dst[op] = (uint8_t)payload;
-                ++op;
-                continue;
+            if (lane == t) {
+                need_build = 0;
+                if (!ok) fail(11);
+                else { state = kind == 1u ? ST_LENS : ST_SYM; hi = 0; prev = 0; }
             }
-            if (kind == 2u) break;
-            const uint32_t eb = payload >> 9;
-            in.refill();
-            const uint32_t len = (payload & 511u) + in.take(eb);
-            uint32_t de = L.dist[in.peek(DIST_BITS)];
-            uint32_t dl = de & 15u, dbase, dext;
-            if (dl == 0u) {
-                if (((de >> 4) & 3u) == 3u) { bad = 17; break; }
-                const int s = walk_long(in, L.dcount, L.dsym);
-                if (s < 0 || s >= 30) { bad = 18; break; }
-                dbase = DIST_BASE[s]; dext = DIST_EXTRA[s];
-            } else {
-                if (((de >> 4) & 3u) == 3u) { bad = 19; break; }
-                in.drop(dl);
-                dbase = (de >> 8) & 0xFFFFu; dext = de >> 24;
+        }
+        // ---- symbols: one Huffman symbol per step and lane -- a literal, a length, or (the step after a length) its distance.
+        // The step is straight-line code: every lane pays for every branch any lane takes, so the three common cases are computed
+        // side by side and selected, ring stores that are not due go to a junk slot, and whatever is rare -- an end of block, a code
+        // longer than the root's bits, the 255th literal of a run, a stored block's bytes, every error -- is left to
+        // rare_cases(), twice per period, while the lane waits.
+        for (int it = 0; it < K_SYM; ++it) {
+            topup();
+            {
+                const bool c = nb <= 32u && nav != 0u;
+                bb |= c ? (uint64_t)nx0 << (nb & 63u) : 0ull;
+                nb += c ? 32u : 0u; nx0 = c ? nx1 : nx0; nav -= c ? 1u : 0u;
             }
-            in.refill();
-            const uint32_t dist = dbase + in.take(dext);
-            if (dist > op || op + len > me.out_len || nmatch >= match_cap) { bad = 20; break; }
-            if (lane == 0) ml[nmatch] = make_uint2(op, len | (dist << 16)); // resolved by pass 2, in order
-            ++nmatch;
-            op += len;
+            const bool room = ent_w - ent_f <= (uint32_t)(ENT_RING - 2) && (lit_n >> 2) - out_f < (uint32_t)(OUT_RING - 1); // (the partial dword's slot stays free)
+            const bool act = state == ST_SYM && nb > 32u && room && (want | slow) == 0u;
+            const bool dstep = phase != 0u;
+            const uint32_t slot = dstep ? (uint32_t)offsetof(LaneLds, dist) / 2u + ((uint32_t)bb & ((1u << DT) - 1u)) * IW
+                                        : (uint32_t)offsetof(LaneLds, lit) / 2u + ((uint32_t)bb & ((1u << LT) - 1u)) * IW;
+            const uint32_t e = reinterpret_cast<const uint16_t*>(&L)[slot + (uint32_t)lane];
+            const uint32_t l = have_w ? wlen : e >> 12, sym = have_w ? wsym : e & 0xFFFu;
+            const bool coded = l != 0u;
+            const bool is_lit = !dstep && sym < 256u, is_len = !dstep && sym - 257u < 29u, is_dist = dstep && sym < 30u;
+            const bool known = act && coded && (is_lit || is_len || is_dist);
+            const bool go = known && !(is_lit && op >= me.out_len);
+            want = act && !coded ? (dstep ? 2u : 1u) : want;                 // a long code, or no code at all: rare_cases() finds out
+            if (act && coded && !go) { slow = known ? 2u : 1u; have_w = 1; wlen = l; wsym = sym; } // end of block / a symbol outside the alphabet / text beyond ISIZE
+            have_w = go ? 0u : have_w;
+            // base and extra bits of a length (RFC 1951 3.2.5: four codes per extra bit) and of a distance (two per extra bit)
+            const uint32_t li = sym - 257u;
+            const uint32_t leb = li < 8u || li == 28u ? 0u : (li - 4u) >> 2;
+            const uint32_t lbase = li < 8u ? li + 3u : (li == 28u ? 258u : 3u + ((4u + (li & 3u)) << (leb & 7u)));
+            const uint32_t deb = sym < 4u ? 0u : (sym - 2u) >> 1;
+            const uint32_t dbase = sym < 4u ? sym + 1u : 1u + ((2u + (sym & 1u)) << (deb & 15u));
+            const uint32_t eb = !go || is_lit ? 0u : (is_len ? leb : deb) & 15u;
+            const uint32_t n1 = go ? l : 0u;
+            bb >>= n1;
+            const uint32_t x = (uint32_t)bb & ((1u << eb) - 1u);
+            bb >>= eb;
+            nb -= n1 + eb;
+            // a literal
+            const bool lit = go && is_lit;
+            lit_acc |= lit ? sym << (8u * (lit_n & 3u)) : 0u;
+            const bool full = lit && (lit_n & 3u) == 3u;
+            L.outr[full ? ((lit_n >> 2) & (OUT_RING - 1)) * IW + lane : OUT_RING * IW + lane] = lit_acc; // (row OUT_RING: the junk row)
+            lit_acc = full ? 0u : lit_acc;
+            lit_n += lit ? 1u : 0u; op += lit ? 1u : 0u; run += lit ? 1u : 0u;
+            slow = lit && run == 255u ? 3u : slow;
+            // a length: its distance is the next step's
+            pend_len = go && is_len ? lbase + x : pend_len;
+            phase = go && is_len ? 1u : phase;
+            // a distance: the match becomes an entry
+            const uint32_t dist = dbase + x;
+            const bool dgo = go && is_dist;
+            const bool match = dgo && dist <= op && op + pend_len <= me.out_len;
+            slow = dgo && !match ? 4u : slow;
+            L.entr[match ? (ent_w & (ENT_RING - 1)) * IW + lane : ENT_RING * IW + lane] = run | (pend_len << 8) | ((dist - 1u) << 17);
+            ent_w += match ? 1u : 0u;
+            run = match ? 0u : run;
+            op += match ? pend_len : 0u;
+            phase = match ? 0u : phase;
+#ifdef RK_INFLATE_DEBUG
+            ++dbg_steps; dbg_sym += (uint32_t)__popcll(__ballot(go)); dbg_symlanes += (uint32_t)__popcll(__ballot(state == ST_SYM));
+            if ((it & 3) == 3 && __ballot((want | slow) != 0u)) ++dbg_long;
+#endif
+            if ((it & 3) == 3) rare_cases();
         }
     }
-    if (!bad && op != me.out_len) bad = 21;
-    if (lane == 0) { status[m] = bad; status[nmem + m] = bad ? 0u : nmatch; }
+#ifdef RK_INFLATE_DEBUG
+    if (blockIdx.x == 0 && lane == 0) printf("inflate dbg: periods %u steps %u symbols %u (%.1f lanes per step; %.1f lanes in SYM state) header iterations %u long-code passes %u builds %u\n", periods, dbg_steps, dbg_sym, (double)dbg_sym / dbg_steps, (double)dbg_symlanes / dbg_steps, dbg_hdr, dbg_long, dbg_build);
+#endif
+    if (live) { status[m] = bad; status[nmem + m] = bad ? 0u : ent_w | (lit_n << 15); } // (at most 22 106 entries, 65 536 literals)
 }
 
-// pass 2: the member's matches applied in order inside a 64 KB LDS window (a match may copy what an earlier match wrote)
-__global__ __launch_bounds__(IW) void k_inflate_resolve(const InflateMember* __restrict__ mem, uint32_t nmem, uint8_t* __restrict__ text, const uint2* __restrict__ matches,
-                                                        const uint32_t* __restrict__ status) {
+// Pass 2: the member's text built in a 64 KB LDS window from its literal stream and its entries, 64 entries at a time.
+// (Two variants were measured and dropped, profiles/r05_gz.txt: the literals staged at the end of the window first -- twice the time,
+// the extra LDS passes cost more than the loads they save --, and the dependent matches copied in rounds by their own lanes -- no gain.)
+__global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __restrict__ mem, uint32_t nmem, uint8_t* __restrict__ text, const uint32_t* __restrict__ scratch,
+                                                      const uint32_t* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) uint8_t win[WIN_BYTES];
+    __shared__ uint32_t s_r[IW], s_d[IW];
     const int lane = threadIdx.x;
     const uint32_t m = blockIdx.x;
-    if (m >= nmem) return;
-    const uint32_t nmatch = status[nmem + m];
-    if (status[m] != 0u || nmatch == 0u) return; // (no matches: the literals are the text)
+    if (m >= nmem || status[m] != 0u) return;
+    const uint32_t nent = status[nmem + m] & 0x7FFFu, nlit = status[nmem + m] >> 15;
     const InflateMember me = mem[m];
-    uint8_t* const dst = text + me.out_off;
     const uint32_t n = me.out_len;
-    // the text so far (literals in place, holes where matches go): 4 bytes per lane where the address allows
-    const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u) < n ? (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u) : n;
-    const uint32_t nd = (n - head) >> 2, done = head + 4u * nd;
-    if ((uint32_t)lane < head) win[lane] = dst[lane];
-    for (uint32_t i = (uint32_t)lane; i < nd; i += IW) {
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(dst + head + 4u * i);
-        const uint32_t o = head + 4u * i;
-        win[o] = (uint8_t)v; win[o + 1] = (uint8_t)(v >> 8); win[o + 2] = (uint8_t)(v >> 16); win[o + 3] = (uint8_t)(v >> 24);
-    }
-    if ((uint32_t)lane < n - done) win[done + lane] = dst[done + lane];
-    isync();
-    const uint2* ml = matches + me.match_off;
-    for (uint32_t q0 = 0; q0 < nmatch; q0 += IW) { // 64 entries per load (one per lane), handed round by v_readlane
-        uint2 mine = make_uint2(0u, 0u);
-        if (q0 + (uint32_t)lane < nmatch) mine = ml[q0 + (uint32_t)lane];
-        const uint32_t cnt = nmatch - q0 < (uint32_t)IW ? nmatch - q0 : (uint32_t)IW;
-        for (uint32_t j = 0; j < cnt; ++j) {
-            const uint32_t op = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, (int)__builtin_amdgcn_readfirstlane((int)j));
-            const uint32_t ld = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, (int)__builtin_amdgcn_readfirstlane((int)j));
-            const uint32_t len = ld & 0xFFFFu, dist = ld >> 16;
-            if (dist >= len || dist >= (uint32_t)IW) {
-                for (uint32_t i0 = 0; i0 < len; i0 += IW) { // (dist >= 64: a step's 64 source bytes were all written before it)
+    const uint32_t* const ents = scratch + me.match_off;
+    const uint8_t* const lits = reinterpret_cast<const uint8_t*>(ents + entry_cap(n));
+    uint8_t* const dst = text + me.out_off;
+    uint32_t op0 = 0, lp0 = 0;
+    for (uint32_t q0 = 0; q0 < nent; q0 += IW) {
+        const uint32_t e = q0 + (uint32_t)lane < nent ? ents[q0 + (uint32_t)lane] : 0u;
+        const uint32_t run = e & 255u, len = (e >> 8) & 511u, dist = (e >> 17) + 1u;
+        uint32_t r = run, t = run + len; // inclusive prefix sums over the lanes
+#pragma unroll
+        for (int d = 1; d < IW; d <<= 1) {
+            const uint32_t ur = (uint32_t)__shfl_up((int)r, d), ut = (uint32_t)__shfl_up((int)t, d);
+            if (lane >= d) { r += ur; t += ut; }
+        }
+        const uint32_t tot_r = (uint32_t)__builtin_amdgcn_readlane((int)r, IW - 1), tot_t = (uint32_t)__builtin_amdgcn_readlane((int)t, IW - 1);
+        if (op0 + tot_t > n || lp0 + tot_r > nlit) return; // (pass 1 checked every entry against out_len: unreachable for its output)
+        const uint32_t at = op0 + t - len; // where this lane's match begins; its run ends there
+        s_r[lane] = r;
+        s_d[lane] = at - r; // literal i of the batch (r_prev <= i < r) goes to s_d + i
+        isync();
+        for (uint32_t i = (uint32_t)lane; i < tot_r; i += IW) {
+            uint32_t j = 0; // the first lane whose inclusive sum exceeds i
+#pragma unroll
+            for (int s = IW / 2; s; s >>= 1) if (s_r[j + s - 1] <= i) j += s;
+            win[s_d[j] + i] = lits[lp0 + i];
+        }
+        isync();
+        // matches whose source ends at or before the batch's first byte depend on nothing in the batch: one lane each
+        const bool indep = len != 0u && at - dist + len <= op0;
+        if (indep) for (uint32_t i = 0; i < len; ++i) win[at + i] = win[at - dist + i];
+        isync();
+        for (uint64_t todo = __ballot(len != 0u && !indep); todo; todo &= todo - 1ull) {
+            const int j = __builtin_ctzll(todo);
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)at, j), ln = (uint32_t)__builtin_amdgcn_readlane((int)len, j),
+                           ds = (uint32_t)__builtin_amdgcn_readlane((int)dist, j);
+            if (ds >= ln || ds >= (uint32_t)IW) {
+                for (uint32_t i0 = 0; i0 < ln; i0 += IW) { // (distance >= 64: a step's 64 source bytes were all written before it)
                     const uint32_t i = i0 + (uint32_t)lane;
                     uint8_t v = 0;
-                    if (i < len) v = win[op - dist + i];
+                    if (i < ln) v = win[o - ds + i];
                     isync();
-                    if (i < len) win[op + i] = v;
+                    if (i < ln) win[o + i] = v;
                     isync();
                 }
-            } else { // the source overlaps the destination: it repeats with period dist
-                for (uint32_t i = (uint32_t)lane; i < len; i += IW) win[op + i] = win[op - dist + i % dist];
+            } else { // the source overlaps the destination: it repeats with period ds
+                for (uint32_t i = (uint32_t)lane; i < ln; i += IW) win[o + i] = win[o - ds + i % ds];
                 isync();
             }
         }
+        op0 += tot_t; lp0 += tot_r;
     }
+    isync();
+    const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u) < n ? (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u) : n;
+    const uint32_t nd = (n - head) >> 2, done = head + 4u * nd;
     if ((uint32_t)lane < head) dst[lane] = win[lane];
     for (uint32_t i = (uint32_t)lane; i < nd; i += IW) {
         const uint32_t o = head + 4u * i;
@@ -370,11 +530,14 @@ __global__ __launch_bounds__(256) void k_fastq_first_start(const uint8_t* __rest
     }
 }
 
-hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint2* matches, uint32_t* status,
+uint32_t inflate_scratch_dwords(uint32_t out_len) { return entry_cap(out_len) + out_len / 4u + 2u; }
+hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint32_t* scratch, uint32_t* status,
                                   hipStream_t st) {
     if (!nmem) return hipSuccess;
-    hipLaunchKernelGGL(k_inflate_members, dim3(nmem), dim3(IW), 0, st, comp, comp_bytes, mem, nmem, text, matches, status);
-    hipLaunchKernelGGL(k_inflate_resolve, dim3(nmem), dim3(IW), 0, st, mem, nmem, text, matches, status);
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds));
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(k_inflate_lanes, dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds), st, comp, comp_bytes, mem, nmem, scratch, status);
+    hipLaunchKernelGGL(k_inflate_place, dim3(nmem), dim3(IW), 0, st, mem, nmem, text, scratch, status);
     return hipGetLastError();
 }
 hipError_t launch_fastq_first_start(const uint8_t* text, uint32_t n, uint32_t from, uint32_t window, bool at_eof, uint32_t* cuts, int which, hipStream_t st) {

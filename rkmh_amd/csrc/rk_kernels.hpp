@@ -130,10 +130,13 @@ uint64_t fa_chunks(uint64_t nbytes);
 hipError_t launch_fasta_count(const FaDev& d, const uint8_t* raw, uint64_t nbytes, hipStream_t st);
 hipError_t launch_fasta_compact(const FaDev& d, const uint8_t* raw, uint64_t nbytes, uint64_t nrec, hipStream_t st);
 hipError_t launch_fasta_names(const FaDev& d, const uint8_t* raw, uint64_t nrec, hipStream_t st);
-// ---- DEFLATE on the device for BGZF members (rk_inflate.hip): one wave per member ----
-struct InflateMember { uint32_t in_off, in_len, out_off, out_len, match_off, pad; }; // deflate payload in the compressed buffer; text in the output buffer; first entry of its match list
-// status[0 .. nmem) = 0 / why the member could not be inflated, status[nmem .. 2 nmem) = its matches; matches: out_len / 3 + 1 entries per member
-hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint2* matches, uint32_t* status,
+// ---- DEFLATE on the device for BGZF members (rk_inflate.hip): pass 1 one lane per member, pass 2 one wave per member ----
+// deflate payload in the compressed buffer (which has 64 readable bytes beyond the last member); text in the output buffer;
+// match_off = first dword of the member's part of `scratch` (inflate_scratch_dwords(out_len) dwords: its entries, then its literals)
+struct InflateMember { uint32_t in_off, in_len, out_off, out_len, match_off, pad; };
+uint32_t inflate_scratch_dwords(uint32_t out_len);
+// status[0 .. nmem) = 0 / why the member could not be inflated, status[nmem .. 2 nmem) = its entries
+hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint32_t* scratch, uint32_t* status,
                                   hipStream_t st);
 // cuts[which] = first FASTQ record start (four-line rule) at or after `from`; n: none and the text ends here; 0xFFFFFFFF: not decidable from this text
 hipError_t launch_fastq_first_start(const uint8_t* text, uint32_t n, uint32_t from, uint32_t window, bool at_eof, uint32_t* cuts, int which, hipStream_t st);

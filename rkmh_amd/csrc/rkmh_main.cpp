@@ -149,6 +149,17 @@ template <typename V> struct QueueT {
         cv.notify_all();
         return true;
     }
+    // the next element and, in the same step, up to maxn - 1 more that are queued right now: a run no other consumer can cut into
+    // (maxn_of: how many at most, given the first one)
+    template <typename F> bool pop_run(std::vector<V>* run, F maxn_of) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !q.empty() || done; });
+        run->clear();
+        const size_t maxn = q.empty() ? 0 : (size_t)maxn_of(q.front());
+        while (!q.empty() && run->size() < maxn) { run->push_back(std::move(q.front())); q.pop_front(); }
+        cv.notify_all();
+        return !run->empty();
+    }
     void finish() { std::lock_guard<std::mutex> l(m); done = true; cv.notify_all(); }
 };
 typedef QueueT<rk_seqset> Queue;
@@ -382,10 +393,15 @@ static int granted_cpus_main() {
 
 // BGZF (bgzip) read files found by raw_eligible: the device front end's workers inflate their members themselves (rk_bgzf_*)
 static std::map<std::string, rk_bgzf*> g_bgzf;
-// RKMH_BGZF_DEVICE=1: the members are inflated on the device (rk_inflate.hip).  Not the default: one wave per member decodes its
-// Huffman symbols serially with a 64 KB LDS window (two waves per CU): 2.6 GB/s of text on MI355X against 6.8 GB/s for fourteen
-// host threads with libdeflate (profiles/r05_gz.txt) -- the device needs ~10^4 members in flight, not the few hundred of a block.
-static bool bgzf_on_device() { static const bool on = getenv("RKMH_BGZF_DEVICE") && atoi(getenv("RKMH_BGZF_DEVICE")) != 0; return on; }
+// RKMH_BGZF_DEVICE: who inflates the members.  0: the workers (libdeflate / zlib on the host).  1: the device (rk_inflate.hip: a lane per
+// member, ~34 ms per launch whatever its size -- it pays with about a thousand members per job and several jobs in flight).
+// 2: both -- the last RKMH_BGZF_DEVICE_WORKERS workers take RKMH_BGZF_DEVICE_MERGE consecutive jobs at a time to the device while
+// the others inflate theirs (profiles/r05_gz.txt).
+static int bgzf_device_mode() {
+    static const int mode = [] { const char* e = getenv("RKMH_BGZF_DEVICE"); const int v = e ? atoi(e) : 0; return v < 0 || v > 2 ? 0 : v; }();
+    return mode;
+}
+static long env_long(const char* name, long dflt, long lo, long hi) { const char* e = getenv(name); if (!e) return dflt; const long v = atol(e); return v < lo || v > hi ? dflt : v; }
 static rk_bgzf* bgzf_of(const char* path) { auto it = g_bgzf.find(path); return it == g_bgzf.end() ? nullptr : it->second; }
 
 // a regular, uncompressed file that begins with '@' (FASTQ reads) / '>' (FASTA references) -- or, for reads, a BGZF file whose text
@@ -516,7 +532,8 @@ struct OrderedOut {
 };
 
 struct RawEngine {
-    struct Worker { rk_fastq_slot* slot[2] = {nullptr, nullptr}; size_t dev = 0; }; // two slots: one block on the device while the next is read
+    // two slots: one block on the device while the next is read; inflate: this worker's BGZF jobs are inflated on the device, `merge` planned jobs at a time
+    struct Worker { rk_fastq_slot* slot[2] = {nullptr, nullptr}; size_t dev = 0; bool inflate = false; int merge = 1; uint64_t bytes = 0; };
     std::vector<Worker> w;
     uint64_t block = 0;
     bool two_slots = false; // RKMH_RAW_SLOTS=2: a worker reads its next block while the previous one is on the device.  Measured (profiles/r04_e2e_ab.txt,
@@ -537,15 +554,24 @@ struct RawEngine {
         // BGZF input: a worker inflates its job's members before the upload (~1 GB/s of text per core with libdeflate, a third of
         // that with zlib) -- the CPUs, not the link, set the rate, so all but two of them work
         // (inflated on the device -- the default -- the workers only copy the compressed bytes: two more than for plain text)
-        if (!g_bgzf.empty()) nw = bgzf_on_device() ? std::min<long>(cap, nw + 2) : std::max<long>(nw, std::min<long>(32, granted_cpus_main() - 2));
+        const int zmode = g_bgzf.empty() ? 0 : bgzf_device_mode();
+        if (!g_bgzf.empty()) nw = zmode == 1 ? std::min<long>(cap, nw + 2) : std::max<long>(nw, std::min<long>(32, granted_cpus_main() - 2));
         if (const char* e = getenv("RKMH_RAW_WORKERS")) { long v = atol(e); if (v >= 1 && v <= 64) nw = v; }
         if ((size_t)nw < g.size()) nw = (long)g.size();
         if (const char* e = getenv("RKMH_RAW_SLOTS")) two_slots = atoi(e) == 2;
-        w.resize((size_t)nw);
-        for (size_t i = 0; i < w.size(); ++i) w[i].dev = i % g.size();
+        // (the device's workers wait for their kernels most of the time: they come on top of the inflating ones)
+        const long ndev = zmode == 2 ? env_long("RKMH_BGZF_DEVICE_WORKERS", 6, 1, 32) * (long)g.size() : 0;
+        const int merge = zmode == 2 ? (int)env_long("RKMH_BGZF_DEVICE_MERGE", 4, 1, 64) : 1;
+        w.resize((size_t)(nw + ndev));
+        for (size_t i = 0; i < w.size(); ++i) {
+            w[i].dev = i % g.size();
+            w[i].inflate = zmode == 1 || (zmode == 2 && i >= (size_t)nw);
+            w[i].merge = w[i].inflate ? merge : 1;
+            w[i].bytes = block * (uint64_t)w[i].merge + 64; // (+ 64: a last block of exactly `block` bytes may get its missing newline)
+        }
         // each worker creates its own slot when it starts (page-locking ~50 MB takes ~10 ms): the first blocks are on their way
         // while the later workers are still setting up.  Only the first slot is made here, to find out whether the front end works at all.
-        if (rk_fastq_slot_create(g.ctx[0], block + 64, &w[0].slot[0]) != RK_OK) { // (+ 64: a last block of exactly `block` bytes may get its missing newline)
+        if (rk_fastq_slot_create(g.ctx[0], w[0].bytes, &w[0].slot[0]) != RK_OK) {
             fprintf(stderr, "rkmh: device FASTQ front end unavailable (%s): using the host scanner\n", rk_last_error());
             w.clear();
             return false;
@@ -599,7 +625,9 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     if (kind == RAW_STREAM) CK(rk_line_parts_create(refs.names, refs.name_offsets, refs.nseq, o.sketch, o.min_matches, o.min_diff, &lp));
     const bool counting = kind == RAW_COUNT;
     rk_bgzf* const bz = bgzf_of(path); // compressed (BGZF): a job is a run of members [lo, hi), inflated by the worker that takes it
-    struct Job { int64_t seq = 0, lo = 0, hi = 0, at = 0; const uint8_t* ext = nullptr; }; // at: where the job's first record starts in the (uncompressed) text; ext: its text in the mapped file
+    // at: where the job's first record starts in the (uncompressed) text; ext: its text in the mapped file; nseq: planned jobs merged into this one
+    // left: planned jobs after this one
+    struct Job { int64_t seq = 0, lo = 0, hi = 0, at = 0; const uint8_t* ext = nullptr; int64_t nseq = 1, left = INT64_MAX; };
     // RKMH_RAW_MMAP=1: the file is mapped and the mapping page-locked (hipHostRegister): the link reads the page cache itself, the
     // workers copy nothing (tools/ubench/mmap_register.hip)
     const uint8_t* fmap = nullptr;
@@ -621,7 +649,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     std::atomic<int> live{(int)eng.w.size()};
     auto work = [&](size_t wi) {
         for (int k = 0; k < (eng.two_slots ? 2 : 1); ++k)
-            if (!eng.w[wi].slot[k] && rk_fastq_slot_create(g.ctx[eng.w[wi].dev], eng.block + 64, &eng.w[wi].slot[k]) != RK_OK) {
+            if (!eng.w[wi].slot[k] && rk_fastq_slot_create(g.ctx[eng.w[wi].dev], eng.w[wi].bytes, &eng.w[wi].slot[k]) != RK_OK) {
                 // (memory for another slot ran out: the other workers carry on -- unless this was the last one)
                 fprintf(stderr, "rkmh: worker %zu: %s\n", wi, rk_last_error());
                 if (live.fetch_sub(1) == 1) { fprintf(stderr, "rkmh: no worker of the device front end could start\n"); fail_exit(); }
@@ -629,10 +657,13 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
             }
         const int64_t window = (int64_t)eng.w.size() * 4 + 2;
         Job cur, prev;
+        std::vector<Job> run;
         bool have_prev = false;
         int k = 0;
         double t_rd = 0, t_dv = 0, t_fm = 0;
         int64_t nblk = 0, nrec_ = 0;
+        // (a merged job's other block numbers carry no output of their own)
+        auto put_rest = [&](const Job& jb) { if (!counting) for (int64_t e = 1; e < jb.nseq; ++e) out.put(jb.seq + e, std::vector<char>(), 0, window); };
         auto finish_block = [&](const Job& jb, rk_fastq_slot* slot) {
             const double b = now_s();
             rk_fastq_result res;
@@ -649,11 +680,26 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
             else outlen = format_raw(lp, res, jb.ext ? jb.ext : rk_fastq_slot_text(slot), buf);
             t_dv += c - b; t_fm += now_s() - c; ++nblk; nrec_ += res.status == 0 ? res.nrec : 0;
             out.put(jb.seq, std::move(buf), outlen, window);
+            put_rest(jb);
+            if (getenv("RKMH_TRACE_JOBS")) fprintf(stderr, "[job] worker %zu parked blocks %lld..%lld\n", wi, (long long)jb.seq, (long long)(jb.seq + jb.nseq - 1));
         };
         // block b is on its way to the device and through the index kernels (submit) while block b + 1 is read into the other slot
         for (;;) {
-            const bool got = jobs.pop(&cur);
-            if (got && cur.seq > fail_seq.load()) { if (!counting) out.put(cur.seq, std::vector<char>(), 0, window); continue; } // the scanner will redo this range
+            bool got;
+            bool to_device = bz && eng.w[wi].inflate;
+            if (to_device && eng.w[wi].merge > 1) { // the device takes a run of planned jobs as one (consecutive: one producer, the run leaves the queue in one step)
+                // (a file's last jobs are taken one by one and inflated here: a merged job is ~100 ms that the other workers would wait for at the end)
+                const int64_t tail = 2 * eng.w[wi].merge;
+                got = jobs.pop_run(&run, [&](const Job& f) { return f.left < tail ? 1 : eng.w[wi].merge; });
+                if (got) { cur = run[0]; cur.hi = run.back().hi; cur.nseq = (int64_t)run.size(); to_device = cur.left >= tail; }
+            } else got = jobs.pop(&cur);
+            // (a failure is declared at the first block number of the failing worker's own job: never inside another job's run)
+            if (got && cur.seq > fail_seq.load()) { // the scanner will redo this range
+                if (!counting) { out.put(cur.seq, std::vector<char>(), 0, window); put_rest(cur); }
+                continue;
+            }
+            static const bool trace = getenv("RKMH_TRACE_JOBS") != nullptr;
+            if (trace && got) fprintf(stderr, "[job] worker %zu (%s) takes blocks %lld..%lld\n", wi, eng.w[wi].inflate ? "device" : "host", (long long)cur.seq, (long long)(cur.seq + cur.nseq - 1));
             if (got) {
                 const double a = now_s();
                 uint8_t* text = rk_fastq_slot_text(eng.w[wi].slot[k]);
@@ -662,10 +708,10 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                 if (bz) {
                     uint64_t off = 0;
                     // the members inflated by this thread, or (RKMH_BGZF_DEVICE=1) on the device, which may hand a job back
-                    int rc = bgzf_on_device() ? rk_fastq_slot_load_bgzf(eng.w[wi].slot[k], bz, cur.lo, cur.hi, &nbytes, &off) : 1;
+                    int rc = to_device ? rk_fastq_slot_load_bgzf(eng.w[wi].slot[k], bz, cur.lo, cur.hi, &nbytes, &off) : 1;
                     if (rc < 0) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
                     const bool on_device = rc == RK_OK;
-                    if (!on_device) rc = rk_bgzf_fastq_records(bz, cur.lo, cur.hi, text, eng.block + 63, &nbytes, &off);
+                    if (!on_device) rc = rk_bgzf_fastq_records(bz, cur.lo, cur.hi, text, eng.w[wi].bytes - 1, &nbytes, &off);
                     cur.at = (int64_t)off;
                     if (rc == 1 || rc == RK_ERR_LIMIT) { refused = true; nbytes = 0; }
                     else if (rc != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
@@ -692,6 +738,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                     int64_t curf = fail_seq.load();
                     while (cur.seq < curf && !fail_seq.compare_exchange_weak(curf, cur.seq)) {}
                     if (!counting) out.put(cur.seq, std::vector<char>(), 0, window);
+                    put_rest(cur);
                     t_rd += now_s() - a;
                     continue;
                 }
@@ -731,7 +778,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
         const uint64_t target = eng.block > ((uint64_t)1 << 20) ? eng.block - ((uint64_t)1 << 18) : eng.block * 3 / 4;
         const int64_t nj = rk_bgzf_plan(bz, target, first.data(), (int64_t)first.size());
         if (nj < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
-        for (int64_t j = 0; j < nj && fail_seq.load() == INT64_MAX; ++j) { Job jb; jb.seq = j; jb.lo = first[(size_t)j]; jb.hi = first[(size_t)j + 1]; jobs.push(jb); }
+        for (int64_t j = 0; j < nj && fail_seq.load() == INT64_MAX; ++j) { Job jb; jb.seq = j; jb.lo = first[(size_t)j]; jb.hi = first[(size_t)j + 1]; jb.left = nj - 1 - j; jobs.push(jb); }
         jobs.finish();
     } else {
         std::vector<uint8_t> win;
@@ -862,7 +909,7 @@ static bool refs_through_device(RawEngine& eng, DeviceGroup& g, const Opts& o, i
     std::atomic<bool> failed{false};
     auto work = [&](size_t wi) {
         if (eng.w[wi].dev != 0) return; // the text goes to the device that sketches
-        if (!eng.w[wi].slot[0] && rk_fastq_slot_create(g.ctx[0], eng.block + 64, &eng.w[wi].slot[0]) != RK_OK) return;
+        if (!eng.w[wi].slot[0] && rk_fastq_slot_create(g.ctx[0], eng.w[wi].bytes, &eng.w[wi].slot[0]) != RK_OK) return;
         rk_fastq_slot* slot = eng.w[wi].slot[0];
         uint8_t* text = rk_fastq_slot_text(slot);
         for (size_t j = next.fetch_add(1); j < jobs.size() && !failed.load(); j = next.fetch_add(1)) {
@@ -1959,6 +2006,10 @@ static int main_hpv16(int argc, char** argv) {
 
 int main(int argc, char** argv) {
     if (argc <= 1) { print_help(); exit(1); }
+    // The device front end's workers have a stream each; the runtime maps streams onto four hardware queues unless told otherwise,
+    // and kernels of two streams on one queue run one after the other -- the long inflate kernels of BGZF jobs above all
+    // (profiles/r05_gz.txt: 2.4 of 8 launches overlapped, 4.2 with 16 queues).  Read by the runtime when it starts: set before any HIP call.
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     std::string cmd = argv[1];
     if (cmd == "stream") return main_stream(argc, argv);
     if (cmd == "classify") {

@@ -21,7 +21,8 @@ with open("/tmp/sw.fq.gz", "wb") as fb:
         img = synth.bgzf_compress(rec.tobytes(), level=1, threads=16)
         fb.write(img[:-28] if lo + m < n else img)
 PY
-for cfg in "16384 8" "65536 8" "65536 12" "131072 8" "262144 6"; do
+IFS=";" read -ra LIST <<< "${CFGS:-16384 8;65536 8;131072 8;131072 12;262144 8;262144 12;524288 8}"
+for cfg in "${LIST[@]}"; do
   set -- $cfg
   for rep in 1 2; do
     S=$(date +%s.%N)
