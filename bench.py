@@ -156,10 +156,11 @@ def e2e_stream(n, L, rb, ro, synth):
                         with open(sg, "wb") as fs:
                             fs.write(gzip.compress(raw[: n1 * rl], 1))
 
-            def timed(files):
+            def timed(files, env=None):
                 fo_ = fresh_out()
                 t_ = time.perf_counter()
-                r_ = subprocess.run([exe, "stream", "-r", ref, "-k", "16", "-s", "1000"] + sum((["-f", x] for x in files), []), stdout=fo_, stderr=subprocess.PIPE)
+                r_ = subprocess.run([exe, "stream", "-r", ref, "-k", "16", "-s", "1000"] + sum((["-f", x] for x in files), []), stdout=fo_, stderr=subprocess.PIPE,
+                                    env=dict(os.environ, **(env or {})))
                 d_ = time.perf_counter() - t_
                 fo_.close()
                 if r_.returncode != 0:
@@ -171,20 +172,26 @@ def e2e_stream(n, L, rb, ro, synth):
                 return d_, h.hexdigest()
             try:
                 p1, hp = timed([gq])
-                b1, hb = timed([bg])
-                b4, _ = timed([bg] * 4)
+                b1, hb = timed([bg], {"RKMH_BGZF_DEVICE": "0"})
+                b4, _ = timed([bg] * 4, {"RKMH_BGZF_DEVICE": "0"})
+                d1, hd = timed([bg], {"RKMH_BGZF_DEVICE": "1"})
+                d4, _ = timed([bg] * 4, {"RKMH_BGZF_DEVICE": "1"})
                 s1, _ = timed([sg])
                 s4, _ = timed([sg] * 4)
                 res["gz"] = {"reads": ng, "fastq_bytes": os.path.getsize(gq), "bgzf_bytes": os.path.getsize(bg),
                              "plain_wall_s": p1, "bgzf_wall_s": b1, "bgzf_x4_wall_s": b4,
                              "bgzf_marginal_reads_per_s": 3 * ng / (b4 - b1) if b4 > b1 else None,
-                             "bgzf_output_identical_to_plain": hb == hp,
+                             "bgzf_output_identical_to_plain": hb == hp and hd == hp,
+                             "bgzf_device_wall_s": d1, "bgzf_device_x4_wall_s": d4,
+                             "bgzf_device_marginal_reads_per_s": 3 * ng / (d4 - d1) if d4 > d1 else None,
                              "single_member_reads": n1, "single_member_wall_s": s1,
                              "single_member_marginal_reads_per_s": 3 * n1 / (s4 - s1) if s4 > s1 else None,
-                             "note": "bin/rkmh stream on the same reads as plain FASTQ, as BGZF (level 1, 64 KB members; the workers of the device "
-                                     "front end inflate their jobs' members: libdeflate, all but two CPUs) and as single-member gzip (zlib on its "
-                                     "own thread + the block-parallel scanner); marginal = the extra reads of four -f files over one, per extra second"}
-                if hb != hp:
+                             "note": "bin/rkmh stream on the same reads as plain FASTQ, as BGZF (level 1, 64 KB members; bgzf_*: the workers of the "
+                                     "device front end inflate their jobs' members, libdeflate, all but two CPUs = RKMH_BGZF_DEVICE=0, what a file "
+                                     "of this size gets by default; bgzf_device_*: RKMH_BGZF_DEVICE=1, the members inflated on the GPU, rk_inflate.hip, "
+                                     "the default from 5 GB of text on) and as single-member gzip (zlib on its own thread + the block-parallel "
+                                     "scanner); marginal = the extra reads of four -f files over one, per extra second"}
+                if hb != hp or hd != hp:
                     raise SystemExit("e2e: the BGZF run printed other bytes than the plain-text run")
             except RuntimeError as e:
                 res["gz"] = {"error": str(e)}

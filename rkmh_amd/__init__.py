@@ -7,6 +7,12 @@ one-process-per-GPU sharding over torch.distributed / RCCL (`rkmh_amd.dist`).
 
 There is no CPU fallback: without the built library or without a GPU every compute call raises.
 """
+import os as _os
+
+# A stream per front-end worker: the runtime maps streams onto four hardware queues unless told otherwise, and kernels of two streams
+# on one queue run one after the other (profiles/r05_gz.txt).  Read when the HIP runtime starts -- without effect if it already has.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 from .api import Context, Counter, RkmhError, library_path, load_library, parse_files  # noqa: F401
 
 __all__ = ["Context", "Counter", "RkmhError", "library_path", "load_library", "parse_files"]

@@ -394,11 +394,18 @@ static int granted_cpus_main() {
 // BGZF (bgzip) read files found by raw_eligible: the device front end's workers inflate their members themselves (rk_bgzf_*)
 static std::map<std::string, rk_bgzf*> g_bgzf;
 // RKMH_BGZF_DEVICE: who inflates the members.  0: the workers (libdeflate / zlib on the host).  1: the device (rk_inflate.hip: a lane per
-// member, ~34 ms per launch whatever its size -- it pays with about a thousand members per job and several jobs in flight).
-// 2: both -- the last RKMH_BGZF_DEVICE_WORKERS workers take RKMH_BGZF_DEVICE_MERGE consecutive jobs at a time to the device while
-// the others inflate theirs (profiles/r05_gz.txt).
+// member, ~27 ms per launch whatever its size -- it pays with about a thousand members per job and several jobs in flight, so its
+// workers take RKMH_BGZF_DEVICE_MERGE planned jobs at a time).  2: both -- RKMH_BGZF_DEVICE_WORKERS workers feed the device, the
+// others inflate their jobs themselves.  Unset: by size -- the device's slots are four times as large and take ~0.2 s longer to set
+// up, which 24 M reads win back and 8 M do not (profiles/r05_gz.txt): the device from 5 GB of text on, the host below.
 static int bgzf_device_mode() {
-    static const int mode = [] { const char* e = getenv("RKMH_BGZF_DEVICE"); const int v = e ? atoi(e) : 0; return v < 0 || v > 2 ? 0 : v; }();
+    static const int mode = [] {
+        const char* e = getenv("RKMH_BGZF_DEVICE");
+        if (e) { const int v = atoi(e); return v < 0 || v > 2 ? 0 : v; }
+        uint64_t text = 0;
+        for (auto& kv : g_bgzf) text += rk_bgzf_text_bytes(kv.second);
+        return text >= (uint64_t)5 << 30 ? 1 : 0;
+    }();
     return mode;
 }
 static long env_long(const char* name, long dflt, long lo, long hi) { const char* e = getenv(name); if (!e) return dflt; const long v = atol(e); return v < lo || v > hi ? dflt : v; }
@@ -555,17 +562,18 @@ struct RawEngine {
         // that with zlib) -- the CPUs, not the link, set the rate, so all but two of them work
         // (inflated on the device -- the default -- the workers only copy the compressed bytes: two more than for plain text)
         const int zmode = g_bgzf.empty() ? 0 : bgzf_device_mode();
-        if (!g_bgzf.empty()) nw = zmode == 1 ? std::min<long>(cap, nw + 2) : std::max<long>(nw, std::min<long>(32, granted_cpus_main() - 2));
+        if (!g_bgzf.empty()) nw = std::max<long>(nw, std::min<long>(32, granted_cpus_main() - 2));
         if (const char* e = getenv("RKMH_RAW_WORKERS")) { long v = atol(e); if (v >= 1 && v <= 64) nw = v; }
         if ((size_t)nw < g.size()) nw = (long)g.size();
+        if (zmode == 1) nw = 0; // (its workers are the device's, below)
         if (const char* e = getenv("RKMH_RAW_SLOTS")) two_slots = atoi(e) == 2;
         // (the device's workers wait for their kernels most of the time: they come on top of the inflating ones)
-        const long ndev = zmode == 2 ? env_long("RKMH_BGZF_DEVICE_WORKERS", 6, 1, 32) * (long)g.size() : 0;
-        const int merge = zmode == 2 ? (int)env_long("RKMH_BGZF_DEVICE_MERGE", 4, 1, 64) : 1;
+        const long ndev = zmode ? env_long("RKMH_BGZF_DEVICE_WORKERS", zmode == 1 ? 8 : 6, 1, 32) * (long)g.size() : 0;
+        const int merge = zmode ? (int)env_long("RKMH_BGZF_DEVICE_MERGE", 4, 1, 64) : 1;
         w.resize((size_t)(nw + ndev));
         for (size_t i = 0; i < w.size(); ++i) {
             w[i].dev = i % g.size();
-            w[i].inflate = zmode == 1 || (zmode == 2 && i >= (size_t)nw);
+            w[i].inflate = zmode != 0 && i >= (size_t)nw;
             w[i].merge = w[i].inflate ? merge : 1;
             w[i].bytes = block * (uint64_t)w[i].merge + 64; // (+ 64: a last block of exactly `block` bytes may get its missing newline)
         }

@@ -486,7 +486,10 @@ def test_cli_bgzf_input_goes_through_the_device_front_end(root, data_dir, tmp_pa
         assert len(want) > 1000
         # (RKMH_BGZF_DEVICE=1: the members inflated on the device, rk_inflate.hip -- same bytes)
         for member, level, env in ((0xff00, 1, {}), (300, 6, {"RKMH_RAW_BLOCK_KB": "40"}), (20000, 6, {"RKMH_RAW_BLOCK_KB": "128", "RKMH_RAW_WORKERS": "3"}),
-                                   (0xff00, 1, {"RKMH_BGZF_DEVICE": "1", "RKMH_RAW_BLOCK_KB": "2048"}), (20000, 6, {"RKMH_BGZF_DEVICE": "1", "RKMH_RAW_BLOCK_KB": "300"})):
+                                   (0xff00, 1, {"RKMH_BGZF_DEVICE": "1", "RKMH_RAW_BLOCK_KB": "2048"}), (20000, 6, {"RKMH_BGZF_DEVICE": "1", "RKMH_RAW_BLOCK_KB": "300"}),
+                                   # (2: some workers feed the device runs of planned jobs, the others inflate theirs)
+                                   (0xff00, 1, {"RKMH_BGZF_DEVICE": "2", "RKMH_RAW_BLOCK_KB": "512", "RKMH_BGZF_DEVICE_WORKERS": "3", "RKMH_BGZF_DEVICE_MERGE": "3"}),
+                                   (20000, 6, {"RKMH_BGZF_DEVICE": "2", "RKMH_RAW_BLOCK_KB": "200", "RKMH_RAW_WORKERS": "2"})):
             if cmd == "filter" and member == 300:
                 continue
             gz = tmp_path / ("reads_%d.fq.gz" % member)
@@ -505,6 +508,12 @@ def test_cli_bgzf_input_goes_through_the_device_front_end(root, data_dir, tmp_pa
     plain_gz = tmp_path / "plain.fq.gz"
     plain_gz.write_bytes(gzip.compress(text, 1))
     assert _cli(root, base + ["-f", str(nonl), "-f", str(fq), "-f", str(plain_gz)], env={"RKMH_RAW_BLOCK_KB": "700"}) == want * 3
+    # several files, runs of jobs taken by the device's workers while the others inflate (the run leaves the queue in one step)
+    for mode, extra in (("1", {}), ("2", {"RKMH_RAW_WORKERS": "5"}), ("2", {"RKMH_BGZF_DEVICE_MERGE": "7", "RKMH_BGZF_DEVICE_WORKERS": "2"})):
+        for rep in range(2):
+            got = _cli(root, base + ["-f", str(nonl), "-f", str(tmp_path / "reads_65280.fq.gz"), "-f", str(nonl), "-f", str(fq)],
+                       env=dict({"RKMH_RAW_BLOCK_KB": "150", "RKMH_BGZF_DEVICE": mode}, **extra))
+            assert got == want * 4, (mode, extra)
     # irregular from the middle on (sequences on two lines): the scanner takes over at that job's first record
     half = _fastq(reads[: n // 2], names=[b"read%07d comment" % i for i in range(n // 2)])
     odd = b"".join(b"@m%d\n" % i + r[:70] + b"\n" + r[70:] + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(reads[n // 2: n // 2 + 800]) if len(r) > 80)
@@ -516,6 +525,10 @@ def test_cli_bgzf_input_goes_through_the_device_front_end(root, data_dir, tmp_pa
     r = subprocess.run([exe] + base + ["-f", str(mixed_gz)], capture_output=True, env=dict(os.environ, RKMH_TIMING="1", RKMH_RAW_BLOCK_KB="256"))
     assert r.returncode == 0 and r.stdout == want_mixed
     assert b"not four lines per record" in r.stderr
+    for mode in ("1", "2"):     # (the hand-over happens at the first block number of a merged job)
+        r = subprocess.run([exe] + base + ["-f", str(mixed_gz)], capture_output=True, env=dict(os.environ, RKMH_TIMING="1", RKMH_RAW_BLOCK_KB="256", RKMH_BGZF_DEVICE=mode))
+        assert r.returncode == 0 and r.stdout == want_mixed, mode
+        assert b"not four lines per record" in r.stderr
 
 
 def test_cli_reads_from_a_registered_file_mapping(root, data_dir, tmp_path):

@@ -16,9 +16,8 @@ run() { # label, env...
   python3 -c "print('%-44s 8 M reads %.3f s, 24 M reads %.3f s, marginal %.1f M reads/s   sha %s' % ('$label', $best1, $best3, 16.0 / ($best3 - $best1), '$(sha256sum /tmp/sw.out1 | cut -c1-12)'))"
 }
 run "host inflate" RKMH_BGZF_DEVICE=0
-run "device inflate, 64 MB x 8" RKMH_BGZF_DEVICE=1 RKMH_RAW_BLOCK_KB=65536 RKMH_RAW_WORKERS=8
-run "device inflate, 64 MB x 12" RKMH_BGZF_DEVICE=1 RKMH_RAW_BLOCK_KB=65536 RKMH_RAW_WORKERS=12
+run "device inflate (8 workers x 4 jobs)" RKMH_BGZF_DEVICE=1
+run "device inflate (12 workers x 4 jobs)" RKMH_BGZF_DEVICE=1 RKMH_BGZF_DEVICE_WORKERS=12
 run "both: 6 device workers x 4 jobs" RKMH_BGZF_DEVICE=2
-run "both: 8 device workers x 4 jobs" RKMH_BGZF_DEVICE=2 RKMH_BGZF_DEVICE_WORKERS=8
 run "both: 8 x 4, 12 host workers" RKMH_BGZF_DEVICE=2 RKMH_RAW_WORKERS=12 RKMH_BGZF_DEVICE_WORKERS=8
-run "both: 10 x 4, 10 host workers" RKMH_BGZF_DEVICE=2 RKMH_RAW_WORKERS=10 RKMH_BGZF_DEVICE_WORKERS=10
+run "by size (unset)" RKMH_NOTHING=1
