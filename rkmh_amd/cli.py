@@ -276,7 +276,7 @@ def _device_ingest(ctx, rank, local, world, reads, ref_names, sketch, min_occ, m
                             on_device = False
                             if bz is not None:      # members [s0, s1): inflated on the device (rk_inflate.hip), else here; cut to the whole records that start in them
                                 st = 1
-                                if os.environ.get("RKMH_BGZF_DEVICE", "0") not in ("", "0"):      # opt-in: the host inflater is faster (profiles/r05_gz.txt)
+                                if os.environ.get("RKMH_BGZF_DEVICE", "0") not in ("", "0"):      # opt-in here: it pays with ~1 000 members per job and several jobs in flight (RKMH_RAW_BLOCK_KB=65536; bin/rkmh arranges that itself, profiles/r05_gz.txt)
                                     st, n, _ = slot.load_bgzf(bz, s0, s1)
                                     on_device = st == 0
                                 if st != 0:
