@@ -366,7 +366,8 @@ struct ScopedHostRegister {
 // memory runs at a fraction of the link rate and blocks the caller for the whole transfer.
 static int upload_staged(rk_ctx* c, void* dst, const uint8_t* src, size_t bytes, hipStream_t st) {
     const size_t CH = 16u << 20;
-    if (bytes <= (1u << 20)) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); return RK_OK; }
+    // (a few megabytes -- a reference panel -- are not worth two 16 MB page-locked buffers: creating those takes longer than the copy)
+    if (bytes <= (4u << 20)) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); return RK_OK; }
     for (int i = 0; i < 2; ++i) {
         if (c->slot[i].busy) { HIPCHK(hipEventSynchronize(c->slot[i].done)); c->slot[i].busy = false; }
         RKCHK(c->slot[i].h_bases.reserve(CH));
@@ -402,6 +403,14 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
     const uint64_t PRESEL_MAX_HASHES = 1ull << 18; // one block streams its sequence a few times; beyond this the multi-block select is faster (measured: 3 M hashes 4 ms vs 0.7 ms)
     uint64_t hash_cursor = 0; // position in out.hashes
     int64_t i0 = 0;
+    static const bool gtiming = getenv("RKMH_INDEX_TIMING") != nullptr; // (stderr: where a general-path batch spends its time)
+    auto gt0 = std::chrono::steady_clock::now();
+    auto gtick = [&](const char* what) {
+        if (!gtiming) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rkmh general] %-24s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - gt0).count());
+        gt0 = now;
+    };
     while (i0 < n) {
         // ---- pick a chunk [i0,i1)
         int64_t i1 = i0;
@@ -456,6 +465,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
             cb += len; ch += nh; ++i1;
         }
         const int64_t cn = i1 - i0;
+        gtick("chunk planned");
         // ---- upload
         const uint8_t* d_bases;
         if (d_bases_in) d_bases = cfg.abs_starts ? d_bases_in : d_bases_in + base0;
@@ -478,6 +488,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
         HIPCHK(launch_hash_tiles(d_bases, c->w_tiles.as<TileDesc>(), (uint32_t)tiles.size(), c->w_hashes.as<uint64_t>(),
                                  cfg.inc_counter ? cfg.inc_counter->d : nullptr, cfg.inc_counter ? cfg.inc_counter->slots : 1,
                                  c->pol, c->st));
+        gtick("uploaded, hashing launched");
         if (out.hashes && !out.write_back_sorted && ch)
             HIPCHK(hipMemcpyAsync(out.hashes + hash_cursor, c->w_hashes.p, ch * 8, hipMemcpyDeviceToHost, c->st));
         if (cfg.depth_insert) HIPCHK(launch_depth_insert(c->w_hashes.as<uint64_t>(), ch, *cfg.depth_insert, c->st));
@@ -585,8 +596,10 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
                     HIPCHK(hipStreamSynchronize(c->st)); // w_sel / state are reused by the next long sequence
                 }
             }
+            gtick("sorts launched");
             // the ids vectors must outlive the async copies
             HIPCHK(hipStreamSynchronize(c->st));
+            gtick("kernels done");
             if (out.write_back_sorted && out.hashes && ch)
                 HIPCHK(hipMemcpyAsync(out.hashes + hash_cursor, c->w_hashes.p, ch * 8, hipMemcpyDeviceToHost, c->st));
             if (out.sketches) HIPCHK(hipMemcpyAsync(out.sketches + (size_t)i0 * S, c->w_sk.p, (size_t)cn * S * 8, hipMemcpyDeviceToHost, c->st));
@@ -595,6 +608,7 @@ static int general_run(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases_i
             if (ntail) HIPCHK(hipMemcpyAsync(out.tail_counts + (size_t)i0 * ntail, c->w_tail.p, (size_t)cn * ntail * 4, hipMemcpyDeviceToHost, c->st));
         }
         HIPCHK(hipStreamSynchronize(c->st));
+        gtick("results downloaded");
         // -M with a bounded min_num: the general path computes min_num exactly; rows carry min(min_num, bound) on every path
         if (out.out4 && cfg.classify && !cfg.keep_all && (cfg.filter_mode == FILTER_MASK_MIN || cfg.filter_mode == FILTER_KEYMASK) && c->min_num_bound >= 0)
             for (int64_t q = i0; q < i1; ++q) if (out.out4[q * 4 + 3] > c->min_num_bound) out.out4[q * 4 + 3] = c->min_num_bound;
@@ -1340,7 +1354,20 @@ static int build_index(rk_ctx* c) {
             uint64_t h = c->h_sk[(size_t)r * S + j];
             if (h != 0) pairs.push_back(Pair{h, (uint32_t)r});
         }
-    std::sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) { return a.h != b.h ? a.h < b.h : a.ref < b.ref; });
+    // by (hash, reference): the pairs come in reference order, so a stable radix sort on the hash alone (four 16-bit digits) does it
+    {
+        std::vector<Pair> tmp(pairs.size());
+        std::vector<uint32_t> cnt((size_t)1 << 16);
+        for (int pass = 0; pass < 4; ++pass) {
+            const int sh = 16 * pass;
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            for (const Pair& p : pairs) ++cnt[(size_t)((p.h >> sh) & 0xFFFFu)];
+            uint32_t run = 0;
+            for (uint32_t& v : cnt) { const uint32_t here = v; v = run; run += here; }
+            for (const Pair& p : pairs) tmp[cnt[(size_t)((p.h >> sh) & 0xFFFFu)]++] = p;
+            pairs.swap(tmp);
+        }
+    }
     clk.tick("pairs sorted");
     size_t distinct = 0;
     for (size_t i = 0; i < pairs.size(); ++i) if (i == 0 || pairs[i].h != pairs[i - 1].h) ++distinct;
