@@ -404,7 +404,9 @@ static int bgzf_device_mode() {
         if (e) { const int v = atoi(e); return v < 0 || v > 2 ? 0 : v; }
         uint64_t text = 0;
         for (auto& kv : g_bgzf) text += rk_bgzf_text_bytes(kv.second);
-        return text >= (uint64_t)5 << 30 ? 1 : 0;
+        const char* m = getenv("RKMH_BGZF_DEVICE_MIN_MB"); // (the size from which the device inflates; tests lower it)
+        const uint64_t from = m && atol(m) >= 0 ? (uint64_t)atol(m) << 20 : (uint64_t)5 << 30;
+        return text >= from ? 1 : 0;
     }();
     return mode;
 }

@@ -509,11 +509,16 @@ def test_cli_bgzf_input_goes_through_the_device_front_end(root, data_dir, tmp_pa
     plain_gz.write_bytes(gzip.compress(text, 1))
     assert _cli(root, base + ["-f", str(nonl), "-f", str(fq), "-f", str(plain_gz)], env={"RKMH_RAW_BLOCK_KB": "700"}) == want * 3
     # several files, runs of jobs taken by the device's workers while the others inflate (the run leaves the queue in one step)
-    for mode, extra in (("1", {}), ("2", {"RKMH_RAW_WORKERS": "5"}), ("2", {"RKMH_BGZF_DEVICE_MERGE": "7", "RKMH_BGZF_DEVICE_WORKERS": "2"})):
+    for mode, extra in (("1", {}), ("2", {"RKMH_RAW_WORKERS": "5"}), ("2", {"RKMH_BGZF_DEVICE_MERGE": "7", "RKMH_BGZF_DEVICE_WORKERS": "2"}),
+                        (None, {"RKMH_BGZF_DEVICE_MIN_MB": "1"})):      # (unset: the device from a size on -- here from 1 MB)
         for rep in range(2):
-            got = _cli(root, base + ["-f", str(nonl), "-f", str(tmp_path / "reads_65280.fq.gz"), "-f", str(nonl), "-f", str(fq)],
-                       env=dict({"RKMH_RAW_BLOCK_KB": "150", "RKMH_BGZF_DEVICE": mode}, **extra))
-            assert got == want * 4, (mode, extra)
+            env = dict({"RKMH_RAW_BLOCK_KB": "150"}, **extra)
+            if mode is not None:
+                env["RKMH_BGZF_DEVICE"] = mode
+            r = subprocess.run([exe] + base + ["-f", str(nonl), "-f", str(tmp_path / "reads_65280.fq.gz"), "-f", str(nonl), "-f", str(fq)], capture_output=True,
+                               env=dict({k: v for k, v in os.environ.items() if k != "RKMH_BGZF_DEVICE"}, RKMH_BGZF_TIMING="1", **env))
+            assert r.returncode == 0 and r.stdout == want * 4, (mode, extra, r.stderr[-600:])
+            assert b"[bgzf device]" in r.stderr, (mode, extra)      # (jobs did go through rk_inflate.hip)
     # irregular from the middle on (sequences on two lines): the scanner takes over at that job's first record
     half = _fastq(reads[: n // 2], names=[b"read%07d comment" % i for i in range(n // 2)])
     odd = b"".join(b"@m%d\n" % i + r[:70] + b"\n" + r[70:] + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(reads[n // 2: n // 2 + 800]) if len(r) > 80)
