@@ -22,6 +22,7 @@
 // CRC-32 is NOT checked here (ISIZE and the stream's own end-of-block structure are); a damaged member almost surely breaks the
 // four-line grammar that the front end verifies next, and RKMH_BGZF_DEVICE=0 keeps the host inflater with its CRC check.
 #include "rk_kernels.hpp"
+#include <atomic>
 
 namespace rk {
 
@@ -534,8 +535,15 @@ uint32_t inflate_scratch_dwords(uint32_t out_len) { return entry_cap(out_len) + 
 hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint32_t* scratch, uint32_t* status,
                                   hipStream_t st) {
     if (!nmem) return hipSuccess;
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds));
-    if (attr != hipSuccess) return attr;
+    // (once per device: the call takes the runtime's lock, and a dozen workers launch from their own threads)
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
+    if (!((attr_set.load(std::memory_order_acquire) >> dev) & 1ull) || dev == 63) {
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds));
+        if (attr != hipSuccess) return attr;
+        attr_set.fetch_or(1ull << dev, std::memory_order_release);
+    }
     hipLaunchKernelGGL(k_inflate_lanes, dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds), st, comp, comp_bytes, mem, nmem, scratch, status);
     hipLaunchKernelGGL(k_inflate_place, dim3(nmem), dim3(IW), 0, st, mem, nmem, text, scratch, status);
     return hipGetLastError();

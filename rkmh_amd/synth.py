@@ -118,10 +118,11 @@ def synthetic_panel(nref=182, min_len=7100, max_len=8104, seed=SEED ^ 0xFFFF):
     return bases, offs
 
 
-def bgzf_compress(data, level=1, block=0xff00, threads=8):
+def bgzf_compress(data, level=1, block=0xff00, threads=8, strategy=0, mem_level=8):
     """`data` (bytes-like) as a BGZF file image: independent gzip members of at most `block` bytes of text each, the 'BC' extra
     field carrying each member's length, the empty end-of-file member last -- what `bgzip` writes (SAM specification, section 4.1).
-    Members are deflated in `threads` threads (zlib releases the GIL)."""
+    Members are deflated in `threads` threads (zlib releases the GIL).  strategy / mem_level: zlib's (Z_FIXED, Z_RLE, Z_HUFFMAN_ONLY ...;
+    a small mem_level means many deflate blocks per member) -- for tests of inflaters."""
     import struct
     import zlib
     from concurrent.futures import ThreadPoolExecutor
@@ -129,7 +130,7 @@ def bgzf_compress(data, level=1, block=0xff00, threads=8):
 
     def member(lo):
         chunk = mv[lo: lo + block]
-        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, mem_level, strategy)
         body = co.compress(chunk) + co.flush()
         if len(body) + 26 > 65536:                       # incompressible: store it
             co = zlib.compressobj(0, zlib.DEFLATED, -15)

@@ -77,6 +77,61 @@ def test_device_inflate_equals_host_inflate(gctx, tmp_path, level, member, qual)
         z.close()
 
 
+def _skewed_fastq(rng, n, alphabet):
+    """records whose names and qualities draw from `alphabet` with geometric weights: the rare symbols get Huffman codes far longer
+    than the decoder's root tables (9 bits literal/length, 7 bits distance)"""
+    a = np.frombuffer(alphabet, np.uint8)
+    w = 0.82 ** np.arange(len(a)); w /= w.sum()
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(20, 600))
+        s = bytes(rng.choice(np.frombuffer(b"ACGTNacgtn", np.uint8), size=L, p=[0.28, 0.2, 0.2, 0.28, 0.01, 0.01, 0.005, 0.005, 0.005, 0.005]))
+        q = bytes(rng.choice(a, size=L, p=w))
+        nm = bytes(rng.choice(a, size=int(rng.integers(1, 60)), p=w)).replace(b"@", b"a")
+        recs.append(b"@" + nm + b"\n" + s + b"\n+" + (nm if i % 5 == 0 else b"") + b"\n" + q + b"\n")
+    return b"".join(recs)
+
+
+@pytest.mark.parametrize("level,strategy,mem_level,member", [(6, 0, 8, 0xff00), (9, 0, 1, 0xff00), (6, 4, 8, 0xff00), (6, 3, 8, 50000), (6, 2, 8, 0xff00), (6, 1, 2, 30000),
+                                                              (1, 0, 1, 0xff00), (9, 0, 9, 7000)])
+def test_device_inflate_long_codes_many_blocks_every_strategy(gctx, tmp_path, level, strategy, mem_level, member):
+    """zlib's strategies (0 default, 1 filtered, 2 Huffman only, 3 RLE: distance 1, 4 fixed codes) and memory levels (1: a deflate block
+    every ~128 symbols' worth of buffer -- hundreds of block headers and code tables per member) on text with a skewed 90-symbol
+    alphabet (code lengths up to 15): the device's text equals the host inflater's for every job."""
+    import zlib
+    from rkmh_amd import api, synth
+    rng = np.random.default_rng(1000 * level + 10 * strategy + mem_level)
+    alphabet = bytes(c for c in range(33, 127) if c != ord("@"))
+    text = _skewed_fastq(rng, 2500, alphabet)
+    path = tmp_path / "s.fq.gz"
+    path.write_bytes(synth.bgzf_compress(text, level=level, block=member, strategy=strategy, mem_level=mem_level))
+    z = api.Bgzf.open(str(path))
+    assert z is not None and z.text_bytes == len(text)
+    cap = 1 << 21
+    slot = api.FastqSlot(gctx, max_bytes=cap)
+    host = C.create_string_buffer(cap + 64)
+    try:
+        for target in (200000, 1500000):
+            first = z.plan(target)
+            got_all = b""
+            on_device = 0
+            for b0, b1 in zip(first, first[1:]):
+                st, n, off = z.fastq_records(b0, b1, host, cap)
+                assert st == 0
+                dst, dn, doff = slot.load_bgzf(z, b0, b1)
+                if dst == 0:
+                    on_device += 1
+                    assert (dn, doff) == (n, off) or n == 0, (b0, b1, dn, n, doff, off)
+                    res = slot.classify_raw(dn)
+                    assert bytes(slot.text_buffer()[:dn]) == host.raw[:n], (level, strategy, mem_level, b0, b1)
+                got_all += host.raw[:n]
+            assert got_all == text
+            assert on_device >= len(first) - 2, (on_device, len(first))      # (the device inflated them: no silent hand-over of whole files)
+    finally:
+        slot.destroy()
+        z.close()
+
+
 def test_device_inflate_refuses_damaged_members(gctx, tmp_path):
     from rkmh_amd import api, synth
     rng = np.random.default_rng(3)
