@@ -433,7 +433,7 @@ int64_t rk_bgzf_plan(const rk_bgzf* z, uint64_t target_bytes, int64_t* first, in
 int rk_bgzf_fastq_records(const rk_bgzf* z, int64_t b0, int64_t b1, uint8_t* dst, uint64_t cap, uint64_t* nbytes, uint64_t* text_off);
 const uint8_t* rk_bgzf_image(const rk_bgzf* z);   /* the mapped file */
 int rk_bgzf_member(const rk_bgzf* z, int64_t member, uint64_t* file_off, uint32_t* total_bytes, uint32_t* header_bytes, uint32_t* text_bytes);
-/* The same job inflated ON THE DEVICE (rk_inflate.hip: one wave per member, the text built in LDS): the compressed bytes cross the
+/* The same job inflated ON THE DEVICE (rk_inflate.hip: a lane per member decodes, a wave per member resolves the matches in LDS): the compressed bytes cross the
  * link instead of the text, the records that start in members [b0, b1) land in the slot's device text buffer and a copy of them in
  * rk_fastq_slot_text() (for the output formatters); the NEXT rk_fastq_slot_submit / _classify / _count of the slot is given
  * *nbytes and skips its upload.  Returns RK_OK, or 1: take the host route (rk_bgzf_fastq_records) for this job.  CRC-32 is not
