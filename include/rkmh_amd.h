@@ -439,6 +439,11 @@ int rk_bgzf_member(const rk_bgzf* z, int64_t member, uint64_t* file_off, uint32_
  * *nbytes and skips its upload.  Returns RK_OK, or 1: take the host route (rk_bgzf_fastq_records) for this job.  CRC-32 is not
  * checked on this route (ISIZE and the four-line grammar are). */
 int rk_fastq_slot_load_bgzf(rk_fastq_slot* slot, const rk_bgzf* z, int64_t b0, int64_t b1, uint64_t* nbytes, uint64_t* text_off);
+/* Its two halves, for callers that keep two slots per thread: _begin enqueues the upload and the inflate kernels and returns at
+ * once (RK_OK, or 1: host route); _end waits for them and moves the records into place (RK_OK, or 1: host route after all).  The
+ * ~30 ms a job spends in the decode kernel pass while the caller finishes its previous job in the other slot. */
+int rk_fastq_slot_load_bgzf_begin(rk_fastq_slot* slot, const rk_bgzf* z, int64_t b0, int64_t b1);
+int rk_fastq_slot_load_bgzf_end(rk_fastq_slot* slot, uint64_t* nbytes, uint64_t* text_off);
 
 #ifdef __cplusplus
 }

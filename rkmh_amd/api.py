@@ -113,6 +113,8 @@ _SIGS = {
     "rk_bgzf_plan": (C.c_int64, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), C.c_int64]),
     "rk_bgzf_fastq_records": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_fastq_slot_load_bgzf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rk_fastq_slot_load_bgzf_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "rk_fastq_slot_load_bgzf_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_counter_create_compact": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rk_counter_compact_entries": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rk_counter_entries": (C.c_uint64, [C.c_void_p]),

@@ -2486,6 +2486,7 @@ struct rk_fastq_slot {
     PinBuf h_comp, h_mem;
     DevBuf d_comp, d_mem, d_inf, d_match;
     bool text_on_device = false;
+    struct { bool pending = false; int64_t b0 = 0, b1 = 0, nb = 0; uint64_t u_lo = 0, ntext = 0; uint32_t nm = 0; } inf; // between load_bgzf_begin and _end
     // rk_fastq_slot_set_source: the block's text lies in caller memory (a page-locked mapping of the file): the next submit uploads it
     // from there, and the slot reads the text there where it needs it on the host (rerouted reads)
     const uint8_t* src = nullptr;      // of the block in flight (nullptr: h_text)
@@ -2564,14 +2565,13 @@ extern "C" int rk_fastq_slot_set_source(rk_fastq_slot* s, const uint8_t* text) {
 // formatters.  The NEXT rk_fastq_slot_submit / _classify / _count of this slot takes *nbytes and skips its upload.
 // Returns RK_OK, or 1: this job is for the host route (rk_bgzf_fastq_records) -- a member the device could not inflate, text that
 // does not begin with '@', a record that outgrows the lookahead or the slot.
-extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64_t b0, int64_t b1, uint64_t* nbytes, uint64_t* text_off) {
+extern "C" int rk_fastq_slot_load_bgzf_begin(rk_fastq_slot* s, const rk_bgzf* z, int64_t b0, int64_t b1) {
     static const bool timing = getenv("RKMH_BGZF_TIMING") != nullptr;
     const auto t_0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-
-    if (!s || !z || !nbytes || b0 < 0 || b1 <= b0 || b1 > rk_bgzf_members(z)) return fail(RK_ERR_ARG, "bad arguments");
-    *nbytes = 0;
+    if (!s || !z || b0 < 0 || b1 <= b0 || b1 > rk_bgzf_members(z)) return fail(RK_ERR_ARG, "bad arguments");
     s->text_on_device = false;
+    s->inf.pending = false;
     rk_ctx* c = s->c;
     RKCHK(set_dev(c));
     hipStream_t st = s->st;
@@ -2585,7 +2585,6 @@ extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64
     const uint64_t cbytes = f_hi + tot - f_lo;
     const uint64_t u_lo = rk_bgzf_text_offset(z, lo), u_b0 = rk_bgzf_text_offset(z, b0), u_b1 = rk_bgzf_text_offset(z, b1), u_ext = rk_bgzf_text_offset(z, ext);
     const uint64_t ntext = u_ext - u_lo;
-    if (text_off) *text_off = u_b0;
     if (ntext > s->max_bytes + 4 * 65536ull || cbytes >= ((uint64_t)1 << 31)) return 1;
     // (sized for the slot, not for this job: growing a page-locked buffer by a few kilobytes per job costs ~100 ms each time, and
     // every job of a file is a little different -- 5/8 of the text covers level-1 FASTQ, a member is at most 64 KB of text)
@@ -2628,12 +2627,31 @@ extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64
     HIPCHK(hipMemcpyAsync(h_info + 2, s->d_inf.as<uint8_t>(), 1, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(h_info + 2) + 1, s->d_inf.as<uint8_t>() + (ntext ? ntext - 1 : 0), 1, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(s->ev, st));
-    const double t_enq = ms_since(t_0);
+    if (timing) fprintf(stderr, "[bgzf device] %u members, %.1f MB in, %.1f MB text: reserve %.1f ms, copy %.1f, enqueue %.1f\n", nm, cbytes / 1e6, ntext / 1e6,
+                        t_reserve, t_copy - t_reserve, ms_since(t_0) - t_copy);
+    s->inf.pending = true; s->inf.b0 = b0; s->inf.b1 = b1; s->inf.nb = nb; s->inf.u_lo = u_lo; s->inf.ntext = ntext; s->inf.nm = nm;
+    return RK_OK;
+}
+
+extern "C" int rk_fastq_slot_load_bgzf_end(rk_fastq_slot* s, uint64_t* nbytes, uint64_t* text_off) {
+    if (!s || !nbytes) return fail(RK_ERR_ARG, "bad arguments");
+    *nbytes = 0;
+    if (!s->inf.pending) return fail(RK_ERR_STATE, "rk_fastq_slot_load_bgzf_end without a begun job");
+    s->inf.pending = false;
+    rk_ctx* c = s->c;
+    RKCHK(set_dev(c));
+    hipStream_t st = s->st;
+    const int64_t b0 = s->inf.b0, b1 = s->inf.b1, nb = s->inf.nb;
+    const uint64_t u_lo = s->inf.u_lo, ntext = s->inf.ntext;
+    const uint32_t nm = s->inf.nm;
+    const uint32_t* h_status = reinterpret_cast<const uint32_t*>(s->h_mem.as<uint8_t>() + (((size_t)nm * sizeof(InflateMember) + 15) & ~(size_t)15));
+    const uint32_t* h_info = s->h_info.as<uint32_t>();
+    static const bool timing = getenv("RKMH_BGZF_TIMING") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
     HIPCHK(hipEventSynchronize(s->ev));
-    if (timing) fprintf(stderr, "[bgzf device] %u members, %.1f MB in, %.1f MB text: reserve %.1f ms, copy %.1f, enqueue %.1f, wait %.1f\n", nm, cbytes / 1e6, ntext / 1e6,
-                        t_reserve, t_copy - t_reserve, t_enq - t_copy, ms_since(t_0) - t_enq);
+    if (timing) fprintf(stderr, "[bgzf device] waited %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count());
     for (uint32_t i = 0; i < nm; ++i) if (h_status[i] != 0) return 1;
-    const uint8_t first_byte = reinterpret_cast<uint8_t*>(h_info + 2)[0], last_byte = reinterpret_cast<uint8_t*>(h_info + 2)[1];
+    const uint8_t first_byte = reinterpret_cast<const uint8_t*>(h_info + 2)[0], last_byte = reinterpret_cast<const uint8_t*>(h_info + 2)[1];
     uint64_t head = b0 > 0 ? h_info[0] : 0, tail = b1 < nb ? h_info[1] : ntext;
     if (head == 0xFFFFFFFFull || tail == 0xFFFFFFFFull) return 1;
     if (head > tail) head = tail;
@@ -2649,6 +2667,15 @@ extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64
     s->text_on_device = true;
     *nbytes = n;
     return RK_OK;
+}
+
+extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64_t b0, int64_t b1, uint64_t* nbytes, uint64_t* text_off) {
+    if (!nbytes) return fail(RK_ERR_ARG, "bad arguments");
+    *nbytes = 0;
+    if (text_off && z && b0 >= 0 && b0 < rk_bgzf_members(z)) *text_off = rk_bgzf_text_offset(z, b0);
+    const int rc = rk_fastq_slot_load_bgzf_begin(s, z, b0, b1);
+    if (rc != RK_OK) return rc;
+    return rk_fastq_slot_load_bgzf_end(s, nbytes, text_off);
 }
 
 // The two halves of rk_fastq_slot_classify, for callers that keep two slots per thread: submit() enqueues the upload and the

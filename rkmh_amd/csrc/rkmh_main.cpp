@@ -542,7 +542,7 @@ struct OrderedOut {
 
 struct RawEngine {
     // two slots: one block on the device while the next is read; inflate: this worker's BGZF jobs are inflated on the device, `merge` planned jobs at a time
-    struct Worker { rk_fastq_slot* slot[2] = {nullptr, nullptr}; size_t dev = 0; bool inflate = false; int merge = 1; uint64_t bytes = 0; };
+    struct Worker { rk_fastq_slot* slot[2] = {nullptr, nullptr}; size_t dev = 0; bool inflate = false; int merge = 1; uint64_t bytes = 0; bool two = false; };
     std::vector<Worker> w;
     uint64_t block = 0;
     bool two_slots = false; // RKMH_RAW_SLOTS=2: a worker reads its next block while the previous one is on the device.  Measured (profiles/r04_e2e_ab.txt,
@@ -578,6 +578,9 @@ struct RawEngine {
             w[i].inflate = zmode != 0 && i >= (size_t)nw;
             w[i].merge = w[i].inflate ? merge : 1;
             w[i].bytes = block * (uint64_t)w[i].merge + 64; // (+ 64: a last block of exactly `block` bytes may get its missing newline)
+            // RKMH_BGZF_DEVICE_SLOTS=2: a worker that feeds the device keeps two jobs going -- the next one's inflate kernels run while it finishes
+            // the previous one.  Measured slower (profiles/r05_gz.txt): sixteen jobs' decode waves then hold the LDS of every CU
+            w[i].two = two_slots || (w[i].inflate && env_long("RKMH_BGZF_DEVICE_SLOTS", 1, 1, 2) == 2);
         }
         // each worker creates its own slot when it starts (page-locking ~50 MB takes ~10 ms): the first blocks are on their way
         // while the later workers are still setting up.  Only the first slot is made here, to find out whether the front end works at all.
@@ -637,7 +640,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     rk_bgzf* const bz = bgzf_of(path); // compressed (BGZF): a job is a run of members [lo, hi), inflated by the worker that takes it
     // at: where the job's first record starts in the (uncompressed) text; ext: its text in the mapped file; nseq: planned jobs merged into this one
     // left: planned jobs after this one
-    struct Job { int64_t seq = 0, lo = 0, hi = 0, at = 0; const uint8_t* ext = nullptr; int64_t nseq = 1, left = INT64_MAX; };
+    struct Job { int64_t seq = 0, lo = 0, hi = 0, at = 0; const uint8_t* ext = nullptr; int64_t nseq = 1, left = INT64_MAX; bool begun = false; }; // begun: its inflate kernels are under way (rk_fastq_slot_load_bgzf_begin)
     // RKMH_RAW_MMAP=1: the file is mapped and the mapping page-locked (hipHostRegister): the link reads the page cache itself, the
     // workers copy nothing (tools/ubench/mmap_register.hip)
     const uint8_t* fmap = nullptr;
@@ -658,7 +661,8 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
     std::mutex tm;
     std::atomic<int> live{(int)eng.w.size()};
     auto work = [&](size_t wi) {
-        for (int k = 0; k < (eng.two_slots ? 2 : 1); ++k)
+        const bool two = eng.w[wi].two;
+        for (int k = 0; k < (two ? 2 : 1); ++k)
             if (!eng.w[wi].slot[k] && rk_fastq_slot_create(g.ctx[eng.w[wi].dev], eng.w[wi].bytes, &eng.w[wi].slot[k]) != RK_OK) {
                 // (memory for another slot ran out: the other workers carry on -- unless this was the last one)
                 fprintf(stderr, "rkmh: worker %zu: %s\n", wi, rk_last_error());
@@ -693,6 +697,32 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
             put_rest(jb);
             if (getenv("RKMH_TRACE_JOBS")) fprintf(stderr, "[job] worker %zu parked blocks %lld..%lld\n", wi, (long long)jb.seq, (long long)(jb.seq + jb.nseq - 1));
         };
+        // the scanner takes the file over from this job's first record
+        auto refuse = [&](const Job& jb) {
+            { std::lock_guard<std::mutex> l(fm); fail_at[jb.seq] = jb.at; }
+            if (!counting) out.lower_limit(jb.seq);
+            int64_t curf = fail_seq.load();
+            while (jb.seq < curf && !fail_seq.compare_exchange_weak(curf, jb.seq)) {}
+            if (!counting) out.put(jb.seq, std::vector<char>(), 0, window);
+            put_rest(jb);
+        };
+        // a job whose inflate was begun: wait for it, cut its records (or inflate it here after all), hand it to the index kernels
+        auto finish_load = [&](Job& jb, rk_fastq_slot* slot) {
+            const double a = now_s();
+            uint64_t nbytes = 0, off = (uint64_t)jb.at;
+            int rc = rk_fastq_slot_load_bgzf_end(slot, &nbytes, &off);
+            if (rc < 0) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
+            uint8_t* text = rk_fastq_slot_text(slot);
+            const bool on_device = rc == RK_OK;
+            if (!on_device) rc = rk_bgzf_fastq_records(bz, jb.lo, jb.hi, text, eng.w[wi].bytes - 1, &nbytes, &off);
+            jb.at = (int64_t)off;
+            if (rc == 1 || rc == RK_ERR_LIMIT) { refuse(jb); t_rd += now_s() - a; return false; }
+            if (rc != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
+            if (!on_device && jb.hi == rk_bgzf_members(bz) && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n';
+            if (rk_fastq_slot_submit(slot, nbytes) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+            t_rd += now_s() - a;
+            return true;
+        };
         // block b is on its way to the device and through the index kernels (submit) while block b + 1 is read into the other slot
         for (;;) {
             bool got;
@@ -710,7 +740,16 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
             }
             static const bool trace = getenv("RKMH_TRACE_JOBS") != nullptr;
             if (trace && got) fprintf(stderr, "[job] worker %zu (%s) takes blocks %lld..%lld\n", wi, eng.w[wi].inflate ? "device" : "host", (long long)cur.seq, (long long)(cur.seq + cur.nseq - 1));
-            if (got) {
+            cur.begun = false;
+            if (got && to_device && two && !counting) { // its kernels start now; the job is completed (finish_load) after the previous one has left
+                const double a = now_s();
+                const int rc = rk_fastq_slot_load_bgzf_begin(eng.w[wi].slot[k], bz, cur.lo, cur.hi);
+                if (rc < 0) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
+                cur.begun = rc == RK_OK;
+                if (!cur.begun) to_device = false; // (too large for the slot: inflated here, below)
+                t_rd += now_s() - a;
+            }
+            if (got && !cur.begun) {
                 const double a = now_s();
                 uint8_t* text = rk_fastq_slot_text(eng.w[wi].slot[k]);
                 uint64_t nbytes = 0;
@@ -742,13 +781,8 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                     nbytes = (uint64_t)(cur.hi - cur.lo);
                     if (cur.hi == fsize && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n'; // a last line without its newline (the slot holds 64 spare bytes)
                 }
-                if (refused) { // the scanner takes the file over from this job's first record
-                    { std::lock_guard<std::mutex> l(fm); fail_at[cur.seq] = cur.at; }
-                    if (!counting) out.lower_limit(cur.seq);
-                    int64_t curf = fail_seq.load();
-                    while (cur.seq < curf && !fail_seq.compare_exchange_weak(curf, cur.seq)) {}
-                    if (!counting) out.put(cur.seq, std::vector<char>(), 0, window);
-                    put_rest(cur);
+                if (refused) {
+                    refuse(cur);
                     t_rd += now_s() - a;
                     continue;
                 }
@@ -770,8 +804,11 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                 if (rk_fastq_slot_submit(eng.w[wi].slot[k], nbytes) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
                 t_rd += now_s() - a;
             }
-            if (got && !eng.two_slots) { finish_block(cur, eng.w[wi].slot[k]); continue; } // RKMH_RAW_SLOTS=1: one block per worker at a time
-            if (have_prev) { finish_block(prev, eng.w[wi].slot[k ^ 1]); have_prev = false; }
+            if (got && !two) { finish_block(cur, eng.w[wi].slot[k]); continue; } // one block per worker at a time
+            if (have_prev) {
+                if (!prev.begun || finish_load(prev, eng.w[wi].slot[k ^ 1])) finish_block(prev, eng.w[wi].slot[k ^ 1]);
+                have_prev = false;
+            }
             if (!got) break;
             prev = cur; have_prev = true; k ^= 1;
         }
