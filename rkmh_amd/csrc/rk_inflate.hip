@@ -29,8 +29,9 @@ namespace rk {
 namespace {
 
 constexpr int IW = 64;
-constexpr int LT = 9, DT = 7, CT = 7;         // root table bits: literal/length, distance, code-length code
-constexpr int LONG_CAP = 96, DLONG_CAP = 32;  // symbols with codes longer than the root (more: the member is the host's)
+constexpr int LT = 9, DT = 7, CT = 7;         // root table bits: literal/length, distance, code-length code (LT = 8 frees 32 KB -- a pass-2
+                                              // window then fits beside a pass-1 wave -- but 83 % instead of 62 % of the windows meet a long code: 28.7 vs 26.6 ms, no gain end to end)
+constexpr int LONG_CAP = 128, DLONG_CAP = 32;  // symbols with codes longer than the root (more: the member is the host's)
 constexpr int CL_AT = 320, LENS_N = 352;      // lens[0 .. 316): literal/length + distance code lengths; lens[320 .. 339): code-length code
 constexpr int IN_RING = 16, ENT_RING = 16, OUT_RING = 4; // dwords per lane
 constexpr int K_SYM = 8, K_HDR = 8;           // symbol steps / header steps (inside a header window) per period
@@ -51,9 +52,16 @@ struct LaneLds {
     uint32_t inr[IN_RING * IW];
     uint32_t entr[(ENT_RING + 1) * IW]; // (one more row each: where a step's store goes that is not due)
     uint32_t outr[(OUT_RING + 1) * IW];
-    uint8_t lens[LENS_N * IW];
+    uint8_t lens[LENS_N / 2 * IW]; // (code lengths are 0 .. 15: two per byte)
     uint8_t clorder[32];
 };
+
+__device__ __forceinline__ uint32_t len_at(const LaneLds& L, int i, int t) { return (L.lens[(i >> 1) * IW + t] >> (4 * (i & 1))) & 15u; }
+// (a stream's column is written by its own lane only -- or by the whole wave, a byte per lane, when the wave fills it)
+__device__ __forceinline__ void set_len(LaneLds& L, int i, int t, uint32_t v) {
+    uint8_t& b = L.lens[(i >> 1) * IW + t];
+    b = (uint8_t)((i & 1) ? (b & 0x0Fu) | (v << 4) : (b & 0xF0u) | v);
+}
 
 enum : uint32_t { ST_BLOCK = 0, ST_STORED_HDR, ST_DYN_HDR, ST_CL_READ, ST_LENS, ST_WAIT, ST_SYM, ST_STORED, ST_DONE, ST_FIN };
 
@@ -74,7 +82,7 @@ __device__ bool coop_build(LaneLds& L, int t, int at, int n, uint16_t* tab, uint
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int s = lane + IW * c;
-        l[c] = s < n ? L.lens[(at + s) * IW + t] : 0u;
+        l[c] = s < n ? len_at(L, at + s, t) : 0u;
         code_of[c] = 0;
     }
     for (int i = lane; i < (1 << TB); i += IW) tab[i * IW + t] = (uint16_t)E_INVALID;
@@ -302,12 +310,12 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
                     nlit = take(5) + 257u; ndist = take(5) + 1u; ncl = take(4) + 4u;
                     if (nlit > 286u || ndist > 30u) fail(5);
                     else {
-                        for (int i = 0; i < 19; ++i) L.lens[(CL_AT + i) * IW + lane] = 0;
+                        for (int i = 0; i < 10; ++i) L.lens[(CL_AT / 2 + i) * IW + lane] = 0;
                         hi = 0; state = ST_CL_READ;
                     }
                 }
             } else if (state == ST_CL_READ) {
-                for (int j = 0; j < 8 && hi < ncl && nb >= 3u; ++j) { L.lens[(CL_AT + L.clorder[hi]) * IW + lane] = (uint8_t)take(3); ++hi; }
+                for (int j = 0; j < 8 && hi < ncl && nb >= 3u; ++j) { set_len(L, CL_AT + L.clorder[hi], lane, take(3)); ++hi; }
                 if (hi == ncl) { need_build = 1; state = ST_WAIT; }
             } else if (state == ST_LENS) {
                 if (nb >= 14u) {
@@ -316,17 +324,17 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
                     if (l == 0u) fail(7);
                     else {
                         take(l);
-                        if (sym < 16u) { L.lens[hi * IW + lane] = (uint8_t)sym; prev = sym; ++hi; }
+                        if (sym < 16u) { set_len(L, (int)hi, lane, sym); prev = sym; ++hi; }
                         else {
                             uint32_t rep, val = 0;
                             if (sym == 16u) { rep = 3u + take(2); val = prev; if (hi == 0u) rep = 1000u; }
                             else if (sym == 17u) { rep = 3u + take(3); prev = 0; }
                             else { rep = 11u + take(7); prev = 0; }
                             if (hi + rep > nlit + ndist) fail(9);
-                            else { for (uint32_t j = 0; j < rep; ++j) L.lens[(hi + j) * IW + lane] = (uint8_t)val; hi += rep; }
+                            else { for (uint32_t j = 0; j < rep; ++j) set_len(L, (int)(hi + j), lane, val); hi += rep; }
                         }
                         if (state == ST_LENS && hi == nlit + ndist) {
-                            if (L.lens[256 * IW + lane] == 0) fail(10);
+                            if (len_at(L, 256, lane) == 0u) fail(10);
                             else { need_build = 2; state = ST_WAIT; }
                         }
                     }
@@ -347,8 +355,8 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
             } else {
                 const int nl = __builtin_amdgcn_readlane((int)nlit, t), nd = __builtin_amdgcn_readlane((int)ndist, t);
                 if (kind == 3u) {
-                    for (int i = lane; i < 288; i += IW) L.lens[i * IW + t] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
-                    if (lane < 30) L.lens[(288 + lane) * IW + t] = 5;
+                    for (int i = lane; i < 144; i += IW) L.lens[i * IW + t] = i < 72 ? 0x88 : (i < 128 ? 0x99 : (i < 140 ? 0x77 : 0x88)); // two symbols per byte
+                    if (lane < 15) L.lens[(144 + lane) * IW + t] = 0x55;
                 }
                 isync();
                 ok = coop_build<LT, 5>(L, t, 0, nl, L.lit, L.lsort, LONG_CAP, L.lwalk, lane);

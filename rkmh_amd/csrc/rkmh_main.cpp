@@ -54,7 +54,9 @@ static void die(const char* what) {
     fail_exit();
 }
 // Leaving after success: only if every byte really reached standard output (a full disk or a closed pipe must not exit 0)
+static const double g_loaded_s = now_s(); // (static initialisation: the program and its libraries are loaded)
 [[noreturn]] static void done_exit() {
+    if (g_timing) fprintf(stderr, "[rkmh timing] %-28s %.3f s\n", "since the program was loaded", now_s() - g_loaded_s);
     const bool bad = fflush(stdout) != 0 || ferror(stdout);
     fflush(stderr);
     if (bad) fprintf(stderr, "rkmh: write error on standard output\n");
