@@ -1579,23 +1579,27 @@ static void json_escape(std::string& out, const char* s) {
 }
 static void help_sketch() {
     fprintf(stderr,
-            "rkmh sketch -f <seqs.fa|fq> [-k <k>]... [-s <sketch>] [-o <out.json>]\n"
+            "rkmh sketch -f <seqs.fa|fq> [-k <k>]... [-s <sketch>] [-o <out.json>] [--kmer-cache <file>]\n"
             "  writes a JSON array with one MinHash sketch per sequence (schema of the reference's dump_hash_json);\n"
-            "  `rkmh stream -R <out.json>` loads it instead of sketching references again\n");
+            "  `rkmh stream -R <out.json>` loads it instead of sketching references again;\n"
+            "  --kmer-cache <file>: also enumerates the k-mers behind these sketches (k 8 .. 18) into <file>, which\n"
+            "  `rkmh stream -R <out.json> --kmer-cache <file>` then loads instead of enumerating them at every start\n");
 }
 static int main_sketch(int argc, char** argv) {
     std::vector<const char*> files;
     std::vector<int> ks;
     int S = 1000, device = 0;
     const char* outp = nullptr;
+    const char* kmer_cache = nullptr;
     if (argc <= 2) { help_sketch(); exit(1); }
     optind = 2;
     int c;
     static struct option long_options[] = {{"help", no_argument, 0, 'h'}, {"kmer", required_argument, 0, 'k'},
         {"fasta", required_argument, 0, 'f'}, {"reference", required_argument, 0, 'r'}, {"sketch-size", required_argument, 0, 's'},
-        {"output", required_argument, 0, 'o'}, {"device", required_argument, 0, 1000}, {0, 0, 0, 0}};
+        {"output", required_argument, 0, 'o'}, {"device", required_argument, 0, 1000}, {"kmer-cache", required_argument, 0, 1003}, {0, 0, 0, 0}};
     while ((c = getopt_long(argc, argv, "hk:f:r:s:o:t:", long_options, nullptr)) != -1) {
         switch (c) {
+            case 1003: kmer_cache = optarg; break;
             case 'f': case 'r': files.push_back(optarg); break;
             case 'k': ks.push_back(atoi(optarg)); break;
             case 's': S = atoi(optarg); break;
@@ -1614,6 +1618,13 @@ static int main_sketch(int argc, char** argv) {
     std::vector<uint64_t> sk((size_t)s.nseq * (size_t)S);
     std::vector<int32_t> lens((size_t)s.nseq);
     CK(rk_sketch_batch(ctx, s.bases, s.offsets, s.nseq, ks.data(), (int)ks.size(), S, sk.data(), lens.data()));
+    if (kmer_cache && *kmer_cache) {
+        // the index of these sketches is built once here, for its k-mer enumeration: the file's tag hashes the index keys, k and the
+        // hashing policy, so a later `stream -R <these sketches> --kmer-cache <file>` finds it -- and anything else does not use it
+        CK(rk_set_kmer_cache(ctx, kmer_cache));
+        CK(rk_set_reference_sketches(ctx, sk.data(), lens.data(), (int)s.nseq, ks.data(), (int)ks.size(), S));
+        if (rk_kmer_cache_state(ctx) == 0) fprintf(stderr, "rkmh: no k-mer enumeration for these sketches (k-mer sizes outside 8 .. 18, or a hash with two k-mers): %s not written\n", kmer_cache);
+    }
     FILE* fo = outp ? fopen(outp, "w") : stdout;
     if (!fo) { fprintf(stderr, "rkmh: cannot write %s\n", outp); exit(1); }
     std::string kstr;

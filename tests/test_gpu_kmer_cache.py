@@ -92,3 +92,28 @@ def test_cli_kmer_cache(root, data_dir, tmp_path):
     assert r.returncode == 0 and r.stdout == want.stdout
     r = subprocess.run([exe, "filter", "-r", ref, "-f", str(fq), "-k", "16", "--kmer-cache", str(cache)], capture_output=True)
     assert r.returncode == 0 and r.stdout == subprocess.run([exe, "filter", "-r", ref, "-f", str(fq), "-k", "16"], capture_output=True).stdout
+
+
+def test_sketch_writes_the_cache_that_stream_R_loads(root, data_dir, tmp_path):
+    """`rkmh sketch --kmer-cache F` enumerates the k-mers behind the sketches it writes; `rkmh stream -R sketches.json --kmer-cache F`
+    loads them (RKMH_INDEX_TIMING names the stage) and prints what a run without any cache prints; sketches of other references do
+    not use the file (they enumerate, and overwrite it)."""
+    from rkmh_amd import api, synth
+    exe = os.path.join(root, "bin", "rkmh")
+    ref = os.path.join(data_dir, "all_pave_ref.fa.gz")
+    refs = api.parse_files([ref])
+    qb, qo = synth.generate_reads_fast(refs["bases"], refs["offsets"], 0, 5000)
+    fq = tmp_path / "r.fq"
+    synth.write_fastq(str(fq), qb, qo, synth.read_names(0, 5000))
+    want = subprocess.run([exe, "stream", "-r", ref, "-f", str(fq), "-k", "16"], capture_output=True)
+    assert want.returncode == 0
+    js, cache = tmp_path / "refs.json", tmp_path / "refs.kmers"
+    r = subprocess.run([exe, "sketch", "-f", ref, "-k", "16", "-s", "1000", "-o", str(js), "--kmer-cache", str(cache)], capture_output=True)
+    assert r.returncode == 0 and cache.exists() and cache.stat().st_size > 100000, r.stderr[-500:]
+    env = dict(os.environ, RKMH_INDEX_TIMING="1")
+    r = subprocess.run([exe, "stream", "-R", str(js), "-f", str(fq), "-k", "16", "--kmer-cache", str(cache)], capture_output=True, env=env)
+    assert r.returncode == 0 and r.stdout == want.stdout
+    assert b"k-mer lists from the cache" in r.stderr and b"k-mer enumeration" not in r.stderr, r.stderr[-800:]
+    other = os.path.join(data_dir, "zika.refs.fa.gz")
+    r = subprocess.run([exe, "stream", "-r", other, "-f", str(fq), "-k", "16", "--kmer-cache", str(cache)], capture_output=True, env=env)
+    assert r.returncode == 0 and b"k-mer enumeration" in r.stderr and b"k-mer lists from the cache" not in r.stderr
