@@ -445,6 +445,10 @@ int rk_fastq_slot_load_bgzf(rk_fastq_slot* slot, const rk_bgzf* z, int64_t b0, i
 int rk_fastq_slot_load_bgzf_begin(rk_fastq_slot* slot, const rk_bgzf* z, int64_t b0, int64_t b1);
 int rk_fastq_slot_load_bgzf_end(rk_fastq_slot* slot, uint64_t* nbytes, uint64_t* text_off);
 
+/* Loads the code objects of the device front end's kernels (with_inflate != 0: and of the device inflater) on `device` ahead of
+ * their first launch -- tens of milliseconds a caller can spend on a second thread while its references are sketched.  Optional. */
+int rk_warm_up(int device, int with_inflate);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,7 @@ _SIGS = {
     "rk_fastq_slot_set_source": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rk_host_register_readonly": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rk_host_unregister": (None, [C.c_void_p]),
+    "rk_warm_up": (C.c_int, [C.c_int, C.c_int]),
     "rk_bgzf_plan": (C.c_int64, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), C.c_int64]),
     "rk_bgzf_fastq_records": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_fastq_slot_load_bgzf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

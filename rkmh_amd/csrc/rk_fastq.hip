@@ -188,4 +188,18 @@ hipError_t launch_fastq_index(const FqDev& d, const uint8_t* raw, uint64_t nbyte
     return hipGetLastError();
 }
 
+hipError_t warm_inflate(); // rk_inflate.hip
+static const void* k_fq_count_for_warm_up() { return reinterpret_cast<const void*>(k_fq_count); }
+
 } // namespace rk
+
+// Loads the code objects of the device front end's kernels (and, with_inflate != 0, of the device inflater) for the CURRENT device
+// ahead of their first launch: ~50 ms (150 ms with the inflater) that a caller can spend on a second thread while its
+// references are sketched, instead of in front of its first block.  Thread-safe; harmless to repeat.
+extern "C" int rk_warm_up(int device, int with_inflate) {
+    if (hipSetDevice(device) != hipSuccess) return -3;
+    hipFuncAttributes a;
+    hipError_t e = hipFuncGetAttributes(&a, rk::k_fq_count_for_warm_up());
+    if (e == hipSuccess && with_inflate) e = rk::warm_inflate();
+    return e == hipSuccess ? 0 : -3;
+}

@@ -556,6 +556,13 @@ hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, cons
     hipLaunchKernelGGL(k_inflate_place, dim3(nmem), dim3(IW), 0, st, mem, nmem, text, scratch, status);
     return hipGetLastError();
 }
+// (code objects are loaded at a TU's first launch -- tens of milliseconds; rk_warm_up asks for a kernel's attributes ahead of time instead)
+hipError_t warm_inflate() {
+    hipFuncAttributes a;
+    hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_inflate_lanes));
+    if (e == hipSuccess) e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_inflate_place));
+    return e;
+}
 hipError_t launch_fastq_first_start(const uint8_t* text, uint32_t n, uint32_t from, uint32_t window, bool at_eof, uint32_t* cuts, int which, hipStream_t st) {
     hipLaunchKernelGGL(k_fastq_first_start, dim3(1), dim3(256), 0, st, text, n, from, window, at_eof ? 1u : 0u, cuts, which);
     return hipGetLastError();

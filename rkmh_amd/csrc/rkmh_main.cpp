@@ -1161,6 +1161,13 @@ static int main_stream(int argc, char** argv) {
     if (o.read_depth) for (rk_ctx* cx : group.ctx) CK(rk_set_min_num_bound(cx, min_num_bound_for(o.min_matches)));
     rk_ctx* ctx = group.ctx[0];
     tick("context", t0);
+    // the front end's kernels (and the inflater's) are loaded while the references are sketched, not in front of the first block
+    std::thread warm;
+    if (any_raw && !(getenv("RKMH_WARM_UP") && atoi(getenv("RKMH_WARM_UP")) == 0))
+        warm = std::thread([&o] {
+            const std::vector<int> ids = o.devices.empty() ? std::vector<int>{o.device} : o.devices;
+            for (int id : ids) rk_warm_up(id, !g_bgzf.empty() && bgzf_device_mode() != 0);
+        });
     rk_seqset refs;
     memset(&refs, 0, sizeof refs);
     RawEngine eng;       // the workers and page-locked buffers of the device front ends (created by whoever needs them first)
@@ -1185,6 +1192,7 @@ static int main_stream(int argc, char** argv) {
     }
     group.share_references(o);
     tick("references", t0);
+    if (warm.joinable()) { warm.join(); tick("kernels loaded (waited)", t0); }
     std::string buf;
     std::vector<int32_t> out4;
     bool depth_done = false;
