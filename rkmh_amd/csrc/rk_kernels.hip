@@ -489,45 +489,90 @@ hipError_t launch_min_num_probe(const uint8_t* bases, const uint32_t* offs, uint
 // the group filter (kf4) and the exact map (km1) from the list, so that kernel's decision "this window cannot matter" is a
 // theorem about this index, not a probabilistic filter.  4^16 k-mers take ~25 ms on MI355X (two murmurs + one 4-byte read of
 // the hash-space filter each; the bucket table is only touched by the few that pass).
+// (Only the smaller member of a strand pair is hashed -- half of the k-mers a wave walks over -- so each wave queues the ones it
+// keeps in LDS and hashes them 64 at a time: all lanes busy in the part that costs, instead of every second one.)
+template <typename V>
+struct EnumQueue {
+    V* q;        // this wave's 128 entries
+    uint32_t n;  // queued (wave-uniform)
+    __device__ __forceinline__ void sync() const {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // every lane offers one k-mer (keep: whether it is taken); afterwards full(): 64 or more are queued
+    __device__ __forceinline__ void push(bool keep, V v, int lane) {
+        const uint64_t m = __ballot(keep);
+        if (keep) q[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
+        n += (uint32_t)__popcll(m);
+        sync();
+    }
+    // the first min(n, 64) entries, one per lane (has: this lane got one); the rest move to the front
+    __device__ __forceinline__ V pop(int lane, bool& has) {
+        const uint32_t take = n < 64u ? n : 64u, rest = n - take;
+        has = (uint32_t)lane < take;
+        const V v = q[lane];                 // (lanes past the end read stale entries they do not use)
+        const V w = q[64 + lane];
+        sync();
+        if ((uint32_t)lane < rest) q[lane] = w;
+        n = rest;
+        sync();
+        return v;
+    }
+};
+
 __global__ __launch_bounds__(256) void k_enum_kmers(RefIndex ix, DevPolicy pol, int k, uint64_t total, uint32_t* stats, uint2* list,
                                                     uint32_t list_cap) {
-    for (uint64_t v64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v64 < total; v64 += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t v = (uint32_t)v64;
-        const uint32_t rv = packed_revcomp(v, k);
-        if (rv < v) continue; // each strand pair once, through its smaller member (a palindrome is its own)
+    __shared__ uint32_t qmem[4][128];
+    const int lane = threadIdx.x & 63;
+    EnumQueue<uint32_t> Q{qmem[threadIdx.x >> 6], 0u};
+    auto hash_one = [&](uint32_t v) {
         const uint64_t h = canonical_packed(v, k, pol.seed, pol.fold);
         uint32_t slot = IDX_NOT_FOUND;
         if (h != 0) {
             if (ix.pre) { // hash-space filter first: one word instead of a bucket for the 99.99 % that are not keys
                 const uint32_t bm = index_pre_bits(h);
-                if ((ix.pre[index_pre_word(h, ix.pmask)] & bm) != bm) continue;
+                if ((ix.pre[index_pre_word(h, ix.pmask)] & bm) != bm) return;
             }
             slot = index_find(ix, h);
-            if (slot == IDX_NOT_FOUND) continue;
+            if (slot == IDX_NOT_FOUND) return;
         }
         const uint32_t pos = atomicAdd(stats, 1u);
         if (pos < list_cap) list[pos] = make_uint2(v, slot); // slot = IDX_NOT_FOUND: the k-mer hashes to 0
+    };
+    // (the loop bound is the same for all lanes of a wave: v64 - lane is)
+    for (uint64_t v64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v64 - (uint64_t)lane < total; v64 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = (uint32_t)v64;
+        Q.push(v64 < total && packed_revcomp(v, k) >= v, v, lane); // each strand pair once, through its smaller member (a palindrome is its own)
+        if (Q.n >= 64u) { bool has; const uint32_t x = Q.pop(lane, has); if (has) hash_one(x); }
     }
+    while (Q.n) { bool has; const uint32_t x = Q.pop(lane, has); if (has) hash_one(x); }
 }
 // the same for wide k-mers (16 < k <= KW_MAX_K): 4^k is 1.7 * 10^10 at k = 17 and 1.1 * 10^12 at k = 20 -- 0.1 s to several seconds, once per
 // reference set (rk_set_kmer_cache keeps the list); list entries (k-mer low, k-mer high, key id or IDX_NOT_FOUND, 0)
 __global__ __launch_bounds__(256) void k_enum_kmers64(RefIndex ix, DevPolicy pol, int k, uint64_t total, uint32_t* stats, uint4* list, uint32_t list_cap) {
-    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t rv = packed_revcomp64(v, k);
-        if (rv < v) continue;
+    __shared__ uint64_t qmem[4][128];
+    const int lane = threadIdx.x & 63;
+    EnumQueue<uint64_t> Q{qmem[threadIdx.x >> 6], 0u};
+    auto hash_one = [&](uint64_t v) {
         const uint64_t h = canonical_packed64(v, k, pol.seed, pol.fold);
         uint32_t slot = IDX_NOT_FOUND;
         if (h != 0) {
             if (ix.pre) {
                 const uint32_t bm = index_pre_bits(h);
-                if ((ix.pre[index_pre_word(h, ix.pmask)] & bm) != bm) continue;
+                if ((ix.pre[index_pre_word(h, ix.pmask)] & bm) != bm) return;
             }
             slot = index_find(ix, h);
-            if (slot == IDX_NOT_FOUND) continue;
+            if (slot == IDX_NOT_FOUND) return;
         }
         const uint32_t pos = atomicAdd(stats, 1u);
         if (pos < list_cap) list[pos] = make_uint4((uint32_t)v, (uint32_t)(v >> 32), slot, 0u);
+    };
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v - (uint64_t)lane < total; v += (uint64_t)gridDim.x * blockDim.x) {
+        Q.push(v < total && packed_revcomp64(v, k) >= v, v, lane);
+        if (Q.n >= 64u) { bool has; const uint64_t x = Q.pop(lane, has); if (has) hash_one(x); }
     }
+    while (Q.n) { bool has; const uint64_t x = Q.pop(lane, has); if (has) hash_one(x); }
 }
 hipError_t launch_enum_kmers(const RefIndex& ix, const DevPolicy& pol, int k, uint32_t* stats, uint2* list, uint32_t list_cap,
                              hipStream_t st) {
