@@ -4,7 +4,7 @@ ARCH := gfx950
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result $(EXTRA_HIPFLAGS)
 CSRC := rkmh_amd/csrc
 LIB := rkmh_amd/lib/librkmh_amd.so
-OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_kmer.o $(CSRC)/rk_count.o $(CSRC)/rk_call.o $(CSRC)/rk_sort.o $(CSRC)/rk_fastq.o $(CSRC)/rk_fasta.o $(CSRC)/rk_inflate.o $(CSRC)/rk_api.o $(CSRC)/rk_parse.o $(CSRC)/rk_format.o $(CSRC)/rk_synth.o
+OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_kmer.o $(CSRC)/rk_count.o $(CSRC)/rk_call.o $(CSRC)/rk_sort.o $(CSRC)/rk_fastq.o $(CSRC)/rk_fasta.o $(CSRC)/rk_inflate.o $(CSRC)/rk_api.o $(CSRC)/rk_parse.o $(CSRC)/rk_format.o $(CSRC)/rk_synth.o $(CSRC)/rk_policy.o
 
 all: $(LIB) bin/rkmh oracle
 
@@ -39,6 +39,8 @@ $(CSRC)/rk_parse.o: $(CSRC)/rk_parse.cpp include/rkmh_amd.h
 $(CSRC)/rk_format.o: $(CSRC)/rk_format.cpp include/rkmh_amd.h
 	g++ -O3 -std=c++17 -fPIC -Wall -c $< -o $@
 
+$(CSRC)/rk_policy.o: $(CSRC)/rk_policy.cpp include/rkmh_amd.h
+	g++ -O2 -std=c++17 -fPIC -Wall -c $< -o $@
 $(CSRC)/rk_synth.o: $(CSRC)/rk_synth.cpp include/rkmh_amd.h
 	g++ -O3 -std=c++17 -fPIC -Wall -pthread -c $< -o $@
 

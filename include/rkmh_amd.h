@@ -54,6 +54,16 @@ typedef struct rk_policy {
     uint32_t seed;               /* 42, src/rkmh.cpp:497 */
 } rk_policy;
 void rk_default_policy(rk_policy* p);
+/* The policy as text -- what `--hash-policy` / RKMH_POLICY of bin/rkmh and rkmh_amd.cli take and what a sketch file records
+ * ("hashPolicy", next to the hashType / hashSeed keys of src/rkmh.cpp:493-497).  spec = comma-separated items applied left to
+ * right onto *p (initialise it first, e.g. rk_default_policy): a preset -- `default`, or `mash`: the first 64 bits of
+ * MurmurHash3_x64_128 over all len-k+1 windows, seed 42, the sketches Mash / sourmash compute (README.md:12) -- or key=value:
+ * fold=swap32|h1|w2w1 (U1), windows=len-k|len-k+1 (U3), zero=count|skip (U12), mask=lt|le (U9), freqmax=incl|excl (U10), seed=<n>.
+ * rk_policy_describe writes the canonical text with every key spelled out (returns its length or a negative error).
+ * rk_policy_same_hashes: 1 when two policies give the same hash values and sketches (fold, window rule, seed). */
+int rk_policy_parse(const char* spec, rk_policy* p);
+int rk_policy_describe(const rk_policy* p, char* dst, size_t cap);
+int rk_policy_same_hashes(const rk_policy* a, const rk_policy* b);
 
 typedef struct rk_ctx rk_ctx;
 typedef struct rk_counter rk_counter;
@@ -67,6 +77,7 @@ int rk_device_props(int device, int32_t* compute_units, int32_t* clock_khz, int6
 
 /* One context = one GPU (one process per GPU in multi-GPU runs). policy may be NULL (defaults). */
 int rk_ctx_create(int device, const rk_policy* policy, rk_ctx** out);
+int rk_ctx_policy(const rk_ctx* ctx, rk_policy* out); /* the policy the context was created with */
 void rk_ctx_destroy(rk_ctx* ctx);
 int rk_ctx_synchronize(rk_ctx* ctx);
 /* The context's own non-blocking hipStream_t (what the host-buffer entry points enqueue on). */
@@ -432,6 +443,8 @@ int rk_bgzf_first_byte(const rk_bgzf* z);
 int64_t rk_bgzf_plan(const rk_bgzf* z, uint64_t target_bytes, int64_t* first, int64_t cap);
 int rk_bgzf_fastq_records(const rk_bgzf* z, int64_t b0, int64_t b1, uint8_t* dst, uint64_t cap, uint64_t* nbytes, uint64_t* text_off);
 const uint8_t* rk_bgzf_image(const rk_bgzf* z);   /* the mapped file */
+/* the member whose text ends with the byte in front of member b0's text (b0 - 1 unless that one is empty; b0 when no text precedes) */
+int64_t rk_bgzf_lead_member(const rk_bgzf* z, int64_t b0);
 int rk_bgzf_member(const rk_bgzf* z, int64_t member, uint64_t* file_off, uint32_t* total_bytes, uint32_t* header_bytes, uint32_t* text_bytes);
 /* The same job inflated ON THE DEVICE (rk_inflate.hip: a lane per member decodes, a wave per member resolves the matches in LDS): the compressed bytes cross the
  * link instead of the text, the records that start in members [b0, b1) land in the slot's device text buffer and a copy of them in

@@ -50,6 +50,10 @@ _u8p, _u64p, _i32p, _ip = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER
 
 _SIGS = {
     "rk_default_policy": (None, [C.POINTER(Policy)]),
+    "rk_policy_parse": (C.c_int, [C.c_char_p, C.POINTER(Policy)]),
+    "rk_policy_describe": (C.c_int, [C.POINTER(Policy), C.c_char_p, C.c_size_t]),
+    "rk_policy_same_hashes": (C.c_int, [C.POINTER(Policy), C.POINTER(Policy)]),
+    "rk_ctx_policy": (C.c_int, [C.c_void_p, C.POINTER(Policy)]),
     "rk_last_error": (C.c_char_p, []),
     "rk_version": (C.c_char_p, []),
     "rk_device_count": (C.c_int, []),
@@ -106,6 +110,7 @@ _SIGS = {
     "rk_bgzf_text_offset": (C.c_uint64, [C.c_void_p, C.c_int64]),
     "rk_bgzf_first_byte": (C.c_int, [C.c_void_p]),
     "rk_bgzf_image": (C.c_void_p, [C.c_void_p]),
+    "rk_bgzf_lead_member": (C.c_int64, [C.c_void_p, C.c_int64]),
     "rk_bgzf_member": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rk_fastq_slot_set_source": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rk_host_register_readonly": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -731,13 +736,37 @@ class Counter:
             pass
 
 
+def parse_policy(spec=None, base=None):
+    """rk_policy_parse: `spec` (presets default / mash, or fold= / windows= / zero= / mask= / freqmax= / seed=) applied onto `base`
+    (default: the build's defaults).  Raises RkmhError on text it does not know."""
+    lib = load_library()
+    p = Policy()
+    if base is None:
+        lib.rk_default_policy(C.byref(p))
+    else:
+        C.memmove(C.byref(p), C.byref(base), C.sizeof(Policy))
+    if spec:
+        _chk(lib.rk_policy_parse(spec.encode() if isinstance(spec, str) else spec, C.byref(p)))
+    return p
+
+
+def describe_policy(p):
+    """rk_policy_describe: the canonical text of a policy, every key spelled out."""
+    buf = C.create_string_buffer(160)
+    n = load_library().rk_policy_describe(C.byref(p), buf, len(buf))
+    if n < 0:
+        _chk(n)
+    return buf.value.decode()
+
+
 class Context:
     """One GPU. Methods are named after the reference's functions they replace."""
 
-    def __init__(self, device=0, **policy):
+    def __init__(self, device=0, policy_spec=None, **policy):
+        """policy_spec: the text form (`--hash-policy` of the command lines: presets default / mash, key=value; rk_policy_parse),
+        applied to the defaults first; keyword arguments then set single fields of the struct."""
         self._lib = load_library()
-        p = Policy()
-        self._lib.rk_default_policy(C.byref(p))
+        p = parse_policy(policy_spec)
         for k, v in policy.items():
             setattr(p, k, v)
         self.policy = p

@@ -18,7 +18,9 @@ import numpy as np
 
 from . import api, dist as rdist
 
-HELP = """rkmh stream|classify -r <refs.fa> -f <reads.fq> [-k <k>]... [-s <sketch>] [-M n] [-I n] [-N n] [-D n]
+HELP = """rkmh stream|classify -r <refs.fa> -f <reads.fq> [-k <k>]... [-s <sketch>] [-M n] [-I n] [-N n] [-D n] [--hash-policy <spec>]
+  --hash-policy <spec>   presets (default, mash) and/or fold=swap32|h1|w2w1, windows=len-k|len-k+1, zero=count|skip, mask=lt|le,
+                         freqmax=incl|excl, seed=<n> (rk_policy_parse); RKMH_POLICY: the same, read first
 """
 
 
@@ -396,7 +398,7 @@ def main_stream(argv, filter_mode=False):
         return 1
     longopts = ["help", "kmer=", "fasta=", "reference=", "sketch-size=", "ref-sketch=", "threads=", "min-kmer-occurence=",
                 "min-matches=", "min-diff=", "max-samples=", "pre-reads=", "pre-references=", "read-kmer-map-file=",
-                "ref-kmer-map-file=", "in-stream", "output-reads", "merge-sketch"]
+                "ref-kmer-map-file=", "in-stream", "output-reads", "merge-sketch", "hash-policy="]
     try:
         opts, _ = getopt.getopt(argv[2:], "zmhdk:f:r:s:S:t:M:N:I:R:F:p:q:iD:", longopts)
     except getopt.GetoptError:
@@ -405,6 +407,15 @@ def main_stream(argv, filter_mode=False):
     refs, reads, ks = [], [], []
     sketch, min_occ, min_matches, min_diff, max_samples = 1000, None, -1, 0, None
     in_stream = False
+    # the hashing policy: defaults, then RKMH_POLICY, then --hash-policy (as bin/rkmh; one parser for both: rk_policy_parse)
+    try:
+        policy = api.parse_policy(os.environ.get("RKMH_POLICY"))
+        for o, a in opts:
+            if o == "--hash-policy":
+                policy = api.parse_policy(a, base=policy)
+    except api.RkmhError as e:
+        sys.stderr.write("rkmh: --hash-policy / RKMH_POLICY: %s\n" % e)
+        return 1
     for o, a in opts:
         if o in ("-r", "--reference"): refs.append(a)
         elif o in ("-f", "--fasta"): reads.append(a)
@@ -434,7 +445,7 @@ def main_stream(argv, filter_mode=False):
     os.dup2(2, 1)
     out = os.fdopen(result_fd, "wb")
     rank, local, world = rdist.init()
-    ctx = api.Context(local)
+    ctx = api.Context(local, policy_spec=api.describe_policy(policy))
     if os.environ.get("RKMH_KMER_CACHE"):
         ctx.set_kmer_cache(os.environ["RKMH_KMER_CACHE"])    # the k-mer enumeration of these references, kept between runs
     compact_ok = False

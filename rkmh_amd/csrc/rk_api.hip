@@ -202,6 +202,12 @@ extern "C" int rk_ctx_create(int device, const rk_policy* policy, rk_ctx** out) 
     *out = c;
     return RK_OK;
 }
+extern "C" int rk_ctx_policy(const rk_ctx* c, rk_policy* out) {
+    if (!c || !out) return fail(RK_ERR_ARG, "bad arguments");
+    out->fold = c->pol.fold; out->drop_last_window = c->pol.drop_last_window; out->counter_counts_zero = c->pol.counter_counts_zero;
+    out->mask_strict_less = c->pol.mask_strict_less; out->freq_max_inclusive = c->pol.freq_max_inclusive; out->seed = c->pol.seed;
+    return RK_OK;
+}
 extern "C" void rk_ctx_destroy(rk_ctx* c) {
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;

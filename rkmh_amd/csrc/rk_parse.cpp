@@ -195,9 +195,28 @@ struct rk_reader {
     gzFile fp = nullptr;
     AsyncGz* az = nullptr;       // compressed input only
     bool compressed = false;
+    // a read that FAILED (gzread < 0: a corrupt or truncated gzip stream, an I/O error) -- not an end of input.  Set by whichever
+    // thread reads (the inflater thread of compressed input included), reported by rk_reader_next / rk_parse_files: the reference's
+    // kseq takes the failed gzread for the end of the file and exits 0 with what it had (src/kseq.hpp:75-85); this build says so
+    std::atomic<bool> io_failed{false};
+    std::mutex io_mu;
+    std::string io_msg;
+    // after a gzread that returned r for `want` bytes: r < 0 is a failure, and so is a short read that zlib explains with an error
+    // (Z_BUF_ERROR: the compressed stream ends before its end-of-stream mark; Z_DATA_ERROR: damaged)
+    void check_read(int r, size_t want) {
+        if (r >= 0 && (size_t)r >= want) return;
+        int errnum = 0;
+        const char* m = gzerror(fp, &errnum);
+        if (r >= 0 && (errnum == Z_OK || errnum == Z_STREAM_END)) return;
+        std::lock_guard<std::mutex> l(io_mu);
+        if (io_failed.load()) return;
+        io_msg = m && *m ? m : "read error";
+        io_failed.store(true);
+    }
+    std::string read_error() { std::lock_guard<std::mutex> l(io_mu); return io_msg; }
     // `want` bytes of the (inflated) input, fewer only at its end
     size_t pull(unsigned char* dst, size_t want) {
-        if (!compressed) { const int r = gzread(fp, dst, (unsigned)want); return r > 0 ? (size_t)r : 0; }
+        if (!compressed) { const int r = gzread(fp, dst, (unsigned)want); check_read(r, want); return r > 0 ? (size_t)r : 0; }
         if (!az) {
             az = new AsyncGz();
             az->th = std::thread([this] {
@@ -206,6 +225,7 @@ struct rk_reader {
                     AsyncGz::Piece piece;
                     piece.p.reset(new unsigned char[want_n]);
                     const int r = gzread(fp, piece.p.get(), (unsigned)want_n);
+                    check_read(r, want_n); // (before `done` is published under the lock: the consumer sees it)
                     piece.n = r > 0 ? (size_t)r : 0;
                     const bool last = piece.n < want_n;
                     if (want_n < ((size_t)8 << 20)) want_n *= 4;
@@ -924,6 +944,7 @@ int rk_reader_next(rk_reader* r, int64_t max_records, uint64_t max_bases, rk_seq
         if (rc == -3) return perr(RK_ERR_NOMEM, "out of memory");
         if (rc <= 0) { r->finished = true; break; } // EOF, or truncated record: ends the file (rkmh.cpp:251)
     }
+    if (r->io_failed.load()) return perr(RK_ERR_IO, ("read failed (corrupt or truncated input?): " + r->read_error()).c_str());
     return hand_over(b, out);
 }
 
@@ -941,6 +962,11 @@ int rk_parse_files(const char* const* paths, int npaths, rk_seqset* out) {
             if (k == -3) { rk_reader_close(r); return perr(RK_ERR_NOMEM, "out of memory"); }
             if (k == -1) continue;
             if (k <= 0) break;
+        }
+        if (r->io_failed.load()) {
+            const std::string msg = std::string(paths[i]) + ": read failed (corrupt or truncated input?): " + r->io_msg;
+            rk_reader_close(r);
+            return perr(RK_ERR_IO, msg.c_str());
         }
         rk_reader_close(r);
     }
@@ -1105,6 +1131,17 @@ int64_t rk_bgzf_plan(const rk_bgzf* z, uint64_t target_bytes, int64_t* first, in
     first[nj] = (int64_t)nb;
     return nj;
 }
+// The member that holds the byte in front of member b0's text: b0 - 1, unless that one is empty (the end-of-file marker `cat a.gz
+// b.gz` leaves in the middle of a file) -- then the nearest one before it with text; b0 itself when no text precedes it.  Both
+// record cutters (here and rk_inflate.hip's) begin their text there, so the cut at b0 sees the real previous byte and agrees with
+// the cut the previous job made at its end.
+int64_t rk_bgzf_lead_member(const rk_bgzf* z, int64_t b0) {
+    if (!z || b0 <= 0) return 0;
+    if ((size_t)b0 > z->hlen.size()) b0 = (int64_t)z->hlen.size();
+    int64_t m = b0 - 1;
+    while (m > 0 && z->uoff[(size_t)m + 1] == z->uoff[(size_t)m]) --m;
+    return z->uoff[(size_t)m + 1] == z->uoff[(size_t)m] ? b0 : m;
+}
 // The whole FASTQ records that START in the text of members [b0, b1): the members are inflated (with the one in front, for its
 // last byte, and as many behind as the last record reaches into), the first record start at or after the text of b0 and of b1
 // is found by the four-line rule of find_record_start -- the same function at both ends, so neighbouring jobs agree -- and the
@@ -1114,7 +1151,7 @@ int rk_bgzf_fastq_records(const rk_bgzf* z, int64_t b0, int64_t b1, uint8_t* dst
     if (!z || !dst || !nbytes || b0 < 0 || b1 < b0 || (size_t)b1 > z->hlen.size()) return perr(RK_ERR_ARG, "bad arguments");
     *nbytes = 0;
     const size_t nb = z->hlen.size();
-    const size_t lo = b0 > 0 ? (size_t)b0 - 1 : 0;
+    const size_t lo = (size_t)rk_bgzf_lead_member(z, b0);
     static thread_local std::vector<unsigned char> buf;
     size_t have_b = lo; // members [lo, have_b) are in buf
     auto extend_to = [&](size_t upto) -> bool {
@@ -1132,7 +1169,7 @@ int rk_bgzf_fastq_records(const rk_bgzf* z, int64_t b0, int64_t b1, uint8_t* dst
         const unsigned char* base = buf.data();
         const unsigned char* e = base + (z->uoff[have_b] - u_lo);
         const unsigned char* from = base + (z->uoff[member] - u_lo);
-        if (member == 0) return 0;
+        if (z->uoff[member] == 0) return 0; // (no text in front of it: the file's first record)
         if (from >= e) { *need_more = have_b < nb; return (size_t)(e - base); }
         const unsigned char* q = find_record_start(base, from, e, true);
         if (q) return (size_t)(q - base);

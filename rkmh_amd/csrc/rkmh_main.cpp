@@ -65,6 +65,24 @@ static const double g_loaded_s = now_s(); // (static initialisation: the program
 }
 #define CK(call) do { if ((call) != RK_OK) die(#call); } while (0)
 
+// The hashing policy of this run: the build's defaults, then RKMH_POLICY, then --hash-policy (rk_policy_parse: presets `default`
+// and `mash`, or fold= / windows= / zero= / mask= / freqmax= / seed=).  The arithmetic behind these switches is mkmh's, which the
+// reference's tree does not hold (src/rkmh.cpp:17); every context of the process is created with g_policy.
+static rk_policy g_policy;
+static void policy_apply(const char* spec, const char* from) {
+    if (rk_policy_parse(spec, &g_policy) != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", from, rk_last_error()); exit(1); }
+}
+static std::string policy_text(const rk_policy& p) {
+    char b[160];
+    if (rk_policy_describe(&p, b, sizeof b) < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); exit(1); }
+    return b;
+}
+#define HASH_POLICY_OPTION {"hash-policy", required_argument, 0, 1004}
+#define HASH_POLICY_HELP \
+    "  --hash-policy <spec>    the mkmh choices the reference's tree does not fix, as presets (default, mash) and/or key=value:\n" \
+    "                          fold=swap32|h1|w2w1, windows=len-k|len-k+1, zero=count|skip, mask=lt|le, freqmax=incl|excl, seed=<n>;\n" \
+    "                          `mash` = fold=h1,windows=len-k+1 (the sketches Mash / sourmash compute).  RKMH_POLICY: the same, read first\n"
+
 static void print_help() {
     fprintf(stderr,
             "rkmh (MI355X build): MinHash read classification on AMD Instinct GPUs\n"
@@ -92,8 +110,10 @@ static void help_stream() {
             "  -p/-q/-F <file>, -S <n>, -i, -z, -m   parsed and ignored, as in the reference\n"
             "  -R <sketches.json>      reference sketches written by `rkmh sketch` instead of -r\n"
             "  --depth-map-cache <file>  (with -M) save the read-depth map of this run, or reuse the file if it was saved\n"
-            "  --kmer-cache <file>       keep the k-mer enumeration of these references (k <= 16) in <file>; reused while references, k and hashing match\n"
             "                          from the same reads, k-mer sizes and hashing policy (anything else is refused)\n"
+            "  --kmer-cache <file>       keep the k-mer enumeration of these references (k 8 .. 18; up to 20 once the file exists) in\n"
+            "                          <file>; reused while references, k and hashing policy match\n"
+            HASH_POLICY_HELP
             "  --device <id>           GPU to use (default 0)\n"
             "  --devices <a,b,..|all>  spread the reads over several GPUs of this node (stream, filter): one host thread and one\n"
             "                          context per device, reference sketches built on the first and imported by the others, -M depth\n"
@@ -101,8 +121,8 @@ static void help_stream() {
 }
 static void help_hash() {
     fprintf(stderr,
-            "rkmh hash -f <seqs.fa|fq> [-k <k>]...\n"
-            "  prints one line per sequence: name, then every k-mer hash, tab separated\n");
+            "rkmh hash -f <seqs.fa|fq> [-k <k>]... [--hash-policy <spec>]\n"
+            "  prints one line per sequence: name, then every k-mer hash, tab separated\n" HASH_POLICY_HELP);
 }
 
 struct Opts {
@@ -248,7 +268,7 @@ static void emit_lines(const rk_seqset& refs, const rk_seqset& reads, const int3
     }
 }
 
-struct LoadedSketches { std::vector<std::string> names; std::vector<uint64_t> sk; std::vector<int32_t> lens; std::vector<int> ks; int S = 0; };
+struct LoadedSketches { std::vector<std::string> names; std::vector<uint64_t> sk; std::vector<int32_t> lens; std::vector<int> ks; int S = 0; std::string policy; };
 static bool load_sketch_json(const char* path, LoadedSketches& L);
 
 // The devices of one run (--devices): context 0 builds the reference sketches (rk_set_references on its GPU), the others import
@@ -270,7 +290,7 @@ struct DeviceGroup {
         std::vector<std::thread> th;
         std::vector<std::string> err(ids.size());
         for (size_t i = 0; i < ids.size(); ++i)
-            th.emplace_back([&, i] { if (rk_ctx_create(ids[i], nullptr, &ctx[i]) != RK_OK) err[i] = rk_last_error(); });
+            th.emplace_back([&, i] { if (rk_ctx_create(ids[i], &g_policy, &ctx[i]) != RK_OK) err[i] = rk_last_error(); });
         for (auto& t : th) t.join();
         for (auto& e : err) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
         if (o.kmer_cache && *o.kmer_cache) for (rk_ctx* cx : ctx) CK(rk_set_kmer_cache(cx, o.kmer_cache));
@@ -1099,11 +1119,12 @@ static int main_stream(int argc, char** argv) {
         {"ref-kmer-map-file", required_argument, 0, 'q'}, {"in-stream", no_argument, 0, 'i'},
         {"output-reads", no_argument, 0, 'z'},   {"merge-sketch", no_argument, 0, 'm'},
         {"device", required_argument, 0, 1000},  {"depth-map-cache", required_argument, 0, 1001}, {"kmer-cache", required_argument, 0, 1003},
-        {"devices", required_argument, 0, 1002}, {0, 0, 0, 0}};
+        {"devices", required_argument, 0, 1002}, HASH_POLICY_OPTION, {0, 0, 0, 0}};
     optind = 2;
     int c;
     while ((c = getopt_long(argc, argv, "zmhdk:f:r:s:S:t:M:N:I:R:F:p:q:iD:", long_options, nullptr)) != -1) {
         switch (c) {
+            case 1004: policy_apply(optarg, "--hash-policy"); break;
             case 'm': case 'i': case 'z': break;                 // parsed and ignored, rkmh.cpp:656-658,709-714
             case 'R': pre_refs = optarg; break;               // pre-hashed references: parsed but unimplemented in the reference (:662-664)
             // -p/-q (k-mer map files): the reference parses them and does nothing (bodies commented out, :665-670, :744-769);
@@ -1128,6 +1149,15 @@ static int main_stream(int argc, char** argv) {
     LoadedSketches pre;
     if (pre_refs) {
         if (!load_sketch_json(pre_refs, pre)) { fprintf(stderr, "rkmh: cannot load sketches from %s\n", pre_refs); exit(1); }
+        // sketches hashed under another policy would meet read hashes they can never equal: refused, not classified against
+        rk_policy theirs;
+        rk_default_policy(&theirs);
+        if (rk_policy_parse(pre.policy.c_str(), &theirs) != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", pre_refs, rk_last_error()); exit(1); }
+        if (!rk_policy_same_hashes(&theirs, &g_policy)) {
+            fprintf(stderr, "rkmh: %s holds sketches hashed with %s, this run hashes with %s: pass --hash-policy %s\n", pre_refs,
+                    policy_text(theirs).c_str(), policy_text(g_policy).c_str(), policy_text(theirs).c_str());
+            exit(1);
+        }
         o.ks = pre.ks; o.sketch = pre.S;
     }
     if (o.ks.empty()) {
@@ -1287,7 +1317,7 @@ static void help_filter() {
     fprintf(stderr,
             "rkmh filter -r <refs.fa> -f <reads.fq> [-k <k>]... [-s <sketch>] [-M n] [-I n] [-N n] [-D n] [-i]\n"
             "  prints the reads (as >name / SEQ / + / QUAL) whose best reference passes the match and diff filters;\n"
-            "  -i then classifies reads arriving on STDIN and prints one 'Sample: ... Result: ...' line each\n");
+            "  -i then classifies reads arriving on STDIN and prints one 'Sample: ... Result: ...' line each\n" HASH_POLICY_HELP);
 }
 
 static int main_filter(int argc, char** argv) {
@@ -1303,11 +1333,12 @@ static int main_filter(int argc, char** argv) {
         {"max-samples", required_argument, 0, 'I'}, {"pre-reads", required_argument, 0, 'F'},
         {"pre-references", required_argument, 0, 'R'}, {"read-kmer-map-file", required_argument, 0, 'p'},
         {"ref-kmer-map-file", required_argument, 0, 'q'}, {"in-stream", no_argument, 0, 'i'},
-        {"device", required_argument, 0, 1000}, {"devices", required_argument, 0, 1002}, {"kmer-cache", required_argument, 0, 1003}, {0, 0, 0, 0}};
+        {"device", required_argument, 0, 1000}, {"devices", required_argument, 0, 1002}, {"kmer-cache", required_argument, 0, 1003}, HASH_POLICY_OPTION, {0, 0, 0, 0}};
     optind = 2;
     int c;
     while ((c = getopt_long(argc, argv, "hdk:f:r:s:S:t:M:N:I:R:F:p:q:iD:", long_options, nullptr)) != -1) {
         switch (c) {
+            case 1004: policy_apply(optarg, "--hash-policy"); break;
             case 1003: o.kmer_cache = optarg; break;
             case 'F': case 'R': case 'p': case 'q': case 'S': break; // parsed, bodies empty (rkmh.cpp:1139-1151)
             case 't': o.threads = atoi(optarg); break;
@@ -1492,7 +1523,7 @@ static int main_filter(int argc, char** argv) {
 static void help_call() {
     fprintf(stderr,
             "rkmh call -r <ref.fa> -f <reads.fq> [-k <k>] [-w <window>]\n"
-            "  calls SNPs and 1-bp deletions from the k-mer depth of the reads along the reference (VCF-like rows)\n");
+            "  calls SNPs and 1-bp deletions from the k-mer depth of the reads along the reference (VCF-like rows)\n" HASH_POLICY_HELP);
 }
 #include <map>
 static int main_call(int argc, char** argv) {
@@ -1506,11 +1537,12 @@ static int main_call(int argc, char** argv) {
         {"fasta", required_argument, 0, 'f'}, {"reference", required_argument, 0, 'r'},
         {"sketch", required_argument, 0, 's'}, {"threads", required_argument, 0, 't'},
         {"window-len", required_argument, 0, 'w'}, {"show-depth", no_argument, 0, 'd'},
-        {"device", required_argument, 0, 1000}, {0, 0, 0, 0}};
+        {"device", required_argument, 0, 1000}, HASH_POLICY_OPTION, {0, 0, 0, 0}};
     optind = 2;
     int c;
     while ((c = getopt_long(argc, argv, "hdk:f:r:s:t:w:", long_options, nullptr)) != -1) {
         switch (c) {
+            case 1004: policy_apply(optarg, "--hash-policy"); break;
             case 'r': refs.push_back(optarg); break;
             case 'f': reads.push_back(optarg); break;
             case 'k': ks.push_back(atoi(optarg)); break;
@@ -1546,7 +1578,7 @@ static int main_call(int argc, char** argv) {
     if (R.nseq > 1) fprintf(stderr, "WARNING: more than one ref provided. VCF will not be correct\n");
     if (show_depth) return 0;
     rk_ctx* ctx = nullptr;
-    CK(rk_ctx_create(device, nullptr, &ctx));
+    CK(rk_ctx_create(device, &g_policy, &ctx));
     rk_call_record* rec = nullptr;
     int64_t nrec = 0;
     CK(rk_call(ctx, R.bases, R.offsets, (int)R.nseq, Q.bases, Q.offsets, Q.nseq, ks[0], window_len, &rec, &nrec));
@@ -1591,7 +1623,8 @@ static void help_sketch() {
             "  writes a JSON array with one MinHash sketch per sequence (schema of the reference's dump_hash_json);\n"
             "  `rkmh stream -R <out.json>` loads it instead of sketching references again;\n"
             "  --kmer-cache <file>: also enumerates the k-mers behind these sketches (k 8 .. 18) into <file>, which\n"
-            "  `rkmh stream -R <out.json> --kmer-cache <file>` then loads instead of enumerating them at every start\n");
+            "  `rkmh stream -R <out.json> --kmer-cache <file>` then loads instead of enumerating them at every start\n"
+            "  the file records the hashing policy (\"hashPolicy\"); stream -R refuses sketches hashed under another one\n" HASH_POLICY_HELP);
 }
 static int main_sketch(int argc, char** argv) {
     std::vector<const char*> files;
@@ -1604,9 +1637,10 @@ static int main_sketch(int argc, char** argv) {
     int c;
     static struct option long_options[] = {{"help", no_argument, 0, 'h'}, {"kmer", required_argument, 0, 'k'},
         {"fasta", required_argument, 0, 'f'}, {"reference", required_argument, 0, 'r'}, {"sketch-size", required_argument, 0, 's'},
-        {"output", required_argument, 0, 'o'}, {"device", required_argument, 0, 1000}, {"kmer-cache", required_argument, 0, 1003}, {0, 0, 0, 0}};
+        {"output", required_argument, 0, 'o'}, {"device", required_argument, 0, 1000}, {"kmer-cache", required_argument, 0, 1003}, HASH_POLICY_OPTION, {0, 0, 0, 0}};
     while ((c = getopt_long(argc, argv, "hk:f:r:s:o:t:", long_options, nullptr)) != -1) {
         switch (c) {
+            case 1004: policy_apply(optarg, "--hash-policy"); break;
             case 1003: kmer_cache = optarg; break;
             case 'f': case 'r': files.push_back(optarg); break;
             case 'k': ks.push_back(atoi(optarg)); break;
@@ -1620,7 +1654,7 @@ static int main_sketch(int argc, char** argv) {
     if (ks.empty()) { fprintf(stderr, "No kmer size(s) provided. Will use a default kmer size of 16.\n"); ks.push_back(16); }
     if (files.empty()) { fprintf(stderr, "rkmh: -f <file> is required\n"); exit(1); }
     rk_ctx* ctx = nullptr;
-    CK(rk_ctx_create(device, nullptr, &ctx));
+    CK(rk_ctx_create(device, &g_policy, &ctx));
     rk_seqset s;
     CK(rk_parse_files(files.data(), (int)files.size(), &s));
     std::vector<uint64_t> sk((size_t)s.nseq * (size_t)S);
@@ -1639,11 +1673,14 @@ static int main_sketch(int argc, char** argv) {
     for (size_t i = 0; i < ks.size(); ++i) { kstr += std::to_string(ks[i]); if (i + 1 < ks.size()) kstr += ' '; }
     std::string o = "[";
     char num[32];
+    // "hashPolicy": this build's addition to dump_hash_json's keys (src/rkmh.cpp:489-525) -- what hashType / hashSeed leave open
+    const std::string pol_text = policy_text(g_policy);
     for (int64_t i = 0; i < s.nseq; ++i) {
         std::string name;
         json_escape(name, s.names + s.name_offsets[i]);
         if (i) o += ',';
-        o += "{\"alphabet\":\"ATGC\",\"canonical\":\"true\",\"hashBits\":64,\"hashSeed\":42,\"hashType\":\"MurmurHash3_x64_128\",\"kmer\":\"" + kstr +
+        o += "{\"alphabet\":\"ATGC\",\"canonical\":\"true\",\"hashBits\":64,\"hashPolicy\":\"" + pol_text + "\",\"hashSeed\":" + std::to_string(g_policy.seed) +
+             ",\"hashType\":\"MurmurHash3_x64_128\",\"kmer\":\"" + kstr +
              "\",\"name\":\"" + name + "\",\"preserveCase\":\"false\",\"seqLen\":" + std::to_string(s.offsets[i + 1] - s.offsets[i]) +
              ",\"sketches\":{\"comment\":\"\",\"hashes\":[";
         for (int j = 0; j < lens[(size_t)i]; ++j) {
@@ -1700,6 +1737,11 @@ static bool load_sketch_json(const char* path, LoadedSketches& L) {
         std::vector<int> ks;
         { std::string kk = json_string_at(t, v); char* e = &kk[0]; while (*e) { while (*e == ' ') ++e; if (!*e) break; ks.push_back((int)strtol(e, &e, 10)); } }
         if (L.ks.empty()) L.ks = ks; else if (ks != L.ks) return false;
+        { // the policy the sketches were hashed under (absent: a file of an earlier build, which knew the defaults only)
+            std::string pol = "default";
+            if (json_find(t, pos, end, "hashPolicy", v)) pol = json_string_at(t, v);
+            if (L.names.empty()) L.policy = pol; else if (pol != L.policy) return false;
+        }
         if (!json_find(t, pos, end, "name", v)) return false;
         L.names.push_back(json_string_at(t, v));
         size_t sp;
@@ -1744,12 +1786,13 @@ static int main_hash(int argc, char** argv) {
         {"fasta", required_argument, 0, 'f'}, {"sketch-size", required_argument, 0, 's'},
         {"threads", required_argument, 0, 't'}, {"min-kmer-occurence", required_argument, 0, 'M'},
         {"max-samples", required_argument, 0, 'I'}, {"output", required_argument, 0, 'o'},
-        {"device", required_argument, 0, 1000}, {0, 0, 0, 0}};
+        {"device", required_argument, 0, 1000}, HASH_POLICY_OPTION, {0, 0, 0, 0}};
     optind = 2;
     int c;
     bool use_freqs = false;
     while ((c = getopt_long(argc, argv, "ThcwKk:f:s:t:mM:I:o:", long_options, nullptr)) != -1) {
         switch (c) {
+            case 1004: policy_apply(optarg, "--hash-policy"); break;
             case 'f': files.push_back(optarg); break;
             case 'k': ks.push_back(atoi(optarg)); break;
             case 'K': print_kmers = true; break;
@@ -1766,7 +1809,7 @@ static int main_hash(int argc, char** argv) {
     if (files.empty()) { fprintf(stderr, "rkmh: -f <file> is required\n"); exit(1); }
     if (use_freqs) return 0;
     rk_ctx* ctx = nullptr;
-    if (!print_kmers) CK(rk_ctx_create(device, nullptr, &ctx));
+    if (!print_kmers) CK(rk_ctx_create(device, &g_policy, &ctx));
     rk_reader* rd = nullptr;
     CK(rk_reader_open(files[0], &rd)); // only input_files[0] is used, rkmh.cpp:2064,2085
     std::string buf;
@@ -1781,7 +1824,7 @@ static int main_hash(int argc, char** argv) {
                 const uint8_t* seq = s.bases + s.offsets[i];
                 int64_t len = (int64_t)(s.offsets[i + 1] - s.offsets[i]);
                 for (int k : ks)
-                    for (int64_t w = 0; w + k < len; ++w) { // len-k windows (policy U3)
+                    for (int64_t w = 0; w + k < len + (g_policy.drop_last_window ? 0 : 1); ++w) { // len-k windows, or len-k+1 (policy U3)
                         buf += '\t';
                         for (int j = 0; j < k; ++j) {
                             signed char ch = (signed char)seq[w + j];
@@ -1827,7 +1870,7 @@ static void help_hpv16() {
             "  HPV16 lineages / sublineages of <dir>/new_refs.fa; <dir> defaults to ./data (as the reference: run it from the\n"
             "  rkmh directory).  Also writes lineage_specific_hashes.<k>.tst into the working directory.\n"
             "  -s/-N/-D are accepted and unused, as in the reference.  --device <id>: GPU to use.\n"
-            "  Reads of any length are accepted; those with more than 16384 k-mers (all -k together) are answered one at a time.\n");
+            "  Reads of any length are accepted; those with more than 16384 k-mers (all -k together) are answered one at a time.\n" HASH_POLICY_HELP);
 }
 static int main_hpv16(int argc, char** argv) {
     std::vector<const char*> read_files;
@@ -1842,11 +1885,12 @@ static int main_hpv16(int argc, char** argv) {
         {"sketch", required_argument, 0, 's'},   {"threads", required_argument, 0, 't'},
         {"min-kmer-occurence", required_argument, 0, 'M'}, {"min-matches", required_argument, 0, 'N'},
         {"min-diff", required_argument, 0, 'D'}, {"max-samples", required_argument, 0, 'I'},
-        {"device", required_argument, 0, 1000},  {0, 0, 0, 0}};
+        {"device", required_argument, 0, 1000},  HASH_POLICY_OPTION, {0, 0, 0, 0}};
     optind = 2;
     int c;
     while ((c = getopt_long(argc, argv, "hk:f:R:s:t:M:N:D:", long_options, nullptr)) != -1) {
         switch (c) {
+            case 1004: policy_apply(optarg, "--hash-policy"); break;
             case 't': case 's': case 'N': case 'D': break;          // parsed; nothing downstream reads them (:2411, :2428, :2435-2440)
             case 'f': read_files.push_back(optarg); break;
             case 'R': refpath = optarg; break;
@@ -1872,9 +1916,8 @@ static int main_hpv16(int argc, char** argv) {
     const std::string type_file = existing(refpath + "/all_pave_ref.fa"), sub_file = existing(refpath + "/new_refs.fa");   // :2453-2456
     double t0 = now_s();
     rk_ctx* ctx = nullptr;
-    CK(rk_ctx_create(device, nullptr, &ctx));
-    rk_policy pol;
-    rk_default_policy(&pol);
+    CK(rk_ctx_create(device, &g_policy, &ctx));
+    const rk_policy pol = g_policy;
     rk_seqset types, subs, reads;
     const char* p1[1] = {type_file.c_str()};
     const char* p2[1] = {sub_file.c_str()};
@@ -2078,6 +2121,8 @@ int main(int argc, char** argv) {
     // and kernels of two streams on one queue run one after the other -- the long inflate kernels of BGZF jobs above all
     // (profiles/r05_gz.txt: 2.4 of 8 launches overlapped, 4.2 with 16 queues).  Read by the runtime when it starts: set before any HIP call.
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    rk_default_policy(&g_policy);
+    if (const char* e = getenv("RKMH_POLICY")) policy_apply(e, "RKMH_POLICY");
     std::string cmd = argv[1];
     if (cmd == "stream") return main_stream(argc, argv);
     if (cmd == "classify") {

@@ -65,3 +65,35 @@ run("c2mini_pave_k12_k16", "all_pave_ref.fa.gz", ([n.decode() for n in synth.rea
     {"reads": "rkmh_amd.synth.generate_reads(refs, 0, 1000)"})
 run("c2mini_pave_M2", "all_pave_ref.fa.gz", ([n.decode() for n in synth.read_names(0, 1000)], b, o), [16], 1000,
     {"reads": "rkmh_amd.synth.generate_reads(refs, 0, 1000)"}, min_kmer_occ=2, counter_slots=1000003)
+
+
+# ---- the command lines under two hashing-policy presets (--hash-policy default | mash; rk_policy_parse): the stdout of
+# `rkmh classify` (C1), of `rkmh stream -N 2 -D 1` (the tie-heavy Zika panel) and the head + digest of `rkmh hash`, from the oracle
+# with the same policy.  tests/test_gpu_parity.py::test_cli_stream_and_hash_output runs the binaries against these.
+import hashlib  # noqa: E402
+
+PRESETS = {"default": {}, "mash": {"fold": oracle.FOLD_H1, "drop_last_window": 0}}
+
+
+def cli_golden(preset, fields):
+    pol = oracle.default_policy(**fields)
+    doc = {"note": "oracle output under --hash-policy %s (parity unpinned: self-consistent)" % preset, "preset": preset,
+           "policy_fields": {k: int(v) for k, v in fields.items()}}
+    for tag, ref_file, reads_file, ks, S, mm, md in (("classify_c1", "hpv_16.fa.gz", "minION25.fq.gz", [12], 1000, -1, 0),
+                                                       ("stream_zika_N2_D1", "zika.refs.fa.gz", "z1.fq.gz", [16], 1000, 2, 1)):
+        rn, rb, ro = load(ref_file)
+        qn, qb, qo = load(reads_file)
+        sk, ln = oracle.sketch_refs(rb, ro, ks, S, policy=pol, threads=8)
+        out = oracle.classify_stream(qb, qo, ks, S, sk, ln, policy=pol, threads=8)
+        doc[tag] = "".join(oracle.stream_line(rn[out[i, 0]], qn[i], out[i, 1], out[i, 2], out[i, 3], S, min_matches=mm, min_diff=md)
+                           for i in range(len(qn)))
+    rec = oracle.kseq_parse_file(os.path.join(DATA, "hpv_16.fa.gz"))[0]
+    h = oracle.calc_hashes(oracle.to_upper(rec[1]), [12], pol)
+    line = rec[0].decode() + "".join("\t%d" % v for v in h) + "\n"
+    doc["hash_hpv16_k12"] = {"n_hashes": int(len(h)), "first": [int(v) for v in h[:6]], "sha256": hashlib.sha256(line.encode()).hexdigest()}
+    json.dump(doc, open(os.path.join(HERE, "cli_%s.json" % preset), "w"))
+    print("cli", preset, len(h), "hashes;", doc["classify_c1"].count("\n"), "+", doc["stream_zika_N2_D1"].count("\n"), "lines")
+
+
+for preset, fields in PRESETS.items():
+    cli_golden(preset, fields)

@@ -204,3 +204,22 @@ def test_cut_before_finds_record_starts(tmp_path):
             last = c
     finally:
         os.close(fd)
+
+
+def test_hash_policy_text_round_trips():
+    """rk_policy_parse / rk_policy_describe (host code: no GPU needed): presets, single keys, order of application, refusals."""
+    from rkmh_amd import api
+    d = api.describe_policy
+    assert d(api.parse_policy(None)) == "fold=swap32,windows=len-k,zero=count,mask=lt,freqmax=incl,seed=42"
+    assert d(api.parse_policy("mash")) == "fold=h1,windows=len-k+1,zero=count,mask=lt,freqmax=incl,seed=42"
+    assert d(api.parse_policy("mash,default")) == d(api.parse_policy("default"))
+    assert d(api.parse_policy(" fold=w2w1 , seed=0x10,zero=skip,mask=le,freqmax=excl")) == "fold=w2w1,windows=len-k,zero=skip,mask=le,freqmax=excl,seed=16"
+    p = api.parse_policy("windows=len-k+1", base=api.parse_policy("fold=h1"))
+    assert d(p) == d(api.parse_policy("mash")) and d(api.parse_policy(d(p))) == d(p)
+    lib = api.load_library()
+    import ctypes as C
+    assert lib.rk_policy_same_hashes(C.byref(p), C.byref(api.parse_policy("mash,mask=le"))) == 1
+    assert lib.rk_policy_same_hashes(C.byref(p), C.byref(api.parse_policy("default"))) == 0
+    for bad in ("mesh", "fold", "fold=", "fold=H1", "windows=len", "seed=", "seed=4294967296", "k=3"):
+        with pytest.raises(api.RkmhError):
+            api.parse_policy(bad)

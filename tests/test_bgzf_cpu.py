@@ -100,3 +100,60 @@ def test_what_is_not_bgzf_is_refused_and_corruption_is_an_error(tmp_path):
     zf = api.Bgzf.open(str(fa))
     assert zf.first_byte() == ord(">") and zf.fastq_records(0, zf.members, dst, len(text) + 64)[0] == 1
     zf.close()
+
+
+def test_empty_member_inside_the_file_does_not_hide_the_previous_byte(tmp_path):
+    """`cat a.fq.gz b.fq.gz`: the end-of-file marker of a.fq.gz is an EMPTY member in the middle of the file.  A job that begins
+    right behind it must still see the last byte of the text in front (rk_bgzf_lead_member) -- here that text ends INSIDE a line
+    whose continuation begins with '@', which a cutter that takes the empty member for a line start would call a record."""
+    from rkmh_amd import api, synth
+    rng = np.random.default_rng(8)
+    text = _fastq(rng, 400, lo=60, hi=90, tricky=False)
+    # cut inside a quality line, so that the second file begins with "@..." in mid-line, two lines above a '+' line
+    recs = text.split(b"\n")
+    lines = [recs[i] for i in range(len(recs))]
+    k = 4 * 200 + 3                                            # a quality line
+    q = bytearray(lines[k]); q[10] = ord("@"); lines[k] = bytes(q)
+    text = b"\n".join(lines)
+    at = sum(len(x) + 1 for x in lines[:k]) + 10               # the '@' inside the quality line
+    a, b = text[:at], text[at:]
+    img = synth.bgzf_compress(a, level=1, block=5000) + synth.bgzf_compress(b, level=1, block=5000)
+    path = tmp_path / "cat.fq.gz"
+    path.write_bytes(img)
+    z = api.Bgzf.open(str(path))
+    assert z is not None and z.text_bytes == len(text)
+    cap = len(text) + 64
+    dst = C.create_string_buffer(cap)
+    na = (len(a) + 4999) // 5000                               # members of a's text; member na is the empty marker
+    assert api.load_library().rk_bgzf_lead_member(z._h, na + 1) == na - 1
+    for first in ([0, na + 1, z.members], [0, na, z.members], [0, na - 1, na + 1, na + 2, z.members]):
+        got = b""
+        for b0, b1 in zip(first, first[1:]):
+            st, n, off = z.fastq_records(b0, b1, dst, cap)
+            assert st == 0 and (n == 0 or off == len(got)), (first, b0, b1, off, len(got))
+            got += dst.raw[:n]
+        assert got == text, first
+    z.close()
+
+
+def test_corrupt_gzip_is_an_error_not_an_end_of_file(tmp_path):
+    """A single-member .gz whose deflate stream is damaged (or cut off): gzread fails on the inflater thread; rk_parse_files and
+    rk_reader_next report RK_ERR_IO instead of ending as if at a clean end of input."""
+    from rkmh_amd import api
+    rng = np.random.default_rng(9)
+    text = _fastq(rng, 20000, tricky=False)
+    img = bytearray(gzip.compress(text, 6))
+    good = tmp_path / "good.fq.gz"
+    good.write_bytes(bytes(img))
+    assert api.parse_files([str(good)])["nseq"] == 20000
+    img[len(img) // 2] ^= 0x5a
+    img[len(img) // 2 + 1] ^= 0xff
+    bad = tmp_path / "bad.fq.gz"
+    bad.write_bytes(bytes(img))
+    with pytest.raises(api.RkmhError) as e:
+        api.parse_files([str(bad)])
+    assert "read failed" in str(e.value)
+    cut = tmp_path / "cut.fq.gz"
+    cut.write_bytes(bytes(gzip.compress(text, 6))[: len(img) // 3])
+    with pytest.raises(api.RkmhError):
+        api.parse_files([str(cut)])

@@ -172,9 +172,13 @@ def test_ref_sketches_bit_exact(ctx, orc, pave):
 
 
 def _classify_both(ctx, orc, rb, ro, qb, qo, ks, S, **kw):
+    """The device's rows against the oracle's -- the oracle sketches the references ITSELF (a wrong device sketch cannot hide
+    behind rows computed from it), and the device's sketches must equal the oracle's."""
     ctx.set_references(rb, ro, ks, S)
     sk, ln = ctx.get_reference_sketches()
-    want = orc.classify_stream(qb, qo, ks, S, sk, ln, threads=8, **kw)
+    wsk, wln = orc.sketch_refs(rb, ro, ks, S, threads=8)
+    assert (ln == wln).all() and (sk == wsk).all(), "reference sketches differ from the oracle's"
+    want = orc.classify_stream(qb, qo, ks, S, wsk, wln, threads=8, **kw)
     got = ctx.classify(qb, qo)
     return got, want
 
@@ -564,6 +568,64 @@ def test_full_size_properties(ctx, orc, pave):
         assert (out[lo: lo + 2000] == want).all()
     # most reads come back to a reference that shares >= 5 sketch hashes (1 % error reads of 150 bp)
     assert (out[:, 1] >= 5).mean() > 0.9
+
+
+@pytest.mark.parametrize("preset", ["default", "mash"])
+@pytest.mark.parametrize("how", ["flag", "env"])
+def test_cli_hash_policy_presets(root, data_dir, golden_dir, preset, how):
+    """--hash-policy / RKMH_POLICY (rk_policy_parse) through bin/rkmh and rkmh_amd.cli: stdout equals the committed goldens of
+    tests/golden/gen_golden.py for both presets -- `mash` = the first 64 bits of the murmur output over all len-k+1 windows."""
+    import hashlib
+    exe = os.path.join(root, "bin", "rkmh")
+    g = json.load(open(os.path.join(golden_dir, "cli_%s.json" % preset)))
+    env = dict(os.environ)
+    env.pop("RKMH_POLICY", None)
+    flag = ["--hash-policy", preset] if how == "flag" else []
+    if how == "env":
+        env["RKMH_POLICY"] = "fold=w2w1" if preset == "default" else "mash"   # (the flag is applied after the variable)
+        flag = ["--hash-policy", "default"] if preset == "default" else []
+    r = subprocess.run([exe, "classify", "-r", os.path.join(data_dir, "hpv_16.fa.gz"), "-f", os.path.join(data_dir, "minION25.fq.gz"),
+                        "-k", "12", "-s", "1000"] + flag, capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.decode() == g["classify_c1"]
+    for cmd in ([exe, "stream"], [sys.executable, "-m", "rkmh_amd.cli", "stream"]):
+        r = subprocess.run(cmd + ["-r", os.path.join(data_dir, "zika.refs.fa.gz"), "-f", os.path.join(data_dir, "z1.fq.gz"), "-N", "2",
+                                  "-D", "1", "-k", "16"] + flag, capture_output=True, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.decode() == g["stream_zika_N2_D1"], cmd
+    r = subprocess.run([exe, "hash", "-f", os.path.join(data_dir, "hpv_16.fa.gz"), "-k", "12"] + flag, capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr
+    h = g["hash_hpv16_k12"]
+    fields = r.stdout.decode().rstrip("\n").split("\t")
+    assert len(fields) - 1 == h["n_hashes"] and [int(x) for x in fields[1:7]] == h["first"]
+    assert hashlib.sha256(r.stdout).hexdigest() == h["sha256"]
+
+
+def test_cli_hash_policy_is_checked(root, data_dir, tmp_path):
+    """Text rk_policy_parse does not know ends the run; sketches record their policy and stream -R refuses another one."""
+    exe = os.path.join(root, "bin", "rkmh")
+    env = dict(os.environ)
+    env.pop("RKMH_POLICY", None)
+    for bad in ("fold=xx", "nonsense", "seed=-"):
+        r = subprocess.run([exe, "stream", "-r", os.path.join(data_dir, "hpv_16.fa.gz"), "-f", os.path.join(data_dir, "minION25.fq.gz"),
+                            "--hash-policy", bad], capture_output=True, env=env)
+        assert r.returncode == 1 and r.stdout == b"" and b"hash policy" in r.stderr
+    r = subprocess.run([sys.executable, "-m", "rkmh_amd.cli", "stream", "-r", os.path.join(data_dir, "hpv_16.fa.gz"), "-f",
+                        os.path.join(data_dir, "minION25.fq.gz"), "--hash-policy", "fold=xx"], capture_output=True, env=env, cwd=root)
+    assert r.returncode == 1 and r.stdout == b"" and b"hash policy" in r.stderr
+    js = tmp_path / "mash.json"
+    r = subprocess.run([exe, "sketch", "-f", os.path.join(data_dir, "zika.refs.fa.gz"), "-k", "16", "-o", str(js), "--hash-policy", "mash"],
+                       capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr
+    doc = json.load(open(js))
+    assert doc[0]["hashPolicy"] == "fold=h1,windows=len-k+1,zero=count,mask=lt,freqmax=incl,seed=42" and doc[0]["hashSeed"] == 42
+    r = subprocess.run([exe, "stream", "-R", str(js), "-f", os.path.join(data_dir, "z1.fq.gz")], capture_output=True, env=env)
+    assert r.returncode == 1 and r.stdout == b"" and b"--hash-policy fold=h1,windows=len-k+1" in r.stderr
+    g = json.load(open(os.path.join(root, "tests", "golden", "cli_mash.json")))
+    r = subprocess.run([exe, "stream", "-R", str(js), "-f", os.path.join(data_dir, "z1.fq.gz"), "-N", "2", "-D", "1", "--hash-policy", "mash"],
+                       capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.decode() == g["stream_zika_N2_D1"]
 
 
 def test_cli_stream_and_hash_output(ctx, orc, root, data_dir, golden_dir, tmp_path):
@@ -1029,7 +1091,8 @@ def test_json_sketches_roundtrip(orc, root, data_dir, golden_dir, tmp_path):
     sk, ln = orc.sketch_refs(rb, ro, [16], 1000, threads=4)
     assert len(doc) == len(refs)
     for i, d in enumerate(doc):
-        assert list(d.keys()) == ["alphabet", "canonical", "hashBits", "hashSeed", "hashType", "kmer", "name", "preserveCase", "seqLen", "sketches"]
+        assert list(d.keys()) == ["alphabet", "canonical", "hashBits", "hashPolicy", "hashSeed", "hashType", "kmer", "name", "preserveCase", "seqLen", "sketches"]
+        assert d["hashPolicy"] == "fold=swap32,windows=len-k,zero=count,mask=lt,freqmax=incl,seed=42"
         assert d["name"] == refs[i][0].decode() and d["kmer"] == "16" and d["hashSeed"] == 42 and d["hashBits"] == 64
         assert d["hashType"] == "MurmurHash3_x64_128" and d["alphabet"] == "ATGC" and d["seqLen"] == len(refs[i][1])
         assert d["sketches"]["length"] == 1000 and d["sketches"]["hashes"] == [int(x) for x in sk[i, :ln[i]]]

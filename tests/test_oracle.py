@@ -245,3 +245,26 @@ def test_pin_tooling_reports_exactly_the_policy_of_the_probed_library(tmp_path):
         rc, flips, out = run(policy)
         assert rc == 1 and flips == policy, (policy, out)
         assert "AMBIGUOUS" not in out and "NO candidate" not in out
+
+
+@pytest.mark.parametrize("preset", ["default", "mash"])
+def test_cli_preset_goldens_match_oracle(orc, golden_dir, data_dir, preset):
+    """tests/golden/cli_<preset>.json (what the binaries must print under --hash-policy <preset>) against the oracle run with the
+    policy fields the file names; the two presets really differ (another fold and one more window per sequence)."""
+    import hashlib
+    g = json.load(open(os.path.join(golden_dir, "cli_%s.json" % preset)))
+    pol = orc.default_policy(**g["policy_fields"])
+    recs = orc.kseq_parse_file(os.path.join(data_dir, "hpv_16.fa.gz"))
+    reads = orc.kseq_parse_file(os.path.join(data_dir, "minION25.fq.gz"))
+    rb, ro = orc.pack([r[1] for r in recs])
+    qb, qo = orc.pack([r[1] for r in reads])
+    sk, ln = orc.sketch_refs(rb, ro, [12], 1000, policy=pol)
+    out = orc.classify_stream(qb, qo, [12], 1000, sk, ln, policy=pol)
+    want = "".join(orc.stream_line(recs[out[i, 0]][0].decode(), reads[i][0].decode(), out[i, 1], out[i, 2], out[i, 3], 1000) for i in range(len(reads)))
+    assert want == g["classify_c1"]
+    h = orc.calc_hashes(orc.to_upper(recs[0][1]), [12], pol)
+    line = recs[0][0].decode() + "".join("\t%d" % v for v in h) + "\n"
+    assert hashlib.sha256(line.encode()).hexdigest() == g["hash_hpv16_k12"]["sha256"] and len(h) == g["hash_hpv16_k12"]["n_hashes"]
+    other = json.load(open(os.path.join(golden_dir, "cli_%s.json" % ("mash" if preset == "default" else "default"))))
+    assert other["hash_hpv16_k12"]["sha256"] != g["hash_hpv16_k12"]["sha256"]
+    assert abs(other["hash_hpv16_k12"]["n_hashes"] - g["hash_hpv16_k12"]["n_hashes"]) == 1

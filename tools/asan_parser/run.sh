@@ -3,7 +3,7 @@
 # through the block-parallel and the sequential scanner, whose outputs must agree.  Usage: bash tools/asan_parser/run.sh
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../.." && pwd); W=${TMPDIR:-/tmp}/rk_asan_parser; mkdir -p $W
-g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I$ROOT/include $HERE/main.cpp $ROOT/rkmh_amd/csrc/rk_parse.cpp -o $W/parse_asan -lz -lpthread
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I$ROOT/include $HERE/main.cpp $ROOT/rkmh_amd/csrc/rk_parse.cpp -o $W/parse_asan -lz -lpthread -ldl
 python3 $HERE/gen.py ${1:-1} $W/corpus ${2:-300}
 for cfg in "4 4" "8 16" "1 64"; do set -- $cfg
   RKMH_PARSE_THREADS=$1 RKMH_PARSE_BLOCK_KB=$2 $W/parse_asan $W/corpus/*.txt > $W/out_$1.txt 2> $W/err_$1.txt
