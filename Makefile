@@ -4,7 +4,9 @@ ARCH := gfx950
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result $(EXTRA_HIPFLAGS)
 CSRC := rkmh_amd/csrc
 LIB := rkmh_amd/lib/librkmh_amd.so
-OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_kmer.o $(CSRC)/rk_count.o $(CSRC)/rk_call.o $(CSRC)/rk_sort.o $(CSRC)/rk_fastq.o $(CSRC)/rk_fasta.o $(CSRC)/rk_inflate.o $(CSRC)/rk_api.o $(CSRC)/rk_parse.o $(CSRC)/rk_format.o $(CSRC)/rk_synth.o $(CSRC)/rk_policy.o
+OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_kmer.o $(CSRC)/rk_count.o $(CSRC)/rk_call.o $(CSRC)/rk_sort.o $(CSRC)/rk_fastq.o $(CSRC)/rk_fasta.o $(CSRC)/rk_inflate.o $(CSRC)/rk_api.o $(CSRC)/rk_index.o $(CSRC)/rk_counters.o $(CSRC)/rk_frontend.o $(CSRC)/rk_parse.o $(CSRC)/rk_format.o $(CSRC)/rk_synth.o $(CSRC)/rk_policy.o
+
+API_DEPS := $(CSRC)/rk_api_internal.hpp $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp include/rkmh_amd.h
 
 all: $(LIB) bin/rkmh oracle
 
@@ -26,17 +28,23 @@ $(CSRC)/rk_sort.o: $(CSRC)/rk_sort.hip $(CSRC)/rk_kernels.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/rk_fasta.o: $(CSRC)/rk_fasta.hip $(CSRC)/rk_kernels.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(CSRC)/rk_fastq.o: $(CSRC)/rk_fastq.hip $(CSRC)/rk_kernels.hpp
+$(CSRC)/rk_fastq.o: $(CSRC)/rk_fastq.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_filter_rule.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(CSRC)/rk_inflate.o: $(CSRC)/rk_inflate.hip $(CSRC)/rk_kernels.hpp
+$(CSRC)/rk_inflate.o: $(CSRC)/rk_inflate.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_crc32.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(CSRC)/rk_call.o: $(CSRC)/rk_call.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp
+$(CSRC)/rk_call.o: $(CSRC)/rk_call.hip $(API_DEPS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(CSRC)/rk_api.o: $(CSRC)/rk_api.hip $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp include/rkmh_amd.h
+$(CSRC)/rk_api.o: $(CSRC)/rk_api.hip $(API_DEPS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/rk_index.o: $(CSRC)/rk_index.hip $(API_DEPS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/rk_counters.o: $(CSRC)/rk_counters.hip $(API_DEPS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/rk_frontend.o: $(CSRC)/rk_frontend.hip $(API_DEPS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/rk_parse.o: $(CSRC)/rk_parse.cpp include/rkmh_amd.h
 	g++ -O3 -std=c++17 -fPIC -Wall -c $< -o $@
-$(CSRC)/rk_format.o: $(CSRC)/rk_format.cpp include/rkmh_amd.h
+$(CSRC)/rk_format.o: $(CSRC)/rk_format.cpp $(CSRC)/rk_filter_rule.hpp include/rkmh_amd.h
 	g++ -O3 -std=c++17 -fPIC -Wall -c $< -o $@
 
 $(CSRC)/rk_policy.o: $(CSRC)/rk_policy.cpp include/rkmh_amd.h

@@ -369,7 +369,17 @@ typedef struct rk_fastq_result {
 #define RK_FASTQ_CHAR 8        /* a sequence byte kseq would not keep, or a quality byte outside 33..127 */
 #define RK_FASTQ_CAP 16        /* more records than a block of this size is sized for (records of under 64 bytes on average) */
 int rk_fastq_slot_create(rk_ctx* ctx, uint64_t max_bytes, rk_fastq_slot** out);
-uint8_t* rk_fastq_slot_text(rk_fastq_slot* slot);  /* page-locked buffer of max_bytes: the caller fills it with the block's text */
+/* flags: RK_SLOT_DEVICE_TEXT = the block's text never visits the host.  Such a slot has no text buffer of its own (blocks come from
+ * rk_fastq_slot_load_bgzf, or from caller memory named with rk_fastq_slot_set_source), may be hundreds of megabytes large at little
+ * page-locked memory, and its finish() brings back -- besides the rows -- only the bytes the output needs, packed on the device:
+ * the record NAMES (what stream / classify print, src/rkmh.cpp:887-892) or, after rk_fastq_slot_set_filter_output, name, sequence
+ * and quality string of the records filter prints (src/rkmh.cpp:1292-1300).  The result's name_off / seq_off / qual_off then index
+ * rk_fastq_slot_spans_base() -- which is what the formatters below are to be given as `text` for ANY slot. */
+#define RK_SLOT_DEVICE_TEXT 1
+int rk_fastq_slot_create2(rk_ctx* ctx, uint64_t max_bytes, int flags, rk_fastq_slot** out);
+int rk_fastq_slot_set_filter_output(rk_fastq_slot* slot, int min_matches, int min_diff);
+const uint8_t* rk_fastq_slot_spans_base(const rk_fastq_slot* slot);   /* of the last finished block; valid until the slot's next call */
+uint8_t* rk_fastq_slot_text(rk_fastq_slot* slot);  /* page-locked buffer of max_bytes: the caller fills it with the block's text (NULL for a device-text slot) */
 /* ... or names the text where it lies: the slot's NEXT block (submit / classify / count) is uploaded from `text` -- caller memory,
  * ideally page-locked (a mapping of the input file registered with hipHostRegister: the link reads the page cache, no copy), valid
  * and unchanged until that block's finish / count has returned.  The formatters are given the same pointer. */
@@ -446,17 +456,16 @@ const uint8_t* rk_bgzf_image(const rk_bgzf* z);   /* the mapped file */
 /* the member whose text ends with the byte in front of member b0's text (b0 - 1 unless that one is empty; b0 when no text precedes) */
 int64_t rk_bgzf_lead_member(const rk_bgzf* z, int64_t b0);
 int rk_bgzf_member(const rk_bgzf* z, int64_t member, uint64_t* file_off, uint32_t* total_bytes, uint32_t* header_bytes, uint32_t* text_bytes);
-/* The same job inflated ON THE DEVICE (rk_inflate.hip: a lane per member decodes, a wave per member resolves the matches in LDS): the compressed bytes cross the
- * link instead of the text, the records that start in members [b0, b1) land in the slot's device text buffer and a copy of them in
- * rk_fastq_slot_text() (for the output formatters); the NEXT rk_fastq_slot_submit / _classify / _count of the slot is given
- * *nbytes and skips its upload.  Returns RK_OK, or 1: take the host route (rk_bgzf_fastq_records) for this job.  CRC-32 is not
- * checked on this route (ISIZE and the four-line grammar are). */
+/* The same job inflated ON THE DEVICE (rk_inflate.hip: a lane per member decodes, a wave per member resolves the matches in LDS,
+ * another checks the member's CRC-32 -- as gzread does for everything the reference reads, src/rkmh.cpp:238-263): the compressed
+ * bytes cross the link instead of the text (by DMA straight from the mapped file when the caller page-locked it:
+ * rk_host_register_readonly(rk_bgzf_image(z), rk_bgzf_file_bytes(z))), the records that start in members [b0, b1) land in the slot's
+ * device text buffer -- and, for a slot without RK_SLOT_DEVICE_TEXT, a copy of them in rk_fastq_slot_text().  The NEXT
+ * rk_fastq_slot_submit / _classify / _count of the slot is given *nbytes and skips its upload.  A job may hold tens of thousands
+ * of members (one launch decodes them all: the decode kernel takes the same ~15 ms for 64 members as for 32 768).
+ * Returns RK_OK, or 1: take the host route (rk_bgzf_fastq_records) for this job -- it reports damaged members. */
 int rk_fastq_slot_load_bgzf(rk_fastq_slot* slot, const rk_bgzf* z, int64_t b0, int64_t b1, uint64_t* nbytes, uint64_t* text_off);
-/* Its two halves, for callers that keep two slots per thread: _begin enqueues the upload and the inflate kernels and returns at
- * once (RK_OK, or 1: host route); _end waits for them and moves the records into place (RK_OK, or 1: host route after all).  The
- * ~30 ms a job spends in the decode kernel pass while the caller finishes its previous job in the other slot. */
-int rk_fastq_slot_load_bgzf_begin(rk_fastq_slot* slot, const rk_bgzf* z, int64_t b0, int64_t b1);
-int rk_fastq_slot_load_bgzf_end(rk_fastq_slot* slot, uint64_t* nbytes, uint64_t* text_off);
+uint64_t rk_bgzf_file_bytes(const rk_bgzf* z);   /* length of rk_bgzf_image */
 
 /* Loads the code objects of the device front end's kernels (with_inflate != 0: and of the device inflater) on `device` ahead of
  * their first launch -- tens of milliseconds a caller can spend on a second thread while its references are sketched.  Optional. */

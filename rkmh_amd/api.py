@@ -119,8 +119,10 @@ _SIGS = {
     "rk_bgzf_plan": (C.c_int64, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), C.c_int64]),
     "rk_bgzf_fastq_records": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_fastq_slot_load_bgzf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "rk_fastq_slot_load_bgzf_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
-    "rk_fastq_slot_load_bgzf_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rk_bgzf_file_bytes": (C.c_uint64, [C.c_void_p]),
+    "rk_fastq_slot_create2": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
+    "rk_fastq_slot_set_filter_output": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rk_fastq_slot_spans_base": (C.c_void_p, [C.c_void_p]),
     "rk_counter_create_compact": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rk_counter_compact_entries": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rk_counter_entries": (C.c_uint64, [C.c_void_p]),
@@ -480,11 +482,17 @@ class LineParts:
 class FastqSlot:
     """One block of raw FASTQ text in flight (rk_fastq_slot_*): the text is split into records, checked, packed and classified on the device."""
 
-    def __init__(self, ctx, max_bytes=1 << 26):
+    def __init__(self, ctx, max_bytes=1 << 26, device_text=False):
+        """device_text: RK_SLOT_DEVICE_TEXT -- the block's text stays on the device (blocks come from load_bgzf), only rows and the
+        packed names (or, after set_filter_output, the records filter prints) come back."""
         self._lib = load_library()
         self._h = C.c_void_p()
         self.max_bytes = max_bytes
-        _chk(self._lib.rk_fastq_slot_create(ctx._h, max_bytes, C.byref(self._h)))
+        self.device_text = bool(device_text)
+        _chk(self._lib.rk_fastq_slot_create2(ctx._h, max_bytes, 1 if device_text else 0, C.byref(self._h)))
+
+    def set_filter_output(self, min_matches, min_diff):
+        _chk(self._lib.rk_fastq_slot_set_filter_output(self._h, min_matches, min_diff))
 
     def classify(self, text: bytes):
         """Returns (status, rows [n,4] int32, names [n] bytes, seqs [n] bytes); status != 0: the block must be parsed on the host."""
@@ -537,7 +545,7 @@ class FastqSlot:
         """The stream / classify lines of a classified block (rk_fastq_stream_lines), as bytes."""
         cap = int(self._lib.rk_fastq_stream_lines_bound(parts._h, C.byref(res)))
         buf = self._out_buffer(cap)
-        n = self._lib.rk_fastq_stream_lines(parts._h, C.byref(res), self._lib.rk_fastq_slot_text(self._h), buf, len(self._obuf))
+        n = self._lib.rk_fastq_stream_lines(parts._h, C.byref(res), self._lib.rk_fastq_slot_spans_base(self._h), buf, len(self._obuf))
         del buf
         if n < 0:
             _chk(int(n))
@@ -547,7 +555,7 @@ class FastqSlot:
         """filter's records of a classified block (rk_fastq_filter_records), as bytes."""
         cap = int(self._lib.rk_fastq_filter_records_bound(C.byref(res)))
         buf = self._out_buffer(cap)
-        n = self._lib.rk_fastq_filter_records(C.byref(res), self._lib.rk_fastq_slot_text(self._h), min_matches, min_diff, buf, len(self._obuf))
+        n = self._lib.rk_fastq_filter_records(C.byref(res), self._lib.rk_fastq_slot_spans_base(self._h), min_matches, min_diff, buf, len(self._obuf))
         del buf
         if n < 0:
             _chk(int(n))

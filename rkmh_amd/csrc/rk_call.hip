@@ -194,3 +194,92 @@ hipError_t launch_call_enumerate(const uint8_t* ref_upper, const uint64_t* ref_o
 }
 
 } // namespace rk
+
+// ---- the C ABI of `call` (include/rkmh_amd.h) ----
+#include "rk_api_internal.hpp"
+
+// ---- call ------------------------------------------------------------------------------------------
+extern "C" int rk_call(rk_ctx* c, const uint8_t* ref_bases, const uint64_t* ref_offsets, int nref,
+                       const uint8_t* read_bases, const uint64_t* read_offsets, int64_t nreads, int k, int window_len,
+                       rk_call_record** out, int64_t* nout) {
+    static_assert(sizeof(rk_call_record) == sizeof(CallRecord), "record layouts must match");
+    if (!c || !ref_offsets || !read_offsets || nref < 1 || nreads < 0 || !out || !nout) return fail(RK_ERR_ARG, "bad arguments");
+    if (k < 1 || k > RK_MAX_K) return fail(RK_ERR_LIMIT, "k=%d outside [1,%d]", k, RK_MAX_K);
+    if (window_len < 1) return fail(RK_ERR_ARG, "window length must be positive");
+    RKCHK(set_dev(c));
+    *out = nullptr; *nout = 0;
+    GeneralCfg cfg; cfg.ks.n = 1; cfg.ks.k[0] = k;
+    // windows of the reads / of the references
+    uint64_t wr = 0;
+    for (int64_t i = 0; i < nreads; ++i) wr += (uint64_t)num_windows((int)(read_offsets[i + 1] - read_offsets[i]), k, c->pol.drop_last_window);
+    std::vector<uint64_t> win_off((size_t)nref + 1, 0);
+    for (int i = 0; i < nref; ++i)
+        win_off[(size_t)i + 1] = win_off[(size_t)i] + (uint64_t)num_windows((int)(ref_offsets[i + 1] - ref_offsets[i]), k, c->pol.drop_last_window);
+    const uint64_t wtot = win_off[(size_t)nref];
+    if (wtot >= (1ull << 30)) return fail(RK_ERR_LIMIT, "more than 2^30 reference positions");
+    // exact depth map
+    uint64_t cap = 1024;
+    while (cap < 2 * wr) cap <<= 1;
+    DevBuf d_keys, d_counts, d_depth, d_prefix, d_scratch, d_ref, d_refoff, d_winoff, d_rec, d_cnt;
+    int rc = RK_OK;
+    auto cleanup = [&]() { for (DevBuf* b : {&d_keys, &d_counts, &d_depth, &d_prefix, &d_scratch, &d_ref, &d_refoff, &d_winoff, &d_rec, &d_cnt}) b->release(); };
+#define CALLCHK(expr) do { rc = (expr); if (rc != RK_OK) { cleanup(); return rc; } } while (0)
+#define CALLHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(RK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
+    CALLCHK(d_keys.reserve(cap * 8));
+    CALLCHK(d_counts.reserve(cap * 4 + 16));
+    CALLHIP(hipMemsetAsync(d_keys.p, 0, cap * 8, c->st));
+    CALLHIP(hipMemsetAsync(d_counts.p, 0, cap * 4 + 16, c->st));
+    DepthTable t;
+    t.keys = d_keys.as<uint64_t>(); t.counts = d_counts.as<uint32_t>(); t.zero_count = d_counts.as<uint32_t>() + cap; t.mask = cap - 1;
+    {   // pass over the reads: read_hash_to_depth[h] += 1 (rkmh.cpp:1613-1622)
+        GeneralCfg c1 = cfg; c1.depth_insert = &t;
+        GeneralOut none;
+        CALLCHK(general_run(c, read_bases, nullptr, read_offsets, nreads, c1, none));
+    }
+    // references: upper-cased copy stays on the device for the candidate enumeration
+    const uint64_t rbytes = ref_offsets[nref];
+    CALLCHK(d_ref.reserve(rbytes + 64));
+    CALLCHK(d_refoff.reserve(((size_t)nref + 1) * 8));
+    CALLCHK(d_winoff.reserve(((size_t)nref + 1) * 8));
+    CALLCHK(d_depth.reserve((wtot + 1) * 4));
+    CALLCHK(d_prefix.reserve((wtot + 2) * 8));
+    CALLCHK(d_scratch.reserve(((wtot / 1024 + 2) * 2 + 4200) * 8));
+    if (rbytes) CALLHIP(hipMemcpyAsync(d_ref.p, ref_bases, rbytes, hipMemcpyHostToDevice, c->st));
+    CALLHIP(launch_to_upper(d_ref.as<uint8_t>(), rbytes, c->st));
+    CALLHIP(hipMemcpyAsync(d_refoff.p, ref_offsets, ((size_t)nref + 1) * 8, hipMemcpyHostToDevice, c->st));
+    CALLHIP(hipMemcpyAsync(d_winoff.p, win_off.data(), ((size_t)nref + 1) * 8, hipMemcpyHostToDevice, c->st));
+    {   // depth of every reference window, in reference order (rkmh.cpp:1785)
+        GeneralCfg c2 = cfg; c2.depth_lookup = &t; c2.depth_out = d_depth.as<int32_t>();
+        GeneralOut none;
+        CALLCHK(general_run(c, ref_bases, nullptr, ref_offsets, nref, c2, none));
+    }
+    CALLHIP(hipMemsetAsync(d_prefix.p, 0, (wtot + 2) * 8, c->st));
+    CALLHIP(launch_exclusive_scan(d_depth.as<int32_t>(), wtot, d_prefix.as<int64_t>(), d_scratch.as<int64_t>(), c->st));
+    uint32_t rcap = 1u << 16;
+    CALLCHK(d_cnt.reserve(16));
+    std::vector<rk_call_record> recs;
+    for (;;) {
+        CALLCHK(d_rec.reserve((size_t)rcap * sizeof(CallRecord)));
+        CALLHIP(hipMemsetAsync(d_cnt.p, 0, 16, c->st));
+        CALLHIP(launch_call_enumerate(d_ref.as<uint8_t>(), d_refoff.as<uint64_t>(), d_winoff.as<uint64_t>(), nref, wtot,
+                                      d_depth.as<int32_t>(), d_prefix.as<int64_t>(), k, window_len, t, c->pol, d_rec.as<CallRecord>(),
+                                      d_cnt.as<uint32_t>(), rcap, c->st));
+        uint32_t n = 0;
+        CALLHIP(hipMemcpyAsync(&n, d_cnt.p, 4, hipMemcpyDeviceToHost, c->st));
+        CALLHIP(hipStreamSynchronize(c->st));
+        if (n > rcap) { rcap = n + 1024; continue; } // rare: more calls than expected, run again with room for all
+        recs.resize(n);
+        if (n) CALLHIP(hipMemcpy(recs.data(), d_rec.p, (size_t)n * sizeof(CallRecord), hipMemcpyDeviceToHost));
+        break;
+    }
+    cleanup();
+#undef CALLCHK
+#undef CALLHIP
+    rk_call_record* r = (rk_call_record*)malloc(sizeof(rk_call_record) * (recs.empty() ? 1 : recs.size()));
+    if (!r) return fail(RK_ERR_NOMEM, "malloc");
+    if (!recs.empty()) memcpy(r, recs.data(), recs.size() * sizeof(rk_call_record));
+    *out = r; *nout = (int64_t)recs.size();
+    return RK_OK;
+}
+
+

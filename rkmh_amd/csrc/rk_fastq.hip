@@ -20,6 +20,7 @@
 //   (exclusive scan of the sequence lengths = the batch's offsets: rocPRIM)
 //   k_fq_gather    one wave per record (grid-stride): sequence bytes -> packed batch, keeper / quality range checks
 #include "rk_kernels.hpp"
+#include "rk_filter_rule.hpp"
 
 #include <hipcub/hipcub.hpp>
 
@@ -153,7 +154,64 @@ __global__ __launch_bounds__(256) void k_fq_gather(const uint8_t* __restrict__ r
     if (bad) atomicOr(&info[0], bad);
 }
 
+// ---- what the host still needs of the text (launch_fastq_pack) ----
+// pack_len[r] = bytes record r contributes; entries from the block's last record on are zeroed (the scan runs over the capacity)
+__global__ __launch_bounds__(256) void k_fq_pack_sizes(const uint32_t* __restrict__ info, uint32_t rec_cap, const uint32_t* __restrict__ name_len,
+                                                       const uint32_t* __restrict__ seq_len, const int32_t* __restrict__ out4, int names_only,
+                                                       int min_matches, int min_diff, uint32_t* __restrict__ pack_len) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r > rec_cap) return;
+    uint32_t n = 0;
+    if (info[0] == 0 && r < info[1]) {
+        if (names_only) n = name_len[r];
+        else if (rk_filter_keeps(out4 + (size_t)r * 4, min_matches, min_diff)) n = name_len[r] + 2u * seq_len[r];
+    }
+    pack_len[r] = n;
+}
+// 16 lanes per record: name (and sequence, quality) -> pack[pack_off[r] ..)
+__global__ __launch_bounds__(256) void k_fq_pack_copy(const uint8_t* __restrict__ raw, uint32_t* __restrict__ info, const uint32_t* __restrict__ name_off,
+                                                      const uint32_t* __restrict__ name_len, const uint32_t* __restrict__ seq_off,
+                                                      const uint32_t* __restrict__ seq_len, const uint32_t* __restrict__ qual_off,
+                                                      const uint32_t* __restrict__ pack_len, const uint32_t* __restrict__ pack_off, int names_only,
+                                                      uint8_t* __restrict__ pack, uint64_t pack_cap) {
+    if (info[0] != 0) return;
+    const uint32_t nrec = info[1];
+    const uint32_t total = pack_off[nrec];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        info[3] = total;
+        if ((uint64_t)total > pack_cap) atomicOr(&info[0], FQ_BAD_CAP);
+    }
+    if ((uint64_t)total > pack_cap) return;
+    const uint32_t sub = threadIdx.x & 15u, per = 16;
+    for (uint32_t r = blockIdx.x * per + (threadIdx.x >> 4); r < nrec; r += gridDim.x * per) {
+        const uint32_t n = pack_len[r];
+        if (n == 0) continue;
+        uint8_t* const dst = pack + pack_off[r];
+        const uint32_t nn = name_len[r];
+        const uint8_t* src = raw + name_off[r];
+        for (uint32_t i = sub; i < nn; i += 16) dst[i] = src[i];
+        if (!names_only) {
+            const uint32_t ns = seq_len[r];
+            src = raw + seq_off[r];
+            for (uint32_t i = sub; i < ns; i += 16) dst[nn + i] = src[i];
+            src = raw + qual_off[r];
+            for (uint32_t i = sub; i < ns; i += 16) dst[nn + ns + i] = src[i];
+        }
+    }
+}
+
 } // namespace
+
+hipError_t launch_fastq_pack(const FqDev& d, const uint8_t* raw, bool names_only, const int32_t* out4, int min_matches, int min_diff, hipStream_t st) {
+    hipLaunchKernelGGL(k_fq_pack_sizes, dim3((d.rec_cap + 256) / 256), dim3(256), 0, st, d.info, d.rec_cap, d.name_len, d.seq_len, out4, names_only ? 1 : 0,
+                       min_matches, min_diff, d.pack_len);
+    size_t tb = d.scan_tmp_bytes;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(d.scan_tmp, tb, d.pack_len, d.pack_off, (int)(d.rec_cap + 1), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fq_pack_copy, dim3(4096), dim3(256), 0, st, raw, d.info, d.name_off, d.name_len, d.seq_off, d.seq_len, d.qual_off, d.pack_len,
+                       d.pack_off, names_only ? 1 : 0, d.pack, d.pack_cap);
+    return hipGetLastError();
+}
 
 size_t fq_scan_temp_bytes(uint32_t n) {
     size_t tb = 0;

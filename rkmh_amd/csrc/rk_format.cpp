@@ -4,6 +4,7 @@
 // the decision of classify_and_count_diff_filter (/root/reference/src/equiv.hpp:324-353).  Used by bin/rkmh (rkmh_main.cpp) and,
 // through ctypes, by the one-process-per-GPU front end (rkmh_amd/cli.py).
 #include "../../include/rkmh_amd.h"
+#include "rk_filter_rule.hpp"
 
 #include <cstdint>
 #include <cstring>
@@ -114,14 +115,7 @@ extern "C" int64_t rk_fastq_filter_records(const rk_fastq_result* r, const uint8
     if (cap < rk_fastq_filter_records_bound(r)) return bad("rk_fastq_filter_records: buffer smaller than rk_fastq_filter_records_bound");
     char* w = dst;
     for (int64_t i = 0; i < r->nrec; ++i) {
-        const int32_t* q = r->out4 + i * 4;
-        // classify_and_count_diff_filter (equiv.hpp:324-353): the scan starts from max_shared = prev_best = 0 (the stream scan: -1)
-        int shared = 0;
-        bool diff_ok = 0 > min_diff;
-        if (q[1] > 0) { shared = q[1]; diff_ok = q[2] - (q[0] == 0 ? 1 : 0) > min_diff; }
-        // rkmh.cpp:1292-1293.  read_min_lens <= 0 implies shared == 0 (a shared hash is a min): the conjunction is the same predicate on
-        // exact rows and stays right on rows whose min_num was clamped to 0 (rk_set_min_num_bound(ctx, 0), which callers use with -D >= 0)
-        if ((q[3] <= 0 && shared <= 0) || shared < min_matches || !diff_ok) continue;
+        if (!rk_filter_keeps(r->out4 + i * 4, min_matches, min_diff)) continue; // (rk_filter_rule.hpp: equiv.hpp:324-353, rkmh.cpp:1292-1293)
         *w++ = '>';
         memcpy(w, text + r->name_off[i], r->name_len[i]); w += r->name_len[i];
         *w++ = '\n';

@@ -22,16 +22,22 @@
 // CRC-32 is NOT checked here (ISIZE and the stream's own end-of-block structure are); a damaged member almost surely breaks the
 // four-line grammar that the front end verifies next, and RKMH_BGZF_DEVICE=0 keeps the host inflater with its CRC check.
 #include "rk_kernels.hpp"
+#include "rk_crc32.hpp"
 #include <atomic>
+#include <cstdlib>
 
 namespace rk {
 
 namespace {
 
 constexpr int IW = 64;
-constexpr int LT = 9, DT = 7, CT = 7;         // root table bits: literal/length, distance, code-length code (LT = 8 frees 32 KB -- a pass-2
-                                              // window then fits beside a pass-1 wave -- but 83 % instead of 62 % of the windows meet a long code: 28.7 vs 26.6 ms, no gain end to end)
+constexpr int CT = 7;                         // root table bits of the code-length code
+// Root table bits of the literal/length and the distance code are template parameters of the kernel (LT, DT).  The shipped form is
+// <8, 6>: 73.5 KB of LDS per wave, so TWO waves decode on every CU (160 KB) -- a wave is issue-latency bound on its own SIMD and the
+// other three SIMDs of the CU idle, so the second wave is almost free (round 5 ran <9, 7>: 124.5 KB, one wave per CU, 26.6 ms per
+// launch whatever its size).  The price: 83 % instead of 62 % of the symbol windows meet a code longer than the root.
 constexpr int LONG_CAP = 128, DLONG_CAP = 32;  // symbols with codes longer than the root (more: the member is the host's)
+constexpr int WALK_N = 10;                    // code lengths above the root's bits (15 - 6 = 9 at most)
 constexpr int CL_AT = 320, LENS_N = 352;      // lens[0 .. 316): literal/length + distance code lengths; lens[320 .. 339): code-length code
 constexpr int IN_RING = 16, ENT_RING = 16, OUT_RING = 4; // dwords per lane
 constexpr int K_SYM = 8, K_HDR = 8;           // symbol steps / header steps (inside a header window) per period
@@ -43,24 +49,33 @@ constexpr uint32_t WIN_BYTES = 65536;
 __device__ const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // everything a wave of 64 streams keeps in LDS; arrays are [index][lane]
+template <int LT, int DT>
 struct LaneLds {
     uint16_t lit[(1 << LT) * IW];
     uint16_t dist[(1 << DT) * IW];
-    uint16_t lsort[LONG_CAP * IW], dsort[DLONG_CAP * IW]; // long-coded symbols in (length, symbol) order: the canonical walk
+    // lsort / dsort: long-coded symbols in (length, symbol) order: the canonical walk.  A stream's code lengths (lens: 0 .. 15,
+    // four per 16-bit word) are only alive between its block header and the table build, its sorted long symbols from the build to
+    // the block's end -- the same column of the same lane serves both (the build reads every length before it writes a symbol)
+    union {
+        uint16_t lsort[LONG_CAP * IW];
+        uint16_t lens[LENS_N / 4 * IW];
+    };
+    uint16_t dsort[DLONG_CAP * IW];
     // per code length above the root's bits: left-justified 15-bit upper limit of its codes | (index in the sorted list - first code) << 16
-    uint32_t lwalk[8 * IW], dwalk[8 * IW];
+    uint32_t lwalk[WALK_N * IW], dwalk[WALK_N * IW];
     uint32_t inr[IN_RING * IW];
     uint32_t entr[(ENT_RING + 1) * IW]; // (one more row each: where a step's store goes that is not due)
     uint32_t outr[(OUT_RING + 1) * IW];
-    uint8_t lens[LENS_N / 2 * IW]; // (code lengths are 0 .. 15: two per byte)
     uint8_t clorder[32];
 };
+static_assert(LENS_N / 4 <= LONG_CAP, "the code lengths live in the sorted list's rows");
 
-__device__ __forceinline__ uint32_t len_at(const LaneLds& L, int i, int t) { return (L.lens[(i >> 1) * IW + t] >> (4 * (i & 1))) & 15u; }
-// (a stream's column is written by its own lane only -- or by the whole wave, a byte per lane, when the wave fills it)
-__device__ __forceinline__ void set_len(LaneLds& L, int i, int t, uint32_t v) {
-    uint8_t& b = L.lens[(i >> 1) * IW + t];
-    b = (uint8_t)((i & 1) ? (b & 0x0Fu) | (v << 4) : (b & 0xF0u) | v);
+template <class LDS> __device__ __forceinline__ uint32_t len_at(const LDS& L, int i, int t) { return ((uint32_t)L.lens[(i >> 2) * IW + t] >> (4 * (i & 3))) & 15u; }
+// (a stream's column is written by its own lane only -- or by the whole wave, a word per lane, when the wave fills it)
+template <class LDS> __device__ __forceinline__ void set_len(LDS& L, int i, int t, uint32_t v) {
+    uint16_t& w = L.lens[(i >> 2) * IW + t];
+    const uint32_t sh = 4u * ((uint32_t)i & 3u);
+    w = (uint16_t)(((uint32_t)w & ~(15u << sh)) | (v << sh));
 }
 
 enum : uint32_t { ST_BLOCK = 0, ST_STORED_HDR, ST_DYN_HDR, ST_CL_READ, ST_LENS, ST_WAIT, ST_SYM, ST_STORED, ST_DONE, ST_FIN };
@@ -75,19 +90,26 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t m, int lane) { return (
 __device__ __host__ __forceinline__ uint32_t entry_cap(uint32_t out_len) { return out_len / 3u + out_len / 255u + 4u; }
 
 // The wave builds stream t's canonical Huffman table from lens[(at + s) * 64 + t], s < n: root table of 2^TB entries, counts per
-// length above the root (limit | offset, see LaneLds), the long-coded symbols in canonical order.  NCH = chunks of 64 symbols.  False: over-subscribed, or more long codes than cap.
-template <int TB, int NCH>
-__device__ bool coop_build(LaneLds& L, int t, int at, int n, uint16_t* tab, uint16_t* sorted, int cap, uint32_t* walk, int lane) {
-    uint32_t l[NCH], code_of[NCH];
+// length above the root (limit | offset, see LaneLds), the long-coded symbols in canonical order.  NCH = chunks of 64 symbols.  False:
+// over-subscribed, more long codes than cap, or incomplete where zlib refuses that (inftrees.c: an incomplete set is accepted only
+// for a literal/length or distance code whose longest code has one bit -- or none at all; never for the code-length code).
+// l[c] = the code length of symbol lane + 64 c (the build's input, taken before anything of the build is written: the sorted list shares the lengths' rows)
+template <int NCH, class LDS>
+__device__ __forceinline__ void load_lens(const LDS& L, int t, int at, int n, int lane, uint32_t (&l)[NCH]) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int s = lane + IW * c;
         l[c] = s < n ? len_at(L, at + s, t) : 0u;
-        code_of[c] = 0;
     }
+}
+template <int TB, int NCH>
+__device__ bool coop_build(const uint32_t (&l)[NCH], int t, uint16_t* tab, uint16_t* sorted, int cap, uint32_t* walk, int lane, bool is_codes) {
+    uint32_t code_of[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) code_of[c] = 0;
     for (int i = lane; i < (1 << TB); i += IW) tab[i * IW + t] = (uint16_t)E_INVALID;
-    if (walk && lane < 8) walk[lane * IW + t] = 0; // (limit 0: no code of that length)
-    uint32_t code = 0, longbase = 0;
+    if (walk && lane < WALK_N) walk[lane * IW + t] = 0; // (limit 0: no code of that length)
+    uint32_t code = 0, longbase = 0, maxlen = 0;
     int left = 1;
     bool ok = true;
     for (uint32_t len = 1; len <= 15; ++len) {
@@ -100,9 +122,10 @@ __device__ bool coop_build(LaneLds& L, int t, int at, int n, uint16_t* tab, uint
         }
         left = (left << 1) - (int)n_len;
         if (left < 0) ok = false;
+        if (n_len) maxlen = len;
         if (len > (uint32_t)TB) {
             if (longbase + n_len > (uint32_t)cap) ok = false;
-            else {
+            else if (n_len) {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c)
                     if (l[c] == len) sorted[(longbase + code_of[c] - code) * IW + t] = (uint16_t)(lane + IW * c);
@@ -112,6 +135,7 @@ __device__ bool coop_build(LaneLds& L, int t, int at, int n, uint16_t* tab, uint
         }
         code = (code + n_len) << 1;
     }
+    if (left > 0 && maxlen != 0u && (is_codes || maxlen != 1u)) ok = false;
     isync(); // (the invalid fill is in the table before the entries)
     if (ok) {
 #pragma unroll
@@ -136,10 +160,12 @@ struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };
 
 // Pass 1.  scratch: per member at dword me.match_off: entry_cap(out_len) entries, then the literal stream.
 // status[m]: 0 ok, else why the member is the host's; status[nmem + m] = its entries | its literals << 15.
+template <int LT, int DT>
 __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict__ comp, uint32_t comp_bytes, const InflateMember* __restrict__ mem, uint32_t nmem,
                                                       uint32_t* __restrict__ scratch, uint32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) uint8_t inflate_lds[];
-    LaneLds& L = *reinterpret_cast<LaneLds*>(inflate_lds);
+    typedef LaneLds<LT, DT> Lds;
+    Lds& L = *reinterpret_cast<Lds*>(inflate_lds);
     const int lane = threadIdx.x;
     const uint32_t m = blockIdx.x * IW + (uint32_t)lane;
     const bool live = m < nmem;
@@ -201,13 +227,13 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
             const uint32_t* const wk = is_lit ? L.lwalk : L.dwalk;
             const uint32_t tb = is_lit ? (uint32_t)LT : (uint32_t)DT;
             const uint32_t v = bitrev((uint32_t)bb & 0x7FFFu, 15);
-            uint32_t w[8];
+            uint32_t w[WALK_N];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = wk[i * IW + lane];
+            for (int i = 0; i < WALK_N; ++i) w[i] = wk[i * IW + lane];
             uint32_t len = 0, idx = 0;
 #pragma unroll
-            for (int i = 7; i >= 0; --i)
-                if (v < (w[i] & 0xFFFFu)) { len = tb + 1u + (uint32_t)i; idx = ((w[i] >> 16) + (v >> (14u - tb - (uint32_t)i))) & 0xFFFFu; }
+            for (int i = WALK_N - 1; i >= 0; --i) // (rows past length 15 hold limit 0; the shift stays in range for them)
+                if (v < (w[i] & 0xFFFFu)) { len = tb + 1u + (uint32_t)i; idx = ((w[i] >> 16) + (v >> ((14u - tb - (uint32_t)i) & 15u))) & 0xFFFFu; }
             if (len == 0u || idx >= (is_lit ? (uint32_t)LONG_CAP : (uint32_t)DLONG_CAP)) fail(13);
             else { wsym = (is_lit ? L.lsort : L.dsort)[idx * IW + lane]; wlen = len; have_w = 1; }
             want = 0;
@@ -310,7 +336,7 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
                     nlit = take(5) + 257u; ndist = take(5) + 1u; ncl = take(4) + 4u;
                     if (nlit > 286u || ndist > 30u) fail(5);
                     else {
-                        for (int i = 0; i < 10; ++i) L.lens[(CL_AT / 2 + i) * IW + lane] = 0;
+                        for (int i = 0; i < 5; ++i) L.lens[(CL_AT / 4 + i) * IW + lane] = 0;
                         hi = 0; state = ST_CL_READ;
                     }
                 }
@@ -351,16 +377,21 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
             bool ok;
             if (kind == 1u) {
                 isync();
-                ok = coop_build<CT, 1>(L, t, CL_AT, 19, L.lit, L.lsort, 0, nullptr, lane);
+                uint32_t lc[1];
+                load_lens<1>(L, t, CL_AT, 19, lane, lc);
+                ok = coop_build<CT, 1>(lc, t, L.lit, L.dsort, 0, nullptr, lane, true); // (cap 0: a code-length code has no symbol beyond the root's 7 bits)
             } else {
                 const int nl = __builtin_amdgcn_readlane((int)nlit, t), nd = __builtin_amdgcn_readlane((int)ndist, t);
-                if (kind == 3u) {
-                    for (int i = lane; i < 144; i += IW) L.lens[i * IW + t] = i < 72 ? 0x88 : (i < 128 ? 0x99 : (i < 140 ? 0x77 : 0x88)); // two symbols per byte
-                    if (lane < 15) L.lens[(144 + lane) * IW + t] = 0x55;
+                if (kind == 3u) { // the fixed codes (RFC 1951 3.2.6), four symbols per word: 144 x 8, 112 x 9, 24 x 7, 8 x 8 bits; 30 (32) x 5
+                    for (int i = lane; i < 80; i += IW) L.lens[i * IW + t] = (uint16_t)(i < 36 ? 0x8888 : (i < 64 ? 0x9999 : (i < 70 ? 0x7777 : (i < 72 ? 0x8888 : 0x5555))));
                 }
                 isync();
-                ok = coop_build<LT, 5>(L, t, 0, nl, L.lit, L.lsort, LONG_CAP, L.lwalk, lane);
-                ok = coop_build<DT, 1>(L, t, nl, nd, L.dist, L.dsort, DLONG_CAP, L.dwalk, lane) && ok;
+                uint32_t ll[5], ld[1];
+                load_lens<5>(L, t, 0, nl, lane, ll);
+                load_lens<1>(L, t, nl, nd, lane, ld);
+                isync(); // (every length is in a register before the sorted list takes their rows)
+                ok = coop_build<LT, 5>(ll, t, L.lit, L.lsort, LONG_CAP, L.lwalk, lane, false);
+                ok = coop_build<DT, 1>(ld, t, L.dist, L.dsort, DLONG_CAP, L.dwalk, lane, false) && ok;
             }
             if (lane == t) {
                 need_build = 0;
@@ -383,8 +414,8 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
             const bool room = ent_w - ent_f <= (uint32_t)(ENT_RING - 2) && (lit_n >> 2) - out_f < (uint32_t)(OUT_RING - 1); // (the partial dword's slot stays free)
             const bool act = state == ST_SYM && nb > 32u && room && (want | slow) == 0u;
             const bool dstep = phase != 0u;
-            const uint32_t slot = dstep ? (uint32_t)offsetof(LaneLds, dist) / 2u + ((uint32_t)bb & ((1u << DT) - 1u)) * IW
-                                        : (uint32_t)offsetof(LaneLds, lit) / 2u + ((uint32_t)bb & ((1u << LT) - 1u)) * IW;
+            const uint32_t slot = dstep ? (uint32_t)offsetof(Lds, dist) / 2u + ((uint32_t)bb & ((1u << DT) - 1u)) * IW
+                                        : (uint32_t)offsetof(Lds, lit) / 2u + ((uint32_t)bb & ((1u << LT) - 1u)) * IW;
             const uint32_t e = reinterpret_cast<const uint16_t*>(&L)[slot + (uint32_t)lane];
             const uint32_t l = have_w ? wlen : e >> 12, sym = have_w ? wsym : e & 0xFFFu;
             const bool coded = l != 0u;
@@ -514,6 +545,41 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __res
     if ((uint32_t)lane < n - done) dst[done + lane] = win[done + lane];
 }
 
+// The members' CRC-32 (gzread checks it for every member the reference reads, /root/reference/src/rkmh.cpp:238-263): one wave per
+// member over the text pass 2 wrote, the lanes' pieces and the recombination as rk_crc32.hpp states them (pinned against zlib on
+// the host by tools/crc32_check.cpp).  A member whose text does not give the CRC-32 of its footer gets status 30 -- the caller hands
+// the job to the host inflater, which reports the damage.
+__device__ const Crc32Tables CRC32_TABLES = make_crc32_tables();
+__global__ __launch_bounds__(256) void k_crc32_members(const InflateMember* __restrict__ mem, uint32_t nmem, const uint8_t* __restrict__ text,
+                                                       const uint8_t* __restrict__ comp, uint32_t* __restrict__ status) {
+    __shared__ uint32_t byte_t[256];
+    byte_t[threadIdx.x] = CRC32_TABLES.byte[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, m = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (m >= nmem || status[m] != 0u) return;
+    const InflateMember me = mem[m];
+    const Crc32Piece p = crc32_piece(me.out_off, me.out_len, lane);
+    uint32_t s = p.init;
+    for (uint32_t g = p.b & ~15u; g < p.e; g += 16u) { // (the text buffer is 16-byte aligned and readable a little past its end)
+        const uint4 v = *reinterpret_cast<const uint4*>(text + g);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t at = g + (uint32_t)j, byte = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            const uint32_t nxt = byte_t[(s ^ byte) & 0xFFu] ^ (s >> 8);
+            s = (at >= p.b && at < p.e) ? nxt : s;
+        }
+    }
+    uint32_t x = (p.e > p.b || lane == 0u) ? crc32_advance(CRC32_TABLES, s, p.z) : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x ^= (uint32_t)__shfl_xor((int)x, d);
+    if (lane == 0u) {
+        const uint8_t* f = comp + me.in_off + me.in_len; // the member's footer: CRC-32, ISIZE (little endian, any alignment)
+        const uint32_t want = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 24);
+        if (~x != want) status[m] = 30u;
+    }
+}
+
 // first record start (four-line rule, as find_record_start in rk_parse.cpp) at or after `from` in text[0 .. n): a line start p with
 // text[p] == '@' whose line two below begins with '+'.  One workgroup; cuts[which] = the position, n if there is none (the text
 // ends inside the last record's lines), 0xFFFFFFFF if the lookahead ran out of text (the caller inflates more members).
@@ -543,24 +609,30 @@ uint32_t inflate_scratch_dwords(uint32_t out_len) { return entry_cap(out_len) + 
 hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint32_t* scratch, uint32_t* status,
                                   hipStream_t st) {
     if (!nmem) return hipSuccess;
-    // (once per device: the call takes the runtime's lock, and a dozen workers launch from their own threads)
+    // RKMH_INFLATE_ROOT=9: round 5's root tables (9 / 7 bits, one wave per CU) -- kept for A/B runs of the same build
+    static const bool wide_root = [] { const char* e = getenv("RKMH_INFLATE_ROOT"); return e && atoi(e) == 9; }();
+    // (once per device: the call takes the runtime's lock, and several workers launch from their own threads)
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
     if (!((attr_set.load(std::memory_order_acquire) >> dev) & 1ull) || dev == 63) {
-        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds));
+        hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<8, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds<8, 6>));
+        if (attr == hipSuccess) attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<9, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds<9, 7>));
         if (attr != hipSuccess) return attr;
         attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
-    hipLaunchKernelGGL(k_inflate_lanes, dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds), st, comp, comp_bytes, mem, nmem, scratch, status);
+    if (wide_root) hipLaunchKernelGGL((k_inflate_lanes<9, 7>), dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds<9, 7>), st, comp, comp_bytes, mem, nmem, scratch, status);
+    else hipLaunchKernelGGL((k_inflate_lanes<8, 6>), dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds<8, 6>), st, comp, comp_bytes, mem, nmem, scratch, status);
     hipLaunchKernelGGL(k_inflate_place, dim3(nmem), dim3(IW), 0, st, mem, nmem, text, scratch, status);
+    hipLaunchKernelGGL(k_crc32_members, dim3((nmem + 3) / 4), dim3(256), 0, st, mem, nmem, text, comp, status);
     return hipGetLastError();
 }
 // (code objects are loaded at a TU's first launch -- tens of milliseconds; rk_warm_up asks for a kernel's attributes ahead of time instead)
 hipError_t warm_inflate() {
     hipFuncAttributes a;
-    hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_inflate_lanes));
+    hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_inflate_lanes<8, 6>));
     if (e == hipSuccess) e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_inflate_place));
+    if (e == hipSuccess) e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_crc32_members));
     return e;
 }
 hipError_t launch_fastq_first_start(const uint8_t* text, uint32_t n, uint32_t from, uint32_t window, bool at_eof, uint32_t* cuts, int which, hipStream_t st) {

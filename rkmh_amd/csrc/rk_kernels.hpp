@@ -105,12 +105,23 @@ struct FqDev {
     uint32_t *seq_off, *seq_len, *qual_off, *name_off, *name_len; // [rec_cap + 1]
     uint32_t* out_off;     // [rec_cap + 1] offsets of the packed batch
     uint8_t* bases;        // packed batch (block bytes + slack)
-    uint32_t* info;        // [4] status bits, records, longest sequence, -
+    uint32_t* info;        // [4] status bits, records, longest sequence, bytes packed by launch_fastq_pack
     void* scan_tmp;
     size_t scan_tmp_bytes;
+    // launch_fastq_pack: the spans of the text the HOST still needs, back to back in `pack` (pack_cap bytes + 16 of slack)
+    uint32_t* pack_len;    // [rec_cap + 1] bytes record r contributes
+    uint32_t* pack_off;    // [rec_cap + 1] their exclusive scan: where record r's spans begin in pack
+    uint8_t* pack;
+    uint64_t pack_cap;
 };
 size_t fq_scan_temp_bytes(uint32_t n);
 hipError_t launch_fastq_index(const FqDev& d, const uint8_t* raw, uint64_t nbytes, hipStream_t st);
+// After launch_fastq_index (and, for the filter form, after the rows are final): what the output formatters read of each record,
+// copied out of the raw text into d.pack so that only those bytes travel to the host.  names_only: every record's name (stream /
+// classify lines, src/rkmh.cpp:887-892).  Otherwise name, sequence and quality string of the records filter prints
+// (rk_filter_keeps on rows out4: src/rkmh.cpp:1292-1300).  Record r's spans begin at pack_off[r]: name, then sequence, then quality.
+// info[3] = bytes packed; FQ_BAD_CAP in info[0] when they exceed pack_cap (nothing is trusted then).
+hipError_t launch_fastq_pack(const FqDev& d, const uint8_t* raw, bool names_only, const int32_t* out4, int min_matches, int min_diff, hipStream_t st);
 // ---- reference FASTA text stripped on the device (rk_fasta.hip) ----
 enum { FA_BAD_CHAR = 1, FA_BAD_NAME = 2, FA_BAD_LEAD = 4, FA_BAD_EMPTY = 8 }; // status bits: any of them = parse the files on the host
 struct FaDev {

@@ -1092,6 +1092,7 @@ void rk_bgzf_close(rk_bgzf* z) {
 int64_t rk_bgzf_members(const rk_bgzf* z) { return z ? (int64_t)z->hlen.size() : 0; }
 // the file image and one member's place in it: bytes [*file_off, *file_off + *total) = header (*header bytes) + deflate stream + CRC-32 + ISIZE
 const uint8_t* rk_bgzf_image(const rk_bgzf* z) { return z ? z->map : nullptr; }
+uint64_t rk_bgzf_file_bytes(const rk_bgzf* z) { return z ? (uint64_t)z->size : 0; }
 int rk_bgzf_member(const rk_bgzf* z, int64_t m, uint64_t* file_off, uint32_t* total, uint32_t* header, uint32_t* text_bytes) {
     if (!z || m < 0 || (size_t)m >= z->hlen.size()) return perr(RK_ERR_ARG, "bad arguments");
     if (file_off) *file_off = z->coff[(size_t)m];
@@ -1184,7 +1185,7 @@ int rk_bgzf_fastq_records(const rk_bgzf* z, int64_t b0, int64_t b1, uint8_t* dst
     }
     size_t head = first_start((size_t)b0, &more);
     if (head > tail) head = tail;
-    if (b0 == 0 && tail > 0 && buf[0] != '@') return 1;
+    if (z->uoff[(size_t)b0] == 0 && tail > 0 && buf[0] != '@') return 1; // (the job begins the file's text)
     const size_t n = tail - head;
     if (text_off) *text_off = u_lo + head;
     if (n > cap) return perr(RK_ERR_LIMIT, "rk_bgzf_fastq_records: the records of the job need more bytes than the buffer holds");

@@ -413,24 +413,12 @@ static int granted_cpus_main() {
     return n < 1 ? 1 : n;
 }
 
-// BGZF (bgzip) read files found by raw_eligible: the device front end's workers inflate their members themselves (rk_bgzf_*)
+// BGZF (bgzip) read files found by raw_eligible: their members are inflated ON THE DEVICE (rk_inflate.hip), thousands per launch,
+// by a few workers with device-text slots -- or, RKMH_BGZF_DEVICE=0, by all but two of the CPUs (libdeflate / zlib), job by job
 static std::map<std::string, rk_bgzf*> g_bgzf;
-// RKMH_BGZF_DEVICE: who inflates the members.  0: the workers (libdeflate / zlib on the host).  1: the device (rk_inflate.hip: a lane per
-// member, ~27 ms per launch whatever its size -- it pays with about a thousand members per job and several jobs in flight, so its
-// workers take RKMH_BGZF_DEVICE_MERGE planned jobs at a time).  2: both -- RKMH_BGZF_DEVICE_WORKERS workers feed the device, the
-// others inflate their jobs themselves.  Unset: by size -- the device's slots are four times as large and take ~0.2 s longer to set
-// up, which 24 M reads win back and 8 M do not (profiles/r05_gz.txt): the device from 5 GB of text on, the host below.
-static int bgzf_device_mode() {
-    static const int mode = [] {
-        const char* e = getenv("RKMH_BGZF_DEVICE");
-        if (e) { const int v = atoi(e); return v < 0 || v > 2 ? 0 : v; }
-        uint64_t text = 0;
-        for (auto& kv : g_bgzf) text += rk_bgzf_text_bytes(kv.second);
-        const char* m = getenv("RKMH_BGZF_DEVICE_MIN_MB"); // (the size from which the device inflates; tests lower it)
-        const uint64_t from = m && atol(m) >= 0 ? (uint64_t)atol(m) << 20 : (uint64_t)5 << 30;
-        return text >= from ? 1 : 0;
-    }();
-    return mode;
+static bool bgzf_on_device() {
+    static const bool on = [] { const char* e = getenv("RKMH_BGZF_DEVICE"); return !(e && atoi(e) == 0); }();
+    return on;
 }
 static long env_long(const char* name, long dflt, long lo, long hi) { const char* e = getenv(name); if (!e) return dflt; const long v = atol(e); return v < lo || v > hi ? dflt : v; }
 static rk_bgzf* bgzf_of(const char* path) { auto it = g_bgzf.find(path); return it == g_bgzf.end() ? nullptr : it->second; }
@@ -562,14 +550,57 @@ struct OrderedOut {
     }
 };
 
+// Work handed to a few helper threads: the lines of a device-inflated BGZF job (hundreds of megabytes of text, millions of records)
+// are formatted piece by piece by all of them while its worker waits, each piece parked under its own block number
+struct FormatPool {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    std::vector<std::thread> th;
+    bool closing = false;
+    void start(int n) {
+        for (int i = (int)th.size(); i < n; ++i)
+            th.emplace_back([this] {
+                std::unique_lock<std::mutex> l(m);
+                for (;;) {
+                    cv.wait(l, [&] { return !q.empty() || closing; });
+                    if (q.empty()) return;
+                    std::function<void()> f = std::move(q.front());
+                    q.pop_front();
+                    l.unlock();
+                    f();
+                    l.lock();
+                }
+            });
+    }
+    void run(std::function<void()> f) { { std::lock_guard<std::mutex> l(m); q.push_back(std::move(f)); } cv.notify_one(); }
+    void stop() {
+        { std::lock_guard<std::mutex> l(m); closing = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+        th.clear();
+        closing = false;
+    }
+};
+struct Latch {
+    std::mutex m;
+    std::condition_variable cv;
+    int left = 0;
+    void done() { std::lock_guard<std::mutex> l(m); if (--left == 0) cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return left == 0; }); }
+};
+
+static const std::vector<const char*>* g_read_paths = nullptr; // the -f files of this run (RawEngine::create: are they all BGZF?)
 struct RawEngine {
-    // two slots: one block on the device while the next is read; inflate: this worker's BGZF jobs are inflated on the device, `merge` planned jobs at a time
-    struct Worker { rk_fastq_slot* slot[2] = {nullptr, nullptr}; size_t dev = 0; bool inflate = false; int merge = 1; uint64_t bytes = 0; bool two = false; };
+    // one slot per worker: one block on the device at a time.  (Two slots per worker -- the next block read while the previous one is on
+    // the device -- were measured no faster on 64 M reads and 0.2 s slower on 16 M, profiles/r04_e2e_ab.txt, and are gone.)
+    struct Worker { rk_fastq_slot* slot = nullptr; size_t dev = 0; bool device_text = false; uint64_t bytes = 0; std::vector<uint8_t> host_text; };
     std::vector<Worker> w;
-    uint64_t block = 0;
-    bool two_slots = false; // RKMH_RAW_SLOTS=2: a worker reads its next block while the previous one is on the device.  Measured (profiles/r04_e2e_ab.txt,
-                            // medians of three): no faster on 64 M reads (1.54 against 1.53-1.58 s to a file, 1.25 against 1.16-1.29 to /dev/null) and
-                            // 0.2 s slower on 16 M (twice the page-locked buffers to create), so one slot per worker is the default
+    uint64_t block = 0;  // text per job: plain files, and BGZF files inflated on the host
+    uint64_t mega = 0;   // text per job of BGZF files inflated on the device (0: no such file in this run)
+    int pieces = 1;      // block numbers (= output pieces, formatted in parallel) per device-inflated job
+    bool need_plain_workers = false; // the references go through the workers' page-locked text buffers (refs_through_device)
+    FormatPool pool;
     double t_read = 0, t_dev = 0, t_fmt = 0;
     int64_t blocks = 0, records = 0;
     bool create(DeviceGroup& g) {
@@ -582,41 +613,60 @@ struct RawEngine {
         // gets that many as long as the CPUs last -- not measured (one-GPU boxes), the same reasoning per link
         const long cap = g.size() > 1 ? std::min<long>(64, 6 * (long)g.size()) : 12;
         if (nw > cap) nw = cap;
-        // BGZF input: a worker inflates its job's members before the upload (~1 GB/s of text per core with libdeflate, a third of
-        // that with zlib) -- the CPUs, not the link, set the rate, so all but two of them work
-        // (inflated on the device -- the default -- the workers only copy the compressed bytes: two more than for plain text)
-        const int zmode = g_bgzf.empty() ? 0 : bgzf_device_mode();
-        if (!g_bgzf.empty()) nw = std::max<long>(nw, std::min<long>(32, granted_cpus_main() - 2));
+        const bool dev_inflate = !g_bgzf.empty() && bgzf_on_device();
+        // BGZF inflated on the host: a worker inflates its job's members before the upload (~1 GB/s of text per core with libdeflate,
+        // a third of that with zlib) -- the CPUs, not the link, set the rate, so all but two of them work
+        if (!g_bgzf.empty() && !dev_inflate) nw = std::max<long>(nw, std::min<long>(32, granted_cpus_main() - 2));
         if (const char* e = getenv("RKMH_RAW_WORKERS")) { long v = atol(e); if (v >= 1 && v <= 64) nw = v; }
         if ((size_t)nw < g.size()) nw = (long)g.size();
-        if (zmode == 1) nw = 0; // (its workers are the device's, below)
-        if (const char* e = getenv("RKMH_RAW_SLOTS")) two_slots = atoi(e) == 2;
-        // (the device's workers wait for their kernels most of the time: they come on top of the inflating ones)
-        const long ndev = zmode ? env_long("RKMH_BGZF_DEVICE_WORKERS", zmode == 1 ? 8 : 6, 1, 32) * (long)g.size() : 0;
-        const int merge = zmode ? (int)env_long("RKMH_BGZF_DEVICE_MERGE", 4, 1, 64) : 1;
+        // BGZF inflated on the device: the decode kernel takes the same time for 64 members as for 16 384 (a lane per member, one
+        // wave per 64, two waves per CU: up to 32 768 members per launch in one round), so a job is as large as the file allows --
+        // a third of the largest file, at most 1 GiB of text -- and three workers per device keep upload, decode, parsing and
+        // formatting of consecutive jobs overlapped.  Their slots hold the text on the device only.
+        bool all_bgzf = dev_inflate;
+        if (dev_inflate) {
+            uint64_t largest = 0;
+            for (auto& kv : g_bgzf) largest = std::max<uint64_t>(largest, rk_bgzf_text_bytes(kv.second));
+            mega = std::min<uint64_t>((uint64_t)1 << 30, std::max<uint64_t>((uint64_t)4 << 20, largest / 3 + ((uint64_t)1 << 20)));
+            if (const long kb = env_long("RKMH_BGZF_JOB_KB", 0, 64, 1536 << 10)) mega = (uint64_t)kb << 10; // (tests: small jobs)
+            pieces = (int)std::min<uint64_t>(32, std::max<uint64_t>(1, mega >> 25)); // ~32 MB of text per output piece
+            pieces = (int)env_long("RKMH_BGZF_PIECES", pieces, 1, 32);
+        }
+        const long ndev = dev_inflate ? env_long("RKMH_BGZF_DEVICE_WORKERS", 3, 1, 16) * (long)g.size() : 0;
+        // (a run whose read files are ALL BGZF needs no plain-text workers -- their page-locked buffers are the start-up cost of this path)
+        if (need_plain_workers || !g_read_paths) all_bgzf = false;
+        else for (const char* p : *g_read_paths) if (!g_bgzf.count(p)) all_bgzf = false;
+        if (all_bgzf) nw = 0;
         w.resize((size_t)(nw + ndev));
         for (size_t i = 0; i < w.size(); ++i) {
             w[i].dev = i % g.size();
-            w[i].inflate = zmode != 0 && i >= (size_t)nw;
-            w[i].merge = w[i].inflate ? merge : 1;
-            w[i].bytes = block * (uint64_t)w[i].merge + 64; // (+ 64: a last block of exactly `block` bytes may get its missing newline)
-            // RKMH_BGZF_DEVICE_SLOTS=2: a worker that feeds the device keeps two jobs going -- the next one's inflate kernels run while it finishes
-            // the previous one.  Measured slower (profiles/r05_gz.txt): sixteen jobs' decode waves then hold the LDS of every CU
-            w[i].two = two_slots || (w[i].inflate && env_long("RKMH_BGZF_DEVICE_SLOTS", 1, 1, 2) == 2);
+            w[i].device_text = i >= (size_t)nw;
+            w[i].bytes = (w[i].device_text ? mega : block) + 64; // (+ 64: a last block of exactly `block` bytes may get its missing newline)
         }
         // each worker creates its own slot when it starts (page-locking ~50 MB takes ~10 ms): the first blocks are on their way
         // while the later workers are still setting up.  Only the first slot is made here, to find out whether the front end works at all.
-        if (rk_fastq_slot_create(g.ctx[0], w[0].bytes, &w[0].slot[0]) != RK_OK) {
+        if (rk_fastq_slot_create2(g.ctx[0], w[0].bytes, w[0].device_text ? RK_SLOT_DEVICE_TEXT : 0, &w[0].slot) != RK_OK) {
             fprintf(stderr, "rkmh: device FASTQ front end unavailable (%s): using the host scanner\n", rk_last_error());
             w.clear();
             return false;
         }
+        if (pieces > 1) pool.start((int)std::min<long>(16, std::max<long>(2, granted_cpus_main() - 2)));
         return true;
     }
-    void destroy() { for (auto& x : w) for (auto* sl : x.slot) if (sl) rk_fastq_slot_destroy(sl); w.clear(); }
+    void destroy() { pool.stop(); for (auto& x : w) if (x.slot) rk_fastq_slot_destroy(x.slot); w.clear(); }
 };
 
-// the lines of one block (rk_fastq_stream_lines: rk_format.cpp), names taken from the raw text
+// records [lo, hi) of a classified block as a result of their own (the spans index the same text)
+static rk_fastq_result sub_result(const rk_fastq_result& r, int64_t lo, int64_t hi) {
+    rk_fastq_result p = r;
+    p.nrec = hi - lo;
+    p.out4 = r.out4 + lo * 4;
+    p.name_off = r.name_off + lo; p.name_len = r.name_len + lo;
+    p.seq_off = r.seq_off + lo; p.seq_len = r.seq_len + lo; p.qual_off = r.qual_off + lo;
+    return p;
+}
+
+// the lines of one block (rk_fastq_stream_lines: rk_format.cpp), names taken from where the slot says they lie
 static size_t format_raw(const rk_line_parts* lp, const rk_fastq_result& r, const uint8_t* text, std::vector<char>& buf) {
     const size_t need = (size_t)rk_fastq_stream_lines_bound(lp, &r);
     if (buf.size() < need) buf.resize(need + need / 8); // (grows a few times, then stays: no per-block allocation or zero-fill)
@@ -648,211 +698,209 @@ static size_t format_filter_raw(const rk_fastq_result& r, const uint8_t* text, c
 // what a pass over a file does with each block
 enum RawKind { RAW_STREAM, RAW_FILTER, RAW_COUNT };
 
-// One file through the device front end.  Returns -1 when the whole file was taken, else the byte offset (a record start) from
-// which the kseq-grammar scanner must continue.
+// A run of read files through the device front end, as ONE pipeline: the workers go from the last blocks of a file straight to the
+// first ones of the next (nothing drains between files), the output keeps the order of the command line.  Returns -1 when every
+// file was taken whole; else *fail_file (an index into paths) and the byte offset in that file's text (a record start) from which
+// the kseq-grammar scanner must continue -- nothing of that file from there on, and nothing of the files behind it, was printed.
 // RAW_STREAM prints stream's lines, RAW_FILTER filter's records; RAW_COUNT prints nothing: it is pass 1 of -M (rkmh.cpp:904-910),
 // every worker counts its blocks into its device's table cnts[dev] (summed by the caller), and the first refused block ends the pass.
-static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& refs, const Opts& o, const char* path, int64_t fsize,
-                               RawKind kind = RAW_STREAM, std::vector<rk_counter*>* cnts = nullptr) {
-    const int fd = open(path, O_RDONLY);
-    if (fd < 0) { fprintf(stderr, "rkmh: cannot open %s\n", path); fail_exit(); }
+static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& refs, const Opts& o, const std::vector<const char*>& paths,
+                                const std::vector<int64_t>& fsizes, RawKind kind, std::vector<rk_counter*>* cnts, size_t* fail_file) {
     rk_line_parts* lp = nullptr;
     if (kind == RAW_STREAM) CK(rk_line_parts_create(refs.names, refs.name_offsets, refs.nseq, o.sketch, o.min_matches, o.min_diff, &lp));
     const bool counting = kind == RAW_COUNT;
-    rk_bgzf* const bz = bgzf_of(path); // compressed (BGZF): a job is a run of members [lo, hi), inflated by the worker that takes it
-    // at: where the job's first record starts in the (uncompressed) text; ext: its text in the mapped file; nseq: planned jobs merged into this one
-    // left: planned jobs after this one
-    struct Job { int64_t seq = 0, lo = 0, hi = 0, at = 0; const uint8_t* ext = nullptr; int64_t nseq = 1, left = INT64_MAX; bool begun = false; }; // begun: its inflate kernels are under way (rk_fastq_slot_load_bgzf_begin)
-    // RKMH_RAW_MMAP=1: the file is mapped and the mapping page-locked (hipHostRegister): the link reads the page cache itself, the
-    // workers copy nothing (tools/ubench/mmap_register.hip)
-    const uint8_t* fmap = nullptr;
-    if (!bz && fsize > 0 && getenv("RKMH_RAW_MMAP") && atoi(getenv("RKMH_RAW_MMAP")) != 0) {
-        void* mp = mmap(nullptr, (size_t)fsize, PROT_READ, MAP_SHARED, fd, 0);
-        if (mp != MAP_FAILED) {
-            if (rk_host_register_readonly(mp, (size_t)fsize) == RK_OK) fmap = (const uint8_t*)mp;
-            else munmap(mp, (size_t)fsize);
+    // bz: compressed (BGZF) -- a job is a run of members [lo, hi); mega: ... inflated on the device: large jobs, device-text slots,
+    // eng.pieces block numbers each (else by the worker that takes the job)
+    struct File { const char* path = nullptr; int fd = -1; int64_t fsize = 0; rk_bgzf* bz = nullptr; bool mega = false; const uint8_t* fmap = nullptr; };
+    std::vector<File> files(paths.size());
+    const bool want_mmap = getenv("RKMH_RAW_MMAP") && atoi(getenv("RKMH_RAW_MMAP")) != 0;
+    for (size_t i = 0; i < paths.size(); ++i) {
+        File& F = files[i];
+        F.path = paths[i]; F.fsize = fsizes[i];
+        F.fd = open(F.path, O_RDONLY);
+        if (F.fd < 0) { fprintf(stderr, "rkmh: cannot open %s\n", F.path); fail_exit(); }
+        F.bz = bgzf_of(F.path);
+        F.mega = F.bz && eng.mega != 0;
+        // RKMH_RAW_MMAP=1: the file is mapped and the mapping page-locked (hipHostRegister): the link reads the page cache itself, the
+        // workers copy nothing (tools/ubench/mmap_register.hip)
+        if (!F.bz && F.fsize > 0 && want_mmap) {
+            void* mp = mmap(nullptr, (size_t)F.fsize, PROT_READ, MAP_SHARED, F.fd, 0);
+            if (mp != MAP_FAILED) {
+                if (rk_host_register_readonly(mp, (size_t)F.fsize) == RK_OK) F.fmap = (const uint8_t*)mp;
+                else munmap(mp, (size_t)F.fsize);
+            }
+        }
+        // a BGZF file that goes to the device: its mapping is page-locked once (14 ms per GB), the DMA engine then reads the compressed
+        // members out of the page cache itself.  (Refused -- a platform limit -- the uploads go through the runtime's staging.)
+        if (F.mega) {
+            static std::mutex rm;
+            static std::map<const rk_bgzf*, bool> registered;
+            std::lock_guard<std::mutex> l(rm);
+            if (!registered.count(F.bz) && !(getenv("RKMH_BGZF_REGISTER") && atoi(getenv("RKMH_BGZF_REGISTER")) == 0))
+                registered[F.bz] = rk_host_register_readonly(rk_bgzf_image(F.bz), (size_t)rk_bgzf_file_bytes(F.bz)) == RK_OK;
         }
     }
-    QueueT<Job> jobs;
-    jobs.cap = eng.w.size();
+    // file: index into files; at: where the job's first record starts in the (uncompressed) text; ext: its text in the mapped file; nseq: block numbers it owns
+    struct Job { size_t file = 0; int64_t seq = 0, lo = 0, hi = 0, at = 0; const uint8_t* ext = nullptr; int64_t nseq = 1; };
+    QueueT<Job> jobs_plain, jobs_mega; // (a worker takes the jobs its slot is made for)
+    jobs_plain.cap = jobs_mega.cap = eng.w.size();
+    bool any_mega = false, any_plain = false;
+    for (const File& F : files) (F.mega ? any_mega : any_plain) = true;
     OrderedOut out;
     if (!counting) out.start(g.size());
     std::atomic<int64_t> fail_seq{INT64_MAX};
     std::mutex fm;
-    std::map<int64_t, int64_t> fail_at; // block number -> its first byte
+    std::map<int64_t, std::pair<size_t, int64_t>> fail_at; // block number -> (file, its first byte)
     std::mutex tm;
-    std::atomic<int> live{(int)eng.w.size()};
+    std::atomic<int> live_plain{0}, live_mega{0};
+    for (auto& x : eng.w) ++(x.device_text ? live_mega : live_plain);
+    const int64_t window = (int64_t)eng.w.size() * 4 * (any_mega ? eng.pieces : 1) + 2;
     auto work = [&](size_t wi) {
-        const bool two = eng.w[wi].two;
-        for (int k = 0; k < (two ? 2 : 1); ++k)
-            if (!eng.w[wi].slot[k] && rk_fastq_slot_create(g.ctx[eng.w[wi].dev], eng.w[wi].bytes, &eng.w[wi].slot[k]) != RK_OK) {
-                // (memory for another slot ran out: the other workers carry on -- unless this was the last one)
-                fprintf(stderr, "rkmh: worker %zu: %s\n", wi, rk_last_error());
-                if (live.fetch_sub(1) == 1) { fprintf(stderr, "rkmh: no worker of the device front end could start\n"); fail_exit(); }
-                return;
-            }
-        const int64_t window = (int64_t)eng.w.size() * 4 + 2;
-        Job cur, prev;
-        std::vector<Job> run;
-        bool have_prev = false;
-        int k = 0;
+        RawEngine::Worker& W = eng.w[wi];
+        if (!(W.device_text ? any_mega : any_plain)) return; // (no file of this run is for this worker's kind of slot)
+        QueueT<Job>& jobs = W.device_text ? jobs_mega : jobs_plain;
+        std::atomic<int>& live = W.device_text ? live_mega : live_plain;
+        if (!W.slot && rk_fastq_slot_create2(g.ctx[W.dev], W.bytes, W.device_text ? RK_SLOT_DEVICE_TEXT : 0, &W.slot) != RK_OK) {
+            // (memory for another slot ran out: the other workers carry on -- unless this was the last one)
+            fprintf(stderr, "rkmh: worker %zu: %s\n", wi, rk_last_error());
+            if (live.fetch_sub(1) == 1) { fprintf(stderr, "rkmh: no worker of the device front end could start\n"); fail_exit(); }
+            return;
+        }
+        rk_fastq_slot* const slot = W.slot;
+        if (W.device_text && kind == RAW_FILTER) CK(rk_fastq_slot_set_filter_output(slot, o.min_matches, o.min_diff));
+        Job cur;
         double t_rd = 0, t_dv = 0, t_fm = 0;
         int64_t nblk = 0, nrec_ = 0;
-        // (a merged job's other block numbers carry no output of their own)
-        auto put_rest = [&](const Job& jb) { if (!counting) for (int64_t e = 1; e < jb.nseq; ++e) out.put(jb.seq + e, std::vector<char>(), 0, window); };
-        auto finish_block = [&](const Job& jb, rk_fastq_slot* slot) {
+        // (block numbers of a job that carry no output of their own)
+        auto put_empty = [&](const Job& jb, int64_t from) { if (!counting) for (int64_t e = from; e < jb.nseq; ++e) out.put(jb.seq + e, std::vector<char>(), 0, window); };
+        auto declare_failed = [&](const Job& jb) { // the scanner takes the file over from this job's first record
+            { std::lock_guard<std::mutex> l(fm); fail_at[jb.seq] = std::make_pair(jb.file, jb.at); }
+            if (!counting) out.lower_limit(jb.seq); // (before this block is parked: the sink cannot pass it)
+            int64_t curf = fail_seq.load();
+            while (jb.seq < curf && !fail_seq.compare_exchange_weak(curf, jb.seq)) {}
+        };
+        auto finish_block = [&](const Job& jb) {
             const double b = now_s();
             rk_fastq_result res;
             if (rk_fastq_slot_finish(slot, &res) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
             const double c = now_s();
-            std::vector<char> buf = out.take_buffer();
-            size_t outlen = 0;
-            if (res.status != 0) {
-                { std::lock_guard<std::mutex> l(fm); fail_at[jb.seq] = jb.at; }
-                out.lower_limit(jb.seq); // (before this block is parked: the sink cannot pass it)
-                int64_t curf = fail_seq.load();
-                while (jb.seq < curf && !fail_seq.compare_exchange_weak(curf, jb.seq)) {}
-            } else if (kind == RAW_FILTER) outlen = format_filter_raw(res, jb.ext ? jb.ext : rk_fastq_slot_text(slot), o, buf);
-            else outlen = format_raw(lp, res, jb.ext ? jb.ext : rk_fastq_slot_text(slot), buf);
-            t_dv += c - b; t_fm += now_s() - c; ++nblk; nrec_ += res.status == 0 ? res.nrec : 0;
-            out.put(jb.seq, std::move(buf), outlen, window);
-            put_rest(jb);
-            if (getenv("RKMH_TRACE_JOBS")) fprintf(stderr, "[job] worker %zu parked blocks %lld..%lld\n", wi, (long long)jb.seq, (long long)(jb.seq + jb.nseq - 1));
+            t_dv += c - b; ++nblk; nrec_ += res.status == 0 ? res.nrec : 0;
+            if (res.status != 0) { declare_failed(jb); put_empty(jb, 0); return; }
+            const uint8_t* const text = rk_fastq_slot_spans_base(slot);
+            auto format_piece = [&](const rk_fastq_result& part, int64_t seq) {
+                std::vector<char> buf = out.take_buffer();
+                const size_t n = part.nrec == 0 ? 0 : (kind == RAW_FILTER ? format_filter_raw(part, text, o, buf) : format_raw(lp, part, text, buf));
+                out.put(seq, std::move(buf), n, window);
+            };
+            if (jb.nseq == 1) format_piece(res, jb.seq);
+            else { // the helpers format the pieces; the slot's arrays stay untouched until all of them are parked
+                Latch latch;
+                latch.left = (int)jb.nseq;
+                for (int64_t e = 0; e < jb.nseq; ++e)
+                    eng.pool.run([&, e] {
+                        format_piece(sub_result(res, res.nrec * e / jb.nseq, res.nrec * (e + 1) / jb.nseq), jb.seq + e);
+                        latch.done();
+                    });
+                latch.wait();
+            }
+            t_fm += now_s() - c;
+            if (getenv("RKMH_TRACE_JOBS")) fprintf(stderr, "[job] worker %zu parked blocks %lld..%lld (%lld records)\n", wi, (long long)jb.seq, (long long)(jb.seq + jb.nseq - 1), (long long)res.nrec);
         };
-        // the scanner takes the file over from this job's first record
-        auto refuse = [&](const Job& jb) {
-            { std::lock_guard<std::mutex> l(fm); fail_at[jb.seq] = jb.at; }
-            if (!counting) out.lower_limit(jb.seq);
-            int64_t curf = fail_seq.load();
-            while (jb.seq < curf && !fail_seq.compare_exchange_weak(curf, jb.seq)) {}
-            if (!counting) out.put(jb.seq, std::vector<char>(), 0, window);
-            put_rest(jb);
-        };
-        // a job whose inflate was begun: wait for it, cut its records (or inflate it here after all), hand it to the index kernels
-        auto finish_load = [&](Job& jb, rk_fastq_slot* slot) {
-            const double a = now_s();
-            uint64_t nbytes = 0, off = (uint64_t)jb.at;
-            int rc = rk_fastq_slot_load_bgzf_end(slot, &nbytes, &off);
-            if (rc < 0) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
-            uint8_t* text = rk_fastq_slot_text(slot);
-            const bool on_device = rc == RK_OK;
-            if (!on_device) rc = rk_bgzf_fastq_records(bz, jb.lo, jb.hi, text, eng.w[wi].bytes - 1, &nbytes, &off);
-            jb.at = (int64_t)off;
-            if (rc == 1 || rc == RK_ERR_LIMIT) { refuse(jb); t_rd += now_s() - a; return false; }
-            if (rc != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
-            if (!on_device && jb.hi == rk_bgzf_members(bz) && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n';
-            if (rk_fastq_slot_submit(slot, nbytes) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
-            t_rd += now_s() - a;
-            return true;
-        };
-        // block b is on its way to the device and through the index kernels (submit) while block b + 1 is read into the other slot
         for (;;) {
-            bool got;
-            bool to_device = bz && eng.w[wi].inflate;
-            if (to_device && eng.w[wi].merge > 1) { // the device takes a run of planned jobs as one (consecutive: one producer, the run leaves the queue in one step)
-                // (a file's last jobs are taken one by one and inflated here: a merged job is ~100 ms that the other workers would wait for at the end)
-                const int64_t tail = 2 * eng.w[wi].merge;
-                got = jobs.pop_run(&run, [&](const Job& f) { return f.left < tail ? 1 : eng.w[wi].merge; });
-                if (got) { cur = run[0]; cur.hi = run.back().hi; cur.nseq = (int64_t)run.size(); to_device = cur.left >= tail; }
-            } else got = jobs.pop(&cur);
+            if (!jobs.pop(&cur)) break;
             // (a failure is declared at the first block number of the failing worker's own job: never inside another job's run)
-            if (got && cur.seq > fail_seq.load()) { // the scanner will redo this range
-                if (!counting) { out.put(cur.seq, std::vector<char>(), 0, window); put_rest(cur); }
-                continue;
-            }
-            static const bool trace = getenv("RKMH_TRACE_JOBS") != nullptr;
-            if (trace && got) fprintf(stderr, "[job] worker %zu (%s) takes blocks %lld..%lld\n", wi, eng.w[wi].inflate ? "device" : "host", (long long)cur.seq, (long long)(cur.seq + cur.nseq - 1));
-            cur.begun = false;
-            if (got && to_device && two && !counting) { // its kernels start now; the job is completed (finish_load) after the previous one has left
-                const double a = now_s();
-                const int rc = rk_fastq_slot_load_bgzf_begin(eng.w[wi].slot[k], bz, cur.lo, cur.hi);
+            if (cur.seq > fail_seq.load()) { put_empty(cur, 0); continue; } // the scanner will redo this range
+            const File& F = files[cur.file];
+            rk_bgzf* const bz = F.bz;
+            const char* const path = F.path;
+            const int fd = F.fd;
+            const int64_t fsize = F.fsize;
+            const uint8_t* const fmap = F.fmap;
+            const double a = now_s();
+            uint64_t nbytes = 0;
+            bool refused = false; // (BGZF: text that does not begin with '@', or a job whose records outgrow the slot)
+            if (bz) {
+                uint64_t off = 0;
+                // the members inflated on the device (which may hand a job back: a member it cannot decode, a failed CRC-32 -- the host
+                // inflater then reports the damage) or by this thread
+                int rc = W.device_text ? rk_fastq_slot_load_bgzf(slot, bz, cur.lo, cur.hi, &nbytes, &off) : 1;
                 if (rc < 0) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
-                cur.begun = rc == RK_OK;
-                if (!cur.begun) to_device = false; // (too large for the slot: inflated here, below)
-                t_rd += now_s() - a;
-            }
-            if (got && !cur.begun) {
-                const double a = now_s();
-                uint8_t* text = rk_fastq_slot_text(eng.w[wi].slot[k]);
-                uint64_t nbytes = 0;
-                bool refused = false; // (BGZF: text that does not begin with '@', or a job whose records outgrow the slot)
-                if (bz) {
-                    uint64_t off = 0;
-                    // the members inflated by this thread, or (RKMH_BGZF_DEVICE=1) on the device, which may hand a job back
-                    int rc = to_device ? rk_fastq_slot_load_bgzf(eng.w[wi].slot[k], bz, cur.lo, cur.hi, &nbytes, &off) : 1;
-                    if (rc < 0) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
-                    const bool on_device = rc == RK_OK;
-                    if (!on_device) rc = rk_bgzf_fastq_records(bz, cur.lo, cur.hi, text, eng.w[wi].bytes - 1, &nbytes, &off);
-                    cur.at = (int64_t)off;
+                if (rc != RK_OK) {
+                    uint8_t* text = rk_fastq_slot_text(slot);
+                    if (W.device_text) { if (W.host_text.size() < W.bytes) W.host_text.resize(W.bytes); text = W.host_text.data(); }
+                    rc = rk_bgzf_fastq_records(bz, cur.lo, cur.hi, text, W.bytes - 1, &nbytes, &off);
                     if (rc == 1 || rc == RK_ERR_LIMIT) { refused = true; nbytes = 0; }
                     else if (rc != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", path, rk_last_error()); fail_exit(); }
-                    if (!on_device && cur.hi == rk_bgzf_members(bz) && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n';
-                } else if (fmap && !(cur.hi == fsize && fmap[fsize - 1] != '\n')) { // (a last block without its newline is copied, to get one)
-                    cur.at = cur.lo;
-                    cur.ext = fmap + cur.lo;
-                    nbytes = (uint64_t)(cur.hi - cur.lo);
-                    if (rk_fastq_slot_set_source(eng.w[wi].slot[k], cur.ext) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
-                } else {
-                    cur.at = cur.lo;
-                    int64_t have = 0;
-                    while (have < cur.hi - cur.lo) {
-                        const ssize_t n = pread(fd, text + have, (size_t)(cur.hi - cur.lo - have), (off_t)(cur.lo + have));
-                        if (n <= 0) { fprintf(stderr, "rkmh: read error on %s\n", path); fail_exit(); } // (the other workers may be waiting for this block)
-                        have += n;
-                    }
-                    nbytes = (uint64_t)(cur.hi - cur.lo);
-                    if (cur.hi == fsize && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n'; // a last line without its newline (the slot holds 64 spare bytes)
+                    if (!refused && cur.hi == rk_bgzf_members(bz) && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n';
+                    if (!refused && W.device_text && rk_fastq_slot_set_source(slot, text) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
                 }
-                if (refused) {
-                    refuse(cur);
-                    t_rd += now_s() - a;
-                    continue;
+                cur.at = (int64_t)off;
+            } else if (fmap && !(cur.hi == fsize && fmap[fsize - 1] != '\n')) { // (a last block without its newline is copied, to get one)
+                cur.at = cur.lo;
+                cur.ext = fmap + cur.lo;
+                nbytes = (uint64_t)(cur.hi - cur.lo);
+                if (rk_fastq_slot_set_source(slot, cur.ext) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+            } else {
+                uint8_t* text = rk_fastq_slot_text(slot);
+                cur.at = cur.lo;
+                int64_t have = 0;
+                while (have < cur.hi - cur.lo) {
+                    const ssize_t n = pread(fd, text + have, (size_t)(cur.hi - cur.lo - have), (off_t)(cur.lo + have));
+                    if (n <= 0) { fprintf(stderr, "rkmh: read error on %s\n", path); fail_exit(); } // (the other workers may be waiting for this block)
+                    have += n;
                 }
-                if (counting) {
-                    t_rd += now_s() - a;
-                    const double b = now_s();
-                    int32_t status = 0; int64_t nrec = 0;
-                    const int crc = rk_fastq_slot_count(eng.w[wi].slot[k], nbytes, (*cnts)[eng.w[wi].dev], &status, &nrec);
-                    if (crc == RK_ERR_NEED_FULL) { g_need_full.store(true); status = 1; } // a read with more hashes than the sketch keeps: the pass ends, the caller repeats it with full tables
-                    else if (crc != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
-                    if (status != 0) {
-                        { std::lock_guard<std::mutex> l(fm); fail_at[cur.seq] = cur.at; }
-                        int64_t curf = fail_seq.load();
-                        while (cur.seq < curf && !fail_seq.compare_exchange_weak(curf, cur.seq)) {}
-                    }
-                    t_dv += now_s() - b; ++nblk; nrec_ += nrec;
-                    continue;
-                }
-                if (rk_fastq_slot_submit(eng.w[wi].slot[k], nbytes) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+                nbytes = (uint64_t)(cur.hi - cur.lo);
+                if (cur.hi == fsize && nbytes && text[nbytes - 1] != '\n') text[nbytes++] = '\n'; // a last line without its newline (the slot holds 64 spare bytes)
+            }
+            if (refused) {
+                declare_failed(cur);
+                put_empty(cur, 0);
                 t_rd += now_s() - a;
+                continue;
             }
-            if (got && !two) { finish_block(cur, eng.w[wi].slot[k]); continue; } // one block per worker at a time
-            if (have_prev) {
-                if (!prev.begun || finish_load(prev, eng.w[wi].slot[k ^ 1])) finish_block(prev, eng.w[wi].slot[k ^ 1]);
-                have_prev = false;
+            if (counting) {
+                t_rd += now_s() - a;
+                const double b = now_s();
+                int32_t status = 0; int64_t nrec = 0;
+                const int crc = rk_fastq_slot_count(slot, nbytes, (*cnts)[W.dev], &status, &nrec);
+                if (crc == RK_ERR_NEED_FULL) { g_need_full.store(true); status = 1; } // a read with more hashes than the sketch keeps: the pass ends, the caller repeats it with full tables
+                else if (crc != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+                if (status != 0) declare_failed(cur);
+                t_dv += now_s() - b; ++nblk; nrec_ += nrec;
+                continue;
             }
-            if (!got) break;
-            prev = cur; have_prev = true; k ^= 1;
+            if (rk_fastq_slot_submit(slot, nbytes) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+            t_rd += now_s() - a;
+            finish_block(cur);
         }
         std::lock_guard<std::mutex> l(tm);
         eng.t_read += t_rd; eng.t_dev += t_dv; eng.t_fmt += t_fm; eng.blocks += nblk; eng.records += nrec_;
     };
     std::vector<std::thread> workers;
     for (size_t i = 0; i < eng.w.size(); ++i) workers.emplace_back(work, i);
-    // coordinator: ranges of whole records.  The end of a range is the last record start (four-line rule, rk_fastq_cut) inside a
-    // window in front of its nominal end; a range that is cut wrongly (possible only in text that is not four lines per record) is
-    // refused by the device and the scanner takes over from its first byte.
-    if (bz) { // jobs = runs of members holding about a block of text (the records are cut by the worker, after inflating)
-        std::vector<int64_t> first((size_t)rk_bgzf_members(bz) + 2);
-        const uint64_t target = eng.block > ((uint64_t)1 << 20) ? eng.block - ((uint64_t)1 << 18) : eng.block * 3 / 4;
-        const int64_t nj = rk_bgzf_plan(bz, target, first.data(), (int64_t)first.size());
-        if (nj < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
-        for (int64_t j = 0; j < nj && fail_seq.load() == INT64_MAX; ++j) { Job jb; jb.seq = j; jb.lo = first[(size_t)j]; jb.hi = first[(size_t)j + 1]; jb.left = nj - 1 - j; jobs.push(jb); }
-        jobs.finish();
-    } else {
+    // coordinator: ranges of whole records, file after file.  The end of a range is the last record start (four-line rule,
+    // rk_fastq_cut) inside a window in front of its nominal end; a range that is cut wrongly (possible only in text that is not
+    // four lines per record) is refused by the device and the scanner takes over from its first byte.
+    int64_t seq = 0;
+    for (size_t fi = 0; fi < files.size() && fail_seq.load() == INT64_MAX; ++fi) {
+        const File& F = files[fi];
+        if (F.bz) { // jobs = runs of members holding about a block of text (the records are cut after inflating)
+            const uint64_t per_job = F.mega ? eng.mega : eng.block;
+            const uint64_t target = per_job > ((uint64_t)1 << 20) ? per_job - ((uint64_t)1 << 18) : per_job * 3 / 4;
+            std::vector<int64_t> first((size_t)rk_bgzf_members(F.bz) + 4);
+            const int64_t nj = rk_bgzf_plan(F.bz, target, first.data(), (int64_t)first.size());
+            if (nj < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+            const int64_t per = F.mega ? eng.pieces : 1;
+            for (int64_t j = 0; j < nj && fail_seq.load() == INT64_MAX; ++j) {
+                Job jb; jb.file = fi; jb.seq = seq; jb.nseq = per; jb.lo = first[(size_t)j]; jb.hi = first[(size_t)j + 1];
+                seq += per;
+                (F.mega ? jobs_mega : jobs_plain).push(jb);
+            }
+            continue;
+        }
         std::vector<uint8_t> win;
-        int64_t pos = 0, seq = 0;
-        const int64_t B = (int64_t)eng.block;
+        int64_t pos = 0;
+        const int64_t B = (int64_t)eng.block, fsize = F.fsize;
         while (pos < fsize && fail_seq.load() == INT64_MAX) {
             int64_t hi = fsize;
             if (fsize - pos > B) {
@@ -864,7 +912,7 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                     win.resize((size_t)wlen);
                     int64_t got = 0;
                     while (got < wlen) {
-                        const ssize_t n = pread(fd, win.data() + got, (size_t)(wlen - got), (off_t)(wlo + got));
+                        const ssize_t n = pread(F.fd, win.data() + got, (size_t)(wlen - got), (off_t)(wlo + got));
                         if (n <= 0) break;
                         got += n;
                     }
@@ -875,28 +923,32 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
                 }
                 if (hi < 0) { // hand the file over from here
                     std::lock_guard<std::mutex> l(fm);
-                    fail_at[seq] = pos;
+                    fail_at[seq] = std::make_pair(fi, pos);
                     if (!counting) out.lower_limit(seq);
                     int64_t cur = fail_seq.load();
                     while (seq < cur && !fail_seq.compare_exchange_weak(cur, seq)) {}
                     break;
                 }
             }
-            Job j; j.seq = seq++; j.lo = pos; j.hi = hi;
-            jobs.push(j);
+            Job j; j.file = fi; j.seq = seq++; j.lo = pos; j.hi = hi;
+            jobs_plain.push(j);
             pos = hi;
         }
-        jobs.finish();
     }
+    jobs_plain.finish();
+    jobs_mega.finish();
     for (auto& t : workers) t.join();
     if (!counting) out.finish();
     rk_line_parts_destroy(lp);
-    if (fmap) { rk_host_unregister(fmap); munmap((void*)fmap, (size_t)fsize); }
-    close(fd);
+    for (File& F : files) {
+        if (F.fmap) { rk_host_unregister(F.fmap); munmap((void*)F.fmap, (size_t)F.fsize); }
+        close(F.fd);
+    }
     if (out.failed) { fprintf(stderr, "rkmh: write error on standard output\n"); fail_exit(); }
     const int64_t fs = fail_seq.load();
     if (fs == INT64_MAX) return -1;
-    return fail_at[fs];
+    if (fail_file) *fail_file = fail_at[fs].first;
+    return fail_at[fs].second;
 }
 
 
@@ -905,29 +957,31 @@ static int64_t stream_file_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& 
 // is not four lines per record -- nothing was printed, the tables are clear again and the caller takes the parse-everything path.
 static bool two_pass_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& refs, const Opts& o, const std::vector<int64_t>& sizes,
                          std::vector<rk_counter*>& cnts, RawKind kind, double& t0, uint64_t slots) {
-    for (size_t i = 0; i < o.reads.size(); ++i)
-        if (stream_file_raw(eng, g, refs, o, o.reads[i], sizes[i], RAW_COUNT, &cnts) >= 0) {
-            if (g_need_full.exchange(false) && rk_counter_is_compact(cnts[0])) {
-                // a compact depth map cannot serve reads whose hashes exceed the sketch: the same pass again into full tables
-                if (g_timing) fprintf(stderr, "[rkmh timing] %s: reads with more hashes than the sketch keeps: pass 1 restarts with full depth tables\n", o.reads[i]);
-                make_depth_maps(g, slots, false, cnts);
-                i = (size_t)-1; // (the loop's ++i starts over at file 0)
-                continue;
-            }
-            group_run(g, [&](size_t d) { return rk_counter_clear(cnts[d]); });
-            if (g_timing) fprintf(stderr, "[rkmh timing] %s: not four lines per record: the host scanner reads the run\n", o.reads[i]);
-            return false;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        size_t ff = 0;
+        if (stream_files_raw(eng, g, refs, o, o.reads, sizes, RAW_COUNT, &cnts, &ff) < 0) break;
+        if (attempt == 0 && g_need_full.exchange(false) && rk_counter_is_compact(cnts[0])) {
+            // a compact depth map cannot serve reads whose hashes exceed the sketch: the same pass again into full tables
+            if (g_timing) fprintf(stderr, "[rkmh timing] %s: reads with more hashes than the sketch keeps: pass 1 restarts with full depth tables\n", o.reads[ff]);
+            make_depth_maps(g, slots, false, cnts);
+            continue;
         }
+        group_run(g, [&](size_t d) { return rk_counter_clear(cnts[d]); });
+        if (g_timing) fprintf(stderr, "[rkmh timing] %s: not four lines per record: the host scanner reads the run\n", o.reads[ff]);
+        return false;
+    }
     tick("pass 1 (device front end + count)", t0);
     sum_counters_on_group(g, cnts);
     share_counters_on_group(g, cnts);
     group_run(g, [&](size_t d) { return rk_set_depth_filter(g.ctx[d], cnts[d], o.min_occ); });
     tick("depth tables summed, mask built", t0);
-    for (size_t i = 0; i < o.reads.size(); ++i)
-        if (stream_file_raw(eng, g, refs, o, o.reads[i], sizes[i], kind) >= 0) {
-            fprintf(stderr, "rkmh: %s changed between the two passes\n", o.reads[i]);
+    {
+        size_t ff = 0;
+        if (stream_files_raw(eng, g, refs, o, o.reads, sizes, kind, nullptr, &ff) >= 0) {
+            fprintf(stderr, "rkmh: %s changed between the two passes\n", o.reads[ff]);
             fail_exit();
         }
+    }
     fflush(stdout);
     tick("pass 2 (device front end + classify)", t0);
     return true;
@@ -952,6 +1006,7 @@ static bool refs_through_device(RawEngine& eng, DeviceGroup& g, const Opts& o, i
         total += (uint64_t)size[i] + 1; // a '\n' after every file
     }
     if (o.refs.empty() || (!forced && total < ((uint64_t)64 << 20))) return false;
+    eng.need_plain_workers = true;
     if (!eng.create(g)) return false;
     rk_fasta_load* load = nullptr;
     if (rk_fasta_load_create(g.ctx[0], total, &load) != RK_OK) {
@@ -977,9 +1032,9 @@ static bool refs_through_device(RawEngine& eng, DeviceGroup& g, const Opts& o, i
     std::atomic<size_t> next{0};
     std::atomic<bool> failed{false};
     auto work = [&](size_t wi) {
-        if (eng.w[wi].dev != 0) return; // the text goes to the device that sketches
-        if (!eng.w[wi].slot[0] && rk_fastq_slot_create(g.ctx[0], eng.w[wi].bytes, &eng.w[wi].slot[0]) != RK_OK) return;
-        rk_fastq_slot* slot = eng.w[wi].slot[0];
+        if (eng.w[wi].dev != 0 || eng.w[wi].device_text) return; // the text goes to the device that sketches, through a page-locked text buffer
+        if (!eng.w[wi].slot && rk_fastq_slot_create(g.ctx[0], eng.w[wi].bytes, &eng.w[wi].slot) != RK_OK) return;
+        rk_fastq_slot* slot = eng.w[wi].slot;
         uint8_t* text = rk_fastq_slot_text(slot);
         for (size_t j = next.fetch_add(1); j < jobs.size() && !failed.load(); j = next.fetch_add(1)) {
             const Job& jb = jobs[j];
@@ -1168,6 +1223,7 @@ static int main_stream(int argc, char** argv) {
 
     // Which front end reads the reads: regular uncompressed FASTQ files go through the device (stream_file_raw); everything else --
     // gzip, STDIN, FASTA, -M (which needs all reads twice) -- through the kseq-grammar scanner.  RKMH_RAW=0 forces the scanner.
+    g_read_paths = &o.reads;
     std::vector<int64_t> raw_size(o.reads.size(), -1);
     bool any_raw = false, all_raw = !o.reads.empty();
     if (!(getenv("RKMH_RAW") && atoi(getenv("RKMH_RAW")) == 0))
@@ -1196,7 +1252,7 @@ static int main_stream(int argc, char** argv) {
     if (any_raw && !(getenv("RKMH_WARM_UP") && atoi(getenv("RKMH_WARM_UP")) == 0))
         warm = std::thread([&o] {
             const std::vector<int> ids = o.devices.empty() ? std::vector<int>{o.device} : o.devices;
-            for (int id : ids) rk_warm_up(id, !g_bgzf.empty() && bgzf_device_mode() != 0);
+            for (int id : ids) rk_warm_up(id, !g_bgzf.empty() && bgzf_on_device());
         });
     rk_seqset refs;
     memset(&refs, 0, sizeof refs);
@@ -1282,11 +1338,17 @@ static int main_stream(int argc, char** argv) {
         else {
             const bool eng_ok = eng.create(group);
             tick("device front end", t0);
-            for (size_t i = 0; i < o.reads.size(); ++i) {
+            for (size_t i = 0; i < o.reads.size();) {
                 int64_t resume = 0;
-                if (eng_ok && raw_size[i] >= 0) {
-                    resume = stream_file_raw(eng, group, refs, o, o.reads[i], raw_size[i]);
-                    if (resume < 0) continue;
+                if (eng_ok && raw_size[i] >= 0) { // the run of files from here on that the device front end reads, as one pipeline
+                    size_t j = i;
+                    while (j < o.reads.size() && raw_size[j] >= 0) ++j;
+                    const std::vector<const char*> run(o.reads.begin() + (long)i, o.reads.begin() + (long)j);
+                    const std::vector<int64_t> sizes(raw_size.begin() + (long)i, raw_size.begin() + (long)j);
+                    size_t ff = 0;
+                    resume = stream_files_raw(eng, group, refs, o, run, sizes, RAW_STREAM, nullptr, &ff);
+                    if (resume < 0) { i = j; continue; }
+                    i += ff; // (the files in front of the refused block are done)
                     fflush(stdout);
                     if (g_timing) fprintf(stderr, "[rkmh timing] %s: not four lines per record at byte %lld: the scanner reads on from there\n", o.reads[i], (long long)resume);
                 }
@@ -1294,6 +1356,7 @@ static int main_stream(int argc, char** argv) {
                 q1.cap = 4;
                 std::thread p1 = start_scanner(q1, {{o.reads[i], (uint64_t)resume}});
                 run_scanner_pipeline(group, refs, o, q1, p1);
+                ++i;
             }
             if (g_timing) fprintf(stderr, "[rkmh timing] device front end: %lld blocks, %lld records; read %.3f s, upload + index + classify %.3f s, format %.3f s (summed over %zu workers)\n",
                                   (long long)eng.blocks, (long long)eng.records, eng.t_read, eng.t_dev, eng.t_fmt, eng.w.size());
@@ -1361,6 +1424,13 @@ static int main_filter(int argc, char** argv) {
         o.ks.push_back(16);
     }
     if (o.refs.empty()) { fprintf(stderr, "rkmh: at least one -r reference file is required\n"); exit(1); }
+    // Regular uncompressed FASTQ files and BGZF files go through the device front end (stream_file_raw / two_pass_raw): the host neither
+    // parses the reads nor holds them.  RKMH_RAW=0, plain gzip, FASTA and text that is not four lines per record take the parse-everything
+    // path.  (Looked at before the engine is made: it is laid out for the kinds of read files there are.)
+    g_read_paths = &o.reads;
+    std::vector<int64_t> raw_size(o.reads.size(), -1);
+    bool all_raw = !o.reads.empty() && !(getenv("RKMH_RAW") && atoi(getenv("RKMH_RAW")) == 0);
+    for (size_t i = 0; all_raw && i < o.reads.size(); ++i) all_raw = raw_eligible(o.reads[i], &raw_size[i]);
     double t0 = now_s();
     DeviceGroup group;
     group.create(o);
@@ -1421,11 +1491,6 @@ static int main_filter(int argc, char** argv) {
         fwrite(buf.data(), 1, buf.size(), stdout);
         buf.clear();
     };
-    // Regular uncompressed FASTQ files go through the device front end (stream_file_raw / two_pass_raw): the host neither parses
-    // the reads nor holds them.  RKMH_RAW=0, gzip, FASTA and text that is not four lines per record take the parse-everything path.
-    std::vector<int64_t> raw_size(o.reads.size(), -1);
-    bool all_raw = !o.reads.empty() && !(getenv("RKMH_RAW") && atoi(getenv("RKMH_RAW")) == 0);
-    for (size_t i = 0; all_raw && i < o.reads.size(); ++i) all_raw = raw_eligible(o.reads[i], &raw_size[i]);
     bool files_done = o.reads.empty();
     if (all_raw) {
         if (eng.create(group)) {
@@ -1435,8 +1500,12 @@ static int main_filter(int argc, char** argv) {
             }
             else {
                 for (size_t i = 0; i < o.reads.size(); ++i) {
-                    const int64_t resume = stream_file_raw(eng, group, refs, o, o.reads[i], raw_size[i], RAW_FILTER);
-                    if (resume < 0) continue;
+                    const std::vector<const char*> run(o.reads.begin() + (long)i, o.reads.end());
+                    const std::vector<int64_t> sizes(raw_size.begin() + (long)i, raw_size.end());
+                    size_t ff = 0;
+                    const int64_t resume = stream_files_raw(eng, group, refs, o, run, sizes, RAW_FILTER, nullptr, &ff);
+                    if (resume < 0) break;
+                    i += ff; // (the files in front of the refused block are done; this one goes on through the scanner)
                     fflush(stdout);
                     // the rest of this file through the kseq-grammar scanner, batch by batch
                     if (g_timing) fprintf(stderr, "[rkmh timing] %s: not four lines per record at byte %lld: the scanner reads on from there\n", o.reads[i], (long long)resume);

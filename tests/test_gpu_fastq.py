@@ -427,7 +427,7 @@ def test_ranks_read_their_own_byte_range(root, data_dir, tmp_path):
     assert ranks(3, st + ["-f", str(bg), "-f", str(fq), "-M", "2"], {"RKMH_RAW_BLOCK_KB": "128"}) == one(st + ["-f", str(fq), "-f", str(fq), "-M", "2"])
     assert ranks(2, fl + ["-f", str(bg)], {"RKMH_RAW_BLOCK_KB": "512"}) == wf
     assert ranks(2, st + ["-f", str(bg)], {"RKMH_BGZF": "0"}) == want                # left to zlib: whole parse on every rank
-    assert ranks(2, st + ["-f", str(bg), "-M", "2"], {"RKMH_BGZF_DEVICE": "1", "RKMH_RAW_BLOCK_KB": "200"}) == one(st + ["-f", str(fq), "-M", "2"])   # inflated on the device
+    assert ranks(2, st + ["-f", str(bg), "-M", "2"], {"RKMH_BGZF_DEVICE": "1", "RKMH_RAW_BLOCK_KB": "200"}) == one(st + ["-f", str(fq), "-M", "2"])   # inflated on the device (rkmh_amd.cli: opt-in, block-sized jobs)
     # rank 0 alone reads the references (here forced through the device: rk_fasta_load_*), the others get names and sketches
     plain_ref = tmp_path / "pave.fa"
     plain_ref.write_bytes(gzip.open(ref).read())
@@ -484,12 +484,14 @@ def test_cli_bgzf_input_goes_through_the_device_front_end(root, data_dir, tmp_pa
         base = [cmd, "-r", ref, "-k", "16", "-s", "1000"] + flags
         want = _cli(root, base + ["-f", str(fq)])
         assert len(want) > 1000
-        # (RKMH_BGZF_DEVICE=1: the members inflated on the device, rk_inflate.hip -- same bytes)
-        for member, level, env in ((0xff00, 1, {}), (300, 6, {"RKMH_RAW_BLOCK_KB": "40"}), (20000, 6, {"RKMH_RAW_BLOCK_KB": "128", "RKMH_RAW_WORKERS": "3"}),
-                                   (0xff00, 1, {"RKMH_BGZF_DEVICE": "1", "RKMH_RAW_BLOCK_KB": "2048"}), (20000, 6, {"RKMH_BGZF_DEVICE": "1", "RKMH_RAW_BLOCK_KB": "300"}),
-                                   # (2: some workers feed the device runs of planned jobs, the others inflate theirs)
-                                   (0xff00, 1, {"RKMH_BGZF_DEVICE": "2", "RKMH_RAW_BLOCK_KB": "512", "RKMH_BGZF_DEVICE_WORKERS": "3", "RKMH_BGZF_DEVICE_MERGE": "3"}),
-                                   (20000, 6, {"RKMH_BGZF_DEVICE": "2", "RKMH_RAW_BLOCK_KB": "200", "RKMH_RAW_WORKERS": "2"})):
+        # (the default: the members inflated on the device, rk_inflate.hip, a third of the file per job, the text never on the host;
+        # RKMH_BGZF_DEVICE=0: by the workers, libdeflate / zlib -- same bytes)
+        for member, level, env in ((0xff00, 1, {"RKMH_BGZF_DEVICE": "0"}), (300, 6, {"RKMH_BGZF_DEVICE": "0", "RKMH_RAW_BLOCK_KB": "40"}),
+                                   (20000, 6, {"RKMH_BGZF_DEVICE": "0", "RKMH_RAW_BLOCK_KB": "128", "RKMH_RAW_WORKERS": "3"}),
+                                   (0xff00, 1, {}), (20000, 6, {"RKMH_BGZF_JOB_KB": "300"}),
+                                   # (several output pieces per job, formatted by the helper threads; one device worker; many small jobs)
+                                   (0xff00, 1, {"RKMH_BGZF_JOB_KB": "2048", "RKMH_BGZF_PIECES": "5"}),
+                                   (20000, 6, {"RKMH_BGZF_JOB_KB": "200", "RKMH_BGZF_DEVICE_WORKERS": "1", "RKMH_BGZF_PIECES": "2"})):
             if cmd == "filter" and member == 300:
                 continue
             gz = tmp_path / ("reads_%d.fq.gz" % member)
@@ -509,8 +511,8 @@ def test_cli_bgzf_input_goes_through_the_device_front_end(root, data_dir, tmp_pa
     plain_gz.write_bytes(gzip.compress(text, 1))
     assert _cli(root, base + ["-f", str(nonl), "-f", str(fq), "-f", str(plain_gz)], env={"RKMH_RAW_BLOCK_KB": "700"}) == want * 3
     # several files, runs of jobs taken by the device's workers while the others inflate (the run leaves the queue in one step)
-    for mode, extra in (("1", {}), ("2", {"RKMH_RAW_WORKERS": "5"}), ("2", {"RKMH_BGZF_DEVICE_MERGE": "7", "RKMH_BGZF_DEVICE_WORKERS": "2"}),
-                        (None, {"RKMH_BGZF_DEVICE_MIN_MB": "1"})):      # (unset: the device from a size on -- here from 1 MB)
+    for mode, extra in ((None, {}), (None, {"RKMH_BGZF_JOB_KB": "500", "RKMH_BGZF_PIECES": "4"}), (None, {"RKMH_BGZF_JOB_KB": "150", "RKMH_BGZF_DEVICE_WORKERS": "2"}),
+                        (None, {"RKMH_BGZF_REGISTER": "0"})):      # (the last one: the compressed bytes uploaded from the unpinned mapping)
         for rep in range(2):
             env = dict({"RKMH_RAW_BLOCK_KB": "150"}, **extra)
             if mode is not None:
@@ -530,9 +532,9 @@ def test_cli_bgzf_input_goes_through_the_device_front_end(root, data_dir, tmp_pa
     r = subprocess.run([exe] + base + ["-f", str(mixed_gz)], capture_output=True, env=dict(os.environ, RKMH_TIMING="1", RKMH_RAW_BLOCK_KB="256"))
     assert r.returncode == 0 and r.stdout == want_mixed
     assert b"not four lines per record" in r.stderr
-    for mode in ("1", "2"):     # (the hand-over happens at the first block number of a merged job)
-        r = subprocess.run([exe] + base + ["-f", str(mixed_gz)], capture_output=True, env=dict(os.environ, RKMH_TIMING="1", RKMH_RAW_BLOCK_KB="256", RKMH_BGZF_DEVICE=mode))
-        assert r.returncode == 0 and r.stdout == want_mixed, mode
+    for env in ({"RKMH_BGZF_DEVICE": "0"}, {"RKMH_BGZF_JOB_KB": "256", "RKMH_BGZF_PIECES": "3"}):     # (the hand-over happens at the first block number of a job)
+        r = subprocess.run([exe] + base + ["-f", str(mixed_gz)], capture_output=True, env=dict(os.environ, RKMH_TIMING="1", RKMH_RAW_BLOCK_KB="256", **env))
+        assert r.returncode == 0 and r.stdout == want_mixed, env
         assert b"not four lines per record" in r.stderr
 
 
@@ -559,3 +561,40 @@ def test_cli_reads_from_a_registered_file_mapping(root, data_dir, tmp_path):
             assert _cli(root, base + ["-f", str(fq)], env=env) == want, (cmd, flags, env)
         two = base + ["-f", str(nonl), "-f", str(fq)]      # (-M counts over both files: compare the same command with and without the mapping)
         assert _cli(root, two, env={"RKMH_RAW_MMAP": "1", "RKMH_RAW_BLOCK_KB": "512"}) == _cli(root, two, env={"RKMH_RAW_BLOCK_KB": "512"})
+
+
+def test_cli_bgzf_payload_damage_is_refused_on_both_routes(root, data_dir, tmp_path):
+    """A member whose payload was changed WITHOUT changing its length or the four-line shape of the text (a base of a stored block
+    replaced by another base: every structural check still passes) fails its CRC-32: the device route (k_crc32_members) hands the
+    job to the host inflater, which reports the member; the host route (RKMH_BGZF_DEVICE=0) reports it itself.  Either way the run
+    ends with an error instead of classifying the changed read -- what gzread does for the reference (src/rkmh.cpp:238-263)."""
+    from rkmh_amd import api, synth
+    refs = api.parse_files([os.path.join(data_dir, "all_pave_ref.fa.gz")])
+    n = 6000
+    qb, qo = synth.generate_reads_fast(refs["bases"], refs["offsets"], 0, n, read_len=150, threads=4)
+    reads = [bytes(qb[int(qo[i]):int(qo[i + 1])]) for i in range(n)]
+    text = _fastq(reads, names=[b"d%06d" % i for i in range(n)])
+    ref = os.path.join(data_dir, "all_pave_ref.fa.gz")
+    exe = os.path.join(root, "bin", "rkmh")
+    base = ["stream", "-r", ref, "-k", "16", "-s", "1000"]
+    for level in (0, 1):
+        img = bytearray(synth.bgzf_compress(text, level=level, block=0xff00))
+        good = tmp_path / ("good%d.fq.gz" % level)
+        good.write_bytes(bytes(img))
+        want = _cli(root, base + ["-f", str(good)])
+        assert want.count(b"\n") == n
+        if level == 0:      # stored blocks: the text lies in the file as it is -- change one base of a read in the second member
+            at = bytes(img).find(reads[300][20:60])
+            assert at > 70000
+            img[at + 7] = ord("A") if img[at + 7] != ord("A") else ord("C")
+        else:               # deflated: flip one bit of the CRC-32 in a footer (the text is intact, the member is not)
+            import struct
+            bsize = struct.unpack_from("<H", img, 16)[0] + 1
+            img[bsize - 8] ^= 0x10
+        bad = tmp_path / ("bad%d.fq.gz" % level)
+        bad.write_bytes(bytes(img))
+        for env in ({}, {"RKMH_BGZF_DEVICE": "0"}, {"RKMH_BGZF_JOB_KB": "200"}):
+            r = subprocess.run([exe] + base + ["-f", str(bad)], capture_output=True, env=dict(os.environ, **env))
+            assert r.returncode != 0, (level, env)
+            assert b"corrupt BGZF member" in r.stderr, (level, env, r.stderr[-400:])
+            assert r.stdout != want

@@ -156,13 +156,54 @@ def test_device_inflate_refuses_damaged_members(gctx, tmp_path):
             if zb is None:
                 continue
             st, n, _ = slot.load_bgzf(zb, 0, zb.members)
-            if st == 0:                                 # the flip left a valid stream of the right length: the text differs or not
-                res = slot.classify_raw(n)
-                if bytes(slot.text_buffer()[:n]) != text and res.status == 0:
-                    pass                                # (possible in principle: CRC-32 is the host route's business)
+            if st == 0:                                 # accepted: then the text is the original's (k_crc32_members checked every member;
+                slot.classify_raw(n)                    # a flip in a header field nobody reads leaves the members intact)
+                assert bytes(slot.text_buffer()[:n]) == text, trial
             else:
                 refused += 1
             zb.close()
-        assert refused >= 6
+        assert refused >= 8
     finally:
         slot.destroy()
+
+
+def test_device_text_slot_brings_back_names_and_filtered_records_only(gctx, tmp_path):
+    """RK_SLOT_DEVICE_TEXT: the job's text stays in HBM; finish() returns the rows and the NAMES packed on the device (stream's
+    lines are written from them) or, after set_filter_output, the records filter prints -- byte-identical to what an ordinary slot,
+    which brings the whole text back, gives the same formatters.  Jobs of one member to the whole file; a pack larger than the
+    slot's page-locked buffer (filter that keeps everything)."""
+    from rkmh_amd import api, synth
+    rng = np.random.default_rng(11)
+    text = _fastq(rng, 7000)
+    path = tmp_path / "d.fq.gz"
+    path.write_bytes(synth.bgzf_compress(text, level=1, block=0xff00))
+    z = api.Bgzf.open(str(path))
+    cap = 4 << 20
+    plain, dev, devf = api.FastqSlot(gctx, max_bytes=cap), api.FastqSlot(gctx, max_bytes=cap, device_text=True), api.FastqSlot(gctx, max_bytes=cap, device_text=True)
+    parts = api.LineParts([b"ref%d" % i for i in range(int(gctx._lib.rk_num_references(gctx._h)))], 1000, 2, 1)
+    try:
+        for mm, md in ((-1, -100), (3, 0)):         # (-1, -100): every read passes -- the packed records outgrow max_bytes / 8
+            devf.set_filter_output(mm, md)
+            for target in (1, 300000, 1 << 30):
+                first = z.plan(target)[:40]
+                for b0, b1 in zip(first, first[1:]):
+                    st, n, off = plain.load_bgzf(z, b0, b1)
+                    assert st == 0
+                    res = plain.classify_raw(n)
+                    want_lines, want_recs = (plain.stream_lines(parts, res), plain.filter_records(res, mm, md)) if res.nrec else (b"", b"")
+                    for slot in (dev, devf):
+                        st2, n2, off2 = slot.load_bgzf(z, b0, b1)
+                        assert (st2, n2, off2) == (0, n, off)
+                        r2 = slot.classify_raw(n2)
+                        assert r2.status == 0 and r2.nrec == res.nrec
+                        if r2.nrec == 0:
+                            continue
+                        if slot is dev:
+                            assert slot.stream_lines(parts, r2) == want_lines, (target, b0, b1)
+                        else:
+                            assert slot.filter_records(r2, mm, md) == want_recs, (mm, md, target, b0, b1)
+            assert len(want_recs) > 0 if mm < 0 else True
+    finally:
+        for sl in (plain, dev, devf):
+            sl.destroy()
+        z.close()

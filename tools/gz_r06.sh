@@ -1,0 +1,64 @@
+#!/bin/bash
+# Usage (GPU box): [N=8000000] bash tools/gz_r06.sh [tag] -- ONE BGZF file of N reads (and the same text plain) through bin/rkmh stream: one file
+# and four, plain text / device inflate (two root-table forms) / host inflate: wall, marginal reads/s of the three extra files, the
+# [bgzf device] job lines, then a rocprofv3 kernel trace of the four-file device run.  Output: gpurun_out/<tag>_gz.txt, <tag>_gz_kernel_stats.csv
+cd ${GRAFT_REPO_ROOT:-.}
+N=${N:-8000000}
+TAG=${1:-r06}
+OUT=gpurun_out/${TAG}_gz.txt
+mkdir -p gpurun_out
+python3 - <<PY
+import os, sys, numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+from rkmh_amd import api, synth
+refs = api.parse_files(["tests/golden/data/all_pave_ref.fa.gz"])
+rb, ro = refs["bases"], refs["offsets"]
+n, L = $N, 150
+with open("/tmp/big.fq.gz", "wb") as fb, open("/tmp/big.fq", "wb") as fp:
+    for lo in range(0, n, 1000000):
+        m = min(1000000, n - lo)
+        qb, _ = synth.generate_reads_fast(rb, ro, lo, lo + m, read_len=L, threads=16)
+        rec = np.empty((m, 11 + L + 3 + L + 1), dtype=np.uint8)
+        rec[:, 0] = ord("@"); rec[:, 1] = ord("r"); rec[:, 11 + L] = 10; rec[:, 10] = 10
+        idx = np.arange(lo, lo + m, dtype=np.int64)
+        for d in range(9):
+            rec[:, 9 - d] = 48 + (idx // 10 ** d) % 10
+        rec[:, 11:11 + L] = qb[: m * L].reshape(m, L)
+        rec[:, 12 + L] = ord("+"); rec[:, 13 + L] = 10
+        rec[:, 14 + L:14 + 2 * L] = np.random.default_rng(lo).integers(35, 75, size=(m, L), dtype=np.uint8); rec[:, 14 + 2 * L] = 10
+        raw = rec.tobytes()
+        fp.write(raw)
+        img = synth.bgzf_compress(raw, level=1, threads=16)
+        fb.write(img[:-28] if lo + m < n else img)
+PY
+ls -la /tmp/big.fq.gz /tmp/big.fq > $OUT
+R="-r tests/golden/data/all_pave_ref.fa.gz -k 16"
+want=$(bin/rkmh stream $R -f /tmp/big.fq 2>/dev/null | sha256sum | cut -c1-16)
+run() { # label file env...
+  local label=$1 f=$2; shift 2
+  local t1 t4
+  for rep in 1 2; do
+    S=$(date +%s.%N); env "$@" RKMH_TIMING=1 timeout -s ABRT 300 bin/rkmh stream $R -f $f > /tmp/big.out 2>/tmp/big.err1 || { echo "$label failed" >> $OUT; tail -3 /tmp/big.err1 >> $OUT; return; }; E=$(date +%s.%N)
+    t1=$(python3 -c "print($E - $S)")
+  done
+  got=$(sha256sum /tmp/big.out | cut -c1-16)
+  for rep in 1 2; do
+    S=$(date +%s.%N); env "$@" RKMH_TIMING=1 RKMH_BGZF_TIMING=1 timeout -s ABRT 300 bin/rkmh stream $R -f $f -f $f -f $f -f $f > /tmp/big.out 2>/tmp/big.err4 || { echo "$label x4 failed" >> $OUT; tail -3 /tmp/big.err4 >> $OUT; return; }; E=$(date +%s.%N)
+    t4=$(python3 -c "print($E - $S)")
+  done
+  python3 -c "print('%-44s 1 file %.3f s, 4 files %.3f s: marginal %.1f M reads/s; output %s' % ('$label', $t1, $t4, 3 * $N / ($t4 - $t1) / 1e6, 'identical to plain' if '$got' == '$want' else 'DIFFERS'))" >> $OUT
+  grep -E "main loop|references|device front end:" /tmp/big.err4 | tr -s " " | sed 's/^/      /' >> $OUT
+  grep "bgzf device" /tmp/big.err4 | head -4 | sed 's/^/      /' >> $OUT
+}
+run "plain text" /tmp/big.fq X=1
+run "BGZF, device inflate (default)" /tmp/big.fq.gz X=1
+run "BGZF, device inflate, 9/7-bit roots" /tmp/big.fq.gz RKMH_INFLATE_ROOT=9
+run "BGZF, device inflate, 2 workers" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=2
+run "BGZF, device inflate, 4 workers" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=4
+run "BGZF, device inflate, 256 MB jobs" /tmp/big.fq.gz RKMH_BGZF_JOB_KB=262144
+run "BGZF, host inflate" /tmp/big.fq.gz RKMH_BGZF_DEVICE=0
+cat $OUT
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/pgz && RKMH_SLOW_EXIT=1 rocprofv3 --kernel-trace --stats -d /tmp/pgz -o p --output-format csv -- $GRAFT_REPO_ROOT/bin/rkmh stream -r $GRAFT_REPO_ROOT/tests/golden/data/all_pave_ref.fa.gz -k 16 -f /tmp/big.fq.gz -f /tmp/big.fq.gz -f /tmp/big.fq.gz -f /tmp/big.fq.gz > /dev/null 2> /tmp/pgz.err
+f=$(find /tmp/pgz -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp $f $GRAFT_REPO_ROOT/gpurun_out/${TAG}_gz_kernel_stats.csv && cut -c1-150 $f | head -12
