@@ -265,16 +265,6 @@ __device__ __forceinline__ uint64_t canonical_packed64(uint64_t v, int k, uint32
 typedef uint32_t rk_u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed)) rk_unaligned16 { rk_u32x4 v; };
 __device__ __forceinline__ rk_u32x4 lds_load16_unaligned(const uint32_t* w32, uint32_t byte_off) {
-#ifdef RK_HACK_ALIGNED_WINDOWS // timing experiment only (wrong hashes): what do the unaligned LDS reads cost?
-    rk_u32x4 hv = reinterpret_cast<const rk_unaligned16*>(reinterpret_cast<const uint8_t*>(w32) + (byte_off & ~15u))->v;
-    hv.x ^= byte_off * 0x9E3779B1u;
-    return hv;
-#endif
-#ifdef RK_HACK_RANDOM_WINDOWS // companion experiment: unaligned reads, same hash perturbation
-    rk_u32x4 hv = reinterpret_cast<const rk_unaligned16*>(reinterpret_cast<const uint8_t*>(w32) + byte_off)->v;
-    hv.x ^= byte_off * 0x9E3779B1u;
-    return hv;
-#endif
     return reinterpret_cast<const rk_unaligned16*>(reinterpret_cast<const uint8_t*>(w32) + byte_off)->v;
 }
 template <int KT, int FOLD = -1>
@@ -598,6 +588,7 @@ struct RefIndex {
     // eight BASE lists stored as (base, exceptions); kbase = [8 x (start, members)] then the members
     const uint32_t* kpost;
     const uint32_t* kbase;
+    uint32_t kbase_n;     // base lists in use (0: no list of this index is stored as (base, exceptions))
     const uint2* kkeys;   // wide k-mers (k = 17 .. 20, kpk says which): km1 then holds km2 buckets, see KW_C above
     const uint32_t* kslots;
     // -M with a bounded min_num (rk_set_min_num_bound): bit (key id) set <=> the key's slot of the depth map passes the threshold

@@ -316,7 +316,7 @@ int build_index(rk_ctx* c) {
     clk.tick("index + prefilter uploaded");
     std::vector<uint32_t> kpost, kbase;
     std::unordered_map<uint32_t, KList> kremap;
-    c->ix.kpost = nullptr; c->ix.kbase = nullptr; c->ix.kkeys = nullptr; c->ix.kslots = nullptr;
+    c->ix.kpost = nullptr; c->ix.kbase = nullptr; c->ix.kbase_n = 0; c->ix.kkeys = nullptr; c->ix.kslots = nullptr;
     if (all_k_ok) {
         build_kpost(post, R, kpost, kbase, kremap);
         if (kpost.size() >= 0x3fffffffull) all_k_ok = false;
@@ -326,6 +326,7 @@ int build_index(rk_ctx* c) {
             HIPCHK(hipMemcpy(c->d_kpost.p, kpost.data(), kpost.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(c->d_kbase.p, kbase.data(), kbase.size() * 4, hipMemcpyHostToDevice));
             c->ix.kpost = c->d_kpost.as<uint32_t>(); c->ix.kbase = c->d_kbase.as<uint32_t>();
+            for (int b = 0; b < KBASE_MAX; ++b) c->ix.kbase_n += kbase[2 * (size_t)b + 1] != 0u ? 1u : 0u;
         }
     }
     clk.tick("posting lists (kpost)");

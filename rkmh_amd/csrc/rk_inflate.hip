@@ -103,7 +103,7 @@ __device__ __forceinline__ void load_lens(const LDS& L, int t, int at, int n, in
     }
 }
 template <int TB, int NCH>
-__device__ bool coop_build(const uint32_t (&l)[NCH], int t, uint16_t* tab, uint16_t* sorted, int cap, uint32_t* walk, int lane, bool is_codes) {
+__device__ bool coop_build(const uint32_t (&l)[NCH], int t, uint16_t* tab, uint16_t* sorted, int cap, uint32_t* walk, int lane, bool is_codes, bool may_be_incomplete = false) {
     uint32_t code_of[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) code_of[c] = 0;
@@ -135,7 +135,7 @@ __device__ bool coop_build(const uint32_t (&l)[NCH], int t, uint16_t* tab, uint1
         }
         code = (code + n_len) << 1;
     }
-    if (left > 0 && maxlen != 0u && (is_codes || maxlen != 1u)) ok = false;
+    if (left > 0 && maxlen != 0u && (is_codes || maxlen != 1u) && !may_be_incomplete) ok = false;
     isync(); // (the invalid fill is in the table before the entries)
     if (ok) {
 #pragma unroll
@@ -391,7 +391,8 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
                 load_lens<1>(L, t, nl, nd, lane, ld);
                 isync(); // (every length is in a register before the sorted list takes their rows)
                 ok = coop_build<LT, 5>(ll, t, L.lit, L.lsort, LONG_CAP, L.lwalk, lane, false);
-                ok = coop_build<DT, 1>(ld, t, L.dist, L.dsort, DLONG_CAP, L.dwalk, lane, false) && ok;
+                // (the fixed distance code, 30 codes of 5 bits, is incomplete by definition: RFC 1951 3.2.6)
+                ok = coop_build<DT, 1>(ld, t, L.dist, L.dsort, DLONG_CAP, L.dwalk, lane, false, kind == 3u) && ok;
             }
             if (lane == t) {
                 need_build = 0;
@@ -471,13 +472,35 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
     if (live) { status[m] = bad; status[nmem + m] = bad ? 0u : ent_w | (lit_n << 15); } // (at most 22 106 entries, 65 536 literals)
 }
 
-// Pass 2: the member's text built in a 64 KB LDS window from its literal stream and its entries, 64 entries at a time.
-// (Two variants were measured and dropped, profiles/r05_gz.txt: the literals staged at the end of the window first -- twice the time,
-// the extra LDS passes cost more than the loads they save --, and the dependent matches copied in rounds by their own lanes -- no gain.)
+// Pass 2: the member's text built in a 64 KB LDS window from its literal stream and its entries.
+// Round 5's form took one batch of 64 entries at a time straight from global memory -- entries, then (their place known) literals: two
+// dependent round trips per batch, ~5 us each, with two waves per CU to hide them: 1 ms per member, as long as pass 1.  Now the
+// inputs come in bulk: 1 024 entries and 4 KB of the literal stream are staged in LDS together (one round trip per ~5 KB of text,
+// every load in flight at once); a batch then works on LDS alone:
+//   * one packed prefix sum (DPP) places every literal run and match of the batch;
+//   * a lane copies its own run (the first 8 bytes; longer runs are finished by the whole wave, one after the other);
+//   * matches resolve in ROUNDS behind a frontier: F = the first unresolved match -- everything below its start is final, so every
+//     match whose source ends there (and F itself, whose source may overlap its own output) is copied now, a lane each, long ones
+//     (>= 24 bytes, runs of one repeated byte above all) by the whole wave.  Three quarters of the matches of level-1 FASTQ go in
+//     the first round.
+// The window is addressed like the text (window byte k <-> address of the text - its low four bits + k), so it leaves through
+// aligned 16-byte LDS reads and global stores.
+constexpr int P2_SB = 1024;   // entries staged at a time
+constexpr int P2_LIT = 4096;  // literal bytes staged at a time (+ 4: the stage begins at a dword boundary)
+__device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1 (a lane without a source adds 0)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return v;
+}
 __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __restrict__ mem, uint32_t nmem, uint8_t* __restrict__ text, const uint32_t* __restrict__ scratch,
                                                       const uint32_t* __restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint8_t win[WIN_BYTES];
-    __shared__ uint32_t s_r[IW], s_d[IW];
+    __shared__ __attribute__((aligned(16))) uint8_t win[WIN_BYTES + 16];
+    __shared__ uint32_t s_ent[P2_SB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_lit[P2_LIT / 4 + 4];
     const int lane = threadIdx.x;
     const uint32_t m = blockIdx.x;
     if (m >= nmem || status[m] != 0u) return;
@@ -485,64 +508,104 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __res
     const InflateMember me = mem[m];
     const uint32_t n = me.out_len;
     const uint32_t* const ents = scratch + me.match_off;
-    const uint8_t* const lits = reinterpret_cast<const uint8_t*>(ents + entry_cap(n));
+    const uint32_t* const lits32 = ents + entry_cap(n);
+    const uint8_t* const lits8 = reinterpret_cast<const uint8_t*>(lits32);
     uint8_t* const dst = text + me.out_off;
+    const uint32_t wb = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u); // window index of the text's first byte
+    uint8_t* const w = win + wb;
+    const uint8_t* const sl8 = reinterpret_cast<const uint8_t*>(s_lit);
     uint32_t op0 = 0, lp0 = 0;
-    for (uint32_t q0 = 0; q0 < nent; q0 += IW) {
-        const uint32_t e = q0 + (uint32_t)lane < nent ? ents[q0 + (uint32_t)lane] : 0u;
-        const uint32_t run = e & 255u, len = (e >> 8) & 511u, dist = (e >> 17) + 1u;
-        uint32_t r = run, t = run + len; // inclusive prefix sums over the lanes
+    uint32_t lit_base = 0, lit_have = 0; // s_lit holds the literal bytes [lit_base, lit_base + lit_have)
+    constexpr uint32_t LIT_DW = P2_LIT / 4 + 1, LIT_K = (LIT_DW + IW - 1) / IW;
+    for (uint32_t e0 = 0; e0 < nent; e0 += P2_SB) {
+        const uint32_t ne = nent - e0 < (uint32_t)P2_SB ? nent - e0 : (uint32_t)P2_SB;
+        { // stage: the entries of this stretch and the literal stream from where it stands -- all loads first, then the stores
+            uint32_t ev[P2_SB / IW], lv[LIT_K];
+            lit_base = lp0 & ~3u;
+            const uint32_t lit_dw_end = (nlit + 3u) >> 2; // dwords pass 1 wrote
 #pragma unroll
-        for (int d = 1; d < IW; d <<= 1) {
-            const uint32_t ur = (uint32_t)__shfl_up((int)r, d), ut = (uint32_t)__shfl_up((int)t, d);
-            if (lane >= d) { r += ur; t += ut; }
-        }
-        const uint32_t tot_r = (uint32_t)__builtin_amdgcn_readlane((int)r, IW - 1), tot_t = (uint32_t)__builtin_amdgcn_readlane((int)t, IW - 1);
-        if (op0 + tot_t > n || lp0 + tot_r > nlit) return; // (pass 1 checked every entry against out_len: unreachable for its output)
-        const uint32_t at = op0 + t - len; // where this lane's match begins; its run ends there
-        s_r[lane] = r;
-        s_d[lane] = at - r; // literal i of the batch (r_prev <= i < r) goes to s_d + i
-        isync();
-        for (uint32_t i = (uint32_t)lane; i < tot_r; i += IW) {
-            uint32_t j = 0; // the first lane whose inclusive sum exceeds i
+            for (int k = 0; k < P2_SB / IW; ++k) { const uint32_t i = (uint32_t)lane + IW * k; ev[k] = i < ne ? ents[e0 + i] : 0u; }
 #pragma unroll
-            for (int s = IW / 2; s; s >>= 1) if (s_r[j + s - 1] <= i) j += s;
-            win[s_d[j] + i] = lits[lp0 + i];
+            for (uint32_t k = 0; k < LIT_K; ++k) { const uint32_t i = (uint32_t)lane + IW * k, d = (lit_base >> 2) + i; lv[k] = (i < LIT_DW && d < lit_dw_end) ? lits32[d] : 0u; }
+            isync(); // (the previous stretch's last batch has read its literals)
+#pragma unroll
+            for (int k = 0; k < P2_SB / IW; ++k) s_ent[lane + IW * k] = ev[k];
+#pragma unroll
+            for (uint32_t k = 0; k < LIT_K; ++k) { const uint32_t i = (uint32_t)lane + IW * k; if (i < LIT_DW) s_lit[i] = lv[k]; }
+            lit_have = nlit - lit_base < LIT_DW * 4u ? nlit - lit_base : LIT_DW * 4u;
+            isync();
         }
-        isync();
-        // matches whose source ends at or before the batch's first byte depend on nothing in the batch: one lane each
-        const bool indep = len != 0u && at - dist + len <= op0;
-        if (indep) for (uint32_t i = 0; i < len; ++i) win[at + i] = win[at - dist + i];
-        isync();
-        for (uint64_t todo = __ballot(len != 0u && !indep); todo; todo &= todo - 1ull) {
-            const int j = __builtin_ctzll(todo);
-            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)at, j), ln = (uint32_t)__builtin_amdgcn_readlane((int)len, j),
-                           ds = (uint32_t)__builtin_amdgcn_readlane((int)dist, j);
-            if (ds >= ln || ds >= (uint32_t)IW) {
-                for (uint32_t i0 = 0; i0 < ln; i0 += IW) { // (distance >= 64: a step's 64 source bytes were all written before it)
-                    const uint32_t i = i0 + (uint32_t)lane;
-                    uint8_t v = 0;
-                    if (i < ln) v = win[o - ds + i];
+        for (uint32_t q0 = 0; q0 < ne; q0 += IW) {
+            const uint32_t e = q0 + (uint32_t)lane < ne ? s_ent[q0 + lane] : 0u;
+            const uint32_t run = e & 255u, len = (e >> 8) & 511u, dist = (e >> 17) + 1u;
+            // inclusive sums over the lanes, both in one word: literals (< 2^14) | literals + match bytes (< 2^16) << 16
+            const uint32_t sc = wave_incl_scan_add(run | ((run + len) << 16));
+            const uint32_t r = sc & 0xFFFFu, t = sc >> 16;
+            const uint32_t tot_r = (uint32_t)__builtin_amdgcn_readlane((int)r, IW - 1), tot_t = (uint32_t)__builtin_amdgcn_readlane((int)t, IW - 1);
+            if (op0 + tot_t > n || lp0 + tot_r > nlit) return; // (pass 1 checked every entry against out_len: unreachable for its output)
+            const uint32_t at = op0 + t - len;     // where this lane's match begins; its run ends there
+            const uint32_t lsrc = lp0 + r - run;   // its run's first byte in the literal stream
+            // the batch's literals: from the stage, which moves up when the batch reaches past it (a batch with more literals than
+            // the stage holds -- an all-literal stretch -- reads them from global memory where they lie)
+            bool direct = false;
+            if (lp0 + tot_r > lit_base + lit_have) { // wave-uniform
+                if (tot_r + 3u <= (uint32_t)P2_LIT) {
+                    uint32_t lv[LIT_K];
+                    lit_base = lp0 & ~3u;
+                    const uint32_t lit_dw_end = (nlit + 3u) >> 2;
+#pragma unroll
+                    for (uint32_t k = 0; k < LIT_K; ++k) { const uint32_t i = (uint32_t)lane + IW * k, d = (lit_base >> 2) + i; lv[k] = (i < LIT_DW && d < lit_dw_end) ? lits32[d] : 0u; }
                     isync();
-                    if (i < ln) win[o + i] = v;
+#pragma unroll
+                    for (uint32_t k = 0; k < LIT_K; ++k) { const uint32_t i = (uint32_t)lane + IW * k; if (i < LIT_DW) s_lit[i] = lv[k]; }
+                    lit_have = nlit - lit_base < LIT_DW * 4u ? nlit - lit_base : LIT_DW * 4u;
                     isync();
+                } else direct = true;
+            }
+            auto lit = [&](uint32_t idx) -> uint8_t { return direct ? lits8[idx] : sl8[idx - lit_base]; };
+            // literal runs: the first 8 bytes by the run's own lane ...
+            {
+                const uint32_t o = at - run;
+#pragma unroll
+                for (uint32_t b = 0; b < 8u; ++b) if (b < run) w[o + b] = lit(lsrc + b);
+            }
+            // ... the rest of a longer run by the whole wave
+            for (uint64_t lm = __ballot(run > 8u); lm; lm &= lm - 1ull) {
+                const int j = __builtin_ctzll(lm);
+                const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)run, j), oj = (uint32_t)__builtin_amdgcn_readlane((int)at, j) - rj,
+                               sj = (uint32_t)__builtin_amdgcn_readlane((int)lsrc, j);
+                for (uint32_t i = 8u + (uint32_t)lane; i < rj; i += IW) w[oj + i] = lit(sj + i);
+            }
+            isync();
+            // matches, in rounds behind the frontier
+            for (uint64_t um = __ballot(len != 0u); um;) {
+                const int F = __builtin_ctzll(um);
+                const uint32_t atF = (uint32_t)__builtin_amdgcn_readlane((int)at, F);
+                const bool mine = ((um >> lane) & 1ull) != 0ull && (at - dist + len <= atF || lane == F);
+                for (uint64_t lm = __ballot(mine && len >= 24u); lm; lm &= lm - 1ull) { // long: 64 lanes per copy; a source that overlaps its output repeats with period dist
+                    const int j = __builtin_ctzll(lm);
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)at, j), ln = (uint32_t)__builtin_amdgcn_readlane((int)len, j),
+                                   ds = (uint32_t)__builtin_amdgcn_readlane((int)dist, j);
+                    if (ds >= ln) { for (uint32_t i = (uint32_t)lane; i < ln; i += IW) w[o + i] = w[o - ds + i]; }
+                    else { for (uint32_t i = (uint32_t)lane; i < ln; i += IW) w[o + i] = w[o - ds + i % ds]; }
                 }
-            } else { // the source overlaps the destination: it repeats with period ds
-                for (uint32_t i = (uint32_t)lane; i < ln; i += IW) win[o + i] = win[o - ds + i % ds];
+                const bool sh = mine && len < 24u; // short: a lane each, byte after byte (its own earlier bytes may be its source)
+                for (uint32_t i = 0; __ballot(sh && i < len) != 0ull; ++i) if (sh && i < len) w[at + i] = w[at - dist + i];
+                um &= ~__ballot(mine);
                 isync();
             }
+            op0 += tot_t; lp0 += tot_r;
         }
-        op0 += tot_t; lp0 += tot_r;
     }
     isync();
-    const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u) < n ? (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u) : n;
-    const uint32_t nd = (n - head) >> 2, done = head + 4u * nd;
-    if ((uint32_t)lane < head) dst[lane] = win[lane];
-    for (uint32_t i = (uint32_t)lane; i < nd; i += IW) {
-        const uint32_t o = head + 4u * i;
-        *reinterpret_cast<uint32_t*>(dst + o) = (uint32_t)win[o] | ((uint32_t)win[o + 1] << 8) | ((uint32_t)win[o + 2] << 16) | ((uint32_t)win[o + 3] << 24);
-    }
-    if ((uint32_t)lane < n - done) dst[done + lane] = win[done + lane];
+    // the window leaves: whole aligned 16-byte pieces, single bytes at the two ends
+    uint8_t* const a0 = dst - wb;
+    const uint32_t endk = wb + n, c0 = wb ? 1u : 0u, c1 = endk >> 4;
+    for (uint32_t c = c0 + (uint32_t)lane; c < c1; c += IW) *reinterpret_cast<uint4*>(a0 + 16u * c) = *reinterpret_cast<const uint4*>(win + 16u * c);
+    const uint32_t hb = 16u * c0 < endk ? 16u * c0 : endk;           // head bytes [wb, hb)
+    const uint32_t tb = 16u * c1 > hb ? 16u * c1 : hb;               // tail bytes [tb, endk)
+    if (wb + (uint32_t)lane < hb) a0[wb + lane] = win[wb + lane];
+    if (tb + (uint32_t)lane < endk) a0[tb + lane] = win[tb + lane];
 }
 
 // The members' CRC-32 (gzread checks it for every member the reference reads, /root/reference/src/rkmh.cpp:238-263): one wave per

@@ -29,9 +29,13 @@
 
 #include <fcntl.h>
 #include <sched.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
+
+#include <cerrno>
 
 #include <chrono>
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -43,10 +47,28 @@ static void tick(const char* what, double& t0) {
     t0 = t;
 }
 
+// The command returns when its OUTPUT is complete, not when the kernel has finished taking the process apart.  After _exit the
+// driver still unpins every page-locked buffer, unmaps the queues and frees the device memory of the process -- 0.2 to 0.7 s that grew
+// with the run (profiles/r05_c3_e2e.txt: "the process leaving"), as much as the main loop of a 64 M-read run.  So main() forks before
+// anything touches the GPU: the child does the work, and once every byte is written it closes its output descriptors, tells the parent
+// its exit status through a pipe and leaves; the parent -- which holds no GPU state at all -- exits with that status at once, and the
+// child's teardown runs on behind it.  A child that dies any other way is waited for and its status passed on.  Not under a
+// profiler or RKMH_SLOW_EXIT=1 (the orderly way out), nor with RKMH_FORK=0.
+static int g_done_fd = -1; // (child) write end of the status pipe
+static void tell_parent(int status) {
+    if (g_done_fd < 0) return;
+    fflush(stdout); fflush(stderr);
+    close(1); close(2); // a reader of our pipes sees their end now, not when the teardown is over
+    const unsigned char b = (unsigned char)status;
+    if (write(g_done_fd, &b, 1) != 1) {}
+    close(g_done_fd);
+    g_done_fd = -1;
+}
 // Leaving after an error: flush what there is and go, WITHOUT running static destructors -- a parser or worker thread may still be
 // running, and the HIP runtime's exit handlers are not something to run under it.
 [[noreturn]] static void fail_exit() {
     fflush(stdout); fflush(stderr);
+    tell_parent(1);
     _exit(1);
 }
 static void die(const char* what) {
@@ -61,6 +83,7 @@ static const double g_loaded_s = now_s(); // (static initialisation: the program
     fflush(stderr);
     if (bad) fprintf(stderr, "rkmh: write error on standard output\n");
     if (getenv("RKMH_SLOW_EXIT")) exit(bad ? 1 : 0); // profilers (rocprofv3) write their tables from an exit handler
+    tell_parent(bad ? 1 : 0);
     _exit(bad ? 1 : 0); // skips the HIP runtime's and the loader's exit handlers (~0.1-0.2 s of a 1 s run)
 }
 #define CK(call) do { if ((call) != RK_OK) die(#call); } while (0)
@@ -2184,8 +2207,36 @@ static int main_hpv16(int argc, char** argv) {
 }
 
 
+static pid_t g_child = -1;
+static void forward_signal(int sig) { if (g_child > 0) kill(g_child, sig); }
+// see tell_parent: the parent's side.  Returns in the child (and in a process that does not fork); the parent never returns.
+static void fork_for_fast_exit() {
+    const char* pre = getenv("LD_PRELOAD");
+    if (getenv("RKMH_SLOW_EXIT") || (getenv("RKMH_FORK") && atoi(getenv("RKMH_FORK")) == 0) || (pre && *pre)) return;
+    int fds[2];
+    if (pipe(fds) != 0) return;
+    fflush(stdout); fflush(stderr);
+    const pid_t pid = fork();
+    if (pid < 0) { close(fds[0]); close(fds[1]); return; }
+    if (pid == 0) { close(fds[0]); g_done_fd = fds[1]; return; }
+    close(fds[1]);
+    g_child = pid;
+    for (int sig : {SIGINT, SIGTERM, SIGHUP, SIGQUIT, SIGABRT, SIGPIPE}) signal(sig, forward_signal); // (timeout(1), ^C: they mean the worker)
+    close(0); // (the child reads standard input, if anyone does)
+    unsigned char b = 0;
+    ssize_t n;
+    while ((n = read(fds[0], &b, 1)) < 0 && errno == EINTR) {}
+    if (n == 1) _exit((int)b); // the output is complete: the child finishes dying on its own
+    int st = 0;
+    while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}
+    if (WIFEXITED(st)) _exit(WEXITSTATUS(st));
+    if (WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); _exit(128 + WTERMSIG(st)); }
+    _exit(1);
+}
+
 int main(int argc, char** argv) {
     if (argc <= 1) { print_help(); exit(1); }
+    fork_for_fast_exit();
     // The device front end's workers have a stream each; the runtime maps streams onto four hardware queues unless told otherwise,
     // and kernels of two streams on one queue run one after the other -- the long inflate kernels of BGZF jobs above all
     // (profiles/r05_gz.txt: 2.4 of 8 launches overlapped, 4.2 with 16 queues).  Read by the runtime when it starts: set before any HIP call.

@@ -1,3 +1,8 @@
+// tools/ubench/rk_kmer_ablation.hip -- LAB COPY of rkmh_amd/csrc/rk_kmer.hip as of round 5, kept for its timing experiments: the
+// RK_KMER_ABL switches (every one of them gives WRONG results: they remove or fake a part of the kernel to see what it costs) and
+// the RK_KMER_NT / _DR / _CH / _QSTEP / _WAVES knobs.  NOT built by the Makefile and not part of the product; the numbers it
+// produced are in profiles/r03_ablation.txt, r04_variants*.txt and docs/history/.  To rerun an experiment: copy it over
+// rkmh_amd/csrc/rk_kmer.hip in a scratch tree and build with EXTRA_HIPFLAGS="-DRK_KMER_ABL=<bits> -DRK_KMER_FAST_BUILD".
 // rk_kmer.hip -- the k-mer-space form of the fused per-read kernel (gfx950, wave64): the shipped hot loop for a single k from 8 to 16.
 //
 // Replaces the body of main_stream's read loop, /root/reference/src/rkmh.cpp:856-888
@@ -32,12 +37,28 @@ namespace {
 constexpr int KW = 64;
 constexpr int KM_MAX_T = 8;          // reads per tile (phase 2 takes eight reads in one pass; the group -> read search is unrolled for it)
 constexpr int KM_MQ = 32;            // deferred multi-posting hits (a full list is worked off at once: 16 lanes per hit)
-// (the timing experiments this kernel was shaped by -- parts switched off, loads faked -- live in tools/ubench/rk_kmer_ablation.hip, not here)
-constexpr int KM_CH = 2;             // steps (64 groups = 256 windows each) whose filter sectors are requested together
+#ifndef RK_KMER_ABL
+#define RK_KMER_ABL 0 // timing experiments with WRONG results (-DRK_KMER_ABL=<bits> -DRK_KMER_FAST_BUILD builds): 1 no test/push, 2 no apply, 4 no drain, 8 no phase 2, 16 no second probe of the map, 32 no compound values, 64 offsets computed from a fixed read length, 128 filter sectors of lane pairs in one line, 256 map look-ups from a 4 KB corner of the map (L1 hits), 512 no hit multiset (every occurrence has rank 0), 1024 hits with a posting list dropped, 2048 two of three lanes' filter sectors in one 32-byte piece
+#endif
+#ifndef RK_KMER_NT
+#define RK_KMER_NT 1 // the bases are read once: streaming loads keep them from evicting the filter and the map from L2
+#endif
+#ifndef RK_KMER_DR
+#define RK_KMER_DR 2 // drain rounds whose map lookups are in flight together
+#endif
+#ifndef RK_KMER_CH
+#define RK_KMER_CH 2
+#endif
+constexpr int KM_CH = RK_KMER_CH;     // steps (64 groups = 256 windows each) whose filter sectors are requested together
 constexpr int KM_QCAP = 64 + 4 * KW; // candidate queue entries (4 bytes each): a step adds at most 256 to a remainder of < 64
+#ifndef RK_KMER_QSTEP
+#define RK_KMER_QSTEP 1 // a last step of at most 16 groups runs a quarter wide (four lanes per group, one window each)
+#endif
 constexpr int KM_LDS_SMALL = 5120;   // static LDS of the common instantiation: 32 single-wave workgroups per CU (8 per SIMD)
 constexpr int KM_LDS_BIG = 20480;    // ... of the one for large hit multisets / counter rows (8 per CU)
-constexpr int KM_WAVES = 8;
+#ifndef RK_KMER_WAVES
+#define RK_KMER_WAVES 8
+#endif
 
 // per-read reference counters: packed 8-bit (no read has more than 255 windows), packed 16-bit, or a 128-entry map ref -> count
 enum { CM_DENSE8 = 0, CM_DENSE16 = 1, CM_SPARSE = 2 };
@@ -124,11 +145,8 @@ __device__ __forceinline__ uint32_t km_nonzero4(uint32_t m) {
     return ((y >> 7) * 0x01020408u) >> 24;
 }
 
-// FAM: the index holds posting lists stored as (base, exceptions) (genome families, build_kpost).  A panel without them -- BASELINE
-// config 2's -- runs the instantiation that carries none of their state: no per-read base counters, no test for such values, no
-// expansion in phase 2.
-template <int KT, int NQ, int CMODE, bool BIG, bool FAM>
-__global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
+template <int KT, int NQ, int CMODE, bool BIG>
+__global__ __launch_bounds__(KW, BIG ? 2 : RK_KMER_WAVES) void k_classify_kmer(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ offs,
                                                                               uint32_t nreads, int S, RefIndex ix, KmerSets ksets,
                                                                               int32_t* __restrict__ out4, DevPolicy pol, KmerGeom geo) {
     // KT = 0: several k-mer sizes (ksets.k[], each from 8 to 16), one pass over the tile's windows per size
@@ -170,6 +188,10 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
     auto load_offsets = [&](uint32_t tl, uint32_t& a_, uint32_t& b_, uint32_t& o_) {
         const uint32_t r = tl * (uint32_t)T;
         const int n = tile_reads(tl);
+        if (RK_KMER_ABL & 64) { // timing experiment: reads of exactly geo.L bases starting at offset 0 -- no dependent offset load
+            a_ = r * (uint32_t)geo.L; b_ = (r + (uint32_t)n) * (uint32_t)geo.L; o_ = (r + (uint32_t)(lane <= n ? lane : n)) * (uint32_t)geo.L;
+            return;
+        }
         a_ = offs[r];
         b_ = offs[r + (uint32_t)n];
         o_ = offs[r + (uint32_t)(lane <= n ? lane : n)];
@@ -193,7 +215,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
                 const uintptr_t qa = base16 + 16u * (uintptr_t)qi;
                 if (safe) { // through a global-address-space pointer: the integer round trip would otherwise make it a flat load
                     typedef const u32x4 __attribute__((address_space(1))) * gq_t;
-                    v = __builtin_nontemporal_load((gq_t)qa); // the bases are read once: streaming loads keep them from evicting the filter and the map from L2
+                    v = RK_KMER_NT ? __builtin_nontemporal_load((gq_t)qa) : *(gq_t)qa;
                 }
                 else {
                     uint32_t d[4];
@@ -246,10 +268,9 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
 #pragma unroll
             for (int j = 0; j < NKC; ++j) if (j < NK) nw_all += (uint32_t)num_windows((int)len, WIDE ? (int)ix.kpk : (KT ? KT : ksets.k[j]), pol.drop_last_window);
         }
-        if constexpr (FAM) { if (lane < 4 * KM_MAX_T) fam[lane] = 0; }
+        if (lane < 4 * KM_MAX_T) fam[lane] = 0;
         if (lane < KM_MAX_T) {
-            nzero[lane] = 0; best[lane] = 0; nwtot[lane] = nw_all;
-            if constexpr (FAM) famf[lane] = 0;
+            nzero[lane] = 0; best[lane] = 0; nwtot[lane] = nw_all; famf[lane] = 0;
             // more windows than a packed counter can count (only possible when the caller's length hint was too small)
             flags[lane] = nw_all > (CMODE == CM_SPARSE ? 0x7FFu : cmask) ? 1u : 0u;
         }
@@ -358,7 +379,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
             // (Also tried and rejected: the four rows of a step -- often four hits of one read with one list -- starting at different
             // chunks of the list, so that they do not add to the same counter words in the same instruction: 1.08 -> 1.14 ms.)
             auto walk = [&](uint32_t tr, const uint32_t* lp, uint32_t hdr, const km_pair4& pm0) {
-                const uint32_t t = tr & 0xFFu, n = hdr & 0xFFFFFFu, base = FAM ? hdr >> 24 : 0u;
+                const uint32_t t = tr & 0xFFu, n = hdr & 0xFFFFFFu, base = hdr >> 24;
                 if (base) {
                     // a list stored as (base, exceptions) (build_kpost; every member holds the hash once, so only a k-mer's first
                     // occurrence counts): one more hit on the base -- expanded once per read in phase 2 -- and +1 / -1 for the few
@@ -451,7 +472,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
             c.key = x < r ? x : r;
             c.key_hi = 0;
             c.y = km1_y(c.key, k);
-            c.c = km1p[c.y >> km_r];
+            c.c = km1p[(RK_KMER_ABL & 256) ? ((c.y >> km_r) & 255u) : (c.y >> km_r)];
             return c;
         };
         // the cell of the bucket whose tag equals the one in wantsh (all ones: none)
@@ -486,14 +507,14 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
             }
             uint32_t val = vid | (1u << 20); // a single posting of multiplicity 1, in the RefIndex::kv value format
             uint32_t valy = 0, valz = 0, valw = 0;
-            if (hit && vid >= nref && !zero) { // compound value, four dwords (a few KB: L1-resident)
+            if (!(RK_KMER_ABL & 32) && hit && vid >= nref && !zero) { // compound value, four dwords (a few KB: L1-resident)
                 const uint4 vv = *reinterpret_cast<const uint4*>(km1v + 4u * (vid - nref));
                 val = vv.x; valy = vv.y; valz = vv.z; valw = vv.w;
                 if constexpr (CMODE == CM_SPARSE) { if ((val >> 29) == 7u) val = 0x80000000u | valz; } // (base, exceptions): the sparse counters cannot subtract
             }
             uint32_t rank = 0;
             bool multi = false;
-            if (hit) {
+            if ((RK_KMER_ABL & 2) ? (val == 0x12345u) : hit) {
                 if (zero) atomicAdd(&nzero[c.t], 1u); // a k-mer whose canonical hash is 0
                 else {
                     // hit MULTISET of the read: the canonical k-mer (+1: never 0xFFFFFFFF) is the key's identity, every occurrence
@@ -503,7 +524,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
                     uint32_t* ds = dset + c.t * DS;
                     const uint32_t id = (WIDE ? wres.z : c.key) + 1u; // (wide: the key's number in kkeys)
                     uint32_t idx = ((id - 1u) * 0x9E3779B1u) >> ds_shift;
-                    uint32_t old = atomicCAS(&ds[idx], 0u, id);
+                    uint32_t old = (RK_KMER_ABL & 512) ? 0u : atomicCAS(&ds[idx], 0u, id);
                     uint32_t probes = 1;
                     while (old != 0u && probes < DS) { // the wave leaves this loop when its last lane has found a free slot
                         rank += old == id ? 1u : 0u;
@@ -512,7 +533,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
                         ++probes;
                     }
                     if (old != 0u) flags[c.t] = 1; // more hits than the set holds: general path
-                    else if (FAM && (val >> 29) == 7u) { // a list within eight exceptions of a base list (build_kpost): one more hit on the base, +-1 for the exceptions
+                    else if ((val >> 29) == 7u) { // a list within eight exceptions of a base list (build_kpost): one more hit on the base, +-1 for the exceptions
                         if (rank == 0) {
                             const uint32_t base = (val >> 26) & 7u, nex = (val >> 22) & 15u, crow_b = __umul24(c.t, CW * 4u);
                             atomicAdd(&fam[4u * c.t + (base >> 1)], 1u << (16u * (base & 1u)));
@@ -548,7 +569,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
                             add_posting(c.t, crow_b, val & (two ? 0x7FFu : 0xFFFFFu));
                             if (two) add_posting(c.t, crow_b, (val >> 11) & 0x7FFu);
                         }
-                    } else multi = true;
+                    } else multi = !(RK_KMER_ABL & 1024);
                 }
             }
             // hits with a posting list are deferred to the end of the drain (16 lanes then walk each list); when the list of deferred
@@ -596,7 +617,8 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
                 if (two) first_match(b, cb, gb);
                 // the searches that go on (about one lookup in ten, once) are continued for both rounds together: one more memory
                 // round trip per hop for the tile, not per round; the wave leaves when its last lane is done
-                for (uint32_t hop = 1; hop < (1u << KM1_HB) && __ballot(ga || gb); ++hop) { next_match(a, hop, ca, ga); next_match(b, hop, cb, gb); }
+                if (!(RK_KMER_ABL & 16))
+                    for (uint32_t hop = 1; hop < (1u << KM1_HB) && __ballot(ga || gb); ++hop) { next_match(a, hop, ca, ga); next_match(b, hop, cb, gb); }
                 apply(a, ca);
                 if (two) apply(b, cb);
             }
@@ -607,7 +629,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
         const uint32_t nsteps = (NG + KW - 1) / KW;
         // a last step of 1 .. 16 groups runs a QUARTER wide: four lanes per group, one window (and one dword of the sector) each --
         // a fourth of the window tests for the step that would otherwise run 64 lanes for a dozen groups (six 150-base reads: 204 groups)
-        const bool qlast = !WIDE && NG != 0u && ((NG - 1u) & (uint32_t)(KW - 1)) < 16u;
+        const bool qlast = RK_KMER_QSTEP && !WIDE && NG != 0u && ((NG - 1u) & (uint32_t)(KW - 1)) < 16u;
         const uint32_t kf4_n16 = kf4_n << 4; // (sector count < 2^28: checked where the filter is built)
         uint32_t qcount = 0;
         uint32_t step = 0;
@@ -643,7 +665,18 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
                 uint32_t core = k == 16 ? wl[s] >> 6 : (wl[s] >> 6) & CMASK; // k = 16: the 13-mer is all of bits 6..31
                 if constexpr (WIDE) core = kw_fold((join64(wl[s], wh[s]) >> 6) & CMASK64); // the (k - 3)-mer, up to 34 bits, folded to 32
                 // byte offset of the sector: 16 * (hashed core scaled to [0, kf4_n)) = the high product with 16 kf4_n, less its low four bits
-                const uint32_t sect_b = __umulhi(core * 0x85EBCA6Bu, kf4_n16) & ~15u;
+                uint32_t sect_b = __umulhi(core * 0x85EBCA6Bu, kf4_n16) & ~15u;
+                if (RK_KMER_ABL & 128) { // timing experiment (WRONG results): an odd lane reads the other half of its even neighbour's 32 bytes --
+                    // what halving the filter's L2 requests would buy before anything is built for it
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sect_b, 0x111, 0xf, 0xf, true); // row_shr:1
+                    if (lane & 1) sect_b = (nb & ~31u) | 16u; else sect_b &= ~31u;
+                }
+                if (RK_KMER_ABL & 2048) { // timing experiment (WRONG results): two of every three lanes share 32 bytes -- the filter requests of
+                    // six-window groups (22.5 per read instead of 34) at today's instruction count
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sect_b, 0x111, 0xf, 0xf, true); // row_shr:1
+                    const uint32_t l3 = (uint32_t)lane % 3u;
+                    if (l3 == 2u) sect_b = (nb & ~31u) | 16u; else if (l3 == 1u) sect_b &= ~31u;
+                }
                 e0v[s] = P0 | (t << 12);
                 fq[s] = 0u;
                 fw[s] = u32x4{0u, 0u, 0u, 0u}; // (defined on both paths: left undefined, the compiler reuses a register still in flight and waits)
@@ -701,7 +734,8 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
                     if (qcount + 4u * KW > (uint32_t)KM_QCAP) stop = true;
                     else {
                         ++done;
-                        if (isqv[s]) { // wave-uniform
+                        if (RK_KMER_ABL & 1) { if (wl[s] == 0x12345u && fw[s].x == 77u) q[qcount++] = e0v[s]; }
+                        else if (isqv[s]) { // wave-uniform
                             if (has_invalid) test_step(s, std::true_type{}, std::integral_constant<int, 1>{});
                             else test_step(s, std::false_type{}, std::integral_constant<int, 1>{});
                         } else if (has_invalid) test_step(s, std::true_type{}, std::integral_constant<int, 4>{});
@@ -713,7 +747,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
             const bool last = step >= nsteps;
             wave_sync();
             const uint32_t qn = last ? qcount : (qcount & ~(uint32_t)(KW - 1)); // mid-tile: whole waves of candidates only
-            drain(qn);
+            if (!(RK_KMER_ABL & 4)) drain(qn);
             wave_sync();
             if (last) break;
             const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
@@ -732,7 +766,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
         {
             const int lsh = Tn > 4 ? 3 : 4, LPR = 1 << lsh; // wave-uniform
             const int g = lane >> lsh, sl = lane & (LPR - 1);
-            for (int t = g; t < Tn; t += KW >> lsh) {
+            for (int t = g; t < ((RK_KMER_ABL & 8) ? 0 : Tn); t += KW >> lsh) {
                 uint32_t* ct = cnt + (uint32_t)t * CW;
                 const int nmins = (int)nwtot[t] - (int)nzero[t];
                 // bottom-S selection matters, or the hit multiset overflowed: exact answer comes from the general path
@@ -742,7 +776,7 @@ __global__ __launch_bounds__(KW, BIG ? 2 : KM_WAVES) void k_classify_kmer(const 
                     if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = make_int4(-2, 0, 0, 0);
                     continue;
                 }
-                if constexpr (FAM && CMODE != CM_SPARSE) {
+                if constexpr (CMODE != CM_SPARSE) {
                     if (famf[t]) { // hits on (base, exceptions) lists: each touched base is expanded into the counters ONCE, then the
                         // maximum and its first reference come from a scan of the row (the running best saw partial counts)
                         for (uint32_t b = 0; b < 8u; ++b) {
@@ -849,15 +883,14 @@ bool make_kmer_geom(KmerGeom& g, int maxlen, int nref, int expect_hits, int win_
 }
 
 template <int KT>
-hipError_t launch_k(int nq, int cmode, bool big, bool fam, dim3 grid, hipStream_t st, const uint8_t* bases, const uint32_t* offs, uint32_t nreads,
+hipError_t launch_k(int nq, int cmode, bool big, dim3 grid, hipStream_t st, const uint8_t* bases, const uint32_t* offs, uint32_t nreads,
                     int S, const RefIndex& ix, const KmerSets& ksets, int32_t* out4, const DevPolicy& pol, const KmerGeom& geo) {
-#define RK_KM_GO(NQ, CM, BIG, FAM) hipLaunchKernelGGL((k_classify_kmer<KT, NQ, CM, BIG, FAM>), grid, dim3(KW), 0, st, bases, offs, nreads, S, ix, ksets, out4, pol, geo)
-    // (the sparse counters cannot subtract: they walk the plain form of every list and never see a (base, exceptions) value)
+#define RK_KM_GO(NQ, CM, BIG) hipLaunchKernelGGL((k_classify_kmer<KT, NQ, CM, BIG>), grid, dim3(KW), 0, st, bases, offs, nreads, S, ix, ksets, out4, pol, geo)
 #define RK_KM_CM(NQ, BIG)                                                                                    \
     do {                                                                                                     \
-        if (cmode == CM_DENSE8) { if (fam) RK_KM_GO(NQ, CM_DENSE8, BIG, true); else RK_KM_GO(NQ, CM_DENSE8, BIG, false); } \
-        else if (cmode == CM_DENSE16) { if (fam) RK_KM_GO(NQ, CM_DENSE16, BIG, true); else RK_KM_GO(NQ, CM_DENSE16, BIG, false); } \
-        else RK_KM_GO(NQ, CM_SPARSE, BIG, true);                                                             \
+        if (cmode == CM_DENSE8) RK_KM_GO(NQ, CM_DENSE8, BIG);                                                \
+        else if (cmode == CM_DENSE16) RK_KM_GO(NQ, CM_DENSE16, BIG);                                         \
+        else RK_KM_GO(NQ, CM_SPARSE, BIG);                                                                   \
     } while (0)
     if (nq == 1 && !big) RK_KM_CM(1, false);
     else if (nq == 1) RK_KM_CM(1, true);
@@ -891,15 +924,17 @@ hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint
     if (xcd_env >= 0) geo.xcd = xcd_env != 0;
     geo.nmin_cap = nmin_cap;
     const uint32_t ntiles = (nreads + (uint32_t)geo.T - 1) / (uint32_t)geo.T;
-    const bool fam = ix.kbase_n != 0u; // lists stored as (base, exceptions) exist
     uint32_t grid = ntiles;
     grid = (grid + 7u) & ~7u; // whole rounds of the 8 XCDs: the virtual ids then cover [0, grid) exactly
-    if (ksets.n > 1) return launch_k<0>(nq, cmode, big, fam, dim3(grid), st, bases, offs, nreads, S, ix, ksets, out4, pol, geo);
-#define RK_KM_K(KT) case KT: return launch_k<KT>(nq, cmode, big, fam, dim3(grid), st, bases, offs, nreads, S, ix, ksets, out4, pol, geo)
+    if (ksets.n > 1) return launch_k<0>(nq, cmode, big, dim3(grid), st, bases, offs, nreads, S, ix, ksets, out4, pol, geo);
+#define RK_KM_K(KT) case KT: return launch_k<KT>(nq, cmode, big, dim3(grid), st, bases, offs, nreads, S, ix, ksets, out4, pol, geo)
     switch (ksets.k[0]) {
-        RK_KM_K(8); RK_KM_K(9); RK_KM_K(10); RK_KM_K(11); RK_KM_K(12); RK_KM_K(13); RK_KM_K(14); RK_KM_K(15); RK_KM_K(16);
+#ifndef RK_KMER_FAST_BUILD // timing experiments compile the k = 16 kernels only
+        RK_KM_K(8); RK_KM_K(9); RK_KM_K(10); RK_KM_K(11); RK_KM_K(12); RK_KM_K(13); RK_KM_K(14); RK_KM_K(15);
+#endif
+        RK_KM_K(16);
         case 17: case 18: case 19: case 20: // wide k-mers: one run-time-k instantiation (KT = 32)
-            return ix.kkeys ? launch_k<32>(nq, cmode, big, fam, dim3(grid), st, bases, offs, nreads, S, ix, ksets, out4, pol, geo) : hipErrorInvalidValue;
+            return ix.kkeys ? launch_k<32>(nq, cmode, big, dim3(grid), st, bases, offs, nreads, S, ix, ksets, out4, pol, geo) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 #undef RK_KM_K
