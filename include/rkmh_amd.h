@@ -212,7 +212,8 @@ int rk_set_kmer_form(rk_ctx* ctx, int enable);
 /* The k-mer-space form rests on an enumeration of the whole 4^k k-mer universe (every k-mer whose canonical hash is an index key:
  * 26 ms at k = 16 on MI355X, 4 x per further base) -- a function of the index keys, k, fold and seed alone.  With a cache file set,
  * the NEXT rk_set_references / rk_set_reference_sketches loads the lists from it when its tag (a hash of exactly those inputs)
- * matches and skips the enumeration; otherwise it enumerates and (re)writes the file.  A stale or foreign file is never used.
+ * matches and skips the enumeration; otherwise it enumerates -- k = 19 and 20 (1.7 s, 6.7 s) included, which without a cache file
+ * are left to the hash-space kernel -- and (re)writes the file.  A stale or foreign file is never used.
  * path NULL or "": no cache.  rk_kmer_cache_state: of the last index build -- 0 none, 1 loaded, 2 enumerated and written, 3
  * enumerated (the file could not be written). */
 int rk_set_kmer_cache(rk_ctx* ctx, const char* path);

@@ -307,7 +307,7 @@ int build_index(rk_ctx* c) {
     const size_t kmer_max_keys = kmer_max_keys_env >= 0 ? (size_t)kmer_max_keys_env : 6000000;
     bool all_k_ok = kmer_mode > 0 && c->kmer_form_allowed && c->ks.n >= 1 && c->ks.n <= KM_MAX_KS && distinct <= kmer_max_keys;
     // one k of 17 .. 20 (wide k-mers, 64-bit): the 4^k enumeration takes 0.1 s (k = 17), 0.4 s (18), 1.7 s (19), 6.7 s (20) -- done unasked
-    // up to RKMH_KMER_ENUM_MAXK (default 18); beyond that only when the cache file (rk_set_kmer_cache) already holds the list
+    // up to RKMH_KMER_ENUM_MAXK (default 18); beyond that only with a cache file (rk_set_kmer_cache): from it, or -- once -- into it
     const int enum_maxk = getenv("RKMH_KMER_ENUM_MAXK") ? atoi(getenv("RKMH_KMER_ENUM_MAXK")) : 18; // (read per build: a few per process)
     const bool wide_k = c->ks.n == 1 && c->ks.k[0] > 16 && c->ks.k[0] <= KW_MAX_K;
     for (int j = 0; j < c->ks.n; ++j) all_k_ok = all_k_ok && c->ks.k[j] >= KPRE_MIN_K && (c->ks.k[j] <= 16 || wide_k);
@@ -338,7 +338,7 @@ int build_index(rk_ctx* c) {
         kcache_tag = kmer_cache_tag(c, dense, nkeys);
         if (kmer_cache_read(c->kmer_cache_path, kcache_tag, kcache)) c->kmer_cache_state = 1;
     }
-    if (all_k_ok && wide_k && c->ks.k[0] > enum_maxk && kcache.find(c->ks.k[0]) == kcache.end()) all_k_ok = false; // too long to do unasked
+    if (all_k_ok && wide_k && c->ks.k[0] > enum_maxk && kcache.find(c->ks.k[0]) == kcache.end() && c->kmer_cache_path.empty()) all_k_ok = false; // too long to do for one run
     std::vector<uint8_t> seen(all_k_ok ? nkeys + 1 : 0, 0); // across the sizes: a key found by two k-mers of ANY sizes disables the form
     int built = 0;
     for (int kidx = 0; all_k_ok && kidx < c->ks.n; ++kidx) {

@@ -485,6 +485,7 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
 //     the first round.
 // The window is addressed like the text (window byte k <-> address of the text - its low four bits + k), so it leaves through
 // aligned 16-byte LDS reads and global stores.
+struct __attribute__((packed, aligned(1))) lds_u64 { uint64_t v; }; // eight bytes at any LDS address (gfx950 runs with unaligned DS access)
 constexpr int P2_SB = 1024;   // entries staged at a time
 constexpr int P2_LIT = 4096;  // literal bytes staged at a time (+ 4: the stage begins at a dword boundary)
 __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
@@ -563,11 +564,17 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __res
                 } else direct = true;
             }
             auto lit = [&](uint32_t idx) -> uint8_t { return direct ? lits8[idx] : sl8[idx - lit_base]; };
-            // literal runs: the first 8 bytes by the run's own lane ...
+            // literal runs: the first 8 bytes by the run's own lane (one 8-byte read of the stage, byte stores that wait for nothing) ...
             {
                 const uint32_t o = at - run;
+                if (direct) {
 #pragma unroll
-                for (uint32_t b = 0; b < 8u; ++b) if (b < run) w[o + b] = lit(lsrc + b);
+                    for (uint32_t b = 0; b < 8u; ++b) if (b < run) w[o + b] = lits8[lsrc + b];
+                } else {
+                    const uint64_t v = reinterpret_cast<const lds_u64*>(sl8 + (lsrc - lit_base))->v; // (the stage is followed by 12 spare bytes)
+#pragma unroll
+                    for (uint32_t b = 0; b < 8u; ++b) if (b < run) w[o + b] = (uint8_t)(v >> (8u * b));
+                }
             }
             // ... the rest of a longer run by the whole wave
             for (uint64_t lm = __ballot(run > 8u); lm; lm &= lm - 1ull) {
@@ -589,8 +596,25 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __res
                     if (ds >= ln) { for (uint32_t i = (uint32_t)lane; i < ln; i += IW) w[o + i] = w[o - ds + i]; }
                     else { for (uint32_t i = (uint32_t)lane; i < ln; i += IW) w[o + i] = w[o - ds + i % ds]; }
                 }
-                const bool sh = mine && len < 24u; // short: a lane each, byte after byte (its own earlier bytes may be its source)
-                for (uint32_t i = 0; __ballot(sh && i < len) != 0ull; ++i) if (sh && i < len) w[at + i] = w[at - dist + i];
+                // short and apart from its source (all of them but, at most, F): the source in three 8-byte reads, then stores that
+                // wait for nothing -- a byte-by-byte copy pays the LDS round trip twice per byte
+                const bool sh = mine && len < 24u && dist >= len;
+                {
+                    const uint8_t* const sp = w + (sh ? at - dist : 0u);
+                    uint64_t r0 = reinterpret_cast<const lds_u64*>(sp)->v;
+                    const uint64_t r1 = reinterpret_cast<const lds_u64*>(sp + 8)->v, r2 = reinterpret_cast<const lds_u64*>(sp + 16)->v;
+                    if (sh) {
+                        uint8_t* dp = w + at;
+                        uint32_t left = len;
+                        if (left >= 8u) { reinterpret_cast<lds_u64*>(dp)->v = r0; dp += 8; left -= 8u; r0 = r1; }
+                        if (left >= 8u) { reinterpret_cast<lds_u64*>(dp)->v = r0; dp += 8; left -= 8u; r0 = r2; }
+#pragma unroll
+                        for (uint32_t b = 0; b < 7u; ++b) if (b < left) dp[b] = (uint8_t)(r0 >> (8u * b));
+                    }
+                }
+                // short and overlapping its own output (F only: a repeat with a period below its length): byte after byte
+                const bool ov = mine && len < 24u && dist < len;
+                if (__ballot(ov) != 0ull) { if (ov) for (uint32_t i = 0; i < len; ++i) w[at + i] = w[at - dist + i]; }
                 um &= ~__ballot(mine);
                 isync();
             }

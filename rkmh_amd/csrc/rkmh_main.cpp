@@ -135,7 +135,8 @@ static void help_stream() {
             "  --depth-map-cache <file>  (with -M) save the read-depth map of this run, or reuse the file if it was saved\n"
             "                          from the same reads, k-mer sizes and hashing policy (anything else is refused)\n"
             "  --kmer-cache <file>       keep the k-mer enumeration of these references (k 8 .. 18; up to 20 once the file exists) in\n"
-            "                          <file>; reused while references, k and hashing policy match\n"
+            "                          <file>; reused while references, k and hashing policy match.  Without it, ONE k of 17 .. 20 keeps\n"
+            "                          its enumeration in <first -r file>.k<k>.s<s>.rkkc (--no-kmer-cache: not; k 19 / 20 then hash every window)\n"
             HASH_POLICY_HELP
             "  --device <id>           GPU to use (default 0)\n"
             "  --devices <a,b,..|all>  spread the reads over several GPUs of this node (stream, filter): one host thread and one\n"
@@ -305,6 +306,22 @@ static int min_num_bound_for(int compare_with) {
     if (getenv("RKMH_EXACT_MIN_NUM") && atoi(getenv("RKMH_EXACT_MIN_NUM")) != 0) return -1;
     return compare_with < 0 ? 0 : (compare_with >= 0x3fffffff ? -1 : compare_with + 1);
 }
+// One k-mer size of 17 .. 20 and no --kmer-cache: the enumeration behind the wide k-mer kernel (0.1 s at k = 17 ... 6.7 s at k = 20)
+// is kept beside the first reference file, <ref>.k<k>.s<s>.rkkc, so that it is paid once -- the first run at k = 19 / 20 spends it
+// (and classifies with the k-mer kernel itself), every later run with these references, k, sketch size and hashing policy loads
+// the file in milliseconds (a file for other references is recognised by its tag and rewritten; with --devices the first
+// context writes it while it builds its index, the others -- whose indexes are built afterwards -- load it).  RKMH_KMER_CACHE_AUTO=0 / --no-kmer-cache: off (k = 19 / 20 then stay with the hash-space kernel).  Nothing happens
+// when the directory cannot be written.
+static bool g_no_kmer_cache = false;
+static std::string auto_kmer_cache(const Opts& o) {
+    if (g_no_kmer_cache || (getenv("RKMH_KMER_CACHE_AUTO") && atoi(getenv("RKMH_KMER_CACHE_AUTO")) == 0)) return "";
+    if (o.ks.size() != 1 || o.ks[0] < 17 || o.ks[0] > 20 || o.refs.empty() || !strcmp(o.refs[0], "-")) return "";
+    const std::string path = std::string(o.refs[0]) + ".k" + std::to_string(o.ks[0]) + ".s" + std::to_string(o.sketch) + ".rkkc";
+    FILE* f = fopen(path.c_str(), "ab"); // (creates it empty when new: an empty file is "no list yet")
+    if (!f) return "";
+    fclose(f);
+    return path;
+}
 struct DeviceGroup {
     std::vector<rk_ctx*> ctx;
     void create(const Opts& o) {
@@ -317,6 +334,7 @@ struct DeviceGroup {
         for (auto& t : th) t.join();
         for (auto& e : err) if (!e.empty()) { fprintf(stderr, "rkmh: %s\n", e.c_str()); exit(1); }
         if (o.kmer_cache && *o.kmer_cache) for (rk_ctx* cx : ctx) CK(rk_set_kmer_cache(cx, o.kmer_cache));
+        else { const std::string ac = auto_kmer_cache(o); if (!ac.empty()) for (rk_ctx* cx : ctx) CK(rk_set_kmer_cache(cx, ac.c_str())); }
     }
     // after the references were set on ctx[0]: the same sketches on every other context
     void share_references(const Opts& o) {
@@ -1197,7 +1215,7 @@ static int main_stream(int argc, char** argv) {
         {"ref-kmer-map-file", required_argument, 0, 'q'}, {"in-stream", no_argument, 0, 'i'},
         {"output-reads", no_argument, 0, 'z'},   {"merge-sketch", no_argument, 0, 'm'},
         {"device", required_argument, 0, 1000},  {"depth-map-cache", required_argument, 0, 1001}, {"kmer-cache", required_argument, 0, 1003},
-        {"devices", required_argument, 0, 1002}, HASH_POLICY_OPTION, {0, 0, 0, 0}};
+        {"devices", required_argument, 0, 1002}, {"no-kmer-cache", no_argument, 0, 1005}, HASH_POLICY_OPTION, {0, 0, 0, 0}};
     optind = 2;
     int c;
     while ((c = getopt_long(argc, argv, "zmhdk:f:r:s:S:t:M:N:I:R:F:p:q:iD:", long_options, nullptr)) != -1) {
@@ -1210,6 +1228,7 @@ static int main_stream(int argc, char** argv) {
             case 'F': case 'p': case 'q': case 'S': break; // parsed, bodies empty in the reference (:659-670,:697-700)
             case 1001: read_map = optarg; break;              // --depth-map-cache FILE (not a reference flag): see the -M block
             case 1003: o.kmer_cache = optarg; break;          // --kmer-cache FILE (not a reference flag): rk_set_kmer_cache
+            case 1005: g_no_kmer_cache = true; break;
             case 't': o.threads = atoi(optarg); break;
             case 'r': o.refs.push_back(optarg); break;
             case 'f': o.reads.push_back(optarg); break;
@@ -1419,11 +1438,12 @@ static int main_filter(int argc, char** argv) {
         {"max-samples", required_argument, 0, 'I'}, {"pre-reads", required_argument, 0, 'F'},
         {"pre-references", required_argument, 0, 'R'}, {"read-kmer-map-file", required_argument, 0, 'p'},
         {"ref-kmer-map-file", required_argument, 0, 'q'}, {"in-stream", no_argument, 0, 'i'},
-        {"device", required_argument, 0, 1000}, {"devices", required_argument, 0, 1002}, {"kmer-cache", required_argument, 0, 1003}, HASH_POLICY_OPTION, {0, 0, 0, 0}};
+        {"device", required_argument, 0, 1000}, {"devices", required_argument, 0, 1002}, {"kmer-cache", required_argument, 0, 1003}, {"no-kmer-cache", no_argument, 0, 1005}, HASH_POLICY_OPTION, {0, 0, 0, 0}};
     optind = 2;
     int c;
     while ((c = getopt_long(argc, argv, "hdk:f:r:s:S:t:M:N:I:R:F:p:q:iD:", long_options, nullptr)) != -1) {
         switch (c) {
+            case 1005: g_no_kmer_cache = true; break;
             case 1004: policy_apply(optarg, "--hash-policy"); break;
             case 1003: o.kmer_cache = optarg; break;
             case 'F': case 'R': case 'p': case 'q': case 'S': break; // parsed, bodies empty (rkmh.cpp:1139-1151)

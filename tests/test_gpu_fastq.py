@@ -587,10 +587,11 @@ def test_cli_bgzf_payload_damage_is_refused_on_both_routes(root, data_dir, tmp_p
             at = bytes(img).find(reads[300][20:60])
             assert at > 70000
             img[at + 7] = ord("A") if img[at + 7] != ord("A") else ord("C")
-        else:               # deflated: flip one bit of the CRC-32 in a footer (the text is intact, the member is not)
+        else:               # deflated: flip one bit of the CRC-32 in the SECOND member's footer (the text is intact, the member is not)
             import struct
-            bsize = struct.unpack_from("<H", img, 16)[0] + 1
-            img[bsize - 8] ^= 0x10
+            first = struct.unpack_from("<H", img, 16)[0] + 1
+            second = struct.unpack_from("<H", img, first + 16)[0] + 1
+            img[first + second - 8] ^= 0x10
         bad = tmp_path / ("bad%d.fq.gz" % level)
         bad.write_bytes(bytes(img))
         for env in ({}, {"RKMH_BGZF_DEVICE": "0"}, {"RKMH_BGZF_JOB_KB": "200"}):

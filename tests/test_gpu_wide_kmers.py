@@ -103,3 +103,34 @@ def test_k19_is_not_enumerated_unasked(orc, data_dir):
         assert (c.classify(qb, qo) == orc.classify_stream(qb, qo, [19], 1000, sk, ln, threads=8)).all()
     finally:
         c.close()
+
+
+def test_cli_keeps_the_wide_enumeration_beside_the_references(root, data_dir, tmp_path):
+    """bin/rkmh at ONE k of 17 .. 20 without --kmer-cache: the first run enumerates (k = 19 here: beyond what is done unasked) and
+    leaves <ref>.k19.s600.rkkc beside the reference file, the second run loads it; both use the k-mer kernel and print what
+    --no-kmer-cache (the hash-space kernel) prints.  Another sketch size gets a file of its own."""
+    import gzip
+    import shutil
+    import subprocess
+    from rkmh_amd import api, synth
+    ref = tmp_path / "panel.fa"
+    with gzip.open(os.path.join(data_dir, "all_pave_ref.fa.gz"), "rb") as f, open(ref, "wb") as g:
+        shutil.copyfileobj(f, g)
+    refs = api.parse_files([str(ref)])
+    qb, qo = synth.generate_reads_fast(refs["bases"], refs["offsets"], 0, 20000, read_len=150, threads=4)
+    fq = tmp_path / "r.fq"
+    synth.write_fastq(str(fq), qb, qo, synth.read_names(0, 20000))
+    exe = os.path.join(root, "bin", "rkmh")
+    env = dict(os.environ, RKMH_INDEX_TIMING="1")
+    env.pop("RKMH_KMER_CACHE", None)
+    for cmd in ("stream", "filter"):
+        base = [exe, cmd, "-r", str(ref), "-f", str(fq), "-k", "19", "-s", "600" if cmd == "stream" else "700", "-N", "2"]
+        cache = str(ref) + ".k19.s%s.rkkc" % ("600" if cmd == "stream" else "700")
+        plain = subprocess.run(base + ["--no-kmer-cache"], capture_output=True, env=env)
+        assert plain.returncode == 0 and not os.path.exists(cache) and b"k-mer enumeration" not in plain.stderr
+        first = subprocess.run(base, capture_output=True, env=env)
+        assert first.returncode == 0, first.stderr[-500:]
+        assert os.path.getsize(cache) > 1000 and b"k-mer enumeration" in first.stderr
+        second = subprocess.run(base, capture_output=True, env=env)
+        assert second.returncode == 0 and b"k-mer lists from the cache" in second.stderr and b"k-mer enumeration" not in second.stderr
+        assert first.stdout == plain.stdout and second.stdout == plain.stdout and len(plain.stdout) > 1000
