@@ -74,12 +74,12 @@ extern "C" int rk_fastq_slot_create2(rk_ctx* c, uint64_t max_bytes, int flags, r
     HIPCHK(hipEventCreateWithFlags(&s->ev, hipEventBlockingSync | hipEventDisableTiming));
     // capacities: records of fewer than 64 bytes on average (reads of about 25 bases) make the block "irregular" (FQ_BAD_CAP) --
     // the host scanner takes it -- instead of sizing every device array for the worst case.  The page-locked host arrays of a
-    // device-text slot (hundreds of megabytes of text per block) are sized for records of 200 bytes and names of an eighth of
-    // the text; a block beyond that lands in pageable memory (HostArr).
+    // device-text slot (hundreds of megabytes of text per block; page-locking costs ~0.2 ms per MB at start-up) are sized for
+    // records of 256 bytes and names of a twentieth of the text; a block beyond that lands in pageable memory (HostArr).
     const uint32_t chunks = (uint32_t)((max_bytes + 4095) / 4096);
     const uint32_t rec_cap = (uint32_t)(max_bytes / 64 + 64), line_cap = 4 * rec_cap + 16;
     const bool dt = s->device_text();
-    const size_t host_recs = dt ? (size_t)(max_bytes / 200 + 4096) : (size_t)rec_cap;
+    const size_t host_recs = dt ? (size_t)(max_bytes / 256 + 4096) : (size_t)rec_cap;
     if (!dt) RKCHK(s->h_text.reserve(max_bytes + 64));
     RKCHK(s->h_out4.reserve_pinned(host_recs * 16));
     RKCHK(s->h_spans.reserve_pinned(host_recs * (dt ? 8 : 20)));
@@ -110,7 +110,7 @@ extern "C" int rk_fastq_slot_create2(rk_ctx* c, uint64_t max_bytes, int flags, r
     if (dt) {
         RKCHK(s->d_pack.reserve(max_bytes + 64));
         d.pack = s->d_pack.as<uint8_t>(); d.pack_cap = max_bytes;
-        RKCHK(s->h_pack.reserve_pinned(std::max<uint64_t>((uint64_t)1 << 20, max_bytes / 8) + 64));
+        RKCHK(s->h_pack.reserve_pinned(std::max<uint64_t>((uint64_t)1 << 20, max_bytes / 20) + 64));
     }
     HIPCHK(hipMemsetAsync(s->d_u32.p, 0, n32 * 4, s->st)); // stale lengths past a block's last record must at least be defined
     HIPCHK(hipStreamSynchronize(s->st));

@@ -801,6 +801,7 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
         if (!(W.device_text ? any_mega : any_plain)) return; // (no file of this run is for this worker's kind of slot)
         QueueT<Job>& jobs = W.device_text ? jobs_mega : jobs_plain;
         std::atomic<int>& live = W.device_text ? live_mega : live_plain;
+        const double t_slot = now_s();
         if (!W.slot && rk_fastq_slot_create2(g.ctx[W.dev], W.bytes, W.device_text ? RK_SLOT_DEVICE_TEXT : 0, &W.slot) != RK_OK) {
             // (memory for another slot ran out: the other workers carry on -- unless this was the last one)
             fprintf(stderr, "rkmh: worker %zu: %s\n", wi, rk_last_error());
@@ -808,6 +809,7 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
             return;
         }
         rk_fastq_slot* const slot = W.slot;
+        if (g_timing && W.device_text && now_s() - t_slot > 0.002) fprintf(stderr, "[rkmh timing] worker %zu: device-text slot of %.0f MB made in %.3f s\n", wi, (double)W.bytes / 1e6, now_s() - t_slot);
         if (W.device_text && kind == RAW_FILTER) CK(rk_fastq_slot_set_filter_output(slot, o.min_matches, o.min_diff));
         Job cur;
         double t_rd = 0, t_dv = 0, t_fm = 0;

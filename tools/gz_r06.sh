@@ -47,11 +47,14 @@ run() { # label file env...
     t4=$(python3 -c "print($E - $S)")
   done
   python3 -c "print('%-44s 1 file %.3f s, 4 files %.3f s: marginal %.1f M reads/s; output %s' % ('$label', $t1, $t4, 3 * $N / ($t4 - $t1) / 1e6, 'identical to plain' if '$got' == '$want' else 'DIFFERS'))" >> $OUT
-  grep -E "main loop|references|device front end:" /tmp/big.err4 | tr -s " " | sed 's/^/      /' >> $OUT
+  echo "      one file:   $(grep -E "context|references|device front end  |main loop|since the program" /tmp/big.err1 | sed 's/\[rkmh timing\] //' | tr -s " " | tr "\n" ";")" >> $OUT
+  echo "      four files: $(grep -E "context|references|device front end  |main loop|since the program" /tmp/big.err4 | sed 's/\[rkmh timing\] //' | tr -s " " | tr "\n" ";")" >> $OUT
+  grep -E "device front end:" /tmp/big.err4 | tr -s " " | sed 's/^/      /' >> $OUT
   grep "bgzf device" /tmp/big.err4 | head -4 | sed 's/^/      /' >> $OUT
 }
 run "plain text" /tmp/big.fq X=1
 run "BGZF, device inflate (default: 3 workers)" /tmp/big.fq.gz X=1
+[ -n "$QUICK" ] && { cat $OUT; exit 0; }
 run "BGZF, device inflate, 2 workers" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=2
 run "BGZF, device inflate, 1 worker" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=1
 run "BGZF, device inflate, 512 MB jobs" /tmp/big.fq.gz RKMH_BGZF_JOB_KB=524288
