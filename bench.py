@@ -195,6 +195,38 @@ def e2e_stream(n, L, rb, ro, synth):
                                      "block-parallel scanner); marginal = the extra reads of four -f files over one, per extra second of wall clock"}
                 if hb != hp or hd != hp:
                     raise SystemExit("e2e: the BGZF run printed other bytes than the plain-text run")
+                # the same reads packed once (`rkmh pack`: 2 bits per base + names; qualities dropped) and classified from the packed file
+                # (`stream -F`): ~42 bytes per read over the link, nothing parsed, lines formatted from the names in the mapped file
+                rkp = os.path.join(tmp, "gz.rkp")
+                extra.append(rkp)
+                t_ = time.perf_counter()
+                rp = subprocess.run([exe, "pack", "-f", gq, "-o", rkp, "--no-quals"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                pack_s = time.perf_counter() - t_
+                if rp.returncode != 0:
+                    raise RuntimeError(rp.stderr.decode()[-300:])
+
+                def timed_packed(nf):
+                    fo_ = fresh_out()
+                    t2 = time.perf_counter()
+                    r2 = subprocess.run([exe, "stream", "-r", ref, "-k", "16", "-s", "1000"] + ["-F", rkp] * nf, stdout=fo_, stderr=subprocess.PIPE)
+                    d2 = time.perf_counter() - t2
+                    fo_.close()
+                    if r2.returncode != 0:
+                        raise RuntimeError(r2.stderr.decode()[-300:])
+                    h2 = hashlib.sha256()
+                    with open(tsv, "rb") as f_:
+                        for blk in iter(lambda: f_.read(1 << 24), b""):
+                            h2.update(blk)
+                    return d2, h2.hexdigest()
+                k1, hk = timed_packed(1)
+                k8, _ = timed_packed(8)
+                res["packed"] = {"reads": ng, "packed_bytes": os.path.getsize(rkp), "bytes_per_read_in_file": os.path.getsize(rkp) / ng, "pack_s": pack_s,
+                                 "wall_s": k1, "x8_wall_s": k8, "marginal_reads_per_s": 7 * ng / (k8 - k1) if k8 > k1 else None,
+                                 "output_identical_to_plain": hk == hp,
+                                 "note": "bin/rkmh pack once, then stream -F: per read 37.5 B of 2-bit bases + a 4 B offset go up, 16 B of row come back; "
+                                         "marginal = the extra reads of eight -F files over one, per extra second of wall clock"}
+                if hk != hp:
+                    raise SystemExit("e2e: the packed run printed other bytes than the plain-text run")
             except RuntimeError as e:
                 res["gz"] = {"error": str(e)}
         return res

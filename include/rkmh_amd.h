@@ -468,6 +468,67 @@ int rk_bgzf_member(const rk_bgzf* z, int64_t member, uint64_t* file_off, uint32_
 int rk_fastq_slot_load_bgzf(rk_fastq_slot* slot, const rk_bgzf* z, int64_t b0, int64_t b1, uint64_t* nbytes, uint64_t* text_off);
 uint64_t rk_bgzf_file_bytes(const rk_bgzf* z);   /* length of rk_bgzf_image */
 
+/* ------------------------------------------------------------------------------------------------
+ * PACKED READS (`rkmh pack`, `stream|filter -F`; the reference parses -F/--pre-reads and does nothing with it, src/rkmh.cpp:659-664).
+ * FASTQ text costs ~315 bytes per 150-base read on every hop; a packed file keeps per read 2 bits per base, a 4-byte offset and --
+ * for the host only -- its name (and, optionally, its quality string): ~42 bytes per read cross the link, 16 come back.
+ * File (little endian; every section 16-byte aligned so a mapping of the file can be uploaded as it lies):
+ *   header  rk_packed_header
+ *   blocks  per block: offsets u32[nrec + 1] (in BASES, from the block's first base), bases2 u8[ceil(nbases / 4)] (base i in bits
+ *           2 (i & 3) of byte i >> 2; A = 0, C = 1, T = 2, G = 3 -- (ASCII >> 1) & 3 --, anything else stored as 0 and listed in),
+ *           exceptions {u32 base index, u32 original byte}[nexc] (every byte that is not one of ACGTacgt: N, IUPAC codes ...; lower case
+ *           acgt is NOT kept -- mkmh's to_upper folds it before anything looks, src/rkmh.cpp:856), name_offsets u32[nrec + 1], names
+ *           (back to back, no terminators), quals u8[nbases] when the file keeps them
+ *   directory  rk_packed_block[nblocks] at header.directory_off
+ * rk_packed_encode fills one block's device-bound sections from ASCII bases (host code); rk_classify_batch_device_packed /
+ * rk_count_batch_device_packed take them from device memory: the bases are expanded to ASCII in HBM (exceptions restored) and go
+ * through the same kernels as rk_classify_batch_device_all / rk_count_batch_device -- rows are bit-identical by construction. */
+#define RK_PACKED_MAGIC "RKPK1\n\0"
+#define RK_PACKED_QUALS 1u
+typedef struct rk_packed_header {
+    char magic[8];
+    uint32_t version, flags;          /* flags: RK_PACKED_QUALS */
+    uint64_t nreads, nbases, nblocks;
+    uint64_t directory_off;           /* rk_packed_block[nblocks] */
+    uint64_t reserved[2];
+} rk_packed_header;                   /* 64 bytes */
+typedef struct rk_packed_block {
+    uint64_t offsets_off, bases_off, exc_off, name_offsets_off, names_off, quals_off;  /* from the start of the file; quals_off 0: none */
+    uint32_t nrec, nexc;
+    uint64_t nbases, name_bytes;
+    uint32_t max_len, pad;
+} rk_packed_block;                    /* 80 bytes */
+typedef struct rk_packed_exception { uint32_t pos, byte; } rk_packed_exception;
+/* bases[0 .. n) -> bases2 (ceil(n / 4) bytes, the last byte's unused bits 0) and the exceptions (at most cap; positions are
+ * base_index0 + i); returns the number of exceptions, or a negative error (more than cap).  Host code, thread-safe. */
+int64_t rk_packed_encode(const uint8_t* bases, uint64_t n, uint64_t base_index0, uint8_t* bases2, rk_packed_exception* exc, uint64_t cap);
+/* the inverse on the host (what filter prints of a passing read): bases [first, first + n) of a block -> ASCII, exceptions restored
+ * (exc sorted by pos, as rk_packed_encode leaves them) */
+void rk_packed_decode(const uint8_t* bases2, uint64_t first, uint64_t n, const rk_packed_exception* exc, uint32_t nexc, uint8_t* out);
+/* d_bases2: ceil(nbases / 4) bytes (4-byte aligned, readable to the next multiple of 4); d_offsets_u32[nreads + 1] in bases;
+ * d_exc: nexc pairs (may be NULL when nexc == 0); d_ascii: the caller's scratch, 16 * ceil(nbases / 16) + 64 bytes of device memory,
+ * 16-byte aligned -- it holds the batch's ASCII bases on return.  Rows as rk_classify_batch_device_all (no row left flagged);
+ * synchronises the stream. */
+int rk_classify_batch_device_packed(rk_ctx* ctx, const void* d_bases2, const void* d_offsets_u32, int64_t nreads, uint64_t nbases,
+                                    const void* d_exc, uint32_t nexc, void* d_ascii, void* d_out4, uint32_t max_read_len, void* hip_stream);
+/* pass 1 of -M on such a batch (src/rkmh.cpp:904-910).  max_read_len: the longest read (the file's directory has it; required).  Asynchronous. */
+int rk_count_batch_device_packed(rk_ctx* ctx, const void* d_bases2, const void* d_offsets_u32, int64_t nreads, uint64_t nbases,
+                                 const void* d_exc, uint32_t nexc, void* d_ascii, rk_counter* counter, uint32_t max_read_len, void* hip_stream);
+
+/* One block of a packed file in flight (own stream and device arrays): what `stream|filter -F` is made of.  file = the packed file
+ * in memory (a mapping; page-locked with rk_host_register_readonly the DMA engine reads the page cache itself).  classify: res->out4 =
+ * the rows; name_off / name_len index file + block->names_off (the stream formatter rk_fastq_stream_lines takes that as `text`);
+ * seq_off (= qual_off) / seq_len are in BASES from the block's first base -- rk_packed_filter_records decodes what filter prints.
+ * The arrays live in the slot and in the mapping until the slot's next call.  count: pass 1 of -M. */
+typedef struct rk_packed_slot rk_packed_slot;
+int rk_packed_slot_create(rk_ctx* ctx, uint64_t max_reads, uint64_t max_bases, rk_packed_slot** out);
+void rk_packed_slot_destroy(rk_packed_slot* slot);
+int rk_packed_slot_classify(rk_packed_slot* slot, const rk_packed_block* block, const uint8_t* file, rk_fastq_result* res);
+int rk_packed_slot_count(rk_packed_slot* slot, const rk_packed_block* block, const uint8_t* file, rk_counter* counter);
+uint64_t rk_packed_filter_records_bound(const rk_fastq_result* res);
+int64_t rk_packed_filter_records(const rk_fastq_result* res, const rk_packed_block* block, const uint8_t* file, int min_matches, int min_diff,
+                                 char* dst, uint64_t cap);
+
 /* Loads the code objects of the device front end's kernels (with_inflate != 0: and of the device inflater) on `device` ahead of
  * their first launch -- tens of milliseconds a caller can spend on a second thread while its references are sketched.  Optional. */
 int rk_warm_up(int device, int with_inflate);

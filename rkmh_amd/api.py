@@ -120,6 +120,19 @@ _SIGS = {
     "rk_bgzf_fastq_records": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_fastq_slot_load_bgzf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_bgzf_file_bytes": (C.c_uint64, [C.c_void_p]),
+    # packed reads (`rkmh pack`, -F): include/rkmh_amd.h "PACKED READS"
+    "rk_packed_encode": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "rk_packed_decode": (None, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rk_classify_batch_device_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                  C.c_uint32, C.c_void_p]),
+    "rk_count_batch_device_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                               C.c_uint32, C.c_void_p]),
+    "rk_packed_slot_create": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "rk_packed_slot_destroy": (None, [C.c_void_p]),
+    "rk_packed_slot_classify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rk_packed_slot_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rk_packed_filter_records_bound": (C.c_uint64, [C.c_void_p]),
+    "rk_packed_filter_records": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64]),
     "rk_fastq_slot_create2": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
     "rk_fastq_slot_set_filter_output": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rk_fastq_slot_spans_base": (C.c_void_p, [C.c_void_p]),

@@ -63,6 +63,21 @@ static void build_kpost(const std::vector<uint32_t>& post, int R, std::vector<ui
         for (auto& x : dl[i].e) b.push_back(x.first);
         bases.push_back(std::move(b));
     }
+    // Are the bases worth their price?  The kernel that knows (base, exceptions) lists carries per-read base counters, a test of every
+    // compound value and an expansion step for EVERY read of every batch (k_classify_kmer<..., FAM>: 313.7 against 304.1 us per 1 M
+    // reads on BASELINE config 2's panel, whose 182 HPV types share a handful of conserved k-mers and nothing else).  They stay only
+    // where they take a real share of the posting walks away: at least 5 % of all postings of the index (config 3's panel: 70 %).
+    if (!bases.empty()) {
+        uint64_t total = 0, saved = 0;
+        for (auto& d : dl) {
+            total += (uint64_t)d.weight * d.e.size();
+            if (!d.simple || d.e.size() < 8) continue;
+            size_t bd = ~(size_t)0;
+            for (auto& b : bases) bd = std::min(bd, sym_diff(d.e, b));
+            if (2 * (1 + bd) <= d.e.size()) saved += (uint64_t)d.weight * (d.e.size() - bd - 1);
+        }
+        if (saved * 20 < total) bases.clear();
+    }
     kbase.assign(2 * KBASE_MAX, 0u);
     for (size_t b = 0; b < bases.size(); ++b) {
         kbase[2 * b] = (uint32_t)kbase.size(); kbase[2 * b + 1] = (uint32_t)bases[b].size();

@@ -116,6 +116,7 @@ static void print_help() {
             "  hash                print the k-mer hashes of every sequence\n"
             "  hpv16               HPV type and HPV16 lineage / sublineage k-mer matches of every read\n"
             "  sketch              write MinHash sketches as JSON (load them with stream -R)\n"
+            "  pack                write reads as a packed file (2 bits per base + names): stream|filter -F <file> classifies it without parsing\n"
             "Run a command without options for its help text.\n");
 }
 static void help_stream() {
@@ -130,7 +131,8 @@ static void help_stream() {
             "  -I/--max-samples <n>    drop reference k-mers counted more than n times across references\n"
             "  -N/--min-matches <n>    flag FAIL:DEPTH / FAIL:MATCHES\n"
             "  -D/--min-diff <n>       flag FAIL:DIFF\n"
-            "  -p/-q/-F <file>, -S <n>, -i, -z, -m   parsed and ignored, as in the reference\n"
+            "  -p/-q <file>, -S <n>, -i, -z, -m   parsed and ignored, as in the reference\n"
+            "  -F/--pre-reads <file.rkp>  reads packed by `rkmh pack` (2 bits per base + names) instead of -f text; repeatable\n"
             "  -R <sketches.json>      reference sketches written by `rkmh sketch` instead of -r\n"
             "  --depth-map-cache <file>  (with -M) save the read-depth map of this run, or reuse the file if it was saved\n"
             "                          from the same reads, k-mer sizes and hashing policy (anything else is refused)\n"
@@ -151,6 +153,7 @@ static void help_hash() {
 
 struct Opts {
     std::vector<const char*> refs, reads;
+    std::vector<const char*> packed; // -F <file>: reads written by `rkmh pack`
     std::vector<int> ks;
     int sketch = 1000, threads = 1, min_occ = -1, min_matches = -1, min_diff = 0, max_samples = 100000;
     const char* kmer_cache = getenv("RKMH_KMER_CACHE"); // --kmer-cache FILE: the k-mer enumeration of these references, kept between runs (rk_set_kmer_cache)
@@ -1030,6 +1033,292 @@ static bool two_pass_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset& refs, 
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Packed reads: `rkmh pack` writes them, `stream|filter -F` reads them (include/rkmh_amd.h, "PACKED READS").  The reference parses
+// -F/--pre-reads and does nothing with it (src/rkmh.cpp:659-664); here it names reads that were parsed ONCE: 2 bits per base, the
+// names and (optionally) the quality strings kept for the host -- a run then moves ~42 bytes per 150-base read over the link
+// instead of 315 of FASTQ text, parses nothing, and formats its lines from the names where they lie in the mapped file.
+static void help_pack() {
+    fprintf(stderr,
+            "rkmh pack -f <reads.fq|fa[.gz]> [-f ...] -o <out.rkp> [--no-quals] [--block-reads <n>]\n"
+            "  writes the reads as a packed file (2 bits per base, names, quality strings unless --no-quals) that\n"
+            "  `rkmh stream|filter -F <out.rkp>` classifies without parsing; independent of k, sketch size and hashing policy\n");
+}
+static int main_pack(int argc, char** argv) {
+    std::vector<const char*> files;
+    const char* outp = nullptr;
+    bool keep_quals = true;
+    long block_reads = 1 << 20;
+    if (argc <= 2) { help_pack(); exit(1); }
+    static struct option long_options[] = {{"help", no_argument, 0, 'h'}, {"fasta", required_argument, 0, 'f'}, {"output", required_argument, 0, 'o'},
+                                           {"no-quals", no_argument, 0, 1010}, {"block-reads", required_argument, 0, 1011}, {"threads", required_argument, 0, 't'}, {0, 0, 0, 0}};
+    optind = 2;
+    int c;
+    while ((c = getopt_long(argc, argv, "hf:o:t:", long_options, nullptr)) != -1) {
+        switch (c) {
+            case 'f': files.push_back(optarg); break;
+            case 'o': outp = optarg; break;
+            case 't': break;
+            case 1010: keep_quals = false; break;
+            case 1011: block_reads = atol(optarg); break;
+            default: help_pack(); exit(1);
+        }
+    }
+    if (files.empty() || !outp) { help_pack(); exit(1); }
+    if (block_reads < 1024 || block_reads > (16 << 20)) { fprintf(stderr, "rkmh pack: --block-reads must lie between 1024 and 16777216\n"); exit(1); }
+    FILE* fo = fopen(outp, "wb");
+    if (!fo) { fprintf(stderr, "rkmh pack: cannot write %s\n", outp); exit(1); }
+    rk_packed_header hdr;
+    memset(&hdr, 0, sizeof hdr);
+    memcpy(hdr.magic, RK_PACKED_MAGIC, 8);
+    hdr.version = 1;
+    std::vector<rk_packed_block> dir;
+    uint64_t at = 0;
+    bool quals_everywhere = keep_quals;
+    auto put = [&](const void* p, size_t n) { if (n && fwrite(p, 1, n, fo) != n) { fprintf(stderr, "rkmh pack: write error on %s\n", outp); exit(1); } at += n; };
+    auto align16 = [&]() { static const char z[16] = {0}; const size_t pad = (size_t)((16 - (at & 15)) & 15); put(z, pad); };
+    put(&hdr, sizeof hdr); // (rewritten at the end)
+    const int nt = std::max(1, std::min(granted_cpus_main(), 16));
+    std::vector<uint8_t> b2;
+    std::vector<std::vector<rk_packed_exception>> exc_t((size_t)nt);
+    std::vector<uint32_t> offs, noffs;
+    std::vector<char> names;
+    for (const char* path : files) {
+        rk_reader* rd = nullptr;
+        CK(rk_reader_open(path, &rd));
+        if (!keep_quals) rk_reader_set_options(rd, RK_READER_NO_QUALS);
+        for (;;) {
+            rk_seqset s;
+            CK(rk_reader_next(rd, block_reads, (uint64_t)3 << 30, &s));
+            if (s.nseq == 0) { rk_seqset_free(&s); break; }
+            const uint64_t b0 = s.offsets[0], nb = s.offsets[s.nseq] - b0;
+            if (nb >= ((uint64_t)1 << 32) - 64 || s.nseq > 0x7ffffff0ll) { fprintf(stderr, "rkmh pack: a block of more than 4 G bases\n"); exit(1); }
+            rk_packed_block blk;
+            memset(&blk, 0, sizeof blk);
+            blk.nrec = (uint32_t)s.nseq; blk.nbases = nb;
+            offs.resize((size_t)s.nseq + 1);
+            uint32_t maxlen = 0;
+            for (int64_t i = 0; i <= s.nseq; ++i) offs[(size_t)i] = (uint32_t)(s.offsets[i] - b0);
+            for (int64_t i = 0; i < s.nseq; ++i) maxlen = std::max(maxlen, offs[(size_t)i + 1] - offs[(size_t)i]);
+            blk.max_len = maxlen;
+            // 2-bit bases and exceptions: pieces of whole bytes (4 bases), a thread each
+            b2.assign((size_t)((nb + 3) / 4), 0);
+            {
+                std::vector<std::thread> th;
+                const uint64_t per = (((nb + (uint64_t)nt - 1) / (uint64_t)nt) + 3) & ~(uint64_t)3;
+                for (int t = 0; t < nt; ++t)
+                    th.emplace_back([&, t] {
+                        const uint64_t lo = std::min(nb, per * (uint64_t)t), hi = std::min(nb, lo + per);
+                        auto& ex = exc_t[(size_t)t];
+                        ex.resize((size_t)(hi - lo) + 1);
+                        const int64_t ne = rk_packed_encode(s.bases + b0 + lo, hi - lo, lo, b2.data() + lo / 4, ex.data(), ex.size());
+                        if (ne < 0) { fprintf(stderr, "rkmh pack: %s\n", rk_last_error()); fail_exit(); }
+                        ex.resize((size_t)ne);
+                    });
+                for (auto& t : th) t.join();
+            }
+            noffs.resize((size_t)s.nseq + 1);
+            names.clear();
+            for (int64_t i = 0; i < s.nseq; ++i) {
+                noffs[(size_t)i] = (uint32_t)names.size();
+                const char* nm = s.names + s.name_offsets[i];
+                names.insert(names.end(), nm, nm + (s.name_offsets[i + 1] - s.name_offsets[i] - 1)); // (the offsets include the NUL)
+            }
+            noffs[(size_t)s.nseq] = (uint32_t)names.size();
+            if (names.size() >= ((uint64_t)1 << 32)) { fprintf(stderr, "rkmh pack: more than 4 GB of names in one block\n"); exit(1); }
+            blk.name_bytes = names.size();
+            align16(); blk.offsets_off = at; put(offs.data(), offs.size() * 4);
+            align16(); blk.bases_off = at; put(b2.data(), b2.size());
+            { static const char z[16] = {0}; put(z, 16); } // (the bases are uploaded in whole dwords; the unpacked tail is never read)
+            align16(); blk.exc_off = at;
+            uint64_t nexc = 0;
+            for (auto& ex : exc_t) { put(ex.data(), ex.size() * sizeof(rk_packed_exception)); nexc += ex.size(); }
+            if (nexc > 0xffffffffull) { fprintf(stderr, "rkmh pack: too many non-ACGT bases in one block\n"); exit(1); }
+            blk.nexc = (uint32_t)nexc;
+            align16(); blk.name_offsets_off = at; put(noffs.data(), noffs.size() * 4);
+            align16(); blk.names_off = at; put(names.data(), names.size());
+            { static const char z[32] = {0}; put(z, 32); } // (the formatters copy names in 16-byte steps)
+            if (keep_quals && s.quals) { align16(); blk.quals_off = at; put(s.quals + b0, (size_t)nb); }
+            else quals_everywhere = false;
+            dir.push_back(blk);
+            hdr.nreads += (uint64_t)s.nseq; hdr.nbases += nb;
+            rk_seqset_free(&s);
+        }
+        rk_reader_close(rd);
+    }
+    if (!quals_everywhere) for (auto& b : dir) b.quals_off = 0; // (all or nothing: a file that keeps qualities keeps them for every read)
+    align16();
+    hdr.directory_off = at; hdr.nblocks = dir.size(); hdr.flags = quals_everywhere && !dir.empty() ? RK_PACKED_QUALS : 0u;
+    put(dir.data(), dir.size() * sizeof(rk_packed_block));
+    { static const char z[64] = {0}; put(z, 64); }
+    if (fseek(fo, 0, SEEK_SET) != 0 || fwrite(&hdr, sizeof hdr, 1, fo) != 1 || fclose(fo) != 0) { fprintf(stderr, "rkmh pack: write error on %s\n", outp); exit(1); }
+    fprintf(stderr, "rkmh pack: %llu reads, %llu bases in %zu blocks%s -> %s (%.1f bytes per read)\n", (unsigned long long)hdr.nreads, (unsigned long long)hdr.nbases, dir.size(),
+            hdr.flags & RK_PACKED_QUALS ? ", with qualities" : "", outp, hdr.nreads ? (double)(at + dir.size() * sizeof(rk_packed_block)) / (double)hdr.nreads : 0.0);
+    return 0;
+}
+
+struct PackedFile {
+    const char* path = nullptr;
+    const uint8_t* map = nullptr;
+    size_t size = 0;
+    const rk_packed_header* hdr = nullptr;
+    const rk_packed_block* dir = nullptr;
+};
+// maps and checks a packed file (every section inside the file, counts consistent); exits with a message otherwise
+static PackedFile packed_open(const char* path) {
+    PackedFile pf;
+    pf.path = path;
+    const int fd = open(path, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0 || st.st_size < (off_t)sizeof(rk_packed_header)) { fprintf(stderr, "rkmh: cannot read packed reads from %s\n", path); exit(1); }
+    void* mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mp == MAP_FAILED) { fprintf(stderr, "rkmh: cannot map %s\n", path); exit(1); }
+    pf.map = (const uint8_t*)mp; pf.size = (size_t)st.st_size;
+    pf.hdr = reinterpret_cast<const rk_packed_header*>(pf.map);
+    auto bad = [&](const char* why) { fprintf(stderr, "rkmh: %s is not a packed read file of this build (%s): write it with `rkmh pack`\n", path, why); exit(1); };
+    if (memcmp(pf.hdr->magic, RK_PACKED_MAGIC, 8) != 0 || pf.hdr->version != 1) bad("magic / version");
+    const uint64_t nb = pf.hdr->nblocks, doff = pf.hdr->directory_off;
+    if ((doff & 15) || doff > pf.size || nb > (pf.size - doff) / sizeof(rk_packed_block)) bad("directory");
+    pf.dir = reinterpret_cast<const rk_packed_block*>(pf.map + doff);
+    uint64_t nreads = 0;
+    for (uint64_t i = 0; i < nb; ++i) {
+        const rk_packed_block& b = pf.dir[i];
+        auto inside = [&](uint64_t off, uint64_t n) { return (off & 15) == 0 && off <= doff && n <= doff - off; };
+        if (!inside(b.offsets_off, ((uint64_t)b.nrec + 1) * 4) || !inside(b.bases_off, (b.nbases + 3) / 4 + 16) || !inside(b.exc_off, (uint64_t)b.nexc * 8) ||
+            !inside(b.name_offsets_off, ((uint64_t)b.nrec + 1) * 4) || !inside(b.names_off, b.name_bytes + 32) || (b.quals_off && !inside(b.quals_off, b.nbases)))
+            bad("a block's sections");
+        const uint32_t* so = reinterpret_cast<const uint32_t*>(pf.map + b.offsets_off);
+        const uint32_t* no = reinterpret_cast<const uint32_t*>(pf.map + b.name_offsets_off);
+        if (so[0] != 0 || so[b.nrec] != b.nbases || no[0] != 0 || no[b.nrec] != b.name_bytes) bad("a block's offsets");
+        nreads += b.nrec;
+    }
+    if (nreads != pf.hdr->nreads) bad("read count");
+    return pf;
+}
+
+// The blocks of the packed files through the devices: per device a few workers, each with a packed slot (rk_packed_slot_*): upload the
+// block's offsets, 2-bit bases and exceptions from the mapping, classify (or count: pass 1 of -M), format the lines from the names in
+// the mapping -- large blocks in pieces, by the helper threads -- and park them in input order.
+static void stream_packed(DeviceGroup& g, const rk_seqset& refs, const Opts& o, const std::vector<PackedFile>& files, RawKind kind, std::vector<rk_counter*>* cnts) {
+    const bool counting = kind == RAW_COUNT;
+    rk_line_parts* lp = nullptr;
+    if (kind == RAW_STREAM) CK(rk_line_parts_create(refs.names, refs.name_offsets, refs.nseq, o.sketch, o.min_matches, o.min_diff, &lp));
+    struct Job { size_t file; uint64_t block; int64_t seq, nseq; };
+    std::vector<Job> jobs;
+    uint64_t max_reads = 1, max_bases = 16;
+    const int64_t PIECE = 1 << 18; // reads per output piece
+    int64_t seq = 0;
+    for (size_t f = 0; f < files.size(); ++f)
+        for (uint64_t b = 0; b < files[f].hdr->nblocks; ++b) {
+            const rk_packed_block& blk = files[f].dir[b];
+            max_reads = std::max<uint64_t>(max_reads, blk.nrec); max_bases = std::max<uint64_t>(max_bases, blk.nbases);
+            const int64_t pieces = std::max<int64_t>(1, ((int64_t)blk.nrec + PIECE - 1) / PIECE);
+            jobs.push_back(Job{f, b, seq, pieces});
+            seq += pieces;
+        }
+    static std::map<const uint8_t*, bool> registered; // (a mapping is page-locked once; both passes of -M use it)
+    for (const PackedFile& pf : files)
+        if (!registered.count(pf.map) && !(getenv("RKMH_PACKED_REGISTER") && atoi(getenv("RKMH_PACKED_REGISTER")) == 0))
+            registered[pf.map] = rk_host_register_readonly(pf.map, pf.size) == RK_OK;
+    const size_t nw = (size_t)env_long("RKMH_PACKED_WORKERS", 3, 1, 16) * g.size();
+    OrderedOut out;
+    if (!counting) out.start(g.size());
+    FormatPool pool;
+    if (!counting) pool.start((int)std::min<long>(16, std::max<long>(2, granted_cpus_main() - 2)));
+    const int64_t window = (int64_t)nw * 8 + 2;
+    std::atomic<size_t> next{0};
+    std::mutex tm;
+    double t_dev = 0, t_fmt = 0;
+    auto work = [&](size_t wi) {
+        rk_packed_slot* slot = nullptr;
+        const size_t dev = wi % g.size();
+        if (rk_packed_slot_create(g.ctx[dev], max_reads, max_bases, &slot) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+        double dv = 0, fm = 0;
+        for (size_t j = next.fetch_add(1); j < jobs.size(); j = next.fetch_add(1)) {
+            const Job& jb = jobs[j];
+            const PackedFile& pf = files[jb.file];
+            const rk_packed_block& blk = pf.dir[jb.block];
+            const double a = now_s();
+            if (counting) {
+                const int rc = rk_packed_slot_count(slot, &blk, pf.map, (*cnts)[dev]);
+                if (rc == RK_ERR_NEED_FULL) g_need_full.store(true);
+                else if (rc != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", pf.path, rk_last_error()); fail_exit(); }
+                dv += now_s() - a;
+                continue;
+            }
+            rk_fastq_result res;
+            if (rk_packed_slot_classify(slot, &blk, pf.map, &res) != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", pf.path, rk_last_error()); fail_exit(); }
+            const double b = now_s();
+            const uint8_t* const text = pf.map + blk.names_off;
+            auto format_piece = [&](int64_t lo, int64_t hi, int64_t sq) {
+                std::vector<char> buf = out.take_buffer();
+                size_t n = 0;
+                if (hi > lo) {
+                    const rk_fastq_result part = sub_result(res, lo, hi);
+                    if (kind == RAW_FILTER) {
+                        const size_t need = (size_t)rk_packed_filter_records_bound(&part);
+                        if (buf.size() < need) buf.resize(need + need / 8);
+                        const int64_t w = rk_packed_filter_records(&part, &blk, pf.map, o.min_matches, o.min_diff, buf.data(), buf.size());
+                        if (w < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+                        n = (size_t)w;
+                    } else n = format_raw(lp, part, text, buf);
+                }
+                out.put(sq, std::move(buf), n, window);
+            };
+            if (jb.nseq == 1) format_piece(0, res.nrec, jb.seq);
+            else {
+                Latch latch;
+                latch.left = (int)jb.nseq;
+                for (int64_t e = 0; e < jb.nseq; ++e)
+                    pool.run([&, e] { format_piece(res.nrec * e / jb.nseq, res.nrec * (e + 1) / jb.nseq, jb.seq + e); latch.done(); });
+                latch.wait();
+            }
+            dv += b - a; fm += now_s() - b;
+        }
+        rk_packed_slot_destroy(slot);
+        std::lock_guard<std::mutex> l(tm);
+        t_dev += dv; t_fmt += fm;
+    };
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < nw; ++i) th.emplace_back(work, i);
+    for (auto& t : th) t.join();
+    pool.stop();
+    if (!counting) out.finish();
+    rk_line_parts_destroy(lp);
+    if (out.failed) { fprintf(stderr, "rkmh: write error on standard output\n"); fail_exit(); }
+    if (g_timing) fprintf(stderr, "[rkmh timing] packed reads: %zu blocks; upload + classify %.3f s, format %.3f s (summed over %zu workers)\n", jobs.size(), t_dev, t_fmt, nw);
+}
+
+// stream / filter over packed files, with or without -M (two passes: count, sum over the devices, mask, classify)
+static void run_packed(DeviceGroup& g, const rk_seqset& refs, const Opts& o, const std::vector<const char*>& paths, RawKind kind, uint64_t slots, int bound, double& t0) {
+    std::vector<PackedFile> files;
+    for (const char* p : paths) files.push_back(packed_open(p));
+    if (kind == RAW_FILTER && !files.empty() && !(files[0].hdr->flags & RK_PACKED_QUALS) && g_timing) fprintf(stderr, "[rkmh timing] %s keeps no qualities: filter prints empty quality lines\n", files[0].path);
+    if (o.read_depth) {
+        std::vector<rk_counter*> cnts;
+        bool compact = compact_maps_wanted(bound, nullptr);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            make_depth_maps(g, slots, compact, cnts);
+            g_need_full.store(false);
+            stream_packed(g, refs, o, files, RAW_COUNT, &cnts);
+            if (!g_need_full.exchange(false)) break;
+            if (!compact) { fprintf(stderr, "rkmh: the count pass failed\n"); fail_exit(); }
+            compact = false; // a read with more hashes than the sketch keeps: the pass again into full tables
+        }
+        tick("pass 1 (packed reads, count)", t0);
+        sum_counters_on_group(g, cnts);
+        share_counters_on_group(g, cnts);
+        group_run(g, [&](size_t d) { return rk_set_depth_filter(g.ctx[d], cnts[d], o.min_occ); });
+        tick("depth tables summed, mask built", t0);
+        stream_packed(g, refs, o, files, kind, nullptr);
+        tick("pass 2 (packed reads, classify)", t0);
+        return;
+    }
+    stream_packed(g, refs, o, files, kind, nullptr);
+    tick("packed reads: classify + format", t0);
+}
+
 // The -r files through the device (rk_fasta_load_*, rkmh_amd/csrc/rk_fasta.hip) instead of parse_fastas (rkmh.cpp:238-263): the
 // workers of the read pipeline pread the raw text into their page-locked buffers and upload it, the GPU strips header lines and
 // line ends, and the references are sketched from the packed bases where they lie -- the host never sees a base.  Worth its set-up
@@ -1227,7 +1516,8 @@ static int main_stream(int argc, char** argv) {
             case 'R': pre_refs = optarg; break;               // pre-hashed references: parsed but unimplemented in the reference (:662-664)
             // -p/-q (k-mer map files): the reference parses them and does nothing (bodies commented out, :665-670, :744-769);
             // so do we -- no file is read or written.  The reusable depth map is this build's own, explicit option below.
-            case 'F': case 'p': case 'q': case 'S': break; // parsed, bodies empty in the reference (:659-670,:697-700)
+            case 'F': o.packed.push_back(optarg); break;      // --pre-reads: parsed and unused in the reference (:659-664); here: reads packed by `rkmh pack`
+            case 'p': case 'q': case 'S': break; // parsed, bodies empty in the reference (:665-670,:697-700)
             case 1001: read_map = optarg; break;              // --depth-map-cache FILE (not a reference flag): see the -M block
             case 1003: o.kmer_cache = optarg; break;          // --kmer-cache FILE (not a reference flag): rk_set_kmer_cache
             case 1005: g_no_kmer_cache = true; break;
@@ -1264,6 +1554,7 @@ static int main_stream(int argc, char** argv) {
         o.ks.push_back(16);
     }
     if (o.refs.empty() && !pre_refs) { fprintf(stderr, "rkmh: at least one -r reference file (or -R sketches) is required\n"); exit(1); }
+    if (!o.packed.empty() && !o.reads.empty()) { fprintf(stderr, "rkmh: give the reads either as text (-f) or as packed files (-F), not both\n"); exit(1); }
 
     // Which front end reads the reads: regular uncompressed FASTQ files go through the device (stream_file_raw); everything else --
     // gzip, STDIN, FASTA, -M (which needs all reads twice) -- through the kseq-grammar scanner.  RKMH_RAW=0 forces the scanner.
@@ -1279,7 +1570,7 @@ static int main_stream(int argc, char** argv) {
     QueueT<Numbered> q;
     q.cap = 4;
     std::thread producer;
-    if (!o.read_depth && !any_raw) {
+    if (!o.read_depth && !any_raw && o.packed.empty()) {
         std::vector<std::pair<const char*, uint64_t>> files;
         for (const char* path : o.reads) files.emplace_back(path, 0);
         producer = start_scanner(q, files);
@@ -1323,6 +1614,12 @@ static int main_stream(int argc, char** argv) {
     group.share_references(o);
     tick("references", t0);
     if (warm.joinable()) { warm.join(); tick("kernels loaded (waited)", t0); }
+    if (!o.packed.empty()) { // reads written by `rkmh pack`: nothing to parse
+        run_packed(group, refs, o, o.packed, RAW_STREAM, 200000000ull, min_num_bound_for(o.min_matches), t0);
+        fflush(stdout);
+        tick("main loop + flush", t0);
+        done_exit();
+    }
     std::string buf;
     std::vector<int32_t> out4;
     bool depth_done = false;
@@ -1448,7 +1745,8 @@ static int main_filter(int argc, char** argv) {
             case 1005: g_no_kmer_cache = true; break;
             case 1004: policy_apply(optarg, "--hash-policy"); break;
             case 1003: o.kmer_cache = optarg; break;
-            case 'F': case 'R': case 'p': case 'q': case 'S': break; // parsed, bodies empty (rkmh.cpp:1139-1151)
+            case 'F': o.packed.push_back(optarg); break;      // reads packed by `rkmh pack` (--pre-reads is parsed and unused in the reference, rkmh.cpp:1139-1141)
+            case 'R': case 'p': case 'q': case 'S': break; // parsed, bodies empty (rkmh.cpp:1142-1151)
             case 't': o.threads = atoi(optarg); break;
             case 'r': o.refs.push_back(optarg); break;
             case 'f': o.reads.push_back(optarg); break;
@@ -1469,6 +1767,7 @@ static int main_filter(int argc, char** argv) {
         o.ks.push_back(16);
     }
     if (o.refs.empty()) { fprintf(stderr, "rkmh: at least one -r reference file is required\n"); exit(1); }
+    if (!o.packed.empty() && (!o.reads.empty() || in_stream)) { fprintf(stderr, "rkmh: give the reads either as text (-f / -i) or as packed files (-F), not both\n"); exit(1); }
     // Regular uncompressed FASTQ files and BGZF files go through the device front end (stream_file_raw / two_pass_raw): the host neither
     // parses the reads nor holds them.  RKMH_RAW=0, plain gzip, FASTA and text that is not four lines per record take the parse-everything
     // path.  (Looked at before the engine is made: it is laid out for the kinds of read files there are.)
@@ -1508,6 +1807,11 @@ static int main_filter(int argc, char** argv) {
     }
     group.share_references(o);
     tick("sketch references", t0);
+    if (!o.packed.empty()) { // reads written by `rkmh pack`: nothing to parse
+        run_packed(group, refs, o, o.packed, RAW_FILTER, 10000000ull, filter_bound, t0);
+        fflush(stdout);
+        done_exit();
+    }
     std::vector<rk_counter*> cnts;
     const bool compact_ok = o.read_depth && !in_stream && compact_maps_wanted(filter_bound, nullptr);
     std::string buf;
@@ -2275,6 +2579,7 @@ int main(int argc, char** argv) {
     if (cmd == "filter") return main_filter(argc, argv);
     if (cmd == "call") return main_call(argc, argv);
     if (cmd == "sketch") return main_sketch(argc, argv);
+    if (cmd == "pack") return main_pack(argc, argv);
     if (cmd == "hpv16") return main_hpv16(argc, argv);
     print_help();
     exit(1);

@@ -51,6 +51,7 @@ run() { # label file env...
   echo "      four files: $(grep -E "context|references|device front end  |main loop|since the program" /tmp/big.err4 | sed 's/\[rkmh timing\] //' | tr -s " " | tr "\n" ";")" >> $OUT
   grep -E "device front end:" /tmp/big.err4 | tr -s " " | sed 's/^/      /' >> $OUT
   grep "bgzf device" /tmp/big.err4 | head -4 | sed 's/^/      /' >> $OUT
+  [ -n "$DETAIL" ] && { echo "      --- the one-file run, every timing line:" >> $OUT; env "$@" RKMH_TIMING=1 RKMH_BGZF_TIMING=1 RKMH_INDEX_TIMING=1 bin/rkmh stream $R -f $f 2>&1 >/dev/null | grep -v "^\[rkmh index\]" | sed 's/^/        /' >> $OUT; }
 }
 run "plain text" /tmp/big.fq X=1
 run "BGZF, device inflate (default: 3 workers)" /tmp/big.fq.gz X=1

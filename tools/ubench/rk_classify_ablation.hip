@@ -1,3 +1,6 @@
+// tools/ubench/rk_classify_ablation.hip -- LAB COPY of rkmh_amd/csrc/rk_classify.hip as of round 5, kept for its timing experiments
+// (-DRK_ABLATE=1 builds read RKMH_DBG: parts of the kernel switched off or faked, WRONG results; RKMH_TILE_* geometry overrides).
+// NOT built by the Makefile and not part of the product; the numbers are in profiles/r03_ablation.txt, r03_k20_ablation.txt.
 // rk_classify.hip -- the fused per-read kernel of the classify/stream hot path (gfx950, wave64).
 //
 // Replaces the body of main_stream's read loop, /root/reference/src/rkmh.cpp:856-888 (and the two
@@ -45,7 +48,14 @@
 
 namespace rk {
 
-// (the ablation switches this kernel was attributed with -- RK_ABLATE builds, RKMH_DBG -- live in tools/ubench/rk_classify_ablation.hip, not here)
+// Ablation switches used to attribute kernel time to its parts: build with
+// -DRK_ABLATE=1 and set RKMH_DBG (1 no queueing, 2 no phase 2, 4 cheap hash, 8 no bucket loads, 32 no drain,
+// 64 no hit multiset, 128 no counter updates, 256 no index verification in the drain).  Always available:
+// RKMH_DBG=1024 turns the split-strand last step off (A/B), RKMH_TILE_* override the tile geometry (read once per process).
+#ifndef RK_ABLATE
+#define RK_ABLATE 0
+#endif
+#define RK_DBG(bit) (RK_ABLATE && (geo.dbg & (bit)))
 
 constexpr int WAVE = 64;
 // Occupancy target: the kernel is sensitive to it (5 -> 6 waves/SIMD = +11 % measured), so registers and LDS are
@@ -93,6 +103,7 @@ struct TileGeom {
     int32_t csparse;    // 1: the per-read counters are a small open-addressing map ref -> count (many references) and
                         //    cwords is its size (power of two); entry = (ref + 1) << 11 | count
     int32_t dset;       // slots of the per-read hit multiset (power of two)
+    int32_t dbg;        // ablation switches (only read when built with -DRK_ABLATE=1)
     int32_t tpb;        // consecutive tiles per workgroup
     int32_t xcd;        // 1: workgroups that share an XCD (blockIdx % 8, round-robin dispatch) take neighbouring tiles
     uint64_t slots_m;   // floor((2^64 - 1) / slots) of the -M counter table: hash % slots by Barrett reduction (mod_slots)
@@ -391,6 +402,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         // +1 for reference `ref` of read t; the monotone counters make (max_shared, first max_id) a running atomicMax
         // count_posting: the +1 alone; returns the candidate for the running maximum (0: nothing to report)
         auto count_posting = [&](int t, uint32_t ref) -> uint32_t {
+            if RK_DBG(128) return 0u;
             // packed counters: 16 bits each, or 8 bits when no read of the batch has more than 255 windows (a count never
             // exceeds the number of windows, so no field can carry into its neighbour)
             uint32_t cnt;
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         // the 16-lanes-per-hit pass instead of looping here with 63 lanes idle.
         auto apply_hit = [&](uint32_t slot, uint32_t v, int t, uint32_t& m_tr, uint32_t& m_off) -> bool {
             uint32_t rank = 0;
-            {
+            if (!RK_DBG(64)) {
                 uint32_t* ds = dset + (uint32_t)t * DS;
                 const uint32_t key = slot + 1u;
                 uint32_t idx = ((slot * 0x9E3779B1u) >> 16) & (DS - 1);
@@ -457,6 +469,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
         auto take_candidate = [&](uint64_t h, int t, uint32_t& m_tr, uint32_t& m_off) -> bool {
             uint32_t slot = 0, v = 0;
             bool dropped = false;
+            if RK_DBG(256) { slot = (uint32_t)h & 0xFFFFu; v = (uint32_t)(h >> 40) % 180u | (1u << 20); } else
             if (!index_lookup(ix, h, slot, v, dropped)) return false; // re-reads the bucket (L1/L2 hit), then key + value together
             // -M with a bounded min_num: the mask is applied per KEY (the verdict rides in the key's entry) -- a masked hash is 0 (rkmh.cpp:916)
             if (dropped) { atomicAdd(&nzero[t], 1u); return false; }
@@ -571,7 +584,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                                 if (hh == 0) atomicAdd(&nzero[tt], 1u);
                             }
                         };
-                        const bool split = compact && it + 1 == nIt && nW - it * WAVE <= 32u; // wave-uniform
+                        const bool split = compact && it + 1 == nIt && nW - it * WAVE <= 32u && !RK_DBG(4) && !(geo.dbg & 1024); // wave-uniform (RKMH_DBG=1024: A/B off)
                         if (split) {
                             // The tile's last <= 32 windows: lanes l and l + 32 take window l together -- the low half hashes
                             // the forward strand, the high half the reverse complement, one exchange gives both the minimum.
@@ -602,7 +615,9 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                         }
                         if (ok) { // idle lanes (read tails, the end of the tile) keep h = 0 and are never looked up
                             if (MODE == 1 && has_invalid && !window_valid<KT>(s, p, k)) h = 0;
-                            else {
+                            else if RK_DBG(4) {
+                                h = ((uint64_t)(s.fwd[(s.fbase + p) >> 2] * 0x9E3779B1u) << 32) | (s.rc[(B - (uint32_t)k - p) >> 2] * 0x85EBCA6Bu);
+                            } else {
                                 if constexpr (KT == 0) { // run-time k: both strands through one block loop, uniform tail masks
                                     h = canonical_rt(s.fwd, s.fbase + p, s.rc, B - (uint32_t)k - p, k, tmasks, pol.seed, pol.fold);
                                 } else {
@@ -660,7 +675,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                         continue;
                     }
                     bucket_wait(fb);
-                    {
+                    if (!RK_DBG(1)) {
                         const uint32_t fp = index_fp(hp);
                         // eight halfword compares (SDWA word selects, one VALU each).  A bucket whose overflow flag (bit 15 of slot
                         // 0) is set makes every window that lands in it a candidate (its slot-0 compare fails by design, the drain
@@ -681,6 +696,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                         }
                         qcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qcount + (uint32_t)__popcll(m)));
                     }
+                    if RK_DBG(8) { if (h == 0x1234567ull) nzero[0] = 1; } else
                     bucket_load_async(ix.fpb, index_bucket(h, ix.bmask) << 4, fb); // lands while the next position is hashed
                     hp = h;
                     tp = t;
@@ -690,7 +706,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 wave_sync();
                 const bool last = it > nIt;
                 const uint32_t qn = last ? qcount : (qcount & ~(uint32_t)(WAVE - 1)); // mid-tile: whole waves of candidates only
-                drain_queue(qn);
+                if (!RK_DBG(32)) drain_queue(qn);
                 wave_sync();
                 if (last) { qcount = 0; break; }
                 const uint32_t rem = qcount - qn; // < 64 candidates move to the front of the queue
@@ -715,7 +731,7 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
                 // bottom-S selection matters, or the hit multiset overflowed: exact answer comes from the general path
                 const bool reroute = nmins > S || flags[t] != 0;
                 const uint32_t bk = best[t];
-                if (reroute) {
+                if (reroute || RK_DBG(2)) {
                     for (int w = sl; w < geo.cwords; w += LPR) ct[w] = 0;
                     if (sl == 0) reinterpret_cast<int4*>(out4)[r0 + t] = reroute ? make_int4(-2, 0, 0, 0) : make_int4(0, (int)(bk >> 16), 0, nmins);
                     continue;
@@ -764,11 +780,21 @@ __global__ __launch_bounds__(WAVE, RK_WAVES_PER_SIMD) void k_classify_tile(const
 // saturates VALU issue at 6 waves/SIMD and loses ~11 % at 5 (measured), so tiles never grow past this.
 constexpr size_t LDS_BUDGET_6_WAVES = 6656;
 
-// RKMH_PRE_MASKED (tests: the -M classify kernel without / with the first-level filter) is read ONCE per process: a launch costs no getenv.
-// (The geometry sweeps that chose the values below ran with RKMH_TILE_* overrides; those are gone, the measurements are in profiles/.)
+// The RKMH_* knobs (A/B runs, the geometry sweeps of the test suite) are read ONCE per process: a launch costs no getenv.
 struct TileKnobs {
-    int qcap = 0, c16 = 0, sparse = 0, dset = 0, tile_t = 0, tpb = 0, xcd = -1, pre_masked = -1;
-    TileKnobs() { const char* e = getenv("RKMH_PRE_MASKED"); pre_masked = e ? atoi(e) : -1; }
+    int qcap = 0, c16 = 0, sparse = 0, dset = 0, dbg = 0, tile_t = 0, tpb = 0, xcd = -1, pre_masked = -1;
+    TileKnobs() {
+        auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        qcap = num("RKMH_TILE_QCAP", 0);
+        c16 = num("RKMH_TILE_C16", 0);
+        sparse = getenv("RKMH_TILE_SPARSE") ? (num("RKMH_TILE_SPARSE", 0) > 0 ? 1 : -1) : 0;
+        dset = num("RKMH_TILE_DSET", 0);
+        dbg = num("RKMH_DBG", 0);
+        tile_t = num("RKMH_TILE_T", 0);
+        tpb = num("RKMH_TILE_TPB", 0);
+        xcd = num("RKMH_TILE_XCD", -1);
+        pre_masked = num("RKMH_PRE_MASKED", -1);
+    }
 };
 static const TileKnobs& knobs() { static const TileKnobs k; return k; }
 
@@ -789,6 +815,7 @@ static TileGeom make_geom(int maxlen, int nref, int expect_hits, int win_per_rea
     while (ds < 3 * expect_hits && ds < 1024) ds <<= 1;
     if (kn.dset > 0) ds = kn.dset;
     g.dset = ds;
+    g.dbg = kn.dbg;
     // Reads per tile: the hashing loop walks T * win_per_read windows 64 at a time, so T is chosen for the best fill of
     // its last step (150 bp, k=16: T=3 fills 89.7 %, T=4 93.1 %) among the sizes that keep the occupancy target and
     // the short prefetch (<= 3 dwords per lane).
