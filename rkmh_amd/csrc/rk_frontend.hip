@@ -111,6 +111,15 @@ extern "C" int rk_fastq_slot_create2(rk_ctx* c, uint64_t max_bytes, int flags, r
         RKCHK(s->d_pack.reserve(max_bytes + 64));
         d.pack = s->d_pack.as<uint8_t>(); d.pack_cap = max_bytes;
         RKCHK(s->h_pack.reserve_pinned(std::max<uint64_t>((uint64_t)1 << 20, max_bytes / 20) + 64));
+        // the inflater's buffers, at the sizes rk_fastq_slot_load_bgzf asks for: made here (beside the caller's reference stage),
+        // not in front of the slot's first job
+        const uint64_t cap_text = max_bytes + 5 * 65536ull + 64, cap_mem = cap_text / 16384 + 16;
+        const size_t mem_bytes = (((size_t)cap_mem * sizeof(InflateMember) + 15) & ~(size_t)15) + (size_t)cap_mem * 8 + 64;
+        RKCHK(s->h_mem.reserve(mem_bytes));
+        RKCHK(s->d_mem.reserve(mem_bytes));
+        RKCHK(s->d_comp.reserve(cap_text * 5 / 8 + 256));
+        RKCHK(s->d_inf.reserve(cap_text));
+        RKCHK(s->d_match.reserve(cap_text * 5 / 2 + cap_mem * 32));
     }
     HIPCHK(hipMemsetAsync(s->d_u32.p, 0, n32 * 4, s->st)); // stale lengths past a block's last record must at least be defined
     HIPCHK(hipStreamSynchronize(s->st));

@@ -697,8 +697,27 @@ struct RawEngine {
         if (pieces > 1) pool.start((int)std::min<long>(16, std::max<long>(2, granted_cpus_main() - 2)));
         return true;
     }
+    // every worker's slot, each made by a thread of its own (page-locked buffers, a few GB of device memory for a device-text slot:
+    // tens of milliseconds each, and the runtime takes them one at a time) -- called while the references are still being read
+    // and sketched, so that the first blocks do not wait for it.  A slot that cannot be made is left to its worker (which reports it).
+    void create_slots(DeviceGroup& g) {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < w.size(); ++i)
+            if (!w[i].slot) th.emplace_back([this, &g, i] { rk_fastq_slot* sl = nullptr; if (rk_fastq_slot_create2(g.ctx[w[i].dev], w[i].bytes, w[i].device_text ? RK_SLOT_DEVICE_TEXT : 0, &sl) == RK_OK) w[i].slot = sl; });
+        for (auto& t : th) t.join();
+    }
     void destroy() { pool.stop(); for (auto& x : w) if (x.slot) rk_fastq_slot_destroy(x.slot); w.clear(); }
 };
+// BGZF files that go to the device: the mapping is page-locked once (14 ms per GB), the DMA engine then reads the compressed
+// members out of the page cache itself.  (Refused -- a platform limit -- the uploads go through the runtime's staging.)
+static void register_bgzf_mappings() {
+    static std::mutex rm;
+    static std::map<const rk_bgzf*, bool> registered;
+    if (!bgzf_on_device() || (getenv("RKMH_BGZF_REGISTER") && atoi(getenv("RKMH_BGZF_REGISTER")) == 0)) return;
+    std::lock_guard<std::mutex> l(rm);
+    for (auto& kv : g_bgzf)
+        if (!registered.count(kv.second)) registered[kv.second] = rk_host_register_readonly(rk_bgzf_image(kv.second), (size_t)rk_bgzf_file_bytes(kv.second)) == RK_OK;
+}
 
 // records [lo, hi) of a classified block as a result of their own (the spans index the same text)
 static rk_fastq_result sub_result(const rk_fastq_result& r, int64_t lo, int64_t hi) {
@@ -774,15 +793,7 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
                 else munmap(mp, (size_t)F.fsize);
             }
         }
-        // a BGZF file that goes to the device: its mapping is page-locked once (14 ms per GB), the DMA engine then reads the compressed
-        // members out of the page cache itself.  (Refused -- a platform limit -- the uploads go through the runtime's staging.)
-        if (F.mega) {
-            static std::mutex rm;
-            static std::map<const rk_bgzf*, bool> registered;
-            std::lock_guard<std::mutex> l(rm);
-            if (!registered.count(F.bz) && !(getenv("RKMH_BGZF_REGISTER") && atoi(getenv("RKMH_BGZF_REGISTER")) == 0))
-                registered[F.bz] = rk_host_register_readonly(rk_bgzf_image(F.bz), (size_t)rk_bgzf_file_bytes(F.bz)) == RK_OK;
-        }
+        if (F.mega) register_bgzf_mappings(); // (normally done already, beside the references)
     }
     // file: index into files; at: where the job's first record starts in the (uncompressed) text; ext: its text in the mapped file; nseq: block numbers it owns
     struct Job { size_t file = 0; int64_t seq = 0, lo = 0, hi = 0, at = 0; const uint8_t* ext = nullptr; int64_t nseq = 1; };
@@ -1326,8 +1337,8 @@ static void run_packed(DeviceGroup& g, const rk_seqset& refs, const Opts& o, con
 // RKMH_RAW_REFS=1 forces it for any size, =0 turns it off.  false: not taken (small, compressed, not regular FASTA, no memory):
 // the caller parses on the host.  On success refs carries the names only (all that stream / filter print).
 struct DeviceRefs { std::vector<char> names; std::vector<uint64_t> name_offsets; };
-static bool refs_through_device(RawEngine& eng, DeviceGroup& g, const Opts& o, int max_samples, uint64_t counter_slots, rk_seqset& refs,
-                                DeviceRefs& keep) {
+// will refs_through_device take the -r files?  (sizes, total: the files' lengths and their sum with a newline after each)
+static bool refs_for_device(const Opts& o, std::vector<int64_t>* sizes = nullptr, uint64_t* total_out = nullptr) {
     const char* env = getenv("RKMH_RAW_REFS");
     if (env && atoi(env) == 0) return false;
     const bool forced = env && atoi(env) == 1;
@@ -1338,6 +1349,15 @@ static bool refs_through_device(RawEngine& eng, DeviceGroup& g, const Opts& o, i
         total += (uint64_t)size[i] + 1; // a '\n' after every file
     }
     if (o.refs.empty() || (!forced && total < ((uint64_t)64 << 20))) return false;
+    if (sizes) *sizes = size;
+    if (total_out) *total_out = total;
+    return true;
+}
+static bool refs_through_device(RawEngine& eng, DeviceGroup& g, const Opts& o, int max_samples, uint64_t counter_slots, rk_seqset& refs,
+                                DeviceRefs& keep) {
+    std::vector<int64_t> size;
+    uint64_t total = 0;
+    if (!refs_for_device(o, &size, &total)) return false;
     eng.need_plain_workers = true;
     if (!eng.create(g)) return false;
     rk_fasta_load* load = nullptr;
@@ -1583,15 +1603,21 @@ static int main_stream(int argc, char** argv) {
     rk_ctx* ctx = group.ctx[0];
     tick("context", t0);
     // the front end's kernels (and the inflater's) are loaded while the references are sketched, not in front of the first block
+    // ... and so are the front end's workers' slots made and the BGZF mappings page-locked (unless the references themselves go
+    // through the engine: then it is made for them first)
+    RawEngine eng;       // the workers and page-locked buffers of the device front ends (created by whoever needs them first)
     std::thread warm;
-    if (any_raw && !(getenv("RKMH_WARM_UP") && atoi(getenv("RKMH_WARM_UP")) == 0))
-        warm = std::thread([&o] {
+    const bool raw_run = any_raw || (o.read_depth && all_raw && !read_map);
+    if (raw_run && !(getenv("RKMH_WARM_UP") && atoi(getenv("RKMH_WARM_UP")) == 0)) {
+        const bool prepare = !pre_refs ? !refs_for_device(o) : true;
+        warm = std::thread([&o, &eng, &group, prepare] {
             const std::vector<int> ids = o.devices.empty() ? std::vector<int>{o.device} : o.devices;
             for (int id : ids) rk_warm_up(id, !g_bgzf.empty() && bgzf_on_device());
+            if (prepare && eng.create(group)) { eng.create_slots(group); register_bgzf_mappings(); }
         });
+    }
     rk_seqset refs;
     memset(&refs, 0, sizeof refs);
-    RawEngine eng;       // the workers and page-locked buffers of the device front ends (created by whoever needs them first)
     DeviceRefs dev_refs;
     bool refs_owned = !pre_refs;
     std::string pre_names;
@@ -1778,6 +1804,15 @@ static int main_filter(int argc, char** argv) {
     double t0 = now_s();
     DeviceGroup group;
     group.create(o);
+    RawEngine eng;       // the workers and page-locked buffers of the device front ends
+    // (its slots are made and the BGZF mappings page-locked while the references are read and sketched -- unless those go through the engine themselves)
+    std::thread prep;
+    if (all_raw && !refs_for_device(o) && !(getenv("RKMH_WARM_UP") && atoi(getenv("RKMH_WARM_UP")) == 0))
+        prep = std::thread([&o, &eng, &group] {
+            const std::vector<int> ids = o.devices.empty() ? std::vector<int>{o.device} : o.devices;
+            for (int id : ids) rk_warm_up(id, !g_bgzf.empty() && bgzf_on_device());
+            if (eng.create(group)) { eng.create_slots(group); register_bgzf_mappings(); }
+        });
     // file mode compares read_min_lens with 0 (rkmh.cpp:1292); the STDIN lines print min(len) itself (:1397): exact there
     // (with -D >= 0 a read that shares nothing fails the diff test anyway, so not even min(read_min_lens, 1) is needed: bound 0)
     const int filter_bound = (o.read_depth && !in_stream) ? min_num_bound_for(o.min_diff >= 0 ? -1 : 0) : -1;
@@ -1786,7 +1821,6 @@ static int main_filter(int argc, char** argv) {
     tick("context", t0);
     rk_seqset refs;
     memset(&refs, 0, sizeof refs);
-    RawEngine eng;       // the workers and page-locked buffers of the device front ends
     DeviceRefs dev_refs;
     // reference sketches: the sample-count filter applies when max_samples < 100000 (rkmh.cpp:1211); its counter is
     // filled once per distinct hash per reference and only when -I was given (rkmh.cpp:1193, :348-355); 10 M slots (:1188)
@@ -1807,6 +1841,7 @@ static int main_filter(int argc, char** argv) {
     }
     group.share_references(o);
     tick("sketch references", t0);
+    if (prep.joinable()) prep.join();
     if (!o.packed.empty()) { // reads written by `rkmh pack`: nothing to parse
         run_packed(group, refs, o, o.packed, RAW_FILTER, 10000000ull, filter_bound, t0);
         fflush(stdout);
