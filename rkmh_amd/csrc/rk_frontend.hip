@@ -79,11 +79,16 @@ extern "C" int rk_fastq_slot_create2(rk_ctx* c, uint64_t max_bytes, int flags, r
     const uint32_t chunks = (uint32_t)((max_bytes + 4095) / 4096);
     const uint32_t rec_cap = (uint32_t)(max_bytes / 64 + 64), line_cap = 4 * rec_cap + 16;
     const bool dt = s->device_text();
+    static const bool timing = getenv("RKMH_BGZF_TIMING") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     const size_t host_recs = dt ? (size_t)(max_bytes / 256 + 4096) : (size_t)rec_cap;
     if (!dt) RKCHK(s->h_text.reserve(max_bytes + 64));
     RKCHK(s->h_out4.reserve_pinned(host_recs * 16));
     RKCHK(s->h_spans.reserve_pinned(host_recs * (dt ? 8 : 20)));
     RKCHK(s->h_info.reserve(64));
+    if (dt) RKCHK(s->h_pack.reserve_pinned(std::max<uint64_t>((uint64_t)1 << 20, max_bytes / 20) + 64));
+    const double t_pinned = ms_since(t_0);
     RKCHK(s->d_text.reserve(max_bytes + 64));
     RKCHK(s->d_bases.reserve(max_bytes + 64));
     RKCHK(s->d_out4.reserve((size_t)rec_cap * 16));
@@ -108,9 +113,9 @@ extern "C" int rk_fastq_slot_create2(rk_ctx* c, uint64_t max_bytes, int flags, r
     d.bases = s->d_bases.as<uint8_t>();
     d.scan_tmp = s->d_scan.p; d.scan_tmp_bytes = tb;
     if (dt) {
-        RKCHK(s->d_pack.reserve(max_bytes + 64));
-        d.pack = s->d_pack.as<uint8_t>(); d.pack_cap = max_bytes;
-        RKCHK(s->h_pack.reserve_pinned(std::max<uint64_t>((uint64_t)1 << 20, max_bytes / 20) + 64));
+        // (names: an eighth of the text at most -- a block with more is left to the host scanner; the records filter prints may be all of it: rk_fastq_slot_set_filter_output)
+        RKCHK(s->d_pack.reserve(max_bytes / 8 + 64));
+        d.pack = s->d_pack.as<uint8_t>(); d.pack_cap = max_bytes / 8;
         // the inflater's buffers, at the sizes rk_fastq_slot_load_bgzf asks for: made here (beside the caller's reference stage),
         // not in front of the slot's first job
         const uint64_t cap_text = max_bytes + 5 * 65536ull + 64, cap_mem = cap_text / 16384 + 16;
@@ -119,10 +124,13 @@ extern "C" int rk_fastq_slot_create2(rk_ctx* c, uint64_t max_bytes, int flags, r
         RKCHK(s->d_mem.reserve(mem_bytes));
         RKCHK(s->d_comp.reserve(cap_text * 5 / 8 + 256));
         RKCHK(s->d_inf.reserve(cap_text));
-        RKCHK(s->d_match.reserve(cap_text * 5 / 2 + cap_mem * 32));
+        RKCHK(s->d_match.reserve(cap_text * 4 / 3 + cap_mem * 32 + 64));
     }
+    const double t_device = ms_since(t_0) - t_pinned;
     HIPCHK(hipMemsetAsync(s->d_u32.p, 0, n32 * 4, s->st)); // stale lengths past a block's last record must at least be defined
     HIPCHK(hipStreamSynchronize(s->st));
+    if (timing && dt) fprintf(stderr, "[bgzf device] slot of %.0f MB: page-locked arrays %.1f ms, device arrays %.1f ms, clear %.1f ms\n", (double)max_bytes / 1e6, t_pinned, t_device,
+                              ms_since(t_0) - t_pinned - t_device);
     guard.s = nullptr;
     *out = s;
     return RK_OK;
@@ -133,6 +141,12 @@ extern "C" uint8_t* rk_fastq_slot_text(rk_fastq_slot* s) { return s ? s->h_text.
 extern "C" const uint8_t* rk_fastq_slot_spans_base(const rk_fastq_slot* s) { return s ? s->spans_base : nullptr; }
 extern "C" int rk_fastq_slot_set_filter_output(rk_fastq_slot* s, int min_matches, int min_diff) {
     if (!s || !s->device_text()) return fail(RK_ERR_ARG, "rk_fastq_slot_set_filter_output: a slot created with RK_SLOT_DEVICE_TEXT is needed");
+    if (s->d.pack_cap < s->max_bytes) {
+        RKCHK(set_dev(s->c));
+        HIPCHK(hipStreamSynchronize(s->st));
+        RKCHK(s->d_pack.reserve(s->max_bytes + 64));
+        s->d.pack = s->d_pack.as<uint8_t>(); s->d.pack_cap = s->max_bytes;
+    }
     s->pack_filter = true; s->min_matches = min_matches; s->min_diff = min_diff;
     return RK_OK;
 }
@@ -197,7 +211,7 @@ extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64
         scratch_dw += inflate_scratch_dwords(us);
     }
     if (scratch_dw >= ((uint64_t)1 << 32)) return 1;
-    RKCHK(s->d_match.reserve(std::max<uint64_t>(scratch_dw * 4 + 64, cap_text * 5 / 2 + cap_mem * 32)));
+    RKCHK(s->d_match.reserve(std::max<uint64_t>(scratch_dw * 4 + 64, cap_text * 4 / 3 + cap_mem * 32 + 64)));
     const double t_reserve = ms_since(t_0);
     // the compressed bytes: by DMA from where the file is mapped when the caller page-locked the mapping, else through the
     // runtime's own staging of pageable memory (no page-locked copy of ours: that buffer would be as large as the job)

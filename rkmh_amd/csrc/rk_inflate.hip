@@ -44,7 +44,7 @@ constexpr int K_SYM = 8, K_HDR = 8;           // symbol steps / header steps (in
 constexpr uint32_t HDR_EVERY = 64;            // periods between header windows (a power of two)
 constexpr int HDR_LANES = 12;                 // ... unless this many lanes wait
 constexpr uint32_t E_INVALID = 0x0FFFu;       // table entry: code length << 12 | symbol; length 0: E_INVALID, or a long code's prefix
-constexpr uint32_t WIN_BYTES = 65536;
+constexpr uint32_t WIN_BYTES = 65536;       // a member's text at most (pass 1 hands larger ones to the host)
 
 __device__ const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
@@ -87,7 +87,11 @@ __device__ __forceinline__ void isync() {
 }
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t n) { return __builtin_bitreverse32(v) >> (32u - n); }
 __device__ __forceinline__ uint32_t lanes_below(uint64_t m, int lane) { return (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); }
-__device__ __host__ __forceinline__ uint32_t entry_cap(uint32_t out_len) { return out_len / 3u + out_len / 255u + 4u; }
+// A member's part of the scratch buffer, in dwords.  Entries (one dword each) grow UP from its first dword, the literal stream (four
+// literals per dword) grows DOWN from its last: a match entry stands for >= 3 bytes of text, a literal for one, so the two together
+// never need more than out_len / 3 + 2 dwords (all matches of length 3: out_len / 3 entries, no literals; every literal more takes a
+// byte of text from the matches) -- 1.34 bytes per byte of text instead of the 2.35 of two separate worst-case regions.
+__device__ __host__ __forceinline__ uint32_t scratch_dwords(uint32_t out_len) { return out_len / 3u + 8u; }
 
 // The wave builds stream t's canonical Huffman table from lens[(at + s) * 64 + t], s < n: root table of 2^TB entries, counts per
 // length above the root (limit | offset, see LaneLds), the long-coded symbols in canonical order.  NCH = chunks of 64 symbols.  False:
@@ -158,7 +162,7 @@ struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };
 
 } // namespace
 
-// Pass 1.  scratch: per member at dword me.match_off: entry_cap(out_len) entries, then the literal stream.
+// Pass 1.  scratch: per member at dword me.match_off: scratch_dwords(out_len) dwords -- entries from the front, the literal stream from the back.
 // status[m]: 0 ok, else why the member is the host's; status[nmem + m] = its entries | its literals << 15.
 template <int LT, int DT>
 __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict__ comp, uint32_t comp_bytes, const InflateMember* __restrict__ mem, uint32_t nmem,
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
     { const uint32_t have = (comp_bytes >> 2) > w0 ? (comp_bytes >> 2) - w0 : 0u; if (in_lim > have) in_lim = have; }
     in_lim &= ~3u; // (whole 16-byte requests; the 32 bytes above leave the deflate data and two more dwords inside them)
     uint32_t* const ents = scratch + me.match_off;
-    uint32_t* const lits = ents + entry_cap(me.out_len);
+    uint32_t* const lits_top = ents + (scratch_dwords(me.out_len) - 1u); // literal dword d lives at lits_top[-d]
     uint64_t bb = 0;
     uint32_t nb = 0, in_r = 0, in_w = 0;
     uint32_t state = live ? ST_BLOCK : ST_FIN, bad = 0, need_build = 0;
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
         if (bad) ent_f = ent_w;
 #pragma unroll
         for (int f = 0; f < 2; ++f)
-            if (out_f < out_target) { lits[out_f] = L.outr[(out_f & (OUT_RING - 1)) * IW + lane]; ++out_f; }
+            if (out_f < out_target) { *(lits_top - out_f) = L.outr[(out_f & (OUT_RING - 1)) * IW + lane]; ++out_f; }
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             if (__ballot(ent_f < ent_w) == 0ull) break;
@@ -472,22 +476,27 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
     if (live) { status[m] = bad; status[nmem + m] = bad ? 0u : ent_w | (lit_n << 15); } // (at most 22 106 entries, 65 536 literals)
 }
 
-// Pass 2: the member's text built in a 64 KB LDS window from its literal stream and its entries.
+// Pass 2: the member's text built in LDS from its literal stream and its entries, and written out as it becomes final.
 // Round 5's form took one batch of 64 entries at a time straight from global memory -- entries, then (their place known) literals: two
-// dependent round trips per batch, ~5 us each, with two waves per CU to hide them: 1 ms per member, as long as pass 1.  Now the
-// inputs come in bulk: 1 024 entries and 4 KB of the literal stream are staged in LDS together (one round trip per ~5 KB of text,
-// every load in flight at once); a batch then works on LDS alone:
-//   * one packed prefix sum (DPP) places every literal run and match of the batch;
-//   * a lane copies its own run (the first 8 bytes; longer runs are finished by the whole wave, one after the other);
-//   * matches resolve in ROUNDS behind a frontier: F = the first unresolved match -- everything below its start is final, so every
-//     match whose source ends there (and F itself, whose source may overlap its own output) is copied now, a lane each, long ones
-//     (>= 24 bytes, runs of one repeated byte above all) by the whole wave.  Three quarters of the matches of level-1 FASTQ go in
-//     the first round.
-// The window is addressed like the text (window byte k <-> address of the text - its low four bits + k), so it leaves through
+// dependent round trips per batch, ~5 us each -- in a 64 KB window, two members per CU: 1 ms per member, as long as pass 1.  Now:
+//   * the inputs come in bulk: 512 entries and 1.5 KB of the literal stream are staged in LDS together (every load in flight at once);
+//   * one packed prefix sum (DPP) places every literal run and match of a batch; a lane copies its own run (the first 8 bytes, from
+//     one 8-byte read of the stage; longer runs are finished by the whole wave); matches resolve in ROUNDS behind a frontier:
+//     F = the first unresolved match -- everything below its start is final, so every match whose source ends there (and F itself,
+//     whose source may overlap its own output) is copied now, a lane each (three 8-byte reads, then stores that wait for nothing),
+//     long ones by the whole wave.  Level-1 FASTQ takes ~7 rounds per batch;
+//   * the window is 35 KB, not 64: a match reaches at most 32 KB back, so once a batch is final its 16-byte groups leave for global
+//     memory and window index k >= P2_R reuses the place of k - P2_R (a batch is cut so that it spans < P2_R - 32 KB).  39.5 KB of
+//     LDS per member: FOUR members per CU (or two beside a pass-1 wave) instead of two -- the kernel is bound by the latency of its
+//     dependent LDS steps, not by any throughput, so members in flight are what it scales with.
+// The window is addressed like the text (window index k <-> address of the text - its low four bits + k), so it leaves through
 // aligned 16-byte LDS reads and global stores.
 struct __attribute__((packed, aligned(1))) lds_u64 { uint64_t v; }; // eight bytes at any LDS address (gfx950 runs with unaligned DS access)
-constexpr int P2_SB = 1024;   // entries staged at a time
-constexpr int P2_LIT = 4096;  // literal bytes staged at a time (+ 4: the stage begins at a dword boundary)
+constexpr int P2_SB = 512;                 // entries staged at a time
+constexpr int P2_LIT = 1536;               // literal bytes staged at a time (+ 4: the stage begins at a dword boundary)
+constexpr uint32_t P2_R = 35840;           // window bytes (a multiple of 16): index k and k + P2_R share a place
+constexpr uint32_t P2_SPAN = 2816;         // most bytes a batch may produce: P2_R > 32768 + P2_SPAN + 16
+static_assert(P2_R % 16 == 0 && P2_R > 32768 + P2_SPAN + 16 && P2_SPAN >= 513, "a batch's sources must outlive the batch; one entry always fits");
 __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1 (a lane without a source adds 0)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
@@ -499,7 +508,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
 }
 __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __restrict__ mem, uint32_t nmem, uint8_t* __restrict__ text, const uint32_t* __restrict__ scratch,
                                                       const uint32_t* __restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint8_t win[WIN_BYTES + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t win[P2_R + 16];
     __shared__ uint32_t s_ent[P2_SB];
     __shared__ __attribute__((aligned(16))) uint32_t s_lit[P2_LIT / 4 + 4];
     const int lane = threadIdx.x;
@@ -509,71 +518,81 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __res
     const InflateMember me = mem[m];
     const uint32_t n = me.out_len;
     const uint32_t* const ents = scratch + me.match_off;
-    const uint32_t* const lits32 = ents + entry_cap(n);
-    const uint8_t* const lits8 = reinterpret_cast<const uint8_t*>(lits32);
+    const uint32_t* const lits_top = ents + (scratch_dwords(n) - 1u); // literal dword d lives at lits_top[-d] (pass 1)
+    auto lit_global = [&](uint32_t idx) -> uint8_t { return (uint8_t)(*(lits_top - (idx >> 2)) >> (8u * (idx & 3u))); };
     uint8_t* const dst = text + me.out_off;
     const uint32_t wb = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u); // window index of the text's first byte
-    uint8_t* const w = win + wb;
+    uint8_t* const a0 = dst - wb;                                            // address of window index 0 (16-byte aligned)
     const uint8_t* const sl8 = reinterpret_cast<const uint8_t*>(s_lit);
-    uint32_t op0 = 0, lp0 = 0;
+    auto wi = [](uint32_t k) -> uint32_t { return k >= P2_R ? k - P2_R : k; }; // place of window index k (k < 2 P2_R: a member is at most 64 KB)
+    uint32_t kp = wb, lp0 = 0;           // window index of the next output byte; position in the literal stream
+    uint32_t flushed = 0;                // window indices below it are in global memory (a multiple of 16, or the head's end)
     uint32_t lit_base = 0, lit_have = 0; // s_lit holds the literal bytes [lit_base, lit_base + lit_have)
     constexpr uint32_t LIT_DW = P2_LIT / 4 + 1, LIT_K = (LIT_DW + IW - 1) / IW;
+    const uint32_t lit_dw_end = (nlit + 3u) >> 2; // dwords pass 1 wrote
+    auto stage_lits = [&]() { // the literal stream from where it stands (wave-uniform call)
+        uint32_t lv[LIT_K];
+        lit_base = lp0 & ~3u;
+#pragma unroll
+        for (uint32_t k = 0; k < LIT_K; ++k) { const uint32_t i = (uint32_t)lane + IW * k, d = (lit_base >> 2) + i; lv[k] = (i < LIT_DW && d < lit_dw_end) ? *(lits_top - d) : 0u; }
+        isync(); // (earlier batches have read their literals)
+#pragma unroll
+        for (uint32_t k = 0; k < LIT_K; ++k) { const uint32_t i = (uint32_t)lane + IW * k; if (i < LIT_DW) s_lit[i] = lv[k]; }
+        lit_have = nlit - lit_base < LIT_DW * 4u ? nlit - lit_base : LIT_DW * 4u;
+        isync();
+    };
+    // whole 16-byte groups below window index `upto` leave (what is below the current batch is final)
+    auto flush_to = [&](uint32_t upto) {
+        if (flushed == 0u && wb != 0u && upto >= 16u) { // the first group holds bytes in front of the text: its text bytes one by one
+            if ((uint32_t)lane >= wb && lane < 16) a0[lane] = win[lane];
+            flushed = 16u;
+        }
+        const uint32_t hi = upto & ~15u;
+        for (uint32_t k = flushed + 16u * (uint32_t)lane; k < hi; k += 16u * IW) *reinterpret_cast<uint4*>(a0 + k) = *reinterpret_cast<const uint4*>(win + wi(k));
+        if (hi > flushed) flushed = hi;
+    };
     for (uint32_t e0 = 0; e0 < nent; e0 += P2_SB) {
         const uint32_t ne = nent - e0 < (uint32_t)P2_SB ? nent - e0 : (uint32_t)P2_SB;
-        { // stage: the entries of this stretch and the literal stream from where it stands -- all loads first, then the stores
-            uint32_t ev[P2_SB / IW], lv[LIT_K];
-            lit_base = lp0 & ~3u;
-            const uint32_t lit_dw_end = (nlit + 3u) >> 2; // dwords pass 1 wrote
+        { // stage the entries of this stretch, and the literals again from where the stream stands
+            uint32_t ev[P2_SB / IW];
 #pragma unroll
             for (int k = 0; k < P2_SB / IW; ++k) { const uint32_t i = (uint32_t)lane + IW * k; ev[k] = i < ne ? ents[e0 + i] : 0u; }
-#pragma unroll
-            for (uint32_t k = 0; k < LIT_K; ++k) { const uint32_t i = (uint32_t)lane + IW * k, d = (lit_base >> 2) + i; lv[k] = (i < LIT_DW && d < lit_dw_end) ? lits32[d] : 0u; }
-            isync(); // (the previous stretch's last batch has read its literals)
+            isync();
 #pragma unroll
             for (int k = 0; k < P2_SB / IW; ++k) s_ent[lane + IW * k] = ev[k];
-#pragma unroll
-            for (uint32_t k = 0; k < LIT_K; ++k) { const uint32_t i = (uint32_t)lane + IW * k; if (i < LIT_DW) s_lit[i] = lv[k]; }
-            lit_have = nlit - lit_base < LIT_DW * 4u ? nlit - lit_base : LIT_DW * 4u;
-            isync();
+            stage_lits();
         }
-        for (uint32_t q0 = 0; q0 < ne; q0 += IW) {
+        for (uint32_t q0 = 0; q0 < ne;) {
             const uint32_t e = q0 + (uint32_t)lane < ne ? s_ent[q0 + lane] : 0u;
-            const uint32_t run = e & 255u, len = (e >> 8) & 511u, dist = (e >> 17) + 1u;
+            uint32_t run = e & 255u, len = (e >> 8) & 511u;
+            const uint32_t dist = (e >> 17) + 1u;
             // inclusive sums over the lanes, both in one word: literals (< 2^14) | literals + match bytes (< 2^16) << 16
-            const uint32_t sc = wave_incl_scan_add(run | ((run + len) << 16));
+            uint32_t sc = wave_incl_scan_add(run | ((run + len) << 16));
+            // the batch = the leading entries that produce at most P2_SPAN bytes together (the first one always does)
+            const uint32_t take = (uint32_t)__popcll(__ballot((sc >> 16) <= P2_SPAN));
+            if ((uint32_t)lane >= take) { run = 0; len = 0; }
             const uint32_t r = sc & 0xFFFFu, t = sc >> 16;
-            const uint32_t tot_r = (uint32_t)__builtin_amdgcn_readlane((int)r, IW - 1), tot_t = (uint32_t)__builtin_amdgcn_readlane((int)t, IW - 1);
-            if (op0 + tot_t > n || lp0 + tot_r > nlit) return; // (pass 1 checked every entry against out_len: unreachable for its output)
-            const uint32_t at = op0 + t - len;     // where this lane's match begins; its run ends there
+            const uint32_t tot_r = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)take - 1), tot_t = (uint32_t)__builtin_amdgcn_readlane((int)t, (int)take - 1);
+            if (kp - wb + tot_t > n || lp0 + tot_r > nlit) return; // (pass 1 checked every entry against out_len: unreachable for its output)
+            const uint32_t at = kp + t - len;      // window index where this lane's match begins; its run ends there (lanes past the batch: unused)
             const uint32_t lsrc = lp0 + r - run;   // its run's first byte in the literal stream
             // the batch's literals: from the stage, which moves up when the batch reaches past it (a batch with more literals than
             // the stage holds -- an all-literal stretch -- reads them from global memory where they lie)
             bool direct = false;
             if (lp0 + tot_r > lit_base + lit_have) { // wave-uniform
-                if (tot_r + 3u <= (uint32_t)P2_LIT) {
-                    uint32_t lv[LIT_K];
-                    lit_base = lp0 & ~3u;
-                    const uint32_t lit_dw_end = (nlit + 3u) >> 2;
-#pragma unroll
-                    for (uint32_t k = 0; k < LIT_K; ++k) { const uint32_t i = (uint32_t)lane + IW * k, d = (lit_base >> 2) + i; lv[k] = (i < LIT_DW && d < lit_dw_end) ? lits32[d] : 0u; }
-                    isync();
-#pragma unroll
-                    for (uint32_t k = 0; k < LIT_K; ++k) { const uint32_t i = (uint32_t)lane + IW * k; if (i < LIT_DW) s_lit[i] = lv[k]; }
-                    lit_have = nlit - lit_base < LIT_DW * 4u ? nlit - lit_base : LIT_DW * 4u;
-                    isync();
-                } else direct = true;
+                if (tot_r + 3u <= (uint32_t)P2_LIT) stage_lits(); else direct = true;
             }
-            auto lit = [&](uint32_t idx) -> uint8_t { return direct ? lits8[idx] : sl8[idx - lit_base]; };
+            auto lit = [&](uint32_t idx) -> uint8_t { return direct ? lit_global(idx) : sl8[idx - lit_base]; };
             // literal runs: the first 8 bytes by the run's own lane (one 8-byte read of the stage, byte stores that wait for nothing) ...
             {
                 const uint32_t o = at - run;
                 if (direct) {
 #pragma unroll
-                    for (uint32_t b = 0; b < 8u; ++b) if (b < run) w[o + b] = lits8[lsrc + b];
+                    for (uint32_t b = 0; b < 8u; ++b) if (b < run) win[wi(o + b)] = lit_global(lsrc + b);
                 } else {
-                    const uint64_t v = reinterpret_cast<const lds_u64*>(sl8 + (lsrc - lit_base))->v; // (the stage is followed by 12 spare bytes)
+                    const uint64_t v = reinterpret_cast<const lds_u64*>(sl8 + (run ? lsrc - lit_base : 0u))->v; // (the stage is followed by 12 spare bytes)
 #pragma unroll
-                    for (uint32_t b = 0; b < 8u; ++b) if (b < run) w[o + b] = (uint8_t)(v >> (8u * b));
+                    for (uint32_t b = 0; b < 8u; ++b) if (b < run) win[wi(o + b)] = (uint8_t)(v >> (8u * b));
                 }
             }
             // ... the rest of a longer run by the whole wave
@@ -581,7 +600,7 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __res
                 const int j = __builtin_ctzll(lm);
                 const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)run, j), oj = (uint32_t)__builtin_amdgcn_readlane((int)at, j) - rj,
                                sj = (uint32_t)__builtin_amdgcn_readlane((int)lsrc, j);
-                for (uint32_t i = 8u + (uint32_t)lane; i < rj; i += IW) w[oj + i] = lit(sj + i);
+                for (uint32_t i = 8u + (uint32_t)lane; i < rj; i += IW) win[wi(oj + i)] = lit(sj + i);
             }
             isync();
             // matches, in rounds behind the frontier
@@ -589,22 +608,25 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __res
                 const int F = __builtin_ctzll(um);
                 const uint32_t atF = (uint32_t)__builtin_amdgcn_readlane((int)at, F);
                 const bool mine = ((um >> lane) & 1ull) != 0ull && (at - dist + len <= atF || lane == F);
+                const uint32_t ks = at - dist; // window index of the source
+                // a copy that would touch both sides of the wrap at P2_R (source or destination; one match in a thousand) goes byte by byte
+                const bool wrap = (ks < P2_R && ks + 24u > P2_R) || (at < P2_R && at + len > P2_R);
                 for (uint64_t lm = __ballot(mine && len >= 24u); lm; lm &= lm - 1ull) { // long: 64 lanes per copy; a source that overlaps its output repeats with period dist
                     const int j = __builtin_ctzll(lm);
                     const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)at, j), ln = (uint32_t)__builtin_amdgcn_readlane((int)len, j),
                                    ds = (uint32_t)__builtin_amdgcn_readlane((int)dist, j);
-                    if (ds >= ln) { for (uint32_t i = (uint32_t)lane; i < ln; i += IW) w[o + i] = w[o - ds + i]; }
-                    else { for (uint32_t i = (uint32_t)lane; i < ln; i += IW) w[o + i] = w[o - ds + i % ds]; }
+                    if (ds >= ln) { for (uint32_t i = (uint32_t)lane; i < ln; i += IW) win[wi(o + i)] = win[wi(o - ds + i)]; }
+                    else { for (uint32_t i = (uint32_t)lane; i < ln; i += IW) win[wi(o + i)] = win[wi(o - ds + i % ds)]; }
                 }
                 // short and apart from its source (all of them but, at most, F): the source in three 8-byte reads, then stores that
                 // wait for nothing -- a byte-by-byte copy pays the LDS round trip twice per byte
-                const bool sh = mine && len < 24u && dist >= len;
+                const bool sh = mine && len < 24u && dist >= len && !wrap;
                 {
-                    const uint8_t* const sp = w + (sh ? at - dist : 0u);
+                    const uint8_t* const sp = win + (sh ? wi(ks) : 0u);
                     uint64_t r0 = reinterpret_cast<const lds_u64*>(sp)->v;
                     const uint64_t r1 = reinterpret_cast<const lds_u64*>(sp + 8)->v, r2 = reinterpret_cast<const lds_u64*>(sp + 16)->v;
                     if (sh) {
-                        uint8_t* dp = w + at;
+                        uint8_t* dp = win + wi(at);
                         uint32_t left = len;
                         if (left >= 8u) { reinterpret_cast<lds_u64*>(dp)->v = r0; dp += 8; left -= 8u; r0 = r1; }
                         if (left >= 8u) { reinterpret_cast<lds_u64*>(dp)->v = r0; dp += 8; left -= 8u; r0 = r2; }
@@ -612,24 +634,28 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __res
                         for (uint32_t b = 0; b < 7u; ++b) if (b < left) dp[b] = (uint8_t)(r0 >> (8u * b));
                     }
                 }
-                // short and overlapping its own output (F only: a repeat with a period below its length): byte after byte
-                const bool ov = mine && len < 24u && dist < len;
-                if (__ballot(ov) != 0ull) { if (ov) for (uint32_t i = 0; i < len; ++i) w[at + i] = w[at - dist + i]; }
+                // short and overlapping its own output (F only: a repeat with a period below its length), or across the wrap: byte after byte
+                const bool ov = mine && len < 24u && (dist < len || wrap);
+                if (__ballot(ov) != 0ull) { if (ov) for (uint32_t i = 0; i < len; ++i) win[wi(at + i)] = win[wi(ks + i)]; }
                 um &= ~__ballot(mine);
                 isync();
             }
-            op0 += tot_t; lp0 += tot_r;
+            kp += tot_t; lp0 += tot_r; q0 += take;
+            flush_to(kp);
         }
     }
     isync();
-    // the window leaves: whole aligned 16-byte pieces, single bytes at the two ends
-    uint8_t* const a0 = dst - wb;
-    const uint32_t endk = wb + n, c0 = wb ? 1u : 0u, c1 = endk >> 4;
-    for (uint32_t c = c0 + (uint32_t)lane; c < c1; c += IW) *reinterpret_cast<uint4*>(a0 + 16u * c) = *reinterpret_cast<const uint4*>(win + 16u * c);
-    const uint32_t hb = 16u * c0 < endk ? 16u * c0 : endk;           // head bytes [wb, hb)
-    const uint32_t tb = 16u * c1 > hb ? 16u * c1 : hb;               // tail bytes [tb, endk)
-    if (wb + (uint32_t)lane < hb) a0[wb + lane] = win[wb + lane];
-    if (tb + (uint32_t)lane < endk) a0[tb + lane] = win[tb + lane];
+    // what is left: the head (a text that ends inside the first group), the last whole groups, the tail bytes
+    const uint32_t endk = wb + n;
+    if (flushed == 0u && wb != 0u) {
+        const uint32_t hb = endk < 16u ? endk : 16u;
+        if ((uint32_t)lane >= wb && (uint32_t)lane < hb) a0[lane] = win[lane];
+        flushed = hb;
+    }
+    if (flushed < endk) {
+        flush_to(endk);
+        if (flushed + (uint32_t)lane < endk) a0[flushed + lane] = win[wi(flushed + lane)];
+    }
 }
 
 // The members' CRC-32 (gzread checks it for every member the reference reads, /root/reference/src/rkmh.cpp:238-263): one wave per
@@ -692,7 +718,7 @@ __global__ __launch_bounds__(256) void k_fastq_first_start(const uint8_t* __rest
     }
 }
 
-uint32_t inflate_scratch_dwords(uint32_t out_len) { return entry_cap(out_len) + out_len / 4u + 2u; }
+uint32_t inflate_scratch_dwords(uint32_t out_len) { return scratch_dwords(out_len); }
 hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint32_t* scratch, uint32_t* status,
                                   hipStream_t st) {
     if (!nmem) return hipSuccess;

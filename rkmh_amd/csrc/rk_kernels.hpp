@@ -143,7 +143,7 @@ hipError_t launch_fasta_compact(const FaDev& d, const uint8_t* raw, uint64_t nby
 hipError_t launch_fasta_names(const FaDev& d, const uint8_t* raw, uint64_t nrec, hipStream_t st);
 // ---- DEFLATE on the device for BGZF members (rk_inflate.hip): pass 1 one lane per member, pass 2 one wave per member ----
 // deflate payload in the compressed buffer (which has 64 readable bytes beyond the last member); text in the output buffer;
-// match_off = first dword of the member's part of `scratch` (inflate_scratch_dwords(out_len) dwords: its entries, then its literals)
+// match_off = first dword of the member's part of `scratch` (inflate_scratch_dwords(out_len) dwords: its entries from the front, its literals from the back)
 struct InflateMember { uint32_t in_off, in_len, out_off, out_len, match_off, pad; };
 uint32_t inflate_scratch_dwords(uint32_t out_len);
 // status[0 .. nmem) = 0 / why the member could not be inflated, status[nmem .. 2 nmem) = its entries
