@@ -894,10 +894,9 @@ static int host_pipeline(rk_ctx* c, const uint8_t* bases, const uint64_t* offset
     RKCHK(set_dev(c));
     // reads per chunk: the last chunk's kernel and D2H are not overlapped with anything, and a chunk's H2D cannot start before the
     // chunk two places earlier has left its slot, so shorter chunks finish sooner.  Measured (150 bp reads from page-locked buffers;
-    // chunks of 2 M / 512 k / 128 k reads): 4 M reads 278 / 292 / 252 M reads/s, 16 M reads 300 / 313 M reads/s.  RKMH_CHUNK_READS overrides.
+    // chunks of 2 M / 512 k / 128 k reads): 4 M reads 278 / 292 / 252 M reads/s, 16 M reads 300 / 313 M reads/s.  (Fixed: the override this was measured with is gone.)
     // (The count pass keeps chunks of 2 M reads: its slot-partitioned form streams the whole table once per launch, rk_count.hip.)
-    static const int64_t CHUNK_ENV = [] { const char* e = getenv("RKMH_CHUNK_READS"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 4096 ? v : 0); }();
-    const int64_t MAX_READS = CHUNK_ENV ? CHUNK_ENV : (mode == 1 ? (int64_t)1 << 21 : (int64_t)1 << 19);
+    const int64_t MAX_READS = mode == 1 ? (int64_t)1 << 21 : (int64_t)1 << 19;
     const uint64_t MAX_BASES = 1ull << 29;
     bool src_pinned = nreads > 0 && caller_pinned_host(bases + offsets[0], (size_t)(offsets[nreads] - offsets[0]) + 4);
     bool out_pinned = mode == 0 && nreads > 0 && caller_pinned_host(out4, (size_t)nreads * 16);

@@ -111,8 +111,7 @@ static void build_kpost(const std::vector<uint32_t>& post, int R, std::vector<ui
             else if (i == d.e.size() || B[j] < d.e[i].first) { exception(B[j], true); ++j; }
             else { ++i; ++j; }
         }
-        static const bool inline_ok = !(getenv("RKMH_KBASE_INLINE") && atoi(getenv("RKMH_KBASE_INLINE")) == 0);
-        if (inline_ok && nex <= 8 && small_refs) {
+        if (nex <= 8 && small_refs) {
             d.ix = 0xE0000000u | ((uint32_t)best << 26) | (nex << 22) | ex[0] | (ex[1] << 10);
             d.iy = ex[2] | (ex[3] << 10) | (ex[4] << 20);
             d.iw = ex[5] | (ex[6] << 10) | (ex[7] << 20);
@@ -211,8 +210,7 @@ int build_index(rk_ctx* c) {
     for (size_t i = 0; i < pairs.size(); ++i) if (i == 0 || pairs[i].h != pairs[i - 1].h) ++distinct;
     // bucketed table: 8 slots per bucket, at most 2.5 keys per bucket on average (P(more than 8) ~ 0.1 %)
     uint32_t nb = 256, lg = 8;
-    size_t load_pct = 250;
-    if (const char* e = getenv("RKMH_INDEX_LOAD")) { long v = atol(e); if (v >= 10 && v <= 700) load_pct = (size_t)v; }
+    const size_t load_pct = 250;
     while ((size_t)nb * load_pct < distinct * 100 + 100) { nb <<= 1; ++lg; }
     const uint32_t size = nb * IDX_SLOTS;
     std::vector<uint16_t> fpb(size, 0);
@@ -242,8 +240,7 @@ int build_index(rk_ctx* c) {
             // counters, four (or two) references per LDS word: in ascending order the 16 lanes of a step meet four by four in one word
             // (the genomes of one family have consecutive ids) and the LDS serves them one after the other.  Ordered by
             // (ref mod 4, ref) a step's postings fall into 16 different words instead.
-            static const bool spread = !(getenv("RKMH_POST_ORDER") && atoi(getenv("RKMH_POST_ORDER")) == 0);
-            if (spread) std::stable_sort(grp.begin(), grp.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return (a.first & 3u) < (b.first & 3u); });
+            std::stable_sort(grp.begin(), grp.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return (a.first & 3u) < (b.first & 3u); });
             for (auto& g : grp) { post.push_back(g.first); post.push_back(g.second); }
         }
         uint32_t b = index_bucket(pairs[i].h, bmask);
@@ -294,13 +291,12 @@ int build_index(rk_ctx* c) {
     // 32 bits per key where that fits in 1 MB -- measured at C2 (163 k keys): 256 KB 0.976 ms, 512 KB 0.959, 1 MB 0.953,
     // 2 MB 0.997 (the filter then crowds the reads and the table out of the 4 MB L2); at 10^6 keys 1 MB beats 2 MB (1.07 vs
     // 1.12 ms) although one window in twenty then passes by chance; only beyond 2 * 10^6 keys does 2 MB win (4 * 10^6
-    // keys: 1 MB 2.28 ms, 2 MB 1.77, 4 MB 1.99).  RKMH_PRE_BITS / RKMH_PRE_MAXKB override both numbers.
+    // keys: 1 MB 2.28 ms, 2 MB 1.77, 4 MB 1.99).  (RKMH_PRE_MAXKB overrides the cap: tests.)
     c->ix.pre = nullptr; c->ix.pmask = 0;
     int pre_mode = 1;
     if (const char* e = getenv("RKMH_PREFILTER")) pre_mode = atoi(e);
     if (pre_mode > 0) {
         size_t bits_per_key = 32, max_words = (size_t)(distinct > 2000000 ? 2048 : 1024) * 256;
-        if (const char* e = getenv("RKMH_PRE_BITS")) { long v = atol(e); if (v >= 2 && v <= 256) bits_per_key = (size_t)v; }
         if (const char* e = getenv("RKMH_PRE_MAXKB")) { long v = atol(e); if (v >= 16 && v <= (1 << 20)) max_words = (size_t)v * 256; }
         uint32_t pwords = 1u << 12;
         while ((size_t)pwords * 32 < distinct * bits_per_key && (size_t)pwords * 2 <= max_words) pwords <<= 1;
@@ -318,8 +314,7 @@ int build_index(rk_ctx* c) {
     memset(&c->ksets, 0, sizeof c->ksets);
     static const int kmer_env = getenv("RKMH_KMER_PREFILTER") ? atoi(getenv("RKMH_KMER_PREFILTER")) : -1;
     const int kmer_mode = kmer_env >= 0 ? kmer_env : (pre_mode > 0 ? 1 : 0);
-    static const long kmer_max_keys_env = getenv("RKMH_KPRE_MAXKEYS") ? atol(getenv("RKMH_KPRE_MAXKEYS")) : -1;
-    const size_t kmer_max_keys = kmer_max_keys_env >= 0 ? (size_t)kmer_max_keys_env : 6000000;
+    const size_t kmer_max_keys = 6000000;
     bool all_k_ok = kmer_mode > 0 && c->kmer_form_allowed && c->ks.n >= 1 && c->ks.n <= KM_MAX_KS && distinct <= kmer_max_keys;
     // one k of 17 .. 20 (wide k-mers, 64-bit): the 4^k enumeration takes 0.1 s (k = 17), 0.4 s (18), 1.7 s (19), 6.7 s (20) -- done unasked
     // up to RKMH_KMER_ENUM_MAXK (default 18); beyond that only with a cache file (rk_set_kmer_cache): from it, or -- once -- into it
@@ -474,7 +469,7 @@ int build_index(rk_ctx* c) {
             }
             const uint32_t kbits = 2u * (uint32_t)k;
             uint32_t b = 12;
-            static const double km2_load = getenv("RKMH_KM2_LOAD") ? atof(getenv("RKMH_KM2_LOAD")) : 0.65;
+            const double km2_load = 0.65;
             while (b < 26 && (double)found > km2_load * 4.0 * (double)((size_t)1 << b)) ++b;
             std::vector<uint32_t> c1;
             bool placed_all = false;
@@ -535,7 +530,7 @@ int build_index(rk_ctx* c) {
             uint32_t nsect = 0;
             {
                 static const double kf4_entries = getenv("RKMH_KF4_ENTRIES") ? atof(getenv("RKMH_KF4_ENTRIES")) : 0.0; // forced density (A/B runs)
-                static const double km1_load_est = getenv("RKMH_KM1_LOAD") ? atof(getenv("RKMH_KM1_LOAD")) : 0.65;
+                const double km1_load_est = 0.65;
                 uint32_t be = 2u * (uint32_t)k < 12u ? 2u * (uint32_t)k : 12u;           // the map's size, as its builder below will choose it
                 while (be < 2u * (uint32_t)k && be < 28 && (double)found > km1_load_est * 4.0 * (double)((size_t)1 << be)) ++be;
                 const size_t map_bytes = (size_t)16 << be;
@@ -564,7 +559,7 @@ int build_index(rk_ctx* c) {
             // exact map (KM1_C in rk_device.hpp).  A key whose bucket is full moves on by up to 2^KM1_HB - 1 buckets; if that is not
             // enough, or the value ids do not fit the cell, the table doubles (shorter remainders leave more bits for the id).
             {
-                static const double km1_load = getenv("RKMH_KM1_LOAD") ? atof(getenv("RKMH_KM1_LOAD")) : 0.65;
+                const double km1_load = 0.65;
                 std::vector<uint32_t> vid(found);
                 const uint32_t VID_ZERO = 0xFFFFFFFEu; // placeholder, mapped to the layout's id below
                 for (uint32_t i = 0; i < found; ++i) {

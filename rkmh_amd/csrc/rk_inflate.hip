@@ -35,7 +35,7 @@ constexpr int CT = 7;                         // root table bits of the code-len
 // Root table bits of the literal/length and the distance code are template parameters of the kernel (LT, DT).  The shipped form is
 // <8, 6>: 73.5 KB of LDS per wave, so TWO waves decode on every CU (160 KB) -- a wave is issue-latency bound on its own SIMD and the
 // other three SIMDs of the CU idle, so the second wave is almost free (round 5 ran <9, 7>: 124.5 KB, one wave per CU, 26.6 ms per
-// launch whatever its size).  The price: 83 % instead of 62 % of the symbol windows meet a code longer than the root.
+// launch whatever its size).  The price: 83 % instead of 62 % of the symbol windows meet a code longer than the root: 30.3 ms per wave.
 constexpr int LONG_CAP = 128, DLONG_CAP = 32;  // symbols with codes longer than the root (more: the member is the host's)
 constexpr int WALK_N = 10;                    // code lengths above the root's bits (15 - 6 = 9 at most)
 constexpr int CL_AT = 320, LENS_N = 352;      // lens[0 .. 316): literal/length + distance code lengths; lens[320 .. 339): code-length code
@@ -722,20 +722,16 @@ uint32_t inflate_scratch_dwords(uint32_t out_len) { return scratch_dwords(out_le
 hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint32_t* scratch, uint32_t* status,
                                   hipStream_t st) {
     if (!nmem) return hipSuccess;
-    // RKMH_INFLATE_ROOT=9: round 5's root tables (9 / 7 bits, one wave per CU) -- kept for A/B runs of the same build
-    static const bool wide_root = [] { const char* e = getenv("RKMH_INFLATE_ROOT"); return e && atoi(e) == 9; }();
     // (once per device: the call takes the runtime's lock, and several workers launch from their own threads)
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
     if (!((attr_set.load(std::memory_order_acquire) >> dev) & 1ull) || dev == 63) {
-        hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<8, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds<8, 6>));
-        if (attr == hipSuccess) attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<9, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds<9, 7>));
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<8, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds<8, 6>));
         if (attr != hipSuccess) return attr;
         attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
-    if (wide_root) hipLaunchKernelGGL((k_inflate_lanes<9, 7>), dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds<9, 7>), st, comp, comp_bytes, mem, nmem, scratch, status);
-    else hipLaunchKernelGGL((k_inflate_lanes<8, 6>), dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds<8, 6>), st, comp, comp_bytes, mem, nmem, scratch, status);
+    hipLaunchKernelGGL((k_inflate_lanes<8, 6>), dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds<8, 6>), st, comp, comp_bytes, mem, nmem, scratch, status);
     hipLaunchKernelGGL(k_inflate_place, dim3(nmem), dim3(IW), 0, st, mem, nmem, text, scratch, status);
     hipLaunchKernelGGL(k_crc32_members, dim3((nmem + 3) / 4), dim3(256), 0, st, mem, nmem, text, comp, status);
     return hipGetLastError();

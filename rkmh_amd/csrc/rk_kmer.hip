@@ -827,8 +827,6 @@ bool make_kmer_geom(KmerGeom& g, int maxlen, int nref, int expect_hits, int win_
     int T = (nq * 1024 - 15) / maxlen;
     if (T > KM_MAX_T) T = KM_MAX_T;
     if (T < 1) T = 1;
-    static const int forced_t = getenv("RKMH_KMER_T") ? atoi(getenv("RKMH_KMER_T")) : 0;
-    if (forced_t > 0 && forced_t < T) T = forced_t;
     g.T = T;
     big = false;
     // the small layout if at least half the reads the staged quads could hold fit it, else the large one
@@ -887,8 +885,6 @@ hipError_t launch_classify_kmer(const uint8_t* bases, const uint32_t* offs, uint
     int cmode = 0;
     bool big = false;
     if (!make_kmer_geom(geo, maxlen, ix.nref, expect_hits, win_total, nw_k, ksets.n, nq, cmode, big)) return hipErrorInvalidConfiguration;
-    static const int xcd_env = getenv("RKMH_TILE_XCD") ? atoi(getenv("RKMH_TILE_XCD")) : -1;
-    if (xcd_env >= 0) geo.xcd = xcd_env != 0;
     geo.nmin_cap = nmin_cap;
     const uint32_t ntiles = (nreads + (uint32_t)geo.T - 1) / (uint32_t)geo.T;
     const bool fam = ix.kbase_n != 0u; // lists stored as (base, exceptions) exist

@@ -697,15 +697,11 @@ struct RawEngine {
         if (pieces > 1) pool.start((int)std::min<long>(16, std::max<long>(2, granted_cpus_main() - 2)));
         return true;
     }
-    // every worker's slot, each made by a thread of its own (page-locked buffers, a few GB of device memory for a device-text slot:
-    // tens of milliseconds each, and the runtime takes them one at a time) -- called while the references are still being read
-    // and sketched, so that the first blocks do not wait for it.  A slot that cannot be made is left to its worker (which reports it).
-    void create_slots(DeviceGroup& g) {
-        std::vector<std::thread> th;
-        for (size_t i = 0; i < w.size(); ++i)
-            if (!w[i].slot) th.emplace_back([this, &g, i] { rk_fastq_slot* sl = nullptr; if (rk_fastq_slot_create2(g.ctx[w[i].dev], w[i].bytes, w[i].device_text ? RK_SLOT_DEVICE_TEXT : 0, &sl) == RK_OK) w[i].slot = sl; });
-        for (auto& t : th) t.join();
-    }
+    // A worker makes its slot when it starts, ONE worker at a time: allocations of several threads queue up inside the runtime anyway,
+    // and they slow every other call down while they do (measured: a device-text slot of 841 MB takes 24 ms on its own -- 23 of
+    // them page-locking its host arrays --, 60 to 230 ms when three are made at once beside the reference stage, which then takes
+    // 0.45 s instead of 0.15).  The first worker's slot exists already (create); the others follow 24 ms apart.
+    std::mutex slot_mu;
     void destroy() { pool.stop(); for (auto& x : w) if (x.slot) rk_fastq_slot_destroy(x.slot); w.clear(); }
 };
 // BGZF files that go to the device: the mapping is page-locked once (14 ms per GB), the DMA engine then reads the compressed
@@ -816,7 +812,9 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
         QueueT<Job>& jobs = W.device_text ? jobs_mega : jobs_plain;
         std::atomic<int>& live = W.device_text ? live_mega : live_plain;
         const double t_slot = now_s();
-        if (!W.slot && rk_fastq_slot_create2(g.ctx[W.dev], W.bytes, W.device_text ? RK_SLOT_DEVICE_TEXT : 0, &W.slot) != RK_OK) {
+        bool slot_ok = true;
+        if (!W.slot) { std::lock_guard<std::mutex> sl(eng.slot_mu); slot_ok = rk_fastq_slot_create2(g.ctx[W.dev], W.bytes, W.device_text ? RK_SLOT_DEVICE_TEXT : 0, &W.slot) == RK_OK; }
+        if (!slot_ok) {
             // (memory for another slot ran out: the other workers carry on -- unless this was the last one)
             fprintf(stderr, "rkmh: worker %zu: %s\n", wi, rk_last_error());
             if (live.fetch_sub(1) == 1) { fprintf(stderr, "rkmh: no worker of the device front end could start\n"); fail_exit(); }
@@ -1603,8 +1601,8 @@ static int main_stream(int argc, char** argv) {
     rk_ctx* ctx = group.ctx[0];
     tick("context", t0);
     // the front end's kernels (and the inflater's) are loaded while the references are sketched, not in front of the first block
-    // ... and so are the front end's workers' slots made and the BGZF mappings page-locked (unless the references themselves go
-    // through the engine: then it is made for them first)
+    // ... and so are the front end's engine and its first slot made and the BGZF mappings page-locked (unless the references themselves
+    // go through the engine: then it is made for them first)
     RawEngine eng;       // the workers and page-locked buffers of the device front ends (created by whoever needs them first)
     std::thread warm;
     const bool raw_run = any_raw || (o.read_depth && all_raw && !read_map);
@@ -1613,7 +1611,7 @@ static int main_stream(int argc, char** argv) {
         warm = std::thread([&o, &eng, &group, prepare] {
             const std::vector<int> ids = o.devices.empty() ? std::vector<int>{o.device} : o.devices;
             for (int id : ids) rk_warm_up(id, !g_bgzf.empty() && bgzf_on_device());
-            if (prepare && eng.create(group)) { eng.create_slots(group); register_bgzf_mappings(); }
+            if (prepare && eng.create(group)) register_bgzf_mappings();
         });
     }
     rk_seqset refs;
@@ -1805,13 +1803,13 @@ static int main_filter(int argc, char** argv) {
     DeviceGroup group;
     group.create(o);
     RawEngine eng;       // the workers and page-locked buffers of the device front ends
-    // (its slots are made and the BGZF mappings page-locked while the references are read and sketched -- unless those go through the engine themselves)
+    // (it is made, with its first slot, and the BGZF mappings are page-locked while the references are read and sketched -- unless those go through the engine themselves)
     std::thread prep;
     if (all_raw && !refs_for_device(o) && !(getenv("RKMH_WARM_UP") && atoi(getenv("RKMH_WARM_UP")) == 0))
         prep = std::thread([&o, &eng, &group] {
             const std::vector<int> ids = o.devices.empty() ? std::vector<int>{o.device} : o.devices;
             for (int id : ids) rk_warm_up(id, !g_bgzf.empty() && bgzf_on_device());
-            if (eng.create(group)) { eng.create_slots(group); register_bgzf_mappings(); }
+            if (eng.create(group)) register_bgzf_mappings();
         });
     // file mode compares read_min_lens with 0 (rkmh.cpp:1292); the STDIN lines print min(len) itself (:1397): exact there
     // (with -D >= 0 a read that shares nothing fails the diff test anyway, so not even min(read_min_lens, 1) is needed: bound 0)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (GPU box): [N=8000000] bash tools/gz_r06.sh [tag] -- ONE BGZF file of N reads (and the same text plain) through bin/rkmh stream: one file
+# Usage (GPU box): [N=8000000] bash tools/gz_e2e.sh [tag] -- ONE BGZF file of N reads (and the same text plain) through bin/rkmh stream: one file
 # and four, plain text / device inflate (two root-table forms) / host inflate: wall, marginal reads/s of the three extra files, the
 # [bgzf device] job lines, then a rocprofv3 kernel trace of the four-file device run.  Output: gpurun_out/<tag>_gz.txt, <tag>_gz_kernel_stats.csv
 cd ${GRAFT_REPO_ROOT:-.}
