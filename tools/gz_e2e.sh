@@ -55,6 +55,12 @@ run() { # label file env...
 }
 run "plain text" /tmp/big.fq X=1
 run "BGZF, device inflate (default: 3 workers)" /tmp/big.fq.gz X=1
+if [ -n "$SWEEP" ]; then
+  for w in 2 4 5 6; do run "BGZF, device inflate, $w workers" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=$w; done
+  run "BGZF, device inflate, 5 workers, 512 MB jobs" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=5 RKMH_BGZF_JOB_KB=524288
+  run "BGZF, device inflate, 6 workers, 384 MB jobs" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=6 RKMH_BGZF_JOB_KB=393216
+  cat $OUT; exit 0
+fi
 [ -n "$QUICK" ] && { cat $OUT; exit 0; }
 run "BGZF, device inflate, 2 workers" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=2
 run "BGZF, device inflate, 1 worker" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=1
