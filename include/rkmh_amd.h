@@ -452,6 +452,7 @@ uint64_t rk_bgzf_text_bytes(const rk_bgzf* z);
 uint64_t rk_bgzf_text_offset(const rk_bgzf* z, int64_t member);
 int rk_bgzf_first_byte(const rk_bgzf* z);
 int64_t rk_bgzf_plan(const rk_bgzf* z, uint64_t target_bytes, int64_t* first, int64_t cap);
+int64_t rk_bgzf_plan_members(const rk_bgzf* z, uint64_t target_bytes, int64_t max_members, int64_t* first, int64_t cap);   /* ... and of at most max_members members each */
 int rk_bgzf_fastq_records(const rk_bgzf* z, int64_t b0, int64_t b1, uint8_t* dst, uint64_t cap, uint64_t* nbytes, uint64_t* text_off);
 const uint8_t* rk_bgzf_image(const rk_bgzf* z);   /* the mapped file */
 /* the member whose text ends with the byte in front of member b0's text (b0 - 1 unless that one is empty; b0 when no text precedes) */

@@ -117,6 +117,7 @@ _SIGS = {
     "rk_host_unregister": (None, [C.c_void_p]),
     "rk_warm_up": (C.c_int, [C.c_int, C.c_int]),
     "rk_bgzf_plan": (C.c_int64, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), C.c_int64]),
+    "rk_bgzf_plan_members": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_int64), C.c_int64]),
     "rk_bgzf_fastq_records": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_fastq_slot_load_bgzf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_bgzf_file_bytes": (C.c_uint64, [C.c_void_p]),

@@ -1117,8 +1117,11 @@ int rk_bgzf_first_byte(const rk_bgzf* z) {
     return 0;
 }
 // consecutive members grouped into jobs of about target_bytes of text: first[j] = first member of job j, first[jobs] = members
-int64_t rk_bgzf_plan(const rk_bgzf* z, uint64_t target_bytes, int64_t* first, int64_t cap) {
-    if (!z || !first || cap < 2) return perr(RK_ERR_ARG, "bad arguments");
+int64_t rk_bgzf_plan(const rk_bgzf* z, uint64_t target_bytes, int64_t* first, int64_t cap) { return rk_bgzf_plan_members(z, target_bytes, INT64_MAX, first, cap); }
+// ... and of at most max_members members each (the device inflater decodes 64 members per wave: a job of 16 384 members is 256
+// waves, two of which fill the chip -- one member more and a launch has a straggler that waits for the other launch's slots)
+int64_t rk_bgzf_plan_members(const rk_bgzf* z, uint64_t target_bytes, int64_t max_members, int64_t* first, int64_t cap) {
+    if (!z || !first || cap < 2 || max_members < 1) return perr(RK_ERR_ARG, "bad arguments");
     const size_t nb = z->hlen.size();
     int64_t nj = 0;
     size_t b = 0;
@@ -1126,8 +1129,9 @@ int64_t rk_bgzf_plan(const rk_bgzf* z, uint64_t target_bytes, int64_t* first, in
         if (nj + 1 >= cap) return perr(RK_ERR_LIMIT, "rk_bgzf_plan: more jobs than the caller's array holds");
         first[nj++] = (int64_t)b;
         const uint64_t start = z->uoff[b];
-        while (b < nb && z->uoff[b + 1] - start <= target_bytes) ++b;
-        if (z->uoff[b] == start && b < nb) ++b; // (a member larger than the target: alone)
+        const size_t b_first = b;
+        while (b < nb && z->uoff[b + 1] - start <= target_bytes && (int64_t)(b - b_first) < max_members) ++b;
+        if (b == b_first && b < nb) ++b; // (a member larger than the target: alone)
     }
     first[nj] = (int64_t)nb;
     return nj;

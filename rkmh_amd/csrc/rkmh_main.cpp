@@ -943,7 +943,8 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
             const uint64_t per_job = F.mega ? eng.mega : eng.block;
             const uint64_t target = per_job > ((uint64_t)1 << 20) ? per_job - ((uint64_t)1 << 18) : per_job * 3 / 4;
             std::vector<int64_t> first((size_t)rk_bgzf_members(F.bz) + 4);
-            const int64_t nj = rk_bgzf_plan(F.bz, target, first.data(), (int64_t)first.size());
+            // (device jobs: at most 16 381 members + the three around them = 256 waves of 64 members: two launches fill the chip exactly)
+            const int64_t nj = rk_bgzf_plan_members(F.bz, target, F.mega ? 16381 : INT64_MAX, first.data(), (int64_t)first.size());
             if (nj < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
             const int64_t per = F.mega ? eng.pieces : 1;
             for (int64_t j = 0; j < nj && fail_seq.load() == INT64_MAX; ++j) {
