@@ -727,14 +727,11 @@ hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, cons
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
     if (!((attr_set.load(std::memory_order_acquire) >> dev) & 1ull) || dev == 63) {
-        hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<8, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds<8, 6>));
-        if (attr == hipSuccess) attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<7, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds<7, 6>));
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<8, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds<8, 6>));
         if (attr != hipSuccess) return attr;
         attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
-    static const bool lt7 = [] { const char* e = getenv("RKMH_INFLATE_LT"); return e && atoi(e) == 7; }(); // (A/B of the same build: 58 KB per wave)
-    if (lt7) hipLaunchKernelGGL((k_inflate_lanes<7, 6>), dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds<7, 6>), st, comp, comp_bytes, mem, nmem, scratch, status);
-    else hipLaunchKernelGGL((k_inflate_lanes<8, 6>), dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds<8, 6>), st, comp, comp_bytes, mem, nmem, scratch, status);
+    hipLaunchKernelGGL((k_inflate_lanes<8, 6>), dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds<8, 6>), st, comp, comp_bytes, mem, nmem, scratch, status);
     hipLaunchKernelGGL(k_inflate_place, dim3(nmem), dim3(IW), 0, st, mem, nmem, text, scratch, status);
     hipLaunchKernelGGL(k_crc32_members, dim3((nmem + 3) / 4), dim3(256), 0, st, mem, nmem, text, comp, status);
     return hipGetLastError();

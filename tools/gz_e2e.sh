@@ -57,8 +57,6 @@ run "plain text" /tmp/big.fq X=1
 run "BGZF, device inflate (default: 3 workers)" /tmp/big.fq.gz X=1
 if [ -n "$SWEEP" ]; then
   for w in 2 4 5; do run "BGZF, device inflate, $w workers" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=$w; done
-  for w in 3 4 5; do run "BGZF, device inflate, 7-bit roots, $w workers" /tmp/big.fq.gz RKMH_INFLATE_LT=7 RKMH_BGZF_DEVICE_WORKERS=$w; done
-  run "BGZF, device inflate, 7-bit roots, 5 workers, 512 MB jobs" /tmp/big.fq.gz RKMH_INFLATE_LT=7 RKMH_BGZF_DEVICE_WORKERS=5 RKMH_BGZF_JOB_KB=524288
   cat $OUT; exit 0
 fi
 [ -n "$QUICK" ] && { cat $OUT; exit 0; }
