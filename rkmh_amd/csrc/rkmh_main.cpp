@@ -1229,8 +1229,11 @@ static void stream_packed(DeviceGroup& g, const rk_seqset& refs, const Opts& o, 
         }
     static std::map<const uint8_t*, bool> registered; // (a mapping is page-locked once; both passes of -M use it)
     for (const PackedFile& pf : files)
-        if (!registered.count(pf.map) && !(getenv("RKMH_PACKED_REGISTER") && atoi(getenv("RKMH_PACKED_REGISTER")) == 0))
+        if (!registered.count(pf.map) && !(getenv("RKMH_PACKED_REGISTER") && atoi(getenv("RKMH_PACKED_REGISTER")) == 0)) {
+            const double a = now_s();
             registered[pf.map] = rk_host_register_readonly(pf.map, pf.size) == RK_OK;
+            if (g_timing) fprintf(stderr, "[rkmh timing] %s: mapping of %.0f MB %s in %.3f s\n", pf.path, (double)pf.size / 1e6, registered[pf.map] ? "page-locked" : "NOT page-locked (uploads are staged by the runtime)", now_s() - a);
+        }
     const size_t nw = (size_t)env_long("RKMH_PACKED_WORKERS", 3, 1, 16) * g.size();
     OrderedOut out;
     if (!counting) out.start(g.size());
