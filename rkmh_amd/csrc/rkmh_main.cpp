@@ -1239,57 +1239,66 @@ static void stream_packed(DeviceGroup& g, const rk_seqset& refs, const Opts& o, 
     if (!counting) out.start(g.size());
     FormatPool pool;
     if (!counting) pool.start((int)std::min<long>(16, std::max<long>(2, granted_cpus_main() - 2)));
-    const int64_t window = (int64_t)nw * 8 + 2;
+    int64_t most_pieces = 1;
+    for (const Job& jb : jobs) most_pieces = std::max(most_pieces, jb.nseq);
+    // every worker has two slots: while the pool formats the lines of one block (from the rows in that slot's page-locked buffer) the
+    // worker's next block is on the device in the other.  At most 2 nw consecutive blocks are open at a time, so a piece never waits
+    // in put() for a piece that is queued behind it
+    const int64_t window = (int64_t)nw * 2 * most_pieces + 2;
     std::atomic<size_t> next{0};
     std::mutex tm;
     double t_dev = 0, t_fmt = 0;
     auto work = [&](size_t wi) {
-        rk_packed_slot* slot = nullptr;
+        rk_packed_slot* slot[2] = {nullptr, nullptr};
+        rk_fastq_result res[2];
+        Latch latch[2];
         const size_t dev = wi % g.size();
-        if (rk_packed_slot_create(g.ctx[dev], max_reads, max_bases, &slot) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+        const int nslot = counting ? 1 : 2;
+        for (int i = 0; i < nslot; ++i)
+            if (rk_packed_slot_create(g.ctx[dev], max_reads, max_bases, &slot[i]) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
         double dv = 0, fm = 0;
+        int cur = 0;
         for (size_t j = next.fetch_add(1); j < jobs.size(); j = next.fetch_add(1)) {
             const Job& jb = jobs[j];
             const PackedFile& pf = files[jb.file];
             const rk_packed_block& blk = pf.dir[jb.block];
             const double a = now_s();
             if (counting) {
-                const int rc = rk_packed_slot_count(slot, &blk, pf.map, (*cnts)[dev]);
+                const int rc = rk_packed_slot_count(slot[0], &blk, pf.map, (*cnts)[dev]);
                 if (rc == RK_ERR_NEED_FULL) g_need_full.store(true);
                 else if (rc != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", pf.path, rk_last_error()); fail_exit(); }
                 dv += now_s() - a;
                 continue;
             }
-            rk_fastq_result res;
-            if (rk_packed_slot_classify(slot, &blk, pf.map, &res) != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", pf.path, rk_last_error()); fail_exit(); }
+            latch[cur].wait(); // the lines of the block this slot held before are with the sink
+            const double a2 = now_s();
+            if (rk_packed_slot_classify(slot[cur], &blk, pf.map, &res[cur]) != RK_OK) { fprintf(stderr, "rkmh: %s: %s\n", pf.path, rk_last_error()); fail_exit(); }
             const double b = now_s();
-            const uint8_t* const text = pf.map + blk.names_off;
-            auto format_piece = [&](int64_t lo, int64_t hi, int64_t sq) {
-                std::vector<char> buf = out.take_buffer();
-                size_t n = 0;
-                if (hi > lo) {
-                    const rk_fastq_result part = sub_result(res, lo, hi);
-                    if (kind == RAW_FILTER) {
-                        const size_t need = (size_t)rk_packed_filter_records_bound(&part);
-                        if (buf.size() < need) buf.resize(need + need / 8);
-                        const int64_t w = rk_packed_filter_records(&part, &blk, pf.map, o.min_matches, o.min_diff, buf.data(), buf.size());
-                        if (w < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
-                        n = (size_t)w;
-                    } else n = format_raw(lp, part, text, buf);
-                }
-                out.put(sq, std::move(buf), n, window);
-            };
-            if (jb.nseq == 1) format_piece(0, res.nrec, jb.seq);
-            else {
-                Latch latch;
-                latch.left = (int)jb.nseq;
-                for (int64_t e = 0; e < jb.nseq; ++e)
-                    pool.run([&, e] { format_piece(res.nrec * e / jb.nseq, res.nrec * (e + 1) / jb.nseq, jb.seq + e); latch.done(); });
-                latch.wait();
-            }
-            dv += b - a; fm += now_s() - b;
+            const rk_fastq_result* const rs = &res[cur];
+            Latch* const lt = &latch[cur];
+            { std::lock_guard<std::mutex> l(lt->m); lt->left = (int)jb.nseq; }
+            for (int64_t e = 0; e < jb.nseq; ++e)
+                pool.run([&out, &o, &pf, &blk, &jb, rs, lt, lp, kind, window, e] {
+                    const int64_t lo = rs->nrec * e / jb.nseq, hi = rs->nrec * (e + 1) / jb.nseq;
+                    std::vector<char> buf = out.take_buffer();
+                    size_t n = 0;
+                    if (hi > lo) {
+                        const rk_fastq_result part = sub_result(*rs, lo, hi);
+                        if (kind == RAW_FILTER) {
+                            const size_t need = (size_t)rk_packed_filter_records_bound(&part);
+                            if (buf.size() < need) buf.resize(need + need / 8);
+                            const int64_t w = rk_packed_filter_records(&part, &blk, pf.map, o.min_matches, o.min_diff, buf.data(), buf.size());
+                            if (w < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+                            n = (size_t)w;
+                        } else n = format_raw(lp, part, pf.map + blk.names_off, buf);
+                    }
+                    out.put(jb.seq + e, std::move(buf), n, window);
+                    lt->done();
+                });
+            dv += b - a2; fm += a2 - a;
+            cur ^= 1;
         }
-        rk_packed_slot_destroy(slot);
+        for (int i = 0; i < nslot; ++i) { latch[i].wait(); rk_packed_slot_destroy(slot[i]); }
         std::lock_guard<std::mutex> l(tm);
         t_dev += dv; t_fmt += fm;
     };
@@ -1300,7 +1309,7 @@ static void stream_packed(DeviceGroup& g, const rk_seqset& refs, const Opts& o, 
     if (!counting) out.finish();
     rk_line_parts_destroy(lp);
     if (out.failed) { fprintf(stderr, "rkmh: write error on standard output\n"); fail_exit(); }
-    if (g_timing) fprintf(stderr, "[rkmh timing] packed reads: %zu blocks; upload + classify %.3f s, format %.3f s (summed over %zu workers)\n", jobs.size(), t_dev, t_fmt, nw);
+    if (g_timing) fprintf(stderr, "[rkmh timing] packed reads: %zu blocks; upload + classify %.3f s, waiting for the lines of an earlier block %.3f s (summed over %zu workers)\n", jobs.size(), t_dev, t_fmt, nw);
 }
 
 // stream / filter over packed files, with or without -M (two passes: count, sum over the devices, mask, classify)
