@@ -4,7 +4,7 @@ ARCH := gfx950
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-result $(EXTRA_HIPFLAGS)
 CSRC := rkmh_amd/csrc
 LIB := rkmh_amd/lib/librkmh_amd.so
-OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_kmer.o $(CSRC)/rk_count.o $(CSRC)/rk_call.o $(CSRC)/rk_sort.o $(CSRC)/rk_fastq.o $(CSRC)/rk_fasta.o $(CSRC)/rk_inflate.o $(CSRC)/rk_api.o $(CSRC)/rk_index.o $(CSRC)/rk_counters.o $(CSRC)/rk_frontend.o $(CSRC)/rk_packed.o $(CSRC)/rk_pack.o $(CSRC)/rk_parse.o $(CSRC)/rk_format.o $(CSRC)/rk_synth.o $(CSRC)/rk_policy.o
+OBJS := $(CSRC)/rk_kernels.o $(CSRC)/rk_classify.o $(CSRC)/rk_kmer.o $(CSRC)/rk_count.o $(CSRC)/rk_call.o $(CSRC)/rk_sort.o $(CSRC)/rk_fastq.o $(CSRC)/rk_fasta.o $(CSRC)/rk_inflate.o $(CSRC)/rk_api.o $(CSRC)/rk_index.o $(CSRC)/rk_counters.o $(CSRC)/rk_frontend.o $(CSRC)/rk_gunzip.o $(CSRC)/rk_packed.o $(CSRC)/rk_pack.o $(CSRC)/rk_parse.o $(CSRC)/rk_format.o $(CSRC)/rk_synth.o $(CSRC)/rk_policy.o
 
 API_DEPS := $(CSRC)/rk_api_internal.hpp $(CSRC)/rk_kernels.hpp $(CSRC)/rk_device.hpp include/rkmh_amd.h
 
@@ -41,6 +41,8 @@ $(CSRC)/rk_index.o: $(CSRC)/rk_index.hip $(API_DEPS)
 $(CSRC)/rk_counters.o: $(CSRC)/rk_counters.hip $(API_DEPS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/rk_frontend.o: $(CSRC)/rk_frontend.hip $(API_DEPS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/rk_gunzip.o: $(CSRC)/rk_gunzip.hip $(API_DEPS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/rk_packed.o: $(CSRC)/rk_packed.hip $(API_DEPS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

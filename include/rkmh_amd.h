@@ -467,6 +467,29 @@ int rk_bgzf_member(const rk_bgzf* z, int64_t member, uint64_t* file_off, uint32_
  * of members (one launch decodes them all: the decode kernel takes the same ~15 ms for 64 members as for 32 768).
  * Returns RK_OK, or 1: take the host route (rk_bgzf_fastq_records) for this job -- it reports damaged members. */
 int rk_fastq_slot_load_bgzf(rk_fastq_slot* slot, const rk_bgzf* z, int64_t b0, int64_t b1, uint64_t* nbytes, uint64_t* text_off);
+
+/* ---- ordinary gzip files (ONE deflate stream) inflated on the device: rk_gunzip.hip ------------------------------------------
+ * The reference reads every input through gzopen / gzread (/root/reference/src/rkmh.cpp:238-263).  rk_gzip_open maps a gzip file
+ * that is not BGZF (RFC 1952 header, deflate payload, trailer); rk_gzip_plan(slot_bytes) cuts its compressed bytes into stretches
+ * that inflate to about a slot each (by the ratio the trailer's ISIZE implies), rewinds the stream, and returns how many calls of
+ * rk_fastq_slot_load_gzip the file takes.  Each call inflates the next stretch on the device -- block headers found by a kernel, a
+ * lane per chunk, the text in front of a chunk resolved in stream order, CRC-32 and ISIZE checked at the end of the stream -- and
+ * leaves the whole FASTQ records of it in the slot's device text, for rk_fastq_slot_submit / _count; the bytes behind the last
+ * record start wait on the device for the next call.  Calls come in order, all on slots (RK_SLOT_DEVICE_TEXT) of one device.
+ * rk_fastq_slot_load_gzip returns RK_OK, or 1: the device route ends here (stored / fixed-code stretches longer than a chunk's
+ * scratch, text that outgrows the slot, a second member behind the first, no FASTQ) -- nothing of the text from *text_off on has
+ * been delivered, and the caller's sequential reader (rk_reader_open_at(path, *text_off)) continues from there; < 0: damaged data. */
+typedef struct rk_gzip rk_gzip;
+int rk_gzip_open(const char* path, rk_gzip** out);
+void rk_gzip_close(rk_gzip* gz);
+const uint8_t* rk_gzip_image(const rk_gzip* gz);        /* the mapped file (rk_host_register_readonly lets the DMA engine read it) */
+uint64_t rk_gzip_file_bytes(const rk_gzip* gz);
+int rk_gzip_first_byte(const rk_gzip* gz);              /* of the text; -1: not decodable */
+uint64_t rk_gzip_text_bytes_hint(const rk_gzip* gz);    /* from ISIZE (modulo 2^32): for sizing only */
+int64_t rk_gzip_plan(rk_gzip* gz, uint64_t slot_bytes); /* calls the file takes; rewinds */
+int64_t rk_gzip_calls(const rk_gzip* gz);
+void rk_gzip_release_device(rk_gzip* gz);              /* frees the device buffers of a file that has been read; rk_gzip_plan before the next pass */
+int rk_fastq_slot_load_gzip(rk_fastq_slot* s, rk_gzip* gz, int64_t call, uint64_t* nbytes, uint64_t* text_off);
 uint64_t rk_bgzf_file_bytes(const rk_bgzf* z);   /* length of rk_bgzf_image */
 
 /* ------------------------------------------------------------------------------------------------

@@ -120,6 +120,16 @@ _SIGS = {
     "rk_bgzf_plan_members": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_int64), C.c_int64]),
     "rk_bgzf_fastq_records": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_fastq_slot_load_bgzf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rk_gzip_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "rk_gzip_close": (None, [C.c_void_p]),
+    "rk_gzip_image": (C.c_void_p, [C.c_void_p]),
+    "rk_gzip_file_bytes": (C.c_uint64, [C.c_void_p]),
+    "rk_gzip_first_byte": (C.c_int, [C.c_void_p]),
+    "rk_gzip_text_bytes_hint": (C.c_uint64, [C.c_void_p]),
+    "rk_gzip_plan": (C.c_int64, [C.c_void_p, C.c_uint64]),
+    "rk_gzip_calls": (C.c_int64, [C.c_void_p]),
+    "rk_gzip_release_device": (None, [C.c_void_p]),
+    "rk_fastq_slot_load_gzip": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_bgzf_file_bytes": (C.c_uint64, [C.c_void_p]),
     # packed reads (`rkmh pack`, -F): include/rkmh_amd.h "PACKED READS"
     "rk_packed_encode": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
@@ -538,6 +548,15 @@ class FastqSlot:
             _chk(rc)
         return rc, int(n.value), int(off.value)
 
+    def load_gzip(self, gz, call):
+        """Stretch number `call` of a Gzip file (an ordinary one-stream .gz) inflated on the device into this slot
+        (rk_fastq_slot_load_gzip) -> (status, nbytes, text offset); status 1: the sequential reader continues from the text offset."""
+        n, off = C.c_uint64(), C.c_uint64()
+        rc = self._lib.rk_fastq_slot_load_gzip(self._h, gz._h, call, C.byref(n), C.byref(off))
+        if rc < 0:
+            _chk(rc)
+        return rc, int(n.value), int(off.value)
+
     def classify_raw(self, nbytes):
         """rk_fastq_slot_classify on the first nbytes of text_buffer(); returns the FastqResult structure (valid until the next call)."""
         res = FastqResult()
@@ -609,6 +628,52 @@ class FastqSlot:
     def __del__(self):
         try:
             self.destroy()
+        except Exception:
+            pass
+
+
+class Gzip:
+    """An ordinary gzip file -- one deflate stream -- that the device inflates stretch after stretch (rk_gzip_*, rk_gunzip.hip).
+    Gzip.open returns None for anything that is not a gzip file."""
+
+    def __init__(self, handle):
+        self._lib = load_library()
+        self._h = handle
+
+    @staticmethod
+    def open(path):
+        lib = load_library()
+        h = C.c_void_p()
+        rc = lib.rk_gzip_open(os.fsencode(path), C.byref(h))
+        if rc != 0:
+            return None
+        return Gzip(h)
+
+    def first_byte(self):
+        return int(self._lib.rk_gzip_first_byte(self._h))
+
+    @property
+    def text_bytes_hint(self):
+        return int(self._lib.rk_gzip_text_bytes_hint(self._h))
+
+    def plan(self, slot_bytes):
+        """how many load_gzip calls the file takes with slots of slot_bytes; rewinds the stream"""
+        n = int(self._lib.rk_gzip_plan(self._h, slot_bytes))
+        if n < 0:
+            _chk(-1)
+        return n
+
+    def release_device(self):
+        self._lib.rk_gzip_release_device(self._h)
+
+    def close(self):
+        if self._h:
+            self._lib.rk_gzip_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -24,6 +24,7 @@
 #include <unordered_map>
 #include <vector>
 
+struct rk_gzip; // rk_gunzip.hip
 namespace rk {
 // sets the thread's error text (rk_last_error) and returns `code`
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -214,6 +215,7 @@ int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nre
                  hipStream_t st, uint64_t total_bases = 0);
 // rows the fused kernel flagged (max_id == -2; `rows` = host copy of d_out4) answered by the general kernels on the resident bases and scattered back into d_out4 AND rows; synchronises st
 int reroute_flagged_device(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nreads, void* d_out4, int32_t* rows, hipStream_t st);
+int gzip_next(rk_gzip* gz, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t call, uint8_t* d_out, uint64_t cap_out, uint64_t* nbytes, uint64_t* text_off); // rk_gunzip.hip
 int counter_settle(const rk_counter* k);                                                                    // rk_counters.hip
 int build_index(rk_ctx* c);                                                                                 // rk_index.hip
 int set_references_impl(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases, const uint64_t* offsets, int nref, const int* ks, int nks, int S,

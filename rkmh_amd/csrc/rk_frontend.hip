@@ -260,6 +260,22 @@ extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64
     return RK_OK;
 }
 
+// The next stretch of an ORDINARY gzip file (one deflate stream: rk_gzip_open, rk_gzip_plan) inflated on the device (rk_gunzip.hip) into
+// this slot's device text: whole records, *nbytes of them (0: this stretch completed none), the first one at byte *text_off of the
+// file's text.  Calls come in order, call = 0 .. rk_gzip_plan() - 1, all from slots of ONE device; the next rk_fastq_slot_submit /
+// _count of this slot takes *nbytes and skips its upload.  Returns RK_OK; 1: the device route ends here -- the caller's sequential
+// reader continues from *text_off (rk_reader_open_at); < 0: an error (damaged data).
+extern "C" int rk_fastq_slot_load_gzip(rk_fastq_slot* s, rk_gzip* gz, int64_t call, uint64_t* nbytes, uint64_t* text_off) {
+    if (!s || !gz || !nbytes || !text_off) return fail(RK_ERR_ARG, "bad arguments");
+    if (!s->device_text()) return fail(RK_ERR_ARG, "rk_fastq_slot_load_gzip: a slot created with RK_SLOT_DEVICE_TEXT is needed");
+    s->text_on_device = false;
+    const int rc = gzip_next(gz, s->c, s->st, s->ev, call, s->d_text.as<uint8_t>(), s->max_bytes, nbytes, text_off);
+    if (rc != RK_OK) return rc;
+    HIPCHK(hipMemsetAsync(s->d_text.as<uint8_t>() + *nbytes, 'A', 16, s->st)); // the index kernels read whole 16-byte pieces
+    s->text_on_device = true;
+    return RK_OK;
+}
+
 // The two halves of rk_fastq_slot_classify, for callers that keep two slots per thread: submit() enqueues the upload and the
 // index / check / pack kernels and returns at once; finish() waits for them, launches the classification and collects the rows.
 // Between the two the caller can read its next block into its other slot -- the link and the GPU work while the host reads.

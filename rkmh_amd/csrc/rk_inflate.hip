@@ -164,8 +164,12 @@ struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };
 
 // Pass 1.  scratch: per member at dword me.match_off: scratch_dwords(out_len) dwords -- entries from the front, the literal stream from the back.
 // status[m]: 0 ok, else why the member is the host's; status[nmem + m] = its entries | its literals << 15.
-template <int LT, int DT>
-__global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict__ comp, uint32_t comp_bytes, const InflateMember* __restrict__ mem, uint32_t nmem,
+// STREAM: the lanes decode CHUNKS of one long deflate stream (an ordinary .gz file, rk_gunzip.hip) instead of members: a chunk begins at a
+// block header anywhere in the stream (any bit), ends at the first block boundary at or after its stop position (or with the
+// stream's last block), may copy from text in front of it (the 32 KB before its first byte: pass 2 knows what to do), and has no
+// ISIZE -- its part of the scratch buffer bounds it instead.  mem is then a GzChunk array, which also takes the results.
+template <int LT, int DT, bool STREAM>
+__global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict__ comp, uint32_t comp_bytes, const void* __restrict__ mem_, uint32_t nmem,
                                                       uint32_t* __restrict__ scratch, uint32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) uint8_t inflate_lds[];
     typedef LaneLds<LT, DT> Lds;
@@ -175,18 +179,31 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
     const bool live = m < nmem;
     if (lane < 19) L.clorder[lane] = CL_ORDER[lane];
     InflateMember me = {0, 0, 0, 0, 0, 0};
-    if (live) me = mem[m];
+    uint32_t stop_bit = 0, region_dw = 0, start_skip = 0, end_bit = 0;
+    bool no_text_before = true;
+    if constexpr (STREAM) {
+        if (live) {
+            const GzChunk g = reinterpret_cast<const GzChunk*>(mem_)[m];
+            me.in_off = g.start_bit >> 3; start_skip = g.start_bit & 7u;
+            me.out_len = 0xFFFFFFFFu; // (no ISIZE: the scratch region is the bound)
+            me.match_off = g.scratch_off; region_dw = g.scratch_dw; stop_bit = g.stop_bit;
+            no_text_before = (g.flags & 1u) != 0u;
+        }
+    } else {
+        if (live) me = reinterpret_cast<const InflateMember*>(mem_)[m];
+    }
     const uint32_t w0 = me.in_off >> 2;
     const uint32_t* const src = reinterpret_cast<const uint32_t*>(comp) + w0;
-    uint32_t in_lim = live ? ((me.in_off & 3u) + me.in_len + 32u + 3u) >> 2 : 0u; // dwords of this stream worth loading (footer and a little more: the caller's buffer has 64 bytes of slack)
+    uint32_t in_lim = live ? (STREAM ? 0xFFFFFFF0u : ((me.in_off & 3u) + me.in_len + 32u + 3u) >> 2) : 0u; // dwords of this stream worth loading (footer and a little more: the caller's buffer has 64 bytes of slack)
     { const uint32_t have = (comp_bytes >> 2) > w0 ? (comp_bytes >> 2) - w0 : 0u; if (in_lim > have) in_lim = have; }
     in_lim &= ~3u; // (whole 16-byte requests; the 32 bytes above leave the deflate data and two more dwords inside them)
     uint32_t* const ents = scratch + me.match_off;
-    uint32_t* const lits_top = ents + (scratch_dwords(me.out_len) - 1u); // literal dword d lives at lits_top[-d]
+    uint32_t* const lits_top = ents + ((STREAM ? region_dw : scratch_dwords(me.out_len)) - 1u); // literal dword d lives at lits_top[-d]
     uint64_t bb = 0;
     uint32_t nb = 0, in_r = 0, in_w = 0;
     uint32_t state = live ? ST_BLOCK : ST_FIN, bad = 0, need_build = 0;
-    if (live && me.out_len > WIN_BYTES) { bad = 1; state = ST_FIN; }
+    if (!STREAM && live && me.out_len > WIN_BYTES) { bad = 1; state = ST_FIN; }
+    if (STREAM && live && region_dw < 64u) { bad = 22; state = ST_FIN; }
     uint32_t op = 0, run = 0, lit_n = 0, lit_acc = 0, out_f = 0, out_target = 0, ent_w = 0, ent_f = 0;
     uint32_t final_block = 0, nlit = 0, ndist = 0, ncl = 0, hi = 0, prev = 0, stored_left = 0;
     Quad pend = {{0, 0, 0, 0}};
@@ -271,8 +288,12 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
 #endif
     for (;;) {
         // (a stream that cannot go on -- its input used up, or nothing decoded for far longer than a member takes -- is the host's)
-        if (state != ST_FIN && state != ST_DONE && ((!pending && in_w + 4u > in_lim && in_r == in_w && nav == 0u && nb <= 32u) || periods > 400000u)) fail(2);
+        if (state != ST_FIN && state != ST_DONE && ((!pending && in_w + 4u > in_lim && in_r == in_w && nav == 0u && nb <= 32u) || periods > (STREAM ? 6000000u : 400000u))) fail(2);
         ++periods;
+        if constexpr (STREAM) { // what a period can add at most (8 entries, 2 literal dwords, a carry entry) still fits
+            if (state != ST_FIN && ent_w + ((lit_n + 3u) >> 2) + 24u > region_dw) fail(22);
+            if (state != ST_FIN && state != ST_DONE && !first_period && 32u * (w0 + in_r - nav) - nb > stop_bit + (1u << 27)) fail(23);
+        }
         // ---- the wave's memory traffic: once per period, for all lanes
         if (pending) {
 #pragma unroll
@@ -282,11 +303,12 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
         if (first_period) { // the stream begins inside its first dword
             first_period = false;
             topup(); topup(); refill(); topup();
-            if (live && nb) { const uint32_t skip = (me.in_off & 3u) * 8u; bb >>= skip; nb -= skip; }
+            if (live && nb) { const uint32_t skip = (me.in_off & 3u) * 8u + start_skip; bb >>= skip; nb -= skip; }
         }
         if (state == ST_DONE && ent_w - ent_f < (uint32_t)ENT_RING) { // the tail: literals after the last match, the last partial dword
-            if (op != me.out_len) fail(21);
+            if (!STREAM && op != me.out_len) fail(21);
             else {
+                if constexpr (STREAM) end_bit = 32u * (w0 + in_r - nav) - nb; // (nothing was taken since the block ended)
                 push_entry(run);
                 if (lit_n & 3u) L.outr[((lit_n >> 2) & (OUT_RING - 1)) * IW + lane] = lit_acc;
                 state = ST_FIN;
@@ -320,6 +342,11 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
             ++dbg_hdr;
 #endif
             topup(); refill(); topup();
+            if constexpr (STREAM) {
+                // at a block boundary: the chunk ends here once the stop position is reached (the next chunk begins at this very bit --
+                // the host checks that it does; a chunk that runs 16 MB past it without meeting a boundary is no deflate data: above)
+                if (state == ST_BLOCK && 32u * (w0 + in_r - nav) - nb >= stop_bit) state = ST_DONE;
+            }
             if (state == ST_BLOCK) {
                 if (nb >= 3u) {
                     final_block = take(1);
@@ -456,7 +483,7 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
             // a distance: the match becomes an entry
             const uint32_t dist = dbase + x;
             const bool dgo = go && is_dist;
-            const bool match = dgo && dist <= op && op + pend_len <= me.out_len;
+            const bool match = dgo && (dist <= op || (STREAM && !no_text_before)) && op + pend_len <= me.out_len;
             slow = dgo && !match ? 4u : slow;
             L.entr[match ? (ent_w & (ENT_RING - 1)) * IW + lane : ENT_RING * IW + lane] = run | (pend_len << 8) | ((dist - 1u) << 17);
             ent_w += match ? 1u : 0u;
@@ -473,7 +500,15 @@ __global__ __launch_bounds__(IW) void k_inflate_lanes(const uint8_t* __restrict_
 #ifdef RK_INFLATE_DEBUG
     if (blockIdx.x == 0 && lane == 0) printf("inflate dbg: periods %u steps %u symbols %u (%.1f lanes per step; %.1f lanes in SYM state) header iterations %u long-code passes %u builds %u\n", periods, dbg_steps, dbg_sym, (double)dbg_sym / dbg_steps, (double)dbg_symlanes / dbg_steps, dbg_hdr, dbg_long, dbg_build);
 #endif
-    if (live) { status[m] = bad; status[nmem + m] = bad ? 0u : ent_w | (lit_n << 15); } // (at most 22 106 entries, 65 536 literals)
+    if constexpr (STREAM) {
+        if (live) {
+            GzChunk& g = reinterpret_cast<GzChunk*>(const_cast<void*>(mem_))[m];
+            g.status = bad; g.end_bit = end_bit; g.final_seen = bad ? 0u : final_block;
+            g.out_len = bad ? 0u : op; g.nent = bad ? 0u : ent_w; g.nlit = bad ? 0u : lit_n;
+        }
+    } else {
+        if (live) { status[m] = bad; status[nmem + m] = bad ? 0u : ent_w | (lit_n << 15); } // (at most 22 106 entries, 65 536 literals)
+    }
 }
 
 // Pass 2: the member's text built in LDS from its literal stream and its entries, and written out as it becomes final.
@@ -506,27 +541,49 @@ __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
     return v;
 }
-__global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __restrict__ mem, uint32_t nmem, uint8_t* __restrict__ text, const uint32_t* __restrict__ scratch,
-                                                      const uint32_t* __restrict__ status) {
+// STREAM (chunks of an ordinary gzip stream, rk_gunzip.hip): a chunk's matches may copy from the 32 KB of text in front of it, which
+// nobody knows yet when the chunks are placed side by side.  The window is then given 32 KB of PATTERN in front of the text --
+// window index j < 32768 holds pattern(j) -- and the chunk is placed three times, into three planes: pattern A (j & 255),
+// B (j >> 8), C (255).  A byte of the text that is its own shows the same value in all planes; one that was copied (through any chain
+// of matches) from byte j of the text in front shows (j & 255, j >> 8, 255), and j >> 8 < 128 tells the two apart when all else is
+// equal -- k_gz_resolve turns the planes into text once the windows are known (k_gz_windows, in stream order).
+// A chunk may be of any length: window indices wrap modulo P2_R as often as it takes.
+template <bool STREAM>
+__global__ __launch_bounds__(IW) void k_inflate_place(const void* __restrict__ mem_, uint32_t nmem, uint8_t* __restrict__ text, const uint32_t* __restrict__ scratch,
+                                                      const uint32_t* __restrict__ status, uint32_t pattern) {
     __shared__ __attribute__((aligned(16))) uint8_t win[P2_R + 16];
     __shared__ uint32_t s_ent[P2_SB];
     __shared__ __attribute__((aligned(16))) uint32_t s_lit[P2_LIT / 4 + 4];
     const int lane = threadIdx.x;
     const uint32_t m = blockIdx.x;
-    if (m >= nmem || status[m] != 0u) return;
-    const uint32_t nent = status[nmem + m] & 0x7FFFu, nlit = status[nmem + m] >> 15;
-    const InflateMember me = mem[m];
-    const uint32_t n = me.out_len;
-    const uint32_t* const ents = scratch + me.match_off;
-    const uint32_t* const lits_top = ents + (scratch_dwords(n) - 1u); // literal dword d lives at lits_top[-d] (pass 1)
+    if (m >= nmem) return;
+    uint32_t nent, nlit, n, out_off, match_off, region_dw = 0;
+    if constexpr (STREAM) {
+        const GzChunk g = reinterpret_cast<const GzChunk*>(mem_)[m];
+        if (g.status != 0u) return;
+        nent = g.nent; nlit = g.nlit; n = g.out_len; out_off = g.out_off; match_off = g.scratch_off; region_dw = g.scratch_dw;
+    } else {
+        if (status[m] != 0u) return;
+        nent = status[nmem + m] & 0x7FFFu; nlit = status[nmem + m] >> 15;
+        const InflateMember me = reinterpret_cast<const InflateMember*>(mem_)[m];
+        n = me.out_len; out_off = me.out_off; match_off = me.match_off;
+    }
+    constexpr uint32_t K0 = STREAM ? 32768u : 0u; // window index of the first 16-byte group that holds text
+    const uint32_t* const ents = scratch + match_off;
+    const uint32_t* const lits_top = ents + ((STREAM ? region_dw : scratch_dwords(n)) - 1u); // literal dword d lives at lits_top[-d] (pass 1)
     auto lit_global = [&](uint32_t idx) -> uint8_t { return (uint8_t)(*(lits_top - (idx >> 2)) >> (8u * (idx & 3u))); };
-    uint8_t* const dst = text + me.out_off;
-    const uint32_t wb = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u); // window index of the text's first byte
+    uint8_t* const dst = text + out_off;
+    const uint32_t wb = K0 + (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u); // window index of the text's first byte
     uint8_t* const a0 = dst - wb;                                            // address of window index 0 (16-byte aligned)
     const uint8_t* const sl8 = reinterpret_cast<const uint8_t*>(s_lit);
-    auto wi = [](uint32_t k) -> uint32_t { return k >= P2_R ? k - P2_R : k; }; // place of window index k (k < 2 P2_R: a member is at most 64 KB)
+    // place of window index k (members: k < 2 P2_R, a member is at most 64 KB)
+    auto wi = [](uint32_t k) -> uint32_t { if constexpr (STREAM) return k % P2_R; else return k >= P2_R ? k - P2_R : k; };
     uint32_t kp = wb, lp0 = 0;           // window index of the next output byte; position in the literal stream
-    uint32_t flushed = 0;                // window indices below it are in global memory (a multiple of 16, or the head's end)
+    uint32_t flushed = K0;               // window indices below it are in global memory (a multiple of 16, or the head's end)
+    if constexpr (STREAM) {
+        for (uint32_t j = (uint32_t)lane; j < 32768u; j += IW) win[j] = (uint8_t)(pattern == 0u ? j : (pattern == 1u ? j >> 8 : 255u));
+        isync();
+    }
     uint32_t lit_base = 0, lit_have = 0; // s_lit holds the literal bytes [lit_base, lit_base + lit_have)
     constexpr uint32_t LIT_DW = P2_LIT / 4 + 1, LIT_K = (LIT_DW + IW - 1) / IW;
     const uint32_t lit_dw_end = (nlit + 3u) >> 2; // dwords pass 1 wrote
@@ -543,9 +600,9 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __res
     };
     // whole 16-byte groups below window index `upto` leave (what is below the current batch is final)
     auto flush_to = [&](uint32_t upto) {
-        if (flushed == 0u && wb != 0u && upto >= 16u) { // the first group holds bytes in front of the text: its text bytes one by one
-            if ((uint32_t)lane >= wb && lane < 16) a0[lane] = win[lane];
-            flushed = 16u;
+        if (flushed == K0 && wb != K0 && upto >= K0 + 16u) { // the first group holds bytes in front of the text: its text bytes one by one
+            if ((uint32_t)lane >= wb - K0 && lane < 16) a0[K0 + lane] = win[K0 + lane];
+            flushed = K0 + 16u;
         }
         const uint32_t hi = upto & ~15u;
         for (uint32_t k = flushed + 16u * (uint32_t)lane; k < hi; k += 16u * IW) *reinterpret_cast<uint4*>(a0 + k) = *reinterpret_cast<const uint4*>(win + wi(k));
@@ -610,7 +667,7 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __res
                 const bool mine = ((um >> lane) & 1ull) != 0ull && (at - dist + len <= atF || lane == F);
                 const uint32_t ks = at - dist; // window index of the source
                 // a copy that would touch both sides of the wrap at P2_R (source or destination; one match in a thousand) goes byte by byte
-                const bool wrap = (ks < P2_R && ks + 24u > P2_R) || (at < P2_R && at + len > P2_R);
+                const bool wrap = STREAM ? (wi(ks) + 24u > P2_R || wi(at) + len > P2_R) : ((ks < P2_R && ks + 24u > P2_R) || (at < P2_R && at + len > P2_R));
                 for (uint64_t lm = __ballot(mine && len >= 24u); lm; lm &= lm - 1ull) { // long: 64 lanes per copy; a source that overlaps its output repeats with period dist
                     const int j = __builtin_ctzll(lm);
                     const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)at, j), ln = (uint32_t)__builtin_amdgcn_readlane((int)len, j),
@@ -647,9 +704,9 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __res
     isync();
     // what is left: the head (a text that ends inside the first group), the last whole groups, the tail bytes
     const uint32_t endk = wb + n;
-    if (flushed == 0u && wb != 0u) {
-        const uint32_t hb = endk < 16u ? endk : 16u;
-        if ((uint32_t)lane >= wb && (uint32_t)lane < hb) a0[lane] = win[lane];
+    if (flushed == K0 && wb != K0) {
+        const uint32_t hb = endk < K0 + 16u ? endk : K0 + 16u;
+        if (K0 + (uint32_t)lane >= wb && K0 + (uint32_t)lane < hb) a0[K0 + lane] = win[K0 + lane];
         flushed = hb;
     }
     if (flushed < endk) {
@@ -663,15 +720,9 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const InflateMember* __res
 // the host by tools/crc32_check.cpp).  A member whose text does not give the CRC-32 of its footer gets status 30 -- the caller hands
 // the job to the host inflater, which reports the damage.
 __device__ const Crc32Tables CRC32_TABLES = make_crc32_tables();
-__global__ __launch_bounds__(256) void k_crc32_members(const InflateMember* __restrict__ mem, uint32_t nmem, const uint8_t* __restrict__ text,
-                                                       const uint8_t* __restrict__ comp, uint32_t* __restrict__ status) {
-    __shared__ uint32_t byte_t[256];
-    byte_t[threadIdx.x] = CRC32_TABLES.byte[threadIdx.x];
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, m = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (m >= nmem || status[m] != 0u) return;
-    const InflateMember me = mem[m];
-    const Crc32Piece p = crc32_piece(me.out_off, me.out_len, lane);
+// the wave's CRC-32 of text[off, off + len), len <= 65536 (every lane returns it); byte_t = the byte table in LDS
+__device__ __forceinline__ uint32_t wave_crc32(const uint32_t* byte_t, const uint8_t* __restrict__ text, uint32_t off, uint32_t len, uint32_t lane) {
+    const Crc32Piece p = crc32_piece(off, len, lane);
     uint32_t s = p.init;
     for (uint32_t g = p.b & ~15u; g < p.e; g += 16u) { // (the text buffer is 16-byte aligned and readable a little past its end)
         const uint4 v = *reinterpret_cast<const uint4*>(text + g);
@@ -686,11 +737,33 @@ __global__ __launch_bounds__(256) void k_crc32_members(const InflateMember* __re
     uint32_t x = (p.e > p.b || lane == 0u) ? crc32_advance(CRC32_TABLES, s, p.z) : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) x ^= (uint32_t)__shfl_xor((int)x, d);
+    return ~x;
+}
+__global__ __launch_bounds__(256) void k_crc32_members(const InflateMember* __restrict__ mem, uint32_t nmem, const uint8_t* __restrict__ text,
+                                                       const uint8_t* __restrict__ comp, uint32_t* __restrict__ status) {
+    __shared__ uint32_t byte_t[256];
+    byte_t[threadIdx.x] = CRC32_TABLES.byte[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, m = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (m >= nmem || status[m] != 0u) return;
+    const InflateMember me = mem[m];
+    const uint32_t crc = wave_crc32(byte_t, text, me.out_off, me.out_len, lane);
     if (lane == 0u) {
         const uint8_t* f = comp + me.in_off + me.in_len; // the member's footer: CRC-32, ISIZE (little endian, any alignment)
         const uint32_t want = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 24);
-        if (~x != want) status[m] = 30u;
+        if (crc != want) status[m] = 30u;
     }
+}
+// crc[i] = CRC-32 of text[64 K i, 64 K (i + 1)) within [0, n): the host joins them (crc32_combine) into the stream's
+__global__ __launch_bounds__(256) void k_crc32_segments(const uint8_t* __restrict__ text, uint32_t n, uint32_t* __restrict__ crc) {
+    __shared__ uint32_t byte_t[256];
+    byte_t[threadIdx.x] = CRC32_TABLES.byte[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, m = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t off = m << 16;
+    if (off >= n) return;
+    const uint32_t c = wave_crc32(byte_t, text, off, n - off < 65536u ? n - off : 65536u, lane);
+    if (lane == 0u) crc[m] = c;
 }
 
 // first record start (four-line rule, as find_record_start in rk_parse.cpp) at or after `from` in text[0 .. n): a line start p with
@@ -718,6 +791,160 @@ __global__ __launch_bounds__(256) void k_fastq_first_start(const uint8_t* __rest
     }
 }
 
+// ---- an ordinary gzip file: ONE deflate stream (rk_gunzip.hip drives these; the reference reads it with gzread, rkmh.cpp:238-263) ----
+// Pass 1's output needs no window, so a lane can decode from any block header of the stream.  Block headers are not marked in a
+// deflate stream; k_gz_find_starts looks for them: from every chunk boundary (a fixed stride of compressed bytes) on, every bit
+// position is tried as the start of a non-final dynamic-Huffman block -- 3 header bits, counts in range, a complete code-length
+// code, nlit + ndist code lengths that decode and form complete literal/length and distance codes, an end-of-block code.  Random
+// bits pass all of that about once in 10^8..10^9 positions; a false start costs only the work of one lane: the chunk in front of
+// it does not end at it (pass 1 reports where every chunk ended), and the host joins the chain from true starts only.
+struct __attribute__((packed, aligned(1))) g_u64 { uint64_t v; }; // eight bytes at any global address
+__device__ __forceinline__ uint64_t gz_peek(const uint8_t* __restrict__ comp, uint32_t pos) { return reinterpret_cast<const g_u64*>(comp + (pos >> 3))->v >> (pos & 7u); } // >= 57 bits
+__device__ bool gz_header_ok(const uint8_t* __restrict__ comp, uint32_t pos, uint32_t nbits) {
+    if (pos + 4096u > nbits) return false; // (a last block this close to the end is left to the chunk in front of it)
+    uint64_t w = gz_peek(comp, pos);
+    if ((w & 7u) != 4u) return false; // BFINAL = 0, BTYPE = 2
+    const uint32_t nlit = (uint32_t)((w >> 3) & 31u) + 257u, ndist = (uint32_t)((w >> 8) & 31u) + 1u, ncl = (uint32_t)((w >> 13) & 15u) + 4u;
+    if (nlit > 286u || ndist > 30u) return false;
+    // the code-length code: 3 bits per length, complete (zlib refuses anything else: inftrees.c, type CODES)
+    uint32_t p = pos + 17u;
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint8_t cl[19];
+#pragma unroll
+    for (int i = 0; i < 19; ++i) cl[i] = 0;
+    w = gz_peek(comp, p); // (>= 57 bits: all 19 lengths)
+    uint32_t kraft = 0;
+    for (uint32_t i = 0; i < ncl; ++i) {
+        const uint32_t l = (uint32_t)(w >> (3u * i)) & 7u;
+        cl[CL_ORDER[i]] = (uint8_t)l;
+        if (l) { kraft += 128u >> l; ++cnt[l]; }
+    }
+    if (kraft != 128u) return false;
+    p += 3u * ncl;
+    // symbols in (length, symbol) order, for a canonical walk (puff.c's decode): 19 symbols at most
+    uint8_t sym[19];
+    {
+        uint32_t offs[8];
+        offs[1] = 0;
+        for (int l = 1; l < 7; ++l) offs[l + 1] = offs[l] + cnt[l];
+        for (int i = 0; i < 19; ++i) if (cl[i]) sym[offs[cl[i]]++] = (uint8_t)i;
+    }
+    uint32_t lit_kraft = 0, dist_kraft = 0, lit_max = 0, dist_max = 0, prev = 0, eob_len = 0;
+    const uint32_t total = nlit + ndist;
+    for (uint32_t i = 0; i < total;) {
+        w = gz_peek(comp, p);
+        int code = 0, first = 0, index = 0;
+        uint32_t s = 99, used = 0;
+        for (uint32_t l = 1; l <= 7u; ++l) {
+            code |= (int)((w >> (l - 1u)) & 1u);
+            const int c = (int)cnt[l];
+            if (code - c < first) { s = sym[index + (code - first)]; used = l; break; }
+            index += c; first += c; first <<= 1; code <<= 1;
+        }
+        if (s == 99u) return false;
+        w >>= used; p += used;
+        uint32_t rep = 1, val = s;
+        if (s == 16u) { if (i == 0u) return false; rep = 3u + (uint32_t)(w & 3u); p += 2u; val = prev; }
+        else if (s == 17u) { rep = 3u + (uint32_t)(w & 7u); p += 3u; val = 0; }
+        else if (s == 18u) { rep = 11u + (uint32_t)(w & 127u); p += 7u; val = 0; }
+        if (i + rep > total) return false;
+        if (s < 16u) prev = s; else if (s != 16u) prev = 0;
+        for (uint32_t j = 0; j < rep; ++j, ++i) {
+            if (!val) continue;
+            if (i < nlit) { lit_kraft += 32768u >> val; if (val > lit_max) lit_max = val; if (i == 256u) eob_len = val; }
+            else { dist_kraft += 32768u >> val; if (val > dist_max) dist_max = val; }
+        }
+        if (p + 64u > nbits) return false;
+    }
+    if (eob_len == 0u) return false;
+    if (lit_kraft > 32768u || (lit_kraft < 32768u && lit_max != 1u)) return false;
+    if (dist_kraft > 32768u || (dist_kraft < 32768u && dist_max > 1u)) return false;
+    return true;
+}
+// found[b] = the first bit position in [from[b], to[b]) that looks like a block header, 0xFFFFFFFF if none does
+__global__ __launch_bounds__(256) void k_gz_find_starts(const uint8_t* __restrict__ comp, uint32_t nbits, const uint32_t* __restrict__ from, const uint32_t* __restrict__ to,
+                                                        uint32_t* __restrict__ found) {
+    __shared__ uint32_t best;
+    if (threadIdx.x == 0) best = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t lo = from[blockIdx.x], hi = to[blockIdx.x];
+    for (uint32_t base = lo; base < hi; base += 256u) {
+        const uint32_t pos = base + threadIdx.x;
+        if (pos < hi && gz_header_ok(comp, pos, nbits)) atomicMin(&best, pos);
+        __syncthreads();
+        if (best != 0xFFFFFFFFu) break;
+    }
+    if (threadIdx.x == 0) found[blockIdx.x] = best;
+}
+
+// The windows, in stream order (ONE workgroup: every chunk's window is the one before it plus its own last 32 KB).  rings[c] = the
+// 32 KB of text in front of chunk c as a ring -- byte j of that window (j = 0: 32 KB back) lies at rings[c][(heads[c] + j) & 32767];
+// rings[0] / heads[0] are given (the text in front of the first chunk; any bytes for the stream's first), rings[1 .. n] are written.
+__global__ __launch_bounds__(1024) void k_gz_windows(const GzChunk* __restrict__ chunks, uint32_t nchunk, const uint8_t* __restrict__ planes, size_t plane_stride,
+                                                     uint8_t* __restrict__ rings, uint32_t* __restrict__ heads) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring[32768];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t r = 0; r < 2u; ++r) reinterpret_cast<uint4*>(ring)[tid + 1024u * r] = reinterpret_cast<const uint4*>(rings)[tid + 1024u * r];
+    uint32_t head = heads[0] & 32767u;
+    __syncthreads();
+    for (uint32_t c = 0; c < nchunk; ++c) {
+        const uint32_t n = chunks[c].out_len, take = n < 32768u ? n : 32768u;
+        const size_t src = (size_t)chunks[c].out_off + (n - take);
+        uint8_t v[32];
+        const uint32_t i0 = tid * 32u;
+        if (i0 < take) {
+#pragma unroll
+            for (uint32_t b = 0; b < 32u; ++b) {
+                const uint32_t i = i0 + b;
+                uint32_t A = 0, B = 0, C = 0;
+                if (i < take) { A = planes[src + i]; B = planes[plane_stride + src + i]; C = planes[2 * plane_stride + src + i]; }
+                v[b] = (uint8_t)((C != 255u || B == 255u) ? C : ring[(head + (A | (B << 8))) & 32767u]);
+            }
+        }
+        __syncthreads();
+        if (i0 < take) {
+#pragma unroll
+            for (uint32_t b = 0; b < 32u; ++b) if (i0 + b < take) ring[(head + i0 + b) & 32767u] = v[b];
+        }
+        head = (head + take) & 32767u;
+        __syncthreads();
+        uint4* const dst = reinterpret_cast<uint4*>(rings + (size_t)(c + 1u) * 32768u);
+        for (uint32_t r = 0; r < 2u; ++r) dst[tid + 1024u * r] = reinterpret_cast<const uint4*>(ring)[tid + 1024u * r];
+        if (tid == 0) heads[c + 1u] = head;
+    }
+}
+// text[out_off + i] of every chunk from its planes and the window in front of it; gridDim.y workgroups share a chunk
+__global__ __launch_bounds__(256) void k_gz_resolve(const GzChunk* __restrict__ chunks, const uint8_t* __restrict__ planes, size_t plane_stride,
+                                                    const uint8_t* __restrict__ rings, const uint32_t* __restrict__ heads, uint8_t* __restrict__ text) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring[32768];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = chunks[c].out_len, off = chunks[c].out_off;
+    const uint32_t g_lo = off & ~15u, groups = (off + n + 15u - g_lo) >> 4; // whole 16-byte groups (the buffers are 16-byte aligned)
+    const uint32_t per = (groups + gridDim.y - 1u) / gridDim.y, ga = per * blockIdx.y, gb = ga + per < groups ? ga + per : groups;
+    if (ga >= gb) return;
+    for (uint32_t r = tid; r < 2048u; r += 256u) reinterpret_cast<uint4*>(ring)[r] = reinterpret_cast<const uint4*>(rings + (size_t)c * 32768u)[r];
+    const uint32_t head = heads[c] & 32767u;
+    __syncthreads();
+    for (uint32_t g = ga + tid; g < gb; g += 256u) {
+        const size_t at = (size_t)g_lo + 16u * (size_t)g;
+        const uint4 a = *reinterpret_cast<const uint4*>(planes + at), b = *reinterpret_cast<const uint4*>(planes + plane_stride + at),
+                    cc = *reinterpret_cast<const uint4*>(planes + 2 * plane_stride + at);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w}, cw[4] = {cc.x, cc.y, cc.z, cc.w};
+        uint32_t ow[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t A = (aw[j >> 2] >> (8 * (j & 3))) & 255u, B = (bw[j >> 2] >> (8 * (j & 3))) & 255u, C = (cw[j >> 2] >> (8 * (j & 3))) & 255u;
+            const uint32_t v = (C != 255u || B == 255u) ? C : ring[(head + (A | (B << 8))) & 32767u];
+            ow[j >> 2] |= v << (8 * (j & 3));
+        }
+        if (at >= off && at + 16u <= (size_t)off + n) *reinterpret_cast<uint4*>(text + at) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        else {
+            for (int j = 0; j < 16; ++j)
+                if (at + j >= off && at + j < (size_t)off + n) text[at + j] = (uint8_t)(ow[j >> 2] >> (8 * (j & 3)));
+        }
+    }
+}
+
 uint32_t inflate_scratch_dwords(uint32_t out_len) { return scratch_dwords(out_len); }
 hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint32_t* scratch, uint32_t* status,
                                   hipStream_t st) {
@@ -727,20 +954,53 @@ hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, cons
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
     if (!((attr_set.load(std::memory_order_acquire) >> dev) & 1ull) || dev == 63) {
-        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<8, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds<8, 6>));
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<8, 6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds<8, 6>));
         if (attr != hipSuccess) return attr;
         attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_inflate_lanes<8, 6>), dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds<8, 6>), st, comp, comp_bytes, mem, nmem, scratch, status);
-    hipLaunchKernelGGL(k_inflate_place, dim3(nmem), dim3(IW), 0, st, mem, nmem, text, scratch, status);
+    hipLaunchKernelGGL((k_inflate_lanes<8, 6, false>), dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds<8, 6>), st, comp, comp_bytes, mem, nmem, scratch, status);
+    hipLaunchKernelGGL(k_inflate_place<false>, dim3(nmem), dim3(IW), 0, st, mem, nmem, text, scratch, status, 0u);
     hipLaunchKernelGGL(k_crc32_members, dim3((nmem + 3) / 4), dim3(256), 0, st, mem, nmem, text, comp, status);
+    return hipGetLastError();
+}
+// the stream kernels (rk_gunzip.hip)
+static hipError_t stream_lanes_attr() {
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
+    if (!((attr_set.load(std::memory_order_acquire) >> dev) & 1ull) || dev == 63) {
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_lanes<8, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LaneLds<8, 6>));
+        if (attr != hipSuccess) return attr;
+        attr_set.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    return hipSuccess;
+}
+hipError_t launch_gz_find_starts(const uint8_t* comp, uint32_t nbits, const uint32_t* from, const uint32_t* to, uint32_t n, uint32_t* found, hipStream_t st) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_gz_find_starts, dim3(n), dim3(256), 0, st, comp, nbits, from, to, found);
+    return hipGetLastError();
+}
+hipError_t launch_gz_lanes(const uint8_t* comp, uint32_t comp_bytes, GzChunk* chunks, uint32_t n, uint32_t* scratch, hipStream_t st) {
+    if (!n) return hipSuccess;
+    const hipError_t a = stream_lanes_attr();
+    if (a != hipSuccess) return a;
+    hipLaunchKernelGGL((k_inflate_lanes<8, 6, true>), dim3((n + IW - 1) / IW), dim3(IW), sizeof(LaneLds<8, 6>), st, comp, comp_bytes, chunks, n, scratch, nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_gz_place(const GzChunk* chunks, uint32_t n, uint8_t* planes, size_t plane_stride, const uint32_t* scratch, uint8_t* rings, uint32_t* heads, uint8_t* text,
+                           uint32_t text_bytes, uint32_t* crc, hipStream_t st) {
+    if (!n) return hipSuccess;
+    for (uint32_t p = 0; p < 3u; ++p) hipLaunchKernelGGL(k_inflate_place<true>, dim3(n), dim3(IW), 0, st, chunks, n, planes + p * plane_stride, scratch, nullptr, p);
+    hipLaunchKernelGGL(k_gz_windows, dim3(1), dim3(1024), 0, st, chunks, n, planes, plane_stride, rings, heads);
+    hipLaunchKernelGGL(k_gz_resolve, dim3(n, 4), dim3(256), 0, st, chunks, planes, plane_stride, rings, heads, text);
+    if (text_bytes) hipLaunchKernelGGL(k_crc32_segments, dim3((((text_bytes + 65535u) >> 16) + 3u) / 4u), dim3(256), 0, st, text, text_bytes, crc);
     return hipGetLastError();
 }
 // (code objects are loaded at a TU's first launch -- tens of milliseconds; rk_warm_up asks for a kernel's attributes ahead of time instead)
 hipError_t warm_inflate() {
     hipFuncAttributes a;
-    hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_inflate_lanes<8, 6>));
-    if (e == hipSuccess) e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_inflate_place));
+    hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_inflate_lanes<8, 6, false>));
+    if (e == hipSuccess) e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_inflate_place<false>));
     if (e == hipSuccess) e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_crc32_members));
     return e;
 }

@@ -149,6 +149,26 @@ uint32_t inflate_scratch_dwords(uint32_t out_len);
 // status[0 .. nmem) = 0 / why the member could not be inflated, status[nmem .. 2 nmem) = its entries
 hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, const InflateMember* mem, uint32_t nmem, uint8_t* text, uint32_t* scratch, uint32_t* status,
                                   hipStream_t st);
+// ---- an ordinary gzip stream on the device (kernels in rk_inflate.hip, driven by rk_gunzip.hip) ----
+// A chunk of the stream: pass 1 decodes it from start_bit (a block header; bit offsets count from the compressed buffer's first byte) to
+// the first block boundary at or after stop_bit, into its part of the scratch buffer (scratch_dw dwords at dword scratch_off: entries
+// from the front, literals from the back), and reports where it ended and what it made; the host then gives the chunks that form
+// the stream their places in the text (out_off) for pass 2.
+struct GzChunk {
+    uint32_t start_bit, stop_bit, scratch_off, scratch_dw;
+    uint32_t flags;      // 1: the stream's first chunk (a match may not reach in front of it)
+    uint32_t status;     // out: 0, or why the lane gave up
+    uint32_t end_bit;    // out: the block boundary where it stopped
+    uint32_t final_seen; // out: 1 = it ended with the stream's last block
+    uint32_t out_len, nent, nlit; // out: bytes of text, entries, literals
+    uint32_t out_off;    // host: its text's place (pass 2)
+};
+hipError_t launch_gz_find_starts(const uint8_t* comp, uint32_t nbits, const uint32_t* from, const uint32_t* to, uint32_t n, uint32_t* found, hipStream_t st);
+hipError_t launch_gz_lanes(const uint8_t* comp, uint32_t comp_bytes, GzChunk* chunks, uint32_t n, uint32_t* scratch, hipStream_t st);
+// pass 2 of n chunks in stream order: three planes (plane_stride apart), the windows (rings: (n + 1) x 32 KB, heads: n + 1 -- [0] given),
+// the text (text[out_off ..) of every chunk), and the CRC-32 of every 64 KB segment of text[0, text_bytes)
+hipError_t launch_gz_place(const GzChunk* chunks, uint32_t n, uint8_t* planes, size_t plane_stride, const uint32_t* scratch, uint8_t* rings, uint32_t* heads, uint8_t* text,
+                           uint32_t text_bytes, uint32_t* crc, hipStream_t st);
 // cuts[which] = first FASTQ record start (four-line rule) at or after `from`; n: none and the text ends here; 0xFFFFFFFF: not decidable from this text
 hipError_t launch_fastq_first_start(const uint8_t* text, uint32_t n, uint32_t from, uint32_t window, bool at_eof, uint32_t* cuts, int which, hipStream_t st);
 // whole-array ascending sort of u64 keys in place (rk_sort.hip: rocPRIM radix sort); tmp holds sort_u64_temp_bytes(n) bytes

@@ -466,6 +466,14 @@ static bool bgzf_on_device() {
 }
 static long env_long(const char* name, long dflt, long lo, long hi) { const char* e = getenv(name); if (!e) return dflt; const long v = atol(e); return v < lo || v > hi ? dflt : v; }
 static rk_bgzf* bgzf_of(const char* path) { auto it = g_bgzf.find(path); return it == g_bgzf.end() ? nullptr : it->second; }
+// ordinary gzip read files (one deflate stream): inflated on the device as well (rk_gunzip.hip), stretch after stretch, one worker per
+// file; RKMH_GZIP_DEVICE=0 (or RKMH_BGZF_DEVICE=0) leaves them to zlib and the host scanner
+static std::map<std::string, rk_gzip*> g_gzip;
+static bool gzip_on_device() {
+    static const bool on = [] { const char* e = getenv("RKMH_GZIP_DEVICE"); return !(e && atoi(e) == 0); }();
+    return on && bgzf_on_device();
+}
+static rk_gzip* gzip_of(const char* path) { auto it = g_gzip.find(path); return it == g_gzip.end() ? nullptr : it->second; }
 
 // a regular, uncompressed file that begins with '@' (FASTQ reads) / '>' (FASTA references) -- or, for reads, a BGZF file whose text
 // does (*size is then the length of the text); RKMH_BGZF=0 leaves compressed files to the sequential zlib scanner
@@ -478,6 +486,15 @@ static bool raw_eligible(const char* path, int64_t* size, char first = '@') {
             if (rk_bgzf_first_byte(z) == '@') { g_bgzf[path] = z; *size = (int64_t)rk_bgzf_text_bytes(z); return true; }
             rk_bgzf_close(z);
             return false;
+        }
+        if (gzip_on_device()) {
+            if (rk_gzip* gz = gzip_of(path)) { *size = (int64_t)rk_gzip_text_bytes_hint(gz); return true; }
+            rk_gzip* gz = nullptr;
+            if (rk_gzip_open(path, &gz) == RK_OK) {
+                if (rk_gzip_first_byte(gz) == '@') { g_gzip[path] = gz; *size = (int64_t)rk_gzip_text_bytes_hint(gz); return true; }
+                rk_gzip_close(gz);
+                return false;
+            }
         }
     }
     const int fd = open(path, O_RDONLY);
@@ -657,7 +674,7 @@ struct RawEngine {
         // gets that many as long as the CPUs last -- not measured (one-GPU boxes), the same reasoning per link
         const long cap = g.size() > 1 ? std::min<long>(64, 6 * (long)g.size()) : 12;
         if (nw > cap) nw = cap;
-        const bool dev_inflate = !g_bgzf.empty() && bgzf_on_device();
+        const bool dev_inflate = (!g_bgzf.empty() || !g_gzip.empty()) && bgzf_on_device();
         // BGZF inflated on the host: a worker inflates its job's members before the upload (~1 GB/s of text per core with libdeflate,
         // a third of that with zlib) -- the CPUs, not the link, set the rate, so all but two of them work
         if (!g_bgzf.empty() && !dev_inflate) nw = std::max<long>(nw, std::min<long>(32, granted_cpus_main() - 2));
@@ -672,14 +689,19 @@ struct RawEngine {
             uint64_t largest = 0;
             for (auto& kv : g_bgzf) largest = std::max<uint64_t>(largest, rk_bgzf_text_bytes(kv.second));
             mega = std::min<uint64_t>((uint64_t)1 << 30, std::max<uint64_t>((uint64_t)4 << 20, largest / 3 + ((uint64_t)1 << 20)));
+            // (an ordinary gzip file is ONE stream: its stretches follow each other on one worker, so a slot takes a whole file when it can)
+            for (auto& kv : g_gzip) mega = std::max<uint64_t>(mega, std::min<uint64_t>((uint64_t)1 << 30, rk_gzip_text_bytes_hint(kv.second) * 9 / 8 + ((uint64_t)8 << 20)));
             if (const long kb = env_long("RKMH_BGZF_JOB_KB", 0, 64, 1536 << 10)) mega = (uint64_t)kb << 10; // (tests: small jobs)
             pieces = (int)std::min<uint64_t>(32, std::max<uint64_t>(1, mega >> 25)); // ~32 MB of text per output piece
             pieces = (int)env_long("RKMH_BGZF_PIECES", pieces, 1, 32);
         }
-        const long ndev = dev_inflate ? env_long("RKMH_BGZF_DEVICE_WORKERS", 3, 1, 16) * (long)g.size() : 0;
+        // (pass 1 holds two waves per CU, 512 on the chip, for ~30 ms whatever a launch's size: the jobs in flight together should fill
+        // those and not more -- three workers for jobs of 200-256 waves, up to six for the smaller jobs of smaller files)
+        const long job_waves = (long)(mega / 65280 / 64) + 1;
+        const long ndev = dev_inflate ? env_long("RKMH_BGZF_DEVICE_WORKERS", std::min<long>(6, std::max<long>(3, 512 / job_waves)), 1, 16) * (long)g.size() : 0;
         // (a run whose read files are ALL BGZF needs no plain-text workers -- their page-locked buffers are the start-up cost of this path)
         if (need_plain_workers || !g_read_paths) all_bgzf = false;
-        else for (const char* p : *g_read_paths) if (!g_bgzf.count(p)) all_bgzf = false;
+        else for (const char* p : *g_read_paths) if (!g_bgzf.count(p) && !g_gzip.count(p)) all_bgzf = false;
         if (all_bgzf) nw = 0;
         w.resize((size_t)(nw + ndev));
         for (size_t i = 0; i < w.size(); ++i) {
@@ -713,6 +735,9 @@ static void register_bgzf_mappings() {
     std::lock_guard<std::mutex> l(rm);
     for (auto& kv : g_bgzf)
         if (!registered.count(kv.second)) registered[kv.second] = rk_host_register_readonly(rk_bgzf_image(kv.second), (size_t)rk_bgzf_file_bytes(kv.second)) == RK_OK;
+    static std::map<const rk_gzip*, bool> registered_gz;
+    for (auto& kv : g_gzip)
+        if (!registered_gz.count(kv.second)) registered_gz[kv.second] = rk_host_register_readonly(rk_gzip_image(kv.second), (size_t)rk_gzip_file_bytes(kv.second)) == RK_OK;
 }
 
 // records [lo, hi) of a classified block as a result of their own (the spans index the same text)
@@ -770,7 +795,7 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
     const bool counting = kind == RAW_COUNT;
     // bz: compressed (BGZF) -- a job is a run of members [lo, hi); mega: ... inflated on the device: large jobs, device-text slots,
     // eng.pieces block numbers each (else by the worker that takes the job)
-    struct File { const char* path = nullptr; int fd = -1; int64_t fsize = 0; rk_bgzf* bz = nullptr; bool mega = false; const uint8_t* fmap = nullptr; };
+    struct File { const char* path = nullptr; int fd = -1; int64_t fsize = 0; rk_bgzf* bz = nullptr; rk_gzip* gz = nullptr; bool mega = false; const uint8_t* fmap = nullptr; };
     std::vector<File> files(paths.size());
     const bool want_mmap = getenv("RKMH_RAW_MMAP") && atoi(getenv("RKMH_RAW_MMAP")) != 0;
     for (size_t i = 0; i < paths.size(); ++i) {
@@ -779,10 +804,12 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
         F.fd = open(F.path, O_RDONLY);
         if (F.fd < 0) { fprintf(stderr, "rkmh: cannot open %s\n", F.path); fail_exit(); }
         F.bz = bgzf_of(F.path);
-        F.mega = F.bz && eng.mega != 0;
+        F.gz = F.bz ? nullptr : gzip_of(F.path);
+        if (F.gz && eng.mega == 0) { fprintf(stderr, "rkmh: %s: no device-text slots for a gzip stream\n", F.path); fail_exit(); }
+        F.mega = (F.bz || F.gz) && eng.mega != 0;
         // RKMH_RAW_MMAP=1: the file is mapped and the mapping page-locked (hipHostRegister): the link reads the page cache itself, the
         // workers copy nothing (tools/ubench/mmap_register.hip)
-        if (!F.bz && F.fsize > 0 && want_mmap) {
+        if (!F.bz && !F.gz && F.fsize > 0 && want_mmap) {
             void* mp = mmap(nullptr, (size_t)F.fsize, PROT_READ, MAP_SHARED, F.fd, 0);
             if (mp != MAP_FAILED) {
                 if (rk_host_register_readonly(mp, (size_t)F.fsize) == RK_OK) F.fmap = (const uint8_t*)mp;
@@ -861,10 +888,49 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
             t_fm += now_s() - c;
             if (getenv("RKMH_TRACE_JOBS")) fprintf(stderr, "[job] worker %zu parked blocks %lld..%lld (%lld records)\n", wi, (long long)jb.seq, (long long)(jb.seq + jb.nseq - 1), (long long)res.nrec);
         };
+        // an ordinary gzip file: ONE job of this worker -- its stretches in order, eng.pieces block numbers each
+        auto gzip_file = [&](const Job& fj) {
+            const File& F = files[fj.file];
+            const int64_t per = eng.pieces, ncalls = fj.nseq / per;
+            bool handed_over = false;
+            for (int64_t r = 0; r < ncalls; ++r) {
+                Job sub; sub.file = fj.file; sub.seq = fj.seq + r * per; sub.nseq = per;
+                if (handed_over || sub.seq > fail_seq.load()) { put_empty(sub, 0); continue; }
+                const double a = now_s();
+                uint64_t nbytes = 0, off = 0;
+                const int rc = rk_fastq_slot_load_gzip(slot, F.gz, r, &nbytes, &off);
+                if (rc < 0) { fprintf(stderr, "rkmh: %s: %s\n", F.path, rk_last_error()); fail_exit(); }
+                sub.at = (int64_t)off;
+                if (rc != RK_OK) { // the sequential reader takes the file over from this stretch's first record
+                    if (g_timing) fprintf(stderr, "[rkmh timing] %s: the device inflater stops at byte %lld of the text\n", F.path, (long long)off);
+                    declare_failed(sub); put_empty(sub, 0); handed_over = true;
+                    t_rd += now_s() - a;
+                    continue;
+                }
+                if (nbytes == 0) { put_empty(sub, 0); t_rd += now_s() - a; continue; }
+                if (counting) {
+                    t_rd += now_s() - a;
+                    const double b = now_s();
+                    int32_t status = 0; int64_t nrec = 0;
+                    const int crc = rk_fastq_slot_count(slot, nbytes, (*cnts)[W.dev], &status, &nrec);
+                    if (crc == RK_ERR_NEED_FULL) { g_need_full.store(true); status = 1; }
+                    else if (crc != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+                    if (status != 0) { declare_failed(sub); handed_over = true; }
+                    t_dv += now_s() - b; ++nblk; nrec_ += nrec;
+                    continue;
+                }
+                if (rk_fastq_slot_submit(slot, nbytes) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+                t_rd += now_s() - a;
+                finish_block(sub);
+                if (fail_seq.load() <= sub.seq) handed_over = true; // (text that is not four lines per record)
+            }
+            rk_gzip_release_device(F.gz);
+        };
         for (;;) {
             if (!jobs.pop(&cur)) break;
             // (a failure is declared at the first block number of the failing worker's own job: never inside another job's run)
             if (cur.seq > fail_seq.load()) { put_empty(cur, 0); continue; } // the scanner will redo this range
+            if (files[cur.file].gz) { gzip_file(cur); continue; }
             const File& F = files[cur.file];
             rk_bgzf* const bz = F.bz;
             const char* const path = F.path;
@@ -939,6 +1005,14 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
     int64_t seq = 0;
     for (size_t fi = 0; fi < files.size() && fail_seq.load() == INT64_MAX; ++fi) {
         const File& F = files[fi];
+        if (F.gz) { // one job: the file's stretches, in order, on one worker
+            const int64_t ncalls = rk_gzip_plan(F.gz, eng.mega);
+            if (ncalls < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+            Job jb; jb.file = fi; jb.seq = seq; jb.nseq = ncalls * eng.pieces;
+            seq += jb.nseq;
+            jobs_mega.push(jb);
+            continue;
+        }
         if (F.bz) { // jobs = runs of members holding about a block of text (the records are cut after inflating)
             const uint64_t per_job = F.mega ? eng.mega : eng.block;
             const uint64_t target = per_job > ((uint64_t)1 << 20) ? per_job - ((uint64_t)1 << 18) : per_job * 3 / 4;
@@ -1623,7 +1697,7 @@ static int main_stream(int argc, char** argv) {
         const bool prepare = !pre_refs ? !refs_for_device(o) : true;
         warm = std::thread([&o, &eng, &group, prepare] {
             const std::vector<int> ids = o.devices.empty() ? std::vector<int>{o.device} : o.devices;
-            for (int id : ids) rk_warm_up(id, !g_bgzf.empty() && bgzf_on_device());
+            for (int id : ids) rk_warm_up(id, (!g_bgzf.empty() || !g_gzip.empty()) && bgzf_on_device());
             if (prepare && eng.create(group)) register_bgzf_mappings();
         });
     }
@@ -1821,7 +1895,7 @@ static int main_filter(int argc, char** argv) {
     if (all_raw && !refs_for_device(o) && !(getenv("RKMH_WARM_UP") && atoi(getenv("RKMH_WARM_UP")) == 0))
         prep = std::thread([&o, &eng, &group] {
             const std::vector<int> ids = o.devices.empty() ? std::vector<int>{o.device} : o.devices;
-            for (int id : ids) rk_warm_up(id, !g_bgzf.empty() && bgzf_on_device());
+            for (int id : ids) rk_warm_up(id, (!g_bgzf.empty() || !g_gzip.empty()) && bgzf_on_device());
             if (eng.create(group)) register_bgzf_mappings();
         });
     // file mode compares read_min_lens with 0 (rkmh.cpp:1292); the STDIN lines print min(len) itself (:1397): exact there
