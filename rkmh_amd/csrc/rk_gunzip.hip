@@ -329,6 +329,12 @@ int gzip_next(rk_gzip* gz, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t cal
         HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(h_info + 1) + 1, all + ntext - 1, 1, hipMemcpyDeviceToHost, st));
     }
     RKCHK(sync());
+    if (const char* dump = getenv("RKMH_GZIP_DUMP")) { // (debugging: this call's text, as the device built it, appended to a file)
+        std::vector<uint8_t> h(total);
+        if (total) HIPCHK(hipMemcpy(h.data(), text, total, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(dump, "ab")) { fwrite(h.data(), 1, h.size(), f); fclose(f); }
+        if (timing) for (uint32_t i = 0; i < nch; ++i) fprintf(stderr, "[gzip device] chunk %u: bits %u .. %u, text %u + %u, %u entries, %u literals\n", i, hc[i].start_bit, hc[i].end_bit, hc[i].out_off, hc[i].out_len, hc[i].nent, hc[i].nlit);
+    }
     // the stream's CRC-32 so far; at its end, the trailer's word on it
     for (uint32_t sg = 0; sg < nseg; ++sg) {
         const uint32_t len = std::min<uint32_t>(65536u, total - (sg << 16));

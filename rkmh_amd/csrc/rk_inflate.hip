@@ -581,7 +581,8 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const void* __restrict__ m
     uint32_t kp = wb, lp0 = 0;           // window index of the next output byte; position in the literal stream
     uint32_t flushed = K0;               // window indices below it are in global memory (a multiple of 16, or the head's end)
     if constexpr (STREAM) {
-        for (uint32_t j = (uint32_t)lane; j < 32768u; j += IW) win[j] = (uint8_t)(pattern == 0u ? j : (pattern == 1u ? j >> 8 : 255u));
+        // (the text's first byte has window index wb: byte j of the window in front of it -- j = 0: 32 KB back -- has index wb - 32768 + j)
+        for (uint32_t j = (uint32_t)lane; j < 32768u; j += IW) win[wb - K0 + j] = (uint8_t)(pattern == 0u ? j : (pattern == 1u ? j >> 8 : 255u));
         isync();
     }
     uint32_t lit_base = 0, lit_have = 0; // s_lit holds the literal bytes [lit_base, lit_base + lit_have)

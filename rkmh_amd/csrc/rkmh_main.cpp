@@ -695,10 +695,7 @@ struct RawEngine {
             pieces = (int)std::min<uint64_t>(32, std::max<uint64_t>(1, mega >> 25)); // ~32 MB of text per output piece
             pieces = (int)env_long("RKMH_BGZF_PIECES", pieces, 1, 32);
         }
-        // (pass 1 holds two waves per CU, 512 on the chip, for ~30 ms whatever a launch's size: the jobs in flight together should fill
-        // those and not more -- three workers for jobs of 200-256 waves, up to six for the smaller jobs of smaller files)
-        const long job_waves = (long)(mega / 65280 / 64) + 1;
-        const long ndev = dev_inflate ? env_long("RKMH_BGZF_DEVICE_WORKERS", std::min<long>(6, std::max<long>(3, 512 / job_waves)), 1, 16) * (long)g.size() : 0;
+        const long ndev = dev_inflate ? env_long("RKMH_BGZF_DEVICE_WORKERS", 3, 1, 16) * (long)g.size() : 0;
         // (a run whose read files are ALL BGZF needs no plain-text workers -- their page-locked buffers are the start-up cost of this path)
         if (need_plain_workers || !g_read_paths) all_bgzf = false;
         else for (const char* p : *g_read_paths) if (!g_bgzf.count(p) && !g_gzip.count(p)) all_bgzf = false;
@@ -795,7 +792,7 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
     const bool counting = kind == RAW_COUNT;
     // bz: compressed (BGZF) -- a job is a run of members [lo, hi); mega: ... inflated on the device: large jobs, device-text slots,
     // eng.pieces block numbers each (else by the worker that takes the job)
-    struct File { const char* path = nullptr; int fd = -1; int64_t fsize = 0; rk_bgzf* bz = nullptr; rk_gzip* gz = nullptr; bool mega = false; const uint8_t* fmap = nullptr; };
+    struct File { const char* path = nullptr; int fd = -1; int64_t fsize = 0; rk_bgzf* bz = nullptr; rk_gzip* gz = nullptr; bool gz_own = false, gz_locked = false; bool mega = false; const uint8_t* fmap = nullptr; };
     std::vector<File> files(paths.size());
     const bool want_mmap = getenv("RKMH_RAW_MMAP") && atoi(getenv("RKMH_RAW_MMAP")) != 0;
     for (size_t i = 0; i < paths.size(); ++i) {
@@ -805,6 +802,13 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
         if (F.fd < 0) { fprintf(stderr, "rkmh: cannot open %s\n", F.path); fail_exit(); }
         F.bz = bgzf_of(F.path);
         F.gz = F.bz ? nullptr : gzip_of(F.path);
+        // (a gzip stream has a position: a file named twice in one run is opened once more for its second turn)
+        for (size_t j = 0; F.gz && !F.gz_own && j < i; ++j)
+            if (files[j].gz == F.gz) {
+                if (rk_gzip_open(F.path, &F.gz) != RK_OK) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+                F.gz_own = true;
+                F.gz_locked = rk_host_register_readonly(rk_gzip_image(F.gz), (size_t)rk_gzip_file_bytes(F.gz)) == RK_OK;
+            }
         if (F.gz && eng.mega == 0) { fprintf(stderr, "rkmh: %s: no device-text slots for a gzip stream\n", F.path); fail_exit(); }
         F.mega = (F.bz || F.gz) && eng.mega != 0;
         // RKMH_RAW_MMAP=1: the file is mapped and the mapping page-locked (hipHostRegister): the link reads the page cache itself, the
@@ -1072,6 +1076,7 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
     rk_line_parts_destroy(lp);
     for (File& F : files) {
         if (F.fmap) { rk_host_unregister(F.fmap); munmap((void*)F.fmap, (size_t)F.fsize); }
+        if (F.gz_own) { if (F.gz_locked) rk_host_unregister(rk_gzip_image(F.gz)); rk_gzip_close(F.gz); }
         close(F.fd);
     }
     if (out.failed) { fprintf(stderr, "rkmh: write error on standard output\n"); fail_exit(); }

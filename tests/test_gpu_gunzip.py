@@ -211,9 +211,12 @@ def test_cli_gzip_equals_plain(tmp_path, data_dir):
     assert got == want * 3
     got, err = run("stream", [gz2, gz1])             # the second member is the sequential reader's; the file behind it as well
     assert got == want * 2 and b"stops at byte" in err
-    wantf, _ = run("filter", [fq], extra=("-m", "2"))
-    gotf, _ = run("filter", [gz1], {"RKMH_GZIP_STRETCH_KB": "700"}, extra=("-m", "2"))
+    wantf, _ = run("filter", [fq])
+    gotf, _ = run("filter", [gz1], {"RKMH_GZIP_STRETCH_KB": "700"})
     assert gotf == wantf and len(wantf) > 0
+    wantf, _ = run("filter", [fq], extra=("-M", "2", "-N", "3"))
+    gotf, _ = run("filter", [gz1, ], extra=("-M", "2", "-N", "3"))
+    assert gotf == wantf
     wantm, _ = run("stream", [fq], extra=("-M", "2"))
     gotm, _ = run("stream", [gz1], extra=("-M", "2"))
     assert gotm == wantm

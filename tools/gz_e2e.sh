@@ -50,7 +50,7 @@ run() { # label file env...
   echo "      one file:   $(grep -E "context|references|device front end  |main loop|since the program" /tmp/big.err1 | sed 's/\[rkmh timing\] //' | tr -s " " | tr "\n" ";")" >> $OUT
   echo "      four files: $(grep -E "context|references|device front end  |main loop|since the program" /tmp/big.err4 | sed 's/\[rkmh timing\] //' | tr -s " " | tr "\n" ";")" >> $OUT
   grep -E "device front end:" /tmp/big.err4 | tr -s " " | sed 's/^/      /' >> $OUT
-  grep "bgzf device" /tmp/big.err4 | head -4 | sed 's/^/      /' >> $OUT
+  grep "bgzf device\|gzip device" /tmp/big.err4 | head -6 | sed 's/^/      /' >> $OUT
   [ -n "$DETAIL" ] && { echo "      --- the one-file run, every timing line:" >> $OUT; env "$@" RKMH_TIMING=1 RKMH_BGZF_TIMING=1 RKMH_INDEX_TIMING=1 bin/rkmh stream $R -f $f 2>&1 >/dev/null | grep -v "^\[rkmh index\]" | sed 's/^/        /' >> $OUT; }
 }
 run "plain text" /tmp/big.fq X=1
@@ -59,6 +59,28 @@ if [ -n "$SWEEP" ]; then
   for w in 2 4 5; do run "BGZF, device inflate, $w workers" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=$w; done
   cat $OUT; exit 0
 fi
+# the first N1 reads as an ORDINARY gzip file (one deflate stream, zlib level GZL): inflated on the device (rk_gunzip.hip) / by zlib on the host
+N1=${N1:-2000000}; [ $N1 -gt $N ] && N1=$N
+GZL=${GZL:-6}
+python3 - <<PY
+import zlib
+L = 11 + 150 + 3 + 150 + 1
+with open("/tmp/big.fq", "rb") as f, open("/tmp/one.fq", "wb") as fo, open("/tmp/one.fq.gz", "wb") as fz:
+    co = zlib.compressobj($GZL, zlib.DEFLATED, 31)
+    left = $N1
+    while left:
+        m = min(left, 200000)
+        raw = f.read(m * L)
+        fo.write(raw); fz.write(co.compress(raw)); left -= m
+    fz.write(co.flush())
+PY
+ls -la /tmp/one.fq /tmp/one.fq.gz >> $OUT
+want=$(bin/rkmh stream $R -f /tmp/one.fq 2>/dev/null | sha256sum | cut -c1-16)
+NALL=$N; N=$N1
+run "plain text, the first $N1 reads" /tmp/one.fq X=1
+run "ordinary gzip (level $GZL), device inflate" /tmp/one.fq.gz X=1
+run "ordinary gzip (level $GZL), zlib on the host" /tmp/one.fq.gz RKMH_GZIP_DEVICE=0
+N=$NALL
 [ -n "$QUICK" ] && { cat $OUT; exit 0; }
 run "BGZF, device inflate, 2 workers" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=2
 run "BGZF, device inflate, 1 worker" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=1
