@@ -215,7 +215,17 @@ int fused_device(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nre
                  hipStream_t st, uint64_t total_bases = 0);
 // rows the fused kernel flagged (max_id == -2; `rows` = host copy of d_out4) answered by the general kernels on the resident bases and scattered back into d_out4 AND rows; synchronises st
 int reroute_flagged_device(rk_ctx* c, const void* d_bases, const void* d_offs, int64_t nreads, void* d_out4, int32_t* rows, hipStream_t st);
-int gzip_next(rk_gzip* gz, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t call, uint8_t* d_out, uint64_t cap_out, uint64_t* nbytes, uint64_t* text_off); // rk_gunzip.hip
+// the work buffers of the device gunzip (rk_gunzip.hip): they belong to the SLOT that makes the calls, so a worker that reads file
+// after file allocates them once (several gigabytes for a file of 600 MB of text; made and freed per file they cost more than the kernels)
+struct GzScratch {
+    DevBuf d_comp, d_chunks, d_scratch, d_planes, d_rings, d_heads, d_stage, d_misc;
+    PinBuf h_chunks, h_misc;
+    void release() {
+        for (DevBuf* b : {&d_comp, &d_chunks, &d_scratch, &d_planes, &d_rings, &d_heads, &d_stage, &d_misc}) b->release();
+        h_chunks.release(); h_misc.release();
+    }
+};
+int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t call, uint8_t* d_out, uint64_t cap_out, uint64_t* nbytes, uint64_t* text_off); // rk_gunzip.hip
 int counter_settle(const rk_counter* k);                                                                    // rk_counters.hip
 int build_index(rk_ctx* c);                                                                                 // rk_index.hip
 int set_references_impl(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases, const uint64_t* offsets, int nref, const int* ks, int nks, int S,

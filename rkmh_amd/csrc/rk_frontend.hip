@@ -50,6 +50,7 @@ struct rk_fastq_slot {
     bool pack_filter = false;
     int min_matches = -1, min_diff = 0;
     const uint8_t* spans_base = nullptr; // what the spans of the last finished block index (rk_fastq_slot_spans_base)
+    GzScratch* gzs = nullptr;            // the work buffers of rk_fastq_slot_load_gzip (made at its first call)
 };
 
 extern "C" void rk_fastq_slot_destroy(rk_fastq_slot* s) {
@@ -60,6 +61,7 @@ extern "C" void rk_fastq_slot_destroy(rk_fastq_slot* s) {
     for (PinBuf* b : {&s->h_text, &s->h_info, &s->h_mem}) b->release();
     for (HostArr* b : {&s->h_out4, &s->h_spans, &s->h_pack}) b->release();
     for (DevBuf* b : {&s->d_text, &s->d_u32, &s->d_bases, &s->d_out4, &s->d_scan, &s->d_pack, &s->d_comp, &s->d_mem, &s->d_inf, &s->d_match}) b->release();
+    if (s->gzs) { s->gzs->release(); delete s->gzs; }
     delete s;
 }
 
@@ -269,7 +271,8 @@ extern "C" int rk_fastq_slot_load_gzip(rk_fastq_slot* s, rk_gzip* gz, int64_t ca
     if (!s || !gz || !nbytes || !text_off) return fail(RK_ERR_ARG, "bad arguments");
     if (!s->device_text()) return fail(RK_ERR_ARG, "rk_fastq_slot_load_gzip: a slot created with RK_SLOT_DEVICE_TEXT is needed");
     s->text_on_device = false;
-    const int rc = gzip_next(gz, s->c, s->st, s->ev, call, s->d_text.as<uint8_t>(), s->max_bytes, nbytes, text_off);
+    if (!s->gzs) s->gzs = new GzScratch();
+    const int rc = gzip_next(gz, *s->gzs, s->c, s->st, s->ev, call, s->d_text.as<uint8_t>(), s->max_bytes, nbytes, text_off);
     if (rc != RK_OK) return rc;
     HIPCHK(hipMemsetAsync(s->d_text.as<uint8_t>() + *nbytes, 'A', 16, s->st)); // the index kernels read whole 16-byte pieces
     s->text_on_device = true;

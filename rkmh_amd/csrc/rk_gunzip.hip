@@ -59,26 +59,24 @@ struct rk_gzip {
     bool finished = false;     // the stream's last block has been decoded
     // device side (made at the first call, for the device of the slot that calls)
     rk_ctx* c = nullptr;
-    DevBuf d_comp, d_chunks, d_scratch, d_planes, d_rings, d_heads, d_stage, d_misc, d_tmp;
-    PinBuf h_chunks, h_misc;
-    uint64_t cap_text = 0;
+    DevBuf d_tmp; // what lives from call to call: [32 KB: the ring of the window behind the last chunk][its head][16: a cut][64 KB on: the carry]
 };
 
 extern "C" void rk_gzip_close(rk_gzip* gz) {
     if (!gz) return;
     if (gz->c) { hipError_t e = hipSetDevice(gz->c->device); (void)e; }
-    for (DevBuf* b : {&gz->d_comp, &gz->d_chunks, &gz->d_scratch, &gz->d_planes, &gz->d_rings, &gz->d_heads, &gz->d_stage, &gz->d_misc, &gz->d_tmp}) b->release();
-    gz->h_chunks.release(); gz->h_misc.release();
+    gz->d_tmp.release();
     if (gz->map) munmap(const_cast<uint8_t*>(gz->map), (size_t)gz->size);
     if (gz->fd >= 0) close(gz->fd);
     delete gz;
 }
 
-// the device buffers of a file that has been read (several gigabytes for a large one); the next rk_gzip_plan + calls make them again
+// the device memory of a file that has been read (the window and the carry: 4 MB; the work buffers are the slot's); the next
+// rk_gzip_plan + calls make it again
 extern "C" void rk_gzip_release_device(rk_gzip* gz) {
     if (!gz) return;
     if (gz->c) { hipError_t e = hipSetDevice(gz->c->device); (void)e; }
-    for (DevBuf* b : {&gz->d_comp, &gz->d_chunks, &gz->d_scratch, &gz->d_planes, &gz->d_rings, &gz->d_heads, &gz->d_stage, &gz->d_misc, &gz->d_tmp}) b->release();
+    gz->d_tmp.release();
     gz->c = nullptr;
     gz->stretch = 0; // (a plan is needed before the next call)
 }
@@ -160,7 +158,7 @@ extern "C" int64_t rk_gzip_calls(const rk_gzip* gz) { return gz ? gz->ncalls : 0
 // The next stretch of gz's stream -> whole records at d_out (at most cap_out bytes), *nbytes of them; *text_off = the offset of the
 // first of them in the file's text.  RK_OK; 1: not for the device from *text_off on (see the head of this file); < 0: an error
 // (damaged data: a CRC-32 or length that does not match the trailer).  Calls come in order, call = 0 .. ncalls - 1, on stream st.
-int gzip_next(rk_gzip* gz, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t call, uint8_t* d_out, uint64_t cap_out, uint64_t* nbytes, uint64_t* text_off) {
+int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t call, uint8_t* d_out, uint64_t cap_out, uint64_t* nbytes, uint64_t* text_off) {
     static const bool timing = getenv("RKMH_BGZF_TIMING") != nullptr;
     const auto t_0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
@@ -173,15 +171,16 @@ int gzip_next(rk_gzip* gz, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t cal
     ++gz->next_call;
     const bool last_call = call == gz->ncalls - 1;
     auto sync = [&]() -> int { HIPCHK(hipEventRecord(ev, st)); HIPCHK(hipEventSynchronize(ev)); return RK_OK; };
-    // buffers whose CONTENT lives from call to call are made once, at their full size (a DevBuf that grows forgets what it held):
-    //   d_stage = [carry area: CARRY_CAP bytes, the carry at its end][this call's text: up to cap_out bytes]
-    //   d_tmp   = [32 KB: the ring of the window behind the last chunk][its head][16: a cut][64 KB on: a carry on its way]
-    RKCHK(gz->d_stage.reserve((size_t)CARRY_CAP + cap_out + 4096));
-    RKCHK(gz->d_tmp.reserve((size_t)65536 + CARRY_CAP + 64));
+    double t_alloc = 0; // (time in allocations: zero from a slot's second file on)
+#define GZ_RESERVE(buf, bytes) do { const auto t_a = std::chrono::steady_clock::now(); RKCHK((buf).reserve(bytes)); t_alloc += ms_since(t_a); } while (0)
+    // d_tmp lives from call to call and is made once, at its full size (a DevBuf that grows forgets what it held); the stage is the
+    // slot's: [CARRY_CAP bytes: the carry is copied to their end][this call's text: up to cap_out bytes]
+    GZ_RESERVE(gz->d_tmp, (size_t)65536 + CARRY_CAP + 64);
+    GZ_RESERVE(S.d_stage, (size_t)CARRY_CAP + cap_out + 4096);
     // page-locked words of this call: [0, 16) cut and edge bytes, [16, 16 + segments) CRC-32 per 64 KB of text, then from / to / found per chunk boundary
     const size_t seg_max = (size_t)(cap_out >> 16) + 8, bound_max = (size_t)(gz->stretch >> 10) + 8;
-    RKCHK(gz->h_misc.reserve((16 + seg_max + 3 * bound_max) * 4));
-    uint32_t* const h_info = gz->h_misc.as<uint32_t>();
+    GZ_RESERVE(S.h_misc, (16 + seg_max + 3 * bound_max) * 4);
+    uint32_t* const h_info = S.h_misc.as<uint32_t>();
     uint32_t* const h_crc = h_info + 16;
     // ---- the compressed bytes of this stretch
     const uint64_t range_end = std::min<uint64_t>(gz->data_off + (uint64_t)(call + 1) * gz->stretch, gz->data_end); // (file offset)
@@ -197,8 +196,8 @@ int gzip_next(rk_gzip* gz, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t cal
         const uint64_t cbytes = up1 - up0;
         if (cbytes >= ((uint64_t)440 << 20)) return 1;
         const size_t cpad = ((size_t)cbytes + 15) & ~(size_t)15;
-        RKCHK(gz->d_comp.reserve(cpad + 256));
-        uint8_t* const d_comp = gz->d_comp.as<uint8_t>();
+        GZ_RESERVE(S.d_comp, cpad + 256);
+        uint8_t* const d_comp = S.d_comp.as<uint8_t>();
         HIPCHK(hipMemcpyAsync(d_comp, gz->map + up0, (size_t)cbytes, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(d_comp + cbytes, 0, cpad + 192 - cbytes, st));
         const uint32_t nbits = (uint32_t)((cpad + 64) * 8);
@@ -211,11 +210,11 @@ int gzip_next(rk_gzip* gz, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t cal
         const uint32_t nbound = end_rel > first ? (end_rel - first - 1) / chunk_bits : 0; // boundaries first + k chunk_bits < end_rel, k >= 1
         const size_t cap_chunks = (size_t)nbound + 1 + PATCH_MAX;
         if ((size_t)nbound + 1 > bound_max) return fail(RK_ERR_STATE, "rk_fastq_slot_load_gzip: more chunk boundaries than planned");
-        RKCHK(gz->d_misc.reserve((size_t)(nbound + 1) * 12 + 64));
+        GZ_RESERVE(S.d_misc, (size_t)(nbound + 1) * 12 + 64);
         uint32_t* const h_from = h_crc + seg_max;
         uint32_t* const h_to = h_from + nbound + 1;
         uint32_t* const h_found = h_to + nbound + 1;
-        uint32_t* const d_from = gz->d_misc.as<uint32_t>();
+        uint32_t* const d_from = S.d_misc.as<uint32_t>();
         uint32_t* const d_to = d_from + nbound + 1;
         uint32_t* const d_found = d_to + nbound + 1;
         for (uint32_t k = 0; k < nbound; ++k) { h_from[k] = first + (k + 1) * chunk_bits; h_to[k] = std::min<uint32_t>(end_rel, first + (k + 2) * chunk_bits); }
@@ -227,9 +226,9 @@ int gzip_next(rk_gzip* gz, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t cal
         RKCHK(sync());
         t_find = ms_since(t_0);
         // ---- pass 1
-        RKCHK(gz->h_chunks.reserve(cap_chunks * sizeof(GzChunk)));
-        RKCHK(gz->d_chunks.reserve(cap_chunks * sizeof(GzChunk)));
-        hc = gz->h_chunks.as<GzChunk>();
+        GZ_RESERVE(S.h_chunks, cap_chunks * sizeof(GzChunk));
+        GZ_RESERVE(S.d_chunks, cap_chunks * sizeof(GzChunk));
+        hc = S.h_chunks.as<GzChunk>();
         std::vector<uint32_t> starts;
         starts.push_back(first);
         for (uint32_t k = 0; k < nbound; ++k) if (h_found[k] != 0xFFFFFFFFu && h_found[k] > starts.back()) starts.push_back(h_found[k]);
@@ -248,10 +247,10 @@ int gzip_next(rk_gzip* gz, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t cal
         }
         const uint64_t patch_dw = region_of(2 * chunk_bits + (uint32_t)(OVER * 8 / 4));
         if (sdw + patch_dw * PATCH_MAX >= ((uint64_t)1 << 32)) return 1;
-        RKCHK(gz->d_scratch.reserve((size_t)(sdw + patch_dw * PATCH_MAX) * 4 + 64));
-        GzChunk* const d_chunks = gz->d_chunks.as<GzChunk>();
+        GZ_RESERVE(S.d_scratch, (size_t)(sdw + patch_dw * PATCH_MAX) * 4 + 64);
+        GzChunk* const d_chunks = S.d_chunks.as<GzChunk>();
         HIPCHK(hipMemcpyAsync(d_chunks, hc, (size_t)nchunk * sizeof(GzChunk), hipMemcpyHostToDevice, st));
-        HIPCHK(launch_gz_lanes(d_comp, (uint32_t)(cpad + 64), d_chunks, nchunk, gz->d_scratch.as<uint32_t>(), st));
+        HIPCHK(launch_gz_lanes(d_comp, (uint32_t)(cpad + 64), d_chunks, nchunk, S.d_scratch.as<uint32_t>(), st));
         HIPCHK(hipMemcpyAsync(hc, d_chunks, (size_t)nchunk * sizeof(GzChunk), hipMemcpyDeviceToHost, st));
         RKCHK(sync());
         // ---- the chain: from the first chunk (a true header: the stream's first, or where the call before ended) on
@@ -275,7 +274,7 @@ int gzip_next(rk_gzip* gz, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t cal
             p.scratch_off = (uint32_t)(sdw + patch_dw * patches); p.scratch_dw = (uint32_t)patch_dw;
             if (timing) fprintf(stderr, "[gzip device] a false block header before bit %u: the gap %u .. %u is decoded on its own\n", e, e, p.stop_bit);
             HIPCHK(hipMemcpyAsync(d_chunks + nchunk, &p, sizeof(GzChunk), hipMemcpyHostToDevice, st));
-            HIPCHK(launch_gz_lanes(d_comp, (uint32_t)(cpad + 64), d_chunks + nchunk, 1, gz->d_scratch.as<uint32_t>(), st));
+            HIPCHK(launch_gz_lanes(d_comp, (uint32_t)(cpad + 64), d_chunks + nchunk, 1, S.d_scratch.as<uint32_t>(), st));
             HIPCHK(hipMemcpyAsync(&p, d_chunks + nchunk, sizeof(GzChunk), hipMemcpyDeviceToHost, st));
             RKCHK(sync());
             cur = nchunk++;
@@ -287,30 +286,31 @@ int gzip_next(rk_gzip* gz, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t cal
     const uint32_t carry = gz->carry_len;
     if ((uint64_t)carry + total > cap_out + CARRY_CAP / 2 || total > cap_out) return 1; // (more text than the file's ratio promised)
     const size_t plane_stride = ((size_t)total + 15 + 64) & ~(size_t)15;
-    uint8_t* const text = gz->d_stage.as<uint8_t>() + CARRY_CAP; // this call's text; the carry ends where it begins
+    uint8_t* const text = S.d_stage.as<uint8_t>() + CARRY_CAP; // this call's text; the carry ends where it begins
+    if (carry) HIPCHK(hipMemcpyAsync(text - carry, gz->d_tmp.as<uint8_t>() + 65536, carry, hipMemcpyDeviceToDevice, st));
     const uint32_t nch = (uint32_t)chain.size();
     const uint32_t nseg = (total + 65535u) >> 16;
     if (nseg > seg_max) return 1;
     if (nch) {
-        RKCHK(gz->d_planes.reserve(3 * plane_stride + 256));
-        RKCHK(gz->d_rings.reserve((size_t)(nch + 1) * 32768));
-        RKCHK(gz->d_heads.reserve((size_t)(nch + 2) * 4 + (size_t)(nseg + 1) * 4));
+        GZ_RESERVE(S.d_planes, 3 * plane_stride + 256);
+        GZ_RESERVE(S.d_rings, (size_t)(nch + 1) * 32768);
+        GZ_RESERVE(S.d_heads, (size_t)(nch + 2) * 4 + (size_t)(nseg + 1) * 4);
         // (rings[0] / heads[0]: the window the call before left -- see the end of this function; the stream's first call: zeros)
         if (gz->text_made == 0) { HIPCHK(hipMemsetAsync(gz->d_tmp.p, 0, 32768 + 4, st)); }
-        HIPCHK(hipMemcpyAsync(gz->d_rings.p, gz->d_tmp.p, 32768, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(gz->d_heads.p, gz->d_tmp.as<uint8_t>() + 32768, 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(S.d_rings.p, gz->d_tmp.p, 32768, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(S.d_heads.p, gz->d_tmp.as<uint8_t>() + 32768, 4, hipMemcpyDeviceToDevice, st));
         std::vector<GzChunk> cc(nch);
         uint32_t off = 0;
         for (uint32_t i = 0; i < nch; ++i) { cc[i] = hc[chain[i]]; cc[i].out_off = off; off += cc[i].out_len; }
         memcpy(hc, cc.data(), (size_t)nch * sizeof(GzChunk)); // (page-locked: the upload reads it after this function's next lines)
-        GzChunk* const d_chunks = gz->d_chunks.as<GzChunk>();
+        GzChunk* const d_chunks = S.d_chunks.as<GzChunk>();
         HIPCHK(hipMemcpyAsync(d_chunks, hc, (size_t)nch * sizeof(GzChunk), hipMemcpyHostToDevice, st));
-        uint32_t* const d_crc = gz->d_heads.as<uint32_t>() + nch + 2;
-        HIPCHK(launch_gz_place(d_chunks, nch, gz->d_planes.as<uint8_t>(), plane_stride, gz->d_scratch.as<uint32_t>(), gz->d_rings.as<uint8_t>(), gz->d_heads.as<uint32_t>(), text,
+        uint32_t* const d_crc = S.d_heads.as<uint32_t>() + nch + 2;
+        HIPCHK(launch_gz_place(d_chunks, nch, S.d_planes.as<uint8_t>(), plane_stride, S.d_scratch.as<uint32_t>(), S.d_rings.as<uint8_t>(), S.d_heads.as<uint32_t>(), text,
                                total, d_crc, st));
         // the window behind this call's last chunk, for the next call (d_tmp: 32 KB of ring + its head)
-        HIPCHK(hipMemcpyAsync(gz->d_tmp.p, gz->d_rings.as<uint8_t>() + (size_t)nch * 32768, 32768, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(gz->d_tmp.as<uint8_t>() + 32768, gz->d_heads.as<uint32_t>() + nch, 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(gz->d_tmp.p, S.d_rings.as<uint8_t>() + (size_t)nch * 32768, 32768, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(gz->d_tmp.as<uint8_t>() + 32768, S.d_heads.as<uint32_t>() + nch, 4, hipMemcpyDeviceToDevice, st));
         if (nseg) HIPCHK(hipMemcpyAsync(h_crc, d_crc, (size_t)nseg * 4, hipMemcpyDeviceToHost, st));
     }
     // ---- the records: everything in front of the last record start near the end (all of it at the end of the stream)
@@ -360,18 +360,15 @@ int gzip_next(rk_gzip* gz, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t cal
     if (cut) HIPCHK(hipMemcpyAsync(d_out, all, cut, hipMemcpyDeviceToDevice, st));
     uint64_t n = cut;
     if (at_end && ntext && last_byte != '\n') { HIPCHK(hipMemsetAsync(d_out + n, '\n', 1, st)); ++n; } // a last line without its newline
-    // the carry: the text behind the cut, moved in front of where the next call's text begins (through a buffer of its own: the two may overlap)
+    // the carry: the text behind the cut waits in the file's own buffer for the next call
     const uint32_t new_carry = ntext - cut;
-    if (new_carry) {
-        uint8_t* const tmp = gz->d_tmp.as<uint8_t>() + 65536;
-        HIPCHK(hipMemcpyAsync(tmp, all + cut, new_carry, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(gz->d_stage.as<uint8_t>() + CARRY_CAP - new_carry, tmp, new_carry, hipMemcpyDeviceToDevice, st));
-    }
+    if (new_carry) HIPCHK(hipMemcpyAsync(gz->d_tmp.as<uint8_t>() + 65536, all + cut, new_carry, hipMemcpyDeviceToDevice, st));
     gz->carry_len = new_carry;
     *text_off = gz->text_given;
     gz->text_given += cut;
     *nbytes = n;
-    if (timing) fprintf(stderr, "[gzip device] %s call %lld of %lld: %u chunks (%u in the chain), %.1f MB of text; headers %.1f ms, pass 1 %.1f, all %.1f\n", gz->path.c_str(),
-                        (long long)call + 1, (long long)gz->ncalls, nchunk, nch, total / 1e6, t_find, t_p1 - t_find, ms_since(t_0));
+    if (timing) fprintf(stderr, "[gzip device] %s call %lld of %lld: %u chunks (%u in the chain), %.1f MB of text; headers %.1f ms, pass 1 %.1f, all %.1f (allocations %.1f)\n", gz->path.c_str(),
+                        (long long)call + 1, (long long)gz->ncalls, nchunk, nch, total / 1e6, t_find, t_p1 - t_find, ms_since(t_0), t_alloc);
+#undef GZ_RESERVE
     return RK_OK;
 }

@@ -47,6 +47,7 @@ constexpr uint32_t E_INVALID = 0x0FFFu;       // table entry: code length << 12 
 constexpr uint32_t WIN_BYTES = 65536;       // a member's text at most (pass 1 hands larger ones to the host)
 
 __device__ const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+constexpr uint8_t CL_ORDER_C[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15}; // (the same, for unrolled loops)
 
 // everything a wave of 64 streams keeps in LDS; arrays are [index][lane]
 template <int LT, int DT>
@@ -800,61 +801,91 @@ __global__ __launch_bounds__(256) void k_fastq_first_start(const uint8_t* __rest
 // bits pass all of that about once in 10^8..10^9 positions; a false start costs only the work of one lane: the chunk in front of
 // it does not end at it (pass 1 reports where every chunk ended), and the host joins the chain from true starts only.
 struct __attribute__((packed, aligned(1))) g_u64 { uint64_t v; }; // eight bytes at any global address
+struct __attribute__((packed, aligned(1))) g_u128 { uint4 v; }; // sixteen
 __device__ __forceinline__ uint64_t gz_peek(const uint8_t* __restrict__ comp, uint32_t pos) { return reinterpret_cast<const g_u64*>(comp + (pos >> 3))->v >> (pos & 7u); } // >= 57 bits
-__device__ bool gz_header_ok(const uint8_t* __restrict__ comp, uint32_t pos, uint32_t nbits) {
+// stages 1 and 2, a few dozen instructions: the three header bits, the counts, a complete code-length code
+__device__ __forceinline__ bool gz_header_maybe(const uint8_t* __restrict__ comp, uint32_t pos, uint32_t nbits) {
     if (pos + 4096u > nbits) return false; // (a last block this close to the end is left to the chunk in front of it)
-    uint64_t w = gz_peek(comp, pos);
+    const uint64_t w = gz_peek(comp, pos);
     if ((w & 7u) != 4u) return false; // BFINAL = 0, BTYPE = 2
     const uint32_t nlit = (uint32_t)((w >> 3) & 31u) + 257u, ndist = (uint32_t)((w >> 8) & 31u) + 1u, ncl = (uint32_t)((w >> 13) & 15u) + 4u;
     if (nlit > 286u || ndist > 30u) return false;
-    // the code-length code: 3 bits per length, complete (zlib refuses anything else: inftrees.c, type CODES)
-    uint32_t p = pos + 17u;
-    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint8_t cl[19];
-#pragma unroll
-    for (int i = 0; i < 19; ++i) cl[i] = 0;
-    w = gz_peek(comp, p); // (>= 57 bits: all 19 lengths)
+    const uint64_t c = gz_peek(comp, pos + 17u); // (>= 57 bits: all 19 lengths of 3 bits)
     uint32_t kraft = 0;
-    for (uint32_t i = 0; i < ncl; ++i) {
-        const uint32_t l = (uint32_t)(w >> (3u * i)) & 7u;
-        cl[CL_ORDER[i]] = (uint8_t)l;
-        if (l) { kraft += 128u >> l; ++cnt[l]; }
+#pragma unroll
+    for (uint32_t i = 0; i < 19u; ++i) {
+        const uint32_t l = (uint32_t)(c >> (3u * i)) & 7u;
+        kraft += (i < ncl && l) ? 128u >> l : 0u;
     }
-    if (kraft != 128u) return false;
+    return kraft == 128u; // (zlib refuses an incomplete code-length code: inftrees.c, type CODES)
+}
+// stage 3: the nlit + ndist code lengths decode and form complete codes.  Everything lives in registers -- the code-length code's
+// symbols in (length, symbol) order, 5 bits each, in two words; a first form kept them in arrays, which the compiler put into
+// scratch memory: ~1 us per symbol, 300 us per candidate, and one candidate in every other step of 256 positions: 42 ms per stretch
+__device__ bool gz_header_ok(const uint8_t* __restrict__ comp, uint32_t pos, uint32_t nbits) {
+    uint64_t w = gz_peek(comp, pos);
+    const uint32_t nlit = (uint32_t)((w >> 3) & 31u) + 257u, ndist = (uint32_t)((w >> 8) & 31u) + 1u, ncl = (uint32_t)((w >> 13) & 15u) + 4u;
+    uint32_t p = pos + 17u;
+    const uint64_t c = gz_peek(comp, p);
     p += 3u * ncl;
-    // symbols in (length, symbol) order, for a canonical walk (puff.c's decode): 19 symbols at most
-    uint8_t sym[19];
-    {
-        uint32_t offs[8];
-        offs[1] = 0;
-        for (int l = 1; l < 7; ++l) offs[l + 1] = offs[l] + cnt[l];
-        for (int i = 0; i < 19; ++i) if (cl[i]) sym[offs[cl[i]]++] = (uint8_t)i;
+    // lengths by symbol: cl3 holds 3 bits per symbol 0 .. 18; counts per length in cnt (4 bits each: at most 19... packed 5 bits)
+    uint64_t cl3 = 0;
+    uint32_t cnt[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) cnt[l] = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 19u; ++i) {
+        const uint32_t l = i < ncl ? (uint32_t)(c >> (3u * i)) & 7u : 0u;
+        cl3 |= (uint64_t)l << (3u * CL_ORDER_C[i]);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) cnt[k] += l == (uint32_t)k ? 1u : 0u;
     }
-    uint32_t lit_kraft = 0, dist_kraft = 0, lit_max = 0, dist_max = 0, prev = 0, eob_len = 0;
+    // symbols sorted by (length, symbol): slot k of (s_lo, s_hi), 5 bits each, 12 per word
+    uint64_t s_lo = 0, s_hi = 0;
+    {
+        uint32_t k = 0;
+#pragma unroll
+        for (uint32_t l = 1; l < 8u; ++l)
+#pragma unroll
+            for (uint32_t sy = 0; sy < 19u; ++sy) {
+                const bool is = ((uint32_t)(cl3 >> (3u * sy)) & 7u) == l;
+                if (is) { if (k < 12u) s_lo |= (uint64_t)sy << (5u * k); else s_hi |= (uint64_t)sy << (5u * (k - 12u)); ++k; }
+            }
+    }
+    uint32_t lit_kraft = 0, dist_kraft = 0, lit_max = 0, dist_max = 0, prev = 0, eob_len = 0, have = 0;
     const uint32_t total = nlit + ndist;
     for (uint32_t i = 0; i < total;) {
-        w = gz_peek(comp, p);
+        if (have < 14u) { w = gz_peek(comp, p); have = 57u; }
         int code = 0, first = 0, index = 0;
         uint32_t s = 99, used = 0;
+#pragma unroll
         for (uint32_t l = 1; l <= 7u; ++l) {
             code |= (int)((w >> (l - 1u)) & 1u);
-            const int c = (int)cnt[l];
-            if (code - c < first) { s = sym[index + (code - first)]; used = l; break; }
-            index += c; first += c; first <<= 1; code <<= 1;
+            const int cn = (int)cnt[l];
+            if (s == 99u && code - cn < first) {
+                const uint32_t k = (uint32_t)(index + (code - first));
+                s = k < 12u ? (uint32_t)(s_lo >> (5u * k)) & 31u : (uint32_t)(s_hi >> (5u * (k - 12u))) & 31u;
+                used = l;
+            }
+            index += cn; first += cn; first <<= 1; code <<= 1;
         }
         if (s == 99u) return false;
-        w >>= used; p += used;
+        w >>= used; p += used; have -= used;
         uint32_t rep = 1, val = s;
-        if (s == 16u) { if (i == 0u) return false; rep = 3u + (uint32_t)(w & 3u); p += 2u; val = prev; }
-        else if (s == 17u) { rep = 3u + (uint32_t)(w & 7u); p += 3u; val = 0; }
-        else if (s == 18u) { rep = 11u + (uint32_t)(w & 127u); p += 7u; val = 0; }
+        if (s == 16u) { if (i == 0u) return false; rep = 3u + (uint32_t)(w & 3u); w >>= 2; p += 2u; have -= 2u; val = prev; }
+        else if (s == 17u) { rep = 3u + (uint32_t)(w & 7u); w >>= 3; p += 3u; have -= 3u; val = 0; }
+        else if (s == 18u) { rep = 11u + (uint32_t)(w & 127u); w >>= 7; p += 7u; have -= 7u; val = 0; }
         if (i + rep > total) return false;
         if (s < 16u) prev = s; else if (s != 16u) prev = 0;
-        for (uint32_t j = 0; j < rep; ++j, ++i) {
-            if (!val) continue;
-            if (i < nlit) { lit_kraft += 32768u >> val; if (val > lit_max) lit_max = val; if (i == 256u) eob_len = val; }
-            else { dist_kraft += 32768u >> val; if (val > dist_max) dist_max = val; }
+        if (val) {
+            // the run lies in the literal/length code up to symbol nlit - 1, in the distance code behind it
+            const uint32_t in_lit = i < nlit ? (i + rep <= nlit ? rep : nlit - i) : 0u, in_dist = rep - in_lit;
+            lit_kraft += in_lit * (32768u >> val); dist_kraft += in_dist * (32768u >> val);
+            if (in_lit && val > lit_max) lit_max = val;
+            if (in_dist && val > dist_max) dist_max = val;
+            if (i <= 256u && i + rep > 256u) eob_len = val;
         }
+        i += rep;
         if (p + 64u > nbits) return false;
     }
     if (eob_len == 0u) return false;
@@ -862,16 +893,25 @@ __device__ bool gz_header_ok(const uint8_t* __restrict__ comp, uint32_t pos, uin
     if (dist_kraft > 32768u || (dist_kraft < 32768u && dist_max > 1u)) return false;
     return true;
 }
-// found[b] = the first bit position in [from[b], to[b]) that looks like a block header, 0xFFFFFFFF if none does
+// found[b] = the first bit position in [from[b], to[b]) that looks like a block header, 0xFFFFFFFF if none does.  A workgroup takes the
+// range in pieces of 64 K positions: every thread tries its positions with the cheap stages and notes the survivors (one in a few
+// hundred) in LDS; then the survivors are checked in full, a thread each; the first piece with a header ends the search.
+constexpr uint32_t GZ_PIECE = 65536, GZ_CAND = 4096;
 __global__ __launch_bounds__(256) void k_gz_find_starts(const uint8_t* __restrict__ comp, uint32_t nbits, const uint32_t* __restrict__ from, const uint32_t* __restrict__ to,
                                                         uint32_t* __restrict__ found) {
-    __shared__ uint32_t best;
-    if (threadIdx.x == 0) best = 0xFFFFFFFFu;
-    __syncthreads();
+    __shared__ uint32_t best, ncand, cand[GZ_CAND];
     const uint32_t lo = from[blockIdx.x], hi = to[blockIdx.x];
-    for (uint32_t base = lo; base < hi; base += 256u) {
-        const uint32_t pos = base + threadIdx.x;
-        if (pos < hi && gz_header_ok(comp, pos, nbits)) atomicMin(&best, pos);
+    if (threadIdx.x == 0) best = 0xFFFFFFFFu;
+    for (uint32_t base = lo; base < hi; base += GZ_PIECE) {
+        if (threadIdx.x == 0) ncand = 0;
+        __syncthreads();
+        const uint32_t end = hi - base < GZ_PIECE ? hi : base + GZ_PIECE;
+        for (uint32_t pos = base + threadIdx.x; pos < end; pos += 256u)
+            if (gz_header_maybe(comp, pos, nbits)) { const uint32_t k = atomicAdd(&ncand, 1u); if (k < GZ_CAND) cand[k] = pos; }
+        __syncthreads();
+        const uint32_t n = ncand < GZ_CAND ? ncand : GZ_CAND; // (more survivors than the list holds -- not deflate data, or all zeros: the rest of them are skipped)
+        for (uint32_t k = threadIdx.x; k < n; k += 256u)
+            if (gz_header_ok(comp, cand[k], nbits)) atomicMin(&best, cand[k]);
         __syncthreads();
         if (best != 0xFFFFFFFFu) break;
     }
@@ -883,35 +923,91 @@ __global__ __launch_bounds__(256) void k_gz_find_starts(const uint8_t* __restric
 // rings[0] / heads[0] are given (the text in front of the first chunk; any bytes for the stream's first), rings[1 .. n] are written.
 __global__ __launch_bounds__(1024) void k_gz_windows(const GzChunk* __restrict__ chunks, uint32_t nchunk, const uint8_t* __restrict__ planes, size_t plane_stride,
                                                      uint8_t* __restrict__ rings, uint32_t* __restrict__ heads) {
-    __shared__ __attribute__((aligned(16))) uint8_t ring[32768];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[32768 + 16];
+    __shared__ uint32_t s_len[256], s_off[256];
     const uint32_t tid = threadIdx.x;
     for (uint32_t r = 0; r < 2u; ++r) reinterpret_cast<uint4*>(ring)[tid + 1024u * r] = reinterpret_cast<const uint4*>(rings)[tid + 1024u * r];
     uint32_t head = heads[0] & 32767u;
     __syncthreads();
-    for (uint32_t c = 0; c < nchunk; ++c) {
-        const uint32_t n = chunks[c].out_len, take = n < 32768u ? n : 32768u;
-        const size_t src = (size_t)chunks[c].out_off + (n - take);
-        uint8_t v[32];
-        const uint32_t i0 = tid * 32u;
-        if (i0 < take) {
+    // a thread owns 32 consecutive bytes of the chunk's last 32 KB: two unaligned 16-byte loads per plane, all six in flight together
+    // (the first version read them byte by byte: 160 us per chunk -- ten thousand chunks of a 600 MB stretch took 1.6 s)
+    for (uint32_t c0 = 0; c0 < nchunk; c0 += 256u) {
+        __syncthreads();
+        if (tid < 256u && c0 + tid < nchunk) { s_len[tid] = chunks[c0 + tid].out_len; s_off[tid] = chunks[c0 + tid].out_off; }
+        __syncthreads();
+        const uint32_t cn = nchunk - c0 < 256u ? nchunk - c0 : 256u;
+        // the plane words of a chunk do not depend on the ring: they are requested one chunk ahead, so their latency (~2 us from HBM)
+        // hides behind the chunk before (the first form waited for them inside every step: 6.6 us per chunk)
+        uint32_t w[3][8];
+        bool mine = false, whole = false;
+        uint32_t take = 0;
+        auto fetch = [&](uint32_t ci) {
+            const uint32_t n = s_len[ci];
+            take = n < 32768u ? n : 32768u;
+            const size_t src = (size_t)s_off[ci] + (n - take);
+            const uint32_t i0 = tid * 32u;
+            mine = i0 < take; whole = i0 + 32u <= take;
+            if (whole) {
 #pragma unroll
-            for (uint32_t b = 0; b < 32u; ++b) {
-                const uint32_t i = i0 + b;
-                uint32_t A = 0, B = 0, C = 0;
-                if (i < take) { A = planes[src + i]; B = planes[plane_stride + src + i]; C = planes[2 * plane_stride + src + i]; }
-                v[b] = (uint8_t)((C != 255u || B == 255u) ? C : ring[(head + (A | (B << 8))) & 32767u]);
+                for (int p = 0; p < 3; ++p) {
+                    const g_u128* q = reinterpret_cast<const g_u128*>(planes + (size_t)p * plane_stride + src + i0);
+                    const uint4 x = q[0].v, y = q[1].v;
+                    w[p][0] = x.x; w[p][1] = x.y; w[p][2] = x.z; w[p][3] = x.w; w[p][4] = y.x; w[p][5] = y.y; w[p][6] = y.z; w[p][7] = y.w;
+                }
+            } else if (mine) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) w[p][d] = 0;
+                    for (uint32_t b = 0; b < 32u && i0 + b < take; ++b) w[p][b >> 2] |= (uint32_t)planes[(size_t)p * plane_stride + src + i0 + b] << (8u * (b & 3u));
+                }
             }
-        }
-        __syncthreads();
-        if (i0 < take) {
+        };
+        fetch(0);
+        for (uint32_t ci = 0; ci < cn; ++ci) {
+            const uint32_t i0 = tid * 32u;
+            const bool mine_c = mine, whole_c = whole;
+            const uint32_t take_c = take;
+            uint32_t wc[3][8];
 #pragma unroll
-            for (uint32_t b = 0; b < 32u; ++b) if (i0 + b < take) ring[(head + i0 + b) & 32767u] = v[b];
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int d = 0; d < 8; ++d) wc[p][d] = w[p][d];
+            if (ci + 1u < cn) fetch(ci + 1u);
+            uint32_t o[8];
+            if (mine_c) {
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    // a byte that came out of the window: plane C shows 255 and plane B < 128 (a byte of the text that IS 255 shows 255 in all)
+                    const uint32_t cw = wc[2][d], bw = wc[1][d], aw = wc[0][d];
+                    uint32_t ow = cw;
+                    const uint32_t is255 = cw & (cw >> 1) & (cw >> 2) & (cw >> 3) & (cw >> 4) & (cw >> 5) & (cw >> 6) & (cw >> 7) & 0x01010101u; // bytes of C equal to 255
+                    if (is255) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t C = (cw >> (8 * j)) & 255u, B = (bw >> (8 * j)) & 255u, A = (aw >> (8 * j)) & 255u;
+                            if (C == 255u && B != 255u) ow = (ow & ~(255u << (8 * j))) | ((uint32_t)ring[(head + (A | (B << 8))) & 32767u] << (8 * j));
+                        }
+                    }
+                    o[d] = ow;
+                }
+            }
+            __syncthreads();
+            if (mine_c) {
+                const uint32_t at = (head + i0) & 32767u;
+                if (whole_c && at + 32u <= 32768u) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) reinterpret_cast<lds_u64*>(ring + at + 8 * d)->v = (uint64_t)o[2 * d] | ((uint64_t)o[2 * d + 1] << 32);
+                } else {
+                    for (uint32_t b = 0; b < 32u && i0 + b < take_c; ++b) ring[(at + b) & 32767u] = (uint8_t)(o[b >> 2] >> (8u * (b & 3u)));
+                }
+            }
+            head = (head + take_c) & 32767u;
+            __syncthreads();
+            uint4* const dst = reinterpret_cast<uint4*>(rings + (size_t)(c0 + ci + 1u) * 32768u);
+            for (uint32_t r = 0; r < 2u; ++r) dst[tid + 1024u * r] = reinterpret_cast<const uint4*>(ring)[tid + 1024u * r];
+            if (tid == 0) heads[c0 + ci + 1u] = head;
         }
-        head = (head + take) & 32767u;
-        __syncthreads();
-        uint4* const dst = reinterpret_cast<uint4*>(rings + (size_t)(c + 1u) * 32768u);
-        for (uint32_t r = 0; r < 2u; ++r) dst[tid + 1024u * r] = reinterpret_cast<const uint4*>(ring)[tid + 1024u * r];
-        if (tid == 0) heads[c + 1u] = head;
     }
 }
 // text[out_off + i] of every chunk from its planes and the window in front of it; gridDim.y workgroups share a chunk

@@ -690,7 +690,7 @@ struct RawEngine {
             for (auto& kv : g_bgzf) largest = std::max<uint64_t>(largest, rk_bgzf_text_bytes(kv.second));
             mega = std::min<uint64_t>((uint64_t)1 << 30, std::max<uint64_t>((uint64_t)4 << 20, largest / 3 + ((uint64_t)1 << 20)));
             // (an ordinary gzip file is ONE stream: its stretches follow each other on one worker, so a slot takes a whole file when it can)
-            for (auto& kv : g_gzip) mega = std::max<uint64_t>(mega, std::min<uint64_t>((uint64_t)1 << 30, rk_gzip_text_bytes_hint(kv.second) * 9 / 8 + ((uint64_t)8 << 20)));
+            for (auto& kv : g_gzip) mega = std::max<uint64_t>(mega, std::min<uint64_t>((uint64_t)1 << 30, rk_gzip_text_bytes_hint(kv.second) * 5 / 4 + ((uint64_t)8 << 20)));
             if (const long kb = env_long("RKMH_BGZF_JOB_KB", 0, 64, 1536 << 10)) mega = (uint64_t)kb << 10; // (tests: small jobs)
             pieces = (int)std::min<uint64_t>(32, std::max<uint64_t>(1, mega >> 25)); // ~32 MB of text per output piece
             pieces = (int)env_long("RKMH_BGZF_PIECES", pieces, 1, 32);
@@ -2658,12 +2658,16 @@ static int main_hpv16(int argc, char** argv) {
 }
 
 
+extern char** environ;
 static pid_t g_child = -1;
 static void forward_signal(int sig) { if (g_child > 0) kill(g_child, sig); }
 // see tell_parent: the parent's side.  Returns in the child (and in a process that does not fork); the parent never returns.
 static void fork_for_fast_exit() {
     const char* pre = getenv("LD_PRELOAD");
     if (getenv("RKMH_SLOW_EXIT") || (getenv("RKMH_FORK") && atoi(getenv("RKMH_FORK")) == 0) || (pre && *pre)) return;
+    // (a profiler's tool library has initialised the GPU runtime in this process already: a forked child could not use it)
+    for (char** e = environ; e && *e; ++e)
+        if (strncmp(*e, "ROCP", 4) == 0 || strncmp(*e, "HSA_TOOLS_LIB=", 14) == 0 || strncmp(*e, "ROCPROFILER", 11) == 0) return;
     int fds[2];
     if (pipe(fds) != 0) return;
     fflush(stdout); fflush(stderr);
