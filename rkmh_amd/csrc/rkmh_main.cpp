@@ -928,7 +928,8 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
                 finish_block(sub);
                 if (fail_seq.load() <= sub.seq) handed_over = true; // (text that is not four lines per record)
             }
-            rk_gzip_release_device(F.gz);
+            // (the file's 4 MB on the device stay until the run ends: hipFree waits for every stream of the device to drain -- seconds, while
+            // the other workers' kernels run, tools/ubench/malloc_vs_kernels.hip -- and holds the runtime's lock meanwhile)
         };
         for (;;) {
             if (!jobs.pop(&cur)) break;
