@@ -1,4 +1,4 @@
-// rk_inflate.hip -- DEFLATE (RFC 1951) on the device, for BGZF members (gfx950, wave64).
+// rk_inflate.hip -- DEFLATE (RFC 1951) on the device: BGZF members, and the chunks of ordinary gzip streams (gfx950, wave64).
 //
 // The reference opens every input with gzopen (/root/reference/src/rkmh.cpp:238-263): one sequential inflater.  A BGZF file is a chain
 // of INDEPENDENT gzip members of at most 64 KB of text each (SAM specification 4.1), about a thousand per block of the device FASTQ
@@ -6,7 +6,7 @@
 //   * pass 1, k_inflate_lanes: ONE LANE PER MEMBER.  Huffman decoding is a serial chain per stream; a wave that decodes one stream
 //     uniformly spends 64 lanes on it (the first version here: ~800 cycles per symbol, the chip's issue slots full at 3 GB/s of
 //     text, profiles/r05_gz.txt).  Here every lane runs its own stream: bit buffer, position and block state in registers, its code
-//     tables (9-bit literal/length root, 7-bit distance root, 16-bit entries), its input ring and its output rings in LDS, all
+//     tables (8-bit literal/length root, 6-bit distance root, 16-bit entries), its input ring and its output rings in LDS, all
 //     arrays interleaved by lane.  What a lane produces is NOT text but (a) the member's literals as one packed byte stream and (b) a
 //     32-bit entry per match: run of literals before it (8 bits) | length (9) | distance - 1 (15); an entry of length 0 carries 255
 //     literals of a longer run, or the tail.
@@ -15,12 +15,10 @@
 //     earlier into its ring, flushes whole literal dwords and entries, and requests its next 16 bytes; a lane whose ring runs low or
 //     whose output rings fill idles until the next period.  Block headers are decoded a few steps per period by the lanes that are
 //     at one; a lane that needs code tables asks for them and the WAVE builds them (64 symbols at a time: codes by ballot ranks);
-//   * pass 2, k_inflate_place: one wave per member and a 64 KB LDS window.  Entries are taken 64 at a time: prefix sums give every
-//     literal run and match its place; the runs are copied from the literal stream (64 bytes per step), then the matches whose
-//     source lies before the batch -- most of them: a batch covers about a kilobyte -- are copied by one lane each, and the rest in
-//     order, 64 lanes per copy.
-// CRC-32 is NOT checked here (ISIZE and the stream's own end-of-block structure are); a damaged member almost surely breaks the
-// four-line grammar that the front end verifies next, and RKMH_BGZF_DEVICE=0 keeps the host inflater with its CRC check.
+//   * pass 2, k_inflate_place: one wave per member and a 35 KB wrapping LDS window (see the kernel);
+//   * k_crc32_members: every member's CRC-32 against its footer (what gzread checks); a mismatch hands the job to the host inflater.
+// The STREAM forms of the two passes, k_gz_find_starts, k_gz_windows and k_gz_resolve inflate ORDINARY gzip files -- one deflate
+// stream -- from block headers found in the stream (rk_gunzip.hip drives them; the section further down explains how).
 #include "rk_kernels.hpp"
 #include "rk_crc32.hpp"
 #include <atomic>
