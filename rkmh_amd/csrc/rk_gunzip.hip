@@ -172,7 +172,8 @@ int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t e
     const bool last_call = call == gz->ncalls - 1;
     auto sync = [&]() -> int { HIPCHK(hipEventRecord(ev, st)); HIPCHK(hipEventSynchronize(ev)); return RK_OK; };
     double t_alloc = 0; // (time in allocations: zero from a slot's second file on)
-#define GZ_RESERVE(buf, bytes) do { const auto t_a = std::chrono::steady_clock::now(); RKCHK((buf).reserve(bytes)); t_alloc += ms_since(t_a); } while (0)
+#define GZ_RESERVE(buf, bytes) do { const auto t_a = std::chrono::steady_clock::now(); RKCHK((buf).reserve(bytes)); const double t_b = ms_since(t_a); t_alloc += t_b; \
+        if (timing && t_b > 5.0) fprintf(stderr, "[gzip device] %s: %.0f MB reserved in %.1f ms\n", #buf, (double)(bytes) / 1e6, t_b); } while (0)
     // d_tmp lives from call to call and is made once, at its full size (a DevBuf that grows forgets what it held); the stage is the
     // slot's: [CARRY_CAP bytes: the carry is copied to their end][this call's text: up to cap_out bytes]
     GZ_RESERVE(gz->d_tmp, (size_t)65536 + CARRY_CAP + 64);
@@ -208,7 +209,7 @@ int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t e
         if (const char* e = getenv("RKMH_GZIP_CHUNK_KB")) { const long v = atol(e); if (v >= 1 && v <= 4096) ckb = v; }
         const uint32_t chunk_bits = (uint32_t)ckb << 13;
         const uint32_t nbound = end_rel > first ? (end_rel - first - 1) / chunk_bits : 0; // boundaries first + k chunk_bits < end_rel, k >= 1
-        const size_t cap_chunks = (size_t)nbound + 1 + PATCH_MAX;
+        const size_t cap_chunks = 2 * ((size_t)nbound + 1) + PATCH_MAX + 8; // (the chunks, and behind them the units pass 2 groups them into)
         if ((size_t)nbound + 1 > bound_max) return fail(RK_ERR_STATE, "rk_fastq_slot_load_gzip: more chunk boundaries than planned");
         GZ_RESERVE(S.d_misc, (size_t)(nbound + 1) * 12 + 64);
         uint32_t* const h_from = h_crc + seg_max;
@@ -233,19 +234,23 @@ int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t e
         starts.push_back(first);
         for (uint32_t k = 0; k < nbound; ++k) if (h_found[k] != 0xFFFFFFFFu && h_found[k] > starts.back()) starts.push_back(h_found[k]);
         nchunk = (uint32_t)starts.size();
-        // a chunk's scratch: 6 bytes per compressed byte (a literal of 4 bits: 2 bytes per byte; a match of 8 bits: 4) + what it may run past its stop
+        // a chunk's scratch: 5 bytes per compressed byte (a literal of 4 bits: 2 bytes per byte; a match of 10 bits: 3.2) and a little
+        // for what it writes last.  A chunk normally stops exactly at its stop position -- the next chunk's header; one that runs on (a
+        // false header in its way; the stretch's last chunk) or is denser than that overflows (status 22) and is decoded again, alone,
+        // into a roomy region.  (The first form gave every chunk 128 KB of slack: 5.6 GB for a file of 183 MB -- and allocations of
+        // that size take 0.15 - 0.8 s while other workers set up.)
         uint64_t sdw = 0;
-        auto region_of = [](uint32_t bits) { return (uint32_t)((((uint64_t)bits / 8 + 131072) * 6 + 4096) / 4); };
+        auto region_of = [](uint64_t bits, uint64_t slack) { return (uint32_t)(((bits / 8 + slack) * 5 + 4096) / 4); };
         for (uint32_t i = 0; i < nchunk; ++i) {
             GzChunk& g = hc[i];
             memset(&g, 0, sizeof g);
             g.start_bit = starts[i]; g.stop_bit = i + 1 < nchunk ? starts[i + 1] : stop_last;
             const uint32_t span = (i + 1 < nchunk ? starts[i + 1] : end_rel) - starts[i];
-            g.scratch_off = (uint32_t)sdw; g.scratch_dw = region_of(span);
+            g.scratch_off = (uint32_t)sdw; g.scratch_dw = region_of(span, i + 1 < nchunk ? 8192 : 262144);
             g.flags = (i == 0 && gz->text_made == 0) ? 1u : 0u;
             sdw += g.scratch_dw;
         }
-        const uint64_t patch_dw = region_of(2 * chunk_bits + (uint32_t)(OVER * 8 / 4));
+        const uint64_t patch_dw = region_of(2 * (uint64_t)chunk_bits + OVER * 8 / 4, 262144);
         if (sdw + patch_dw * PATCH_MAX >= ((uint64_t)1 << 32)) return 1;
         GZ_RESERVE(S.d_scratch, (size_t)(sdw + patch_dw * PATCH_MAX) * 4 + 64);
         GzChunk* const d_chunks = S.d_chunks.as<GzChunk>();
@@ -257,6 +262,20 @@ int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t e
         uint32_t cur = 0, patches = 0;
         for (;;) {
             const GzChunk& g = hc[cur];
+            if (g.status == 22u && patches < PATCH_MAX && g.scratch_dw < (uint32_t)patch_dw) { // its region was too small: once more, alone, into a roomy one
+                GzChunk& p = hc[nchunk];
+                p = g;
+                p.scratch_off = (uint32_t)(sdw + patch_dw * patches); p.scratch_dw = (uint32_t)patch_dw;
+                p.status = 0;
+                if (timing) fprintf(stderr, "[gzip device] the chunk at bit %u outgrew its scratch region: decoded again on its own\n", p.start_bit);
+                HIPCHK(hipMemcpyAsync(d_chunks + nchunk, &p, sizeof(GzChunk), hipMemcpyHostToDevice, st));
+                HIPCHK(launch_gz_lanes(d_comp, (uint32_t)(cpad + 64), d_chunks + nchunk, 1, S.d_scratch.as<uint32_t>(), st));
+                HIPCHK(hipMemcpyAsync(&p, d_chunks + nchunk, sizeof(GzChunk), hipMemcpyDeviceToHost, st));
+                RKCHK(sync());
+                cur = nchunk++;
+                ++patches;
+                continue;
+            }
             if (g.status != 0) { if (timing) fprintf(stderr, "[gzip device] chunk at bit %u: status %u\n", g.start_bit, g.status); return 1; }
             chain.push_back(cur);
             if ((uint64_t)total + g.out_len >= ((uint64_t)1 << 31)) return 1;
@@ -293,24 +312,37 @@ int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t e
     if (nseg > seg_max) return 1;
     if (nch) {
         GZ_RESERVE(S.d_planes, 3 * plane_stride + 256);
-        GZ_RESERVE(S.d_rings, (size_t)(nch + 1) * 32768);
+        const uint32_t group = std::min<uint32_t>(8u, std::max<uint32_t>(1u, (nch + 3071u) / 3072u)); // (chunks per unit of pass 2: see below)
+        const uint32_t nunits = (nch + group - 1) / group;
+        GZ_RESERVE(S.d_rings, (size_t)(nunits + 1) * 32768);
         GZ_RESERVE(S.d_heads, (size_t)(nch + 2) * 4 + (size_t)(nseg + 1) * 4);
         // (rings[0] / heads[0]: the window the call before left -- see the end of this function; the stream's first call: zeros)
         if (gz->text_made == 0) { HIPCHK(hipMemsetAsync(gz->d_tmp.p, 0, 32768 + 4, st)); }
         HIPCHK(hipMemcpyAsync(S.d_rings.p, gz->d_tmp.p, 32768, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(S.d_heads.p, gz->d_tmp.as<uint8_t>() + 32768, 4, hipMemcpyDeviceToDevice, st));
-        std::vector<GzChunk> cc(nch);
+        // the chain's chunks in order with their places, then the UNITS pass 2 works in: `group` consecutive chunks placed as one
+        // stretch of text (a step of the sequential window walk per unit: ~3 000 units keep the CUs busy and the walk short)
+        std::vector<GzChunk> cc((size_t)nch + nunits);
         uint32_t off = 0;
         for (uint32_t i = 0; i < nch; ++i) { cc[i] = hc[chain[i]]; cc[i].out_off = off; off += cc[i].out_len; }
-        memcpy(hc, cc.data(), (size_t)nch * sizeof(GzChunk)); // (page-locked: the upload reads it after this function's next lines)
+        for (uint32_t uix = 0; uix < nunits; ++uix) {
+            GzChunk& un = cc[(size_t)nch + uix];
+            memset(&un, 0, sizeof un);
+            un.out_off = cc[(size_t)uix * group].out_off;
+            for (uint32_t j = uix * group; j < std::min(nch, (uix + 1) * group); ++j) un.out_len += cc[j].out_len;
+        }
+        GZ_RESERVE(S.h_chunks, cc.size() * sizeof(GzChunk));
+        GZ_RESERVE(S.d_chunks, cc.size() * sizeof(GzChunk));
+        hc = S.h_chunks.as<GzChunk>();
+        memcpy(hc, cc.data(), cc.size() * sizeof(GzChunk)); // (page-locked: the upload reads it after this function's next lines)
         GzChunk* const d_chunks = S.d_chunks.as<GzChunk>();
-        HIPCHK(hipMemcpyAsync(d_chunks, hc, (size_t)nch * sizeof(GzChunk), hipMemcpyHostToDevice, st));
-        uint32_t* const d_crc = S.d_heads.as<uint32_t>() + nch + 2;
-        HIPCHK(launch_gz_place(d_chunks, nch, S.d_planes.as<uint8_t>(), plane_stride, S.d_scratch.as<uint32_t>(), S.d_rings.as<uint8_t>(), S.d_heads.as<uint32_t>(), text,
-                               total, d_crc, st));
+        HIPCHK(hipMemcpyAsync(d_chunks, hc, cc.size() * sizeof(GzChunk), hipMemcpyHostToDevice, st));
+        uint32_t* const d_crc = S.d_heads.as<uint32_t>() + nunits + 2;
+        HIPCHK(launch_gz_place(d_chunks, nch, group, d_chunks + nch, nunits, S.d_planes.as<uint8_t>(), plane_stride, S.d_scratch.as<uint32_t>(), S.d_rings.as<uint8_t>(),
+                               S.d_heads.as<uint32_t>(), text, total, d_crc, st));
         // the window behind this call's last chunk, for the next call (d_tmp: 32 KB of ring + its head)
-        HIPCHK(hipMemcpyAsync(gz->d_tmp.p, S.d_rings.as<uint8_t>() + (size_t)nch * 32768, 32768, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(gz->d_tmp.as<uint8_t>() + 32768, S.d_heads.as<uint32_t>() + nch, 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(gz->d_tmp.p, S.d_rings.as<uint8_t>() + (size_t)nunits * 32768, 32768, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(gz->d_tmp.as<uint8_t>() + 32768, S.d_heads.as<uint32_t>() + nunits, 4, hipMemcpyDeviceToDevice, st));
         if (nseg) HIPCHK(hipMemcpyAsync(h_crc, d_crc, (size_t)nseg * 4, hipMemcpyDeviceToHost, st));
     }
     // ---- the records: everything in front of the last record start near the end (all of it at the end of the stream)

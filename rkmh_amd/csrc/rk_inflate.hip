@@ -549,27 +549,36 @@ __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
 // A chunk may be of any length: window indices wrap modulo P2_R as often as it takes.
 template <bool STREAM>
 __global__ __launch_bounds__(IW) void k_inflate_place(const void* __restrict__ mem_, uint32_t nmem, uint8_t* __restrict__ text, const uint32_t* __restrict__ scratch,
-                                                      const uint32_t* __restrict__ status, uint32_t pattern) {
+                                                      const uint32_t* __restrict__ status, uint32_t group, size_t plane_stride) {
     __shared__ __attribute__((aligned(16))) uint8_t win[P2_R + 16];
     __shared__ uint32_t s_ent[P2_SB];
     __shared__ __attribute__((aligned(16))) uint32_t s_lit[P2_LIT / 4 + 4];
     const int lane = threadIdx.x;
-    const uint32_t m = blockIdx.x;
+    // STREAM: a workgroup places `group` consecutive chunks as ONE stretch of text in one window -- only the first of them needs the
+    // stand-in pattern, and the window walk (k_gz_windows, the one sequential kernel of the route) has a step per group, not per
+    // chunk; blockIdx.y = the plane (its pattern, its copy of the text).
+    const uint32_t m = STREAM ? blockIdx.x * group : blockIdx.x;
+    const uint32_t pattern = STREAM ? blockIdx.y : 0u;
+    if constexpr (STREAM) text += (size_t)pattern * plane_stride;
     if (m >= nmem) return;
-    uint32_t nent, nlit, n, out_off, match_off, region_dw = 0;
+    uint32_t nent, nlit, n, out_off, match_off, region_dw = 0, nsub = 1, n_end;
     if constexpr (STREAM) {
-        const GzChunk g = reinterpret_cast<const GzChunk*>(mem_)[m];
-        if (g.status != 0u) return;
+        const GzChunk* const gc = reinterpret_cast<const GzChunk*>(mem_);
+        const GzChunk g = gc[m];
         nent = g.nent; nlit = g.nlit; n = g.out_len; out_off = g.out_off; match_off = g.scratch_off; region_dw = g.scratch_dw;
+        n_end = n;
+        nsub = nmem - m < group ? nmem - m : group;
+        for (uint32_t j = 1; j < nsub; ++j) n += gc[m + j].out_len;
     } else {
         if (status[m] != 0u) return;
         nent = status[nmem + m] & 0x7FFFu; nlit = status[nmem + m] >> 15;
         const InflateMember me = reinterpret_cast<const InflateMember*>(mem_)[m];
         n = me.out_len; out_off = me.out_off; match_off = me.match_off;
+        n_end = n;
     }
     constexpr uint32_t K0 = STREAM ? 32768u : 0u; // window index of the first 16-byte group that holds text
-    const uint32_t* const ents = scratch + match_off;
-    const uint32_t* const lits_top = ents + ((STREAM ? region_dw : scratch_dwords(n)) - 1u); // literal dword d lives at lits_top[-d] (pass 1)
+    const uint32_t* ents = scratch + match_off;
+    const uint32_t* lits_top = ents + ((STREAM ? region_dw : scratch_dwords(n)) - 1u); // literal dword d lives at lits_top[-d] (pass 1)
     auto lit_global = [&](uint32_t idx) -> uint8_t { return (uint8_t)(*(lits_top - (idx >> 2)) >> (8u * (idx & 3u))); };
     uint8_t* const dst = text + out_off;
     const uint32_t wb = K0 + (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u); // window index of the text's first byte
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const void* __restrict__ m
     }
     uint32_t lit_base = 0, lit_have = 0; // s_lit holds the literal bytes [lit_base, lit_base + lit_have)
     constexpr uint32_t LIT_DW = P2_LIT / 4 + 1, LIT_K = (LIT_DW + IW - 1) / IW;
-    const uint32_t lit_dw_end = (nlit + 3u) >> 2; // dwords pass 1 wrote
+    uint32_t lit_dw_end = (nlit + 3u) >> 2; // dwords pass 1 wrote
     auto stage_lits = [&]() { // the literal stream from where it stands (wave-uniform call)
         uint32_t lv[LIT_K];
         lit_base = lp0 & ~3u;
@@ -608,6 +617,15 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const void* __restrict__ m
         for (uint32_t k = flushed + 16u * (uint32_t)lane; k < hi; k += 16u * IW) *reinterpret_cast<uint4*>(a0 + k) = *reinterpret_cast<const uint4*>(win + wi(k));
         if (hi > flushed) flushed = hi;
     };
+    for (uint32_t sub = 0; sub < nsub; ++sub) {
+    if constexpr (STREAM) {
+        if (sub) { // the next chunk of the group: its entries and literals, the same window and text
+            const GzChunk g = reinterpret_cast<const GzChunk*>(mem_)[m + sub];
+            nent = g.nent; nlit = g.nlit; n_end += g.out_len;
+            ents = scratch + g.scratch_off; lits_top = ents + (g.scratch_dw - 1u);
+            lit_dw_end = (nlit + 3u) >> 2; lp0 = 0; lit_base = 0; lit_have = 0;
+        }
+    }
     for (uint32_t e0 = 0; e0 < nent; e0 += P2_SB) {
         const uint32_t ne = nent - e0 < (uint32_t)P2_SB ? nent - e0 : (uint32_t)P2_SB;
         { // stage the entries of this stretch, and the literals again from where the stream stands
@@ -630,7 +648,7 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const void* __restrict__ m
             if ((uint32_t)lane >= take) { run = 0; len = 0; }
             const uint32_t r = sc & 0xFFFFu, t = sc >> 16;
             const uint32_t tot_r = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)take - 1), tot_t = (uint32_t)__builtin_amdgcn_readlane((int)t, (int)take - 1);
-            if (kp - wb + tot_t > n || lp0 + tot_r > nlit) return; // (pass 1 checked every entry against out_len: unreachable for its output)
+            if (kp - wb + tot_t > n_end || lp0 + tot_r > nlit) return; // (pass 1 checked every entry against out_len: unreachable for its output)
             const uint32_t at = kp + t - len;      // window index where this lane's match begins; its run ends there (lanes past the batch: unused)
             const uint32_t lsrc = lp0 + r - run;   // its run's first byte in the literal stream
             // the batch's literals: from the stage, which moves up when the batch reaches past it (a batch with more literals than
@@ -700,6 +718,7 @@ __global__ __launch_bounds__(IW) void k_inflate_place(const void* __restrict__ m
             kp += tot_t; lp0 += tot_r; q0 += take;
             flush_to(kp);
         }
+    }
     }
     isync();
     // what is left: the head (a text that ends inside the first group), the last whole groups, the tail bytes
@@ -1054,7 +1073,7 @@ hipError_t launch_inflate_members(const uint8_t* comp, uint32_t comp_bytes, cons
         attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_inflate_lanes<8, 6, false>), dim3((nmem + IW - 1) / IW), dim3(IW), sizeof(LaneLds<8, 6>), st, comp, comp_bytes, mem, nmem, scratch, status);
-    hipLaunchKernelGGL(k_inflate_place<false>, dim3(nmem), dim3(IW), 0, st, mem, nmem, text, scratch, status, 0u);
+    hipLaunchKernelGGL(k_inflate_place<false>, dim3(nmem), dim3(IW), 0, st, mem, nmem, text, scratch, status, 1u, (size_t)0);
     hipLaunchKernelGGL(k_crc32_members, dim3((nmem + 3) / 4), dim3(256), 0, st, mem, nmem, text, comp, status);
     return hipGetLastError();
 }
@@ -1082,12 +1101,12 @@ hipError_t launch_gz_lanes(const uint8_t* comp, uint32_t comp_bytes, GzChunk* ch
     hipLaunchKernelGGL((k_inflate_lanes<8, 6, true>), dim3((n + IW - 1) / IW), dim3(IW), sizeof(LaneLds<8, 6>), st, comp, comp_bytes, chunks, n, scratch, nullptr);
     return hipGetLastError();
 }
-hipError_t launch_gz_place(const GzChunk* chunks, uint32_t n, uint8_t* planes, size_t plane_stride, const uint32_t* scratch, uint8_t* rings, uint32_t* heads, uint8_t* text,
-                           uint32_t text_bytes, uint32_t* crc, hipStream_t st) {
+hipError_t launch_gz_place(const GzChunk* chunks, uint32_t n, uint32_t group, const GzChunk* units, uint32_t nunits, uint8_t* planes, size_t plane_stride, const uint32_t* scratch,
+                           uint8_t* rings, uint32_t* heads, uint8_t* text, uint32_t text_bytes, uint32_t* crc, hipStream_t st) {
     if (!n) return hipSuccess;
-    for (uint32_t p = 0; p < 3u; ++p) hipLaunchKernelGGL(k_inflate_place<true>, dim3(n), dim3(IW), 0, st, chunks, n, planes + p * plane_stride, scratch, nullptr, p);
-    hipLaunchKernelGGL(k_gz_windows, dim3(1), dim3(1024), 0, st, chunks, n, planes, plane_stride, rings, heads);
-    hipLaunchKernelGGL(k_gz_resolve, dim3(n, 4), dim3(256), 0, st, chunks, planes, plane_stride, rings, heads, text);
+    hipLaunchKernelGGL(k_inflate_place<true>, dim3(nunits, 3), dim3(IW), 0, st, chunks, n, planes, scratch, nullptr, group, plane_stride);
+    hipLaunchKernelGGL(k_gz_windows, dim3(1), dim3(1024), 0, st, units, nunits, planes, plane_stride, rings, heads);
+    hipLaunchKernelGGL(k_gz_resolve, dim3(nunits, 4), dim3(256), 0, st, units, planes, plane_stride, rings, heads, text);
     if (text_bytes) hipLaunchKernelGGL(k_crc32_segments, dim3((((text_bytes + 65535u) >> 16) + 3u) / 4u), dim3(256), 0, st, text, text_bytes, crc);
     return hipGetLastError();
 }

@@ -165,10 +165,11 @@ struct GzChunk {
 };
 hipError_t launch_gz_find_starts(const uint8_t* comp, uint32_t nbits, const uint32_t* from, const uint32_t* to, uint32_t n, uint32_t* found, hipStream_t st);
 hipError_t launch_gz_lanes(const uint8_t* comp, uint32_t comp_bytes, GzChunk* chunks, uint32_t n, uint32_t* scratch, hipStream_t st);
-// pass 2 of n chunks in stream order: three planes (plane_stride apart), the windows (rings: (n + 1) x 32 KB, heads: n + 1 -- [0] given),
-// the text (text[out_off ..) of every chunk), and the CRC-32 of every 64 KB segment of text[0, text_bytes)
-hipError_t launch_gz_place(const GzChunk* chunks, uint32_t n, uint8_t* planes, size_t plane_stride, const uint32_t* scratch, uint8_t* rings, uint32_t* heads, uint8_t* text,
-                           uint32_t text_bytes, uint32_t* crc, hipStream_t st);
+// pass 2 of n chunks in stream order, `group` consecutive chunks placed together as one unit (units[u]: out_off / out_len of unit u,
+// nunits = ceil(n / group)): three planes (plane_stride apart), the windows in front of the units (rings: (nunits + 1) x 32 KB,
+// heads: nunits + 1 -- [0] given), the text (text[out_off ..) of every chunk), and the CRC-32 of every 64 KB segment of text[0, text_bytes)
+hipError_t launch_gz_place(const GzChunk* chunks, uint32_t n, uint32_t group, const GzChunk* units, uint32_t nunits, uint8_t* planes, size_t plane_stride, const uint32_t* scratch,
+                           uint8_t* rings, uint32_t* heads, uint8_t* text, uint32_t text_bytes, uint32_t* crc, hipStream_t st);
 // cuts[which] = first FASTQ record start (four-line rule) at or after `from`; n: none and the text ends here; 0xFFFFFFFF: not decidable from this text
 hipError_t launch_fastq_first_start(const uint8_t* text, uint32_t n, uint32_t from, uint32_t window, bool at_eof, uint32_t* cuts, int which, hipStream_t st);
 // whole-array ascending sort of u64 keys in place (rk_sort.hip: rocPRIM radix sort); tmp holds sort_u64_temp_bytes(n) bytes

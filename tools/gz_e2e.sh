@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (GPU box): [N=8000000] bash tools/gz_e2e.sh [tag] -- ONE BGZF file of N reads (and the same text plain) through bin/rkmh stream: one file
+# Usage (GPU box): [N=8000000] [N1=2000000] [GZL=6] [QUICK=1|SWEEP=1|DETAIL=1] bash tools/gz_e2e.sh [tag] -- ONE BGZF file of N reads (and the same text plain) through bin/rkmh stream: one file
 # and four, plain text / device inflate (two root-table forms) / host inflate: wall, marginal reads/s of the three extra files, the
 # [bgzf device] job lines, then a rocprofv3 kernel trace of the four-file device run.  Output: gpurun_out/<tag>_gz.txt, <tag>_gz_kernel_stats.csv
 cd ${GRAFT_REPO_ROOT:-.}
@@ -38,12 +38,12 @@ run() { # label file env...
   local label=$1 f=$2; shift 2
   local t1 t4
   for rep in 1 2; do
-    S=$(date +%s.%N); env "$@" RKMH_TIMING=1 timeout -s ABRT 300 bin/rkmh stream $R -f $f > /tmp/big.out 2>/tmp/big.err1 || { echo "$label failed" >> $OUT; tail -3 /tmp/big.err1 >> $OUT; return; }; E=$(date +%s.%N)
+    rm -f /tmp/big.out; S=$(date +%s.%N); env "$@" RKMH_TIMING=1 timeout -s ABRT 300 bin/rkmh stream $R -f $f > /tmp/big.out 2>/tmp/big.err1 || { echo "$label failed" >> $OUT; tail -3 /tmp/big.err1 >> $OUT; return; }; E=$(date +%s.%N)
     t1=$(python3 -c "print($E - $S)")
   done
   got=$(sha256sum /tmp/big.out | cut -c1-16)
   for rep in 1 2; do
-    S=$(date +%s.%N); env "$@" RKMH_TIMING=1 RKMH_BGZF_TIMING=1 timeout -s ABRT 300 bin/rkmh stream $R -f $f -f $f -f $f -f $f > /tmp/big.out 2>/tmp/big.err4 || { echo "$label x4 failed" >> $OUT; tail -3 /tmp/big.err4 >> $OUT; return; }; E=$(date +%s.%N)
+    rm -f /tmp/big.out; S=$(date +%s.%N); env "$@" RKMH_TIMING=1 RKMH_BGZF_TIMING=1 timeout -s ABRT 300 bin/rkmh stream $R -f $f -f $f -f $f -f $f > /tmp/big.out 2>/tmp/big.err4 || { echo "$label x4 failed" >> $OUT; tail -3 /tmp/big.err4 >> $OUT; return; }; E=$(date +%s.%N)
     t4=$(python3 -c "print($E - $S)")
   done
   python3 -c "print('%-44s 1 file %.3f s, 4 files %.3f s: marginal %.1f M reads/s; output %s' % ('$label', $t1, $t4, 3 * $N / ($t4 - $t1) / 1e6, 'identical to plain' if '$got' == '$want' else 'DIFFERS'))" >> $OUT
