@@ -490,6 +490,8 @@ int64_t rk_gzip_plan(rk_gzip* gz, uint64_t slot_bytes); /* calls the file takes;
 int64_t rk_gzip_calls(const rk_gzip* gz);
 void rk_gzip_release_device(rk_gzip* gz);              /* frees the device buffers of a file that has been read; rk_gzip_plan before the next pass */
 int rk_fastq_slot_load_gzip(rk_fastq_slot* s, rk_gzip* gz, int64_t call, uint64_t* nbytes, uint64_t* text_off);
+uint64_t rk_gzip_stretch_bytes(const rk_gzip* gz);      /* compressed bytes per call, after rk_gzip_plan */
+int rk_fastq_slot_reserve_gzip(rk_fastq_slot* s, uint64_t comp_bytes); /* optional: the work buffers of the calls, made ahead of the first one */
 uint64_t rk_bgzf_file_bytes(const rk_bgzf* z);   /* length of rk_bgzf_image */
 
 /* ------------------------------------------------------------------------------------------------

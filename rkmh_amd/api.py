@@ -129,6 +129,8 @@ _SIGS = {
     "rk_gzip_plan": (C.c_int64, [C.c_void_p, C.c_uint64]),
     "rk_gzip_calls": (C.c_int64, [C.c_void_p]),
     "rk_gzip_release_device": (None, [C.c_void_p]),
+    "rk_gzip_stretch_bytes": (C.c_uint64, [C.c_void_p]),
+    "rk_fastq_slot_reserve_gzip": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rk_fastq_slot_load_gzip": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_bgzf_file_bytes": (C.c_uint64, [C.c_void_p]),
     # packed reads (`rkmh pack`, -F): include/rkmh_amd.h "PACKED READS"

@@ -262,6 +262,14 @@ extern "C" int rk_fastq_slot_load_bgzf(rk_fastq_slot* s, const rk_bgzf* z, int64
     return RK_OK;
 }
 
+// The work buffers of rk_fastq_slot_load_gzip made ahead of the first call, for stretches of up to comp_bytes compressed bytes
+// (rk_gzip_stretch_bytes after rk_gzip_plan).  Optional: the first call makes whatever is missing.
+extern "C" int rk_fastq_slot_reserve_gzip(rk_fastq_slot* s, uint64_t comp_bytes) {
+    if (!s || !s->device_text()) return fail(RK_ERR_ARG, "rk_fastq_slot_reserve_gzip: a slot created with RK_SLOT_DEVICE_TEXT is needed");
+    if (!s->gzs) s->gzs = new GzScratch();
+    return gzip_reserve(*s->gzs, s->c, comp_bytes, s->max_bytes);
+}
+
 // The next stretch of an ORDINARY gzip file (one deflate stream: rk_gzip_open, rk_gzip_plan) inflated on the device (rk_gunzip.hip) into
 // this slot's device text: whole records, *nbytes of them (0: this stretch completed none), the first one at byte *text_off of the
 // file's text.  Calls come in order, call = 0 .. rk_gzip_plan() - 1, all from slots of ONE device; the next rk_fastq_slot_submit /

@@ -155,6 +155,27 @@ extern "C" int64_t rk_gzip_plan(rk_gzip* gz, uint64_t slot_bytes) {
 }
 extern "C" int64_t rk_gzip_calls(const rk_gzip* gz) { return gz ? gz->ncalls : 0; }
 
+// The slot's work buffers at the sizes a stretch of comp_bytes compressed bytes that inflates to at most cap_out bytes will ask for
+// (rk_fastq_slot_reserve_gzip: a worker makes them when it makes its slot -- one worker at a time, beside the reference stage --
+// instead of in front of its first file: allocations of this size take 10 - 50 ms each while other workers are setting up)
+int gzip_reserve(GzScratch& S, rk_ctx* c, uint64_t comp_bytes, uint64_t cap_out) {
+    RKCHK(set_dev(c));
+    const uint64_t up = comp_bytes + OVER + 4096;
+    const uint64_t chunks = up / 32768 + 16;
+    RKCHK(S.d_stage.reserve((size_t)CARRY_CAP + cap_out + 4096));
+    RKCHK(S.d_comp.reserve((size_t)up + 512));
+    RKCHK(S.d_scratch.reserve((size_t)(up + chunks * 8192 + (PATCH_MAX + 1) * ((uint64_t)3 << 20)) * 5 + (chunks + PATCH_MAX) * 4096 + 64));
+    RKCHK(S.d_planes.reserve((size_t)3 * (cap_out + 256) + 256));
+    RKCHK(S.d_rings.reserve((size_t)(std::min<uint64_t>(chunks, 3100) + 2) * 32768));
+    RKCHK(S.d_heads.reserve((size_t)(chunks + 8) * 4 + (size_t)((cap_out >> 16) + 8) * 4));
+    RKCHK(S.d_chunks.reserve((size_t)(2 * chunks + PATCH_MAX + 8) * sizeof(GzChunk)));
+    RKCHK(S.h_chunks.reserve((size_t)(2 * chunks + PATCH_MAX + 8) * sizeof(GzChunk)));
+    RKCHK(S.d_misc.reserve((size_t)(chunks + 1) * 12 + 64));
+    RKCHK(S.h_misc.reserve((16 + (size_t)(cap_out >> 16) + 8 + 3 * ((size_t)(comp_bytes >> 10) + 8)) * 4));
+    return RK_OK;
+}
+extern "C" uint64_t rk_gzip_stretch_bytes(const rk_gzip* gz) { return gz ? gz->stretch : 0; }
+
 // The next stretch of gz's stream -> whole records at d_out (at most cap_out bytes), *nbytes of them; *text_off = the offset of the
 // first of them in the file's text.  RK_OK; 1: not for the device from *text_off on (see the head of this file); < 0: an error
 // (damaged data: a CRC-32 or length that does not match the trailer).  Calls come in order, call = 0 .. ncalls - 1, on stream st.

@@ -660,6 +660,7 @@ struct RawEngine {
     uint64_t block = 0;  // text per job: plain files, and BGZF files inflated on the host
     uint64_t mega = 0;   // text per job of BGZF files inflated on the device (0: no such file in this run)
     int pieces = 1;      // block numbers (= output pieces, formatted in parallel) per device-inflated job
+    uint64_t gz_stretch = 0; // ordinary gzip files in this run: the most compressed bytes one call takes (0: none)
     bool need_plain_workers = false; // the references go through the workers' page-locked text buffers (refs_through_device)
     FormatPool pool;
     double t_read = 0, t_dev = 0, t_fmt = 0;
@@ -714,6 +715,10 @@ struct RawEngine {
             return false;
         }
         if (pieces > 1) pool.start((int)std::min<long>(16, std::max<long>(2, granted_cpus_main() - 2)));
+        if (dev_inflate)
+            for (auto& kv : g_gzip)
+                if (rk_gzip_plan(kv.second, mega) > 0) gz_stretch = std::max<uint64_t>(gz_stretch, rk_gzip_stretch_bytes(kv.second));
+        if (gz_stretch && w[0].device_text && rk_fastq_slot_reserve_gzip(w[0].slot, gz_stretch) != RK_OK) fprintf(stderr, "rkmh: %s\n", rk_last_error());
         return true;
     }
     // A worker makes its slot when it starts, ONE worker at a time: allocations of several threads queue up inside the runtime anyway,
@@ -844,7 +849,11 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
         std::atomic<int>& live = W.device_text ? live_mega : live_plain;
         const double t_slot = now_s();
         bool slot_ok = true;
-        if (!W.slot) { std::lock_guard<std::mutex> sl(eng.slot_mu); slot_ok = rk_fastq_slot_create2(g.ctx[W.dev], W.bytes, W.device_text ? RK_SLOT_DEVICE_TEXT : 0, &W.slot) == RK_OK; }
+        if (!W.slot) {
+            std::lock_guard<std::mutex> sl(eng.slot_mu);
+            slot_ok = rk_fastq_slot_create2(g.ctx[W.dev], W.bytes, W.device_text ? RK_SLOT_DEVICE_TEXT : 0, &W.slot) == RK_OK;
+            if (slot_ok && W.device_text && eng.gz_stretch) slot_ok = rk_fastq_slot_reserve_gzip(W.slot, eng.gz_stretch) == RK_OK;
+        }
         if (!slot_ok) {
             // (memory for another slot ran out: the other workers carry on -- unless this was the last one)
             fprintf(stderr, "rkmh: worker %zu: %s\n", wi, rk_last_error());
