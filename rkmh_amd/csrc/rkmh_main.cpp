@@ -718,7 +718,6 @@ struct RawEngine {
         if (dev_inflate)
             for (auto& kv : g_gzip)
                 if (rk_gzip_plan(kv.second, mega) > 0) gz_stretch = std::max<uint64_t>(gz_stretch, rk_gzip_stretch_bytes(kv.second));
-        if (gz_stretch && w[0].device_text && rk_fastq_slot_reserve_gzip(w[0].slot, gz_stretch) != RK_OK) fprintf(stderr, "rkmh: %s\n", rk_last_error());
         return true;
     }
     // A worker makes its slot when it starts, ONE worker at a time: allocations of several threads queue up inside the runtime anyway,
@@ -831,8 +830,8 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
     struct Job { size_t file = 0; int64_t seq = 0, lo = 0, hi = 0, at = 0; const uint8_t* ext = nullptr; int64_t nseq = 1; };
     QueueT<Job> jobs_plain, jobs_mega; // (a worker takes the jobs its slot is made for)
     jobs_plain.cap = jobs_mega.cap = eng.w.size();
-    bool any_mega = false, any_plain = false;
-    for (const File& F : files) (F.mega ? any_mega : any_plain) = true;
+    bool any_mega = false, any_plain = false, any_gz = false;
+    for (const File& F : files) { (F.mega ? any_mega : any_plain) = true; if (F.gz) any_gz = true; }
     OrderedOut out;
     if (!counting) out.start(g.size());
     std::atomic<int64_t> fail_seq{INT64_MAX};
@@ -852,7 +851,12 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
         if (!W.slot) {
             std::lock_guard<std::mutex> sl(eng.slot_mu);
             slot_ok = rk_fastq_slot_create2(g.ctx[W.dev], W.bytes, W.device_text ? RK_SLOT_DEVICE_TEXT : 0, &W.slot) == RK_OK;
-            if (slot_ok && W.device_text && eng.gz_stretch) slot_ok = rk_fastq_slot_reserve_gzip(W.slot, eng.gz_stretch) == RK_OK;
+        }
+        // the gunzip work buffers (gigabytes): one worker at a time, and not beside the reference stage (allocations of that size slow
+        // every other call of the runtime down while they last: the first slot's, made in create(), cost the references 0.45 s)
+        if (slot_ok && W.device_text && eng.gz_stretch && any_gz) {
+            std::lock_guard<std::mutex> sl(eng.slot_mu);
+            slot_ok = rk_fastq_slot_reserve_gzip(W.slot, eng.gz_stretch) == RK_OK;
         }
         if (!slot_ok) {
             // (memory for another slot ran out: the other workers carry on -- unless this was the last one)
