@@ -42,8 +42,11 @@ using namespace rk;
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool view = false; // p lies inside another allocation (GzScratch's arena): never freed from here
+    void set_view(void* at, size_t bytes) { release(); p = at; cap = bytes; view = true; }
     int reserve(size_t bytes) {
         if (bytes <= cap) return RK_OK;
+        if (view) { p = nullptr; cap = 0; view = false; }
         if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
         size_t want = bytes + (bytes >> 3) + 256;
         hipError_t e = hipMalloc(&p, want);
@@ -51,21 +54,24 @@ struct DevBuf {
         cap = want;
         return RK_OK;
     }
-    void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; cap = 0; }
+    void release() { if (p && !view) { hipError_t e = hipFree(p); (void)e; } p = nullptr; cap = 0; view = false; }
     template <typename T> T* as() { return reinterpret_cast<T*>(p); }
 };
 struct PinBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool view = false;
+    void set_view(void* at, size_t bytes) { release(); p = at; cap = bytes; view = true; }
     int reserve(size_t bytes) {
         if (bytes <= cap) return RK_OK;
+        if (view) { p = nullptr; cap = 0; view = false; }
         if (p) { hipError_t e = hipHostFree(p); (void)e; p = nullptr; cap = 0; }
         hipError_t e = hipHostMalloc(&p, bytes + 256, hipHostMallocDefault);
         if (e != hipSuccess) { p = nullptr; return fail(RK_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
         cap = bytes + 256;
         return RK_OK;
     }
-    void release() { if (p) { hipError_t e = hipHostFree(p); (void)e; } p = nullptr; cap = 0; }
+    void release() { if (p && !view) { hipError_t e = hipHostFree(p); (void)e; } p = nullptr; cap = 0; view = false; }
     template <typename T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
@@ -220,9 +226,12 @@ int reroute_flagged_device(rk_ctx* c, const void* d_bases, const void* d_offs, i
 struct GzScratch {
     DevBuf d_comp, d_chunks, d_scratch, d_planes, d_rings, d_heads, d_stage, d_misc;
     PinBuf h_chunks, h_misc;
+    DevBuf arena;  // gzip_reserve: ONE device allocation that the eight buffers above are views of (a runtime call of this kind costs
+    PinBuf harena; // ~40 ms while other workers are busy, whatever its size: two calls instead of ten)
     void release() {
         for (DevBuf* b : {&d_comp, &d_chunks, &d_scratch, &d_planes, &d_rings, &d_heads, &d_stage, &d_misc}) b->release();
         h_chunks.release(); h_misc.release();
+        arena.release(); harena.release();
     }
 };
 int gzip_reserve(GzScratch& S, rk_ctx* c, uint64_t comp_bytes, uint64_t cap_out); // rk_gunzip.hip

@@ -162,16 +162,31 @@ int gzip_reserve(GzScratch& S, rk_ctx* c, uint64_t comp_bytes, uint64_t cap_out)
     RKCHK(set_dev(c));
     const uint64_t up = comp_bytes + OVER + 4096;
     const uint64_t chunks = up / 32768 + 16;
-    RKCHK(S.d_stage.reserve((size_t)CARRY_CAP + cap_out + 4096));
-    RKCHK(S.d_comp.reserve((size_t)up + 512));
-    RKCHK(S.d_scratch.reserve((size_t)(up + chunks * 8192 + (PATCH_MAX + 1) * ((uint64_t)3 << 20)) * 5 + (chunks + PATCH_MAX) * 4096 + 64));
-    RKCHK(S.d_planes.reserve((size_t)3 * (cap_out + 256) + 256));
-    RKCHK(S.d_rings.reserve((size_t)(std::min<uint64_t>(chunks, 3100) + 2) * 32768));
-    RKCHK(S.d_heads.reserve((size_t)(chunks + 8) * 4 + (size_t)((cap_out >> 16) + 8) * 4));
-    RKCHK(S.d_chunks.reserve((size_t)(2 * chunks + PATCH_MAX + 8) * sizeof(GzChunk)));
-    RKCHK(S.h_chunks.reserve((size_t)(2 * chunks + PATCH_MAX + 8) * sizeof(GzChunk)));
-    RKCHK(S.d_misc.reserve((size_t)(chunks + 1) * 12 + 64));
-    RKCHK(S.h_misc.reserve((16 + (size_t)(cap_out >> 16) + 8 + 3 * ((size_t)(comp_bytes >> 10) + 8)) * 4));
+    struct Want { DevBuf* b; size_t bytes; };
+    const Want dev[] = {
+        {&S.d_stage, (size_t)CARRY_CAP + cap_out + 4096},
+        {&S.d_comp, (size_t)up + 512},
+        {&S.d_scratch, (size_t)(up + chunks * 8192 + (PATCH_MAX + 1) * ((uint64_t)3 << 20)) * 5 + (chunks + PATCH_MAX) * 4096 + 64},
+        {&S.d_planes, (size_t)3 * (cap_out + 256) + 256},
+        {&S.d_rings, (size_t)(std::min<uint64_t>(chunks, 3100) + 2) * 32768},
+        {&S.d_heads, (size_t)(chunks + 8) * 4 + (size_t)((cap_out >> 16) + 8) * 4},
+        {&S.d_chunks, (size_t)(2 * chunks + PATCH_MAX + 8) * sizeof(GzChunk)},
+        {&S.d_misc, (size_t)(chunks + 1) * 12 + 64},
+    };
+    bool enough = true;
+    size_t total = 0;
+    for (const Want& w : dev) { if (w.b->cap < w.bytes) enough = false; total += (w.bytes + 4095) & ~(size_t)4095; }
+    const size_t h_chunks = (size_t)(2 * chunks + PATCH_MAX + 8) * sizeof(GzChunk), h_misc = (16 + (size_t)(cap_out >> 16) + 8 + 3 * ((size_t)(comp_bytes >> 10) + 8)) * 4;
+    if (enough && S.h_chunks.cap >= h_chunks && S.h_misc.cap >= h_misc) return RK_OK;
+    for (const Want& w : dev) w.b->release();
+    S.h_chunks.release(); S.h_misc.release();
+    S.arena.release(); S.harena.release();
+    RKCHK(S.arena.reserve(total + 4096));
+    RKCHK(S.harena.reserve(((h_chunks + 4095) & ~(size_t)4095) + h_misc + 4096));
+    size_t at = 0;
+    for (const Want& w : dev) { w.b->set_view(S.arena.as<uint8_t>() + at, w.bytes); at += (w.bytes + 4095) & ~(size_t)4095; }
+    S.h_chunks.set_view(S.harena.p, h_chunks);
+    S.h_misc.set_view(S.harena.as<uint8_t>() + ((h_chunks + 4095) & ~(size_t)4095), h_misc);
     return RK_OK;
 }
 extern "C" uint64_t rk_gzip_stretch_bytes(const rk_gzip* gz) { return gz ? gz->stretch : 0; }
