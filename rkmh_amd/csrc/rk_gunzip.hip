@@ -201,7 +201,11 @@ int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t e
     *nbytes = 0;
     *text_off = gz->text_given;
     if (gz->stretch == 0 || call != gz->next_call || call >= gz->ncalls) return fail(RK_ERR_STATE, "rk_fastq_slot_load_gzip: calls come in order, after rk_gzip_plan");
-    if (gz->c && gz->c != c) return fail(RK_ERR_STATE, "rk_fastq_slot_load_gzip: one device per file");
+    if (gz->c && gz->c != c) { // another device than the pass before (-M: two passes over the file): the window and the carry move house
+        if (call != 0) return fail(RK_ERR_STATE, "rk_fastq_slot_load_gzip: the calls of one pass come from slots of one device");
+        RKCHK(set_dev(gz->c));
+        gz->d_tmp.release();
+    }
     gz->c = c;
     RKCHK(set_dev(c));
     ++gz->next_call;

@@ -58,11 +58,19 @@ static int g_done_fd = -1; // (child) write end of the status pipe
 static void tell_parent(int status) {
     if (g_done_fd < 0) return;
     fflush(stdout); fflush(stderr);
-    close(1); close(2); // a reader of our pipes sees their end now, not when the teardown is over
+    // Standard output a regular file: every byte is in the page cache, the parent may go -- and only then is the file closed: this is
+    // the last descriptor of it (the parent closed its copy after the fork), and ext4 starts allocating and writing back a file that
+    // was opened with O_TRUNC ("> out.tsv") at its last close (auto_da_alloc): ~0.1 s per GB, 0.45 s of a 100 M-read run's wall
+    // clock (profiles/r06_c3_e2e.txt), which no reader of the file waits for.  A pipe or a terminal: closed first, so that a reader
+    // sees the end of the stream no later than the command's return.
+    struct stat st;
+    const bool regular = fstat(1, &st) == 0 && S_ISREG(st.st_mode);
+    if (!regular) { close(1); close(2); }
     const unsigned char b = (unsigned char)status;
     if (write(g_done_fd, &b, 1) != 1) {}
     close(g_done_fd);
     g_done_fd = -1;
+    if (regular) { close(1); close(2); }
 }
 // Leaving after an error: flush what there is and go, WITHOUT running static destructors -- a parser or worker thread may still be
 // running, and the HIP runtime's exit handlers are not something to run under it.
@@ -2689,6 +2697,7 @@ static void fork_for_fast_exit() {
     if (pid < 0) { close(fds[0]); close(fds[1]); return; }
     if (pid == 0) { close(fds[0]); g_done_fd = fds[1]; return; }
     close(fds[1]);
+    close(1); // (the parent writes nothing: the child's descriptor is the file's last one -- see tell_parent)
     g_child = pid;
     for (int sig : {SIGINT, SIGTERM, SIGHUP, SIGQUIT, SIGABRT, SIGPIPE}) signal(sig, forward_signal); // (timeout(1), ^C: they mean the worker)
     close(0); // (the child reads standard input, if anyone does)

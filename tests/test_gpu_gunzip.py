@@ -118,6 +118,17 @@ def test_device_gunzip_gives_the_text(gctx, tmp_path, level, qual, nrec, chunk_k
     assert st and all(s == 0 for s in st), st
 
 
+def test_device_gunzip_tiny_and_odd_files(gctx, tmp_path):
+    """three records; one record; a text without its last newline; a 70 KB record-free... no: records of 20 KB (long reads)"""
+    rng = np.random.default_rng(2)
+    for k, text in enumerate((_fastq(rng, 3), _fastq(rng, 1), _fastq(rng, 400)[:-1],
+                              b"".join(b"@long%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=20000)) + b"\n+\n" + b"F" * 20000 + b"\n" for i in range(40)))):
+        path = tmp_path / ("odd%d.fq.gz" % k)
+        path.write_bytes(gzip.compress(text, 6))
+        st = _through_device(gctx, path, text, 8 << 20, {"RKMH_GZIP_CHUNK_KB": "4"})
+        assert st and all(s == 0 for s in st), (k, st)
+
+
 def test_device_gunzip_stored_fixed_and_dynamic_blocks_with_far_matches(gctx, tmp_path):
     """stored (level 0), fixed-code (Z_FIXED) and dynamic blocks in one stream; the piece after every joint repeats records of the
     text ~31 KB back, so its first matches reach (almost) a whole window back -- across a chunk edge whenever a chunk begins there"""
