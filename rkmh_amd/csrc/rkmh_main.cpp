@@ -83,14 +83,34 @@ static void die(const char* what) {
     fprintf(stderr, "rkmh: %s: %s\n", what, rk_last_error());
     fail_exit();
 }
+// A profiler's tool library has initialised the GPU runtime before main() (a forked child could not use it) and writes its tables
+// from an exit handler (so the process must leave through exit()): rocprofv3 / rocprof / roctracer announce themselves through
+// ROCP* / HSA_TOOLS_LIB variables or a preloaded library of theirs.  (Any OTHER preloaded library -- a sanitizer, an exec guard --
+// is no reason to give up the fast exit: a first form tested LD_PRELOAD alone, and on a machine that preloads a guard library into
+// every process the fork never happened.)
+extern char** environ;
+static bool under_profiler() {
+    static const bool yes = [] {
+        for (char** e = environ; e && *e; ++e)
+            if (strncmp(*e, "ROCP", 4) == 0 || strncmp(*e, "HSA_TOOLS_LIB=", 14) == 0) return true;
+        const char* pre = getenv("LD_PRELOAD");
+        return pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "rocsys") || strstr(pre, "omnitrace") || strstr(pre, "omniperf"));
+    }();
+    return yes;
+}
 // Leaving after success: only if every byte really reached standard output (a full disk or a closed pipe must not exit 0)
 static const double g_loaded_s = now_s(); // (static initialisation: the program and its libraries are loaded)
 [[noreturn]] static void done_exit() {
-    if (g_timing) fprintf(stderr, "[rkmh timing] %-28s %.3f s\n", "since the program was loaded", now_s() - g_loaded_s);
+    if (g_timing) {
+        fprintf(stderr, "[rkmh timing] %-28s %.3f s\n", "since the program was loaded", now_s() - g_loaded_s);
+        // (for scripts that bracket the command with `date +%s.%N`: where the wall clock outside the program goes -- before it was loaded or after its last line)
+        const double epoch = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+        fprintf(stderr, "[rkmh timing] loaded at epoch %.3f, leaving at epoch %.3f\n", epoch - (now_s() - g_loaded_s), epoch);
+    }
     const bool bad = fflush(stdout) != 0 || ferror(stdout);
     fflush(stderr);
     if (bad) fprintf(stderr, "rkmh: write error on standard output\n");
-    if (getenv("RKMH_SLOW_EXIT")) exit(bad ? 1 : 0); // profilers (rocprofv3) write their tables from an exit handler
+    if (getenv("RKMH_SLOW_EXIT") || under_profiler()) exit(bad ? 1 : 0); // profilers (rocprofv3) write their tables from an exit handler
     tell_parent(bad ? 1 : 0);
     _exit(bad ? 1 : 0); // skips the HIP runtime's and the loader's exit handlers (~0.1-0.2 s of a 1 s run)
 }
@@ -2680,16 +2700,11 @@ static int main_hpv16(int argc, char** argv) {
 }
 
 
-extern char** environ;
 static pid_t g_child = -1;
 static void forward_signal(int sig) { if (g_child > 0) kill(g_child, sig); }
 // see tell_parent: the parent's side.  Returns in the child (and in a process that does not fork); the parent never returns.
 static void fork_for_fast_exit() {
-    const char* pre = getenv("LD_PRELOAD");
-    if (getenv("RKMH_SLOW_EXIT") || (getenv("RKMH_FORK") && atoi(getenv("RKMH_FORK")) == 0) || (pre && *pre)) return;
-    // (a profiler's tool library has initialised the GPU runtime in this process already: a forked child could not use it)
-    for (char** e = environ; e && *e; ++e)
-        if (strncmp(*e, "ROCP", 4) == 0 || strncmp(*e, "HSA_TOOLS_LIB=", 14) == 0 || strncmp(*e, "ROCPROFILER", 11) == 0) return;
+    if (getenv("RKMH_SLOW_EXIT") || (getenv("RKMH_FORK") && atoi(getenv("RKMH_FORK")) == 0) || under_profiler()) return;
     int fds[2];
     if (pipe(fds) != 0) return;
     fflush(stdout); fflush(stderr);
@@ -2704,7 +2719,14 @@ static void fork_for_fast_exit() {
     unsigned char b = 0;
     ssize_t n;
     while ((n = read(fds[0], &b, 1)) < 0 && errno == EINTR) {}
-    if (n == 1) _exit((int)b); // the output is complete: the child finishes dying on its own
+    if (n == 1) { // the output is complete: the child finishes dying on its own
+        if (getenv("RKMH_TIMING")) {
+            char line[96];
+            const int len = snprintf(line, sizeof line, "[rkmh timing] parent released at epoch %.3f\n", std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
+            if (len > 0 && write(2, line, (size_t)len) < 0) {}
+        }
+        _exit((int)b);
+    }
     int st = 0;
     while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}
     if (WIFEXITED(st)) _exit(WEXITSTATUS(st));
