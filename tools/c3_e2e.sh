@@ -11,6 +11,7 @@ for f in all_pave_ref zika.refs dengue new_refs hpv_16 zika yellow_fever hpv_16_
 C3_PANEL=1 python3 tools/make_fastq.py /tmp/c3_reads.fq $N
 ls -la /tmp/c3_reads.fq | awk '{print "fastq bytes", $5}'
 for rep in 1 2 3; do
+  sleep 2 # (the run before is still being taken apart by the kernel -- behind the command's return: a fresh context beside that is slower)
   rm -f /tmp/c3_out.tsv; : > /tmp/c3_out.tsv
   t0=$EPOCHREALTIME # (a shell variable: `date` would have to be forked, beside a process that is being taken apart)
   RKMH_TIMING=1 bin/rkmh stream $REFS -f /tmp/c3_reads.fq -k 16 -s 1000 > /tmp/c3_out.tsv 2> /tmp/c3_err.txt; rc=$?
