@@ -85,7 +85,26 @@ def e2e_stream(n, L, rb, ro, synth):
                 f.write(rec.tobytes())
         size = os.path.getsize(fq)
         best = None
+        def settle():
+            # bin/rkmh returns when its output is complete; the kernel takes the GPU context of its worker process apart behind that
+            # (0.2-0.8 s).  A timed run must not start beside the last one's teardown: wait until no process called rkmh is left.
+            for _ in range(60):
+                alive = False
+                for pid in os.listdir("/proc"):
+                    if pid.isdigit():
+                        try:
+                            with open("/proc/%s/comm" % pid) as f_:
+                                if f_.read().strip() == "rkmh":
+                                    alive = True
+                                    break
+                        except OSError:
+                            pass
+                if not alive:
+                    return
+                time.sleep(0.05)
+
         def fresh_out():                              # a NEW output file per run, opened before the clock starts: truncating the previous run's
+            settle()
             if os.path.exists(tsv):                   # gigabyte of cached pages is the harness's cost, not the pipeline's
                 os.remove(tsv)
             return open(tsv, "wb")
@@ -116,6 +135,7 @@ def e2e_stream(n, L, rb, ro, synth):
         # the same two runs with the lines going to /dev/null (one writer thread with fwrite, as for a pipe)
         t1 = []
         for nf in (1, 4):
+            settle()
             t = time.perf_counter()
             r = subprocess.run([exe, "stream", "-r", ref] + ["-f", fq] * nf + ["-k", "16", "-s", "1000"], stdout=open(os.devnull, "wb"), stderr=subprocess.PIPE)
             t1.append(time.perf_counter() - t if r.returncode == 0 else None)
@@ -225,6 +245,7 @@ def e2e_stream(n, L, rb, ro, synth):
                     best_ = None
                     for _ in range(2):
                         fo_ = fresh_out() if to_file else open(os.devnull, "wb")
+                        settle()
                         t2 = time.perf_counter()
                         r2 = subprocess.run([exe, "stream", "-r", ref, "-k", "16", "-s", "1000"] + ["-F", rkp] * nf, stdout=fo_, stderr=subprocess.PIPE)
                         d2 = time.perf_counter() - t2

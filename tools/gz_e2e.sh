@@ -38,12 +38,12 @@ run() { # label file env...
   local label=$1 f=$2; shift 2
   local t1 t4
   for rep in 1 2; do
-    rm -f /tmp/big.out; S=$(date +%s.%N); env "$@" RKMH_TIMING=1 timeout -s ABRT 300 bin/rkmh stream $R -f $f > /tmp/big.out 2>/tmp/big.err1 || { echo "$label failed" >> $OUT; tail -3 /tmp/big.err1 >> $OUT; return; }; E=$(date +%s.%N)
+    rm -f /tmp/big.out; sleep 1; S=$(date +%s.%N); env "$@" RKMH_TIMING=1 timeout -s ABRT 300 bin/rkmh stream $R -f $f > /tmp/big.out 2>/tmp/big.err1 || { echo "$label failed" >> $OUT; tail -3 /tmp/big.err1 >> $OUT; return; }; E=$(date +%s.%N)
     t1=$(python3 -c "print($E - $S)")
   done
   got=$(sha256sum /tmp/big.out | cut -c1-16)
   for rep in 1 2; do
-    rm -f /tmp/big.out; S=$(date +%s.%N); env "$@" RKMH_TIMING=1 RKMH_BGZF_TIMING=1 timeout -s ABRT 300 bin/rkmh stream $R -f $f -f $f -f $f -f $f > /tmp/big.out 2>/tmp/big.err4 || { echo "$label x4 failed" >> $OUT; tail -3 /tmp/big.err4 >> $OUT; return; }; E=$(date +%s.%N)
+    rm -f /tmp/big.out; sleep 1; S=$(date +%s.%N); env "$@" RKMH_TIMING=1 RKMH_BGZF_TIMING=1 timeout -s ABRT 300 bin/rkmh stream $R -f $f -f $f -f $f -f $f > /tmp/big.out 2>/tmp/big.err4 || { echo "$label x4 failed" >> $OUT; tail -3 /tmp/big.err4 >> $OUT; return; }; E=$(date +%s.%N)
     t4=$(python3 -c "print($E - $S)")
   done
   python3 -c "print('%-44s 1 file %.3f s, 4 files %.3f s: marginal %.1f M reads/s; output %s' % ('$label', $t1, $t4, 3 * $N / ($t4 - $t1) / 1e6, 'identical to plain' if '$got' == '$want' else 'DIFFERS'))" >> $OUT
@@ -56,7 +56,7 @@ run() { # label file env...
 run "plain text" /tmp/big.fq X=1
 run "BGZF, device inflate (default: 3 workers)" /tmp/big.fq.gz X=1
 if [ -n "$SWEEP" ]; then
-  for w in 2 4 5; do run "BGZF, device inflate, $w workers" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=$w; done
+  for w in 2 4 5 6; do run "BGZF, device inflate, $w workers" /tmp/big.fq.gz RKMH_BGZF_DEVICE_WORKERS=$w; done
   cat $OUT; exit 0
 fi
 # the first N1 reads as an ORDINARY gzip file (one deflate stream, zlib level GZL): inflated on the device (rk_gunzip.hip) / by zlib on the host
