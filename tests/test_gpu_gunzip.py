@@ -118,6 +118,28 @@ def test_device_gunzip_gives_the_text(gctx, tmp_path, level, qual, nrec, chunk_k
     assert st and all(s == 0 for s in st), st
 
 
+@pytest.mark.parametrize("level,mem_level,wbits,strategy", [(6, 1, 15, 0), (6, 4, 15, 0), (9, 9, 15, 0), (6, 8, 9, 0), (1, 8, 12, 0), (6, 8, 15, zlib.Z_FILTERED),
+                                                            (6, 2, 10, zlib.Z_RLE), (4, 9, 15, zlib.Z_HUFFMAN_ONLY), (3, 8, 15, zlib.Z_FIXED), (0, 8, 15, 0)])
+def test_device_gunzip_zlib_parameters(gctx, tmp_path, level, mem_level, wbits, strategy):
+    """deflate streams as zlib writes them with other parameters than gzip's defaults: tiny blocks (memLevel 1: 128 symbols each --
+    hundreds of code tables per chunk), 32 K-symbol blocks (memLevel 9), small windows (wbits 9 .. 12), every strategy, stored only.
+    Every stretch the device takes must be the text; a stream it hands over (status 1) must have been right up to there."""
+    rng = np.random.default_rng(level * 7 + mem_level * 3 + wbits)
+    text = _fastq(rng, 6000, "wide" if strategy == zlib.Z_HUFFMAN_ONLY else "random")
+    co = zlib.compressobj(level, zlib.DEFLATED, -wbits, mem_level, strategy)
+    raw = co.compress(text) + co.flush()
+    path = tmp_path / "p.fq.gz"
+    path.write_bytes(_gzip_container(raw, text))
+    assert gzip.decompress(path.read_bytes()) == text
+    st = _through_device(gctx, path, text, 16 << 20, {"RKMH_GZIP_CHUNK_KB": "4", "RKMH_GZIP_STRETCH_KB": "400"})
+    assert st and all(s == 0 for s in st[:-1]) and st[-1] in (0, 1), st
+    if st[-1] == 1:
+        print("handed over:", (level, mem_level, wbits, strategy), st)
+    # all but the all-stored and all-fixed streams (no dynamic header to start a chunk from: one long chunk per stretch) are the device's
+    if strategy != zlib.Z_FIXED and level != 0:
+        assert st[-1] == 0, st
+
+
 def test_device_gunzip_tiny_and_odd_files(gctx, tmp_path):
     """three records; one record; a text without its last newline; a 70 KB record-free... no: records of 20 KB (long reads)"""
     rng = np.random.default_rng(2)
