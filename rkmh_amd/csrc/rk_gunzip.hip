@@ -13,13 +13,14 @@
 //   4. the host follows the chain: a chunk belongs to the stream when the one before it ended exactly at its header (a false header
 //      -- random bits that look like one -- is stepped over: the gap behind the chunk that met it is decoded in a launch of its own);
 //   5. k_inflate_place<STREAM> x 3, k_gz_windows, k_gz_resolve: the text; k_crc32_segments: its CRC-32 in 64 KB segments, joined on
-//      the host (crc32_combine) and compared with the file's trailer at the end of the stream, as is ISIZE;
+//      the host (the zero-advance matrices of rk_crc32.hpp) and compared with the file's trailer at the end of the stream, as is ISIZE;
 //   6. the records: the text in front of the last record start (four-line rule) goes to the caller, the rest waits for the next call.
 // Whatever the device cannot do -- a stored or fixed-code stretch longer than a chunk's scratch, text that outgrows the buffers, a
 // second gzip member behind the first -- ends with return code 1 and the offset in the TEXT of the first record that was not
 // delivered: the caller's sequential reader goes on from there (rk_reader_open_at).
 #include "rk_api_internal.hpp"
 #include "rk_kernels.hpp"
+#include "rk_crc32.hpp"
 #include <zlib.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -37,6 +38,7 @@ constexpr uint64_t CARRY_CAP = (uint64_t)4 << 20;  // text in front of a call's 
 constexpr uint64_t OVER = (uint64_t)8 << 20;       // compressed bytes uploaded beyond a stretch: its last chunk ends at the first block boundary behind it
 constexpr uint32_t TAIL_WINDOW = 1u << 18;         // the last record start is looked for this far in front of the text's end
 constexpr uint32_t PATCH_MAX = 8;                  // gaps (behind false headers) decoded one launch each, per call
+const Crc32Tables CRC_TABLES = make_crc32_tables();
 }
 
 struct rk_gzip {
@@ -410,7 +412,9 @@ int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t e
     // the stream's CRC-32 so far; at its end, the trailer's word on it
     for (uint32_t sg = 0; sg < nseg; ++sg) {
         const uint32_t len = std::min<uint32_t>(65536u, total - (sg << 16));
-        gz->crc_run = (gz->text_made == 0 && sg == 0) ? h_crc[sg] : (uint32_t)crc32_combine(gz->crc_run, h_crc[sg], (z_off_t)len);
+        // CRC(A B) = advance(CRC(A), |B| zero bytes) ^ CRC(B) -- what zlib's crc32_combine computes; zlib 1.2.11 rebuilds its operator
+        // matrices in every call (~10 us: 0.1 s for the 11 000 segments of a 700 MB stretch), the tables of rk_crc32.hpp hold them
+        gz->crc_run = crc32_advance(CRC_TABLES, gz->crc_run, len) ^ h_crc[sg];
         gz->text_made += len;
     }
     if (gz->finished) {
