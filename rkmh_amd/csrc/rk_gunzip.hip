@@ -158,8 +158,8 @@ extern "C" int64_t rk_gzip_plan(rk_gzip* gz, uint64_t slot_bytes) {
 extern "C" int64_t rk_gzip_calls(const rk_gzip* gz) { return gz ? gz->ncalls : 0; }
 
 // The slot's work buffers at the sizes a stretch of comp_bytes compressed bytes that inflates to at most cap_out bytes will ask for
-// (rk_fastq_slot_reserve_gzip: a worker makes them when it makes its slot -- one worker at a time, beside the reference stage --
-// instead of in front of its first file: allocations of this size take 10 - 50 ms each while other workers are setting up)
+// (rk_fastq_slot_reserve_gzip: a worker makes them when it starts -- one worker at a time -- as ONE arena: a runtime call of this kind
+// takes 10 - 50 ms while other workers are setting up, whatever its size)
 int gzip_reserve(GzScratch& S, rk_ctx* c, uint64_t comp_bytes, uint64_t cap_out) {
     RKCHK(set_dev(c));
     const uint64_t up = comp_bytes + OVER + 4096;
