@@ -140,6 +140,27 @@ def test_device_gunzip_zlib_parameters(gctx, tmp_path, level, mem_level, wbits, 
         assert st[-1] == 0, st
 
 
+# soak: RKMH_TEST_GZ_SEEDS=400 [RKMH_TEST_SEED_BASE=...]
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RKMH_TEST_SEED_BASE", "0")), int(os.environ.get("RKMH_TEST_SEED_BASE", "0")) + int(os.environ.get("RKMH_TEST_GZ_SEEDS", "8"))))
+def test_device_gunzip_randomized(gctx, tmp_path, seed):
+    """random FASTQ text (1 to 20 000 records, three kinds of quality strings) deflated with random zlib parameters, inflated on the
+    device with random chunk and stretch sizes: every stretch is the text, record for record"""
+    rng = np.random.default_rng(77000 + seed)
+    nrec = int(rng.choice([1, 7, 60, 400, 3000, 9000, 20000]))
+    text = _fastq(rng, nrec, str(rng.choice(["random", "flat", "wide"])), b"s%d_" % seed)
+    level, mem_level, wbits = int(rng.integers(1, 10)), int(rng.integers(1, 10)), int(rng.integers(9, 16))
+    strategy = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY]))
+    co = zlib.compressobj(level, zlib.DEFLATED, -wbits, mem_level, strategy)
+    raw = co.compress(text) + co.flush()
+    path = tmp_path / "s.fq.gz"
+    path.write_bytes(_gzip_container(raw, text))
+    env = {"RKMH_GZIP_CHUNK_KB": str(int(rng.choice([1, 2, 4, 8, 32])))}
+    if rng.integers(0, 2):
+        env["RKMH_GZIP_STRETCH_KB"] = str(int(rng.integers(32, 3000)))
+    st = _through_device(gctx, path, text, 16 << 20, env)
+    assert st and all(x == 0 for x in st), (seed, level, mem_level, wbits, strategy, nrec, env, st)
+
+
 def test_device_gunzip_tiny_and_odd_files(gctx, tmp_path):
     """three records; one record; a text without its last newline; a 70 KB record-free... no: records of 20 KB (long reads)"""
     rng = np.random.default_rng(2)
