@@ -866,12 +866,17 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
     std::mutex fm;
     std::map<int64_t, std::pair<size_t, int64_t>> fail_at; // block number -> (file, its first byte)
     std::mutex tm;
-    std::atomic<int> live_plain{0}, live_mega{0};
+    std::atomic<int> live_plain{0}, live_mega{0}, needed_mega{INT32_MAX};
     for (auto& x : eng.w) ++(x.device_text ? live_mega : live_plain);
     const int64_t window = (int64_t)eng.w.size() * 4 * (any_mega ? eng.pieces : 1) + 2;
     auto work = [&](size_t wi) {
         RawEngine::Worker& W = eng.w[wi];
         if (!(W.device_text ? any_mega : any_plain)) return; // (no file of this run is for this worker's kind of slot)
+        if (W.device_text) { // (... or fewer jobs than workers of it: see needed_mega)
+            size_t rank = 0;
+            for (size_t j = 0; j < wi; ++j) if (eng.w[j].device_text) ++rank;
+            if ((int)rank >= needed_mega.load()) { live_mega.fetch_sub(1); return; }
+        }
         QueueT<Job>& jobs = W.device_text ? jobs_mega : jobs_plain;
         std::atomic<int>& live = W.device_text ? live_mega : live_plain;
         const double t_slot = now_s();
@@ -1043,6 +1048,20 @@ static int64_t stream_files_raw(RawEngine& eng, DeviceGroup& g, const rk_seqset&
         std::lock_guard<std::mutex> l(tm);
         eng.t_read += t_rd; eng.t_dev += t_dv; eng.t_fmt += t_fm; eng.blocks += nblk; eng.records += nrec_;
     };
+    // how many jobs the device-text workers will share (an ordinary gzip file is one job, a BGZF file a few): a worker without a job
+    // to expect does not start -- its slot and work buffers are gigabytes of allocations that slow the others down while they are made
+    // (one gzip file: 0.36 s as a command with one such worker setting up, 0.6 - 0.77 s with four or five)
+    size_t mega_jobs = 0;
+    for (const File& F : files) {
+        if (F.gz) ++mega_jobs;
+        else if (F.bz && F.mega) {
+            const uint64_t target = eng.mega > ((uint64_t)1 << 20) ? eng.mega - ((uint64_t)1 << 18) : eng.mega * 3 / 4;
+            std::vector<int64_t> first((size_t)rk_bgzf_members(F.bz) + 4);
+            const int64_t nj = rk_bgzf_plan_members(F.bz, target, 16381, first.data(), (int64_t)first.size());
+            mega_jobs += nj > 0 ? (size_t)nj : 1;
+        }
+    }
+    needed_mega.store((int)std::min<size_t>(mega_jobs, (size_t)INT32_MAX));
     std::vector<std::thread> workers;
     for (size_t i = 0; i < eng.w.size(); ++i) workers.emplace_back(work, i);
     // coordinator: ranges of whole records, file after file.  The end of a range is the last record start (four-line rule,

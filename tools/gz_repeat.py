@@ -36,25 +36,33 @@ def settle():
             return
         time.sleep(0.05)
 
-def wall(files):
+def wall(files, env=None):
     settle()
     if os.path.exists(out):
         os.remove(out)
     with open(out, "wb") as fo:
         t = time.perf_counter()
-        r = subprocess.run([exe, "stream", "-r", ref, "-k", "16", "-s", "1000"] + sum((["-f", f] for f in files), []), stdout=fo, stderr=subprocess.PIPE)
+        r = subprocess.run([exe, "stream", "-r", ref, "-k", "16", "-s", "1000"] + sum((["-f", f] for f in files), []), stdout=fo, stderr=subprocess.PIPE,
+                           env=dict(os.environ, **(env or {})))
         d = time.perf_counter() - t
     assert r.returncode == 0, r.stderr[-300:]
     return d
 
 rows = {"plain": (fq, n), "BGZF, device": (bg, n), "gzip, device": (sg, 1000000)}
-res = {k: ([], []) for k in rows}
+# GZ_REPEAT_WORKERS="3,4": the device-text worker counts to compare, interleaved run by run (one box, one page cache, one afternoon)
+variants = [w for w in os.environ.get("GZ_REPEAT_WORKERS", "").split(",") if w] or [""]
+res = {(v, k): ([], []) for v in variants for k in rows}
 for rep in range(reps):
-    for k, (f, _) in rows.items():
-        res[k][0].append(wall([f])); res[k][1].append(wall([f] * 4))
-for k, (f, nr) in rows.items():
-    w1, w4 = res[k]
-    marg = sorted(3 * nr / (b - a) / 1e6 for a, b in zip(w1, w4) if b > a)
-    print("%-14s 1 file: median %.3f s (%.3f .. %.3f); 4 files: median %.3f s (%.3f .. %.3f); marginal M reads/s: median %.1f (%.1f .. %.1f); from the median walls %.1f"
-          % (k, statistics.median(w1), min(w1), max(w1), statistics.median(w4), min(w4), max(w4), statistics.median(marg), marg[0], marg[-1],
-             3 * nr / (statistics.median(w4) - statistics.median(w1)) / 1e6))
+    for v in variants:
+        env = {"RKMH_BGZF_DEVICE_WORKERS": v} if v else None
+        for k, (f, _) in rows.items():
+            res[(v, k)][0].append(wall([f], env)); res[(v, k)][1].append(wall([f] * 4, env))
+for v in variants:
+    if v:
+        print("== RKMH_BGZF_DEVICE_WORKERS=%s" % v)
+    for k, (f, nr) in rows.items():
+        w1, w4 = res[(v, k)]
+        marg = sorted(3 * nr / (b - a) / 1e6 for a, b in zip(w1, w4) if b > a) or [float("nan")]
+        print("%-14s 1 file: median %.3f s (%.3f .. %.3f); 4 files: median %.3f s (%.3f .. %.3f); marginal M reads/s: median %.1f (%.1f .. %.1f); from the median walls %.1f"
+              % (k, statistics.median(w1), min(w1), max(w1), statistics.median(w4), min(w4), max(w4), statistics.median(marg), marg[0], marg[-1],
+                 3 * nr / (statistics.median(w4) - statistics.median(w1)) / 1e6))
