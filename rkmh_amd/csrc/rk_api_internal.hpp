@@ -235,7 +235,7 @@ struct GzScratch {
     }
 };
 int gzip_reserve(GzScratch& S, rk_ctx* c, uint64_t comp_bytes, uint64_t cap_out); // rk_gunzip.hip
-int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t call, uint8_t* d_out, uint64_t cap_out, uint64_t* nbytes, uint64_t* text_off); // rk_gunzip.hip
+int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t call, uint8_t* d_out, uint64_t cap_out, uint64_t* nbytes, uint64_t* text_off, bool raw = false); // rk_gunzip.hip
 int counter_settle(const rk_counter* k);                                                                    // rk_counters.hip
 int build_index(rk_ctx* c);                                                                                 // rk_index.hip
 int set_references_impl(rk_ctx* c, const uint8_t* bases, const uint8_t* d_bases, const uint64_t* offsets, int nref, const int* ks, int nks, int S,

@@ -482,6 +482,44 @@ extern "C" int rk_fasta_load_put(rk_fasta_load* L, rk_fastq_slot* via, uint64_t 
     return RK_OK;
 }
 
+// The text of an ORDINARY gzip file (rk_gzip_open: a genome as it is distributed, genome.fa.gz) inflated on the device (rk_gunzip.hip)
+// straight into the load's text at text_offset; *text_bytes = its length.  Returns RK_OK; 1: the device route gave up (a second member
+// behind the first, ...) -- the caller parses the references on the host; < 0: damaged data.  One call at a time per load.
+extern "C" int rk_fasta_load_put_gzip(rk_fasta_load* L, rk_gzip* gz, uint64_t text_offset, uint64_t* text_bytes) {
+    if (!L || !gz || !text_bytes || L->finished || text_offset > L->cap) return fail(RK_ERR_ARG, "bad arguments");
+    *text_bytes = 0;
+    rk_ctx* c = L->c;
+    RKCHK(set_dev(c));
+    // stretches that inflate to ~700 MB each (the work buffers are ~8 x a stretch's compressed bytes; they go when the file is done)
+    const uint64_t per_call = std::min<uint64_t>((uint64_t)832 << 20, std::max<uint64_t>((uint64_t)8 << 20, L->cap - text_offset));
+    const int64_t ncalls = rk_gzip_plan(gz, per_call);
+    if (ncalls < 0) return RK_ERR_ARG;
+    GzScratch S;
+    hipEvent_t ev = nullptr;
+    struct Guard { GzScratch& S; hipEvent_t& ev; ~Guard() { S.release(); if (ev) { hipError_t e = hipEventDestroy(ev); (void)e; } } } guard{S, ev};
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
+    uint64_t done = 0;
+    for (int64_t call = 0; call < ncalls; ++call) {
+        uint64_t n = 0, off = 0;
+        const uint64_t room = L->cap - text_offset - done;
+        const int rc = gzip_next(gz, S, c, c->st, ev, call, L->d_text.as<uint8_t>() + text_offset + done, std::min<uint64_t>(room, per_call), &n, &off, true);
+        if (rc != RK_OK) return rc;
+        done += n;
+    }
+    HIPCHK(hipStreamSynchronize(c->st));
+    *text_bytes = done;
+    return RK_OK;
+}
+
+// one '\n' into the load's text (the separator behind a file whose text was written by rk_fasta_load_put_gzip)
+extern "C" int rk_fasta_load_put_newline(rk_fasta_load* L, uint64_t text_offset) {
+    if (!L || L->finished || text_offset >= L->cap) return fail(RK_ERR_ARG, "bad arguments");
+    RKCHK(set_dev(L->c));
+    HIPCHK(hipMemsetAsync(L->d_text.as<uint8_t>() + text_offset, '\n', 1, L->c->st));
+    HIPCHK(hipStreamSynchronize(L->c->st));
+    return RK_OK;
+}
+
 extern "C" int rk_fasta_load_finish(rk_fasta_load* L, uint64_t total_bytes, rk_fasta_index* out) {
     if (!L || !out || total_bytes < 1 || total_bytes > L->cap || L->finished) return fail(RK_ERR_ARG, "bad arguments");
     memset(out, 0, sizeof *out);

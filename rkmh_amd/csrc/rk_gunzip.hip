@@ -196,7 +196,8 @@ extern "C" uint64_t rk_gzip_stretch_bytes(const rk_gzip* gz) { return gz ? gz->s
 // The next stretch of gz's stream -> whole records at d_out (at most cap_out bytes), *nbytes of them; *text_off = the offset of the
 // first of them in the file's text.  RK_OK; 1: not for the device from *text_off on (see the head of this file); < 0: an error
 // (damaged data: a CRC-32 or length that does not match the trailer).  Calls come in order, call = 0 .. ncalls - 1, on stream st.
-int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t call, uint8_t* d_out, uint64_t cap_out, uint64_t* nbytes, uint64_t* text_off) {
+// raw: the stretch's TEXT, every byte of it, instead of its FASTQ records (references: rk_fasta_load_put_gzip) -- nothing is carried.
+int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t ev, int64_t call, uint8_t* d_out, uint64_t cap_out, uint64_t* nbytes, uint64_t* text_off, bool raw) {
     static const bool timing = getenv("RKMH_BGZF_TIMING") != nullptr;
     const auto t_0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
@@ -393,7 +394,7 @@ int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t e
     const bool at_end = gz->finished || (call == gz->ncalls - 1);
     uint32_t* const d_cuts = gz->d_tmp.as<uint32_t>() + (32768 + 16) / 4;
     h_info[0] = ntext; h_info[1] = 0;
-    if (!at_end && ntext) {
+    if (!at_end && ntext && !raw) {
         const uint32_t from = ntext > TAIL_WINDOW ? ntext - TAIL_WINDOW : 0;
         HIPCHK(launch_fastq_first_start(all, ntext, from, TAIL_WINDOW, false, d_cuts, 0, st));
         HIPCHK(hipMemcpyAsync(h_info, d_cuts, 4, hipMemcpyDeviceToHost, st));
@@ -428,14 +429,14 @@ int gzip_next(rk_gzip* gz, GzScratch& S, rk_ctx* c, hipStream_t st, hipEvent_t e
                         gz->path.c_str(), gz->crc_run, gz->crc_want, (unsigned long long)gz->text_made, gz->isize_want);
     } else if (call == gz->ncalls - 1) return fail(RK_ERR_IO, "%s: the deflate stream does not end inside the file: truncated?", gz->path.c_str());
     const uint8_t first_byte = reinterpret_cast<const uint8_t*>(h_info + 1)[0], last_byte = reinterpret_cast<const uint8_t*>(h_info + 1)[1];
-    uint32_t cut = at_end ? ntext : h_info[0];
+    uint32_t cut = (at_end || raw) ? ntext : h_info[0];
     if (cut == 0xFFFFFFFFu) return 1;          // no record start in the tail window: records longer than 256 KB, or no FASTQ
     if (cut > ntext) cut = ntext;
-    if (ntext && gz->text_given == 0 && first_byte != '@') return 1;
-    if (cut > cap_out - 1 || ntext - cut > CARRY_CAP) return 1;
+    if (!raw && ntext && gz->text_given == 0 && first_byte != '@') return 1;
+    if (cut > cap_out - (raw ? 0 : 1) || ntext - cut > CARRY_CAP) return 1;
     if (cut) HIPCHK(hipMemcpyAsync(d_out, all, cut, hipMemcpyDeviceToDevice, st));
     uint64_t n = cut;
-    if (at_end && ntext && last_byte != '\n') { HIPCHK(hipMemsetAsync(d_out + n, '\n', 1, st)); ++n; } // a last line without its newline
+    if (!raw && at_end && ntext && last_byte != '\n') { HIPCHK(hipMemsetAsync(d_out + n, '\n', 1, st)); ++n; } // a last line without its newline
     // the carry: the text behind the cut waits in the file's own buffer for the next call
     const uint32_t new_carry = ntext - cut;
     if (new_carry) HIPCHK(hipMemcpyAsync(gz->d_tmp.as<uint8_t>() + 65536, all + cut, new_carry, hipMemcpyDeviceToDevice, st));

@@ -1488,6 +1488,15 @@ static void run_packed(DeviceGroup& g, const rk_seqset& refs, const Opts& o, con
 // RKMH_RAW_REFS=1 forces it for any size, =0 turns it off.  false: not taken (small, compressed, not regular FASTA, no memory):
 // the caller parses on the host.  On success refs carries the names only (all that stream / filter print).
 struct DeviceRefs { std::vector<char> names; std::vector<uint64_t> name_offsets; };
+static std::map<std::string, rk_gzip*> g_gzip_refs; // -r files that are ordinary gzip (opened once; nullptr: looked at, not gzip)
+static rk_gzip* gzip_ref_of(const char* path) {
+    auto it = g_gzip_refs.find(path);
+    if (it != g_gzip_refs.end()) return it->second;
+    rk_gzip* gz = nullptr;
+    if (rk_gzip_open(path, &gz) != RK_OK) gz = nullptr;
+    g_gzip_refs[path] = gz;
+    return gz;
+}
 // will refs_through_device take the -r files?  (sizes, total: the files' lengths and their sum with a newline after each)
 static bool refs_for_device(const Opts& o, std::vector<int64_t>* sizes = nullptr, uint64_t* total_out = nullptr) {
     const char* env = getenv("RKMH_RAW_REFS");
@@ -1496,7 +1505,13 @@ static bool refs_for_device(const Opts& o, std::vector<int64_t>* sizes = nullptr
     std::vector<int64_t> size(o.refs.size(), 0);
     uint64_t total = 0;
     for (size_t i = 0; i < o.refs.size(); ++i) {
-        if (!raw_eligible(o.refs[i], &size[i], '>')) return false;
+        if (!raw_eligible(o.refs[i], &size[i], '>')) {
+            // an ordinary gzip file (genome.fa.gz as it is distributed): inflated on the device (rk_fasta_load_put_gzip); its text's
+            // length is the trailer's word for it (a file of 4 GB of text or more ends up with the host parser)
+            rk_gzip* gz = gzip_on_device() ? gzip_ref_of(o.refs[i]) : nullptr;
+            if (!gz || rk_gzip_first_byte(gz) != '>') return false;
+            size[i] = (int64_t)rk_gzip_text_bytes_hint(gz);
+        }
         total += (uint64_t)size[i] + 1; // a '\n' after every file
     }
     if (o.refs.empty() || (!forced && total < ((uint64_t)64 << 20))) return false;
@@ -1518,11 +1533,18 @@ static bool refs_through_device(RawEngine& eng, DeviceGroup& g, const Opts& o, i
     }
     struct Job { size_t file; int64_t lo, hi; uint64_t at; bool last; };
     std::vector<Job> jobs;
+    struct GzRef { rk_gzip* gz; uint64_t at, size; };
+    std::vector<GzRef> gz_refs;
     std::vector<int> fds(o.refs.size(), -1);
     {
         uint64_t at = 0;
         const int64_t B = (int64_t)eng.block;
         for (size_t i = 0; i < o.refs.size(); ++i) {
+            if (rk_gzip* gz = g_gzip_refs.count(o.refs[i]) ? g_gzip_refs[o.refs[i]] : nullptr) { // (refs_for_device found it to be gzip)
+                gz_refs.push_back(GzRef{gz, at, (uint64_t)size[i]});
+                at += (uint64_t)size[i] + 1;
+                continue;
+            }
             fds[i] = open(o.refs[i], O_RDONLY);
             if (fds[i] < 0) { fprintf(stderr, "rkmh: cannot open %s\n", o.refs[i]); fail_exit(); }
             for (int64_t lo = 0; lo < size[i]; lo += B) {
@@ -1555,8 +1577,14 @@ static bool refs_through_device(RawEngine& eng, DeviceGroup& g, const Opts& o, i
     double tr = now_s();
     std::vector<std::thread> th;
     for (size_t i = 0; i < eng.w.size(); ++i) th.emplace_back(work, i);
+    for (const GzRef& gr : gz_refs) { // (this thread: a gzip stream is inflated stretch after stretch)
+        uint64_t nb = 0;
+        const int rc = failed.load() ? 1 : rk_fasta_load_put_gzip(load, gr.gz, gr.at, &nb);
+        if (rc < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
+        if (rc != RK_OK || nb != gr.size || rk_fasta_load_put_newline(load, gr.at + nb) != RK_OK) failed = true; // (the host parser reads the references)
+    }
     for (auto& t : th) t.join();
-    for (int fd : fds) close(fd);
+    for (int fd : fds) if (fd >= 0) close(fd);
     tick("references: text read and uploaded", tr);
     bool ok = !failed.load() && next.load() >= jobs.size();
     rk_fasta_index ix;

@@ -280,3 +280,44 @@ def test_cli_gzip_equals_plain(tmp_path, data_dir):
     bad.write_bytes(bytes(img))
     r = subprocess.run([exe, "stream"] + base + ["-f", str(bad)], capture_output=True)
     assert r.returncode != 0
+
+
+def test_cli_gzip_references_through_the_device(tmp_path, data_dir):
+    """-r genome.fa.gz (ordinary gzip): with RKMH_RAW_REFS=1 the references' text is inflated on the device straight into the FASTA
+    loader (rk_fasta_load_put_gzip) -- same stdout as the host parser and as the uncompressed file, for the bundled panel and for a
+    12 MB synthetic genome in 60-column lines inflated in several stretches, alone and beside a plain -r file."""
+    from rkmh_amd import api, synth
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "rkmh")
+    rng = np.random.default_rng(12)
+    recs = []
+    for i in range(6):
+        sq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(1500000, 2500000))))
+        recs.append(b">chr%d synthetic\n" % i + b"\n".join(sq[j:j + 60] for j in range(0, len(sq), 60)) + b"\n")
+    fa = tmp_path / "g.fa"
+    fa.write_bytes(b"".join(recs))
+    fagz = tmp_path / "g.fa.gz"
+    fagz.write_bytes(gzip.compress(fa.read_bytes(), 6))
+    refs = api.parse_files([str(fa)])
+    n = 20000
+    qb, qo = synth.generate_reads_fast(refs["bases"], refs["offsets"], 0, n, read_len=150, threads=4)
+    fq = tmp_path / "r.fq"
+    fq.write_bytes(b"".join(b"@q%06d\n" % i + bytes(qb[int(qo[i]):int(qo[i + 1])]) + b"\n+\n" + b"I" * 150 + b"\n" for i in range(n)))
+    panel_gz = os.path.join(data_dir, "hpv_16.fa.gz")
+
+    def run(refs_, env):
+        r = subprocess.run([exe, "stream", "-k", "16", "-s", "1000", "-f", str(fq)] + sum((["-r", str(x)] for x in refs_), []), capture_output=True,
+                           env=dict(os.environ, RKMH_TIMING="1", **env))
+        assert r.returncode == 0, r.stderr[-500:]
+        return r.stdout, r.stderr
+
+    want, _ = run([fa], {"RKMH_RAW_REFS": "0"})
+    assert want.count(b"\n") == n
+    for refs_, env in (([fagz], {"RKMH_RAW_REFS": "1"}), ([fagz], {"RKMH_RAW_REFS": "1", "RKMH_GZIP_STRETCH_KB": "900", "RKMH_GZIP_CHUNK_KB": "8"}), ([fa], {"RKMH_RAW_REFS": "1"})):
+        got, err = run(refs_, env)
+        assert got == want, (refs_, env)
+        assert b"references through the device" in err, err[-600:]
+    got, _ = run([fagz], {"RKMH_RAW_REFS": "0"})
+    assert got == want
+    want2, _ = run([fa, panel_gz], {"RKMH_RAW_REFS": "0"})
+    got2, err2 = run([fagz, panel_gz], {"RKMH_RAW_REFS": "1"})      # (the small panel is gzip as well; its lower-case text may send all of them to the host parser: same lines either way)
+    assert got2 == want2
