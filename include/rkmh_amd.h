@@ -432,6 +432,9 @@ int rk_fasta_load_finish(rk_fasta_load* load, uint64_t total_bytes, rk_fasta_ind
 struct rk_gzip;
 /* the text of an ordinary gzip file (rk_gzip_open) inflated on the device into the load's text at text_offset; 1: parse on the host instead */
 int rk_fasta_load_put_gzip(rk_fasta_load* load, struct rk_gzip* gz, uint64_t text_offset, uint64_t* text_bytes);
+/* ... and of members [b0, b1) of a BGZF file (a bgzip'd genome), inflated in the buffers of `via` (RK_SLOT_DEVICE_TEXT); 1: parse on the host */
+struct rk_bgzf;
+int rk_fasta_load_put_bgzf(rk_fasta_load* load, rk_fastq_slot* via, const struct rk_bgzf* z, int64_t b0, int64_t b1, uint64_t text_offset);
 int rk_fasta_load_put_newline(rk_fasta_load* load, uint64_t text_offset);   /* the separator behind such a file */
 int rk_fasta_load_get_bases(rk_fasta_load* load, uint8_t* dst);   /* the packed bases, offsets[nseq] bytes, to the host */
 int rk_set_references_fasta(rk_ctx* ctx, rk_fasta_load* load, const int* ks, int nks, int sketch_size, int max_samples, uint64_t counter_slots);

@@ -122,6 +122,7 @@ _SIGS = {
     "rk_fastq_slot_load_bgzf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rk_fasta_load_put_gzip": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rk_fasta_load_put_newline": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "rk_fasta_load_put_bgzf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint64]),
     "rk_gzip_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "rk_gzip_close": (None, [C.c_void_p]),
     "rk_gzip_image": (C.c_void_p, [C.c_void_p]),

@@ -511,6 +511,59 @@ extern "C" int rk_fasta_load_put_gzip(rk_fasta_load* L, rk_gzip* gz, uint64_t te
     return RK_OK;
 }
 
+// The text of members [b0, b1) of a BGZF file (a bgzip'd genome) inflated on the device -- pass 1, pass 2 and the CRC-32 check of
+// rk_inflate.hip, in the buffers of `via` (a slot created with RK_SLOT_DEVICE_TEXT whose max_bytes holds the members' text) -- and
+// copied into the load's text at text_offset.  Returns RK_OK; 1: a member the device could not inflate or whose CRC-32 does not
+// match (the caller parses the references on the host, which reports the damage).
+extern "C" int rk_fasta_load_put_bgzf(rk_fasta_load* L, rk_fastq_slot* via, const rk_bgzf* z, int64_t b0, int64_t b1, uint64_t text_offset) {
+    if (!L || !via || !z || L->finished || b0 < 0 || b1 <= b0 || b1 > rk_bgzf_members(z)) return fail(RK_ERR_ARG, "bad arguments");
+    if (!via->device_text() || via->c->device != L->c->device) return fail(RK_ERR_ARG, "rk_fasta_load_put_bgzf: a device-text slot of the load's device is needed");
+    rk_fastq_slot* s = via;
+    RKCHK(set_dev(s->c));
+    hipStream_t st = s->st;
+    const uint32_t nm = (uint32_t)(b1 - b0);
+    uint64_t f_lo = 0, f_hi = 0;
+    uint32_t tot = 0, hd = 0, us = 0;
+    RKCHK(rk_bgzf_member(z, b0, &f_lo, &tot, &hd, &us));
+    RKCHK(rk_bgzf_member(z, b1 - 1, &f_hi, &tot, &hd, &us));
+    const uint64_t cbytes = f_hi + tot - f_lo;
+    const uint64_t u_lo = rk_bgzf_text_offset(z, b0), ntext = rk_bgzf_text_offset(z, b1) - u_lo;
+    if (ntext > s->max_bytes || cbytes >= ((uint64_t)1 << 31) || text_offset > L->cap || ntext > L->cap - text_offset) return fail(RK_ERR_ARG, "rk_fasta_load_put_bgzf: the members' text does not fit the slot or the load");
+    if (ntext == 0) return RK_OK;
+    const size_t mem_bytes = (((size_t)nm * sizeof(InflateMember) + 15) & ~(size_t)15) + (size_t)nm * 8 + 64;
+    RKCHK(s->h_mem.reserve(mem_bytes));
+    RKCHK(s->d_mem.reserve(mem_bytes));
+    RKCHK(s->d_comp.reserve(cbytes + 256));
+    RKCHK(s->d_inf.reserve(ntext + 64));
+    InflateMember* mt = s->h_mem.as<InflateMember>();
+    uint64_t scratch_dw = 0;
+    for (uint32_t i = 0; i < nm; ++i) {
+        uint64_t fo = 0;
+        RKCHK(rk_bgzf_member(z, b0 + i, &fo, &tot, &hd, &us));
+        if (tot < hd + 8u) return fail(RK_ERR_IO, "BGZF member %lld is shorter than its header and footer", (long long)(b0 + i));
+        mt[i].in_off = (uint32_t)(fo - f_lo) + hd; mt[i].in_len = tot - hd - 8;
+        mt[i].out_off = (uint32_t)(rk_bgzf_text_offset(z, b0 + i) - u_lo); mt[i].out_len = us;
+        mt[i].match_off = (uint32_t)scratch_dw; mt[i].pad = 0;
+        scratch_dw += inflate_scratch_dwords(us);
+    }
+    if (scratch_dw >= ((uint64_t)1 << 32)) return 1;
+    RKCHK(s->d_match.reserve(scratch_dw * 4 + 64));
+    HIPCHK(hipMemcpyAsync(s->d_comp.p, rk_bgzf_image(z) + f_lo, cbytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(s->d_comp.as<uint8_t>() + cbytes, 0, 160, st));
+    const size_t cpad = ((cbytes + 15) & ~(size_t)15) + 64;
+    HIPCHK(hipMemcpyAsync(s->d_mem.p, mt, (size_t)nm * sizeof(InflateMember), hipMemcpyHostToDevice, st));
+    const size_t status_at = ((size_t)nm * sizeof(InflateMember) + 15) & ~(size_t)15;
+    uint32_t* d_status = reinterpret_cast<uint32_t*>(s->d_mem.as<uint8_t>() + status_at);
+    uint32_t* h_status = reinterpret_cast<uint32_t*>(s->h_mem.as<uint8_t>() + status_at);
+    HIPCHK(launch_inflate_members(s->d_comp.as<uint8_t>(), (uint32_t)cpad, s->d_mem.as<InflateMember>(), nm, s->d_inf.as<uint8_t>(), s->d_match.as<uint32_t>(), d_status, st));
+    HIPCHK(hipMemcpyAsync(h_status, d_status, (size_t)nm * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(L->d_text.as<uint8_t>() + text_offset, s->d_inf.p, ntext, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipEventRecord(s->ev, st));
+    HIPCHK(hipEventSynchronize(s->ev));
+    for (uint32_t i = 0; i < nm; ++i) if (h_status[i] != 0) return 1;
+    return RK_OK;
+}
+
 // one '\n' into the load's text (the separator behind a file whose text was written by rk_fasta_load_put_gzip)
 extern "C" int rk_fasta_load_put_newline(rk_fasta_load* L, uint64_t text_offset) {
     if (!L || L->finished || text_offset >= L->cap) return fail(RK_ERR_ARG, "bad arguments");

@@ -1497,6 +1497,16 @@ static rk_gzip* gzip_ref_of(const char* path) {
     g_gzip_refs[path] = gz;
     return gz;
 }
+static std::map<std::string, rk_bgzf*> g_bgzf_refs; // ... that are BGZF
+static rk_bgzf* bgzf_ref_of(const char* path) {
+    auto it = g_bgzf_refs.find(path);
+    if (it != g_bgzf_refs.end()) return it->second;
+    rk_bgzf* bz = nullptr;
+    if (getenv("RKMH_BGZF") && atoi(getenv("RKMH_BGZF")) == 0) bz = nullptr;
+    else if (rk_bgzf_open(path, &bz) != RK_OK) bz = nullptr;
+    g_bgzf_refs[path] = bz;
+    return bz;
+}
 // will refs_through_device take the -r files?  (sizes, total: the files' lengths and their sum with a newline after each)
 static bool refs_for_device(const Opts& o, std::vector<int64_t>* sizes = nullptr, uint64_t* total_out = nullptr) {
     const char* env = getenv("RKMH_RAW_REFS");
@@ -1508,6 +1518,12 @@ static bool refs_for_device(const Opts& o, std::vector<int64_t>* sizes = nullptr
         if (!raw_eligible(o.refs[i], &size[i], '>')) {
             // an ordinary gzip file (genome.fa.gz as it is distributed): inflated on the device (rk_fasta_load_put_gzip); its text's
             // length is the trailer's word for it (a file of 4 GB of text or more ends up with the host parser)
+            if (rk_bgzf* bz = bgzf_on_device() ? bgzf_ref_of(o.refs[i]) : nullptr) { // a bgzip'd genome: independent members (rk_fasta_load_put_bgzf)
+                if (rk_bgzf_first_byte(bz) != '>') return false;
+                size[i] = (int64_t)rk_bgzf_text_bytes(bz);
+                total += (uint64_t)size[i] + 1;
+                continue;
+            }
             rk_gzip* gz = gzip_on_device() ? gzip_ref_of(o.refs[i]) : nullptr;
             if (!gz || rk_gzip_first_byte(gz) != '>') return false;
             size[i] = (int64_t)rk_gzip_text_bytes_hint(gz);
@@ -1535,11 +1551,18 @@ static bool refs_through_device(RawEngine& eng, DeviceGroup& g, const Opts& o, i
     std::vector<Job> jobs;
     struct GzRef { rk_gzip* gz; uint64_t at, size; };
     std::vector<GzRef> gz_refs;
+    struct BzRef { rk_bgzf* bz; uint64_t at, size; };
+    std::vector<BzRef> bz_refs;
     std::vector<int> fds(o.refs.size(), -1);
     {
         uint64_t at = 0;
         const int64_t B = (int64_t)eng.block;
         for (size_t i = 0; i < o.refs.size(); ++i) {
+            if (rk_bgzf* bz = g_bgzf_refs.count(o.refs[i]) ? g_bgzf_refs[o.refs[i]] : nullptr) { // (refs_for_device found it to be BGZF)
+                bz_refs.push_back(BzRef{bz, at, (uint64_t)size[i]});
+                at += (uint64_t)size[i] + 1;
+                continue;
+            }
             if (rk_gzip* gz = g_gzip_refs.count(o.refs[i]) ? g_gzip_refs[o.refs[i]] : nullptr) { // (refs_for_device found it to be gzip)
                 gz_refs.push_back(GzRef{gz, at, (uint64_t)size[i]});
                 at += (uint64_t)size[i] + 1;
@@ -1582,6 +1605,24 @@ static bool refs_through_device(RawEngine& eng, DeviceGroup& g, const Opts& o, i
         const int rc = failed.load() ? 1 : rk_fasta_load_put_gzip(load, gr.gz, gr.at, &nb);
         if (rc < 0) { fprintf(stderr, "rkmh: %s\n", rk_last_error()); fail_exit(); }
         if (rc != RK_OK || nb != gr.size || rk_fasta_load_put_newline(load, gr.at + nb) != RK_OK) failed = true; // (the host parser reads the references)
+    }
+    if (!bz_refs.empty() && !failed.load()) { // bgzip'd references: runs of members inflated in the buffers of one device-text slot made for the purpose
+        const uint64_t job_text = (uint64_t)512 << 20;
+        rk_fastq_slot* via = nullptr;
+        if (rk_fastq_slot_create2(g.ctx[0], job_text + ((uint64_t)1 << 20), RK_SLOT_DEVICE_TEXT, &via) != RK_OK) failed = true;
+        for (const BzRef& br : bz_refs) {
+            if (failed.load()) break;
+            std::vector<int64_t> first((size_t)rk_bgzf_members(br.bz) + 4);
+            const int64_t nj = rk_bgzf_plan_members(br.bz, job_text - ((uint64_t)1 << 18), 16381, first.data(), (int64_t)first.size());
+            if (nj < 0) { failed = true; break; }
+            rk_host_register_readonly(rk_bgzf_image(br.bz), (size_t)rk_bgzf_file_bytes(br.bz)); // (the DMA engine reads the mapping itself; refused: staged uploads)
+            for (int64_t j = 0; j < nj && !failed.load(); ++j) {
+                const int rc = rk_fasta_load_put_bgzf(load, via, br.bz, first[(size_t)j], first[(size_t)j + 1], br.at + rk_bgzf_text_offset(br.bz, first[(size_t)j]));
+                if (rc != RK_OK) failed = true; // (a damaged member as well: the host parser reports it)
+            }
+            if (!failed.load() && rk_fasta_load_put_newline(load, br.at + br.size) != RK_OK) failed = true;
+        }
+        if (via) rk_fastq_slot_destroy(via);
     }
     for (auto& t : th) t.join();
     for (int fd : fds) if (fd >= 0) close(fd);

@@ -312,12 +312,16 @@ def test_cli_gzip_references_through_the_device(tmp_path, data_dir):
 
     want, _ = run([fa], {"RKMH_RAW_REFS": "0"})
     assert want.count(b"\n") == n
-    for refs_, env in (([fagz], {"RKMH_RAW_REFS": "1"}), ([fagz], {"RKMH_RAW_REFS": "1", "RKMH_GZIP_STRETCH_KB": "900", "RKMH_GZIP_CHUNK_KB": "8"}), ([fa], {"RKMH_RAW_REFS": "1"})):
+    fabz = tmp_path / "g.bgzf.fa.gz"
+    fabz.write_bytes(synth.bgzf_compress(fa.read_bytes(), level=6))      # a bgzip'd genome: rk_fasta_load_put_bgzf
+    for refs_, env in (([fagz], {"RKMH_RAW_REFS": "1"}), ([fagz], {"RKMH_RAW_REFS": "1", "RKMH_GZIP_STRETCH_KB": "900", "RKMH_GZIP_CHUNK_KB": "8"}), ([fa], {"RKMH_RAW_REFS": "1"}),
+                       ([fabz], {"RKMH_RAW_REFS": "1"})):
         got, err = run(refs_, env)
         assert got == want, (refs_, env)
         assert b"references through the device" in err, err[-600:]
-    got, _ = run([fagz], {"RKMH_RAW_REFS": "0"})
-    assert got == want
+    for f_ in (fagz, fabz):
+        got, _ = run([f_], {"RKMH_RAW_REFS": "0"})
+        assert got == want
     want2, _ = run([fa, panel_gz], {"RKMH_RAW_REFS": "0"})
     got2, err2 = run([fagz, panel_gz], {"RKMH_RAW_REFS": "1"})      # (the small panel is gzip as well; its lower-case text may send all of them to the host parser: same lines either way)
     assert got2 == want2
