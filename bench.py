@@ -154,7 +154,7 @@ def e2e_stream(n, L, rb, ro, synth):
         res["kmer_cache"] = {"references_s_enumerated": ref_s[0], "references_s_from_cache": ref_s[1], "file_bytes": os.path.getsize(kc) if os.path.exists(kc) else 0}
         # compressed reads (the reference opens every input with gzopen, rkmh.cpp:238-263): the first reads of the file again with
         # qualities that do not compress to nothing, as plain text, as BGZF (bgzip: independent members, inflated by the front end's
-        # workers) and as ordinary single-member gzip (one deflate stream: zlib on one thread, the block scanner behind it)
+        # workers) and as ordinary single-member gzip (one deflate stream: inflated on the GPU chunk by chunk, rk_gunzip.hip -- or zlib on one thread)
         ng = min(n, 4000000)
         if ng >= 1000:
             import gzip
